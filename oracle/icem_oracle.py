@@ -1,0 +1,549 @@
+"""CPU oracle for the iCEM inner planning loop.  TEST INFRASTRUCTURE ONLY.
+
+This file is the *checker*, never the product: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+it.  ``icem_amd`` (the product) never imports anything under ``oracle/``.
+
+It restates, in plain NumPy (float64 by default, like the reference), the
+algorithm of the reference's hot path.  Every function cites the reference
+file:line it follows (paths relative to ``/root/reference``):
+
+* ``colorednoise.powerlaw_psd_gaussian`` -- third-party PyPI package
+  ``colorednoise`` (F. Patzelt), **unpinned** in the reference
+  (``Pipfile:10``: ``colorednoise = "*"``), source absent from
+  ``/root/reference``.  Restated from its published 1.x algorithm; call site
+  ``icem/controllers/icem.py:73-75``.
+* ``MpcICem.sample_action_sequences``      ``icem/controllers/icem.py:61-82``
+* ``MpcICem.prepare_action_sequences``     ``icem/controllers/icem.py:84-89``
+* ``MpcICem.elites_2_action_sequences``    ``icem/controllers/icem.py:91-104``
+* ``MpcICem.get_action``                   ``icem/controllers/icem.py:106-189``
+* ``MpcICem.update_distributions``         ``icem/controllers/icem.py:194-211``
+* ``ModelBasedController.trajectory_cost_fn``
+                                           ``icem/controllers/abstract_controller.py:74-91``
+* ``ForwardModelWithDefaults.predict_n_steps`` (batched rollout loop)
+                                           ``icem/models/abstract_models.py:17-53``
+* HalfCheetah / HumanoidStandup ``cost_fn`` ``icem/environments/mujoco.py:67-99, 259-277``
+
+Pinning: the reference has no tests and no golden vectors for this path, and
+``colorednoise`` is unpinned; the oracle is pinned against outputs of the
+reference *itself*, imported in the build container (with stub modules for
+its missing third-party imports) by ``tests/golden/make_golden.py``; the
+resulting fixtures are ``tests/golden/*.npz`` and are checked by
+``tests/test_oracle_golden.py``.  The MuJoCo ground-truth dynamics cannot run
+here (mujoco-py absent): rollouts are pinned through the model *interface*
+with synthetic batched models only.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+# --------------------------------------------------------------------------
+# a-1  colorednoise.powerlaw_psd_gaussian  (third-party; icem.py:73-75 call site)
+# --------------------------------------------------------------------------
+
+
+def psd_scale(h: int, beta: float) -> Tuple[np.ndarray, float]:
+    """Per-frequency amplitude ``s_scale[F]`` and the normalising ``sigma``.
+
+    Follows colorednoise 1.x ``powerlaw_psd_gaussian`` with ``fmin=0``:
+    ``f = rfftfreq(h)``; frequencies below ``1/h`` (only DC) take the value of
+    the first non-cut bin; ``s = f**(-beta/2)``; ``sigma`` is the theoretical
+    output std.
+    """
+    f = np.fft.rfftfreq(h)
+    s = f.copy()
+    fmin = max(0.0, 1.0 / h)
+    ix = int(np.sum(s < fmin))
+    if ix and ix < len(s):
+        s[:ix] = s[ix]
+    s = s ** (-beta / 2.0)
+    w = s[1:].copy()
+    w[-1] *= (1 + (h % 2)) / 2.0
+    sigma = 2.0 * math.sqrt(float(np.sum(w ** 2))) / h
+    return s, sigma
+
+
+def colored_from_white(beta: float, h: int, z_r: np.ndarray, z_i: np.ndarray) -> np.ndarray:
+    """``powerlaw_psd_gaussian(beta, size=(..., h))`` given the white draws.
+
+    ``z_r, z_i`` are the standard-normal draws ``[..., F]`` (F = h//2+1) that
+    upstream obtains from two consecutive ``numpy.random.normal(scale=s_scale,
+    size=[..., F])`` calls (``sr = z_r*s_scale`` bit-exactly).  Returns
+    ``[..., h]`` with the temporal correlation along the last axis.
+    """
+    s, sigma = psd_scale(h, beta)
+    sr = z_r * s
+    si = z_i * s
+    if not (h % 2):
+        si[..., -1] = 0
+    si[..., 0] = 0
+    spec = sr + 1j * si
+    return np.fft.irfft(spec, n=h, axis=-1) / sigma
+
+
+def synthesis_matrices(h: int, beta: float) -> Tuple[np.ndarray, np.ndarray]:
+    """Real synthesis matrices ``Cr, Ci`` of shape ``[F, h]`` (float64) with
+
+        colored_from_white(beta, h, z_r, z_i) == z_r @ Cr + z_i @ Ci
+
+    up to rounding: the inverse real DFT, ``s_scale`` and ``1/sigma`` folded
+    into one table.  Rows ``Ci[0]`` (DC) and, for even ``h``, ``Ci[F-1]``
+    (Nyquist) are zero -- those draws are discarded by upstream.
+    """
+    s, sigma = psd_scale(h, beta)
+    F = h // 2 + 1
+    k = np.arange(F, dtype=np.float64)[:, None]
+    t = np.arange(h, dtype=np.float64)[None, :]
+    ang = 2.0 * np.pi * k * t / h
+    mult = np.full((F, 1), 2.0)
+    mult[0, 0] = 1.0
+    if h % 2 == 0:
+        mult[F - 1, 0] = 1.0
+    amp = mult * s[:, None] / (h * sigma)
+    Cr = amp * np.cos(ang)
+    Ci = -amp * np.sin(ang)
+    Ci[0, :] = 0.0
+    if h % 2 == 0:
+        Ci[F - 1, :] = 0.0
+    return Cr, Ci
+
+
+def legacy_white_noise(num: int, d: int, h: int) -> Tuple[np.ndarray, np.ndarray]:
+    """The two draws upstream takes from the *global legacy* ``np.random``
+    stream for ``size=(num, d, h)`` (reference seeding: ``misc/seeding.py:13-19``)."""
+    F = h // 2 + 1
+    z_r = np.random.normal(size=(num, d, F))
+    z_i = np.random.normal(size=(num, d, F))
+    return z_r, z_i
+
+
+# --------------------------------------------------------------------------
+# Philox4x32 counter RNG + Box-Muller (the build's device RNG, restated)
+# --------------------------------------------------------------------------
+
+_M0 = np.uint64(0xD2511F53)
+_M1 = np.uint64(0xCD9E8D57)
+_W0 = 0x9E3779B9
+_W1 = 0xBB67AE85
+_MASK = np.uint64(0xFFFFFFFF)
+_SH = np.uint64(32)
+
+
+def philox4x32(c0, c1, c2, c3, k0: int, k1: int, rounds: int = 10):
+    """Philox4x32-R (Salmon et al. 2011).  Counter words are array-likes of
+    uint32 values (held in uint64 arrays); key words are Python ints."""
+    c0 = np.asarray(c0, dtype=np.uint64) & _MASK
+    c1 = np.asarray(c1, dtype=np.uint64) & _MASK
+    c2 = np.asarray(c2, dtype=np.uint64) & _MASK
+    c3 = np.asarray(c3, dtype=np.uint64) & _MASK
+    c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
+    k0 &= 0xFFFFFFFF
+    k1 &= 0xFFFFFFFF
+    for _ in range(rounds):
+        p0 = _M0 * c0
+        p1 = _M1 * c2
+        hi0, lo0 = p0 >> _SH, p0 & _MASK
+        hi1, lo1 = p1 >> _SH, p1 & _MASK
+        c0, c1, c2, c3 = (hi1 ^ c1 ^ np.uint64(k0)), lo1, (hi0 ^ c3 ^ np.uint64(k1)), lo0
+        k0 = (k0 + _W0) & 0xFFFFFFFF
+        k1 = (k1 + _W1) & 0xFFFFFFFF
+    return c0, c1, c2, c3
+
+
+def box_muller(xa: np.ndarray, xb: np.ndarray, dtype=np.float64):
+    """Two normals from two uint32 words.  ``u1 = (xa+0.5)*2^-32`` (f64) or
+    ``fma(xa, 2^-32, 2^-33)`` (f32); angle ``2*pi*xb*2^-32``; returns
+    ``(r*cos, r*sin)``."""
+    if dtype == np.float64:
+        u1 = (xa.astype(np.float64) + 0.5) * (2.0 ** -32)
+        v = xb.astype(np.float64) * (2.0 ** -32)
+        r = np.sqrt(-2.0 * np.log(u1))
+        ang = 2.0 * np.pi * v
+        return r * np.cos(ang), r * np.sin(ang)
+    xa32 = xa.astype(np.float32)
+    xb32 = xb.astype(np.float32)
+    u1 = xa32 * np.float32(2.0 ** -32) + np.float32(2.0 ** -33)
+    v = xb32 * np.float32(2.0 ** -32)
+    r = np.sqrt(np.float32(-2.0) * np.log(u1))
+    ang = np.float32(2.0 * np.pi) * v
+    return (r * np.cos(ang)).astype(np.float32), (r * np.sin(ang)).astype(np.float32)
+
+
+def philox_white_noise(seed: int, offset: int, num: int, d: int, h: int,
+                       first_index: int = 0, rounds: int = 10,
+                       dtype=np.float64) -> Tuple[np.ndarray, np.ndarray]:
+    """White draws ``z_r, z_i [num, d, F]`` from the build's counter RNG.
+
+    Row ``(n, j)`` (n = *global* trajectory index ``first_index + local``)
+    uses Philox counters ``(n, (j<<16)|b, offset_lo, offset_hi)``, key
+    ``(seed_lo, seed_hi)``, ``b = 0..ceil(h/4)-1``.  Block ``b`` yields the
+    normals ``m = 4b..4b+3`` via Box-Muller on word pairs (0,1) and (2,3).
+    Normal ``m < F`` is ``z_r[k=m]``; ``m >= F`` is ``z_i[k=m-F+1]``.  Unused
+    ``z_i`` slots (DC, even-h Nyquist) are returned as 0.
+    """
+    F = h // 2 + 1
+    nb = (h + 3) // 4
+    n_idx = (first_index + np.arange(num, dtype=np.uint64))[:, None, None]
+    j_idx = np.arange(d, dtype=np.uint64)[None, :, None]
+    b_idx = np.arange(nb, dtype=np.uint64)[None, None, :]
+    c1 = (j_idx << np.uint64(16)) | b_idx
+    x0, x1, x2, x3 = philox4x32(n_idx, c1, offset & 0xFFFFFFFF, (offset >> 32) & 0xFFFFFFFF,
+                                seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, rounds)
+    g0, g1 = box_muller(x0, x1, dtype)
+    g2, g3 = box_muller(x2, x3, dtype)
+    g = np.stack([g0, g1, g2, g3], axis=-1).reshape(num, d, nb * 4)[..., :h]
+    z_r = np.ascontiguousarray(g[..., :F])
+    z_i = np.zeros((num, d, F), dtype=dtype)
+    n_im = h - F
+    z_i[..., 1:1 + n_im] = g[..., F:]
+    return z_r, z_i
+
+
+# --------------------------------------------------------------------------
+# a-2  MpcICem.sample_action_sequences  (icem.py:61-82)
+# --------------------------------------------------------------------------
+
+
+def sample_action_sequences(mean: np.ndarray, std: np.ndarray, low: np.ndarray, high: np.ndarray,
+                            beta: float, z_r: np.ndarray, z_i: np.ndarray) -> np.ndarray:
+    """``clip(colored[N,h,d]*std + mean, low, high)`` -- icem.py:73-79.
+    ``z_r, z_i`` are ``[N, d, F]``; result is ``[N, h, d]``."""
+    h = mean.shape[0]
+    samples = colored_from_white(beta, h, z_r, z_i).transpose([0, 2, 1])
+    return np.clip(samples * std + mean, low, high)
+
+
+def sample_via_matrices(mean, std, low, high, beta, z_r, z_i, dtype=np.float64) -> np.ndarray:
+    """Same as :func:`sample_action_sequences` through the synthesis matrices
+    (the formulation the HIP kernel uses), in ``dtype`` arithmetic, summing
+    ``k = 0..F-1`` in order (real term then imaginary term)."""
+    h = mean.shape[0]
+    Cr, Ci = synthesis_matrices(h, beta)
+    Cr = Cr.astype(dtype)
+    Ci = Ci.astype(dtype)
+    z_r = z_r.astype(dtype)
+    z_i = z_i.astype(dtype)
+    F = Cr.shape[0]
+    y = np.zeros(z_r.shape[:-1] + (h,), dtype=dtype)
+    for k in range(F):
+        y = y + z_r[..., k:k + 1] * Cr[k]
+        y = y + z_i[..., k:k + 1] * Ci[k]
+    y = y.transpose([0, 2, 1])
+    out = y * std.astype(dtype) + mean.astype(dtype)
+    return np.clip(out, low.astype(dtype), high.astype(dtype))
+
+
+# --------------------------------------------------------------------------
+# a-9 / a-10  environment cost functions (mujoco.py:67-99, 259-277)
+# --------------------------------------------------------------------------
+
+
+@dataclass
+class CostSpec:
+    """Parametric restatement of the two shipped cost functions.
+
+    ``cost_t = ctrl_weight*sum_d a^2 + lin_weight*obs[lin_idx]
+               + flip_penalty*([obs[flip_idx] >  flip_thresh] +
+                               [obs[flip_idx] < -flip_thresh])``
+    (flip term only when ``flip_idx >= 0``).
+    """
+    ctrl_weight: float = 0.1
+    lin_idx: int = 8
+    lin_weight: float = -1.0
+    flip_idx: int = 1
+    flip_penalty: float = 10.0
+    flip_thresh: float = math.pi / 2
+
+    @staticmethod
+    def halfcheetah(obs_dim: int = 17, penalise_flipping: bool = True) -> "CostSpec":
+        # mujoco.py:77-82: o=18 -> angle [2], velocity [9]; o=17 -> [1], [8]
+        if obs_dim == 18:
+            a, v = 2, 9
+        elif obs_dim == 17:
+            a, v = 1, 8
+        else:
+            raise ValueError(f"Got state of dimension {obs_dim}. Possible dimensions are 17 or 18.")
+        return CostSpec(0.1, v, -1.0, a if penalise_flipping else -1, 10.0, math.pi / 2)
+
+    @staticmethod
+    def humanoid_standup() -> "CostSpec":
+        # mujoco.py:267-272: -obs[2] + 0.1*sum(a^2)
+        return CostSpec(0.1, 2, -1.0, -1, 0.0, math.pi / 2)
+
+    def __call__(self, obs: np.ndarray, act: np.ndarray, next_obs=None) -> np.ndarray:
+        scores = np.zeros(act.shape[:-1], dtype=act.dtype)
+        if self.flip_idx >= 0:
+            ang = obs[..., self.flip_idx]
+            scores = scores + (ang > self.flip_thresh) * self.flip_penalty
+            scores = scores + (ang < -self.flip_thresh) * self.flip_penalty
+        scores = scores + self.ctrl_weight * np.sum(act ** 2, axis=-1)
+        scores = scores + self.lin_weight * obs[..., self.lin_idx]
+        return scores
+
+
+# --------------------------------------------------------------------------
+# Synthetic batched forward models (the contract of abstract_models.py:17-53)
+# --------------------------------------------------------------------------
+
+MODEL_LINEAR = 0
+MODEL_TANH = 1
+
+
+@dataclass
+class SyntheticModel:
+    """``o' = act(o @ A + a @ B)`` with ``A [o,o]``, ``B [d,o]``; ``band >= 0``
+    keeps only ``|row-col| <= band`` of ``A`` (the masked entries are zeroed
+    in ``A`` itself at construction)."""
+    A: np.ndarray
+    B: np.ndarray
+    kind: int = MODEL_LINEAR
+    band: int = -1
+
+    def __post_init__(self):
+        if self.band >= 0:
+            o = self.A.shape[0]
+            r = np.arange(o)
+            mask = np.abs(r[:, None] - r[None, :]) <= self.band
+            self.A = np.where(mask, self.A, 0.0)
+
+    @staticmethod
+    def make(o: int, d: int, kind: int = MODEL_LINEAR, band: int = -1,
+             seed_a: int = 0, seed_b: int = 1) -> "SyntheticModel":
+        # A = 0.95 I + 0.05 N(0,1) (RandomState(0)), B = 0.1 N(0,1) (RandomState(1))
+        A = 0.95 * np.eye(o) + 0.05 * np.random.RandomState(seed_a).randn(o, o) / math.sqrt(o)
+        B = 0.1 * np.random.RandomState(seed_b).randn(d, o)
+        return SyntheticModel(A, B, kind, band)
+
+    def predict(self, obs: np.ndarray, act: np.ndarray) -> np.ndarray:
+        # Accumulate in a fixed order (k ascending over obs, then j ascending
+        # over actions) so float32 runs are reproducible on the device.
+        dt = obs.dtype
+        A = self.A.astype(dt)
+        B = self.B.astype(dt)
+        nxt = np.zeros_like(obs)
+        for k in range(A.shape[0]):
+            nxt = nxt + obs[..., k:k + 1] * A[k]
+        for j in range(B.shape[0]):
+            nxt = nxt + act[..., j:j + 1] * B[j]
+        if self.kind == MODEL_TANH:
+            nxt = np.tanh(nxt)
+        return nxt
+
+
+def rollout_observations(model: SyntheticModel, obs0: np.ndarray, actions: np.ndarray) -> np.ndarray:
+    """Batched open-loop rollout (abstract_models.py:17-26): returns the
+    *pre-action* observations ``[P, h, o]`` (``observations`` field); the state
+    reached by the last action is never scored (mujoco.py cost_fn ignores
+    ``next_observations``)."""
+    P, h, _ = actions.shape
+    obs = np.broadcast_to(obs0.astype(actions.dtype), (P, obs0.shape[0])).copy()
+    out = np.empty((P, h, obs0.shape[0]), dtype=actions.dtype)
+    for t in range(h):
+        out[:, t] = obs
+        obs = model.predict(obs, actions[:, t])
+    return out
+
+
+def trajectory_costs(cost_fn: Callable, observations: np.ndarray, actions: np.ndarray,
+                     mode: str = "sum") -> np.ndarray:
+    """abstract_controller.py:74-91: per-step cost ``[P,h]`` reduced over h."""
+    costs_path = cost_fn(observations, actions, None)
+    if mode == "sum":
+        return np.sum(costs_path, axis=1)
+    if mode == "best":
+        return np.amin(costs_path, axis=1)
+    if mode == "final":
+        return costs_path[:, -1]
+    raise NotImplementedError("Implement method {} to compute cost along trajectory".format(mode))
+
+
+def rollout_costs(model: SyntheticModel, cost: CostSpec, obs0, actions, mode="sum", dtype=None):
+    """Fused rollout+cost with a running accumulation over ``t`` (the order
+    the HIP kernel uses): returns ``costs [P]``."""
+    dt = actions.dtype if dtype is None else dtype
+    actions = actions.astype(dt)
+    P, h, _ = actions.shape
+    obs = np.broadcast_to(np.asarray(obs0, dtype=dt), (P, len(obs0))).copy()
+    acc = None
+    for t in range(h):
+        a = actions[:, t]
+        ctrl = np.zeros(P, dtype=dt)
+        for j in range(a.shape[1]):
+            ctrl = ctrl + a[:, j] * a[:, j]
+        c = np.zeros(P, dtype=dt)
+        if cost.flip_idx >= 0:
+            ang = obs[:, cost.flip_idx]
+            c = c + (ang > dt(cost.flip_thresh)).astype(dt) * dt(cost.flip_penalty)
+            c = c + (ang < dt(-cost.flip_thresh)).astype(dt) * dt(cost.flip_penalty)
+        c = c + dt(cost.ctrl_weight) * ctrl
+        c = c + dt(cost.lin_weight) * obs[:, cost.lin_idx]
+        if acc is None:
+            acc = c
+        elif mode == "sum":
+            acc = acc + c
+        elif mode == "best":
+            acc = np.minimum(acc, c)
+        elif mode == "final":
+            acc = c
+        else:
+            raise NotImplementedError(mode)
+        obs = model.predict(obs, a)
+    return acc
+
+
+# --------------------------------------------------------------------------
+# a-11  elite selection + refit (icem.py:194-211)
+# --------------------------------------------------------------------------
+
+
+def topk_sorted(costs: np.ndarray, k: int) -> np.ndarray:
+    """Indices of the k smallest costs, ascending by ``(cost, index)``; NaN is
+    treated as +inf.  The reference's ``argsort()[:k]`` (icem.py:199) is an
+    unstable quicksort, identical on tie-free inputs."""
+    c = np.where(np.isnan(costs), np.inf, costs)
+    order = np.lexsort((np.arange(len(c)), c))
+    return order[:k]
+
+
+def refit(elite_actions: np.ndarray, mean: np.ndarray, std: np.ndarray, alpha: float):
+    """icem.py:207-211: mean / population std (ddof=0) over the K elites, then
+    momentum ``alpha``."""
+    new_mean = elite_actions.mean(axis=0)
+    new_std = elite_actions.std(axis=0)
+    return (1 - alpha) * new_mean + alpha * mean, (1 - alpha) * new_std + alpha * std
+
+
+def population_sizes(N: int, K: int, gamma: float, iters: int) -> List[int]:
+    """icem.py:123-127: iterated ``max(2K, int(N_{i-1}/gamma))`` (NOT the
+    closed form printed at icem.py:38-40)."""
+    out, n = [], N
+    for i in range(iters):
+        if i > 0:
+            n = max(K * 2, int(n / gamma))
+        out.append(n)
+    return out
+
+
+# --------------------------------------------------------------------------
+# a-12 / a-13  the controller loop (icem.py:31-43, 106-189)
+# --------------------------------------------------------------------------
+
+
+@dataclass
+class IcemParams:
+    horizon: int = 30
+    num_simulated_trajectories: int = 128
+    factor_decrease_num: float = 1.25
+    cost_along_trajectory: str = "sum"
+    alpha: float = 0.1
+    elites_size: int = 10
+    opt_iterations: int = 3
+    init_std: float = 0.5
+    use_mean_actions: bool = True
+    keep_previous_elites: bool = True
+    shift_elites_over_time: bool = True
+    fraction_elites_reused: float = 0.3
+    noise_beta: float = 0.25
+
+    @property
+    def num_elites(self) -> int:
+        # icem.py:235-240
+        return max(2, min(self.elites_size, self.num_simulated_trajectories // 2))
+
+
+@dataclass
+class IterationTrace:
+    actions: np.ndarray          # simulated batch [P_sim, h, d]
+    costs: np.ndarray            # pool costs [P_pool]
+    elite_idx: np.ndarray        # sorted, best first, indices into the pool
+    mean: np.ndarray             # after refit
+    std: np.ndarray
+    best_idx: int
+
+
+NoiseFn = Callable[[int], Tuple[np.ndarray, np.ndarray]]
+
+
+class IcemOracle:
+    """Array-based restatement of ``MpcICem`` (no Rollout objects).
+
+    ``noise(num_traj)`` must return the white draws ``(z_r, z_i) [num,d,F]``
+    for one ``sample_action_sequences`` call, in the order the reference makes
+    those calls: per MPC step, main batch of iteration 0, then (if elites are
+    shifted) the ``(n_reuse, d, h)`` batch, then the main batches of
+    iterations 1.. .  ``rollout_cost(obs, actions) -> costs[P]``.
+    """
+
+    def __init__(self, params: IcemParams, low: np.ndarray, high: np.ndarray,
+                 rollout_cost: Callable[[np.ndarray, np.ndarray], np.ndarray], noise: NoiseFn):
+        self.p = params
+        self.low = np.asarray(low)
+        self.high = np.asarray(high)
+        self.d = len(low)
+        self.rollout_cost = rollout_cost
+        self.noise = noise
+        self.was_reset = False
+        self.trace: List[List[IterationTrace]] = []
+
+    # icem.py:31-59
+    def beginning_of_rollout(self):
+        h, d = self.p.horizon, self.d
+        self.mean = np.zeros((h, d)) + (self.high + self.low) / 2.0
+        self.std = np.ones((h, d)) * (self.high - self.low) / 2.0 * self.p.init_std
+        self.elite_actions = None
+        self.elite_costs = None
+        self.was_reset = True
+
+    def _sample(self, num_traj: int) -> np.ndarray:
+        z_r, z_i = self.noise(num_traj)
+        if self.p.noise_beta > 0:
+            return sample_action_sequences(self.mean, self.std, self.low, self.high,
+                                           self.p.noise_beta, z_r, z_i)
+        raise NotImplementedError("beta <= 0 (white randn, icem.py:77) is not on the golden path")
+
+    def get_action(self, obs: np.ndarray) -> np.ndarray:
+        if not self.was_reset:
+            raise AttributeError("beginning_of_rollout() needs to be called before")
+        p = self.p
+        K = p.num_elites
+        step_trace: List[IterationTrace] = []
+        num_sim_traj = p.num_simulated_trajectories
+        pool_actions = None
+        costs = None
+        best = None
+        for i in range(p.opt_iterations):
+            if i > 0:
+                num_sim_traj = max(p.elites_size * 2, int(num_sim_traj / p.factor_decrease_num))
+            actions = self._sample(num_sim_traj)                       # icem.py:85
+            if p.use_mean_actions and i == p.opt_iterations - 1:        # icem.py:87-88
+                actions[0] = self.mean
+            if i == 0 and p.shift_elites_over_time and self.elite_actions is not None:
+                # icem.py:91-104: best int(K*xi) elites, shifted by one step, new last action
+                reused = self.elite_actions[:, 1:]
+                n_reuse = int(reused.shape[0] * p.fraction_elites_reused)
+                reused = reused[:n_reuse]
+                last = self._sample(n_reuse)[:, -1:, :]
+                actions = np.concatenate([actions, np.concatenate([reused, last], axis=1)], axis=0)
+            sim_costs = self.rollout_cost(obs, actions)                # mpc.py:56-67 + abstract_controller.py:74-91
+            pool_actions, costs = actions, sim_costs
+            if i > 0 and p.keep_previous_elites:                        # icem.py:143-145
+                n_keep = int(len(self.elite_actions) * p.fraction_elites_reused)
+                pool_actions = np.concatenate([actions, self.elite_actions[:n_keep]], axis=0)
+                costs = np.concatenate([sim_costs, self.elite_costs[:n_keep]])
+            best = int(np.argmin(costs))                                # icem.py:149
+            idx = topk_sorted(costs, K)                                 # icem.py:199
+            self.elite_actions = pool_actions[idx].copy()
+            self.elite_costs = costs[idx].copy()
+            self.mean, self.std = refit(self.elite_actions, self.mean, self.std, p.alpha)
+            step_trace.append(IterationTrace(actions.copy(), costs.copy(), idx.copy(),
+                                             self.mean.copy(), self.std.copy(), best))
+        executed = pool_actions[best][0].copy()                         # icem.py:163
+        self.mean[:-1] = self.mean[1:]                                  # icem.py:167 (last kept: :171,191-192)
+        self.std = np.ones_like(self.std) * (self.high - self.low) / 2.0 * p.init_std  # icem.py:175
+        self.last_min_cost = float(np.min(costs))                       # icem.py:177
+        self.trace.append(step_trace)
+        return executed

@@ -1,0 +1,332 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by running the REFERENCE's own ``MpcICem``.
+
+Runs only in the build container (needs ``/root/reference``); the reference's
+source never travels -- only the ``.npz`` data this script writes (inputs and
+expected outputs) is committed under ``tests/golden/``.
+
+The reference imports four modules that are absent from the image
+(``allogger``, ``forwardable``, ``gym``, ``colorednoise``) plus, for its cost
+functions, ``gym.envs.mujoco`` / ``mujoco_py``.  Minimal stand-ins are written
+to a temp directory at run time:
+
+* ``allogger`` / ``forwardable`` / ``gym`` / ``mujoco_py``: interface stubs only
+  (no arithmetic).
+* ``colorednoise``: third-party, unpinned, not vendored by the reference.  The
+  stand-in restates the published 1.x ``powerlaw_psd_gaussian`` using the
+  *module-level* ``numpy.random.normal`` so it consumes the global legacy
+  stream exactly as upstream does.
+
+What is captured (per case): the white draws of every sampling call (recovered
+by replaying the saved ``np.random`` state), the simulated action batches,
+pool costs, elite indices, refit mean/std, best index and executed action of
+every CEM iteration of several consecutive MPC steps, the fake-model matrices,
+and direct outputs of the reference's HalfCheetah / HumanoidStandup
+``cost_fn``.
+
+Usage:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+import tempfile
+import textwrap
+import types
+
+import numpy as np
+
+REF = "/root/reference/icem"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+STUBS = {
+    "allogger.py": """
+        class _L:
+            logdir = "/tmp"
+            def log(self, *a, **k): pass
+            def info(self, *a, **k): pass
+        def get_logger(*a, **k): return _L()
+    """,
+    "forwardable.py": """
+        import sys
+        def forwardable():
+            return lambda cls: cls
+        def def_delegators(attr, names):
+            ns = sys._getframe(1).f_locals
+            for name in [n.strip() for n in names.split(",")]:
+                def mk(name):
+                    def f(self, *a, **k):
+                        return getattr(getattr(self, attr), name)(*a, **k)
+                    f.__name__ = name
+                    return f
+                ns[name] = mk(name)
+    """,
+    "gym/__init__.py": """
+        from . import spaces
+        class Env:
+            def __init__(self, *a, **k): pass
+    """,
+    "gym/spaces.py": """
+        import numpy as np
+        class Space: pass
+        class Box(Space):
+            def __init__(self, low, high, dtype=np.float32):
+                self.low = np.asarray(low, dtype=dtype); self.high = np.asarray(high, dtype=dtype)
+                self.shape = self.low.shape
+        class Discrete(Space):
+            def __init__(self, n): self.n = n
+        class Dict(Space):
+            def __init__(self, d): self.spaces = d
+    """,
+    "gym/utils.py": """
+        class EzPickle:
+            def __init__(self, *a, **k): pass
+    """,
+    "gym/envs/__init__.py": "",
+    "gym/envs/mujoco/__init__.py": """
+        class MujocoEnv:
+            def __init__(self, *a, **k): pass
+        class ReacherEnv(MujocoEnv): pass
+    """,
+    "gym/envs/mujoco/half_cheetah_v3.py": "from . import MujocoEnv\nclass HalfCheetahEnv(MujocoEnv): pass\n",
+    "gym/envs/mujoco/ant_v3.py": "from . import MujocoEnv\nclass AntEnv(MujocoEnv): pass\n",
+    "gym/envs/mujoco/humanoid_v3.py": "from . import MujocoEnv\nclass HumanoidEnv(MujocoEnv): pass\n",
+    "gym/envs/mujoco/humanoidstandup.py": "from . import MujocoEnv\nclass HumanoidStandupEnv(MujocoEnv): pass\n",
+    "gym/envs/mujoco/hopper_v3.py": "from . import MujocoEnv\nclass HopperEnv(MujocoEnv): pass\n",
+    "mujoco_py/__init__.py": "",
+    "mujoco_py/generated/__init__.py": "",
+    "mujoco_py/generated/const.py": "CAMERA_FIXED = 2\n",
+    # restatement of colorednoise 1.x (third-party, unpinned: Pipfile:10)
+    "colorednoise.py": """
+        from numpy import sqrt, newaxis
+        from numpy.fft import irfft, rfftfreq
+        from numpy.random import normal
+        from numpy import sum as npsum
+        CALLS = []
+        def powerlaw_psd_gaussian(exponent, size, fmin=0):
+            import numpy as np
+            state = np.random.get_state()
+            try:
+                size = list(size)
+            except TypeError:
+                size = [size]
+            samples = size[-1]
+            f = rfftfreq(samples)
+            s_scale = f
+            fmin = max(fmin, 1. / samples)
+            ix = npsum(s_scale < fmin)
+            if ix and ix < len(s_scale):
+                s_scale[:ix] = s_scale[ix]
+            s_scale = s_scale ** (-exponent / 2.)
+            w = s_scale[1:].copy()
+            w[-1] *= (1 + (samples % 2)) / 2.
+            sigma = 2 * sqrt(npsum(w ** 2)) / samples
+            size[-1] = len(f)
+            dims_to_add = len(size) - 1
+            s_scale = s_scale[(newaxis,) * dims_to_add + (Ellipsis,)]
+            sr = normal(scale=s_scale, size=size)
+            si = normal(scale=s_scale, size=size)
+            after = np.random.get_state()
+            # recover the underlying standard-normal draws by replaying the stream
+            np.random.set_state(state)
+            z_r = np.random.normal(size=size)
+            z_i = np.random.normal(size=size)
+            assert np.array_equal(z_r * s_scale, sr) and np.array_equal(z_i * s_scale, si)
+            a2 = np.random.get_state()
+            assert a2[2] == after[2] and np.array_equal(a2[1], after[1])
+            if not (samples % 2):
+                si[..., -1] = 0
+            si[..., 0] = 0
+            s = sr + 1J * si
+            y = irfft(s, n=samples, axis=-1) / sigma
+            CALLS.append((z_r, z_i, y))
+            return y
+    """,
+}
+
+
+def install_stubs():
+    root = tempfile.mkdtemp(prefix="icem_stubs_")
+    for rel, body in STUBS.items():
+        path = os.path.join(root, rel)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            f.write(textwrap.dedent(body))
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    sys.path.insert(0, root)
+    return root
+
+
+def make_model_mats(o, d, seed_a=0, seed_b=1):
+    A = 0.95 * np.eye(o) + 0.05 * np.random.RandomState(seed_a).randn(o, o) / np.sqrt(o)
+    B = 0.1 * np.random.RandomState(seed_b).randn(d, o)
+    return A, B
+
+
+def run_case(name, *, N, h, d, o, beta, iters, seed, n_steps, kind, env_kind,
+             cost_mode="sum", K=10, xi=0.3, gamma=1.25, alpha=0.1, init_std=0.5,
+             use_mean=True, keep=True, shift=True, bounds=1.0):
+    import colorednoise
+    from controllers.icem import MpcICem
+    from models.abstract_models import ForwardModelWithDefaults
+    from gym import spaces
+    import environments.mujoco as ref_mj
+
+    A, B = make_model_mats(o, d)
+
+    class FakeEnv:
+        def __init__(self):
+            self.name = "Fake" + env_kind
+            self.action_space = spaces.Box(low=-bounds * np.ones(d), high=bounds * np.ones(d))
+            self.penalise_flipping = True
+
+        def cost_fn(self, obs, act, next_obs):
+            # the REFERENCE's own cost functions, called unbound on this object
+            if env_kind == "halfcheetah":
+                return ref_mj.HalfCheetahMaybeWithPosition.cost_fn(self, obs, act, next_obs)
+            return ref_mj.HumanoidStandup.cost_fn(self, obs, act, next_obs)
+
+        def reward_fn(self, obs, act, next_obs):
+            return -self.cost_fn(obs, act, next_obs)
+
+    class FakeModel(ForwardModelWithDefaults):
+        def train(self, buffer): pass
+        def save(self, path): pass
+        def load(self, path): pass
+
+        def predict(self, *, observations, states, actions):
+            nxt = np.zeros_like(observations)
+            for k in range(o):
+                nxt = nxt + observations[..., k:k + 1] * A[k]
+            for j in range(d):
+                nxt = nxt + actions[..., j:j + 1] * B[j]
+            if kind == 1:
+                nxt = np.tanh(nxt)
+            r = np.zeros(observations.shape[:-1] + (1,))
+            return nxt, None, r
+
+    env = FakeEnv()
+    ctrl = MpcICem(env=env, forward_model=FakeModel(env=env), horizon=h,
+                   num_simulated_trajectories=N, factor_decrease_num=gamma,
+                   cost_along_trajectory=cost_mode, verbose=False, do_visualize_plan=False,
+                   action_sampler_params=dict(alpha=alpha, elites_size=K, opt_iterations=iters,
+                                              init_std=init_std, use_mean_actions=use_mean,
+                                              keep_previous_elites=keep, shift_elites_over_time=shift,
+                                              fraction_elites_reused=xi, noise_beta=beta))
+    log = {"sim_actions": [], "costs": [], "elite_idx": [], "mean": [], "std": [], "best": []}
+    orig_sim = ctrl.simulate_trajectories
+    orig_upd = ctrl.update_distributions
+
+    def sim(*, obs, state, action_sequences):
+        log["sim_actions"].append(np.array(action_sequences))
+        return orig_sim(obs=obs, state=state, action_sequences=action_sequences)
+
+    def upd(paths, costs):
+        log["costs"].append(np.array(costs))
+        log["elite_idx"].append(np.array(costs).argsort()[:ctrl.num_elites])
+        log["best"].append(int(np.argmin(costs)))
+        orig_upd(paths, costs)
+        log["mean"].append(ctrl.mean.copy())
+        log["std"].append(ctrl.std.copy())
+        ec = ctrl.trajectory_cost_fn(ctrl.cost_fn, ctrl.elite_samples)
+        assert np.all(np.diff(ec) >= 0), "elites not ascending"
+
+    ctrl.simulate_trajectories = sim
+    ctrl.update_distributions = upd
+
+    colorednoise.CALLS.clear()
+    np.random.seed(seed)
+    obs_rs = np.random.RandomState(1000 + seed)
+    obs = 0.1 * obs_rs.randn(o)
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        ctrl.beginning_of_rollout(observation=obs, state=None, mode="train")
+    out = {"obs": [], "executed": []}
+    for s in range(n_steps):
+        out["obs"].append(obs.copy())
+        a = ctrl.get_action(obs, None)
+        assert a.dtype == np.float64 and a.shape == (d,)
+        out["executed"].append(np.array(a))
+        # advance the "real" system with the same fake dynamics
+        nxt, _, _ = ctrl.forward_model.predict(observations=obs[None], states=None, actions=a[None])
+        obs = nxt[0]
+
+    # costs must be tie-free for argsort to be well defined
+    for c in log["costs"]:
+        assert len(np.unique(c)) == len(c), "golden case has tied costs"
+
+    data = dict(
+        cfg=np.array([N, h, d, o, iters, seed, n_steps, kind, K], dtype=np.int64),
+        cfg_f=np.array([beta, xi, gamma, alpha, init_std, bounds], dtype=np.float64),
+        flags=np.array([use_mean, keep, shift], dtype=np.int64),
+        env_kind=np.array(env_kind), cost_mode=np.array(cost_mode),
+        A=A, B=B, low=env.action_space.low.astype(np.float64), high=env.action_space.high.astype(np.float64),
+        obs=np.array(out["obs"]), executed=np.array(out["executed"]),
+        n_noise_calls=np.array(len(colorednoise.CALLS)), n_iters_total=np.array(len(log["costs"])),
+    )
+    for i, (zr, zi, y) in enumerate(colorednoise.CALLS):
+        data[f"zr_{i}"] = zr
+        data[f"zi_{i}"] = zi
+        if i < 2:
+            data[f"y_{i}"] = y
+    for i in range(len(log["costs"])):
+        data[f"simact_{i}"] = log["sim_actions"][i]
+        data[f"costs_{i}"] = log["costs"][i]
+        data[f"elite_{i}"] = log["elite_idx"][i].astype(np.int64)
+        data[f"mean_{i}"] = log["mean"][i]
+        data[f"std_{i}"] = log["std"][i]
+        data[f"best_{i}"] = np.array(log["best"][i])
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **data)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB, "
+          f"{len(colorednoise.CALLS)} noise calls, {len(log['costs'])} iterations")
+
+
+def cost_fn_vectors():
+    """Direct input/output vectors of the reference's two cost functions."""
+    import environments.mujoco as ref_mj
+    rs = np.random.RandomState(7)
+    fake = types.SimpleNamespace(penalise_flipping=True)
+    fake_nf = types.SimpleNamespace(penalise_flipping=False)
+    o17 = rs.randn(16, 10, 17) * 1.5
+    o18 = rs.randn(16, 10, 18) * 1.5
+    a6 = rs.uniform(-1, 1, (16, 10, 6))
+    o378 = rs.randn(4, 10, 378)
+    a17 = rs.uniform(-0.4, 0.4, (4, 10, 17))
+    HC = ref_mj.HalfCheetahMaybeWithPosition
+    data = dict(
+        o17=o17, o18=o18, a6=a6, o378=o378, a17=a17,
+        hc17=HC.cost_fn(fake, o17, a6, None), hc18=HC.cost_fn(fake, o18, a6, None),
+        hc17_noflip=HC.cost_fn(fake_nf, o17, a6, None),
+        hc17_single=HC.cost_fn(fake, o17[0, 0], a6[0, 0], None),
+        hs=ref_mj.HumanoidStandup.cost_fn(fake, o378, a17, None),
+    )
+    path = os.path.join(OUT, "cost_fn_vectors.npz")
+    np.savez_compressed(path, **data)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def main():
+    if not os.path.isdir(REF):
+        sys.exit("needs /root/reference (build container only)")
+    install_stubs()
+    cost_fn_vectors()
+    # C1-shaped: HalfCheetah shapes, beta=0.25, 3 iterations (BASELINE.json configs[0])
+    run_case("c1_halfcheetah_n128", N=128, h=30, d=6, o=17, beta=0.25, iters=3, seed=11,
+             n_steps=3, kind=0, env_kind="halfcheetah")
+    # HumanoidStandup-shaped actions (d=17, bounds 0.4, beta=2.0); o kept small (synthetic latent)
+    run_case("humanoid_n40_d17", N=40, h=30, d=17, o=24, beta=2.0, iters=3, seed=12,
+             n_steps=2, kind=1, env_kind="humanoid", bounds=0.4)
+    # PlaNet-horizon shapes h=12
+    run_case("h12_n64", N=64, h=12, d=6, o=17, beta=0.25, iters=3, seed=13,
+             n_steps=3, kind=1, env_kind="halfcheetah")
+    # odd horizon: no Nyquist bin
+    run_case("h13_odd_n48", N=48, h=13, d=4, o=17, beta=1.0, iters=4, seed=14,
+             n_steps=3, kind=0, env_kind="halfcheetah", cost_mode="best")
+    # 'final' cost mode, no elite keeping / shifting, no mean action
+    run_case("final_noreuse_n40", N=40, h=10, d=3, o=17, beta=3.0, iters=3, seed=15,
+             n_steps=2, kind=1, env_kind="halfcheetah", cost_mode="final",
+             use_mean=False, keep=False, shift=False)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,35 @@
+"""Helpers to load the golden fixtures written by tests/golden/make_golden.py."""
+import glob
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
+               if not p.endswith("cost_fn_vectors.npz"))
+
+
+class Golden:
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN, name + ".npz"))
+        self.z = z
+        (self.N, self.h, self.d, self.o, self.iters, self.seed, self.n_steps,
+         self.kind, self.K) = [int(v) for v in z["cfg"]]
+        (self.beta, self.xi, self.gamma, self.alpha, self.init_std, self.bounds) = [float(v) for v in z["cfg_f"]]
+        self.use_mean, self.keep, self.shift = [bool(v) for v in z["flags"]]
+        self.env_kind = str(z["env_kind"])
+        self.cost_mode = str(z["cost_mode"])
+        self.A, self.B = z["A"], z["B"]
+        self.low, self.high = z["low"], z["high"]
+        self.obs, self.executed = z["obs"], z["executed"]
+        self.n_noise_calls = int(z["n_noise_calls"])
+        self.n_iters_total = int(z["n_iters_total"])
+
+    def noise(self, i):
+        return self.z[f"zr_{i}"], self.z[f"zi_{i}"]
+
+    def it(self, i):
+        z = self.z
+        return dict(simact=z[f"simact_{i}"], costs=z[f"costs_{i}"], elite=z[f"elite_{i}"],
+                    mean=z[f"mean_{i}"], std=z[f"std_{i}"], best=int(z[f"best_{i}"]))

@@ -1,0 +1,111 @@
+"""Pin the CPU oracle against outputs of the reference itself (tests/golden)."""
+import numpy as np
+import pytest
+
+from oracle import icem_oracle as O
+from golden_util import CASES, Golden, GOLDEN
+import os
+
+
+def _oracle_for(g: Golden, noise_fn):
+    p = O.IcemParams(horizon=g.h, num_simulated_trajectories=g.N, factor_decrease_num=g.gamma,
+                     cost_along_trajectory=g.cost_mode, alpha=g.alpha, elites_size=g.K,
+                     opt_iterations=g.iters, init_std=g.init_std, use_mean_actions=g.use_mean,
+                     keep_previous_elites=g.keep, shift_elites_over_time=g.shift,
+                     fraction_elites_reused=g.xi, noise_beta=g.beta)
+    model = O.SyntheticModel(g.A, g.B, g.kind)
+    cost = O.CostSpec.halfcheetah(g.o) if g.env_kind == "halfcheetah" else O.CostSpec.humanoid_standup()
+
+    def rollout_cost(obs, actions):
+        observations = O.rollout_observations(model, obs, actions)
+        return O.trajectory_costs(cost, observations, actions, g.cost_mode)
+
+    return O.IcemOracle(p, g.low, g.high, rollout_cost, noise_fn)
+
+
+def test_cases_present():
+    assert len(CASES) >= 5
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_colored_noise_matches_reference_call(name):
+    """colored_from_white(z) == what the reference's sampling call returned."""
+    g = Golden(name)
+    for i in range(2):
+        zr, zi = g.noise(i)
+        y = O.colored_from_white(g.beta, g.h, zr, zi)
+        assert np.array_equal(y, g.z[f"y_{i}"])
+        # synthesis-matrix formulation (the one the HIP kernel uses) agrees to rounding
+        Cr, Ci = O.synthesis_matrices(g.h, g.beta)
+        y2 = zr @ Cr + zi @ Ci
+        np.testing.assert_allclose(y2, y, rtol=0, atol=5e-14)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_full_loop_matches_reference(name):
+    """Replay the recorded white noise through the oracle controller: every
+    iteration's actions / costs / elites / mean / std and the executed actions
+    must match the reference run (bit-exact indices; floats to 1e-12)."""
+    g = Golden(name)
+    calls = iter(range(g.n_noise_calls))
+
+    def noise(num):
+        zr, zi = g.noise(next(calls))
+        assert zr.shape[0] == num
+        return zr, zi
+
+    orc = _oracle_for(g, noise)
+    orc.beginning_of_rollout()
+    it = 0
+    for s in range(g.n_steps):
+        a = orc.get_action(g.obs[s])
+        np.testing.assert_allclose(a, g.executed[s], rtol=1e-12, atol=1e-14)
+        for tr in orc.trace[s]:
+            ref = g.it(it)
+            assert tr.actions.shape == ref["simact"].shape
+            np.testing.assert_allclose(tr.actions, ref["simact"], rtol=1e-12, atol=1e-14)
+            np.testing.assert_allclose(tr.costs, ref["costs"], rtol=1e-12, atol=1e-13)
+            assert np.array_equal(tr.elite_idx, ref["elite"])
+            assert tr.best_idx == ref["best"]
+            np.testing.assert_allclose(tr.mean, ref["mean"], rtol=1e-12, atol=1e-14)
+            np.testing.assert_allclose(tr.std, ref["std"], rtol=1e-12, atol=1e-14)
+            it += 1
+    assert it == g.n_iters_total
+    assert next(calls, None) is None
+
+
+def test_noise_call_order_and_sizes():
+    """batch sizes 128->102->81, +3 shifted elites on steps >= 1."""
+    g = Golden("c1_halfcheetah_n128")
+    sizes = [g.noise(i)[0].shape[0] for i in range(g.n_noise_calls)]
+    assert sizes == [128, 102, 81, 128, 3, 102, 81, 128, 3, 102, 81]
+    assert O.population_sizes(128, 10, 1.25, 3) == [128, 102, 81]
+    assert O.population_sizes(4096, 10, 1.25, 5) == [4096, 3276, 2620, 2096, 1676]
+    assert [g.it(i)["simact"].shape[0] for i in range(6)] == [128, 102, 81, 131, 102, 81]
+    assert [g.it(i)["costs"].shape[0] for i in range(6)] == [128, 105, 84, 131, 105, 84]
+
+
+def test_legacy_stream_reproduces_reference():
+    """Under np.random.seed the oracle's legacy draw order reproduces the reference run."""
+    g = Golden("c1_halfcheetah_n128")
+    np.random.seed(g.seed)
+    orc = _oracle_for(g, lambda num: O.legacy_white_noise(num, g.d, g.h))
+    orc.beginning_of_rollout()
+    for s in range(g.n_steps):
+        a = orc.get_action(g.obs[s])
+        np.testing.assert_allclose(a, g.executed[s], rtol=1e-12, atol=1e-14)
+
+
+def test_cost_functions_match_reference():
+    z = np.load(os.path.join(GOLDEN, "cost_fn_vectors.npz"))
+    hc17 = O.CostSpec.halfcheetah(17)
+    hc18 = O.CostSpec.halfcheetah(18)
+    assert np.array_equal(hc17(z["o17"], z["a6"]), z["hc17"])
+    assert np.array_equal(hc18(z["o18"], z["a6"]), z["hc18"])
+    assert np.array_equal(O.CostSpec.halfcheetah(17, False)(z["o17"], z["a6"]), z["hc17_noflip"])
+    assert np.array_equal(hc17(z["o17"][0, 0][None], z["a6"][0, 0][None])[0], z["hc17_single"])
+    assert np.array_equal(O.CostSpec.humanoid_standup()(z["o378"], z["a17"]), z["hs"])
+    with pytest.raises(ValueError):
+        O.CostSpec.halfcheetah(16)
+    # the flip penalty is exercised by the vectors
+    assert (np.abs(z["o17"][..., 1]) > np.pi / 2).any()
