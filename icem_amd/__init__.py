@@ -1,0 +1,16 @@
+"""icem_amd -- MI355X-native iCEM inner planning loop.
+
+The hot path of martius-lab/iCEM's ``MpcICem.get_action`` (colored-noise
+sampling + clip, batched rollout, per-trajectory cost, sorted top-k, mean/std
+refit) as hand-written HIP for gfx950 behind a C ABI (``include/icem_hip.h``,
+``libicem_hip.so``), with a host-side mirror of the reference's controller /
+forward-model interface.  There is no CPU fallback: every operator raises if
+the HIP library is missing.
+"""
+from ._lib import IcemError, lib_path, load_library  # noqa: F401
+from .planner import IcemConfig, IcemPlanner  # noqa: F401
+from .envs import SyntheticEnv, halfcheetah_env, humanoid_standup_env  # noqa: F401
+from .models import DeviceSyntheticModel  # noqa: F401
+from .controllers import (MpcICemHip, controller_from_string, ControllerFactory)  # noqa: F401
+
+__version__ = "0.1.0"

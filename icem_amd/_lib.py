@@ -1,0 +1,107 @@
+"""ctypes binding of ``libicem_hip.so`` (the C ABI declared in ``include/icem_hip.h``)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB: Optional[C.CDLL] = None
+
+ICEM_F32, ICEM_F64 = 0, 1
+COST_MODES = {"sum": 0, "best": 1, "final": 2}
+MODEL_LINEAR, MODEL_TANH = 0, 1
+(BUF_MEAN, BUF_STD, BUF_LOW, BUF_HIGH, BUF_OBS0, BUF_ACTIONS, BUF_COSTS, BUF_ELITES, BUF_RECORDS,
+ BUF_WORKSPACE, BUF_EXECUTED, BUF_BEST_COST, BUF_COUNT) = range(13)
+
+ERR_NAMES = {-1: "ICEM_E_INVALID", -2: "ICEM_E_UNSUPPORTED", -3: "ICEM_E_HIP", -4: "ICEM_E_NO_DEVICE",
+             -5: "ICEM_E_STATE"}
+
+
+class IcemError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+class IcemConfigC(C.Structure):
+    _fields_ = [
+        ("horizon", C.c_int32), ("act_dim", C.c_int32), ("num_traj", C.c_int32), ("num_elites", C.c_int32),
+        ("elites_size", C.c_int32), ("opt_iters", C.c_int32), ("cost_mode", C.c_int32),
+        ("use_mean_actions", C.c_int32), ("keep_previous_elites", C.c_int32), ("shift_elites", C.c_int32),
+        ("dtype", C.c_int32), ("rng_rounds", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32),
+        ("factor_decrease", C.c_double), ("alpha", C.c_double), ("init_std", C.c_double),
+        ("fraction_reused", C.c_double), ("noise_beta", C.c_double), ("seed", C.c_uint64),
+    ]
+
+
+class IcemCostSpecC(C.Structure):
+    _fields_ = [("ctrl_weight", C.c_double), ("lin_weight", C.c_double), ("flip_penalty", C.c_double),
+                ("flip_thresh", C.c_double), ("lin_idx", C.c_int32), ("flip_idx", C.c_int32)]
+
+
+class IcemPlanBuffersC(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "mean", "std", "low", "high", "obs0", "actions", "costs", "elites", "records", "workspace",
+        "executed", "best_cost", "z_r", "z_i", "z_r_shift", "z_i_shift")]
+
+
+# every symbol include/icem_hip.h declares: (name, restype, argtypes)
+_VP, _I32, _I64, _U64, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_size_t
+_H = C.c_void_p
+SYMBOLS = [
+    ("icem_abi_version", C.c_int, []),
+    ("icem_last_error", C.c_char_p, []),
+    ("icem_device_count", C.c_int, []),
+    ("icem_create", C.c_int, [C.POINTER(IcemConfigC), C.POINTER(_H)]),
+    ("icem_destroy", C.c_int, [_H]),
+    ("icem_population_sizes", C.c_int, [_H, C.POINTER(_I32)]),
+    ("icem_noise_tables_host", C.c_int, [_I32, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("icem_set_model", C.c_int, [_H, _I32, _I32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("icem_set_cost", C.c_int, [_H, C.POINTER(IcemCostSpecC)]),
+    ("icem_sample_clip", C.c_int, [_H, _I32, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _U64, _I32, _I32, _VP, _VP]),
+    ("icem_philox_normals", C.c_int, [_H, _I32, _I64, _U64, _VP, _VP, _VP]),
+    ("icem_rollout_cost", C.c_int, [_H, _I32, _VP, _VP, _VP, _VP, _VP]),
+    ("icem_cost_reduce", C.c_int, [_H, _I32, _VP, _VP, _VP]),
+    ("icem_topk_workspace_bytes", _SZ, [_H, _I32, _I32]),
+    ("icem_topk_sorted", C.c_int, [_H, _I32, _VP, _I32, _VP, _VP, _VP, _VP]),
+    ("icem_gather_refit", C.c_int, [_H, _VP, _VP, _I32, _VP, _VP, _VP, _VP]),
+    ("icem_shift", C.c_int, [_H, _VP, _VP, _VP, _VP, _VP]),
+    ("icem_reset_distribution", C.c_int, [_H, _VP, _VP, _VP, _VP, _VP]),
+    ("icem_plan_buffer_bytes", _SZ, [_H, _I32]),
+    ("icem_plan_iter_local", C.c_int, [_H, C.POINTER(IcemPlanBuffersC), _I32, _I32, _VP]),
+    ("icem_plan_iter_merge", C.c_int, [_H, C.POINTER(IcemPlanBuffersC), _I32, _I32, _VP]),
+    ("icem_plan_step", C.c_int, [_H, C.POINTER(IcemPlanBuffersC), _I32, _VP]),
+    ("icem_record_bytes", _SZ, [_H]),
+]
+
+
+def lib_path() -> str:
+    return os.environ.get("ICEM_HIP_LIB", os.path.join(_HERE, "libicem_hip.so"))
+
+
+def load_library() -> C.CDLL:
+    """Load ``libicem_hip.so`` and bind every exported symbol.  Raises if the
+    library has not been built -- there is deliberately no fallback."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not found: build it first (python -c 'import __graft_entry__ as g; g.build()'"
+                          f" or python -m icem_amd.build)")
+    lib = C.CDLL(path)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if lib.icem_abi_version() != 1:
+        raise ImportError(f"{path}: ABI version {lib.icem_abi_version()} != 1")
+    _LIB = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = load_library().icem_last_error()
+        raise IcemError(rc, msg.decode() if msg else "")

@@ -1,0 +1,385 @@
+"""Host-side mirror of the reference's controller interface for the hot path.
+
+``MpcICemHip`` keeps the constructor kwargs, ``beginning_of_rollout`` / ``get_action`` /
+``end_of_rollout`` signatures, attributes (``has_state``, ``needs_data`` ...) and error
+behaviour of the reference's ``MpcICem`` (icem/controllers/icem.py:15-247 on top of
+icem/controllers/mpc.py:21-83 and icem/controllers/abstract_controller.py:43-91), so the
+episode runner (icem/misc/rollout_utils.py:166-216) and ``main.py`` drive it unchanged.  The
+arithmetic inside the CEM loop runs in ``libicem_hip.so``; nothing here computes on the CPU
+except the optional *foreign* forward model (a reference-style CPU simulator), which is the
+caller's code.
+
+Two execution paths, chosen by the forward model:
+
+* device path  -- ``forward_model`` is a :class:`~icem_amd.models.DeviceSyntheticModel` and the
+  env carries a ``cost_spec``: the whole MPC step (all CEM iterations) is enqueued on one HIP
+  stream with no host synchronisation; only ``obs`` goes in and the action comes out.
+* host-model path -- any object with the reference's ``predict_n_steps`` contract: sampling,
+  top-k and refit run on the GPU, the model/cost run wherever the model runs.
+"""
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+from collections.abc import Mapping
+from importlib import import_module
+from typing import Callable, Optional, Union
+from warnings import warn
+
+import numpy as np
+import torch
+
+from .envs import Box, Discrete
+from .models import DeviceSyntheticModel, TrajectoryBatch
+from .planner import IcemConfig, IcemPlanner
+
+try:  # the reference logs through `allogger` (icem.py:28,177); optional here
+    import allogger as _allogger
+except Exception:  # pragma: no cover - allogger is not in the image
+    _allogger = None
+
+
+class _NullLogger:
+    logdir = None
+
+    def log(self, value, key=None):
+        pass
+
+    def info(self, *a, **k):
+        pass
+
+
+def _get_logger(scope):
+    if _allogger is not None:
+        try:
+            return _allogger.get_logger(scope=scope, default_outputs=["tensorboard"])
+        except Exception:
+            pass
+    return _NullLogger()
+
+
+# ---------------------------------------------------------------------------------------------
+# base types (icem/misc/base_types.py:39-59, icem/controllers/abstract_controller.py)
+# ---------------------------------------------------------------------------------------------
+
+class Controller(ABC):
+    needs_training = False
+    needs_data = False
+    has_state = False
+    required_settings = []
+
+    def __init__(self, *, env):
+        self.env = env
+
+    @abstractmethod
+    def get_action(self, obs, state, mode="train"):
+        """obs: observation from the environment; state: env-internal state; mode: train/eval/expert"""
+
+
+class StatefulController(Controller, ABC):
+    has_state = True
+
+    @abstractmethod
+    def beginning_of_rollout(self, *, observation, state=None, mode):
+        pass
+
+    @abstractmethod
+    def end_of_rollout(self, total_time, total_return, mode):
+        pass
+
+
+class ParallelController(Controller, ABC):
+    @abstractmethod
+    def get_parallel_policy_copy(self, indices):
+        pass
+
+
+class ModelBasedController(Controller, ABC):
+    def __init__(self, *, forward_model, env, cost_along_trajectory, do_visualize_plan=None,
+                 use_env_reward_as_cost=False, **kwargs):
+        super().__init__(env=env, **kwargs)
+        self.forward_model = forward_model
+        self.do_visualize_plan = do_visualize_plan
+        self.cost_fn = self.env.cost_fn
+        self.cost_along_trajectory = cost_along_trajectory
+        self.use_env_reward_as_cost = use_env_reward_as_cost
+
+    def trajectory_cost_fn(self, cost_fn, rollout_buffer):
+        """Per-trajectory cost of a batch of rollouts (abstract_controller.py:74-91)."""
+        if self.use_env_reward_as_cost:
+            costs_path = -np.asarray(rollout_buffer.as_array("rewards"))
+        else:
+            costs_path = np.asarray([cost_fn(r["observations"], r["actions"], r["next_observations"])
+                                     for r in rollout_buffer])
+        if self.cost_along_trajectory == "sum":
+            return np.sum(costs_path, axis=1)
+        if self.cost_along_trajectory == "best":
+            return np.amin(costs_path, axis=1)
+        if self.cost_along_trajectory == "final":
+            return costs_path[:, -1]
+        raise NotImplementedError(
+            "Implement method {} to compute cost along trajectory".format(self.cost_along_trajectory))
+
+
+class OpenLoopPolicy(ParallelController):
+    """Feeds column ``t`` of ``action_sequences [p,h,d]`` at the t-th call
+    (abstract_controller.py:153-184 with the fully-parallel iterator of controllers/utils.py:47-50)."""
+
+    def __init__(self, action_sequences, *, env=None):
+        super().__init__(env=env)
+        self.action_sequences = action_sequences
+        self._t = 0
+
+    def get_action(self, obs, state=None, mode="train"):
+        n_par = 1 if np.ndim(obs) == 1 else np.shape(obs)[0]
+        if n_par > self.action_sequences.shape[0]:
+            raise AttributeError("too many parallel rows requested!")
+        if self._t >= self.action_sequences.shape[1]:
+            raise AttributeError("I don't have any item(s) left.")
+        if n_par != self.action_sequences.shape[0]:
+            raise NotImplementedError("OpenLoopPolicy here serves the fully parallel case only")
+        col = self.action_sequences[:, self._t]
+        self._t += 1
+        return col if np.ndim(obs) > 1 else col[0]
+
+    def get_parallel_policy_copy(self, indices):
+        return OpenLoopPolicy(self.action_sequences[indices], env=self.env)
+
+
+class MpcController(ModelBasedController, StatefulController, ABC):
+    def __init__(self, *, horizon, num_simulated_trajectories, factor_decrease_num=1, verbose=False, **kwargs):
+        super().__init__(**kwargs)
+        self.horizon = horizon
+        self.num_sim_traj = num_simulated_trajectories
+        self.factor_decrease_num = factor_decrease_num
+        if num_simulated_trajectories < 2:
+            raise ValueError("At least two trajectories needed!")
+        self.verbose = verbose
+        self.forward_model_state = None
+
+    def simulate_trajectories(self, *, obs, state, action_sequences):
+        """mpc.py:56-67: tile the start observation, wrap the actions in an open-loop policy and
+        hand both to the model's ``predict_n_steps``."""
+        p = action_sequences.shape[0]
+        start_obs = np.array([obs] * p)
+        start_states = [state] * p
+        return self.forward_model.predict_n_steps(start_observations=start_obs, start_states=start_states,
+                                                  policy=OpenLoopPolicy(action_sequences), horizon=self.horizon)[0]
+
+    def beginning_of_rollout(self, *, observation, state=None, mode):
+        self.forward_model_state = self.forward_model.reset(observation)
+
+    def end_of_rollout(self, total_time, total_return, mode):
+        pass
+
+
+# ---------------------------------------------------------------------------------------------
+# the drop-in controller
+# ---------------------------------------------------------------------------------------------
+
+class MpcICemHip(MpcController):
+    """iCEM with the inner loop on MI355X (drop-in for ``controllers.icem.MpcICem``).
+
+    Extra keyword arguments (all optional, so the reference's settings JSON works untouched):
+    ``dtype`` ("f32" | "f64"), ``seed``, ``rng_rounds`` (10 | 7), ``device``,
+    ``noise_source`` ("philox": device counter RNG; "numpy_legacy": the reference's draws from
+    the global ``np.random`` stream, in the reference's order -- parity mode; or a callable
+    ``noise(num) -> (z_r, z_i)``), ``process_group`` / ``rank`` / ``world`` to shard N over GPUs.
+    """
+
+    def __init__(self, *, action_sampler_params, dtype="f32", seed=0, rng_rounds=10, device="cuda:0",
+                 noise_source: Union[str, Callable] = "philox", process_group=None, rank=0, world=1, **kwargs):
+        super().__init__(**kwargs)
+        self._parse_action_sampler_params(**dict(action_sampler_params))
+        self._check_validity_parameters()
+        self.logger = _get_logger(self.__class__.__name__)
+        self.was_reset = False
+        self.noise_source = noise_source
+        cfg = IcemConfig(
+            horizon=self.horizon, act_dim=self.dim_samples[1], num_traj=self.num_sim_traj,
+            elites_size=self.elites_size, opt_iters=self.opt_iter, cost_mode=self.cost_along_trajectory,
+            use_mean_actions=bool(self.use_mean_actions), keep_previous_elites=bool(self.keep_previous_elites),
+            shift_elites=bool(self.shift_elites_over_time), factor_decrease=float(self.factor_decrease_num),
+            alpha=float(self.alpha), init_std=float(self.init_std), fraction_reused=float(self.fraction_elites_reused),
+            noise_beta=float(self.noise_beta), dtype=dtype, rng_rounds=rng_rounds, seed=seed, rank=rank, world=world)
+        if cfg.cost_mode not in ("sum", "best", "final"):
+            raise NotImplementedError(
+                "Implement method {} to compute cost along trajectory".format(cfg.cost_mode))
+        self.planner = IcemPlanner(cfg, self.env.action_space.low, self.env.action_space.high, device=device,
+                                   process_group=process_group)
+        self.device_path = (isinstance(self.forward_model, DeviceSyntheticModel)
+                            and getattr(self.env, "cost_spec", None) is not None
+                            and not self.use_env_reward_as_cost)
+        if self.device_path:
+            m, c = self.forward_model, self.env.cost_spec
+            self.planner.set_model(m.kind, m.A, m.B)
+            self.planner.set_cost(c.ctrl_weight, c.lin_idx, c.lin_weight, c.flip_idx, c.flip_penalty, c.flip_thresh)
+        elif world != 1:
+            raise NotImplementedError("sharding over GPUs needs the device path (built-in model + cost_spec)")
+        self._elite_costs = None
+        self._elite_actions = None
+        self.last_min_cost = None
+
+    # -- parameter handling: icem.py:213-247 ---------------------------------------------------
+    def _parse_action_sampler_params(self, *, alpha, elites_size, opt_iterations, init_std, use_mean_actions,
+                                     keep_previous_elites, shift_elites_over_time, fraction_elites_reused,
+                                     noise_beta=1):
+        self.alpha = alpha
+        self.elites_size = elites_size
+        self.opt_iter = opt_iterations
+        self.init_std = init_std
+        self.use_mean_actions = use_mean_actions
+        self.keep_previous_elites = keep_previous_elites
+        self.shift_elites_over_time = shift_elites_over_time
+        self.fraction_elites_reused = fraction_elites_reused
+        self.noise_beta = noise_beta
+
+    def _check_validity_parameters(self):
+        self.num_elites = min(self.elites_size, self.num_sim_traj // 2)
+        if self.num_elites < 2:
+            warn('Number of trajectories is too low for given elites_frac. Setting num_elites to 2.')
+            self.num_elites = 2
+        space = self.env.action_space
+        if isinstance(space, Discrete) or type(space).__name__ == "Discrete":
+            raise NotImplementedError("CEM ERROR: Implement categorical distribution for discrete envs.")
+        if isinstance(space, Box) or type(space).__name__ == "Box":
+            self.dim_samples = (self.horizon, space.shape[0])
+        else:
+            raise NotImplementedError
+
+    # -- state views ---------------------------------------------------------------------------
+    @property
+    def mean(self) -> np.ndarray:
+        return self.planner.mean.detach().cpu().numpy().astype(np.float64)
+
+    @property
+    def std(self) -> np.ndarray:
+        return self.planner.std.detach().cpu().numpy().astype(np.float64)
+
+    @property
+    def elite_samples(self) -> TrajectoryBatch:
+        """Actions (and costs) of the current elite set, best first -- materialised on demand."""
+        if self.device_path:
+            if self.planner.mpc_step == 0:
+                return TrajectoryBatch()
+            a, c = self.planner.current_elites()
+        else:
+            if self._elite_actions is None:
+                return TrajectoryBatch()
+            a, c = self._elite_actions, self._elite_costs
+        return TrajectoryBatch(actions=a.detach().cpu().numpy().astype(np.float64),
+                               costs=c.detach().cpu().numpy().astype(np.float64))
+
+    # -- rollout hooks: icem.py:31-46 ----------------------------------------------------------
+    def beginning_of_rollout(self, *, observation, state=None, mode):
+        super().beginning_of_rollout(observation=observation, state=state, mode=mode)
+        if self.device_path:
+            self.planner.reset()
+        else:
+            p = self.planner
+            self._mean = torch.empty((p.h, p.d), dtype=p.dt, device=p.device)
+            self._std = torch.empty_like(self._mean)
+            p.reset_distribution(self._mean, self._std)
+            p.mean, p.std = self._mean, self._std
+            p.mpc_step = 0
+        self._elite_actions = None
+        self._elite_costs = None
+        self.was_reset = True
+        self.model_evals_per_timestep = sum(
+            max(self.elites_size * 2, int(self.num_sim_traj / (self.factor_decrease_num ** i)))
+            for i in range(self.opt_iter)) * self.horizon
+        if self.verbose:
+            print(f"iCEM using {self.model_evals_per_timestep} evaluations per step "
+                  f"and {self.model_evals_per_timestep / self.horizon} trajectories per step")
+
+    def end_of_rollout(self, total_time, total_return, mode):
+        super().end_of_rollout(total_time, total_return, mode)
+
+    # -- noise sources -------------------------------------------------------------------------
+    def _noise_fn(self):
+        if callable(self.noise_source):
+            return self.noise_source
+        if self.noise_source == "numpy_legacy":
+            d, F = self.dim_samples[1], self.horizon // 2 + 1
+
+            def legacy(num):  # the two global-stream draws of colorednoise (call site icem.py:73)
+                return np.random.normal(size=(num, d, F)), np.random.normal(size=(num, d, F))
+            return legacy
+        if self.noise_source == "philox":
+            return None
+        raise ValueError(f"unknown noise_source {self.noise_source!r}")
+
+    # -- one MPC step: icem.py:106-189 ---------------------------------------------------------
+    def get_action(self, obs, state, mode="train"):
+        if not self.was_reset:
+            raise AttributeError("beginning_of_rollout() needs to be called before")
+        self.forward_model_state = self.forward_model.got_actual_observation_and_env_state(
+            observation=obs, env_state=state, model_state=self.forward_model_state)
+        noise = self._noise_fn()
+        if self.device_path:
+            executed_dev = self.planner.plan_step(obs, noise=noise)
+            host = torch.cat([executed_dev, self.planner.best_cost]).cpu().numpy().astype(np.float64)  # one D2H sync
+            executed_action, self.last_min_cost = host[:-1], float(host[-1])
+        else:
+            executed_action = self._get_action_host_model(obs, noise)
+        self.logger.log(self.last_min_cost, key="Expected_trajectory_cost")
+        if self.forward_model_state is not None:  # stateful models advance with the executed action
+            _, self.forward_model_state, _ = self.forward_model.predict(
+                observations=obs, states=self.forward_model_state, actions=executed_action)
+        return executed_action
+
+    def _get_action_host_model(self, obs, noise):
+        p = self.planner
+        K, it_n = self.num_elites, self.opt_iter
+        call_base = p.mpc_step * (it_n + 1)
+        pool = costs_dev = idx = None
+        for i, n_i in enumerate(p.population_sizes):
+            z = noise(n_i) if noise is not None else (None, None)
+            actions = p.sample_clip(n_i, p.mean, p.std, z[0], z[1], offset=call_base + i,
+                                    row0_mean=bool(self.use_mean_actions and i == it_n - 1))
+            if i == 0 and self.shift_elites_over_time and self._elite_actions is not None and p.n_reuse > 0:
+                zs = noise(p.n_reuse) if noise is not None else (None, None)
+                shifted = torch.empty((p.n_reuse, p.h, p.d), dtype=p.dt, device=p.device)
+                shifted[:, :-1] = self._elite_actions[:p.n_reuse, 1:]
+                p.sample_clip(p.n_reuse, p.mean, p.std, zs[0], zs[1], offset=call_base + it_n, t_begin=p.h - 1,
+                              out=shifted)
+                actions = torch.cat([actions, shifted], dim=0)
+            batch = self.simulate_trajectories(obs=obs, state=self.forward_model_state,
+                                               action_sequences=actions.cpu().numpy().astype(np.float64))
+            costs = torch.as_tensor(self.trajectory_cost_fn(self.cost_fn, batch), dtype=p.dt, device=p.device)
+            pool = actions
+            if i > 0 and self.keep_previous_elites:
+                pool = torch.cat([actions, self._elite_actions[:p.n_reuse]], dim=0)
+                costs = torch.cat([costs, self._elite_costs[:p.n_reuse]])
+            costs_dev, idx = p.topk_sorted(costs, K)
+            self._elite_actions = p.gather_refit(pool, idx, p.mean, p.std)
+            self._elite_costs = costs_dev
+        executed = self._elite_actions[0, 0].cpu().numpy().astype(np.float64)  # best of the last pool (icem.py:163)
+        self.last_min_cost = float(costs_dev[0])
+        p.shift(p.mean, p.std)
+        p.mpc_step += 1
+        return executed
+
+
+# ---------------------------------------------------------------------------------------------
+# registry: icem/controllers/__init__.py:6-31
+# ---------------------------------------------------------------------------------------------
+
+def controller_from_string(controller_str):
+    return ControllerFactory(controller_str=controller_str)
+
+
+class ControllerFactory:
+    valid_base_controllers = {
+        "mpc-icem-hip": (".controllers", "MpcICemHip"),
+        "mpc-icem": (".controllers", "MpcICemHip"),
+    }
+    controller = None
+
+    def __new__(cls, *, controller_str):
+        if controller_str in cls.valid_base_controllers:
+            pkg, name = cls.valid_base_controllers[controller_str]
+            cls.controller = getattr(import_module(pkg, "icem_amd"), name)
+        else:
+            raise ImportError(f"cannot find '{controller_str}' in known controller: "
+                              f"{cls.valid_base_controllers.keys()}")
+        return cls.controller

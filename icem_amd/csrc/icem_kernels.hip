@@ -1,0 +1,1191 @@
+// icem_kernels.hip -- gfx950 kernels of the iCEM inner planning loop + the C ABI (include/icem_hip.h).
+//
+// Data layout in HBM (all C-contiguous, T = float or double):
+//   actions [n, h, d]   the reference's `action_sequences` (icem/controllers/icem.py:73-79)
+//   costs   [n]
+//   mean/std [h, d], low/high [d]
+//   W [h, HMAX]         colored-noise synthesis table, row t holds the h coefficients that turn the
+//                       h white draws of one (trajectory, action-dim) row into sample t (zero padded)
+//   records [world*K, 2+h*d]   {cost, gidx, actions[h*d]} -- what the ranks all-gather
+//
+// Kernels (one section each): sample_clip (K1), rollout_cost (K2), block top-k (K3),
+// local_pack / merge_refit (K3+K4 of the fused step), small epilogue kernels.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/icem_hip.h"
+#include "philox.h"
+
+namespace icem {
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define ICEM_HIP_TRY(expr)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(ICEM_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+constexpr int WG = 256;          // 4 wavefronts of 64
+constexpr int TOPK_CHUNK = 1024; // costs per workgroup in the block-level top-k
+
+template <typename T>
+__device__ __forceinline__ T inf_v() {
+    return (T)INFINITY;
+}
+
+// (cost, index) lexicographic order; the index breaks ties (np.argmin / stable argsort semantics).
+template <typename T>
+__device__ __forceinline__ bool key_less(T ca, int ia, T cb, int ib) {
+    return ca < cb || (ca == cb && ia < ib);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1  colored-noise sampling + affine + clip          (icem.py:61-82 + colorednoise)
+// ---------------------------------------------------------------------------------------------
+// One thread per (trajectory, action-dim) row: it owns the h white draws of that row, applies the
+// [h x h] synthesis (inverse real DFT with f^(-beta/2)/sigma folded in) with the table row as a
+// wave-uniform (scalar) operand, and parks the h samples in an LDS tile laid out like the output,
+// so the workgroup's slab of `actions` (tpw consecutive trajectories = one contiguous span) goes
+// out as coalesced stores.  The reference's transpose([0,2,1]) is absorbed by the tile indexing.
+
+template <typename T>
+struct SampleArgs {
+    int n, h, d, F, tpw;
+    long long first_index;
+    const T* W;
+    const T* mean;
+    const T* std;
+    const T* low;
+    const T* high;
+    const T* zr;
+    const T* zi;
+    uint32_t seed_lo, seed_hi, off_lo, off_hi;
+    int t_begin, row0_mean;
+    T* out;
+};
+
+template <typename T, int HMAX, int ROUNDS>
+__device__ __forceinline__ void white_row(const SampleArgs<T>& a, int row_local, long long gi, int j, T (&g)[HMAX]) {
+    if (a.zr != nullptr) {
+        const size_t base = ((size_t)row_local * a.d + j) * a.F;
+#pragma unroll
+        for (int m = 0; m < HMAX; ++m) {
+            T v = (T)0;
+            if (m < a.F)
+                v = a.zr[base + m];
+            else if (m < a.h)
+                v = a.zi[base + (m - a.F + 1)];
+            g[m] = v;
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < HMAX / 4; ++b) {
+            if (4 * b < a.h) {
+                const U4 r = philox4x32<ROUNDS>((uint32_t)gi, ((uint32_t)j << 16) | (uint32_t)b, a.off_lo,
+                                                a.off_hi, a.seed_lo, a.seed_hi);
+                box_muller(r.x, r.y, g[4 * b], g[4 * b + 1]);
+                box_muller(r.z, r.w, g[4 * b + 2], g[4 * b + 3]);
+            } else {
+                g[4 * b] = g[4 * b + 1] = g[4 * b + 2] = g[4 * b + 3] = (T)0;
+            }
+        }
+    }
+}
+
+template <typename T, int HMAX, int ROUNDS>
+__global__ __launch_bounds__(WG) void sample_clip_kernel(SampleArgs<T> a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* tile = reinterpret_cast<T*>(smem_raw);
+    const int tid = threadIdx.x;
+    const int hd = a.h * a.d;
+    const int n_base = blockIdx.x * a.tpw;
+    const int n_here = min(a.tpw, a.n - n_base);
+    const int rows = n_here * a.d;
+    if (tid < rows) {
+        const int nl = tid / a.d;
+        const int j = tid - nl * a.d;
+        T g[HMAX];
+        white_row<T, HMAX, ROUNDS>(a, n_base + nl, a.first_index + n_base + nl, j, g);
+        const T lo = a.low[j], hi = a.high[j];
+        for (int t = a.t_begin; t < a.h; ++t) {
+            const T* __restrict__ w = a.W + (size_t)t * HMAX;
+            T acc = (T)0;
+#pragma unroll
+            for (int m = 0; m < HMAX; ++m) acc = __builtin_fma(g[m], w[m], acc);
+            T v = __builtin_fma(acc, a.std[t * a.d + j], a.mean[t * a.d + j]);
+            v = v < lo ? lo : v;
+            v = v > hi ? hi : v;
+            tile[nl * hd + t * a.d + j] = v;
+        }
+    }
+    __syncthreads();
+    if (a.row0_mean && a.first_index + n_base == 0) {  // icem.py:87-88
+        for (int e = tid; e < hd; e += WG) tile[e] = a.mean[e];
+        __syncthreads();
+    }
+    const size_t base = (size_t)n_base * hd;
+    const int total = n_here * hd;
+    const int e_begin = a.t_begin * a.d;
+    for (int e = tid; e < total; e += WG) {
+        if (e_begin == 0 || (e % hd) >= e_begin) a.out[base + e] = tile[e];
+    }
+}
+
+// Raw Philox white noise in the reference's [n, d, F] x 2 layout (RNG known-answer tests).
+template <typename T, int HMAX, int ROUNDS>
+__global__ __launch_bounds__(WG) void philox_normals_kernel(SampleArgs<T> a, T* zr_out, T* zi_out) {
+    const int row = blockIdx.x * WG + threadIdx.x;
+    if (row >= a.n * a.d) return;
+    const int nl = row / a.d;
+    const int j = row - nl * a.d;
+    T g[HMAX];
+    white_row<T, HMAX, ROUNDS>(a, nl, a.first_index + nl, j, g);
+    const size_t base = (size_t)row * a.F;
+#pragma unroll
+    for (int m = 0; m < HMAX; ++m) {
+        if (m < a.F) {
+            zr_out[base + m] = g[m];
+            zi_out[base + m] = (T)0;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < HMAX; ++m) {
+        if (m >= a.F && m < a.h) zi_out[base + (m - a.F + 1)] = g[m];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2  batched open-loop rollout + per-trajectory cost   (abstract_models.py:17-53,
+//     abstract_controller.py:74-91, environments/mujoco.py:67-99 / 259-277)
+// ---------------------------------------------------------------------------------------------
+// One thread per trajectory; the observation lives in registers (O compile-time, zero padded),
+// the model matrices are wave-uniform operands.  Cost is scored on the PRE-action observation.
+
+template <typename T>
+struct CostArgs {
+    T ctrl_w, lin_w, flip_pen, flip_th;
+    int lin_idx, flip_idx;
+};
+
+template <typename T>
+struct RolloutArgs {
+    int n, h, d, o;
+    const T* A;  // [O, O] padded
+    const T* B;  // [d, O] padded
+    const T* obs0;
+    const T* actions;
+    T* costs;
+    T* observations;  // nullable [n, h, o]
+    CostArgs<T> cs;
+    int cost_mode;
+};
+
+__device__ __forceinline__ float act_tanh(float x) { return tanhf(x); }
+__device__ __forceinline__ double act_tanh(double x) { return tanh(x); }
+
+template <typename T, int O, int KIND>
+__global__ __launch_bounds__(WG) void rollout_cost_kernel(RolloutArgs<T> a) {
+    const int n = blockIdx.x * WG + threadIdx.x;
+    if (n >= a.n) return;
+    T obs[O];
+#pragma unroll
+    for (int k = 0; k < O; ++k) obs[k] = k < a.o ? a.obs0[k] : (T)0;
+    const T* __restrict__ act = a.actions + (size_t)n * a.h * a.d;
+    const T* __restrict__ A = a.A;
+    const T* __restrict__ B = a.B;
+    T acc = (T)0;
+    for (int t = 0; t < a.h; ++t) {
+        T nxt[O];
+#pragma unroll
+        for (int i = 0; i < O; ++i) nxt[i] = (T)0;
+#pragma unroll
+        for (int k = 0; k < O; ++k) {
+            const T ok = obs[k];
+#pragma unroll
+            for (int i = 0; i < O; ++i) nxt[i] = __builtin_fma(ok, A[k * O + i], nxt[i]);
+        }
+        T ctrl = (T)0;
+        for (int j = 0; j < a.d; ++j) {
+            const T aj = act[t * a.d + j];
+            ctrl = __builtin_fma(aj, aj, ctrl);
+#pragma unroll
+            for (int i = 0; i < O; ++i) nxt[i] = __builtin_fma(aj, B[j * O + i], nxt[i]);
+        }
+        T lin = (T)0, ang = (T)0;
+#pragma unroll
+        for (int k = 0; k < O; ++k) {
+            lin = (k == a.cs.lin_idx) ? obs[k] : lin;
+            ang = (k == a.cs.flip_idx) ? obs[k] : ang;
+        }
+        T c = (T)0;
+        if (a.cs.flip_idx >= 0) {
+            c += (ang > a.cs.flip_th) ? a.cs.flip_pen : (T)0;
+            c += (ang < -a.cs.flip_th) ? a.cs.flip_pen : (T)0;
+        }
+        c += a.cs.ctrl_w * ctrl;
+        c += a.cs.lin_w * lin;
+        if (t == 0 || a.cost_mode == ICEM_COST_FINAL)
+            acc = c;
+        else if (a.cost_mode == ICEM_COST_SUM)
+            acc += c;
+        else
+            acc = c < acc ? c : acc;
+        if (a.observations != nullptr) {
+            T* dst = a.observations + ((size_t)n * a.h + t) * a.o;
+#pragma unroll
+            for (int k = 0; k < O; ++k)
+                if (k < a.o) dst[k] = obs[k];
+        }
+#pragma unroll
+        for (int i = 0; i < O; ++i) obs[i] = (KIND == ICEM_MODEL_TANH) ? act_tanh(nxt[i]) : nxt[i];
+    }
+    a.costs[n] = acc;
+}
+
+template <typename T>
+__global__ __launch_bounds__(WG) void cost_reduce_kernel(int n, int h, int mode, const T* step, T* costs) {
+    const int i = blockIdx.x * WG + threadIdx.x;
+    if (i >= n) return;
+    const T* row = step + (size_t)i * h;
+    T acc = row[0];
+    for (int t = 1; t < h; ++t) {
+        const T c = row[t];
+        if (mode == ICEM_COST_SUM)
+            acc += c;
+        else if (mode == ICEM_COST_BEST)
+            acc = c < acc ? c : acc;
+        else
+            acc = c;
+    }
+    costs[i] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3  sorted top-k                                       (icem.py:199 argsort()[:K], :149 argmin)
+// ---------------------------------------------------------------------------------------------
+// Threshold selection: round r takes the smallest (cost, idx) key strictly greater than round
+// r-1's winner, so nothing is mutated and the K winners come out already sorted.  Per round: a
+// strided scan of the keys, a 64-lane butterfly, and one LDS hop across the 4 waves.
+
+template <typename T>
+__device__ __forceinline__ void wave_min_key(T& c, int& i) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const T oc = __shfl_xor(c, s, 64);
+        const int oi = __shfl_xor(i, s, 64);
+        if (key_less(oc, oi, c, i)) {
+            c = oc;
+            i = oi;
+        }
+    }
+}
+
+// getc(e)/geti(e) expose `cnt` keys; winners go to out_c/out_i[0..K) (any address space),
+// `slot(e)` is returned through out_e (position of the winner in the key array) when non-null.
+template <typename T, typename GetC, typename GetI>
+__device__ __forceinline__ void block_select_sorted(int cnt, int K, GetC getc, GetI geti, T* out_c, int* out_i,
+                                                    int* out_e, T* red_c, int* red_i, int* red_e) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    T pc = -inf_v<T>();
+    int pi = -1;
+    for (int r = 0; r < K; ++r) {
+        T bc = inf_v<T>();
+        int bi = INT_MAX, be = -1;
+        for (int e = tid; e < cnt; e += WG) {
+            const T c = getc(e);
+            const int i = geti(e);
+            const bool after_prev = c > pc || (c == pc && i > pi);
+            if (after_prev && key_less(c, i, bc, bi)) {
+                bc = c;
+                bi = i;
+                be = e;
+            }
+        }
+        // reduce (bc, bi); carry `be` along with the winner
+        T wc = bc;
+        int wi = bi;
+        wave_min_key(wc, wi);
+        const bool mine = (wc == bc && wi == bi);
+        // several lanes can hold the sentinel; the lowest such lane reports
+        const unsigned long long m = __ballot(mine);
+        if (mine && lane == __ffsll((long long)m) - 1) {
+            red_c[wave] = bc;
+            red_i[wave] = bi;
+            red_e[wave] = be;
+        }
+        __syncthreads();
+        T fc = red_c[0];
+        int fi = red_i[0], fe = red_e[0];
+#pragma unroll
+        for (int w = 1; w < WG / 64; ++w) {
+            if (key_less(red_c[w], red_i[w], fc, fi)) {
+                fc = red_c[w];
+                fi = red_i[w];
+                fe = red_e[w];
+            }
+        }
+        if (tid == 0) {
+            out_c[r] = fc;
+            out_i[r] = fi;
+            if (out_e != nullptr) out_e[r] = fe;
+        }
+        pc = fc;
+        pi = fi;
+        __syncthreads();
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ T nan_to_inf(T c) {
+    return c != c ? inf_v<T>() : c;
+}
+
+// Stage 1: each workgroup reduces TOPK_CHUNK costs to its K best -> part_c/part_i[block*K + r].
+template <typename T>
+__global__ __launch_bounds__(WG) void topk_partial_kernel(int n, int K, const T* costs, T* part_c, int* part_i) {
+    __shared__ T keys[TOPK_CHUNK];
+    __shared__ T red_c[WG / 64];
+    __shared__ int red_i[WG / 64];
+    __shared__ int red_e[WG / 64];
+    const int base = blockIdx.x * TOPK_CHUNK;
+    const int cnt = min(TOPK_CHUNK, n - base);
+    for (int e = threadIdx.x; e < cnt; e += WG) keys[e] = nan_to_inf(costs[base + e]);
+    __syncthreads();
+    block_select_sorted<T>(
+        cnt, K, [&](int e) { return keys[e]; }, [&](int e) { return base + e; }, part_c + (size_t)blockIdx.x * K,
+        part_i + (size_t)blockIdx.x * K, nullptr, red_c, red_i, red_e);
+}
+
+// Stage 2 (stand-alone API): one workgroup merges the partial lists.
+template <typename T>
+__global__ __launch_bounds__(WG) void topk_final_kernel(int cnt, int K, const T* part_c, const int* part_i, T* out_c,
+                                                        int* out_i) {
+    __shared__ T red_c[WG / 64];
+    __shared__ int red_i[WG / 64];
+    __shared__ int red_e[WG / 64];
+    block_select_sorted<T>(
+        cnt, K, [&](int e) { return part_c[e]; }, [&](int e) { return part_i[e]; }, out_c, out_i, nullptr, red_c,
+        red_i, red_e);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4  gather + refit                                     (icem.py:201-211)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(WG) void gather_refit_kernel(int hd, int K, T alpha, const T* actions, const int* idx,
+                                                          T* mean, T* std, T* elites_out) {
+    for (int e = blockIdx.x * WG + threadIdx.x; e < hd; e += gridDim.x * WG) {
+        T s = (T)0;
+        for (int r = 0; r < K; ++r) {
+            const T x = actions[(size_t)idx[r] * hd + e];
+            if (elites_out != nullptr) elites_out[(size_t)r * hd + e] = x;
+            s += x;
+        }
+        const T m = s / (T)K;
+        T v = (T)0;
+        for (int r = 0; r < K; ++r) {
+            const T dx = actions[(size_t)idx[r] * hd + e] - m;
+            v = __builtin_fma(dx, dx, v);
+        }
+        const T sd = sqrt(v / (T)K);
+        mean[e] = ((T)1 - alpha) * m + alpha * mean[e];
+        std[e] = ((T)1 - alpha) * sd + alpha * std[e];
+    }
+}
+
+// get_action epilogue (icem.py:167-175) and beginning_of_rollout (icem.py:48-59).
+template <typename T>
+__global__ __launch_bounds__(WG) void shift_kernel(int h, int d, T init_std, T* mean, T* std, const T* low,
+                                                   const T* high) {
+    // single workgroup: read every element before any is overwritten
+    const int hd = h * d;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* tmp = reinterpret_cast<T*>(smem_raw);
+    for (int e = threadIdx.x; e < hd; e += WG) tmp[e] = mean[e];
+    __syncthreads();
+    for (int e = threadIdx.x; e < hd; e += WG) {
+        const int j = e % d;
+        mean[e] = (e + d < hd) ? tmp[e + d] : tmp[e];
+        std[e] = (high[j] - low[j]) / (T)2 * init_std;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(WG) void reset_kernel(int h, int d, T init_std, T* mean, T* std, const T* low,
+                                                   const T* high) {
+    const int hd = h * d;
+    for (int e = blockIdx.x * WG + threadIdx.x; e < hd; e += gridDim.x * WG) {
+        const int j = e % d;
+        mean[e] = (high[j] + low[j]) / (T)2;
+        std[e] = (high[j] - low[j]) / (T)2 * init_std;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused-step glue: shifted elites, local candidate packing, global merge + refit
+// ---------------------------------------------------------------------------------------------
+
+// icem.py:97-100: rows [0, n_reuse) of dst <- elites[e, 1:, :] (the last time step is sampled after).
+template <typename T>
+__global__ __launch_bounds__(WG) void shift_elites_kernel(int n_reuse, int h, int d, const T* elites, T* dst) {
+    const int hd = h * d;
+    const int total = n_reuse * (hd - d);
+    for (int x = blockIdx.x * WG + threadIdx.x; x < total; x += gridDim.x * WG) {
+        const int e = x / (hd - d);
+        const int r = x - e * (hd - d);
+        dst[(size_t)e * hd + r] = elites[(size_t)e * hd + d + r];
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ int rec_gidx(const T* rec) {
+    return reinterpret_cast<const int*>(rec + 1)[0];
+}
+template <typename T>
+__device__ __forceinline__ void rec_set(T* rec, T cost, int gidx) {
+    rec[0] = cost;
+    rec[1] = (T)0;
+    reinterpret_cast<int*>(rec + 1)[0] = gidx;
+}
+
+// One workgroup: pick this rank's K best among the block partials (sorted), translate local pool
+// indices to global trajectory indices, and pack {cost, gidx, actions row} records.
+//   local idx < n_loc           -> gidx = shard_lo + idx
+//   local idx >= n_loc (shifted elites simulated at iteration 0) -> gidx = n_global + (idx - n_loc)
+template <typename T>
+__global__ __launch_bounds__(WG) void local_pack_kernel(int cnt, int K, int hd, int n_loc, int shard_lo, int n_global,
+                                                        const T* part_c, const int* part_i, const T* actions,
+                                                        T* records) {
+    __shared__ T red_c[WG / 64];
+    __shared__ int red_i[WG / 64];
+    __shared__ int red_e[WG / 64];
+    __shared__ T sel_c[ICEM_MAX_ELITES];
+    __shared__ int sel_i[ICEM_MAX_ELITES];
+    block_select_sorted<T>(
+        cnt, K, [&](int e) { return part_c[e]; }, [&](int e) { return part_i[e]; }, sel_c, sel_i, nullptr, red_c,
+        red_i, red_e);
+    __syncthreads();
+    const int rs = hd + 2;
+    for (int r = 0; r < K; ++r) {
+        const int li = sel_i[r];
+        T* rec = records + (size_t)r * rs;
+        if (li == INT_MAX) {  // fewer than K candidates on this rank
+            if (threadIdx.x == 0) rec_set(rec, inf_v<T>(), INT_MAX);
+            for (int e = threadIdx.x; e < hd; e += WG) rec[2 + e] = (T)0;
+        } else {
+            const int g = li < n_loc ? shard_lo + li : n_global + (li - n_loc);
+            if (threadIdx.x == 0) rec_set(rec, sel_c[r], g);
+            const T* src = actions + (size_t)li * hd;
+            for (int e = threadIdx.x; e < hd; e += WG) rec[2 + e] = src[e];
+        }
+    }
+}
+
+template <typename T>
+struct MergeArgs {
+    int n_rec;        // world*K candidate records
+    int n_keep;       // kept elites appended as candidates (icem.py:143-145)
+    int K, h, d;
+    int n_global;     // N_it: kept elite e gets gidx = n_global + e
+    int last;         // last CEM iteration of the MPC step
+    T alpha, init_std;
+    const T* records;
+    const T* elites_cur;       // [K, hd]
+    const T* elites_cost_cur;  // [K]
+    T* elites_next;
+    T* elites_cost_next;
+    T* mean;
+    T* std;
+    const T* low;
+    const T* high;
+    T* executed;
+    T* best_cost;
+};
+
+// One workgroup: global sorted top-K over the gathered records (+ kept elites), new elite set,
+// mean/std refit with momentum (icem.py:199-211); on the last iteration also the executed action,
+// min cost, time shift of the mean and std reset (icem.py:163-177).
+template <typename T>
+__global__ __launch_bounds__(WG) void merge_refit_kernel(MergeArgs<T> a) {
+    __shared__ T red_c[WG / 64];
+    __shared__ int red_i[WG / 64];
+    __shared__ int red_e[WG / 64];
+    __shared__ T sel_c[ICEM_MAX_ELITES];
+    __shared__ int sel_i[ICEM_MAX_ELITES];
+    __shared__ int sel_e[ICEM_MAX_ELITES];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* new_mean = reinterpret_cast<T*>(smem_raw);  // [hd]
+    const int hd = a.h * a.d;
+    const int rs = hd + 2;
+    const int cnt = a.n_rec + a.n_keep;
+    block_select_sorted<T>(
+        cnt, a.K,
+        [&](int e) { return e < a.n_rec ? nan_to_inf(a.records[(size_t)e * rs]) : a.elites_cost_cur[e - a.n_rec]; },
+        [&](int e) { return e < a.n_rec ? rec_gidx(a.records + (size_t)e * rs) : a.n_global + (e - a.n_rec); }, sel_c,
+        sel_i, sel_e, red_c, red_i, red_e);
+    __syncthreads();
+    auto src_row = [&](int r) -> const T* {
+        const int e = sel_e[r];
+        return e < a.n_rec ? a.records + (size_t)e * rs + 2 : a.elites_cur + (size_t)(e - a.n_rec) * hd;
+    };
+    for (int e = threadIdx.x; e < hd; e += WG) {
+        T s = (T)0;
+        for (int r = 0; r < a.K; ++r) {
+            const T x = src_row(r)[e];
+            a.elites_next[(size_t)r * hd + e] = x;
+            s += x;
+        }
+        const T m = s / (T)a.K;
+        T v = (T)0;
+        for (int r = 0; r < a.K; ++r) {
+            const T dx = src_row(r)[e] - m;
+            v = __builtin_fma(dx, dx, v);
+        }
+        const T sd = sqrt(v / (T)a.K);
+        const T nm = ((T)1 - a.alpha) * m + a.alpha * a.mean[e];
+        const T ns = ((T)1 - a.alpha) * sd + a.alpha * a.std[e];
+        if (!a.last) {
+            a.mean[e] = nm;
+            a.std[e] = ns;
+        } else {
+            new_mean[e] = nm;
+        }
+    }
+    if (threadIdx.x < a.K) a.elites_cost_next[threadIdx.x] = sel_c[threadIdx.x];
+    if (a.last) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < hd; e += WG) {
+            const int j = e % a.d;
+            a.mean[e] = (e + a.d < hd) ? new_mean[e + a.d] : new_mean[e];
+            a.std[e] = (a.high[j] - a.low[j]) / (T)2 * a.init_std;
+        }
+        if (threadIdx.x < a.d) a.executed[threadIdx.x] = src_row(0)[threadIdx.x];
+        if (threadIdx.x == 0) a.best_cost[0] = sel_c[0];
+    }
+}
+
+}  // namespace icem
+
+// =============================================================================================
+// host side: handle + C ABI
+// =============================================================================================
+
+using namespace icem;
+
+struct icem_handle {
+    icem_config cfg;
+    int F = 0, HMAX = 0, hd = 0;
+    size_t tsize = 4;
+    void* W_dev = nullptr;
+    int model_kind = 0, obs_dim = 0, O = 0;
+    void* A_dev = nullptr;
+    void* B_dev = nullptr;
+    bool has_model = false, has_cost = false;
+    icem_cost_spec cost;
+    std::vector<int> pop;
+    int n_reuse = 0;
+    int n_local_max = 0;
+};
+
+namespace {
+
+void psd_scale_host(int h, double beta, std::vector<double>& s, double& sigma) {
+    // colorednoise.powerlaw_psd_gaussian (third-party, call site icem.py:73): f = rfftfreq(h),
+    // DC takes the first bin's value, s = f^(-beta/2), sigma = 2*sqrt(sum w^2)/h.
+    const int F = h / 2 + 1;
+    s.resize(F);
+    for (int k = 0; k < F; ++k) s[k] = (double)k * (1.0 / (double)h);
+    const double fmin = 1.0 / (double)h;
+    int ix = 0;
+    for (int k = 0; k < F; ++k) ix += s[k] < fmin ? 1 : 0;
+    if (ix && ix < F)
+        for (int k = 0; k < ix; ++k) s[k] = s[ix];
+    for (int k = 0; k < F; ++k) s[k] = std::pow(s[k], -beta / 2.0);
+    double acc = 0.0;
+    for (int k = 1; k < F; ++k) {
+        double w = s[k];
+        if (k == F - 1) w *= (1 + (h % 2)) / 2.0;
+        acc += w * w;
+    }
+    sigma = 2.0 * std::sqrt(acc) / (double)h;
+}
+
+void noise_tables(int h, double beta, std::vector<double>& cr, std::vector<double>& ci) {
+    std::vector<double> s;
+    double sigma;
+    psd_scale_host(h, beta, s, sigma);
+    const int F = h / 2 + 1;
+    cr.assign((size_t)F * h, 0.0);
+    ci.assign((size_t)F * h, 0.0);
+    for (int k = 0; k < F; ++k) {
+        double mult = 2.0;
+        if (k == 0 || (h % 2 == 0 && k == F - 1)) mult = 1.0;
+        const double amp = mult * s[k] / ((double)h * sigma);
+        const bool imag_dropped = (k == 0) || (h % 2 == 0 && k == F - 1);
+        for (int t = 0; t < h; ++t) {
+            const double ang = 2.0 * M_PI * (double)k * (double)t / (double)h;
+            cr[(size_t)k * h + t] = amp * std::cos(ang);
+            ci[(size_t)k * h + t] = imag_dropped ? 0.0 : -amp * std::sin(ang);
+        }
+    }
+}
+
+std::vector<int> population_sizes(const icem_config& c) {
+    std::vector<int> out;
+    int n = c.num_traj;
+    for (int i = 0; i < c.opt_iters; ++i) {
+        if (i > 0) n = std::max(c.elites_size * 2, (int)((double)n / c.factor_decrease));
+        out.push_back(n);
+    }
+    return out;
+}
+
+template <typename T>
+int upload(void** dev, const std::vector<double>& host) {
+    std::vector<T> tmp(host.size());
+    for (size_t i = 0; i < host.size(); ++i) tmp[i] = (T)host[i];
+    if (*dev) {
+        (void)hipFree(*dev);
+        *dev = nullptr;
+    }
+    ICEM_HIP_TRY(hipMalloc(dev, tmp.size() * sizeof(T)));
+    ICEM_HIP_TRY(hipMemcpy(*dev, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice));
+    return ICEM_OK;
+}
+
+int pick_O(int o) {
+    const int sizes[] = {8, 16, 17, 18, 24, 32};
+    for (int s : sizes)
+        if (o <= s) return s;
+    return -1;
+}
+
+inline int shard_chunk(int n_global, int world) { return (n_global + world - 1) / world; }
+
+// ---- typed launchers -------------------------------------------------------------------------
+
+template <typename T>
+SampleArgs<T> make_sample_args(const icem_handle* h, int n, long long first_index, const void* mean, const void* std,
+                               const void* low, const void* high, const void* zr, const void* zi, uint64_t offset,
+                               int t_begin, int row0_mean, void* out) {
+    SampleArgs<T> a;
+    a.n = n;
+    a.h = h->cfg.horizon;
+    a.d = h->cfg.act_dim;
+    a.F = h->F;
+    a.tpw = std::max(1, WG / a.d);
+    a.first_index = first_index;
+    a.W = (const T*)h->W_dev;
+    a.mean = (const T*)mean;
+    a.std = (const T*)std;
+    a.low = (const T*)low;
+    a.high = (const T*)high;
+    a.zr = (const T*)zr;
+    a.zi = (const T*)zi;
+    a.seed_lo = (uint32_t)h->cfg.seed;
+    a.seed_hi = (uint32_t)(h->cfg.seed >> 32);
+    a.off_lo = (uint32_t)offset;
+    a.off_hi = (uint32_t)(offset >> 32);
+    a.t_begin = t_begin;
+    a.row0_mean = row0_mean;
+    a.out = (T*)out;
+    return a;
+}
+
+template <typename T>
+int launch_sample(const icem_handle* h, const SampleArgs<T>& a, hipStream_t st) {
+    if (a.n <= 0) return ICEM_OK;
+    const int grid = (a.n + a.tpw - 1) / a.tpw;
+    const size_t lds = (size_t)a.tpw * a.h * a.d * sizeof(T);
+    const bool r7 = h->cfg.rng_rounds == 7;
+    if (h->HMAX == 32) {
+        if (r7)
+            hipLaunchKernelGGL((sample_clip_kernel<T, 32, 7>), dim3(grid), dim3(WG), lds, st, a);
+        else
+            hipLaunchKernelGGL((sample_clip_kernel<T, 32, 10>), dim3(grid), dim3(WG), lds, st, a);
+    } else {
+        if (r7)
+            hipLaunchKernelGGL((sample_clip_kernel<T, 64, 7>), dim3(grid), dim3(WG), lds, st, a);
+        else
+            hipLaunchKernelGGL((sample_clip_kernel<T, 64, 10>), dim3(grid), dim3(WG), lds, st, a);
+    }
+    ICEM_HIP_TRY(hipGetLastError());
+    return ICEM_OK;
+}
+
+template <typename T, int KIND>
+int launch_rollout_k(const icem_handle* h, const RolloutArgs<T>& a, hipStream_t st) {
+    const int grid = (a.n + WG - 1) / WG;
+    switch (h->O) {
+#define ICEM_CASE(OV)                                                                                  \
+    case OV:                                                                                           \
+        hipLaunchKernelGGL((rollout_cost_kernel<T, OV, KIND>), dim3(grid), dim3(WG), 0, st, a);        \
+        break;
+        ICEM_CASE(8)
+        ICEM_CASE(16)
+        ICEM_CASE(17)
+        ICEM_CASE(18)
+        ICEM_CASE(24)
+        ICEM_CASE(32)
+#undef ICEM_CASE
+        default:
+            return fail(ICEM_E_UNSUPPORTED, "obs_dim not compiled");
+    }
+    ICEM_HIP_TRY(hipGetLastError());
+    return ICEM_OK;
+}
+
+template <typename T>
+int launch_rollout(const icem_handle* h, int n, const void* obs0, const void* actions, void* costs, void* observations,
+                   hipStream_t st) {
+    if (n <= 0) return ICEM_OK;
+    RolloutArgs<T> a;
+    a.n = n;
+    a.h = h->cfg.horizon;
+    a.d = h->cfg.act_dim;
+    a.o = h->obs_dim;
+    a.A = (const T*)h->A_dev;
+    a.B = (const T*)h->B_dev;
+    a.obs0 = (const T*)obs0;
+    a.actions = (const T*)actions;
+    a.costs = (T*)costs;
+    a.observations = (T*)observations;
+    a.cs.ctrl_w = (T)h->cost.ctrl_weight;
+    a.cs.lin_w = (T)h->cost.lin_weight;
+    a.cs.flip_pen = (T)h->cost.flip_penalty;
+    a.cs.flip_th = (T)h->cost.flip_thresh;
+    a.cs.lin_idx = h->cost.lin_idx;
+    a.cs.flip_idx = h->cost.flip_idx;
+    a.cost_mode = h->cfg.cost_mode;
+    return h->model_kind == ICEM_MODEL_TANH ? launch_rollout_k<T, ICEM_MODEL_TANH>(h, a, st)
+                                            : launch_rollout_k<T, ICEM_MODEL_LINEAR>(h, a, st);
+}
+
+inline int topk_blocks(int n) { return (n + TOPK_CHUNK - 1) / TOPK_CHUNK; }
+
+template <typename T>
+void split_partial_ws(void* ws, int nblk, int K, T** pc, int** pi) {
+    *pc = (T*)ws;
+    *pi = (int*)((unsigned char*)ws + (size_t)nblk * K * sizeof(T));
+}
+
+template <typename T>
+int launch_topk(int n, int K, const void* costs, void* out_c, int* out_i, void* ws, hipStream_t st) {
+    const int nblk = topk_blocks(n);
+    T* pc;
+    int* pi;
+    split_partial_ws<T>(ws, nblk, K, &pc, &pi);
+    hipLaunchKernelGGL((topk_partial_kernel<T>), dim3(nblk), dim3(WG), 0, st, n, K, (const T*)costs, pc, pi);
+    hipLaunchKernelGGL((topk_final_kernel<T>), dim3(1), dim3(WG), 0, st, nblk * K, K, (const T*)pc, (const int*)pi,
+                       (T*)out_c, out_i);
+    ICEM_HIP_TRY(hipGetLastError());
+    return ICEM_OK;
+}
+
+template <typename T>
+int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, int it, hipStream_t st) {
+    const icem_config& c = h->cfg;
+    const int hd = h->hd, K = c.num_elites;
+    const int n_global = h->pop[it];
+    const int chunk = shard_chunk(n_global, c.world);
+    const int lo = std::min(n_global, c.rank * chunk);
+    const int n_loc = std::max(0, std::min(n_global - lo, chunk));
+    const uint64_t call_base = (uint64_t)mpc_step * (uint64_t)(c.opt_iters + 1);
+    const bool last = it == c.opt_iters - 1;
+    T* actions = (T*)b->actions;
+    // main batch of this rank's shard (icem.py:84-89)
+    {
+        SampleArgs<T> a = make_sample_args<T>(h, n_loc, lo, b->mean, b->std, b->low, b->high, b->z_r, b->z_i,
+                                              call_base + (uint64_t)it, 0, (last && c.use_mean_actions) ? 1 : 0, actions);
+        int rc = launch_sample<T>(h, a, st);
+        if (rc) return rc;
+    }
+    // shifted elites, simulated at iteration 0 of every MPC step but the first (icem.py:131-137)
+    int n_extra = 0;
+    if (it == 0 && c.shift_elites && mpc_step > 0 && h->n_reuse > 0) {
+        n_extra = h->n_reuse;
+        const int g = (int)(((long long)mpc_step * c.opt_iters) & 1);  // elite buffer holding the previous step's set
+        const T* el = (const T*)b->elites + (size_t)g * K * hd;
+        T* dst = actions + (size_t)n_loc * hd;
+        hipLaunchKernelGGL((shift_elites_kernel<T>), dim3(1), dim3(WG), 0, st, n_extra, c.horizon, c.act_dim, el, dst);
+        SampleArgs<T> a = make_sample_args<T>(h, n_extra, 0, b->mean, b->std, b->low, b->high, b->z_r_shift, b->z_i_shift,
+                                              call_base + (uint64_t)c.opt_iters, c.horizon - 1, 0, dst);
+        int rc = launch_sample<T>(h, a, st);
+        if (rc) return rc;
+    }
+    int rc = launch_rollout<T>(h, n_loc + n_extra, b->obs0, actions, b->costs, nullptr, st);
+    if (rc) return rc;
+    // candidates: the shard, plus the shifted elites on rank 0 only (they are replicated)
+    const int n_cand = n_loc + (c.rank == 0 ? n_extra : 0);
+    const int nblk = std::max(1, topk_blocks(n_cand));
+    T* pc;
+    int* pi;
+    split_partial_ws<T>(b->workspace, nblk, K, &pc, &pi);
+    hipLaunchKernelGGL((topk_partial_kernel<T>), dim3(nblk), dim3(WG), 0, st, n_cand, K, (const T*)b->costs, pc, pi);
+    T* rec = (T*)b->records + (size_t)c.rank * K * (hd + 2);
+    hipLaunchKernelGGL((local_pack_kernel<T>), dim3(1), dim3(WG), 0, st, nblk * K, K, hd, n_loc, lo, n_global,
+                       (const T*)pc, (const int*)pi, (const T*)actions, rec);
+    ICEM_HIP_TRY(hipGetLastError());
+    return ICEM_OK;
+}
+
+template <typename T>
+int plan_iter_merge_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, int it, hipStream_t st) {
+    const icem_config& c = h->cfg;
+    const int hd = h->hd, K = c.num_elites;
+    const long long g = (long long)mpc_step * c.opt_iters + it;  // global iteration number
+    const int cur = (int)(g & 1), nxt = cur ^ 1;
+    T* el = (T*)b->elites;
+    T* elc = el + (size_t)2 * K * hd;
+    MergeArgs<T> a;
+    a.n_rec = c.world * K;
+    a.n_keep = (it > 0 && c.keep_previous_elites) ? h->n_reuse : 0;
+    a.K = K;
+    a.h = c.horizon;
+    a.d = c.act_dim;
+    a.n_global = h->pop[it];
+    a.last = it == c.opt_iters - 1;
+    a.alpha = (T)c.alpha;
+    a.init_std = (T)c.init_std;
+    a.records = (const T*)b->records;
+    a.elites_cur = el + (size_t)cur * K * hd;
+    a.elites_cost_cur = elc + (size_t)cur * K;
+    a.elites_next = el + (size_t)nxt * K * hd;
+    a.elites_cost_next = elc + (size_t)nxt * K;
+    a.mean = (T*)b->mean;
+    a.std = (T*)b->std;
+    a.low = (const T*)b->low;
+    a.high = (const T*)b->high;
+    a.executed = (T*)b->executed;
+    a.best_cost = (T*)b->best_cost;
+    hipLaunchKernelGGL((merge_refit_kernel<T>), dim3(1), dim3(WG), (size_t)hd * sizeof(T), st, a);
+    ICEM_HIP_TRY(hipGetLastError());
+    return ICEM_OK;
+}
+
+int check_handle(const icem_handle* h) {
+    if (!h) return fail(ICEM_E_INVALID, "null handle");
+    return ICEM_OK;
+}
+
+}  // namespace
+
+#define ICEM_DISPATCH(h, expr_f32, expr_f64) ((h)->cfg.dtype == ICEM_F64 ? (expr_f64) : (expr_f32))
+
+extern "C" {
+
+int icem_abi_version(void) { return ICEM_ABI_VERSION; }
+
+const char* icem_last_error(void) { return g_err.c_str(); }
+
+int icem_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int icem_noise_tables_host(int32_t horizon, double beta, double* cr_host, double* ci_host) {
+    if (horizon < 2 || !cr_host || !ci_host) return fail(ICEM_E_INVALID, "bad horizon / null output");
+    std::vector<double> cr, ci;
+    noise_tables(horizon, beta, cr, ci);
+    std::memcpy(cr_host, cr.data(), cr.size() * sizeof(double));
+    std::memcpy(ci_host, ci.data(), ci.size() * sizeof(double));
+    return ICEM_OK;
+}
+
+int icem_create(const icem_config* cfg, icem_handle** out) {
+    if (!cfg || !out) return fail(ICEM_E_INVALID, "null argument");
+    const icem_config& c = *cfg;
+    if (c.num_traj < 2) return fail(ICEM_E_INVALID, "At least two trajectories needed!");  // mpc.py:30-31
+    if (c.horizon < 2 || c.horizon > ICEM_MAX_HORIZON) return fail(ICEM_E_UNSUPPORTED, "horizon must be in [2, 64]");
+    if (c.act_dim < 1 || c.act_dim > ICEM_MAX_ACT_DIM) return fail(ICEM_E_UNSUPPORTED, "act_dim must be in [1, 64]");
+    if (c.num_elites < 1 || c.num_elites > ICEM_MAX_ELITES) return fail(ICEM_E_UNSUPPORTED, "num_elites must be in [1, 64]");
+    if (c.opt_iters < 1) return fail(ICEM_E_INVALID, "opt_iters < 1");
+    if (c.dtype != ICEM_F32 && c.dtype != ICEM_F64) return fail(ICEM_E_INVALID, "dtype");
+    if (c.rng_rounds != 10 && c.rng_rounds != 7) return fail(ICEM_E_INVALID, "rng_rounds must be 10 or 7");
+    if (c.world < 1 || c.rank < 0 || c.rank >= c.world) return fail(ICEM_E_INVALID, "rank/world");
+    if (!(c.noise_beta > 0)) return fail(ICEM_E_UNSUPPORTED, "noise_beta must be > 0");
+    if (!(c.factor_decrease >= 1.0)) return fail(ICEM_E_INVALID, "factor_decrease must be >= 1");
+    if (c.cost_mode < 0 || c.cost_mode > 2)
+        return fail(ICEM_E_UNSUPPORTED, "Implement method to compute cost along trajectory");  // abstract_controller.py:88-91
+    if (icem_device_count() < 1) return fail(ICEM_E_NO_DEVICE, "no HIP device visible");
+    icem_handle* h = new icem_handle();
+    h->cfg = c;
+    h->F = c.horizon / 2 + 1;
+    h->HMAX = c.horizon <= 32 ? 32 : 64;
+    h->hd = c.horizon * c.act_dim;
+    h->tsize = c.dtype == ICEM_F64 ? 8 : 4;
+    h->pop = population_sizes(c);
+    h->n_reuse = (int)((double)c.num_elites * c.fraction_reused);  // int(len(elites)*xi), icem.py:98,145
+    h->n_local_max = shard_chunk(c.num_traj, c.world);
+    // synthesis table W[t][m]: m < F real part of bin m, F <= m < h imaginary part of bin m-F+1
+    std::vector<double> cr, ci, W((size_t)c.horizon * h->HMAX, 0.0);
+    noise_tables(c.horizon, c.noise_beta, cr, ci);
+    for (int t = 0; t < c.horizon; ++t)
+        for (int m = 0; m < c.horizon; ++m)
+            W[(size_t)t * h->HMAX + m] = m < h->F ? cr[(size_t)m * c.horizon + t] : ci[(size_t)(m - h->F + 1) * c.horizon + t];
+    int rc = c.dtype == ICEM_F64 ? upload<double>(&h->W_dev, W) : upload<float>(&h->W_dev, W);
+    if (rc) {
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return ICEM_OK;
+}
+
+int icem_destroy(icem_handle* h) {
+    if (!h) return ICEM_OK;
+    if (h->W_dev) (void)hipFree(h->W_dev);
+    if (h->A_dev) (void)hipFree(h->A_dev);
+    if (h->B_dev) (void)hipFree(h->B_dev);
+    delete h;
+    return ICEM_OK;
+}
+
+int icem_population_sizes(const icem_handle* h, int32_t* out_host) {
+    if (!h || !out_host) return fail(ICEM_E_INVALID, "null argument");
+    for (size_t i = 0; i < h->pop.size(); ++i) out_host[i] = h->pop[i];
+    return ICEM_OK;
+}
+
+int icem_set_model(icem_handle* h, int32_t kind, int32_t obs_dim, const double* A_host, const double* B_host) {
+    if (!h || !A_host || !B_host) return fail(ICEM_E_INVALID, "null argument");
+    if (kind != ICEM_MODEL_LINEAR && kind != ICEM_MODEL_TANH) return fail(ICEM_E_INVALID, "model kind");
+    const int O = pick_O(obs_dim);
+    if (obs_dim < 1 || O < 0) return fail(ICEM_E_UNSUPPORTED, "obs_dim must be in [1, 32] for the built-in models");
+    const int d = h->cfg.act_dim;
+    std::vector<double> A((size_t)O * O, 0.0), B((size_t)d * O, 0.0);
+    for (int k = 0; k < obs_dim; ++k)
+        for (int i = 0; i < obs_dim; ++i) A[(size_t)k * O + i] = A_host[(size_t)k * obs_dim + i];
+    for (int j = 0; j < d; ++j)
+        for (int i = 0; i < obs_dim; ++i) B[(size_t)j * O + i] = B_host[(size_t)j * obs_dim + i];
+    int rc = h->cfg.dtype == ICEM_F64 ? upload<double>(&h->A_dev, A) : upload<float>(&h->A_dev, A);
+    if (rc) return rc;
+    rc = h->cfg.dtype == ICEM_F64 ? upload<double>(&h->B_dev, B) : upload<float>(&h->B_dev, B);
+    if (rc) return rc;
+    h->model_kind = kind;
+    h->obs_dim = obs_dim;
+    h->O = O;
+    h->has_model = true;
+    return ICEM_OK;
+}
+
+int icem_set_cost(icem_handle* h, const icem_cost_spec* spec) {
+    if (!h || !spec) return fail(ICEM_E_INVALID, "null argument");
+    h->cost = *spec;
+    h->has_cost = true;
+    return ICEM_OK;
+}
+
+int icem_sample_clip(icem_handle* h, int32_t n, int64_t first_index, const void* mean, const void* std,
+                     const void* low, const void* high, const void* z_r, const void* z_i, uint64_t offset,
+                     int32_t t_begin, int32_t row0_mean, void* actions, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (n < 0 || !mean || !std || !low || !high || !actions) return fail(ICEM_E_INVALID, "null tensor / negative n");
+    if ((z_r == nullptr) != (z_i == nullptr)) return fail(ICEM_E_INVALID, "z_r and z_i must both be given or both NULL");
+    if (t_begin < 0 || t_begin >= h->cfg.horizon) return fail(ICEM_E_INVALID, "t_begin out of range");
+    hipStream_t st = (hipStream_t)stream;
+    return ICEM_DISPATCH(h,
+                         launch_sample<float>(h, make_sample_args<float>(h, n, first_index, mean, std, low, high, z_r, z_i, offset, t_begin, row0_mean, actions), st),
+                         launch_sample<double>(h, make_sample_args<double>(h, n, first_index, mean, std, low, high, z_r, z_i, offset, t_begin, row0_mean, actions), st));
+}
+
+int icem_philox_normals(icem_handle* h, int32_t n, int64_t first_index, uint64_t offset, void* z_r, void* z_i,
+                        void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (n <= 0 || !z_r || !z_i) return fail(ICEM_E_INVALID, "null tensor / n <= 0");
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (n * h->cfg.act_dim + WG - 1) / WG;
+    const bool r7 = h->cfg.rng_rounds == 7;
+#define ICEM_PN(T, HM, R)                                                                                           \
+    hipLaunchKernelGGL((philox_normals_kernel<T, HM, R>), dim3(grid), dim3(WG), 0, st,                              \
+                       make_sample_args<T>(h, n, first_index, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, \
+                                           offset, 0, 0, nullptr),                                                  \
+                       (T*)z_r, (T*)z_i)
+    if (h->cfg.dtype == ICEM_F64) {
+        if (h->HMAX == 32) { if (r7) ICEM_PN(double, 32, 7); else ICEM_PN(double, 32, 10); }
+        else { if (r7) ICEM_PN(double, 64, 7); else ICEM_PN(double, 64, 10); }
+    } else {
+        if (h->HMAX == 32) { if (r7) ICEM_PN(float, 32, 7); else ICEM_PN(float, 32, 10); }
+        else { if (r7) ICEM_PN(float, 64, 7); else ICEM_PN(float, 64, 10); }
+    }
+#undef ICEM_PN
+    ICEM_HIP_TRY(hipGetLastError());
+    return ICEM_OK;
+}
+
+int icem_rollout_cost(icem_handle* h, int32_t n, const void* obs0, const void* actions, void* costs,
+                      void* observations, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (!h->has_model || !h->has_cost) return fail(ICEM_E_STATE, "icem_set_model / icem_set_cost must be called first");
+    if (n < 0 || !obs0 || !actions || !costs) return fail(ICEM_E_INVALID, "null tensor / negative n");
+    if (h->cost.lin_idx < 0 || h->cost.lin_idx >= h->obs_dim || h->cost.flip_idx >= h->obs_dim)
+        return fail(ICEM_E_INVALID, "cost index outside the observation");
+    hipStream_t st = (hipStream_t)stream;
+    return ICEM_DISPATCH(h, launch_rollout<float>(h, n, obs0, actions, costs, observations, st),
+                         launch_rollout<double>(h, n, obs0, actions, costs, observations, st));
+}
+
+int icem_cost_reduce(icem_handle* h, int32_t n, const void* step_costs, void* costs, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (n < 0 || !step_costs || !costs) return fail(ICEM_E_INVALID, "null tensor / negative n");
+    if (n == 0) return ICEM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (n + WG - 1) / WG;
+    if (h->cfg.dtype == ICEM_F64)
+        hipLaunchKernelGGL((cost_reduce_kernel<double>), dim3(grid), dim3(WG), 0, st, n, h->cfg.horizon, h->cfg.cost_mode,
+                           (const double*)step_costs, (double*)costs);
+    else
+        hipLaunchKernelGGL((cost_reduce_kernel<float>), dim3(grid), dim3(WG), 0, st, n, h->cfg.horizon, h->cfg.cost_mode,
+                           (const float*)step_costs, (float*)costs);
+    ICEM_HIP_TRY(hipGetLastError());
+    return ICEM_OK;
+}
+
+size_t icem_topk_workspace_bytes(const icem_handle* h, int32_t n, int32_t k) {
+    if (!h || n < 1 || k < 1) return 0;
+    return (size_t)topk_blocks(n) * (size_t)k * (h->tsize + sizeof(int));
+}
+
+int icem_topk_sorted(icem_handle* h, int32_t n, const void* costs, int32_t k, void* out_cost, int32_t* out_idx,
+                     void* workspace, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (n < 1 || k < 1 || k > ICEM_MAX_ELITES || !costs || !out_cost || !out_idx || !workspace)
+        return fail(ICEM_E_INVALID, "bad n/k or null tensor");
+    hipStream_t st = (hipStream_t)stream;
+    return ICEM_DISPATCH(h, launch_topk<float>(n, k, costs, out_cost, out_idx, workspace, st),
+                         launch_topk<double>(n, k, costs, out_cost, out_idx, workspace, st));
+}
+
+int icem_gather_refit(icem_handle* h, const void* actions, const int32_t* idx, int32_t k, void* mean, void* std,
+                      void* elites_out, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (k < 1 || !actions || !idx || !mean || !std) return fail(ICEM_E_INVALID, "bad k or null tensor");
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (h->hd + WG - 1) / WG;
+    if (h->cfg.dtype == ICEM_F64)
+        hipLaunchKernelGGL((gather_refit_kernel<double>), dim3(grid), dim3(WG), 0, st, h->hd, k, (double)h->cfg.alpha,
+                           (const double*)actions, idx, (double*)mean, (double*)std, (double*)elites_out);
+    else
+        hipLaunchKernelGGL((gather_refit_kernel<float>), dim3(grid), dim3(WG), 0, st, h->hd, k, (float)h->cfg.alpha,
+                           (const float*)actions, idx, (float*)mean, (float*)std, (float*)elites_out);
+    ICEM_HIP_TRY(hipGetLastError());
+    return ICEM_OK;
+}
+
+int icem_shift(icem_handle* h, void* mean, void* std, const void* low, const void* high, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (!mean || !std || !low || !high) return fail(ICEM_E_INVALID, "null tensor");
+    hipStream_t st = (hipStream_t)stream;
+    if (h->cfg.dtype == ICEM_F64)
+        hipLaunchKernelGGL((shift_kernel<double>), dim3(1), dim3(WG), (size_t)h->hd * 8, st, h->cfg.horizon, h->cfg.act_dim,
+                           (double)h->cfg.init_std, (double*)mean, (double*)std, (const double*)low, (const double*)high);
+    else
+        hipLaunchKernelGGL((shift_kernel<float>), dim3(1), dim3(WG), (size_t)h->hd * 4, st, h->cfg.horizon, h->cfg.act_dim,
+                           (float)h->cfg.init_std, (float*)mean, (float*)std, (const float*)low, (const float*)high);
+    ICEM_HIP_TRY(hipGetLastError());
+    return ICEM_OK;
+}
+
+int icem_reset_distribution(icem_handle* h, void* mean, void* std, const void* low, const void* high, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (!mean || !std || !low || !high) return fail(ICEM_E_INVALID, "null tensor");
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (h->hd + WG - 1) / WG;
+    if (h->cfg.dtype == ICEM_F64)
+        hipLaunchKernelGGL((reset_kernel<double>), dim3(grid), dim3(WG), 0, st, h->cfg.horizon, h->cfg.act_dim,
+                           (double)h->cfg.init_std, (double*)mean, (double*)std, (const double*)low, (const double*)high);
+    else
+        hipLaunchKernelGGL((reset_kernel<float>), dim3(grid), dim3(WG), 0, st, h->cfg.horizon, h->cfg.act_dim,
+                           (float)h->cfg.init_std, (float*)mean, (float*)std, (const float*)low, (const float*)high);
+    ICEM_HIP_TRY(hipGetLastError());
+    return ICEM_OK;
+}
+
+size_t icem_record_bytes(const icem_handle* h) { return h ? (size_t)(h->hd + 2) * h->tsize : 0; }
+
+size_t icem_plan_buffer_bytes(const icem_handle* h, int32_t which) {
+    if (!h) return 0;
+    const size_t ts = h->tsize, hd = (size_t)h->hd, K = (size_t)h->cfg.num_elites;
+    const size_t rows = (size_t)h->n_local_max + (size_t)h->n_reuse;
+    switch (which) {
+        case ICEM_BUF_MEAN:
+        case ICEM_BUF_STD:
+            return hd * ts;
+        case ICEM_BUF_LOW:
+        case ICEM_BUF_HIGH:
+        case ICEM_BUF_EXECUTED:
+            return (size_t)h->cfg.act_dim * ts;
+        case ICEM_BUF_OBS0:
+            return (size_t)std::max(1, h->obs_dim) * ts;
+        case ICEM_BUF_ACTIONS:
+            return rows * hd * ts;
+        case ICEM_BUF_COSTS:
+            return rows * ts;
+        case ICEM_BUF_ELITES:
+            return 2 * K * hd * ts + 2 * K * ts;
+        case ICEM_BUF_RECORDS:
+            return (size_t)h->cfg.world * K * (hd + 2) * ts;
+        case ICEM_BUF_WORKSPACE:
+            return (size_t)topk_blocks((int)rows) * K * (ts + sizeof(int));
+        case ICEM_BUF_BEST_COST:
+            return ts;
+        default:
+            return 0;
+    }
+}
+
+static int check_plan(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, int32_t it) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (!b) return fail(ICEM_E_INVALID, "null buffers");
+    if (!h->has_model || !h->has_cost) return fail(ICEM_E_STATE, "icem_set_model / icem_set_cost must be called first");
+    if (mpc_step < 0 || it < 0 || it >= h->cfg.opt_iters) return fail(ICEM_E_INVALID, "mpc_step / iteration out of range");
+    if (!b->mean || !b->std || !b->low || !b->high || !b->obs0 || !b->actions || !b->costs || !b->elites || !b->records ||
+        !b->workspace || !b->executed || !b->best_cost)
+        return fail(ICEM_E_INVALID, "null plan buffer");
+    if ((b->z_r == nullptr) != (b->z_i == nullptr) || (b->z_r_shift == nullptr) != (b->z_i_shift == nullptr))
+        return fail(ICEM_E_INVALID, "z_r/z_i must be given in pairs");
+    return ICEM_OK;
+}
+
+int icem_plan_iter_local(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, int32_t it, void* stream) {
+    int rc = check_plan(h, b, mpc_step, it);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    return ICEM_DISPATCH(h, plan_iter_local_t<float>(h, b, mpc_step, it, st), plan_iter_local_t<double>(h, b, mpc_step, it, st));
+}
+
+int icem_plan_iter_merge(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, int32_t it, void* stream) {
+    int rc = check_plan(h, b, mpc_step, it);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    return ICEM_DISPATCH(h, plan_iter_merge_t<float>(h, b, mpc_step, it, st), plan_iter_merge_t<double>(h, b, mpc_step, it, st));
+}
+
+int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (h->cfg.world != 1) return fail(ICEM_E_INVALID, "icem_plan_step is the world == 1 path; use iter_local/iter_merge");
+    for (int it = 0; it < h->cfg.opt_iters; ++it) {
+        int rc = icem_plan_iter_local(h, b, mpc_step, it, stream);
+        if (rc) return rc;
+        rc = icem_plan_iter_merge(h, b, mpc_step, it, stream);
+        if (rc) return rc;
+    }
+    return ICEM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,135 @@
+"""Forward-model side of the boundary.
+
+``ForwardModel`` mirrors the reference's batched model contract
+(icem/misc/base_types.py:62-118, icem/models/abstract_models.py:8-53): ``predict`` maps
+``([N,o], states, [N,d]) -> ([N,o], states, [N,1])`` and ``predict_n_steps`` rolls a policy out
+for ``horizon`` steps.  ``DeviceSyntheticModel`` is the built-in analytic model the HIP rollout
+kernel evaluates on the GPU; its NumPy ``predict`` exists so the same object can be driven
+through the reference-style interface (used by the host-model path and by tests).
+"""
+from __future__ import annotations
+
+import math
+from abc import ABC, abstractmethod
+
+import numpy as np
+
+MODEL_LINEAR, MODEL_TANH = 0, 1
+
+
+class TrajectoryBatch:
+    """What ``predict_n_steps`` returns here instead of N ``Rollout`` objects (the reference
+    spends ~90 % of a step building those -- icem/misc/rolloutbuffer.py:16-39,155-172): flat
+    arrays ``[N,h,.]``.  Indexing yields per-trajectory dict views so reference-style consumers
+    (``r["observations"]``, ``buffer.as_array("actions")``) keep working."""
+
+    fields = ("observations", "next_observations", "actions", "rewards")
+
+    def __init__(self, **arrays):
+        self._a = {k: np.asarray(v) for k, v in arrays.items()}
+        n = {len(v) for v in self._a.values()}
+        if len(n) > 1:
+            raise TypeError("Turning rollout structure into numpy array failed. Rollouts of unequal length?")
+
+    def __len__(self):
+        return len(next(iter(self._a.values()))) if self._a else 0
+
+    def __bool__(self):
+        return len(self) > 0
+
+    def as_array(self, key):
+        return self._a[key]
+
+    def __getitem__(self, item):
+        if isinstance(item, str):
+            return self._a[item].reshape((-1,) + self._a[item].shape[2:])
+        if isinstance(item, (int, np.integer)):
+            return {k: v[item] for k, v in self._a.items()}
+        return TrajectoryBatch(**{k: v[item] for k, v in self._a.items()})
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+
+class ForwardModel(ABC):
+    supports_stochastic = False
+
+    def __init__(self, *, env=None):
+        self.env = env
+
+    def reset(self, observation):
+        return None
+
+    def got_actual_observation_and_env_state(self, *, observation, env_state=None, model_state=None):
+        return None
+
+    @abstractmethod
+    def predict(self, *, observations, states, actions):
+        """-> (next_observations [N,o], next_states, rewards [N,1])"""
+
+    def rollout_generator(self, start_states, start_observations, horizon, policy, mode=None):
+        states, obs = start_states, start_observations
+        for _ in range(horizon):
+            actions = policy.get_action(obs, state=states, mode=mode)
+            next_obs, next_states, r = self.predict(observations=obs, states=states, actions=actions)
+            yield obs, next_obs, actions, states, r
+            states, obs = next_states, next_obs
+
+    def rollout_field_names(self):
+        return TrajectoryBatch.fields
+
+    def predict_n_steps(self, *, start_observations, start_states, policy, horizon):
+        if start_observations.ndim != 2:
+            raise AttributeError("call predict_n_steps with a batch of states")
+        if len(start_observations) != len(start_states):
+            raise AttributeError("number of observations and states have to be the same")
+        obs, nxt, act, states, rew = zip(*self.rollout_generator(start_states, start_observations, horizon, policy))
+        tr = lambda x: np.asarray(x).transpose((1, 0, 2))
+        return TrajectoryBatch(observations=tr(obs), next_observations=tr(nxt), actions=tr(act),
+                               rewards=tr(rew)), states[-1]
+
+    def train(self, buffer):
+        pass
+
+    def save(self, path):
+        pass
+
+    def load(self, path):
+        pass
+
+
+class DeviceSyntheticModel(ForwardModel):
+    """``o' = act(o @ A + a @ B)``, ``A [o,o]``, ``B [d,o]``; ``kind`` linear or tanh; ``band >= 0``
+    zeroes ``A`` outside ``|row-col| <= band``."""
+
+    def __init__(self, A, B, kind: int = MODEL_LINEAR, band: int = -1, env=None):
+        super().__init__(env=env)
+        A = np.array(A, dtype=np.float64)
+        B = np.array(B, dtype=np.float64)
+        if band >= 0:
+            r = np.arange(A.shape[0])
+            A = np.where(np.abs(r[:, None] - r[None, :]) <= band, A, 0.0)
+        self.A, self.B, self.kind, self.band = A, B, kind, band
+        self.obs_dim, self.act_dim = A.shape[0], B.shape[0]
+
+    @staticmethod
+    def make(obs_dim: int, act_dim: int, kind: int = MODEL_LINEAR, band: int = -1, seed_a: int = 0,
+             seed_b: int = 1, env=None) -> "DeviceSyntheticModel":
+        """The synthetic dynamics of the benchmark configs: ``A = 0.95 I + 0.05 N(0,1)/sqrt(o)``
+        (RandomState(seed_a)), ``B = 0.1 N(0,1)`` (RandomState(seed_b))."""
+        A = 0.95 * np.eye(obs_dim) + 0.05 * np.random.RandomState(seed_a).randn(obs_dim, obs_dim) / math.sqrt(obs_dim)
+        B = 0.1 * np.random.RandomState(seed_b).randn(act_dim, obs_dim)
+        return DeviceSyntheticModel(A, B, kind, band, env)
+
+    def predict(self, *, observations, states, actions):
+        observations = np.asarray(observations, dtype=np.float64)
+        actions = np.asarray(actions, dtype=np.float64)
+        nxt = np.zeros_like(observations)
+        for k in range(self.obs_dim):
+            nxt = nxt + observations[..., k:k + 1] * self.A[k]
+        for j in range(self.act_dim):
+            nxt = nxt + actions[..., j:j + 1] * self.B[j]
+        if self.kind == MODEL_TANH:
+            nxt = np.tanh(nxt)
+        return nxt, None, np.zeros(observations.shape[:-1] + (1,))

@@ -1,0 +1,313 @@
+"""Torch-tensor level wrapper of the C ABI: one :class:`IcemPlanner` per controller.
+
+PyTorch is plumbing here (device memory, streams, ``torch.distributed``); all
+arithmetic happens in ``libicem_hip.so``.  Each method names the reference
+call site it replaces (paths relative to ``/root/reference``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Callable, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .distributed import exchange_records, shard_range
+
+
+@dataclass
+class IcemConfig:
+    """Constructor kwargs of the reference's ``MpcICem`` (icem/controllers/icem.py:213-233,
+    icem/controllers/mpc.py:22) plus the device-side knobs."""
+    horizon: int
+    act_dim: int
+    num_traj: int
+    elites_size: int = 10
+    opt_iters: int = 3
+    cost_mode: str = "sum"
+    use_mean_actions: bool = True
+    keep_previous_elites: bool = True
+    shift_elites: bool = True
+    factor_decrease: float = 1.25
+    alpha: float = 0.1
+    init_std: float = 0.5
+    fraction_reused: float = 0.3
+    noise_beta: float = 0.25
+    dtype: str = "f32"
+    rng_rounds: int = 10
+    seed: int = 0
+    rank: int = 0
+    world: int = 1
+
+    @property
+    def num_elites(self) -> int:
+        # icem/controllers/icem.py:235-240
+        return max(2, min(self.elites_size, self.num_traj // 2))
+
+    @property
+    def torch_dtype(self):
+        return torch.float64 if self.dtype == "f64" else torch.float32
+
+    def to_c(self) -> L.IcemConfigC:
+        if self.cost_mode not in L.COST_MODES:
+            raise NotImplementedError(
+                "Implement method {} to compute cost along trajectory".format(self.cost_mode))
+        return L.IcemConfigC(
+            horizon=self.horizon, act_dim=self.act_dim, num_traj=self.num_traj, num_elites=self.num_elites,
+            elites_size=self.elites_size, opt_iters=self.opt_iters, cost_mode=L.COST_MODES[self.cost_mode],
+            use_mean_actions=int(self.use_mean_actions), keep_previous_elites=int(self.keep_previous_elites),
+            shift_elites=int(self.shift_elites), dtype=L.ICEM_F64 if self.dtype == "f64" else L.ICEM_F32,
+            rng_rounds=self.rng_rounds, rank=self.rank, world=self.world, factor_decrease=self.factor_decrease,
+            alpha=self.alpha, init_std=self.init_std, fraction_reused=self.fraction_reused,
+            noise_beta=self.noise_beta, seed=self.seed & 0xFFFFFFFFFFFFFFFF)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+# noise callback of the parity mode: noise(num_traj) -> (z_r, z_i) float64 arrays [num, d, F]
+NoiseFn = Callable[[int], Tuple[np.ndarray, np.ndarray]]
+
+
+class IcemPlanner:
+    """Owns one ``icem_handle`` and the device buffers of one controller."""
+
+    def __init__(self, cfg: IcemConfig, low, high, device="cuda:0", process_group=None):
+        self.lib = L.load_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError("icem_amd needs a HIP device (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.dt = cfg.torch_dtype
+        self.group = process_group
+        torch.cuda.set_device(self.device)
+        self._h = C.c_void_p()
+        ccfg = cfg.to_c()
+        L.check(self.lib.icem_create(C.byref(ccfg), C.byref(self._h)))
+        self.h, self.d, self.K = cfg.horizon, cfg.act_dim, cfg.num_elites
+        self.F = self.h // 2 + 1
+        self.low = torch.as_tensor(np.asarray(low, dtype=np.float64), dtype=self.dt, device=self.device).contiguous()
+        self.high = torch.as_tensor(np.asarray(high, dtype=np.float64), dtype=self.dt, device=self.device).contiguous()
+        if self.low.shape != (self.d,) or self.high.shape != (self.d,):
+            raise ValueError("low/high must have shape [act_dim]")
+        pops = (C.c_int32 * cfg.opt_iters)()
+        L.check(self.lib.icem_population_sizes(self._h, pops))
+        self.population_sizes = list(pops)
+        self.n_reuse = int(self.K * cfg.fraction_reused)
+        self.obs_dim = 0
+        self._bufs = None
+        self.mpc_step = 0
+        self._topk_ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self.lib.icem_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ model / cost
+    def set_model(self, kind: int, A: np.ndarray, B: np.ndarray):
+        """Built-in batched model ``o' = act(o@A + a@B)`` (predict contract of
+        icem/models/abstract_models.py:17-26)."""
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        B = np.ascontiguousarray(B, dtype=np.float64)
+        o = A.shape[0]
+        if A.shape != (o, o) or B.shape != (self.d, o):
+            raise ValueError("A must be [o,o] and B [act_dim,o]")
+        L.check(self.lib.icem_set_model(self._h, kind, o, A.ctypes.data_as(C.POINTER(C.c_double)),
+                                        B.ctypes.data_as(C.POINTER(C.c_double))))
+        self.obs_dim = o
+        self._bufs = None
+
+    def set_cost(self, ctrl_weight=0.1, lin_idx=8, lin_weight=-1.0, flip_idx=1, flip_penalty=10.0,
+                 flip_thresh=float(np.pi / 2)):
+        """Parametric HalfCheetah / HumanoidStandup cost (icem/environments/mujoco.py:67-99, 259-277)."""
+        spec = L.IcemCostSpecC(ctrl_weight, lin_weight, flip_penalty, flip_thresh, lin_idx, flip_idx)
+        L.check(self.lib.icem_set_cost(self._h, C.byref(spec)))
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _t(self, x, shape=None) -> torch.Tensor:
+        t = torch.as_tensor(x, dtype=self.dt, device=self.device).contiguous()
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        return t
+
+    def noise_tables(self) -> Tuple[np.ndarray, np.ndarray]:
+        cr = np.zeros((self.F, self.h))
+        ci = np.zeros((self.F, self.h))
+        L.check(self.lib.icem_noise_tables_host(self.h, self.cfg.noise_beta, cr.ctypes.data_as(C.POINTER(C.c_double)),
+                                                ci.ctypes.data_as(C.POINTER(C.c_double))))
+        return cr, ci
+
+    # ------------------------------------------------------------------ stateless operators
+    def sample_clip(self, n: int, mean, std, z_r=None, z_i=None, offset: int = 0, first_index: int = 0,
+                    t_begin: int = 0, row0_mean: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """K1: ``MpcICem.sample_action_sequences`` (icem/controllers/icem.py:61-82)."""
+        mean = self._t(mean, (self.h, self.d))
+        std = self._t(std, (self.h, self.d))
+        if z_r is not None:
+            z_r = self._t(z_r, (n, self.d, self.F))
+            z_i = self._t(z_i, (n, self.d, self.F))
+        if out is None:
+            out = torch.empty((n, self.h, self.d), dtype=self.dt, device=self.device)
+        L.check(self.lib.icem_sample_clip(self._h, n, first_index, _ptr(mean), _ptr(std), _ptr(self.low),
+                                          _ptr(self.high), _ptr(z_r), _ptr(z_i), offset, t_begin, int(row0_mean),
+                                          _ptr(out), self._stream()))
+        return out
+
+    def philox_normals(self, n: int, offset: int = 0, first_index: int = 0):
+        z_r = torch.empty((n, self.d, self.F), dtype=self.dt, device=self.device)
+        z_i = torch.empty_like(z_r)
+        L.check(self.lib.icem_philox_normals(self._h, n, first_index, offset, _ptr(z_r), _ptr(z_i), self._stream()))
+        return z_r, z_i
+
+    def rollout_cost(self, obs0, actions: torch.Tensor, return_observations: bool = False):
+        """K2: ``simulate_trajectories`` + ``trajectory_cost_fn`` (icem/controllers/mpc.py:56-67,
+        icem/controllers/abstract_controller.py:74-91) with the built-in model."""
+        obs0 = self._t(obs0, (self.obs_dim,))
+        actions = self._t(actions)
+        n = actions.shape[0]
+        if tuple(actions.shape[1:]) != (self.h, self.d):
+            raise ValueError("actions must be [n, h, d]")
+        costs = torch.empty((n,), dtype=self.dt, device=self.device)
+        obs = torch.empty((n, self.h, self.obs_dim), dtype=self.dt, device=self.device) if return_observations else None
+        L.check(self.lib.icem_rollout_cost(self._h, n, _ptr(obs0), _ptr(actions), _ptr(costs), _ptr(obs), self._stream()))
+        return (costs, obs) if return_observations else costs
+
+    def cost_reduce(self, step_costs) -> torch.Tensor:
+        step_costs = self._t(step_costs)
+        n = step_costs.shape[0]
+        if step_costs.shape[1] != self.h:
+            raise ValueError("step_costs must be [n, h]")
+        costs = torch.empty((n,), dtype=self.dt, device=self.device)
+        L.check(self.lib.icem_cost_reduce(self._h, n, _ptr(step_costs), _ptr(costs), self._stream()))
+        return costs
+
+    def topk_sorted(self, costs, k: Optional[int] = None):
+        """K3: ``np.array(costs).argsort()[:K]`` (icem/controllers/icem.py:199)."""
+        costs = self._t(costs)
+        n = costs.shape[0]
+        k = self.K if k is None else k
+        nbytes = self.lib.icem_topk_workspace_bytes(self._h, n, k)
+        if self._topk_ws is None or self._topk_ws.numel() < nbytes:
+            self._topk_ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=self.device)
+        out_c = torch.empty((k,), dtype=self.dt, device=self.device)
+        out_i = torch.empty((k,), dtype=torch.int32, device=self.device)
+        L.check(self.lib.icem_topk_sorted(self._h, n, _ptr(costs), k, _ptr(out_c), _ptr(out_i), _ptr(self._topk_ws),
+                                          self._stream()))
+        return out_c, out_i
+
+    def gather_refit(self, actions: torch.Tensor, idx: torch.Tensor, mean: torch.Tensor, std: torch.Tensor):
+        """K4: ``update_distributions`` (icem/controllers/icem.py:201-211); mean/std updated in place."""
+        assert mean.dtype == self.dt and std.dtype == self.dt and mean.is_contiguous() and std.is_contiguous()
+        actions = self._t(actions)
+        idx = idx.to(device=self.device, dtype=torch.int32).contiguous()
+        k = idx.shape[0]
+        elites = torch.empty((k, self.h, self.d), dtype=self.dt, device=self.device)
+        L.check(self.lib.icem_gather_refit(self._h, _ptr(actions), _ptr(idx), k, _ptr(mean), _ptr(std), _ptr(elites),
+                                           self._stream()))
+        return elites
+
+    def shift(self, mean: torch.Tensor, std: torch.Tensor):
+        """Epilogue of get_action (icem/controllers/icem.py:167-175), in place."""
+        L.check(self.lib.icem_shift(self._h, _ptr(mean), _ptr(std), _ptr(self.low), _ptr(self.high), self._stream()))
+
+    def reset_distribution(self, mean: torch.Tensor, std: torch.Tensor):
+        """beginning_of_rollout (icem/controllers/icem.py:31-59), in place."""
+        L.check(self.lib.icem_reset_distribution(self._h, _ptr(mean), _ptr(std), _ptr(self.low), _ptr(self.high),
+                                                 self._stream()))
+
+    # ------------------------------------------------------------------ fused MPC step
+    def _ensure_buffers(self):
+        if self._bufs is not None:
+            return
+        if self.obs_dim == 0:
+            raise RuntimeError("set_model()/set_cost() must be called before planning")
+        names = ["mean", "std", "low", "high", "obs0", "actions", "costs", "elites", "records", "workspace",
+                 "executed", "best_cost"]
+        t = {}
+        for which, name in enumerate(names):
+            nbytes = self.lib.icem_plan_buffer_bytes(self._h, which)
+            if name in ("low", "high"):
+                t[name] = self.low if name == "low" else self.high
+                continue
+            t[name] = torch.zeros((max(1, nbytes),), dtype=torch.uint8, device=self.device)
+        self._bufs = t
+        self.mean = t["mean"].view(self.dt).view(self.h, self.d)
+        self.std = t["std"].view(self.dt).view(self.h, self.d)
+        self.obs0 = t["obs0"].view(self.dt)
+        self.executed = t["executed"].view(self.dt)
+        self.best_cost = t["best_cost"].view(self.dt)
+        self.actions = t["actions"].view(self.dt).view(-1, self.h, self.d)
+        self.costs = t["costs"].view(self.dt)
+        rs = self.h * self.d + 2
+        self.records = t["records"].view(self.dt).view(self.cfg.world * self.K, rs)
+        el = t["elites"].view(self.dt)
+        khd = self.K * self.h * self.d
+        self.elites_actions = el[:2 * khd].view(2, self.K, self.h, self.d)
+        self.elites_costs = el[2 * khd:].view(2, self.K)
+        self._cb = L.IcemPlanBuffersC(**{n: t[n].data_ptr() for n in names})
+        self._cb.z_r = self._cb.z_i = self._cb.z_r_shift = self._cb.z_i_shift = None
+
+    def reset(self):
+        """``MpcICem.beginning_of_rollout`` (icem/controllers/icem.py:31-43)."""
+        self._ensure_buffers()
+        self.reset_distribution(self.mean, self.std)
+        self.mpc_step = 0
+
+    def current_elites(self):
+        """Elite actions [K,h,d] and costs [K] of the latest iteration (best first)."""
+        g = (self.mpc_step * self.cfg.opt_iters) & 1
+        return self.elites_actions[g], self.elites_costs[g]
+
+    def local_count(self, it: int) -> int:
+        lo, hi = shard_range(self.population_sizes[it], self.cfg.rank, self.cfg.world)
+        return hi - lo
+
+    def plan_step(self, obs, noise: Optional[NoiseFn] = None, on_iteration=None) -> torch.Tensor:
+        """One MPC step = the loop of ``MpcICem.get_action`` (icem/controllers/icem.py:123-175).
+        Returns the executed action as a device tensor ``[d]`` (no host sync).  ``noise`` switches to
+        the parity mode: the white draws come from the callback (in the reference's call order)."""
+        self._ensure_buffers()
+        self.obs0.copy_(torch.as_tensor(np.asarray(obs, dtype=np.float64), dtype=self.dt), non_blocking=False)
+        cfg = self.cfg
+        st = self._stream()
+        if noise is None and cfg.world == 1 and on_iteration is None:
+            self._cb.z_r = self._cb.z_i = self._cb.z_r_shift = self._cb.z_i_shift = None
+            L.check(self.lib.icem_plan_step(self._h, C.byref(self._cb), self.mpc_step, st))
+        else:
+            keep = []
+            for it in range(cfg.opt_iters):
+                self._cb.z_r = self._cb.z_i = self._cb.z_r_shift = self._cb.z_i_shift = None
+                if noise is not None:
+                    n_it = self.population_sizes[it]
+                    lo, hi = shard_range(n_it, cfg.rank, cfg.world)
+                    z_r, z_i = noise(n_it)  # the reference draws the whole batch (icem.py:73)
+                    zr = self._t(z_r[lo:hi])
+                    zi = self._t(z_i[lo:hi])
+                    keep += [zr, zi]
+                    self._cb.z_r, self._cb.z_i = zr.data_ptr(), zi.data_ptr()
+                    if it == 0 and cfg.shift_elites and self.mpc_step > 0 and self.n_reuse > 0:
+                        s_r, s_i = noise(self.n_reuse)  # icem.py:102
+                        sr, si = self._t(s_r), self._t(s_i)
+                        keep += [sr, si]
+                        self._cb.z_r_shift, self._cb.z_i_shift = sr.data_ptr(), si.data_ptr()
+                L.check(self.lib.icem_plan_iter_local(self._h, C.byref(self._cb), self.mpc_step, it, st))
+                if cfg.world > 1:
+                    exchange_records(self.records, self.K, cfg.rank, cfg.world, self.group)
+                L.check(self.lib.icem_plan_iter_merge(self._h, C.byref(self._cb), self.mpc_step, it, st))
+                if on_iteration is not None:
+                    on_iteration(it)
+            if keep:
+                torch.cuda.current_stream(self.device).synchronize()  # z tensors must outlive the kernels
+        self.mpc_step += 1
+        return self.executed

@@ -1,0 +1,225 @@
+/*
+ * icem_hip.h -- C ABI of libicem_hip.so: the MI355X-native iCEM inner planning loop.
+ *
+ * This is the drop-in boundary for ONE hot path of martius-lab/iCEM: everything inside the
+ * `for i in range(opt_iter)` loop of MpcICem.get_action (reference icem/controllers/icem.py:106-189).
+ * The reference is pure Python/NumPy and has no FFI; each entry point below names the reference
+ * call site (file:line, relative to /root/reference) whose arithmetic it replaces.  The binding a
+ * reference maintainer would add is a ctypes stub -- see INTEGRATION.md.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - Every pointer is a DEVICE pointer owned by the caller (e.g. torch tensor.data_ptr())
+ *     unless its name ends in `_host`.  `stream` is a hipStream_t passed as void*
+ *     (torch.cuda.current_stream().cuda_stream); all work is enqueued on it and nothing
+ *     synchronises unless stated.
+ *   - `dtype` selects the arithmetic/storage type of every floating tensor of a call:
+ *     ICEM_F32 (throughput) or ICEM_F64 (the reference's type; strict-parity mode).
+ *   - Return value: 0 on success, <0 on error (ICEM_E_*); icem_last_error() returns a
+ *     thread-local message.  No exceptions cross the boundary.
+ *   - Tensor layouts are C-contiguous: actions [n, h, d]; mean/std [h, d]; low/high [d];
+ *     white noise z_r/z_i [n, d, F] with F = h/2+1 (the layout of the reference's draws).
+ *   - A handle is not thread-safe; different handles may be used concurrently.
+ */
+#ifndef ICEM_HIP_H
+#define ICEM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICEM_ABI_VERSION 1
+
+enum { ICEM_F32 = 0, ICEM_F64 = 1 };
+enum { ICEM_COST_SUM = 0, ICEM_COST_BEST = 1, ICEM_COST_FINAL = 2 }; /* abstract_controller.py:82-87 */
+enum { ICEM_MODEL_LINEAR = 0, ICEM_MODEL_TANH = 1 };
+
+enum {
+    ICEM_OK = 0,
+    ICEM_E_INVALID = -1,      /* bad argument (the reference raises ValueError/AttributeError)   */
+    ICEM_E_UNSUPPORTED = -2,  /* shape outside the compiled kernels (NotImplementedError)          */
+    ICEM_E_HIP = -3,          /* a HIP runtime call failed                                         */
+    ICEM_E_NO_DEVICE = -4,    /* no gfx950 device visible                                          */
+    ICEM_E_STATE = -5         /* call order violated (e.g. rollout before icem_set_model)          */
+};
+
+#define ICEM_MAX_HORIZON 64
+#define ICEM_MAX_ACT_DIM 64
+#define ICEM_MAX_OBS_DIM 64
+#define ICEM_MAX_ELITES 64
+
+/* Constructor kwargs of MpcICem (icem.py:213-233, mpc.py:22, abstract_controller.py:64-65). */
+typedef struct icem_config {
+    int32_t horizon;              /* h                                                   */
+    int32_t act_dim;              /* d  = env.action_space.shape[0] (icem.py:245)        */
+    int32_t num_traj;             /* N  = num_simulated_trajectories (GLOBAL, all ranks) */
+    int32_t num_elites;           /* K  = min(elites_size, N/2), >= 2 (icem.py:235-240)  */
+    int32_t elites_size;          /* raw elites_size (the N-decay floor is 2*elites_size, icem.py:127) */
+    int32_t opt_iters;            /* opt_iterations                                      */
+    int32_t cost_mode;            /* ICEM_COST_*  (cost_along_trajectory)                */
+    int32_t use_mean_actions;     /* icem.py:87-88                                       */
+    int32_t keep_previous_elites; /* icem.py:143-145                                     */
+    int32_t shift_elites;         /* icem.py:131-137                                     */
+    int32_t dtype;                /* ICEM_F32 / ICEM_F64                                 */
+    int32_t rng_rounds;           /* Philox4x32 rounds: 10 (default) or 7                */
+    int32_t rank;                 /* this process' shard of the N dimension              */
+    int32_t world;                /* number of shards (GPUs)                             */
+    double factor_decrease;       /* gamma = factor_decrease_num                         */
+    double alpha;                 /* momentum                                            */
+    double init_std;              /* relative to (high-low)/2 (icem.py:55-59)            */
+    double fraction_reused;       /* xi = fraction_elites_reused                         */
+    double noise_beta;            /* colored-noise exponent (>0)                         */
+    uint64_t seed;                /* Philox key                                          */
+} icem_config;
+
+/* Parametric form of the shipped cost functions (environments/mujoco.py:67-99 HalfCheetah,
+ * :259-277 HumanoidStandup):
+ *   cost_t = ctrl_weight*sum_j a_j^2 + lin_weight*obs[lin_idx]
+ *            + flip_penalty*([obs[flip_idx] > flip_thresh] + [obs[flip_idx] < -flip_thresh])
+ * with the flip term dropped when flip_idx < 0.  `obs` is the PRE-action observation. */
+typedef struct icem_cost_spec {
+    double ctrl_weight;
+    double lin_weight;
+    double flip_penalty;
+    double flip_thresh;
+    int32_t lin_idx;
+    int32_t flip_idx;
+} icem_cost_spec;
+
+typedef struct icem_handle icem_handle;
+
+/* ---- library / handle ------------------------------------------------------------------ */
+
+int icem_abi_version(void);
+const char* icem_last_error(void);
+
+/* Number of visible HIP devices (0 on a CPU-only host); never fails. */
+int icem_device_count(void);
+
+/* Creates a planner for one controller instance (replaces MpcICem.__init__ state, icem.py:22-29).
+ * Builds the colored-noise synthesis table on the current device. */
+int icem_create(const icem_config* cfg, icem_handle** out);
+int icem_destroy(icem_handle* h);
+
+/* Sequence of population sizes N_i the loop will use (icem.py:123-127); out_host[opt_iters]. */
+int icem_population_sizes(const icem_handle* h, int32_t* out_host);
+
+/* Colored-noise synthesis matrices (float64, host): y[t] = sum_k z_r[k]*cr[k*h+t] + z_i[k]*ci[k*h+t]
+ * restating colorednoise.powerlaw_psd_gaussian (third-party; call site icem.py:73-75). */
+int icem_noise_tables_host(int32_t horizon, double beta, double* cr_host, double* ci_host);
+
+/* Built-in batched forward model o' = act(o.A + a.B) (the `predict` contract of
+ * models/abstract_models.py:17-26).  A [obs_dim, obs_dim], B [act_dim, obs_dim] are HOST float64
+ * arrays; they are converted to the handle dtype and copied to the device.  `kind` = ICEM_MODEL_*. */
+int icem_set_model(icem_handle* h, int32_t kind, int32_t obs_dim, const double* A_host, const double* B_host);
+int icem_set_cost(icem_handle* h, const icem_cost_spec* spec);
+
+/* ---- stateless operators (each replaces one NumPy call site) ------------------------------ */
+
+/* K1  MpcICem.sample_action_sequences (icem.py:61-82) + colorednoise.powerlaw_psd_gaussian:
+ *   actions[i, t, j] = clip(colored(i, j)[t] * std[t, j] + mean[t, j], low[j], high[j]),  i < n.
+ * White noise: if z_r/z_i are non-NULL they are the [n, d, F] standard-normal draws (parity mode:
+ * the same draws the reference takes from np.random); otherwise Philox4x32 keyed by
+ * (cfg.seed, offset, first_index + i, j).  Only time steps t >= t_begin are written
+ * (t_begin = h-1 restates the time_slice=slice(-1, None) call of icem.py:102).
+ * If row0_mean != 0 and first_index == 0, row 0 is overwritten with `mean` (icem.py:87-88). */
+int icem_sample_clip(icem_handle* h, int32_t n, int64_t first_index, const void* mean, const void* std,
+                     const void* low, const void* high, const void* z_r, const void* z_i,
+                     uint64_t offset, int32_t t_begin, int32_t row0_mean, void* actions, void* stream);
+
+/* Raw white noise of the Philox path (for RNG known-answer tests): z_r, z_i [n, d, F]. */
+int icem_philox_normals(icem_handle* h, int32_t n, int64_t first_index, uint64_t offset,
+                        void* z_r, void* z_i, void* stream);
+
+/* K2  MpcController.simulate_trajectories (mpc.py:56-67) through the batched model loop
+ * (abstract_models.py:17-53) + trajectory_cost_fn (abstract_controller.py:74-91) with the built-in
+ * model/cost:  costs[i] = reduce_t cost(o_t, a_t),  o_{t+1} = model(o_t, a_t),  o_0 = obs0[obs_dim].
+ * If observations != NULL the pre-action observations [n, h, obs_dim] are also stored. */
+int icem_rollout_cost(icem_handle* h, int32_t n, const void* obs0, const void* actions, void* costs,
+                      void* observations, void* stream);
+
+/* trajectory_cost_fn's reduction alone (abstract_controller.py:82-87) for step costs [n, h]
+ * produced by an external (e.g. torch) model. */
+int icem_cost_reduce(icem_handle* h, int32_t n, const void* step_costs, void* costs, void* stream);
+
+/* K3  costs.argsort()[:k] (icem.py:199) and argmin (icem.py:149): the k smallest (cost, index)
+ * pairs in ascending order, ties broken by index, NaN treated as +inf.
+ * out_cost [k] (handle dtype), out_idx [k] int32.  workspace: icem_topk_workspace_bytes(n, k). */
+size_t icem_topk_workspace_bytes(const icem_handle* h, int32_t n, int32_t k);
+int icem_topk_sorted(icem_handle* h, int32_t n, const void* costs, int32_t k, void* out_cost,
+                     int32_t* out_idx, void* workspace, void* stream);
+
+/* K4  update_distributions (icem.py:201-211): gather the k elite rows of `actions` [*, h, d] in
+ * `idx` order into elites_out [k, h, d]; mean <- (1-alpha)*mean_k + alpha*mean,
+ * std <- (1-alpha)*std_k(ddof=0) + alpha*std (in place). */
+int icem_gather_refit(icem_handle* h, const void* actions, const int32_t* idx, int32_t k, void* mean,
+                      void* std, void* elites_out, void* stream);
+
+/* Epilogue of get_action (icem.py:167-175): mean[:-1] = mean[1:] (last row kept);
+ * std = (high-low)/2*init_std. */
+int icem_shift(icem_handle* h, void* mean, void* std, const void* low, const void* high, void* stream);
+
+/* beginning_of_rollout (icem.py:31-59): mean = (high+low)/2, std = (high-low)/2*init_std. */
+int icem_reset_distribution(icem_handle* h, void* mean, void* std, const void* low, const void* high,
+                            void* stream);
+
+/* ---- fused MPC step ------------------------------------------------------------------------ */
+
+/* Device buffers of one planner; all owned by the caller, sized by icem_plan_buffer_bytes(). */
+typedef struct icem_plan_buffers {
+    void* mean;        /* [h, d]              in/out: persistent across MPC steps               */
+    void* std;         /* [h, d]              in/out                                            */
+    void* low;         /* [d]                                                                   */
+    void* high;        /* [d]                                                                   */
+    void* obs0;        /* [obs_dim]           current observation                               */
+    void* actions;     /* [n_local_max + r, h, d]  sampled pool of this rank (r = reused elites)*/
+    void* costs;       /* [n_local_max + r]                                                     */
+    void* elites;      /* 2 x [K, h, d] + 2 x [K] costs: persistent elite set (double buffered) */
+    void* records;     /* [world*K + r] candidate records {cost, gidx, actions[h*d]}            */
+    void* workspace;   /* scratch for the block-level top-k                                     */
+    void* executed;    /* [d]   out: first action of the best trajectory (icem.py:163)          */
+    void* best_cost;   /* [1]   out: min(costs) of the last iteration (icem.py:177)             */
+    /* Optional external white noise for the CURRENT iteration (parity mode, NULL = Philox):
+     * z_r/z_i [n_local, d, F] for the main batch; z_r_shift/z_i_shift [r, d, F] for the
+     * shifted elites' last action (iteration 0 only).                                          */
+    const void* z_r;
+    const void* z_i;
+    const void* z_r_shift;
+    const void* z_i_shift;
+} icem_plan_buffers;
+
+enum {
+    ICEM_BUF_MEAN = 0, ICEM_BUF_STD, ICEM_BUF_LOW, ICEM_BUF_HIGH, ICEM_BUF_OBS0, ICEM_BUF_ACTIONS,
+    ICEM_BUF_COSTS, ICEM_BUF_ELITES, ICEM_BUF_RECORDS, ICEM_BUF_WORKSPACE, ICEM_BUF_EXECUTED,
+    ICEM_BUF_BEST_COST, ICEM_BUF_COUNT
+};
+/* Bytes required for buffer `which` (ICEM_BUF_*) of icem_plan_buffers. */
+size_t icem_plan_buffer_bytes(const icem_handle* h, int32_t which);
+
+/* One CEM iteration `it` (0..opt_iters-1) of MPC step number `mpc_step` (0 = first after
+ * beginning_of_rollout), local part: sample this rank's shard of N_it (+ shifted / kept elites),
+ * roll out, cost, block-level top-k, and pack this rank's sorted local top-K candidate records
+ * into records[rank*K .. rank*K+K).  icem.py:124-147. */
+int icem_plan_iter_local(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, int32_t it,
+                         void* stream);
+/* After the ranks' records have been all-gathered in place (world > 1; nothing to do for world == 1):
+ * merge world*K candidates (+ kept elites), take the global sorted top-K, refit mean/std, store the
+ * new elite set; on the last iteration also write executed/best_cost and shift mean/std
+ * (icem.py:149-175, 194-211). */
+int icem_plan_iter_merge(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, int32_t it,
+                         void* stream);
+/* Whole MPC step for world == 1: opt_iters x (local + merge), no host synchronisation
+ * (the body of MpcICem.get_action, icem.py:123-175). */
+int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, void* stream);
+
+/* Byte size / layout of one candidate record: {cost (T), gidx (int32, padded to sizeof(T)),
+ * actions[h*d] (T)}; all-gather moves K records per rank. */
+size_t icem_record_bytes(const icem_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICEM_HIP_H */

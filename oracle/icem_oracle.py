@@ -203,6 +203,36 @@ def philox_white_noise(seed: int, offset: int, num: int, d: int, h: int,
     return z_r, z_i
 
 
+class PhiloxNoiseSchedule:
+    """Noise callback for :class:`IcemOracle` reproducing the device's Philox
+    offsets: per MPC step ``s`` the main batch of iteration ``i`` uses offset
+    ``s*(iters+1)+i`` and the shifted-elite batch uses ``s*(iters+1)+iters``.
+    The oracle asks for noise in the reference's order (main 0, [shift],
+    main 1, ...); the shift batch is recognised by its position."""
+
+    def __init__(self, seed: int, iters: int, d: int, h: int, shift: bool = True,
+                 rounds: int = 10, dtype=np.float64):
+        self.seed, self.iters, self.d, self.h = seed, iters, d, h
+        self.shift, self.rounds, self.dtype = shift, rounds, dtype
+        self.step = -1
+        self.begin_step()
+
+    def begin_step(self):
+        self.step += 1
+        self.it = 0
+        self.shift_done = False
+
+    def __call__(self, num: int):
+        base = self.step * (self.iters + 1)
+        if self.shift and self.step > 0 and self.it == 1 and not self.shift_done:
+            self.shift_done = True
+            off = base + self.iters
+        else:
+            off = base + self.it
+            self.it += 1
+        return philox_white_noise(self.seed, off, num, self.d, self.h, 0, self.rounds, self.dtype)
+
+
 # --------------------------------------------------------------------------
 # a-2  MpcICem.sample_action_sequences  (icem.py:61-82)
 # --------------------------------------------------------------------------

@@ -1,0 +1,91 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/icem_hip.h
+declares, and its host-only helpers agree with the oracle.  No device compute here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from icem_amd import _lib as L
+from oracle import icem_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(L.lib_path()):
+        import __graft_entry__ as g
+        g.build()
+    return L.load_library()
+
+
+def test_header_symbols_all_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "icem_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(icem_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    bound = {name for name, _, _ in L.SYMBOLS}
+    assert declared == bound, (declared ^ bound)
+    for name in declared:
+        assert hasattr(lib, name)
+
+
+def test_abi_version_and_error_string(lib):
+    assert lib.icem_abi_version() == 1
+    assert isinstance(lib.icem_last_error(), bytes)
+
+
+def test_struct_sizes_match_header():
+    # icem_config: 14 int32 + 5 double + uint64 = 56 + 48 = 104 bytes, no padding surprises
+    assert C.sizeof(L.IcemConfigC) == 104
+    assert C.sizeof(L.IcemCostSpecC) == 40
+    assert C.sizeof(L.IcemPlanBuffersC) == 16 * 8
+
+
+def test_create_rejects_bad_config_like_the_reference(lib):
+    from icem_amd.planner import IcemConfig
+    h = C.c_void_p()
+    cfg = IcemConfig(horizon=30, act_dim=6, num_traj=1).to_c()
+    rc = lib.icem_create(C.byref(cfg), C.byref(h))
+    assert rc == -1 and b"At least two trajectories needed!" in lib.icem_last_error()  # mpc.py:30-31
+    cfg = IcemConfig(horizon=30, act_dim=6, num_traj=64, noise_beta=0.0).to_c()
+    assert lib.icem_create(C.byref(cfg), C.byref(h)) == -2
+    with pytest.raises(NotImplementedError):
+        IcemConfig(horizon=30, act_dim=6, num_traj=64, cost_mode="median").to_c()
+
+
+@pytest.mark.parametrize("h,beta", [(30, 0.25), (12, 0.25), (13, 1.0), (30, 2.0), (10, 3.0), (64, 0.5), (2, 1.0), (3, 1.0)])
+def test_noise_tables_match_oracle(lib, h, beta):
+    F = h // 2 + 1
+    cr = np.zeros((F, h))
+    ci = np.zeros((F, h))
+    assert lib.icem_noise_tables_host(h, beta, cr.ctypes.data_as(C.POINTER(C.c_double)),
+                                      ci.ctypes.data_as(C.POINTER(C.c_double))) == 0
+    Cr, Ci = O.synthesis_matrices(h, beta)
+    np.testing.assert_allclose(cr, Cr, rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(ci, Ci, rtol=1e-13, atol=1e-15)
+    # and through them, the reference's irfft formulation
+    rs = np.random.RandomState(0)
+    zr, zi = rs.randn(5, 3, F), rs.randn(5, 3, F)
+    np.testing.assert_allclose(zr @ cr + zi @ ci, O.colored_from_white(beta, h, zr, zi), rtol=0, atol=1e-13)
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from icem_amd import IcemConfig, IcemPlanner
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        IcemPlanner(IcemConfig(horizon=30, act_dim=6, num_traj=64), -np.ones(6), np.ones(6))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "icem_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "icem_oracle" not in src, f

@@ -1,0 +1,447 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden
+fixtures captured from the reference.  Tolerances (from BASELINE.json north_star): elite index
+sets bit-exact; costs / mean / std within 1e-5 relative in f32; the f64 kernels (the reference's
+own type) are held to 1e-10."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import CASES, Golden
+from oracle import icem_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+F64_RTOL, F64_ATOL = 1e-10, 1e-12
+F32_RTOL, F32_ATOL = 1e-5, 2e-6
+
+
+def tol(dtype):
+    return (dict(rtol=F64_RTOL, atol=F64_ATOL) if dtype == "f64" else dict(rtol=F32_RTOL, atol=F32_ATOL))
+
+
+def make_planner(g: Golden, dtype, **over):
+    from icem_amd import IcemConfig, IcemPlanner
+    kw = dict(horizon=g.h, act_dim=g.d, num_traj=g.N, elites_size=g.K, opt_iters=g.iters, cost_mode=g.cost_mode,
+              use_mean_actions=g.use_mean, keep_previous_elites=g.keep, shift_elites=g.shift,
+              factor_decrease=g.gamma, alpha=g.alpha, init_std=g.init_std, fraction_reused=g.xi,
+              noise_beta=g.beta, dtype=dtype, seed=1234)
+    kw.update(over)
+    pl = IcemPlanner(IcemConfig(**kw), g.low, g.high)
+    pl.set_model(g.kind, g.A, g.B)
+    spec = O.CostSpec.halfcheetah(g.o) if g.env_kind == "halfcheetah" else O.CostSpec.humanoid_standup()
+    pl.set_cost(spec.ctrl_weight, spec.lin_idx, spec.lin_weight, spec.flip_idx, spec.flip_penalty, spec.flip_thresh)
+    return pl
+
+
+def np_(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+# ---------------------------------------------------------------------------------------------
+# K1 sampling
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("name", CASES)
+def test_sample_clip_external_noise_matches_reference(name, dtype):
+    """First sampling call of each golden run: same white draws in -> the reference's actions out."""
+    g = Golden(name)
+    pl = make_planner(g, dtype)
+    zr, zi = g.noise(0)
+    mean0 = np.zeros((g.h, g.d)) + (g.high + g.low) / 2
+    std0 = np.ones((g.h, g.d)) * (g.high - g.low) / 2 * g.init_std
+    got = np_(pl.sample_clip(g.N, mean0, std0, zr, zi))
+    ref = g.it(0)["simact"]
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, **tol(dtype))
+    np.testing.assert_allclose(got, O.sample_action_sequences(mean0, std0, g.low, g.high, g.beta, zr, zi), **tol(dtype))
+    assert got.min() >= g.low.min() - 1e-7 and got.max() <= g.high.max() + 1e-7
+    if g.beta >= 2:  # enough mass outside the box that clipping is actually exercised
+        assert (got == g.high.max()).any() or (got == g.low.min()).any()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_sample_clip_time_slice_and_row0_mean(dtype):
+    g = Golden("c1_halfcheetah_n128")
+    pl = make_planner(g, dtype)
+    rs = np.random.RandomState(0)
+    mean = rs.uniform(-0.3, 0.3, (g.h, g.d))
+    std = rs.uniform(0.1, 0.6, (g.h, g.d))
+    zr, zi = rs.randn(7, g.d, g.h // 2 + 1), rs.randn(7, g.d, g.h // 2 + 1)
+    full = O.sample_action_sequences(mean, std, g.low, g.high, g.beta, zr, zi)
+    # icem.py:102: only the last time step is written
+    out = torch.full((7, g.h, g.d), 9.0, dtype=pl.dt, device=pl.device)
+    pl.sample_clip(7, mean, std, zr, zi, t_begin=g.h - 1, out=out)
+    got = np_(out)
+    assert (got[:, :-1] == 9.0).all()
+    np.testing.assert_allclose(got[:, -1], full[:, -1], **tol(dtype))
+    # icem.py:87-88: row 0 <- mean (only where first_index == 0)
+    got = np_(pl.sample_clip(7, mean, std, zr, zi, row0_mean=True))
+    np.testing.assert_allclose(got[0], mean, **tol(dtype))
+    np.testing.assert_allclose(got[1:], full[1:], **tol(dtype))
+    got = np_(pl.sample_clip(7, mean, std, zr, zi, row0_mean=True, first_index=7))
+    np.testing.assert_allclose(got, full, **tol(dtype))
+
+
+@pytest.mark.parametrize("rounds", [10, 7])
+@pytest.mark.parametrize("h,d", [(30, 6), (12, 6), (13, 4), (30, 17), (64, 3), (2, 1)])
+def test_philox_normals_match_oracle(h, d, rounds):
+    """Device Philox4x32 + Box-Muller == the oracle's restatement (f64: tight; f32: the
+    hardware log2/sin/cos path within 2e-6 absolute of the float32 formula)."""
+    from icem_amd import IcemConfig, IcemPlanner
+    n, seed, off, first = 37, 0xDEADBEEFCAFE1234, (5 << 32) | 17, 1000
+    for dtype, npdt, atol in (("f64", np.float64, 1e-12), ("f32", np.float32, 4e-6)):
+        pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=64, dtype=dtype, seed=seed, rng_rounds=rounds),
+                         -np.ones(d), np.ones(d))
+        zr, zi = pl.philox_normals(n, offset=off, first_index=first)
+        ozr, ozi = O.philox_white_noise(seed, off, n, d, h, first_index=first, rounds=rounds, dtype=npdt)
+        np.testing.assert_allclose(np_(zr), ozr, rtol=0, atol=atol)
+        np.testing.assert_allclose(np_(zi), ozi, rtol=0, atol=atol)
+        # sampling from the same counters == oracle sampling from the oracle's normals
+        mean = np.zeros((h, d))
+        std = 0.5 * np.ones((h, d))
+        got = np_(pl.sample_clip(n, mean, std, offset=off, first_index=first))
+        ref = O.sample_action_sequences(mean, std, -np.ones(d), np.ones(d), 0.25, ozr.astype(np.float64),
+                                        ozi.astype(np.float64))
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-11 if dtype == "f64" else 1e-5)
+
+
+def test_philox_known_answers_and_moments():
+    """Random123 known-answer vectors pin the oracle's Philox; moments pin the device normals."""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, out in kat:
+        got = O.philox4x32(*[np.array([c]) for c in ctr], key[0], key[1], 10)
+        assert tuple(int(x[0]) for x in got) == out
+    from icem_amd import IcemConfig, IcemPlanner
+    pl = IcemPlanner(IcemConfig(horizon=30, act_dim=6, num_traj=64, dtype="f32", seed=7), -np.ones(6), np.ones(6))
+    zr, zi = pl.philox_normals(20000, offset=3)
+    z = np.concatenate([np_(zr).ravel(), np_(zi)[..., 1:-1].ravel()])
+    assert abs(z.mean()) < 5e-3 and abs(z.std() - 1) < 5e-3
+    assert abs((z ** 3).mean()) < 2e-2 and abs((z ** 4).mean() - 3) < 5e-2
+    assert (np_(zi)[..., 0] == 0).all() and (np_(zi)[..., -1] == 0).all()
+
+
+def test_colored_noise_statistics():
+    """KATs of SURVEY 8(c): unit variance and PSD slope -beta of the sampled sequences."""
+    from icem_amd import IcemConfig, IcemPlanner
+    h, d, n, beta = 30, 6, 20000, 2.0
+    pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=64, dtype="f32", seed=11, noise_beta=beta),
+                     -100 * np.ones(d), 100 * np.ones(d))
+    x = np_(pl.sample_clip(n, np.zeros((h, d)), np.ones((h, d)), offset=1))  # [n,h,d], no clipping
+    assert abs(x.std() - 1.0) < 2e-2
+    psd = (np.abs(np.fft.rfft(x, axis=1)) ** 2).mean(axis=(0, 2))
+    k = np.arange(1, h // 2)
+    slope = np.polyfit(np.log(k), np.log(psd[1:h // 2]), 1)[0]
+    assert abs(slope + beta) < 0.1
+
+
+# ---------------------------------------------------------------------------------------------
+# K2 rollout + cost
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("name", CASES)
+def test_rollout_cost_matches_reference(name, dtype):
+    g = Golden(name)
+    pl = make_planner(g, dtype)
+    model = O.SyntheticModel(g.A, g.B, g.kind)
+    for i in (0, g.iters):  # first iteration of MPC steps 0 and 1 (the latter includes shifted elites)
+        ref = g.it(i)
+        act = ref["simact"]
+        costs, obs = pl.rollout_cost(g.obs[i // g.iters], act, return_observations=True)
+        n_sim = act.shape[0]
+        np.testing.assert_allclose(np_(costs), ref["costs"][:n_sim], **tol(dtype))
+        np.testing.assert_allclose(np_(obs), O.rollout_observations(model, g.obs[i // g.iters], act),
+                                   rtol=tol(dtype)["rtol"], atol=10 * tol(dtype)["atol"])
+
+
+@pytest.mark.parametrize("mode", ["sum", "best", "final"])
+def test_cost_reduce(mode):
+    g = Golden("c1_halfcheetah_n128")
+    pl = make_planner(g, "f64", cost_mode=mode)
+    x = np.random.RandomState(1).randn(333, g.h)
+    ref = {"sum": x.sum(1), "best": x.min(1), "final": x[:, -1]}[mode]
+    np.testing.assert_allclose(np_(pl.cost_reduce(x)), ref, rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.parametrize("o", [3, 8, 16, 17, 18, 24, 29, 32])
+@pytest.mark.parametrize("kind", [0, 1])
+def test_rollout_cost_obs_dims(o, kind):
+    """Every compiled observation width (incl. zero-padded ones) against the oracle."""
+    from icem_amd import IcemConfig, IcemPlanner
+    h, d, n = 12, 5, 300
+    rs = np.random.RandomState(o)
+    m = O.SyntheticModel.make(o, d, kind)
+    spec = O.CostSpec(0.1, o - 1, -1.0, min(1, o - 1), 10.0, 0.3)
+    act = rs.uniform(-1, 1, (n, h, d))
+    obs0 = rs.randn(o)
+    for dtype in ("f64", "f32"):
+        pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=64, dtype=dtype), -np.ones(d), np.ones(d))
+        pl.set_model(kind, m.A, m.B)
+        pl.set_cost(spec.ctrl_weight, spec.lin_idx, spec.lin_weight, spec.flip_idx, spec.flip_penalty, spec.flip_thresh)
+        got = np_(pl.rollout_cost(obs0, act))
+        ref = O.rollout_costs(m, spec, obs0, act)
+        np.testing.assert_allclose(got, ref, rtol=tol(dtype)["rtol"] * 10, atol=tol(dtype)["atol"] * 50)
+    with pytest.raises(Exception, match="UNSUPPORTED"):
+        pl.set_model(0, np.eye(40), np.zeros((d, 40)))
+
+
+# ---------------------------------------------------------------------------------------------
+# K3 top-k, K4 refit
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("n,k", [(1, 1), (5, 10), (10, 10), (128, 10), (1024, 10), (1025, 10), (4099, 10),
+                                 (65536, 10), (65539, 64), (300000, 10)])
+def test_topk_sorted_exact(n, k, dtype):
+    g = Golden("c1_halfcheetah_n128")
+    pl = make_planner(g, dtype)
+    rs = np.random.RandomState(n + k)
+    c = rs.randn(n).astype(np.float32 if dtype == "f32" else np.float64)
+    if n > 20:  # ties, NaN, infinities
+        c[rs.randint(0, n, 8)] = c.min() - 1.0
+        c[rs.randint(0, n, 3)] = np.nan
+        c[rs.randint(0, n, 2)] = -np.inf
+        c[rs.randint(0, n, 2)] = np.inf
+    oc, oi = pl.topk_sorted(c, k)
+    ref = O.topk_sorted(c.astype(np.float64), k)
+    kk = min(k, n)
+    assert np.array_equal(oi.cpu().numpy()[:kk], ref[:kk])
+    cc = np.where(np.isnan(c), np.inf, c)
+    assert np.array_equal(np_(oc)[:kk], cc[ref[:kk]].astype(np.float64))
+    if n < k:  # fewer candidates than K: padded with (+inf, INT_MAX)
+        assert (oi.cpu().numpy()[n:] == np.iinfo(np.int32).max).all() and np.isinf(np_(oc)[n:]).all()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_gather_refit(dtype):
+    g = Golden("c1_halfcheetah_n128")
+    pl = make_planner(g, dtype)
+    rs = np.random.RandomState(3)
+    act = rs.uniform(-1, 1, (500, g.h, g.d))
+    idx = rs.permutation(500)[:10]
+    mean = rs.randn(g.h, g.d) * 0.1
+    std = rs.uniform(0.1, 0.5, (g.h, g.d))
+    m, s = pl._t(mean).clone(), pl._t(std).clone()
+    el = pl.gather_refit(pl._t(act), torch.as_tensor(idx), m, s)
+    rm, rstd = O.refit(act[idx], mean, std, g.alpha)
+    np.testing.assert_allclose(np_(el), act[idx], **tol(dtype))
+    np.testing.assert_allclose(np_(m), rm, **tol(dtype))
+    np.testing.assert_allclose(np_(s), rstd, **tol(dtype))
+    pl.shift(m, s)
+    rm2 = rm.copy()
+    rm2[:-1] = rm[1:]
+    np.testing.assert_allclose(np_(m), rm2, **tol(dtype))
+    np.testing.assert_allclose(np_(s), np.ones_like(rm) * (g.high - g.low) / 2 * g.init_std, **tol(dtype))
+
+
+# ---------------------------------------------------------------------------------------------
+# the whole loop
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("name", CASES)
+def test_fused_plan_replays_reference_run(name, dtype):
+    """Fused device path, fed the reference's own white draws: after every CEM iteration of every
+    MPC step the elite costs (sorted), mean and std match the reference run, and so do the executed
+    actions.  Elite identity is checked through the elite costs + actions (bit-exact index sets)."""
+    g = Golden(name)
+    pl = make_planner(g, dtype)
+    pl.reset()
+    calls = iter(range(g.n_noise_calls))
+    it_global = [0]
+    t = tol(dtype)
+
+    def noise(num):
+        zr, zi = g.noise(next(calls))
+        assert zr.shape[0] == num
+        return zr, zi
+
+    for s in range(g.n_steps):
+        def check(it):
+            ref = g.it(it_global[0])
+            gi = (pl.mpc_step * g.iters + it + 1) & 1
+            ea, ec = np_(pl.elites_actions[gi]), np_(pl.elites_costs[gi])
+            ref_c = ref["costs"][ref["elite"]]
+            np.testing.assert_allclose(ec, ref_c, **t)
+            # elite index set: rows of the reference pool at the reference's elite indices
+            sim = ref["simact"]
+            for r, e in enumerate(ref["elite"]):
+                if e < sim.shape[0]:
+                    np.testing.assert_allclose(ea[r], sim[e], **t)
+            if it < g.iters - 1:
+                np.testing.assert_allclose(np_(pl.mean), ref["mean"], **t)
+                np.testing.assert_allclose(np_(pl.std), ref["std"], **t)
+            else:  # after the last iteration the mean is already shifted, std reset
+                sh = ref["mean"].copy()
+                sh[:-1] = ref["mean"][1:]
+                np.testing.assert_allclose(np_(pl.mean), sh, **t)
+            it_global[0] += 1
+
+        a = np_(pl.plan_step(g.obs[s], noise=noise, on_iteration=check))
+        np.testing.assert_allclose(a, g.executed[s], **t)
+        ref_last = g.it(it_global[0] - 1)
+        np.testing.assert_allclose(np_(pl.best_cost)[0], ref_last["costs"].min(), **t)
+    assert next(calls, None) is None
+
+
+@pytest.mark.parametrize("name", ["c1_halfcheetah_n128", "h13_odd_n48", "final_noreuse_n40"])
+def test_controller_device_path_legacy_stream(name):
+    """MpcICemHip under np.random.seed draws the reference's stream in the reference's order."""
+    from icem_amd import DeviceSyntheticModel, MpcICemHip, halfcheetah_env
+    g = Golden(name)
+    env = halfcheetah_env(g.o)
+    env.action_space.low[:] = -g.bounds
+    env.action_space.high[:] = g.bounds
+    if g.d != 6:
+        from icem_amd.envs import Box
+        env.action_space = Box(-g.bounds * np.ones(g.d), g.bounds * np.ones(g.d))
+    ctrl = MpcICemHip(env=env, forward_model=DeviceSyntheticModel(g.A, g.B, g.kind), horizon=g.h,
+                      num_simulated_trajectories=g.N, factor_decrease_num=g.gamma,
+                      cost_along_trajectory=g.cost_mode, dtype="f64", noise_source="numpy_legacy",
+                      action_sampler_params=dict(alpha=g.alpha, elites_size=g.K, opt_iterations=g.iters,
+                                                 init_std=g.init_std, use_mean_actions=g.use_mean,
+                                                 keep_previous_elites=g.keep, shift_elites_over_time=g.shift,
+                                                 fraction_elites_reused=g.xi, noise_beta=g.beta))
+    assert ctrl.device_path and ctrl.has_state and not ctrl.needs_data
+    with pytest.raises(AttributeError):
+        ctrl.get_action(g.obs[0], None)
+    np.random.seed(g.seed)
+    ctrl.beginning_of_rollout(observation=g.obs[0], state=None, mode="train")
+    for s in range(g.n_steps):
+        a = ctrl.get_action(g.obs[s], None)
+        assert a.dtype == np.float64 and a.shape == (g.d,)
+        np.testing.assert_allclose(a, g.executed[s], rtol=F64_RTOL, atol=F64_ATOL)
+    ctrl.end_of_rollout(1.0, 0.0, "train")
+    assert len(ctrl.elite_samples) == ctrl.num_elites
+
+
+@pytest.mark.parametrize("name", ["c1_halfcheetah_n128", "h12_n64"])
+def test_controller_host_model_path(name):
+    """A reference-style CPU forward model (predict / predict_n_steps) behind the same controller:
+    sampling, top-k and refit on the GPU, model + env.cost_fn on the host."""
+    from icem_amd import MpcICemHip, halfcheetah_env
+    from icem_amd.models import ForwardModel
+    g = Golden(name)
+    env = halfcheetah_env(g.o)
+    om = O.SyntheticModel(g.A, g.B, g.kind)
+
+    class HostModel(ForwardModel):
+        def predict(self, *, observations, states, actions):
+            return om.predict(observations, actions), None, np.zeros(observations.shape[:-1] + (1,))
+
+    ctrl = MpcICemHip(env=env, forward_model=HostModel(env=env), horizon=g.h, num_simulated_trajectories=g.N,
+                      factor_decrease_num=g.gamma, cost_along_trajectory=g.cost_mode, dtype="f64",
+                      noise_source="numpy_legacy",
+                      action_sampler_params=dict(alpha=g.alpha, elites_size=g.K, opt_iterations=g.iters,
+                                                 init_std=g.init_std, use_mean_actions=g.use_mean,
+                                                 keep_previous_elites=g.keep, shift_elites_over_time=g.shift,
+                                                 fraction_elites_reused=g.xi, noise_beta=g.beta))
+    assert not ctrl.device_path
+    np.random.seed(g.seed)
+    ctrl.beginning_of_rollout(observation=g.obs[0], state=None, mode="train")
+    for s in range(g.n_steps):
+        a = ctrl.get_action(g.obs[s], None)
+        np.testing.assert_allclose(a, g.executed[s], rtol=F64_RTOL, atol=F64_ATOL)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_philox_plan_matches_oracle_and_is_shard_invariant(dtype):
+    """Philox mode end to end: (a) world=1 fused step == oracle driven by the same counters;
+    (b) world=2 and world=3, emulated on one GPU by two/three planners whose records are
+    concatenated in place of the all-gather, reproduce world=1 (RNG keyed by the global index)."""
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env
+    env = halfcheetah_env(17)
+    model = DeviceSyntheticModel.make(17, 6, kind=1)
+    seed, iters, N, h, d = 99, 4, 1000, 30, 6
+    spec = env.cost_spec
+
+    def mk(rank, world):
+        pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=N, opt_iters=iters, dtype=dtype, seed=seed,
+                                    rank=rank, world=world), env.action_space.low, env.action_space.high)
+        pl.set_model(model.kind, model.A, model.B)
+        pl.set_cost(spec.ctrl_weight, spec.lin_idx, spec.lin_weight, spec.flip_idx, spec.flip_penalty, spec.flip_thresh)
+        pl.reset()
+        return pl
+
+    obs_seq = [0.1 * np.random.RandomState(s).randn(17) for s in range(3)]
+    single = mk(0, 1)
+    acts1 = [np_(single.plan_step(o)).copy() for o in obs_seq]
+    mean1 = np_(single.mean)
+
+    # (a) oracle
+    npdt = np.float64 if dtype == "f64" else np.float32
+    noise = O.PhiloxNoiseSchedule(seed, iters, d, h, dtype=npdt)
+    om, oc = O.SyntheticModel(model.A, model.B, model.kind), O.CostSpec.halfcheetah(17)
+    orc = O.IcemOracle(O.IcemParams(horizon=h, num_simulated_trajectories=N, opt_iterations=iters),
+                       env.action_space.low.astype(np.float64), env.action_space.high.astype(np.float64),
+                       lambda ob, ac: O.rollout_costs(om, oc, ob, ac), lambda num: tuple(
+                           z.astype(np.float64) for z in noise(num)))
+    orc.beginning_of_rollout()
+    t = dict(rtol=1e-9, atol=1e-11) if dtype == "f64" else dict(rtol=2e-4, atol=2e-5)
+    for s, o in enumerate(obs_seq):
+        if s:
+            noise.begin_step()
+        np.testing.assert_allclose(acts1[s], orc.get_action(o), **t)
+    np.testing.assert_allclose(mean1, orc.mean, **t)
+
+    # (b) shard invariance
+    import ctypes as C
+    from icem_amd import _lib as L
+    for world in (2, 3):
+        pls = [mk(r, world) for r in range(world)]
+        st = pls[0]._stream()
+        for s, o in enumerate(obs_seq):
+            for pl in pls:
+                pl.obs0.copy_(torch.as_tensor(o, dtype=pl.dt))
+            for it in range(iters):
+                for pl in pls:
+                    L.check(pl.lib.icem_plan_iter_local(pl._h, C.byref(pl._cb), s, it, st))
+                K = pls[0].K
+                full = torch.cat([pl.records[r * K:(r + 1) * K] for r, pl in enumerate(pls)], dim=0)
+                for pl in pls:
+                    pl.records.copy_(full)  # stands in for the RCCL all-gather
+                    L.check(pl.lib.icem_plan_iter_merge(pl._h, C.byref(pl._cb), s, it, st))
+            for pl in pls:
+                # every rank holds the same replicated result, identical to the single-GPU run
+                assert np.array_equal(np_(pl.executed), acts1[s])
+        for pl in pls:
+            assert np.array_equal(np_(pl.mean), mean1)
+
+
+def test_large_population_properties():
+    """BASELINE sizes (N=65536, h=30, d=6): size-independent checks of the fused f32 path:
+    device top-k == lexsort of the device costs (bit-exact); oracle costs of the device's own
+    actions within 1e-5 relative; refit of the gathered elites within 1e-5."""
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env
+    env = halfcheetah_env(17)
+    model = DeviceSyntheticModel.make(17, 6)
+    N, h, d = 65536, 30, 6
+    pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=N, opt_iters=1, dtype="f32", seed=5,
+                                use_mean_actions=False), env.action_space.low, env.action_space.high)
+    pl.set_model(model.kind, model.A, model.B)
+    c = env.cost_spec
+    pl.set_cost(c.ctrl_weight, c.lin_idx, c.lin_weight, c.flip_idx, c.flip_penalty, c.flip_thresh)
+    pl.reset()
+    obs = 0.1 * np.random.RandomState(0).randn(17)
+    mean0, std0 = np_(pl.mean), np_(pl.std)
+    pl.plan_step(obs)
+    act = np_(pl.actions[:N])
+    costs = np_(pl.costs[:N])
+    assert act.min() >= -1 and act.max() <= 1
+    om, oc = O.SyntheticModel(model.A, model.B, model.kind), O.CostSpec.halfcheetah(17)
+    ref_costs = O.rollout_costs(om, oc, obs, act)
+    np.testing.assert_allclose(costs, ref_costs, rtol=1e-5, atol=2e-5)
+    idx = O.topk_sorted(pl.costs[:N].cpu().numpy(), pl.K)
+    ea, ec = pl.current_elites()
+    assert np.array_equal(np_(ec), costs[idx])
+    assert np.array_equal(np_(ea), act[idx])           # bit-exact elite index set
+    assert set(idx) == set(O.topk_sorted(ref_costs, pl.K))  # and the same set as the f64 oracle's costs
+    rm, rs_ = O.refit(act[idx], mean0, std0, 0.1)
+    sh = rm.copy()
+    sh[:-1] = rm[1:]
+    np.testing.assert_allclose(np_(pl.mean), sh, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(np_(pl.executed), act[idx[0], 0], rtol=0, atol=0)
