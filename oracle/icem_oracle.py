@@ -394,7 +394,7 @@ def trajectory_costs(cost_fn: Callable, observations: np.ndarray, actions: np.nd
 def rollout_costs(model: SyntheticModel, cost: CostSpec, obs0, actions, mode="sum", dtype=None):
     """Fused rollout+cost with a running accumulation over ``t`` (the order
     the HIP kernel uses): returns ``costs [P]``."""
-    dt = actions.dtype if dtype is None else dtype
+    dt = np.dtype(actions.dtype if dtype is None else dtype).type
     actions = actions.astype(dt)
     P, h, _ = actions.shape
     obs = np.broadcast_to(np.asarray(obs0, dtype=dt), (P, len(obs0))).copy()

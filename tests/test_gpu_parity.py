@@ -131,7 +131,12 @@ def test_colored_noise_statistics():
     pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=64, dtype="f32", seed=11, noise_beta=beta),
                      -100 * np.ones(d), 100 * np.ones(d))
     x = np_(pl.sample_clip(n, np.zeros((h, d)), np.ones((h, d)), offset=1))  # [n,h,d], no clipping
-    assert abs(x.std() - 1.0) < 2e-2
+    # sigma normalises the non-DC bins to unit variance; the random DC bin adds (s0/(h sigma))^2
+    Cr, Ci = O.synthesis_matrices(h, beta)
+    var_t = (Cr ** 2 + Ci ** 2).sum(axis=0)
+    assert np.allclose(var_t, var_t[0]) and abs(var_t[0] - Cr[0, 0] ** 2 - 1.0) < 1e-12
+    assert abs(x.std() - np.sqrt(var_t[0])) < 1e-2
+    assert abs((x - x.mean(axis=1, keepdims=True)).var(axis=1).mean() - 1.0) < 2e-2
     psd = (np.abs(np.fft.rfft(x, axis=1)) ** 2).mean(axis=(0, 2))
     k = np.arange(1, h // 2)
     slope = np.polyfit(np.log(k), np.log(psd[1:h // 2]), 1)[0]
