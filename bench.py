@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- iCEM inner planning loop on MI355X: traj-steps/s of whole MPC steps.
+
+  python bench.py --gpus N --steps K --warmup W [--workload c2|c4]
+
+A "step" is one MPC step = all CEM iterations (sample -> rollout -> cost -> top-k -> refit) of one
+`get_action`, on synthetic HalfCheetah-shaped input already resident in HBM.  Workload c2 (default;
+BASELINE.json's metric is quoted on it): N=4096, h=30, d=6, o=17, beta=0.25, 5 iterations with
+population decay (4096, 3276, 2620, 2096, 1676), K=10, f32.  Workload c4: N=65536, same otherwise.
+For --gpus G > 1 (launched by torch.distributed.run, one rank per GPU over RCCL) the per-GPU
+population is fixed (weak scaling): global N = G * N, sharded by global trajectory index, with one
+all-gather of the ranks' K candidate records per CEM iteration.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel, from HIP events recorded on
+the launch stream inside the library (icem_profile_*), in a second pass over the same steps;
+`cpu_baseline` times oracle/icem_oracle.c (a plain-C restatement, "port") on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+
+WORKLOADS = {
+    "c2": dict(N=4096, h=30, d=6, o=17, beta=0.25, iters=5, name="HalfCheetah-shaped synthetic, N=4096 h=30 d=6 o=17 beta=0.25, 5 CEM iters"),
+    "c4": dict(N=65536, h=30, d=6, o=17, beta=0.25, iters=5, name="HalfCheetah-shaped synthetic, N=65536 h=30 d=6 o=17 beta=0.25, 5 CEM iters"),
+}
+
+
+def make_planner(w, rank, world, seed=1234):
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env
+    env = halfcheetah_env(w["o"])
+    model = DeviceSyntheticModel.make(w["o"], w["d"], kind=0)
+    cfg = IcemConfig(horizon=w["h"], act_dim=w["d"], num_traj=w["N"] * world, opt_iters=w["iters"],
+                     noise_beta=w["beta"], dtype="f32", seed=seed, rank=rank, world=world)
+    pl = IcemPlanner(cfg, env.action_space.low, env.action_space.high, device=f"cuda:{torch.cuda.current_device()}")
+    pl.set_model(model.kind, model.A, model.B)
+    c = env.cost_spec
+    pl.set_cost(c.ctrl_weight, c.lin_idx, c.lin_weight, c.flip_idx, c.flip_penalty, c.flip_thresh)
+    pl.reset()
+    pl.obs0.copy_(torch.as_tensor(0.1 * np.random.RandomState(0).randn(w["o"]), dtype=pl.dt))
+    return pl, model, env
+
+
+def run_steps(pl, n, world):
+    if world == 1:
+        for _ in range(n):
+            pl.plan_step_resident()
+    else:
+        obs = pl.obs0.cpu().numpy()
+        for _ in range(n):
+            pl.plan_step(obs)
+
+
+def algorithmic_bytes_per_trajstep(kernel, d, h):
+    """the whole loop moves 8d + 8/h bytes per traj-step in f32 (actions written once and
+    read once, costs written once and read once).  A kernel is charged its own share of that."""
+    return {"sample_clip": 4.0 * d, "rollout_cost": 4.0 * d + 4.0 / h, "fused": 8.0 * d + 8.0 / h}.get(kernel)
+
+
+def cpu_baseline(w, model, env, budget_s=12.0):
+    """oracle/icem_oracle.c (float64, OpenMP over trajectories) on one MPC step's worth of
+    iterations of the same workload, repeated until ~budget_s of wall time."""
+    from oracle import c_oracle as CO
+    lib = CO.load()
+    cores = lib.icem_c_num_threads()
+    h, d, o, K = w["h"], w["d"], w["o"], 10
+    pops = []
+    n = w["N"]
+    for i in range(w["iters"]):
+        if i:
+            n = max(2 * K, int(n / 1.25))
+        pops.append(n)
+    A, B = CO.c64(model.A), CO.c64(model.B)
+    obs0 = 0.1 * np.random.RandomState(0).randn(o)
+    low, high = -np.ones(d), np.ones(d)
+    c = env.cost_spec
+    actions = np.zeros((pops[0], h, d))
+    costs = np.zeros(pops[0])
+    idx = np.zeros(K, dtype=np.int32)
+    ec = np.zeros(K)
+    done, t0 = 0, time.perf_counter()
+    reps = 0
+    while True:
+        mean = np.zeros((h, d))
+        std = 0.5 * np.ones((h, d))
+        for it, n_it in enumerate(pops):
+            lib.icem_c_iteration(n_it, h, d, o, K, w["beta"], 0.1, 1234, reps * 8 + it, 10, 0, A, B, obs0, low, high,
+                                 c.ctrl_weight, c.lin_idx, c.lin_weight, c.flip_idx, c.flip_penalty, c.flip_thresh,
+                                 mean, std, actions, costs, idx, ec)
+            done += n_it * h
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or reps >= 64:
+            break
+    return {"value": done / el, "unit": "traj-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} MPC step(s) of the same workload ({sum(pops)} trajectories x h={h} each) in "
+                      f"{el:.1f} s; oracle/icem_oracle.c, float64, OpenMP over trajectories"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+
+    w = WORKLOADS[args.workload]
+    pl, model, env = make_planner(w, rank, world)
+    per_step_trajsteps = sum(pl.population_sizes) * w["h"]  # global (all ranks) traj-steps per MPC step
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run_steps(pl, args.warmup, world)
+    sync()
+    t0 = time.perf_counter()
+    run_steps(pl, args.steps, world)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # second pass: per-kernel durations from HIP events on the launch stream
+    pl.profile_enable(True)
+    run_steps(pl, min(args.steps, 50), world)
+    torch.cuda.synchronize()
+    prof = pl.profile_read()
+    pl.profile_enable(False)
+
+    if rank == 0:
+        dom = max(prof, key=lambda k: prof[k][0])
+        ms, launches, units = prof[dom]
+        bpu = algorithmic_bytes_per_trajstep(dom, w["d"], w["h"])
+        roofline = None
+        if bpu is not None and ms > 0:
+            achieved = units * bpu / (ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": dom,
+                        "avg_launch_us": 1e3 * ms / launches, "launches": launches,
+                        "algorithmic_bytes_per_launch": units * bpu / launches,
+                        "bytes_per_traj_step": bpu}
+        out = {
+            "metric": "traj-steps/sec (N x h), iCEM inner planning loop", "value": per_step_trajsteps * args.steps / elapsed,
+            "unit": "traj-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": w["name"], "per_gpu_population": w["N"], "global_population": w["N"] * world,
+                       "traj_per_mpc_step": sum(pl.population_sizes), "model": "o' = o.A + a.B dense linear (synthetic)",
+                       "cost": "HalfCheetah cost_fn", "rng": "Philox4x32-10 + Box-Muller", "parallelism": f"n-shard x{world}"},
+            "ms_per_mpc_step": 1e3 * elapsed / args.steps,
+            "roofline": roofline,
+            "kernels_us": {k: round(1e3 * v[0] / v[1], 2) for k, v in prof.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(w, model, env)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,8 @@ MODEL_LINEAR, MODEL_TANH = 0, 1
 (BUF_MEAN, BUF_STD, BUF_LOW, BUF_HIGH, BUF_OBS0, BUF_ACTIONS, BUF_COSTS, BUF_ELITES, BUF_RECORDS,
  BUF_WORKSPACE, BUF_EXECUTED, BUF_BEST_COST, BUF_COUNT) = range(13)
 
+KERNEL_NAMES = ["sample_clip", "rollout_cost", "topk_partial", "local_pack", "merge_refit", "fused"]
+
 ERR_NAMES = {-1: "ICEM_E_INVALID", -2: "ICEM_E_UNSUPPORTED", -3: "ICEM_E_HIP", -4: "ICEM_E_NO_DEVICE",
              -5: "ICEM_E_STATE"}
 
@@ -73,6 +75,8 @@ SYMBOLS = [
     ("icem_plan_iter_merge", C.c_int, [_H, C.POINTER(IcemPlanBuffersC), _I32, _I32, _VP]),
     ("icem_plan_step", C.c_int, [_H, C.POINTER(IcemPlanBuffersC), _I32, _VP]),
     ("icem_record_bytes", _SZ, [_H]),
+    ("icem_profile_enable", C.c_int, [_H, _I32]),
+    ("icem_profile_read", C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 ]
 
 

@@ -41,6 +41,10 @@ static int fail(int code, const std::string& msg) {
 constexpr int WG = 256;          // 4 wavefronts of 64
 constexpr int TOPK_CHUNK = 1024; // costs per workgroup in the block-level top-k
 
+// __builtin_fma is the DOUBLE fma: route by type so the f32 kernels stay in f32.
+__device__ __forceinline__ float fmad(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fmad(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 template <typename T>
 __device__ __forceinline__ T inf_v() {
     return (T)INFINITY;
@@ -124,8 +128,8 @@ __global__ __launch_bounds__(WG) void sample_clip_kernel(SampleArgs<T> a) {
             const T* __restrict__ w = a.W + (size_t)t * HMAX;
             T acc = (T)0;
 #pragma unroll
-            for (int m = 0; m < HMAX; ++m) acc = __builtin_fma(g[m], w[m], acc);
-            T v = __builtin_fma(acc, a.std[t * a.d + j], a.mean[t * a.d + j]);
+            for (int m = 0; m < HMAX; ++m) acc = fmad(g[m], w[m], acc);
+            T v = fmad(acc, a.std[t * a.d + j], a.mean[t * a.d + j]);
             v = v < lo ? lo : v;
             v = v > hi ? hi : v;
             tile[nl * hd + t * a.d + j] = v;
@@ -215,14 +219,14 @@ __global__ __launch_bounds__(WG) void rollout_cost_kernel(RolloutArgs<T> a) {
         for (int k = 0; k < O; ++k) {
             const T ok = obs[k];
 #pragma unroll
-            for (int i = 0; i < O; ++i) nxt[i] = __builtin_fma(ok, A[k * O + i], nxt[i]);
+            for (int i = 0; i < O; ++i) nxt[i] = fmad(ok, A[k * O + i], nxt[i]);
         }
         T ctrl = (T)0;
         for (int j = 0; j < a.d; ++j) {
             const T aj = act[t * a.d + j];
-            ctrl = __builtin_fma(aj, aj, ctrl);
+            ctrl = fmad(aj, aj, ctrl);
 #pragma unroll
-            for (int i = 0; i < O; ++i) nxt[i] = __builtin_fma(aj, B[j * O + i], nxt[i]);
+            for (int i = 0; i < O; ++i) nxt[i] = fmad(aj, B[j * O + i], nxt[i]);
         }
         T lin = (T)0, ang = (T)0;
 #pragma unroll
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(WG) void gather_refit_kernel(int hd, int K, T alpha
         T v = (T)0;
         for (int r = 0; r < K; ++r) {
             const T dx = actions[(size_t)idx[r] * hd + e] - m;
-            v = __builtin_fma(dx, dx, v);
+            v = fmad(dx, dx, v);
         }
         const T sd = sqrt(v / (T)K);
         mean[e] = ((T)1 - alpha) * m + alpha * mean[e];
@@ -553,7 +557,7 @@ __global__ __launch_bounds__(WG) void merge_refit_kernel(MergeArgs<T> a) {
         T v = (T)0;
         for (int r = 0; r < a.K; ++r) {
             const T dx = src_row(r)[e] - m;
-            v = __builtin_fma(dx, dx, v);
+            v = fmad(dx, dx, v);
         }
         const T sd = sqrt(v / (T)a.K);
         const T nm = ((T)1 - a.alpha) * m + a.alpha * a.mean[e];
@@ -599,7 +603,48 @@ struct icem_handle {
     std::vector<int> pop;
     int n_reuse = 0;
     int n_local_max = 0;
+    // optional per-kernel timing with HIP events on the caller's stream (bench.py roofline leg)
+    bool profiling = false;
+    struct Span {
+        int kind;
+        long long units;
+        hipEvent_t a, b;
+    };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> free_events;
 };
+
+namespace {
+struct ProfScope {
+    icem_handle* h;
+    hipStream_t st;
+    hipEvent_t a = nullptr, b = nullptr;
+    int kind;
+    long long units;
+    static hipEvent_t get(icem_handle* h) {
+        if (!h->free_events.empty()) {
+            hipEvent_t e = h->free_events.back();
+            h->free_events.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    ProfScope(const icem_handle* hc, int kind_, long long units_, hipStream_t st_)
+        : h(const_cast<icem_handle*>(hc)), st(st_), kind(kind_), units(units_) {
+        if (!h->profiling) return;
+        a = get(h);
+        b = get(h);
+        (void)hipEventRecord(a, st);
+    }
+    ~ProfScope() {
+        if (!a) return;
+        (void)hipEventRecord(b, st);
+        h->spans.push_back({kind, units, a, b});
+    }
+};
+}  // namespace
 
 namespace {
 
@@ -711,6 +756,7 @@ int launch_sample(const icem_handle* h, const SampleArgs<T>& a, hipStream_t st) 
     if (a.n <= 0) return ICEM_OK;
     const int grid = (a.n + a.tpw - 1) / a.tpw;
     const size_t lds = (size_t)a.tpw * a.h * a.d * sizeof(T);
+    ProfScope prof(h, ICEM_K_SAMPLE, (long long)a.n * (a.h - a.t_begin), st);
     const bool r7 = h->cfg.rng_rounds == 7;
     if (h->HMAX == 32) {
         if (r7)
@@ -730,6 +776,7 @@ int launch_sample(const icem_handle* h, const SampleArgs<T>& a, hipStream_t st) 
 template <typename T, int KIND>
 int launch_rollout_k(const icem_handle* h, const RolloutArgs<T>& a, hipStream_t st) {
     const int grid = (a.n + WG - 1) / WG;
+    ProfScope prof(h, ICEM_K_ROLLOUT, (long long)a.n * a.h, st);
     switch (h->O) {
 #define ICEM_CASE(OV)                                                                                  \
     case OV:                                                                                           \
@@ -835,10 +882,16 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
     T* pc;
     int* pi;
     split_partial_ws<T>(b->workspace, nblk, K, &pc, &pi);
-    hipLaunchKernelGGL((topk_partial_kernel<T>), dim3(nblk), dim3(WG), 0, st, n_cand, K, (const T*)b->costs, pc, pi);
+    {
+        ProfScope prof(h, ICEM_K_TOPK_PARTIAL, n_cand, st);
+        hipLaunchKernelGGL((topk_partial_kernel<T>), dim3(nblk), dim3(WG), 0, st, n_cand, K, (const T*)b->costs, pc, pi);
+    }
     T* rec = (T*)b->records + (size_t)c.rank * K * (hd + 2);
-    hipLaunchKernelGGL((local_pack_kernel<T>), dim3(1), dim3(WG), 0, st, nblk * K, K, hd, n_loc, lo, n_global,
-                       (const T*)pc, (const int*)pi, (const T*)actions, rec);
+    {
+        ProfScope prof(h, ICEM_K_LOCAL_PACK, nblk * K, st);
+        hipLaunchKernelGGL((local_pack_kernel<T>), dim3(1), dim3(WG), 0, st, nblk * K, K, hd, n_loc, lo, n_global,
+                           (const T*)pc, (const int*)pi, (const T*)actions, rec);
+    }
     ICEM_HIP_TRY(hipGetLastError());
     return ICEM_OK;
 }
@@ -872,7 +925,10 @@ int plan_iter_merge_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
     a.high = (const T*)b->high;
     a.executed = (T*)b->executed;
     a.best_cost = (T*)b->best_cost;
-    hipLaunchKernelGGL((merge_refit_kernel<T>), dim3(1), dim3(WG), (size_t)hd * sizeof(T), st, a);
+    {
+        ProfScope prof(h, ICEM_K_MERGE_REFIT, a.n_rec + a.n_keep, st);
+        hipLaunchKernelGGL((merge_refit_kernel<T>), dim3(1), dim3(WG), (size_t)hd * sizeof(T), st, a);
+    }
     ICEM_HIP_TRY(hipGetLastError());
     return ICEM_OK;
 }
@@ -952,6 +1008,11 @@ int icem_destroy(icem_handle* h) {
     if (h->W_dev) (void)hipFree(h->W_dev);
     if (h->A_dev) (void)hipFree(h->A_dev);
     if (h->B_dev) (void)hipFree(h->B_dev);
+    for (auto& sp : h->spans) {
+        (void)hipEventDestroy(sp.a);
+        (void)hipEventDestroy(sp.b);
+    }
+    for (auto e : h->free_events) (void)hipEventDestroy(e);
     delete h;
     return ICEM_OK;
 }
@@ -1113,6 +1174,34 @@ int icem_reset_distribution(icem_handle* h, void* mean, void* std, const void* l
         hipLaunchKernelGGL((reset_kernel<float>), dim3(grid), dim3(WG), 0, st, h->cfg.horizon, h->cfg.act_dim,
                            (float)h->cfg.init_std, (float*)mean, (float*)std, (const float*)low, (const float*)high);
     ICEM_HIP_TRY(hipGetLastError());
+    return ICEM_OK;
+}
+
+int icem_profile_enable(icem_handle* h, int32_t on) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    h->profiling = on != 0;
+    return ICEM_OK;
+}
+
+int icem_profile_read(icem_handle* h, double* total_ms, int64_t* launches, int64_t* units) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (!total_ms || !launches || !units) return fail(ICEM_E_INVALID, "null output");
+    for (int k = 0; k < ICEM_K_COUNT; ++k) {
+        total_ms[k] = 0.0;
+        launches[k] = 0;
+        units[k] = 0;
+    }
+    for (auto& sp : h->spans) {
+        ICEM_HIP_TRY(hipEventSynchronize(sp.b));
+        float ms = 0.f;
+        ICEM_HIP_TRY(hipEventElapsedTime(&ms, sp.a, sp.b));
+        total_ms[sp.kind] += ms;
+        launches[sp.kind] += 1;
+        units[sp.kind] += sp.units;
+        h->free_events.push_back(sp.a);
+        h->free_events.push_back(sp.b);
+    }
+    h->spans.clear();
     return ICEM_OK;
 }
 

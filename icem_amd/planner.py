@@ -226,6 +226,24 @@ class IcemPlanner:
         L.check(self.lib.icem_reset_distribution(self._h, _ptr(mean), _ptr(std), _ptr(self.low), _ptr(self.high),
                                                  self._stream()))
 
+    # ------------------------------------------------------------------ measurement
+    def profile_enable(self, on: bool = True):
+        L.check(self.lib.icem_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        """{kernel: (total_ms, launches, units)} since the last read (HIP events on the launch stream)."""
+        n = len(L.KERNEL_NAMES)
+        ms, cnt, units = (C.c_double * n)(), (C.c_int64 * n)(), (C.c_int64 * n)()
+        L.check(self.lib.icem_profile_read(self._h, ms, cnt, units))
+        return {L.KERNEL_NAMES[i]: (ms[i], cnt[i], units[i]) for i in range(n) if cnt[i]}
+
+    def plan_step_resident(self):
+        """plan_step with the observation already in ``self.obs0`` (world == 1, Philox): no host
+        work besides the launches -- the bench's timed region."""
+        self._cb.z_r = self._cb.z_i = self._cb.z_r_shift = self._cb.z_i_shift = None
+        L.check(self.lib.icem_plan_step(self._h, C.byref(self._cb), self.mpc_step, self._stream()))
+        self.mpc_step += 1
+
     # ------------------------------------------------------------------ fused MPC step
     def _ensure_buffers(self):
         if self._bufs is not None:

@@ -215,6 +215,18 @@ int icem_plan_iter_merge(icem_handle* h, const icem_plan_buffers* b, int32_t mpc
  * (the body of MpcICem.get_action, icem.py:123-175). */
 int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, void* stream);
 
+/* ---- per-kernel timing (measurement only) ------------------------------------------------- */
+enum {
+    ICEM_K_SAMPLE = 0, ICEM_K_ROLLOUT, ICEM_K_TOPK_PARTIAL, ICEM_K_LOCAL_PACK, ICEM_K_MERGE_REFIT,
+    ICEM_K_FUSED, ICEM_K_COUNT
+};
+/* While enabled, every kernel launch of this handle is bracketed by hipEventRecord on the
+ * caller's stream.  icem_profile_read synchronises those events, returns per kernel class the
+ * summed duration [ms], the number of launches and the units processed (traj-steps for
+ * SAMPLE/ROLLOUT/FUSED, keys for the top-k kernels), and clears the log. */
+int icem_profile_enable(icem_handle* h, int32_t on);
+int icem_profile_read(icem_handle* h, double* total_ms, int64_t* launches, int64_t* units);
+
 /* Byte size / layout of one candidate record: {cost (T), gidx (int32, padded to sizeof(T)),
  * actions[h*d] (T)}; all-gather moves K records per rank. */
 size_t icem_record_bytes(const icem_handle* h);

@@ -1,0 +1,88 @@
+"""N>1 path on CPU: world_size-2/3 gloo runs of the product's sharding + record exchange
+(icem_amd.distributed), with the oracle standing in for the kernels.  Every rank must end with
+the replicated global elite set of the single-process run."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from icem_amd.distributed import exchange_records, shard_range
+from oracle import icem_oracle as O
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 2, 7, 128, 4096, 3276, 65536, 1676):
+        for w in (1, 2, 3, 4, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c and a <= b
+            assert all(hi - lo <= -(-n // w) for lo, hi in spans)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, N, K, h, d, o, seed, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model, cost = O.SyntheticModel.make(o, d), O.CostSpec.halfcheetah(o)
+        obs = 0.1 * np.random.RandomState(0).randn(o)
+        mean = np.zeros((h, d))
+        std = 0.5 * np.ones((h, d))
+        low, high = -np.ones(d), np.ones(d)
+        hd, rs = h * d, h * d + 2
+        for it, n_it in enumerate(O.population_sizes(N, K, 1.25, 3)):
+            lo, hi = shard_range(n_it, rank, world)
+            zr, zi = O.philox_white_noise(seed, it, hi - lo, d, h, first_index=lo)  # keyed by GLOBAL index
+            act = O.sample_action_sequences(mean, std, low, high, 0.25, zr, zi)
+            costs = O.rollout_costs(model, cost, obs, act)
+            idx = O.topk_sorted(costs, min(K, hi - lo))
+            records = torch.zeros((world * K, rs), dtype=torch.float64)
+            mine = records[rank * K:(rank + 1) * K]
+            mine[:, 0] = float("inf")
+            mine[:, 1] = float(np.iinfo(np.int32).max)
+            for r, li in enumerate(idx):
+                mine[r, 0] = costs[li]
+                mine[r, 1] = lo + li
+                mine[r, 2:] = torch.from_numpy(act[li].reshape(-1))
+            exchange_records(records, K, rank, world)          # the ONE collective of the iteration
+            rec = records.numpy()
+            order = np.lexsort((rec[:, 1], rec[:, 0]))[:K]     # (cost, gidx) ascending
+            elites = rec[order, 2:].reshape(K, h, d)
+            mean, std = O.refit(elites, mean, std, 0.1)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), mean=mean, std=std, gidx=rec[order, 1], cost=rec[order, 0])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_exchange_matches_single_process(tmp_path, world):
+    N, K, h, d, o, seed = 257, 10, 12, 4, 17, 5
+    mp.spawn(_worker, args=(world, _free_port(), N, K, h, d, o, seed, str(tmp_path)), nprocs=world, join=True)
+    # single process reference
+    model, cost = O.SyntheticModel.make(o, d), O.CostSpec.halfcheetah(o)
+    obs = 0.1 * np.random.RandomState(0).randn(o)
+    mean, std = np.zeros((h, d)), 0.5 * np.ones((h, d))
+    for it, n_it in enumerate(O.population_sizes(N, K, 1.25, 3)):
+        zr, zi = O.philox_white_noise(seed, it, n_it, d, h)
+        act = O.sample_action_sequences(mean, std, -np.ones(d), np.ones(d), 0.25, zr, zi)
+        costs = O.rollout_costs(model, cost, obs, act)
+        idx = O.topk_sorted(costs, K)
+        mean, std = O.refit(act[idx], mean, std, 0.1)
+    for r in range(world):
+        z = np.load(tmp_path / f"rank{r}.npz")
+        assert np.array_equal(z["gidx"].astype(np.int64), idx)           # bit-exact global elite indices
+        assert np.array_equal(z["cost"], costs[idx])
+        assert np.array_equal(z["mean"], mean) and np.array_equal(z["std"], std)
