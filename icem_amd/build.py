@@ -4,9 +4,10 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "csrc", "icem_kernels.hip")
+SRCS = [os.path.join(HERE, "csrc", "icem_kernels.hip"), os.path.join(HERE, "csrc", "icem_fused.hip")]
 OUT = os.path.join(HERE, "libicem_hip.so")
-DEPS = [SRC, os.path.join(HERE, "csrc", "philox.h"), os.path.join(os.path.dirname(HERE), "include", "icem_hip.h")]
+DEPS = SRCS + [os.path.join(HERE, "csrc", "philox.h"), os.path.join(HERE, "csrc", "icem_fused.h"),
+               os.path.join(os.path.dirname(HERE), "include", "icem_hip.h")]
 
 
 def up_to_date() -> bool:
@@ -17,7 +18,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not force and up_to_date():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", SRC, "-o", OUT]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-parallel-jobs=4", *SRCS, "-o", OUT]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

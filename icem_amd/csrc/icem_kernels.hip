@@ -15,12 +15,15 @@
 #include <climits>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "../../include/icem_hip.h"
 #include "philox.h"
+#include "icem_fused.h"
+#include <type_traits>
 
 namespace icem {
 
@@ -610,6 +613,8 @@ struct icem_handle {
         long long units;
         hipEvent_t a, b;
     };
+    bool use_fused = true;
+    int fused_grid = 0;  // candidate lists written by the last fused launch (0 = unfused path ran)
     std::vector<Span> spans;
     std::vector<hipEvent_t> free_events;
 };
@@ -854,13 +859,6 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
     const uint64_t call_base = (uint64_t)mpc_step * (uint64_t)(c.opt_iters + 1);
     const bool last = it == c.opt_iters - 1;
     T* actions = (T*)b->actions;
-    // main batch of this rank's shard (icem.py:84-89)
-    {
-        SampleArgs<T> a = make_sample_args<T>(h, n_loc, lo, b->mean, b->std, b->low, b->high, b->z_r, b->z_i,
-                                              call_base + (uint64_t)it, 0, (last && c.use_mean_actions) ? 1 : 0, actions);
-        int rc = launch_sample<T>(h, a, st);
-        if (rc) return rc;
-    }
     // shifted elites, simulated at iteration 0 of every MPC step but the first (icem.py:131-137)
     int n_extra = 0;
     if (it == 0 && c.shift_elites && mpc_step > 0 && h->n_reuse > 0) {
@@ -874,10 +872,80 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
         int rc = launch_sample<T>(h, a, st);
         if (rc) return rc;
     }
-    int rc = launch_rollout<T>(h, n_loc + n_extra, b->obs0, actions, b->costs, nullptr, st);
-    if (rc) return rc;
     // candidates: the shard, plus the shifted elites on rank 0 only (they are replicated)
     const int n_cand = n_loc + (c.rank == 0 ? n_extra : 0);
+    const int row0 = (last && c.use_mean_actions) ? 1 : 0;
+    T* rec = (T*)b->records + (size_t)c.rank * K * (hd + 2);
+    h->fused_grid = 0;
+    if constexpr (std::is_same<T, float>::value) {
+        if (b->z_r == nullptr && h->use_fused && fused_supported(h->O, c.act_dim, c.horizon, K)) {
+            // f32 throughput path: sample -> LDS tile -> HBM, rollout + cost from LDS, per-workgroup top-K
+            FusedArgs a;
+            a.n = n_loc;
+            a.n_extra = n_extra;
+            a.n_cand = n_cand;
+            a.h = c.horizon;
+            a.d = c.act_dim;
+            a.F = h->F;
+            a.o = h->obs_dim;
+            a.tpw = fused_tile_traj(c.act_dim, K);
+            a.tile_stride = fused_tile_stride(c.horizon, c.act_dim);
+            a.K = K;
+            a.cost_mode = c.cost_mode;
+            a.row0_mean = row0;
+            a.first_index = lo;
+            a.W = (const float*)h->W_dev;
+            a.mean = (const float*)b->mean;
+            a.std = (const float*)b->std;
+            a.low = (const float*)b->low;
+            a.high = (const float*)b->high;
+            const uint64_t off = call_base + (uint64_t)it;
+            a.seed_lo = (uint32_t)c.seed;
+            a.seed_hi = (uint32_t)(c.seed >> 32);
+            a.off_lo = (uint32_t)off;
+            a.off_hi = (uint32_t)(off >> 32);
+            a.A = (const float*)h->A_dev;
+            a.B = (const float*)h->B_dev;
+            a.obs0 = (const float*)b->obs0;
+            a.ctrl_w = (float)h->cost.ctrl_weight;
+            a.lin_w = (float)h->cost.lin_weight;
+            a.flip_pen = (float)h->cost.flip_penalty;
+            a.flip_th = (float)h->cost.flip_thresh;
+            a.lin_idx = h->cost.lin_idx;
+            a.flip_idx = h->cost.flip_idx;
+            a.actions = (float*)actions;
+            a.costs = (float*)b->costs;
+            const int tiles = (n_loc + a.tpw - 1) / a.tpw + (n_extra + a.tpw - 1) / a.tpw;
+            const int grid = std::max(1, std::min(tiles, FUSED_MAX_GRID - ICEM_MAX_ELITES));
+            float* pc;
+            int* pi;
+            split_partial_ws<float>(b->workspace, grid, K, &pc, &pi);
+            a.part_c = pc;
+            a.part_i = pi;
+            {
+                ProfScope prof(h, ICEM_K_FUSED, (long long)(n_loc + n_extra) * c.horizon, st);
+                if (launch_fused_iter(a, h->O, h->model_kind, c.rng_rounds, grid, st) != 0)
+                    return fail(ICEM_E_UNSUPPORTED, "fused kernel shape not compiled");
+            }
+            h->fused_grid = grid;
+            if (c.world > 1) {
+                ProfScope prof(h, ICEM_K_LOCAL_PACK, grid * K, st);
+                hipLaunchKernelGGL((local_pack_kernel<float>), dim3(1), dim3(WG), 0, st, grid * K, K, hd, n_loc, lo,
+                                   n_global, (const float*)pc, (const int*)pi, (const float*)actions, (float*)rec);
+            }
+            ICEM_HIP_TRY(hipGetLastError());
+            return ICEM_OK;
+        }
+    }
+    // generic path (f64, external noise, shapes outside the fused list): one kernel per stage
+    {
+        SampleArgs<T> a = make_sample_args<T>(h, n_loc, lo, b->mean, b->std, b->low, b->high, b->z_r, b->z_i,
+                                              call_base + (uint64_t)it, 0, row0, actions);
+        int rc = launch_sample<T>(h, a, st);
+        if (rc) return rc;
+    }
+    int rc = launch_rollout<T>(h, n_loc + n_extra, b->obs0, actions, b->costs, nullptr, st);
+    if (rc) return rc;
     const int nblk = std::max(1, topk_blocks(n_cand));
     T* pc;
     int* pi;
@@ -886,7 +954,6 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
         ProfScope prof(h, ICEM_K_TOPK_PARTIAL, n_cand, st);
         hipLaunchKernelGGL((topk_partial_kernel<T>), dim3(nblk), dim3(WG), 0, st, n_cand, K, (const T*)b->costs, pc, pi);
     }
-    T* rec = (T*)b->records + (size_t)c.rank * K * (hd + 2);
     {
         ProfScope prof(h, ICEM_K_LOCAL_PACK, nblk * K, st);
         hipLaunchKernelGGL((local_pack_kernel<T>), dim3(1), dim3(WG), 0, st, nblk * K, K, hd, n_loc, lo, n_global,
@@ -904,6 +971,42 @@ int plan_iter_merge_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
     const int cur = (int)(g & 1), nxt = cur ^ 1;
     T* el = (T*)b->elites;
     T* elc = el + (size_t)2 * K * hd;
+    if constexpr (std::is_same<T, float>::value) {
+        if (c.world == 1 && h->fused_grid > 0) {
+            MergeSingleArgs m;
+            m.n_lists = h->fused_grid;
+            m.n_keep = (it > 0 && c.keep_previous_elites) ? h->n_reuse : 0;
+            const int n_extra = (it == 0 && c.shift_elites && mpc_step > 0) ? h->n_reuse : 0;
+            m.n_pool = h->pop[it] + n_extra;
+            m.n_global = h->pop[it];
+            m.K = K;
+            m.h = c.horizon;
+            m.d = c.act_dim;
+            m.last = it == c.opt_iters - 1;
+            m.alpha = (float)c.alpha;
+            m.init_std = (float)c.init_std;
+            float* pc;
+            int* pi;
+            split_partial_ws<float>(b->workspace, h->fused_grid, K, &pc, &pi);
+            m.part_c = pc;
+            m.part_i = pi;
+            m.actions = (const float*)b->actions;
+            m.elites_cur = (const float*)el + (size_t)cur * K * hd;
+            m.elites_cost_cur = (const float*)elc + (size_t)cur * K;
+            m.elites_next = (float*)el + (size_t)nxt * K * hd;
+            m.elites_cost_next = (float*)elc + (size_t)nxt * K;
+            m.mean = (float*)b->mean;
+            m.std = (float*)b->std;
+            m.low = (const float*)b->low;
+            m.high = (const float*)b->high;
+            m.executed = (float*)b->executed;
+            m.best_cost = (float*)b->best_cost;
+            ProfScope prof(h, ICEM_K_MERGE_REFIT, h->fused_grid * K + m.n_keep, st);
+            launch_merge_single(m, st);
+            ICEM_HIP_TRY(hipGetLastError());
+            return ICEM_OK;
+        }
+    }
     MergeArgs<T> a;
     a.n_rec = c.world * K;
     a.n_keep = (it > 0 && c.keep_previous_elites) ? h->n_reuse : 0;
@@ -988,6 +1091,7 @@ int icem_create(const icem_config* cfg, icem_handle** out) {
     h->pop = population_sizes(c);
     h->n_reuse = (int)((double)c.num_elites * c.fraction_reused);  // int(len(elites)*xi), icem.py:98,145
     h->n_local_max = shard_chunk(c.num_traj, c.world);
+    if (const char* e = getenv("ICEM_DISABLE_FUSED")) h->use_fused = !(e[0] == '1');
     // synthesis table W[t][m]: m < F real part of bin m, F <= m < h imaginary part of bin m-F+1
     std::vector<double> cr, ci, W((size_t)c.horizon * h->HMAX, 0.0);
     noise_tables(c.horizon, c.noise_beta, cr, ci);
@@ -1230,7 +1334,7 @@ size_t icem_plan_buffer_bytes(const icem_handle* h, int32_t which) {
         case ICEM_BUF_RECORDS:
             return (size_t)h->cfg.world * K * (hd + 2) * ts;
         case ICEM_BUF_WORKSPACE:
-            return (size_t)topk_blocks((int)rows) * K * (ts + sizeof(int));
+            return (size_t)std::max(topk_blocks((int)rows), FUSED_MAX_GRID) * K * (ts + sizeof(int));
         case ICEM_BUF_BEST_COST:
             return ts;
         default:
