@@ -76,6 +76,7 @@ SYMBOLS = [
     ("icem_plan_step", C.c_int, [_H, C.POINTER(IcemPlanBuffersC), _I32, _VP]),
     ("icem_record_bytes", _SZ, [_H]),
     ("icem_profile_enable", C.c_int, [_H, _I32]),
+    ("icem_debug_stamps", C.c_int, [_H, _VP]),
     ("icem_profile_read", C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 ]
 

@@ -40,13 +40,14 @@ struct FusedArgs {
     float* costs;    // [n + n_extra]
     float* part_c;   // [grid, K] sorted candidates of each workgroup
     int* part_i;
+    long long* dbg;  // optional [grid, 8] phase cycle stamps (nullptr in production)
 };
 
 // Returns 0 when a kernel for (O, d, model kind, rounds) exists and was launched, 1 when the
 // combination is not compiled (caller falls back to the unfused kernels).
 int launch_fused_iter(const FusedArgs& a, int O, int kind, int rounds, int grid, hipStream_t st);
 bool fused_supported(int O, int d, int h, int K);
-int fused_tile_traj(int d, int K);
+int fused_tile_traj(int h, int d);
 int fused_tile_stride(int h, int d);
 
 // world == 1: global sorted top-K straight from the workgroups' candidate lists (+ kept elites),

@@ -33,13 +33,14 @@ namespace {
 constexpr int HMAX = 32;
 
 __host__ __device__ constexpr int cmin(int a, int b) { return a < b ? a : b; }
-__host__ __device__ constexpr int tile_traj(int d) { return cmin(FUSED_WG / d, 48); }
 __host__ __device__ constexpr int tile_stride(int h, int d) {
     int s = h * d;
     s += s & 1;
     if (s % 32 == 0) s += 2;
     return s;
 }
+// trajectories per tile: one rollout lane each (<= 64), tile kept under 48 KiB of LDS
+__host__ __device__ constexpr int tile_traj(int h, int d) { return cmin(64, (12288 / tile_stride(h, d)) & ~3); }
 
 // ---- packed (cost, index) keys: unsigned order == (cost, index) lexicographic order ------------
 __device__ __forceinline__ unsigned long long make_key(float c, int idx) {
@@ -73,77 +74,46 @@ __device__ __forceinline__ unsigned long long wave_sort64(unsigned long long k, 
     return k;
 }
 
-// ---- DPP exchange inside a group of L consecutive lanes ----------------------------------------
-template <int L, int Q>
-__device__ __forceinline__ float group_bcast(float x) {
-    if constexpr (L == 1) {
-        return x;
-    } else {
-        constexpr int ctrl = (L == 4) ? (Q | (Q << 2) | (Q << 4) | (Q << 6)) : (Q | (Q << 2) | ((2 + Q) << 4) | ((2 + Q) << 6));
-        return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), ctrl, 0xF, 0xF, true));
-    }
-}
-template <int L>
-__device__ __forceinline__ float group_sum(float x) {
-    if constexpr (L >= 2) {
-        x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
-    }
-    if constexpr (L >= 4) {
-        x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
-    }
-    return x;
-}
-
-template <int N, typename Fn>
-__device__ __forceinline__ void static_for(Fn&& fn) {
-    if constexpr (N > 0) {
-        static_for<N - 1>(fn);
-        fn(std::integral_constant<int, N - 1>{});
-    }
-}
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float act_fn(float x, std::integral_constant<int, 0>) { return x; }
 __device__ __forceinline__ float act_fn(float x, std::integral_constant<int, 1>) { return tanhf(x); }
 
 // -------------------------------------------------------------------------------------------------
-template <int H, int D, int O, int L, int KIND, int ROUNDS>
+template <int H, int D, int O, int KIND, int ROUNDS>
 __global__ __launch_bounds__(FUSED_WG) void fused_iter_kernel(FusedArgs a) {
     constexpr int F = H / 2 + 1;
     constexpr int HD = H * D;
-    constexpr int TPW = tile_traj(D);
+    constexpr int TPW = tile_traj(H, D);
     constexpr int S = tile_stride(H, D);
-    constexpr int OPL = (O + L - 1) / L;  // model output columns per lane
+    constexpr int CT = (O + 3) / 4;  // model output column tiles of 4
+    constexpr int KK = O + D;        // contraction length of one model step: [o | a] . [A ; B]
     static_assert(H <= 31 && H >= 2, "folded DFT keeps real/imag halves in 16 + 16 registers");
-    static_assert(TPW * L <= FUSED_WG, "rollout lanes must fit the workgroup");
+    static_assert(TPW <= 64 && TPW % 4 == 0, "one rollout lane per trajectory, MFMA blocks of 4");
 
-    __shared__ float tile[TPW * S];
-    __shared__ float cost_lds[TPW];
+    __shared__ __attribute__((aligned(16))) float tile[TPW * S];
+    __shared__ float ms_lds[2 * HD];  // mean | std, staged once: the S-phase reads them per sample
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int tiles_s = (a.n + TPW - 1) / TPW;
     const int tiles_x = (a.n_extra + TPW - 1) / TPW;
+    const bool r_wave = tid < 64;  // wave 0 rolls the tile out on the matrix pipe
 
-    // --- per-lane model columns, resident in VGPRs for the whole kernel -------------------------
-    const bool r_lane = tid < TPW * L;
-    const int r_nl = tid / L;
-    const int q = tid - r_nl * L;
-    float Ac[O][OPL], Bc[D][OPL], wlin[OPL], wflip[OPL], obs_init[OPL];
-#pragma unroll
-    for (int i = 0; i < OPL; ++i) {
-        const int col = q * OPL + i;
-        const bool ok = col < O;
-#pragma unroll
-        for (int k = 0; k < O; ++k) Ac[k][i] = ok ? a.A[k * O + col] : 0.f;
-#pragma unroll
-        for (int j = 0; j < D; ++j) Bc[j][i] = ok ? a.B[j * O + col] : 0.f;
-        wlin[i] = (col == a.lin_idx) ? a.lin_w : 0.f;
-        wflip[i] = (col == a.flip_idx) ? 1.f : 0.f;
-        obs_init[i] = col < a.o ? a.obs0[col] : 0.f;
+    // --- model operand of the MFMA, resident in VGPRs: lane holds M[k][4*ct + (lane & 3)] ---------
+    // D^T = M^T . X^T with v_mfma_f32_4x4x1 (16 blocks of 4 trajectories): A-operand = 4 output
+    // columns of the model (row i = lane & 3), B-operand = the lane's own trajectory value x_k,
+    // result register i of tile ct = column 4*ct + i of THIS lane's trajectory: no transposes, the
+    // accumulation is the same k-ordered fmaf chain as the scalar kernels.
+    for (int e = tid; e < HD; e += FUSED_WG) {
+        ms_lds[e] = a.mean[e];
+        ms_lds[HD + e] = a.std[e];
     }
-    const bool owns_flip = a.flip_idx >= 0 && (a.flip_idx / OPL) == q;
+    __syncthreads();
 
     unsigned long long run_key = KEY_SENTINEL;  // wave 0: lane r < K holds the r-th best so far
+    long long stamp[6] = {0, 0, 0, 0, 0, 0};
+    if (a.dbg) stamp[0] = __builtin_readcyclecounter();
 
     for (int tile_id = blockIdx.x; tile_id < tiles_s + tiles_x; tile_id += gridDim.x) {
         const bool sampled = tile_id < tiles_s;
@@ -153,9 +123,9 @@ __global__ __launch_bounds__(FUSED_WG) void fused_iter_kernel(FusedArgs a) {
 
         if (sampled) {
             // ---------------- phase S ----------------
-            if (tid < n_here * D) {
-                const int nl = tid / D;
-                const int j = tid - nl * D;
+            for (int row = tid; row < n_here * D; row += FUSED_WG) {
+                const int nl = row / D;
+                const int j = row - nl * D;
                 const unsigned gi = (unsigned)(a.first_index + n_base + nl);
                 float g[HMAX];
 #pragma unroll
@@ -168,7 +138,7 @@ __global__ __launch_bounds__(FUSED_WG) void fused_iter_kernel(FusedArgs a) {
                 const float lo = a.low[j], hi = a.high[j];
                 float* trow = tile + nl * S + j;
                 auto emit = [&](int t, float y) {
-                    float v = __builtin_fmaf(y, a.std[t * D + j], a.mean[t * D + j]);
+                    float v = __builtin_fmaf(y, ms_lds[HD + t * D + j], ms_lds[t * D + j]);
                     v = v < lo ? lo : v;
                     v = v > hi ? hi : v;
                     trow[t * D] = v;
@@ -183,6 +153,7 @@ __global__ __launch_bounds__(FUSED_WG) void fused_iter_kernel(FusedArgs a) {
                     }
                     emit(0, e0 + e1);
                 }
+#pragma unroll 1
                 for (int tp = 1; tp <= H / 2; ++tp) {
                     const float* __restrict__ w = a.W + tp * HMAX;
                     float e0 = 0.f, e1 = 0.f, o0 = 0.f, o1 = 0.f;
@@ -202,8 +173,9 @@ __global__ __launch_bounds__(FUSED_WG) void fused_iter_kernel(FusedArgs a) {
                 }
             }
             __syncthreads();
+            if (a.dbg && tile_id == blockIdx.x) stamp[1] = __builtin_readcyclecounter();
             if (a.row0_mean && a.first_index == 0 && tile_id == 0) {  // icem.py:87-88
-                for (int e = tid; e < HD; e += FUSED_WG) tile[e] = a.mean[e];
+                for (int e = tid; e < HD; e += FUSED_WG) tile[e] = ms_lds[e];
                 __syncthreads();
             }
             // ---------------- phase W ----------------
@@ -219,82 +191,95 @@ __global__ __launch_bounds__(FUSED_WG) void fused_iter_kernel(FusedArgs a) {
             __syncthreads();
         }
 
-        // ---------------- phase R ----------------
-        if (r_lane && r_nl < n_here) {
-            float obs[OPL];
+        // ---------------- phase R + K (wave 0) ----------------
+        if (a.dbg && tile_id == blockIdx.x) stamp[2] = __builtin_readcyclecounter();
+        if (r_wave) {
+            // (re)load the model operand here so it is not live across the sampling phase
+            float mA[KK][CT];
 #pragma unroll
-            for (int i = 0; i < OPL; ++i) obs[i] = obs_init[i];
-            const float* arow = tile + r_nl * S;
-            float acc = 0.f;
+            for (int ct = 0; ct < CT; ++ct) {
+                const int col = ct * 4 + (lane & 3);
+                const bool ok = col < O;
+#pragma unroll
+                for (int k = 0; k < O; ++k) mA[k][ct] = ok ? a.A[k * O + col] : 0.f;
+#pragma unroll
+                for (int j = 0; j < D; ++j) mA[O + j][ct] = ok ? a.B[j * O + col] : 0.f;
+            }
+            const bool live = lane < n_here;
+            float obs[O];
+#pragma unroll
+            for (int k = 0; k < O; ++k) obs[k] = k < a.o ? a.obs0[k] : 0.f;
+            const float* arow = tile + (live ? lane : 0) * S;
+            float acc_cost = 0.f;
+#pragma unroll 1
             for (int t = 0; t < H; ++t) {
                 float act[D];
 #pragma unroll
                 for (int j = 0; j < D; ++j) act[j] = arow[t * D + j];
-                float nxt[OPL];
+                f32x4 acc[CT];
 #pragma unroll
-                for (int i = 0; i < OPL; ++i) nxt[i] = 0.f;
-                // o . A : the owner lane of obs[k] broadcasts it inside the lane group
-                static_for<L>([&](auto QQ) {
+                for (int ct = 0; ct < CT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int kp = 0; kp < OPL; ++kp) {
-                        constexpr int QV = decltype(QQ)::value;
-                        const int k = QV * OPL + kp;
-                        if (k < O) {
-                            const float x = group_bcast<L, QV>(obs[kp]);
+                for (int k = 0; k < O; ++k) {
 #pragma unroll
-                            for (int i = 0; i < OPL; ++i) nxt[i] = __builtin_fmaf(x, Ac[k][i], nxt[i]);
-                        }
-                    }
-                });
-                float ctrl = 0.f;
+                    for (int ct = 0; ct < CT; ++ct)
+                        acc[ct] = __builtin_amdgcn_mfma_f32_4x4x1f32(mA[k][ct], obs[k], acc[ct], 0, 0, 0);
+                }
 #pragma unroll
                 for (int j = 0; j < D; ++j) {
-                    ctrl = __builtin_fmaf(act[j], act[j], ctrl);
 #pragma unroll
-                    for (int i = 0; i < OPL; ++i) nxt[i] = __builtin_fmaf(act[j], Bc[j][i], nxt[i]);
+                    for (int ct = 0; ct < CT; ++ct)
+                        acc[ct] = __builtin_amdgcn_mfma_f32_4x4x1f32(mA[O + j][ct], act[j], acc[ct], 0, 0, 0);
                 }
-                // cost of (o_t, a_t): each lane scores the observation entries it owns
+                // cost of (o_t, a_t) on the VALU while the matrix pipe works
+                float ctrl = 0.f;
+#pragma unroll
+                for (int j = 0; j < D; ++j) ctrl = __builtin_fmaf(act[j], act[j], ctrl);
                 float lin = 0.f, ang = 0.f;
 #pragma unroll
-                for (int i = 0; i < OPL; ++i) {
-                    lin = __builtin_fmaf(wlin[i], obs[i], lin);
-                    ang = __builtin_fmaf(wflip[i], obs[i], ang);
+                for (int k = 0; k < O; ++k) {
+                    lin = (k == a.lin_idx) ? obs[k] : lin;
+                    ang = (k == a.flip_idx) ? obs[k] : ang;
                 }
-                float part = lin;
-                if (owns_flip) {
-                    part += (ang > a.flip_th) ? a.flip_pen : 0.f;
-                    part += (ang < -a.flip_th) ? a.flip_pen : 0.f;
+                float c = 0.f;
+                if (a.flip_idx >= 0) {
+                    c += (ang > a.flip_th) ? a.flip_pen : 0.f;
+                    c += (ang < -a.flip_th) ? a.flip_pen : 0.f;
                 }
-                if (q == 0) part = __builtin_fmaf(a.ctrl_w, ctrl, part);
-                const float c = group_sum<L>(part);
+                c += a.ctrl_w * ctrl;
+                c += a.lin_w * lin;
                 if (t == 0 || a.cost_mode == 2)
-                    acc = c;
+                    acc_cost = c;
                 else if (a.cost_mode == 0)
-                    acc += c;
+                    acc_cost += c;
                 else
-                    acc = c < acc ? c : acc;
+                    acc_cost = c < acc_cost ? c : acc_cost;
 #pragma unroll
-                for (int i = 0; i < OPL; ++i) obs[i] = act_fn(nxt[i], std::integral_constant<int, KIND>{});
+                for (int k = 0; k < O; ++k) obs[k] = act_fn(acc[k / 4][k % 4], std::integral_constant<int, KIND>{});
             }
-            if (q == 0) {
-                cost_lds[r_nl] = acc;
-                a.costs[n_base + r_nl] = acc;
-            }
-        }
-        __syncthreads();
-
-        // ---------------- phase K ----------------
-        if (tid < 64) {
+            if (live) a.costs[n_base + lane] = acc_cost;
+            if (a.dbg && tile_id == blockIdx.x) stamp[3] = __builtin_readcyclecounter();
+            // phase K: this tile's 64 keys, then a bitonic merge with the running top-K
             unsigned long long key = KEY_SENTINEL;
-            if (lane < a.K) {
-                key = run_key;
-            } else {
-                const int nl = lane - a.K;
-                if (nl < n_here && n_base + nl < a.n_cand) key = make_key(cost_lds[nl], n_base + nl);
+            if (live && n_base + lane < a.n_cand) key = make_key(acc_cost, n_base + lane);
+            key = wave_sort64(key, lane);
+            if (tile_id != (int)blockIdx.x) {  // not the first pass of this workgroup
+                const unsigned long long top = __shfl(key, lane - a.K, 64);
+                unsigned long long k2 = KEY_SENTINEL;
+                if (lane < a.K)
+                    k2 = run_key;
+                else if (lane < 2 * a.K)
+                    k2 = top;
+                key = wave_sort64(k2, lane);
             }
-            run_key = wave_sort64(key, lane);
+            run_key = key;
         }
-        __syncthreads();  // tile and cost_lds are rewritten by the next pass
+        __syncthreads();  // the tile is rewritten by the next pass
+        if (a.dbg && tile_id == blockIdx.x) stamp[4] = __builtin_readcyclecounter();
+    }
+    if (a.dbg && tid == 0) {
+        stamp[5] = __builtin_readcyclecounter();
+        for (int i = 0; i < 6; ++i) a.dbg[(size_t)blockIdx.x * 8 + i] = stamp[i];
     }
     if (tid < a.K) {
         a.part_c[(size_t)blockIdx.x * a.K + tid] = key_cost(run_key);
@@ -398,18 +383,18 @@ __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs 
     }
 }
 
-template <int H, int D, int O, int L>
+template <int H, int D, int O>
 int launch_hdo(const FusedArgs& a, int kind, int rounds, int grid, hipStream_t st) {
     if (kind == 1) {
         if (rounds == 7)
-            hipLaunchKernelGGL((fused_iter_kernel<H, D, O, L, 1, 7>), dim3(grid), dim3(FUSED_WG), 0, st, a);
+            hipLaunchKernelGGL((fused_iter_kernel<H, D, O, 1, 7>), dim3(grid), dim3(FUSED_WG), 0, st, a);
         else
-            hipLaunchKernelGGL((fused_iter_kernel<H, D, O, L, 1, 10>), dim3(grid), dim3(FUSED_WG), 0, st, a);
+            hipLaunchKernelGGL((fused_iter_kernel<H, D, O, 1, 10>), dim3(grid), dim3(FUSED_WG), 0, st, a);
     } else {
         if (rounds == 7)
-            hipLaunchKernelGGL((fused_iter_kernel<H, D, O, L, 0, 7>), dim3(grid), dim3(FUSED_WG), 0, st, a);
+            hipLaunchKernelGGL((fused_iter_kernel<H, D, O, 0, 7>), dim3(grid), dim3(FUSED_WG), 0, st, a);
         else
-            hipLaunchKernelGGL((fused_iter_kernel<H, D, O, L, 0, 10>), dim3(grid), dim3(FUSED_WG), 0, st, a);
+            hipLaunchKernelGGL((fused_iter_kernel<H, D, O, 0, 10>), dim3(grid), dim3(FUSED_WG), 0, st, a);
     }
     return 0;
 }
@@ -421,7 +406,7 @@ int launch_hdo(const FusedArgs& a, int kind, int rounds, int grid, hipStream_t s
 #define ICEM_FUSED_SHAPES(X) X(30, 6, 17) X(30, 6, 18) X(12, 6, 17) X(13, 4, 17) X(10, 3, 17) X(30, 17, 24)
 
 bool fused_supported(int O, int d, int h, int K) {
-    if (K > 16) return false;
+    if (K > 32) return false;
 #define X(HH, DD, OO) \
     if (h == HH && d == DD && O == OO) return true;
     ICEM_FUSED_SHAPES(X)
@@ -429,15 +414,12 @@ bool fused_supported(int O, int d, int h, int K) {
     return false;
 }
 
-int fused_tile_traj(int d, int K) {
-    (void)K;
-    return tile_traj(d);
-}
+int fused_tile_traj(int h, int d) { return tile_traj(h, d); }
 int fused_tile_stride(int h, int d) { return tile_stride(h, d); }
 
 int launch_fused_iter(const FusedArgs& a, int O, int kind, int rounds, int grid, hipStream_t st) {
 #define X(HH, DD, OO) \
-    if (a.h == HH && a.d == DD && O == OO) return launch_hdo<HH, DD, OO, 4>(a, kind, rounds, grid, st);
+    if (a.h == HH && a.d == DD && O == OO) return launch_hdo<HH, DD, OO>(a, kind, rounds, grid, st);
     ICEM_FUSED_SHAPES(X)
 #undef X
     return 1;

@@ -614,6 +614,7 @@ struct icem_handle {
         hipEvent_t a, b;
     };
     bool use_fused = true;
+    long long* dbg = nullptr;
     int fused_grid = 0;  // candidate lists written by the last fused launch (0 = unfused path ran)
     std::vector<Span> spans;
     std::vector<hipEvent_t> free_events;
@@ -888,7 +889,7 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
             a.d = c.act_dim;
             a.F = h->F;
             a.o = h->obs_dim;
-            a.tpw = fused_tile_traj(c.act_dim, K);
+            a.tpw = fused_tile_traj(c.horizon, c.act_dim);
             a.tile_stride = fused_tile_stride(c.horizon, c.act_dim);
             a.K = K;
             a.cost_mode = c.cost_mode;
@@ -922,6 +923,7 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
             split_partial_ws<float>(b->workspace, grid, K, &pc, &pi);
             a.part_c = pc;
             a.part_i = pi;
+            a.dbg = h->dbg;
             {
                 ProfScope prof(h, ICEM_K_FUSED, (long long)(n_loc + n_extra) * c.horizon, st);
                 if (launch_fused_iter(a, h->O, h->model_kind, c.rng_rounds, grid, st) != 0)
@@ -1278,6 +1280,12 @@ int icem_reset_distribution(icem_handle* h, void* mean, void* std, const void* l
         hipLaunchKernelGGL((reset_kernel<float>), dim3(grid), dim3(WG), 0, st, h->cfg.horizon, h->cfg.act_dim,
                            (float)h->cfg.init_std, (float*)mean, (float*)std, (const float*)low, (const float*)high);
     ICEM_HIP_TRY(hipGetLastError());
+    return ICEM_OK;
+}
+
+int icem_debug_stamps(icem_handle* h, void* dev_ptr) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    h->dbg = (long long*)dev_ptr;
     return ICEM_OK;
 }
 

@@ -225,6 +225,9 @@ enum {
  * summed duration [ms], the number of launches and the units processed (traj-steps for
  * SAMPLE/ROLLOUT/FUSED, keys for the top-k kernels), and clears the log. */
 int icem_profile_enable(icem_handle* h, int32_t on);
+/* Development aid: [grid, 8] int64 device buffer receiving per-workgroup phase cycle stamps of the
+ * fused kernel (NULL disables). */
+int icem_debug_stamps(icem_handle* h, void* dev_ptr);
 int icem_profile_read(icem_handle* h, double* total_ms, int64_t* launches, int64_t* units);
 
 /* Byte size / layout of one candidate record: {cost (T), gidx (int32, padded to sizeof(T)),
