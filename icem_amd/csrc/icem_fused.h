@@ -1,60 +1,55 @@
-// icem_fused.h -- interface between the C-ABI translation unit and the fused f32 kernels
-// (icem_fused.hip).  Internal; not part of the public ABI.
+// icem_fused.h -- interface between the C-ABI translation unit (icem_kernels.hip) and the f32
+// throughput kernels (icem_fused.hip).  Internal; not part of the public ABI.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace icem {
 
-constexpr int FUSED_WG = 256;      // threads per workgroup (4 wavefronts)
-constexpr int FUSED_MAX_GRID = 1024;  // one sorted candidate list per workgroup; merged by 1024 threads
+constexpr int FAST_MAX_LISTS = 256;  // candidate lists (one per rollout workgroup of 4 waves) the merge accepts
 
-// One CEM iteration's data-parallel part for this rank's shard (f32):
-//   tile of TPW trajectories per workgroup pass:  sample (Philox -> Box-Muller -> folded inverse
-//   real DFT -> affine -> clip) into an LDS tile  ->  tile to HBM as coalesced stores  ->  rollout
-//   + cost with L lanes per trajectory straight out of LDS  ->  wave-level bitonic merge into the
-//   workgroup's running sorted top-K.  Workgroups stride over tiles and emit K candidates each.
-struct FusedArgs {
-    int n;        // sampled trajectories of this rank (rows [0, n) of actions)
-    int n_extra;  // pre-filled rows [n, n + n_extra) (shifted elites): rolled out, not sampled
-    int n_cand;   // rows [0, n_cand) are top-k candidates (n, or n + n_extra on rank 0)
-    int h, d, F, o;
-    int tpw;          // trajectories per tile
-    int tile_stride;  // floats per trajectory in the LDS tile (h*d padded)
-    int K;
-    int cost_mode;
-    int row0_mean;
+// K1 fast: colored-noise sampling with the inverse real DFT folded on its symmetry (f32, Philox).
+struct FastSampleArgs {
+    int n, h, d;
     long long first_index;
-    const float* W;  // [h, HMAX]
+    const float* W;  // [h, 32]
     const float* mean;
     const float* std;
     const float* low;
     const float* high;
     uint32_t seed_lo, seed_hi, off_lo, off_hi;
-    const float* A;  // [O, O] padded
-    const float* B;  // [d, O] padded
+    int row0_mean;
+    float* out;  // [n, h, d]
+};
+bool fast_sample_supported(int h, int d);
+void launch_sample_folded(const FastSampleArgs& a, int rounds, hipStream_t st);
+
+// K2+K3 fast: rollout on the matrix pipe (v_mfma_f32_4x4x1, exact f32), cost on the VALU, and a
+// per-wave bitonic top-K; one wavefront per 64 trajectories.
+struct FastRolloutArgs {
+    int n_rows;   // trajectories to roll out (rows of `actions`)
+    int n_cand;   // rows [0, n_cand) enter the top-K
+    int K;        // 0 = no candidate output
+    int o;        // true observation width (<= O)
+    int cost_mode;
+    const float* Mp;    // [O + D, 4*ceil(O/4)] permuted, zero padded model [A ; B]
+    const int* perm;    // [O] permuted column k holds observation entry perm[k]
     const float* obs0;
     float ctrl_w, lin_w, flip_pen, flip_th;
-    int lin_idx, flip_idx;
-    float* actions;  // [n + n_extra, h, d]
-    float* costs;    // [n + n_extra]
-    float* part_c;   // [grid, K] sorted candidates of each workgroup
+    int flip_col;       // column holding obs[flip_idx] after the permutation, -1 = no flip term
+    const float* actions;
+    float* costs;
+    float* part_c;  // [grid, K]
     int* part_i;
-    long long* dbg;  // optional [grid, 8] phase cycle stamps (nullptr in production)
 };
+bool fast_rollout_supported(int h, int d, int O, int K);
+void launch_rollout_mfma(const FastRolloutArgs& a, int h, int d, int O, int kind, int grid, hipStream_t st);
 
-// Returns 0 when a kernel for (O, d, model kind, rounds) exists and was launched, 1 when the
-// combination is not compiled (caller falls back to the unfused kernels).
-int launch_fused_iter(const FusedArgs& a, int O, int kind, int rounds, int grid, hipStream_t st);
-bool fused_supported(int O, int d, int h, int K);
-int fused_tile_traj(int h, int d);
-int fused_tile_stride(int h, int d);
-
-// world == 1: global sorted top-K straight from the workgroups' candidate lists (+ kept elites),
-// gather of the elite rows from the pool, refit, and the last-iteration epilogue.
+// world == 1: global sorted top-K straight from the waves' candidate lists (+ kept elites), gather of
+// the elite rows from the pool, refit, and the last-iteration epilogue.
 struct MergeSingleArgs {
-    int n_lists;   // candidate lists (one per fused workgroup), each K long and sorted
-    int n_keep;    // kept elites appended as candidates (icem.py:143-145), gidx = n_pool + e
+    int n_lists;   // candidate lists, each K long and sorted
+    int n_keep;    // kept elites appended as candidates (icem.py:143-145), gidx = n_global + e
     int n_pool;    // sampled + shifted rows in `actions` this iteration (local == global, world 1)
     int n_global;  // N_it: index offset of shifted (it == 0) or kept (it > 0) elites
     int K, h, d, last;
@@ -72,6 +67,7 @@ struct MergeSingleArgs {
     const float* high;
     float* executed;
     float* best_cost;
+    int dbg_stop;  // development: 1 = return after loading lists, 2 = after the rounds
 };
 void launch_merge_single(const MergeSingleArgs& a, hipStream_t st);
 

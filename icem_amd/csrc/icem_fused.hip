@@ -1,20 +1,19 @@
-// icem_fused.hip -- the fused f32 CEM-iteration kernels for gfx950 (see icem_fused.h).
+// icem_fused.hip -- the f32 throughput kernels for gfx950 (see icem_fused.h).
 //
-// fused_iter_kernel<H, D, O, L, KIND, ROUNDS>
-//   Workgroup = 256 threads = 4 wavefronts, one tile of TPW trajectories per pass.
-//   phase S  one thread per (trajectory, action-dim) row: Philox4x32 -> Box-Muller -> the h white
-//            draws of the row in registers; inverse real DFT folded on its cos/sin symmetry
-//            (t and h-t share the even sum and negate the odd one: ~h*h/2 FMAs instead of h*h),
-//            table rows as wave-uniform scalar operands; affine + clip; samples parked in an LDS
-//            tile laid out like the [n, h, d] output.
-//   phase W  the tile goes to HBM as one contiguous, coalesced span (the reference's
-//            `action_sequences`, icem/controllers/icem.py:73-79).
-//   phase R  rollout + cost with L lanes per trajectory: each lane owns ceil(O/L) output columns
-//            of the model, held in VGPRs for the whole kernel (no model traffic in the time
-//            loop); the observation is exchanged inside the lane group with DPP quad permutes;
-//            actions are read back from the LDS tile (never from HBM).
-//   phase K  wave 0 bitonic-sorts {running top-K, this tile's (cost, index) keys} as 64 packed
-//            u64 keys; after the last tile the workgroup emits its K sorted candidates.
+// sample_folded_kernel<H, ROUNDS>   (K1)
+//   one thread per (trajectory, action-dim) row: Philox4x32 -> Box-Muller -> the h white draws of
+//   the row in registers; inverse real DFT folded on its cos/sin symmetry (t and h-t share the even
+//   sum and negate the odd one: ~h*h/2 FMAs instead of h*h) with the table rows as wave-uniform
+//   scalar operands; affine (mean/std staged in LDS) + clip; samples parked in an LDS tile laid out
+//   like the [n, h, d] output so the slab leaves as coalesced stores.
+// rollout_mfma_kernel<H, D, O, KIND> (K2 + K3)
+//   one wavefront per 64 trajectories, lane = trajectory.  The model step [o | a] . [A ; B] runs on
+//   the matrix pipe as v_mfma_f32_4x4x1 (16 blocks of 4 trajectories, exact f32, the same k-ordered
+//   fmaf chain as scalar code): A-operand = 4 model output columns (resident in VGPRs), B-operand =
+//   the lane's own x_k, result register i of column tile ct = output 4*ct + i of THIS lane's
+//   trajectory -- no transposes, no LDS.  The cost runs on the VALU under the MFMAs; actions stream
+//   from HBM/L2 as 16-byte loads one group of steps ahead.  The wave then bitonic-sorts its 64
+//   (cost, index) keys and keeps a running sorted top-K: K candidates per wave.
 // merge_single_kernel: 1024 threads, one per candidate list; K tournament rounds over the list
 //   heads give the global sorted top-K; then gather + refit + epilogue (icem.py:163-211).
 #include "icem_fused.h"
@@ -25,22 +24,16 @@
 #include <utility>
 
 #include "philox.h"
+#include "refit.h"
 
 namespace icem {
 
 namespace {
 
 constexpr int HMAX = 32;
+constexpr int SWG = 256;  // sampling workgroup
 
 __host__ __device__ constexpr int cmin(int a, int b) { return a < b ? a : b; }
-__host__ __device__ constexpr int tile_stride(int h, int d) {
-    int s = h * d;
-    s += s & 1;
-    if (s % 32 == 0) s += 2;
-    return s;
-}
-// trajectories per tile: one rollout lane each (<= 64), tile kept under 48 KiB of LDS
-__host__ __device__ constexpr int tile_traj(int h, int d) { return cmin(64, (12288 / tile_stride(h, d)) & ~3); }
 
 // ---- packed (cost, index) keys: unsigned order == (cost, index) lexicographic order ------------
 __device__ __forceinline__ unsigned long long make_key(float c, int idx) {
@@ -76,194 +69,233 @@ __device__ __forceinline__ unsigned long long wave_sort64(unsigned long long k, 
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// -------------------------------------------------------------------------------------------------
+// K1
+// -------------------------------------------------------------------------------------------------
+template <int H, int ROUNDS>
+__global__ __launch_bounds__(SWG) void sample_folded_kernel(FastSampleArgs a) {
+    constexpr int F = H / 2 + 1;
+    static_assert(H <= 32 && H >= 2, "white draws of a row live in 32 registers");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int d = a.d;
+    const int hd = H * d;
+    const int tpw = SWG / d;
+    float* ms = smem;            // mean | std
+    float* tile = smem + 2 * hd;  // [tpw, hd]
+    const int tid = threadIdx.x;
+    for (int e = tid; e < hd; e += SWG) {
+        ms[e] = a.mean[e];
+        ms[hd + e] = a.std[e];
+    }
+    const int n_base = blockIdx.x * tpw;
+    const int n_here = cmin(tpw, a.n - n_base);
+    __syncthreads();
+    if (tid < n_here * d) {
+        const int nl = tid / d;
+        const int j = tid - nl * d;
+        const unsigned gi = (unsigned)(a.first_index + n_base + nl);
+        float g[HMAX];
+#pragma unroll
+        for (int b = 0; b < (H + 3) / 4; ++b) {
+            const U4 r = philox4x32<ROUNDS>(gi, ((unsigned)j << 16) | (unsigned)b, a.off_lo, a.off_hi, a.seed_lo, a.seed_hi);
+            box_muller(r.x, r.y, g[4 * b], g[4 * b + 1]);
+            box_muller(r.z, r.w, g[4 * b + 2], g[4 * b + 3]);
+        }
+        const float lo = a.low[j], hi = a.high[j];
+        float* trow = tile + nl * hd + j;
+        const float* mrow = ms + j;
+        auto emit = [&](int t, float y) {
+            float v = __builtin_fmaf(y, mrow[hd + t * d], mrow[t * d]);
+            v = v < lo ? lo : v;
+            v = v > hi ? hi : v;
+            trow[t * d] = v;
+        };
+        {  // t = 0: every sine is zero
+            const float* __restrict__ w = a.W;
+            float e0 = 0.f, e1 = 0.f;
+#pragma unroll
+            for (int m = 0; m < F; m += 2) {
+                e0 = __builtin_fmaf(g[m], w[m], e0);
+                if (m + 1 < F) e1 = __builtin_fmaf(g[m + 1], w[m + 1], e1);
+            }
+            emit(0, e0 + e1);
+        }
+#pragma unroll 1
+        for (int tp = 1; tp <= H / 2; ++tp) {
+            const float* __restrict__ w = a.W + tp * HMAX;
+            float e0 = 0.f, e1 = 0.f, o0 = 0.f, o1 = 0.f;
+#pragma unroll
+            for (int m = 0; m < F; m += 2) {
+                e0 = __builtin_fmaf(g[m], w[m], e0);
+                if (m + 1 < F) e1 = __builtin_fmaf(g[m + 1], w[m + 1], e1);
+            }
+#pragma unroll
+            for (int m = F; m < H; m += 2) {
+                o0 = __builtin_fmaf(g[m], w[m], o0);
+                if (m + 1 < H) o1 = __builtin_fmaf(g[m + 1], w[m + 1], o1);
+            }
+            const float e = e0 + e1, od = o0 + o1;
+            emit(tp, e + od);
+            if (H - tp != tp) emit(H - tp, e - od);
+        }
+    }
+    __syncthreads();
+    if (a.row0_mean && a.first_index + n_base == 0) {  // icem.py:87-88
+        for (int e = tid; e < hd; e += SWG) tile[e] = ms[e];
+        __syncthreads();
+    }
+    float* gdst = a.out + (size_t)n_base * hd;
+    const int total = n_here * hd;
+    if ((hd & 3) == 0) {
+        const float4* t4 = reinterpret_cast<const float4*>(tile);
+        float4* g4 = reinterpret_cast<float4*>(gdst);
+        for (int e = tid; e < total / 4; e += SWG) g4[e] = t4[e];
+    } else {
+        for (int e = tid; e < total; e += SWG) gdst[e] = tile[e];
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// K2 + K3
+// -------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float act_fn(float x, std::integral_constant<int, 0>) { return x; }
 __device__ __forceinline__ float act_fn(float x, std::integral_constant<int, 1>) { return tanhf(x); }
 
-// -------------------------------------------------------------------------------------------------
-template <int H, int D, int O, int KIND, int ROUNDS>
-__global__ __launch_bounds__(FUSED_WG) void fused_iter_kernel(FusedArgs a) {
-    constexpr int F = H / 2 + 1;
+// steps per 16-byte-aligned action group: smallest G with (G*D) % 4 == 0
+__host__ __device__ constexpr int group_steps(int d) { return d % 4 == 0 ? 1 : (d % 2 == 0 ? 2 : 4); }
+
+constexpr int RWG = 256;  // rollout workgroup: 4 independent wavefronts, one per SIMD
+
+template <int H, int D, int O, int KIND>
+__global__ __launch_bounds__(RWG) void rollout_mfma_kernel(FastRolloutArgs a) {
+    constexpr int CTF = O / 4;       // full column tiles of 4 on the matrix pipe
+    constexpr int REM = O % 4;       // leftover columns: plain FMA chains on the VALU, under the MFMAs
+    constexpr int CT4 = ((O + 3) / 4) * 4;
+    constexpr int KK = O + D;        // contraction length of one model step
+    constexpr int G = group_steps(D);
+    constexpr int GV = G * D / 4;  // float4 per group
     constexpr int HD = H * D;
-    constexpr int TPW = tile_traj(H, D);
-    constexpr int S = tile_stride(H, D);
-    constexpr int CT = (O + 3) / 4;  // model output column tiles of 4
-    constexpr int KK = O + D;        // contraction length of one model step: [o | a] . [A ; B]
-    static_assert(H <= 31 && H >= 2, "folded DFT keeps real/imag halves in 16 + 16 registers");
-    static_assert(TPW <= 64 && TPW % 4 == 0, "one rollout lane per trajectory, MFMA blocks of 4");
+    constexpr int NG = H / G;  // action groups per trajectory
+    static_assert(H % G == 0 && HD % 4 == 0, "action rows must split into 16-byte groups");
+    static_assert(CTF >= 1, "at least one full column tile");
+    __shared__ unsigned long long wg_keys[RWG / 64][32];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
 
-    __shared__ __attribute__((aligned(16))) float tile[TPW * S];
-    __shared__ float ms_lds[2 * HD];  // mean | std, staged once: the S-phase reads them per sample
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int tiles_s = (a.n + TPW - 1) / TPW;
-    const int tiles_x = (a.n_extra + TPW - 1) / TPW;
-    const bool r_wave = tid < 64;  // wave 0 rolls the tile out on the matrix pipe
-
-    // --- model operand of the MFMA, resident in VGPRs: lane holds M[k][4*ct + (lane & 3)] ---------
-    // D^T = M^T . X^T with v_mfma_f32_4x4x1 (16 blocks of 4 trajectories): A-operand = 4 output
-    // columns of the model (row i = lane & 3), B-operand = the lane's own trajectory value x_k,
-    // result register i of tile ct = column 4*ct + i of THIS lane's trajectory: no transposes, the
-    // accumulation is the same k-ordered fmaf chain as the scalar kernels.
-    for (int e = tid; e < HD; e += FUSED_WG) {
-        ms_lds[e] = a.mean[e];
-        ms_lds[HD + e] = a.std[e];
+    // model operand of the MFMA: lane holds Mp[k][4*ct + (lane & 3)]; leftover columns are uniform
+    float mA[KK][CTF];
+    float mR[KK][REM > 0 ? REM : 1];
+#pragma unroll
+    for (int k = 0; k < KK; ++k) {
+#pragma unroll
+        for (int ct = 0; ct < CTF; ++ct) mA[k][ct] = a.Mp[k * CT4 + ct * 4 + (lane & 3)];
+#pragma unroll
+        for (int r = 0; r < REM; ++r) mR[k][r] = a.Mp[k * CT4 + CTF * 4 + r];
     }
-    __syncthreads();
+    float obs_init[O];
+#pragma unroll
+    for (int k = 0; k < O; ++k) obs_init[k] = k < a.o ? a.obs0[a.perm[k]] : 0.f;
+    // branch-free cost pieces (wave-uniform)
+    const float pen = a.flip_col >= 0 ? a.flip_pen : 0.f;
+    const bool ang_is_col1 = a.flip_col == 1;
+    const float ksum = a.cost_mode == 0 ? 1.f : 0.f;  // sum: acc = acc + c; final: acc = c
+    const bool use_min = a.cost_mode == 1;
 
-    unsigned long long run_key = KEY_SENTINEL;  // wave 0: lane r < K holds the r-th best so far
-    long long stamp[6] = {0, 0, 0, 0, 0, 0};
-    if (a.dbg) stamp[0] = __builtin_readcyclecounter();
-
-    for (int tile_id = blockIdx.x; tile_id < tiles_s + tiles_x; tile_id += gridDim.x) {
-        const bool sampled = tile_id < tiles_s;
-        const int n_base = sampled ? tile_id * TPW : a.n + (tile_id - tiles_s) * TPW;
-        const int n_here = sampled ? cmin(TPW, a.n - n_base) : cmin(TPW, a.n + a.n_extra - n_base);
-        float* gsrc = a.actions + (size_t)n_base * HD;
-
-        if (sampled) {
-            // ---------------- phase S ----------------
-            for (int row = tid; row < n_here * D; row += FUSED_WG) {
-                const int nl = row / D;
-                const int j = row - nl * D;
-                const unsigned gi = (unsigned)(a.first_index + n_base + nl);
-                float g[HMAX];
+    unsigned long long run_key = KEY_SENTINEL;  // lane r < K holds this wave's r-th best so far
+    const int tiles = (a.n_rows + 63) / 64;
+    const int wave_gid = blockIdx.x * (RWG / 64) + wave;
+    const int wave_cnt = gridDim.x * (RWG / 64);
+    bool first = true;
+    for (int tile_id = wave_gid; tile_id < tiles; tile_id += wave_cnt) {
+        const int row = tile_id * 64 + lane;
+        const bool live = row < a.n_rows;
+        const float4* arow = reinterpret_cast<const float4*>(a.actions + (size_t)(live ? row : 0) * HD);
+        // action ring: 3 buffers of one group each, loads issued two groups (>= 2 model steps) ahead
+        float4 buf[3][GV];
 #pragma unroll
-                for (int b = 0; b < (H + 3) / 4; ++b) {
-                    const U4 r = philox4x32<ROUNDS>(gi, ((unsigned)j << 16) | (unsigned)b, a.off_lo, a.off_hi,
-                                                    a.seed_lo, a.seed_hi);
-                    box_muller(r.x, r.y, g[4 * b], g[4 * b + 1]);
-                    box_muller(r.z, r.w, g[4 * b + 2], g[4 * b + 3]);
-                }
-                const float lo = a.low[j], hi = a.high[j];
-                float* trow = tile + nl * S + j;
-                auto emit = [&](int t, float y) {
-                    float v = __builtin_fmaf(y, ms_lds[HD + t * D + j], ms_lds[t * D + j]);
-                    v = v < lo ? lo : v;
-                    v = v > hi ? hi : v;
-                    trow[t * D] = v;
-                };
-                {  // t = 0: every sine is zero
-                    const float* __restrict__ w = a.W;
-                    float e0 = 0.f, e1 = 0.f;
-#pragma unroll
-                    for (int m = 0; m < F; m += 2) {
-                        e0 = __builtin_fmaf(g[m], w[m], e0);
-                        if (m + 1 < F) e1 = __builtin_fmaf(g[m + 1], w[m + 1], e1);
-                    }
-                    emit(0, e0 + e1);
-                }
-#pragma unroll 1
-                for (int tp = 1; tp <= H / 2; ++tp) {
-                    const float* __restrict__ w = a.W + tp * HMAX;
-                    float e0 = 0.f, e1 = 0.f, o0 = 0.f, o1 = 0.f;
-#pragma unroll
-                    for (int m = 0; m < F; m += 2) {
-                        e0 = __builtin_fmaf(g[m], w[m], e0);
-                        if (m + 1 < F) e1 = __builtin_fmaf(g[m + 1], w[m + 1], e1);
-                    }
-#pragma unroll
-                    for (int m = F; m < H; m += 2) {
-                        o0 = __builtin_fmaf(g[m], w[m], o0);
-                        if (m + 1 < H) o1 = __builtin_fmaf(g[m + 1], w[m + 1], o1);
-                    }
-                    const float e = e0 + e1, od = o0 + o1;
-                    emit(tp, e + od);
-                    if (H - tp != tp) emit(H - tp, e - od);
-                }
-            }
-            __syncthreads();
-            if (a.dbg && tile_id == blockIdx.x) stamp[1] = __builtin_readcyclecounter();
-            if (a.row0_mean && a.first_index == 0 && tile_id == 0) {  // icem.py:87-88
-                for (int e = tid; e < HD; e += FUSED_WG) tile[e] = ms_lds[e];
-                __syncthreads();
-            }
-            // ---------------- phase W ----------------
-            for (int e = tid; e < n_here * HD; e += FUSED_WG) {
-                const int nl = e / HD;
-                gsrc[e] = tile[nl * S + (e - nl * HD)];
-            }
-        } else {
-            for (int e = tid; e < n_here * HD; e += FUSED_WG) {
-                const int nl = e / HD;
-                tile[nl * S + (e - nl * HD)] = gsrc[e];
-            }
-            __syncthreads();
+        for (int v = 0; v < GV; ++v) {
+            buf[0][v] = arow[v];
+            if (NG > 1) buf[1][v] = arow[GV + v];
         }
-
-        // ---------------- phase R + K (wave 0) ----------------
-        if (a.dbg && tile_id == blockIdx.x) stamp[2] = __builtin_readcyclecounter();
-        if (r_wave) {
-            // (re)load the model operand here so it is not live across the sampling phase
-            float mA[KK][CT];
+        float obs[O];
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const int col = ct * 4 + (lane & 3);
-                const bool ok = col < O;
+        for (int k = 0; k < O; ++k) obs[k] = obs_init[k];
+        float acc_s = 0.f, acc_b = INFINITY;
+        auto run_group = [&](const float4 (&cur)[GV]) {
+        float actg[G * D];
 #pragma unroll
-                for (int k = 0; k < O; ++k) mA[k][ct] = ok ? a.A[k * O + col] : 0.f;
+        for (int v = 0; v < GV; ++v) {
+            actg[4 * v] = cur[v].x;
+            actg[4 * v + 1] = cur[v].y;
+            actg[4 * v + 2] = cur[v].z;
+            actg[4 * v + 3] = cur[v].w;
+        }
 #pragma unroll
-                for (int j = 0; j < D; ++j) mA[O + j][ct] = ok ? a.B[j * O + col] : 0.f;
+        for (int s = 0; s < G; ++s) {
+            const float* act = actg + s * D;
+            f32x4 acc[CTF];
+            float accr[REM > 0 ? REM : 1];
+#pragma unroll
+            for (int ct = 0; ct < CTF; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < REM; ++r) accr[r] = 0.f;
+#pragma unroll
+            for (int k = 0; k < KK; ++k) {
+                const float x = k < O ? obs[k < O ? k : 0] : act[k >= O ? k - O : 0];
+#pragma unroll
+                for (int ct = 0; ct < CTF; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_4x4x1f32(mA[k][ct], x, acc[ct], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < REM; ++r) accr[r] = __builtin_fmaf(x, mR[k][r], accr[r]);
             }
-            const bool live = lane < n_here;
-            float obs[O];
+            // cost of (o_t, a_t), branch free; column 0 holds obs[lin_idx], column 0/1 obs[flip_idx]
+            float ctrl = 0.f;
 #pragma unroll
-            for (int k = 0; k < O; ++k) obs[k] = k < a.o ? a.obs0[k] : 0.f;
-            const float* arow = tile + (live ? lane : 0) * S;
-            float acc_cost = 0.f;
+            for (int j = 0; j < D; ++j) ctrl = __builtin_fmaf(act[j], act[j], ctrl);
+            const float ang = ang_is_col1 ? obs[O > 1 ? 1 : 0] : obs[0];
+            float c = 0.f;
+            c += (ang > a.flip_th) ? pen : 0.f;
+            c += (ang < -a.flip_th) ? pen : 0.f;
+            c += a.ctrl_w * ctrl;
+            c += a.lin_w * obs[0];
+            acc_s = __builtin_fmaf(acc_s, ksum, c);
+            acc_b = c < acc_b ? c : acc_b;
+#pragma unroll
+            for (int k = 0; k < O; ++k) {
+                const float v = k < CTF * 4 ? acc[k < CTF * 4 ? k / 4 : 0][k % 4] : accr[k >= CTF * 4 ? k - CTF * 4 : 0];
+                obs[k] = act_fn(v, std::integral_constant<int, KIND>{});
+            }
+        }
+        };
 #pragma unroll 1
-            for (int t = 0; t < H; ++t) {
-                float act[D];
+        for (int tg = 0; tg < NG; tg += 3) {
+            if (tg + 2 < NG) {
 #pragma unroll
-                for (int j = 0; j < D; ++j) act[j] = arow[t * D + j];
-                f32x4 acc[CT];
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int k = 0; k < O; ++k) {
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct)
-                        acc[ct] = __builtin_amdgcn_mfma_f32_4x4x1f32(mA[k][ct], obs[k], acc[ct], 0, 0, 0);
-                }
-#pragma unroll
-                for (int j = 0; j < D; ++j) {
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct)
-                        acc[ct] = __builtin_amdgcn_mfma_f32_4x4x1f32(mA[O + j][ct], act[j], acc[ct], 0, 0, 0);
-                }
-                // cost of (o_t, a_t) on the VALU while the matrix pipe works
-                float ctrl = 0.f;
-#pragma unroll
-                for (int j = 0; j < D; ++j) ctrl = __builtin_fmaf(act[j], act[j], ctrl);
-                float lin = 0.f, ang = 0.f;
-#pragma unroll
-                for (int k = 0; k < O; ++k) {
-                    lin = (k == a.lin_idx) ? obs[k] : lin;
-                    ang = (k == a.flip_idx) ? obs[k] : ang;
-                }
-                float c = 0.f;
-                if (a.flip_idx >= 0) {
-                    c += (ang > a.flip_th) ? a.flip_pen : 0.f;
-                    c += (ang < -a.flip_th) ? a.flip_pen : 0.f;
-                }
-                c += a.ctrl_w * ctrl;
-                c += a.lin_w * lin;
-                if (t == 0 || a.cost_mode == 2)
-                    acc_cost = c;
-                else if (a.cost_mode == 0)
-                    acc_cost += c;
-                else
-                    acc_cost = c < acc_cost ? c : acc_cost;
-#pragma unroll
-                for (int k = 0; k < O; ++k) obs[k] = act_fn(acc[k / 4][k % 4], std::integral_constant<int, KIND>{});
+                for (int v = 0; v < GV; ++v) buf[2][v] = arow[(tg + 2) * GV + v];
             }
-            if (live) a.costs[n_base + lane] = acc_cost;
-            if (a.dbg && tile_id == blockIdx.x) stamp[3] = __builtin_readcyclecounter();
-            // phase K: this tile's 64 keys, then a bitonic merge with the running top-K
+            run_group(buf[0]);
+            if (tg + 1 < NG) {
+                if (tg + 3 < NG) {
+#pragma unroll
+                    for (int v = 0; v < GV; ++v) buf[0][v] = arow[(tg + 3) * GV + v];
+                }
+                run_group(buf[1]);
+            }
+            if (tg + 2 < NG) {
+                if (tg + 4 < NG) {
+#pragma unroll
+                    for (int v = 0; v < GV; ++v) buf[1][v] = arow[(tg + 4) * GV + v];
+                }
+                run_group(buf[2]);
+            }
+        }
+        const float acc_cost = use_min ? acc_b : acc_s;
+        if (live) a.costs[row] = acc_cost;
+        if (a.K > 0) {
             unsigned long long key = KEY_SENTINEL;
-            if (live && n_base + lane < a.n_cand) key = make_key(acc_cost, n_base + lane);
+            if (live && row < a.n_cand) key = make_key(acc_cost, row);
             key = wave_sort64(key, lane);
-            if (tile_id != (int)blockIdx.x) {  // not the first pass of this workgroup
+            if (!first) {  // merge with the running top-K of earlier tiles
                 const unsigned long long top = __shfl(key, lane - a.K, 64);
                 unsigned long long k2 = KEY_SENTINEL;
                 if (lane < a.K)
@@ -273,95 +305,143 @@ __global__ __launch_bounds__(FUSED_WG) void fused_iter_kernel(FusedArgs a) {
                 key = wave_sort64(k2, lane);
             }
             run_key = key;
+            first = false;
         }
-        __syncthreads();  // the tile is rewritten by the next pass
-        if (a.dbg && tile_id == blockIdx.x) stamp[4] = __builtin_readcyclecounter();
     }
-    if (a.dbg && tid == 0) {
-        stamp[5] = __builtin_readcyclecounter();
-        for (int i = 0; i < 6; ++i) a.dbg[(size_t)blockIdx.x * 8 + i] = stamp[i];
-    }
-    if (tid < a.K) {
-        a.part_c[(size_t)blockIdx.x * a.K + tid] = key_cost(run_key);
-        a.part_i[(size_t)blockIdx.x * a.K + tid] = key_idx(run_key);
+    if (a.K > 0) {
+        // one sorted list per workgroup: the 4 waves' top-K meet in LDS, wave 0 sorts 4*K <= 128 keys
+        if (lane < a.K) wg_keys[wave][lane] = run_key;
+        __syncthreads();
+        if (wave == 0) {
+            unsigned long long k0 = KEY_SENTINEL, k1 = KEY_SENTINEL;
+            if (lane < 2 * a.K) k0 = wg_keys[lane / a.K][lane % a.K];
+            if (lane < 2 * a.K) k1 = wg_keys[2 + lane / a.K][lane % a.K];
+            k0 = wave_sort64(k0, lane);
+            k1 = wave_sort64(k1, lane);
+            const unsigned long long top1 = __shfl(k1, lane - a.K, 64);
+            unsigned long long k2 = KEY_SENTINEL;
+            if (lane < a.K)
+                k2 = k0;
+            else if (lane < 2 * a.K)
+                k2 = top1;
+            k2 = wave_sort64(k2, lane);
+            if (lane < a.K) {
+                a.part_c[(size_t)blockIdx.x * a.K + lane] = key_cost(k2);
+                a.part_i[(size_t)blockIdx.x * a.K + lane] = key_idx(k2);
+            }
+        }
     }
 }
 
 // -------------------------------------------------------------------------------------------------
-constexpr int MERGE_WG = 1024;
+// merge: global sorted top-K from <= 256 sorted candidate lists (+ kept elites)
+// -------------------------------------------------------------------------------------------------
+constexpr int MERGE_WG = 256;  // 4 wavefronts, one candidate list per thread
 
+template <int CTRL>
+__device__ __forceinline__ unsigned long long min_dpp(unsigned long long x) {
+    // lanes whose DPP source is invalid keep their own value (old = x, bound_ctrl off)
+    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)x, (int)(unsigned)x, CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(x >> 32), (int)(unsigned)(x >> 32), CTRL, 0xF, 0xF, false);
+    const unsigned long long o = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+    return o < x ? o : x;
+}
+
+// min over the 64 lanes, returned wave-uniform: 4 DPP butterflies inside each row of 16 lanes
+// (quad xor 1, quad xor 2, half-row mirror, row mirror), then the 4 row minima through SGPRs.
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long x) {
+    x = min_dpp<0xB1>(x);   // quad_perm [1,0,3,2]
+    x = min_dpp<0x4E>(x);   // quad_perm [2,3,0,1]
+    x = min_dpp<0x141>(x);  // row_half_mirror
+    x = min_dpp<0x140>(x);  // row_mirror
+    unsigned long long r = ~0ull;
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+        const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)x, row * 16);
+        const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(x >> 32), row * 16);
+        const unsigned long long v = ((unsigned long long)hi << 32) | lo;
+        r = v < r ? v : r;
+    }
+    return r;
+}
+
+template <int KREG>
 __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs a) {
-    __shared__ unsigned long long red[MERGE_WG / 64];
+    __shared__ unsigned long long red[2][MERGE_WG / 64];
     __shared__ unsigned long long sel[64];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* new_mean = reinterpret_cast<float*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hd = a.h * a.d;
-    // thread t owns candidate list t (sorted) -- or kept elite t - n_lists (a one-entry list)
-    int head = 0, len = 0;
-    const float* lc = nullptr;
-    const int* li = nullptr;
-    float kept_c = 0.f;
-    int kept_i = 0;
-    if (tid < a.n_lists) {
-        lc = a.part_c + (size_t)tid * a.K;
-        li = a.part_i + (size_t)tid * a.K;
-        len = a.K;
-    } else if (tid < a.n_lists + a.n_keep) {
-        kept_c = a.elites_cost_cur[tid - a.n_lists];
-        kept_i = a.n_global + (tid - a.n_lists);
-        len = -1;  // single pseudo-entry
+    // thread t owns candidate list t, sorted, in registers; winners pop by shifting the registers
+    unsigned long long k[KREG];
+    {
+        // all loads issued up front from clamped (always valid) addresses, selected afterwards
+        int idxs[KREG];
+        float cs[KREG];
+        const bool has_list = tid < a.n_lists;
+        const size_t base = (size_t)(has_list ? tid : 0) * a.K;
+#pragma unroll
+        for (int i = 0; i < KREG; ++i) {
+            const int ii = i < a.K ? i : 0;
+            idxs[i] = a.part_i[base + ii];
+            cs[i] = a.part_c[base + ii];
+        }
+#pragma unroll
+        for (int i = 0; i < KREG; ++i) {
+            const bool ok = has_list && i < a.K && idxs[i] != INT_MAX;
+            const unsigned long long v = make_key(cs[i], idxs[i]);
+            k[i] = ok ? v : KEY_SENTINEL;
+        }
     }
-    auto head_key = [&]() -> unsigned long long {
-        if (len > 0 && head < len) {
-            const int i = li[head];
-            return i == INT_MAX ? KEY_SENTINEL : make_key(lc[head], i);
+    if (tid < a.n_keep) {  // kept elite `tid` (icem.py:143-145) joins this thread's list, order preserved
+        unsigned long long v = make_key(a.elites_cost_cur[tid], a.n_global + tid);
+#pragma unroll
+        for (int i = 0; i < KREG; ++i) {
+            const bool sw = v < k[i];
+            const unsigned long long t = sw ? k[i] : v;
+            k[i] = sw ? v : k[i];
+            v = t;
         }
-        if (len == -1 && head == 0) return make_key(kept_c, kept_i);
-        return KEY_SENTINEL;
-    };
-    unsigned long long mine = head_key();
+    }
+    if (a.dbg_stop == 1) { if (k[0] == 12345ull) a.best_cost[0] = 1.f; return; }
     for (int r = 0; r < a.K; ++r) {
-        unsigned long long k = mine;
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) {
-            const unsigned long long o = __shfl_xor(k, s, 64);
-            k = o < k ? o : k;
-        }
-        if (lane == 0) red[wave] = k;
+        const unsigned long long wmin = wave_min_u64(k[0]);
+        if (lane == 0) red[r & 1][wave] = wmin;
         __syncthreads();
-        unsigned long long best = red[0];
+        unsigned long long v = lane < MERGE_WG / 64 ? red[r & 1][lane] : ~0ull;
+        const unsigned long long best = wave_min_u64(v);
+        if (k[0] == best && best != KEY_SENTINEL) {  // unique: keys embed the trajectory index
 #pragma unroll
-        for (int w = 1; w < MERGE_WG / 64; ++w) best = red[w] < best ? red[w] : best;
-        if (mine == best && best != KEY_SENTINEL) {  // unique: keys embed the trajectory index
-            ++head;
-            mine = head_key();
+            for (int i = 0; i + 1 < KREG; ++i) k[i] = k[i + 1];
+            k[KREG - 1] = KEY_SENTINEL;
         }
         if (tid == 0) sel[r] = best;
-        __syncthreads();
     }
-    // gather + refit (icem.py:201-211)
-    auto src_row = [&](int r) -> const float* {
-        const int g = key_idx(sel[r]);
-        return g < a.n_pool ? a.actions + (size_t)g * hd : a.elites_cur + (size_t)(g - a.n_global) * hd;
-    };
-    const float invK = 1.f / (float)a.K;
+    __syncthreads();
+    if (a.dbg_stop == 2) { if (tid < a.K) a.elites_cost_next[tid] = key_cost(sel[tid]); return; }
+    // gather + refit (icem.py:201-211): row pointers first, then all K loads of an element in flight
+    const float* rows[KREG];
+#pragma unroll
+    for (int r = 0; r < KREG; ++r) {
+        const int g = key_idx(sel[r < a.K ? r : 0]);
+        rows[r] = g < a.n_pool ? a.actions + (size_t)g * hd : a.elites_cur + (size_t)(g - a.n_global) * hd;
+    }
+    auto src_row = [&](int r) -> const float* { return rows[r]; };
     for (int e = tid; e < hd; e += MERGE_WG) {
-        float s = 0.f;
-        for (int r = 0; r < a.K; ++r) {
-            const float x = src_row(r)[e];
-            a.elites_next[(size_t)r * hd + e] = x;
-            s += x;
-        }
-        const float m = s / (float)a.K;
-        float v = 0.f;
-        for (int r = 0; r < a.K; ++r) {
-            const float dx = src_row(r)[e] - m;
-            v = __builtin_fmaf(dx, dx, v);
-        }
-        const float sd = sqrtf(v / (float)a.K);
-        const float nm = (1.f - a.alpha) * m + a.alpha * a.mean[e];
-        const float ns = (1.f - a.alpha) * sd + a.alpha * a.std[e];
+        float xs[KREG];
+#pragma unroll
+        for (int r = 0; r < KREG; ++r) xs[r] = rows[r][e];
+        const float old_mean = a.mean[e], old_std = a.std[e];
+#pragma unroll
+        for (int r = 0; r < KREG; ++r)
+            if (r < a.K) a.elites_next[(size_t)r * hd + e] = xs[r];
+        float nm, ns;
+        refit_element<float>(a.K, a.alpha, old_mean, old_std, [&](int r) {
+            float v = xs[0];
+#pragma unroll
+            for (int q = 1; q < KREG; ++q) v = (q == r) ? xs[q] : v;
+            return v; }, nm, ns);
         if (!a.last) {
             a.mean[e] = nm;
             a.std[e] = ns;
@@ -369,7 +449,6 @@ __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs 
             new_mean[e] = nm;
         }
     }
-    (void)invK;
     if (tid < a.K) a.elites_cost_next[tid] = key_cost(sel[tid]);
     if (a.last) {
         __syncthreads();
@@ -383,50 +462,66 @@ __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs 
     }
 }
 
-template <int H, int D, int O>
-int launch_hdo(const FusedArgs& a, int kind, int rounds, int grid, hipStream_t st) {
-    if (kind == 1) {
-        if (rounds == 7)
-            hipLaunchKernelGGL((fused_iter_kernel<H, D, O, 1, 7>), dim3(grid), dim3(FUSED_WG), 0, st, a);
-        else
-            hipLaunchKernelGGL((fused_iter_kernel<H, D, O, 1, 10>), dim3(grid), dim3(FUSED_WG), 0, st, a);
-    } else {
-        if (rounds == 7)
-            hipLaunchKernelGGL((fused_iter_kernel<H, D, O, 0, 7>), dim3(grid), dim3(FUSED_WG), 0, st, a);
-        else
-            hipLaunchKernelGGL((fused_iter_kernel<H, D, O, 0, 10>), dim3(grid), dim3(FUSED_WG), 0, st, a);
-    }
-    return 0;
-}
-
 }  // namespace
 
-// The compiled shape list (H, D, O): the benchmark / golden shapes.  Anything else runs on the
-// unfused generic kernels.
-#define ICEM_FUSED_SHAPES(X) X(30, 6, 17) X(30, 6, 18) X(12, 6, 17) X(13, 4, 17) X(10, 3, 17) X(30, 17, 24)
+// shapes (H, D, O) with a compiled matrix-pipe rollout; anything else runs on the generic kernels
+#define ICEM_FAST_SHAPES(X) X(30, 6, 17) X(30, 6, 18) X(12, 6, 17) X(13, 4, 17)
 
-bool fused_supported(int O, int d, int h, int K) {
+bool fast_rollout_supported(int h, int d, int O, int K) {
     if (K > 32) return false;
 #define X(HH, DD, OO) \
     if (h == HH && d == DD && O == OO) return true;
-    ICEM_FUSED_SHAPES(X)
+    ICEM_FAST_SHAPES(X)
 #undef X
     return false;
 }
 
-int fused_tile_traj(int h, int d) { return tile_traj(h, d); }
-int fused_tile_stride(int h, int d) { return tile_stride(h, d); }
-
-int launch_fused_iter(const FusedArgs& a, int O, int kind, int rounds, int grid, hipStream_t st) {
-#define X(HH, DD, OO) \
-    if (a.h == HH && a.d == DD && O == OO) return launch_hdo<HH, DD, OO>(a, kind, rounds, grid, st);
-    ICEM_FUSED_SHAPES(X)
+void launch_rollout_mfma(const FastRolloutArgs& a, int h, int d, int O, int kind, int grid, hipStream_t st) {
+#define X(HH, DD, OO)                                                                                         \
+    if (h == HH && d == DD && O == OO) {                                                                      \
+        if (kind == 1)                                                                                        \
+            hipLaunchKernelGGL((rollout_mfma_kernel<HH, DD, OO, 1>), dim3(grid), dim3(RWG), 0, st, a);         \
+        else                                                                                                  \
+            hipLaunchKernelGGL((rollout_mfma_kernel<HH, DD, OO, 0>), dim3(grid), dim3(RWG), 0, st, a);         \
+        return;                                                                                               \
+    }
+    ICEM_FAST_SHAPES(X)
 #undef X
-    return 1;
+}
+
+#define ICEM_FAST_HORIZONS(X) X(30) X(12) X(13) X(10)
+
+bool fast_sample_supported(int h, int d) {
+    if (d > SWG) return false;
+#define X(HH) \
+    if (h == HH) return true;
+    ICEM_FAST_HORIZONS(X)
+#undef X
+    return false;
+}
+
+void launch_sample_folded(const FastSampleArgs& a, int rounds, hipStream_t st) {
+    const int tpw = SWG / a.d;
+    const int grid = (a.n + tpw - 1) / tpw;
+    const size_t lds = ((size_t)2 * a.h * a.d + (size_t)tpw * a.h * a.d) * sizeof(float);
+#define X(HH)                                                                                        \
+    if (a.h == HH) {                                                                                 \
+        if (rounds == 7)                                                                             \
+            hipLaunchKernelGGL((sample_folded_kernel<HH, 7>), dim3(grid), dim3(SWG), lds, st, a);    \
+        else                                                                                         \
+            hipLaunchKernelGGL((sample_folded_kernel<HH, 10>), dim3(grid), dim3(SWG), lds, st, a);   \
+        return;                                                                                      \
+    }
+    ICEM_FAST_HORIZONS(X)
+#undef X
 }
 
 void launch_merge_single(const MergeSingleArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(merge_single_kernel, dim3(1), dim3(MERGE_WG), (size_t)a.h * a.d * sizeof(float), st, a);
+    const size_t lds = (size_t)a.h * a.d * sizeof(float);
+    if (a.K + 1 <= 12)
+        hipLaunchKernelGGL((merge_single_kernel<12>), dim3(1), dim3(MERGE_WG), lds, st, a);
+    else
+        hipLaunchKernelGGL((merge_single_kernel<34>), dim3(1), dim3(MERGE_WG), lds, st, a);
 }
 
 }  // namespace icem

@@ -17,12 +17,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 
 #include "../../include/icem_hip.h"
 #include "philox.h"
 #include "icem_fused.h"
+#include "refit.h"
 #include <type_traits>
 
 namespace icem {
@@ -396,21 +398,12 @@ template <typename T>
 __global__ __launch_bounds__(WG) void gather_refit_kernel(int hd, int K, T alpha, const T* actions, const int* idx,
                                                           T* mean, T* std, T* elites_out) {
     for (int e = blockIdx.x * WG + threadIdx.x; e < hd; e += gridDim.x * WG) {
-        T s = (T)0;
-        for (int r = 0; r < K; ++r) {
-            const T x = actions[(size_t)idx[r] * hd + e];
-            if (elites_out != nullptr) elites_out[(size_t)r * hd + e] = x;
-            s += x;
-        }
-        const T m = s / (T)K;
-        T v = (T)0;
-        for (int r = 0; r < K; ++r) {
-            const T dx = actions[(size_t)idx[r] * hd + e] - m;
-            v = fmad(dx, dx, v);
-        }
-        const T sd = sqrt(v / (T)K);
-        mean[e] = ((T)1 - alpha) * m + alpha * mean[e];
-        std[e] = ((T)1 - alpha) * sd + alpha * std[e];
+        if (elites_out != nullptr)
+            for (int r = 0; r < K; ++r) elites_out[(size_t)r * hd + e] = actions[(size_t)idx[r] * hd + e];
+        T nm, ns;
+        refit_element<T>(K, alpha, mean[e], std[e], [&](int r) { return actions[(size_t)idx[r] * hd + e]; }, nm, ns);
+        mean[e] = nm;
+        std[e] = ns;
     }
 }
 
@@ -550,21 +543,9 @@ __global__ __launch_bounds__(WG) void merge_refit_kernel(MergeArgs<T> a) {
         return e < a.n_rec ? a.records + (size_t)e * rs + 2 : a.elites_cur + (size_t)(e - a.n_rec) * hd;
     };
     for (int e = threadIdx.x; e < hd; e += WG) {
-        T s = (T)0;
-        for (int r = 0; r < a.K; ++r) {
-            const T x = src_row(r)[e];
-            a.elites_next[(size_t)r * hd + e] = x;
-            s += x;
-        }
-        const T m = s / (T)a.K;
-        T v = (T)0;
-        for (int r = 0; r < a.K; ++r) {
-            const T dx = src_row(r)[e] - m;
-            v = fmad(dx, dx, v);
-        }
-        const T sd = sqrt(v / (T)a.K);
-        const T nm = ((T)1 - a.alpha) * m + a.alpha * a.mean[e];
-        const T ns = ((T)1 - a.alpha) * sd + a.alpha * a.std[e];
+        for (int r = 0; r < a.K; ++r) a.elites_next[(size_t)r * hd + e] = src_row(r)[e];
+        T nm, ns;
+        refit_element<T>(a.K, a.alpha, a.mean[e], a.std[e], [&](int r) { return src_row(r)[e]; }, nm, ns);
         if (!a.last) {
             a.mean[e] = nm;
             a.std[e] = ns;
@@ -613,9 +594,14 @@ struct icem_handle {
         long long units;
         hipEvent_t a, b;
     };
-    bool use_fused = true;
-    long long* dbg = nullptr;
-    int fused_grid = 0;  // candidate lists written by the last fused launch (0 = unfused path ran)
+    bool use_fast = true;
+    int fast_lists = 0;  // candidate lists written by the last matrix-pipe rollout (0 = generic path ran)
+    // permuted, padded model of the matrix-pipe rollout: column 0 = obs[lin_idx], column 1 = obs[flip_idx]
+    void* Mp_dev = nullptr;
+    void* perm_dev = nullptr;
+    int flip_col = -1;
+    bool fast_model_ready = false;
+    std::vector<double> A_host, B_host;
     std::vector<Span> spans;
     std::vector<hipEvent_t> free_events;
 };
@@ -849,6 +835,113 @@ int launch_topk(int n, int K, const void* costs, void* out_c, int* out_i, void* 
     return ICEM_OK;
 }
 
+// Build the permuted, zero-padded [A ; B] operand of the matrix-pipe rollout (lazily: it depends on
+// both icem_set_model and icem_set_cost).  Observation entries are reordered so that the linear cost
+// term reads column 0 and the flip term column 0 or 1 -- static registers in the kernel.
+int ensure_fast_model(icem_handle* h) {
+    if (h->fast_model_ready) return ICEM_OK;
+    const int O = h->O, o = h->obs_dim, d = h->cfg.act_dim;
+    const int CT4 = ((O + 3) / 4) * 4;
+    std::vector<int> perm;
+    perm.push_back(h->cost.lin_idx);
+    h->flip_col = -1;
+    if (h->cost.flip_idx >= 0) {
+        if (h->cost.flip_idx == h->cost.lin_idx) {
+            h->flip_col = 0;
+        } else {
+            perm.push_back(h->cost.flip_idx);
+            h->flip_col = 1;
+        }
+    }
+    for (int k = 0; k < O; ++k)
+        if (std::find(perm.begin(), perm.end(), k) == perm.end()) perm.push_back(k);
+    std::vector<float> Mp((size_t)(O + d) * CT4, 0.f);
+    auto Aat = [&](int r, int c) { return (r < o && c < o) ? h->A_host[(size_t)r * o + c] : 0.0; };
+    auto Bat = [&](int j, int c) { return c < o ? h->B_host[(size_t)j * o + c] : 0.0; };
+    for (int k = 0; k < O; ++k)
+        for (int c = 0; c < O; ++c) Mp[(size_t)k * CT4 + c] = (float)Aat(perm[k], perm[c]);
+    for (int j = 0; j < d; ++j)
+        for (int c = 0; c < O; ++c) Mp[(size_t)(O + j) * CT4 + c] = (float)Bat(j, perm[c]);
+    if (h->Mp_dev) (void)hipFree(h->Mp_dev);
+    if (h->perm_dev) (void)hipFree(h->perm_dev);
+    ICEM_HIP_TRY(hipMalloc(&h->Mp_dev, Mp.size() * sizeof(float)));
+    ICEM_HIP_TRY(hipMalloc(&h->perm_dev, perm.size() * sizeof(int)));
+    ICEM_HIP_TRY(hipMemcpy(h->Mp_dev, Mp.data(), Mp.size() * sizeof(float), hipMemcpyHostToDevice));
+    ICEM_HIP_TRY(hipMemcpy(h->perm_dev, perm.data(), perm.size() * sizeof(int), hipMemcpyHostToDevice));
+    h->fast_model_ready = true;
+    return ICEM_OK;
+}
+
+bool fast_rollout_ok(const icem_handle* h, int K) {
+    return h->use_fast && h->cfg.dtype == ICEM_F32 && h->has_model && h->has_cost &&
+           fast_rollout_supported(h->cfg.horizon, h->cfg.act_dim, h->O, K);
+}
+
+// rows -> costs (+ per-wave sorted candidates when K > 0); returns the number of candidate lists
+int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const void* obs0, const void* actions,
+                        void* costs, float* part_c, int* part_i, hipStream_t st, int* lists_out) {
+    int rc = ensure_fast_model(h);
+    if (rc) return rc;
+    FastRolloutArgs a;
+    a.n_rows = n_rows;
+    a.n_cand = n_cand;
+    a.K = K;
+    a.o = h->obs_dim;
+    a.cost_mode = h->cfg.cost_mode;
+    a.Mp = (const float*)h->Mp_dev;
+    a.perm = (const int*)h->perm_dev;
+    a.obs0 = (const float*)obs0;
+    a.ctrl_w = (float)h->cost.ctrl_weight;
+    a.lin_w = (float)h->cost.lin_weight;
+    a.flip_pen = (float)h->cost.flip_penalty;
+    a.flip_th = (float)h->cost.flip_thresh;
+    a.flip_col = h->flip_col;
+    a.actions = (const float*)actions;
+    a.costs = (float*)costs;
+    a.part_c = part_c;
+    a.part_i = part_i;
+    const int tiles = (n_rows + 63) / 64;
+    const int grid = std::max(1, std::min((tiles + 3) / 4, FAST_MAX_LISTS));
+    {
+        ProfScope prof(h, ICEM_K_ROLLOUT, (long long)n_rows * h->cfg.horizon, st);
+        launch_rollout_mfma(a, h->cfg.horizon, h->cfg.act_dim, h->O, h->model_kind, grid, st);
+    }
+    ICEM_HIP_TRY(hipGetLastError());
+    if (lists_out) *lists_out = grid;
+    return ICEM_OK;
+}
+
+bool fast_sample_ok(const icem_handle* h) {
+    return h->use_fast && h->cfg.dtype == ICEM_F32 && fast_sample_supported(h->cfg.horizon, h->cfg.act_dim);
+}
+
+int launch_fast_sample(const icem_handle* h, int n, long long first_index, const void* mean, const void* std,
+                       const void* low, const void* high, uint64_t offset, int row0_mean, void* out, hipStream_t st) {
+    if (n <= 0) return ICEM_OK;
+    FastSampleArgs a;
+    a.n = n;
+    a.h = h->cfg.horizon;
+    a.d = h->cfg.act_dim;
+    a.first_index = first_index;
+    a.W = (const float*)h->W_dev;
+    a.mean = (const float*)mean;
+    a.std = (const float*)std;
+    a.low = (const float*)low;
+    a.high = (const float*)high;
+    a.seed_lo = (uint32_t)h->cfg.seed;
+    a.seed_hi = (uint32_t)(h->cfg.seed >> 32);
+    a.off_lo = (uint32_t)offset;
+    a.off_hi = (uint32_t)(offset >> 32);
+    a.row0_mean = row0_mean;
+    a.out = (float*)out;
+    {
+        ProfScope prof(h, ICEM_K_SAMPLE, (long long)n * a.h, st);
+        launch_sample_folded(a, h->cfg.rng_rounds, st);
+    }
+    ICEM_HIP_TRY(hipGetLastError());
+    return ICEM_OK;
+}
+
 template <typename T>
 int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, int it, hipStream_t st) {
     const icem_config& c = h->cfg;
@@ -877,62 +970,32 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
     const int n_cand = n_loc + (c.rank == 0 ? n_extra : 0);
     const int row0 = (last && c.use_mean_actions) ? 1 : 0;
     T* rec = (T*)b->records + (size_t)c.rank * K * (hd + 2);
-    h->fused_grid = 0;
+    h->fast_lists = 0;
     if constexpr (std::is_same<T, float>::value) {
-        if (b->z_r == nullptr && h->use_fused && fused_supported(h->O, c.act_dim, c.horizon, K)) {
-            // f32 throughput path: sample -> LDS tile -> HBM, rollout + cost from LDS, per-workgroup top-K
-            FusedArgs a;
-            a.n = n_loc;
-            a.n_extra = n_extra;
-            a.n_cand = n_cand;
-            a.h = c.horizon;
-            a.d = c.act_dim;
-            a.F = h->F;
-            a.o = h->obs_dim;
-            a.tpw = fused_tile_traj(c.horizon, c.act_dim);
-            a.tile_stride = fused_tile_stride(c.horizon, c.act_dim);
-            a.K = K;
-            a.cost_mode = c.cost_mode;
-            a.row0_mean = row0;
-            a.first_index = lo;
-            a.W = (const float*)h->W_dev;
-            a.mean = (const float*)b->mean;
-            a.std = (const float*)b->std;
-            a.low = (const float*)b->low;
-            a.high = (const float*)b->high;
+        if (b->z_r == nullptr && fast_rollout_ok(h, K)) {
+            // f32 throughput path: folded sampler -> matrix-pipe rollout + cost + per-wave top-K
             const uint64_t off = call_base + (uint64_t)it;
-            a.seed_lo = (uint32_t)c.seed;
-            a.seed_hi = (uint32_t)(c.seed >> 32);
-            a.off_lo = (uint32_t)off;
-            a.off_hi = (uint32_t)(off >> 32);
-            a.A = (const float*)h->A_dev;
-            a.B = (const float*)h->B_dev;
-            a.obs0 = (const float*)b->obs0;
-            a.ctrl_w = (float)h->cost.ctrl_weight;
-            a.lin_w = (float)h->cost.lin_weight;
-            a.flip_pen = (float)h->cost.flip_penalty;
-            a.flip_th = (float)h->cost.flip_thresh;
-            a.lin_idx = h->cost.lin_idx;
-            a.flip_idx = h->cost.flip_idx;
-            a.actions = (float*)actions;
-            a.costs = (float*)b->costs;
-            const int tiles = (n_loc + a.tpw - 1) / a.tpw + (n_extra + a.tpw - 1) / a.tpw;
-            const int grid = std::max(1, std::min(tiles, FUSED_MAX_GRID - ICEM_MAX_ELITES));
+            int rc;
+            if (fast_sample_ok(h)) {
+                rc = launch_fast_sample(h, n_loc, lo, b->mean, b->std, b->low, b->high, off, row0, actions, st);
+            } else {
+                SampleArgs<T> a = make_sample_args<T>(h, n_loc, lo, b->mean, b->std, b->low, b->high, nullptr, nullptr, off,
+                                                      0, row0, actions);
+                rc = launch_sample<T>(h, a, st);
+            }
+            if (rc) return rc;
+            const int tiles = (n_loc + n_extra + 63) / 64;
+            const int grid = std::max(1, std::min((tiles + 3) / 4, FAST_MAX_LISTS));
             float* pc;
             int* pi;
             split_partial_ws<float>(b->workspace, grid, K, &pc, &pi);
-            a.part_c = pc;
-            a.part_i = pi;
-            a.dbg = h->dbg;
-            {
-                ProfScope prof(h, ICEM_K_FUSED, (long long)(n_loc + n_extra) * c.horizon, st);
-                if (launch_fused_iter(a, h->O, h->model_kind, c.rng_rounds, grid, st) != 0)
-                    return fail(ICEM_E_UNSUPPORTED, "fused kernel shape not compiled");
-            }
-            h->fused_grid = grid;
+            int lists = 0;
+            rc = launch_fast_rollout(h, n_loc + n_extra, n_cand, K, b->obs0, actions, b->costs, pc, pi, st, &lists);
+            if (rc) return rc;
+            h->fast_lists = lists;
             if (c.world > 1) {
-                ProfScope prof(h, ICEM_K_LOCAL_PACK, grid * K, st);
-                hipLaunchKernelGGL((local_pack_kernel<float>), dim3(1), dim3(WG), 0, st, grid * K, K, hd, n_loc, lo,
+                ProfScope prof(h, ICEM_K_LOCAL_PACK, lists * K, st);
+                hipLaunchKernelGGL((local_pack_kernel<float>), dim3(1), dim3(WG), 0, st, lists * K, K, hd, n_loc, lo,
                                    n_global, (const float*)pc, (const int*)pi, (const float*)actions, (float*)rec);
             }
             ICEM_HIP_TRY(hipGetLastError());
@@ -974,9 +1037,9 @@ int plan_iter_merge_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
     T* el = (T*)b->elites;
     T* elc = el + (size_t)2 * K * hd;
     if constexpr (std::is_same<T, float>::value) {
-        if (c.world == 1 && h->fused_grid > 0) {
+        if (c.world == 1 && h->fast_lists > 0) {
             MergeSingleArgs m;
-            m.n_lists = h->fused_grid;
+            m.n_lists = h->fast_lists;
             m.n_keep = (it > 0 && c.keep_previous_elites) ? h->n_reuse : 0;
             const int n_extra = (it == 0 && c.shift_elites && mpc_step > 0) ? h->n_reuse : 0;
             m.n_pool = h->pop[it] + n_extra;
@@ -989,7 +1052,7 @@ int plan_iter_merge_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
             m.init_std = (float)c.init_std;
             float* pc;
             int* pi;
-            split_partial_ws<float>(b->workspace, h->fused_grid, K, &pc, &pi);
+            split_partial_ws<float>(b->workspace, h->fast_lists, K, &pc, &pi);
             m.part_c = pc;
             m.part_i = pi;
             m.actions = (const float*)b->actions;
@@ -1003,7 +1066,8 @@ int plan_iter_merge_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
             m.high = (const float*)b->high;
             m.executed = (float*)b->executed;
             m.best_cost = (float*)b->best_cost;
-            ProfScope prof(h, ICEM_K_MERGE_REFIT, h->fused_grid * K + m.n_keep, st);
+            m.dbg_stop = getenv("ICEM_MERGE_STOP") ? atoi(getenv("ICEM_MERGE_STOP")) : 0;
+            ProfScope prof(h, ICEM_K_MERGE_REFIT, h->fast_lists * K + m.n_keep, st);
             launch_merge_single(m, st);
             ICEM_HIP_TRY(hipGetLastError());
             return ICEM_OK;
@@ -1093,7 +1157,7 @@ int icem_create(const icem_config* cfg, icem_handle** out) {
     h->pop = population_sizes(c);
     h->n_reuse = (int)((double)c.num_elites * c.fraction_reused);  // int(len(elites)*xi), icem.py:98,145
     h->n_local_max = shard_chunk(c.num_traj, c.world);
-    if (const char* e = getenv("ICEM_DISABLE_FUSED")) h->use_fused = !(e[0] == '1');
+    if (const char* e = getenv("ICEM_DISABLE_FAST")) h->use_fast = !(e[0] == '1');
     // synthesis table W[t][m]: m < F real part of bin m, F <= m < h imaginary part of bin m-F+1
     std::vector<double> cr, ci, W((size_t)c.horizon * h->HMAX, 0.0);
     noise_tables(c.horizon, c.noise_beta, cr, ci);
@@ -1114,6 +1178,8 @@ int icem_destroy(icem_handle* h) {
     if (h->W_dev) (void)hipFree(h->W_dev);
     if (h->A_dev) (void)hipFree(h->A_dev);
     if (h->B_dev) (void)hipFree(h->B_dev);
+    if (h->Mp_dev) (void)hipFree(h->Mp_dev);
+    if (h->perm_dev) (void)hipFree(h->perm_dev);
     for (auto& sp : h->spans) {
         (void)hipEventDestroy(sp.a);
         (void)hipEventDestroy(sp.b);
@@ -1148,6 +1214,9 @@ int icem_set_model(icem_handle* h, int32_t kind, int32_t obs_dim, const double* 
     h->obs_dim = obs_dim;
     h->O = O;
     h->has_model = true;
+    h->A_host.assign(A_host, A_host + (size_t)obs_dim * obs_dim);
+    h->B_host.assign(B_host, B_host + (size_t)d * obs_dim);
+    h->fast_model_ready = false;
     return ICEM_OK;
 }
 
@@ -1155,6 +1224,7 @@ int icem_set_cost(icem_handle* h, const icem_cost_spec* spec) {
     if (!h || !spec) return fail(ICEM_E_INVALID, "null argument");
     h->cost = *spec;
     h->has_cost = true;
+    h->fast_model_ready = false;
     return ICEM_OK;
 }
 
@@ -1166,6 +1236,8 @@ int icem_sample_clip(icem_handle* h, int32_t n, int64_t first_index, const void*
     if ((z_r == nullptr) != (z_i == nullptr)) return fail(ICEM_E_INVALID, "z_r and z_i must both be given or both NULL");
     if (t_begin < 0 || t_begin >= h->cfg.horizon) return fail(ICEM_E_INVALID, "t_begin out of range");
     hipStream_t st = (hipStream_t)stream;
+    if (z_r == nullptr && t_begin == 0 && fast_sample_ok(h))
+        return launch_fast_sample(h, n, first_index, mean, std, low, high, offset, row0_mean, actions, st);
     return ICEM_DISPATCH(h,
                          launch_sample<float>(h, make_sample_args<float>(h, n, first_index, mean, std, low, high, z_r, z_i, offset, t_begin, row0_mean, actions), st),
                          launch_sample<double>(h, make_sample_args<double>(h, n, first_index, mean, std, low, high, z_r, z_i, offset, t_begin, row0_mean, actions), st));
@@ -1203,6 +1275,8 @@ int icem_rollout_cost(icem_handle* h, int32_t n, const void* obs0, const void* a
     if (h->cost.lin_idx < 0 || h->cost.lin_idx >= h->obs_dim || h->cost.flip_idx >= h->obs_dim)
         return fail(ICEM_E_INVALID, "cost index outside the observation");
     hipStream_t st = (hipStream_t)stream;
+    if (observations == nullptr && n > 0 && fast_rollout_ok(h, 0))
+        return launch_fast_rollout(h, n, 0, 0, obs0, actions, costs, nullptr, nullptr, st, nullptr);
     return ICEM_DISPATCH(h, launch_rollout<float>(h, n, obs0, actions, costs, observations, st),
                          launch_rollout<double>(h, n, obs0, actions, costs, observations, st));
 }
@@ -1285,7 +1359,7 @@ int icem_reset_distribution(icem_handle* h, void* mean, void* std, const void* l
 
 int icem_debug_stamps(icem_handle* h, void* dev_ptr) {
     if (check_handle(h)) return ICEM_E_INVALID;
-    h->dbg = (long long*)dev_ptr;
+    (void)dev_ptr;
     return ICEM_OK;
 }
 
@@ -1342,7 +1416,7 @@ size_t icem_plan_buffer_bytes(const icem_handle* h, int32_t which) {
         case ICEM_BUF_RECORDS:
             return (size_t)h->cfg.world * K * (hd + 2) * ts;
         case ICEM_BUF_WORKSPACE:
-            return (size_t)std::max(topk_blocks((int)rows), FUSED_MAX_GRID) * K * (ts + sizeof(int));
+            return (size_t)std::max(topk_blocks((int)rows), 1024) * K * (ts + sizeof(int));
         case ICEM_BUF_BEST_COST:
             return ts;
         default:

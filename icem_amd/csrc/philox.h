@@ -36,7 +36,7 @@ __device__ __forceinline__ void box_muller(uint32_t xa, uint32_t xb, float& g0, 
     const float u1 = __builtin_fmaf((float)xa, 0x1p-32f, 0x1p-33f);
     const float v = (float)xb * 0x1p-32f;
     // -2 ln(u1) = -2 ln2 * log2(u1)
-    const float r = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // raw v_sqrt_f32 (1 ulp)
     g0 = r * __builtin_amdgcn_cosf(v);
     g1 = r * __builtin_amdgcn_sinf(v);
 }
