@@ -41,6 +41,7 @@ struct FastRolloutArgs {
     float* costs;
     float* part_c;  // [grid, K]
     int* part_i;
+    long long* dbg;  // development: [waves, 8] cycle stamps, nullptr in production
 };
 bool fast_rollout_supported(int h, int d, int O, int K);
 void launch_rollout_mfma(const FastRolloutArgs& a, int h, int d, int O, int kind, int grid, hipStream_t st);

@@ -165,11 +165,17 @@ __device__ __forceinline__ float act_fn(float x, std::integral_constant<int, 1>)
 __host__ __device__ constexpr int group_steps(int d) { return d % 4 == 0 ? 1 : (d % 2 == 0 ? 2 : 4); }
 
 constexpr int RWG = 256;  // rollout workgroup: 4 independent wavefronts, one per SIMD
+// Unused dynamic LDS that makes a workgroup claim more than half of a CU's 160 KiB, so the dispatcher
+// can never put two rollout workgroups on one CU (two MFMA-bound waves on one SIMD halve each other).
+constexpr size_t ROLLOUT_LDS_PAD = 84 * 1024;
 
 template <int H, int D, int O, int KIND>
-__global__ __launch_bounds__(RWG) void rollout_mfma_kernel(FastRolloutArgs a) {
-    constexpr int CTF = O / 4;       // full column tiles of 4 on the matrix pipe
-    constexpr int REM = O % 4;       // leftover columns: plain FMA chains on the VALU, under the MFMAs
+__global__ __launch_bounds__(RWG) __attribute__((amdgpu_waves_per_eu(1, 1))) void rollout_mfma_kernel(FastRolloutArgs a) {
+#ifndef ICEM_REM_ON_VALU
+#define ICEM_REM_ON_VALU 1
+#endif
+    constexpr int CTF = ICEM_REM_ON_VALU ? O / 4 : (O + 3) / 4;  // column tiles of 4 on the matrix pipe
+    constexpr int REM = ICEM_REM_ON_VALU ? O % 4 : 0;  // leftover columns: FMA chains on the VALU, under the MFMAs
     constexpr int CT4 = ((O + 3) / 4) * 4;
     constexpr int KK = O + D;        // contraction length of one model step
     constexpr int G = group_steps(D);
@@ -201,6 +207,7 @@ __global__ __launch_bounds__(RWG) void rollout_mfma_kernel(FastRolloutArgs a) {
     const float ksum = a.cost_mode == 0 ? 1.f : 0.f;  // sum: acc = acc + c; final: acc = c
     const bool use_min = a.cost_mode == 1;
 
+    long long st0 = __builtin_readcyclecounter(), st1 = 0, st2 = 0, st3 = 0, st4 = 0;
     unsigned long long run_key = KEY_SENTINEL;  // lane r < K holds this wave's r-th best so far
     const int tiles = (a.n_rows + 63) / 64;
     const int wave_gid = blockIdx.x * (RWG / 64) + wave;
@@ -221,6 +228,7 @@ __global__ __launch_bounds__(RWG) void rollout_mfma_kernel(FastRolloutArgs a) {
 #pragma unroll
         for (int k = 0; k < O; ++k) obs[k] = obs_init[k];
         float acc_s = 0.f, acc_b = INFINITY;
+        if (a.dbg) st1 = __builtin_readcyclecounter();
         auto run_group = [&](const float4 (&cur)[GV]) {
         float actg[G * D];
 #pragma unroll
@@ -290,6 +298,7 @@ __global__ __launch_bounds__(RWG) void rollout_mfma_kernel(FastRolloutArgs a) {
             }
         }
         const float acc_cost = use_min ? acc_b : acc_s;
+        if (a.dbg) st2 = __builtin_readcyclecounter();
         if (live) a.costs[row] = acc_cost;
         if (a.K > 0) {
             unsigned long long key = KEY_SENTINEL;
@@ -307,6 +316,11 @@ __global__ __launch_bounds__(RWG) void rollout_mfma_kernel(FastRolloutArgs a) {
             run_key = key;
             first = false;
         }
+        if (a.dbg) st3 = __builtin_readcyclecounter();
+    }
+    if (a.dbg && lane == 0) {
+        long long* d = a.dbg + (size_t)wave_gid * 8;
+        d[0] = st0; d[1] = st1; d[2] = st2; d[3] = st3;
     }
     if (a.K > 0) {
         // one sorted list per workgroup: the 4 waves' top-K meet in LDS, wave 0 sorts 4*K <= 128 keys
@@ -329,92 +343,102 @@ __global__ __launch_bounds__(RWG) void rollout_mfma_kernel(FastRolloutArgs a) {
                 a.part_c[(size_t)blockIdx.x * a.K + lane] = key_cost(k2);
                 a.part_i[(size_t)blockIdx.x * a.K + lane] = key_idx(k2);
             }
+            if (a.dbg && lane == 0) a.dbg[(size_t)wave_gid * 8 + 4] = __builtin_readcyclecounter();
         }
     }
 }
 
 // -------------------------------------------------------------------------------------------------
-// merge: global sorted top-K from <= 256 sorted candidate lists (+ kept elites)
+// merge: global sorted top-K from <= 256 sorted candidate lists (+ kept elites), one wavefront
 // -------------------------------------------------------------------------------------------------
-constexpr int MERGE_WG = 256;  // 4 wavefronts, one candidate list per thread
+constexpr int MERGE_WG = 64;  // ONE wavefront: no LDS hops, no barriers in the selection rounds
+constexpr int LPL = 4;        // candidate lists per lane (<= 256 lists)
 
-template <int CTRL>
+template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ unsigned long long min_dpp(unsigned long long x) {
-    // lanes whose DPP source is invalid keep their own value (old = x, bound_ctrl off)
-    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)x, (int)(unsigned)x, CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(x >> 32), (int)(unsigned)(x >> 32), CTRL, 0xF, 0xF, false);
+    // lanes whose DPP source is invalid / masked keep their own value (old = x, bound_ctrl off)
+    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)x, (int)(unsigned)x, CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(x >> 32), (int)(unsigned)(x >> 32), CTRL, ROW_MASK, 0xF, false);
     const unsigned long long o = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
     return o < x ? o : x;
 }
 
-// min over the 64 lanes, returned wave-uniform: 4 DPP butterflies inside each row of 16 lanes
-// (quad xor 1, quad xor 2, half-row mirror, row mirror), then the 4 row minima through SGPRs.
+// min over the 64 lanes, returned wave-uniform.  DPP only: butterflies inside each row of 16 lanes
+// (quad xor 1, quad xor 2, half-row mirror, row mirror), then row_bcast:15 into rows 1/3 and
+// row_bcast:31 into rows 2/3; lane 63 ends up with the total.
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long x) {
-    x = min_dpp<0xB1>(x);   // quad_perm [1,0,3,2]
-    x = min_dpp<0x4E>(x);   // quad_perm [2,3,0,1]
-    x = min_dpp<0x141>(x);  // row_half_mirror
-    x = min_dpp<0x140>(x);  // row_mirror
-    unsigned long long r = ~0ull;
-#pragma unroll
-    for (int row = 0; row < 4; ++row) {
-        const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)x, row * 16);
-        const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(x >> 32), row * 16);
-        const unsigned long long v = ((unsigned long long)hi << 32) | lo;
-        r = v < r ? v : r;
-    }
-    return r;
+    x = min_dpp<0xB1, 0xF>(x);   // quad_perm [1,0,3,2]
+    x = min_dpp<0x4E, 0xF>(x);   // quad_perm [2,3,0,1]
+    x = min_dpp<0x141, 0xF>(x);  // row_half_mirror
+    x = min_dpp<0x140, 0xF>(x);  // row_mirror
+    x = min_dpp<0x142, 0xA>(x);  // row_bcast:15 -> rows 1 and 3
+    x = min_dpp<0x143, 0xC>(x);  // row_bcast:31 -> rows 2 and 3
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)x, 63);
+    const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(x >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
 }
 
 template <int KREG>
 __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs a) {
-    __shared__ unsigned long long red[2][MERGE_WG / 64];
     __shared__ unsigned long long sel[64];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* new_mean = reinterpret_cast<float*>(smem_raw);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int hd = a.h * a.d;
-    // thread t owns candidate list t, sorted, in registers; winners pop by shifting the registers
-    unsigned long long k[KREG];
+    // lane t owns candidate lists t, t+64, t+128, t+192 (each sorted) in registers; a winner pops by
+    // shifting its list's registers
+    unsigned long long k[LPL][KREG];
     {
         // all loads issued up front from clamped (always valid) addresses, selected afterwards
-        int idxs[KREG];
-        float cs[KREG];
-        const bool has_list = tid < a.n_lists;
-        const size_t base = (size_t)(has_list ? tid : 0) * a.K;
+        int idxs[LPL][KREG];
+        float cs[LPL][KREG];
 #pragma unroll
-        for (int i = 0; i < KREG; ++i) {
-            const int ii = i < a.K ? i : 0;
-            idxs[i] = a.part_i[base + ii];
-            cs[i] = a.part_c[base + ii];
+        for (int l = 0; l < LPL; ++l) {
+            const int list = tid + l * MERGE_WG;
+            const size_t base = (size_t)(list < a.n_lists ? list : 0) * a.K;
+#pragma unroll
+            for (int i = 0; i < KREG; ++i) {
+                const int ii = i < a.K ? i : 0;
+                idxs[l][i] = a.part_i[base + ii];
+                cs[l][i] = a.part_c[base + ii];
+            }
         }
 #pragma unroll
-        for (int i = 0; i < KREG; ++i) {
-            const bool ok = has_list && i < a.K && idxs[i] != INT_MAX;
-            const unsigned long long v = make_key(cs[i], idxs[i]);
-            k[i] = ok ? v : KEY_SENTINEL;
+        for (int l = 0; l < LPL; ++l) {
+            const bool has_list = tid + l * MERGE_WG < a.n_lists;
+#pragma unroll
+            for (int i = 0; i < KREG; ++i) {
+                const bool ok = has_list && i < a.K && idxs[l][i] != INT_MAX;
+                const unsigned long long v = make_key(cs[l][i], idxs[l][i]);
+                k[l][i] = ok ? v : KEY_SENTINEL;
+            }
         }
     }
-    if (tid < a.n_keep) {  // kept elite `tid` (icem.py:143-145) joins this thread's list, order preserved
+    if (tid < a.n_keep) {  // kept elite `tid` (icem.py:143-145) joins this lane's first list, order preserved
         unsigned long long v = make_key(a.elites_cost_cur[tid], a.n_global + tid);
 #pragma unroll
         for (int i = 0; i < KREG; ++i) {
-            const bool sw = v < k[i];
-            const unsigned long long t = sw ? k[i] : v;
-            k[i] = sw ? v : k[i];
+            const bool sw = v < k[0][i];
+            const unsigned long long t = sw ? k[0][i] : v;
+            k[0][i] = sw ? v : k[0][i];
             v = t;
         }
     }
-    if (a.dbg_stop == 1) { if (k[0] == 12345ull) a.best_cost[0] = 1.f; return; }
+    if (a.dbg_stop == 1) { if (k[0][0] == 12345ull) a.best_cost[0] = 1.f; return; }
     for (int r = 0; r < a.K; ++r) {
-        const unsigned long long wmin = wave_min_u64(k[0]);
-        if (lane == 0) red[r & 1][wave] = wmin;
-        __syncthreads();
-        unsigned long long v = lane < MERGE_WG / 64 ? red[r & 1][lane] : ~0ull;
-        const unsigned long long best = wave_min_u64(v);
-        if (k[0] == best && best != KEY_SENTINEL) {  // unique: keys embed the trajectory index
+        unsigned long long mine = k[0][0];
 #pragma unroll
-            for (int i = 0; i + 1 < KREG; ++i) k[i] = k[i + 1];
-            k[KREG - 1] = KEY_SENTINEL;
+        for (int l = 1; l < LPL; ++l) mine = k[l][0] < mine ? k[l][0] : mine;
+        const unsigned long long best = wave_min_u64(mine);
+        if (best != KEY_SENTINEL) {  // keys embed the trajectory index: exactly one (lane, list) matches
+#pragma unroll
+            for (int l = 0; l < LPL; ++l) {
+                if (k[l][0] == best) {
+#pragma unroll
+                    for (int i = 0; i + 1 < KREG; ++i) k[l][i] = k[l][i + 1];
+                    k[l][KREG - 1] = KEY_SENTINEL;
+                }
+            }
         }
         if (tid == 0) sel[r] = best;
     }
@@ -480,9 +504,9 @@ void launch_rollout_mfma(const FastRolloutArgs& a, int h, int d, int O, int kind
 #define X(HH, DD, OO)                                                                                         \
     if (h == HH && d == DD && O == OO) {                                                                      \
         if (kind == 1)                                                                                        \
-            hipLaunchKernelGGL((rollout_mfma_kernel<HH, DD, OO, 1>), dim3(grid), dim3(RWG), 0, st, a);         \
+            hipLaunchKernelGGL((rollout_mfma_kernel<HH, DD, OO, 1>), dim3(grid), dim3(RWG), ROLLOUT_LDS_PAD, st, a);         \
         else                                                                                                  \
-            hipLaunchKernelGGL((rollout_mfma_kernel<HH, DD, OO, 0>), dim3(grid), dim3(RWG), 0, st, a);         \
+            hipLaunchKernelGGL((rollout_mfma_kernel<HH, DD, OO, 0>), dim3(grid), dim3(RWG), ROLLOUT_LDS_PAD, st, a);         \
         return;                                                                                               \
     }
     ICEM_FAST_SHAPES(X)

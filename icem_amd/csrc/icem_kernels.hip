@@ -595,6 +595,7 @@ struct icem_handle {
         hipEvent_t a, b;
     };
     bool use_fast = true;
+    long long* dbg = nullptr;
     int fast_lists = 0;  // candidate lists written by the last matrix-pipe rollout (0 = generic path ran)
     // permuted, padded model of the matrix-pipe rollout: column 0 = obs[lin_idx], column 1 = obs[flip_idx]
     void* Mp_dev = nullptr;
@@ -900,6 +901,7 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
     a.costs = (float*)costs;
     a.part_c = part_c;
     a.part_i = part_i;
+    a.dbg = h->dbg;
     const int tiles = (n_rows + 63) / 64;
     const int grid = std::max(1, std::min((tiles + 3) / 4, FAST_MAX_LISTS));
     {
@@ -1359,7 +1361,7 @@ int icem_reset_distribution(icem_handle* h, void* mean, void* std, const void* l
 
 int icem_debug_stamps(icem_handle* h, void* dev_ptr) {
     if (check_handle(h)) return ICEM_E_INVALID;
-    (void)dev_ptr;
+    h->dbg = (long long*)dev_ptr;
     return ICEM_OK;
 }
 

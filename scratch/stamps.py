@@ -10,13 +10,11 @@ for N in (4096, 65536):
     pl.set_cost(c.ctrl_weight, c.lin_idx, c.lin_weight, c.flip_idx, c.flip_penalty, c.flip_thresh)
     pl.reset(); obs = 0.1*np.random.RandomState(0).randn(17)
     for _ in range(3): pl.plan_step(obs)
-    dbg = torch.zeros((1024, 8), dtype=torch.int64, device="cuda")
+    dbg = torch.zeros((2048, 8), dtype=torch.int64, device="cuda")
     L.check(pl.lib.icem_debug_stamps(pl._h, C.c_void_p(dbg.data_ptr())))
     pl.plan_step(obs); torch.cuda.synchronize()
     d = dbg.cpu().numpy(); d = d[d[:, 0] > 0]
-    t0 = d[:, 0].min()
-    names = ["start->S done", "S->W done(R start)", "R", "K", "total(first tile)"]
-    seg = np.stack([d[:,1]-d[:,0], d[:,2]-d[:,1], d[:,3]-d[:,2], d[:,4]-d[:,3], d[:,5]-d[:,0]], 1)
-    print(f"N={N}: WGs={len(d)}  cycles median per phase (first tile of each WG):")
-    for i, nme in enumerate(names): print(f"   {nme:24s} median {np.median(seg[:,i]):9.0f}  min {seg[:,i].min():9.0f} max {seg[:,i].max():9.0f}")
-    print("   kernel span cycles:", d[:,5].max() - t0, " start skew:", d[:,0].max()-t0)
+    seg = np.stack([d[:,1]-d[:,0], d[:,2]-d[:,1], d[:,3]-d[:,2]], 1)
+    print(f"N={N}: waves={len(d)} median cycles: load model+first actions {np.median(seg[:,0]):.0f}, time loop {np.median(seg[:,1]):.0f} ({np.median(seg[:,1])/30:.0f}/step), tile sort {np.median(seg[:,2]):.0f}; loop min/max {seg[:,1].min()}/{seg[:,1].max()}")
+    w0 = d[d[:,4] > 0]
+    if len(w0): print("   wg merge (wave 0):", np.median(w0[:,4]-w0[:,3]))
