@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile_round.sh output dir into profiles/: kernel stats (copied) + per-kernel HBM
+traffic from the FETCH_SIZE / WRITE_SIZE passes.  usage: summarize_profile.py gpurun_out/r01-c4 profiles/r01_c4"""
+import csv, json, os, shutil, sys
+from collections import defaultdict
+
+src, dst = sys.argv[1], sys.argv[2]
+os.makedirs(os.path.dirname(dst), exist_ok=True)
+shutil.copy(os.path.join(src, "trace", "t_kernel_stats.csv"), dst + "_kernel_stats.csv")
+bench = open(os.path.join(src, "bench_trace.json")).read().strip().splitlines()[-1]
+open(dst + "_bench_under_rocprof.json", "w").write(bench + "\n")
+
+
+def counter(path, name):
+    acc = defaultdict(lambda: [0.0, 0])
+    for row in csv.DictReader(open(path)):
+        if row["Counter_Name"] == name:
+            nm = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+            k = nm.split("(")[0][:60] + f" grid={row['Grid_Size']}"
+            acc[k][0] += float(row["Counter_Value"])
+            acc[k][1] += 1
+    return acc
+
+
+fetch = counter(os.path.join(src, "pmc_fetch", "f_counter_collection.csv"), "FETCH_SIZE")
+write = counter(os.path.join(src, "pmc_write", "w_counter_collection.csv"), "WRITE_SIZE")
+with open(dst + "_hbm_traffic.md", "w") as f:
+    f.write("# HBM traffic per launch from rocprofv3 PMC passes (separate runs: --pmc FETCH_SIZE, --pmc WRITE_SIZE)\n\n")
+    f.write("Units: counters are KiB. Per MI355X_MICROARCH.md §HBM, FETCH_SIZE on gfx950 reports half the bytes of a wide\n"
+            "coalesced read: the `fetch x2` column applies that correction; WRITE_SIZE is uncalibrated (reported raw).\n\n")
+    f.write("| kernel (grid threads) | launches | FETCH_SIZE KiB/launch | fetch x2 MB | WRITE_SIZE KiB/launch | write MB |\n|---|---|---|---|---|---|\n")
+    for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch[k][0] + write[k][0])):
+        fv, fn = fetch[k]
+        wv, wn = write[k]
+        if max(fn, wn) < 5 or "icem" not in k:
+            continue
+        fa = fv / max(fn, 1)
+        wa = wv / max(wn, 1)
+        f.write(f"| `{k}` | {max(fn, wn)} | {fa:.1f} | {2 * fa * 1024 / 1e6:.2f} | {wa:.1f} | {wa * 1024 / 1e6:.2f} |\n")
+print(open(dst + "_hbm_traffic.md").read())
