@@ -247,12 +247,13 @@ __global__ __launch_bounds__(RWG) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int ct = 0; ct < CTF; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < REM; ++r) accr[r] = 0.f;
+            // VALU block first, as ONE cluster: on gfx950 every MFMA<->VALU switch of a lone wave costs
+            // ~12 cycles (scratch/ubench3: 92 MFMAs = 762 cycles alone, 1862 with one v_fmac after each),
+            // so nothing may be interleaved into the MFMA stream.
+            // leftover model columns as scalar-operand FMA chains (same k order as the MFMA chain)
 #pragma unroll
             for (int k = 0; k < KK; ++k) {
                 const float x = k < O ? obs[k < O ? k : 0] : act[k >= O ? k - O : 0];
-#pragma unroll
-                for (int ct = 0; ct < CTF; ++ct)
-                    acc[ct] = __builtin_amdgcn_mfma_f32_4x4x1f32(mA[k][ct], x, acc[ct], 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < REM; ++r) accr[r] = __builtin_fmaf(x, mR[k][r], accr[r]);
             }
@@ -268,6 +269,16 @@ __global__ __launch_bounds__(RWG) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             c += a.lin_w * obs[0];
             acc_s = __builtin_fmaf(acc_s, ksum, c);
             acc_b = c < acc_b ? c : acc_b;
+            __builtin_amdgcn_sched_barrier(0);
+            // matrix-pipe block: (o+d) x floor(o/4) back-to-back MFMAs, 4 independent accumulator chains
+#pragma unroll
+            for (int k = 0; k < KK; ++k) {
+                const float x = k < O ? obs[k < O ? k : 0] : act[k >= O ? k - O : 0];
+#pragma unroll
+                for (int ct = 0; ct < CTF; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_4x4x1f32(mA[k][ct], x, acc[ct], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < O; ++k) {
                 const float v = k < CTF * 4 ? acc[k < CTF * 4 ? k / 4 : 0][k % 4] : accr[k >= CTF * 4 ? k - CTF * 4 : 0];
@@ -327,18 +338,23 @@ __global__ __launch_bounds__(RWG) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (lane < a.K) wg_keys[wave][lane] = run_key;
         __syncthreads();
         if (wave == 0) {
-            unsigned long long k0 = KEY_SENTINEL, k1 = KEY_SENTINEL;
-            if (lane < 2 * a.K) k0 = wg_keys[lane / a.K][lane % a.K];
-            if (lane < 2 * a.K) k1 = wg_keys[2 + lane / a.K][lane % a.K];
-            k0 = wave_sort64(k0, lane);
-            k1 = wave_sort64(k1, lane);
-            const unsigned long long top1 = __shfl(k1, lane - a.K, 64);
             unsigned long long k2 = KEY_SENTINEL;
-            if (lane < a.K)
-                k2 = k0;
-            else if (lane < 2 * a.K)
-                k2 = top1;
-            k2 = wave_sort64(k2, lane);
+            if (4 * a.K <= 64) {  // all 4 lists fit one key per lane: a single sort
+                if (lane < 4 * a.K) k2 = wg_keys[lane / a.K][lane % a.K];
+                k2 = wave_sort64(k2, lane);
+            } else {
+                unsigned long long k0 = KEY_SENTINEL, k1 = KEY_SENTINEL;
+                if (lane < 2 * a.K) k0 = wg_keys[lane / a.K][lane % a.K];
+                if (lane < 2 * a.K) k1 = wg_keys[2 + lane / a.K][lane % a.K];
+                k0 = wave_sort64(k0, lane);
+                k1 = wave_sort64(k1, lane);
+                const unsigned long long top1 = __shfl(k1, lane - a.K, 64);
+                if (lane < a.K)
+                    k2 = k0;
+                else if (lane < 2 * a.K)
+                    k2 = top1;
+                k2 = wave_sort64(k2, lane);
+            }
             if (lane < a.K) {
                 a.part_c[(size_t)blockIdx.x * a.K + lane] = key_cost(k2);
                 a.part_i[(size_t)blockIdx.x * a.K + lane] = key_idx(k2);

@@ -1,5 +1,5 @@
 import time, numpy as np, torch, sys
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from icem_amd import IcemConfig, IcemPlanner, DeviceSyntheticModel, halfcheetah_env
 env = halfcheetah_env(17)
 cfgs = [(4096, 5, -1), (65536, 1, -1)] if len(sys.argv) < 2 else [tuple(int(x) for x in a.split(',')) for a in sys.argv[1:]]
