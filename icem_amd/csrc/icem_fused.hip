@@ -95,12 +95,22 @@ __global__ __launch_bounds__(SWG) void sample_folded_kernel(FastSampleArgs a) {
         const int j = tid - nl * d;
         const unsigned gi = (unsigned)(a.first_index + n_base + nl);
         float g[HMAX];
+#if defined(ICEM_EXP_SKIP_RNG)
 #pragma unroll
-        for (int b = 0; b < (H + 3) / 4; ++b) {
-            const U4 r = philox4x32<ROUNDS>(gi, ((unsigned)j << 16) | (unsigned)b, a.off_lo, a.off_hi, a.seed_lo, a.seed_hi);
-            box_muller(r.x, r.y, g[4 * b], g[4 * b + 1]);
-            box_muller(r.z, r.w, g[4 * b + 2], g[4 * b + 3]);
+        for (int m = 0; m < HMAX; ++m) g[m] = (float)(gi + m) * 1e-9f;
+#else
+        Xoshiro128pp rng = row_stream<ROUNDS>(gi, (unsigned)j, a.off_lo, a.off_hi, a.seed_lo, a.seed_hi);
+#pragma unroll
+        for (int m = 0; m < H; m += 2) {
+            const uint32_t xa = rng.next();
+            const uint32_t xb = rng.next();
+#if defined(ICEM_EXP_SKIP_BM)
+            g[m] = (float)xa * 1e-9f; g[m + 1] = (float)xb * 1e-9f;
+#else
+            box_muller(xa, xb, g[m], g[m + 1]);
+#endif
         }
+#endif
         const float lo = a.low[j], hi = a.high[j];
         float* trow = tile + nl * hd + j;
         const float* mrow = ms + j;
@@ -120,6 +130,9 @@ __global__ __launch_bounds__(SWG) void sample_folded_kernel(FastSampleArgs a) {
             }
             emit(0, e0 + e1);
         }
+#if defined(ICEM_EXP_SKIP_DFT)
+        for (int tp = 1; tp <= H / 2; ++tp) { emit(tp, g[tp]); if (H - tp != tp) emit(H - tp, g[H - tp]); }
+#else
 #pragma unroll 1
         for (int tp = 1; tp <= H / 2; ++tp) {
             const float* __restrict__ w = a.W + tp * HMAX;
@@ -138,8 +151,13 @@ __global__ __launch_bounds__(SWG) void sample_folded_kernel(FastSampleArgs a) {
             emit(tp, e + od);
             if (H - tp != tp) emit(H - tp, e - od);
         }
+#endif
     }
     __syncthreads();
+#if defined(ICEM_EXP_SKIP_STORE)
+    if (a.n == 12345) a.out[tid] = tile[tid];
+    return;
+#endif
     if (a.row0_mean && a.first_index + n_base == 0) {  // icem.py:87-88
         for (int e = tid; e < hd; e += SWG) tile[e] = ms[e];
         __syncthreads();
@@ -250,12 +268,19 @@ __global__ __launch_bounds__(RWG) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // VALU block first, as ONE cluster: on gfx950 every MFMA<->VALU switch of a lone wave costs
             // ~12 cycles (scratch/ubench3: 92 MFMAs = 762 cycles alone, 1862 with one v_fmac after each),
             // so nothing may be interleaved into the MFMA stream.
-            // leftover model columns as scalar-operand FMA chains (same k order as the MFMA chain)
+            // leftover model columns as scalar-operand FMA chains
+            {
+                float part[REM > 0 ? REM : 1][4];  // 4 partial sums per column: short dependency chains
 #pragma unroll
-            for (int k = 0; k < KK; ++k) {
-                const float x = k < O ? obs[k < O ? k : 0] : act[k >= O ? k - O : 0];
+                for (int r = 0; r < REM; ++r) part[r][0] = part[r][1] = part[r][2] = part[r][3] = 0.f;
 #pragma unroll
-                for (int r = 0; r < REM; ++r) accr[r] = __builtin_fmaf(x, mR[k][r], accr[r]);
+                for (int k = 0; k < KK; ++k) {
+                    const float x = k < O ? obs[k < O ? k : 0] : act[k >= O ? k - O : 0];
+#pragma unroll
+                    for (int r = 0; r < REM; ++r) part[r][k & 3] = __builtin_fmaf(x, mR[k][r], part[r][k & 3]);
+                }
+#pragma unroll
+                for (int r = 0; r < REM; ++r) accr[r] = (part[r][0] + part[r][1]) + (part[r][2] + part[r][3]);
             }
             // cost of (o_t, a_t), branch free; column 0 holds obs[lin_idx], column 0/1 obs[flip_idx]
             float ctrl = 0.f;

@@ -100,15 +100,15 @@ __device__ __forceinline__ void white_row(const SampleArgs<T>& a, int row_local,
             g[m] = v;
         }
     } else {
+        Xoshiro128pp rng = row_stream<ROUNDS>((uint32_t)gi, (uint32_t)j, a.off_lo, a.off_hi, a.seed_lo, a.seed_hi);
 #pragma unroll
-        for (int b = 0; b < HMAX / 4; ++b) {
-            if (4 * b < a.h) {
-                const U4 r = philox4x32<ROUNDS>((uint32_t)gi, ((uint32_t)j << 16) | (uint32_t)b, a.off_lo,
-                                                a.off_hi, a.seed_lo, a.seed_hi);
-                box_muller(r.x, r.y, g[4 * b], g[4 * b + 1]);
-                box_muller(r.z, r.w, g[4 * b + 2], g[4 * b + 3]);
+        for (int m = 0; m < HMAX; m += 2) {
+            if (m < a.h) {
+                const uint32_t xa = rng.next();
+                const uint32_t xb = rng.next();
+                box_muller(xa, xb, g[m], g[m + 1]);
             } else {
-                g[4 * b] = g[4 * b + 1] = g[4 * b + 2] = g[4 * b + 3] = (T)0;
+                g[m] = g[m + 1] = (T)0;
             }
         }
     }

@@ -30,6 +30,33 @@ __device__ __forceinline__ U4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, 
     return U4{c0, c1, c2, c3};
 }
 
+// Per-row stream: ONE Philox4x32-R call keyed by (seed, call offset, trajectory, action dim) seeds a
+// xoshiro128++ state (Blackman & Vigna); the h words of the row come from that generator: 10
+// full-rate integer ops per word instead of 5 quarter-rate 32x32->64 multiplies.  Counter based where
+// it matters (any row of any call is reproducible on any shard), cheap where it is hot.
+struct Xoshiro128pp {
+    uint32_t s0, s1, s2, s3;
+    __device__ __forceinline__ uint32_t next() {
+        const uint32_t sum = s0 + s3;
+        const uint32_t result = ((sum << 7) | (sum >> 25)) + s0;
+        const uint32_t t = s1 << 9;
+        s2 ^= s0;
+        s3 ^= s1;
+        s1 ^= s2;
+        s0 ^= s3;
+        s2 ^= t;
+        s3 = (s3 << 11) | (s3 >> 21);
+        return result;
+    }
+};
+
+template <int R>
+__device__ __forceinline__ Xoshiro128pp row_stream(uint32_t traj, uint32_t dim, uint32_t off_lo, uint32_t off_hi,
+                                                   uint32_t seed_lo, uint32_t seed_hi) {
+    const U4 r = philox4x32<R>(traj, dim << 16, off_lo, off_hi, seed_lo, seed_hi);
+    return Xoshiro128pp{r.x, r.y, r.z, r.w};
+}
+
 // Two normals from two words.  f32: hardware log2 / sqrt / sin / cos (the angle is fed in
 // revolutions, which is what v_sin_f32 / v_cos_f32 take).  f64: libm-grade.
 __device__ __forceinline__ void box_muller(uint32_t xa, uint32_t xb, float& g0, float& g1) {

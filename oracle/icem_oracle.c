@@ -9,7 +9,7 @@
  *   rollout + cost  icem/models/abstract_models.py:17-53, icem/controllers/abstract_controller.py:74-91,
  *                   icem/environments/mujoco.py:67-99 / 259-277 (parametric form)
  *   elites + refit  icem/controllers/icem.py:194-211 (argsort()[:K], mean, population std, momentum)
- * RNG: Philox4x32-R + Box-Muller, keyed exactly like the device path (see oracle/icem_oracle.py
+ * RNG: Philox4x32-R-seeded xoshiro128++ + Box-Muller, keyed exactly like the device path (see oracle/icem_oracle.py
  * philox_white_noise); pinned against the NumPy oracle by tests/test_oracle_c.py, which is itself
  * pinned against golden vectors captured from the reference.
  *
@@ -47,17 +47,28 @@ static void box_muller(uint32_t xa, uint32_t xb, double* g0, double* g1) {
     *g1 = r * sin(ang);
 }
 
-/* h white normals of row (n, j): g[m], m < F real part of bin m, m >= F imaginary part of bin m-F+1 */
+/* h white normals of row (n, j): one Philox call seeds xoshiro128++; normals 2i, 2i+1 from words 2i, 2i+1.
+ * g[m], m < F real part of bin m, m >= F imaginary part of bin m-F+1 */
 static void white_row(uint64_t seed, uint64_t offset, uint32_t n, uint32_t j, int h, int rounds, double* g) {
-    const int nb = (h + 3) / 4;
-    double tmp[4];
-    for (int b = 0; b < nb; ++b) {
-        uint32_t c[4] = {n, (j << 16) | (uint32_t)b, (uint32_t)offset, (uint32_t)(offset >> 32)};
-        philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32), rounds);
-        box_muller(c[0], c[1], &tmp[0], &tmp[1]);
-        box_muller(c[2], c[3], &tmp[2], &tmp[3]);
-        for (int r = 0; r < 4; ++r)
-            if (4 * b + r < h) g[4 * b + r] = tmp[r];
+    uint32_t s[4] = {n, j << 16, (uint32_t)offset, (uint32_t)(offset >> 32)};
+    philox4x32(s, (uint32_t)seed, (uint32_t)(seed >> 32), rounds);
+    double tmp[2];
+    for (int m = 0; m < h; m += 2) {
+        uint32_t x[2];
+        for (int q = 0; q < 2; ++q) {
+            const uint32_t sum = s[0] + s[3];
+            x[q] = ((sum << 7) | (sum >> 25)) + s[0];
+            const uint32_t t = s[1] << 9;
+            s[2] ^= s[0];
+            s[3] ^= s[1];
+            s[1] ^= s[2];
+            s[0] ^= s[3];
+            s[2] ^= t;
+            s[3] = (s[3] << 11) | (s[3] >> 21);
+        }
+        box_muller(x[0], x[1], &tmp[0], &tmp[1]);
+        g[m] = tmp[0];
+        if (m + 1 < h) g[m + 1] = tmp[1];
     }
 }
 

@@ -122,7 +122,7 @@ def legacy_white_noise(num: int, d: int, h: int) -> Tuple[np.ndarray, np.ndarray
 
 
 # --------------------------------------------------------------------------
-# Philox4x32 counter RNG + Box-Muller (the build's device RNG, restated)
+# Philox4x32-seeded xoshiro128++ + Box-Muller (the build's device RNG, restated)
 # --------------------------------------------------------------------------
 
 _M0 = np.uint64(0xD2511F53)
@@ -173,29 +173,48 @@ def box_muller(xa: np.ndarray, xb: np.ndarray, dtype=np.float64):
     return (r * np.cos(ang)).astype(np.float32), (r * np.sin(ang)).astype(np.float32)
 
 
+def xoshiro128pp_words(s0, s1, s2, s3, count: int):
+    """``count`` successive outputs of xoshiro128++ (Blackman & Vigna) for arrays of uint32 states
+    (held in uint64 arrays)."""
+    M = _MASK
+    out = []
+    for _ in range(count):
+        sm = (s0 + s3) & M
+        res = ((((sm << np.uint64(7)) | (sm >> np.uint64(25))) & M) + s0) & M
+        t = (s1 << np.uint64(9)) & M
+        s2 = s2 ^ s0
+        s3 = s3 ^ s1
+        s1 = s1 ^ s2
+        s0 = s0 ^ s3
+        s2 = s2 ^ t
+        s3 = ((s3 << np.uint64(11)) | (s3 >> np.uint64(21))) & M
+        out.append(res)
+    return out
+
+
 def philox_white_noise(seed: int, offset: int, num: int, d: int, h: int,
                        first_index: int = 0, rounds: int = 10,
                        dtype=np.float64) -> Tuple[np.ndarray, np.ndarray]:
-    """White draws ``z_r, z_i [num, d, F]`` from the build's counter RNG.
+    """White draws ``z_r, z_i [num, d, F]`` from the build's device RNG.
 
-    Row ``(n, j)`` (n = *global* trajectory index ``first_index + local``)
-    uses Philox counters ``(n, (j<<16)|b, offset_lo, offset_hi)``, key
-    ``(seed_lo, seed_hi)``, ``b = 0..ceil(h/4)-1``.  Block ``b`` yields the
-    normals ``m = 4b..4b+3`` via Box-Muller on word pairs (0,1) and (2,3).
-    Normal ``m < F`` is ``z_r[k=m]``; ``m >= F`` is ``z_i[k=m-F+1]``.  Unused
-    ``z_i`` slots (DC, even-h Nyquist) are returned as 0.
+    Row ``(n, j)`` (n = *global* trajectory index ``first_index + local``): ONE
+    Philox4x32-``rounds`` call with counter ``(n, j<<16, offset_lo, offset_hi)`` and key
+    ``(seed_lo, seed_hi)`` seeds a xoshiro128++ state; its successive words ``x_0, x_1, ...``
+    give the normals ``m = 2i, 2i+1`` by Box-Muller on ``(x_{2i}, x_{2i+1})``.  Normal
+    ``m < F`` is ``z_r[k=m]``; ``m >= F`` is ``z_i[k=m-F+1]``.  Unused ``z_i`` slots (DC,
+    even-h Nyquist) are returned as 0.
     """
     F = h // 2 + 1
-    nb = (h + 3) // 4
-    n_idx = (first_index + np.arange(num, dtype=np.uint64))[:, None, None]
-    j_idx = np.arange(d, dtype=np.uint64)[None, :, None]
-    b_idx = np.arange(nb, dtype=np.uint64)[None, None, :]
-    c1 = (j_idx << np.uint64(16)) | b_idx
-    x0, x1, x2, x3 = philox4x32(n_idx, c1, offset & 0xFFFFFFFF, (offset >> 32) & 0xFFFFFFFF,
+    n_idx = np.broadcast_to((first_index + np.arange(num, dtype=np.uint64))[:, None], (num, d))
+    j_idx = np.broadcast_to((np.arange(d, dtype=np.uint64) << np.uint64(16))[None, :], (num, d))
+    s0, s1, s2, s3 = philox4x32(n_idx, j_idx, offset & 0xFFFFFFFF, (offset >> 32) & 0xFFFFFFFF,
                                 seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, rounds)
-    g0, g1 = box_muller(x0, x1, dtype)
-    g2, g3 = box_muller(x2, x3, dtype)
-    g = np.stack([g0, g1, g2, g3], axis=-1).reshape(num, d, nb * 4)[..., :h]
+    npairs = (h + 1) // 2
+    words = xoshiro128pp_words(s0, s1, s2, s3, 2 * npairs)
+    g = np.empty((num, d, 2 * npairs), dtype=dtype)
+    for i in range(npairs):
+        g[..., 2 * i], g[..., 2 * i + 1] = box_muller(words[2 * i], words[2 * i + 1], dtype)
+    g = g[..., :h]
     z_r = np.ascontiguousarray(g[..., :F])
     z_i = np.zeros((num, d, F), dtype=dtype)
     n_im = h - F
