@@ -46,6 +46,34 @@ struct FastRolloutArgs {
 bool fast_rollout_supported(int h, int d, int O, int K);
 void launch_rollout_mfma(const FastRolloutArgs& a, int h, int d, int O, int kind, int grid, hipStream_t st);
 
+// Fused iteration (sample + rollout + cost + per-workgroup top-K in one launch); same shape list as the
+// matrix-pipe rollout.  Field names shared with FastRolloutArgs are read by the same device code.
+struct FusedArgs {
+    int n;        // trajectories to sample: rows [0, n) of `actions`
+    int n_extra;  // pre-filled rows [n, n + n_extra) (shifted elites): rolled out, not sampled
+    int n_cand;   // rows [0, n_cand) enter the top-K
+    int K, h, d, o, cost_mode, row0_mean;
+    int tpb;      // trajectories per workgroup pass: 64, 128 or 256
+    long long first_index;
+    const float* W;
+    const float* mean;
+    const float* std;
+    const float* low;
+    const float* high;
+    uint32_t seed_lo, seed_hi, off_lo, off_hi;
+    const float* Mp;
+    const int* perm;
+    const float* obs0;
+    float ctrl_w, lin_w, flip_pen, flip_th;
+    int flip_col;
+    float* actions;
+    float* costs;
+    float* part_c;
+    int* part_i;
+    long long* dbg;
+};
+void launch_fused_iter(const FusedArgs& a, int O, int kind, int rounds, int grid, hipStream_t st);
+
 // world == 1: global sorted top-K straight from the waves' candidate lists (+ kept elites), gather of
 // the elite rows from the pool, refit, and the last-iteration epilogue.
 struct MergeSingleArgs {

@@ -72,10 +72,128 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // -------------------------------------------------------------------------------------------------
 // K1
 // -------------------------------------------------------------------------------------------------
-template <int H, int ROUNDS>
-__global__ __launch_bounds__(SWG) void sample_folded_kernel(FastSampleArgs a) {
+// The h colored samples of one (trajectory, action-dim) row: per-row RNG stream -> Box-Muller -> h white
+// draws in registers -> inverse real DFT folded on its symmetry; emit(t, y) receives sample y of step t.
+template <int H, int ROUNDS, typename Emit>
+__device__ __forceinline__ void sample_row(const float* __restrict__ W, unsigned gi, unsigned j, unsigned off_lo,
+                                           unsigned off_hi, unsigned seed_lo, unsigned seed_hi, Emit&& emit) {
     constexpr int F = H / 2 + 1;
     static_assert(H <= 32 && H >= 2, "white draws of a row live in 32 registers");
+    float g[HMAX];
+    Xoshiro128pp rng = row_stream<ROUNDS>(gi, j, off_lo, off_hi, seed_lo, seed_hi);
+#pragma unroll
+    for (int m = 0; m < H; m += 2) {
+        const uint32_t xa = rng.next();
+        const uint32_t xb = rng.next();
+        box_muller(xa, xb, g[m], g[m + 1]);
+    }
+    {  // t = 0: every sine is zero
+        float e0 = 0.f, e1 = 0.f;
+#pragma unroll
+        for (int m = 0; m < F; m += 2) {
+            e0 = __builtin_fmaf(g[m], W[m], e0);
+            if (m + 1 < F) e1 = __builtin_fmaf(g[m + 1], W[m + 1], e1);
+        }
+        emit(0, e0 + e1);
+    }
+    // table rows are wave-uniform scalar loads: double-buffered so the load of row tp+1 flies under the
+    // FMAs of row tp (the compiler otherwise waits for each row right after issuing its load)
+    float wc[HMAX];
+#pragma unroll
+    for (int m = 0; m < H; ++m) wc[m] = W[HMAX + m];
+#pragma unroll 1
+    for (int tp = 1; tp <= H / 2; ++tp) {
+        float wn[HMAX];
+        const float* __restrict__ wnext = W + (tp < H / 2 ? tp + 1 : tp) * HMAX;
+#pragma unroll
+        for (int m = 0; m < H; ++m) wn[m] = wnext[m];
+        float e0 = 0.f, e1 = 0.f, o0 = 0.f, o1 = 0.f;
+#pragma unroll
+        for (int m = 0; m < F; m += 2) {
+            e0 = __builtin_fmaf(g[m], wc[m], e0);
+            if (m + 1 < F) e1 = __builtin_fmaf(g[m + 1], wc[m + 1], e1);
+        }
+#pragma unroll
+        for (int m = F; m < H; m += 2) {
+            o0 = __builtin_fmaf(g[m], wc[m], o0);
+            if (m + 1 < H) o1 = __builtin_fmaf(g[m + 1], wc[m + 1], o1);
+        }
+        const float e = e0 + e1, od = o0 + o1;
+        emit(tp, e + od);
+        if (H - tp != tp) emit(H - tp, e - od);
+#pragma unroll
+        for (int m = 0; m < H; ++m) wc[m] = wn[m];
+    }
+}
+
+// NR rows at once (independent RNG / DFT chains interleaved by the unrolled r loops): instruction-level
+// parallelism for the low-occupancy fused kernel.  emit(r, t, y).
+template <int H, int ROUNDS, int NR, typename Emit>
+__device__ __forceinline__ void sample_rows(const float* __restrict__ W, const unsigned (&gi)[NR], const unsigned (&jj)[NR],
+                                            unsigned off_lo, unsigned off_hi, unsigned seed_lo, unsigned seed_hi,
+                                            Emit&& emit, long long* tst = nullptr) {
+    constexpr int F = H / 2 + 1;
+    static_assert(H <= 32 && H >= 2, "white draws of a row live in 32 registers");
+    float g[NR][HMAX];
+    Xoshiro128pp rng[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) rng[r] = row_stream<ROUNDS>(gi[r], jj[r], off_lo, off_hi, seed_lo, seed_hi);
+#pragma unroll
+    for (int m = 0; m < H; m += 2) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const uint32_t xa = rng[r].next();
+            const uint32_t xb = rng[r].next();
+            box_muller(xa, xb, g[r][m], g[r][m + 1]);
+        }
+    }
+    if (tst) { __builtin_amdgcn_sched_barrier(0); tst[0] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+    {  // t = 0: every sine is zero
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            float e0 = 0.f, e1 = 0.f;
+#pragma unroll
+            for (int m = 0; m < F; m += 2) {
+                e0 = __builtin_fmaf(g[r][m], W[m], e0);
+                if (m + 1 < F) e1 = __builtin_fmaf(g[r][m + 1], W[m + 1], e1);
+            }
+            emit(r, 0, e0 + e1);
+        }
+    }
+    float wc[HMAX];
+#pragma unroll
+    for (int m = 0; m < H; ++m) wc[m] = W[HMAX + m];
+#pragma unroll 1
+    for (int tp = 1; tp <= H / 2; ++tp) {
+        float wn[HMAX];
+        const float* __restrict__ wnext = W + (tp < H / 2 ? tp + 1 : tp) * HMAX;
+#pragma unroll
+        for (int m = 0; m < H; ++m) wn[m] = wnext[m];
+        const float* w = wc;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            float e0 = 0.f, e1 = 0.f, o0 = 0.f, o1 = 0.f;
+#pragma unroll
+            for (int m = 0; m < F; m += 2) {
+                e0 = __builtin_fmaf(g[r][m], w[m], e0);
+                if (m + 1 < F) e1 = __builtin_fmaf(g[r][m + 1], w[m + 1], e1);
+            }
+#pragma unroll
+            for (int m = F; m < H; m += 2) {
+                o0 = __builtin_fmaf(g[r][m], w[m], o0);
+                if (m + 1 < H) o1 = __builtin_fmaf(g[r][m + 1], w[m + 1], o1);
+            }
+            const float e = e0 + e1, od = o0 + o1;
+            emit(r, tp, e + od);
+            if (H - tp != tp) emit(r, H - tp, e - od);
+        }
+#pragma unroll
+        for (int m = 0; m < H; ++m) wc[m] = wn[m];
+    }
+}
+
+template <int H, int ROUNDS>
+__global__ __launch_bounds__(SWG) void sample_folded_kernel(FastSampleArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int d = a.d;
     const int hd = H * d;
@@ -93,71 +211,18 @@ __global__ __launch_bounds__(SWG) void sample_folded_kernel(FastSampleArgs a) {
     if (tid < n_here * d) {
         const int nl = tid / d;
         const int j = tid - nl * d;
-        const unsigned gi = (unsigned)(a.first_index + n_base + nl);
-        float g[HMAX];
-#if defined(ICEM_EXP_SKIP_RNG)
-#pragma unroll
-        for (int m = 0; m < HMAX; ++m) g[m] = (float)(gi + m) * 1e-9f;
-#else
-        Xoshiro128pp rng = row_stream<ROUNDS>(gi, (unsigned)j, a.off_lo, a.off_hi, a.seed_lo, a.seed_hi);
-#pragma unroll
-        for (int m = 0; m < H; m += 2) {
-            const uint32_t xa = rng.next();
-            const uint32_t xb = rng.next();
-#if defined(ICEM_EXP_SKIP_BM)
-            g[m] = (float)xa * 1e-9f; g[m + 1] = (float)xb * 1e-9f;
-#else
-            box_muller(xa, xb, g[m], g[m + 1]);
-#endif
-        }
-#endif
         const float lo = a.low[j], hi = a.high[j];
         float* trow = tile + nl * hd + j;
         const float* mrow = ms + j;
-        auto emit = [&](int t, float y) {
-            float v = __builtin_fmaf(y, mrow[hd + t * d], mrow[t * d]);
-            v = v < lo ? lo : v;
-            v = v > hi ? hi : v;
-            trow[t * d] = v;
-        };
-        {  // t = 0: every sine is zero
-            const float* __restrict__ w = a.W;
-            float e0 = 0.f, e1 = 0.f;
-#pragma unroll
-            for (int m = 0; m < F; m += 2) {
-                e0 = __builtin_fmaf(g[m], w[m], e0);
-                if (m + 1 < F) e1 = __builtin_fmaf(g[m + 1], w[m + 1], e1);
-            }
-            emit(0, e0 + e1);
-        }
-#if defined(ICEM_EXP_SKIP_DFT)
-        for (int tp = 1; tp <= H / 2; ++tp) { emit(tp, g[tp]); if (H - tp != tp) emit(H - tp, g[H - tp]); }
-#else
-#pragma unroll 1
-        for (int tp = 1; tp <= H / 2; ++tp) {
-            const float* __restrict__ w = a.W + tp * HMAX;
-            float e0 = 0.f, e1 = 0.f, o0 = 0.f, o1 = 0.f;
-#pragma unroll
-            for (int m = 0; m < F; m += 2) {
-                e0 = __builtin_fmaf(g[m], w[m], e0);
-                if (m + 1 < F) e1 = __builtin_fmaf(g[m + 1], w[m + 1], e1);
-            }
-#pragma unroll
-            for (int m = F; m < H; m += 2) {
-                o0 = __builtin_fmaf(g[m], w[m], o0);
-                if (m + 1 < H) o1 = __builtin_fmaf(g[m + 1], w[m + 1], o1);
-            }
-            const float e = e0 + e1, od = o0 + o1;
-            emit(tp, e + od);
-            if (H - tp != tp) emit(H - tp, e - od);
-        }
-#endif
+        sample_row<H, ROUNDS>(a.W, (unsigned)(a.first_index + n_base + nl), (unsigned)j, a.off_lo, a.off_hi, a.seed_lo,
+                              a.seed_hi, [&](int t, float y) {
+                                  float v = __builtin_fmaf(y, mrow[hd + t * d], mrow[t * d]);
+                                  v = v < lo ? lo : v;
+                                  v = v > hi ? hi : v;
+                                  trow[t * d] = v;
+                              });
     }
     __syncthreads();
-#if defined(ICEM_EXP_SKIP_STORE)
-    if (a.n == 12345) a.out[tid] = tile[tid];
-    return;
-#endif
     if (a.row0_mean && a.first_index + n_base == 0) {  // icem.py:87-88
         for (int e = tid; e < hd; e += SWG) tile[e] = ms[e];
         __syncthreads();
@@ -182,51 +247,209 @@ __device__ __forceinline__ float act_fn(float x, std::integral_constant<int, 1>)
 // steps per 16-byte-aligned action group: smallest G with (G*D) % 4 == 0
 __host__ __device__ constexpr int group_steps(int d) { return d % 4 == 0 ? 1 : (d % 2 == 0 ? 2 : 4); }
 
+#ifndef ICEM_REM_ON_VALU
+#define ICEM_REM_ON_VALU 1
+#endif
+
+// Everything a wavefront needs to roll 64 trajectories out on the matrix pipe (lane = trajectory).
+template <int H, int D, int O, int KIND>
+struct RolloutWave {
+    static constexpr int CTF = ICEM_REM_ON_VALU ? O / 4 : (O + 3) / 4;  // column tiles of 4 on the matrix pipe
+    static constexpr int REM = ICEM_REM_ON_VALU ? O % 4 : 0;  // leftover columns: FMA chains on the VALU
+    static constexpr int CT4 = ((O + 3) / 4) * 4;
+    static constexpr int KK = O + D;  // contraction length of one model step
+    static constexpr int G = group_steps(D);
+    static constexpr int GV = G * D / 4;  // float4 per group
+    static constexpr int HD = H * D;
+    static constexpr int NG = H / G;  // action groups per trajectory
+    static constexpr int RING = NG >= 5 ? 5 : (NG >= 3 ? 3 : NG);  // prefetch ring depth (groups)
+    static_assert(H % G == 0 && HD % 4 == 0, "action rows must split into 16-byte groups");
+    static_assert(CTF >= 1, "at least one full column tile");
+
+    // model operand of the MFMA: lane holds Mp[k][4*ct + (lane & 3)]; leftover columns are uniform
+    float mA[KK][CTF];
+    float mR[KK][REM > 0 ? REM : 1];
+    float obs_init[O];
+    float pen, ksum, flip_th, ctrl_w, lin_w;
+    bool ang_is_col1, use_min;
+
+    template <typename Args>
+    __device__ __forceinline__ void load(const Args& a, int lane) {
+#pragma unroll
+        for (int k = 0; k < KK; ++k) {
+#pragma unroll
+            for (int ct = 0; ct < CTF; ++ct) mA[k][ct] = a.Mp[k * CT4 + ct * 4 + (lane & 3)];
+#pragma unroll
+            for (int r = 0; r < REM; ++r) mR[k][r] = a.Mp[k * CT4 + CTF * 4 + r];
+        }
+#pragma unroll
+        for (int k = 0; k < O; ++k) obs_init[k] = k < a.o ? a.obs0[a.perm[k]] : 0.f;
+        // branch-free cost pieces (wave-uniform)
+        pen = a.flip_col >= 0 ? a.flip_pen : 0.f;
+        ang_is_col1 = a.flip_col == 1;
+        ksum = a.cost_mode == 0 ? 1.f : 0.f;  // sum: acc = acc + c; final: acc = c
+        use_min = a.cost_mode == 1;
+        flip_th = a.flip_th;
+        ctrl_w = a.ctrl_w;
+        lin_w = a.lin_w;
+    }
+
+    // cost of the trajectory whose [H, D] action row starts at `arow` (16-byte aligned, global memory)
+    __device__ __forceinline__ float run(const float4* __restrict__ arow) {
+        // action ring: RING buffers of one group each; loads are issued RING-1 groups ahead (~3.5 us of
+        // MFMA work at RING = 5), enough to cover a cold HBM fetch right after the sampler's kernel boundary
+        float4 buf[RING][GV];
+#pragma unroll
+        for (int b = 0; b < RING - 1; ++b) {
+            if (b < NG) {
+#pragma unroll
+                for (int v = 0; v < GV; ++v) buf[b][v] = arow[b * GV + v];
+            }
+        }
+        float obs[O];
+#pragma unroll
+        for (int k = 0; k < O; ++k) obs[k] = obs_init[k];
+        float acc_s = 0.f, acc_b = INFINITY;
+        auto run_group = [&](const float4 (&cur)[GV]) {
+            float actg[G * D];
+#pragma unroll
+            for (int v = 0; v < GV; ++v) {
+                actg[4 * v] = cur[v].x;
+                actg[4 * v + 1] = cur[v].y;
+                actg[4 * v + 2] = cur[v].z;
+                actg[4 * v + 3] = cur[v].w;
+            }
+#pragma unroll
+            for (int s = 0; s < G; ++s) {
+                const float* act = actg + s * D;
+                f32x4 acc[CTF];
+                float accr[REM > 0 ? REM : 1];
+#pragma unroll
+                for (int ct = 0; ct < CTF; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+                // VALU block first, as ONE cluster: on gfx950 every MFMA<->VALU switch of a lone wave costs
+                // ~12 cycles (scratch/ubench3: 92 MFMAs = 762 cycles alone, 1862 with one v_fmac after
+                // each), so nothing may be interleaved into the MFMA stream.
+                {   // leftover model columns as scalar-operand FMA chains, 4 partial sums per column
+                    float part[REM > 0 ? REM : 1][4];
+#pragma unroll
+                    for (int r = 0; r < REM; ++r) part[r][0] = part[r][1] = part[r][2] = part[r][3] = 0.f;
+#pragma unroll
+                    for (int k = 0; k < KK; ++k) {
+                        const float x = k < O ? obs[k < O ? k : 0] : act[k >= O ? k - O : 0];
+#pragma unroll
+                        for (int r = 0; r < REM; ++r) part[r][k & 3] = __builtin_fmaf(x, mR[k][r], part[r][k & 3]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < REM; ++r) accr[r] = (part[r][0] + part[r][1]) + (part[r][2] + part[r][3]);
+                }
+                // cost of (o_t, a_t), branch free; column 0 holds obs[lin_idx], column 0/1 obs[flip_idx]
+                float ctrl = 0.f;
+#pragma unroll
+                for (int j = 0; j < D; ++j) ctrl = __builtin_fmaf(act[j], act[j], ctrl);
+                const float ang = ang_is_col1 ? obs[O > 1 ? 1 : 0] : obs[0];
+                float c = 0.f;
+                c += (ang > flip_th) ? pen : 0.f;
+                c += (ang < -flip_th) ? pen : 0.f;
+                c += ctrl_w * ctrl;
+                c += lin_w * obs[0];
+                acc_s = __builtin_fmaf(acc_s, ksum, c);
+                acc_b = c < acc_b ? c : acc_b;
+                __builtin_amdgcn_sched_barrier(0);
+                // matrix-pipe block: (o+d) x floor(o/4) back-to-back MFMAs, independent accumulator chains
+#pragma unroll
+                for (int k = 0; k < KK; ++k) {
+                    const float x = k < O ? obs[k < O ? k : 0] : act[k >= O ? k - O : 0];
+#pragma unroll
+                    for (int ct = 0; ct < CTF; ++ct)
+                        acc[ct] = __builtin_amdgcn_mfma_f32_4x4x1f32(mA[k][ct], x, acc[ct], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < O; ++k) {
+                    const float v = k < CTF * 4 ? acc[k < CTF * 4 ? k / 4 : 0][k % 4]
+                                                : accr[(k >= CTF * 4 && REM > 0) ? k - CTF * 4 : 0];
+                    obs[k] = act_fn(v, std::integral_constant<int, KIND>{});
+                }
+            }
+        };
+#pragma unroll 1
+        for (int tg = 0; tg < NG; tg += RING) {
+#pragma unroll
+            for (int b = 0; b < RING; ++b) {
+                if (tg + b < NG) {
+                    // refill the buffer freed by the previous group with group tg + b + RING - 1
+                    if (tg + b + RING - 1 < NG) {
+#pragma unroll
+                        for (int v = 0; v < GV; ++v) buf[(b + RING - 1) % RING][v] = arow[(tg + b + RING - 1) * GV + v];
+                    }
+                    run_group(buf[b]);
+                }
+            }
+        }
+        return use_min ? acc_b : acc_s;
+    }
+};
+
+// this tile's key joins the wave's running sorted top-K (lane r < K holds the r-th best)
+__device__ __forceinline__ unsigned long long topk_push(unsigned long long run_key, unsigned long long key, bool first,
+                                                        int K, int lane) {
+    key = wave_sort64(key, lane);
+    if (!first) {
+        const unsigned long long top = __shfl(key, lane - K, 64);
+        unsigned long long k2 = KEY_SENTINEL;
+        if (lane < K)
+            k2 = run_key;
+        else if (lane < 2 * K)
+            k2 = top;
+        key = wave_sort64(k2, lane);
+    }
+    return key;
+}
+
+// one sorted list per workgroup: up to 4 waves' top-K meet in LDS, wave 0 sorts them and emits K keys
+__device__ __forceinline__ void wg_emit_list(unsigned long long (*wg_keys)[32], unsigned long long run_key, int K, int lane,
+                                             int wave, float* part_c, int* part_i) {
+    if (wave < 4 && lane < K) wg_keys[wave][lane] = run_key;
+    __syncthreads();
+    if (wave == 0) {
+        unsigned long long k2 = KEY_SENTINEL;
+        if (4 * K <= 64) {  // all 4 lists fit one key per lane: a single sort
+            if (lane < 4 * K) k2 = wg_keys[lane / K][lane % K];
+            k2 = wave_sort64(k2, lane);
+        } else {
+            unsigned long long k0 = KEY_SENTINEL, k1 = KEY_SENTINEL;
+            if (lane < 2 * K) k0 = wg_keys[lane / K][lane % K];
+            if (lane < 2 * K) k1 = wg_keys[2 + lane / K][lane % K];
+            k0 = wave_sort64(k0, lane);
+            k1 = wave_sort64(k1, lane);
+            const unsigned long long top1 = __shfl(k1, lane - K, 64);
+            if (lane < K)
+                k2 = k0;
+            else if (lane < 2 * K)
+                k2 = top1;
+            k2 = wave_sort64(k2, lane);
+        }
+        if (lane < K) {
+            part_c[(size_t)blockIdx.x * K + lane] = key_cost(k2);
+            part_i[(size_t)blockIdx.x * K + lane] = key_idx(k2);
+        }
+    }
+}
+
 constexpr int RWG = 256;  // rollout workgroup: 4 independent wavefronts, one per SIMD
 // Unused dynamic LDS that makes a workgroup claim more than half of a CU's 160 KiB, so the dispatcher
 // can never put two rollout workgroups on one CU (two MFMA-bound waves on one SIMD halve each other).
 constexpr size_t ROLLOUT_LDS_PAD = 84 * 1024;
 
 template <int H, int D, int O, int KIND>
-__global__ __launch_bounds__(RWG) __attribute__((amdgpu_waves_per_eu(1, 1))) void rollout_mfma_kernel(FastRolloutArgs a) {
-#ifndef ICEM_REM_ON_VALU
-#define ICEM_REM_ON_VALU 1
-#endif
-    constexpr int CTF = ICEM_REM_ON_VALU ? O / 4 : (O + 3) / 4;  // column tiles of 4 on the matrix pipe
-    constexpr int REM = ICEM_REM_ON_VALU ? O % 4 : 0;  // leftover columns: FMA chains on the VALU, under the MFMAs
-    constexpr int CT4 = ((O + 3) / 4) * 4;
-    constexpr int KK = O + D;        // contraction length of one model step
-    constexpr int G = group_steps(D);
-    constexpr int GV = G * D / 4;  // float4 per group
+__global__ __launch_bounds__(RWG) void rollout_mfma_kernel(FastRolloutArgs a) {
     constexpr int HD = H * D;
-    constexpr int NG = H / G;  // action groups per trajectory
-    static_assert(H % G == 0 && HD % 4 == 0, "action rows must split into 16-byte groups");
-    static_assert(CTF >= 1, "at least one full column tile");
-    __shared__ unsigned long long wg_keys[RWG / 64][32];
+    __shared__ unsigned long long wg_keys[4][32];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-
-    // model operand of the MFMA: lane holds Mp[k][4*ct + (lane & 3)]; leftover columns are uniform
-    float mA[KK][CTF];
-    float mR[KK][REM > 0 ? REM : 1];
-#pragma unroll
-    for (int k = 0; k < KK; ++k) {
-#pragma unroll
-        for (int ct = 0; ct < CTF; ++ct) mA[k][ct] = a.Mp[k * CT4 + ct * 4 + (lane & 3)];
-#pragma unroll
-        for (int r = 0; r < REM; ++r) mR[k][r] = a.Mp[k * CT4 + CTF * 4 + r];
-    }
-    float obs_init[O];
-#pragma unroll
-    for (int k = 0; k < O; ++k) obs_init[k] = k < a.o ? a.obs0[a.perm[k]] : 0.f;
-    // branch-free cost pieces (wave-uniform)
-    const float pen = a.flip_col >= 0 ? a.flip_pen : 0.f;
-    const bool ang_is_col1 = a.flip_col == 1;
-    const float ksum = a.cost_mode == 0 ? 1.f : 0.f;  // sum: acc = acc + c; final: acc = c
-    const bool use_min = a.cost_mode == 1;
-
-    long long st0 = __builtin_readcyclecounter(), st1 = 0, st2 = 0, st3 = 0, st4 = 0;
-    unsigned long long run_key = KEY_SENTINEL;  // lane r < K holds this wave's r-th best so far
+    RolloutWave<H, D, O, KIND> rw;
+    rw.load(a, lane);
+    unsigned long long run_key = KEY_SENTINEL;
     const int tiles = (a.n_rows + 63) / 64;
     const int wave_gid = blockIdx.x * (RWG / 64) + wave;
     const int wave_cnt = gridDim.x * (RWG / 64);
@@ -234,158 +457,112 @@ __global__ __launch_bounds__(RWG) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int tile_id = wave_gid; tile_id < tiles; tile_id += wave_cnt) {
         const int row = tile_id * 64 + lane;
         const bool live = row < a.n_rows;
-        const float4* arow = reinterpret_cast<const float4*>(a.actions + (size_t)(live ? row : 0) * HD);
-        // action ring: 3 buffers of one group each, loads issued two groups (>= 2 model steps) ahead
-        float4 buf[3][GV];
-#pragma unroll
-        for (int v = 0; v < GV; ++v) {
-            buf[0][v] = arow[v];
-            if (NG > 1) buf[1][v] = arow[GV + v];
-        }
-        float obs[O];
-#pragma unroll
-        for (int k = 0; k < O; ++k) obs[k] = obs_init[k];
-        float acc_s = 0.f, acc_b = INFINITY;
-        if (a.dbg) st1 = __builtin_readcyclecounter();
-        auto run_group = [&](const float4 (&cur)[GV]) {
-        float actg[G * D];
-#pragma unroll
-        for (int v = 0; v < GV; ++v) {
-            actg[4 * v] = cur[v].x;
-            actg[4 * v + 1] = cur[v].y;
-            actg[4 * v + 2] = cur[v].z;
-            actg[4 * v + 3] = cur[v].w;
-        }
-#pragma unroll
-        for (int s = 0; s < G; ++s) {
-            const float* act = actg + s * D;
-            f32x4 acc[CTF];
-            float accr[REM > 0 ? REM : 1];
-#pragma unroll
-            for (int ct = 0; ct < CTF; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int r = 0; r < REM; ++r) accr[r] = 0.f;
-            // VALU block first, as ONE cluster: on gfx950 every MFMA<->VALU switch of a lone wave costs
-            // ~12 cycles (scratch/ubench3: 92 MFMAs = 762 cycles alone, 1862 with one v_fmac after each),
-            // so nothing may be interleaved into the MFMA stream.
-            // leftover model columns as scalar-operand FMA chains
-            {
-                float part[REM > 0 ? REM : 1][4];  // 4 partial sums per column: short dependency chains
-#pragma unroll
-                for (int r = 0; r < REM; ++r) part[r][0] = part[r][1] = part[r][2] = part[r][3] = 0.f;
-#pragma unroll
-                for (int k = 0; k < KK; ++k) {
-                    const float x = k < O ? obs[k < O ? k : 0] : act[k >= O ? k - O : 0];
-#pragma unroll
-                    for (int r = 0; r < REM; ++r) part[r][k & 3] = __builtin_fmaf(x, mR[k][r], part[r][k & 3]);
-                }
-#pragma unroll
-                for (int r = 0; r < REM; ++r) accr[r] = (part[r][0] + part[r][1]) + (part[r][2] + part[r][3]);
-            }
-            // cost of (o_t, a_t), branch free; column 0 holds obs[lin_idx], column 0/1 obs[flip_idx]
-            float ctrl = 0.f;
-#pragma unroll
-            for (int j = 0; j < D; ++j) ctrl = __builtin_fmaf(act[j], act[j], ctrl);
-            const float ang = ang_is_col1 ? obs[O > 1 ? 1 : 0] : obs[0];
-            float c = 0.f;
-            c += (ang > a.flip_th) ? pen : 0.f;
-            c += (ang < -a.flip_th) ? pen : 0.f;
-            c += a.ctrl_w * ctrl;
-            c += a.lin_w * obs[0];
-            acc_s = __builtin_fmaf(acc_s, ksum, c);
-            acc_b = c < acc_b ? c : acc_b;
-            __builtin_amdgcn_sched_barrier(0);
-            // matrix-pipe block: (o+d) x floor(o/4) back-to-back MFMAs, 4 independent accumulator chains
-#pragma unroll
-            for (int k = 0; k < KK; ++k) {
-                const float x = k < O ? obs[k < O ? k : 0] : act[k >= O ? k - O : 0];
-#pragma unroll
-                for (int ct = 0; ct < CTF; ++ct)
-                    acc[ct] = __builtin_amdgcn_mfma_f32_4x4x1f32(mA[k][ct], x, acc[ct], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < O; ++k) {
-                const float v = k < CTF * 4 ? acc[k < CTF * 4 ? k / 4 : 0][k % 4] : accr[k >= CTF * 4 ? k - CTF * 4 : 0];
-                obs[k] = act_fn(v, std::integral_constant<int, KIND>{});
-            }
-        }
-        };
-#pragma unroll 1
-        for (int tg = 0; tg < NG; tg += 3) {
-            if (tg + 2 < NG) {
-#pragma unroll
-                for (int v = 0; v < GV; ++v) buf[2][v] = arow[(tg + 2) * GV + v];
-            }
-            run_group(buf[0]);
-            if (tg + 1 < NG) {
-                if (tg + 3 < NG) {
-#pragma unroll
-                    for (int v = 0; v < GV; ++v) buf[0][v] = arow[(tg + 3) * GV + v];
-                }
-                run_group(buf[1]);
-            }
-            if (tg + 2 < NG) {
-                if (tg + 4 < NG) {
-#pragma unroll
-                    for (int v = 0; v < GV; ++v) buf[1][v] = arow[(tg + 4) * GV + v];
-                }
-                run_group(buf[2]);
-            }
-        }
-        const float acc_cost = use_min ? acc_b : acc_s;
-        if (a.dbg) st2 = __builtin_readcyclecounter();
-        if (live) a.costs[row] = acc_cost;
+        const float cost = rw.run(reinterpret_cast<const float4*>(a.actions + (size_t)(live ? row : 0) * HD));
+        if (live) a.costs[row] = cost;
         if (a.K > 0) {
-            unsigned long long key = KEY_SENTINEL;
-            if (live && row < a.n_cand) key = make_key(acc_cost, row);
-            key = wave_sort64(key, lane);
-            if (!first) {  // merge with the running top-K of earlier tiles
-                const unsigned long long top = __shfl(key, lane - a.K, 64);
-                unsigned long long k2 = KEY_SENTINEL;
-                if (lane < a.K)
-                    k2 = run_key;
-                else if (lane < 2 * a.K)
-                    k2 = top;
-                key = wave_sort64(k2, lane);
-            }
-            run_key = key;
+            const unsigned long long key = (live && row < a.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
+            run_key = topk_push(run_key, key, first, a.K, lane);
             first = false;
         }
-        if (a.dbg) st3 = __builtin_readcyclecounter();
     }
-    if (a.dbg && lane == 0) {
-        long long* d = a.dbg + (size_t)wave_gid * 8;
-        d[0] = st0; d[1] = st1; d[2] = st2; d[3] = st3;
+    if (a.K > 0) wg_emit_list(wg_keys, run_key, a.K, lane, wave, a.part_c, a.part_i);
+}
+
+// -------------------------------------------------------------------------------------------------
+// fused iteration: sample -> HBM (through an LDS tile) -> rollout of the same trajectories by the same
+// workgroup (actions re-read through L2, never after a kernel boundary) -> cost -> per-workgroup top-K
+// -------------------------------------------------------------------------------------------------
+constexpr int FWG = 512;  // 8 wavefronts: all sample; waves 0..tpb/64-1 (distinct SIMDs) roll out
+
+// sampling pass of the fused kernel: rows [0, n_rows) of the workgroup's slab (row = traj*D + j), NR rows
+// per thread, samples stored straight to actions[traj][t][j] (6 adjacent lanes fill 24 contiguous bytes; L2
+// write-combines the rest) -- no LDS tile, no barrier inside the pass.
+template <int H, int D, int ROUNDS, int NR>
+__device__ __forceinline__ void fused_sample_pass(const FusedArgs& a, const float* ms, int sb, int n_rows, int tid) {
+    constexpr int HD = H * D;
+    unsigned gi[NR], jj[NR];
+    float lo[NR], hi[NR];
+    float* dst[NR];
+    bool ok[NR], is_mean[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int row = tid + r * FWG;
+        ok[r] = row < n_rows;
+        const int rr = ok[r] ? row : 0;
+        const int nl = rr / D;
+        const int j = rr - nl * D;
+        gi[r] = (unsigned)(a.first_index + sb + nl);
+        jj[r] = (unsigned)j;
+        lo[r] = a.low[j];
+        hi[r] = a.high[j];
+        dst[r] = a.actions + (size_t)(sb + nl) * HD + j;
+        is_mean[r] = a.row0_mean && (a.first_index + sb + nl == 0);  // icem.py:87-88
     }
-    if (a.K > 0) {
-        // one sorted list per workgroup: the 4 waves' top-K meet in LDS, wave 0 sorts 4*K <= 128 keys
-        if (lane < a.K) wg_keys[wave][lane] = run_key;
-        __syncthreads();
-        if (wave == 0) {
-            unsigned long long k2 = KEY_SENTINEL;
-            if (4 * a.K <= 64) {  // all 4 lists fit one key per lane: a single sort
-                if (lane < 4 * a.K) k2 = wg_keys[lane / a.K][lane % a.K];
-                k2 = wave_sort64(k2, lane);
-            } else {
-                unsigned long long k0 = KEY_SENTINEL, k1 = KEY_SENTINEL;
-                if (lane < 2 * a.K) k0 = wg_keys[lane / a.K][lane % a.K];
-                if (lane < 2 * a.K) k1 = wg_keys[2 + lane / a.K][lane % a.K];
-                k0 = wave_sort64(k0, lane);
-                k1 = wave_sort64(k1, lane);
-                const unsigned long long top1 = __shfl(k1, lane - a.K, 64);
-                if (lane < a.K)
-                    k2 = k0;
-                else if (lane < 2 * a.K)
-                    k2 = top1;
-                k2 = wave_sort64(k2, lane);
-            }
-            if (lane < a.K) {
-                a.part_c[(size_t)blockIdx.x * a.K + lane] = key_cost(k2);
-                a.part_i[(size_t)blockIdx.x * a.K + lane] = key_idx(k2);
-            }
-            if (a.dbg && lane == 0) a.dbg[(size_t)wave_gid * 8 + 4] = __builtin_readcyclecounter();
+    long long tmid = 0;
+    sample_rows<H, ROUNDS, NR>(a.W, gi, jj, a.off_lo, a.off_hi, a.seed_lo, a.seed_hi, [&](int r, int t, float y) {
+        const float m = ms[t * D + jj[r]];
+        float v = __builtin_fmaf(y, ms[HD + t * D + jj[r]], m);
+        v = v < lo[r] ? lo[r] : v;
+        v = v > hi[r] ? hi[r] : v;
+        v = is_mean[r] ? m : v;
+        if (ok[r]) dst[r][t * D] = v;
+    }, a.dbg ? &tmid : nullptr);
+    if (a.dbg && (tid & 63) == 0) a.dbg[((size_t)blockIdx.x * 8 + (tid >> 6)) * 8 + 5] = tmid;
+}
+
+template <int H, int D, int O, int KIND, int ROUNDS>
+__global__ __launch_bounds__(FWG) void fused_iter_kernel(FusedArgs a) {
+    constexpr int HD = H * D;
+    __shared__ float ms[2 * HD];
+    __shared__ unsigned long long wg_keys[4][32];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int tpb = a.tpb;            // trajectories per workgroup pass: 64, 128 or 256
+    const int n_rwaves = tpb >> 6;
+    const int n_total = a.n + a.n_extra;  // rows [n, n_total) are pre-filled (shifted elites): rollout only
+    for (int e = tid; e < HD; e += FWG) {
+        ms[e] = a.mean[e];
+        ms[HD + e] = a.std[e];
+    }
+    __syncthreads();
+    unsigned long long run_key = KEY_SENTINEL;
+    bool first = true;
+    long long st[5] = {0, 0, 0, 0, 0};
+    if (a.dbg) st[0] = __builtin_readcyclecounter();
+    for (int base = blockIdx.x * tpb; base < n_total; base += gridDim.x * tpb) {
+        // ---- sample + store ----
+        const int n_samp = cmin(tpb, a.n - base);
+        if (n_samp > 0) {
+            const int n_rows = n_samp * D;
+            if (n_rows > 2 * FWG)
+                fused_sample_pass<H, D, ROUNDS, 3>(a, ms, base, n_rows, tid);
+            else if (n_rows > FWG)
+                fused_sample_pass<H, D, ROUNDS, 2>(a, ms, base, n_rows, tid);
+            else
+                fused_sample_pass<H, D, ROUNDS, 1>(a, ms, base, n_rows, tid);
         }
+        if (a.dbg) st[1] = __builtin_readcyclecounter();
+        __syncthreads();  // the slab is stored and visible to the workgroup
+        if (a.dbg) st[2] = __builtin_readcyclecounter();
+        // ---- rollout + cost + top-K: wave w takes rows base + 64 w + lane ----
+        if (wave < n_rwaves && base + wave * 64 < n_total) {  // wave-uniform
+            RolloutWave<H, D, O, KIND> rw;  // loaded here so the model operand is not live across the sampling
+            rw.load(a, lane);
+            const int row = base + wave * 64 + lane;
+            const bool live = row < n_total;
+            const float cost = rw.run(reinterpret_cast<const float4*>(a.actions + (size_t)(live ? row : 0) * HD));
+            if (a.dbg) st[3] = __builtin_readcyclecounter();
+            if (live) a.costs[row] = cost;
+            const unsigned long long key = (live && row < a.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
+            run_key = topk_push(run_key, key, first, a.K, lane);
+            first = false;
+        }
+    }
+    wg_emit_list(wg_keys, run_key, a.K, lane, wave, a.part_c, a.part_i);
+    if (a.dbg && lane == 0) {
+        st[4] = __builtin_readcyclecounter();
+        for (int i = 0; i < 5; ++i) a.dbg[((size_t)blockIdx.x * 8 + wave) * 8 + i] = st[i];
     }
 }
 
@@ -579,6 +756,22 @@ void launch_sample_folded(const FastSampleArgs& a, int rounds, hipStream_t st) {
     }
     ICEM_FAST_HORIZONS(X)
 #undef X
+}
+
+#define ICEM_FUSED_LAUNCH(HH, DD, OO)                                                                             \
+    if (a.h == HH && a.d == DD && O == OO) {                                                                      \
+        if (kind == 1) {                                                                                          \
+            if (rounds == 7) hipLaunchKernelGGL((fused_iter_kernel<HH, DD, OO, 1, 7>), dim3(grid), dim3(FWG), 0, st, a);   \
+            else hipLaunchKernelGGL((fused_iter_kernel<HH, DD, OO, 1, 10>), dim3(grid), dim3(FWG), 0, st, a);      \
+        } else {                                                                                                  \
+            if (rounds == 7) hipLaunchKernelGGL((fused_iter_kernel<HH, DD, OO, 0, 7>), dim3(grid), dim3(FWG), 0, st, a);   \
+            else hipLaunchKernelGGL((fused_iter_kernel<HH, DD, OO, 0, 10>), dim3(grid), dim3(FWG), 0, st, a);      \
+        }                                                                                                         \
+        return;                                                                                                   \
+    }
+
+void launch_fused_iter(const FusedArgs& a, int O, int kind, int rounds, int grid, hipStream_t st) {
+    ICEM_FAST_SHAPES(ICEM_FUSED_LAUNCH)
 }
 
 void launch_merge_single(const MergeSingleArgs& a, hipStream_t st) {

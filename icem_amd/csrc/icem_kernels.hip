@@ -595,6 +595,7 @@ struct icem_handle {
         hipEvent_t a, b;
     };
     bool use_fast = true;
+    bool use_fused = false;  // experimental single-launch iteration (ICEM_ENABLE_FUSED=1); slower than the two-kernel path today
     long long* dbg = nullptr;
     int fast_lists = 0;  // candidate lists written by the last matrix-pipe rollout (0 = generic path ran)
     // permuted, padded model of the matrix-pipe rollout: column 0 = obs[lin_idx], column 1 = obs[flip_idx]
@@ -975,25 +976,73 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
     h->fast_lists = 0;
     if constexpr (std::is_same<T, float>::value) {
         if (b->z_r == nullptr && fast_rollout_ok(h, K)) {
-            // f32 throughput path: folded sampler -> matrix-pipe rollout + cost + per-wave top-K
+            // f32 throughput path
             const uint64_t off = call_base + (uint64_t)it;
-            int rc;
-            if (fast_sample_ok(h)) {
-                rc = launch_fast_sample(h, n_loc, lo, b->mean, b->std, b->low, b->high, off, row0, actions, st);
-            } else {
-                SampleArgs<T> a = make_sample_args<T>(h, n_loc, lo, b->mean, b->std, b->low, b->high, nullptr, nullptr, off,
-                                                      0, row0, actions);
-                rc = launch_sample<T>(h, a, st);
-            }
+            int rc = ensure_fast_model(h);
             if (rc) return rc;
-            const int tiles = (n_loc + n_extra + 63) / 64;
-            const int grid = std::max(1, std::min((tiles + 3) / 4, FAST_MAX_LISTS));
+            int lists = 0;
             float* pc;
             int* pi;
-            split_partial_ws<float>(b->workspace, grid, K, &pc, &pi);
-            int lists = 0;
-            rc = launch_fast_rollout(h, n_loc + n_extra, n_cand, K, b->obs0, actions, b->costs, pc, pi, st, &lists);
-            if (rc) return rc;
+            const int n_rows = n_loc + n_extra;
+            if (h->use_fused && fast_sample_ok(h)) {
+                // ONE launch: sample -> LDS tile -> HBM, rollout of the same trajectories by the same workgroup
+                // (actions re-read through L2), cost, per-workgroup sorted top-K
+                FusedArgs a;
+                a.n = n_loc;
+                a.n_extra = n_extra;
+                a.n_cand = n_cand;
+                a.K = K;
+                a.h = c.horizon;
+                a.d = c.act_dim;
+                a.o = h->obs_dim;
+                a.cost_mode = c.cost_mode;
+                a.row0_mean = row0;
+                a.tpb = n_rows > 128 * 256 ? 256 : (n_rows > 64 * 256 ? 128 : 64);
+                a.first_index = lo;
+                a.W = (const float*)h->W_dev;
+                a.mean = (const float*)b->mean;
+                a.std = (const float*)b->std;
+                a.low = (const float*)b->low;
+                a.high = (const float*)b->high;
+                a.seed_lo = (uint32_t)c.seed;
+                a.seed_hi = (uint32_t)(c.seed >> 32);
+                a.off_lo = (uint32_t)off;
+                a.off_hi = (uint32_t)(off >> 32);
+                a.Mp = (const float*)h->Mp_dev;
+                a.perm = (const int*)h->perm_dev;
+                a.obs0 = (const float*)b->obs0;
+                a.ctrl_w = (float)h->cost.ctrl_weight;
+                a.lin_w = (float)h->cost.lin_weight;
+                a.flip_pen = (float)h->cost.flip_penalty;
+                a.flip_th = (float)h->cost.flip_thresh;
+                a.flip_col = h->flip_col;
+                a.actions = (float*)actions;
+                a.costs = (float*)b->costs;
+                lists = std::max(1, std::min((n_rows + a.tpb - 1) / a.tpb, FAST_MAX_LISTS));
+                split_partial_ws<float>(b->workspace, lists, K, &pc, &pi);
+                a.part_c = pc;
+                a.part_i = pi;
+                a.dbg = h->dbg;
+                {
+                    ProfScope prof(h, ICEM_K_FUSED, (long long)n_rows * c.horizon, st);
+                    launch_fused_iter(a, h->O, h->model_kind, c.rng_rounds, lists, st);
+                }
+                ICEM_HIP_TRY(hipGetLastError());
+            } else {
+                if (fast_sample_ok(h)) {
+                    rc = launch_fast_sample(h, n_loc, lo, b->mean, b->std, b->low, b->high, off, row0, actions, st);
+                } else {
+                    SampleArgs<T> a = make_sample_args<T>(h, n_loc, lo, b->mean, b->std, b->low, b->high, nullptr, nullptr,
+                                                          off, 0, row0, actions);
+                    rc = launch_sample<T>(h, a, st);
+                }
+                if (rc) return rc;
+                const int tiles = (n_rows + 63) / 64;
+                const int grid = std::max(1, std::min((tiles + 3) / 4, FAST_MAX_LISTS));
+                split_partial_ws<float>(b->workspace, grid, K, &pc, &pi);
+                rc = launch_fast_rollout(h, n_rows, n_cand, K, b->obs0, actions, b->costs, pc, pi, st, &lists);
+                if (rc) return rc;
+            }
             h->fast_lists = lists;
             if (c.world > 1) {
                 ProfScope prof(h, ICEM_K_LOCAL_PACK, lists * K, st);
@@ -1160,6 +1209,7 @@ int icem_create(const icem_config* cfg, icem_handle** out) {
     h->n_reuse = (int)((double)c.num_elites * c.fraction_reused);  // int(len(elites)*xi), icem.py:98,145
     h->n_local_max = shard_chunk(c.num_traj, c.world);
     if (const char* e = getenv("ICEM_DISABLE_FAST")) h->use_fast = !(e[0] == '1');
+    if (const char* e = getenv("ICEM_ENABLE_FUSED")) h->use_fused = (e[0] == '1');
     // synthesis table W[t][m]: m < F real part of bin m, F <= m < h imaginary part of bin m-F+1
     std::vector<double> cr, ci, W((size_t)c.horizon * h->HMAX, 0.0);
     noise_tables(c.horizon, c.noise_beta, cr, ci);

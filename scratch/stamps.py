@@ -10,11 +10,13 @@ for N in (4096, 65536):
     pl.set_cost(c.ctrl_weight, c.lin_idx, c.lin_weight, c.flip_idx, c.flip_penalty, c.flip_thresh)
     pl.reset(); obs = 0.1*np.random.RandomState(0).randn(17)
     for _ in range(3): pl.plan_step(obs)
-    dbg = torch.zeros((2048, 8), dtype=torch.int64, device="cuda")
+    dbg = torch.zeros((256*8, 8), dtype=torch.int64, device="cuda")
     L.check(pl.lib.icem_debug_stamps(pl._h, C.c_void_p(dbg.data_ptr())))
     pl.plan_step(obs); torch.cuda.synchronize()
-    d = dbg.cpu().numpy(); d = d[d[:, 0] > 0]
-    seg = np.stack([d[:,1]-d[:,0], d[:,2]-d[:,1], d[:,3]-d[:,2]], 1)
-    print(f"N={N}: waves={len(d)} median cycles: load model+first actions {np.median(seg[:,0]):.0f}, time loop {np.median(seg[:,1]):.0f} ({np.median(seg[:,1])/30:.0f}/step), tile sort {np.median(seg[:,2]):.0f}; loop min/max {seg[:,1].min()}/{seg[:,1].max()}")
-    w0 = d[d[:,4] > 0]
-    if len(w0): print("   wg merge (wave 0):", np.median(w0[:,4]-w0[:,3]))
+    d = dbg.cpu().numpy().reshape(256, 8, 8)
+    w0 = d[:, 0, :]; w0 = w0[w0[:, 0] > 0]
+    w7 = d[:, 7, :]; w7 = w7[w7[:, 0] > 0]
+    med = lambda x: float(np.median(x))
+    print(f"N={N}: WGs={len(w0)}  wave0: sample {med(w0[:,1]-w0[:,0]):.0f}  barrier wait {med(w0[:,2]-w0[:,1]):.0f}  rollout {med(w0[:,3]-w0[:,2]):.0f}  topk+emit {med(w0[:,4]-w0[:,3]):.0f}  total {med(w0[:,4]-w0[:,0]):.0f} cycles")
+    print(f"          wave0: RNG+BoxMuller {med(w0[:,5]-w0[:,0]):.0f}  DFT+emit {med(w0[:,1]-w0[:,5]):.0f}")
+    print(f"          wave7: sample {med(w7[:,1]-w7[:,0]):.0f}  barrier wait {med(w7[:,2]-w7[:,1]):.0f}")
