@@ -52,13 +52,8 @@ def make_planner(w, rank, world, seed=1234):
 
 
 def run_steps(pl, n, world):
-    if world == 1:
-        for _ in range(n):
-            pl.plan_step_resident()
-    else:
-        obs = pl.obs0.cpu().numpy()
-        for _ in range(n):
-            pl.plan_step(obs)
+    for _ in range(n):
+        pl.plan_step_resident()
 
 
 def algorithmic_bytes_per_trajstep(kernel, d, h):
@@ -107,6 +102,43 @@ def cpu_baseline(w, model, env, budget_s=12.0):
                       f"{el:.1f} s; oracle/icem_oracle.c, float64, OpenMP over trajectories"}
 
 
+def roofline_of(prof, w):
+    dom = max(prof, key=lambda k: prof[k][0])
+    ms, launches, units = prof[dom]
+    bpu = algorithmic_bytes_per_trajstep(dom, w["d"], w["h"])
+    if bpu is None or ms <= 0:
+        return None
+    achieved = units * bpu / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "kernel": dom, "avg_launch_us": 1e3 * ms / launches, "launches": launches,
+            "algorithmic_bytes_per_launch": units * bpu / launches, "bytes_per_traj_step": bpu}
+
+
+def measure_also(name, steps=30, warmup=5):
+    """The large-population configuration the north-star roofline target is stated on (N=65536), measured
+    in the same run: whole-loop traj-steps/s, ms per MPC step, dominant-kernel roofline, and the whole
+    loop's algorithmic bytes (8d+8/h per traj-step) over the MPC-step time."""
+    w = WORKLOADS[name]
+    pl, _, _ = make_planner(w, 0, 1)
+    run_steps(pl, warmup, 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(pl, steps, 1)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    pl.profile_enable(True)
+    run_steps(pl, 10, 1)
+    torch.cuda.synchronize()
+    prof = pl.profile_read()
+    pl.profile_enable(False)
+    ts = sum(pl.population_sizes) * w["h"]
+    loop_bytes = ts * (8.0 * w["d"] + 8.0 / w["h"])
+    return {"workload": w["name"], "value": ts * steps / el, "unit": "traj-steps/s", "ms_per_mpc_step": 1e3 * el / steps,
+            "roofline": roofline_of(prof, w), "kernels_us": {k: round(1e3 * v[0] / v[1], 2) for k, v in prof.items()},
+            "whole_loop_algorithmic_GBps": loop_bytes * steps / el / 1e9,
+            "whole_loop_frac_of_hbm_peak": loop_bytes * steps / el / 1e9 / HBM_PEAK_GBS}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,6 +146,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra large-population (c4) measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -163,17 +196,7 @@ def main():
     pl.profile_enable(False)
 
     if rank == 0:
-        dom = max(prof, key=lambda k: prof[k][0])
-        ms, launches, units = prof[dom]
-        bpu = algorithmic_bytes_per_trajstep(dom, w["d"], w["h"])
-        roofline = None
-        if bpu is not None and ms > 0:
-            achieved = units * bpu / (ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": dom,
-                        "avg_launch_us": 1e3 * ms / launches, "launches": launches,
-                        "algorithmic_bytes_per_launch": units * bpu / launches,
-                        "bytes_per_traj_step": bpu}
+        roofline = roofline_of(prof, w)
         out = {
             "metric": "traj-steps/sec (N x h), iCEM inner planning loop", "value": per_step_trajsteps * args.steps / elapsed,
             "unit": "traj-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -181,7 +204,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": w["name"], "per_gpu_population": w["N"], "global_population": w["N"] * world,
                        "traj_per_mpc_step": sum(pl.population_sizes), "model": "o' = o.A + a.B dense linear (synthetic)",
-                       "cost": "HalfCheetah cost_fn", "rng": "Philox4x32-10 + Box-Muller", "parallelism": f"n-shard x{world}"},
+                       "cost": "HalfCheetah cost_fn", "rng": "Philox4x32-10-seeded xoshiro128++ + Box-Muller", "parallelism": f"n-shard x{world}"},
             "ms_per_mpc_step": 1e3 * elapsed / args.steps,
             "roofline": roofline,
             "kernels_us": {k: round(1e3 * v[0] / v[1], 2) for k, v in prof.items()},
@@ -190,6 +213,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(w, model, env)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and args.workload == "c2" and not args.no_also:
+            out["also"] = measure_also("c4")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -30,6 +30,13 @@ def exchange_records(records: torch.Tensor, K: int, rank: int, world: int, group
     if world == 1:
         return records
     mine = records[rank * K:(rank + 1) * K]
+    backend = dist.get_backend(group)
+    if records.is_cuda and backend != "nccl":
+        # no RCCL (e.g. several ranks sharing one GPU in a test): stage the K records through the host
+        host = torch.empty(records.shape, dtype=records.dtype)
+        dist.all_gather_into_tensor(host, mine.cpu(), group=group)
+        records.copy_(host)
+        return records
     if not records.is_cuda:
         mine = mine.clone()  # gloo: keep input and output disjoint
     dist.all_gather_into_tensor(records, mine, group=group)

@@ -238,10 +238,17 @@ class IcemPlanner:
         return {L.KERNEL_NAMES[i]: (ms[i], cnt[i], units[i]) for i in range(n) if cnt[i]}
 
     def plan_step_resident(self):
-        """plan_step with the observation already in ``self.obs0`` (world == 1, Philox): no host
-        work besides the launches -- the bench's timed region."""
+        """plan_step with the observation already in ``self.obs0`` (Philox noise): no host work besides
+        the launches (and, for world > 1, the one all-gather per iteration) -- the bench's timed region."""
         self._cb.z_r = self._cb.z_i = self._cb.z_r_shift = self._cb.z_i_shift = None
-        L.check(self.lib.icem_plan_step(self._h, C.byref(self._cb), self.mpc_step, self._stream()))
+        st = self._stream()
+        if self.cfg.world == 1:
+            L.check(self.lib.icem_plan_step(self._h, C.byref(self._cb), self.mpc_step, st))
+        else:
+            for it in range(self.cfg.opt_iters):
+                L.check(self.lib.icem_plan_iter_local(self._h, C.byref(self._cb), self.mpc_step, it, st))
+                exchange_records(self.records, self.K, self.cfg.rank, self.cfg.world, self.group)
+                L.check(self.lib.icem_plan_iter_merge(self._h, C.byref(self._cb), self.mpc_step, it, st))
         self.mpc_step += 1
 
     # ------------------------------------------------------------------ fused MPC step

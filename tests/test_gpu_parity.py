@@ -450,3 +450,54 @@ def test_large_population_properties():
     sh[:-1] = rm[1:]
     np.testing.assert_allclose(np_(pl.mean), sh, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(np_(pl.executed), act[idx[0], 0], rtol=0, atol=0)
+
+
+def _sharded_worker(rank, world, port, out_dir):
+    import os
+    import torch.distributed as dist
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        env = halfcheetah_env(17)
+        model = DeviceSyntheticModel.make(17, 6)
+        pl = IcemPlanner(IcemConfig(horizon=30, act_dim=6, num_traj=2000, opt_iters=3, dtype="f32", seed=21,
+                                    rank=rank, world=world), env.action_space.low, env.action_space.high)
+        pl.set_model(model.kind, model.A, model.B)
+        c = env.cost_spec
+        pl.set_cost(c.ctrl_weight, c.lin_idx, c.lin_weight, c.flip_idx, c.flip_penalty, c.flip_thresh)
+        pl.reset()
+        acts = []
+        for s in range(3):
+            acts.append(np_(pl.plan_step(0.1 * np.random.RandomState(s).randn(17))).copy())
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), acts=np.array(acts), mean=np_(pl.mean))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_processes_on_one_gpu(tmp_path):
+    """The real multi-process path (IcemPlanner.plan_step with rank/world + the all-gather through
+    torch.distributed) with two processes sharing this GPU over gloo: every rank ends with the
+    single-process result, bit for bit."""
+    import socket
+    import torch.multiprocessing as mp
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_sharded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    env = halfcheetah_env(17)
+    model = DeviceSyntheticModel.make(17, 6)
+    pl = IcemPlanner(IcemConfig(horizon=30, act_dim=6, num_traj=2000, opt_iters=3, dtype="f32", seed=21),
+                     env.action_space.low, env.action_space.high)
+    pl.set_model(model.kind, model.A, model.B)
+    c = env.cost_spec
+    pl.set_cost(c.ctrl_weight, c.lin_idx, c.lin_weight, c.flip_idx, c.flip_penalty, c.flip_thresh)
+    pl.reset()
+    acts = np.array([np_(pl.plan_step(0.1 * np.random.RandomState(s).randn(17))).copy() for s in range(3)])
+    for r in range(2):
+        z = np.load(tmp_path / f"r{r}.npz")
+        assert np.array_equal(z["acts"], acts)
+        assert np.array_equal(z["mean"], np_(pl.mean))
