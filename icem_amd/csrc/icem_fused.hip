@@ -50,20 +50,56 @@ __device__ __forceinline__ float key_cost(unsigned long long k) {
 __device__ __forceinline__ int key_idx(unsigned long long k) { return (int)(unsigned)k; }
 constexpr unsigned long long KEY_SENTINEL = 0xFF8000007FFFFFFFull;  // (+inf, INT_MAX)
 
-// ascending bitonic sort of one key per lane across the 64-lane wave
-__device__ __forceinline__ unsigned long long wave_sort64(unsigned long long k, int lane) {
-#pragma unroll
-    for (int size = 2; size <= 64; size <<= 1) {
-#pragma unroll
-        for (int j = size >> 1; j >= 1; j >>= 1) {
-            const unsigned long long o = __shfl_xor(k, j, 64);
-            const bool up = (lane & size) == 0;       // this block sorts ascending
-            const bool lower = (lane & j) == 0;       // this lane keeps the smaller of the pair
-            const bool take_min = (up == lower);
-            const bool o_less = o < k;
-            k = (take_min == o_less) ? o : k;
-        }
+// value of lane (lane ^ J): DPP inside a row of 16 lanes (quad permutes for 1 / 2, row rotations for
+// 4 / 8), LDS-crossbar shuffle only across rows (16 / 32)
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)x, CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(x >> 32), CTRL, 0xF, 0xF, false);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+template <int J>
+__device__ __forceinline__ unsigned long long xor_partner(unsigned long long k, int lane) {
+    if constexpr (J == 1) {
+        return dpp_u64<0xB1>(k);  // quad_perm [1,0,3,2]
+    } else if constexpr (J == 2) {
+        return dpp_u64<0x4E>(k);  // quad_perm [2,3,0,1]
+    } else if constexpr (J == 4) {
+        const unsigned long long up = dpp_u64<0x12C>(k);    // row_ror:12 -> from lane + 4 (mod 16)
+        const unsigned long long down = dpp_u64<0x124>(k);  // row_ror:4  -> from lane - 4 (mod 16)
+        return (lane & 4) ? down : up;
+    } else if constexpr (J == 8) {
+        return dpp_u64<0x128>(k);  // row_ror:8
+    } else {
+        return __shfl_xor(k, J, 64);
     }
+}
+
+template <int SIZE, int J>
+__device__ __forceinline__ unsigned long long bitonic_step(unsigned long long k, int lane) {
+    const unsigned long long o = xor_partner<J>(k, lane);
+    const bool up = (lane & SIZE) == 0;  // this block sorts ascending
+    const bool lower = (lane & J) == 0;  // this lane keeps the smaller of the pair
+    const bool take_min = (up == lower);
+    const bool o_less = o < k;
+    return (take_min == o_less) ? o : k;
+}
+
+template <int SIZE, int J>
+__device__ __forceinline__ unsigned long long bitonic_merge(unsigned long long k, int lane) {
+    k = bitonic_step<SIZE, J>(k, lane);
+    if constexpr (J > 1) k = bitonic_merge<SIZE, J / 2>(k, lane);
+    return k;
+}
+
+// ascending bitonic sort of one key per lane across the 64-lane wave (21 compare-exchange steps)
+__device__ __forceinline__ unsigned long long wave_sort64(unsigned long long k, int lane) {
+    k = bitonic_merge<2, 1>(k, lane);
+    k = bitonic_merge<4, 2>(k, lane);
+    k = bitonic_merge<8, 4>(k, lane);
+    k = bitonic_merge<16, 8>(k, lane);
+    k = bitonic_merge<32, 16>(k, lane);
+    k = bitonic_merge<64, 32>(k, lane);
     return k;
 }
 
