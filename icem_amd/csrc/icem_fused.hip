@@ -679,22 +679,63 @@ __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs 
         }
     }
     if (a.dbg_stop == 1) { if (k[0][0] == 12345ull) a.best_cost[0] = 1.f; return; }
-    for (int r = 0; r < a.K; ++r) {
-        unsigned long long mine = k[0][0];
+    // old mean/std of this lane's elements: issued now, consumed after the selection
+    constexpr int EPL = 8;
+    const bool pre = hd <= MERGE_WG * EPL;
+    float om[EPL], os[EPL];
 #pragma unroll
-        for (int l = 1; l < LPL; ++l) mine = k[l][0] < mine ? k[l][0] : mine;
-        const unsigned long long best = wave_min_u64(mine);
-        if (best != KEY_SENTINEL) {  // keys embed the trajectory index: exactly one (lane, list) matches
+    for (int i = 0; i < EPL; ++i) {
+        const int e = tid + i * MERGE_WG;
+        om[i] = (pre && e < hd) ? a.mean[e] : 0.f;
+        os[i] = (pre && e < hd) ? a.std[e] : 0.f;
+    }
+    // ---- selection by threshold: the K-th smallest of the 64 lane minima bounds the K-th smallest key
+    // overall, so the global top-K is among the keys <= T; those (usually K..2K of them) are compacted
+    // into one key per lane and sorted.  Two 64-key sorts instead of K dependent tournament rounds.
+    __shared__ unsigned cand_n;
+    __shared__ unsigned long long cand[64];
+    if (tid == 0) cand_n = 0;
+    unsigned long long mine = k[0][0];
 #pragma unroll
-            for (int l = 0; l < LPL; ++l) {
-                if (k[l][0] == best) {
+    for (int l = 1; l < LPL; ++l) mine = k[l][0] < mine ? k[l][0] : mine;
+    const unsigned long long srt = wave_sort64(mine, tid);
+    const unsigned long long T = __shfl(srt, a.K - 1, 64);
+    __syncthreads();
 #pragma unroll
-                    for (int i = 0; i + 1 < KREG; ++i) k[l][i] = k[l][i + 1];
-                    k[l][KREG - 1] = KEY_SENTINEL;
-                }
+    for (int l = 0; l < LPL; ++l) {
+#pragma unroll
+        for (int i = 0; i < KREG; ++i) {
+            if (k[l][i] <= T && k[l][i] != KEY_SENTINEL) {
+                const unsigned slot = atomicAdd(&cand_n, 1u);
+                if (slot < 64) cand[slot] = k[l][i];
             }
         }
-        if (tid == 0) sel[r] = best;
+    }
+    __syncthreads();
+    const unsigned n_cand = cand_n;
+    if (n_cand <= 64) {
+        unsigned long long key = tid < (int)n_cand ? cand[tid] : KEY_SENTINEL;
+        key = wave_sort64(key, tid);
+        if (tid < a.K) sel[tid] = key;
+    } else {
+        // more than 64 keys tie at or below T: K tournament rounds over the list heads
+        for (int r = 0; r < a.K; ++r) {
+            unsigned long long head = k[0][0];
+#pragma unroll
+            for (int l = 1; l < LPL; ++l) head = k[l][0] < head ? k[l][0] : head;
+            const unsigned long long best = wave_min_u64(head);
+            if (best != KEY_SENTINEL) {  // keys embed the trajectory index: exactly one (lane, list) matches
+#pragma unroll
+                for (int l = 0; l < LPL; ++l) {
+                    if (k[l][0] == best) {
+#pragma unroll
+                        for (int i = 0; i + 1 < KREG; ++i) k[l][i] = k[l][i + 1];
+                        k[l][KREG - 1] = KEY_SENTINEL;
+                    }
+                }
+            }
+            if (tid == 0) sel[r] = best;
+        }
     }
     __syncthreads();
     if (a.dbg_stop == 2) { if (tid < a.K) a.elites_cost_next[tid] = key_cost(sel[tid]); return; }
@@ -706,25 +747,49 @@ __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs 
         rows[r] = g < a.n_pool ? a.actions + (size_t)g * hd : a.elites_cur + (size_t)(g - a.n_global) * hd;
     }
     auto src_row = [&](int r) -> const float* { return rows[r]; };
-    for (int e = tid; e < hd; e += MERGE_WG) {
-        float xs[KREG];
-#pragma unroll
-        for (int r = 0; r < KREG; ++r) xs[r] = rows[r][e];
-        const float old_mean = a.mean[e], old_std = a.std[e];
+    auto finish_one = [&](int e, const float (&xs)[KREG], float old_mean, float old_std) {
 #pragma unroll
         for (int r = 0; r < KREG; ++r)
             if (r < a.K) a.elites_next[(size_t)r * hd + e] = xs[r];
         float nm, ns;
-        refit_element<float>(a.K, a.alpha, old_mean, old_std, [&](int r) {
-            float v = xs[0];
-#pragma unroll
-            for (int q = 1; q < KREG; ++q) v = (q == r) ? xs[q] : v;
-            return v; }, nm, ns);
+        refit_element_regs<float, KREG>(a.K, a.alpha, old_mean, old_std, xs, nm, ns);
         if (!a.last) {
             a.mean[e] = nm;
             a.std[e] = ns;
         } else {
             new_mean[e] = nm;
+        }
+    };
+    if (pre) {
+        // every elite value this lane needs, in flight at once (addresses clamped past the end)
+        constexpr int EP2 = 4;
+        for (int i0 = 0; i0 < EPL && tid + i0 * MERGE_WG < hd; i0 += EP2) {
+            float xs[EP2][KREG];
+#pragma unroll
+            for (int i = 0; i < EP2; ++i) {
+                const int e = tid + (i0 + i) * MERGE_WG;
+                const int ec = e < hd ? e : 0;
+#pragma unroll
+                for (int r = 0; r < KREG; ++r) xs[i][r] = rows[r][ec];
+            }
+#pragma unroll
+            for (int i = 0; i < EP2; ++i) {
+                const int e = tid + (i0 + i) * MERGE_WG;
+                float o_m = 0.f, o_s = 0.f;
+#pragma unroll
+                for (int q = 0; q < EPL; ++q) {
+                    o_m = (q == i0 + i) ? om[q] : o_m;
+                    o_s = (q == i0 + i) ? os[q] : o_s;
+                }
+                if (e < hd) finish_one(e, xs[i], o_m, o_s);
+            }
+        }
+    } else {
+        for (int e = tid; e < hd; e += MERGE_WG) {
+            float xs[KREG];
+#pragma unroll
+            for (int r = 0; r < KREG; ++r) xs[r] = rows[r][e];
+            finish_one(e, xs, a.mean[e], a.std[e]);
         }
     }
     if (tid < a.K) a.elites_cost_next[tid] = key_cost(sel[tid]);

@@ -30,4 +30,29 @@ __device__ __forceinline__ void refit_element(int K, T alpha, T old_mean, T old_
     new_std = fma_t(one_m, sd, alpha * old_std);
 }
 
+// Same arithmetic, same order, for K values already in registers (x[r], r < K <= KMAX): every loop is
+// static so nothing is indexed dynamically.
+template <typename T, int KMAX>
+__device__ __forceinline__ void refit_element_regs(int K, T alpha, T old_mean, T old_std, const T (&x)[KMAX], T& new_mean,
+                                                   T& new_std) {
+#pragma clang fp contract(off)
+    T s = (T)0;
+#pragma unroll
+    for (int r = 0; r < KMAX; ++r)
+        if (r < K) s = s + x[r];
+    const T m = s / (T)K;
+    T v = (T)0;
+#pragma unroll
+    for (int r = 0; r < KMAX; ++r) {
+        if (r < K) {
+            const T dx = x[r] - m;
+            v = fma_t(dx, dx, v);
+        }
+    }
+    const T sd = sqrt_t(v / (T)K);
+    const T one_m = (T)1 - alpha;
+    new_mean = fma_t(one_m, m, alpha * old_mean);
+    new_std = fma_t(one_m, sd, alpha * old_std);
+}
+
 }  // namespace icem

@@ -501,3 +501,49 @@ def test_sharded_processes_on_one_gpu(tmp_path):
         z = np.load(tmp_path / f"r{r}.npz")
         assert np.array_equal(z["acts"], acts)
         assert np.array_equal(z["mean"], np_(pl.mean))
+
+
+@pytest.mark.parametrize("h,d,o", [(30, 6, 17), (30, 6, 18), (12, 6, 17), (13, 4, 17)])
+@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("mode", ["sum", "best", "final"])
+def test_fast_kernels_all_compiled_shapes(h, d, o, kind, mode):
+    """The f32 throughput kernels (folded sampler, matrix-pipe rollout with per-workgroup top-K, one-wave
+    merge) on every compiled shape, both model kinds, all three cost reductions and ragged populations
+    (not multiples of 64 / of the sampler tile), against the oracle driven by the same RNG stream."""
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner
+    from icem_amd.envs import CostSpec
+    N, seed, iters = 777, 31 + h + o, 3
+    low, high = -np.ones(d), np.ones(d)
+    model = DeviceSyntheticModel.make(o, d, kind=kind)
+    spec = O.CostSpec(0.1, o - 2, -1.0, 3, 10.0, 0.05)  # lin/flip on non-default columns: exercises the permutation
+    pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=N, opt_iters=iters, cost_mode=mode, dtype="f32",
+                                seed=seed), low, high)
+    pl.set_model(kind, model.A, model.B)
+    pl.set_cost(spec.ctrl_weight, spec.lin_idx, spec.lin_weight, spec.flip_idx, spec.flip_penalty, spec.flip_thresh)
+    rs = np.random.RandomState(5)
+    obs0 = 0.3 * rs.randn(o)
+    om = O.SyntheticModel(model.A, model.B, kind)
+    # K1 + K2 stand-alone
+    mean, std = rs.uniform(-0.2, 0.2, (h, d)), rs.uniform(0.2, 0.6, (h, d))
+    act = np_(pl.sample_clip(N, mean, std, offset=9, first_index=5))
+    zr, zi = O.philox_white_noise(seed, 9, N, d, h, first_index=5, dtype=np.float32)
+    ref_act = O.sample_action_sequences(mean, std, low, high, 0.25, zr.astype(np.float64), zi.astype(np.float64))
+    np.testing.assert_allclose(act, ref_act, rtol=0, atol=2e-5)
+    costs = np_(pl.rollout_cost(obs0, act))
+    ref_costs = O.rollout_costs(om, spec, obs0, act, mode=mode)
+    np.testing.assert_allclose(costs, ref_costs, rtol=2e-5, atol=5e-5)
+    assert (np.abs(O.rollout_observations(om, obs0, act)[..., 3]) > 0.05).any()  # flip term exercised
+    # whole MPC steps through the fused plan path
+    pl.reset()
+    noise = O.PhiloxNoiseSchedule(seed, iters, d, h, dtype=np.float32)
+    orc = O.IcemOracle(O.IcemParams(horizon=h, num_simulated_trajectories=N, opt_iterations=iters,
+                                    cost_along_trajectory=mode), low, high,
+                       lambda ob, ac: O.rollout_costs(om, spec, ob, ac, mode=mode),
+                       lambda num: tuple(z.astype(np.float64) for z in noise(num)))
+    orc.beginning_of_rollout()
+    for s in range(2):
+        if s:
+            noise.begin_step()
+        a = np_(pl.plan_step(obs0))
+        np.testing.assert_allclose(a, orc.get_action(obs0), rtol=5e-4, atol=5e-5)
+    np.testing.assert_allclose(np_(pl.mean), orc.mean, rtol=5e-4, atol=5e-5)
