@@ -19,7 +19,12 @@ struct FastSampleArgs {
     const float* high;
     uint32_t seed_lo, seed_hi, off_lo, off_hi;
     int row0_mean;
-    float* out;  // [n, h, d]
+    float* out;  // [n (+ n_shift), h, d]
+    // optional shifted elites (icem.py:91-104), handled by one extra workgroup of the same launch:
+    // rows [n, n + n_shift) <- elites_src[e, 1:, :] ++ one freshly sampled last action (stream off2)
+    int n_shift;
+    const float* elites_src;  // [>= n_shift, h, d]
+    uint32_t off2_lo, off2_hi;
 };
 bool fast_sample_supported(int h, int d);
 void launch_sample_folded(const FastSampleArgs& a, int rounds, hipStream_t st);

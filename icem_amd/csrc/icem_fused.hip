@@ -244,6 +244,29 @@ __global__ __launch_bounds__(SWG) void sample_folded_kernel(FastSampleArgs a) {
     const int n_base = blockIdx.x * tpw;
     const int n_here = cmin(tpw, a.n - n_base);
     __syncthreads();
+    if (a.n_shift > 0 && blockIdx.x == gridDim.x - 1) {
+        // the extra workgroup: shifted elites.  Row (e, j) keeps elites[e, 1:, j] and draws its last action
+        // from the full (n_shift, d, h) noise batch of stream off2 (only t = h-1 is used, icem.py:102)
+        if (tid < a.n_shift * d) {
+            const int e = tid / d;
+            const int j = tid - e * d;
+            const float lo = a.low[j], hi = a.high[j];
+            float last = 0.f;
+            sample_row<H, ROUNDS>(a.W, (unsigned)e, (unsigned)j, a.off2_lo, a.off2_hi, a.seed_lo, a.seed_hi,
+                                  [&](int t, float y) {
+                                      if (t == H - 1) {
+                                          float v = __builtin_fmaf(y, ms[hd + t * d + j], ms[t * d + j]);
+                                          v = v < lo ? lo : v;
+                                          last = v > hi ? hi : v;
+                                      }
+                                  });
+            float* dst = a.out + (size_t)(a.n + e) * hd + j;
+            const float* src = a.elites_src + (size_t)e * hd + j;
+            for (int t = 0; t < H - 1; ++t) dst[t * d] = src[(t + 1) * d];
+            dst[(H - 1) * d] = last;
+        }
+        return;
+    }
     if (tid < n_here * d) {
         const int nl = tid / d;
         const int j = tid - nl * d;
@@ -845,7 +868,7 @@ bool fast_sample_supported(int h, int d) {
 
 void launch_sample_folded(const FastSampleArgs& a, int rounds, hipStream_t st) {
     const int tpw = SWG / a.d;
-    const int grid = (a.n + tpw - 1) / tpw;
+    const int grid = (a.n + tpw - 1) / tpw + (a.n_shift > 0 ? 1 : 0);
     const size_t lds = ((size_t)2 * a.h * a.d + (size_t)tpw * a.h * a.d) * sizeof(float);
 #define X(HH)                                                                                        \
     if (a.h == HH) {                                                                                 \

@@ -919,8 +919,9 @@ bool fast_sample_ok(const icem_handle* h) {
 }
 
 int launch_fast_sample(const icem_handle* h, int n, long long first_index, const void* mean, const void* std,
-                       const void* low, const void* high, uint64_t offset, int row0_mean, void* out, hipStream_t st) {
-    if (n <= 0) return ICEM_OK;
+                       const void* low, const void* high, uint64_t offset, int row0_mean, void* out, hipStream_t st,
+                       int n_shift = 0, const void* elites_src = nullptr, uint64_t offset2 = 0) {
+    if (n <= 0 && n_shift <= 0) return ICEM_OK;
     FastSampleArgs a;
     a.n = n;
     a.h = h->cfg.horizon;
@@ -937,6 +938,10 @@ int launch_fast_sample(const icem_handle* h, int n, long long first_index, const
     a.off_hi = (uint32_t)(offset >> 32);
     a.row0_mean = row0_mean;
     a.out = (float*)out;
+    a.n_shift = n_shift;
+    a.elites_src = (const float*)elites_src;
+    a.off2_lo = (uint32_t)offset2;
+    a.off2_hi = (uint32_t)(offset2 >> 32);
     {
         ProfScope prof(h, ICEM_K_SAMPLE, (long long)n * a.h, st);
         launch_sample_folded(a, h->cfg.rng_rounds, st);
@@ -958,16 +963,24 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
     T* actions = (T*)b->actions;
     // shifted elites, simulated at iteration 0 of every MPC step but the first (icem.py:131-137)
     int n_extra = 0;
+    const T* shift_src = nullptr;
+    bool shift_in_sampler = false;
     if (it == 0 && c.shift_elites && mpc_step > 0 && h->n_reuse > 0) {
         n_extra = h->n_reuse;
         const int g = (int)(((long long)mpc_step * c.opt_iters) & 1);  // elite buffer holding the previous step's set
-        const T* el = (const T*)b->elites + (size_t)g * K * hd;
-        T* dst = actions + (size_t)n_loc * hd;
-        hipLaunchKernelGGL((shift_elites_kernel<T>), dim3(1), dim3(WG), 0, st, n_extra, c.horizon, c.act_dim, el, dst);
-        SampleArgs<T> a = make_sample_args<T>(h, n_extra, 0, b->mean, b->std, b->low, b->high, b->z_r_shift, b->z_i_shift,
-                                              call_base + (uint64_t)c.opt_iters, c.horizon - 1, 0, dst);
-        int rc = launch_sample<T>(h, a, st);
-        if (rc) return rc;
+        shift_src = (const T*)b->elites + (size_t)g * K * hd;
+        // the fast sampler prepares them in an extra workgroup of its own launch
+        shift_in_sampler = std::is_same<T, float>::value && b->z_r == nullptr && b->z_r_shift == nullptr &&
+                           fast_rollout_ok(h, K) && fast_sample_ok(h) && !h->use_fused &&
+                           n_extra * c.act_dim <= 256;
+        if (!shift_in_sampler) {
+            T* dst = actions + (size_t)n_loc * hd;
+            hipLaunchKernelGGL((shift_elites_kernel<T>), dim3(1), dim3(WG), 0, st, n_extra, c.horizon, c.act_dim, shift_src, dst);
+            SampleArgs<T> a = make_sample_args<T>(h, n_extra, 0, b->mean, b->std, b->low, b->high, b->z_r_shift, b->z_i_shift,
+                                                  call_base + (uint64_t)c.opt_iters, c.horizon - 1, 0, dst);
+            int rc = launch_sample<T>(h, a, st);
+            if (rc) return rc;
+        }
     }
     // candidates: the shard, plus the shifted elites on rank 0 only (they are replicated)
     const int n_cand = n_loc + (c.rank == 0 ? n_extra : 0);
@@ -1030,7 +1043,8 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                 ICEM_HIP_TRY(hipGetLastError());
             } else {
                 if (fast_sample_ok(h)) {
-                    rc = launch_fast_sample(h, n_loc, lo, b->mean, b->std, b->low, b->high, off, row0, actions, st);
+                    rc = launch_fast_sample(h, n_loc, lo, b->mean, b->std, b->low, b->high, off, row0, actions, st,
+                                            shift_in_sampler ? n_extra : 0, shift_src, call_base + (uint64_t)c.opt_iters);
                 } else {
                     SampleArgs<T> a = make_sample_args<T>(h, n_loc, lo, b->mean, b->std, b->low, b->high, nullptr, nullptr,
                                                           off, 0, row0, actions);
