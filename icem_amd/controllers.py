@@ -14,6 +14,8 @@ Two execution paths, chosen by the forward model:
 * device path  -- ``forward_model`` is a :class:`~icem_amd.models.DeviceSyntheticModel` and the
   env carries a ``cost_spec``: the whole MPC step (all CEM iterations) is enqueued on one HIP
   stream with no host synchronisation; only ``obs`` goes in and the action comes out.
+* torch-model path -- a device-resident ``torch.nn.Module`` model (``TorchForwardModel``): sampling,
+  cost reduction, top-k and refit in HIP, the learned model's batched steps in torch on the same GPU.
 * host-model path -- any object with the reference's ``predict_n_steps`` contract: sampling,
   top-k and refit run on the GPU, the model/cost run wherever the model runs.
 """
@@ -209,6 +211,8 @@ class MpcICemHip(MpcController):
         self.device_path = (isinstance(self.forward_model, DeviceSyntheticModel)
                             and getattr(self.env, "cost_spec", None) is not None
                             and not self.use_env_reward_as_cost)
+        self.torch_path = (not self.device_path and hasattr(self.forward_model, "torch_step")
+                           and hasattr(self.forward_model, "torch_cost"))
         if self.device_path:
             m, c = self.forward_model, self.env.cost_spec
             self.planner.set_model(m.kind, m.A, m.B)
@@ -320,14 +324,34 @@ class MpcICemHip(MpcController):
             host = torch.cat([executed_dev, self.planner.best_cost]).cpu().numpy().astype(np.float64)  # one D2H sync
             executed_action, self.last_min_cost = host[:-1], float(host[-1])
         else:
-            executed_action = self._get_action_host_model(obs, noise)
+            executed_action = self._get_action_stagewise(obs, noise)
         self.logger.log(self.last_min_cost, key="Expected_trajectory_cost")
         if self.forward_model_state is not None:  # stateful models advance with the executed action
             _, self.forward_model_state, _ = self.forward_model.predict(
                 observations=obs, states=self.forward_model_state, actions=executed_action)
         return executed_action
 
-    def _get_action_host_model(self, obs, noise):
+    def _costs_of(self, obs, actions: torch.Tensor) -> torch.Tensor:
+        """Per-trajectory costs (device tensor) of a batch of device action sequences, through whichever
+        model this controller was given."""
+        p = self.planner
+        if self.torch_path:
+            # device-resident torch model (learned dynamics): h batched steps on the GPU, step costs reduced by
+            # the HIP cost_reduce kernel; nothing leaves the device
+            m = self.forward_model
+            o = torch.as_tensor(np.asarray(obs, dtype=np.float64), dtype=m.dtype, device=p.device)
+            o = o.expand(actions.shape[0], -1)
+            step_costs = torch.empty((actions.shape[0], p.h), dtype=p.dt, device=p.device)
+            a_all = actions.to(m.dtype)
+            for t in range(p.h):
+                step_costs[:, t] = m.torch_cost(o, a_all[:, t]).to(p.dt)
+                o = m.torch_step(o, a_all[:, t])
+            return p.cost_reduce(step_costs)
+        batch = self.simulate_trajectories(obs=obs, state=self.forward_model_state,
+                                           action_sequences=actions.cpu().numpy().astype(np.float64))
+        return torch.as_tensor(self.trajectory_cost_fn(self.cost_fn, batch), dtype=p.dt, device=p.device)
+
+    def _get_action_stagewise(self, obs, noise):
         p = self.planner
         K, it_n = self.num_elites, self.opt_iter
         call_base = p.mpc_step * (it_n + 1)
@@ -343,9 +367,7 @@ class MpcICemHip(MpcController):
                 p.sample_clip(p.n_reuse, p.mean, p.std, zs[0], zs[1], offset=call_base + it_n, t_begin=p.h - 1,
                               out=shifted)
                 actions = torch.cat([actions, shifted], dim=0)
-            batch = self.simulate_trajectories(obs=obs, state=self.forward_model_state,
-                                               action_sequences=actions.cpu().numpy().astype(np.float64))
-            costs = torch.as_tensor(self.trajectory_cost_fn(self.cost_fn, batch), dtype=p.dt, device=p.device)
+            costs = self._costs_of(obs, actions)
             pool = actions
             if i > 0 and self.keep_previous_elites:
                 pool = torch.cat([actions, self._elite_actions[:p.n_reuse]], dim=0)

@@ -20,6 +20,7 @@
 
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -132,33 +133,23 @@ __device__ __forceinline__ void sample_row(const float* __restrict__ W, unsigned
         }
         emit(0, e0 + e1);
     }
-    // table rows are wave-uniform scalar loads: double-buffered so the load of row tp+1 flies under the
-    // FMAs of row tp (the compiler otherwise waits for each row right after issuing its load)
-    float wc[HMAX];
-#pragma unroll
-    for (int m = 0; m < H; ++m) wc[m] = W[HMAX + m];
 #pragma unroll 1
     for (int tp = 1; tp <= H / 2; ++tp) {
-        float wn[HMAX];
-        const float* __restrict__ wnext = W + (tp < H / 2 ? tp + 1 : tp) * HMAX;
-#pragma unroll
-        for (int m = 0; m < H; ++m) wn[m] = wnext[m];
+        const float* __restrict__ w = W + tp * HMAX;
         float e0 = 0.f, e1 = 0.f, o0 = 0.f, o1 = 0.f;
 #pragma unroll
         for (int m = 0; m < F; m += 2) {
-            e0 = __builtin_fmaf(g[m], wc[m], e0);
-            if (m + 1 < F) e1 = __builtin_fmaf(g[m + 1], wc[m + 1], e1);
+            e0 = __builtin_fmaf(g[m], w[m], e0);
+            if (m + 1 < F) e1 = __builtin_fmaf(g[m + 1], w[m + 1], e1);
         }
 #pragma unroll
         for (int m = F; m < H; m += 2) {
-            o0 = __builtin_fmaf(g[m], wc[m], o0);
-            if (m + 1 < H) o1 = __builtin_fmaf(g[m + 1], wc[m + 1], o1);
+            o0 = __builtin_fmaf(g[m], w[m], o0);
+            if (m + 1 < H) o1 = __builtin_fmaf(g[m + 1], w[m + 1], o1);
         }
         const float e = e0 + e1, od = o0 + o1;
         emit(tp, e + od);
         if (H - tp != tp) emit(H - tp, e - od);
-#pragma unroll
-        for (int m = 0; m < H; ++m) wc[m] = wn[m];
     }
 }
 

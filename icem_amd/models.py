@@ -133,3 +133,42 @@ class DeviceSyntheticModel(ForwardModel):
         if self.kind == MODEL_TANH:
             nxt = np.tanh(nxt)
         return nxt, None, np.zeros(observations.shape[:-1] + (1,))
+
+
+class TorchForwardModel(ForwardModel):
+    """Adapter for a learned, device-resident dynamics model (the README's PlaNet column has no
+    code in the reference, so the architecture is the caller's).  ``module(obs[N,o], act[N,d]) -> next_obs[N,o]``
+    is any ``torch.nn.Module`` on the GPU (its GEMMs run on the matrix cores through hipBLASLt, bf16 if the
+    module is bf16); ``cost(obs, act) -> [N]`` is a torch callable.  ``MpcICemHip`` keeps the whole CEM loop on
+    the device with it; ``predict`` serves the reference-style NumPy interface."""
+
+    def __init__(self, module, cost, obs_dim: int, act_dim: int, dtype=None, device="cuda:0", env=None):
+        super().__init__(env=env)
+        import torch
+        self.module = module.to(device)
+        self.cost = cost
+        self.obs_dim, self.act_dim = obs_dim, act_dim
+        self.device = torch.device(device)
+        self.dtype = dtype or next(module.parameters()).dtype
+
+    def torch_step(self, obs, act):
+        import torch
+        with torch.no_grad():
+            return self.module(obs, act)
+
+    def torch_cost(self, obs, act):
+        import torch
+        with torch.no_grad():
+            return self.cost(obs, act)
+
+    def predict(self, *, observations, states, actions):
+        import torch
+        o = torch.as_tensor(np.asarray(observations), dtype=self.dtype, device=self.device)
+        a = torch.as_tensor(np.asarray(actions), dtype=self.dtype, device=self.device)
+        single = o.ndim == 1
+        if single:
+            o, a = o[None], a[None]
+        nxt = self.torch_step(o, a).float().cpu().numpy().astype(np.float64)
+        if single:
+            nxt = nxt[0]
+        return nxt, None, np.zeros(nxt.shape[:-1] + (1,))

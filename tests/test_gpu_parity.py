@@ -547,3 +547,71 @@ def test_fast_kernels_all_compiled_shapes(h, d, o, kind, mode):
         a = np_(pl.plan_step(obs0))
         np.testing.assert_allclose(a, orc.get_action(obs0), rtol=5e-4, atol=5e-5)
     np.testing.assert_allclose(np_(pl.mean), orc.mean, rtol=5e-4, atol=5e-5)
+
+
+def test_torch_model_path_matches_oracle():
+    """f-2: a torch nn.Module dynamics (MLP, f32) behind MpcICemHip: sampling / cost reduction / top-k /
+    refit in HIP, the model's batched steps in torch on the GPU; checked against the oracle driving a NumPy
+    copy of the same network with the same RNG stream.  Also runs the module in bf16 (matrix cores) and
+    checks self-consistency of the planner's outputs."""
+    from icem_amd import MpcICemHip, TorchForwardModel, halfcheetah_env
+    torch.manual_seed(0)
+    o, d, h, N, iters, seed = 17, 6, 12, 512, 3, 77
+
+    class Dyn(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.l1 = torch.nn.Linear(o + d, 64)
+            self.l2 = torch.nn.Linear(64, o)
+
+        def forward(self, obs, act):
+            return obs + 0.1 * self.l2(torch.tanh(self.l1(torch.cat([obs, act], dim=-1))))
+
+    net = Dyn()
+    cost_t = lambda ob, ac: 0.1 * (ac ** 2).sum(-1) - ob[:, 8] + 10.0 * (ob[:, 1].abs() > np.pi / 2)
+    env = halfcheetah_env(o)
+    model = TorchForwardModel(net, cost_t, o, d)
+    ctrl = MpcICemHip(env=env, forward_model=model, horizon=h, num_simulated_trajectories=N, factor_decrease_num=1.25,
+                      cost_along_trajectory="sum", dtype="f32", seed=seed,
+                      action_sampler_params=dict(alpha=0.1, elites_size=10, opt_iterations=iters, init_std=0.5,
+                                                 use_mean_actions=True, keep_previous_elites=True,
+                                                 shift_elites_over_time=True, fraction_elites_reused=0.3,
+                                                 noise_beta=0.25))
+    assert ctrl.torch_path and not ctrl.device_path
+    W1, b1 = net.l1.weight.detach().cpu().numpy().astype(np.float64), net.l1.bias.detach().cpu().numpy().astype(np.float64)
+    W2, b2 = net.l2.weight.detach().cpu().numpy().astype(np.float64), net.l2.bias.detach().cpu().numpy().astype(np.float64)
+
+    def rollout_cost(obs, actions):
+        ob = np.broadcast_to(obs, (actions.shape[0], o)).copy()
+        acc = np.zeros(actions.shape[0])
+        for t in range(h):
+            a = actions[:, t]
+            acc += 0.1 * (a ** 2).sum(-1) - ob[:, 8] + 10.0 * (np.abs(ob[:, 1]) > np.pi / 2)
+            ob = ob + 0.1 * (np.tanh(np.concatenate([ob, a], -1) @ W1.T + b1) @ W2.T + b2)
+        return acc
+
+    noise = O.PhiloxNoiseSchedule(seed, iters, d, h, dtype=np.float32)
+    orc = O.IcemOracle(O.IcemParams(horizon=h, num_simulated_trajectories=N, opt_iterations=iters),
+                       env.action_space.low.astype(np.float64), env.action_space.high.astype(np.float64), rollout_cost,
+                       lambda num: tuple(z.astype(np.float64) for z in noise(num)))
+    obs = 0.1 * np.random.RandomState(3).randn(o)
+    ctrl.beginning_of_rollout(observation=obs, state=None, mode="train")
+    orc.beginning_of_rollout()
+    for s in range(2):
+        if s:
+            noise.begin_step()
+        a = ctrl.get_action(obs, None)
+        np.testing.assert_allclose(a, orc.get_action(obs), rtol=2e-4, atol=2e-5)
+    # bf16 module: runs, stays in bounds, deterministic
+    model16 = TorchForwardModel(Dyn().to(torch.bfloat16), cost_t, o, d, dtype=torch.bfloat16)
+    c16 = MpcICemHip(env=env, forward_model=model16, horizon=h, num_simulated_trajectories=N, factor_decrease_num=1.25,
+                     cost_along_trajectory="sum", dtype="f32", seed=seed,
+                     action_sampler_params=dict(alpha=0.1, elites_size=10, opt_iterations=iters, init_std=0.5,
+                                                use_mean_actions=True, keep_previous_elites=True,
+                                                shift_elites_over_time=True, fraction_elites_reused=0.3,
+                                                noise_beta=0.25))
+    outs = []
+    for rep in range(2):
+        c16.beginning_of_rollout(observation=obs, state=None, mode="train")
+        outs.append(c16.get_action(obs, None))
+    assert np.array_equal(outs[0], outs[1]) and np.all(np.abs(outs[0]) <= 1.0)
