@@ -266,10 +266,8 @@ __global__ __launch_bounds__(SWG) void sample_folded_kernel(FastSampleArgs a) {
         const float* mrow = ms + j;
         sample_row<H, ROUNDS>(a.W, (unsigned)(a.first_index + n_base + nl), (unsigned)j, a.off_lo, a.off_hi, a.seed_lo,
                               a.seed_hi, [&](int t, float y) {
-                                  float v = __builtin_fmaf(y, mrow[hd + t * d], mrow[t * d]);
-                                  v = v < lo ? lo : v;
-                                  v = v > hi ? hi : v;
-                                  trow[t * d] = v;
+                                  const float v = __builtin_fmaf(y, mrow[hd + t * d], mrow[t * d]);
+                                  trow[t * d] = __builtin_amdgcn_fmed3f(v, lo, hi);  // clip in one v_med3_f32
                               });
     }
     __syncthreads();
@@ -617,10 +615,10 @@ __global__ __launch_bounds__(FWG) void fused_iter_kernel(FusedArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// merge: global sorted top-K from <= 256 sorted candidate lists (+ kept elites), one wavefront
+// merge: global sorted top-K from <= 256 sorted candidate lists (+ kept elites)
 // -------------------------------------------------------------------------------------------------
-constexpr int MERGE_WG = 64;  // ONE wavefront: no LDS hops, no barriers in the selection rounds
-constexpr int LPL = 4;        // candidate lists per lane (<= 256 lists)
+constexpr int MERGE_WG = 256;  // wave 0 selects (no barriers inside); all 4 waves gather + refit
+constexpr int LPL = 4;         // candidate lists per lane of wave 0 (<= 256 lists)
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ unsigned long long min_dpp(unsigned long long x) {
@@ -649,52 +647,15 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long x)
 template <int KREG>
 __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs a) {
     __shared__ unsigned long long sel[64];
+    __shared__ unsigned cand_n;
+    __shared__ unsigned long long cand[64];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* new_mean = reinterpret_cast<float*>(smem_raw);
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
     const int hd = a.h * a.d;
-    // lane t owns candidate lists t, t+64, t+128, t+192 (each sorted) in registers; a winner pops by
-    // shifting its list's registers
-    unsigned long long k[LPL][KREG];
-    {
-        // all loads issued up front from clamped (always valid) addresses, selected afterwards
-        int idxs[LPL][KREG];
-        float cs[LPL][KREG];
-#pragma unroll
-        for (int l = 0; l < LPL; ++l) {
-            const int list = tid + l * MERGE_WG;
-            const size_t base = (size_t)(list < a.n_lists ? list : 0) * a.K;
-#pragma unroll
-            for (int i = 0; i < KREG; ++i) {
-                const int ii = i < a.K ? i : 0;
-                idxs[l][i] = a.part_i[base + ii];
-                cs[l][i] = a.part_c[base + ii];
-            }
-        }
-#pragma unroll
-        for (int l = 0; l < LPL; ++l) {
-            const bool has_list = tid + l * MERGE_WG < a.n_lists;
-#pragma unroll
-            for (int i = 0; i < KREG; ++i) {
-                const bool ok = has_list && i < a.K && idxs[l][i] != INT_MAX;
-                const unsigned long long v = make_key(cs[l][i], idxs[l][i]);
-                k[l][i] = ok ? v : KEY_SENTINEL;
-            }
-        }
-    }
-    if (tid < a.n_keep) {  // kept elite `tid` (icem.py:143-145) joins this lane's first list, order preserved
-        unsigned long long v = make_key(a.elites_cost_cur[tid], a.n_global + tid);
-#pragma unroll
-        for (int i = 0; i < KREG; ++i) {
-            const bool sw = v < k[0][i];
-            const unsigned long long t = sw ? k[0][i] : v;
-            k[0][i] = sw ? v : k[0][i];
-            v = t;
-        }
-    }
-    if (a.dbg_stop == 1) { if (k[0][0] == 12345ull) a.best_cost[0] = 1.f; return; }
-    // old mean/std of this lane's elements: issued now, consumed after the selection
-    constexpr int EPL = 8;
+    // old mean/std of this thread's elements: issued now, consumed after the selection
+    constexpr int EPL = 4;
     const bool pre = hd <= MERGE_WG * EPL;
     float om[EPL], os[EPL];
 #pragma unroll
@@ -703,65 +664,103 @@ __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs 
         om[i] = (pre && e < hd) ? a.mean[e] : 0.f;
         os[i] = (pre && e < hd) ? a.std[e] : 0.f;
     }
-    // ---- selection by threshold: the K-th smallest of the 64 lane minima bounds the K-th smallest key
-    // overall, so the global top-K is among the keys <= T; those (usually K..2K of them) are compacted
-    // into one key per lane and sorted.  Two 64-key sorts instead of K dependent tournament rounds.
-    __shared__ unsigned cand_n;
-    __shared__ unsigned long long cand[64];
     if (tid == 0) cand_n = 0;
-    unsigned long long mine = k[0][0];
+    if (tid < 64) {
+        // ---- wave 0: lane t owns candidate lists t, t+64, t+128, t+192 (each sorted) in registers ----
+        unsigned long long k[LPL][KREG];
+        {
+            // all loads issued up front from clamped (always valid) addresses, selected afterwards
+            int idxs[LPL][KREG];
+            float cs[LPL][KREG];
 #pragma unroll
-    for (int l = 1; l < LPL; ++l) mine = k[l][0] < mine ? k[l][0] : mine;
-    const unsigned long long srt = wave_sort64(mine, tid);
-    const unsigned long long T = __shfl(srt, a.K - 1, 64);
-    __syncthreads();
+            for (int l = 0; l < LPL; ++l) {
+                const int list = lane + l * 64;
+                const size_t base = (size_t)(list < a.n_lists ? list : 0) * a.K;
 #pragma unroll
-    for (int l = 0; l < LPL; ++l) {
-#pragma unroll
-        for (int i = 0; i < KREG; ++i) {
-            if (k[l][i] <= T && k[l][i] != KEY_SENTINEL) {
-                const unsigned slot = atomicAdd(&cand_n, 1u);
-                if (slot < 64) cand[slot] = k[l][i];
-            }
-        }
-    }
-    __syncthreads();
-    const unsigned n_cand = cand_n;
-    if (n_cand <= 64) {
-        unsigned long long key = tid < (int)n_cand ? cand[tid] : KEY_SENTINEL;
-        key = wave_sort64(key, tid);
-        if (tid < a.K) sel[tid] = key;
-    } else {
-        // more than 64 keys tie at or below T: K tournament rounds over the list heads
-        for (int r = 0; r < a.K; ++r) {
-            unsigned long long head = k[0][0];
-#pragma unroll
-            for (int l = 1; l < LPL; ++l) head = k[l][0] < head ? k[l][0] : head;
-            const unsigned long long best = wave_min_u64(head);
-            if (best != KEY_SENTINEL) {  // keys embed the trajectory index: exactly one (lane, list) matches
-#pragma unroll
-                for (int l = 0; l < LPL; ++l) {
-                    if (k[l][0] == best) {
-#pragma unroll
-                        for (int i = 0; i + 1 < KREG; ++i) k[l][i] = k[l][i + 1];
-                        k[l][KREG - 1] = KEY_SENTINEL;
-                    }
+                for (int i = 0; i < KREG; ++i) {
+                    const int ii = i < a.K ? i : 0;
+                    idxs[l][i] = a.part_i[base + ii];
+                    cs[l][i] = a.part_c[base + ii];
                 }
             }
-            if (tid == 0) sel[r] = best;
+#pragma unroll
+            for (int l = 0; l < LPL; ++l) {
+                const bool has_list = lane + l * 64 < a.n_lists;
+#pragma unroll
+                for (int i = 0; i < KREG; ++i) {
+                    const bool ok = has_list && i < a.K && idxs[l][i] != INT_MAX;
+                    const unsigned long long v = make_key(cs[l][i], idxs[l][i]);
+                    k[l][i] = ok ? v : KEY_SENTINEL;
+                }
+            }
+        }
+        if (lane < a.n_keep) {  // kept elite `lane` (icem.py:143-145) joins this lane's first list, order preserved
+            unsigned long long v = make_key(a.elites_cost_cur[lane], a.n_global + lane);
+#pragma unroll
+            for (int i = 0; i < KREG; ++i) {
+                const bool sw = v < k[0][i];
+                const unsigned long long t = sw ? k[0][i] : v;
+                k[0][i] = sw ? v : k[0][i];
+                v = t;
+            }
+        }
+        // selection by threshold: the K-th smallest of the 64 lane minima bounds the K-th smallest key overall,
+        // so the global top-K is among the keys <= T; those (usually K..2K of them) are compacted into one key
+        // per lane and sorted.  Two 64-key sorts instead of K dependent tournament rounds.
+        unsigned long long mine = k[0][0];
+#pragma unroll
+        for (int l = 1; l < LPL; ++l) mine = k[l][0] < mine ? k[l][0] : mine;
+        const unsigned long long srt = wave_sort64(mine, lane);
+        const unsigned long long T = __shfl(srt, a.K - 1, 64);
+#pragma unroll
+        for (int l = 0; l < LPL; ++l) {
+#pragma unroll
+            for (int i = 0; i < KREG; ++i) {
+                if (k[l][i] <= T && k[l][i] != KEY_SENTINEL) {
+                    const unsigned slot = atomicAdd(&cand_n, 1u);
+                    if (slot < 64) cand[slot] = k[l][i];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        const unsigned n_cand = *((volatile unsigned*)&cand_n);
+        if (n_cand <= 64) {
+            unsigned long long key = lane < (int)n_cand ? *((volatile unsigned long long*)&cand[lane]) : KEY_SENTINEL;
+            key = wave_sort64(key, lane);
+            if (lane < a.K) sel[lane] = key;
+        } else {
+            // more than 64 keys tie at or below T: K tournament rounds over the list heads
+            for (int r = 0; r < a.K; ++r) {
+                unsigned long long head = k[0][0];
+#pragma unroll
+                for (int l = 1; l < LPL; ++l) head = k[l][0] < head ? k[l][0] : head;
+                const unsigned long long best = wave_min_u64(head);
+                if (best != KEY_SENTINEL) {  // keys embed the trajectory index: exactly one (lane, list) matches
+#pragma unroll
+                    for (int l = 0; l < LPL; ++l) {
+                        if (k[l][0] == best) {
+#pragma unroll
+                            for (int i = 0; i + 1 < KREG; ++i) k[l][i] = k[l][i + 1];
+                            k[l][KREG - 1] = KEY_SENTINEL;
+                        }
+                    }
+                }
+                if (lane == 0) sel[r] = best;
+            }
         }
     }
     __syncthreads();
-    if (a.dbg_stop == 2) { if (tid < a.K) a.elites_cost_next[tid] = key_cost(sel[tid]); return; }
-    // gather + refit (icem.py:201-211): row pointers first, then all K loads of an element in flight
+    // ---- all 4 waves: gather + refit (icem.py:201-211); row pointers first, then all K loads in flight ----
     const float* rows[KREG];
 #pragma unroll
     for (int r = 0; r < KREG; ++r) {
         const int g = key_idx(sel[r < a.K ? r : 0]);
         rows[r] = g < a.n_pool ? a.actions + (size_t)g * hd : a.elites_cur + (size_t)(g - a.n_global) * hd;
     }
-    auto src_row = [&](int r) -> const float* { return rows[r]; };
-    auto finish_one = [&](int e, const float (&xs)[KREG], float old_mean, float old_std) {
+    auto finish_one = [&](int e, float old_mean, float old_std) {
+        float xs[KREG];
+#pragma unroll
+        for (int r = 0; r < KREG; ++r) xs[r] = rows[r][e];
 #pragma unroll
         for (int r = 0; r < KREG; ++r)
             if (r < a.K) a.elites_next[(size_t)r * hd + e] = xs[r];
@@ -775,36 +774,13 @@ __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs 
         }
     };
     if (pre) {
-        // every elite value this lane needs, in flight at once (addresses clamped past the end)
-        constexpr int EP2 = 4;
-        for (int i0 = 0; i0 < EPL && tid + i0 * MERGE_WG < hd; i0 += EP2) {
-            float xs[EP2][KREG];
 #pragma unroll
-            for (int i = 0; i < EP2; ++i) {
-                const int e = tid + (i0 + i) * MERGE_WG;
-                const int ec = e < hd ? e : 0;
-#pragma unroll
-                for (int r = 0; r < KREG; ++r) xs[i][r] = rows[r][ec];
-            }
-#pragma unroll
-            for (int i = 0; i < EP2; ++i) {
-                const int e = tid + (i0 + i) * MERGE_WG;
-                float o_m = 0.f, o_s = 0.f;
-#pragma unroll
-                for (int q = 0; q < EPL; ++q) {
-                    o_m = (q == i0 + i) ? om[q] : o_m;
-                    o_s = (q == i0 + i) ? os[q] : o_s;
-                }
-                if (e < hd) finish_one(e, xs[i], o_m, o_s);
-            }
+        for (int i = 0; i < EPL; ++i) {
+            const int e = tid + i * MERGE_WG;
+            if (e < hd) finish_one(e, om[i], os[i]);
         }
     } else {
-        for (int e = tid; e < hd; e += MERGE_WG) {
-            float xs[KREG];
-#pragma unroll
-            for (int r = 0; r < KREG; ++r) xs[r] = rows[r][e];
-            finish_one(e, xs, a.mean[e], a.std[e]);
-        }
+        for (int e = tid; e < hd; e += MERGE_WG) finish_one(e, a.mean[e], a.std[e]);
     }
     if (tid < a.K) a.elites_cost_next[tid] = key_cost(sel[tid]);
     if (a.last) {
@@ -814,7 +790,7 @@ __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs 
             a.mean[e] = (e + a.d < hd) ? new_mean[e + a.d] : new_mean[e];
             a.std[e] = (a.high[j] - a.low[j]) / 2.f * a.init_std;
         }
-        if (tid < a.d) a.executed[tid] = src_row(0)[tid];
+        if (tid < a.d) a.executed[tid] = rows[0][tid];
         if (tid == 0) a.best_cost[0] = key_cost(sel[0]);
     }
 }
