@@ -101,7 +101,6 @@ struct MergeSingleArgs {
     const float* high;
     float* executed;
     float* best_cost;
-    int dbg_stop;  // development: 1 = return after loading lists, 2 = after the rounds
 };
 void launch_merge_single(const MergeSingleArgs& a, hipStream_t st);
 

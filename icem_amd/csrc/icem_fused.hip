@@ -375,7 +375,7 @@ struct RolloutWave {
 #pragma unroll
                 for (int ct = 0; ct < CTF; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
                 // VALU block first, as ONE cluster: on gfx950 every MFMA<->VALU switch of a lone wave costs
-                // ~12 cycles (scratch/ubench3: 92 MFMAs = 762 cycles alone, 1862 with one v_fmac after
+                // ~12 cycles (tools/ubench/mfma_valu_switch.hip: 92 MFMAs = 762 cycles alone, 1862 with one v_fmac after
                 // each), so nothing may be interleaved into the MFMA stream.
                 {   // leftover model columns as scalar-operand FMA chains, 4 partial sums per column
                     float part[REM > 0 ? REM : 1][4];

@@ -1131,7 +1131,6 @@ int plan_iter_merge_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
             m.high = (const float*)b->high;
             m.executed = (float*)b->executed;
             m.best_cost = (float*)b->best_cost;
-            m.dbg_stop = getenv("ICEM_MERGE_STOP") ? atoi(getenv("ICEM_MERGE_STOP")) : 0;
             ProfScope prof(h, ICEM_K_MERGE_REFIT, h->fast_lists * K + m.n_keep, st);
             launch_merge_single(m, st);
             ICEM_HIP_TRY(hipGetLastError());
@@ -1221,7 +1220,9 @@ int icem_create(const icem_config* cfg, icem_handle** out) {
     h->tsize = c.dtype == ICEM_F64 ? 8 : 4;
     h->pop = population_sizes(c);
     h->n_reuse = (int)((double)c.num_elites * c.fraction_reused);  // int(len(elites)*xi), icem.py:98,145
-    h->n_local_max = shard_chunk(c.num_traj, c.world);
+    // the population can GROW after iteration 0 when N < 2*elites_size (icem.py:127 floors N_i at 2*elites_size)
+    h->n_local_max = 0;
+    for (int n_it : h->pop) h->n_local_max = std::max(h->n_local_max, shard_chunk(n_it, c.world));
     if (const char* e = getenv("ICEM_DISABLE_FAST")) h->use_fast = !(e[0] == '1');
     if (const char* e = getenv("ICEM_ENABLE_FUSED")) h->use_fused = (e[0] == '1');
     // synthesis table W[t][m]: m < F real part of bin m, F <= m < h imaginary part of bin m-F+1

@@ -615,3 +615,45 @@ def test_torch_model_path_matches_oracle():
         c16.beginning_of_rollout(observation=obs, state=None, mode="train")
         outs.append(c16.get_action(obs, None))
     assert np.array_equal(outs[0], outs[1]) and np.all(np.abs(outs[0]) <= 1.0)
+
+
+@pytest.mark.parametrize("N,K,iters,keep,shift,use_mean", [
+    (2, 10, 2, True, True, True),       # minimum population: K clamps to 2 (icem.py:237-240)
+    (20, 10, 3, True, True, True),      # N < one 64-lane tile; decay floor 2*elites_size
+    (65, 10, 3, False, True, False),    # one lane into the second tile
+    (300, 32, 2, True, False, True),    # largest K of the fast path
+    (300, 40, 2, True, True, True),     # K > 32: generic kernels take over
+    (1000, 3, 1, True, True, True),     # single iteration per step
+])
+def test_fast_path_edge_populations(N, K, iters, keep, shift, use_mean):
+    """Ragged / tiny populations and K extremes through the whole planner (f32, Philox) vs the oracle."""
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env
+    env = halfcheetah_env(17)
+    model = DeviceSyntheticModel.make(17, 6)
+    seed, h, d = 1000 + N + K, 30, 6
+    cfg = IcemConfig(horizon=h, act_dim=d, num_traj=N, elites_size=K, opt_iters=iters, dtype="f32", seed=seed,
+                     keep_previous_elites=keep, shift_elites=shift, use_mean_actions=use_mean)
+    pl = IcemPlanner(cfg, env.action_space.low, env.action_space.high)
+    pl.set_model(model.kind, model.A, model.B)
+    c = env.cost_spec
+    pl.set_cost(c.ctrl_weight, c.lin_idx, c.lin_weight, c.flip_idx, c.flip_penalty, c.flip_thresh)
+    pl.reset()
+    assert pl.K == max(2, min(K, N // 2))
+    p = O.IcemParams(horizon=h, num_simulated_trajectories=N, elites_size=K, opt_iterations=iters,
+                     keep_previous_elites=keep, shift_elites_over_time=shift, use_mean_actions=use_mean)
+    n_reuse = int(p.num_elites * 0.3)
+    noise = O.PhiloxNoiseSchedule(seed, iters, d, h, shift=shift and n_reuse > 0, dtype=np.float32)
+    om, oc = O.SyntheticModel(model.A, model.B, model.kind), O.CostSpec.halfcheetah(17)
+    orc = O.IcemOracle(p, env.action_space.low.astype(np.float64), env.action_space.high.astype(np.float64),
+                       lambda ob, ac: O.rollout_costs(om, oc, ob, ac), lambda num: tuple(
+                           z.astype(np.float64) for z in noise(num)) if num > 0 else (np.zeros((0, d, h // 2 + 1)),) * 2)
+    orc.beginning_of_rollout()
+    rs = np.random.RandomState(N)
+    for s in range(3):
+        obs = 0.2 * rs.randn(17)
+        if s:
+            noise.begin_step()
+        a = np_(pl.plan_step(obs))
+        np.testing.assert_allclose(a, orc.get_action(obs), rtol=5e-4, atol=5e-5)
+        np.testing.assert_allclose(np_(pl.best_cost)[0], orc.last_min_cost, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(np_(pl.std), orc.std, rtol=5e-4, atol=5e-5)
