@@ -50,6 +50,8 @@ struct FastRolloutArgs {
 };
 bool fast_rollout_supported(int h, int d, int O, int K);
 void launch_rollout_mfma(const FastRolloutArgs& a, int h, int d, int O, int kind, int grid, hipStream_t st);
+// workgroups (= candidate lists) the rollout of n_rows trajectories is launched with
+int rollout_lists(int h, int d, int O, int n_rows);
 
 // Fused iteration (sample + rollout + cost + per-workgroup top-K in one launch); same shape list as the
 // matrix-pipe rollout.  Field names shared with FastRolloutArgs are read by the same device code.

@@ -517,6 +517,161 @@ __global__ __launch_bounds__(RWG) void rollout_mfma_kernel(FastRolloutArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// small populations: ONE tile of 64 trajectories per workgroup, the model step split over the 4 SIMDs
+// -------------------------------------------------------------------------------------------------
+// With <= 256 tiles most SIMDs idle while each rollout wave walks its 30 dependent model steps alone.  Here the
+// 4 waves of a workgroup share one tile (lane = trajectory in every wave): wave w owns output column tile w of
+// the model (23 MFMAs per step instead of 92), the new observation columns are exchanged through a
+// double-buffered LDS array with one barrier per step.  Wave 0 also scores the cost, wave 1 the leftover
+// columns on the VALU.  Requires floor(O/4) == 4 (O = 16..19).
+template <int H, int D, int O, int KIND>
+__global__ __launch_bounds__(256) void rollout_quad_kernel(FastRolloutArgs a) {
+    constexpr int REM = O - 16;
+    constexpr int CT4 = ((O + 3) / 4) * 4;
+    constexpr int KK = O + D;
+    constexpr int G = group_steps(D);
+    constexpr int GV = G * D / 4;
+    constexpr int HD = H * D;
+    constexpr int NG = H / G;
+    constexpr int RING = NG >= 5 ? 5 : (NG >= 3 ? 3 : NG);
+    static_assert(O / 4 == 4, "four column tiles, one per wave");
+    static_assert(H % G == 0 && HD % 4 == 0, "action rows must split into 16-byte groups");
+    __shared__ float xch[2][O][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+
+    float mA[KK];                      // this wave's column tile: lane holds Mp[k][4*wave + (lane & 3)]
+    float mR[KK][REM > 0 ? REM : 1];   // leftover columns (wave 1), wave-uniform
+#pragma unroll
+    for (int k = 0; k < KK; ++k) {
+        mA[k] = a.Mp[k * CT4 + wave * 4 + (lane & 3)];
+#pragma unroll
+        for (int r = 0; r < REM; ++r) mR[k][r] = a.Mp[k * CT4 + 16 + r];
+    }
+    float obs_init[O];
+#pragma unroll
+    for (int k = 0; k < O; ++k) obs_init[k] = k < a.o ? a.obs0[a.perm[k]] : 0.f;
+    const float pen = a.flip_col >= 0 ? a.flip_pen : 0.f;
+    const bool ang_is_col1 = a.flip_col == 1;
+    const float ksum = a.cost_mode == 0 ? 1.f : 0.f;
+    const bool use_min = a.cost_mode == 1;
+
+    unsigned long long run_key = KEY_SENTINEL;
+    bool first = true;
+    const int tiles = (a.n_rows + 63) / 64;
+    for (int tile_id = blockIdx.x; tile_id < tiles; tile_id += gridDim.x) {
+        const int row = tile_id * 64 + lane;
+        const bool live = row < a.n_rows;
+        const float4* __restrict__ arow = reinterpret_cast<const float4*>(a.actions + (size_t)(live ? row : 0) * HD);
+        float4 buf[RING][GV];
+#pragma unroll
+        for (int b = 0; b < RING - 1; ++b) {
+            if (b < NG) {
+#pragma unroll
+                for (int v = 0; v < GV; ++v) buf[b][v] = arow[b * GV + v];
+            }
+        }
+        float obs[O];
+#pragma unroll
+        for (int k = 0; k < O; ++k) obs[k] = obs_init[k];
+        float acc_s = 0.f, acc_b = INFINITY;
+        int par = 0;
+        auto run_group = [&](const float4 (&cur)[GV]) {
+            float actg[G * D];
+#pragma unroll
+            for (int v = 0; v < GV; ++v) {
+                actg[4 * v] = cur[v].x;
+                actg[4 * v + 1] = cur[v].y;
+                actg[4 * v + 2] = cur[v].z;
+                actg[4 * v + 3] = cur[v].w;
+            }
+#pragma unroll
+            for (int s = 0; s < G; ++s) {
+                const float* act = actg + s * D;
+                float accr[REM > 0 ? REM : 1];
+                // VALU block (clustered, see RolloutWave): wave 0 scores the step, wave 1 the leftover columns
+                if (wave == 0) {
+                    float ctrl = 0.f;
+#pragma unroll
+                    for (int j = 0; j < D; ++j) ctrl = __builtin_fmaf(act[j], act[j], ctrl);
+                    const float ang = ang_is_col1 ? obs[1] : obs[0];
+                    float c = 0.f;
+                    c += (ang > a.flip_th) ? pen : 0.f;
+                    c += (ang < -a.flip_th) ? pen : 0.f;
+                    c += a.ctrl_w * ctrl;
+                    c += a.lin_w * obs[0];
+                    acc_s = __builtin_fmaf(acc_s, ksum, c);
+                    acc_b = c < acc_b ? c : acc_b;
+                }
+                if (REM > 0 && wave == 1) {
+                    float part[REM > 0 ? REM : 1][4];
+#pragma unroll
+                    for (int r = 0; r < REM; ++r) part[r][0] = part[r][1] = part[r][2] = part[r][3] = 0.f;
+#pragma unroll
+                    for (int k = 0; k < KK; ++k) {
+                        const float x = k < O ? obs[k < O ? k : 0] : act[k >= O ? k - O : 0];
+#pragma unroll
+                        for (int r = 0; r < REM; ++r) part[r][k & 3] = __builtin_fmaf(x, mR[k][r], part[r][k & 3]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < REM; ++r) accr[r] = (part[r][0] + part[r][1]) + (part[r][2] + part[r][3]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // this wave's column tile: two independent accumulator chains (even / odd k) keep the 8-cycle issue
+                f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < KK; ++k) {
+                    const float x = k < O ? obs[k < O ? k : 0] : act[k >= O ? k - O : 0];
+                    if (k & 1)
+                        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(mA[k], x, acc1, 0, 0, 0);
+                    else
+                        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(mA[k], x, acc0, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // exchange: publish 4 (+ leftover) new columns, read all O back
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    xch[par][wave * 4 + i][lane] = act_fn(acc0[i] + acc1[i], std::integral_constant<int, KIND>{});
+                if (REM > 0 && wave == 1) {
+#pragma unroll
+                    for (int r = 0; r < REM; ++r) xch[par][16 + r][lane] = act_fn(accr[r], std::integral_constant<int, KIND>{});
+                }
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < O; ++k) obs[k] = xch[par][k][lane];
+                par ^= 1;
+            }
+        };
+#pragma unroll 1
+        for (int tg = 0; tg < NG; tg += RING) {
+#pragma unroll
+            for (int b = 0; b < RING; ++b) {
+                if (tg + b < NG) {
+                    if (tg + b + RING - 1 < NG) {
+#pragma unroll
+                        for (int v = 0; v < GV; ++v) buf[(b + RING - 1) % RING][v] = arow[(tg + b + RING - 1) * GV + v];
+                    }
+                    run_group(buf[b]);
+                }
+            }
+        }
+        if (wave == 0) {
+            const float cost = use_min ? acc_b : acc_s;
+            if (live) a.costs[row] = cost;
+            if (a.K > 0) {
+                const unsigned long long key = (live && row < a.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
+                run_key = topk_push(run_key, key, first, a.K, lane);
+                first = false;
+            }
+        }
+    }
+    if (a.K > 0 && wave == 0 && lane < a.K) {
+        a.part_c[(size_t)blockIdx.x * a.K + lane] = key_cost(run_key);
+        a.part_i[(size_t)blockIdx.x * a.K + lane] = key_idx(run_key);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // fused iteration: sample -> HBM (through an LDS tile) -> rollout of the same trajectories by the same
 // workgroup (actions re-read through L2, never after a kernel boundary) -> cost -> per-workgroup top-K
 // -------------------------------------------------------------------------------------------------
@@ -809,7 +964,29 @@ bool fast_rollout_supported(int h, int d, int O, int K) {
     return false;
 }
 
+int rollout_lists(int h, int d, int O, int n_rows) {
+    const int tiles = (n_rows + 63) / 64;
+    if (O / 4 == 4 && tiles <= FAST_MAX_LISTS) return tiles > 0 ? tiles : 1;  // quad kernel: one list per tile
+    const int g = (tiles + 3) / 4;
+    return g < 1 ? 1 : (g > FAST_MAX_LISTS ? FAST_MAX_LISTS : g);
+}
+
 void launch_rollout_mfma(const FastRolloutArgs& a, int h, int d, int O, int kind, int grid, hipStream_t st) {
+    const int tiles = (a.n_rows + 63) / 64;
+    if (O / 4 == 4 && tiles <= FAST_MAX_LISTS) {
+#define XQ(HH, DD, OO)                                                                                     \
+    if constexpr (OO / 4 == 4) {                                                                           \
+        if (h == HH && d == DD && O == OO) {                                                               \
+            if (kind == 1)                                                                                 \
+                hipLaunchKernelGGL((rollout_quad_kernel<HH, DD, OO, 1>), dim3(grid), dim3(256), 0, st, a); \
+            else                                                                                           \
+                hipLaunchKernelGGL((rollout_quad_kernel<HH, DD, OO, 0>), dim3(grid), dim3(256), 0, st, a); \
+            return;                                                                                        \
+        }                                                                                                  \
+    }
+        ICEM_FAST_SHAPES(XQ)
+#undef XQ
+    }
 #define X(HH, DD, OO)                                                                                         \
     if (h == HH && d == DD && O == OO) {                                                                      \
         if (kind == 1)                                                                                        \

@@ -903,8 +903,7 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
     a.part_c = part_c;
     a.part_i = part_i;
     a.dbg = h->dbg;
-    const int tiles = (n_rows + 63) / 64;
-    const int grid = std::max(1, std::min((tiles + 3) / 4, FAST_MAX_LISTS));
+    const int grid = rollout_lists(h->cfg.horizon, h->cfg.act_dim, h->O, n_rows);
     {
         ProfScope prof(h, ICEM_K_ROLLOUT, (long long)n_rows * h->cfg.horizon, st);
         launch_rollout_mfma(a, h->cfg.horizon, h->cfg.act_dim, h->O, h->model_kind, grid, st);
@@ -1051,8 +1050,7 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                     rc = launch_sample<T>(h, a, st);
                 }
                 if (rc) return rc;
-                const int tiles = (n_rows + 63) / 64;
-                const int grid = std::max(1, std::min((tiles + 3) / 4, FAST_MAX_LISTS));
+                const int grid = rollout_lists(c.horizon, c.act_dim, h->O, n_rows);
                 split_partial_ws<float>(b->workspace, grid, K, &pc, &pi);
                 rc = launch_fast_rollout(h, n_rows, n_cand, K, b->obs0, actions, b->costs, pc, pi, st, &lists);
                 if (rc) return rc;
