@@ -657,3 +657,30 @@ def test_fast_path_edge_populations(N, K, iters, keep, shift, use_mean):
         np.testing.assert_allclose(a, orc.get_action(obs), rtol=5e-4, atol=5e-5)
         np.testing.assert_allclose(np_(pl.best_cost)[0], orc.last_min_cost, rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(np_(pl.std), orc.std, rtol=5e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("h,d,o,kind,mode", [(30, 6, 18, 1, "best"), (12, 6, 17, 0, "final"), (13, 4, 17, 1, "sum")])
+def test_large_tile_count_uses_wave_per_tile_rollout(h, d, o, kind, mode):
+    """More than 256 tiles: the one-wave-per-tile matrix-pipe kernel (4 waves per workgroup, running top-K across
+    tiles, workgroup list merge) instead of the quad kernel; costs and the sorted top-K against the oracle."""
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner
+    N = 64 * 257 + 5
+    low, high = -np.ones(d), np.ones(d)
+    model = DeviceSyntheticModel.make(o, d, kind=kind)
+    spec = O.CostSpec(0.1, 5, -1.0, 5, 10.0, 0.05)  # lin and flip on the same column
+    pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=N, opt_iters=1, cost_mode=mode, dtype="f32", seed=3,
+                                use_mean_actions=False), low, high)
+    pl.set_model(kind, model.A, model.B)
+    pl.set_cost(spec.ctrl_weight, spec.lin_idx, spec.lin_weight, spec.flip_idx, spec.flip_penalty, spec.flip_thresh)
+    pl.reset()
+    obs0 = 0.3 * np.random.RandomState(1).randn(o)
+    mean0, std0 = np_(pl.mean), np_(pl.std)
+    pl.plan_step(obs0)
+    act = np_(pl.actions[:N])
+    costs = np_(pl.costs[:N])
+    om = O.SyntheticModel(model.A, model.B, kind)
+    ref = O.rollout_costs(om, spec, obs0, act, mode=mode)
+    np.testing.assert_allclose(costs, ref, rtol=2e-5, atol=5e-5)
+    idx = O.topk_sorted(pl.costs[:N].cpu().numpy(), pl.K)
+    ea, ec = pl.current_elites()
+    assert np.array_equal(np_(ec), costs[idx]) and np.array_equal(np_(ea), act[idx])
