@@ -517,15 +517,17 @@ __global__ __launch_bounds__(RWG) void rollout_mfma_kernel(FastRolloutArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// small populations: ONE tile of 64 trajectories per workgroup, the model step split over the 4 SIMDs
+// quad rollout: a tile of 64 trajectories is shared by the 4 SIMDs of a CU, NQ tiles per workgroup
 // -------------------------------------------------------------------------------------------------
-// With <= 256 tiles most SIMDs idle while each rollout wave walks its 30 dependent model steps alone.  Here the
-// 4 waves of a workgroup share one tile (lane = trajectory in every wave): wave w owns output column tile w of
-// the model (23 MFMAs per step instead of 92), the new observation columns are exchanged through a
-// double-buffered LDS array with one barrier per step.  Wave 0 also scores the cost, wave 1 the leftover
-// columns on the VALU.  Requires floor(O/4) == 4 (O = 16..19).
-template <int H, int D, int O, int KIND>
-__global__ __launch_bounds__(256) void rollout_quad_kernel(FastRolloutArgs a) {
+// A lone rollout wave per SIMD walks its 30 dependent model steps with every latency exposed (dependent MFMA
+// chains, MFMA<->VALU switches, LDS/HBM waits).  Here 4 waves ("a quad") share one tile (lane = trajectory in
+// every wave): wave w owns output column tile w of the model (23 MFMAs per step instead of 92), the new
+// observation columns are exchanged through a double-buffered LDS array with one barrier per step.  Wave 0 of a
+// quad also scores the cost, wave 1 the leftover columns on the VALU.  A workgroup holds NQ quads (NQ waves per
+// SIMD, their MFMA streams interleave): NQ = 1 for <= 256 tiles (every tile its own CU), up to 4 beyond.
+// Requires floor(O/4) == 4 (O = 16..19).
+template <int H, int D, int O, int KIND, int NQ>
+__global__ __launch_bounds__(256 * NQ) void rollout_quad_kernel(FastRolloutArgs a) {
     constexpr int REM = O - 16;
     constexpr int CT4 = ((O + 3) / 4) * 4;
     constexpr int KK = O + D;
@@ -533,12 +535,15 @@ __global__ __launch_bounds__(256) void rollout_quad_kernel(FastRolloutArgs a) {
     constexpr int GV = G * D / 4;
     constexpr int HD = H * D;
     constexpr int NG = H / G;
-    constexpr int RING = NG >= 5 ? 5 : (NG >= 3 ? 3 : NG);
+    constexpr int RING = NQ > 2 ? (NG >= 3 ? 3 : NG) : (NG >= 5 ? 5 : (NG >= 3 ? 3 : NG));
     static_assert(O / 4 == 4, "four column tiles, one per wave");
     static_assert(H % G == 0 && HD % 4 == 0, "action rows must split into 16-byte groups");
-    __shared__ float xch[2][O][64];
+    __shared__ float xch_all[NQ][2][O][64];
+    __shared__ unsigned long long wg_keys[4][32];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int quad = threadIdx.x >> 8;
+    const int wave = (threadIdx.x >> 6) & 3;
+    float (*xch)[O][64] = xch_all[quad];
 
     float mA[KK];                      // this wave's column tile: lane holds Mp[k][4*wave + (lane & 3)]
     float mR[KK][REM > 0 ? REM : 1];   // leftover columns (wave 1), wave-uniform
@@ -559,8 +564,10 @@ __global__ __launch_bounds__(256) void rollout_quad_kernel(FastRolloutArgs a) {
     unsigned long long run_key = KEY_SENTINEL;
     bool first = true;
     const int tiles = (a.n_rows + 63) / 64;
-    for (int tile_id = blockIdx.x; tile_id < tiles; tile_id += gridDim.x) {
-        const int row = tile_id * 64 + lane;
+    // every quad of the workgroup walks the same number of tiles (the step barrier is workgroup wide); a quad
+    // past the end rolls out row 0 again and drops the result
+    for (int tile0 = blockIdx.x * NQ; tile0 < tiles; tile0 += gridDim.x * NQ) {
+        const int row = (tile0 + quad) * 64 + lane;
         const bool live = row < a.n_rows;
         const float4* __restrict__ arow = reinterpret_cast<const float4*>(a.actions + (size_t)(live ? row : 0) * HD);
         float4 buf[RING][GV];
@@ -665,9 +672,249 @@ __global__ __launch_bounds__(256) void rollout_quad_kernel(FastRolloutArgs a) {
             }
         }
     }
-    if (a.K > 0 && wave == 0 && lane < a.K) {
-        a.part_c[(size_t)blockIdx.x * a.K + lane] = key_cost(run_key);
-        a.part_i[(size_t)blockIdx.x * a.K + lane] = key_idx(run_key);
+    if (a.K > 0) {
+        if (NQ == 1) {
+            if (wave == 0 && lane < a.K) {
+                a.part_c[(size_t)blockIdx.x * a.K + lane] = key_cost(run_key);
+                a.part_i[(size_t)blockIdx.x * a.K + lane] = key_idx(run_key);
+            }
+        } else {
+            // wave 0 of each quad holds a list; slots of absent quads stay empty
+            if (wave != 0 || quad >= 4) run_key = KEY_SENTINEL;
+            const int slot = wave == 0 ? quad : (NQ + wave - 1);  // NQ + (1..3) cover slots NQ..3 when NQ < 4
+            wg_emit_list(wg_keys, run_key, a.K, lane, slot, a.part_c, a.part_i);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// rollout16: 16 trajectories per wavefront on v_mfma_f32_16x16x4_f32, model operand in O(1) registers
+// -------------------------------------------------------------------------------------------------
+// D[16 x 16] += A[16 x 4] . B[4 x 16] with A = a 16 x 4 block of M^T (output column i = lane % 16, contraction
+// slot g = lane / 16) and B = X^T (trajectory j = lane % 16, slot g).  The result leaves lane (j, g) holding the
+// new observation columns 4g .. 4g+3 of trajectory j in its 4 accumulator registers -- and MFMA number s of the
+// next step wants, in lane (j, g), one observation column per contraction slot.  Ordering the contraction so that
+// slot g of MFMA s IS column 4g + s makes accumulator register s of one step the B operand of MFMA s of the next:
+// no transposes, no LDS, no cross-lane traffic for the first 16 columns, and the model operand of a lane is ONE
+// register per MFMA (6 for o=17, d=6, against 92 for the 4x4x1 tiling).  Observation columns >= 16 and the
+// actions ride in extra contraction slots: extra e sits in slot e % 4 of MFMA 4 + e/4.  Output columns >= 16 (at
+// most 4) are per-lane partial dot products summed over the 4 lanes of a trajectory with v_permlane32/16_swap;
+// the same reduction sums the step cost.  With ~40 registers a SIMD holds many rollout waves, so one wave's
+// VALU / memory phases hide under the others' MFMAs (the 4x4x1 kernels run one exposed wave per SIMD).
+__device__ __forceinline__ float reduce_groups(float x) {
+    // sum over lanes l, l^16, l^32, l^48 (the 4 contraction slots of one trajectory), result in all of them
+    unsigned u = __float_as_uint(x);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const float s = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    unsigned v = __float_as_uint(s);
+    auto q = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
+// steps per staged action chunk: divides H, whole float4s per row, odd float4 count (16 rows then hit 16 distinct
+// bank groups) when possible
+__host__ __device__ constexpr int r16_chunk_steps(int h, int d) {
+    int best = 0;
+    for (int tc = 1; tc <= h; ++tc)
+        if (h % tc == 0 && (tc * d) % 4 == 0 && tc * d <= 96) best = tc;
+    return best;
+}
+
+template <int H, int D, int O, int KIND, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void rollout16_kernel(FastRolloutArgs a) {
+    constexpr int REM = O > 16 ? O - 16 : 0;   // output columns beyond the 16 x 16 tile
+    constexpr int NX = REM + D;                // extra contraction entries: columns >= 16, then the actions
+    constexpr int NKX = (NX + 3) / 4;          // MFMAs that carry them
+    constexpr int CT4 = ((O + 3) / 4) * 4;     // row stride of Mp
+    constexpr int HD = H * D;
+    constexpr int TC = r16_chunk_steps(H, D);  // steps per action chunk
+    static_assert(TC > 0, "no 16-byte aligned action chunk for this (H, D)");
+    constexpr int CB = TC * D;                 // floats per row and chunk
+    constexpr int C4 = CB / 4;
+    constexpr int CBP = (C4 % 2) ? CB : CB + 4;  // LDS row stride: odd number of float4s
+    constexpr int NCH = H / TC;
+    constexpr int F4 = 16 * C4;                // float4s per chunk of a 16-trajectory tile
+    constexpr int NLD = (F4 + 63) / 64;        // cooperative load instructions per chunk
+    constexpr int SLACK = 4;                   // floats in front of a buffer (entries that are not actions read there)
+    constexpr int STG = SLACK + 16 * CBP + 8;  // + tail slack for padding entries of the last row
+    static_assert(REM <= 4, "observation width up to 20");
+    // the tile's actions are one contiguous 16 x H x D block of HBM: the wave fetches it with full-width coalesced
+    // loads, chunk by chunk, into its own LDS buffer; each lane then reads the one or two entries it feeds to the MFMAs
+    __shared__ __attribute__((aligned(16))) float stage[WAVES][STG];
+    __shared__ unsigned long long wg_keys[2][WAVES][32];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+
+    // model operands: one register per MFMA
+    float mA[4 + NKX];
+    float wR[REM > 0 ? REM : 1][4 + NKX];  // weights of this lane's contraction entries into output column 16 + r
+    float cw[NKX];                         // ctrl_w where the extra entry is an action, else 0
+    bool is_act[NKX];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int k = 4 * g + s;
+        mA[s] = (k < O && j < O) ? a.Mp[k * CT4 + j] : 0.f;
+#pragma unroll
+        for (int r = 0; r < REM; ++r) wR[r][s] = k < O ? a.Mp[k * CT4 + 16 + r] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < NKX; ++q) {
+        const int e = 4 * q + g;
+        const int k = e < REM ? 16 + e : O + (e - REM);
+        const bool valid = e < NX;
+        mA[4 + q] = (valid && j < O) ? a.Mp[(valid ? k : 0) * CT4 + j] : 0.f;
+#pragma unroll
+        for (int r = 0; r < REM; ++r) wR[r][4 + q] = valid ? a.Mp[(valid ? k : 0) * CT4 + 16 + r] : 0.f;
+        is_act[q] = valid && e >= REM;
+        cw[q] = is_act[q] ? a.ctrl_w : 0.f;
+    }
+    f32x4 obs_init;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) obs_init[v] = (4 * g + v < a.o) ? a.obs0[a.perm[4 * g + v]] : 0.f;
+    float rem_init[REM > 0 ? REM : 1];
+#pragma unroll
+    for (int r = 0; r < REM; ++r) rem_init[r] = (16 + r < a.o) ? a.obs0[a.perm[16 + r]] : 0.f;
+    // cost terms that read observation columns 0 / 1 live in slot 0 only
+    const float pen = (a.flip_col >= 0 && g == 0) ? a.flip_pen : 0.f;
+    const float lin_w = g == 0 ? a.lin_w : 0.f;
+    const bool ang_is_col1 = a.flip_col == 1;
+    const float ksum = a.cost_mode == 0 ? 1.f : 0.f;
+    const bool use_min = a.cost_mode == 1;
+    const float flip_th = a.flip_th;
+    // this lane's entry q of step tt sits at rd[tt * D + 4 * q] (entries that are not actions read slack or
+    // neighbours and are discarded)
+    const float* rd0 = &stage[wave][SLACK + j * CBP + (g - REM)];
+    // cooperative loads: float4 number f = m * 64 + lane of a chunk is row f / C4, float4 f % C4 of that row
+    int ld_row[NLD], ld_c4[NLD];
+    bool ld_on[NLD];
+#pragma unroll
+    for (int m = 0; m < NLD; ++m) {
+        const int f = m * 64 + lane;
+        ld_on[m] = f < F4;
+        ld_row[m] = ld_on[m] ? f / C4 : 0;
+        ld_c4[m] = ld_on[m] ? f % C4 : 0;
+    }
+
+    unsigned long long run_key = KEY_SENTINEL;
+    bool first = true;
+    const int tiles = (a.n_rows + 15) / 16;
+    // tile t of the launch belongs to wave t / gridDim.x of workgroup t % gridDim.x: a short launch thins every CU
+    for (int tile_id = wave * gridDim.x + blockIdx.x; tile_id < tiles; tile_id += WAVES * gridDim.x) {
+        const int row = tile_id * 16 + j;
+        const bool live = row < a.n_rows;
+        const float4* src[NLD];
+#pragma unroll
+        for (int m = 0; m < NLD; ++m) {
+            const int r = tile_id * 16 + ld_row[m];
+            src[m] = reinterpret_cast<const float4*>(a.actions + (size_t)(r < a.n_rows ? r : 0) * HD) + ld_c4[m];
+        }
+        float4 pre[NLD];
+#pragma unroll
+        for (int m = 0; m < NLD; ++m) pre[m] = src[m][0];
+        f32x4 cur = obs_init;
+        float xr[REM > 0 ? REM : 1];
+#pragma unroll
+        for (int r = 0; r < REM; ++r) xr[r] = rem_init[r];
+        float acc_s = 0.f, acc_b = INFINITY;
+#pragma unroll
+        for (int t = 0; t < H; ++t) {
+            const int ch = t / TC, tt = t % TC;
+            if (tt == 0) {
+                // chunk ch: registers -> this wave's LDS buffer (only this wave touches it and a wave's LDS
+                // operations execute in order: no barrier), then start fetching chunk ch + 1
+#pragma unroll
+                for (int m = 0; m < NLD; ++m)
+                    if (ld_on[m]) *reinterpret_cast<float4*>(&stage[wave][SLACK + ld_row[m] * CBP + 4 * ld_c4[m]]) = pre[m];
+                if (ch + 1 < NCH) {
+#pragma unroll
+                    for (int m = 0; m < NLD; ++m) pre[m] = src[m][(ch + 1) * C4];
+                }
+            }
+            const float* rd = rd0 + tt * D;
+            float xv[NKX];
+#pragma unroll
+            for (int q = 0; q < NKX; ++q) {
+                const float ld = rd[4 * q];
+                float v = is_act[q] ? ld : 0.f;
+#pragma unroll
+                for (int r = 0; r < REM; ++r)
+                    if (r / 4 == q) v = (g == r % 4) ? xr[r] : v;
+                xv[q] = v;
+            }
+            // step cost: this lane's share, then the sum over the trajectory's 4 lanes
+            const float ang = ang_is_col1 ? cur[1] : cur[0];
+            float c = 0.f;
+            c += (ang > flip_th) ? pen : 0.f;
+            c += (ang < -flip_th) ? pen : 0.f;
+#pragma unroll
+            for (int q = 0; q < NKX; ++q) c = __builtin_fmaf(xv[q] * xv[q], cw[q], c);
+            c = __builtin_fmaf(lin_w, cur[0], c);
+            float pr[REM > 0 ? REM : 1];
+#pragma unroll
+            for (int r = 0; r < REM; ++r) {
+                float p = 0.f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) p = __builtin_fmaf(cur[s], wR[r][s], p);
+#pragma unroll
+                for (int q = 0; q < NKX; ++q) p = __builtin_fmaf(xv[q], wR[r][4 + q], p);
+                pr[r] = p;
+            }
+            c = reduce_groups(c);
+#pragma unroll
+            for (int r = 0; r < REM; ++r) pr[r] = reduce_groups(pr[r]);
+            acc_s = __builtin_fmaf(acc_s, ksum, c);
+            acc_b = c < acc_b ? c : acc_b;
+            // model step on the matrix pipe
+            f32x4 nxt = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) nxt = __builtin_amdgcn_mfma_f32_16x16x4f32(mA[s], cur[s], nxt, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < NKX; ++q) nxt = __builtin_amdgcn_mfma_f32_16x16x4f32(mA[4 + q], xv[q], nxt, 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) cur[v] = act_fn(nxt[v], std::integral_constant<int, KIND>{});
+#pragma unroll
+            for (int r = 0; r < REM; ++r) xr[r] = act_fn(pr[r], std::integral_constant<int, KIND>{});
+        }
+        const float cost = use_min ? acc_b : acc_s;
+        if (live && g == 0) a.costs[row] = cost;
+        if (a.K > 0) {
+            // lanes 0..15 carry this tile's keys, lanes 16..16+K-1 the running list: one sort
+            unsigned long long key = (g == 0 && live && row < a.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
+            if (!first) {
+                const unsigned long long prev = __shfl(run_key, lane - 16, 64);
+                if (lane >= 16 && lane < 16 + a.K) key = prev;
+            }
+            run_key = wave_sort64(key, lane);
+            first = false;
+        }
+    }
+    if (a.K > 0) {
+        const int K = a.K;
+        if (WAVES > 1) {
+            // tree merge of the waves' lists through LDS, `fan` lists per sort
+            const int fan = 4 * K <= 64 ? 4 : 2;
+            int lists = WAVES, par = 0;
+            if (lane < K) wg_keys[0][wave][lane] = run_key;
+            __syncthreads();
+            while (lists > 1) {
+                const int f = lists < fan ? lists : fan;
+                const int out = lists / f;
+                if (wave < out) {
+                    unsigned long long k2 = KEY_SENTINEL;
+                    if (lane < f * K) k2 = wg_keys[par][wave * f + lane / K][lane % K];
+                    run_key = wave_sort64(k2, lane);
+                    if (lane < K) wg_keys[par ^ 1][wave][lane] = run_key;
+                }
+                __syncthreads();
+                par ^= 1;
+                lists = out;
+            }
+        }
+        if (wave == 0 && lane < K) {
+            a.part_c[(size_t)blockIdx.x * K + lane] = key_cost(run_key);
+            a.part_i[(size_t)blockIdx.x * K + lane] = key_idx(run_key);
+        }
     }
 }
 
@@ -964,28 +1211,89 @@ bool fast_rollout_supported(int h, int d, int O, int K) {
     return false;
 }
 
+// quads per workgroup of the quad rollout (0: shape not eligible, use the wave-per-tile kernel)
+static int quad_nq(int O, int tiles) {
+    static const int force = [] { const char* e = getenv("ICEM_QUAD_NQ"); return e ? atoi(e) : -1; }();
+    if (O / 4 != 4) return 0;
+    if (force >= 0) return tiles <= FAST_MAX_LISTS ? 1 : force;
+    return tiles <= FAST_MAX_LISTS ? 1 : (tiles <= 2 * FAST_MAX_LISTS ? 2 : 4);
+}
+
+// rollout16 launch shape: one 16-trajectory tile per wave while they fit, at most 256 workgroups (= lists)
+static bool use_r16(int O) {
+    static const int on = [] { const char* e = getenv("ICEM_R16"); return e ? atoi(e) : 1; }();
+    return on && O <= 20;
+}
+static void r16_shape(int n_rows, int* grid, int* waves) {
+    const int tiles = std::max(1, (n_rows + 15) / 16);
+    const int g = std::min(tiles, FAST_MAX_LISTS);
+    int w = 1;
+    while (w < 16 && w * g < tiles) w *= 2;
+    *grid = g;
+    *waves = w;
+}
+
 int rollout_lists(int h, int d, int O, int n_rows) {
+    if (use_r16(O)) {
+        int g, w;
+        r16_shape(n_rows, &g, &w);
+        return g;
+    }
     const int tiles = (n_rows + 63) / 64;
-    if (O / 4 == 4 && tiles <= FAST_MAX_LISTS) return tiles > 0 ? tiles : 1;  // quad kernel: one list per tile
-    const int g = (tiles + 3) / 4;
+    const int nq = quad_nq(O, tiles);
+    const int per = nq > 0 ? nq : 4;  // tiles that share a workgroup (= one candidate list)
+    const int g = (tiles + per - 1) / per;
     return g < 1 ? 1 : (g > FAST_MAX_LISTS ? FAST_MAX_LISTS : g);
 }
 
 void launch_rollout_mfma(const FastRolloutArgs& a, int h, int d, int O, int kind, int grid, hipStream_t st) {
+    if (use_r16(O)) {
+        int g, waves;
+        r16_shape(a.n_rows, &g, &waves);
+#define XW(HH, DD, OO, WW)                                                                                      \
+    if (waves == WW) {                                                                                          \
+        if (kind == 1)                                                                                          \
+            hipLaunchKernelGGL((rollout16_kernel<HH, DD, OO, 1, WW>), dim3(grid), dim3(64 * WW), 0, st, a);     \
+        else                                                                                                    \
+            hipLaunchKernelGGL((rollout16_kernel<HH, DD, OO, 0, WW>), dim3(grid), dim3(64 * WW), 0, st, a);     \
+        return;                                                                                                 \
+    }
+#define XR(HH, DD, OO)                         \
+    if constexpr (OO <= 20) {                  \
+        if (h == HH && d == DD && O == OO) {   \
+            XW(HH, DD, OO, 1)                  \
+            XW(HH, DD, OO, 2)                  \
+            XW(HH, DD, OO, 4)                  \
+            XW(HH, DD, OO, 8)                  \
+            XW(HH, DD, OO, 16)                 \
+        }                                      \
+    }
+        ICEM_FAST_SHAPES(XR)
+#undef XR
+#undef XW
+    }
     const int tiles = (a.n_rows + 63) / 64;
-    if (O / 4 == 4 && tiles <= FAST_MAX_LISTS) {
-#define XQ(HH, DD, OO)                                                                                     \
-    if constexpr (OO / 4 == 4) {                                                                           \
-        if (h == HH && d == DD && O == OO) {                                                               \
-            if (kind == 1)                                                                                 \
-                hipLaunchKernelGGL((rollout_quad_kernel<HH, DD, OO, 1>), dim3(grid), dim3(256), 0, st, a); \
-            else                                                                                           \
-                hipLaunchKernelGGL((rollout_quad_kernel<HH, DD, OO, 0>), dim3(grid), dim3(256), 0, st, a); \
-            return;                                                                                        \
-        }                                                                                                  \
+    const int nq = quad_nq(O, tiles);
+    if (nq > 0) {
+#define XQ1(HH, DD, OO, NQ)                                                                                        \
+    if (nq == NQ) {                                                                                                \
+        if (kind == 1)                                                                                             \
+            hipLaunchKernelGGL((rollout_quad_kernel<HH, DD, OO, 1, NQ>), dim3(grid), dim3(256 * NQ), 0, st, a);    \
+        else                                                                                                       \
+            hipLaunchKernelGGL((rollout_quad_kernel<HH, DD, OO, 0, NQ>), dim3(grid), dim3(256 * NQ), 0, st, a);    \
+        return;                                                                                                    \
+    }
+#define XQ(HH, DD, OO)                          \
+    if constexpr (OO / 4 == 4) {                \
+        if (h == HH && d == DD && O == OO) {    \
+            XQ1(HH, DD, OO, 1)                  \
+            XQ1(HH, DD, OO, 2)                  \
+            XQ1(HH, DD, OO, 4)                  \
+        }                                       \
     }
         ICEM_FAST_SHAPES(XQ)
 #undef XQ
+#undef XQ1
     }
 #define X(HH, DD, OO)                                                                                         \
     if (h == HH && d == DD && O == OO) {                                                                      \
