@@ -6,7 +6,7 @@
 
 namespace icem {
 
-constexpr int FAST_MAX_LISTS = 256;  // candidate lists (one per rollout workgroup of 4 waves) the merge accepts
+constexpr int FAST_MAX_LISTS = 256;  // candidate lists (one per rollout workgroup) the merge accepts
 
 // K1 fast: colored-noise sampling with the inverse real DFT folded on its symmetry (f32, Philox).
 struct FastSampleArgs {
@@ -29,8 +29,8 @@ struct FastSampleArgs {
 bool fast_sample_supported(int h, int d);
 void launch_sample_folded(const FastSampleArgs& a, int rounds, hipStream_t st);
 
-// K2+K3 fast: rollout on the matrix pipe (v_mfma_f32_4x4x1, exact f32), cost on the VALU, and a
-// per-wave bitonic top-K; one wavefront per 64 trajectories.
+// K2+K3 fast: rollout on the matrix pipe (v_mfma_f32_16x16x4, exact f32), cost on the VALU, and a
+// sorted top-K per workgroup; one wavefront per 16 trajectories.
 struct FastRolloutArgs {
     int n_rows;   // trajectories to roll out (rows of `actions`)
     int n_cand;   // rows [0, n_cand) enter the top-K
@@ -49,37 +49,9 @@ struct FastRolloutArgs {
     long long* dbg;  // development: [waves, 8] cycle stamps, nullptr in production
 };
 bool fast_rollout_supported(int h, int d, int O, int K);
-void launch_rollout_mfma(const FastRolloutArgs& a, int h, int d, int O, int kind, int grid, hipStream_t st);
+void launch_rollout16(const FastRolloutArgs& a, int h, int d, int O, int kind, hipStream_t st);
 // workgroups (= candidate lists) the rollout of n_rows trajectories is launched with
 int rollout_lists(int h, int d, int O, int n_rows);
-
-// Fused iteration (sample + rollout + cost + per-workgroup top-K in one launch); same shape list as the
-// matrix-pipe rollout.  Field names shared with FastRolloutArgs are read by the same device code.
-struct FusedArgs {
-    int n;        // trajectories to sample: rows [0, n) of `actions`
-    int n_extra;  // pre-filled rows [n, n + n_extra) (shifted elites): rolled out, not sampled
-    int n_cand;   // rows [0, n_cand) enter the top-K
-    int K, h, d, o, cost_mode, row0_mean;
-    int tpb;      // trajectories per workgroup pass: 64, 128 or 256
-    long long first_index;
-    const float* W;
-    const float* mean;
-    const float* std;
-    const float* low;
-    const float* high;
-    uint32_t seed_lo, seed_hi, off_lo, off_hi;
-    const float* Mp;
-    const int* perm;
-    const float* obs0;
-    float ctrl_w, lin_w, flip_pen, flip_th;
-    int flip_col;
-    float* actions;
-    float* costs;
-    float* part_c;
-    int* part_i;
-    long long* dbg;
-};
-void launch_fused_iter(const FusedArgs& a, int O, int kind, int rounds, int grid, hipStream_t st);
 
 // world == 1: global sorted top-K straight from the waves' candidate lists (+ kept elites), gather of
 // the elite rows from the pool, refit, and the last-iteration epilogue.

@@ -153,72 +153,6 @@ __device__ __forceinline__ void sample_row(const float* __restrict__ W, unsigned
     }
 }
 
-// NR rows at once (independent RNG / DFT chains interleaved by the unrolled r loops): instruction-level
-// parallelism for the low-occupancy fused kernel.  emit(r, t, y).
-template <int H, int ROUNDS, int NR, typename Emit>
-__device__ __forceinline__ void sample_rows(const float* __restrict__ W, const unsigned (&gi)[NR], const unsigned (&jj)[NR],
-                                            unsigned off_lo, unsigned off_hi, unsigned seed_lo, unsigned seed_hi,
-                                            Emit&& emit, long long* tst = nullptr) {
-    constexpr int F = H / 2 + 1;
-    static_assert(H <= 32 && H >= 2, "white draws of a row live in 32 registers");
-    float g[NR][HMAX];
-    Xoshiro128pp rng[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) rng[r] = row_stream<ROUNDS>(gi[r], jj[r], off_lo, off_hi, seed_lo, seed_hi);
-#pragma unroll
-    for (int m = 0; m < H; m += 2) {
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const uint32_t xa = rng[r].next();
-            const uint32_t xb = rng[r].next();
-            box_muller(xa, xb, g[r][m], g[r][m + 1]);
-        }
-    }
-    if (tst) { __builtin_amdgcn_sched_barrier(0); tst[0] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
-    {  // t = 0: every sine is zero
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            float e0 = 0.f, e1 = 0.f;
-#pragma unroll
-            for (int m = 0; m < F; m += 2) {
-                e0 = __builtin_fmaf(g[r][m], W[m], e0);
-                if (m + 1 < F) e1 = __builtin_fmaf(g[r][m + 1], W[m + 1], e1);
-            }
-            emit(r, 0, e0 + e1);
-        }
-    }
-    float wc[HMAX];
-#pragma unroll
-    for (int m = 0; m < H; ++m) wc[m] = W[HMAX + m];
-#pragma unroll 1
-    for (int tp = 1; tp <= H / 2; ++tp) {
-        float wn[HMAX];
-        const float* __restrict__ wnext = W + (tp < H / 2 ? tp + 1 : tp) * HMAX;
-#pragma unroll
-        for (int m = 0; m < H; ++m) wn[m] = wnext[m];
-        const float* w = wc;
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            float e0 = 0.f, e1 = 0.f, o0 = 0.f, o1 = 0.f;
-#pragma unroll
-            for (int m = 0; m < F; m += 2) {
-                e0 = __builtin_fmaf(g[r][m], w[m], e0);
-                if (m + 1 < F) e1 = __builtin_fmaf(g[r][m + 1], w[m + 1], e1);
-            }
-#pragma unroll
-            for (int m = F; m < H; m += 2) {
-                o0 = __builtin_fmaf(g[r][m], w[m], o0);
-                if (m + 1 < H) o1 = __builtin_fmaf(g[r][m + 1], w[m + 1], o1);
-            }
-            const float e = e0 + e1, od = o0 + o1;
-            emit(r, tp, e + od);
-            if (H - tp != tp) emit(r, H - tp, e - od);
-        }
-#pragma unroll
-        for (int m = 0; m < H; ++m) wc[m] = wn[m];
-    }
-}
-
 template <int H, int ROUNDS>
 __global__ __launch_bounds__(SWG) void sample_folded_kernel(FastSampleArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -287,409 +221,12 @@ __global__ __launch_bounds__(SWG) void sample_folded_kernel(FastSampleArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// K2 + K3
+// K2 + K3: rollout + cost + per-workgroup sorted top-K
 // -------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float act_fn(float x, std::integral_constant<int, 0>) { return x; }
 __device__ __forceinline__ float act_fn(float x, std::integral_constant<int, 1>) { return tanhf(x); }
 
-// steps per 16-byte-aligned action group: smallest G with (G*D) % 4 == 0
-__host__ __device__ constexpr int group_steps(int d) { return d % 4 == 0 ? 1 : (d % 2 == 0 ? 2 : 4); }
-
-#ifndef ICEM_REM_ON_VALU
-#define ICEM_REM_ON_VALU 1
-#endif
-
-// Everything a wavefront needs to roll 64 trajectories out on the matrix pipe (lane = trajectory).
-template <int H, int D, int O, int KIND>
-struct RolloutWave {
-    static constexpr int CTF = ICEM_REM_ON_VALU ? O / 4 : (O + 3) / 4;  // column tiles of 4 on the matrix pipe
-    static constexpr int REM = ICEM_REM_ON_VALU ? O % 4 : 0;  // leftover columns: FMA chains on the VALU
-    static constexpr int CT4 = ((O + 3) / 4) * 4;
-    static constexpr int KK = O + D;  // contraction length of one model step
-    static constexpr int G = group_steps(D);
-    static constexpr int GV = G * D / 4;  // float4 per group
-    static constexpr int HD = H * D;
-    static constexpr int NG = H / G;  // action groups per trajectory
-    static constexpr int RING = NG >= 5 ? 5 : (NG >= 3 ? 3 : NG);  // prefetch ring depth (groups)
-    static_assert(H % G == 0 && HD % 4 == 0, "action rows must split into 16-byte groups");
-    static_assert(CTF >= 1, "at least one full column tile");
-
-    // model operand of the MFMA: lane holds Mp[k][4*ct + (lane & 3)]; leftover columns are uniform
-    float mA[KK][CTF];
-    float mR[KK][REM > 0 ? REM : 1];
-    float obs_init[O];
-    float pen, ksum, flip_th, ctrl_w, lin_w;
-    bool ang_is_col1, use_min;
-
-    template <typename Args>
-    __device__ __forceinline__ void load(const Args& a, int lane) {
-#pragma unroll
-        for (int k = 0; k < KK; ++k) {
-#pragma unroll
-            for (int ct = 0; ct < CTF; ++ct) mA[k][ct] = a.Mp[k * CT4 + ct * 4 + (lane & 3)];
-#pragma unroll
-            for (int r = 0; r < REM; ++r) mR[k][r] = a.Mp[k * CT4 + CTF * 4 + r];
-        }
-#pragma unroll
-        for (int k = 0; k < O; ++k) obs_init[k] = k < a.o ? a.obs0[a.perm[k]] : 0.f;
-        // branch-free cost pieces (wave-uniform)
-        pen = a.flip_col >= 0 ? a.flip_pen : 0.f;
-        ang_is_col1 = a.flip_col == 1;
-        ksum = a.cost_mode == 0 ? 1.f : 0.f;  // sum: acc = acc + c; final: acc = c
-        use_min = a.cost_mode == 1;
-        flip_th = a.flip_th;
-        ctrl_w = a.ctrl_w;
-        lin_w = a.lin_w;
-    }
-
-    // cost of the trajectory whose [H, D] action row starts at `arow` (16-byte aligned, global memory)
-    __device__ __forceinline__ float run(const float4* __restrict__ arow) {
-        // action ring: RING buffers of one group each; loads are issued RING-1 groups ahead (~3.5 us of
-        // MFMA work at RING = 5), enough to cover a cold HBM fetch right after the sampler's kernel boundary
-        float4 buf[RING][GV];
-#pragma unroll
-        for (int b = 0; b < RING - 1; ++b) {
-            if (b < NG) {
-#pragma unroll
-                for (int v = 0; v < GV; ++v) buf[b][v] = arow[b * GV + v];
-            }
-        }
-        float obs[O];
-#pragma unroll
-        for (int k = 0; k < O; ++k) obs[k] = obs_init[k];
-        float acc_s = 0.f, acc_b = INFINITY;
-        auto run_group = [&](const float4 (&cur)[GV]) {
-            float actg[G * D];
-#pragma unroll
-            for (int v = 0; v < GV; ++v) {
-                actg[4 * v] = cur[v].x;
-                actg[4 * v + 1] = cur[v].y;
-                actg[4 * v + 2] = cur[v].z;
-                actg[4 * v + 3] = cur[v].w;
-            }
-#pragma unroll
-            for (int s = 0; s < G; ++s) {
-                const float* act = actg + s * D;
-                f32x4 acc[CTF];
-                float accr[REM > 0 ? REM : 1];
-#pragma unroll
-                for (int ct = 0; ct < CTF; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-                // VALU block first, as ONE cluster: on gfx950 every MFMA<->VALU switch of a lone wave costs
-                // ~12 cycles (tools/ubench/mfma_valu_switch.hip: 92 MFMAs = 762 cycles alone, 1862 with one v_fmac after
-                // each), so nothing may be interleaved into the MFMA stream.
-                {   // leftover model columns as scalar-operand FMA chains, 4 partial sums per column
-                    float part[REM > 0 ? REM : 1][4];
-#pragma unroll
-                    for (int r = 0; r < REM; ++r) part[r][0] = part[r][1] = part[r][2] = part[r][3] = 0.f;
-#pragma unroll
-                    for (int k = 0; k < KK; ++k) {
-                        const float x = k < O ? obs[k < O ? k : 0] : act[k >= O ? k - O : 0];
-#pragma unroll
-                        for (int r = 0; r < REM; ++r) part[r][k & 3] = __builtin_fmaf(x, mR[k][r], part[r][k & 3]);
-                    }
-#pragma unroll
-                    for (int r = 0; r < REM; ++r) accr[r] = (part[r][0] + part[r][1]) + (part[r][2] + part[r][3]);
-                }
-                // cost of (o_t, a_t), branch free; column 0 holds obs[lin_idx], column 0/1 obs[flip_idx]
-                float ctrl = 0.f;
-#pragma unroll
-                for (int j = 0; j < D; ++j) ctrl = __builtin_fmaf(act[j], act[j], ctrl);
-                const float ang = ang_is_col1 ? obs[O > 1 ? 1 : 0] : obs[0];
-                float c = 0.f;
-                c += (ang > flip_th) ? pen : 0.f;
-                c += (ang < -flip_th) ? pen : 0.f;
-                c += ctrl_w * ctrl;
-                c += lin_w * obs[0];
-                acc_s = __builtin_fmaf(acc_s, ksum, c);
-                acc_b = c < acc_b ? c : acc_b;
-                __builtin_amdgcn_sched_barrier(0);
-                // matrix-pipe block: (o+d) x floor(o/4) back-to-back MFMAs, independent accumulator chains
-#pragma unroll
-                for (int k = 0; k < KK; ++k) {
-                    const float x = k < O ? obs[k < O ? k : 0] : act[k >= O ? k - O : 0];
-#pragma unroll
-                    for (int ct = 0; ct < CTF; ++ct)
-                        acc[ct] = __builtin_amdgcn_mfma_f32_4x4x1f32(mA[k][ct], x, acc[ct], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int k = 0; k < O; ++k) {
-                    const float v = k < CTF * 4 ? acc[k < CTF * 4 ? k / 4 : 0][k % 4]
-                                                : accr[(k >= CTF * 4 && REM > 0) ? k - CTF * 4 : 0];
-                    obs[k] = act_fn(v, std::integral_constant<int, KIND>{});
-                }
-            }
-        };
-#pragma unroll 1
-        for (int tg = 0; tg < NG; tg += RING) {
-#pragma unroll
-            for (int b = 0; b < RING; ++b) {
-                if (tg + b < NG) {
-                    // refill the buffer freed by the previous group with group tg + b + RING - 1
-                    if (tg + b + RING - 1 < NG) {
-#pragma unroll
-                        for (int v = 0; v < GV; ++v) buf[(b + RING - 1) % RING][v] = arow[(tg + b + RING - 1) * GV + v];
-                    }
-                    run_group(buf[b]);
-                }
-            }
-        }
-        return use_min ? acc_b : acc_s;
-    }
-};
-
-// this tile's key joins the wave's running sorted top-K (lane r < K holds the r-th best)
-__device__ __forceinline__ unsigned long long topk_push(unsigned long long run_key, unsigned long long key, bool first,
-                                                        int K, int lane) {
-    key = wave_sort64(key, lane);
-    if (!first) {
-        const unsigned long long top = __shfl(key, lane - K, 64);
-        unsigned long long k2 = KEY_SENTINEL;
-        if (lane < K)
-            k2 = run_key;
-        else if (lane < 2 * K)
-            k2 = top;
-        key = wave_sort64(k2, lane);
-    }
-    return key;
-}
-
-// one sorted list per workgroup: up to 4 waves' top-K meet in LDS, wave 0 sorts them and emits K keys
-__device__ __forceinline__ void wg_emit_list(unsigned long long (*wg_keys)[32], unsigned long long run_key, int K, int lane,
-                                             int wave, float* part_c, int* part_i) {
-    if (wave < 4 && lane < K) wg_keys[wave][lane] = run_key;
-    __syncthreads();
-    if (wave == 0) {
-        unsigned long long k2 = KEY_SENTINEL;
-        if (4 * K <= 64) {  // all 4 lists fit one key per lane: a single sort
-            if (lane < 4 * K) k2 = wg_keys[lane / K][lane % K];
-            k2 = wave_sort64(k2, lane);
-        } else {
-            unsigned long long k0 = KEY_SENTINEL, k1 = KEY_SENTINEL;
-            if (lane < 2 * K) k0 = wg_keys[lane / K][lane % K];
-            if (lane < 2 * K) k1 = wg_keys[2 + lane / K][lane % K];
-            k0 = wave_sort64(k0, lane);
-            k1 = wave_sort64(k1, lane);
-            const unsigned long long top1 = __shfl(k1, lane - K, 64);
-            if (lane < K)
-                k2 = k0;
-            else if (lane < 2 * K)
-                k2 = top1;
-            k2 = wave_sort64(k2, lane);
-        }
-        if (lane < K) {
-            part_c[(size_t)blockIdx.x * K + lane] = key_cost(k2);
-            part_i[(size_t)blockIdx.x * K + lane] = key_idx(k2);
-        }
-    }
-}
-
-constexpr int RWG = 256;  // rollout workgroup: 4 independent wavefronts, one per SIMD
-// Unused dynamic LDS that makes a workgroup claim more than half of a CU's 160 KiB, so the dispatcher
-// can never put two rollout workgroups on one CU (two MFMA-bound waves on one SIMD halve each other).
-constexpr size_t ROLLOUT_LDS_PAD = 84 * 1024;
-
-template <int H, int D, int O, int KIND>
-__global__ __launch_bounds__(RWG) void rollout_mfma_kernel(FastRolloutArgs a) {
-    constexpr int HD = H * D;
-    __shared__ unsigned long long wg_keys[4][32];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    RolloutWave<H, D, O, KIND> rw;
-    rw.load(a, lane);
-    unsigned long long run_key = KEY_SENTINEL;
-    const int tiles = (a.n_rows + 63) / 64;
-    const int wave_gid = blockIdx.x * (RWG / 64) + wave;
-    const int wave_cnt = gridDim.x * (RWG / 64);
-    bool first = true;
-    for (int tile_id = wave_gid; tile_id < tiles; tile_id += wave_cnt) {
-        const int row = tile_id * 64 + lane;
-        const bool live = row < a.n_rows;
-        const float cost = rw.run(reinterpret_cast<const float4*>(a.actions + (size_t)(live ? row : 0) * HD));
-        if (live) a.costs[row] = cost;
-        if (a.K > 0) {
-            const unsigned long long key = (live && row < a.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
-            run_key = topk_push(run_key, key, first, a.K, lane);
-            first = false;
-        }
-    }
-    if (a.K > 0) wg_emit_list(wg_keys, run_key, a.K, lane, wave, a.part_c, a.part_i);
-}
-
-// -------------------------------------------------------------------------------------------------
-// quad rollout: a tile of 64 trajectories is shared by the 4 SIMDs of a CU, NQ tiles per workgroup
-// -------------------------------------------------------------------------------------------------
-// A lone rollout wave per SIMD walks its 30 dependent model steps with every latency exposed (dependent MFMA
-// chains, MFMA<->VALU switches, LDS/HBM waits).  Here 4 waves ("a quad") share one tile (lane = trajectory in
-// every wave): wave w owns output column tile w of the model (23 MFMAs per step instead of 92), the new
-// observation columns are exchanged through a double-buffered LDS array with one barrier per step.  Wave 0 of a
-// quad also scores the cost, wave 1 the leftover columns on the VALU.  A workgroup holds NQ quads (NQ waves per
-// SIMD, their MFMA streams interleave): NQ = 1 for <= 256 tiles (every tile its own CU), up to 4 beyond.
-// Requires floor(O/4) == 4 (O = 16..19).
-template <int H, int D, int O, int KIND, int NQ>
-__global__ __launch_bounds__(256 * NQ) void rollout_quad_kernel(FastRolloutArgs a) {
-    constexpr int REM = O - 16;
-    constexpr int CT4 = ((O + 3) / 4) * 4;
-    constexpr int KK = O + D;
-    constexpr int G = group_steps(D);
-    constexpr int GV = G * D / 4;
-    constexpr int HD = H * D;
-    constexpr int NG = H / G;
-    constexpr int RING = NQ > 2 ? (NG >= 3 ? 3 : NG) : (NG >= 5 ? 5 : (NG >= 3 ? 3 : NG));
-    static_assert(O / 4 == 4, "four column tiles, one per wave");
-    static_assert(H % G == 0 && HD % 4 == 0, "action rows must split into 16-byte groups");
-    __shared__ float xch_all[NQ][2][O][64];
-    __shared__ unsigned long long wg_keys[4][32];
-    const int lane = threadIdx.x & 63;
-    const int quad = threadIdx.x >> 8;
-    const int wave = (threadIdx.x >> 6) & 3;
-    float (*xch)[O][64] = xch_all[quad];
-
-    float mA[KK];                      // this wave's column tile: lane holds Mp[k][4*wave + (lane & 3)]
-    float mR[KK][REM > 0 ? REM : 1];   // leftover columns (wave 1), wave-uniform
-#pragma unroll
-    for (int k = 0; k < KK; ++k) {
-        mA[k] = a.Mp[k * CT4 + wave * 4 + (lane & 3)];
-#pragma unroll
-        for (int r = 0; r < REM; ++r) mR[k][r] = a.Mp[k * CT4 + 16 + r];
-    }
-    float obs_init[O];
-#pragma unroll
-    for (int k = 0; k < O; ++k) obs_init[k] = k < a.o ? a.obs0[a.perm[k]] : 0.f;
-    const float pen = a.flip_col >= 0 ? a.flip_pen : 0.f;
-    const bool ang_is_col1 = a.flip_col == 1;
-    const float ksum = a.cost_mode == 0 ? 1.f : 0.f;
-    const bool use_min = a.cost_mode == 1;
-
-    unsigned long long run_key = KEY_SENTINEL;
-    bool first = true;
-    const int tiles = (a.n_rows + 63) / 64;
-    // every quad of the workgroup walks the same number of tiles (the step barrier is workgroup wide); a quad
-    // past the end rolls out row 0 again and drops the result
-    for (int tile0 = blockIdx.x * NQ; tile0 < tiles; tile0 += gridDim.x * NQ) {
-        const int row = (tile0 + quad) * 64 + lane;
-        const bool live = row < a.n_rows;
-        const float4* __restrict__ arow = reinterpret_cast<const float4*>(a.actions + (size_t)(live ? row : 0) * HD);
-        float4 buf[RING][GV];
-#pragma unroll
-        for (int b = 0; b < RING - 1; ++b) {
-            if (b < NG) {
-#pragma unroll
-                for (int v = 0; v < GV; ++v) buf[b][v] = arow[b * GV + v];
-            }
-        }
-        float obs[O];
-#pragma unroll
-        for (int k = 0; k < O; ++k) obs[k] = obs_init[k];
-        float acc_s = 0.f, acc_b = INFINITY;
-        int par = 0;
-        auto run_group = [&](const float4 (&cur)[GV]) {
-            float actg[G * D];
-#pragma unroll
-            for (int v = 0; v < GV; ++v) {
-                actg[4 * v] = cur[v].x;
-                actg[4 * v + 1] = cur[v].y;
-                actg[4 * v + 2] = cur[v].z;
-                actg[4 * v + 3] = cur[v].w;
-            }
-#pragma unroll
-            for (int s = 0; s < G; ++s) {
-                const float* act = actg + s * D;
-                float accr[REM > 0 ? REM : 1];
-                // VALU block (clustered, see RolloutWave): wave 0 scores the step, wave 1 the leftover columns
-                if (wave == 0) {
-                    float ctrl = 0.f;
-#pragma unroll
-                    for (int j = 0; j < D; ++j) ctrl = __builtin_fmaf(act[j], act[j], ctrl);
-                    const float ang = ang_is_col1 ? obs[1] : obs[0];
-                    float c = 0.f;
-                    c += (ang > a.flip_th) ? pen : 0.f;
-                    c += (ang < -a.flip_th) ? pen : 0.f;
-                    c += a.ctrl_w * ctrl;
-                    c += a.lin_w * obs[0];
-                    acc_s = __builtin_fmaf(acc_s, ksum, c);
-                    acc_b = c < acc_b ? c : acc_b;
-                }
-                if (REM > 0 && wave == 1) {
-                    float part[REM > 0 ? REM : 1][4];
-#pragma unroll
-                    for (int r = 0; r < REM; ++r) part[r][0] = part[r][1] = part[r][2] = part[r][3] = 0.f;
-#pragma unroll
-                    for (int k = 0; k < KK; ++k) {
-                        const float x = k < O ? obs[k < O ? k : 0] : act[k >= O ? k - O : 0];
-#pragma unroll
-                        for (int r = 0; r < REM; ++r) part[r][k & 3] = __builtin_fmaf(x, mR[k][r], part[r][k & 3]);
-                    }
-#pragma unroll
-                    for (int r = 0; r < REM; ++r) accr[r] = (part[r][0] + part[r][1]) + (part[r][2] + part[r][3]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                // this wave's column tile: two independent accumulator chains (even / odd k) keep the 8-cycle issue
-                f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int k = 0; k < KK; ++k) {
-                    const float x = k < O ? obs[k < O ? k : 0] : act[k >= O ? k - O : 0];
-                    if (k & 1)
-                        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(mA[k], x, acc1, 0, 0, 0);
-                    else
-                        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(mA[k], x, acc0, 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                // exchange: publish 4 (+ leftover) new columns, read all O back
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    xch[par][wave * 4 + i][lane] = act_fn(acc0[i] + acc1[i], std::integral_constant<int, KIND>{});
-                if (REM > 0 && wave == 1) {
-#pragma unroll
-                    for (int r = 0; r < REM; ++r) xch[par][16 + r][lane] = act_fn(accr[r], std::integral_constant<int, KIND>{});
-                }
-                __syncthreads();
-#pragma unroll
-                for (int k = 0; k < O; ++k) obs[k] = xch[par][k][lane];
-                par ^= 1;
-            }
-        };
-#pragma unroll 1
-        for (int tg = 0; tg < NG; tg += RING) {
-#pragma unroll
-            for (int b = 0; b < RING; ++b) {
-                if (tg + b < NG) {
-                    if (tg + b + RING - 1 < NG) {
-#pragma unroll
-                        for (int v = 0; v < GV; ++v) buf[(b + RING - 1) % RING][v] = arow[(tg + b + RING - 1) * GV + v];
-                    }
-                    run_group(buf[b]);
-                }
-            }
-        }
-        if (wave == 0) {
-            const float cost = use_min ? acc_b : acc_s;
-            if (live) a.costs[row] = cost;
-            if (a.K > 0) {
-                const unsigned long long key = (live && row < a.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
-                run_key = topk_push(run_key, key, first, a.K, lane);
-                first = false;
-            }
-        }
-    }
-    if (a.K > 0) {
-        if (NQ == 1) {
-            if (wave == 0 && lane < a.K) {
-                a.part_c[(size_t)blockIdx.x * a.K + lane] = key_cost(run_key);
-                a.part_i[(size_t)blockIdx.x * a.K + lane] = key_idx(run_key);
-            }
-        } else {
-            // wave 0 of each quad holds a list; slots of absent quads stay empty
-            if (wave != 0 || quad >= 4) run_key = KEY_SENTINEL;
-            const int slot = wave == 0 ? quad : (NQ + wave - 1);  // NQ + (1..3) cover slots NQ..3 when NQ < 4
-            wg_emit_list(wg_keys, run_key, a.K, lane, slot, a.part_c, a.part_i);
-        }
-    }
-}
-
-// -------------------------------------------------------------------------------------------------
-// rollout16: 16 trajectories per wavefront on v_mfma_f32_16x16x4_f32, model operand in O(1) registers
-// -------------------------------------------------------------------------------------------------
+// 16 trajectories per wavefront on v_mfma_f32_16x16x4_f32:
 // D[16 x 16] += A[16 x 4] . B[4 x 16] with A = a 16 x 4 block of M^T (output column i = lane % 16, contraction
 // slot g = lane / 16) and B = X^T (trajectory j = lane % 16, slot g).  The result leaves lane (j, g) holding the
 // new observation columns 4g .. 4g+3 of trajectory j in its 4 accumulator registers -- and MFMA number s of the
@@ -699,8 +236,9 @@ __global__ __launch_bounds__(256 * NQ) void rollout_quad_kernel(FastRolloutArgs 
 // register per MFMA (6 for o=17, d=6, against 92 for the 4x4x1 tiling).  Observation columns >= 16 and the
 // actions ride in extra contraction slots: extra e sits in slot e % 4 of MFMA 4 + e/4.  Output columns >= 16 (at
 // most 4) are per-lane partial dot products summed over the 4 lanes of a trajectory with v_permlane32/16_swap;
-// the same reduction sums the step cost.  With ~40 registers a SIMD holds many rollout waves, so one wave's
-// VALU / memory phases hide under the others' MFMAs (the 4x4x1 kernels run one exposed wave per SIMD).
+// the same reduction sums the step cost.  A SIMD holds 4 such waves, whose memory / LDS / hazard stalls hide
+// under each other's arithmetic.  (f32 MFMA and f32 VALU share one pipe on gfx950 -- tools/ubench/
+// mfma_valu_two_waves.hip -- so their cycles add; the kernel is bound by that sum.)
 __device__ __forceinline__ float reduce_groups(float x) {
     // sum over lanes l, l^16, l^32, l^48 (the 4 contraction slots of one trajectory), result in all of them
     unsigned u = __float_as_uint(x);
@@ -919,104 +457,6 @@ __global__ __launch_bounds__(64 * WAVES) void rollout16_kernel(FastRolloutArgs a
 }
 
 // -------------------------------------------------------------------------------------------------
-// fused iteration: sample -> HBM (through an LDS tile) -> rollout of the same trajectories by the same
-// workgroup (actions re-read through L2, never after a kernel boundary) -> cost -> per-workgroup top-K
-// -------------------------------------------------------------------------------------------------
-constexpr int FWG = 512;  // 8 wavefronts: all sample; waves 0..tpb/64-1 (distinct SIMDs) roll out
-
-// sampling pass of the fused kernel: rows [0, n_rows) of the workgroup's slab (row = traj*D + j), NR rows
-// per thread, samples stored straight to actions[traj][t][j] (6 adjacent lanes fill 24 contiguous bytes; L2
-// write-combines the rest) -- no LDS tile, no barrier inside the pass.
-template <int H, int D, int ROUNDS, int NR>
-__device__ __forceinline__ void fused_sample_pass(const FusedArgs& a, const float* ms, int sb, int n_rows, int tid) {
-    constexpr int HD = H * D;
-    unsigned gi[NR], jj[NR];
-    float lo[NR], hi[NR];
-    float* dst[NR];
-    bool ok[NR], is_mean[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        const int row = tid + r * FWG;
-        ok[r] = row < n_rows;
-        const int rr = ok[r] ? row : 0;
-        const int nl = rr / D;
-        const int j = rr - nl * D;
-        gi[r] = (unsigned)(a.first_index + sb + nl);
-        jj[r] = (unsigned)j;
-        lo[r] = a.low[j];
-        hi[r] = a.high[j];
-        dst[r] = a.actions + (size_t)(sb + nl) * HD + j;
-        is_mean[r] = a.row0_mean && (a.first_index + sb + nl == 0);  // icem.py:87-88
-    }
-    long long tmid = 0;
-    sample_rows<H, ROUNDS, NR>(a.W, gi, jj, a.off_lo, a.off_hi, a.seed_lo, a.seed_hi, [&](int r, int t, float y) {
-        const float m = ms[t * D + jj[r]];
-        float v = __builtin_fmaf(y, ms[HD + t * D + jj[r]], m);
-        v = v < lo[r] ? lo[r] : v;
-        v = v > hi[r] ? hi[r] : v;
-        v = is_mean[r] ? m : v;
-        if (ok[r]) dst[r][t * D] = v;
-    }, a.dbg ? &tmid : nullptr);
-    if (a.dbg && (tid & 63) == 0) a.dbg[((size_t)blockIdx.x * 8 + (tid >> 6)) * 8 + 5] = tmid;
-}
-
-template <int H, int D, int O, int KIND, int ROUNDS>
-__global__ __launch_bounds__(FWG) void fused_iter_kernel(FusedArgs a) {
-    constexpr int HD = H * D;
-    __shared__ float ms[2 * HD];
-    __shared__ unsigned long long wg_keys[4][32];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int tpb = a.tpb;            // trajectories per workgroup pass: 64, 128 or 256
-    const int n_rwaves = tpb >> 6;
-    const int n_total = a.n + a.n_extra;  // rows [n, n_total) are pre-filled (shifted elites): rollout only
-    for (int e = tid; e < HD; e += FWG) {
-        ms[e] = a.mean[e];
-        ms[HD + e] = a.std[e];
-    }
-    __syncthreads();
-    unsigned long long run_key = KEY_SENTINEL;
-    bool first = true;
-    long long st[5] = {0, 0, 0, 0, 0};
-    if (a.dbg) st[0] = __builtin_readcyclecounter();
-    for (int base = blockIdx.x * tpb; base < n_total; base += gridDim.x * tpb) {
-        // ---- sample + store ----
-        const int n_samp = cmin(tpb, a.n - base);
-        if (n_samp > 0) {
-            const int n_rows = n_samp * D;
-            if (n_rows > 2 * FWG)
-                fused_sample_pass<H, D, ROUNDS, 3>(a, ms, base, n_rows, tid);
-            else if (n_rows > FWG)
-                fused_sample_pass<H, D, ROUNDS, 2>(a, ms, base, n_rows, tid);
-            else
-                fused_sample_pass<H, D, ROUNDS, 1>(a, ms, base, n_rows, tid);
-        }
-        if (a.dbg) st[1] = __builtin_readcyclecounter();
-        __syncthreads();  // the slab is stored and visible to the workgroup
-        if (a.dbg) st[2] = __builtin_readcyclecounter();
-        // ---- rollout + cost + top-K: wave w takes rows base + 64 w + lane ----
-        if (wave < n_rwaves && base + wave * 64 < n_total) {  // wave-uniform
-            RolloutWave<H, D, O, KIND> rw;  // loaded here so the model operand is not live across the sampling
-            rw.load(a, lane);
-            const int row = base + wave * 64 + lane;
-            const bool live = row < n_total;
-            const float cost = rw.run(reinterpret_cast<const float4*>(a.actions + (size_t)(live ? row : 0) * HD));
-            if (a.dbg) st[3] = __builtin_readcyclecounter();
-            if (live) a.costs[row] = cost;
-            const unsigned long long key = (live && row < a.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
-            run_key = topk_push(run_key, key, first, a.K, lane);
-            first = false;
-        }
-    }
-    wg_emit_list(wg_keys, run_key, a.K, lane, wave, a.part_c, a.part_i);
-    if (a.dbg && lane == 0) {
-        st[4] = __builtin_readcyclecounter();
-        for (int i = 0; i < 5; ++i) a.dbg[((size_t)blockIdx.x * 8 + wave) * 8 + i] = st[i];
-    }
-}
-
-// -------------------------------------------------------------------------------------------------
 // merge: global sorted top-K from <= 256 sorted candidate lists (+ kept elites)
 // -------------------------------------------------------------------------------------------------
 constexpr int MERGE_WG = 256;  // wave 0 selects (no barriers inside); all 4 waves gather + refit
@@ -1211,19 +651,7 @@ bool fast_rollout_supported(int h, int d, int O, int K) {
     return false;
 }
 
-// quads per workgroup of the quad rollout (0: shape not eligible, use the wave-per-tile kernel)
-static int quad_nq(int O, int tiles) {
-    static const int force = [] { const char* e = getenv("ICEM_QUAD_NQ"); return e ? atoi(e) : -1; }();
-    if (O / 4 != 4) return 0;
-    if (force >= 0) return tiles <= FAST_MAX_LISTS ? 1 : force;
-    return tiles <= FAST_MAX_LISTS ? 1 : (tiles <= 2 * FAST_MAX_LISTS ? 2 : 4);
-}
-
-// rollout16 launch shape: one 16-trajectory tile per wave while they fit, at most 256 workgroups (= lists)
-static bool use_r16(int O) {
-    static const int on = [] { const char* e = getenv("ICEM_R16"); return e ? atoi(e) : 1; }();
-    return on && O <= 20;
-}
+// rollout launch shape: one 16-trajectory tile per wave while they fit, at most FAST_MAX_LISTS workgroups (= lists)
 static void r16_shape(int n_rows, int* grid, int* waves) {
     const int tiles = std::max(1, (n_rows + 15) / 16);
     const int g = std::min(tiles, FAST_MAX_LISTS);
@@ -1234,77 +662,33 @@ static void r16_shape(int n_rows, int* grid, int* waves) {
 }
 
 int rollout_lists(int h, int d, int O, int n_rows) {
-    if (use_r16(O)) {
-        int g, w;
-        r16_shape(n_rows, &g, &w);
-        return g;
-    }
-    const int tiles = (n_rows + 63) / 64;
-    const int nq = quad_nq(O, tiles);
-    const int per = nq > 0 ? nq : 4;  // tiles that share a workgroup (= one candidate list)
-    const int g = (tiles + per - 1) / per;
-    return g < 1 ? 1 : (g > FAST_MAX_LISTS ? FAST_MAX_LISTS : g);
+    int g, w;
+    r16_shape(n_rows, &g, &w);
+    return g;
 }
 
-void launch_rollout_mfma(const FastRolloutArgs& a, int h, int d, int O, int kind, int grid, hipStream_t st) {
-    if (use_r16(O)) {
-        int g, waves;
-        r16_shape(a.n_rows, &g, &waves);
-#define XW(HH, DD, OO, WW)                                                                                      \
-    if (waves == WW) {                                                                                          \
-        if (kind == 1)                                                                                          \
-            hipLaunchKernelGGL((rollout16_kernel<HH, DD, OO, 1, WW>), dim3(grid), dim3(64 * WW), 0, st, a);     \
-        else                                                                                                    \
-            hipLaunchKernelGGL((rollout16_kernel<HH, DD, OO, 0, WW>), dim3(grid), dim3(64 * WW), 0, st, a);     \
-        return;                                                                                                 \
+void launch_rollout16(const FastRolloutArgs& a, int h, int d, int O, int kind, hipStream_t st) {
+    int grid, waves;
+    r16_shape(a.n_rows, &grid, &waves);
+#define XW(HH, DD, OO, WW)                                                                                  \
+    if (waves == WW) {                                                                                      \
+        if (kind == 1)                                                                                      \
+            hipLaunchKernelGGL((rollout16_kernel<HH, DD, OO, 1, WW>), dim3(grid), dim3(64 * WW), 0, st, a); \
+        else                                                                                                \
+            hipLaunchKernelGGL((rollout16_kernel<HH, DD, OO, 0, WW>), dim3(grid), dim3(64 * WW), 0, st, a); \
+        return;                                                                                             \
     }
-#define XR(HH, DD, OO)                         \
-    if constexpr (OO <= 20) {                  \
-        if (h == HH && d == DD && O == OO) {   \
-            XW(HH, DD, OO, 1)                  \
-            XW(HH, DD, OO, 2)                  \
-            XW(HH, DD, OO, 4)                  \
-            XW(HH, DD, OO, 8)                  \
-            XW(HH, DD, OO, 16)                 \
-        }                                      \
+#define XR(HH, DD, OO)                   \
+    if (h == HH && d == DD && O == OO) { \
+        XW(HH, DD, OO, 1)                \
+        XW(HH, DD, OO, 2)                \
+        XW(HH, DD, OO, 4)                \
+        XW(HH, DD, OO, 8)                \
+        XW(HH, DD, OO, 16)               \
     }
-        ICEM_FAST_SHAPES(XR)
+    ICEM_FAST_SHAPES(XR)
 #undef XR
 #undef XW
-    }
-    const int tiles = (a.n_rows + 63) / 64;
-    const int nq = quad_nq(O, tiles);
-    if (nq > 0) {
-#define XQ1(HH, DD, OO, NQ)                                                                                        \
-    if (nq == NQ) {                                                                                                \
-        if (kind == 1)                                                                                             \
-            hipLaunchKernelGGL((rollout_quad_kernel<HH, DD, OO, 1, NQ>), dim3(grid), dim3(256 * NQ), 0, st, a);    \
-        else                                                                                                       \
-            hipLaunchKernelGGL((rollout_quad_kernel<HH, DD, OO, 0, NQ>), dim3(grid), dim3(256 * NQ), 0, st, a);    \
-        return;                                                                                                    \
-    }
-#define XQ(HH, DD, OO)                          \
-    if constexpr (OO / 4 == 4) {                \
-        if (h == HH && d == DD && O == OO) {    \
-            XQ1(HH, DD, OO, 1)                  \
-            XQ1(HH, DD, OO, 2)                  \
-            XQ1(HH, DD, OO, 4)                  \
-        }                                       \
-    }
-        ICEM_FAST_SHAPES(XQ)
-#undef XQ
-#undef XQ1
-    }
-#define X(HH, DD, OO)                                                                                         \
-    if (h == HH && d == DD && O == OO) {                                                                      \
-        if (kind == 1)                                                                                        \
-            hipLaunchKernelGGL((rollout_mfma_kernel<HH, DD, OO, 1>), dim3(grid), dim3(RWG), ROLLOUT_LDS_PAD, st, a);         \
-        else                                                                                                  \
-            hipLaunchKernelGGL((rollout_mfma_kernel<HH, DD, OO, 0>), dim3(grid), dim3(RWG), ROLLOUT_LDS_PAD, st, a);         \
-        return;                                                                                               \
-    }
-    ICEM_FAST_SHAPES(X)
-#undef X
 }
 
 #define ICEM_FAST_HORIZONS(X) X(30) X(12) X(13) X(10)
@@ -1332,22 +716,6 @@ void launch_sample_folded(const FastSampleArgs& a, int rounds, hipStream_t st) {
     }
     ICEM_FAST_HORIZONS(X)
 #undef X
-}
-
-#define ICEM_FUSED_LAUNCH(HH, DD, OO)                                                                             \
-    if (a.h == HH && a.d == DD && O == OO) {                                                                      \
-        if (kind == 1) {                                                                                          \
-            if (rounds == 7) hipLaunchKernelGGL((fused_iter_kernel<HH, DD, OO, 1, 7>), dim3(grid), dim3(FWG), 0, st, a);   \
-            else hipLaunchKernelGGL((fused_iter_kernel<HH, DD, OO, 1, 10>), dim3(grid), dim3(FWG), 0, st, a);      \
-        } else {                                                                                                  \
-            if (rounds == 7) hipLaunchKernelGGL((fused_iter_kernel<HH, DD, OO, 0, 7>), dim3(grid), dim3(FWG), 0, st, a);   \
-            else hipLaunchKernelGGL((fused_iter_kernel<HH, DD, OO, 0, 10>), dim3(grid), dim3(FWG), 0, st, a);      \
-        }                                                                                                         \
-        return;                                                                                                   \
-    }
-
-void launch_fused_iter(const FusedArgs& a, int O, int kind, int rounds, int grid, hipStream_t st) {
-    ICEM_FAST_SHAPES(ICEM_FUSED_LAUNCH)
 }
 
 void launch_merge_single(const MergeSingleArgs& a, hipStream_t st) {

@@ -595,7 +595,6 @@ struct icem_handle {
         hipEvent_t a, b;
     };
     bool use_fast = true;
-    bool use_fused = false;  // experimental single-launch iteration (ICEM_ENABLE_FUSED=1); slower than the two-kernel path today
     long long* dbg = nullptr;
     int fast_lists = 0;  // candidate lists written by the last matrix-pipe rollout (0 = generic path ran)
     // permuted, padded model of the matrix-pipe rollout: column 0 = obs[lin_idx], column 1 = obs[flip_idx]
@@ -906,7 +905,7 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
     const int grid = rollout_lists(h->cfg.horizon, h->cfg.act_dim, h->O, n_rows);
     {
         ProfScope prof(h, ICEM_K_ROLLOUT, (long long)n_rows * h->cfg.horizon, st);
-        launch_rollout_mfma(a, h->cfg.horizon, h->cfg.act_dim, h->O, h->model_kind, grid, st);
+        launch_rollout16(a, h->cfg.horizon, h->cfg.act_dim, h->O, h->model_kind, st);
     }
     ICEM_HIP_TRY(hipGetLastError());
     if (lists_out) *lists_out = grid;
@@ -970,7 +969,7 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
         shift_src = (const T*)b->elites + (size_t)g * K * hd;
         // the fast sampler prepares them in an extra workgroup of its own launch
         shift_in_sampler = std::is_same<T, float>::value && b->z_r == nullptr && b->z_r_shift == nullptr &&
-                           fast_rollout_ok(h, K) && fast_sample_ok(h) && !h->use_fused &&
+                           fast_rollout_ok(h, K) && fast_sample_ok(h) &&
                            n_extra * c.act_dim <= 256;
         if (!shift_in_sampler) {
             T* dst = actions + (size_t)n_loc * hd;
@@ -996,65 +995,19 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
             float* pc;
             int* pi;
             const int n_rows = n_loc + n_extra;
-            if (h->use_fused && fast_sample_ok(h)) {
-                // ONE launch: sample -> LDS tile -> HBM, rollout of the same trajectories by the same workgroup
-                // (actions re-read through L2), cost, per-workgroup sorted top-K
-                FusedArgs a;
-                a.n = n_loc;
-                a.n_extra = n_extra;
-                a.n_cand = n_cand;
-                a.K = K;
-                a.h = c.horizon;
-                a.d = c.act_dim;
-                a.o = h->obs_dim;
-                a.cost_mode = c.cost_mode;
-                a.row0_mean = row0;
-                a.tpb = n_rows > 128 * 256 ? 256 : (n_rows > 64 * 256 ? 128 : 64);
-                a.first_index = lo;
-                a.W = (const float*)h->W_dev;
-                a.mean = (const float*)b->mean;
-                a.std = (const float*)b->std;
-                a.low = (const float*)b->low;
-                a.high = (const float*)b->high;
-                a.seed_lo = (uint32_t)c.seed;
-                a.seed_hi = (uint32_t)(c.seed >> 32);
-                a.off_lo = (uint32_t)off;
-                a.off_hi = (uint32_t)(off >> 32);
-                a.Mp = (const float*)h->Mp_dev;
-                a.perm = (const int*)h->perm_dev;
-                a.obs0 = (const float*)b->obs0;
-                a.ctrl_w = (float)h->cost.ctrl_weight;
-                a.lin_w = (float)h->cost.lin_weight;
-                a.flip_pen = (float)h->cost.flip_penalty;
-                a.flip_th = (float)h->cost.flip_thresh;
-                a.flip_col = h->flip_col;
-                a.actions = (float*)actions;
-                a.costs = (float*)b->costs;
-                lists = std::max(1, std::min((n_rows + a.tpb - 1) / a.tpb, FAST_MAX_LISTS));
-                split_partial_ws<float>(b->workspace, lists, K, &pc, &pi);
-                a.part_c = pc;
-                a.part_i = pi;
-                a.dbg = h->dbg;
-                {
-                    ProfScope prof(h, ICEM_K_FUSED, (long long)n_rows * c.horizon, st);
-                    launch_fused_iter(a, h->O, h->model_kind, c.rng_rounds, lists, st);
-                }
-                ICEM_HIP_TRY(hipGetLastError());
+            if (fast_sample_ok(h)) {
+                rc = launch_fast_sample(h, n_loc, lo, b->mean, b->std, b->low, b->high, off, row0, actions, st,
+                                        shift_in_sampler ? n_extra : 0, shift_src, call_base + (uint64_t)c.opt_iters);
             } else {
-                if (fast_sample_ok(h)) {
-                    rc = launch_fast_sample(h, n_loc, lo, b->mean, b->std, b->low, b->high, off, row0, actions, st,
-                                            shift_in_sampler ? n_extra : 0, shift_src, call_base + (uint64_t)c.opt_iters);
-                } else {
-                    SampleArgs<T> a = make_sample_args<T>(h, n_loc, lo, b->mean, b->std, b->low, b->high, nullptr, nullptr,
-                                                          off, 0, row0, actions);
-                    rc = launch_sample<T>(h, a, st);
-                }
-                if (rc) return rc;
-                const int grid = rollout_lists(c.horizon, c.act_dim, h->O, n_rows);
-                split_partial_ws<float>(b->workspace, grid, K, &pc, &pi);
-                rc = launch_fast_rollout(h, n_rows, n_cand, K, b->obs0, actions, b->costs, pc, pi, st, &lists);
-                if (rc) return rc;
+                SampleArgs<T> a = make_sample_args<T>(h, n_loc, lo, b->mean, b->std, b->low, b->high, nullptr, nullptr,
+                                                      off, 0, row0, actions);
+                rc = launch_sample<T>(h, a, st);
             }
+            if (rc) return rc;
+            const int grid = rollout_lists(c.horizon, c.act_dim, h->O, n_rows);
+            split_partial_ws<float>(b->workspace, grid, K, &pc, &pi);
+            rc = launch_fast_rollout(h, n_rows, n_cand, K, b->obs0, actions, b->costs, pc, pi, st, &lists);
+            if (rc) return rc;
             h->fast_lists = lists;
             if (c.world > 1) {
                 ProfScope prof(h, ICEM_K_LOCAL_PACK, lists * K, st);
@@ -1065,7 +1018,7 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
             return ICEM_OK;
         }
     }
-    // generic path (f64, external noise, shapes outside the fused list): one kernel per stage
+    // generic path (f64, external noise, shapes outside the fast list): one kernel per stage
     {
         SampleArgs<T> a = make_sample_args<T>(h, n_loc, lo, b->mean, b->std, b->low, b->high, b->z_r, b->z_i,
                                               call_base + (uint64_t)it, 0, row0, actions);
@@ -1222,7 +1175,6 @@ int icem_create(const icem_config* cfg, icem_handle** out) {
     h->n_local_max = 0;
     for (int n_it : h->pop) h->n_local_max = std::max(h->n_local_max, shard_chunk(n_it, c.world));
     if (const char* e = getenv("ICEM_DISABLE_FAST")) h->use_fast = !(e[0] == '1');
-    if (const char* e = getenv("ICEM_ENABLE_FUSED")) h->use_fused = (e[0] == '1');
     // synthesis table W[t][m]: m < F real part of bin m, F <= m < h imaginary part of bin m-F+1
     std::vector<double> cr, ci, W((size_t)c.horizon * h->HMAX, 0.0);
     noise_tables(c.horizon, c.noise_beta, cr, ci);
