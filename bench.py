@@ -61,7 +61,7 @@ def run_steps(pl, n, world):
 def algorithmic_bytes_per_trajstep(kernel, d, h):
     """the whole loop moves 8d + 8/h bytes per traj-step in f32 (actions written once and
     read once, costs written once and read once).  A kernel is charged its own share of that."""
-    return {"sample_clip": 4.0 * d, "rollout_cost": 4.0 * d + 4.0 / h}.get(kernel)
+    return {"sample_clip": 4.0 * d, "rollout_cost": 4.0 * d + 4.0 / h, "sample_rollout": 8.0 * d + 8.0 / h}.get(kernel)
 
 
 def cpu_baseline(w, model, env, budget_s=12.0):

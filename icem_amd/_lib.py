@@ -14,7 +14,7 @@ MODEL_LINEAR, MODEL_TANH = 0, 1
 (BUF_MEAN, BUF_STD, BUF_LOW, BUF_HIGH, BUF_OBS0, BUF_ACTIONS, BUF_COSTS, BUF_ELITES, BUF_RECORDS,
  BUF_WORKSPACE, BUF_EXECUTED, BUF_BEST_COST, BUF_COUNT) = range(13)
 
-KERNEL_NAMES = ["sample_clip", "rollout_cost", "topk_partial", "local_pack", "merge_refit"]
+KERNEL_NAMES = ["sample_clip", "rollout_cost", "topk_partial", "local_pack", "merge_refit", "sample_rollout"]
 
 ERR_NAMES = {-1: "ICEM_E_INVALID", -2: "ICEM_E_UNSUPPORTED", -3: "ICEM_E_HIP", -4: "ICEM_E_NO_DEVICE",
              -5: "ICEM_E_STATE"}

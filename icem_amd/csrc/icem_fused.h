@@ -53,6 +53,15 @@ void launch_rollout16(const FastRolloutArgs& a, int h, int d, int O, int kind, h
 // workgroups (= candidate lists) the rollout of n_rows trajectories is launched with
 int rollout_lists(int h, int d, int O, int n_rows);
 
+// K1+K2+K3 in one launch (small populations): r.actions == s.out, r.n_rows == s.n + s.n_shift.
+struct FastIterArgs {
+    FastSampleArgs s;
+    FastRolloutArgs r;
+};
+// workgroups (= candidate lists) of that launch; 0 if this shape / generator / size has no single-launch kernel
+int sample_rollout_lists(int h, int d, int O, int rounds, int n_rows);
+void launch_sample_rollout(const FastIterArgs& a, int h, int d, int O, int kind, hipStream_t st);
+
 // world == 1: global sorted top-K straight from the waves' candidate lists (+ kept elites), gather of
 // the elite rows from the pool, refit, and the last-iteration epilogue.
 struct MergeSingleArgs {

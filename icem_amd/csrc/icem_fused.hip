@@ -258,98 +258,71 @@ __host__ __device__ constexpr int r16_chunk_steps(int h, int d) {
     return best;
 }
 
-template <int H, int D, int O, int KIND, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void rollout16_kernel(FastRolloutArgs a) {
-    constexpr int REM = O > 16 ? O - 16 : 0;   // output columns beyond the 16 x 16 tile
-    constexpr int NX = REM + D;                // extra contraction entries: columns >= 16, then the actions
-    constexpr int NKX = (NX + 3) / 4;          // MFMAs that carry them
-    constexpr int CT4 = ((O + 3) / 4) * 4;     // row stride of Mp
-    constexpr int HD = H * D;
-    constexpr int TC = r16_chunk_steps(H, D);  // steps per action chunk
-    static_assert(TC > 0, "no 16-byte aligned action chunk for this (H, D)");
-    constexpr int CB = TC * D;                 // floats per row and chunk
-    constexpr int C4 = CB / 4;
-    constexpr int CBP = (C4 % 2) ? CB : CB + 4;  // LDS row stride: odd number of float4s
-    constexpr int NCH = H / TC;
-    constexpr int F4 = 16 * C4;                // float4s per chunk of a 16-trajectory tile
-    constexpr int NLD = (F4 + 63) / 64;        // cooperative load instructions per chunk
-    constexpr int SLACK = 4;                   // floats in front of a buffer (entries that are not actions read there)
-    constexpr int STG = SLACK + 16 * CBP + 8;  // + tail slack for padding entries of the last row
+// Everything a wavefront needs to roll 16 trajectories out; run() is shared by the stand-alone rollout kernel
+// and the sample+rollout kernel, so both produce the same bits for the same actions.
+template <int H, int D, int O, int KIND>
+struct Tile16 {
+    static constexpr int REM = O > 16 ? O - 16 : 0;   // output columns beyond the 16 x 16 tile
+    static constexpr int NX = REM + D;                // extra contraction entries: columns >= 16, then the actions
+    static constexpr int NKX = (NX + 3) / 4;          // MFMAs that carry them
+    static constexpr int CT4 = ((O + 3) / 4) * 4;     // row stride of Mp
+    static constexpr int SLACK = 4;  // floats in front of an action buffer: entries that are not actions read there
+    static constexpr int TAIL = 8;   // and behind it: padding entries of the last row
     static_assert(REM <= 4, "observation width up to 20");
-    // the tile's actions are one contiguous 16 x H x D block of HBM: the wave fetches it with full-width coalesced
-    // loads, chunk by chunk, into its own LDS buffer; each lane then reads the one or two entries it feeds to the MFMAs
-    __shared__ __attribute__((aligned(16))) float stage[WAVES][STG];
-    __shared__ unsigned long long wg_keys[2][WAVES][32];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int j = lane & 15, g = lane >> 4;
 
-    // model operands: one register per MFMA
-    float mA[4 + NKX];
+    float mA[4 + NKX];                     // model operands: one register per MFMA
     float wR[REM > 0 ? REM : 1][4 + NKX];  // weights of this lane's contraction entries into output column 16 + r
     float cw[NKX];                         // ctrl_w where the extra entry is an action, else 0
     bool is_act[NKX];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int k = 4 * g + s;
-        mA[s] = (k < O && j < O) ? a.Mp[k * CT4 + j] : 0.f;
-#pragma unroll
-        for (int r = 0; r < REM; ++r) wR[r][s] = k < O ? a.Mp[k * CT4 + 16 + r] : 0.f;
-    }
-#pragma unroll
-    for (int q = 0; q < NKX; ++q) {
-        const int e = 4 * q + g;
-        const int k = e < REM ? 16 + e : O + (e - REM);
-        const bool valid = e < NX;
-        mA[4 + q] = (valid && j < O) ? a.Mp[(valid ? k : 0) * CT4 + j] : 0.f;
-#pragma unroll
-        for (int r = 0; r < REM; ++r) wR[r][4 + q] = valid ? a.Mp[(valid ? k : 0) * CT4 + 16 + r] : 0.f;
-        is_act[q] = valid && e >= REM;
-        cw[q] = is_act[q] ? a.ctrl_w : 0.f;
-    }
     f32x4 obs_init;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) obs_init[v] = (4 * g + v < a.o) ? a.obs0[a.perm[4 * g + v]] : 0.f;
     float rem_init[REM > 0 ? REM : 1];
+    float pen, lin_w, ksum, flip_th;
+    bool ang_is_col1, use_min;
+    int g;
+
+    __device__ __forceinline__ void load(const FastRolloutArgs& a, int lane) {
+        const int j = lane & 15;
+        g = lane >> 4;
 #pragma unroll
-    for (int r = 0; r < REM; ++r) rem_init[r] = (16 + r < a.o) ? a.obs0[a.perm[16 + r]] : 0.f;
-    // cost terms that read observation columns 0 / 1 live in slot 0 only
-    const float pen = (a.flip_col >= 0 && g == 0) ? a.flip_pen : 0.f;
-    const float lin_w = g == 0 ? a.lin_w : 0.f;
-    const bool ang_is_col1 = a.flip_col == 1;
-    const float ksum = a.cost_mode == 0 ? 1.f : 0.f;
-    const bool use_min = a.cost_mode == 1;
-    const float flip_th = a.flip_th;
-    // this lane's entry q of step tt sits at rd[tt * D + 4 * q] (entries that are not actions read slack or
-    // neighbours and are discarded)
-    const float* rd0 = &stage[wave][SLACK + j * CBP + (g - REM)];
-    // cooperative loads: float4 number f = m * 64 + lane of a chunk is row f / C4, float4 f % C4 of that row
-    int ld_row[NLD], ld_c4[NLD];
-    bool ld_on[NLD];
+        for (int s = 0; s < 4; ++s) {
+            const int k = 4 * g + s;
+            mA[s] = (k < O && j < O) ? a.Mp[k * CT4 + j] : 0.f;
 #pragma unroll
-    for (int m = 0; m < NLD; ++m) {
-        const int f = m * 64 + lane;
-        ld_on[m] = f < F4;
-        ld_row[m] = ld_on[m] ? f / C4 : 0;
-        ld_c4[m] = ld_on[m] ? f % C4 : 0;
+            for (int r = 0; r < REM; ++r) wR[r][s] = k < O ? a.Mp[k * CT4 + 16 + r] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < NKX; ++q) {
+            const int e = 4 * q + g;
+            const int k = e < REM ? 16 + e : O + (e - REM);
+            const bool valid = e < NX;
+            mA[4 + q] = (valid && j < O) ? a.Mp[(valid ? k : 0) * CT4 + j] : 0.f;
+#pragma unroll
+            for (int r = 0; r < REM; ++r) wR[r][4 + q] = valid ? a.Mp[(valid ? k : 0) * CT4 + 16 + r] : 0.f;
+            is_act[q] = valid && e >= REM;
+            cw[q] = is_act[q] ? a.ctrl_w : 0.f;
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) obs_init[v] = (4 * g + v < a.o) ? a.obs0[a.perm[4 * g + v]] : 0.f;
+#pragma unroll
+        for (int r = 0; r < REM; ++r) rem_init[r] = (16 + r < a.o) ? a.obs0[a.perm[16 + r]] : 0.f;
+        // cost terms that read observation columns 0 / 1 live in slot 0 only
+        pen = (a.flip_col >= 0 && g == 0) ? a.flip_pen : 0.f;
+        lin_w = g == 0 ? a.lin_w : 0.f;
+        ang_is_col1 = a.flip_col == 1;
+        ksum = a.cost_mode == 0 ? 1.f : 0.f;  // sum: acc = acc + c; final: acc = c
+        use_min = a.cost_mode == 1;
+        flip_th = a.flip_th;
     }
 
-    unsigned long long run_key = KEY_SENTINEL;
-    bool first = true;
-    const int tiles = (a.n_rows + 15) / 16;
-    // tile t of the launch belongs to wave t / gridDim.x of workgroup t % gridDim.x: a short launch thins every CU
-    for (int tile_id = wave * gridDim.x + blockIdx.x; tile_id < tiles; tile_id += WAVES * gridDim.x) {
-        const int row = tile_id * 16 + j;
-        const bool live = row < a.n_rows;
-        const float4* src[NLD];
-#pragma unroll
-        for (int m = 0; m < NLD; ++m) {
-            const int r = tile_id * 16 + ld_row[m];
-            src[m] = reinterpret_cast<const float4*>(a.actions + (size_t)(r < a.n_rows ? r : 0) * HD) + ld_c4[m];
-        }
-        float4 pre[NLD];
-#pragma unroll
-        for (int m = 0; m < NLD; ++m) pre[m] = src[m][0];
+    // this lane's read pointer into an LDS action buffer whose row of trajectory j starts at buf + SLACK + j * stride
+    __device__ __forceinline__ const float* read_ptr(const float* buf, int lane, int stride) const {
+        return buf + SLACK + (lane & 15) * stride + ((lane >> 4) - REM);
+    }
+
+    // Cost of the lane's trajectory.  Entry q of step t is read at rd0[(t % TC) * D + 4 * q]; on_chunk(ch) runs
+    // before the first step of every TC-step chunk (it refills the buffer behind rd0).
+    template <int TC, typename Chunk>
+    __device__ __forceinline__ float run(const float* rd0, Chunk&& on_chunk) const {
         f32x4 cur = obs_init;
         float xr[REM > 0 ? REM : 1];
 #pragma unroll
@@ -357,19 +330,8 @@ __global__ __launch_bounds__(64 * WAVES) void rollout16_kernel(FastRolloutArgs a
         float acc_s = 0.f, acc_b = INFINITY;
 #pragma unroll
         for (int t = 0; t < H; ++t) {
-            const int ch = t / TC, tt = t % TC;
-            if (tt == 0) {
-                // chunk ch: registers -> this wave's LDS buffer (only this wave touches it and a wave's LDS
-                // operations execute in order: no barrier), then start fetching chunk ch + 1
-#pragma unroll
-                for (int m = 0; m < NLD; ++m)
-                    if (ld_on[m]) *reinterpret_cast<float4*>(&stage[wave][SLACK + ld_row[m] * CBP + 4 * ld_c4[m]]) = pre[m];
-                if (ch + 1 < NCH) {
-#pragma unroll
-                    for (int m = 0; m < NLD; ++m) pre[m] = src[m][(ch + 1) * C4];
-                }
-            }
-            const float* rd = rd0 + tt * D;
+            if (t % TC == 0) on_chunk(t / TC);
+            const float* rd = rd0 + (t % TC) * D;
             float xv[NKX];
 #pragma unroll
             for (int q = 0; q < NKX; ++q) {
@@ -414,46 +376,219 @@ __global__ __launch_bounds__(64 * WAVES) void rollout16_kernel(FastRolloutArgs a
 #pragma unroll
             for (int r = 0; r < REM; ++r) xr[r] = act_fn(pr[r], std::integral_constant<int, KIND>{});
         }
-        const float cost = use_min ? acc_b : acc_s;
-        if (live && g == 0) a.costs[row] = cost;
-        if (a.K > 0) {
-            // lanes 0..15 carry this tile's keys, lanes 16..16+K-1 the running list: one sort
-            unsigned long long key = (g == 0 && live && row < a.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
-            if (!first) {
-                const unsigned long long prev = __shfl(run_key, lane - 16, 64);
-                if (lane >= 16 && lane < 16 + a.K) key = prev;
+        return use_min ? acc_b : acc_s;
+    }
+};
+
+// a tile's 16 keys (lanes 0..15, the rest sentinels) join the wave's running sorted top-K: lanes 16..16+K-1 carry
+// the running list, one sort
+__device__ __forceinline__ unsigned long long topk_push16(unsigned long long run_key, unsigned long long key, bool first,
+                                                          int K, int lane) {
+    if (!first) {
+        const unsigned long long prev = __shfl(run_key, lane - 16, 64);
+        if (lane >= 16 && lane < 16 + K) key = prev;
+    }
+    return wave_sort64(key, lane);
+}
+
+// one sorted list per workgroup: tree merge of the first WAVES waves' lists through LDS (`fan` lists per sort),
+// wave 0 writes list blockIdx.x.  Every thread of the workgroup must call it.
+template <int WAVES>
+__device__ __forceinline__ void wg_merge_emit(unsigned long long (*wg_keys)[WAVES][32], unsigned long long run_key, int K,
+                                              int lane, int wave, float* part_c, int* part_i) {
+    if (WAVES > 1) {
+        const int fan = 4 * K <= 64 ? 4 : 2;
+        int lists = WAVES, par = 0;
+        if (wave < WAVES && lane < K) wg_keys[0][wave][lane] = run_key;
+        __syncthreads();
+        while (lists > 1) {
+            const int f = lists < fan ? lists : fan;
+            const int out = lists / f;
+            if (wave < out) {
+                unsigned long long k2 = KEY_SENTINEL;
+                if (lane < f * K) k2 = wg_keys[par][wave * f + lane / K][lane % K];
+                run_key = wave_sort64(k2, lane);
+                if (lane < K) wg_keys[par ^ 1][wave][lane] = run_key;
             }
-            run_key = wave_sort64(key, lane);
+            __syncthreads();
+            par ^= 1;
+            lists = out;
+        }
+    }
+    if (wave == 0 && lane < K) {
+        part_c[(size_t)blockIdx.x * K + lane] = key_cost(run_key);
+        part_i[(size_t)blockIdx.x * K + lane] = key_idx(run_key);
+    }
+}
+
+template <int H, int D, int O, int KIND, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void rollout16_kernel(FastRolloutArgs a) {
+    using Tile = Tile16<H, D, O, KIND>;
+    constexpr int HD = H * D;
+    constexpr int TC = r16_chunk_steps(H, D);  // steps per action chunk
+    static_assert(TC > 0, "no 16-byte aligned action chunk for this (H, D)");
+    constexpr int CB = TC * D;                 // floats per row and chunk
+    constexpr int C4 = CB / 4;
+    constexpr int CBP = (C4 % 2) ? CB : CB + 4;  // LDS row stride: odd number of float4s
+    constexpr int NCH = H / TC;
+    constexpr int F4 = 16 * C4;                // float4s per chunk of a 16-trajectory tile
+    constexpr int NLD = (F4 + 63) / 64;        // cooperative load instructions per chunk
+    constexpr int STG = Tile::SLACK + 16 * CBP + Tile::TAIL;
+    // the tile's actions are one contiguous 16 x H x D block of HBM: the wave fetches it with full-width coalesced
+    // loads, chunk by chunk, into its own LDS buffer; each lane then reads the one or two entries it feeds to the MFMAs
+    __shared__ __attribute__((aligned(16))) float stage[WAVES][STG];
+    __shared__ unsigned long long wg_keys[2][WAVES][32];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    Tile tile;
+    tile.load(a, lane);
+    const float* rd0 = tile.read_ptr(stage[wave], lane, CBP);
+    // cooperative loads: float4 number f = m * 64 + lane of a chunk is row f / C4, float4 f % C4 of that row
+    int ld_row[NLD], ld_c4[NLD];
+    bool ld_on[NLD];
+#pragma unroll
+    for (int m = 0; m < NLD; ++m) {
+        const int f = m * 64 + lane;
+        ld_on[m] = f < F4;
+        ld_row[m] = ld_on[m] ? f / C4 : 0;
+        ld_c4[m] = ld_on[m] ? f % C4 : 0;
+    }
+
+    unsigned long long run_key = KEY_SENTINEL;
+    bool first = true;
+    const int tiles = (a.n_rows + 15) / 16;
+    // tile t of the launch belongs to wave t / gridDim.x of workgroup t % gridDim.x: a short launch thins every CU
+    for (int tile_id = wave * gridDim.x + blockIdx.x; tile_id < tiles; tile_id += WAVES * gridDim.x) {
+        const int row = tile_id * 16 + (lane & 15);
+        const bool live = row < a.n_rows;
+        const float4* src[NLD];
+#pragma unroll
+        for (int m = 0; m < NLD; ++m) {
+            const int r = tile_id * 16 + ld_row[m];
+            src[m] = reinterpret_cast<const float4*>(a.actions + (size_t)(r < a.n_rows ? r : 0) * HD) + ld_c4[m];
+        }
+        float4 pre[NLD];
+#pragma unroll
+        for (int m = 0; m < NLD; ++m) pre[m] = src[m][0];
+        const float cost = tile.template run<TC>(rd0, [&](int ch) {
+            // chunk ch: registers -> this wave's LDS buffer (only this wave touches it and a wave's LDS
+            // operations execute in order: no barrier), then start fetching chunk ch + 1
+#pragma unroll
+            for (int m = 0; m < NLD; ++m)
+                if (ld_on[m])
+                    *reinterpret_cast<float4*>(&stage[wave][Tile::SLACK + ld_row[m] * CBP + 4 * ld_c4[m]]) = pre[m];
+            if (ch + 1 < NCH) {
+#pragma unroll
+                for (int m = 0; m < NLD; ++m) pre[m] = src[m][(ch + 1) * C4];
+            }
+        });
+        if (live && lane < 16) a.costs[row] = cost;
+        if (a.K > 0) {
+            const unsigned long long key = (lane < 16 && live && row < a.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
+            run_key = topk_push16(run_key, key, first, a.K, lane);
             first = false;
         }
     }
-    if (a.K > 0) {
-        const int K = a.K;
-        if (WAVES > 1) {
-            // tree merge of the waves' lists through LDS, `fan` lists per sort
-            const int fan = 4 * K <= 64 ? 4 : 2;
-            int lists = WAVES, par = 0;
-            if (lane < K) wg_keys[0][wave][lane] = run_key;
-            __syncthreads();
-            while (lists > 1) {
-                const int f = lists < fan ? lists : fan;
-                const int out = lists / f;
-                if (wave < out) {
-                    unsigned long long k2 = KEY_SENTINEL;
-                    if (lane < f * K) k2 = wg_keys[par][wave * f + lane / K][lane % K];
-                    run_key = wave_sort64(k2, lane);
-                    if (lane < K) wg_keys[par ^ 1][wave][lane] = run_key;
-                }
-                __syncthreads();
-                par ^= 1;
-                lists = out;
+    if (a.K > 0) wg_merge_emit<WAVES>(wg_keys, run_key, a.K, lane, wave, a.part_c, a.part_i);
+}
+
+// -------------------------------------------------------------------------------------------------
+// K1 + K2 + K3 in one launch for small populations
+// -------------------------------------------------------------------------------------------------
+// With a few thousand trajectories the chip is mostly empty and an iteration is a chain of latencies: launch,
+// prologue, one thread's RNG -> DFT chain, HBM round trip of the actions, launch, prologue, 30 dependent model
+// steps.  Here a workgroup samples 16 * RW trajectories into an LDS tile (one thread per (trajectory, dim) row,
+// same code as sample_folded_kernel), writes the tile to HBM for the elite gather, and its first RW waves roll
+// the trajectories out straight from the tile (same code as rollout16_kernel): one launch, no HBM round trip.
+template <int H, int D, int O, int KIND, int ROUNDS, int RW>
+__global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64) void sample_rollout_kernel(FastIterArgs a) {
+    using Tile = Tile16<H, D, O, KIND>;
+    constexpr int HD = H * D;
+    constexpr int TPB = 16 * RW;                     // trajectories per workgroup pass
+    constexpr int ROWS = TPB * D;                    // (trajectory, dim) rows per pass, one thread each
+    constexpr int NT = ((ROWS + 63) / 64) * 64;
+    static_assert(NT <= 1024 && HD % 4 == 0, "workgroup shape");
+    __shared__ __attribute__((aligned(16))) float ms[2 * HD];  // mean | std
+    __shared__ __attribute__((aligned(16))) float tilebuf[Tile::SLACK + TPB * HD + Tile::TAIL];
+    __shared__ unsigned long long wg_keys[2][RW][32];
+    float* tile_rows = tilebuf + Tile::SLACK;
+    const FastSampleArgs& sa = a.s;
+    const FastRolloutArgs& ra = a.r;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    for (int e = tid; e < HD; e += NT) {
+        ms[e] = sa.mean[e];
+        ms[HD + e] = sa.std[e];
+    }
+    Tile tile;
+    if (wave < RW) tile.load(ra, lane);
+    const float* rd0 = tile.read_ptr(tilebuf + (wave < RW ? wave : 0) * 16 * HD, lane, HD);
+    // this thread's sampling row
+    const int nl = tid / D, jd = tid - nl * D;
+    const bool has_row = tid < ROWS;
+    const float lo = sa.low[has_row ? jd : 0], hi = sa.high[has_row ? jd : 0];
+    float* trow = tile_rows + nl * HD + jd;
+    const float* mrow = ms + jd;
+
+    unsigned long long run_key = KEY_SENTINEL;
+    bool first = true;
+    const int n_rows = ra.n_rows;  // sa.n sampled rows, then sa.n_shift shifted elites
+    const int passes = (n_rows + TPB - 1) / TPB;
+    for (int pass = blockIdx.x; pass < passes; pass += gridDim.x) {
+        const int base = pass * TPB;
+        __syncthreads();  // mean / std staged; previous pass's rollout is done with the tile
+        if (has_row) {
+            const int r = base + nl;
+            if (r < sa.n) {
+                sample_row<H, ROUNDS>(sa.W, (unsigned)(sa.first_index + r), (unsigned)jd, sa.off_lo, sa.off_hi, sa.seed_lo,
+                                      sa.seed_hi, [&](int t, float y) {
+                                          const float v = __builtin_fmaf(y, mrow[HD + t * D], mrow[t * D]);
+                                          trow[t * D] = __builtin_amdgcn_fmed3f(v, lo, hi);
+                                      });
+            } else if (r < n_rows) {
+                // shifted elite e: elites[e, 1:, j] and a last action drawn from the full (n_shift, d, h) noise batch
+                // of stream off2 (only t = h-1 is used, icem.py:102)
+                const int e = r - sa.n;
+                float last = 0.f;
+                sample_row<H, ROUNDS>(sa.W, (unsigned)e, (unsigned)jd, sa.off2_lo, sa.off2_hi, sa.seed_lo, sa.seed_hi,
+                                      [&](int t, float y) {
+                                          if (t == H - 1) {
+                                              const float v = __builtin_fmaf(y, mrow[HD + t * D], mrow[t * D]);
+                                              last = __builtin_amdgcn_fmed3f(v, lo, hi);
+                                          }
+                                      });
+                const float* src = sa.elites_src + (size_t)e * HD + jd;
+                for (int t = 0; t < H - 1; ++t) trow[t * D] = src[(t + 1) * D];
+                trow[(H - 1) * D] = last;
+            } else {
+                for (int t = 0; t < H; ++t) trow[t * D] = 0.f;  // past the end: rolled out, dropped
             }
         }
-        if (wave == 0 && lane < K) {
-            a.part_c[(size_t)blockIdx.x * K + lane] = key_cost(run_key);
-            a.part_i[(size_t)blockIdx.x * K + lane] = key_idx(run_key);
+        __syncthreads();
+        if (sa.row0_mean && sa.first_index + base == 0) {  // icem.py:87-88
+            for (int e = tid; e < HD; e += NT) tile_rows[e] = ms[e];
+            __syncthreads();
+        }
+        {   // the tile is a contiguous block of the action tensor
+            const int total4 = (n_rows - base < TPB ? n_rows - base : TPB) * (HD / 4);
+            const float4* t4 = reinterpret_cast<const float4*>(tile_rows);
+            float4* g4 = reinterpret_cast<float4*>(sa.out + (size_t)base * HD);
+            for (int e = tid; e < total4; e += NT) g4[e] = t4[e];
+        }
+        if (wave < RW) {
+            const int row = base + wave * 16 + (lane & 15);
+            const bool live = row < n_rows;
+            const float cost = tile.template run<H>(rd0, [](int) {});
+            if (live && lane < 16) ra.costs[row] = cost;
+            if (ra.K > 0) {
+                const unsigned long long key = (lane < 16 && live && row < ra.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
+                run_key = topk_push16(run_key, key, first, ra.K, lane);
+                first = false;
+            }
         }
     }
+    if (ra.K > 0) wg_merge_emit<RW>(wg_keys, run_key, ra.K, lane, wave, ra.part_c, ra.part_i);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -685,6 +820,50 @@ void launch_rollout16(const FastRolloutArgs& a, int h, int d, int O, int kind, h
         XW(HH, DD, OO, 4)                \
         XW(HH, DD, OO, 8)                \
         XW(HH, DD, OO, 16)               \
+    }
+    ICEM_FAST_SHAPES(XR)
+#undef XR
+#undef XW
+}
+
+// single-launch iteration: compiled for the default generator (10 Philox rounds) and up to 8 rollout waves per
+// workgroup.  sample_rollout_lists: workgroups (= candidate lists) of the launch, 0 when the shape or size is
+// outside that (use the two-kernel path).
+static bool sample_rollout_shape(int h, int d, int O, int rounds, int n_rows, int* grid_out, int* rw_out) {
+    static const int max_rw = [] { const char* e = getenv("ICEM_FUSE_MAX_RW"); return e ? atoi(e) : 8; }();
+    int grid, rw;
+    r16_shape(n_rows, &grid, &rw);
+    if (rounds != 10 || rw > max_rw || n_rows <= 0 || !fast_rollout_supported(h, d, O, 1) || !fast_sample_supported(h, d))
+        return false;
+    if (rw > 8) rw = 8;  // several passes per workgroup
+    *grid_out = std::min(grid, (n_rows + 16 * rw - 1) / (16 * rw));
+    *rw_out = rw;
+    return true;
+}
+
+int sample_rollout_lists(int h, int d, int O, int rounds, int n_rows) {
+    int grid, rw;
+    return sample_rollout_shape(h, d, O, rounds, n_rows, &grid, &rw) ? grid : 0;
+}
+
+void launch_sample_rollout(const FastIterArgs& a, int h, int d, int O, int kind, hipStream_t st) {
+    int grid, rw;
+    if (!sample_rollout_shape(h, d, O, 10, a.r.n_rows, &grid, &rw)) return;
+#define XW(HH, DD, OO, WW)                                                                                           \
+    if (rw == WW) {                                                                                                  \
+        constexpr int NT = ((16 * WW * DD + 63) / 64) * 64;                                                          \
+        if (kind == 1)                                                                                               \
+            hipLaunchKernelGGL((sample_rollout_kernel<HH, DD, OO, 1, 10, WW>), dim3(grid), dim3(NT), 0, st, a);      \
+        else                                                                                                         \
+            hipLaunchKernelGGL((sample_rollout_kernel<HH, DD, OO, 0, 10, WW>), dim3(grid), dim3(NT), 0, st, a);      \
+        return;                                                                                                      \
+    }
+#define XR(HH, DD, OO)                   \
+    if (h == HH && d == DD && O == OO) { \
+        XW(HH, DD, OO, 1)                \
+        XW(HH, DD, OO, 2)                \
+        XW(HH, DD, OO, 4)                \
+        XW(HH, DD, OO, 8)                \
     }
     ICEM_FAST_SHAPES(XR)
 #undef XR

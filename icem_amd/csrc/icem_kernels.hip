@@ -878,11 +878,8 @@ bool fast_rollout_ok(const icem_handle* h, int K) {
            fast_rollout_supported(h->cfg.horizon, h->cfg.act_dim, h->O, K);
 }
 
-// rows -> costs (+ per-wave sorted candidates when K > 0); returns the number of candidate lists
-int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const void* obs0, const void* actions,
-                        void* costs, float* part_c, int* part_i, hipStream_t st, int* lists_out) {
-    int rc = ensure_fast_model(h);
-    if (rc) return rc;
+FastRolloutArgs fast_rollout_args(const icem_handle* h, int n_rows, int n_cand, int K, const void* obs0,
+                                  const void* actions, void* costs, float* part_c, int* part_i) {
     FastRolloutArgs a;
     a.n_rows = n_rows;
     a.n_cand = n_cand;
@@ -902,6 +899,15 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
     a.part_c = part_c;
     a.part_i = part_i;
     a.dbg = h->dbg;
+    return a;
+}
+
+// rows -> costs (+ one sorted candidate list per workgroup when K > 0); returns the number of candidate lists
+int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const void* obs0, const void* actions,
+                        void* costs, float* part_c, int* part_i, hipStream_t st, int* lists_out) {
+    int rc = ensure_fast_model(h);
+    if (rc) return rc;
+    const FastRolloutArgs a = fast_rollout_args(h, n_rows, n_cand, K, obs0, actions, costs, part_c, part_i);
     const int grid = rollout_lists(h->cfg.horizon, h->cfg.act_dim, h->O, n_rows);
     {
         ProfScope prof(h, ICEM_K_ROLLOUT, (long long)n_rows * h->cfg.horizon, st);
@@ -916,10 +922,9 @@ bool fast_sample_ok(const icem_handle* h) {
     return h->use_fast && h->cfg.dtype == ICEM_F32 && fast_sample_supported(h->cfg.horizon, h->cfg.act_dim);
 }
 
-int launch_fast_sample(const icem_handle* h, int n, long long first_index, const void* mean, const void* std,
-                       const void* low, const void* high, uint64_t offset, int row0_mean, void* out, hipStream_t st,
-                       int n_shift = 0, const void* elites_src = nullptr, uint64_t offset2 = 0) {
-    if (n <= 0 && n_shift <= 0) return ICEM_OK;
+FastSampleArgs fast_sample_args(const icem_handle* h, int n, long long first_index, const void* mean, const void* std,
+                                const void* low, const void* high, uint64_t offset, int row0_mean, void* out,
+                                int n_shift, const void* elites_src, uint64_t offset2) {
     FastSampleArgs a;
     a.n = n;
     a.h = h->cfg.horizon;
@@ -940,6 +945,15 @@ int launch_fast_sample(const icem_handle* h, int n, long long first_index, const
     a.elites_src = (const float*)elites_src;
     a.off2_lo = (uint32_t)offset2;
     a.off2_hi = (uint32_t)(offset2 >> 32);
+    return a;
+}
+
+int launch_fast_sample(const icem_handle* h, int n, long long first_index, const void* mean, const void* std,
+                       const void* low, const void* high, uint64_t offset, int row0_mean, void* out, hipStream_t st,
+                       int n_shift = 0, const void* elites_src = nullptr, uint64_t offset2 = 0) {
+    if (n <= 0 && n_shift <= 0) return ICEM_OK;
+    const FastSampleArgs a = fast_sample_args(h, n, first_index, mean, std, low, high, offset, row0_mean, out, n_shift,
+                                              elites_src, offset2);
     {
         ProfScope prof(h, ICEM_K_SAMPLE, (long long)n * a.h, st);
         launch_sample_folded(a, h->cfg.rng_rounds, st);
@@ -995,19 +1009,36 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
             float* pc;
             int* pi;
             const int n_rows = n_loc + n_extra;
-            if (fast_sample_ok(h)) {
-                rc = launch_fast_sample(h, n_loc, lo, b->mean, b->std, b->low, b->high, off, row0, actions, st,
+            const int one = (fast_sample_ok(h) && (n_extra == 0 || shift_in_sampler))
+                                ? sample_rollout_lists(c.horizon, c.act_dim, h->O, c.rng_rounds, n_rows) : 0;
+            // the merge finds the lists' indices behind `lists * K` costs
+            split_partial_ws<float>(b->workspace, one > 0 ? one : rollout_lists(c.horizon, c.act_dim, h->O, n_rows), K, &pc, &pi);
+            if (one > 0) {
+                // small populations: sample + rollout + top-K in one launch
+                FastIterArgs fa;
+                fa.s = fast_sample_args(h, n_loc, lo, b->mean, b->std, b->low, b->high, off, row0, actions,
                                         shift_in_sampler ? n_extra : 0, shift_src, call_base + (uint64_t)c.opt_iters);
-            } else {
-                SampleArgs<T> a = make_sample_args<T>(h, n_loc, lo, b->mean, b->std, b->low, b->high, nullptr, nullptr,
-                                                      off, 0, row0, actions);
-                rc = launch_sample<T>(h, a, st);
+                fa.r = fast_rollout_args(h, n_rows, n_cand, K, b->obs0, actions, b->costs, pc, pi);
+                {
+                    ProfScope prof(h, ICEM_K_SAMPLE_ROLLOUT, (long long)n_rows * c.horizon, st);
+                    launch_sample_rollout(fa, c.horizon, c.act_dim, h->O, h->model_kind, st);
+                }
+                ICEM_HIP_TRY(hipGetLastError());
+                lists = one;
             }
-            if (rc) return rc;
-            const int grid = rollout_lists(c.horizon, c.act_dim, h->O, n_rows);
-            split_partial_ws<float>(b->workspace, grid, K, &pc, &pi);
-            rc = launch_fast_rollout(h, n_rows, n_cand, K, b->obs0, actions, b->costs, pc, pi, st, &lists);
-            if (rc) return rc;
+            if (one == 0) {
+                if (fast_sample_ok(h)) {
+                    rc = launch_fast_sample(h, n_loc, lo, b->mean, b->std, b->low, b->high, off, row0, actions, st,
+                                            shift_in_sampler ? n_extra : 0, shift_src, call_base + (uint64_t)c.opt_iters);
+                } else {
+                    SampleArgs<T> a = make_sample_args<T>(h, n_loc, lo, b->mean, b->std, b->low, b->high, nullptr, nullptr,
+                                                          off, 0, row0, actions);
+                    rc = launch_sample<T>(h, a, st);
+                }
+                if (rc) return rc;
+                rc = launch_fast_rollout(h, n_rows, n_cand, K, b->obs0, actions, b->costs, pc, pi, st, &lists);
+                if (rc) return rc;
+            }
             h->fast_lists = lists;
             if (c.world > 1) {
                 ProfScope prof(h, ICEM_K_LOCAL_PACK, lists * K, st);

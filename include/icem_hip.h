@@ -217,12 +217,13 @@ int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step,
 
 /* ---- per-kernel timing (measurement only) ------------------------------------------------- */
 enum {
-    ICEM_K_SAMPLE = 0, ICEM_K_ROLLOUT, ICEM_K_TOPK_PARTIAL, ICEM_K_LOCAL_PACK, ICEM_K_MERGE_REFIT, ICEM_K_COUNT
+    ICEM_K_SAMPLE = 0, ICEM_K_ROLLOUT, ICEM_K_TOPK_PARTIAL, ICEM_K_LOCAL_PACK, ICEM_K_MERGE_REFIT,
+    ICEM_K_SAMPLE_ROLLOUT, ICEM_K_COUNT
 };
 /* While enabled, every kernel launch of this handle is bracketed by hipEventRecord on the
  * caller's stream.  icem_profile_read synchronises those events, returns per kernel class the
  * summed duration [ms], the number of launches and the units processed (traj-steps for
- * SAMPLE/ROLLOUT, keys for the top-k kernels), and clears the log. */
+ * SAMPLE/ROLLOUT/SAMPLE_ROLLOUT, keys for the top-k kernels), and clears the log. */
 int icem_profile_enable(icem_handle* h, int32_t on);
 /* Development aid: [grid, 8] int64 device buffer a kernel under study may fill with per-workgroup phase
  * cycle stamps (NULL disables; no production kernel writes it). */

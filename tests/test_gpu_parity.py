@@ -660,9 +660,9 @@ def test_fast_path_edge_populations(N, K, iters, keep, shift, use_mean):
 
 
 @pytest.mark.parametrize("h,d,o,kind,mode", [(30, 6, 18, 1, "best"), (12, 6, 17, 0, "final"), (13, 4, 17, 1, "sum")])
-def test_large_tile_count_uses_wave_per_tile_rollout(h, d, o, kind, mode):
-    """More than 256 tiles: the one-wave-per-tile matrix-pipe kernel (4 waves per workgroup, running top-K across
-    tiles, workgroup list merge) instead of the quad kernel; costs and the sorted top-K against the oracle."""
+def test_many_tiles_per_workgroup(h, d, o, kind, mode):
+    """N = 16453: more 16-trajectory tiles than candidate lists, so workgroups hold 8 rollout waves, the last pass
+    is ragged and the workgroup list merge runs; costs and the sorted top-K against the oracle."""
     from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner
     N = 64 * 257 + 5
     low, high = -np.ones(d), np.ones(d)
