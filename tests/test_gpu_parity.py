@@ -659,12 +659,13 @@ def test_fast_path_edge_populations(N, K, iters, keep, shift, use_mean):
     np.testing.assert_allclose(np_(pl.std), orc.std, rtol=5e-4, atol=5e-5)
 
 
-@pytest.mark.parametrize("h,d,o,kind,mode", [(30, 6, 18, 1, "best"), (12, 6, 17, 0, "final"), (13, 4, 17, 1, "sum")])
-def test_many_tiles_per_workgroup(h, d, o, kind, mode):
-    """N = 16453: more 16-trajectory tiles than candidate lists, so workgroups hold 8 rollout waves, the last pass
-    is ragged and the workgroup list merge runs; costs and the sorted top-K against the oracle."""
+@pytest.mark.parametrize("h,d,o,kind,mode,N", [(30, 6, 18, 1, "best", 16453), (12, 6, 17, 0, "final", 5001),
+                                               (13, 4, 17, 1, "sum", 12003), (30, 6, 17, 0, "sum", 33001)])
+def test_many_tiles_per_workgroup(h, d, o, kind, mode, N):
+    """More 16-trajectory tiles than candidate lists: workgroups hold 2, 4 or 8 rollout waves (single-launch kernel)
+    or 16 (N = 33001: sampler + rollout kernels), the last pass is ragged and the workgroup list merge runs.
+    Samples bit-equal to the stand-alone sampler's, costs and the sorted top-K against the oracle."""
     from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner
-    N = 64 * 257 + 5
     low, high = -np.ones(d), np.ones(d)
     model = DeviceSyntheticModel.make(o, d, kind=kind)
     spec = O.CostSpec(0.1, 5, -1.0, 5, 10.0, 0.05)  # lin and flip on the same column
@@ -674,13 +675,15 @@ def test_many_tiles_per_workgroup(h, d, o, kind, mode):
     pl.set_cost(spec.ctrl_weight, spec.lin_idx, spec.lin_weight, spec.flip_idx, spec.flip_penalty, spec.flip_thresh)
     pl.reset()
     obs0 = 0.3 * np.random.RandomState(1).randn(o)
-    mean0, std0 = np_(pl.mean), np_(pl.std)
+    mean0, std0 = pl.mean.clone(), pl.std.clone()
     pl.plan_step(obs0)
     act = np_(pl.actions[:N])
     costs = np_(pl.costs[:N])
+    assert np.array_equal(act, np_(pl.sample_clip(N, mean0, std0, offset=0)))
     om = O.SyntheticModel(model.A, model.B, kind)
     ref = O.rollout_costs(om, spec, obs0, act, mode=mode)
     np.testing.assert_allclose(costs, ref, rtol=2e-5, atol=5e-5)
+    assert np.array_equal(costs, np_(pl.rollout_cost(obs0, pl.actions[:N])))  # same bits as the stand-alone rollout
     idx = O.topk_sorted(pl.costs[:N].cpu().numpy(), pl.K)
     ea, ec = pl.current_elites()
     assert np.array_equal(np_(ec), costs[idx]) and np.array_equal(np_(ea), act[idx])
