@@ -44,8 +44,9 @@ struct FastRolloutArgs {
     int flip_col;       // column holding obs[flip_idx] after the permutation, -1 = no flip term
     const float* actions;
     float* costs;
-    float* part_c;  // [grid, K]
+    float* part_c;  // [grid, K] sorted candidate costs / row indices of every workgroup ...
     int* part_i;
+    unsigned long long* part_k;  // ... or, if not null, their packed keys, key r of workgroup w at [r * grid + w]
     long long* dbg;  // development: [waves, 8] cycle stamps, nullptr in production
 };
 bool fast_rollout_supported(int h, int d, int O, int K);
@@ -71,8 +72,7 @@ struct MergeSingleArgs {
     int n_global;  // N_it: index offset of shifted (it == 0) or kept (it > 0) elites
     int K, h, d, last;
     float alpha, init_std;
-    const float* part_c;
-    const int* part_i;
+    const unsigned long long* part_k;  // [K, n_lists] packed candidate keys (FastRolloutArgs::part_k)
     const float* actions;
     const float* elites_cur;
     const float* elites_cost_cur;
@@ -84,6 +84,7 @@ struct MergeSingleArgs {
     const float* high;
     float* executed;
     float* best_cost;
+    long long* dbg;  // development: 8 wall_clock64 stamps (100 MHz) of thread 0, nullptr in production
 };
 void launch_merge_single(const MergeSingleArgs& a, hipStream_t st);
 

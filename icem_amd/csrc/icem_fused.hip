@@ -52,7 +52,7 @@ __device__ __forceinline__ int key_idx(unsigned long long k) { return (int)(unsi
 constexpr unsigned long long KEY_SENTINEL = 0xFF8000007FFFFFFFull;  // (+inf, INT_MAX)
 
 // value of lane (lane ^ J): DPP inside a row of 16 lanes (quad permutes for 1 / 2, row rotations for
-// 4 / 8), LDS-crossbar shuffle only across rows (16 / 32)
+// 4 / 8), v_permlane16/32_swap across rows (16 / 32): no LDS-crossbar shuffles
 template <int CTRL>
 __device__ __forceinline__ unsigned long long dpp_u64(unsigned long long x) {
     const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)x, CTRL, 0xF, 0xF, false);
@@ -71,8 +71,21 @@ __device__ __forceinline__ unsigned long long xor_partner(unsigned long long k, 
         return (lane & 4) ? down : up;
     } else if constexpr (J == 8) {
         return dpp_u64<0x128>(k);  // row_ror:8
+    } else if constexpr (J == 16) {
+        // v_permlane16_swap(a = x, b = x): a <- [x.row0, x.row0, x.row2, x.row2], b <- [x.row1, x.row1, x.row3, x.row3]
+        const unsigned lo = (unsigned)k, hi = (unsigned)(k >> 32);
+        auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        const bool odd = (lane & 16) != 0;
+        return ((unsigned long long)(odd ? h[0] : h[1]) << 32) | (odd ? l[0] : l[1]);
     } else {
-        return __shfl_xor(k, J, 64);
+        static_assert(J == 32, "xor distance");
+        // v_permlane32_swap(a = x, b = x): a <- [x.rows01, x.rows01], b <- [x.rows23, x.rows23]
+        const unsigned lo = (unsigned)k, hi = (unsigned)(k >> 32);
+        auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        const bool upper = (lane & 32) != 0;
+        return ((unsigned long long)(upper ? h[0] : h[1]) << 32) | (upper ? l[0] : l[1]);
     }
 }
 
@@ -258,7 +271,7 @@ __host__ __device__ constexpr int r16_chunk_steps(int h, int d) {
     return best;
 }
 
-// Everything a wavefront needs to roll 16 trajectories out; run() is shared by the stand-alone rollout kernel
+// Everything a wavefront needs to roll 16 trajectories out; step() is shared by the stand-alone rollout kernel
 // and the sample+rollout kernel, so both produce the same bits for the same actions.
 template <int H, int D, int O, int KIND>
 struct Tile16 {
@@ -319,65 +332,66 @@ struct Tile16 {
         return buf + SLACK + (lane & 15) * stride + ((lane >> 4) - REM);
     }
 
-    // Cost of the lane's trajectory.  Entry q of step t is read at rd0[(t % TC) * D + 4 * q]; on_chunk(ch) runs
-    // before the first step of every TC-step chunk (it refills the buffer behind rd0).
-    template <int TC, typename Chunk>
-    __device__ __forceinline__ float run(const float* rd0, Chunk&& on_chunk) const {
-        f32x4 cur = obs_init;
+    // Rollout state of the lane's trajectory share.  Kernels drive it with their own (unrolled) time loop:
+    // init, H x step(rd) with entry q of the step's actions at rd[4 * q], then cost().
+    struct State {
+        f32x4 cur;
         float xr[REM > 0 ? REM : 1];
+        float acc_s, acc_b;
+    };
+    __device__ __forceinline__ void init(State& st) const {
+        st.cur = obs_init;
 #pragma unroll
-        for (int r = 0; r < REM; ++r) xr[r] = rem_init[r];
-        float acc_s = 0.f, acc_b = INFINITY;
-#pragma unroll
-        for (int t = 0; t < H; ++t) {
-            if (t % TC == 0) on_chunk(t / TC);
-            const float* rd = rd0 + (t % TC) * D;
-            float xv[NKX];
-#pragma unroll
-            for (int q = 0; q < NKX; ++q) {
-                const float ld = rd[4 * q];
-                float v = is_act[q] ? ld : 0.f;
-#pragma unroll
-                for (int r = 0; r < REM; ++r)
-                    if (r / 4 == q) v = (g == r % 4) ? xr[r] : v;
-                xv[q] = v;
-            }
-            // step cost: this lane's share, then the sum over the trajectory's 4 lanes
-            const float ang = ang_is_col1 ? cur[1] : cur[0];
-            float c = 0.f;
-            c += (ang > flip_th) ? pen : 0.f;
-            c += (ang < -flip_th) ? pen : 0.f;
-#pragma unroll
-            for (int q = 0; q < NKX; ++q) c = __builtin_fmaf(xv[q] * xv[q], cw[q], c);
-            c = __builtin_fmaf(lin_w, cur[0], c);
-            float pr[REM > 0 ? REM : 1];
-#pragma unroll
-            for (int r = 0; r < REM; ++r) {
-                float p = 0.f;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) p = __builtin_fmaf(cur[s], wR[r][s], p);
-#pragma unroll
-                for (int q = 0; q < NKX; ++q) p = __builtin_fmaf(xv[q], wR[r][4 + q], p);
-                pr[r] = p;
-            }
-            c = reduce_groups(c);
-#pragma unroll
-            for (int r = 0; r < REM; ++r) pr[r] = reduce_groups(pr[r]);
-            acc_s = __builtin_fmaf(acc_s, ksum, c);
-            acc_b = c < acc_b ? c : acc_b;
-            // model step on the matrix pipe
-            f32x4 nxt = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) nxt = __builtin_amdgcn_mfma_f32_16x16x4f32(mA[s], cur[s], nxt, 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < NKX; ++q) nxt = __builtin_amdgcn_mfma_f32_16x16x4f32(mA[4 + q], xv[q], nxt, 0, 0, 0);
-#pragma unroll
-            for (int v = 0; v < 4; ++v) cur[v] = act_fn(nxt[v], std::integral_constant<int, KIND>{});
-#pragma unroll
-            for (int r = 0; r < REM; ++r) xr[r] = act_fn(pr[r], std::integral_constant<int, KIND>{});
-        }
-        return use_min ? acc_b : acc_s;
+        for (int r = 0; r < REM; ++r) st.xr[r] = rem_init[r];
+        st.acc_s = 0.f;
+        st.acc_b = INFINITY;
     }
+    __device__ __forceinline__ void step(State& st, const float* rd) const {
+        float xv[NKX];
+#pragma unroll
+        for (int q = 0; q < NKX; ++q) {
+            const float ld = rd[4 * q];
+            float v = is_act[q] ? ld : 0.f;
+#pragma unroll
+            for (int r = 0; r < REM; ++r)
+                if (r / 4 == q) v = (g == r % 4) ? st.xr[r] : v;
+            xv[q] = v;
+        }
+        // step cost: this lane's share, then the sum over the trajectory's 4 lanes
+        const float ang = ang_is_col1 ? st.cur[1] : st.cur[0];
+        float c = 0.f;
+        c += (ang > flip_th) ? pen : 0.f;
+        c += (ang < -flip_th) ? pen : 0.f;
+#pragma unroll
+        for (int q = 0; q < NKX; ++q) c = __builtin_fmaf(xv[q] * xv[q], cw[q], c);
+        c = __builtin_fmaf(lin_w, st.cur[0], c);
+        float pr[REM > 0 ? REM : 1];
+#pragma unroll
+        for (int r = 0; r < REM; ++r) {
+            float p = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) p = __builtin_fmaf(st.cur[s], wR[r][s], p);
+#pragma unroll
+            for (int q = 0; q < NKX; ++q) p = __builtin_fmaf(xv[q], wR[r][4 + q], p);
+            pr[r] = p;
+        }
+        c = reduce_groups(c);
+#pragma unroll
+        for (int r = 0; r < REM; ++r) pr[r] = reduce_groups(pr[r]);
+        st.acc_s = __builtin_fmaf(st.acc_s, ksum, c);
+        st.acc_b = c < st.acc_b ? c : st.acc_b;
+        // model step on the matrix pipe
+        f32x4 nxt = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) nxt = __builtin_amdgcn_mfma_f32_16x16x4f32(mA[s], st.cur[s], nxt, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NKX; ++q) nxt = __builtin_amdgcn_mfma_f32_16x16x4f32(mA[4 + q], xv[q], nxt, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) st.cur[v] = act_fn(nxt[v], std::integral_constant<int, KIND>{});
+#pragma unroll
+        for (int r = 0; r < REM; ++r) st.xr[r] = act_fn(pr[r], std::integral_constant<int, KIND>{});
+    }
+    __device__ __forceinline__ float cost(const State& st) const { return use_min ? st.acc_b : st.acc_s; }
 };
 
 // a tile's 16 keys (lanes 0..15, the rest sentinels) join the wave's running sorted top-K: lanes 16..16+K-1 carry
@@ -395,7 +409,7 @@ __device__ __forceinline__ unsigned long long topk_push16(unsigned long long run
 // wave 0 writes list blockIdx.x.  Every thread of the workgroup must call it.
 template <int WAVES>
 __device__ __forceinline__ void wg_merge_emit(unsigned long long (*wg_keys)[WAVES][32], unsigned long long run_key, int K,
-                                              int lane, int wave, float* part_c, int* part_i) {
+                                              int lane, int wave, const FastRolloutArgs& a) {
     if (WAVES > 1) {
         const int fan = 4 * K <= 64 ? 4 : 2;
         int lists = WAVES, par = 0;
@@ -416,8 +430,12 @@ __device__ __forceinline__ void wg_merge_emit(unsigned long long (*wg_keys)[WAVE
         }
     }
     if (wave == 0 && lane < K) {
-        part_c[(size_t)blockIdx.x * K + lane] = key_cost(run_key);
-        part_i[(size_t)blockIdx.x * K + lane] = key_idx(run_key);
+        if (a.part_k) {
+            a.part_k[(size_t)lane * gridDim.x + blockIdx.x] = run_key;
+        } else {
+            a.part_c[(size_t)blockIdx.x * K + lane] = key_cost(run_key);
+            a.part_i[(size_t)blockIdx.x * K + lane] = key_idx(run_key);
+        }
     }
 }
 
@@ -470,18 +488,25 @@ __global__ __launch_bounds__(64 * WAVES) void rollout16_kernel(FastRolloutArgs a
         float4 pre[NLD];
 #pragma unroll
         for (int m = 0; m < NLD; ++m) pre[m] = src[m][0];
-        const float cost = tile.template run<TC>(rd0, [&](int ch) {
-            // chunk ch: registers -> this wave's LDS buffer (only this wave touches it and a wave's LDS
-            // operations execute in order: no barrier), then start fetching chunk ch + 1
+        typename Tile::State st;
+        tile.init(st);
 #pragma unroll
-            for (int m = 0; m < NLD; ++m)
-                if (ld_on[m])
-                    *reinterpret_cast<float4*>(&stage[wave][Tile::SLACK + ld_row[m] * CBP + 4 * ld_c4[m]]) = pre[m];
-            if (ch + 1 < NCH) {
+        for (int t = 0; t < H; ++t) {
+            if (t % TC == 0) {
+                // next chunk: registers -> this wave's LDS buffer (only this wave touches it and a wave's LDS
+                // operations execute in order: no barrier), then start fetching the one after
 #pragma unroll
-                for (int m = 0; m < NLD; ++m) pre[m] = src[m][(ch + 1) * C4];
+                for (int m = 0; m < NLD; ++m)
+                    if (ld_on[m])
+                        *reinterpret_cast<float4*>(&stage[wave][Tile::SLACK + ld_row[m] * CBP + 4 * ld_c4[m]]) = pre[m];
+                if (t / TC + 1 < NCH) {
+#pragma unroll
+                    for (int m = 0; m < NLD; ++m) pre[m] = src[m][(t / TC + 1) * C4];
+                }
             }
-        });
+            tile.step(st, rd0 + (t % TC) * D);
+        }
+        const float cost = tile.cost(st);
         if (live && lane < 16) a.costs[row] = cost;
         if (a.K > 0) {
             const unsigned long long key = (lane < 16 && live && row < a.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
@@ -489,7 +514,7 @@ __global__ __launch_bounds__(64 * WAVES) void rollout16_kernel(FastRolloutArgs a
             first = false;
         }
     }
-    if (a.K > 0) wg_merge_emit<WAVES>(wg_keys, run_key, a.K, lane, wave, a.part_c, a.part_i);
+    if (a.K > 0) wg_merge_emit<WAVES>(wg_keys, run_key, a.K, lane, wave, a);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -517,6 +542,7 @@ __global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64) void sample_rollout
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[8] = wall_clock64();
     for (int e = tid; e < HD; e += NT) {
         ms[e] = sa.mean[e];
         ms[HD + e] = sa.std[e];
@@ -538,6 +564,7 @@ __global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64) void sample_rollout
     for (int pass = blockIdx.x; pass < passes; pass += gridDim.x) {
         const int base = pass * TPB;
         __syncthreads();  // mean / std staged; previous pass's rollout is done with the tile
+        if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[9] = wall_clock64();
         if (has_row) {
             const int r = base + nl;
             if (r < sa.n) {
@@ -565,6 +592,7 @@ __global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64) void sample_rollout
                 for (int t = 0; t < H; ++t) trow[t * D] = 0.f;  // past the end: rolled out, dropped
             }
         }
+        if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[10] = wall_clock64();
         __syncthreads();
         if (sa.row0_mean && sa.first_index + base == 0) {  // icem.py:87-88
             for (int e = tid; e < HD; e += NT) tile_rows[e] = ms[e];
@@ -576,10 +604,16 @@ __global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64) void sample_rollout
             float4* g4 = reinterpret_cast<float4*>(sa.out + (size_t)base * HD);
             for (int e = tid; e < total4; e += NT) g4[e] = t4[e];
         }
+        if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[11] = wall_clock64();
         if (wave < RW) {
             const int row = base + wave * 16 + (lane & 15);
             const bool live = row < n_rows;
-            const float cost = tile.template run<H>(rd0, [](int) {});
+            typename Tile::State st;
+            tile.init(st);
+#pragma unroll
+            for (int t = 0; t < H; ++t) tile.step(st, rd0 + t * D);
+            const float cost = tile.cost(st);
+            if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[12] = wall_clock64();
             if (live && lane < 16) ra.costs[row] = cost;
             if (ra.K > 0) {
                 const unsigned long long key = (lane < 16 && live && row < ra.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
@@ -588,7 +622,9 @@ __global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64) void sample_rollout
             }
         }
     }
-    if (ra.K > 0) wg_merge_emit<RW>(wg_keys, run_key, ra.K, lane, wave, ra.part_c, ra.part_i);
+    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[13] = wall_clock64();
+    if (ra.K > 0) wg_merge_emit<RW>(wg_keys, run_key, ra.K, lane, wave, ra);
+    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[14] = wall_clock64();
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -621,16 +657,32 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long x)
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// inclusive prefix sum over the 64 lanes: Hillis-Steele inside each row of 16 (row_shr 1, 2, 4, 8, zero fill), then
+// row_bcast:15 into rows 1 / 3 and row_bcast:31 into rows 2 / 3
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned add_dpp(unsigned x) {
+    return x + (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
+}
+__device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned x) {
+    x = add_dpp<0x111, 0xF>(x);
+    x = add_dpp<0x112, 0xF>(x);
+    x = add_dpp<0x114, 0xF>(x);
+    x = add_dpp<0x118, 0xF>(x);
+    x = add_dpp<0x142, 0xA>(x);
+    x = add_dpp<0x143, 0xC>(x);
+    return x;
+}
+
 template <int KREG>
 __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs a) {
     __shared__ unsigned long long sel[64];
-    __shared__ unsigned cand_n;
     __shared__ unsigned long long cand[64];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* new_mean = reinterpret_cast<float*>(smem_raw);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int hd = a.h * a.d;
+    if (a.dbg && threadIdx.x == 0) a.dbg[0] = wall_clock64();
     // old mean/std of this thread's elements: issued now, consumed after the selection
     constexpr int EPL = 4;
     const bool pre = hd <= MERGE_WG * EPL;
@@ -641,36 +693,24 @@ __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs 
         om[i] = (pre && e < hd) ? a.mean[e] : 0.f;
         os[i] = (pre && e < hd) ? a.std[e] : 0.f;
     }
-    if (tid == 0) cand_n = 0;
     if (tid < 64) {
-        // ---- wave 0: lane t owns candidate lists t, t+64, t+128, t+192 (each sorted) in registers ----
+        // ---- wave 0: lane t owns candidate lists t, t+64, t+128, t+192 (each sorted) in registers; key r of list w
+        // sits at part_k[r * n_lists + w]: every load is one contiguous 512 bytes ----
         unsigned long long k[LPL][KREG];
-        {
-            // all loads issued up front from clamped (always valid) addresses, selected afterwards
-            int idxs[LPL][KREG];
-            float cs[LPL][KREG];
 #pragma unroll
-            for (int l = 0; l < LPL; ++l) {
-                const int list = lane + l * 64;
-                const size_t base = (size_t)(list < a.n_lists ? list : 0) * a.K;
+        for (int l = 0; l < LPL; ++l) {
+            const int list = lane + l * 64;
 #pragma unroll
-                for (int i = 0; i < KREG; ++i) {
-                    const int ii = i < a.K ? i : 0;
-                    idxs[l][i] = a.part_i[base + ii];
-                    cs[l][i] = a.part_c[base + ii];
-                }
-            }
-#pragma unroll
-            for (int l = 0; l < LPL; ++l) {
-                const bool has_list = lane + l * 64 < a.n_lists;
-#pragma unroll
-                for (int i = 0; i < KREG; ++i) {
-                    const bool ok = has_list && i < a.K && idxs[l][i] != INT_MAX;
-                    const unsigned long long v = make_key(cs[l][i], idxs[l][i]);
-                    k[l][i] = ok ? v : KEY_SENTINEL;
-                }
-            }
+            for (int i = 0; i < KREG; ++i)
+                k[l][i] = a.part_k[(size_t)(i < a.K ? i : 0) * a.n_lists + (list < a.n_lists ? list : 0)];
         }
+#pragma unroll
+        for (int l = 0; l < LPL; ++l) {
+            const bool has_list = lane + l * 64 < a.n_lists;
+#pragma unroll
+            for (int i = 0; i < KREG; ++i) k[l][i] = (has_list && i < a.K) ? k[l][i] : KEY_SENTINEL;
+        }
+        if (a.dbg && threadIdx.x == 0) a.dbg[1] = wall_clock64();
         if (lane < a.n_keep) {  // kept elite `lane` (icem.py:143-145) joins this lane's first list, order preserved
             unsigned long long v = make_key(a.elites_cost_cur[lane], a.n_global + lane);
 #pragma unroll
@@ -684,23 +724,33 @@ __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs 
         // selection by threshold: the K-th smallest of the 64 lane minima bounds the K-th smallest key overall,
         // so the global top-K is among the keys <= T; those (usually K..2K of them) are compacted into one key
         // per lane and sorted.  Two 64-key sorts instead of K dependent tournament rounds.
+        if (a.dbg && threadIdx.x == 0) a.dbg[2] = wall_clock64();
         unsigned long long mine = k[0][0];
 #pragma unroll
         for (int l = 1; l < LPL; ++l) mine = k[l][0] < mine ? k[l][0] : mine;
         const unsigned long long srt = wave_sort64(mine, lane);
         const unsigned long long T = __shfl(srt, a.K - 1, 64);
+        // compaction: every lane counts its keys <= T, an exclusive DPP scan over the lanes gives it a slot range
+        unsigned mine_n = 0;
+#pragma unroll
+        for (int l = 0; l < LPL; ++l)
+#pragma unroll
+            for (int i = 0; i < KREG; ++i) mine_n += (k[l][i] <= T && k[l][i] != KEY_SENTINEL) ? 1u : 0u;
+        const unsigned incl = wave_incl_scan_u32(mine_n);
+        const unsigned n_cand = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+        unsigned pos = incl - mine_n;
 #pragma unroll
         for (int l = 0; l < LPL; ++l) {
 #pragma unroll
             for (int i = 0; i < KREG; ++i) {
                 if (k[l][i] <= T && k[l][i] != KEY_SENTINEL) {
-                    const unsigned slot = atomicAdd(&cand_n, 1u);
-                    if (slot < 64) cand[slot] = k[l][i];
+                    if (pos < 64) cand[pos] = k[l][i];
+                    ++pos;
                 }
             }
         }
+        if (a.dbg && threadIdx.x == 0) a.dbg[3] = wall_clock64();
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        const unsigned n_cand = *((volatile unsigned*)&cand_n);
         if (n_cand <= 64) {
             unsigned long long key = lane < (int)n_cand ? *((volatile unsigned long long*)&cand[lane]) : KEY_SENTINEL;
             key = wave_sort64(key, lane);
@@ -726,6 +776,7 @@ __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs 
             }
         }
     }
+    if (a.dbg && threadIdx.x == 0) a.dbg[4] = wall_clock64();
     __syncthreads();
     // ---- all 4 waves: gather + refit (icem.py:201-211); row pointers first, then all K loads in flight ----
     const float* rows[KREG];
@@ -759,6 +810,7 @@ __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs 
     } else {
         for (int e = tid; e < hd; e += MERGE_WG) finish_one(e, a.mean[e], a.std[e]);
     }
+    if (a.dbg && threadIdx.x == 0) a.dbg[5] = wall_clock64();
     if (tid < a.K) a.elites_cost_next[tid] = key_cost(sel[tid]);
     if (a.last) {
         __syncthreads();
@@ -770,6 +822,7 @@ __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs 
         if (tid < a.d) a.executed[tid] = rows[0][tid];
         if (tid == 0) a.best_cost[0] = key_cost(sel[0]);
     }
+    if (a.dbg && threadIdx.x == 0) a.dbg[6] = wall_clock64();
 }
 
 }  // namespace
@@ -836,6 +889,8 @@ static bool sample_rollout_shape(int h, int d, int O, int rounds, int n_rows, in
     if (rounds != 10 || rw > max_rw || n_rows <= 0 || !fast_rollout_supported(h, d, O, 1) || !fast_sample_supported(h, d))
         return false;
     if (rw > 8) rw = 8;  // several passes per workgroup
+    static const int min_rw = [] { const char* e = getenv("ICEM_FUSE_MIN_RW"); return e ? atoi(e) : 1; }();
+    if (rw < min_rw) rw = min_rw;
     *grid_out = std::min(grid, (n_rows + 16 * rw - 1) / (16 * rw));
     *rw_out = rw;
     return true;

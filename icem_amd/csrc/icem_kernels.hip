@@ -898,16 +898,19 @@ FastRolloutArgs fast_rollout_args(const icem_handle* h, int n_rows, int n_cand, 
     a.costs = (float*)costs;
     a.part_c = part_c;
     a.part_i = part_i;
+    a.part_k = nullptr;
     a.dbg = h->dbg;
     return a;
 }
 
 // rows -> costs (+ one sorted candidate list per workgroup when K > 0); returns the number of candidate lists
 int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const void* obs0, const void* actions,
-                        void* costs, float* part_c, int* part_i, hipStream_t st, int* lists_out) {
+                        void* costs, float* part_c, int* part_i, hipStream_t st, int* lists_out,
+                        unsigned long long* part_k = nullptr) {
     int rc = ensure_fast_model(h);
     if (rc) return rc;
-    const FastRolloutArgs a = fast_rollout_args(h, n_rows, n_cand, K, obs0, actions, costs, part_c, part_i);
+    FastRolloutArgs a = fast_rollout_args(h, n_rows, n_cand, K, obs0, actions, costs, part_c, part_i);
+    a.part_k = part_k;
     const int grid = rollout_lists(h->cfg.horizon, h->cfg.act_dim, h->O, n_rows);
     {
         ProfScope prof(h, ICEM_K_ROLLOUT, (long long)n_rows * h->cfg.horizon, st);
@@ -1019,6 +1022,7 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                 fa.s = fast_sample_args(h, n_loc, lo, b->mean, b->std, b->low, b->high, off, row0, actions,
                                         shift_in_sampler ? n_extra : 0, shift_src, call_base + (uint64_t)c.opt_iters);
                 fa.r = fast_rollout_args(h, n_rows, n_cand, K, b->obs0, actions, b->costs, pc, pi);
+                if (c.world == 1) fa.r.part_k = (unsigned long long*)b->workspace;  // read by merge_single_kernel
                 {
                     ProfScope prof(h, ICEM_K_SAMPLE_ROLLOUT, (long long)n_rows * c.horizon, st);
                     launch_sample_rollout(fa, c.horizon, c.act_dim, h->O, h->model_kind, st);
@@ -1036,7 +1040,8 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                     rc = launch_sample<T>(h, a, st);
                 }
                 if (rc) return rc;
-                rc = launch_fast_rollout(h, n_rows, n_cand, K, b->obs0, actions, b->costs, pc, pi, st, &lists);
+                rc = launch_fast_rollout(h, n_rows, n_cand, K, b->obs0, actions, b->costs, pc, pi, st, &lists,
+                                         c.world == 1 ? (unsigned long long*)b->workspace : nullptr);
                 if (rc) return rc;
             }
             h->fast_lists = lists;
@@ -1097,11 +1102,7 @@ int plan_iter_merge_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
             m.last = it == c.opt_iters - 1;
             m.alpha = (float)c.alpha;
             m.init_std = (float)c.init_std;
-            float* pc;
-            int* pi;
-            split_partial_ws<float>(b->workspace, h->fast_lists, K, &pc, &pi);
-            m.part_c = pc;
-            m.part_i = pi;
+            m.part_k = (const unsigned long long*)b->workspace;
             m.actions = (const float*)b->actions;
             m.elites_cur = (const float*)el + (size_t)cur * K * hd;
             m.elites_cost_cur = (const float*)elc + (size_t)cur * K;
@@ -1113,6 +1114,7 @@ int plan_iter_merge_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
             m.high = (const float*)b->high;
             m.executed = (float*)b->executed;
             m.best_cost = (float*)b->best_cost;
+            m.dbg = h->dbg;
             ProfScope prof(h, ICEM_K_MERGE_REFIT, h->fast_lists * K + m.n_keep, st);
             launch_merge_single(m, st);
             ICEM_HIP_TRY(hipGetLastError());

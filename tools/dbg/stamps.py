@@ -1,0 +1,32 @@
+"""Phase stamps (wall_clock64, 100 MHz) of the merge kernel [0..6] and workgroup 0 of the single-launch kernel [8..14]."""
+import sys, os, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from icem_amd import IcemConfig, IcemPlanner, DeviceSyntheticModel, halfcheetah_env
+from icem_amd import _lib as L
+env = halfcheetah_env(17)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+model = DeviceSyntheticModel.make(17, 6)
+pl = IcemPlanner(IcemConfig(horizon=30, act_dim=6, num_traj=N, opt_iters=1, dtype="f32", seed=1), env.action_space.low, env.action_space.high)
+pl.set_model(model.kind, model.A, model.B)
+c = env.cost_spec
+pl.set_cost(c.ctrl_weight, c.lin_idx, c.lin_weight, c.flip_idx, c.flip_penalty, c.flip_thresh)
+pl.reset()
+obs = 0.1 * np.random.RandomState(0).randn(17)
+dbg = torch.zeros(16, dtype=torch.int64, device="cuda")
+L.check(pl.lib.icem_debug_stamps(pl._h, dbg.data_ptr()))
+for _ in range(5):
+    pl.plan_step(obs)
+torch.cuda.synchronize()
+acc = np.zeros(16)
+R = 20
+for _ in range(R):
+    pl.plan_step(obs); torch.cuda.synchronize()
+    d = dbg.cpu().numpy().astype(np.float64)
+    acc[:7] += (d[:7] - d[0]) / 100.0
+    acc[8:15] += (d[8:15] - d[8]) / 100.0
+    gap = (d[0] - d[14]) / 100.0
+    acc[15] += gap
+acc /= R
+print("merge  [us from kernel start]: lists loaded %.2f | keep merged %.2f | threshold+compact %.2f | selected %.2f | gather+refit %.2f | end %.2f" % tuple(acc[1:7]))
+print("single [us from kernel start]: staged %.2f | sampled %.2f | tile->HBM issued %.2f | rolled out %.2f | before wg merge %.2f | end %.2f" % tuple(acc[9:15]))
+print("gap end(single, wg 0) -> start(merge): %.2f us" % acc[15])
