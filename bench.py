@@ -97,7 +97,7 @@ def cpu_baseline(w, model, env, budget_s=12.0):
             done += n_it * h
         reps += 1
         el = time.perf_counter() - t0
-        if el > budget_s or reps >= 64:
+        if el > budget_s or reps >= 4096:
             break
     return {"value": done / el, "unit": "traj-steps/s", "cores": cores, "kind": "port",
             "sample": f"{reps} MPC step(s) of the same workload ({sum(pops)} trajectories x h={h} each) in "
