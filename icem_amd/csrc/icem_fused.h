@@ -54,15 +54,6 @@ void launch_rollout16(const FastRolloutArgs& a, int h, int d, int O, int kind, h
 // workgroups (= candidate lists) the rollout of n_rows trajectories is launched with
 int rollout_lists(int h, int d, int O, int n_rows);
 
-// K1+K2+K3 in one launch (small populations): r.actions == s.out, r.n_rows == s.n + s.n_shift.
-struct FastIterArgs {
-    FastSampleArgs s;
-    FastRolloutArgs r;
-};
-// workgroups (= candidate lists) of that launch; 0 if this shape / generator / size has no single-launch kernel
-int sample_rollout_lists(int h, int d, int O, int rounds, int n_rows);
-void launch_sample_rollout(const FastIterArgs& a, int h, int d, int O, int kind, hipStream_t st);
-
 // world == 1: global sorted top-K straight from the waves' candidate lists (+ kept elites), gather of
 // the elite rows from the pool, refit, and the last-iteration epilogue.
 struct MergeSingleArgs {
@@ -78,8 +69,10 @@ struct MergeSingleArgs {
     const float* elites_cost_cur;
     float* elites_next;
     float* elites_cost_next;
-    float* mean;
-    float* std;
+    const float* mean;  // distribution before the refit (momentum term)
+    const float* std;
+    float* mean_out;    // ... and after (may alias mean / std)
+    float* std_out;
     const float* low;
     const float* high;
     float* executed;
@@ -87,5 +80,18 @@ struct MergeSingleArgs {
     long long* dbg;  // development: 8 wall_clock64 stamps (100 MHz) of thread 0, nullptr in production
 };
 void launch_merge_single(const MergeSingleArgs& a, hipStream_t st);
+
+// K1+K2+K3 in one launch (small populations): r.actions == s.out, r.n_rows == s.n + s.n_shift.
+struct FastIterArgs {
+    FastSampleArgs s;
+    FastRolloutArgs r;
+    MergeSingleArgs m;  // merge prologue only: the PREVIOUS iteration's merge (last == 0), see sample_rollout_kernel
+};
+// workgroups (= candidate lists) of that launch; 0 if this shape / generator / size has no single-launch kernel
+int sample_rollout_lists(int h, int d, int O, int rounds, int n_rows);
+// may iteration `it >= 1` with n_rows rows fold the previous iteration's merge into its own launch?
+bool sample_rollout_merge_ok(int h, int d, int O, int rounds, int n_rows, int K);
+void launch_sample_rollout(const FastIterArgs& a, int h, int d, int O, int kind, bool merge_prologue, hipStream_t st);
+
 
 }  // namespace icem

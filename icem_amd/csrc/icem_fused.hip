@@ -518,116 +518,6 @@ __global__ __launch_bounds__(64 * WAVES) void rollout16_kernel(FastRolloutArgs a
 }
 
 // -------------------------------------------------------------------------------------------------
-// K1 + K2 + K3 in one launch for small populations
-// -------------------------------------------------------------------------------------------------
-// With a few thousand trajectories the chip is mostly empty and an iteration is a chain of latencies: launch,
-// prologue, one thread's RNG -> DFT chain, HBM round trip of the actions, launch, prologue, 30 dependent model
-// steps.  Here a workgroup samples 16 * RW trajectories into an LDS tile (one thread per (trajectory, dim) row,
-// same code as sample_folded_kernel), writes the tile to HBM for the elite gather, and its first RW waves roll
-// the trajectories out straight from the tile (same code as rollout16_kernel): one launch, no HBM round trip.
-template <int H, int D, int O, int KIND, int ROUNDS, int RW>
-__global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64) void sample_rollout_kernel(FastIterArgs a) {
-    using Tile = Tile16<H, D, O, KIND>;
-    constexpr int HD = H * D;
-    constexpr int TPB = 16 * RW;                     // trajectories per workgroup pass
-    constexpr int ROWS = TPB * D;                    // (trajectory, dim) rows per pass, one thread each
-    constexpr int NT = ((ROWS + 63) / 64) * 64;
-    static_assert(NT <= 1024 && HD % 4 == 0, "workgroup shape");
-    __shared__ __attribute__((aligned(16))) float ms[2 * HD];  // mean | std
-    __shared__ __attribute__((aligned(16))) float tilebuf[Tile::SLACK + TPB * HD + Tile::TAIL];
-    __shared__ unsigned long long wg_keys[2][RW][32];
-    float* tile_rows = tilebuf + Tile::SLACK;
-    const FastSampleArgs& sa = a.s;
-    const FastRolloutArgs& ra = a.r;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[8] = wall_clock64();
-    for (int e = tid; e < HD; e += NT) {
-        ms[e] = sa.mean[e];
-        ms[HD + e] = sa.std[e];
-    }
-    Tile tile;
-    if (wave < RW) tile.load(ra, lane);
-    const float* rd0 = tile.read_ptr(tilebuf + (wave < RW ? wave : 0) * 16 * HD, lane, HD);
-    // this thread's sampling row
-    const int nl = tid / D, jd = tid - nl * D;
-    const bool has_row = tid < ROWS;
-    const float lo = sa.low[has_row ? jd : 0], hi = sa.high[has_row ? jd : 0];
-    float* trow = tile_rows + nl * HD + jd;
-    const float* mrow = ms + jd;
-
-    unsigned long long run_key = KEY_SENTINEL;
-    bool first = true;
-    const int n_rows = ra.n_rows;  // sa.n sampled rows, then sa.n_shift shifted elites
-    const int passes = (n_rows + TPB - 1) / TPB;
-    for (int pass = blockIdx.x; pass < passes; pass += gridDim.x) {
-        const int base = pass * TPB;
-        __syncthreads();  // mean / std staged; previous pass's rollout is done with the tile
-        if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[9] = wall_clock64();
-        if (has_row) {
-            const int r = base + nl;
-            if (r < sa.n) {
-                sample_row<H, ROUNDS>(sa.W, (unsigned)(sa.first_index + r), (unsigned)jd, sa.off_lo, sa.off_hi, sa.seed_lo,
-                                      sa.seed_hi, [&](int t, float y) {
-                                          const float v = __builtin_fmaf(y, mrow[HD + t * D], mrow[t * D]);
-                                          trow[t * D] = __builtin_amdgcn_fmed3f(v, lo, hi);
-                                      });
-            } else if (r < n_rows) {
-                // shifted elite e: elites[e, 1:, j] and a last action drawn from the full (n_shift, d, h) noise batch
-                // of stream off2 (only t = h-1 is used, icem.py:102)
-                const int e = r - sa.n;
-                float last = 0.f;
-                sample_row<H, ROUNDS>(sa.W, (unsigned)e, (unsigned)jd, sa.off2_lo, sa.off2_hi, sa.seed_lo, sa.seed_hi,
-                                      [&](int t, float y) {
-                                          if (t == H - 1) {
-                                              const float v = __builtin_fmaf(y, mrow[HD + t * D], mrow[t * D]);
-                                              last = __builtin_amdgcn_fmed3f(v, lo, hi);
-                                          }
-                                      });
-                const float* src = sa.elites_src + (size_t)e * HD + jd;
-                for (int t = 0; t < H - 1; ++t) trow[t * D] = src[(t + 1) * D];
-                trow[(H - 1) * D] = last;
-            } else {
-                for (int t = 0; t < H; ++t) trow[t * D] = 0.f;  // past the end: rolled out, dropped
-            }
-        }
-        if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[10] = wall_clock64();
-        __syncthreads();
-        if (sa.row0_mean && sa.first_index + base == 0) {  // icem.py:87-88
-            for (int e = tid; e < HD; e += NT) tile_rows[e] = ms[e];
-            __syncthreads();
-        }
-        {   // the tile is a contiguous block of the action tensor
-            const int total4 = (n_rows - base < TPB ? n_rows - base : TPB) * (HD / 4);
-            const float4* t4 = reinterpret_cast<const float4*>(tile_rows);
-            float4* g4 = reinterpret_cast<float4*>(sa.out + (size_t)base * HD);
-            for (int e = tid; e < total4; e += NT) g4[e] = t4[e];
-        }
-        if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[11] = wall_clock64();
-        if (wave < RW) {
-            const int row = base + wave * 16 + (lane & 15);
-            const bool live = row < n_rows;
-            typename Tile::State st;
-            tile.init(st);
-#pragma unroll
-            for (int t = 0; t < H; ++t) tile.step(st, rd0 + t * D);
-            const float cost = tile.cost(st);
-            if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[12] = wall_clock64();
-            if (live && lane < 16) ra.costs[row] = cost;
-            if (ra.K > 0) {
-                const unsigned long long key = (lane < 16 && live && row < ra.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
-                run_key = topk_push16(run_key, key, first, ra.K, lane);
-                first = false;
-            }
-        }
-    }
-    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[13] = wall_clock64();
-    if (ra.K > 0) wg_merge_emit<RW>(wg_keys, run_key, ra.K, lane, wave, ra);
-    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[14] = wall_clock64();
-}
-
-// -------------------------------------------------------------------------------------------------
 // merge: global sorted top-K from <= 256 sorted candidate lists (+ kept elites)
 // -------------------------------------------------------------------------------------------------
 constexpr int MERGE_WG = 256;  // wave 0 selects (no barriers inside); all 4 waves gather + refit
@@ -673,6 +563,104 @@ __device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned x) {
     return x;
 }
 
+// Global sorted top-K of the candidate lists (+ kept elites): ONE wavefront; sel[0..K) receives the keys.
+// Lane t owns lists t, t+64, t+128, t+192 (each sorted) in registers; key r of list w sits at
+// part_k[r * n_lists + w], so every load is one contiguous 512 bytes.
+template <int KREG>
+__device__ __forceinline__ void merge_select(const MergeSingleArgs& a, int lane, unsigned long long* cand,
+                                             unsigned long long* sel) {
+    unsigned long long k[LPL][KREG];
+#pragma unroll
+    for (int l = 0; l < LPL; ++l) {
+        const int list = lane + l * 64;
+#pragma unroll
+        for (int i = 0; i < KREG; ++i)
+            k[l][i] = a.part_k[(size_t)(i < a.K ? i : 0) * a.n_lists + (list < a.n_lists ? list : 0)];
+    }
+#pragma unroll
+    for (int l = 0; l < LPL; ++l) {
+        const bool has_list = lane + l * 64 < a.n_lists;
+#pragma unroll
+        for (int i = 0; i < KREG; ++i) k[l][i] = (has_list && i < a.K) ? k[l][i] : KEY_SENTINEL;
+    }
+    if (a.dbg && threadIdx.x == 0) a.dbg[1] = wall_clock64();
+    if (lane < a.n_keep) {  // kept elite `lane` (icem.py:143-145) joins this lane's first list, order preserved
+        unsigned long long v = make_key(a.elites_cost_cur[lane], a.n_global + lane);
+#pragma unroll
+        for (int i = 0; i < KREG; ++i) {
+            const bool sw = v < k[0][i];
+            const unsigned long long t = sw ? k[0][i] : v;
+            k[0][i] = sw ? v : k[0][i];
+            v = t;
+        }
+    }
+    // selection by threshold: the K-th smallest of the 64 lane minima bounds the K-th smallest key overall,
+    // so the global top-K is among the keys <= T; those (usually K..2K of them) are compacted into one key
+    // per lane and sorted.  Two 64-key sorts instead of K dependent tournament rounds.
+    if (a.dbg && threadIdx.x == 0) a.dbg[2] = wall_clock64();
+    unsigned long long mine = k[0][0];
+#pragma unroll
+    for (int l = 1; l < LPL; ++l) mine = k[l][0] < mine ? k[l][0] : mine;
+    const unsigned long long srt = wave_sort64(mine, lane);
+    const unsigned long long T = __shfl(srt, a.K - 1, 64);
+    // compaction: every lane counts its keys <= T, an exclusive DPP scan over the lanes gives it a slot range
+    unsigned mine_n = 0;
+#pragma unroll
+    for (int l = 0; l < LPL; ++l)
+#pragma unroll
+        for (int i = 0; i < KREG; ++i) mine_n += (k[l][i] <= T && k[l][i] != KEY_SENTINEL) ? 1u : 0u;
+    const unsigned incl = wave_incl_scan_u32(mine_n);
+    const unsigned n_cand = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+    unsigned pos = incl - mine_n;
+#pragma unroll
+    for (int l = 0; l < LPL; ++l) {
+#pragma unroll
+        for (int i = 0; i < KREG; ++i) {
+            if (k[l][i] <= T && k[l][i] != KEY_SENTINEL) {
+                if (pos < 64) cand[pos] = k[l][i];
+                ++pos;
+            }
+        }
+    }
+    if (a.dbg && threadIdx.x == 0) a.dbg[3] = wall_clock64();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    if (n_cand <= 64) {
+        unsigned long long key = lane < (int)n_cand ? *((volatile unsigned long long*)&cand[lane]) : KEY_SENTINEL;
+        key = wave_sort64(key, lane);
+        if (lane < a.K) sel[lane] = key;
+    } else {
+        // more than 64 keys tie at or below T: K tournament rounds over the list heads
+        for (int r = 0; r < a.K; ++r) {
+            unsigned long long head = k[0][0];
+#pragma unroll
+            for (int l = 1; l < LPL; ++l) head = k[l][0] < head ? k[l][0] : head;
+            const unsigned long long best = wave_min_u64(head);
+            if (best != KEY_SENTINEL) {  // keys embed the trajectory index: exactly one (lane, list) matches
+#pragma unroll
+                for (int l = 0; l < LPL; ++l) {
+                    if (k[l][0] == best) {
+#pragma unroll
+                        for (int i = 0; i + 1 < KREG; ++i) k[l][i] = k[l][i + 1];
+                        k[l][KREG - 1] = KEY_SENTINEL;
+                    }
+                }
+            }
+            if (lane == 0) sel[r] = best;
+        }
+    }
+}
+
+// pointers to the K selected rows (icem.py:201): pool rows, or kept elites behind index n_global
+template <int KREG>
+__device__ __forceinline__ void merge_rows(const MergeSingleArgs& a, const unsigned long long* sel, const float* (&rows)[KREG]) {
+    const int hd = a.h * a.d;
+#pragma unroll
+    for (int r = 0; r < KREG; ++r) {
+        const int g = key_idx(sel[r < a.K ? r : 0]);
+        rows[r] = g < a.n_pool ? a.actions + (size_t)g * hd : a.elites_cur + (size_t)(g - a.n_global) * hd;
+    }
+}
+
 template <int KREG>
 __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs a) {
     __shared__ unsigned long long sel[64];
@@ -693,98 +681,12 @@ __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs 
         om[i] = (pre && e < hd) ? a.mean[e] : 0.f;
         os[i] = (pre && e < hd) ? a.std[e] : 0.f;
     }
-    if (tid < 64) {
-        // ---- wave 0: lane t owns candidate lists t, t+64, t+128, t+192 (each sorted) in registers; key r of list w
-        // sits at part_k[r * n_lists + w]: every load is one contiguous 512 bytes ----
-        unsigned long long k[LPL][KREG];
-#pragma unroll
-        for (int l = 0; l < LPL; ++l) {
-            const int list = lane + l * 64;
-#pragma unroll
-            for (int i = 0; i < KREG; ++i)
-                k[l][i] = a.part_k[(size_t)(i < a.K ? i : 0) * a.n_lists + (list < a.n_lists ? list : 0)];
-        }
-#pragma unroll
-        for (int l = 0; l < LPL; ++l) {
-            const bool has_list = lane + l * 64 < a.n_lists;
-#pragma unroll
-            for (int i = 0; i < KREG; ++i) k[l][i] = (has_list && i < a.K) ? k[l][i] : KEY_SENTINEL;
-        }
-        if (a.dbg && threadIdx.x == 0) a.dbg[1] = wall_clock64();
-        if (lane < a.n_keep) {  // kept elite `lane` (icem.py:143-145) joins this lane's first list, order preserved
-            unsigned long long v = make_key(a.elites_cost_cur[lane], a.n_global + lane);
-#pragma unroll
-            for (int i = 0; i < KREG; ++i) {
-                const bool sw = v < k[0][i];
-                const unsigned long long t = sw ? k[0][i] : v;
-                k[0][i] = sw ? v : k[0][i];
-                v = t;
-            }
-        }
-        // selection by threshold: the K-th smallest of the 64 lane minima bounds the K-th smallest key overall,
-        // so the global top-K is among the keys <= T; those (usually K..2K of them) are compacted into one key
-        // per lane and sorted.  Two 64-key sorts instead of K dependent tournament rounds.
-        if (a.dbg && threadIdx.x == 0) a.dbg[2] = wall_clock64();
-        unsigned long long mine = k[0][0];
-#pragma unroll
-        for (int l = 1; l < LPL; ++l) mine = k[l][0] < mine ? k[l][0] : mine;
-        const unsigned long long srt = wave_sort64(mine, lane);
-        const unsigned long long T = __shfl(srt, a.K - 1, 64);
-        // compaction: every lane counts its keys <= T, an exclusive DPP scan over the lanes gives it a slot range
-        unsigned mine_n = 0;
-#pragma unroll
-        for (int l = 0; l < LPL; ++l)
-#pragma unroll
-            for (int i = 0; i < KREG; ++i) mine_n += (k[l][i] <= T && k[l][i] != KEY_SENTINEL) ? 1u : 0u;
-        const unsigned incl = wave_incl_scan_u32(mine_n);
-        const unsigned n_cand = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-        unsigned pos = incl - mine_n;
-#pragma unroll
-        for (int l = 0; l < LPL; ++l) {
-#pragma unroll
-            for (int i = 0; i < KREG; ++i) {
-                if (k[l][i] <= T && k[l][i] != KEY_SENTINEL) {
-                    if (pos < 64) cand[pos] = k[l][i];
-                    ++pos;
-                }
-            }
-        }
-        if (a.dbg && threadIdx.x == 0) a.dbg[3] = wall_clock64();
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        if (n_cand <= 64) {
-            unsigned long long key = lane < (int)n_cand ? *((volatile unsigned long long*)&cand[lane]) : KEY_SENTINEL;
-            key = wave_sort64(key, lane);
-            if (lane < a.K) sel[lane] = key;
-        } else {
-            // more than 64 keys tie at or below T: K tournament rounds over the list heads
-            for (int r = 0; r < a.K; ++r) {
-                unsigned long long head = k[0][0];
-#pragma unroll
-                for (int l = 1; l < LPL; ++l) head = k[l][0] < head ? k[l][0] : head;
-                const unsigned long long best = wave_min_u64(head);
-                if (best != KEY_SENTINEL) {  // keys embed the trajectory index: exactly one (lane, list) matches
-#pragma unroll
-                    for (int l = 0; l < LPL; ++l) {
-                        if (k[l][0] == best) {
-#pragma unroll
-                            for (int i = 0; i + 1 < KREG; ++i) k[l][i] = k[l][i + 1];
-                            k[l][KREG - 1] = KEY_SENTINEL;
-                        }
-                    }
-                }
-                if (lane == 0) sel[r] = best;
-            }
-        }
-    }
+    if (tid < 64) merge_select<KREG>(a, lane, cand, sel);
     if (a.dbg && threadIdx.x == 0) a.dbg[4] = wall_clock64();
     __syncthreads();
     // ---- all 4 waves: gather + refit (icem.py:201-211); row pointers first, then all K loads in flight ----
     const float* rows[KREG];
-#pragma unroll
-    for (int r = 0; r < KREG; ++r) {
-        const int g = key_idx(sel[r < a.K ? r : 0]);
-        rows[r] = g < a.n_pool ? a.actions + (size_t)g * hd : a.elites_cur + (size_t)(g - a.n_global) * hd;
-    }
+    merge_rows<KREG>(a, sel, rows);
     auto finish_one = [&](int e, float old_mean, float old_std) {
         float xs[KREG];
 #pragma unroll
@@ -795,8 +697,8 @@ __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs 
         float nm, ns;
         refit_element_regs<float, KREG>(a.K, a.alpha, old_mean, old_std, xs, nm, ns);
         if (!a.last) {
-            a.mean[e] = nm;
-            a.std[e] = ns;
+            a.mean_out[e] = nm;
+            a.std_out[e] = ns;
         } else {
             new_mean[e] = nm;
         }
@@ -816,13 +718,179 @@ __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs 
         __syncthreads();
         for (int e = tid; e < hd; e += MERGE_WG) {
             const int j = e % a.d;
-            a.mean[e] = (e + a.d < hd) ? new_mean[e + a.d] : new_mean[e];
-            a.std[e] = (a.high[j] - a.low[j]) / 2.f * a.init_std;
+            a.mean_out[e] = (e + a.d < hd) ? new_mean[e + a.d] : new_mean[e];
+            a.std_out[e] = (a.high[j] - a.low[j]) / 2.f * a.init_std;
         }
         if (tid < a.d) a.executed[tid] = rows[0][tid];
         if (tid == 0) a.best_cost[0] = key_cost(sel[0]);
     }
     if (a.dbg && threadIdx.x == 0) a.dbg[6] = wall_clock64();
+}
+
+// -------------------------------------------------------------------------------------------------
+// K1 + K2 + K3 in one launch for small populations (+ the PREVIOUS iteration's K3 + K4 in its prologue)
+// -------------------------------------------------------------------------------------------------
+// With a few thousand trajectories the chip is mostly empty and an iteration is a chain of latencies: launch,
+// prologue, one thread's RNG -> DFT chain, HBM round trip of the actions, launch, prologue, 30 dependent model
+// steps, launch, merge.  Here a workgroup samples 16 * RW trajectories into an LDS tile (one thread per
+// (trajectory, dim) row, same code as sample_folded_kernel), writes the tile to HBM for the elite gather, and its
+// first RW waves roll the trajectories out straight from the tile (same code as rollout16_kernel): one launch, no
+// HBM round trip.
+// KREG > 0 ("merge prologue"): the distribution this iteration samples from is not in memory yet -- every
+// workgroup computes it itself from the previous iteration's candidate lists.  An extra wavefront runs the
+// selection (merge_select) WHILE the sampling waves draw their noise (which does not depend on mean / std: the
+// raw colored samples are parked in the tile); then all threads gather the K elite rows and refit (same
+// arithmetic as merge_single_kernel, so every workgroup gets the same bits), the affine map + clip is applied to
+// the tile, and the iteration proceeds as above.  Workgroup 0 also writes the new distribution and elite set for
+// the host / the next launch.  That removes the merge launch and hides its latency behind the sampling.  The
+// previous pool, lists and distribution are read while this launch writes new ones: all three are ping-pong
+// buffers (icem_plan_step).
+template <int H, int D, int O, int KIND, int ROUNDS, int RW, int KREG>
+__global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64 + (KREG > 0 ? 64 : 0)) void sample_rollout_kernel(FastIterArgs a) {
+    using Tile = Tile16<H, D, O, KIND>;
+    constexpr bool PM = KREG > 0;
+    constexpr int HD = H * D;
+    constexpr int TPB = 16 * RW;                     // trajectories per workgroup pass
+    constexpr int ROWS = TPB * D;                    // (trajectory, dim) rows per pass, one thread each
+    constexpr int NT = ((ROWS + 63) / 64) * 64;      // sampling threads
+    constexpr int NTT = NT + (PM ? 64 : 0);          // + the selection wavefront
+    static_assert(NTT <= 1024 && HD % 4 == 0, "workgroup shape");
+    __shared__ __attribute__((aligned(16))) float ms[2 * HD];  // mean | std
+    __shared__ __attribute__((aligned(16))) float tilebuf[Tile::SLACK + TPB * HD + Tile::TAIL];
+    __shared__ unsigned long long wg_keys[2][RW][32];
+    __shared__ unsigned long long sel[PM ? 64 : 1];
+    __shared__ unsigned long long cand[PM ? 64 : 1];
+    float* tile_rows = tilebuf + Tile::SLACK;
+    const FastSampleArgs& sa = a.s;
+    const FastRolloutArgs& ra = a.r;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[8] = wall_clock64();
+    if (!PM) {
+        for (int e = tid; e < HD; e += NTT) {
+            ms[e] = sa.mean[e];
+            ms[HD + e] = sa.std[e];
+        }
+    }
+    Tile tile;
+    if (wave < RW) tile.load(ra, lane);
+    const float* rd0 = tile.read_ptr(tilebuf + (wave < RW ? wave : 0) * 16 * HD, lane, HD);
+    // this thread's sampling row
+    const int nl = tid / D, jd = tid - nl * D;
+    const bool has_row = tid < ROWS;
+    const float lo = sa.low[has_row ? jd : 0], hi = sa.high[has_row ? jd : 0];
+    float* trow = tile_rows + nl * HD + jd;
+    const float* mrow = ms + jd;
+
+    unsigned long long run_key = KEY_SENTINEL;
+    bool first = true;
+    const int n_rows = ra.n_rows;  // sa.n sampled rows, then sa.n_shift shifted elites
+    const int passes = (n_rows + TPB - 1) / TPB;
+    for (int pass = blockIdx.x; pass < passes; pass += gridDim.x) {
+        const int base = pass * TPB;
+        __syncthreads();  // mean / std staged; previous pass's rollout is done with the tile
+        if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[9] = wall_clock64();
+        const bool raw = PM && first;  // mean / std are still being computed: park the raw colored samples
+        if (has_row) {
+            const int r = base + nl;
+            if (r < sa.n) {
+                if (raw) {
+                    sample_row<H, ROUNDS>(sa.W, (unsigned)(sa.first_index + r), (unsigned)jd, sa.off_lo, sa.off_hi,
+                                          sa.seed_lo, sa.seed_hi, [&](int t, float y) { trow[t * D] = y; });
+                } else {
+                    sample_row<H, ROUNDS>(sa.W, (unsigned)(sa.first_index + r), (unsigned)jd, sa.off_lo, sa.off_hi,
+                                          sa.seed_lo, sa.seed_hi, [&](int t, float y) {
+                                              const float v = __builtin_fmaf(y, mrow[HD + t * D], mrow[t * D]);
+                                              trow[t * D] = __builtin_amdgcn_fmed3f(v, lo, hi);
+                                          });
+                }
+            } else if (r < n_rows && !PM) {
+                // shifted elite e: elites[e, 1:, j] and a last action drawn from the full (n_shift, d, h) noise batch
+                // of stream off2 (only t = h-1 is used, icem.py:102); iteration 0 only, which has no merge prologue
+                const int e = r - sa.n;
+                float last = 0.f;
+                sample_row<H, ROUNDS>(sa.W, (unsigned)e, (unsigned)jd, sa.off2_lo, sa.off2_hi, sa.seed_lo, sa.seed_hi,
+                                      [&](int t, float y) {
+                                          if (t == H - 1) {
+                                              const float v = __builtin_fmaf(y, mrow[HD + t * D], mrow[t * D]);
+                                              last = __builtin_amdgcn_fmed3f(v, lo, hi);
+                                          }
+                                      });
+                const float* src = sa.elites_src + (size_t)e * HD + jd;
+                for (int t = 0; t < H - 1; ++t) trow[t * D] = src[(t + 1) * D];
+                trow[(H - 1) * D] = last;
+            } else {
+                for (int t = 0; t < H; ++t) trow[t * D] = 0.f;  // past the end: rolled out, dropped
+            }
+        }
+        if constexpr (PM) {
+            if (first) {
+                const MergeSingleArgs& m = a.m;
+                if (tid >= NT) merge_select<KREG>(m, lane, cand, sel);
+                __syncthreads();
+                // all threads: gather the elite rows + refit (icem.py:201-211) -> this workgroup's mean / std
+                const float* rows[KREG > 0 ? KREG : 1];
+                merge_rows<KREG>(m, sel, rows);
+                for (int e = tid; e < HD; e += NTT) {
+                    float xs[KREG > 0 ? KREG : 1];
+#pragma unroll
+                    for (int r = 0; r < KREG; ++r) xs[r] = rows[r][e];
+                    float nm, ns;
+                    refit_element_regs<float, KREG>(m.K, m.alpha, m.mean[e], m.std[e], xs, nm, ns);
+                    ms[e] = nm;
+                    ms[HD + e] = ns;
+                    if (blockIdx.x == 0) {
+                        m.mean_out[e] = nm;
+                        m.std_out[e] = ns;
+#pragma unroll
+                        for (int r = 0; r < KREG; ++r)
+                            if (r < m.K) m.elites_next[(size_t)r * HD + e] = xs[r];
+                    }
+                }
+                if (blockIdx.x == 0 && tid < m.K) m.elites_cost_next[tid] = key_cost(sel[tid]);
+                __syncthreads();
+                if (has_row && base + nl < sa.n) {
+                    for (int t = 0; t < H; ++t) {
+                        const float v = __builtin_fmaf(trow[t * D], mrow[HD + t * D], mrow[t * D]);
+                        trow[t * D] = __builtin_amdgcn_fmed3f(v, lo, hi);
+                    }
+                }
+            }
+        }
+        if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[10] = wall_clock64();
+        __syncthreads();
+        if (sa.row0_mean && sa.first_index + base == 0) {  // icem.py:87-88
+            for (int e = tid; e < HD; e += NTT) tile_rows[e] = ms[e];
+            __syncthreads();
+        }
+        {   // the tile is a contiguous block of the action tensor
+            const int total4 = (n_rows - base < TPB ? n_rows - base : TPB) * (HD / 4);
+            const float4* t4 = reinterpret_cast<const float4*>(tile_rows);
+            float4* g4 = reinterpret_cast<float4*>(sa.out + (size_t)base * HD);
+            for (int e = tid; e < total4; e += NTT) g4[e] = t4[e];
+        }
+        if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[11] = wall_clock64();
+        if (wave < RW) {
+            const int row = base + wave * 16 + (lane & 15);
+            const bool live = row < n_rows;
+            typename Tile::State st;
+            tile.init(st);
+#pragma unroll
+            for (int t = 0; t < H; ++t) tile.step(st, rd0 + t * D);
+            const float cost = tile.cost(st);
+            if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[12] = wall_clock64();
+            if (live && lane < 16) ra.costs[row] = cost;
+            if (ra.K > 0) {
+                const unsigned long long key = (lane < 16 && live && row < ra.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
+                run_key = topk_push16(run_key, key, first, ra.K, lane);
+            }
+        }
+        first = false;
+    }
+    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[13] = wall_clock64();
+    if (ra.K > 0) wg_merge_emit<RW>(wg_keys, run_key, ra.K, lane, wave, ra);
+    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[14] = wall_clock64();
 }
 
 }  // namespace
@@ -901,17 +969,32 @@ int sample_rollout_lists(int h, int d, int O, int rounds, int n_rows) {
     return sample_rollout_shape(h, d, O, rounds, n_rows, &grid, &rw) ? grid : 0;
 }
 
-void launch_sample_rollout(const FastIterArgs& a, int h, int d, int O, int kind, hipStream_t st) {
+// merge prologue: selection wavefront + sampling waves must fit the register budget -> up to 4 rollout waves
+bool sample_rollout_merge_ok(int h, int d, int O, int rounds, int n_rows, int K) {
+    static const int on = [] { const char* e = getenv("ICEM_MERGE_PROLOGUE"); return e ? atoi(e) : 1; }();
+    int grid, rw;
+    return on && K + 1 <= 12 && sample_rollout_shape(h, d, O, rounds, n_rows, &grid, &rw) && rw <= 4 &&
+           (n_rows + 16 * rw - 1) / (16 * rw) <= grid;
+}
+
+void launch_sample_rollout(const FastIterArgs& a, int h, int d, int O, int kind, bool merge_prologue, hipStream_t st) {
     int grid, rw;
     if (!sample_rollout_shape(h, d, O, 10, a.r.n_rows, &grid, &rw)) return;
-#define XW(HH, DD, OO, WW)                                                                                           \
-    if (rw == WW) {                                                                                                  \
-        constexpr int NT = ((16 * WW * DD + 63) / 64) * 64;                                                          \
-        if (kind == 1)                                                                                               \
-            hipLaunchKernelGGL((sample_rollout_kernel<HH, DD, OO, 1, 10, WW>), dim3(grid), dim3(NT), 0, st, a);      \
-        else                                                                                                         \
-            hipLaunchKernelGGL((sample_rollout_kernel<HH, DD, OO, 0, 10, WW>), dim3(grid), dim3(NT), 0, st, a);      \
-        return;                                                                                                      \
+#define XK(HH, DD, OO, WW, KR)                                                                                        \
+    {                                                                                                                 \
+        constexpr int NT = ((16 * WW * DD + 63) / 64) * 64 + (KR > 0 ? 64 : 0);                                       \
+        if (kind == 1)                                                                                                \
+            hipLaunchKernelGGL((sample_rollout_kernel<HH, DD, OO, 1, 10, WW, KR>), dim3(grid), dim3(NT), 0, st, a);   \
+        else                                                                                                          \
+            hipLaunchKernelGGL((sample_rollout_kernel<HH, DD, OO, 0, 10, WW, KR>), dim3(grid), dim3(NT), 0, st, a);   \
+        return;                                                                                                       \
+    }
+#define XW(HH, DD, OO, WW)                                    \
+    if (rw == WW) {                                           \
+        if constexpr (WW <= 4) {                              \
+            if (merge_prologue) XK(HH, DD, OO, WW, 12)        \
+        }                                                     \
+        XK(HH, DD, OO, WW, 0)                                 \
     }
 #define XR(HH, DD, OO)                   \
     if (h == HH && d == DD && O == OO) { \
@@ -923,6 +1006,7 @@ void launch_sample_rollout(const FastIterArgs& a, int h, int d, int O, int kind,
     ICEM_FAST_SHAPES(XR)
 #undef XR
 #undef XW
+#undef XK
 }
 
 #define ICEM_FAST_HORIZONS(X) X(30) X(12) X(13) X(10)

@@ -597,6 +597,17 @@ struct icem_handle {
     bool use_fast = true;
     long long* dbg = nullptr;
     int fast_lists = 0;  // candidate lists written by the last matrix-pipe rollout (0 = generic path ran)
+    // icem_plan_step (world == 1): an iteration's merge can ride in the prologue of the next iteration's launch,
+    // which then reads the previous pool / lists / distribution while writing new ones -> ping-pong partners of
+    // the caller's actions / workspace buffers and of mean | std, owned by the handle
+    void* actions_alt = nullptr;
+    void* ws_alt = nullptr;
+    float* pp_stats = nullptr;          // [2][2 * hd]
+    bool defer_merge = false;           // plan_iter_merge: stash the merge instead of launching it
+    bool pm_pending = false;            // a stashed merge waits for the next local launch
+    MergeSingleArgs pm_args;
+    float* merge_mean_out = nullptr;    // where the next merge writes mean / std (nullptr: in place)
+    float* merge_std_out = nullptr;
     // permuted, padded model of the matrix-pipe rollout: column 0 = obs[lin_idx], column 1 = obs[flip_idx]
     void* Mp_dev = nullptr;
     void* perm_dev = nullptr;
@@ -1016,16 +1027,26 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                                 ? sample_rollout_lists(c.horizon, c.act_dim, h->O, c.rng_rounds, n_rows) : 0;
             // the merge finds the lists' indices behind `lists * K` costs
             split_partial_ws<float>(b->workspace, one > 0 ? one : rollout_lists(c.horizon, c.act_dim, h->O, n_rows), K, &pc, &pi);
+            bool prologue = false;
+            if (h->pm_pending) {
+                prologue = one > 0 && sample_rollout_merge_ok(c.horizon, c.act_dim, h->O, c.rng_rounds, n_rows, K);
+                if (!prologue) {  // cannot ride along after all: run it now
+                    ProfScope prof(h, ICEM_K_MERGE_REFIT, h->pm_args.n_lists * K + h->pm_args.n_keep, st);
+                    launch_merge_single(h->pm_args, st);
+                }
+                h->pm_pending = false;
+            }
             if (one > 0) {
                 // small populations: sample + rollout + top-K in one launch
                 FastIterArgs fa;
+                if (prologue) fa.m = h->pm_args;
                 fa.s = fast_sample_args(h, n_loc, lo, b->mean, b->std, b->low, b->high, off, row0, actions,
                                         shift_in_sampler ? n_extra : 0, shift_src, call_base + (uint64_t)c.opt_iters);
                 fa.r = fast_rollout_args(h, n_rows, n_cand, K, b->obs0, actions, b->costs, pc, pi);
                 if (c.world == 1) fa.r.part_k = (unsigned long long*)b->workspace;  // read by merge_single_kernel
                 {
                     ProfScope prof(h, ICEM_K_SAMPLE_ROLLOUT, (long long)n_rows * c.horizon, st);
-                    launch_sample_rollout(fa, c.horizon, c.act_dim, h->O, h->model_kind, st);
+                    launch_sample_rollout(fa, c.horizon, c.act_dim, h->O, h->model_kind, prologue, st);
                 }
                 ICEM_HIP_TRY(hipGetLastError());
                 lists = one;
@@ -1108,13 +1129,20 @@ int plan_iter_merge_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
             m.elites_cost_cur = (const float*)elc + (size_t)cur * K;
             m.elites_next = (float*)el + (size_t)nxt * K * hd;
             m.elites_cost_next = (float*)elc + (size_t)nxt * K;
-            m.mean = (float*)b->mean;
-            m.std = (float*)b->std;
+            m.mean = (const float*)b->mean;
+            m.std = (const float*)b->std;
+            m.mean_out = h->merge_mean_out ? h->merge_mean_out : (float*)b->mean;
+            m.std_out = h->merge_std_out ? h->merge_std_out : (float*)b->std;
             m.low = (const float*)b->low;
             m.high = (const float*)b->high;
             m.executed = (float*)b->executed;
             m.best_cost = (float*)b->best_cost;
             m.dbg = h->dbg;
+            if (h->defer_merge && !m.last) {  // rides in the next iteration's launch (icem_plan_step)
+                h->pm_args = m;
+                h->pm_pending = true;
+                return ICEM_OK;
+            }
             ProfScope prof(h, ICEM_K_MERGE_REFIT, h->fast_lists * K + m.n_keep, st);
             launch_merge_single(m, st);
             ICEM_HIP_TRY(hipGetLastError());
@@ -1226,6 +1254,9 @@ int icem_create(const icem_config* cfg, icem_handle** out) {
 int icem_destroy(icem_handle* h) {
     if (!h) return ICEM_OK;
     if (h->W_dev) (void)hipFree(h->W_dev);
+    if (h->actions_alt) (void)hipFree(h->actions_alt);
+    if (h->ws_alt) (void)hipFree(h->ws_alt);
+    if (h->pp_stats) (void)hipFree(h->pp_stats);
     if (h->A_dev) (void)hipFree(h->A_dev);
     if (h->B_dev) (void)hipFree(h->B_dev);
     if (h->Mp_dev) (void)hipFree(h->Mp_dev);
@@ -1504,11 +1535,54 @@ int icem_plan_iter_merge(icem_handle* h, const icem_plan_buffers* b, int32_t mpc
 int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, void* stream) {
     if (check_handle(h)) return ICEM_E_INVALID;
     if (h->cfg.world != 1) return fail(ICEM_E_INVALID, "icem_plan_step is the world == 1 path; use iter_local/iter_merge");
-    for (int it = 0; it < h->cfg.opt_iters; ++it) {
-        int rc = icem_plan_iter_local(h, b, mpc_step, it, stream);
+    int rc = check_plan(h, b, mpc_step, 0);
+    if (rc) return rc;
+    const icem_config& c = h->cfg;
+    const int iters = c.opt_iters;
+    // f32, device noise: iteration it's merge may ride in the prologue of iteration it+1's launch.  That launch
+    // reads pool / lists / distribution of iteration it while writing its own, so consecutive iterations alternate
+    // between the caller's buffers and the handle's partners (the last iteration always uses the caller's).
+    const bool pingpong = c.dtype == ICEM_F32 && b->z_r == nullptr && h->use_fast && iters > 1;
+    if (pingpong && !h->actions_alt) {
+        ICEM_HIP_TRY(hipMalloc(&h->actions_alt, icem_plan_buffer_bytes(h, ICEM_BUF_ACTIONS)));
+        ICEM_HIP_TRY(hipMalloc(&h->ws_alt, icem_plan_buffer_bytes(h, ICEM_BUF_WORKSPACE)));
+        ICEM_HIP_TRY(hipMalloc((void**)&h->pp_stats, (size_t)4 * h->hd * sizeof(float)));
+    }
+    float* cur_mean = (float*)b->mean;  // where the current distribution lives
+    float* cur_std = (float*)b->std;
+    for (int it = 0; it < iters; ++it) {
+        icem_plan_buffers bb = *b;
+        if (pingpong) {
+            if ((iters - 1 - it) & 1) bb.actions = h->actions_alt;
+            if (it & 1) bb.workspace = h->ws_alt;
+            bb.mean = cur_mean;
+            bb.std = cur_std;
+        }
+        rc = icem_plan_iter_local(h, &bb, mpc_step, it, stream);
         if (rc) return rc;
-        rc = icem_plan_iter_merge(h, b, mpc_step, it, stream);
+        const bool last = it == iters - 1;
+        bool fold = false;
+        if (pingpong && !last && h->fast_lists > 0)
+            fold = sample_rollout_merge_ok(c.horizon, c.act_dim, h->O, c.rng_rounds, h->pop[it + 1], c.num_elites);
+        h->defer_merge = fold;
+        float* pp = pingpong ? h->pp_stats + (size_t)(it & 1) * 2 * h->hd : nullptr;
+        if (last) {  // the final distribution goes to the caller's buffers
+            h->merge_mean_out = (float*)b->mean;
+            h->merge_std_out = (float*)b->std;
+        } else if (fold) {
+            h->merge_mean_out = pp;
+            h->merge_std_out = pp + h->hd;
+        } else {
+            h->merge_mean_out = h->merge_std_out = nullptr;  // in place
+        }
+        rc = icem_plan_iter_merge(h, &bb, mpc_step, it, stream);
+        h->defer_merge = false;
+        h->merge_mean_out = h->merge_std_out = nullptr;
         if (rc) return rc;
+        if (fold && h->pm_pending) {
+            cur_mean = pp;
+            cur_std = pp + h->hd;
+        }
     }
     return ICEM_OK;
 }
