@@ -5,8 +5,9 @@ from icem_amd import IcemConfig, IcemPlanner, DeviceSyntheticModel, halfcheetah_
 from icem_amd import _lib as L
 env = halfcheetah_env(17)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 model = DeviceSyntheticModel.make(17, 6)
-pl = IcemPlanner(IcemConfig(horizon=30, act_dim=6, num_traj=N, opt_iters=1, dtype="f32", seed=1), env.action_space.low, env.action_space.high)
+pl = IcemPlanner(IcemConfig(horizon=30, act_dim=6, num_traj=N, opt_iters=ITERS, dtype="f32", seed=1), env.action_space.low, env.action_space.high)
 pl.set_model(model.kind, model.A, model.B)
 c = env.cost_spec
 pl.set_cost(c.ctrl_weight, c.lin_idx, c.lin_weight, c.flip_idx, c.flip_penalty, c.flip_thresh)
@@ -30,3 +31,5 @@ acc /= R
 print("merge  [us from kernel start]: lists loaded %.2f | keep merged %.2f | threshold+compact %.2f | selected %.2f | gather+refit %.2f | end %.2f" % tuple(acc[1:7]))
 print("single [us from kernel start]: staged %.2f | sampled %.2f | tile->HBM issued %.2f | rolled out %.2f | before wg merge %.2f | end %.2f" % tuple(acc[9:15]))
 print("gap end(single, wg 0) -> start(merge): %.2f us" % acc[15])
+print("(with ITERS > 1 the stamps are those of the LAST iteration: the single-launch kernel then carries the previous merge in its prologue"
+      " and 'sampled' includes selection + gather + refit + affine map)")
