@@ -687,3 +687,36 @@ def test_many_tiles_per_workgroup(h, d, o, kind, mode, N):
     idx = O.topk_sorted(pl.costs[:N].cpu().numpy(), pl.K)
     ea, ec = pl.current_elites()
     assert np.array_equal(np_(ec), costs[idx]) and np.array_equal(np_(ea), act[idx])
+
+
+@pytest.mark.parametrize("h,d,o,kind,N,iters", [(30, 6, 17, 0, 777, 4), (30, 6, 18, 1, 5001, 3), (13, 4, 17, 1, 12003, 4),
+                                                (12, 6, 17, 0, 4096, 5), (30, 6, 17, 0, 20011, 3)])
+def test_plan_step_merge_prologue_equals_split_api(h, d, o, kind, N, iters):
+    """icem_plan_step folds every merge but the last into the next iteration's launch (1, 2 or 4 rollout waves per
+    workgroup; N = 20011 mixes 8-wave launches without and 4-wave launches with the prologue) and ping-pongs the pool
+    between the caller's buffer and its own; the split API (icem_plan_iter_local / icem_plan_iter_merge, one merge
+    launch per iteration) must give the same bits: distribution, elites, executed action and last pool over 3 MPC steps."""
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner
+    low, high = -np.ones(d), np.ones(d)
+    model = DeviceSyntheticModel.make(o, d, kind=kind)
+    spec = O.CostSpec(0.1, 3, -1.0, 1, 10.0, 0.5)
+    pls = []
+    for _ in range(2):
+        pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=N, opt_iters=iters, dtype="f32", seed=11), low, high)
+        pl.set_model(kind, model.A, model.B)
+        pl.set_cost(spec.ctrl_weight, spec.lin_idx, spec.lin_weight, spec.flip_idx, spec.flip_penalty, spec.flip_thresh)
+        pl.reset()
+        pls.append(pl)
+    rs = np.random.RandomState(2)
+    for step in range(3):
+        obs = 0.2 * rs.randn(o)
+        a0 = np_(pls[0].plan_step(obs))
+        a1 = np_(pls[1].plan_step(obs, on_iteration=lambda it: None))
+        assert np.array_equal(a0, a1), step
+        for name in ("mean", "std", "best_cost"):
+            assert np.array_equal(np_(getattr(pls[0], name)), np_(getattr(pls[1], name))), (step, name)
+        (ea0, ec0), (ea1, ec1) = pls[0].current_elites(), pls[1].current_elites()
+        assert np.array_equal(np_(ea0), np_(ea1)) and np.array_equal(np_(ec0), np_(ec1)), step
+        n_last = pls[0].population_sizes[-1]
+        assert np.array_equal(np_(pls[0].actions[:n_last]), np_(pls[1].actions[:n_last])), step
+        assert np.array_equal(np_(pls[0].costs[:n_last]), np_(pls[1].costs[:n_last])), step
