@@ -957,8 +957,6 @@ static bool sample_rollout_shape(int h, int d, int O, int rounds, int n_rows, in
     if (rounds != 10 || rw > max_rw || n_rows <= 0 || !fast_rollout_supported(h, d, O, 1) || !fast_sample_supported(h, d))
         return false;
     if (rw > 8) rw = 8;  // several passes per workgroup
-    static const int min_rw = [] { const char* e = getenv("ICEM_FUSE_MIN_RW"); return e ? atoi(e) : 1; }();
-    if (rw < min_rw) rw = min_rw;
     *grid_out = std::min(grid, (n_rows + 16 * rw - 1) / (16 * rw));
     *rw_out = rw;
     return true;
