@@ -304,6 +304,8 @@ class MpcICemHip(MpcController):
             return self.noise_source
         if self.noise_source == "numpy_legacy":
             d, F = self.dim_samples[1], self.horizon // 2 + 1
+            if self.noise_beta <= 0:
+                return lambda num: (np.random.randn(num, self.horizon, d), None)  # icem.py:77
 
             def legacy(num):  # the two global-stream draws of colorednoise (call site icem.py:73)
                 return np.random.normal(size=(num, d, F)), np.random.normal(size=(num, d, F))

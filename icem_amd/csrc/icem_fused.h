@@ -25,6 +25,7 @@ struct FastSampleArgs {
     int n_shift;
     const float* elites_src;  // [>= n_shift, h, d]
     uint32_t off2_lo, off2_hi;
+    int white;  // noise_beta <= 0 (icem.py:77): normal t of a row is its sample at step t, no synthesis
 };
 bool fast_sample_supported(int h, int d);
 void launch_sample_folded(const FastSampleArgs& a, int rounds, hipStream_t st);

@@ -126,7 +126,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // draws in registers -> inverse real DFT folded on its symmetry; emit(t, y) receives sample y of step t.
 template <int H, int ROUNDS, typename Emit>
 __device__ __forceinline__ void sample_row(const float* __restrict__ W, unsigned gi, unsigned j, unsigned off_lo,
-                                           unsigned off_hi, unsigned seed_lo, unsigned seed_hi, Emit&& emit) {
+                                           unsigned off_hi, unsigned seed_lo, unsigned seed_hi, Emit&& emit,
+                                           bool white = false) {
     constexpr int F = H / 2 + 1;
     static_assert(H <= 32 && H >= 2, "white draws of a row live in 32 registers");
     float g[HMAX];
@@ -136,6 +137,11 @@ __device__ __forceinline__ void sample_row(const float* __restrict__ W, unsigned
         const uint32_t xa = rng.next();
         const uint32_t xb = rng.next();
         box_muller(xa, xb, g[m], g[m + 1]);
+    }
+    if (white) {  // wave-uniform: noise_beta <= 0, the draws are the samples (icem.py:77)
+#pragma unroll
+        for (int t = 0; t < H; ++t) emit(t, g[t]);
+        return;
     }
     {  // t = 0: every sine is zero
         float e0 = 0.f, e1 = 0.f;
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(SWG) void sample_folded_kernel(FastSampleArgs a) {
                                           v = v < lo ? lo : v;
                                           last = v > hi ? hi : v;
                                       }
-                                  });
+                                  }, a.white != 0);
             float* dst = a.out + (size_t)(a.n + e) * hd + j;
             const float* src = a.elites_src + (size_t)e * hd + j;
             for (int t = 0; t < H - 1; ++t) dst[t * d] = src[(t + 1) * d];
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(SWG) void sample_folded_kernel(FastSampleArgs a) {
                               a.seed_hi, [&](int t, float y) {
                                   const float v = __builtin_fmaf(y, mrow[hd + t * d], mrow[t * d]);
                                   trow[t * d] = __builtin_amdgcn_fmed3f(v, lo, hi);  // clip in one v_med3_f32
-                              });
+                              }, a.white != 0);
     }
     __syncthreads();
     if (a.row0_mean && a.first_index + n_base == 0) {  // icem.py:87-88
@@ -797,13 +803,13 @@ __global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64 + (KREG > 0 ? 64 : 0
             if (r < sa.n) {
                 if (raw) {
                     sample_row<H, ROUNDS>(sa.W, (unsigned)(sa.first_index + r), (unsigned)jd, sa.off_lo, sa.off_hi,
-                                          sa.seed_lo, sa.seed_hi, [&](int t, float y) { trow[t * D] = y; });
+                                          sa.seed_lo, sa.seed_hi, [&](int t, float y) { trow[t * D] = y; }, sa.white != 0);
                 } else {
                     sample_row<H, ROUNDS>(sa.W, (unsigned)(sa.first_index + r), (unsigned)jd, sa.off_lo, sa.off_hi,
                                           sa.seed_lo, sa.seed_hi, [&](int t, float y) {
                                               const float v = __builtin_fmaf(y, mrow[HD + t * D], mrow[t * D]);
                                               trow[t * D] = __builtin_amdgcn_fmed3f(v, lo, hi);
-                                          });
+                                          }, sa.white != 0);
                 }
             } else if (r < n_rows && !PM) {
                 // shifted elite e: elites[e, 1:, j] and a last action drawn from the full (n_shift, d, h) noise batch
@@ -816,7 +822,7 @@ __global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64 + (KREG > 0 ? 64 : 0
                                               const float v = __builtin_fmaf(y, mrow[HD + t * D], mrow[t * D]);
                                               last = __builtin_amdgcn_fmed3f(v, lo, hi);
                                           }
-                                      });
+                                      }, sa.white != 0);
                 const float* src = sa.elites_src + (size_t)e * HD + jd;
                 for (int t = 0; t < H - 1; ++t) trow[t * D] = src[(t + 1) * D];
                 trow[(H - 1) * D] = last;

@@ -83,12 +83,16 @@ struct SampleArgs {
     const T* zi;
     uint32_t seed_lo, seed_hi, off_lo, off_hi;
     int t_begin, row0_mean;
+    int white;  // noise_beta <= 0 (icem.py:77): zr is randn[n, h, d], zi unused; W is the identity
     T* out;
 };
 
 template <typename T, int HMAX, int ROUNDS>
 __device__ __forceinline__ void white_row(const SampleArgs<T>& a, int row_local, long long gi, int j, T (&g)[HMAX]) {
-    if (a.zr != nullptr) {
+    if (a.zr != nullptr && a.white) {
+#pragma unroll
+        for (int m = 0; m < HMAX; ++m) g[m] = m < a.h ? a.zr[((size_t)row_local * a.h + m) * a.d + j] : (T)0;
+    } else if (a.zr != nullptr) {
         const size_t base = ((size_t)row_local * a.d + j) * a.F;
 #pragma unroll
         for (int m = 0; m < HMAX; ++m) {
@@ -751,6 +755,7 @@ SampleArgs<T> make_sample_args(const icem_handle* h, int n, long long first_inde
     a.off_hi = (uint32_t)(offset >> 32);
     a.t_begin = t_begin;
     a.row0_mean = row0_mean;
+    a.white = h->cfg.noise_beta <= 0 ? 1 : 0;
     a.out = (T*)out;
     return a;
 }
@@ -959,6 +964,7 @@ FastSampleArgs fast_sample_args(const icem_handle* h, int n, long long first_ind
     a.elites_src = (const float*)elites_src;
     a.off2_lo = (uint32_t)offset2;
     a.off2_hi = (uint32_t)(offset2 >> 32);
+    a.white = h->cfg.noise_beta <= 0 ? 1 : 0;
     return a;
 }
 
@@ -1219,7 +1225,7 @@ int icem_create(const icem_config* cfg, icem_handle** out) {
     if (c.dtype != ICEM_F32 && c.dtype != ICEM_F64) return fail(ICEM_E_INVALID, "dtype");
     if (c.rng_rounds != 10 && c.rng_rounds != 7) return fail(ICEM_E_INVALID, "rng_rounds must be 10 or 7");
     if (c.world < 1 || c.rank < 0 || c.rank >= c.world) return fail(ICEM_E_INVALID, "rank/world");
-    if (!(c.noise_beta > 0)) return fail(ICEM_E_UNSUPPORTED, "noise_beta must be > 0");
+    if (c.noise_beta != c.noise_beta) return fail(ICEM_E_INVALID, "noise_beta is NaN");  // <= 0: white branch, icem.py:77
     if (!(c.factor_decrease >= 1.0)) return fail(ICEM_E_INVALID, "factor_decrease must be >= 1");
     if (c.cost_mode < 0 || c.cost_mode > 2)
         return fail(ICEM_E_UNSUPPORTED, "Implement method to compute cost along trajectory");  // abstract_controller.py:88-91
@@ -1237,11 +1243,17 @@ int icem_create(const icem_config* cfg, icem_handle** out) {
     for (int n_it : h->pop) h->n_local_max = std::max(h->n_local_max, shard_chunk(n_it, c.world));
     if (const char* e = getenv("ICEM_DISABLE_FAST")) h->use_fast = !(e[0] == '1');
     // synthesis table W[t][m]: m < F real part of bin m, F <= m < h imaginary part of bin m-F+1
+    // noise_beta <= 0 is the reference's white branch (np.random.randn(N, h, d), icem.py:77): draw t of a row is
+    // its sample at step t, i.e. the identity table
     std::vector<double> cr, ci, W((size_t)c.horizon * h->HMAX, 0.0);
-    noise_tables(c.horizon, c.noise_beta, cr, ci);
-    for (int t = 0; t < c.horizon; ++t)
-        for (int m = 0; m < c.horizon; ++m)
-            W[(size_t)t * h->HMAX + m] = m < h->F ? cr[(size_t)m * c.horizon + t] : ci[(size_t)(m - h->F + 1) * c.horizon + t];
+    if (c.noise_beta > 0) {
+        noise_tables(c.horizon, c.noise_beta, cr, ci);
+        for (int t = 0; t < c.horizon; ++t)
+            for (int m = 0; m < c.horizon; ++m)
+                W[(size_t)t * h->HMAX + m] = m < h->F ? cr[(size_t)m * c.horizon + t] : ci[(size_t)(m - h->F + 1) * c.horizon + t];
+    } else {
+        for (int t = 0; t < c.horizon; ++t) W[(size_t)t * h->HMAX + t] = 1.0;
+    }
     int rc = c.dtype == ICEM_F64 ? upload<double>(&h->W_dev, W) : upload<float>(&h->W_dev, W);
     if (rc) {
         delete h;
@@ -1314,7 +1326,8 @@ int icem_sample_clip(icem_handle* h, int32_t n, int64_t first_index, const void*
                      int32_t t_begin, int32_t row0_mean, void* actions, void* stream) {
     if (check_handle(h)) return ICEM_E_INVALID;
     if (n < 0 || !mean || !std || !low || !high || !actions) return fail(ICEM_E_INVALID, "null tensor / negative n");
-    if ((z_r == nullptr) != (z_i == nullptr)) return fail(ICEM_E_INVALID, "z_r and z_i must both be given or both NULL");
+    if (h->cfg.noise_beta > 0 && (z_r == nullptr) != (z_i == nullptr))
+        return fail(ICEM_E_INVALID, "z_r and z_i must both be given or both NULL");
     if (t_begin < 0 || t_begin >= h->cfg.horizon) return fail(ICEM_E_INVALID, "t_begin out of range");
     hipStream_t st = (hipStream_t)stream;
     if (z_r == nullptr && t_begin == 0 && fast_sample_ok(h))
@@ -1513,7 +1526,8 @@ static int check_plan(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_st
     if (!b->mean || !b->std || !b->low || !b->high || !b->obs0 || !b->actions || !b->costs || !b->elites || !b->records ||
         !b->workspace || !b->executed || !b->best_cost)
         return fail(ICEM_E_INVALID, "null plan buffer");
-    if ((b->z_r == nullptr) != (b->z_i == nullptr) || (b->z_r_shift == nullptr) != (b->z_i_shift == nullptr))
+    if (h->cfg.noise_beta > 0 &&
+        ((b->z_r == nullptr) != (b->z_i == nullptr) || (b->z_r_shift == nullptr) != (b->z_i_shift == nullptr)))
         return fail(ICEM_E_INVALID, "z_r/z_i must be given in pairs");
     return ICEM_OK;
 }

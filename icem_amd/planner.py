@@ -69,6 +69,7 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 # noise callback of the parity mode: noise(num_traj) -> (z_r, z_i) float64 arrays [num, d, F]
+# (noise_beta <= 0, the white branch of icem.py:77: -> (randn [num, h, d], None))
 NoiseFn = Callable[[int], Tuple[np.ndarray, np.ndarray]]
 
 
@@ -154,7 +155,9 @@ class IcemPlanner:
         """K1: ``MpcICem.sample_action_sequences`` (icem/controllers/icem.py:61-82)."""
         mean = self._t(mean, (self.h, self.d))
         std = self._t(std, (self.h, self.d))
-        if z_r is not None:
+        if z_r is not None and self.cfg.noise_beta <= 0:  # white branch (icem.py:77): the randn(n, h, d) draw itself
+            z_r, z_i = self._t(z_r, (n, self.h, self.d)), None
+        elif z_r is not None:
             z_r = self._t(z_r, (n, self.d, self.F))
             z_i = self._t(z_i, (n, self.d, self.F))
         if out is None:
@@ -316,16 +319,18 @@ class IcemPlanner:
                 if noise is not None:
                     n_it = self.population_sizes[it]
                     lo, hi = shard_range(n_it, cfg.rank, cfg.world)
-                    z_r, z_i = noise(n_it)  # the reference draws the whole batch (icem.py:73)
+                    z_r, z_i = noise(n_it)  # the reference draws the whole batch (icem.py:73 / :77)
                     zr = self._t(z_r[lo:hi])
-                    zi = self._t(z_i[lo:hi])
+                    zi = self._t(z_i[lo:hi]) if z_i is not None and cfg.noise_beta > 0 else None
                     keep += [zr, zi]
-                    self._cb.z_r, self._cb.z_i = zr.data_ptr(), zi.data_ptr()
+                    self._cb.z_r, self._cb.z_i = zr.data_ptr(), (zi.data_ptr() if zi is not None else None)
                     if it == 0 and cfg.shift_elites and self.mpc_step > 0 and self.n_reuse > 0:
                         s_r, s_i = noise(self.n_reuse)  # icem.py:102
-                        sr, si = self._t(s_r), self._t(s_i)
+                        sr = self._t(s_r)
+                        si = self._t(s_i) if s_i is not None and cfg.noise_beta > 0 else None
                         keep += [sr, si]
-                        self._cb.z_r_shift, self._cb.z_i_shift = sr.data_ptr(), si.data_ptr()
+                        self._cb.z_r_shift = sr.data_ptr()
+                        self._cb.z_i_shift = si.data_ptr() if si is not None else None
                 L.check(self.lib.icem_plan_iter_local(self._h, C.byref(self._cb), self.mpc_step, it, st))
                 if cfg.world > 1:
                     exchange_records(self.records, self.K, cfg.rank, cfg.world, self.group)

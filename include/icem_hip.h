@@ -71,7 +71,7 @@ typedef struct icem_config {
     double alpha;                 /* momentum                                            */
     double init_std;              /* relative to (high-low)/2 (icem.py:55-59)            */
     double fraction_reused;       /* xi = fraction_elites_reused                         */
-    double noise_beta;            /* colored-noise exponent (>0)                         */
+    double noise_beta;            /* colored-noise exponent; <= 0: white noise (icem.py:77) */
     uint64_t seed;                /* Philox key                                          */
 } icem_config;
 
@@ -125,6 +125,8 @@ int icem_set_cost(icem_handle* h, const icem_cost_spec* spec);
  * the same draws the reference takes from np.random); otherwise Philox4x32 keyed by
  * (cfg.seed, offset, first_index + i, j).  Only time steps t >= t_begin are written
  * (t_begin = h-1 restates the time_slice=slice(-1, None) call of icem.py:102).
+ * cfg.noise_beta <= 0 is the reference's white branch (np.random.randn(num_traj, h, d), icem.py:77): no synthesis,
+ * draw t of row (i, j) is its sample at step t; an external draw is then passed as z_r = randn [n, h, d], z_i NULL.
  * If row0_mean != 0 and first_index == 0, row 0 is overwritten with `mean` (icem.py:87-88). */
 int icem_sample_clip(icem_handle* h, int32_t n, int64_t first_index, const void* mean, const void* std,
                      const void* low, const void* high, const void* z_r, const void* z_i,
@@ -184,7 +186,8 @@ typedef struct icem_plan_buffers {
     void* best_cost;   /* [1]   out: min(costs) of the last iteration (icem.py:177)             */
     /* Optional external white noise for the CURRENT iteration (parity mode, NULL = Philox):
      * z_r/z_i [n_local, d, F] for the main batch; z_r_shift/z_i_shift [r, d, F] for the
-     * shifted elites' last action (iteration 0 only).                                          */
+     * shifted elites' last action (iteration 0 only).  noise_beta <= 0: z_r = randn [n_local, h, d] and
+     * z_r_shift = randn [r, h, d] (icem.py:77), z_i / z_i_shift NULL.                           */
     const void* z_r;
     const void* z_i;
     const void* z_r_shift;

@@ -125,17 +125,21 @@ void icem_c_sample_clip(int n, int h, int d, double beta, uint64_t seed, uint64_
     const int F = h / 2 + 1;
     double* cr = (double*)malloc(sizeof(double) * F * h);
     double* ci = (double*)malloc(sizeof(double) * F * h);
-    icem_c_noise_tables(h, beta, cr, ci);
+    if (beta > 0) icem_c_noise_tables(h, beta, cr, ci);
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < n; ++i) {
         double g[256], y[256];
         for (int j = 0; j < d; ++j) {
             white_row(seed, offset, (uint32_t)(first_index + i), (uint32_t)j, h, rounds, g);
-            for (int t = 0; t < h; ++t) y[t] = 0.0;
-            for (int k = 0; k < F; ++k) {
-                const double zr = g[k];
-                const double zi = (k >= 1 && F + k - 1 < h) ? g[F + k - 1] : 0.0;
-                for (int t = 0; t < h; ++t) y[t] += zr * cr[k * h + t] + zi * ci[k * h + t];
+            if (beta > 0) {
+                for (int t = 0; t < h; ++t) y[t] = 0.0;
+                for (int k = 0; k < F; ++k) {
+                    const double zr = g[k];
+                    const double zi = (k >= 1 && F + k - 1 < h) ? g[F + k - 1] : 0.0;
+                    for (int t = 0; t < h; ++t) y[t] += zr * cr[k * h + t] + zi * ci[k * h + t];
+                }
+            } else {
+                for (int t = 0; t < h; ++t) y[t] = g[t]; /* icem.py:77: white noise, draw t of the row is step t */
             }
             for (int t = 0; t < h; ++t) {
                 double v = y[t] * std[t * d + j] + mean[t * d + j];

@@ -222,6 +222,16 @@ def philox_white_noise(seed: int, offset: int, num: int, d: int, h: int,
     return z_r, z_i
 
 
+def philox_white_randn(seed: int, offset: int, num: int, d: int, h: int, first_index: int = 0, rounds: int = 10,
+                       dtype=np.float64) -> np.ndarray:
+    """The ``beta <= 0`` draw ``randn(num, h, d)`` (icem.py:77) from the device RNG: entry ``[n, t, j]`` is normal
+    ``t`` of row ``(n, j)``'s stream (the same streams as :func:`philox_white_noise`)."""
+    F = h // 2 + 1
+    z_r, z_i = philox_white_noise(seed, offset, num, d, h, first_index, rounds, dtype)
+    g = np.concatenate([z_r, z_i[..., 1:1 + (h - F)]], axis=-1)  # [num, d, h] in draw order
+    return np.ascontiguousarray(g.transpose([0, 2, 1]))
+
+
 class PhiloxNoiseSchedule:
     """Noise callback for :class:`IcemOracle` reproducing the device's Philox
     offsets: per MPC step ``s`` the main batch of iteration ``i`` uses offset
@@ -230,9 +240,10 @@ class PhiloxNoiseSchedule:
     main 1, ...); the shift batch is recognised by its position."""
 
     def __init__(self, seed: int, iters: int, d: int, h: int, shift: bool = True,
-                 rounds: int = 10, dtype=np.float64):
+                 rounds: int = 10, dtype=np.float64, white: bool = False):
         self.seed, self.iters, self.d, self.h = seed, iters, d, h
         self.shift, self.rounds, self.dtype = shift, rounds, dtype
+        self.white = white  # beta <= 0: return (randn[num, h, d], None)
         self.step = -1
         self.begin_step()
 
@@ -249,6 +260,8 @@ class PhiloxNoiseSchedule:
         else:
             off = base + self.it
             self.it += 1
+        if self.white:
+            return philox_white_randn(self.seed, off, num, self.d, self.h, 0, self.rounds, self.dtype), None
         return philox_white_noise(self.seed, off, num, self.d, self.h, 0, self.rounds, self.dtype)
 
 
@@ -260,9 +273,13 @@ class PhiloxNoiseSchedule:
 def sample_action_sequences(mean: np.ndarray, std: np.ndarray, low: np.ndarray, high: np.ndarray,
                             beta: float, z_r: np.ndarray, z_i: np.ndarray) -> np.ndarray:
     """``clip(colored[N,h,d]*std + mean, low, high)`` -- icem.py:73-79.
-    ``z_r, z_i`` are ``[N, d, F]``; result is ``[N, h, d]``."""
+    ``z_r, z_i`` are ``[N, d, F]``; result is ``[N, h, d]``.  ``beta <= 0``: white noise (icem.py:77),
+    ``z_r`` is the ``randn(N, h, d)`` draw itself and ``z_i`` is ignored."""
     h = mean.shape[0]
-    samples = colored_from_white(beta, h, z_r, z_i).transpose([0, 2, 1])
+    if beta > 0:
+        samples = colored_from_white(beta, h, z_r, z_i).transpose([0, 2, 1])
+    else:
+        samples = np.asarray(z_r)  # icem.py:77: np.random.randn(num_traj, h, d), passed in as z_r (z_i unused)
     return np.clip(samples * std + mean, low, high)
 
 
@@ -521,6 +538,7 @@ class IcemOracle:
     """Array-based restatement of ``MpcICem`` (no Rollout objects).
 
     ``noise(num_traj)`` must return the white draws ``(z_r, z_i) [num,d,F]``
+    (``(randn [num,h,d], None)`` when ``noise_beta <= 0``)
     for one ``sample_action_sequences`` call, in the order the reference makes
     those calls: per MPC step, main batch of iteration 0, then (if elites are
     shifted) the ``(n_reuse, d, h)`` batch, then the main batches of
@@ -549,10 +567,7 @@ class IcemOracle:
 
     def _sample(self, num_traj: int) -> np.ndarray:
         z_r, z_i = self.noise(num_traj)
-        if self.p.noise_beta > 0:
-            return sample_action_sequences(self.mean, self.std, self.low, self.high,
-                                           self.p.noise_beta, z_r, z_i)
-        raise NotImplementedError("beta <= 0 (white randn, icem.py:77) is not on the golden path")
+        return sample_action_sequences(self.mean, self.std, self.low, self.high, self.p.noise_beta, z_r, z_i)
 
     def get_action(self, obs: np.ndarray) -> np.ndarray:
         if not self.was_reset:

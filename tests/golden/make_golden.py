@@ -234,6 +234,14 @@ def run_case(name, *, N, h, d, o, beta, iters, seed, n_steps, kind, env_kind,
     ctrl.update_distributions = upd
 
     colorednoise.CALLS.clear()
+    orig_randn = np.random.randn
+    if beta <= 0:
+        # icem.py:77: white noise straight from np.random.randn(num_traj, h, d); record every draw as (z, empty, z)
+        def randn(*shape):
+            z = orig_randn(*shape)
+            colorednoise.CALLS.append((z.copy(), np.zeros((0,)), z.copy()))
+            return z
+        np.random.randn = randn
     np.random.seed(seed)
     obs_rs = np.random.RandomState(1000 + seed)
     obs = 0.1 * obs_rs.randn(o)
@@ -250,6 +258,7 @@ def run_case(name, *, N, h, d, o, beta, iters, seed, n_steps, kind, env_kind,
         nxt, _, _ = ctrl.forward_model.predict(observations=obs[None], states=None, actions=a[None])
         obs = nxt[0]
 
+    np.random.randn = orig_randn
     # costs must be tie-free for argsort to be well defined
     for c in log["costs"]:
         assert len(np.unique(c)) == len(c), "golden case has tied costs"
@@ -326,6 +335,9 @@ def main():
     run_case("final_noreuse_n40", N=40, h=10, d=3, o=17, beta=3.0, iters=3, seed=15,
              n_steps=2, kind=1, env_kind="halfcheetah", cost_mode="final",
              use_mean=False, keep=False, shift=False)
+    # beta = 0: the white-noise branch (np.random.randn(N, h, d), icem.py:77), elites shifted and kept
+    run_case("white_beta0_n64", N=64, h=30, d=6, o=17, beta=0.0, iters=3, seed=16,
+             n_steps=3, kind=0, env_kind="halfcheetah")
 
 
 if __name__ == "__main__":

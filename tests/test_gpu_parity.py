@@ -720,3 +720,39 @@ def test_plan_step_merge_prologue_equals_split_api(h, d, o, kind, N, iters):
         n_last = pls[0].population_sizes[-1]
         assert np.array_equal(np_(pls[0].actions[:n_last]), np_(pls[1].actions[:n_last])), step
         assert np.array_equal(np_(pls[0].costs[:n_last]), np_(pls[1].costs[:n_last])), step
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_white_noise_branch_philox_plan_matches_oracle(dtype):
+    """noise_beta = 0 (np.random.randn(N, h, d), icem.py:77) with the device RNG: draw t of row (n, j) is the sample
+    at step t.  Whole MPC steps (generic kernels in f64; single-launch + merge prologue kernels in f32, shifted and
+    kept elites) against the oracle driven by the same Philox counters."""
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env
+    env = halfcheetah_env(17)
+    model = DeviceSyntheticModel.make(17, 6, kind=0)
+    seed, iters, N, h, d = 5, 3, 600, 30, 6
+    spec = env.cost_spec
+    pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=N, opt_iters=iters, noise_beta=0.0, dtype=dtype, seed=seed),
+                     env.action_space.low, env.action_space.high)
+    pl.set_model(model.kind, model.A, model.B)
+    pl.set_cost(spec.ctrl_weight, spec.lin_idx, spec.lin_weight, spec.flip_idx, spec.flip_penalty, spec.flip_thresh)
+    pl.reset()
+    npdt = np.float64 if dtype == "f64" else np.float32
+    noise = O.PhiloxNoiseSchedule(seed, iters, d, h, dtype=npdt, white=True)
+    om, oc = O.SyntheticModel(model.A, model.B, model.kind), O.CostSpec.halfcheetah(17)
+    orc = O.IcemOracle(O.IcemParams(horizon=h, num_simulated_trajectories=N, opt_iterations=iters, noise_beta=0.0),
+                       env.action_space.low.astype(np.float64), env.action_space.high.astype(np.float64),
+                       lambda ob, ac: O.rollout_costs(om, oc, ob, ac),
+                       lambda num: (noise(num)[0].astype(np.float64), None))
+    orc.beginning_of_rollout()
+    t = dict(rtol=1e-9, atol=1e-11) if dtype == "f64" else dict(rtol=2e-4, atol=2e-5)
+    for s in range(3):
+        obs = 0.1 * np.random.RandomState(s).randn(17)
+        if s:
+            noise.begin_step()
+        np.testing.assert_allclose(np_(pl.plan_step(obs)), orc.get_action(obs), **t)
+    np.testing.assert_allclose(np_(pl.mean), orc.mean, **t)
+    # the stand-alone sampler agrees with the oracle's white draw for the same stream
+    z = O.philox_white_randn(seed, 7, 50, d, h, dtype=npdt)
+    ref = O.sample_action_sequences(orc.mean, orc.std, env.action_space.low, env.action_space.high, 0.0, z.astype(np.float64), None)
+    np.testing.assert_allclose(np_(pl.sample_clip(50, orc.mean, orc.std, offset=7)), ref, **tol(dtype))
