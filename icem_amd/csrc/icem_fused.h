@@ -82,6 +82,14 @@ struct MergeSingleArgs {
 };
 void launch_merge_single(const MergeSingleArgs& a, hipStream_t st);
 
+// K1 with the previous iteration's merge (last == 0) in its prologue, see sample_folded_merge_kernel
+struct FastSampleMergeArgs {
+    FastSampleArgs s;  // n_shift must be 0
+    MergeSingleArgs m;
+};
+bool sample_folded_merge_ok(int h, int d, int rounds, int K);
+void launch_sample_folded_merge(const FastSampleMergeArgs& a, hipStream_t st);
+
 // K1+K2+K3 in one launch (small populations): r.actions == s.out, r.n_rows == s.n + s.n_shift.
 struct FastIterArgs {
     FastSampleArgs s;

@@ -1035,7 +1035,9 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
             split_partial_ws<float>(b->workspace, one > 0 ? one : rollout_lists(c.horizon, c.act_dim, h->O, n_rows), K, &pc, &pi);
             bool prologue = false;
             if (h->pm_pending) {
-                prologue = one > 0 && sample_rollout_merge_ok(c.horizon, c.act_dim, h->O, c.rng_rounds, n_rows, K);
+                prologue = one > 0 ? sample_rollout_merge_ok(c.horizon, c.act_dim, h->O, c.rng_rounds, n_rows, K)
+                                   : (fast_sample_ok(h) && n_extra == 0 &&
+                                      sample_folded_merge_ok(c.horizon, c.act_dim, c.rng_rounds, K));
                 if (!prologue) {  // cannot ride along after all: run it now
                     ProfScope prof(h, ICEM_K_MERGE_REFIT, h->pm_args.n_lists * K + h->pm_args.n_keep, st);
                     launch_merge_single(h->pm_args, st);
@@ -1058,7 +1060,17 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                 lists = one;
             }
             if (one == 0) {
-                if (fast_sample_ok(h)) {
+                if (prologue) {
+                    FastSampleMergeArgs sm;
+                    sm.s = fast_sample_args(h, n_loc, lo, b->mean, b->std, b->low, b->high, off, row0, actions, 0, nullptr, 0);
+                    sm.m = h->pm_args;
+                    {
+                        ProfScope prof(h, ICEM_K_SAMPLE, (long long)n_loc * c.horizon, st);
+                        launch_sample_folded_merge(sm, st);
+                    }
+                    ICEM_HIP_TRY(hipGetLastError());
+                    rc = ICEM_OK;
+                } else if (fast_sample_ok(h)) {
                     rc = launch_fast_sample(h, n_loc, lo, b->mean, b->std, b->low, b->high, off, row0, actions, st,
                                             shift_in_sampler ? n_extra : 0, shift_src, call_base + (uint64_t)c.opt_iters);
                 } else {
@@ -1577,7 +1589,9 @@ int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step,
         const bool last = it == iters - 1;
         bool fold = false;
         if (pingpong && !last && h->fast_lists > 0)
-            fold = sample_rollout_merge_ok(c.horizon, c.act_dim, h->O, c.rng_rounds, h->pop[it + 1], c.num_elites);
+            fold = sample_rollout_merge_ok(c.horizon, c.act_dim, h->O, c.rng_rounds, h->pop[it + 1], c.num_elites) ||
+                   (sample_rollout_lists(c.horizon, c.act_dim, h->O, c.rng_rounds, h->pop[it + 1]) == 0 && fast_sample_ok(h) &&
+                    sample_folded_merge_ok(c.horizon, c.act_dim, c.rng_rounds, c.num_elites));
         h->defer_merge = fold;
         float* pp = pingpong ? h->pp_stats + (size_t)(it & 1) * 2 * h->hd : nullptr;
         if (last) {  // the final distribution goes to the caller's buffers

@@ -690,10 +690,12 @@ def test_many_tiles_per_workgroup(h, d, o, kind, mode, N):
 
 
 @pytest.mark.parametrize("h,d,o,kind,N,iters", [(30, 6, 17, 0, 777, 4), (30, 6, 18, 1, 5001, 3), (13, 4, 17, 1, 12003, 4),
-                                                (12, 6, 17, 0, 4096, 5), (30, 6, 17, 0, 20011, 3)])
+                                                (12, 6, 17, 0, 4096, 5), (30, 6, 17, 0, 20011, 3),
+                                                (30, 6, 17, 0, 65536, 4), (13, 4, 17, 1, 50001, 3)])
 def test_plan_step_merge_prologue_equals_split_api(h, d, o, kind, N, iters):
     """icem_plan_step folds every merge but the last into the next iteration's launch (1, 2 or 4 rollout waves per
-    workgroup; N = 20011 mixes 8-wave launches without and 4-wave launches with the prologue) and ping-pongs the pool
+    workgroup; N = 20011 mixes 8-wave launches without and 4-wave launches with the prologue; N >= 50001 uses the
+    sampler kernel with the prologue followed by the rollout kernel) and ping-pongs the pool
     between the caller's buffer and its own; the split API (icem_plan_iter_local / icem_plan_iter_merge, one merge
     launch per iteration) must give the same bits: distribution, elites, executed action and last pool over 3 MPC steps."""
     from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner
