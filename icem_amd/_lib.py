@@ -77,6 +77,7 @@ SYMBOLS = [
     ("icem_record_bytes", _SZ, [_H]),
     ("icem_profile_enable", C.c_int, [_H, _I32]),
     ("icem_debug_stamps", C.c_int, [_H, _VP]),
+    ("icem_set_merge_deferral", C.c_int, [_H, C.c_int32]),
     ("icem_profile_read", C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 ]
 

@@ -65,6 +65,10 @@ struct MergeSingleArgs {
     int K, h, d, last;
     float alpha, init_std;
     const unsigned long long* part_k;  // [K, n_lists] packed candidate keys (FastRolloutArgs::part_k)
+    // sharded runs (merge prologues only): the candidates are the all-gathered records {cost, gidx, actions[h*d]}
+    // instead of lists + pool (part_k / actions / n_lists / n_pool unused)
+    const float* records;  // [n_rec, 2 + h*d] or nullptr
+    int n_rec;
     const float* actions;
     const float* elites_cur;
     const float* elites_cost_cur;

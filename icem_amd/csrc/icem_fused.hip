@@ -727,14 +727,79 @@ __device__ __forceinline__ void merge_select_stream(const MergeSingleArgs& a, in
     }
 }
 
+// Sharded runs: the candidates are n_rec <= 128 all-gathered records {cost, gidx, actions} (+ kept elites).  Two
+// records and one kept elite per lane; same threshold selection; slot[r] receives the record number of selected key
+// r (n_rec + e for kept elite e).  Ties cannot occur: keys embed the global trajectory index.
+__device__ __forceinline__ void merge_select_records(const MergeSingleArgs& a, int lane, unsigned long long* cand,
+                                                     unsigned long long* sel, int* slot) {
+    const int K = a.K, rs = a.h * a.d + 2;
+    auto rec_key = [&](int e) -> unsigned long long {
+        if (e >= a.n_rec) return KEY_SENTINEL;
+        const float* rec = a.records + (size_t)e * rs;
+        return make_key(rec[0], reinterpret_cast<const int*>(rec + 1)[0]);
+    };
+    unsigned long long k[3] = {rec_key(lane), rec_key(lane + 64),
+                               lane < a.n_keep ? make_key(a.elites_cost_cur[lane], a.n_global + lane) : KEY_SENTINEL};
+    const unsigned long long k0 = k[0], k1 = k[1], k2 = k[2];
+    unsigned long long mine = k0 < k1 ? k0 : k1;
+    mine = k2 < mine ? k2 : mine;
+    const unsigned long long srt = wave_sort64(mine, lane);
+    const unsigned long long T = __shfl(srt, K - 1, 64);
+    unsigned n_cand = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const bool p = k[i] <= T && k[i] != KEY_SENTINEL;
+        const unsigned long long m = __ballot(p);
+        const unsigned pos = n_cand + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (p && pos < 64) cand[pos] = k[i];
+        n_cand += (unsigned)__popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    if (n_cand <= 64) {
+        unsigned long long key = lane < (int)n_cand ? *((volatile unsigned long long*)&cand[lane]) : KEY_SENTINEL;
+        key = wave_sort64(key, lane);
+        if (lane < K) sel[lane] = key;
+    } else {
+        for (int r = 0; r < K; ++r) {
+            unsigned long long head = k[0] < k[1] ? k[0] : k[1];
+            head = k[2] < head ? k[2] : head;
+            const unsigned long long best = wave_min_u64(head);
+            if (best != KEY_SENTINEL) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    if (k[i] == best) k[i] = KEY_SENTINEL;
+            }
+            if (lane == 0) sel[r] = best;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    for (int r = 0; r < K; ++r) {
+        const unsigned long long s = *((volatile unsigned long long*)&sel[r]);
+        if (s != KEY_SENTINEL) {
+            if (k0 == s) slot[r] = lane;
+            if (k1 == s) slot[r] = lane + 64;
+            if (k2 == s) slot[r] = a.n_rec + lane;
+        } else if (lane == 0) {
+            slot[r] = 0;  // fewer than K live candidates: reference behaviour undefined, stay in bounds
+        }
+    }
+}
+
 // pointers to the K selected rows (icem.py:201): pool rows, or kept elites behind index n_global
 template <int KREG>
-__device__ __forceinline__ void merge_rows(const MergeSingleArgs& a, const unsigned long long* sel, const float* (&rows)[KREG]) {
+__device__ __forceinline__ void merge_rows(const MergeSingleArgs& a, const unsigned long long* sel, const int* slot,
+                                           const float* (&rows)[KREG]) {
     const int hd = a.h * a.d;
 #pragma unroll
     for (int r = 0; r < KREG; ++r) {
-        const int g = key_idx(sel[r < a.K ? r : 0]);
-        rows[r] = g < a.n_pool ? a.actions + (size_t)g * hd : a.elites_cur + (size_t)(g - a.n_global) * hd;
+        const int rr = r < a.K ? r : 0;
+        if (a.records) {  // wave-uniform
+            const int e = slot[rr];
+            rows[r] = e < a.n_rec ? a.records + (size_t)e * (hd + 2) + 2 : a.elites_cur + (size_t)(e - a.n_rec) * hd;
+        } else {
+            const int g = key_idx(sel[rr]);
+            rows[r] = g < a.n_pool ? a.actions + (size_t)g * hd : a.elites_cur + (size_t)(g - a.n_global) * hd;
+        }
     }
 }
 
@@ -763,7 +828,7 @@ __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs 
     __syncthreads();
     // ---- all 4 waves: gather + refit (icem.py:201-211); row pointers first, then all K loads in flight ----
     const float* rows[KREG];
-    merge_rows<KREG>(a, sel, rows);
+    merge_rows<KREG>(a, sel, nullptr, rows);
     auto finish_one = [&](int e, float old_mean, float old_std) {
         float xs[KREG];
 #pragma unroll
@@ -817,6 +882,7 @@ __global__ __launch_bounds__(SWG + 64) void sample_folded_merge_kernel(FastSampl
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ unsigned long long sel[64];
     __shared__ unsigned long long cand[64];
+    __shared__ int slot[64];
     constexpr int NTT = SWG + 64;
     const FastSampleArgs& a = args.s;
     const MergeSingleArgs& m = args.m;
@@ -834,7 +900,10 @@ __global__ __launch_bounds__(SWG + 64) void sample_folded_merge_kernel(FastSampl
     const int j = tid - nl * d;
     float* trow = tile + nl * hd + j;
     if (tid >= SWG) {
-        merge_select_stream(m, lane, cand, sel);
+        if (m.records)
+            merge_select_records(m, lane, cand, sel, slot);
+        else
+            merge_select_stream(m, lane, cand, sel);
     } else if (has_row) {
         sample_row<H, ROUNDS>(a.W, (unsigned)(a.first_index + n_base + nl), (unsigned)j, a.off_lo, a.off_hi, a.seed_lo,
                               a.seed_hi, [&](int t, float y) { trow[t * d] = y; }, a.white != 0);
@@ -842,7 +911,7 @@ __global__ __launch_bounds__(SWG + 64) void sample_folded_merge_kernel(FastSampl
     __syncthreads();
     {
         const float* rows[KREG];
-        merge_rows<KREG>(m, sel, rows);
+        merge_rows<KREG>(m, sel, slot, rows);
         for (int e = tid; e < hd; e += NTT) {
             float xs[KREG];
 #pragma unroll
@@ -919,6 +988,7 @@ __global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64 + (KREG > 0 ? 64 : 0
     __shared__ unsigned long long wg_keys[2][RW][32];
     __shared__ unsigned long long sel[PM ? 64 : 1];
     __shared__ unsigned long long cand[PM ? 64 : 1];
+    __shared__ int slot[PM ? 64 : 1];
     float* tile_rows = tilebuf + Tile::SLACK;
     const FastSampleArgs& sa = a.s;
     const FastRolloutArgs& ra = a.r;
@@ -986,11 +1056,16 @@ __global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64 + (KREG > 0 ? 64 : 0
         if constexpr (PM) {
             if (first) {
                 const MergeSingleArgs& m = a.m;
-                if (tid >= NT) merge_select<KREG>(m, lane, cand, sel);
+                if (tid >= NT) {
+                    if (m.records)
+                        merge_select_records(m, lane, cand, sel, slot);
+                    else
+                        merge_select<KREG>(m, lane, cand, sel);
+                }
                 __syncthreads();
                 // all threads: gather the elite rows + refit (icem.py:201-211) -> this workgroup's mean / std
                 const float* rows[KREG > 0 ? KREG : 1];
-                merge_rows<KREG>(m, sel, rows);
+                merge_rows<KREG>(m, sel, slot, rows);
                 for (int e = tid; e < HD; e += NTT) {
                     float xs[KREG > 0 ? KREG : 1];
 #pragma unroll

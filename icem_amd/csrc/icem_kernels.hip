@@ -512,7 +512,9 @@ struct MergeArgs {
     const T* elites_cost_cur;  // [K]
     T* elites_next;
     T* elites_cost_next;
-    T* mean;
+    const T* mean_in;  // distribution before the refit (momentum term)
+    const T* std_in;
+    T* mean;           // ... and where the new one goes (may alias)
     T* std;
     const T* low;
     const T* high;
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(WG) void merge_refit_kernel(MergeArgs<T> a) {
     for (int e = threadIdx.x; e < hd; e += WG) {
         for (int r = 0; r < a.K; ++r) a.elites_next[(size_t)r * hd + e] = src_row(r)[e];
         T nm, ns;
-        refit_element<T>(a.K, a.alpha, a.mean[e], a.std[e], [&](int r) { return src_row(r)[e]; }, nm, ns);
+        refit_element<T>(a.K, a.alpha, a.mean_in[e], a.std_in[e], [&](int r) { return src_row(r)[e]; }, nm, ns);
         if (!a.last) {
             a.mean[e] = nm;
             a.std[e] = ns;
@@ -612,6 +614,11 @@ struct icem_handle {
     MergeSingleArgs pm_args;
     float* merge_mean_out = nullptr;    // where the next merge writes mean / std (nullptr: in place)
     float* merge_std_out = nullptr;
+    // world > 1 with icem_set_merge_deferral(on): the same folding across the split calls; the distribution of the
+    // running MPC step lives at cur_mean / cur_std (the caller's buffers or pp_stats)
+    bool deferral = false;
+    float* cur_mean = nullptr;
+    float* cur_std = nullptr;
     // permuted, padded model of the matrix-pipe rollout: column 0 = obs[lin_idx], column 1 = obs[flip_idx]
     void* Mp_dev = nullptr;
     void* perm_dev = nullptr;
@@ -982,6 +989,54 @@ int launch_fast_sample(const icem_handle* h, int n, long long first_index, const
     return ICEM_OK;
 }
 
+// Can the f32 launch of an iteration with n_rows local rows (no shifted elites) carry a merge in its prologue?
+// (single-launch kernel with <= 4 rollout waves, or the sampler of the two-kernel path)
+bool prologue_possible(const icem_handle* h, int n_rows) {
+    const icem_config& c = h->cfg;
+    const int K = c.num_elites;
+    if (c.dtype != ICEM_F32 || !fast_rollout_ok(h, K) || !fast_sample_ok(h) || n_rows <= 0) return false;
+    if (sample_rollout_lists(c.horizon, c.act_dim, h->O, c.rng_rounds, n_rows) > 0)
+        return sample_rollout_merge_ok(c.horizon, c.act_dim, h->O, c.rng_rounds, n_rows, K);
+    return sample_folded_merge_ok(c.horizon, c.act_dim, c.rng_rounds, K);
+}
+
+// a stashed merge that found no launch to ride in
+int launch_pending_merge(icem_handle* h, hipStream_t st) {
+    const MergeSingleArgs& m = h->pm_args;
+    if (m.records == nullptr) {
+        ProfScope prof(h, ICEM_K_MERGE_REFIT, m.n_lists * m.K + m.n_keep, st);
+        launch_merge_single(m, st);
+    } else {
+        MergeArgs<float> a;
+        a.n_rec = m.n_rec;
+        a.n_keep = m.n_keep;
+        a.K = m.K;
+        a.h = m.h;
+        a.d = m.d;
+        a.n_global = m.n_global;
+        a.last = 0;
+        a.alpha = m.alpha;
+        a.init_std = m.init_std;
+        a.records = m.records;
+        a.elites_cur = m.elites_cur;
+        a.elites_cost_cur = m.elites_cost_cur;
+        a.elites_next = m.elites_next;
+        a.elites_cost_next = m.elites_cost_next;
+        a.mean_in = m.mean;
+        a.std_in = m.std;
+        a.mean = m.mean_out;
+        a.std = m.std_out;
+        a.low = m.low;
+        a.high = m.high;
+        a.executed = m.executed;
+        a.best_cost = m.best_cost;
+        ProfScope prof(h, ICEM_K_MERGE_REFIT, a.n_rec + a.n_keep, st);
+        hipLaunchKernelGGL((merge_refit_kernel<float>), dim3(1), dim3(WG), (size_t)m.h * m.d * sizeof(float), st, a);
+    }
+    ICEM_HIP_TRY(hipGetLastError());
+    return ICEM_OK;
+}
+
 template <typename T>
 int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, int it, hipStream_t st) {
     const icem_config& c = h->cfg;
@@ -1035,12 +1090,10 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
             split_partial_ws<float>(b->workspace, one > 0 ? one : rollout_lists(c.horizon, c.act_dim, h->O, n_rows), K, &pc, &pi);
             bool prologue = false;
             if (h->pm_pending) {
-                prologue = one > 0 ? sample_rollout_merge_ok(c.horizon, c.act_dim, h->O, c.rng_rounds, n_rows, K)
-                                   : (fast_sample_ok(h) && n_extra == 0 &&
-                                      sample_folded_merge_ok(c.horizon, c.act_dim, c.rng_rounds, K));
+                prologue = n_extra == 0 && prologue_possible(h, n_rows);
                 if (!prologue) {  // cannot ride along after all: run it now
-                    ProfScope prof(h, ICEM_K_MERGE_REFIT, h->pm_args.n_lists * K + h->pm_args.n_keep, st);
-                    launch_merge_single(h->pm_args, st);
+                    rc = launch_pending_merge(h, st);
+                    if (rc) return rc;
                 }
                 h->pm_pending = false;
             }
@@ -1142,6 +1195,8 @@ int plan_iter_merge_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
             m.alpha = (float)c.alpha;
             m.init_std = (float)c.init_std;
             m.part_k = (const unsigned long long*)b->workspace;
+            m.records = nullptr;
+            m.n_rec = 0;
             m.actions = (const float*)b->actions;
             m.elites_cur = (const float*)el + (size_t)cur * K * hd;
             m.elites_cost_cur = (const float*)elc + (size_t)cur * K;
@@ -1182,12 +1237,49 @@ int plan_iter_merge_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
     a.elites_cost_cur = elc + (size_t)cur * K;
     a.elites_next = el + (size_t)nxt * K * hd;
     a.elites_cost_next = elc + (size_t)nxt * K;
-    a.mean = (T*)b->mean;
-    a.std = (T*)b->std;
+    a.mean_in = (const T*)b->mean;
+    a.std_in = (const T*)b->std;
+    a.mean = h->merge_mean_out ? (T*)h->merge_mean_out : (T*)b->mean;
+    a.std = h->merge_std_out ? (T*)h->merge_std_out : (T*)b->std;
     a.low = (const T*)b->low;
     a.high = (const T*)b->high;
     a.executed = (T*)b->executed;
     a.best_cost = (T*)b->best_cost;
+    if constexpr (std::is_same<T, float>::value) {
+        if (h->defer_merge && !a.last) {  // rides in the next iteration's launch, candidates = the gathered records
+            MergeSingleArgs m{};
+            m.n_lists = 0;
+            m.n_keep = a.n_keep;
+            m.n_pool = 0;
+            m.n_global = a.n_global;
+            m.K = K;
+            m.h = a.h;
+            m.d = a.d;
+            m.last = 0;
+            m.alpha = a.alpha;
+            m.init_std = a.init_std;
+            m.part_k = nullptr;
+            m.records = a.records;
+            m.n_rec = a.n_rec;
+            m.actions = nullptr;
+            m.elites_cur = a.elites_cur;
+            m.elites_cost_cur = a.elites_cost_cur;
+            m.elites_next = a.elites_next;
+            m.elites_cost_next = a.elites_cost_next;
+            m.mean = a.mean_in;
+            m.std = a.std_in;
+            m.mean_out = a.mean;
+            m.std_out = a.std;
+            m.low = a.low;
+            m.high = a.high;
+            m.executed = a.executed;
+            m.best_cost = a.best_cost;
+            m.dbg = nullptr;
+            h->pm_args = m;
+            h->pm_pending = true;
+            return ICEM_OK;
+        }
+    }
     {
         ProfScope prof(h, ICEM_K_MERGE_REFIT, a.n_rec + a.n_keep, st);
         hipLaunchKernelGGL((merge_refit_kernel<T>), dim3(1), dim3(WG), (size_t)hd * sizeof(T), st, a);
@@ -1544,18 +1636,83 @@ static int check_plan(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_st
     return ICEM_OK;
 }
 
+// rows of this rank's shard at iteration `it`
+static int local_rows(const icem_handle* h, int it) {
+    const int n_global = h->pop[it];
+    const int chunk = shard_chunk(n_global, h->cfg.world);
+    const int lo = std::min(n_global, h->cfg.rank * chunk);
+    return std::max(0, std::min(n_global - lo, chunk));
+}
+
+static int ensure_pp_stats(icem_handle* h) {
+    if (!h->pp_stats) ICEM_HIP_TRY(hipMalloc((void**)&h->pp_stats, (size_t)4 * h->hd * sizeof(float)));
+    return ICEM_OK;
+}
+
+// world > 1 with merge deferral: the running step's distribution is at cur_mean / cur_std
+static bool deferral_active(const icem_handle* h, const icem_plan_buffers* b) {
+    return h->deferral && h->cfg.world > 1 && h->cfg.dtype == ICEM_F32 && b->z_r == nullptr && h->use_fast;
+}
+
+int icem_set_merge_deferral(icem_handle* h, int32_t on) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (h->pm_pending) return fail(ICEM_E_STATE, "a deferred merge is pending: finish the MPC step first");
+    h->deferral = on != 0;
+    return ICEM_OK;
+}
+
 int icem_plan_iter_local(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, int32_t it, void* stream) {
     int rc = check_plan(h, b, mpc_step, it);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    return ICEM_DISPATCH(h, plan_iter_local_t<float>(h, b, mpc_step, it, st), plan_iter_local_t<double>(h, b, mpc_step, it, st));
+    icem_plan_buffers bb = *b;
+    if (deferral_active(h, b)) {
+        if (it == 0 || !h->cur_mean) {
+            h->cur_mean = (float*)b->mean;
+            h->cur_std = (float*)b->std;
+        }
+        bb.mean = h->cur_mean;
+        bb.std = h->cur_std;
+    }
+    return ICEM_DISPATCH(h, plan_iter_local_t<float>(h, &bb, mpc_step, it, st), plan_iter_local_t<double>(h, &bb, mpc_step, it, st));
 }
 
 int icem_plan_iter_merge(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, int32_t it, void* stream) {
     int rc = check_plan(h, b, mpc_step, it);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    return ICEM_DISPATCH(h, plan_iter_merge_t<float>(h, b, mpc_step, it, st), plan_iter_merge_t<double>(h, b, mpc_step, it, st));
+    if (!deferral_active(h, b) || !h->cur_mean)
+        return ICEM_DISPATCH(h, plan_iter_merge_t<float>(h, b, mpc_step, it, st), plan_iter_merge_t<double>(h, b, mpc_step, it, st));
+    // sharded, deferral on: a non-last merge may ride in the next icem_plan_iter_local launch (mean / std / elites in
+    // the caller's buffers are then current again only after that launch; the last merge always runs here)
+    rc = ensure_pp_stats(h);
+    if (rc) return rc;
+    const bool last = it == h->cfg.opt_iters - 1;
+    const bool fold = !last && h->fast_lists > 0 && prologue_possible(h, local_rows(h, it + 1));
+    icem_plan_buffers bb = *b;
+    bb.mean = h->cur_mean;
+    bb.std = h->cur_std;
+    float* pp = h->pp_stats + (size_t)(it & 1) * 2 * h->hd;
+    h->defer_merge = fold;
+    if (last) {
+        h->merge_mean_out = (float*)b->mean;
+        h->merge_std_out = (float*)b->std;
+    } else if (fold) {
+        h->merge_mean_out = pp;
+        h->merge_std_out = pp + h->hd;
+    } else {
+        h->merge_mean_out = h->merge_std_out = nullptr;
+    }
+    rc = plan_iter_merge_t<float>(h, &bb, mpc_step, it, st);
+    h->defer_merge = false;
+    h->merge_mean_out = h->merge_std_out = nullptr;
+    if (rc) return rc;
+    if (fold && h->pm_pending) {
+        h->cur_mean = pp;
+        h->cur_std = pp + h->hd;
+    }
+    if (last) h->cur_mean = h->cur_std = nullptr;
+    return ICEM_OK;
 }
 
 int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, void* stream) {
@@ -1572,7 +1729,10 @@ int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step,
     if (pingpong && !h->actions_alt) {
         ICEM_HIP_TRY(hipMalloc(&h->actions_alt, icem_plan_buffer_bytes(h, ICEM_BUF_ACTIONS)));
         ICEM_HIP_TRY(hipMalloc(&h->ws_alt, icem_plan_buffer_bytes(h, ICEM_BUF_WORKSPACE)));
-        ICEM_HIP_TRY(hipMalloc((void**)&h->pp_stats, (size_t)4 * h->hd * sizeof(float)));
+    }
+    if (pingpong) {
+        rc = ensure_pp_stats(h);
+        if (rc) return rc;
     }
     float* cur_mean = (float*)b->mean;  // where the current distribution lives
     float* cur_std = (float*)b->std;
@@ -1588,10 +1748,7 @@ int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step,
         if (rc) return rc;
         const bool last = it == iters - 1;
         bool fold = false;
-        if (pingpong && !last && h->fast_lists > 0)
-            fold = sample_rollout_merge_ok(c.horizon, c.act_dim, h->O, c.rng_rounds, h->pop[it + 1], c.num_elites) ||
-                   (sample_rollout_lists(c.horizon, c.act_dim, h->O, c.rng_rounds, h->pop[it + 1]) == 0 && fast_sample_ok(h) &&
-                    sample_folded_merge_ok(c.horizon, c.act_dim, c.rng_rounds, c.num_elites));
+        if (pingpong && !last && h->fast_lists > 0) fold = prologue_possible(h, h->pop[it + 1]);
         h->defer_merge = fold;
         float* pp = pingpong ? h->pp_stats + (size_t)(it & 1) * 2 * h->hd : nullptr;
         if (last) {  // the final distribution goes to the caller's buffers

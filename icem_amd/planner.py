@@ -248,10 +248,13 @@ class IcemPlanner:
         if self.cfg.world == 1:
             L.check(self.lib.icem_plan_step(self._h, C.byref(self._cb), self.mpc_step, st))
         else:
+            # non-last merges ride in the next iteration's launch (nobody looks at mean / std in between)
+            L.check(self.lib.icem_set_merge_deferral(self._h, 1))
             for it in range(self.cfg.opt_iters):
                 L.check(self.lib.icem_plan_iter_local(self._h, C.byref(self._cb), self.mpc_step, it, st))
                 exchange_records(self.records, self.K, self.cfg.rank, self.cfg.world, self.group)
                 L.check(self.lib.icem_plan_iter_merge(self._h, C.byref(self._cb), self.mpc_step, it, st))
+            L.check(self.lib.icem_set_merge_deferral(self._h, 0))
         self.mpc_step += 1
 
     # ------------------------------------------------------------------ fused MPC step

@@ -214,6 +214,12 @@ int icem_plan_iter_local(icem_handle* h, const icem_plan_buffers* b, int32_t mpc
  * (icem.py:149-175, 194-211). */
 int icem_plan_iter_merge(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, int32_t it,
                          void* stream);
+/* Sharded runs (world > 1): allow icem_plan_iter_merge of a non-last iteration to postpone its work into the next
+ * icem_plan_iter_local launch of the same MPC step (the merge of the gathered records then runs in that launch's
+ * prologue, next to the sampling; one kernel launch less per iteration).  While on, mean / std / elites in the plan
+ * buffers are current only after the LAST icem_plan_iter_merge of an MPC step.  Off by default. */
+int icem_set_merge_deferral(icem_handle* h, int32_t on);
+
 /* Whole MPC step for world == 1: opt_iters x (local + merge), no host synchronisation
  * (the body of MpcICem.get_action, icem.py:123-175). */
 int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, void* stream);

@@ -50,8 +50,8 @@ def test_create_rejects_bad_config_like_the_reference(lib):
     cfg = IcemConfig(horizon=30, act_dim=6, num_traj=1).to_c()
     rc = lib.icem_create(C.byref(cfg), C.byref(h))
     assert rc == -1 and b"At least two trajectories needed!" in lib.icem_last_error()  # mpc.py:30-31
-    cfg = IcemConfig(horizon=30, act_dim=6, num_traj=64, noise_beta=0.0).to_c()
-    assert lib.icem_create(C.byref(cfg), C.byref(h)) == -2
+    cfg = IcemConfig(horizon=30, act_dim=6, num_traj=64, noise_beta=float("nan")).to_c()
+    assert lib.icem_create(C.byref(cfg), C.byref(h)) == -1  # (beta <= 0 is valid: the white branch, icem.py:77)
     with pytest.raises(NotImplementedError):
         IcemConfig(horizon=30, act_dim=6, num_traj=64, cost_mode="median").to_c()
 

@@ -353,11 +353,13 @@ def test_controller_host_model_path(name):
         np.testing.assert_allclose(a, g.executed[s], rtol=F64_RTOL, atol=F64_ATOL)
 
 
+@pytest.mark.parametrize("deferral", [False, True])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-def test_philox_plan_matches_oracle_and_is_shard_invariant(dtype):
+def test_philox_plan_matches_oracle_and_is_shard_invariant(dtype, deferral):
     """Philox mode end to end: (a) world=1 fused step == oracle driven by the same counters;
     (b) world=2 and world=3, emulated on one GPU by two/three planners whose records are
-    concatenated in place of the all-gather, reproduce world=1 (RNG keyed by the global index)."""
+    concatenated in place of the all-gather, reproduce world=1 (RNG keyed by the global index) -- also with
+    icem_set_merge_deferral on, where every merge but the last of a step runs in the next launch's prologue."""
     from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env
     env = halfcheetah_env(17)
     model = DeviceSyntheticModel.make(17, 6, kind=1)
@@ -396,9 +398,11 @@ def test_philox_plan_matches_oracle_and_is_shard_invariant(dtype):
     # (b) shard invariance
     import ctypes as C
     from icem_amd import _lib as L
-    for world in (2, 3):
+    for world in (2, 3, 8):
         pls = [mk(r, world) for r in range(world)]
         st = pls[0]._stream()
+        for pl in pls:  # deferral: non-last merges ride in the next icem_plan_iter_local launch (f32 fast path only)
+            L.check(pl.lib.icem_set_merge_deferral(pl._h, int(deferral)))
         for s, o in enumerate(obs_seq):
             for pl in pls:
                 pl.obs0.copy_(torch.as_tensor(o, dtype=pl.dt))
@@ -758,3 +762,52 @@ def test_white_noise_branch_philox_plan_matches_oracle(dtype):
     z = O.philox_white_randn(seed, 7, 50, d, h, dtype=npdt)
     ref = O.sample_action_sequences(orc.mean, orc.std, env.action_space.low, env.action_space.high, 0.0, z.astype(np.float64), None)
     np.testing.assert_allclose(np_(pl.sample_clip(50, orc.mean, orc.std, offset=7)), ref, **tol(dtype))
+
+
+@pytest.mark.parametrize("N,world", [(140000, 2), (40000, 4)])
+def test_sharded_deferred_merge_large_shards(N, world):
+    """Shards of 70 000 (sampler + rollout kernels, merge of the gathered records in the sampler's prologue) and of
+    10 000 rows (single-launch kernel with the records merge in its prologue), ranks emulated on one GPU, deferral
+    on: same executed actions and distribution as the single-GPU icem_plan_step, bit for bit."""
+    import ctypes as C
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env
+    from icem_amd import _lib as L
+    env = halfcheetah_env(17)
+    model = DeviceSyntheticModel.make(17, 6)
+    spec = env.cost_spec
+    iters = 3
+
+    def mk(rank, w):
+        pl = IcemPlanner(IcemConfig(horizon=30, act_dim=6, num_traj=N, opt_iters=iters, dtype="f32", seed=21, rank=rank, world=w),
+                         env.action_space.low, env.action_space.high)
+        pl.set_model(model.kind, model.A, model.B)
+        pl.set_cost(spec.ctrl_weight, spec.lin_idx, spec.lin_weight, spec.flip_idx, spec.flip_penalty, spec.flip_thresh)
+        pl.reset()
+        return pl
+
+    obs_seq = [0.1 * np.random.RandomState(s).randn(17) for s in range(2)]
+    single = mk(0, 1)
+    acts1 = [np_(single.plan_step(o)).copy() for o in obs_seq]
+    pls = [mk(r, world) for r in range(world)]
+    st = pls[0]._stream()
+    for pl in pls:
+        L.check(pl.lib.icem_set_merge_deferral(pl._h, 1))
+    K = pls[0].K
+    pls[0].profile_enable(True)
+    for s, o in enumerate(obs_seq):
+        for pl in pls:
+            pl.obs0.copy_(torch.as_tensor(o, dtype=pl.dt))
+        for it in range(iters):
+            for pl in pls:
+                L.check(pl.lib.icem_plan_iter_local(pl._h, C.byref(pl._cb), s, it, st))
+            full = torch.cat([pl.records[r * K:(r + 1) * K] for r, pl in enumerate(pls)], dim=0)
+            for pl in pls:
+                pl.records.copy_(full)
+                L.check(pl.lib.icem_plan_iter_merge(pl._h, C.byref(pl._cb), s, it, st))
+        for pl in pls:
+            assert np.array_equal(np_(pl.executed), acts1[s])
+    for pl in pls:
+        assert np.array_equal(np_(pl.mean), np_(single.mean)) and np.array_equal(np_(pl.std), np_(single.std))
+    torch.cuda.synchronize()
+    prof = pls[0].profile_read()
+    assert prof["merge_refit"][1] == len(obs_seq), prof  # only the last merge of each MPC step was a launch of its own
