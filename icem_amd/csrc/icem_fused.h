@@ -85,6 +85,8 @@ struct MergeSingleArgs {
     long long* dbg;  // development: 8 wall_clock64 stamps (100 MHz) of thread 0, nullptr in production
 };
 void launch_merge_single(const MergeSingleArgs& a, hipStream_t st);
+// sharded runs: the rank's K best of its candidate lists (part_k / actions / n_lists / n_keep = 0 of `a`) -> records [K, 2 + h*d]
+void launch_pack_records(const MergeSingleArgs& a, int n_loc, int shard_lo, float* records, hipStream_t st);
 
 // K1 with the previous iteration's merge (last == 0) in its prologue, see sample_folded_merge_kernel
 struct FastSampleMergeArgs {

@@ -807,6 +807,7 @@ template <int KREG>
 __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs a) {
     __shared__ unsigned long long sel[64];
     __shared__ unsigned long long cand[64];
+    __shared__ int slot[64];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* new_mean = reinterpret_cast<float*>(smem_raw);
     const int tid = threadIdx.x;
@@ -823,12 +824,17 @@ __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs 
         om[i] = (pre && e < hd) ? a.mean[e] : 0.f;
         os[i] = (pre && e < hd) ? a.std[e] : 0.f;
     }
-    if (tid < 64) merge_select<KREG>(a, lane, cand, sel);
+    if (tid < 64) {
+        if (a.records)
+            merge_select_records(a, lane, cand, sel, slot);
+        else
+            merge_select<KREG>(a, lane, cand, sel);
+    }
     if (a.dbg && threadIdx.x == 0) a.dbg[4] = wall_clock64();
     __syncthreads();
     // ---- all 4 waves: gather + refit (icem.py:201-211); row pointers first, then all K loads in flight ----
     const float* rows[KREG];
-    merge_rows<KREG>(a, sel, nullptr, rows);
+    merge_rows<KREG>(a, sel, slot, rows);
     auto finish_one = [&](int e, float old_mean, float old_std) {
         float xs[KREG];
 #pragma unroll
@@ -867,6 +873,39 @@ __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs 
         if (tid == 0) a.best_cost[0] = key_cost(sel[0]);
     }
     if (a.dbg && threadIdx.x == 0) a.dbg[6] = wall_clock64();
+}
+
+// Sharded runs: this rank's K best candidates (same selection) packed as records {cost, gidx, actions[h*d]} for
+// the all-gather.  Local pool row li is global trajectory shard_lo + li, or n_global + (li - n_loc) for the
+// replicated shifted elites behind the shard (icem_amd/distributed.py).
+template <int KREG>
+__global__ __launch_bounds__(MERGE_WG) void pack_records_kernel(MergeSingleArgs a, int n_loc, int shard_lo, float* records) {
+    __shared__ unsigned long long sel[64];
+    __shared__ unsigned long long cand[64];
+    const int tid = threadIdx.x;
+    const int hd = a.h * a.d;
+    const int rs = hd + 2;
+    if (tid < 64) merge_select<KREG>(a, tid, cand, sel);
+    __syncthreads();
+    for (int r = 0; r < a.K; ++r) {
+        const unsigned long long key = sel[r];
+        float* rec = records + (size_t)r * rs;
+        if (key == KEY_SENTINEL) {  // fewer than K candidates on this rank
+            if (tid == 0) {
+                rec[0] = INFINITY;
+                reinterpret_cast<int*>(rec + 1)[0] = INT_MAX;
+            }
+            for (int e = tid; e < hd; e += MERGE_WG) rec[2 + e] = 0.f;
+        } else {
+            const int li = key_idx(key);
+            if (tid == 0) {
+                rec[0] = key_cost(key);
+                reinterpret_cast<int*>(rec + 1)[0] = li < n_loc ? shard_lo + li : a.n_global + (li - n_loc);
+            }
+            const float* src = a.actions + (size_t)li * hd;
+            for (int e = tid; e < hd; e += MERGE_WG) rec[2 + e] = src[e];
+        }
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1285,6 +1324,13 @@ void launch_sample_folded(const FastSampleArgs& a, int rounds, hipStream_t st) {
     }
     ICEM_FAST_HORIZONS(X)
 #undef X
+}
+
+void launch_pack_records(const MergeSingleArgs& a, int n_loc, int shard_lo, float* records, hipStream_t st) {
+    if (a.K + 1 <= 12)
+        hipLaunchKernelGGL((pack_records_kernel<12>), dim3(1), dim3(MERGE_WG), 0, st, a, n_loc, shard_lo, records);
+    else
+        hipLaunchKernelGGL((pack_records_kernel<34>), dim3(1), dim3(MERGE_WG), 0, st, a, n_loc, shard_lo, records);
 }
 
 void launch_merge_single(const MergeSingleArgs& a, hipStream_t st) {

@@ -1104,7 +1104,7 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                 fa.s = fast_sample_args(h, n_loc, lo, b->mean, b->std, b->low, b->high, off, row0, actions,
                                         shift_in_sampler ? n_extra : 0, shift_src, call_base + (uint64_t)c.opt_iters);
                 fa.r = fast_rollout_args(h, n_rows, n_cand, K, b->obs0, actions, b->costs, pc, pi);
-                if (c.world == 1) fa.r.part_k = (unsigned long long*)b->workspace;  // read by merge_single_kernel
+                fa.r.part_k = (unsigned long long*)b->workspace;  // read by merge_single_kernel / pack_records_kernel
                 {
                     ProfScope prof(h, ICEM_K_SAMPLE_ROLLOUT, (long long)n_rows * c.horizon, st);
                     launch_sample_rollout(fa, c.horizon, c.act_dim, h->O, h->model_kind, prologue, st);
@@ -1133,14 +1133,24 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                 }
                 if (rc) return rc;
                 rc = launch_fast_rollout(h, n_rows, n_cand, K, b->obs0, actions, b->costs, pc, pi, st, &lists,
-                                         c.world == 1 ? (unsigned long long*)b->workspace : nullptr);
+                                         (unsigned long long*)b->workspace);
                 if (rc) return rc;
             }
             h->fast_lists = lists;
             if (c.world > 1) {
+                // this rank's K best -> records for the all-gather (same selection code as the merge)
+                MergeSingleArgs pk{};
+                pk.n_lists = lists;
+                pk.n_keep = 0;
+                pk.n_pool = n_rows;
+                pk.n_global = n_global;
+                pk.K = K;
+                pk.h = c.horizon;
+                pk.d = c.act_dim;
+                pk.part_k = (const unsigned long long*)b->workspace;
+                pk.actions = (const float*)actions;
                 ProfScope prof(h, ICEM_K_LOCAL_PACK, lists * K, st);
-                hipLaunchKernelGGL((local_pack_kernel<float>), dim3(1), dim3(WG), 0, st, lists * K, K, hd, n_loc, lo,
-                                   n_global, (const float*)pc, (const int*)pi, (const float*)actions, (float*)rec);
+                launch_pack_records(pk, n_loc, lo, (float*)rec, st);
             }
             ICEM_HIP_TRY(hipGetLastError());
             return ICEM_OK;
@@ -1246,7 +1256,8 @@ int plan_iter_merge_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
     a.executed = (T*)b->executed;
     a.best_cost = (T*)b->best_cost;
     if constexpr (std::is_same<T, float>::value) {
-        if (h->defer_merge && !a.last) {  // rides in the next iteration's launch, candidates = the gathered records
+        const bool fast_records = h->fast_lists > 0 && a.n_rec <= 128 && K <= 32;
+        if (fast_records) {  // f32 throughput path: the selection / refit code of the single-GPU merge on the records
             MergeSingleArgs m{};
             m.n_lists = 0;
             m.n_keep = a.n_keep;
@@ -1275,8 +1286,15 @@ int plan_iter_merge_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
             m.executed = a.executed;
             m.best_cost = a.best_cost;
             m.dbg = nullptr;
-            h->pm_args = m;
-            h->pm_pending = true;
+            if (h->defer_merge && !a.last) {  // rides in the next iteration's launch
+                h->pm_args = m;
+                h->pm_pending = true;
+                return ICEM_OK;
+            }
+            m.last = a.last;
+            ProfScope prof(h, ICEM_K_MERGE_REFIT, a.n_rec + a.n_keep, st);
+            launch_merge_single(m, st);
+            ICEM_HIP_TRY(hipGetLastError());
             return ICEM_OK;
         }
     }

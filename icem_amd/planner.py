@@ -249,13 +249,17 @@ class IcemPlanner:
             L.check(self.lib.icem_plan_step(self._h, C.byref(self._cb), self.mpc_step, st))
         else:
             # non-last merges ride in the next iteration's launch (nobody looks at mean / std in between)
-            L.check(self.lib.icem_set_merge_deferral(self._h, 1))
+            self._set_deferral(True)
             for it in range(self.cfg.opt_iters):
                 L.check(self.lib.icem_plan_iter_local(self._h, C.byref(self._cb), self.mpc_step, it, st))
                 exchange_records(self.records, self.K, self.cfg.rank, self.cfg.world, self.group)
                 L.check(self.lib.icem_plan_iter_merge(self._h, C.byref(self._cb), self.mpc_step, it, st))
-            L.check(self.lib.icem_set_merge_deferral(self._h, 0))
         self.mpc_step += 1
+
+    def _set_deferral(self, on: bool):
+        if getattr(self, "_deferral", False) != on:
+            L.check(self.lib.icem_set_merge_deferral(self._h, int(on)))
+            self._deferral = on
 
     # ------------------------------------------------------------------ fused MPC step
     def _ensure_buffers(self):
@@ -316,6 +320,7 @@ class IcemPlanner:
             self._cb.z_r = self._cb.z_i = self._cb.z_r_shift = self._cb.z_i_shift = None
             L.check(self.lib.icem_plan_step(self._h, C.byref(self._cb), self.mpc_step, st))
         else:
+            self._set_deferral(False)  # callers of this form look at the buffers between iterations
             keep = []
             for it in range(cfg.opt_iters):
                 self._cb.z_r = self._cb.z_i = self._cb.z_r_shift = self._cb.z_i_shift = None
