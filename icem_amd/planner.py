@@ -250,11 +250,28 @@ class IcemPlanner:
         else:
             # non-last merges ride in the next iteration's launch (nobody looks at mean / std in between)
             self._set_deferral(True)
+            gather = self._resident_gather()
+            local, merge, cb, h, step = self.lib.icem_plan_iter_local, self.lib.icem_plan_iter_merge, C.byref(self._cb), self._h, self.mpc_step
             for it in range(self.cfg.opt_iters):
-                L.check(self.lib.icem_plan_iter_local(self._h, C.byref(self._cb), self.mpc_step, it, st))
-                exchange_records(self.records, self.K, self.cfg.rank, self.cfg.world, self.group)
-                L.check(self.lib.icem_plan_iter_merge(self._h, C.byref(self._cb), self.mpc_step, it, st))
+                L.check(local(h, cb, step, it, st))
+                gather()
+                L.check(merge(h, cb, step, it, st))
         self.mpc_step += 1
+
+    def _resident_gather(self):
+        """The per-iteration all-gather of the bench loop with everything that does not change hoisted out: on RCCL
+        it is one in-place ``all_gather_into_tensor`` of this rank's K records."""
+        g = getattr(self, "_gather_fn", None)
+        if g is None:
+            import torch.distributed as dist
+            rank, world, K, records, group = self.cfg.rank, self.cfg.world, self.K, self.records, self.group
+            if records.is_cuda and dist.get_backend(group) == "nccl":
+                mine = records[rank * K:(rank + 1) * K]
+                g = lambda: dist.all_gather_into_tensor(records, mine, group=group)  # noqa: E731
+            else:
+                g = lambda: exchange_records(records, K, rank, world, group)  # noqa: E731
+            self._gather_fn = g
+        return g
 
     def _set_deferral(self, on: bool):
         if getattr(self, "_deferral", False) != on:
