@@ -268,6 +268,18 @@ __device__ __forceinline__ float reduce_groups(float x) {
     return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
+// Two sums over the 4 lanes of a trajectory for the price of one: a <- sum of a (valid in lanes 0..31), b <- sum of
+// b (valid in lanes 32..63).  v_permlane32_swap exchanges a's upper half with b's lower half, so one add sums both
+// values over lane pairs (l, l^32); v_permlane16_swap + add finishes the pairs (l, l^16).  Same association as
+// reduce_groups: (x0 + x2) + (x1 + x3).
+__device__ __forceinline__ void reduce_groups_pair(float& a, float& b) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    const float s = __uint_as_float(r[0]) + __uint_as_float(r[1]);  // [a0+a2, a1+a3, b0+b2, b1+b3] by row of 16 lanes
+    const unsigned v = __float_as_uint(s);
+    auto q = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    a = b = __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
 // steps per staged action chunk: divides H, whole float4s per row, odd float4 count (16 rows then hit 16 distinct
 // bank groups) when possible
 __host__ __device__ constexpr int r16_chunk_steps(int h, int d) {
@@ -381,9 +393,14 @@ struct Tile16 {
             for (int q = 0; q < NKX; ++q) p = __builtin_fmaf(xv[q], wR[r][4 + q], p);
             pr[r] = p;
         }
-        c = reduce_groups(c);
+        // the first extra column (consumed by slot 0 = lanes 0..15) shares its reduction with the cost, which is
+        // then valid in lanes 32..63 only (see cost())
+        if (REM >= 1)
+            reduce_groups_pair(pr[0], c);
+        else
+            c = reduce_groups(c);
 #pragma unroll
-        for (int r = 0; r < REM; ++r) pr[r] = reduce_groups(pr[r]);
+        for (int r = 1; r < REM; ++r) pr[r] = reduce_groups(pr[r]);
         st.acc_s = __builtin_fmaf(st.acc_s, ksum, c);
         st.acc_b = c < st.acc_b ? c : st.acc_b;
         // model step on the matrix pipe
@@ -397,7 +414,13 @@ struct Tile16 {
 #pragma unroll
         for (int r = 0; r < REM; ++r) st.xr[r] = act_fn(pr[r], std::integral_constant<int, KIND>{});
     }
-    __device__ __forceinline__ float cost(const State& st) const { return use_min ? st.acc_b : st.acc_s; }
+    __device__ __forceinline__ float cost(const State& st) const {
+        const float v = use_min ? st.acc_b : st.acc_s;
+        if (REM == 0) return v;
+        // accumulated in lanes 32..63 (reduce_groups_pair): hand lane l + 32's value to lane l
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return __uint_as_float(r[1]);
+    }
 };
 
 // a tile's 16 keys (lanes 0..15, the rest sentinels) join the wave's running sorted top-K: lanes 16..16+K-1 carry
@@ -786,14 +809,14 @@ __device__ __forceinline__ void merge_select_records(const MergeSingleArgs& a, i
 }
 
 // pointers to the K selected rows (icem.py:201): pool rows, or kept elites behind index n_global
-template <int KREG>
+template <int KREG, bool REC>
 __device__ __forceinline__ void merge_rows(const MergeSingleArgs& a, const unsigned long long* sel, const int* slot,
                                            const float* (&rows)[KREG]) {
     const int hd = a.h * a.d;
 #pragma unroll
     for (int r = 0; r < KREG; ++r) {
         const int rr = r < a.K ? r : 0;
-        if (a.records) {  // wave-uniform
+        if (REC) {  // sharded run: candidates are records
             const int e = slot[rr];
             rows[r] = e < a.n_rec ? a.records + (size_t)e * (hd + 2) + 2 : a.elites_cur + (size_t)(e - a.n_rec) * hd;
         } else {
@@ -803,7 +826,7 @@ __device__ __forceinline__ void merge_rows(const MergeSingleArgs& a, const unsig
     }
 }
 
-template <int KREG>
+template <int KREG, bool REC>
 __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs a) {
     __shared__ unsigned long long sel[64];
     __shared__ unsigned long long cand[64];
@@ -825,7 +848,7 @@ __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs 
         os[i] = (pre && e < hd) ? a.std[e] : 0.f;
     }
     if (tid < 64) {
-        if (a.records)
+        if constexpr (REC)
             merge_select_records(a, lane, cand, sel, slot);
         else
             merge_select<KREG>(a, lane, cand, sel);
@@ -834,7 +857,7 @@ __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs 
     __syncthreads();
     // ---- all 4 waves: gather + refit (icem.py:201-211); row pointers first, then all K loads in flight ----
     const float* rows[KREG];
-    merge_rows<KREG>(a, sel, slot, rows);
+    merge_rows<KREG, REC>(a, sel, slot, rows);
     auto finish_one = [&](int e, float old_mean, float old_std) {
         float xs[KREG];
 #pragma unroll
@@ -916,7 +939,7 @@ __global__ __launch_bounds__(MERGE_WG) void pack_records_kernel(MergeSingleArgs 
 // into the LDS tile; then all 5 waves gather the K elite rows and refit, the affine map + clip is applied to the
 // tile and the tile leaves as before.  Every workgroup redoes the same merge (L2 serves the 20 KB of keys and 7 KB
 // of elite rows), workgroup 0 publishes it.  Saves the merge launch (8.6 + 2.6 us) for ~3 us more sampler time.
-template <int H, int ROUNDS, int KREG>
+template <int H, int ROUNDS, int KREG, bool REC>
 __global__ __launch_bounds__(SWG + 64) void sample_folded_merge_kernel(FastSampleMergeArgs args) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ unsigned long long sel[64];
@@ -939,7 +962,7 @@ __global__ __launch_bounds__(SWG + 64) void sample_folded_merge_kernel(FastSampl
     const int j = tid - nl * d;
     float* trow = tile + nl * hd + j;
     if (tid >= SWG) {
-        if (m.records)
+        if constexpr (REC)
             merge_select_records(m, lane, cand, sel, slot);
         else
             merge_select_stream(m, lane, cand, sel);
@@ -950,7 +973,7 @@ __global__ __launch_bounds__(SWG + 64) void sample_folded_merge_kernel(FastSampl
     __syncthreads();
     {
         const float* rows[KREG];
-        merge_rows<KREG>(m, sel, slot, rows);
+        merge_rows<KREG, REC>(m, sel, slot, rows);
         for (int e = tid; e < hd; e += NTT) {
             float xs[KREG];
 #pragma unroll
@@ -1012,7 +1035,7 @@ __global__ __launch_bounds__(SWG + 64) void sample_folded_merge_kernel(FastSampl
 // the host / the next launch.  That removes the merge launch and hides its latency behind the sampling.  The
 // previous pool, lists and distribution are read while this launch writes new ones: all three are ping-pong
 // buffers (icem_plan_step).
-template <int H, int D, int O, int KIND, int ROUNDS, int RW, int KREG>
+template <int H, int D, int O, int KIND, int ROUNDS, int RW, int KREG, bool REC>
 __global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64 + (KREG > 0 ? 64 : 0)) void sample_rollout_kernel(FastIterArgs a) {
     using Tile = Tile16<H, D, O, KIND>;
     constexpr bool PM = KREG > 0;
@@ -1096,7 +1119,7 @@ __global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64 + (KREG > 0 ? 64 : 0
             if (first) {
                 const MergeSingleArgs& m = a.m;
                 if (tid >= NT) {
-                    if (m.records)
+                    if constexpr (REC)
                         merge_select_records(m, lane, cand, sel, slot);
                     else
                         merge_select<KREG>(m, lane, cand, sel);
@@ -1104,7 +1127,7 @@ __global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64 + (KREG > 0 ? 64 : 0
                 __syncthreads();
                 // all threads: gather the elite rows + refit (icem.py:201-211) -> this workgroup's mean / std
                 const float* rows[KREG > 0 ? KREG : 1];
-                merge_rows<KREG>(m, sel, slot, rows);
+                merge_rows<KREG, REC>(m, sel, slot, rows);
                 for (int e = tid; e < HD; e += NTT) {
                     float xs[KREG > 0 ? KREG : 1];
 #pragma unroll
@@ -1251,21 +1274,22 @@ bool sample_rollout_merge_ok(int h, int d, int O, int rounds, int n_rows, int K)
 void launch_sample_rollout(const FastIterArgs& a, int h, int d, int O, int kind, bool merge_prologue, hipStream_t st) {
     int grid, rw;
     if (!sample_rollout_shape(h, d, O, 10, a.r.n_rows, &grid, &rw)) return;
-#define XK(HH, DD, OO, WW, KR)                                                                                        \
-    {                                                                                                                 \
-        constexpr int NT = ((16 * WW * DD + 63) / 64) * 64 + (KR > 0 ? 64 : 0);                                       \
-        if (kind == 1)                                                                                                \
-            hipLaunchKernelGGL((sample_rollout_kernel<HH, DD, OO, 1, 10, WW, KR>), dim3(grid), dim3(NT), 0, st, a);   \
-        else                                                                                                          \
-            hipLaunchKernelGGL((sample_rollout_kernel<HH, DD, OO, 0, 10, WW, KR>), dim3(grid), dim3(NT), 0, st, a);   \
-        return;                                                                                                       \
+#define XK(HH, DD, OO, WW, KR, RC)                                                                                      \
+    {                                                                                                                   \
+        constexpr int NT = ((16 * WW * DD + 63) / 64) * 64 + (KR > 0 ? 64 : 0);                                         \
+        if (kind == 1)                                                                                                  \
+            hipLaunchKernelGGL((sample_rollout_kernel<HH, DD, OO, 1, 10, WW, KR, RC>), dim3(grid), dim3(NT), 0, st, a); \
+        else                                                                                                            \
+            hipLaunchKernelGGL((sample_rollout_kernel<HH, DD, OO, 0, 10, WW, KR, RC>), dim3(grid), dim3(NT), 0, st, a); \
+        return;                                                                                                         \
     }
 #define XW(HH, DD, OO, WW)                                    \
     if (rw == WW) {                                           \
         if constexpr (WW <= 4) {                              \
-            if (merge_prologue) XK(HH, DD, OO, WW, 12)        \
+            if (merge_prologue && a.m.records) XK(HH, DD, OO, WW, 12, true)  \
+            if (merge_prologue) XK(HH, DD, OO, WW, 12, false) \
         }                                                     \
-        XK(HH, DD, OO, WW, 0)                                 \
+        XK(HH, DD, OO, WW, 0, false)                          \
     }
 #define XR(HH, DD, OO)                   \
     if (h == HH && d == DD && O == OO) { \
@@ -1303,7 +1327,10 @@ void launch_sample_folded_merge(const FastSampleMergeArgs& a, hipStream_t st) {
     const size_t lds = ((size_t)2 * a.s.h * a.s.d + (size_t)tpw * a.s.h * a.s.d) * sizeof(float);
 #define X(HH)                                                                                                  \
     if (a.s.h == HH) {                                                                                         \
-        hipLaunchKernelGGL((sample_folded_merge_kernel<HH, 10, 12>), dim3(grid), dim3(SWG + 64), lds, st, a);  \
+        if (a.m.records)                                                                                       \
+            hipLaunchKernelGGL((sample_folded_merge_kernel<HH, 10, 12, true>), dim3(grid), dim3(SWG + 64), lds, st, a);  \
+        else                                                                                                   \
+            hipLaunchKernelGGL((sample_folded_merge_kernel<HH, 10, 12, false>), dim3(grid), dim3(SWG + 64), lds, st, a); \
         return;                                                                                                \
     }
     ICEM_FAST_HORIZONS(X)
@@ -1335,10 +1362,16 @@ void launch_pack_records(const MergeSingleArgs& a, int n_loc, int shard_lo, floa
 
 void launch_merge_single(const MergeSingleArgs& a, hipStream_t st) {
     const size_t lds = (size_t)a.h * a.d * sizeof(float);
-    if (a.K + 1 <= 12)
-        hipLaunchKernelGGL((merge_single_kernel<12>), dim3(1), dim3(MERGE_WG), lds, st, a);
-    else
-        hipLaunchKernelGGL((merge_single_kernel<34>), dim3(1), dim3(MERGE_WG), lds, st, a);
+    if (a.records) {
+        if (a.K + 1 <= 12)
+            hipLaunchKernelGGL((merge_single_kernel<12, true>), dim3(1), dim3(MERGE_WG), lds, st, a);
+        else
+            hipLaunchKernelGGL((merge_single_kernel<34, true>), dim3(1), dim3(MERGE_WG), lds, st, a);
+    } else if (a.K + 1 <= 12) {
+        hipLaunchKernelGGL((merge_single_kernel<12, false>), dim3(1), dim3(MERGE_WG), lds, st, a);
+    } else {
+        hipLaunchKernelGGL((merge_single_kernel<34, false>), dim3(1), dim3(MERGE_WG), lds, st, a);
+    }
 }
 
 }  // namespace icem
