@@ -104,15 +104,37 @@ def cpu_baseline(w, model, env, budget_s=12.0):
                       f"{el:.1f} s; oracle/icem_oracle.c, float64, OpenMP over trajectories"}
 
 
-def roofline_of(prof, w):
+KERNEL_FAMILY = {"sample_clip": ("sample_folded_kernel", "sample_folded_merge_kernel"), "rollout_cost": ("rollout16_kernel",),
+                 "sample_rollout": ("sample_rollout_kernel",)}
+
+
+def measured_traffic(kernel_class, workload):
+    """HBM bytes per launch of that kernel class from the committed rocprofv3 PMC passes over this same command
+    (profiles/rNN_<workload>_hbm_traffic.json, written by tools/summarize_profile.py: separate --pmc FETCH_SIZE /
+    WRITE_SIZE runs, reads with the gfx950 x2 correction).  None if no such profile is in the tree."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_hbm_traffic.json")))
+    if not files:
+        return None, None
+    tab = json.load(open(files[-1]))
+    tot, n = 0.0, 0
+    for name in KERNEL_FAMILY.get(kernel_class, ()):
+        if name in tab:
+            tot += (tab[name]["read_bytes_per_launch"] + tab[name]["write_bytes_per_launch"]) * tab[name]["launches"]
+            n += tab[name]["launches"]
+    return (tot / n, os.path.relpath(files[-1], ROOT)) if n else (None, None)
+
+
+def roofline_of(prof, w, workload=None):
     dom = max(prof, key=lambda k: prof[k][0])
     ms, launches, units = prof[dom]
     bpu = algorithmic_bytes_per_trajstep(dom, w["d"], w["h"])
     if bpu is None or ms <= 0:
         return None
     achieved = units * bpu / (ms * 1e-3) / 1e9
+    traffic, src = measured_traffic(dom, workload) if workload else (None, None)
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None, "kernel": dom, "avg_launch_us": 1e3 * ms / launches, "launches": launches,
+            "traffic": traffic, "traffic_source": src, "kernel": dom, "avg_launch_us": 1e3 * ms / launches, "launches": launches,
             "algorithmic_bytes_per_launch": units * bpu / launches, "bytes_per_traj_step": bpu}
 
 
@@ -136,7 +158,7 @@ def measure_also(name, steps=30, warmup=5):
     ts = sum(pl.population_sizes) * w["h"]
     loop_bytes = ts * (8.0 * w["d"] + 8.0 / w["h"])
     return {"workload": w["name"], "value": ts * steps / el, "unit": "traj-steps/s", "ms_per_mpc_step": 1e3 * el / steps,
-            "roofline": roofline_of(prof, w), "kernels_us": {k: round(1e3 * v[0] / v[1], 2) for k, v in prof.items()},
+            "roofline": roofline_of(prof, w, name), "kernels_us": {k: round(1e3 * v[0] / v[1], 2) for k, v in prof.items()},
             "whole_loop_algorithmic_GBps": loop_bytes * steps / el / 1e9,
             "whole_loop_frac_of_hbm_peak": loop_bytes * steps / el / 1e9 / HBM_PEAK_GBS}
 
@@ -198,7 +220,7 @@ def main():
     pl.profile_enable(False)
 
     if rank == 0:
-        roofline = roofline_of(prof, w)
+        roofline = roofline_of(prof, w, args.workload if world == 1 else None)
         out = {
             "metric": "traj-steps/sec (N x h), iCEM inner planning loop", "value": per_step_trajsteps * args.steps / elapsed,
             "unit": "traj-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

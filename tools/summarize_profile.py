@@ -37,4 +37,18 @@ with open(dst + "_hbm_traffic.md", "w") as f:
         fa = fv / max(fn, 1)
         wa = wv / max(wn, 1)
         f.write(f"| `{k}` | {max(fn, wn)} | {fa:.1f} | {2 * fa * 1024 / 1e6:.2f} | {wa:.1f} | {wa * 1024 / 1e6:.2f} |\n")
+# machine-readable: per kernel family, launch-weighted HBM bytes per launch (reads x2-corrected per the guide, writes raw)
+fam = defaultdict(lambda: [0.0, 0.0, 0])
+for k in set(fetch) | set(write):
+    name = k.split("<")[0].replace("icem::", "")
+    fv, fn = fetch[k]
+    wv, wn = write[k]
+    n = max(fn, wn)
+    if n < 5:
+        continue
+    fam[name][0] += 2 * fv * 1024 / max(fn, 1) * n
+    fam[name][1] += wv * 1024 / max(wn, 1) * n
+    fam[name][2] += n
+json.dump({name: {"read_bytes_per_launch": v[0] / v[2], "write_bytes_per_launch": v[1] / v[2], "launches": v[2]}
+           for name, v in fam.items() if v[2]}, open(dst + "_hbm_traffic.json", "w"), indent=1)
 print(open(dst + "_hbm_traffic.md").read())
