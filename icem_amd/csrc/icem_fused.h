@@ -38,8 +38,8 @@ struct FastRolloutArgs {
     int K;        // 0 = no candidate output
     int o;        // true observation width (<= O)
     int cost_mode;
-    const float* Mp;    // [O + D, 4*ceil(O/4)] permuted, zero padded model [A ; B]
-    const int* perm;    // [O] permuted column k holds observation entry perm[k]
+    const float* Mp;    // [O + D + 1, 4*ceil(O/4)] permuted, zero padded model [A ; B], then one zero row
+    const int* perm;    // [32] permuted column k holds observation entry perm[k]; 31 (a zero slot) for k >= o
     const float* obs0;
     float ctrl_w, lin_w, flip_pen, flip_th;
     int flip_col;       // column holding obs[flip_idx] after the permutation, -1 = no flip term

@@ -307,35 +307,43 @@ struct Tile16 {
     bool is_act[NKX];
     f32x4 obs_init;
     float rem_init[REM > 0 ? REM : 1];
+    int perm_base[4], perm_rem[REM > 0 ? REM : 1];  // which observation entries this lane starts from
     float pen, lin_w, ksum, flip_th;
     bool ang_is_col1, use_min;
     int g;
 
+    // All loads are unconditional (Mp carries a zero row behind the model, perm is padded to 32 entries that point
+    // at a zero slot): a select behind a load would make the wave wait for it right here, in front of everything
+    // the kernel does before it needs the model.
+    static constexpr int ZROW = O + D;  // the zero row of Mp
     __device__ __forceinline__ void load(const FastRolloutArgs& a, int lane) {
+        static_assert(O >= 16, "Mp rows / columns 0..15 exist");
         const int j = lane & 15;
         g = lane >> 4;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int k = 4 * g + s;
-            mA[s] = (k < O && j < O) ? a.Mp[k * CT4 + j] : 0.f;
+            mA[s] = a.Mp[k * CT4 + j];
 #pragma unroll
-            for (int r = 0; r < REM; ++r) wR[r][s] = k < O ? a.Mp[k * CT4 + 16 + r] : 0.f;
+            for (int r = 0; r < REM; ++r) wR[r][s] = a.Mp[k * CT4 + 16 + r];
         }
 #pragma unroll
         for (int q = 0; q < NKX; ++q) {
             const int e = 4 * q + g;
-            const int k = e < REM ? 16 + e : O + (e - REM);
             const bool valid = e < NX;
-            mA[4 + q] = (valid && j < O) ? a.Mp[(valid ? k : 0) * CT4 + j] : 0.f;
+            const int k = !valid ? ZROW : (e < REM ? 16 + e : O + (e - REM));
+            mA[4 + q] = a.Mp[k * CT4 + j];
 #pragma unroll
-            for (int r = 0; r < REM; ++r) wR[r][4 + q] = valid ? a.Mp[(valid ? k : 0) * CT4 + 16 + r] : 0.f;
+            for (int r = 0; r < REM; ++r) wR[r][4 + q] = a.Mp[k * CT4 + 16 + r];
             is_act[q] = valid && e >= REM;
             cw[q] = is_act[q] ? a.ctrl_w : 0.f;
         }
+        // the start observation is gathered through `perm`: two dependent global round trips if done here.  Only the
+        // indices are fetched now; load_obs() picks the values from an LDS copy the kernel stages meanwhile.
 #pragma unroll
-        for (int v = 0; v < 4; ++v) obs_init[v] = (4 * g + v < a.o) ? a.obs0[a.perm[4 * g + v]] : 0.f;
+        for (int v = 0; v < 4; ++v) perm_base[v] = a.perm[4 * g + v];
 #pragma unroll
-        for (int r = 0; r < REM; ++r) rem_init[r] = (16 + r < a.o) ? a.obs0[a.perm[16 + r]] : 0.f;
+        for (int r = 0; r < REM; ++r) perm_rem[r] = a.perm[16 + r];
         // cost terms that read observation columns 0 / 1 live in slot 0 only
         pen = (a.flip_col >= 0 && g == 0) ? a.flip_pen : 0.f;
         lin_w = g == 0 ? a.lin_w : 0.f;
@@ -343,6 +351,24 @@ struct Tile16 {
         ksum = a.cost_mode == 0 ? 1.f : 0.f;  // sum: acc = acc + c; final: acc = c
         use_min = a.cost_mode == 1;
         flip_th = a.flip_th;
+    }
+
+    // obs: 32 floats in LDS, the o start-observation entries in natural order, zeros behind (perm's padding -> 31)
+    // (the empty asm keeps the compiler from hoisting the address arithmetic -- and with it the wait for the perm
+    // loads -- up into the prologue)
+    __device__ __forceinline__ void load_obs(const float* obs) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            int pb = perm_base[v];
+            asm volatile("" : "+v"(pb));
+            obs_init[v] = obs[pb];
+        }
+#pragma unroll
+        for (int r = 0; r < REM; ++r) {
+            int pb = perm_rem[r];
+            asm volatile("" : "+v"(pb));
+            rem_init[r] = obs[pb];
+        }
     }
 
     // this lane's read pointer into an LDS action buffer whose row of trajectory j starts at buf + SLACK + j * stride
@@ -485,10 +511,17 @@ __global__ __launch_bounds__(64 * WAVES) void rollout16_kernel(FastRolloutArgs a
     // loads, chunk by chunk, into its own LDS buffer; each lane then reads the one or two entries it feeds to the MFMAs
     __shared__ __attribute__((aligned(16))) float stage[WAVES][STG];
     __shared__ unsigned long long wg_keys[2][WAVES][32];
+    __shared__ float obs_stage[32];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    if (threadIdx.x < 32) {
+        const float v = a.obs0[(int)threadIdx.x < a.o ? threadIdx.x : 0];
+        obs_stage[threadIdx.x] = (int)threadIdx.x < a.o ? v : 0.f;
+    }
     Tile tile;
     tile.load(a, lane);
+    __syncthreads();
+    tile.load_obs(obs_stage);
     const float* rd0 = tile.read_ptr(stage[wave], lane, CBP);
     // cooperative loads: float4 number f = m * 64 + lane of a chunk is row f / C4, float4 f % C4 of that row
     int ld_row[NLD], ld_c4[NLD];
@@ -1040,14 +1073,15 @@ __global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64 + (KREG > 0 ? 64 : 0
     using Tile = Tile16<H, D, O, KIND>;
     constexpr bool PM = KREG > 0;
     constexpr int HD = H * D;
-    constexpr int TPB = 16 * RW;                     // trajectories per workgroup pass
-    constexpr int ROWS = TPB * D;                    // (trajectory, dim) rows per pass, one thread each
+    constexpr int TPB = 16 * RW;                     // trajectories per workgroup
+    constexpr int ROWS = TPB * D;                    // (trajectory, dim) rows, one thread each
     constexpr int NT = ((ROWS + 63) / 64) * 64;      // sampling threads
     constexpr int NTT = NT + (PM ? 64 : 0);          // + the selection wavefront
     static_assert(NTT <= 1024 && HD % 4 == 0, "workgroup shape");
     __shared__ __attribute__((aligned(16))) float ms[2 * HD];  // mean | std
     __shared__ __attribute__((aligned(16))) float tilebuf[Tile::SLACK + TPB * HD + Tile::TAIL];
     __shared__ unsigned long long wg_keys[2][RW][32];
+    __shared__ float obs_stage[32];
     __shared__ unsigned long long sel[PM ? 64 : 1];
     __shared__ unsigned long long cand[PM ? 64 : 1];
     __shared__ int slot[PM ? 64 : 1];
@@ -1057,132 +1091,141 @@ __global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64 + (KREG > 0 ? 64 : 0
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    const int n_rows = ra.n_rows;       // sa.n sampled rows, then sa.n_shift shifted elites
+    const int base = blockIdx.x * TPB;  // one slab of TPB trajectories per workgroup (launch_sample_rollout)
+    if (base >= n_rows) return;
     if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[8] = wall_clock64();
-    if (!PM) {
+    // Order matters at this size: kernel arguments arrive through serialized scalar loads, so everything the RNG
+    // chain does not need (start observation, model operands, bounds) is fetched AFTER the sampling got going.
+    const int nl = tid / D, jd = tid - nl * D;
+    const bool has_row = tid < ROWS;
+    float* trow = tile_rows + nl * HD + jd;
+    const float* mrow = ms + jd;
+    Tile tile;
+    float obs_reg = 0.f;
+    if (!PM) {  // iteration 0 of an MPC step: the distribution is in memory; the model operands ride the same wait
+        obs_reg = ra.obs0[(tid < 32 && tid < ra.o) ? tid : 0];
+        if (wave < RW) tile.load(ra, lane);
         for (int e = tid; e < HD; e += NTT) {
             ms[e] = sa.mean[e];
             ms[HD + e] = sa.std[e];
         }
-    }
-    Tile tile;
-    if (wave < RW) tile.load(ra, lane);
-    const float* rd0 = tile.read_ptr(tilebuf + (wave < RW ? wave : 0) * 16 * HD, lane, HD);
-    // this thread's sampling row
-    const int nl = tid / D, jd = tid - nl * D;
-    const bool has_row = tid < ROWS;
-    const float lo = sa.low[has_row ? jd : 0], hi = sa.high[has_row ? jd : 0];
-    float* trow = tile_rows + nl * HD + jd;
-    const float* mrow = ms + jd;
-
-    unsigned long long run_key = KEY_SENTINEL;
-    bool first = true;
-    const int n_rows = ra.n_rows;  // sa.n sampled rows, then sa.n_shift shifted elites
-    const int passes = (n_rows + TPB - 1) / TPB;
-    for (int pass = blockIdx.x; pass < passes; pass += gridDim.x) {
-        const int base = pass * TPB;
-        __syncthreads();  // mean / std staged; previous pass's rollout is done with the tile
-        if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[9] = wall_clock64();
-        const bool raw = PM && first;  // mean / std are still being computed: park the raw colored samples
-        if (has_row) {
-            const int r = base + nl;
-            if (r < sa.n) {
-                if (raw) {
-                    sample_row<H, ROUNDS>(sa.W, (unsigned)(sa.first_index + r), (unsigned)jd, sa.off_lo, sa.off_hi,
-                                          sa.seed_lo, sa.seed_hi, [&](int t, float y) { trow[t * D] = y; }, sa.white != 0);
-                } else {
-                    sample_row<H, ROUNDS>(sa.W, (unsigned)(sa.first_index + r), (unsigned)jd, sa.off_lo, sa.off_hi,
-                                          sa.seed_lo, sa.seed_hi, [&](int t, float y) {
-                                              const float v = __builtin_fmaf(y, mrow[HD + t * D], mrow[t * D]);
-                                              trow[t * D] = __builtin_amdgcn_fmed3f(v, lo, hi);
-                                          }, sa.white != 0);
-                }
-            } else if (r < n_rows && !PM) {
-                // shifted elite e: elites[e, 1:, j] and a last action drawn from the full (n_shift, d, h) noise batch
-                // of stream off2 (only t = h-1 is used, icem.py:102); iteration 0 only, which has no merge prologue
-                const int e = r - sa.n;
-                float last = 0.f;
-                sample_row<H, ROUNDS>(sa.W, (unsigned)e, (unsigned)jd, sa.off2_lo, sa.off2_hi, sa.seed_lo, sa.seed_hi,
-                                      [&](int t, float y) {
-                                          if (t == H - 1) {
-                                              const float v = __builtin_fmaf(y, mrow[HD + t * D], mrow[t * D]);
-                                              last = __builtin_amdgcn_fmed3f(v, lo, hi);
-                                          }
-                                      }, sa.white != 0);
-                const float* src = sa.elites_src + (size_t)e * HD + jd;
-                for (int t = 0; t < H - 1; ++t) trow[t * D] = src[(t + 1) * D];
-                trow[(H - 1) * D] = last;
-            } else {
-                for (int t = 0; t < H; ++t) trow[t * D] = 0.f;  // past the end: rolled out, dropped
-            }
-        }
-        if constexpr (PM) {
-            if (first) {
-                const MergeSingleArgs& m = a.m;
-                if (tid >= NT) {
-                    if constexpr (REC)
-                        merge_select_records(m, lane, cand, sel, slot);
-                    else
-                        merge_select<KREG>(m, lane, cand, sel);
-                }
-                __syncthreads();
-                // all threads: gather the elite rows + refit (icem.py:201-211) -> this workgroup's mean / std
-                const float* rows[KREG > 0 ? KREG : 1];
-                merge_rows<KREG, REC>(m, sel, slot, rows);
-                for (int e = tid; e < HD; e += NTT) {
-                    float xs[KREG > 0 ? KREG : 1];
-#pragma unroll
-                    for (int r = 0; r < KREG; ++r) xs[r] = rows[r][e];
-                    float nm, ns;
-                    refit_element_regs<float, KREG>(m.K, m.alpha, m.mean[e], m.std[e], xs, nm, ns);
-                    ms[e] = nm;
-                    ms[HD + e] = ns;
-                    if (blockIdx.x == 0) {
-                        m.mean_out[e] = nm;
-                        m.std_out[e] = ns;
-#pragma unroll
-                        for (int r = 0; r < KREG; ++r)
-                            if (r < m.K) m.elites_next[(size_t)r * HD + e] = xs[r];
-                    }
-                }
-                if (blockIdx.x == 0 && tid < m.K) m.elites_cost_next[tid] = key_cost(sel[tid]);
-                __syncthreads();
-                if (has_row && base + nl < sa.n) {
-                    for (int t = 0; t < H; ++t) {
-                        const float v = __builtin_fmaf(trow[t * D], mrow[HD + t * D], mrow[t * D]);
-                        trow[t * D] = __builtin_amdgcn_fmed3f(v, lo, hi);
-                    }
-                }
-            }
-        }
-        if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[10] = wall_clock64();
         __syncthreads();
-        if (sa.row0_mean && sa.first_index + base == 0) {  // icem.py:87-88
-            for (int e = tid; e < HD; e += NTT) tile_rows[e] = ms[e];
-            __syncthreads();
+    }
+    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[9] = wall_clock64();
+    const int r_mine = base + nl;
+    if (has_row) {
+        if (r_mine < sa.n) {
+            if (PM) {  // mean / std are still being computed: park the raw colored samples
+                sample_row<H, ROUNDS>(sa.W, (unsigned)(sa.first_index + r_mine), (unsigned)jd, sa.off_lo, sa.off_hi,
+                                      sa.seed_lo, sa.seed_hi, [&](int t, float y) { trow[t * D] = y; }, sa.white != 0);
+            } else {
+                const float lo = sa.low[jd], hi = sa.high[jd];
+                sample_row<H, ROUNDS>(sa.W, (unsigned)(sa.first_index + r_mine), (unsigned)jd, sa.off_lo, sa.off_hi,
+                                      sa.seed_lo, sa.seed_hi, [&](int t, float y) {
+                                          const float v = __builtin_fmaf(y, mrow[HD + t * D], mrow[t * D]);
+                                          trow[t * D] = __builtin_amdgcn_fmed3f(v, lo, hi);
+                                      }, sa.white != 0);
+            }
+        } else if (r_mine < n_rows && !PM) {
+            // shifted elite e: elites[e, 1:, j] and a last action drawn from the full (n_shift, d, h) noise batch
+            // of stream off2 (only t = h-1 is used, icem.py:102); iteration 0 only, which has no merge prologue
+            const int e = r_mine - sa.n;
+            const float lo = sa.low[jd], hi = sa.high[jd];
+            float last = 0.f;
+            sample_row<H, ROUNDS>(sa.W, (unsigned)e, (unsigned)jd, sa.off2_lo, sa.off2_hi, sa.seed_lo, sa.seed_hi,
+                                  [&](int t, float y) {
+                                      if (t == H - 1) {
+                                          const float v = __builtin_fmaf(y, mrow[HD + t * D], mrow[t * D]);
+                                          last = __builtin_amdgcn_fmed3f(v, lo, hi);
+                                      }
+                                  }, sa.white != 0);
+            const float* src = sa.elites_src + (size_t)e * HD + jd;
+            for (int t = 0; t < H - 1; ++t) trow[t * D] = src[(t + 1) * D];
+            trow[(H - 1) * D] = last;
+        } else {
+            for (int t = 0; t < H; ++t) trow[t * D] = 0.f;  // past the end: rolled out, dropped
         }
-        {   // the tile is a contiguous block of the action tensor
-            const int total4 = (n_rows - base < TPB ? n_rows - base : TPB) * (HD / 4);
-            const float4* t4 = reinterpret_cast<const float4*>(tile_rows);
-            float4* g4 = reinterpret_cast<float4*>(sa.out + (size_t)base * HD);
-            for (int e = tid; e < total4; e += NTT) g4[e] = t4[e];
+    }
+    if constexpr (PM) {
+        if (tid >= NT) {
+            if constexpr (REC)
+                merge_select_records(a.m, lane, cand, sel, slot);
+            else
+                merge_select<KREG>(a.m, lane, cand, sel);
         }
-        if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[11] = wall_clock64();
-        if (wave < RW) {
-            const int row = base + wave * 16 + (lane & 15);
-            const bool live = row < n_rows;
-            typename Tile::State st;
-            tile.init(st);
+    }
+    if (PM) {  // now the rest of the inputs: in flight across the barriers below
+        obs_reg = ra.obs0[(tid < 32 && tid < ra.o) ? tid : 0];
+        if (wave < RW) tile.load(ra, lane);
+    }
+    const float* rd0 = tile.read_ptr(tilebuf + (wave < RW ? wave : 0) * 16 * HD, lane, HD);
+    if constexpr (PM) {
+        const MergeSingleArgs& m = a.m;
+        __syncthreads();
+        // all threads: gather the elite rows + refit (icem.py:201-211) -> this workgroup's mean / std
+        const float* rows[KREG > 0 ? KREG : 1];
+        merge_rows<KREG, REC>(m, sel, slot, rows);
+        for (int e = tid; e < HD; e += NTT) {
+            float xs[KREG > 0 ? KREG : 1];
 #pragma unroll
-            for (int t = 0; t < H; ++t) tile.step(st, rd0 + t * D);
-            const float cost = tile.cost(st);
-            if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[12] = wall_clock64();
-            if (live && lane < 16) ra.costs[row] = cost;
-            if (ra.K > 0) {
-                const unsigned long long key = (lane < 16 && live && row < ra.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
-                run_key = topk_push16(run_key, key, first, ra.K, lane);
+            for (int r = 0; r < KREG; ++r) xs[r] = rows[r][e];
+            float nm, ns;
+            refit_element_regs<float, KREG>(m.K, m.alpha, m.mean[e], m.std[e], xs, nm, ns);
+            ms[e] = nm;
+            ms[HD + e] = ns;
+            if (blockIdx.x == 0) {
+                m.mean_out[e] = nm;
+                m.std_out[e] = ns;
+#pragma unroll
+                for (int r = 0; r < KREG; ++r)
+                    if (r < m.K) m.elites_next[(size_t)r * HD + e] = xs[r];
             }
         }
-        first = false;
+        if (blockIdx.x == 0 && tid < m.K) m.elites_cost_next[tid] = key_cost(sel[tid]);
+        __syncthreads();
+        if (has_row && r_mine < sa.n) {  // y * std + mean, clipped (icem.py:79)
+            const float lo = sa.low[jd], hi = sa.high[jd];
+            for (int t = 0; t < H; ++t) {
+                const float v = __builtin_fmaf(trow[t * D], mrow[HD + t * D], mrow[t * D]);
+                trow[t * D] = __builtin_amdgcn_fmed3f(v, lo, hi);
+            }
+        }
+    }
+    if (tid < 32) {  // start observation -> LDS (consumed after the barrier)
+        float ov = obs_reg;
+        asm volatile("" : "+v"(ov));  // wait for the load here, not where it was issued
+        obs_stage[tid] = tid < ra.o ? ov : 0.f;
+    }
+    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[10] = wall_clock64();
+    __syncthreads();
+    if (sa.row0_mean && sa.first_index + base == 0) {  // icem.py:87-88
+        for (int e = tid; e < HD; e += NTT) tile_rows[e] = ms[e];
+        __syncthreads();
+    }
+    {   // the tile is a contiguous block of the action tensor
+        const int total4 = (n_rows - base < TPB ? n_rows - base : TPB) * (HD / 4);
+        const float4* t4 = reinterpret_cast<const float4*>(tile_rows);
+        float4* g4 = reinterpret_cast<float4*>(sa.out + (size_t)base * HD);
+        for (int e = tid; e < total4; e += NTT) g4[e] = t4[e];
+    }
+    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[11] = wall_clock64();
+    unsigned long long run_key = KEY_SENTINEL;
+    if (wave < RW) {
+        tile.load_obs(obs_stage);
+        const int row = base + wave * 16 + (lane & 15);
+        const bool live = row < n_rows;
+        typename Tile::State st;
+        tile.init(st);
+#pragma unroll
+        for (int t = 0; t < H; ++t) tile.step(st, rd0 + t * D);
+        const float cost = tile.cost(st);
+        if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[12] = wall_clock64();
+        if (live && lane < 16) ra.costs[row] = cost;
+        if (ra.K > 0) {
+            const unsigned long long key = (lane < 16 && live && row < ra.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
+            run_key = topk_push16(run_key, key, true, ra.K, lane);
+        }
     }
     if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[13] = wall_clock64();
     if (ra.K > 0) wg_merge_emit<RW>(wg_keys, run_key, ra.K, lane, wave, ra);
@@ -1252,7 +1295,7 @@ static bool sample_rollout_shape(int h, int d, int O, int rounds, int n_rows, in
     r16_shape(n_rows, &grid, &rw);
     if (rounds != 10 || rw > max_rw || n_rows <= 0 || !fast_rollout_supported(h, d, O, 1) || !fast_sample_supported(h, d))
         return false;
-    if (rw > 8) rw = 8;  // several passes per workgroup
+    if (rw > 8) return false;  // one slab of 16 * rw trajectories per workgroup
     *grid_out = std::min(grid, (n_rows + 16 * rw - 1) / (16 * rw));
     *rw_out = rw;
     return true;
@@ -1267,8 +1310,7 @@ int sample_rollout_lists(int h, int d, int O, int rounds, int n_rows) {
 bool sample_rollout_merge_ok(int h, int d, int O, int rounds, int n_rows, int K) {
     static const int on = [] { const char* e = getenv("ICEM_MERGE_PROLOGUE"); return e ? atoi(e) : 1; }();
     int grid, rw;
-    return on && K + 1 <= 12 && sample_rollout_shape(h, d, O, rounds, n_rows, &grid, &rw) && rw <= 4 &&
-           (n_rows + 16 * rw - 1) / (16 * rw) <= grid;
+    return on && K + 1 <= 12 && sample_rollout_shape(h, d, O, rounds, n_rows, &grid, &rw) && rw <= 4;
 }
 
 void launch_sample_rollout(const FastIterArgs& a, int h, int d, int O, int kind, bool merge_prologue, hipStream_t st) {

@@ -879,7 +879,7 @@ int ensure_fast_model(icem_handle* h) {
     }
     for (int k = 0; k < O; ++k)
         if (std::find(perm.begin(), perm.end(), k) == perm.end()) perm.push_back(k);
-    std::vector<float> Mp((size_t)(O + d) * CT4, 0.f);
+    std::vector<float> Mp((size_t)(O + d + 1) * CT4, 0.f);  // + one zero row (contraction slots without an entry)
     auto Aat = [&](int r, int c) { return (r < o && c < o) ? h->A_host[(size_t)r * o + c] : 0.0; };
     auto Bat = [&](int j, int c) { return c < o ? h->B_host[(size_t)j * o + c] : 0.0; };
     for (int k = 0; k < O; ++k)
@@ -888,6 +888,9 @@ int ensure_fast_model(icem_handle* h) {
         for (int c = 0; c < O; ++c) Mp[(size_t)(O + j) * CT4 + c] = (float)Bat(j, perm[c]);
     if (h->Mp_dev) (void)hipFree(h->Mp_dev);
     if (h->perm_dev) (void)hipFree(h->perm_dev);
+    for (int k = 0; k < (int)perm.size(); ++k)
+        if (k >= o || perm[k] >= o) perm[k] = 31;  // padding columns start from the zero slot of the staged observation
+    perm.resize(32, 31);
     ICEM_HIP_TRY(hipMalloc(&h->Mp_dev, Mp.size() * sizeof(float)));
     ICEM_HIP_TRY(hipMalloc(&h->perm_dev, perm.size() * sizeof(int)));
     ICEM_HIP_TRY(hipMemcpy(h->Mp_dev, Mp.data(), Mp.size() * sizeof(float), hipMemcpyHostToDevice));
