@@ -514,12 +514,11 @@ __global__ __launch_bounds__(64 * WAVES) void rollout16_kernel(FastRolloutArgs a
     __shared__ float obs_stage[32];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    if (threadIdx.x < 32) {
-        const float v = a.obs0[(int)threadIdx.x < a.o ? threadIdx.x : 0];
-        obs_stage[threadIdx.x] = (int)threadIdx.x < a.o ? v : 0.f;
-    }
+    // model operands and start observation in flight together: one wait at the barrier
+    const float obs_reg = a.obs0[(threadIdx.x < 32 && (int)threadIdx.x < a.o) ? threadIdx.x : 0];
     Tile tile;
     tile.load(a, lane);
+    if (threadIdx.x < 32) obs_stage[threadIdx.x] = (int)threadIdx.x < a.o ? obs_reg : 0.f;
     __syncthreads();
     tile.load_obs(obs_stage);
     const float* rd0 = tile.read_ptr(stage[wave], lane, CBP);
