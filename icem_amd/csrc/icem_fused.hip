@@ -942,24 +942,34 @@ __global__ __launch_bounds__(MERGE_WG) void pack_records_kernel(MergeSingleArgs 
     const int rs = hd + 2;
     if (tid < 64) merge_select<KREG>(a, tid, cand, sel);
     __syncthreads();
-    for (int r = 0; r < a.K; ++r) {
-        const unsigned long long key = sel[r];
-        float* rec = records + (size_t)r * rs;
+    // headers by the first K threads; rows: element e of all K rows per thread, every load in flight before a store
+    if (tid < a.K) {
+        const unsigned long long key = sel[tid];
+        float* rec = records + (size_t)tid * rs;
         if (key == KEY_SENTINEL) {  // fewer than K candidates on this rank
-            if (tid == 0) {
-                rec[0] = INFINITY;
-                reinterpret_cast<int*>(rec + 1)[0] = INT_MAX;
-            }
-            for (int e = tid; e < hd; e += MERGE_WG) rec[2 + e] = 0.f;
+            rec[0] = INFINITY;
+            reinterpret_cast<int*>(rec + 1)[0] = INT_MAX;
         } else {
             const int li = key_idx(key);
-            if (tid == 0) {
-                rec[0] = key_cost(key);
-                reinterpret_cast<int*>(rec + 1)[0] = li < n_loc ? shard_lo + li : a.n_global + (li - n_loc);
-            }
-            const float* src = a.actions + (size_t)li * hd;
-            for (int e = tid; e < hd; e += MERGE_WG) rec[2 + e] = src[e];
+            rec[0] = key_cost(key);
+            reinterpret_cast<int*>(rec + 1)[0] = li < n_loc ? shard_lo + li : a.n_global + (li - n_loc);
         }
+    }
+    const float* rows[KREG];
+    bool dead[KREG];
+#pragma unroll
+    for (int r = 0; r < KREG; ++r) {
+        const unsigned long long key = sel[r < a.K ? r : 0];
+        dead[r] = key == KEY_SENTINEL;
+        rows[r] = a.actions + (size_t)(dead[r] ? 0 : key_idx(key)) * hd;
+    }
+    for (int e = tid; e < hd; e += MERGE_WG) {
+        float xs[KREG];
+#pragma unroll
+        for (int r = 0; r < KREG; ++r) xs[r] = rows[r][e];
+#pragma unroll
+        for (int r = 0; r < KREG; ++r)
+            if (r < a.K) records[(size_t)r * rs + 2 + e] = dead[r] ? 0.f : xs[r];
     }
 }
 
