@@ -280,34 +280,43 @@ __device__ __forceinline__ void reduce_groups_pair(float& a, float& b) {
     a = b = __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
-// steps per staged action chunk: divides H, whole float4s per row, odd float4 count (16 rows then hit 16 distinct
-// bank groups) when possible
-__host__ __device__ constexpr int r16_chunk_steps(int h, int d) {
+// steps per staged action chunk: divides H, whole vectors (float4, or float2 when h*d is not a multiple of 4) per
+// row, odd vector count (16 rows then hit 16 distinct bank groups) when possible
+__host__ __device__ constexpr int r16_chunk_steps(int h, int d, int vw) {
     int best = 0;
     for (int tc = 1; tc <= h; ++tc)
-        if (h % tc == 0 && (tc * d) % 4 == 0 && tc * d <= 96) best = tc;
+        if (h % tc == 0 && (tc * d) % vw == 0 && tc * d <= 110) best = tc;
     return best;
 }
+template <int VW> struct VecOf;
+template <> struct VecOf<4> { using type = float4; };
+template <> struct VecOf<2> { using type = float2; };
 
 // Everything a wavefront needs to roll 16 trajectories out; step() is shared by the stand-alone rollout kernel
 // and the sample+rollout kernel, so both produce the same bits for the same actions.
 template <int H, int D, int O, int KIND>
 struct Tile16 {
-    static constexpr int REM = O > 16 ? O - 16 : 0;   // output columns beyond the 16 x 16 tile
-    static constexpr int NX = REM + D;                // extra contraction entries: columns >= 16, then the actions
-    static constexpr int NKX = (NX + 3) / 4;          // MFMAs that carry them
-    static constexpr int CT4 = ((O + 3) / 4) * 4;     // row stride of Mp
+    // O <= 20: ONE 16-column output tile on the matrix pipe + up to 4 extra columns as permlane-reduced dot products;
+    // 20 < O <= 28: TWO output tiles (columns 0..15 and 16..31, zero padded), no extra columns.
+    static constexpr int NT = O > 20 ? 2 : 1;
+    static constexpr int OP = NT == 2 ? 32 : O;        // observation rows of Mp (the action rows follow)
+    static constexpr int REM = NT == 1 && O > 16 ? O - 16 : 0;  // output columns beyond the matrix-pipe tiles
+    static constexpr int NKO = 4 * NT;                 // MFMAs fed by accumulator registers (tile s/4, register s%4)
+    static constexpr int NX = REM + D;                 // extra contraction entries: columns >= 16 (NT = 1), then the actions
+    static constexpr int NKX = (NX + 3) / 4;           // MFMAs that carry them
+    static constexpr int NK = NKO + NKX;
+    static constexpr int CT4 = NT == 2 ? 32 : ((O + 3) / 4) * 4;  // row stride of Mp
     static constexpr int SLACK = 4;  // floats in front of an action buffer: entries that are not actions read there
     static constexpr int TAIL = 8;   // and behind it: padding entries of the last row
-    static_assert(REM <= 4, "observation width up to 20");
+    static_assert(O >= 16 && O <= 28, "observation width 16..28 (the staged observation keeps entry 31 as its zero)");
 
-    float mA[4 + NKX];                     // model operands: one register per MFMA
-    float wR[REM > 0 ? REM : 1][4 + NKX];  // weights of this lane's contraction entries into output column 16 + r
-    float cw[NKX];                         // ctrl_w where the extra entry is an action, else 0
+    float mA[NT][NK];                   // model operands: one register per MFMA
+    float wR[REM > 0 ? REM : 1][NK];    // weights of this lane's contraction entries into output column 16 + r
+    float cw[NKX];                      // ctrl_w where the extra entry is an action, else 0
     bool is_act[NKX];
-    f32x4 obs_init;
+    f32x4 obs_init[NT];
     float rem_init[REM > 0 ? REM : 1];
-    int perm_base[4], perm_rem[REM > 0 ? REM : 1];  // which observation entries this lane starts from
+    int perm_base[NT][4], perm_rem[REM > 0 ? REM : 1];  // which observation entries this lane starts from
     float pen, lin_w, ksum, flip_th;
     bool ang_is_col1, use_min;
     int g;
@@ -315,15 +324,15 @@ struct Tile16 {
     // All loads are unconditional (Mp carries a zero row behind the model, perm is padded to 32 entries that point
     // at a zero slot): a select behind a load would make the wave wait for it right here, in front of everything
     // the kernel does before it needs the model.
-    static constexpr int ZROW = O + D;  // the zero row of Mp
+    static constexpr int ZROW = OP + D;  // the zero row of Mp
     __device__ __forceinline__ void load(const FastRolloutArgs& a, int lane) {
-        static_assert(O >= 16, "Mp rows / columns 0..15 exist");
         const int j = lane & 15;
         g = lane >> 4;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int k = 4 * g + s;
-            mA[s] = a.Mp[k * CT4 + j];
+        for (int s = 0; s < NKO; ++s) {
+            const int k = 16 * (s / 4) + 4 * g + (s % 4);  // the observation column accumulator (s/4)[s%4] of slot g holds
+#pragma unroll
+            for (int to = 0; to < NT; ++to) mA[to][s] = a.Mp[k * CT4 + 16 * to + j];
 #pragma unroll
             for (int r = 0; r < REM; ++r) wR[r][s] = a.Mp[k * CT4 + 16 + r];
         }
@@ -331,17 +340,20 @@ struct Tile16 {
         for (int q = 0; q < NKX; ++q) {
             const int e = 4 * q + g;
             const bool valid = e < NX;
-            const int k = !valid ? ZROW : (e < REM ? 16 + e : O + (e - REM));
-            mA[4 + q] = a.Mp[k * CT4 + j];
+            const int k = !valid ? ZROW : (e < REM ? 16 + e : OP + (e - REM));
 #pragma unroll
-            for (int r = 0; r < REM; ++r) wR[r][4 + q] = a.Mp[k * CT4 + 16 + r];
+            for (int to = 0; to < NT; ++to) mA[to][NKO + q] = a.Mp[k * CT4 + 16 * to + j];
+#pragma unroll
+            for (int r = 0; r < REM; ++r) wR[r][NKO + q] = a.Mp[k * CT4 + 16 + r];
             is_act[q] = valid && e >= REM;
             cw[q] = is_act[q] ? a.ctrl_w : 0.f;
         }
         // the start observation is gathered through `perm`: two dependent global round trips if done here.  Only the
         // indices are fetched now; load_obs() picks the values from an LDS copy the kernel stages meanwhile.
 #pragma unroll
-        for (int v = 0; v < 4; ++v) perm_base[v] = a.perm[4 * g + v];
+        for (int to = 0; to < NT; ++to)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) perm_base[to][v] = a.perm[16 * to + 4 * g + v];
 #pragma unroll
         for (int r = 0; r < REM; ++r) perm_rem[r] = a.perm[16 + r];
         // cost terms that read observation columns 0 / 1 live in slot 0 only
@@ -358,11 +370,13 @@ struct Tile16 {
     // loads -- up into the prologue)
     __device__ __forceinline__ void load_obs(const float* obs) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            int pb = perm_base[v];
-            asm volatile("" : "+v"(pb));
-            obs_init[v] = obs[pb];
-        }
+        for (int to = 0; to < NT; ++to)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                int pb = perm_base[to][v];
+                asm volatile("" : "+v"(pb));
+                obs_init[to][v] = obs[pb];
+            }
 #pragma unroll
         for (int r = 0; r < REM; ++r) {
             int pb = perm_rem[r];
@@ -379,12 +393,13 @@ struct Tile16 {
     // Rollout state of the lane's trajectory share.  Kernels drive it with their own (unrolled) time loop:
     // init, H x step(rd) with entry q of the step's actions at rd[4 * q], then cost().
     struct State {
-        f32x4 cur;
+        f32x4 cur[NT];
         float xr[REM > 0 ? REM : 1];
         float acc_s, acc_b;
     };
     __device__ __forceinline__ void init(State& st) const {
-        st.cur = obs_init;
+#pragma unroll
+        for (int to = 0; to < NT; ++to) st.cur[to] = obs_init[to];
 #pragma unroll
         for (int r = 0; r < REM; ++r) st.xr[r] = rem_init[r];
         st.acc_s = 0.f;
@@ -402,21 +417,21 @@ struct Tile16 {
             xv[q] = v;
         }
         // step cost: this lane's share, then the sum over the trajectory's 4 lanes
-        const float ang = ang_is_col1 ? st.cur[1] : st.cur[0];
+        const float ang = ang_is_col1 ? st.cur[0][1] : st.cur[0][0];
         float c = 0.f;
         c += (ang > flip_th) ? pen : 0.f;
         c += (ang < -flip_th) ? pen : 0.f;
 #pragma unroll
         for (int q = 0; q < NKX; ++q) c = __builtin_fmaf(xv[q] * xv[q], cw[q], c);
-        c = __builtin_fmaf(lin_w, st.cur[0], c);
+        c = __builtin_fmaf(lin_w, st.cur[0][0], c);
         float pr[REM > 0 ? REM : 1];
 #pragma unroll
         for (int r = 0; r < REM; ++r) {
             float p = 0.f;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) p = __builtin_fmaf(st.cur[s], wR[r][s], p);
+            for (int s = 0; s < 4; ++s) p = __builtin_fmaf(st.cur[0][s], wR[r][s], p);
 #pragma unroll
-            for (int q = 0; q < NKX; ++q) p = __builtin_fmaf(xv[q], wR[r][4 + q], p);
+            for (int q = 0; q < NKX; ++q) p = __builtin_fmaf(xv[q], wR[r][NKO + q], p);
             pr[r] = p;
         }
         // the first extra column (consumed by slot 0 = lanes 0..15) shares its reduction with the cost, which is
@@ -429,14 +444,24 @@ struct Tile16 {
         for (int r = 1; r < REM; ++r) pr[r] = reduce_groups(pr[r]);
         st.acc_s = __builtin_fmaf(st.acc_s, ksum, c);
         st.acc_b = c < st.acc_b ? c : st.acc_b;
-        // model step on the matrix pipe
-        f32x4 nxt = f32x4{0.f, 0.f, 0.f, 0.f};
+        // model step on the matrix pipe: NT independent accumulator chains
+        f32x4 nxt[NT];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) nxt = __builtin_amdgcn_mfma_f32_16x16x4f32(mA[s], st.cur[s], nxt, 0, 0, 0);
+        for (int to = 0; to < NT; ++to) nxt[to] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < NKX; ++q) nxt = __builtin_amdgcn_mfma_f32_16x16x4f32(mA[4 + q], xv[q], nxt, 0, 0, 0);
+        for (int s = 0; s < NKO; ++s)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) st.cur[v] = act_fn(nxt[v], std::integral_constant<int, KIND>{});
+            for (int to = 0; to < NT; ++to)
+                nxt[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(mA[to][s], st.cur[s / 4][s % 4], nxt[to], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NKX; ++q)
+#pragma unroll
+            for (int to = 0; to < NT; ++to)
+                nxt[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(mA[to][NKO + q], xv[q], nxt[to], 0, 0, 0);
+#pragma unroll
+        for (int to = 0; to < NT; ++to)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) st.cur[to][v] = act_fn(nxt[to][v], std::integral_constant<int, KIND>{});
 #pragma unroll
         for (int r = 0; r < REM; ++r) st.xr[r] = act_fn(pr[r], std::integral_constant<int, KIND>{});
     }
@@ -498,13 +523,16 @@ template <int H, int D, int O, int KIND, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void rollout16_kernel(FastRolloutArgs a) {
     using Tile = Tile16<H, D, O, KIND>;
     constexpr int HD = H * D;
-    constexpr int TC = r16_chunk_steps(H, D);  // steps per action chunk
-    static_assert(TC > 0, "no 16-byte aligned action chunk for this (H, D)");
+    constexpr int VW = HD % 4 == 0 ? 4 : 2;    // floats per load: rows are 16-byte aligned only if h*d % 4 == 0
+    static_assert(HD % 2 == 0, "8-byte aligned action rows");
+    using Vec = typename VecOf<VW>::type;
+    constexpr int TC = r16_chunk_steps(H, D, VW);  // steps per action chunk
+    static_assert(TC > 0, "no aligned action chunk for this (H, D)");
     constexpr int CB = TC * D;                 // floats per row and chunk
-    constexpr int C4 = CB / 4;
-    constexpr int CBP = (C4 % 2) ? CB : CB + 4;  // LDS row stride: odd number of float4s
+    constexpr int C4 = CB / VW;                // vectors per row and chunk
+    constexpr int CBP = (C4 % 2) ? CB : CB + VW;  // LDS row stride: odd number of vectors
     constexpr int NCH = H / TC;
-    constexpr int F4 = 16 * C4;                // float4s per chunk of a 16-trajectory tile
+    constexpr int F4 = 16 * C4;                // vectors per chunk of a 16-trajectory tile
     constexpr int NLD = (F4 + 63) / 64;        // cooperative load instructions per chunk
     constexpr int STG = Tile::SLACK + 16 * CBP + Tile::TAIL;
     // the tile's actions are one contiguous 16 x H x D block of HBM: the wave fetches it with full-width coalesced
@@ -540,13 +568,13 @@ __global__ __launch_bounds__(64 * WAVES) void rollout16_kernel(FastRolloutArgs a
     for (int tile_id = wave * gridDim.x + blockIdx.x; tile_id < tiles; tile_id += WAVES * gridDim.x) {
         const int row = tile_id * 16 + (lane & 15);
         const bool live = row < a.n_rows;
-        const float4* src[NLD];
+        const Vec* src[NLD];
 #pragma unroll
         for (int m = 0; m < NLD; ++m) {
             const int r = tile_id * 16 + ld_row[m];
-            src[m] = reinterpret_cast<const float4*>(a.actions + (size_t)(r < a.n_rows ? r : 0) * HD) + ld_c4[m];
+            src[m] = reinterpret_cast<const Vec*>(a.actions + (size_t)(r < a.n_rows ? r : 0) * HD) + ld_c4[m];
         }
-        float4 pre[NLD];
+        Vec pre[NLD];
 #pragma unroll
         for (int m = 0; m < NLD; ++m) pre[m] = src[m][0];
         typename Tile::State st;
@@ -559,7 +587,7 @@ __global__ __launch_bounds__(64 * WAVES) void rollout16_kernel(FastRolloutArgs a
 #pragma unroll
                 for (int m = 0; m < NLD; ++m)
                     if (ld_on[m])
-                        *reinterpret_cast<float4*>(&stage[wave][Tile::SLACK + ld_row[m] * CBP + 4 * ld_c4[m]]) = pre[m];
+                        *reinterpret_cast<Vec*>(&stage[wave][Tile::SLACK + ld_row[m] * CBP + VW * ld_c4[m]]) = pre[m];
                 if (t / TC + 1 < NCH) {
 #pragma unroll
                     for (int m = 0; m < NLD; ++m) pre[m] = src[m][(t / TC + 1) * C4];
@@ -1086,7 +1114,9 @@ __global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64 + (KREG > 0 ? 64 : 0
     constexpr int ROWS = TPB * D;                    // (trajectory, dim) rows, one thread each
     constexpr int NT = ((ROWS + 63) / 64) * 64;      // sampling threads
     constexpr int NTT = NT + (PM ? 64 : 0);          // + the selection wavefront
-    static_assert(NTT <= 1024 && HD % 4 == 0, "workgroup shape");
+    static_assert(NTT <= 1024 && HD % 2 == 0, "workgroup shape");
+    constexpr int VW = HD % 4 == 0 ? 4 : 2;  // floats per vector of the tile -> HBM copy (rows are 4 * HD bytes)
+    using Vec = typename VecOf<VW>::type;
     __shared__ __attribute__((aligned(16))) float ms[2 * HD];  // mean | std
     __shared__ __attribute__((aligned(16))) float tilebuf[Tile::SLACK + TPB * HD + Tile::TAIL];
     __shared__ unsigned long long wg_keys[2][RW][32];
@@ -1213,9 +1243,9 @@ __global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64 + (KREG > 0 ? 64 : 0
         __syncthreads();
     }
     {   // the tile is a contiguous block of the action tensor
-        const int total4 = (n_rows - base < TPB ? n_rows - base : TPB) * (HD / 4);
-        const float4* t4 = reinterpret_cast<const float4*>(tile_rows);
-        float4* g4 = reinterpret_cast<float4*>(sa.out + (size_t)base * HD);
+        const int total4 = (n_rows - base < TPB ? n_rows - base : TPB) * (HD / VW);
+        const Vec* t4 = reinterpret_cast<const Vec*>(tile_rows);
+        Vec* g4 = reinterpret_cast<Vec*>(sa.out + (size_t)base * HD);
         for (int e = tid; e < total4; e += NTT) g4[e] = t4[e];
     }
     if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[11] = wall_clock64();
@@ -1244,7 +1274,16 @@ __global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64 + (KREG > 0 ? 64 : 0
 }  // namespace
 
 // shapes (H, D, O) with a compiled matrix-pipe rollout; anything else runs on the generic kernels
-#define ICEM_FAST_SHAPES(X) X(30, 6, 17) X(30, 6, 18) X(12, 6, 17) X(13, 4, 17)
+#define ICEM_FAST_SHAPES(X) X(30, 6, 17) X(30, 6, 18) X(12, 6, 17) X(13, 4, 17) X(30, 17, 24)
+
+// rollout waves a single-launch workgroup can hold for this shape: 16 * RW * D sampling threads (+ 64) within 1024
+// threads, the [16 * RW, H, D] tile within ~120 KB of LDS
+constexpr int single_launch_max_rw(int h, int d) {
+    int best = 0;
+    for (int rw = 1; rw <= 8; rw *= 2)
+        if (((16 * rw * d + 63) / 64) * 64 + 64 <= 1024 && 16 * rw * h * d * 4 <= 120 * 1024) best = rw;
+    return best;
+}
 
 bool fast_rollout_supported(int h, int d, int O, int K) {
     if (K > 32) return false;
@@ -1304,7 +1343,7 @@ static bool sample_rollout_shape(int h, int d, int O, int rounds, int n_rows, in
     r16_shape(n_rows, &grid, &rw);
     if (rounds != 10 || rw > max_rw || n_rows <= 0 || !fast_rollout_supported(h, d, O, 1) || !fast_sample_supported(h, d))
         return false;
-    if (rw > 8) return false;  // one slab of 16 * rw trajectories per workgroup
+    if (rw > single_launch_max_rw(h, d)) return false;  // one slab of 16 * rw trajectories per workgroup
     *grid_out = std::min(grid, (n_rows + 16 * rw - 1) / (16 * rw));
     *rw_out = rw;
     return true;
@@ -1334,13 +1373,15 @@ void launch_sample_rollout(const FastIterArgs& a, int h, int d, int O, int kind,
             hipLaunchKernelGGL((sample_rollout_kernel<HH, DD, OO, 0, 10, WW, KR, RC>), dim3(grid), dim3(NT), 0, st, a); \
         return;                                                                                                         \
     }
-#define XW(HH, DD, OO, WW)                                    \
-    if (rw == WW) {                                           \
-        if constexpr (WW <= 4) {                              \
-            if (merge_prologue && a.m.records) XK(HH, DD, OO, WW, 12, true)  \
-            if (merge_prologue) XK(HH, DD, OO, WW, 12, false) \
-        }                                                     \
-        XK(HH, DD, OO, WW, 0, false)                          \
+#define XW(HH, DD, OO, WW)                                                   \
+    if constexpr (WW <= single_launch_max_rw(HH, DD)) {                      \
+        if (rw == WW) {                                                      \
+            if constexpr (WW <= 4) {                                         \
+                if (merge_prologue && a.m.records) XK(HH, DD, OO, WW, 12, true)  \
+                if (merge_prologue) XK(HH, DD, OO, WW, 12, false)            \
+            }                                                                \
+            XK(HH, DD, OO, WW, 0, false)                                     \
+        }                                                                    \
     }
 #define XR(HH, DD, OO)                   \
     if (h == HH && d == DD && O == OO) { \

@@ -865,7 +865,11 @@ int launch_topk(int n, int K, const void* costs, void* out_c, int* out_i, void* 
 int ensure_fast_model(icem_handle* h) {
     if (h->fast_model_ready) return ICEM_OK;
     const int O = h->O, o = h->obs_dim, d = h->cfg.act_dim;
-    const int CT4 = ((O + 3) / 4) * 4;
+    // layout of Tile16 (icem_fused.hip): O <= 20 -> one 16-column matrix-pipe tile + extra columns, Mp [O + d + 1, ceil4(O)];
+    // O > 20 -> two tiles, observation block padded to 32 rows / columns, Mp [32 + d + 1, 32]
+    const bool two = O > 20;
+    const int OP = two ? 32 : O;
+    const int CT4 = two ? 32 : ((O + 3) / 4) * 4;
     std::vector<int> perm;
     perm.push_back(h->cost.lin_idx);
     h->flip_col = -1;
@@ -879,18 +883,18 @@ int ensure_fast_model(icem_handle* h) {
     }
     for (int k = 0; k < O; ++k)
         if (std::find(perm.begin(), perm.end(), k) == perm.end()) perm.push_back(k);
-    std::vector<float> Mp((size_t)(O + d + 1) * CT4, 0.f);  // + one zero row (contraction slots without an entry)
+    std::vector<float> Mp((size_t)(OP + d + 1) * CT4, 0.f);  // + one zero row (contraction slots without an entry)
     auto Aat = [&](int r, int c) { return (r < o && c < o) ? h->A_host[(size_t)r * o + c] : 0.0; };
     auto Bat = [&](int j, int c) { return c < o ? h->B_host[(size_t)j * o + c] : 0.0; };
     for (int k = 0; k < O; ++k)
         for (int c = 0; c < O; ++c) Mp[(size_t)k * CT4 + c] = (float)Aat(perm[k], perm[c]);
     for (int j = 0; j < d; ++j)
-        for (int c = 0; c < O; ++c) Mp[(size_t)(O + j) * CT4 + c] = (float)Bat(j, perm[c]);
-    if (h->Mp_dev) (void)hipFree(h->Mp_dev);
-    if (h->perm_dev) (void)hipFree(h->perm_dev);
+        for (int c = 0; c < O; ++c) Mp[(size_t)(OP + j) * CT4 + c] = (float)Bat(j, perm[c]);
     for (int k = 0; k < (int)perm.size(); ++k)
         if (k >= o || perm[k] >= o) perm[k] = 31;  // padding columns start from the zero slot of the staged observation
     perm.resize(32, 31);
+    if (h->Mp_dev) (void)hipFree(h->Mp_dev);
+    if (h->perm_dev) (void)hipFree(h->perm_dev);
     ICEM_HIP_TRY(hipMalloc(&h->Mp_dev, Mp.size() * sizeof(float)));
     ICEM_HIP_TRY(hipMalloc(&h->perm_dev, perm.size() * sizeof(int)));
     ICEM_HIP_TRY(hipMemcpy(h->Mp_dev, Mp.data(), Mp.size() * sizeof(float), hipMemcpyHostToDevice));

@@ -507,7 +507,7 @@ def test_sharded_processes_on_one_gpu(tmp_path):
         assert np.array_equal(z["mean"], np_(pl.mean))
 
 
-@pytest.mark.parametrize("h,d,o", [(30, 6, 17), (30, 6, 18), (12, 6, 17), (13, 4, 17)])
+@pytest.mark.parametrize("h,d,o", [(30, 6, 17), (30, 6, 18), (12, 6, 17), (13, 4, 17), (30, 17, 24)])
 @pytest.mark.parametrize("kind", [0, 1])
 @pytest.mark.parametrize("mode", ["sum", "best", "final"])
 def test_fast_kernels_all_compiled_shapes(h, d, o, kind, mode):
@@ -664,7 +664,8 @@ def test_fast_path_edge_populations(N, K, iters, keep, shift, use_mean):
 
 
 @pytest.mark.parametrize("h,d,o,kind,mode,N", [(30, 6, 18, 1, "best", 16453), (12, 6, 17, 0, "final", 5001),
-                                               (13, 4, 17, 1, "sum", 12003), (30, 6, 17, 0, "sum", 33001)])
+                                               (13, 4, 17, 1, "sum", 12003), (30, 6, 17, 0, "sum", 33001),
+                                               (30, 17, 24, 1, "sum", 5001), (30, 17, 24, 0, "best", 16389)])
 def test_many_tiles_per_workgroup(h, d, o, kind, mode, N):
     """More 16-trajectory tiles than candidate lists: workgroups hold 2, 4 or 8 rollout waves (single-launch kernel)
     or 16 (N = 33001: sampler + rollout kernels), the last pass is ragged and the workgroup list merge runs.
@@ -695,7 +696,8 @@ def test_many_tiles_per_workgroup(h, d, o, kind, mode, N):
 
 @pytest.mark.parametrize("h,d,o,kind,N,iters", [(30, 6, 17, 0, 777, 4), (30, 6, 18, 1, 5001, 3), (13, 4, 17, 1, 12003, 4),
                                                 (12, 6, 17, 0, 4096, 5), (30, 6, 17, 0, 20011, 3),
-                                                (30, 6, 17, 0, 65536, 4), (13, 4, 17, 1, 50001, 3)])
+                                                (30, 6, 17, 0, 65536, 4), (13, 4, 17, 1, 50001, 3),
+                                                (30, 17, 24, 1, 3001, 3), (30, 17, 24, 0, 16384, 3)])
 def test_plan_step_merge_prologue_equals_split_api(h, d, o, kind, N, iters):
     """icem_plan_step folds every merge but the last into the next iteration's launch (1, 2 or 4 rollout waves per
     workgroup; N = 20011 mixes 8-wave launches without and 4-wave launches with the prologue; N >= 50001 uses the
