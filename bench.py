@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- iCEM inner planning loop on MI355X: traj-steps/s of whole MPC steps.
 
-  python bench.py --gpus N --steps K --warmup W [--workload c2|c4]
+  python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4]
 
 A "step" is one MPC step = all CEM iterations (sample -> rollout -> cost -> top-k -> refit) of one
 `get_action`, on synthetic HalfCheetah-shaped input already resident in HBM.  Workload c2 (default;
 BASELINE.json's metric is quoted on it): N=4096, h=30, d=6, o=17, beta=0.25, 5 iterations with
-population decay (4096, 3276, 2620, 2096, 1676), K=10, f32.  Workload c4: N=65536, same otherwise.
+population decay (4096, 3276, 2620, 2096, 1676), K=10, f32.  Workload c4: N=65536, same otherwise.  Workload c3:
+HumanoidStandup action shapes (N=16384, d=17, beta=2.0, 3 iterations) on a 24-dim tanh latent model.
 For --gpus G > 1 (launched by torch.distributed.run, one rank per GPU over RCCL) the per-GPU
 population is fixed (weak scaling): global N = G * N, sharded by global trajectory index, with one
 all-gather of the ranks' K candidate records per CEM iteration.
@@ -35,13 +36,17 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable
 WORKLOADS = {
     "c2": dict(N=4096, h=30, d=6, o=17, beta=0.25, iters=5, name="HalfCheetah-shaped synthetic, N=4096 h=30 d=6 o=17 beta=0.25, 5 CEM iters"),
     "c4": dict(N=65536, h=30, d=6, o=17, beta=0.25, iters=5, name="HalfCheetah-shaped synthetic, N=65536 h=30 d=6 o=17 beta=0.25, 5 CEM iters"),
+    # BASELINE.json configs[2]: HumanoidStandup action shapes (d=17, bounds +-0.4, beta=2.0, 3 iterations); the real env
+    # has o=378 MuJoCo observations, here a 24-dim tanh latent of which obs[2] enters the cost (not a default bench line)
+    "c3": dict(N=16384, h=30, d=17, o=24, beta=2.0, iters=3, env="humanoid", kind=1,
+               name="HumanoidStandup-shaped synthetic, N=16384 h=30 d=17 o=24 (latent) beta=2.0, 3 CEM iters, tanh model"),
 }
 
 
 def make_planner(w, rank, world, seed=1234):
-    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env
-    env = halfcheetah_env(w["o"])
-    model = DeviceSyntheticModel.make(w["o"], w["d"], kind=0)
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env, humanoid_standup_env
+    env = humanoid_standup_env(w["o"]) if w.get("env") == "humanoid" else halfcheetah_env(w["o"])
+    model = DeviceSyntheticModel.make(w["o"], w["d"], kind=w.get("kind", 0))
     cfg = IcemConfig(horizon=w["h"], act_dim=w["d"], num_traj=w["N"] * world, opt_iters=w["iters"],
                      noise_beta=w["beta"], dtype="f32", seed=seed, rank=rank, world=world)
     pl = IcemPlanner(cfg, env.action_space.low, env.action_space.high, device=f"cuda:{torch.cuda.current_device()}")
@@ -79,7 +84,7 @@ def cpu_baseline(w, model, env, budget_s=12.0):
         pops.append(n)
     A, B = CO.c64(model.A), CO.c64(model.B)
     obs0 = 0.1 * np.random.RandomState(0).randn(o)
-    low, high = -np.ones(d), np.ones(d)
+    low, high = np.asarray(env.action_space.low, dtype=np.float64), np.asarray(env.action_space.high, dtype=np.float64)
     c = env.cost_spec
     actions = np.zeros((pops[0], h, d))
     costs = np.zeros(pops[0])
@@ -88,10 +93,10 @@ def cpu_baseline(w, model, env, budget_s=12.0):
     done, t0 = 0, time.perf_counter()
     reps = 0
     while True:
-        mean = np.zeros((h, d))
-        std = 0.5 * np.ones((h, d))
+        mean = np.zeros((h, d)) + (high + low) / 2
+        std = np.ones((h, d)) * (high - low) / 2 * 0.5
         for it, n_it in enumerate(pops):
-            lib.icem_c_iteration(n_it, h, d, o, K, w["beta"], 0.1, 1234, reps * 8 + it, 10, 0, A, B, obs0, low, high,
+            lib.icem_c_iteration(n_it, h, d, o, K, w["beta"], 0.1, 1234, reps * 8 + it, 10, model.kind, A, B, obs0, low, high,
                                  c.ctrl_weight, c.lin_idx, c.lin_weight, c.flip_idx, c.flip_penalty, c.flip_thresh,
                                  mean, std, actions, costs, idx, ec)
             done += n_it * h
@@ -168,7 +173,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS), help="c2 = the metric's configuration (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra large-population (c4) measurement")
     args = ap.parse_args()
@@ -227,8 +232,9 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": w["name"], "per_gpu_population": w["N"], "global_population": w["N"] * world,
-                       "traj_per_mpc_step": sum(pl.population_sizes), "model": "o' = o.A + a.B dense linear (synthetic)",
-                       "cost": "HalfCheetah cost_fn", "rng": "Philox4x32-10-seeded xoshiro128++ + Box-Muller", "parallelism": f"n-shard x{world}"},
+                       "traj_per_mpc_step": sum(pl.population_sizes),
+                       "model": "o' = tanh(o.A + a.B) dense (synthetic)" if model.kind == 1 else "o' = o.A + a.B dense linear (synthetic)",
+                       "cost": "HumanoidStandup cost_fn" if w.get("env") == "humanoid" else "HalfCheetah cost_fn", "rng": "Philox4x32-10-seeded xoshiro128++ + Box-Muller", "parallelism": f"n-shard x{world}"},
             "ms_per_mpc_step": 1e3 * elapsed / args.steps,
             "roofline": roofline,
             "kernels_us": {k: round(1e3 * v[0] / v[1], 2) for k, v in prof.items()},
