@@ -611,3 +611,67 @@ class IcemOracle:
         self.last_min_cost = float(np.min(costs))                       # icem.py:177
         self.trace.append(step_trace)
         return executed
+
+
+# --------------------------------------------------------------------------
+# f-3  MpcCemStd  (icem/controllers/mpc.py:142-327): the CEM baseline with truncated-normal sampling
+# --------------------------------------------------------------------------
+
+
+def truncnorm_from_uniform(u: np.ndarray, lower, upper, mean: np.ndarray, std: np.ndarray) -> np.ndarray:
+    """``scipy.stats.truncnorm.rvs(lower, upper, loc=mean, scale=std, size=(N, h, d))`` (mpc.py:188-198) given
+    the uniform draws ``u [N, h, d]`` scipy takes from the legacy global stream (one ``uniform(size=(N,h,d))`` call,
+    verified by the golden generator): the third-party inverse CDF, then the affine map."""
+    from scipy.stats import truncnorm
+    return truncnorm.ppf(u, lower, upper) * std[None] + mean[None]
+
+
+def cem_bounds(mean: np.ndarray, std: np.ndarray, low: np.ndarray, high: np.ndarray, like_levine: bool):
+    """``MpcCemStd._update_bounds`` (mpc.py:290-301) -> (std, lower, upper); lower / upper broadcast to ``[h, d]``."""
+    if like_levine:
+        std = np.maximum(1e-8, np.minimum(np.minimum((mean - low) / 2, (high - mean) / 2), std))
+        return std, np.full(mean.shape, -2.0), np.full(mean.shape, 2.0)
+    return std, (low - mean) / (std + 1e-8), (high - mean) / (std + 1e-8)
+
+
+class CemStdOracle:
+    """Array-based restatement of ``MpcCemStd`` (mpc.py:142-327).  ``uniforms(num) -> u [num, h, d]`` supplies the
+    uniform draws of one ``sample_action_sequences`` call; ``rollout_cost(obs, actions) -> costs``."""
+
+    def __init__(self, *, horizon, num_traj, opt_iterations, elites_size, alpha, init_std, like_levine, shift_means,
+                 execute_best_elite, low, high, rollout_cost, uniforms):
+        self.h, self.N, self.iters = horizon, num_traj, opt_iterations
+        self.K = max(2, min(elites_size, num_traj // 2))  # mpc.py:312-316
+        self.alpha, self.init_std = alpha, init_std
+        self.like_levine, self.shift_means, self.execute_best = like_levine, shift_means, execute_best_elite
+        self.low, self.high = np.asarray(low, dtype=np.float64), np.asarray(high, dtype=np.float64)
+        self.rollout_cost, self.uniforms = rollout_cost, uniforms
+        self.trace = []
+
+    def _init_std(self):
+        return np.ones((self.h, len(self.low))) * (self.high - self.low) / 2.0 * self.init_std
+
+    def beginning_of_rollout(self):  # mpc.py:158-170
+        self.mean = np.zeros((self.h, len(self.low))) + (self.high + self.low) / 2.0
+        self.std, self.lower, self.upper = cem_bounds(self.mean, self._init_std(), self.low, self.high, self.like_levine)
+
+    def get_action(self, obs):  # mpc.py:200-262
+        actions = costs = None
+        for _ in range(self.iters):
+            actions = truncnorm_from_uniform(self.uniforms(self.N), self.lower, self.upper, self.mean, self.std)
+            costs = self.rollout_cost(obs, actions)
+            idx = topk_sorted(costs, self.K)                        # mpc.py:270
+            elites = actions[idx]
+            self.mean, self.std = refit(elites, self.mean, self.std, self.alpha)  # mpc.py:277-281
+            self.std, self.lower, self.upper = cem_bounds(self.mean, self.std, self.low, self.high, self.like_levine)
+            self.trace.append((actions, costs, idx, self.mean.copy(), self.std.copy(), self.lower.copy(), self.upper.copy()))
+        best = int(np.argmin(costs))
+        executed = actions[best][0].copy() if self.execute_best else self.mean[0].copy()  # mpc.py:230-233
+        if self.shift_means:                                          # mpc.py:236-241
+            last = self.mean[-1] * 0 if self.like_levine else self.mean[-1].copy()
+            self.mean[:-1] = self.mean[1:]
+            self.mean[-1] = last
+        else:
+            self.mean = np.zeros_like(self.mean)
+        self.std, self.lower, self.upper = cem_bounds(self.mean, self._init_std(), self.low, self.high, self.like_levine)
+        return executed

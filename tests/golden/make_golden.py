@@ -290,6 +290,131 @@ def run_case(name, *, N, h, d, o, beta, iters, seed, n_steps, kind, env_kind,
           f"{len(colorednoise.CALLS)} noise calls, {len(log['costs'])} iterations")
 
 
+def run_cem_std_case(name, *, N, h, d, o, iters, seed, n_steps, kind, like_levine, shift_means=True,
+                     execute_best=True, cost_mode="sum", K=10, alpha=0.1, init_std=0.5, bounds=1.0):
+    """The CEM baseline ``MpcCemStd`` (icem/controllers/mpc.py:142-327): truncated-normal sampling through
+    ``scipy.stats.truncnorm.rvs``.  The uniform draws behind every sampling call are recovered by replaying the
+    legacy global stream (scipy draws ONE ``uniform(size=(N, h, d))`` per call) and checked against the samples."""
+    import controllers.mpc as ref_mpc
+    from models.abstract_models import ForwardModelWithDefaults
+    from gym import spaces
+    from scipy.stats import truncnorm as sp_truncnorm
+    import environments.mujoco as ref_mj
+
+    A, B = make_model_mats(o, d)
+    calls = []
+
+    class RecordingTruncnorm:
+        @staticmethod
+        def rvs(a, b, loc=0, scale=1, size=1):
+            state = np.random.get_state()
+            out = sp_truncnorm.rvs(a, b, loc=loc, scale=scale, size=size)
+            after = np.random.get_state()
+            np.random.set_state(state)
+            u = np.random.uniform(size=size)
+            a2 = np.random.get_state()
+            assert a2[2] == after[2] and np.array_equal(a2[1], after[1]), "uniform replay out of sync with scipy"
+            assert np.array_equal(sp_truncnorm.ppf(u, a, b) * scale + loc, out)
+            shp = tuple(size)[1:]
+            calls.append((u, np.broadcast_to(np.asarray(a, dtype=np.float64), shp).copy(),
+                          np.broadcast_to(np.asarray(b, dtype=np.float64), shp).copy(), out.copy()))
+            return out
+
+    class FakeEnv:
+        def __init__(self):
+            self.name = "FakeHalfCheetah"
+            self.action_space = spaces.Box(low=-bounds * np.ones(d), high=bounds * np.ones(d))
+            self.penalise_flipping = True
+
+        def cost_fn(self, obs, act, next_obs):
+            return ref_mj.HalfCheetahMaybeWithPosition.cost_fn(self, obs, act, next_obs)
+
+        def reward_fn(self, obs, act, next_obs):
+            return -self.cost_fn(obs, act, next_obs)
+
+    class FakeModel(ForwardModelWithDefaults):
+        def train(self, buffer): pass
+        def save(self, path): pass
+        def load(self, path): pass
+
+        def predict(self, *, observations, states, actions):
+            nxt = np.zeros_like(observations)
+            for k in range(o):
+                nxt = nxt + observations[..., k:k + 1] * A[k]
+            for j in range(d):
+                nxt = nxt + actions[..., j:j + 1] * B[j]
+            if kind == 1:
+                nxt = np.tanh(nxt)
+            return nxt, None, np.zeros(observations.shape[:-1] + (1,))
+
+    env = FakeEnv()
+    orig_tn = ref_mpc.truncnorm
+    ref_mpc.truncnorm = RecordingTruncnorm
+    try:
+        import io, contextlib
+        ctrl = ref_mpc.MpcCemStd(env=env, forward_model=FakeModel(env=env), horizon=h, num_simulated_trajectories=N,
+                                 cost_along_trajectory=cost_mode, verbose=False, do_visualize_plan=False,
+                                 action_sampler_params=dict(alpha=alpha, elites_size=K, opt_iterations=iters,
+                                                            init_std=init_std, shift_means=shift_means,
+                                                            execute_best_elite=execute_best,
+                                                            bounds_like_levine=like_levine))
+        log = {"sim_actions": [], "costs": [], "elite_idx": [], "mean": [], "std": [], "lower": [], "upper": []}
+        orig_sim, orig_upd = ctrl.simulate_trajectories, ctrl.update_distributions
+
+        def sim(*, obs, state, action_sequences):
+            log["sim_actions"].append(np.array(action_sequences))
+            return orig_sim(obs=obs, state=state, action_sequences=action_sequences)
+
+        def upd(paths, costs):
+            log["costs"].append(np.array(costs))
+            log["elite_idx"].append(np.array(costs).argsort()[:ctrl.num_elites])
+            orig_upd(paths, costs)
+            shp = ctrl.mean.shape
+            log["mean"].append(ctrl.mean.copy())
+            log["std"].append(ctrl.std.copy())
+            log["lower"].append(np.broadcast_to(np.asarray(ctrl.lower, dtype=np.float64), shp).copy())
+            log["upper"].append(np.broadcast_to(np.asarray(ctrl.upper, dtype=np.float64), shp).copy())
+
+        ctrl.simulate_trajectories = sim
+        ctrl.update_distributions = upd
+        np.random.seed(seed)
+        obs = 0.1 * np.random.RandomState(1000 + seed).randn(o)
+        with contextlib.redirect_stdout(io.StringIO()):
+            ctrl.beginning_of_rollout(observation=obs, state=None, mode="train")
+        out = {"obs": [], "executed": [], "mean_after": [], "std_after": []}
+        for _ in range(n_steps):
+            out["obs"].append(obs.copy())
+            a = ctrl.get_action(obs, None)
+            out["executed"].append(np.array(a))
+            out["mean_after"].append(ctrl.mean.copy())
+            out["std_after"].append(ctrl.std.copy())
+            nxt, _, _ = ctrl.forward_model.predict(observations=obs[None], states=None, actions=a[None])
+            obs = nxt[0]
+    finally:
+        ref_mpc.truncnorm = orig_tn
+    for c in log["costs"]:
+        assert len(np.unique(c)) == len(c), "golden case has tied costs"
+    data = dict(
+        cfg=np.array([N, h, d, o, iters, seed, n_steps, kind, K], dtype=np.int64),
+        cfg_f=np.array([alpha, init_std, bounds], dtype=np.float64),
+        flags=np.array([like_levine, shift_means, execute_best], dtype=np.int64), cost_mode=np.array(cost_mode),
+        A=A, B=B, low=env.action_space.low.astype(np.float64), high=env.action_space.high.astype(np.float64),
+        obs=np.array(out["obs"]), executed=np.array(out["executed"]), mean_after=np.array(out["mean_after"]),
+        std_after=np.array(out["std_after"]), n_calls=np.array(len(calls)),
+    )
+    for i, (u, lo, hi, x) in enumerate(calls):
+        data[f"u_{i}"], data[f"lower_{i}"], data[f"upper_{i}"] = u, lo, hi
+        data[f"simact_{i}"] = log["sim_actions"][i]
+        assert np.array_equal(log["sim_actions"][i], x)
+        data[f"costs_{i}"] = log["costs"][i]
+        data[f"elite_{i}"] = log["elite_idx"][i].astype(np.int64)
+        data[f"mean_{i}"], data[f"std_{i}"] = log["mean"][i], log["std"][i]
+        data[f"lower_next_{i}"], data[f"upper_next_{i}"] = log["lower"][i], log["upper"][i]
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **data)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB, {len(calls)} sampling calls")
+
+
 def cost_fn_vectors():
     """Direct input/output vectors of the reference's two cost functions."""
     import environments.mujoco as ref_mj
@@ -338,6 +463,10 @@ def main():
     # beta = 0: the white-noise branch (np.random.randn(N, h, d), icem.py:77), elites shifted and kept
     run_case("white_beta0_n64", N=64, h=30, d=6, o=17, beta=0.0, iters=3, seed=16,
              n_steps=3, kind=0, env_kind="halfcheetah")
+    # the CEM baseline MpcCemStd (truncated normal): bounds from the action space, and "like Levine" (+-2 sigma, std capped)
+    run_cem_std_case("cemstd_bounds_n48", N=48, h=12, d=6, o=17, iters=3, seed=21, n_steps=3, kind=0, like_levine=False)
+    run_cem_std_case("cemstd_levine_n40", N=40, h=10, d=4, o=17, iters=4, seed=22, n_steps=2, kind=1, like_levine=True,
+                     execute_best=False, cost_mode="best")
 
 
 if __name__ == "__main__":

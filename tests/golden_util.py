@@ -6,8 +6,9 @@ import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
-               if not p.endswith("cost_fn_vectors.npz"))
+_ALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if not p.endswith("cost_fn_vectors.npz"))
+CASES = [n for n in _ALL if not n.startswith("cemstd_")]        # MpcICem runs
+CEMSTD_CASES = [n for n in _ALL if n.startswith("cemstd_")]     # MpcCemStd runs (truncated-normal CEM baseline)
 
 
 class Golden:
@@ -33,3 +34,23 @@ class Golden:
         z = self.z
         return dict(simact=z[f"simact_{i}"], costs=z[f"costs_{i}"], elite=z[f"elite_{i}"],
                     mean=z[f"mean_{i}"], std=z[f"std_{i}"], best=int(z[f"best_{i}"]))
+
+
+class GoldenCemStd:
+    """A recorded run of the reference's ``MpcCemStd`` (tests/golden/make_golden.py::run_cem_std_case)."""
+
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN, name + ".npz"))
+        self.z = z
+        (self.N, self.h, self.d, self.o, self.iters, self.seed, self.n_steps, self.kind, self.K) = [int(v) for v in z["cfg"]]
+        self.alpha, self.init_std, self.bounds = [float(v) for v in z["cfg_f"]]
+        self.like_levine, self.shift_means, self.execute_best = [bool(v) for v in z["flags"]]
+        self.cost_mode = str(z["cost_mode"])
+        self.A, self.B, self.low, self.high = z["A"], z["B"], z["low"], z["high"]
+        self.obs, self.executed = z["obs"], z["executed"]
+        self.mean_after, self.std_after = z["mean_after"], z["std_after"]
+        self.n_calls = int(z["n_calls"])
+
+    def call(self, i):
+        z = self.z
+        return {k: z[f"{k}_{i}"] for k in ("u", "lower", "upper", "simact", "costs", "elite", "mean", "std", "lower_next", "upper_next")}

@@ -114,3 +114,36 @@ def test_cost_functions_match_reference():
         O.CostSpec.halfcheetah(16)
     # the flip penalty is exercised by the vectors
     assert (np.abs(z["o17"][..., 1]) > np.pi / 2).any()
+
+
+@pytest.mark.parametrize("name", __import__("golden_util").CEMSTD_CASES)
+def test_cem_std_oracle_matches_reference(name):
+    """f-3: the CEM baseline MpcCemStd (truncated normal, icem/controllers/mpc.py:142-327): replaying the recorded
+    uniform draws through the oracle reproduces every sampled batch, cost, elite list, distribution and bound of the
+    reference run (bit-exact indices; floats to 1e-12) and the executed actions."""
+    from golden_util import GoldenCemStd
+    g = GoldenCemStd(name)
+    calls = iter(range(g.n_calls))
+    om, oc = O.SyntheticModel(g.A, g.B, g.kind), O.CostSpec.halfcheetah(g.o)
+    orc = O.CemStdOracle(horizon=g.h, num_traj=g.N, opt_iterations=g.iters, elites_size=g.K, alpha=g.alpha,
+                         init_std=g.init_std, like_levine=g.like_levine, shift_means=g.shift_means,
+                         execute_best_elite=g.execute_best, low=g.low, high=g.high,
+                         rollout_cost=lambda ob, ac: O.rollout_costs(om, oc, ob, ac, mode=g.cost_mode),
+                         uniforms=lambda num: g.call(next(calls))["u"])
+    orc.beginning_of_rollout()
+    i = 0
+    for s in range(g.n_steps):
+        a = orc.get_action(g.obs[s])
+        np.testing.assert_allclose(a, g.executed[s], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(orc.mean, g.mean_after[s], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(orc.std, g.std_after[s], rtol=0, atol=1e-12)
+        for _ in range(g.iters):
+            ref, (act, costs, idx, mean, std, lower, upper) = g.call(i), orc.trace[i]
+            np.testing.assert_allclose(act, ref["simact"], rtol=0, atol=1e-12)
+            np.testing.assert_allclose(costs, ref["costs"], rtol=1e-12, atol=1e-12)
+            assert np.array_equal(idx, ref["elite"])
+            np.testing.assert_allclose(mean, ref["mean"], rtol=0, atol=1e-12)
+            np.testing.assert_allclose(std, ref["std"], rtol=0, atol=1e-12)
+            np.testing.assert_allclose(lower, ref["lower_next"], rtol=1e-12, atol=1e-9)
+            np.testing.assert_allclose(upper, ref["upper_next"], rtol=1e-12, atol=1e-9)
+            i += 1
