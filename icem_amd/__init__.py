@@ -11,6 +11,6 @@ from ._lib import IcemError, lib_path, load_library  # noqa: F401
 from .planner import IcemConfig, IcemPlanner  # noqa: F401
 from .envs import SyntheticEnv, halfcheetah_env, humanoid_standup_env  # noqa: F401
 from .models import DeviceSyntheticModel, TorchForwardModel  # noqa: F401
-from .controllers import (MpcICemHip, controller_from_string, ControllerFactory)  # noqa: F401
+from .controllers import (MpcICemHip, MpcCemStdHip, controller_from_string, ControllerFactory)  # noqa: F401
 
 __version__ = "0.1.0"

@@ -173,6 +173,44 @@ class MpcController(ModelBasedController, StatefulController, ABC):
     def end_of_rollout(self, total_time, total_return, mode):
         pass
 
+    def _bind_models(self, world=1):
+        """Which rollout path this controller's model allows: built-in device model + parametric cost (HIP rollout),
+        a device torch model, or any host model through the reference's ``predict_n_steps`` interface."""
+        self.device_path = (isinstance(self.forward_model, DeviceSyntheticModel)
+                            and getattr(self.env, "cost_spec", None) is not None
+                            and not self.use_env_reward_as_cost)
+        self.torch_path = (not self.device_path and hasattr(self.forward_model, "torch_step")
+                           and hasattr(self.forward_model, "torch_cost"))
+        if self.device_path:
+            m, c = self.forward_model, self.env.cost_spec
+            self.planner.set_model(m.kind, m.A, m.B)
+            self.planner.set_cost(c.ctrl_weight, c.lin_idx, c.lin_weight, c.flip_idx, c.flip_penalty, c.flip_thresh)
+        elif world != 1:
+            raise NotImplementedError("sharding over GPUs needs the device path (built-in model + cost_spec)")
+
+    def _costs_of(self, obs, actions: torch.Tensor) -> torch.Tensor:
+        """Per-trajectory costs (device tensor) of a batch of device action sequences, through whichever
+        model this controller was given."""
+        p = self.planner
+        if self.device_path:
+            return p.rollout_cost(np.asarray(obs, dtype=np.float64), actions)
+        if self.torch_path:
+            # device-resident torch model (learned dynamics): h batched steps on the GPU, step costs reduced by
+            # the HIP cost_reduce kernel; nothing leaves the device
+            m = self.forward_model
+            o = torch.as_tensor(np.asarray(obs, dtype=np.float64), dtype=m.dtype, device=p.device)
+            o = o.expand(actions.shape[0], -1)
+            step_costs = torch.empty((actions.shape[0], p.h), dtype=p.dt, device=p.device)
+            a_all = actions.to(m.dtype)
+            for t in range(p.h):
+                step_costs[:, t] = m.torch_cost(o, a_all[:, t]).to(p.dt)
+                o = m.torch_step(o, a_all[:, t])
+            return p.cost_reduce(step_costs)
+        batch = self.simulate_trajectories(obs=obs, state=self.forward_model_state,
+                                           action_sequences=actions.cpu().numpy().astype(np.float64))
+        return torch.as_tensor(self.trajectory_cost_fn(self.cost_fn, batch), dtype=p.dt, device=p.device)
+
+
 
 # ---------------------------------------------------------------------------------------------
 # the drop-in controller
@@ -208,17 +246,7 @@ class MpcICemHip(MpcController):
                 "Implement method {} to compute cost along trajectory".format(cfg.cost_mode))
         self.planner = IcemPlanner(cfg, self.env.action_space.low, self.env.action_space.high, device=device,
                                    process_group=process_group)
-        self.device_path = (isinstance(self.forward_model, DeviceSyntheticModel)
-                            and getattr(self.env, "cost_spec", None) is not None
-                            and not self.use_env_reward_as_cost)
-        self.torch_path = (not self.device_path and hasattr(self.forward_model, "torch_step")
-                           and hasattr(self.forward_model, "torch_cost"))
-        if self.device_path:
-            m, c = self.forward_model, self.env.cost_spec
-            self.planner.set_model(m.kind, m.A, m.B)
-            self.planner.set_cost(c.ctrl_weight, c.lin_idx, c.lin_weight, c.flip_idx, c.flip_penalty, c.flip_thresh)
-        elif world != 1:
-            raise NotImplementedError("sharding over GPUs needs the device path (built-in model + cost_spec)")
+        self._bind_models(world)
         self._elite_costs = None
         self._elite_actions = None
         self.last_min_cost = None
@@ -333,26 +361,6 @@ class MpcICemHip(MpcController):
                 observations=obs, states=self.forward_model_state, actions=executed_action)
         return executed_action
 
-    def _costs_of(self, obs, actions: torch.Tensor) -> torch.Tensor:
-        """Per-trajectory costs (device tensor) of a batch of device action sequences, through whichever
-        model this controller was given."""
-        p = self.planner
-        if self.torch_path:
-            # device-resident torch model (learned dynamics): h batched steps on the GPU, step costs reduced by
-            # the HIP cost_reduce kernel; nothing leaves the device
-            m = self.forward_model
-            o = torch.as_tensor(np.asarray(obs, dtype=np.float64), dtype=m.dtype, device=p.device)
-            o = o.expand(actions.shape[0], -1)
-            step_costs = torch.empty((actions.shape[0], p.h), dtype=p.dt, device=p.device)
-            a_all = actions.to(m.dtype)
-            for t in range(p.h):
-                step_costs[:, t] = m.torch_cost(o, a_all[:, t]).to(p.dt)
-                o = m.torch_step(o, a_all[:, t])
-            return p.cost_reduce(step_costs)
-        batch = self.simulate_trajectories(obs=obs, state=self.forward_model_state,
-                                           action_sequences=actions.cpu().numpy().astype(np.float64))
-        return torch.as_tensor(self.trajectory_cost_fn(self.cost_fn, batch), dtype=p.dt, device=p.device)
-
     def _get_action_stagewise(self, obs, noise):
         p = self.planner
         K, it_n = self.num_elites, self.opt_iter
@@ -385,6 +393,131 @@ class MpcICemHip(MpcController):
 
 
 # ---------------------------------------------------------------------------------------------
+# the CEM baseline on the same kernels
+# ---------------------------------------------------------------------------------------------
+
+class MpcCemStdHip(MpcController):
+    """``controllers.mpc.MpcCemStd`` (icem/controllers/mpc.py:142-327) -- the truncated-normal CEM the paper compares
+    against -- with sampling, rollout (built-in model), top-K, refit and bounds on the device.  Same constructor as the
+    reference; extra optional keywords ``dtype``, ``seed``, ``rng_rounds``, ``device`` and ``noise_source``
+    ("philox": device uniforms; "numpy_legacy": scipy's draws from the global ``np.random`` stream -- parity mode; or
+    a callable ``uniforms(num) -> [num, h, d]``)."""
+
+    def __init__(self, *, action_sampler_params, dtype="f32", seed=0, rng_rounds=10, device="cuda:0",
+                 noise_source: Union[str, Callable] = "philox", **kwargs):
+        super().__init__(**kwargs)
+        self._parse_action_sampler_params(**dict(action_sampler_params))
+        self._check_validity_parameters()
+        self.logger = _get_logger(self.__class__.__name__)
+        self.was_reset = False
+        self.noise_source = noise_source
+        if self.cost_along_trajectory not in ("sum", "best", "final"):
+            raise NotImplementedError(
+                "Implement method {} to compute cost along trajectory".format(self.cost_along_trajectory))
+        cfg = IcemConfig(horizon=self.horizon, act_dim=self.dim_samples[1], num_traj=self.num_sim_traj,
+                         elites_size=self.elites_size, opt_iters=self.opt_iter, cost_mode=self.cost_along_trajectory,
+                         use_mean_actions=False, keep_previous_elites=False, shift_elites=False, factor_decrease=1.0,
+                         alpha=float(self.alpha), init_std=float(self.init_std), dtype=dtype, rng_rounds=rng_rounds, seed=seed)
+        self.planner = IcemPlanner(cfg, self.env.action_space.low, self.env.action_space.high, device=device)
+        self._bind_models()
+        self.last_min_cost = None
+
+    # mpc.py:303-327
+    def _parse_action_sampler_params(self, *, alpha, elites_size, opt_iterations, init_std, shift_means,
+                                     execute_best_elite, bounds_like_levine):
+        self.alpha = alpha
+        self.elites_size = elites_size
+        self.opt_iter = opt_iterations
+        self.init_std = init_std
+        self.execute_best_elite = execute_best_elite
+        self.like_levine = bounds_like_levine
+        self.shift_means = shift_means
+
+    _check_validity_parameters = MpcICemHip._check_validity_parameters
+
+    @property
+    def mean(self) -> np.ndarray:
+        return self._mean.detach().cpu().numpy().astype(np.float64)
+
+    @property
+    def std(self) -> np.ndarray:
+        return self._std.detach().cpu().numpy().astype(np.float64)
+
+    @property
+    def elite_samples(self) -> TrajectoryBatch:
+        if getattr(self, "_elite_actions", None) is None:
+            return TrajectoryBatch()
+        return TrajectoryBatch(actions=self._elite_actions.detach().cpu().numpy().astype(np.float64),
+                               costs=self._elite_costs.detach().cpu().numpy().astype(np.float64))
+
+    def _reset_std(self):  # get_init_std(True), mpc.py:180-185, then _update_bounds
+        p = self.planner
+        scratch = torch.empty_like(self._mean)
+        p.reset_distribution(scratch, self._std)
+        self._lower, self._upper = p.cem_bounds(self._mean, self._std, self.like_levine)
+
+    def beginning_of_rollout(self, *, observation, state=None, mode):  # mpc.py:158-170
+        super().beginning_of_rollout(observation=observation, state=state, mode=mode)
+        p = self.planner
+        self._mean = torch.empty((p.h, p.d), dtype=p.dt, device=p.device)
+        self._std = torch.empty_like(self._mean)
+        p.reset_distribution(self._mean, self._std)
+        self._lower, self._upper = p.cem_bounds(self._mean, self._std, self.like_levine)
+        self._elite_actions = self._elite_costs = None
+        p.mpc_step = 0
+        self.was_reset = True
+        self.model_evals_per_timestep = self.num_sim_traj * self.opt_iter * self.horizon
+        if self.verbose:
+            print(f"CEM-Standard using {self.model_evals_per_timestep} evaluations per step "
+                  f"and {self.model_evals_per_timestep / self.horizon} trajectories per step")
+
+    def _uniform_fn(self):
+        if callable(self.noise_source):
+            return self.noise_source
+        if self.noise_source == "numpy_legacy":  # what scipy.stats.truncnorm.rvs draws (mpc.py:196-197)
+            return lambda num: np.random.uniform(size=(num, self.horizon, self.dim_samples[1]))
+        if self.noise_source == "philox":
+            return None
+        raise ValueError(f"unknown noise_source {self.noise_source!r}")
+
+    def get_action(self, obs, state, mode="train"):  # mpc.py:200-262
+        if not self.was_reset:
+            raise AttributeError("beginning_of_rollout() needs to be called before")
+        self.forward_model_state = self.forward_model.got_actual_observation_and_env_state(
+            observation=obs, env_state=state, model_state=self.forward_model_state)
+        p, uniforms = self.planner, self._uniform_fn()
+        actions = costs_sorted = idx = None
+        for i in range(self.opt_iter):
+            u = uniforms(self.num_sim_traj) if uniforms is not None else None
+            actions = p.sample_truncnorm(self.num_sim_traj, self._mean, self._std, self._lower, self._upper, u,
+                                         offset=p.mpc_step * self.opt_iter + i)
+            costs = self._costs_of(obs, actions)
+            costs_sorted, idx = p.topk_sorted(costs, self.num_elites)      # mpc.py:270
+            self._elite_actions = p.gather_refit(actions, idx, self._mean, self._std)  # mpc.py:271-281
+            self._elite_costs = costs_sorted
+            self._lower, self._upper = p.cem_bounds(self._mean, self._std, self.like_levine)
+        if self.execute_best_elite:                                        # mpc.py:230-233
+            executed_action = self._elite_actions[0, 0].cpu().numpy().astype(np.float64)
+        else:
+            executed_action = self._mean[0].cpu().numpy().astype(np.float64)
+        if self.shift_means:                                               # mpc.py:236-241
+            last = torch.zeros_like(self._mean[-1]) if self.like_levine else self._mean[-1].clone()
+            self._mean[:-1] = self._mean[1:].clone()
+            self._mean[-1] = last
+        else:
+            self._mean.zero_()
+        self._reset_std()                                                  # mpc.py:244-245
+        self.last_min_cost = float(costs_sorted[0])
+        self.logger.log(self.last_min_cost / self.horizon if self.cost_along_trajectory == "sum" else self.last_min_cost,
+                        key="Expected_trajectory_cost")
+        p.mpc_step += 1
+        if self.forward_model_state is not None:
+            _, self.forward_model_state, _ = self.forward_model.predict(
+                observations=obs, states=self.forward_model_state, actions=executed_action)
+        return executed_action
+
+
+# ---------------------------------------------------------------------------------------------
 # registry: icem/controllers/__init__.py:6-31
 # ---------------------------------------------------------------------------------------------
 
@@ -396,6 +529,8 @@ class ControllerFactory:
     valid_base_controllers = {
         "mpc-icem-hip": (".controllers", "MpcICemHip"),
         "mpc-icem": (".controllers", "MpcICemHip"),
+        "mpc-cem-std-hip": (".controllers", "MpcCemStdHip"),
+        "mpc-cem-std": (".controllers", "MpcCemStdHip"),
     }
     controller = None
 

@@ -157,6 +157,57 @@ __global__ __launch_bounds__(WG) void sample_clip_kernel(SampleArgs<T> a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// MpcCemStd (the CEM baseline, icem/controllers/mpc.py:142-327): truncated-normal sampling and its bounds
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double std_normal_cdf(double x) { return normcdf(x); }
+__device__ __forceinline__ float std_normal_cdf(float x) { return normcdff(x); }
+__device__ __forceinline__ double std_normal_icdf(double p) { return normcdfinv(p); }
+__device__ __forceinline__ float std_normal_icdf(float p) { return normcdfinvf(p); }
+
+// actions[i, t, j] = mean[t, j] + std[t, j] * ppf(u; lower[t, j], upper[t, j]) with the truncated standard normal's
+// inverse CDF ppf(u; a, b) = Phi^-1(Phi(a) + u (Phi(b) - Phi(a)))  (scipy.stats.truncnorm.rvs, mpc.py:188-198).
+// u: the caller's uniforms [n, h, d] (parity: scipy draws exactly that array), or, if null, word t of row (i, j)'s
+// Philox / xoshiro stream mapped to (x + 0.5) * 2^-32.  One thread per (trajectory, dim) row.
+template <typename T, int ROUNDS>
+__global__ __launch_bounds__(WG) void sample_truncnorm_kernel(int n, int h, int d, long long first_index, const T* mean,
+                                                             const T* std, const T* lower, const T* upper, const T* u,
+                                                             uint32_t seed_lo, uint32_t seed_hi, uint32_t off_lo,
+                                                             uint32_t off_hi, T* out) {
+    const int row = blockIdx.x * WG + threadIdx.x;
+    if (row >= n * d) return;
+    const int i = row / d, j = row - i * d;
+    Xoshiro128pp rng = row_stream<ROUNDS>((uint32_t)(first_index + i), (uint32_t)j, off_lo, off_hi, seed_lo, seed_hi);
+    for (int t = 0; t < h; ++t) {
+        const size_t e = ((size_t)i * h + t) * d + j;
+        const uint32_t x = rng.next();
+        const T uu = u ? u[e] : ((T)x + (T)0.5) * (T)2.3283064365386963e-10;
+        const T pa = std_normal_cdf(lower[t * d + j]), pb = std_normal_cdf(upper[t * d + j]);
+        const T z = std_normal_icdf(fmad(uu, pb - pa, pa));
+        out[e] = fmad(z, std[t * d + j], mean[t * d + j]);
+    }
+}
+
+// MpcCemStd._update_bounds (mpc.py:290-301), in place on std (like_levine) and into lower / upper [h, d]
+template <typename T>
+__global__ __launch_bounds__(WG) void cem_bounds_kernel(int hd, int d, int like_levine, const T* mean, T* std, const T* low,
+                                                       const T* high, T* lower, T* upper) {
+    const int e = blockIdx.x * WG + threadIdx.x;
+    if (e >= hd) return;
+    const int j = e % d;
+    if (like_levine) {
+        const T lb = (mean[e] - low[j]) / (T)2, ub = (high[j] - mean[e]) / (T)2;
+        T s = lb < ub ? lb : ub;
+        s = s < std[e] ? s : std[e];
+        std[e] = s > (T)1e-8 ? s : (T)1e-8;
+        lower[e] = (T)-2;
+        upper[e] = (T)2;
+    } else {
+        lower[e] = (low[j] - mean[e]) / (std[e] + (T)1e-8);
+        upper[e] = (high[j] - mean[e]) / (std[e] + (T)1e-8);
+    }
+}
+
 // Raw Philox white noise in the reference's [n, d, F] x 2 layout (RNG known-answer tests).
 template <typename T, int HMAX, int ROUNDS>
 __global__ __launch_bounds__(WG) void philox_normals_kernel(SampleArgs<T> a, T* zr_out, T* zi_out) {
@@ -1464,6 +1515,46 @@ int icem_sample_clip(icem_handle* h, int32_t n, int64_t first_index, const void*
     return ICEM_DISPATCH(h,
                          launch_sample<float>(h, make_sample_args<float>(h, n, first_index, mean, std, low, high, z_r, z_i, offset, t_begin, row0_mean, actions), st),
                          launch_sample<double>(h, make_sample_args<double>(h, n, first_index, mean, std, low, high, z_r, z_i, offset, t_begin, row0_mean, actions), st));
+}
+
+int icem_sample_truncnorm(icem_handle* h, int32_t n, int64_t first_index, const void* mean, const void* std,
+                          const void* lower, const void* upper, const void* u, uint64_t offset, void* actions,
+                          void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (n < 0 || !mean || !std || !lower || !upper || !actions) return fail(ICEM_E_INVALID, "null tensor / negative n");
+    if (n == 0) return ICEM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const icem_config& c = h->cfg;
+    const int grid = (n * c.act_dim + WG - 1) / WG;
+    const uint32_t sl = (uint32_t)c.seed, sh = (uint32_t)(c.seed >> 32), ol = (uint32_t)offset, oh = (uint32_t)(offset >> 32);
+#define ICEM_TN(T, R)                                                                                                    \
+    hipLaunchKernelGGL((sample_truncnorm_kernel<T, R>), dim3(grid), dim3(WG), 0, st, n, c.horizon, c.act_dim,            \
+                       (long long)first_index, (const T*)mean, (const T*)std, (const T*)lower, (const T*)upper,          \
+                       (const T*)u, sl, sh, ol, oh, (T*)actions)
+    if (c.dtype == ICEM_F64) {
+        if (c.rng_rounds == 7) ICEM_TN(double, 7); else ICEM_TN(double, 10);
+    } else {
+        if (c.rng_rounds == 7) ICEM_TN(float, 7); else ICEM_TN(float, 10);
+    }
+#undef ICEM_TN
+    ICEM_HIP_TRY(hipGetLastError());
+    return ICEM_OK;
+}
+
+int icem_cem_bounds(icem_handle* h, int32_t like_levine, const void* mean, void* std, const void* low, const void* high,
+                    void* lower, void* upper, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (!mean || !std || !low || !high || !lower || !upper) return fail(ICEM_E_INVALID, "null tensor");
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (h->hd + WG - 1) / WG;
+    if (h->cfg.dtype == ICEM_F64)
+        hipLaunchKernelGGL((cem_bounds_kernel<double>), dim3(grid), dim3(WG), 0, st, h->hd, h->cfg.act_dim, like_levine,
+                           (const double*)mean, (double*)std, (const double*)low, (const double*)high, (double*)lower, (double*)upper);
+    else
+        hipLaunchKernelGGL((cem_bounds_kernel<float>), dim3(grid), dim3(WG), 0, st, h->hd, h->cfg.act_dim, like_levine,
+                           (const float*)mean, (float*)std, (const float*)low, (const float*)high, (float*)lower, (float*)upper);
+    ICEM_HIP_TRY(hipGetLastError());
+    return ICEM_OK;
 }
 
 int icem_philox_normals(icem_handle* h, int32_t n, int64_t first_index, uint64_t offset, void* z_r, void* z_i,

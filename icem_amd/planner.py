@@ -220,6 +220,31 @@ class IcemPlanner:
                                            self._stream()))
         return elites
 
+    def sample_truncnorm(self, n: int, mean, std, lower, upper, u=None, offset: int = 0, first_index: int = 0,
+                         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``MpcCemStd.sample_action_sequences`` (icem/controllers/mpc.py:188-198): truncated-normal samples
+        ``[n, h, d]``; ``lower`` / ``upper`` are ``[h, d]`` in standard-normal units; ``u`` = scipy's uniform draws
+        ``[n, h, d]`` (parity mode) or None (device RNG)."""
+        mean, std = self._t(mean, (self.h, self.d)), self._t(std, (self.h, self.d))
+        lower, upper = self._t(lower, (self.h, self.d)), self._t(upper, (self.h, self.d))
+        if u is not None:
+            u = self._t(u, (n, self.h, self.d))
+        if out is None:
+            out = torch.empty((n, self.h, self.d), dtype=self.dt, device=self.device)
+        L.check(self.lib.icem_sample_truncnorm(self._h, n, first_index, _ptr(mean), _ptr(std), _ptr(lower), _ptr(upper),
+                                               _ptr(u), offset, _ptr(out), self._stream()))
+        return out
+
+    def cem_bounds(self, mean: torch.Tensor, std: torch.Tensor, like_levine: bool):
+        """``MpcCemStd._update_bounds`` (icem/controllers/mpc.py:290-301): returns (lower, upper) ``[h, d]``;
+        ``std`` is capped in place when ``like_levine``."""
+        assert mean.dtype == self.dt and std.dtype == self.dt and mean.is_contiguous() and std.is_contiguous()
+        lower = torch.empty((self.h, self.d), dtype=self.dt, device=self.device)
+        upper = torch.empty_like(lower)
+        L.check(self.lib.icem_cem_bounds(self._h, int(like_levine), _ptr(mean), _ptr(std), _ptr(self.low), _ptr(self.high),
+                                         _ptr(lower), _ptr(upper), self._stream()))
+        return lower, upper
+
     def shift(self, mean: torch.Tensor, std: torch.Tensor):
         """Epilogue of get_action (icem/controllers/icem.py:167-175), in place."""
         L.check(self.lib.icem_shift(self._h, _ptr(mean), _ptr(std), _ptr(self.low), _ptr(self.high), self._stream()))

@@ -132,6 +132,19 @@ int icem_sample_clip(icem_handle* h, int32_t n, int64_t first_index, const void*
                      const void* low, const void* high, const void* z_r, const void* z_i,
                      uint64_t offset, int32_t t_begin, int32_t row0_mean, void* actions, void* stream);
 
+/* MpcCemStd.sample_action_sequences (the CEM baseline, icem/controllers/mpc.py:188-198):
+ *   actions[i, t, j] = mean[t, j] + std[t, j] * truncnorm.ppf(u[i, t, j]; lower[t, j], upper[t, j])
+ * (scipy.stats.truncnorm.rvs draws ONE uniform(size=(n, h, d)) per call).  u: those uniforms [n, h, d] (parity mode),
+ * or NULL: word t of the Philox / xoshiro stream of row (first_index + i, j), offset as in icem_sample_clip.
+ * lower / upper are [h, d] in standard-normal units, as MpcCemStd keeps them. */
+int icem_sample_truncnorm(icem_handle* h, int32_t n, int64_t first_index, const void* mean, const void* std,
+                          const void* lower, const void* upper, const void* u, uint64_t offset, void* actions,
+                          void* stream);
+/* MpcCemStd._update_bounds (mpc.py:290-301): like_levine != 0 caps std at half the distance to the action bounds
+ * (in place, floor 1e-8) and sets lower / upper = -2 / +2; otherwise lower / upper = (low|high - mean) / (std + 1e-8). */
+int icem_cem_bounds(icem_handle* h, int32_t like_levine, const void* mean, void* std, const void* low, const void* high,
+                    void* lower, void* upper, void* stream);
+
 /* Raw white noise of the Philox path (for RNG known-answer tests): z_r, z_i [n, d, F]. */
 int icem_philox_normals(icem_handle* h, int32_t n, int64_t first_index, uint64_t offset,
                         void* z_r, void* z_i, void* stream);

@@ -232,6 +232,19 @@ def philox_white_randn(seed: int, offset: int, num: int, d: int, h: int, first_i
     return np.ascontiguousarray(g.transpose([0, 2, 1]))
 
 
+def philox_uniforms(seed: int, offset: int, num: int, d: int, h: int, first_index: int = 0, rounds: int = 10,
+                    dtype=np.float64) -> np.ndarray:
+    """Uniform draws ``[num, h, d]`` of the device's truncated-normal sampler: entry ``[n, t, j]`` is word ``t`` of row
+    ``(n, j)``'s stream (same streams as :func:`philox_white_noise`) mapped to ``(x + 0.5) * 2**-32``."""
+    n_idx = np.broadcast_to((first_index + np.arange(num, dtype=np.uint64))[:, None], (num, d))
+    j_idx = np.broadcast_to((np.arange(d, dtype=np.uint64) << np.uint64(16))[None, :], (num, d))
+    s0, s1, s2, s3 = philox4x32(n_idx, j_idx, offset & 0xFFFFFFFF, (offset >> 32) & 0xFFFFFFFF,
+                                seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, rounds)
+    words = xoshiro128pp_words(s0, s1, s2, s3, h)
+    u = np.stack([(w.astype(dtype) + dtype(0.5)) * dtype(2.0 ** -32) for w in words], axis=1)  # [num, h, d]
+    return np.ascontiguousarray(u)
+
+
 class PhiloxNoiseSchedule:
     """Noise callback for :class:`IcemOracle` reproducing the device's Philox
     offsets: per MPC step ``s`` the main batch of iteration ``i`` uses offset

@@ -813,3 +813,82 @@ def test_sharded_deferred_merge_large_shards(N, world):
     torch.cuda.synchronize()
     prof = pls[0].profile_read()
     assert prof["merge_refit"][1] == len(obs_seq), prof  # only the last merge of each MPC step was a launch of its own
+
+
+# ---------------------------------------------------------------------------------------------
+# f-3: MpcCemStd (truncated-normal CEM baseline) on the same kernels
+# ---------------------------------------------------------------------------------------------
+from golden_util import CEMSTD_CASES, GoldenCemStd  # noqa: E402
+
+
+def _cemstd_controller(g, dtype, noise_source):
+    from icem_amd import DeviceSyntheticModel, MpcCemStdHip
+    from icem_amd.envs import SyntheticEnv, CostSpec
+    import math
+    spec = O.CostSpec.halfcheetah(g.o)
+    env = SyntheticEnv("HalfCheetah", g.o, g.low.copy(), g.high.copy(),
+                       CostSpec(spec.ctrl_weight, spec.lin_idx, spec.lin_weight, spec.flip_idx, spec.flip_penalty, spec.flip_thresh))
+    model = DeviceSyntheticModel(g.A, g.B, g.kind)
+    return MpcCemStdHip(env=env, forward_model=model, horizon=g.h, num_simulated_trajectories=g.N,
+                        cost_along_trajectory=g.cost_mode, verbose=False, dtype=dtype, noise_source=noise_source,
+                        action_sampler_params=dict(alpha=g.alpha, elites_size=g.K, opt_iterations=g.iters, init_std=g.init_std,
+                                                   shift_means=g.shift_means, execute_best_elite=g.execute_best,
+                                                   bounds_like_levine=g.like_levine))
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("name", CEMSTD_CASES)
+def test_cem_std_controller_replays_reference_run(name, dtype):
+    """MpcCemStdHip fed scipy's recorded uniform draws: every sampled batch, elite set and the executed actions /
+    distribution after every MPC step of the reference's MpcCemStd run (elite indices exact)."""
+    g = GoldenCemStd(name)
+    calls = iter(range(g.n_calls))
+    ctrl = _cemstd_controller(g, dtype, lambda num: g.call(next(calls))["u"])
+    t = dict(rtol=1e-9, atol=1e-10) if dtype == "f64" else dict(rtol=2e-4, atol=2e-5)
+    pl = ctrl.planner
+    # the stand-alone sampler on the first call
+    c0 = g.call(0)
+    mean0 = np.zeros((g.h, g.d)) + (g.high + g.low) / 2
+    std0, lo0, hi0 = O.cem_bounds(mean0, np.ones((g.h, g.d)) * (g.high - g.low) / 2 * g.init_std, g.low, g.high, g.like_levine)
+    np.testing.assert_allclose(lo0, c0["lower"], rtol=1e-12, atol=1e-12)
+    got = np_(pl.sample_truncnorm(g.N, std0 * 0 + mean0, std0, lo0, hi0, c0["u"]))
+    np.testing.assert_allclose(got, c0["simact"], **(dict(rtol=0, atol=1e-9) if dtype == "f64" else dict(rtol=0, atol=3e-5)))
+    ctrl.beginning_of_rollout(observation=g.obs[0], state=None, mode="train")
+    i = 0
+    for s in range(g.n_steps):
+        a = ctrl.get_action(g.obs[s], None)
+        np.testing.assert_allclose(a, g.executed[s], **t)
+        np.testing.assert_allclose(ctrl.mean, g.mean_after[s], **t)
+        np.testing.assert_allclose(ctrl.std, g.std_after[s], **t)
+        i += g.iters
+        ref = g.call(i - 1)
+        np.testing.assert_allclose(ctrl.elite_samples.as_array("actions"), ref["simact"][ref["elite"]], **t)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_cem_std_device_rng_matches_oracle(dtype):
+    """MpcCemStdHip on the device RNG against the oracle fed the same Philox uniforms (2 MPC steps, both bound modes)."""
+    g = GoldenCemStd(CEMSTD_CASES[0])
+    npdt = np.float64 if dtype == "f64" else np.float32
+    for like_levine in (False, True):
+        g.like_levine = like_levine
+        from icem_amd import MpcCemStdHip  # noqa: F401
+        ctrl = _cemstd_controller(g, dtype, "philox")
+        ctrl.planner.cfg.seed = 0
+        om, oc = O.SyntheticModel(g.A, g.B, g.kind), O.CostSpec.halfcheetah(g.o)
+        state = {"call": 0}
+
+        def uniforms(num):
+            u = O.philox_uniforms(0, state["call"], num, g.d, g.h, dtype=npdt).astype(np.float64)
+            state["call"] += 1
+            return u
+        orc = O.CemStdOracle(horizon=g.h, num_traj=g.N, opt_iterations=g.iters, elites_size=g.K, alpha=g.alpha,
+                             init_std=g.init_std, like_levine=like_levine, shift_means=True, execute_best_elite=True,
+                             low=g.low, high=g.high, rollout_cost=lambda ob, ac: O.rollout_costs(om, oc, ob, ac, mode=g.cost_mode),
+                             uniforms=uniforms)
+        orc.beginning_of_rollout()
+        ctrl.beginning_of_rollout(observation=g.obs[0], state=None, mode="train")
+        t = dict(rtol=1e-8, atol=1e-9) if dtype == "f64" else dict(rtol=3e-4, atol=3e-5)
+        for s in range(2):
+            np.testing.assert_allclose(ctrl.get_action(g.obs[s], None), orc.get_action(g.obs[s]), **t)
+        np.testing.assert_allclose(ctrl.mean, orc.mean, **t)
