@@ -105,6 +105,31 @@ class ModelBasedController(Controller, ABC):
         self.cost_along_trajectory = cost_along_trajectory
         self.use_env_reward_as_cost = use_env_reward_as_cost
 
+    def visualize_plan(self, *, obs, state, acts):
+        """abstract_controller.py:93-128: render a plan in a copy of the environment.  Only ground-truth environments
+        with live rendering can (none exists without MuJoCo); for every other environment the reference does nothing,
+        and so does this.  ``obs [h,o]`` / ``acts [h,d]``: the best trajectory of the last CEM iteration."""
+        if self.do_visualize_plan is None or not self.do_visualize_plan:
+            return
+        env = self.env
+        if not getattr(env, "supports_live_rendering", False):
+            return
+        viz = getattr(self, "visualize_env", None)
+        if viz is None:
+            viz = self.visualize_env = env.make_visualization_copy()
+            viz.reset()
+        if self.do_visualize_plan == "last":
+            viz.set_state_from_observation(obs[-1])
+            viz.step(acts[-1])
+            viz.render()
+        elif self.do_visualize_plan == "all":
+            viz.set_GT_state(state)
+            for a in acts:
+                viz.step(a)
+                viz.render()
+        else:
+            raise AttributeError("unknown mode for do_visualize_plan: Options: None, 'last','all'")
+
     def trajectory_cost_fn(self, cost_fn, rollout_buffer):
         """Per-trajectory cost of a batch of rollouts (abstract_controller.py:74-91)."""
         if self.use_env_reward_as_cost:
@@ -356,10 +381,37 @@ class MpcICemHip(MpcController):
         else:
             executed_action = self._get_action_stagewise(obs, noise)
         self.logger.log(self.last_min_cost, key="Expected_trajectory_cost")
+        if self.do_visualize_plan:  # icem.py:180-183
+            bt = self.best_trajectory(obs)
+            self.visualize_plan(obs=bt["observations"], state=self.forward_model_state, acts=bt["actions"])
         if self.forward_model_state is not None:  # stateful models advance with the executed action
             _, self.forward_model_state, _ = self.forward_model.predict(
                 observations=obs, states=self.forward_model_state, actions=executed_action)
         return executed_action
+
+    def best_trajectory(self, obs) -> TrajectoryBatch:
+        """The best trajectory of the last CEM iteration as the reference hands it to ``visualize_plan`` and hooks
+        (``simulated_paths[best_traj_idx]``, icem.py:180-183): a one-row batch with ``actions [1,h,d]``,
+        ``observations`` / ``next_observations [1,h,o]`` and its cost.  The N rollouts of the planning step are never
+        materialised (the reference builds N Rollout objects per iteration, ~90 % of its step time); this one is
+        re-rolled from its action sequence on demand."""
+        es = self.elite_samples
+        if len(es) == 0:
+            return TrajectoryBatch()
+        acts = es.as_array("actions")[:1]
+        if self.device_path:
+            p = self.planner
+            cost, o = p.rollout_cost(np.asarray(obs, dtype=np.float64), torch.as_tensor(acts, dtype=p.dt, device=p.device),
+                                     return_observations=True)
+            o = o.detach().cpu().numpy().astype(np.float64)          # [1, h, o]: observation BEFORE each action
+            m = self.forward_model
+            nxt = o[:, -1] @ np.asarray(m.A, dtype=np.float64) + acts[:, -1] @ np.asarray(m.B, dtype=np.float64)
+            nxt = np.tanh(nxt) if m.kind == 1 else nxt
+            next_o = np.concatenate([o[:, 1:], nxt[:, None]], axis=1)
+            return TrajectoryBatch(observations=o, next_observations=next_o, actions=acts,
+                                   costs=cost.detach().cpu().numpy().astype(np.float64))
+        batch = self.simulate_trajectories(obs=obs, state=self.forward_model_state, action_sequences=acts)
+        return batch
 
     def _get_action_stagewise(self, obs, noise):
         p = self.planner

@@ -892,3 +892,37 @@ def test_cem_std_device_rng_matches_oracle(dtype):
         for s in range(2):
             np.testing.assert_allclose(ctrl.get_action(g.obs[s], None), orc.get_action(g.obs[s]), **t)
         np.testing.assert_allclose(ctrl.mean, orc.mean, **t)
+
+
+def test_best_trajectory_view_matches_oracle_rollout():
+    """f-1: what the reference hands to visualize_plan / hooks (simulated_paths[best_traj_idx], icem.py:180-183) is
+    re-rolled on demand from the best elite's actions: observations / next_observations / actions / cost of that one
+    trajectory against the oracle; the elite view keeps the RolloutBuffer-style accessors."""
+    from icem_amd import DeviceSyntheticModel, MpcICemHip, halfcheetah_env
+    env = halfcheetah_env(17)
+    model = DeviceSyntheticModel.make(17, 6, kind=1)
+    ctrl = MpcICemHip(env=env, forward_model=model, horizon=30, num_simulated_trajectories=600, factor_decrease_num=1.25,
+                      cost_along_trajectory="sum", verbose=False, dtype="f32", seed=4,
+                      action_sampler_params=dict(alpha=0.1, elites_size=10, opt_iterations=3, init_std=0.5, use_mean_actions=True,
+                                                 keep_previous_elites=True, shift_elites_over_time=True,
+                                                 fraction_elites_reused=0.3, noise_beta=0.25))
+    obs = 0.1 * np.random.RandomState(3).randn(17)
+    ctrl.beginning_of_rollout(observation=obs, state=None, mode="train")
+    assert len(ctrl.best_trajectory(obs)) == 0 and len(ctrl.elite_samples) == 0
+    a = ctrl.get_action(obs, None)
+    bt = ctrl.best_trajectory(obs)
+    es = ctrl.elite_samples
+    assert len(bt) == 1 and len(es) == 10
+    acts = bt.as_array("actions")
+    assert np.array_equal(acts[0], es.as_array("actions")[0]) and np.allclose(acts[0, 0], a)
+    om, oc = O.SyntheticModel(model.A, model.B, model.kind), O.CostSpec.halfcheetah(17)
+    ref_obs = O.rollout_observations(om, obs, acts)
+    np.testing.assert_allclose(bt.as_array("observations"), ref_obs, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(bt.as_array("next_observations")[0, :-1], ref_obs[0, 1:], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(bt.as_array("next_observations")[0, -1], om.predict(ref_obs[:, -1], acts[:, -1])[0], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(bt.as_array("costs"), O.rollout_costs(om, oc, obs, acts), rtol=2e-5, atol=5e-5)
+    np.testing.assert_allclose(es.as_array("costs")[0], bt.as_array("costs")[0], rtol=2e-5, atol=5e-5)
+    r0 = bt[0]  # per-trajectory dict view, as the reference's consumers index a RolloutBuffer
+    assert r0["observations"].shape == (30, 17) and r0["actions"].shape == (30, 6)
+    ctrl.do_visualize_plan = "last"   # no live-rendering environment here: must be a no-op, like the reference's guard
+    ctrl.get_action(obs, None)
