@@ -323,12 +323,23 @@ def sample_via_matrices(mean, std, low, high, beta, z_r, z_i, dtype=np.float64) 
 
 @dataclass
 class CostSpec:
-    """Parametric restatement of the two shipped cost functions.
+    """Parametric restatement of the shipped cost functions.
 
-    ``cost_t = ctrl_weight*sum_d a^2 + lin_weight*obs[lin_idx]
-               + flip_penalty*([obs[flip_idx] >  flip_thresh] +
-                               [obs[flip_idx] < -flip_thresh])``
-    (flip term only when ``flip_idx >= 0``).
+    ``cost_t = flip_penalty*([obs[flip_idx] > flip_thresh] + [obs[flip_idx] < -flip_thresh])
+               + ctrl_weight*sum_d a^2 + lin_weight*obs[lin_idx]
+               + diff_weight*(next_obs[diff_idx] - obs[diff_idx])
+               + health_penalty*unhealthy(obs)
+               + sum_j dist_weight[j]*f_j(||obs[a_j:a_j+len_j] - obs[b_j:b_j+len_j]||)``
+    added in that order (each group only when switched on: ``flip_idx/diff_idx/health_idx >= 0``,
+    ``dist_len[j] > 0``).  ``unhealthy = 1 - isfinite(obs).all() * [lo <(=) obs[health_idx] <(=) hi]
+    * [box_lo < obs[k] < box_hi for all k >= box_from]`` (``health_closed``: ``<=`` as in Ant,
+    mujoco.py:146-149; open as in Hopper :189-203 / Humanoid :302-315; the box is Hopper's
+    ``healthy_state_range`` over ``obs[2:]``; Hopper's ``healthy_angle`` never enters the result:
+    it is passed as ``out=`` of ``np.logical_and``, :199).  ``f_j`` is the identity, or ``[. > thresh]``
+    for the sparse robotics costs (robotics.py:159-161, 291-292); ``b_j < 0`` takes the plain norm
+    of the slice (Reacher, mujoco.py:366-368).  HalfCheetah (:67-99) and HumanoidStandup (:259-277)
+    reproduce the reference bit for bit in float64; the others to rounding (the reference adds its
+    terms in a different order per env).
     """
     ctrl_weight: float = 0.1
     lin_idx: int = 8
@@ -336,6 +347,30 @@ class CostSpec:
     flip_idx: int = 1
     flip_penalty: float = 10.0
     flip_thresh: float = math.pi / 2
+    diff_idx: int = -1
+    diff_weight: float = 0.0
+    health_idx: int = -1
+    health_penalty: float = 0.0
+    health_lo: float = 0.0
+    health_hi: float = 0.0
+    health_closed: bool = False
+    box_from: int = -1
+    box_lo: float = -100.0
+    box_hi: float = 100.0
+    dist_a: tuple = (0, 0)
+    dist_b: tuple = (-1, -1)
+    dist_len: tuple = (0, 0)
+    dist_sparse: tuple = (False, False)
+    dist_weight: tuple = (0.0, 0.0)
+    dist_thresh: tuple = (0.0, 0.0)
+
+    @property
+    def extended(self) -> bool:
+        return self.diff_idx >= 0 or self.health_idx >= 0 or any(n > 0 for n in self.dist_len)
+
+    @property
+    def needs_next_obs(self) -> bool:
+        return self.diff_idx >= 0
 
     @staticmethod
     def halfcheetah(obs_dim: int = 17, penalise_flipping: bool = True) -> "CostSpec":
@@ -353,6 +388,73 @@ class CostSpec:
         # mujoco.py:267-272: -obs[2] + 0.1*sum(a^2)
         return CostSpec(0.1, 2, -1.0, -1, 0.0, math.pi / 2)
 
+    @staticmethod
+    def ant(dt: float = 0.05, ctrl_cost_weight: float = 0.5, healthy_z_range=(0.2, 1.0)) -> "CostSpec":
+        # mujoco.py:151-171 (o=113, positions included): -(next[0]-obs[0])/dt + 100*unhealthy + w*sum(a^2)
+        return CostSpec(ctrl_cost_weight, 0, 0.0, -1, 0.0, 0.0, diff_idx=0, diff_weight=-1.0 / dt, health_idx=2,
+                        health_penalty=100.0, health_lo=healthy_z_range[0], health_hi=healthy_z_range[1],
+                        health_closed=True)
+
+    @staticmethod
+    def hopper(dt: float = 0.008, ctrl_cost_weight: float = 1e-3, healthy_z_range=(0.7, float("inf")),
+               healthy_state_range=(-100.0, 100.0)) -> "CostSpec":
+        # mujoco.py:205-225 (o=12): -(next[0]-obs[0])/dt + 200*unhealthy + w*sum(a^2)
+        return CostSpec(ctrl_cost_weight, 0, 0.0, -1, 0.0, 0.0, diff_idx=0, diff_weight=-1.0 / dt, health_idx=1,
+                        health_penalty=200.0, health_lo=healthy_z_range[0], health_hi=healthy_z_range[1],
+                        box_from=2, box_lo=healthy_state_range[0], box_hi=healthy_state_range[1])
+
+    @staticmethod
+    def humanoid(nq: int = 24, exclude_current_positions: bool = True, forward_reward_weight: float = 1.25,
+                 ctrl_cost_weight: float = 0.1, healthy_z_range=(1.0, 2.0)) -> "CostSpec":
+        # mujoco.py:317-343: -w_f*obs[nq-2 | nq] + 100*unhealthy(z = obs[0 | 2]) + w*sum(a^2)
+        return CostSpec(ctrl_cost_weight, nq - 2 if exclude_current_positions else nq, -forward_reward_weight, -1, 0.0,
+                        0.0, health_idx=0 if exclude_current_positions else 2, health_penalty=100.0,
+                        health_lo=healthy_z_range[0], health_hi=healthy_z_range[1])
+
+    @staticmethod
+    def reacher(obs_dim: int = 11) -> "CostSpec":
+        # mujoco.py:366-368: ||obs[-3:]||
+        return CostSpec(0.0, 0, 0.0, -1, 0.0, 0.0, dist_a=(obs_dim - 3, 0), dist_len=(3, 0), dist_weight=(1.0, 0.0))
+
+    @staticmethod
+    def fetch_pick_and_place(orig_obs_len: int = 25, sparse: bool = False, threshold: float = 0.05,
+                             shaped_reward: bool = True) -> "CostSpec":
+        # robotics.py:150-164: ||goal - obs[3:6]|| (+ 0.1*||obs[0:3] - obs[3:6]||), or the [. > threshold] indicators
+        return CostSpec(0.0, 0, 0.0, -1, 0.0, 0.0, dist_a=(orig_obs_len, 0), dist_b=(3, 3),
+                        dist_len=(3, 3 if shaped_reward else 0), dist_sparse=(sparse, sparse),
+                        dist_weight=(1.0, 0.1), dist_thresh=(threshold, threshold))
+
+    @staticmethod
+    def fetch_reach(orig_obs_len: int = 10, sparse: bool = False, threshold: float = 0.05) -> "CostSpec":
+        # robotics.py:286-295: ||goal - obs[0:3]|| or [. > threshold]
+        return CostSpec(0.0, 0, 0.0, -1, 0.0, 0.0, dist_a=(orig_obs_len, 0), dist_b=(0, -1), dist_len=(3, 0),
+                        dist_sparse=(sparse, False), dist_weight=(1.0, 0.0), dist_thresh=(threshold, 0.0))
+
+    def unhealthy(self, obs: np.ndarray) -> np.ndarray:
+        z = obs[..., self.health_idx]
+        if self.health_closed:
+            ok = (self.health_lo <= z) * (z <= self.health_hi)
+        else:
+            ok = (self.health_lo < z) * (z < self.health_hi)
+        if self.box_from >= 0:
+            st = obs[..., self.box_from:]
+            ok = np.logical_and(np.all(np.logical_and(self.box_lo < st, st < self.box_hi), axis=-1), ok)
+        return 1 - np.isfinite(obs).all(axis=-1) * ok
+
+    def dist_term(self, j: int, obs: np.ndarray) -> np.ndarray:
+        """Term j's norm, accumulated element by element in index order (the order the kernels use)."""
+        dt = obs.dtype.type
+        acc = np.zeros(obs.shape[:-1], dtype=obs.dtype)
+        for m in range(self.dist_len[j]):
+            v = obs[..., self.dist_a[j] + m]
+            if self.dist_b[j] >= 0:
+                v = v - obs[..., self.dist_b[j] + m]
+            acc = acc + v * v
+        r = np.sqrt(acc)
+        if self.dist_sparse[j]:
+            r = (r > dt(self.dist_thresh[j])).astype(obs.dtype)
+        return dt(self.dist_weight[j]) * r
+
     def __call__(self, obs: np.ndarray, act: np.ndarray, next_obs=None) -> np.ndarray:
         scores = np.zeros(act.shape[:-1], dtype=act.dtype)
         if self.flip_idx >= 0:
@@ -361,7 +463,61 @@ class CostSpec:
             scores = scores + (ang < -self.flip_thresh) * self.flip_penalty
         scores = scores + self.ctrl_weight * np.sum(act ** 2, axis=-1)
         scores = scores + self.lin_weight * obs[..., self.lin_idx]
-        return scores
+        return scores + self.extended_terms(obs, next_obs)
+
+    def extended_terms(self, obs: np.ndarray, next_obs) -> np.ndarray:
+        dt = obs.dtype.type
+        ext = np.zeros(obs.shape[:-1], dtype=obs.dtype)
+        if self.diff_idx >= 0:
+            ext = ext + dt(self.diff_weight) * (next_obs[..., self.diff_idx] - obs[..., self.diff_idx])
+        if self.health_idx >= 0:
+            ext = ext + dt(self.health_penalty) * self.unhealthy(obs).astype(obs.dtype)
+        for j in range(2):
+            if self.dist_len[j] > 0:
+                ext = ext + self.dist_term(j, obs)
+        return ext
+
+
+def trajectory_costs(cost: CostSpec, observations, actions, next_observations=None, mode="sum", dtype=None):
+    """``trajectory_cost_fn`` (abstract_controller.py:74-91) over rollouts held as arrays
+    ``observations / next_observations [P,h,o]``, ``actions [P,h,d]``: per-step costs in the kernels'
+    order (control cost summed over d in index order, steps reduced in t order)."""
+    dt = np.dtype(actions.dtype if dtype is None else dtype).type
+    observations, actions = observations.astype(dt), actions.astype(dt)
+    nxt = None if next_observations is None else next_observations.astype(dt)
+    acc = None
+    for t in range(actions.shape[1]):
+        c = _step_cost(cost, observations[:, t], actions[:, t], None if nxt is None else nxt[:, t], dt)
+        acc = _reduce_step(acc, c, mode)
+    return acc
+
+
+def _step_cost(cost: CostSpec, obs, a, nxt, dt):
+    ctrl = np.zeros(a.shape[0], dtype=dt)
+    for j in range(a.shape[1]):
+        ctrl = ctrl + a[:, j] * a[:, j]
+    c = np.zeros(a.shape[0], dtype=dt)
+    if cost.flip_idx >= 0:
+        ang = obs[:, cost.flip_idx]
+        c = c + (ang > dt(cost.flip_thresh)).astype(dt) * dt(cost.flip_penalty)
+        c = c + (ang < dt(-cost.flip_thresh)).astype(dt) * dt(cost.flip_penalty)
+    c = c + dt(cost.ctrl_weight) * ctrl
+    c = c + dt(cost.lin_weight) * obs[:, cost.lin_idx]
+    if cost.extended:
+        c = c + cost.extended_terms(obs, nxt)
+    return c
+
+
+def _reduce_step(acc, c, mode):
+    if acc is None:
+        return c
+    if mode == "sum":
+        return acc + c
+    if mode == "best":
+        return np.minimum(acc, c)
+    if mode == "final":
+        return c
+    raise NotImplementedError(mode)
 
 
 # --------------------------------------------------------------------------
@@ -450,27 +606,9 @@ def rollout_costs(model: SyntheticModel, cost: CostSpec, obs0, actions, mode="su
     acc = None
     for t in range(h):
         a = actions[:, t]
-        ctrl = np.zeros(P, dtype=dt)
-        for j in range(a.shape[1]):
-            ctrl = ctrl + a[:, j] * a[:, j]
-        c = np.zeros(P, dtype=dt)
-        if cost.flip_idx >= 0:
-            ang = obs[:, cost.flip_idx]
-            c = c + (ang > dt(cost.flip_thresh)).astype(dt) * dt(cost.flip_penalty)
-            c = c + (ang < dt(-cost.flip_thresh)).astype(dt) * dt(cost.flip_penalty)
-        c = c + dt(cost.ctrl_weight) * ctrl
-        c = c + dt(cost.lin_weight) * obs[:, cost.lin_idx]
-        if acc is None:
-            acc = c
-        elif mode == "sum":
-            acc = acc + c
-        elif mode == "best":
-            acc = np.minimum(acc, c)
-        elif mode == "final":
-            acc = c
-        else:
-            raise NotImplementedError(mode)
-        obs = model.predict(obs, a)
+        nxt = model.predict(obs, a)
+        acc = _reduce_step(acc, _step_cost(cost, obs, a, nxt, dt), mode)
+        obs = nxt
     return acc
 
 

@@ -91,6 +91,11 @@ STUBS = {
     "gym/envs/mujoco/humanoid_v3.py": "from . import MujocoEnv\nclass HumanoidEnv(MujocoEnv): pass\n",
     "gym/envs/mujoco/humanoidstandup.py": "from . import MujocoEnv\nclass HumanoidStandupEnv(MujocoEnv): pass\n",
     "gym/envs/mujoco/hopper_v3.py": "from . import MujocoEnv\nclass HopperEnv(MujocoEnv): pass\n",
+    "gym/envs/robotics/__init__.py": "",
+    "gym/envs/robotics/robot_env.py": "class RobotEnv:\n    def __init__(self, *a, **k): pass\n",
+    "gym/envs/robotics/fetch/__init__.py": "",
+    "gym/envs/robotics/fetch/pick_and_place.py": "class FetchPickAndPlaceEnv:\n    def __init__(self, *a, **k): pass\n",
+    "gym/envs/robotics/fetch/reach.py": "class FetchReachEnv:\n    def __init__(self, *a, **k): pass\n",
     "mujoco_py/__init__.py": "",
     "mujoco_py/generated/__init__.py": "",
     "mujoco_py/generated/const.py": "CAMERA_FIXED = 2\n",
@@ -439,11 +444,85 @@ def cost_fn_vectors():
     print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB")
 
 
+def env_cost_vectors():
+    """f-4: input/output vectors of the reference's remaining parametric cost functions (Ant, Hopper, Humanoid,
+    Reacher in environments/mujoco.py; FetchPickAndPlace, FetchReach in environments/robotics.py), each called
+    unbound on a stand-in ``self`` carrying the attributes it reads (the gym v3 defaults)."""
+    import environments.mujoco as ref_mj
+    import environments.robotics as ref_rb
+    from environments.abstract_environments import MaskedGoalSpaceEnvironmentInterface as MG
+    rs = np.random.RandomState(9)
+    n, h = 8, 6
+
+    def bind(ns, cls, *names):
+        for nm in names:
+            setattr(ns, nm, types.MethodType(getattr(cls, nm), ns))
+        return ns
+
+    data = {}
+    # Ant: o = 113 (positions included), z = obs[2] around the healthy range [0.2, 1.0], a few non-finite rows
+    ant = bind(types.SimpleNamespace(_healthy_z_range=(0.2, 1.0), dt=0.05, _ctrl_cost_weight=0.5), ref_mj.Ant,
+               "are_states_unhealthy")
+    o = rs.randn(n, h, 113)
+    o[..., 2] = rs.uniform(0.0, 1.3, (n, h))
+    o[0, 1, 2], o[0, 2, 2] = 0.2, 1.0            # the closed ends of the range
+    o[1, 0, 50], o[1, 3, 7] = np.inf, np.nan
+    nx = o + 0.05 * rs.randn(n, h, 113)
+    a = rs.uniform(-1, 1, (n, h, 8))
+    data.update(ant_obs=o, ant_next=nx, ant_act=a, ant=ref_mj.Ant.cost_fn(ant, o, a, nx))
+    # Hopper: o = 12, z = obs[1] around 0.7, state box (-100, 100) over obs[2:]
+    hop = bind(types.SimpleNamespace(_healthy_z_range=(0.7, float("inf")), _healthy_state_range=(-100.0, 100.0),
+                                     _healthy_angle_range=(-0.2, 0.2), dt=0.008, _ctrl_cost_weight=1e-3),
+               ref_mj.Hopper, "unhealthy_states")
+    o = rs.randn(n, h, 12)
+    o[..., 1] = rs.uniform(0.4, 1.4, (n, h))
+    o[0, 1, 1] = 0.7                              # open end
+    o[2, 0, 5], o[2, 1, 11], o[2, 2, 0] = 150.0, -100.0, 500.0   # outside / on the edge of the box; obs[0] is not in it
+    o[3, 0, 4] = np.nan
+    nx = o + 0.01 * rs.randn(n, h, 12)
+    a = rs.uniform(-1, 1, (n, h, 3))
+    data.update(hopper_obs=o, hopper_next=nx, hopper_act=a, hopper=ref_mj.Hopper.cost_fn(hop, o, a, nx))
+    # Humanoid: positions excluded (o = 376 here is irrelevant to the cost: any width), z = obs[0], velocity obs[nq-2]
+    for excl, o_dim, tag in ((True, 40, "humanoid_excl"), (False, 42, "humanoid_incl")):
+        hum = bind(types.SimpleNamespace(_healthy_z_range=(1.0, 2.0), _exclude_current_positions_from_observation=excl,
+                                         model=types.SimpleNamespace(nq=24), _forward_reward_weight=1.25,
+                                         _ctrl_cost_weight=0.1), ref_mj.Humanoid, "unhealthy_states")
+        o = rs.randn(n, h, o_dim)
+        o[..., 0 if excl else 2] = rs.uniform(0.6, 2.4, (n, h))
+        o[4, 4, 9] = -np.inf
+        a = rs.uniform(-0.4, 0.4, (n, h, 17))
+        data.update({tag + "_obs": o, tag + "_act": a, tag: ref_mj.Humanoid.cost_fn(hum, o, a, o)})
+    # Reacher: norm of the last three observation entries
+    o = rs.randn(n, h, 11)
+    a = rs.uniform(-1, 1, (n, h, 2))
+    data.update(reacher_obs=o, reacher_act=a, reacher=ref_mj.Reacher.cost_fn(None, o, a, None))
+    # FetchPickAndPlace (obs 25 + goal 3) and FetchReach (obs 10 + goal 3), dense / sparse / shaped
+    for tag, cls, olen, ach in (("fpp", ref_rb.FetchPickAndPlace, 25, [3, 4, 5]), ("freach", ref_rb.FetchReach, 10, [0, 1, 2])):
+        o = 0.1 * rs.randn(n * h, olen + 3)      # robotics cost_fn indexes observation[:, :3] -> 2-D input
+        near = np.arange(0, n * h, 2)            # every other row: goal (and gripper) within ~threshold of the object
+        o[near, olen:] = o[near][:, ach] + 0.03 * rs.randn(len(near), 3)
+        if tag == "fpp":
+            o[near[::2], 0:3] = o[near[::2], 3:6] + 0.03 * rs.randn(len(near[::2]), 3)
+        a = rs.uniform(-1, 1, (n * h, 4))
+        data.update({tag + "_obs": o, tag + "_act": a})
+        for sparse in (False, True):
+            for shaped in ((False, True) if tag == "fpp" else (False,)):
+                ns = bind(types.SimpleNamespace(goal_idx=np.arange(olen, olen + 3), achieved_goal_idx=ach, sparse=sparse,
+                                                threshold=0.05, shaped_reward=shaped), MG,
+                          "goal_from_observation", "achieved_goal_from_observation")
+                key = f"{tag}_{'sparse' if sparse else 'dense'}{'_shaped' if shaped else ''}"
+                data[key] = np.asarray(cls.cost_fn(ns, o, a, None))
+    path = os.path.join(OUT, "env_cost_vectors.npz")
+    np.savez_compressed(path, **data)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference (build container only)")
     install_stubs()
     cost_fn_vectors()
+    env_cost_vectors()
     # C1-shaped: HalfCheetah shapes, beta=0.25, 3 iterations (BASELINE.json configs[0])
     run_case("c1_halfcheetah_n128", N=128, h=30, d=6, o=17, beta=0.25, iters=3, seed=11,
              n_steps=3, kind=0, env_kind="halfcheetah")

@@ -6,7 +6,7 @@ import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-_ALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if not p.endswith("cost_fn_vectors.npz"))
+_ALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if not p.endswith("cost_vectors.npz") and not p.endswith("cost_fn_vectors.npz"))
 CASES = [n for n in _ALL if not n.startswith("cemstd_")]        # MpcICem runs
 CEMSTD_CASES = [n for n in _ALL if n.startswith("cemstd_")]     # MpcCemStd runs (truncated-normal CEM baseline)
 

@@ -116,6 +116,46 @@ def test_cost_functions_match_reference():
     assert (np.abs(z["o17"][..., 1]) > np.pi / 2).any()
 
 
+def env_cost_specs():
+    """(fixture tag, oracle spec, has next_obs) for every cost function in env_cost_vectors.npz."""
+    return [
+        ("ant", O.CostSpec.ant(), True), ("hopper", O.CostSpec.hopper(), True),
+        ("humanoid_excl", O.CostSpec.humanoid(24, True), False), ("humanoid_incl", O.CostSpec.humanoid(24, False), False),
+        ("reacher", O.CostSpec.reacher(11), False),
+        ("fpp_dense", O.CostSpec.fetch_pick_and_place(25, False, 0.05, False), False),
+        ("fpp_dense_shaped", O.CostSpec.fetch_pick_and_place(25, False, 0.05, True), False),
+        ("fpp_sparse", O.CostSpec.fetch_pick_and_place(25, True, 0.05, False), False),
+        ("fpp_sparse_shaped", O.CostSpec.fetch_pick_and_place(25, True, 0.05, True), False),
+        ("freach_dense", O.CostSpec.fetch_reach(10, False, 0.05), False),
+        ("freach_sparse", O.CostSpec.fetch_reach(10, True, 0.05), False),
+    ]
+
+
+def env_cost_inputs(z, tag):
+    base = tag.split("_")[0] if tag.startswith(("fpp", "freach")) else tag
+    obs, act = z[base + "_obs"], z[base + "_act"]
+    nxt = z[base + "_next"] if base + "_next" in z.files else None
+    return obs, act, nxt
+
+
+@pytest.mark.parametrize("tag,spec,has_next", env_cost_specs(), ids=[t for t, _, _ in env_cost_specs()])
+def test_env_cost_functions_match_reference(tag, spec, has_next):
+    """f-4: Ant / Hopper / Humanoid / Reacher (environments/mujoco.py:151-171, 205-225, 317-343, 366-368) and
+    FetchPickAndPlace / FetchReach (environments/robotics.py:150-164, 286-295) as parametric cost terms: indicator
+    terms exact, floats to 1e-12 (the reference adds its terms in an env-specific order)."""
+    z = np.load(os.path.join(GOLDEN, "env_cost_vectors.npz"))
+    obs, act, nxt = env_cost_inputs(z, tag)
+    assert (nxt is not None) == has_next and spec.needs_next_obs == has_next
+    got = spec(obs, act, nxt)
+    tol = 1e-12 if z[tag].dtype == np.float64 else 1e-7     # the sparse robotics costs come back as float32
+    want = z[tag].astype(np.float64)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=tol, atol=tol)
+    if spec.health_idx >= 0:   # both healthy and unhealthy rows, and non-finite observations, are in the vectors
+        u = spec.unhealthy(obs)
+        assert 0 < u.sum() < u.size and not np.isfinite(obs).all()
+
+
 @pytest.mark.parametrize("name", __import__("golden_util").CEMSTD_CASES)
 def test_cem_std_oracle_matches_reference(name):
     """f-3: the CEM baseline MpcCemStd (truncated normal, icem/controllers/mpc.py:142-327): replaying the recorded
