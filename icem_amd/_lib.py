@@ -42,6 +42,16 @@ class IcemCostSpecC(C.Structure):
                 ("flip_thresh", C.c_double), ("lin_idx", C.c_int32), ("flip_idx", C.c_int32)]
 
 
+class IcemCostTermsC(C.Structure):
+    """include/icem_hip.h: struct icem_cost_terms."""
+    _fields_ = [("diff_weight", C.c_double), ("health_penalty", C.c_double), ("health_lo", C.c_double),
+                ("health_hi", C.c_double), ("box_lo", C.c_double), ("box_hi", C.c_double),
+                ("dist_weight", C.c_double * 2), ("dist_thresh", C.c_double * 2),
+                ("diff_idx", C.c_int32), ("health_idx", C.c_int32), ("health_closed", C.c_int32), ("box_from", C.c_int32),
+                ("dist_a", C.c_int32 * 2), ("dist_b", C.c_int32 * 2), ("dist_len", C.c_int32 * 2),
+                ("dist_sparse", C.c_int32 * 2)]
+
+
 class IcemPlanBuffersC(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "mean", "std", "low", "high", "obs0", "actions", "costs", "elites", "records", "workspace",
@@ -61,6 +71,8 @@ SYMBOLS = [
     ("icem_noise_tables_host", C.c_int, [_I32, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("icem_set_model", C.c_int, [_H, _I32, _I32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("icem_set_cost", C.c_int, [_H, C.POINTER(IcemCostSpecC)]),
+    ("icem_set_cost_terms", C.c_int, [_H, C.POINTER(IcemCostTermsC)]),
+    ("icem_trajectory_cost", C.c_int, [_H, _I32, _I32, _VP, _VP, _I64, _I64, _VP, _VP, _VP]),
     ("icem_sample_clip", C.c_int, [_H, _I32, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _U64, _I32, _I32, _VP, _VP]),
     ("icem_philox_normals", C.c_int, [_H, _I32, _I64, _U64, _VP, _VP, _VP]),
     ("icem_rollout_cost", C.c_int, [_H, _I32, _VP, _VP, _VP, _VP, _VP]),

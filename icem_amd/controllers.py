@@ -209,9 +209,14 @@ class MpcController(ModelBasedController, StatefulController, ABC):
         if self.device_path:
             m, c = self.forward_model, self.env.cost_spec
             self.planner.set_model(m.kind, m.A, m.B)
-            self.planner.set_cost(c.ctrl_weight, c.lin_idx, c.lin_weight, c.flip_idx, c.flip_penalty, c.flip_thresh)
+            self.planner.set_cost_spec(c)
         elif world != 1:
             raise NotImplementedError("sharding over GPUs needs the device path (built-in model + cost_spec)")
+        # a torch model without its own cost callable is scored by the env's parametric cost on the device
+        self.torch_spec_cost = (self.torch_path and getattr(self.forward_model, "cost", None) is None
+                                and getattr(self.env, "cost_spec", None) is not None)
+        if self.torch_spec_cost:
+            self.planner.set_cost_spec(self.env.cost_spec)
 
     def _costs_of(self, obs, actions: torch.Tensor) -> torch.Tensor:
         """Per-trajectory costs (device tensor) of a batch of device action sequences, through whichever
@@ -225,6 +230,15 @@ class MpcController(ModelBasedController, StatefulController, ABC):
             m = self.forward_model
             o = torch.as_tensor(np.asarray(obs, dtype=np.float64), dtype=m.dtype, device=p.device)
             o = o.expand(actions.shape[0], -1)
+            if self.torch_spec_cost:
+                # the rollout stays in HBM step-major ([h+1, n, o]); icem_trajectory_cost scores it in one launch
+                buf = torch.empty((p.h + 1,) + tuple(o.shape), dtype=p.dt, device=p.device)
+                buf[0] = o
+                a_all = actions.to(m.dtype)
+                for t in range(p.h):
+                    o = m.torch_step(o, a_all[:, t])
+                    buf[t + 1] = o
+                return p.trajectory_cost(buf[:p.h].transpose(0, 1), actions, buf[1:].transpose(0, 1))
             step_costs = torch.empty((actions.shape[0], p.h), dtype=p.dt, device=p.device)
             a_all = actions.to(m.dtype)
             for t in range(p.h):

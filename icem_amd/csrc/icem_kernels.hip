@@ -12,6 +12,7 @@
 // local_pack / merge_refit (K3+K4 of the fused step), small epilogue kernels.
 #include <hip/hip_runtime.h>
 
+#include <cfloat>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -242,7 +243,41 @@ template <typename T>
 struct CostArgs {
     T ctrl_w, lin_w, flip_pen, flip_th;
     int lin_idx, flip_idx;
+    // icem_cost_terms (include/icem_hip.h); ext = any of them on
+    T diff_w, health_pen, health_lo, health_hi, box_lo, box_hi, dist_w[2], dist_th[2];
+    int ext, diff_idx, health_idx, health_closed, box_from, dist_a[2], dist_b[2], dist_len[2], dist_sparse[2];
 };
+
+__device__ __forceinline__ bool finite_val(float x) { return fabsf(x) <= FLT_MAX; }    // false for NaN / inf
+__device__ __forceinline__ bool finite_val(double x) { return fabs(x) <= DBL_MAX; }
+__device__ __forceinline__ float sqrt_val(float x) { return sqrtf(x); }
+__device__ __forceinline__ double sqrt_val(double x) { return sqrt(x); }
+
+// The extra terms of one step given accessors for the pre- and post-action observation; `bad` = some observation
+// entry is non-finite or outside Hopper's state box (computed by the caller, who owns the sweep over the row).
+template <typename T, typename Obs, typename Nxt>
+__device__ __forceinline__ T cost_terms(const CostArgs<T>& cs, bool bad, Obs obs, Nxt nxt) {
+    T c = (T)0;
+    if (cs.diff_idx >= 0) c += cs.diff_w * (nxt(cs.diff_idx) - obs(cs.diff_idx));
+    if (cs.health_idx >= 0) {
+        const T z = obs(cs.health_idx);
+        const bool in = cs.health_closed ? (cs.health_lo <= z && z <= cs.health_hi) : (cs.health_lo < z && z < cs.health_hi);
+        c += (in && !bad) ? (T)0 : cs.health_pen;
+    }
+    for (int j = 0; j < 2; ++j) {
+        if (cs.dist_len[j] <= 0) continue;
+        T acc = (T)0;
+        for (int m = 0; m < cs.dist_len[j]; ++m) {
+            T v = obs(cs.dist_a[j] + m);
+            if (cs.dist_b[j] >= 0) v -= obs(cs.dist_b[j] + m);
+            acc = fmad(v, v, acc);
+        }
+        T r = sqrt_val(acc);
+        if (cs.dist_sparse[j]) r = r > cs.dist_th[j] ? (T)1 : (T)0;
+        c += cs.dist_w[j] * r;
+    }
+    return c;
+}
 
 template <typename T>
 struct RolloutArgs {
@@ -301,6 +336,25 @@ __global__ __launch_bounds__(WG) void rollout_cost_kernel(RolloutArgs<T> a) {
         }
         c += a.cs.ctrl_w * ctrl;
         c += a.cs.lin_w * lin;
+        if (a.cs.ext) {
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < O; ++k) {
+                if (k >= a.o) continue;
+                bad |= !finite_val(obs[k]);
+                if (a.cs.box_from >= 0 && k >= a.cs.box_from) bad |= !(a.cs.box_lo < obs[k] && obs[k] < a.cs.box_hi);
+            }
+            auto pick = [&](const T* v, int idx) {
+                T r = (T)0;
+#pragma unroll
+                for (int k = 0; k < O; ++k) r = (k == idx) ? v[k] : r;
+                return r;
+            };
+            T post[O];
+#pragma unroll
+            for (int i = 0; i < O; ++i) post[i] = (KIND == ICEM_MODEL_TANH) ? act_tanh(nxt[i]) : nxt[i];
+            c += cost_terms<T>(a.cs, bad, [&](int idx) { return pick(obs, idx); }, [&](int idx) { return pick(post, idx); });
+        }
         if (t == 0 || a.cost_mode == ICEM_COST_FINAL)
             acc = c;
         else if (a.cost_mode == ICEM_COST_SUM)
@@ -335,6 +389,97 @@ __global__ __launch_bounds__(WG) void cost_reduce_kernel(int n, int h, int mode,
             acc = c;
     }
     costs[i] = acc;
+}
+
+// trajectory_cost_fn (abstract_controller.py:74-91) over rollouts an external model left in HBM: one wavefront
+// per trajectory.  Phase A, only when a term needs every entry of the observation (finite check / state box):
+// the rows are swept coalesced (lanes across the observation), one ballot per step leaves a bit mask of the bad
+// steps.  Phase B: lane t scores step t (its actions and the handful of observation entries the terms read).
+// The step costs are then reduced in t order.
+template <typename T>
+struct TrajCostArgs {
+    int n, h, d, o;
+    const T* obs;
+    const T* nxt;     // nullable
+    long long ts, ss;
+    const T* actions;
+    T* costs;
+    CostArgs<T> cs;
+    int cost_mode, sweep;
+};
+
+template <typename T>
+__device__ __forceinline__ bool bad_entry(const TrajCostArgs<T>& a, T v, int k) {
+    bool bad = !finite_val(v);
+    if (a.cs.box_from >= 0 && k >= a.cs.box_from) bad |= !(a.cs.box_lo < v && v < a.cs.box_hi);
+    return bad;
+}
+
+template <typename T>
+__global__ __launch_bounds__(WG) void trajectory_cost_kernel(TrajCostArgs<T> a) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * (WG / 64) + (threadIdx.x >> 6);
+    if (n >= a.n) return;
+    const T* __restrict__ traj = a.obs + (long long)n * a.ts;
+    unsigned long long bad_steps = 0;   // h <= 64 (icem_create)
+    if (a.sweep == 1) {
+        // four rows x two 64-entry columns = eight unconditional loads in flight per lane; indices past the end
+        // of a row / of the trajectory are clamped (a repeated entry changes nothing)
+        for (int t = 0; t < a.h; t += 4) {
+            const T* __restrict__ r0 = traj + (long long)min(t + 0, a.h - 1) * a.ss;
+            const T* __restrict__ r1 = traj + (long long)min(t + 1, a.h - 1) * a.ss;
+            const T* __restrict__ r2 = traj + (long long)min(t + 2, a.h - 1) * a.ss;
+            const T* __restrict__ r3 = traj + (long long)min(t + 3, a.h - 1) * a.ss;
+            bool b0 = false, b1 = false, b2 = false, b3 = false;
+            for (int base = 0; base < a.o; base += 128) {
+                const int k0 = min(base + lane, a.o - 1), k1 = min(base + 64 + lane, a.o - 1);
+                const T v00 = r0[k0], v01 = r0[k1], v10 = r1[k0], v11 = r1[k1];
+                const T v20 = r2[k0], v21 = r2[k1], v30 = r3[k0], v31 = r3[k1];
+                b0 |= bad_entry(a, v00, k0) | bad_entry(a, v01, k1);
+                b1 |= bad_entry(a, v10, k0) | bad_entry(a, v11, k1);
+                b2 |= bad_entry(a, v20, k0) | bad_entry(a, v21, k1);
+                b3 |= bad_entry(a, v30, k0) | bad_entry(a, v31, k1);
+            }
+            bad_steps |= (unsigned long long)(__ballot(b0) != 0) << (t & 63);
+            bad_steps |= (unsigned long long)(__ballot(b1) != 0) << ((t + 1) & 63);   // rows past h repeat row h-1:
+            bad_steps |= (unsigned long long)(__ballot(b2) != 0) << ((t + 2) & 63);   // their bits are never read
+            bad_steps |= (unsigned long long)(__ballot(b3) != 0) << ((t + 3) & 63);
+        }
+    }
+    T c = (T)0;
+    if (lane < a.h) {
+        const int t = lane;
+        const T* __restrict__ row = traj + (long long)t * a.ss;
+        const T* __restrict__ act = a.actions + ((long long)n * a.h + t) * a.d;
+        T ctrl = (T)0;
+        for (int j = 0; j < a.d; ++j) ctrl = fmad(act[j], act[j], ctrl);
+        if (a.cs.flip_idx >= 0) {
+            const T ang = row[a.cs.flip_idx];
+            c += (ang > a.cs.flip_th) ? a.cs.flip_pen : (T)0;
+            c += (ang < -a.cs.flip_th) ? a.cs.flip_pen : (T)0;
+        }
+        c += a.cs.ctrl_w * ctrl;
+        c += a.cs.lin_w * row[a.cs.lin_idx];
+        if (a.cs.ext) {
+            const T* __restrict__ nrow = a.nxt ? a.nxt + (long long)n * a.ts + (long long)t * a.ss : row;
+            bool bad = (bad_steps >> t) & 1ull;
+            if (a.sweep == 2)   // narrow observations: each lane checks its own row
+                for (int k = 0; k < a.o; ++k) bad |= bad_entry(a, row[k], k);
+            c += cost_terms<T>(a.cs, bad, [&](int idx) { return row[idx]; },
+                               [&](int idx) { return nrow[idx]; });
+        }
+    }
+    T acc = __shfl(c, 0);
+    for (int t = 1; t < a.h; ++t) {
+        const T ct = __shfl(c, t);
+        if (a.cost_mode == ICEM_COST_SUM)
+            acc += ct;
+        else if (a.cost_mode == ICEM_COST_BEST)
+            acc = ct < acc ? ct : acc;
+        else
+            acc = ct;
+    }
+    if (lane == 0) a.costs[n] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -641,6 +786,8 @@ struct icem_handle {
     void* B_dev = nullptr;
     bool has_model = false, has_cost = false;
     icem_cost_spec cost;
+    icem_cost_terms terms;
+    bool has_terms = false;  // any term of icem_cost_terms switched on
     std::vector<int> pop;
     int n_reuse = 0;
     int n_local_max = 0;
@@ -864,6 +1011,73 @@ int launch_rollout_k(const icem_handle* h, const RolloutArgs<T>& a, hipStream_t 
 }
 
 template <typename T>
+void fill_cost_args(const icem_handle* h, CostArgs<T>& cs) {
+    cs.ctrl_w = (T)h->cost.ctrl_weight;
+    cs.lin_w = (T)h->cost.lin_weight;
+    cs.flip_pen = (T)h->cost.flip_penalty;
+    cs.flip_th = (T)h->cost.flip_thresh;
+    cs.lin_idx = h->cost.lin_idx;
+    cs.flip_idx = h->cost.flip_idx;
+    const icem_cost_terms& t = h->terms;
+    cs.ext = h->has_terms ? 1 : 0;
+    cs.diff_w = (T)t.diff_weight;
+    cs.health_pen = (T)t.health_penalty;
+    cs.health_lo = (T)t.health_lo;
+    cs.health_hi = (T)t.health_hi;
+    cs.box_lo = (T)t.box_lo;
+    cs.box_hi = (T)t.box_hi;
+    cs.diff_idx = h->has_terms ? t.diff_idx : -1;
+    cs.health_idx = h->has_terms ? t.health_idx : -1;
+    cs.health_closed = t.health_closed;
+    cs.box_from = (h->has_terms && t.health_idx >= 0) ? t.box_from : -1;
+    for (int j = 0; j < 2; ++j) {
+        cs.dist_w[j] = (T)t.dist_weight[j];
+        cs.dist_th[j] = (T)t.dist_thresh[j];
+        cs.dist_a[j] = t.dist_a[j];
+        cs.dist_b[j] = t.dist_b[j];
+        cs.dist_len[j] = h->has_terms ? t.dist_len[j] : 0;
+        cs.dist_sparse[j] = t.dist_sparse[j];
+    }
+}
+
+// every index a cost term reads lies inside an observation of width o
+const char* cost_indices_error(const icem_handle* h, int o) {
+    if (h->cost.lin_idx < 0 || h->cost.lin_idx >= o || h->cost.flip_idx >= o) return "cost index outside the observation";
+    if (!h->has_terms) return nullptr;
+    const icem_cost_terms& t = h->terms;
+    if (t.diff_idx >= o || t.health_idx >= o || t.box_from >= o) return "cost term index outside the observation";
+    for (int j = 0; j < 2; ++j) {
+        if (t.dist_len[j] <= 0) continue;
+        if (t.dist_a[j] < 0 || t.dist_a[j] + t.dist_len[j] > o || (t.dist_b[j] >= 0 && t.dist_b[j] + t.dist_len[j] > o))
+            return "distance term slice outside the observation";
+    }
+    return nullptr;
+}
+
+template <typename T>
+int launch_trajectory_cost(const icem_handle* h, int n, int o, const void* obs, const void* nxt, long long ts,
+                           long long ss, const void* actions, void* costs, hipStream_t st) {
+    TrajCostArgs<T> a;
+    a.n = n;
+    a.h = h->cfg.horizon;
+    a.d = h->cfg.act_dim;
+    a.o = o;
+    a.obs = (const T*)obs;
+    a.nxt = (const T*)nxt;
+    a.ts = ts;
+    a.ss = ss;
+    a.actions = (const T*)actions;
+    a.costs = (T*)costs;
+    fill_cost_args<T>(h, a.cs);
+    a.cost_mode = h->cfg.cost_mode;
+    // all_finite(obs) / the state box are part of `unhealthy` only; 1: coalesced sweep, 2: per-lane rows (narrow obs)
+    a.sweep = a.cs.health_idx < 0 ? 0 : (o <= 32 ? 2 : 1);
+    hipLaunchKernelGGL((trajectory_cost_kernel<T>), dim3((n + WG / 64 - 1) / (WG / 64)), dim3(WG), 0, st, a);
+    ICEM_HIP_TRY(hipGetLastError());
+    return ICEM_OK;
+}
+
+template <typename T>
 int launch_rollout(const icem_handle* h, int n, const void* obs0, const void* actions, void* costs, void* observations,
                    hipStream_t st) {
     if (n <= 0) return ICEM_OK;
@@ -878,12 +1092,7 @@ int launch_rollout(const icem_handle* h, int n, const void* obs0, const void* ac
     a.actions = (const T*)actions;
     a.costs = (T*)costs;
     a.observations = (T*)observations;
-    a.cs.ctrl_w = (T)h->cost.ctrl_weight;
-    a.cs.lin_w = (T)h->cost.lin_weight;
-    a.cs.flip_pen = (T)h->cost.flip_penalty;
-    a.cs.flip_th = (T)h->cost.flip_thresh;
-    a.cs.lin_idx = h->cost.lin_idx;
-    a.cs.flip_idx = h->cost.flip_idx;
+    fill_cost_args<T>(h, a.cs);
     a.cost_mode = h->cfg.cost_mode;
     return h->model_kind == ICEM_MODEL_TANH ? launch_rollout_k<T, ICEM_MODEL_TANH>(h, a, st)
                                             : launch_rollout_k<T, ICEM_MODEL_LINEAR>(h, a, st);
@@ -955,6 +1164,7 @@ int ensure_fast_model(icem_handle* h) {
 }
 
 bool fast_rollout_ok(const icem_handle* h, int K) {
+    if (h->has_terms) return false;  // the extra cost terms live in the general kernel
     return h->use_fast && h->cfg.dtype == ICEM_F32 && h->has_model && h->has_cost &&
            fast_rollout_supported(h->cfg.horizon, h->cfg.act_dim, h->O, K);
 }
@@ -1501,6 +1711,36 @@ int icem_set_cost(icem_handle* h, const icem_cost_spec* spec) {
     return ICEM_OK;
 }
 
+int icem_set_cost_terms(icem_handle* h, const icem_cost_terms* terms) {
+    if (!h) return fail(ICEM_E_INVALID, "null argument");
+    if (terms == nullptr) {
+        h->has_terms = false;
+        return ICEM_OK;
+    }
+    for (int j = 0; j < 2; ++j)
+        if (terms->dist_len[j] < 0 || terms->dist_len[j] > 16) return fail(ICEM_E_INVALID, "dist_len must be in [0, 16]");
+    if (terms->box_from >= 0 && terms->health_idx < 0)
+        return fail(ICEM_E_INVALID, "box_from is part of the health term: health_idx must be set");
+    h->terms = *terms;
+    h->has_terms = terms->diff_idx >= 0 || terms->health_idx >= 0 || terms->dist_len[0] > 0 || terms->dist_len[1] > 0;
+    return ICEM_OK;
+}
+
+int icem_trajectory_cost(icem_handle* h, int32_t n, int32_t obs_dim, const void* observations,
+                         const void* next_observations, int64_t traj_stride, int64_t step_stride, const void* actions,
+                         void* costs, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (!h->has_cost) return fail(ICEM_E_STATE, "icem_set_cost must be called first");
+    if (n < 0 || obs_dim < 1 || !observations || !actions || !costs) return fail(ICEM_E_INVALID, "null tensor / bad n or obs_dim");
+    if (const char* e = cost_indices_error(h, obs_dim)) return fail(ICEM_E_INVALID, e);
+    if (h->has_terms && h->terms.diff_idx >= 0 && !next_observations)
+        return fail(ICEM_E_INVALID, "the difference term needs next_observations");
+    if (n == 0) return ICEM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    return ICEM_DISPATCH(h, launch_trajectory_cost<float>(h, n, obs_dim, observations, next_observations, traj_stride, step_stride, actions, costs, st),
+                         launch_trajectory_cost<double>(h, n, obs_dim, observations, next_observations, traj_stride, step_stride, actions, costs, st));
+}
+
 int icem_sample_clip(icem_handle* h, int32_t n, int64_t first_index, const void* mean, const void* std,
                      const void* low, const void* high, const void* z_r, const void* z_i, uint64_t offset,
                      int32_t t_begin, int32_t row0_mean, void* actions, void* stream) {
@@ -1586,8 +1826,7 @@ int icem_rollout_cost(icem_handle* h, int32_t n, const void* obs0, const void* a
     if (check_handle(h)) return ICEM_E_INVALID;
     if (!h->has_model || !h->has_cost) return fail(ICEM_E_STATE, "icem_set_model / icem_set_cost must be called first");
     if (n < 0 || !obs0 || !actions || !costs) return fail(ICEM_E_INVALID, "null tensor / negative n");
-    if (h->cost.lin_idx < 0 || h->cost.lin_idx >= h->obs_dim || h->cost.flip_idx >= h->obs_dim)
-        return fail(ICEM_E_INVALID, "cost index outside the observation");
+    if (const char* e = cost_indices_error(h, h->obs_dim)) return fail(ICEM_E_INVALID, e);
     hipStream_t st = (hipStream_t)stream;
     if (observations == nullptr && n > 0 && fast_rollout_ok(h, 0))
         return launch_fast_rollout(h, n, 0, 0, obs0, actions, costs, nullptr, nullptr, st, nullptr);
@@ -1743,6 +1982,7 @@ static int check_plan(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_st
     if (!b) return fail(ICEM_E_INVALID, "null buffers");
     if (!h->has_model || !h->has_cost) return fail(ICEM_E_STATE, "icem_set_model / icem_set_cost must be called first");
     if (mpc_step < 0 || it < 0 || it >= h->cfg.opt_iters) return fail(ICEM_E_INVALID, "mpc_step / iteration out of range");
+    if (const char* e = cost_indices_error(h, h->obs_dim)) return fail(ICEM_E_INVALID, e);
     if (!b->mean || !b->std || !b->low || !b->high || !b->obs0 || !b->actions || !b->costs || !b->elites || !b->records ||
         !b->workspace || !b->executed || !b->best_cost)
         return fail(ICEM_E_INVALID, "null plan buffer");

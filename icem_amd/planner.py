@@ -132,6 +132,40 @@ class IcemPlanner:
         spec = L.IcemCostSpecC(ctrl_weight, lin_weight, flip_penalty, flip_thresh, lin_idx, flip_idx)
         L.check(self.lib.icem_set_cost(self._h, C.byref(spec)))
 
+    def set_cost_spec(self, spec):
+        """The whole parametric cost of an env (``envs.CostSpec``): the HalfCheetah / HumanoidStandup form plus the
+        Ant / Hopper / Humanoid / Reacher / Fetch terms (``icem_set_cost_terms``)."""
+        self.set_cost(spec.ctrl_weight, spec.lin_idx, spec.lin_weight, spec.flip_idx, spec.flip_penalty, spec.flip_thresh)
+        if not getattr(spec, "extended", False):
+            L.check(self.lib.icem_set_cost_terms(self._h, None))
+            return
+        t = L.IcemCostTermsC(
+            diff_weight=spec.diff_weight, health_penalty=spec.health_penalty, health_lo=spec.health_lo,
+            health_hi=spec.health_hi, box_lo=spec.box_lo, box_hi=spec.box_hi,
+            dist_weight=(C.c_double * 2)(*spec.dist_weight), dist_thresh=(C.c_double * 2)(*spec.dist_thresh),
+            diff_idx=spec.diff_idx, health_idx=spec.health_idx, health_closed=int(spec.health_closed),
+            box_from=spec.box_from, dist_a=(C.c_int32 * 2)(*spec.dist_a), dist_b=(C.c_int32 * 2)(*spec.dist_b),
+            dist_len=(C.c_int32 * 2)(*spec.dist_len), dist_sparse=(C.c_int32 * 2)(*[int(x) for x in spec.dist_sparse]))
+        L.check(self.lib.icem_set_cost_terms(self._h, C.byref(t)))
+
+    def trajectory_cost(self, observations, actions, next_observations=None) -> torch.Tensor:
+        """``trajectory_cost_fn`` (abstract_controller.py:74-91) on the device for rollouts held as tensors:
+        ``observations`` / ``next_observations`` ``[n, h, o]`` (any strides over n and h, entries of a row
+        contiguous -- a transposed view of a step-major ``[h, n, o]`` buffer works), ``actions [n, h, d]``."""
+        n, h, o = observations.shape
+        if h != self.h or observations.dtype != self.dt or observations.stride(2) != 1:
+            raise ValueError("observations must be [n, horizon, o] of the planner dtype with contiguous rows")
+        if next_observations is not None and (next_observations.shape != observations.shape
+                                              or next_observations.stride() != observations.stride()
+                                              or next_observations.dtype != self.dt):
+            raise ValueError("next_observations must match observations in shape, strides and dtype")
+        actions = self._t(actions, (n, self.h, self.d))
+        costs = torch.empty((n,), dtype=self.dt, device=self.device)
+        L.check(self.lib.icem_trajectory_cost(
+            self._h, n, o, _ptr(observations), _ptr(next_observations) if next_observations is not None else None,
+            observations.stride(0), observations.stride(1), _ptr(actions), _ptr(costs), self._stream()))
+        return costs
+
     # ------------------------------------------------------------------ helpers
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

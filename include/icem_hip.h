@@ -89,6 +89,29 @@ typedef struct icem_cost_spec {
     int32_t flip_idx;
 } icem_cost_spec;
 
+/* The remaining parametric cost functions of the reference's environments, as extra terms on top of
+ * icem_cost_spec (all off in a zero-initialised struct with the idx fields at -1 / dist_len at 0):
+ *   + diff_weight * (next_obs[diff_idx] - obs[diff_idx])            Ant, Hopper: -x_velocity = -(x' - x)/dt
+ *                                                                    (environments/mujoco.py:164, 218)
+ *   + health_penalty * unhealthy(obs),  unhealthy = 1 - all_finite(obs) * [lo <(=) obs[health_idx] <(=) hi]
+ *                                                   * [box_lo < obs[k] < box_hi for all k >= box_from]
+ *       Ant :146-149,166 (closed range), Hopper :189-203,221 (open range + healthy_state_range over obs[2:];
+ *       its healthy_angle is dropped by the reference itself, :199), Humanoid :302-315,338 (open range)
+ *   + dist_weight[j] * f(|| obs[dist_a[j] .. +dist_len[j]) - obs[dist_b[j] .. +dist_len[j]) ||),  j = 0, 1
+ *       f = identity, or [. > dist_thresh[j]] when dist_sparse[j]; dist_b[j] < 0: norm of the slice itself
+ *       Reacher :366-368; FetchPickAndPlace / FetchReach environments/robotics.py:150-164, 286-295. */
+typedef struct icem_cost_terms {
+    double diff_weight;
+    double health_penalty, health_lo, health_hi;
+    double box_lo, box_hi;
+    double dist_weight[2], dist_thresh[2];
+    int32_t diff_idx;        /* -1: off */
+    int32_t health_idx;      /* -1: off */
+    int32_t health_closed;   /* 1: lo <= z <= hi, 0: lo < z < hi */
+    int32_t box_from;        /* -1: off */
+    int32_t dist_a[2], dist_b[2], dist_len[2], dist_sparse[2];   /* dist_len 0: off; at most 16 */
+} icem_cost_terms;
+
 typedef struct icem_handle icem_handle;
 
 /* ---- library / handle ------------------------------------------------------------------ */
@@ -116,6 +139,9 @@ int icem_noise_tables_host(int32_t horizon, double beta, double* cr_host, double
  * arrays; they are converted to the handle dtype and copied to the device.  `kind` = ICEM_MODEL_*. */
 int icem_set_model(icem_handle* h, int32_t kind, int32_t obs_dim, const double* A_host, const double* B_host);
 int icem_set_cost(icem_handle* h, const icem_cost_spec* spec);
+/* Extra cost terms (NULL switches them off again).  With any of them on, icem_rollout_cost / icem_plan_* evaluate
+ * the cost in the general rollout kernel (one thread per trajectory, obs_dim <= 32). */
+int icem_set_cost_terms(icem_handle* h, const icem_cost_terms* terms);
 
 /* ---- stateless operators (each replaces one NumPy call site) ------------------------------ */
 
@@ -159,6 +185,15 @@ int icem_rollout_cost(icem_handle* h, int32_t n, const void* obs0, const void* a
 /* trajectory_cost_fn's reduction alone (abstract_controller.py:82-87) for step costs [n, h]
  * produced by an external (e.g. torch) model. */
 int icem_cost_reduce(icem_handle* h, int32_t n, const void* step_costs, void* costs, void* stream);
+
+/* trajectory_cost_fn as a whole (abstract_controller.py:74-91) for rollouts produced by an external model and
+ * held as tensors: costs[i] = reduce_t cost(observations[i, t, :], actions[i, t, :], next_observations[i, t, :])
+ * with the cost set by icem_set_cost (+ icem_set_cost_terms) and the handle's cost_mode.  Any obs_dim.
+ * observations / next_observations: element (i, t, k) at ptr[i*traj_stride + t*step_stride + k] (so [n, h, o] and
+ * step-major [h, n, o] both work); next_observations may be NULL unless diff_idx >= 0.  actions [n, h, d] dense. */
+int icem_trajectory_cost(icem_handle* h, int32_t n, int32_t obs_dim, const void* observations,
+                         const void* next_observations, int64_t traj_stride, int64_t step_stride,
+                         const void* actions, void* costs, void* stream);
 
 /* K3  costs.argsort()[:k] (icem.py:199) and argmin (icem.py:149): the k smallest (cost, index)
  * pairs in ascending order, ties broken by index, NaN treated as +inf.

@@ -478,7 +478,7 @@ class CostSpec:
         return ext
 
 
-def trajectory_costs(cost: CostSpec, observations, actions, next_observations=None, mode="sum", dtype=None):
+def spec_trajectory_costs(cost: CostSpec, observations, actions, next_observations=None, mode="sum", dtype=None):
     """``trajectory_cost_fn`` (abstract_controller.py:74-91) over rollouts held as arrays
     ``observations / next_observations [P,h,o]``, ``actions [P,h,d]``: per-step costs in the kernels'
     order (control cost summed over d in index order, steps reduced in t order)."""

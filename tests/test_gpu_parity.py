@@ -926,3 +926,184 @@ def test_best_trajectory_view_matches_oracle_rollout():
     assert r0["observations"].shape == (30, 17) and r0["actions"].shape == (30, 6)
     ctrl.do_visualize_plan = "last"   # no live-rendering environment here: must be a no-op, like the reference's guard
     ctrl.get_action(obs, None)
+
+
+# ---------------------------------------------------------------------------------------------
+# f-4: the remaining env cost functions as device cost terms
+# ---------------------------------------------------------------------------------------------
+
+def _env_cost_cases():
+    from test_oracle_golden import env_cost_specs
+    return env_cost_specs()
+
+
+def _device_spec(spec):
+    """oracle CostSpec -> the product's CostSpec (same fields)."""
+    from icem_amd.envs import CostSpec
+    import dataclasses
+    return CostSpec(**dataclasses.asdict(spec))
+
+
+@pytest.mark.parametrize("mode", ["sum", "best", "final"])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("tag,spec,has_next", _env_cost_cases(), ids=[t for t, _, _ in _env_cost_cases()])
+def test_trajectory_cost_matches_reference_vectors(tag, spec, has_next, dtype, mode):
+    """icem_trajectory_cost (trajectory_cost_fn on rollouts an external model left on the device) with the Ant, Hopper,
+    Humanoid, Reacher and Fetch cost terms, on the vectors recorded from the reference's cost functions: f64 against the
+    reference's per-step costs reduced over the horizon, f32 against the oracle in f32.  Both memory layouts
+    ([n, h, o] and a transposed view of a step-major [h, n, o] buffer)."""
+    import os
+    from golden_util import GOLDEN
+    from test_oracle_golden import env_cost_inputs
+    from icem_amd import IcemConfig, IcemPlanner
+    z = np.load(os.path.join(GOLDEN, "env_cost_vectors.npz"))
+    obs, act, nxt = env_cost_inputs(z, tag)
+    n, h = 8, 6
+    obs, act = obs.reshape(n, h, -1), act.reshape(n, h, -1)
+    nxt = None if nxt is None else nxt.reshape(n, h, -1)
+    step = z[tag].astype(np.float64).reshape(n, h)
+    d = act.shape[-1]
+    pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=n, elites_size=2, opt_iters=1, cost_mode=mode, dtype=dtype),
+                     -np.ones(d), np.ones(d))
+    pl.set_cost_spec(_device_spec(spec))
+    if dtype == "f64":
+        want = {"sum": step.sum(1), "best": step.min(1), "final": step[:, -1]}[mode]
+        t = dict(rtol=1e-12, atol=1e-12) if z[tag].dtype == np.float64 else dict(rtol=1e-7, atol=1e-7)
+    else:
+        want = O.spec_trajectory_costs(spec, obs, act, nxt, mode=mode, dtype=np.float32).astype(np.float64)
+        t = dict(rtol=1e-6, atol=1e-6)
+        # the f32 run agrees with the reference too, except where an f32-rounded value crosses a threshold
+        ref = {"sum": step.sum(1), "best": step.min(1), "final": step[:, -1]}[mode]
+        assert np.mean(np.abs(want - ref) <= 1e-4 * (1 + np.abs(ref))) > 0.9
+    to = lambda x: torch.as_tensor(x, dtype=pl.dt, device=pl.device)  # noqa: E731
+    o_t, a_t = to(obs), to(act)
+    n_t = None if nxt is None else to(nxt)
+    np.testing.assert_allclose(np_(pl.trajectory_cost(o_t, a_t, n_t)), want, **t)
+    # step-major storage, as the torch-model path of the controller keeps it
+    o_sm = o_t.transpose(0, 1).contiguous().transpose(0, 1)
+    n_sm = None if n_t is None else n_t.transpose(0, 1).contiguous().transpose(0, 1)
+    assert o_sm.stride() == (o_t.shape[2], n * o_t.shape[2], 1)
+    np.testing.assert_allclose(np_(pl.trajectory_cost(o_sm, a_t, n_sm)), want, **t)
+
+
+def test_trajectory_cost_rejects_bad_arguments():
+    from icem_amd import IcemConfig, IcemPlanner, IcemError
+    from icem_amd.envs import ant_env, reacher_env
+    pl = IcemPlanner(IcemConfig(horizon=4, act_dim=8, num_traj=8, elites_size=2, opt_iters=1), -np.ones(8), np.ones(8))
+    pl.set_cost_spec(ant_env().cost_spec)
+    obs = torch.zeros((3, 4, 113), dtype=pl.dt, device=pl.device)
+    act = torch.zeros((3, 4, 8), dtype=pl.dt, device=pl.device)
+    with pytest.raises(IcemError, match="next_observations"):
+        pl.trajectory_cost(obs, act, None)
+    pl.set_cost_spec(reacher_env(11).cost_spec)
+    with pytest.raises(IcemError, match="outside the observation"):
+        pl.trajectory_cost(obs[..., :2].contiguous(), act, None)   # the slice [8, 11) does not exist in o=2
+    assert np_(pl.trajectory_cost(obs[..., :11].contiguous(), act, None)).tolist() == [0.0] * 3
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("env_name", ["hopper", "reacher", "fetch_sparse"])
+def test_rollout_and_plan_with_cost_terms(env_name, dtype):
+    """The built-in model + the extra cost terms (general rollout kernel): icem_rollout_cost against the oracle's
+    rollout, then whole Philox-driven MPC steps against the oracle loop (elite order decided by those costs)."""
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner
+    from icem_amd import envs as E
+    if env_name == "hopper":
+        # healthy range moved to where the synthetic latent lives so that healthy and unhealthy steps both occur
+        env = E.hopper_env(healthy_z_range=(-0.05, float("inf")), healthy_state_range=(-0.45, 0.45))
+        spec = O.CostSpec.hopper(healthy_z_range=(-0.05, float("inf")), healthy_state_range=(-0.45, 0.45))
+    elif env_name == "reacher":
+        env, spec = E.reacher_env(11), O.CostSpec.reacher(11)
+    else:
+        env, spec = E.fetch_reach_env(10, sparse=True, threshold=0.12), O.CostSpec.fetch_reach(10, True, 0.12)
+    o, d = env.obs_dim, env.action_space.shape[0]
+    h, N, iters, seed = 12, 600, 3, 5
+    model = DeviceSyntheticModel.make(o, d, kind=1)
+    pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=N, opt_iters=iters, dtype=dtype, seed=seed),
+                     env.action_space.low, env.action_space.high)
+    pl.set_model(model.kind, model.A, model.B)
+    pl.set_cost_spec(env.cost_spec)
+    pl.reset()
+    npdt = np.float64 if dtype == "f64" else np.float32
+    om = O.SyntheticModel(model.A, model.B, model.kind)
+    rs = np.random.RandomState(3)
+    obs0 = 0.2 * rs.randn(o)
+    acts = rs.uniform(-1, 1, (257, h, d))
+    got = np_(pl.rollout_cost(obs0, torch.as_tensor(acts, dtype=pl.dt, device=pl.device)))
+    want = O.rollout_costs(om, spec, obs0, acts, dtype=npdt).astype(np.float64)
+    if dtype == "f64":
+        np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-12)
+    else:   # an f32 tanh one ulp off can move a step across a threshold: allow a few whole-penalty mismatches
+        close = np.abs(got - want) <= 1e-4 * (1 + np.abs(want))
+        assert close.mean() > 0.98
+    if env_name == "hopper":   # trajectories with no, some and many unhealthy steps are all in the batch
+        import dataclasses
+        count = O.rollout_costs(om, dataclasses.replace(spec, diff_idx=-1, ctrl_weight=0.0, health_penalty=1.0), obs0, acts)
+        assert (count == 0).any() and (count >= h // 2).any() and 0.1 < count.mean() / h < 0.9
+    if dtype == "f32":
+        return
+    noise = O.PhiloxNoiseSchedule(seed, iters, d, h, dtype=npdt)
+    orc = O.IcemOracle(O.IcemParams(horizon=h, num_simulated_trajectories=N, opt_iterations=iters),
+                       env.action_space.low.astype(np.float64), env.action_space.high.astype(np.float64),
+                       lambda ob, ac: O.rollout_costs(om, spec, ob, ac), lambda num: tuple(
+                           zz.astype(np.float64) for zz in noise(num)))
+    orc.beginning_of_rollout()
+    for s in range(2):
+        ob = 0.2 * np.random.RandomState(10 + s).randn(o)
+        if s:
+            noise.begin_step()
+        np.testing.assert_allclose(np_(pl.plan_step(ob)), orc.get_action(ob), rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(np_(pl.mean), orc.mean, rtol=1e-9, atol=1e-11)
+
+
+def test_torch_model_with_env_cost_spec_uses_trajectory_cost():
+    """f-2 + f-4: a torch dynamics model without its own cost callable is scored by the env's parametric cost through
+    icem_trajectory_cost (Ant-shaped: o=113, difference and health terms); checked against the oracle loop."""
+    from icem_amd import MpcICemHip, TorchForwardModel
+    from icem_amd.envs import ant_env
+    torch.manual_seed(1)
+    env = ant_env()
+    o, d, h, N, iters, seed = 113, 8, 10, 256, 3, 31
+
+    class Dyn(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.l = torch.nn.Linear(o + d, o)
+
+        def forward(self, obs, act):
+            return obs + 0.05 * torch.tanh(self.l(torch.cat([obs, act], dim=-1)))
+
+    net = Dyn().double()
+    model = TorchForwardModel(net, None, o, d)
+    ctrl = MpcICemHip(env=env, forward_model=model, horizon=h, num_simulated_trajectories=N, factor_decrease_num=1.25,
+                      cost_along_trajectory="sum", dtype="f64", seed=seed,
+                      action_sampler_params=dict(alpha=0.1, elites_size=10, opt_iterations=iters, init_std=0.5,
+                                                 use_mean_actions=True, keep_previous_elites=True,
+                                                 shift_elites_over_time=True, fraction_elites_reused=0.3, noise_beta=0.25))
+    assert ctrl.torch_path and ctrl.torch_spec_cost
+    W, b = net.l.weight.detach().cpu().numpy(), net.l.bias.detach().cpu().numpy()
+    spec = O.CostSpec.ant()
+
+    def rollout_cost(obs, actions):
+        ob = np.broadcast_to(obs, (actions.shape[0], o)).copy()
+        obs_all, nxt_all = [], []
+        for t in range(h):
+            nx = ob + 0.05 * np.tanh(np.concatenate([ob, actions[:, t]], -1) @ W.T + b)
+            obs_all.append(ob)
+            nxt_all.append(nx)
+            ob = nx
+        return O.spec_trajectory_costs(spec, np.stack(obs_all, 1), actions, np.stack(nxt_all, 1))
+
+    noise = O.PhiloxNoiseSchedule(seed, iters, d, h, dtype=np.float64)
+    orc = O.IcemOracle(O.IcemParams(horizon=h, num_simulated_trajectories=N, opt_iterations=iters),
+                       env.action_space.low.astype(np.float64), env.action_space.high.astype(np.float64), rollout_cost,
+                       lambda num: tuple(zz.astype(np.float64) for zz in noise(num)))
+    orc.beginning_of_rollout()
+    ctrl.beginning_of_rollout(observation=np.zeros(o), state=None, mode="train")
+    rs = np.random.RandomState(4)
+    for s in range(2):
+        ob = 0.3 * rs.randn(o)
+        ob[2] = 0.25 + 0.1 * s     # z close to the lower end of the healthy range: both outcomes occur in the rollouts
+        if s:
+            noise.begin_step()
+        np.testing.assert_allclose(ctrl.get_action(ob, None), orc.get_action(ob), rtol=1e-8, atol=1e-10)
