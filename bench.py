@@ -43,12 +43,12 @@ WORKLOADS = {
 }
 
 
-def make_planner(w, rank, world, seed=1234):
+def make_planner(w, rank, world, seed=1234, cost_mode="sum"):
     from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env, humanoid_standup_env
     env = humanoid_standup_env(w["o"]) if w.get("env") == "humanoid" else halfcheetah_env(w["o"])
     model = DeviceSyntheticModel.make(w["o"], w["d"], kind=w.get("kind", 0))
     cfg = IcemConfig(horizon=w["h"], act_dim=w["d"], num_traj=w["N"] * world, opt_iters=w["iters"],
-                     noise_beta=w["beta"], dtype="f32", seed=seed, rank=rank, world=world)
+                     noise_beta=w["beta"], dtype="f32", seed=seed, rank=rank, world=world, cost_mode=cost_mode)
     pl = IcemPlanner(cfg, env.action_space.low, env.action_space.high, device=f"cuda:{torch.cuda.current_device()}")
     pl.set_model(model.kind, model.A, model.B)
     c = env.cost_spec
@@ -174,6 +174,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS), help="c2 = the metric's configuration (default)")
+    ap.add_argument("--cost-mode", default="sum", choices=["sum", "best", "final"],
+                    help="cost_along_trajectory (abstract_controller.py:82-87); the metric is quoted on 'sum'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra large-population (c4) measurement")
     args = ap.parse_args()
@@ -197,7 +199,7 @@ def main():
         dist.barrier()
 
     w = WORKLOADS[args.workload]
-    pl, model, env = make_planner(w, rank, world)
+    pl, model, env = make_planner(w, rank, world, cost_mode=args.cost_mode)
     per_step_trajsteps = sum(pl.population_sizes) * w["h"]  # global (all ranks) traj-steps per MPC step
 
     def sync():
@@ -234,7 +236,7 @@ def main():
             "config": {"workload": w["name"], "per_gpu_population": w["N"], "global_population": w["N"] * world,
                        "traj_per_mpc_step": sum(pl.population_sizes),
                        "model": "o' = tanh(o.A + a.B) dense (synthetic)" if model.kind == 1 else "o' = o.A + a.B dense linear (synthetic)",
-                       "cost": "HumanoidStandup cost_fn" if w.get("env") == "humanoid" else "HalfCheetah cost_fn", "rng": "Philox4x32-10-seeded xoshiro128++ + Box-Muller", "parallelism": f"n-shard x{world}"},
+                       "cost": "HumanoidStandup cost_fn" if w.get("env") == "humanoid" else "HalfCheetah cost_fn", "cost_along_trajectory": args.cost_mode, "rng": "Philox4x32-10-seeded xoshiro128++ + Box-Muller", "parallelism": f"n-shard x{world}"},
             "ms_per_mpc_step": 1e3 * elapsed / args.steps,
             "roofline": roofline,
             "kernels_us": {k: round(1e3 * v[0] / v[1], 2) for k, v in prof.items()},
@@ -243,7 +245,7 @@ def main():
         # while after its last parallel region and would slow down kernel launches
         if world == 1 and args.workload == "c2" and not args.no_also:
             out["also"] = measure_also("c4")
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.cost_mode == "sum":   # the C oracle's loop reduces by sum
             out["cpu_baseline"] = cpu_baseline(w, model, env)
         else:
             out["cpu_baseline"] = None
