@@ -186,11 +186,14 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    local_rank %= max(1, torch.cuda.device_count())   # more ranks than GPUs only in a debugging run
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        backend = os.environ.get("ICEM_BENCH_BACKEND", "nccl")   # "gloo": debugging runs with ranks sharing a GPU
+        dist.init_process_group(backend, rank=rank, world_size=world,
+                                **({"device_id": torch.device(f"cuda:{local_rank}")} if backend == "nccl" else {}))
 
     import __graft_entry__ as ge
     if rank == 0:
