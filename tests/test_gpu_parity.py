@@ -1107,3 +1107,31 @@ def test_torch_model_with_env_cost_spec_uses_trajectory_cost():
         if s:
             noise.begin_step()
         np.testing.assert_allclose(ctrl.get_action(ob, None), orc.get_action(ob), rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("N", [4096, 300])
+def test_nan_costs_rank_last_with_index_tie_break(N, dtype):
+    """A NaN in the start observation makes every cost NaN: the loop must not hang, NaN ranks as +inf and ties
+    break by index (icem_topk_sorted's contract, the same on the fast f32 path, the general path and the oracle's
+    topk_sorted) -- so the elites are trajectories 0..K-1 of the last pool and the distribution stays finite."""
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env
+    env = halfcheetah_env(17)
+    model = DeviceSyntheticModel.make(17, 6, kind=0)
+    pl = IcemPlanner(IcemConfig(horizon=30, act_dim=6, num_traj=N, opt_iters=3, dtype=dtype, seed=1,
+                                keep_previous_elites=False, shift_elites=False), env.action_space.low, env.action_space.high)
+    pl.set_model(model.kind, model.A, model.B)
+    pl.set_cost_spec(env.cost_spec)
+    pl.reset()
+    ob = 0.1 * np.random.RandomState(0).randn(17)
+    ob[8] = np.nan
+    executed = np_(pl.plan_step(ob))
+    torch.cuda.synchronize()
+    K = pl.K
+    assert np.isinf(np_(pl.best_cost)).all() and np.isfinite(np_(pl.mean)).all() and np.isfinite(np_(pl.std)).all()
+    last_pool = pl.population_sizes[-1]
+    elite_actions, elite_costs = pl.current_elites()
+    assert np.isinf(np_(elite_costs)).all()
+    assert np.array_equal(np_(elite_actions), np_(pl.actions[:K])) and last_pool >= K
+    assert np.array_equal(executed, np_(pl.actions[0, 0]))
+    assert O.topk_sorted(np.full(last_pool, np.nan), K).tolist() == list(range(K))
