@@ -1115,6 +1115,64 @@ __global__ __launch_bounds__(SWG + 64) void sample_folded_merge_kernel(FastSampl
 // the host / the next launch.  That removes the merge launch and hides its latency behind the sampling.  The
 // previous pool, lists and distribution are read while this launch writes new ones: all three are ping-pong
 // buffers (icem_plan_step).
+// The three kinds of rows of a single-launch slab.  RAW: the
+// distribution is still being computed -- park the raw colored samples (merge prologue, sampled rows only).
+template <int H, int D, int ROUNDS, bool RAW>
+__device__ __forceinline__ void sample_into_tile(const FastSampleArgs& sa, int n_rows, int r_mine, int jd, float* trow,
+                                                 const float* mrow) {
+    constexpr int HD = H * D;
+    if (r_mine < sa.n) {
+        if (RAW) {
+            sample_row<H, ROUNDS>(sa.W, (unsigned)(sa.first_index + r_mine), (unsigned)jd, sa.off_lo, sa.off_hi,
+                                  sa.seed_lo, sa.seed_hi, [&](int t, float y) { trow[t * D] = y; }, sa.white != 0);
+        } else {
+            const float lo = sa.low[jd], hi = sa.high[jd];
+            sample_row<H, ROUNDS>(sa.W, (unsigned)(sa.first_index + r_mine), (unsigned)jd, sa.off_lo, sa.off_hi,
+                                  sa.seed_lo, sa.seed_hi, [&](int t, float y) {
+                                      const float v = __builtin_fmaf(y, mrow[HD + t * D], mrow[t * D]);
+                                      trow[t * D] = __builtin_amdgcn_fmed3f(v, lo, hi);
+                                  }, sa.white != 0);
+        }
+    } else if (r_mine < n_rows && !RAW) {
+        // shifted elite e: elites[e, 1:, j] and a last action drawn from the full (n_shift, d, h) noise batch
+        // of stream off2 (only t = h-1 is used, icem.py:102); iteration 0 only, which has no merge prologue
+        const int e = r_mine - sa.n;
+        const float lo = sa.low[jd], hi = sa.high[jd];
+        float last = 0.f;
+        sample_row<H, ROUNDS>(sa.W, (unsigned)e, (unsigned)jd, sa.off2_lo, sa.off2_hi, sa.seed_lo, sa.seed_hi,
+                              [&](int t, float y) {
+                                  if (t == H - 1) {
+                                      const float v = __builtin_fmaf(y, mrow[HD + t * D], mrow[t * D]);
+                                      last = __builtin_amdgcn_fmed3f(v, lo, hi);
+                                  }
+                              }, sa.white != 0);
+        const float* src = sa.elites_src + (size_t)e * HD + jd;
+        for (int t = 0; t < H - 1; ++t) trow[t * D] = src[(t + 1) * D];
+        trow[(H - 1) * D] = last;
+    } else {
+        for (int t = 0; t < H; ++t) trow[t * D] = 0.f;  // past the end: rolled out, dropped
+    }
+}
+
+// One wave rolls its 16 trajectories of the slab out of the LDS tile, stores the costs and folds them into its
+// running candidate list.
+template <typename Tile, int H, int D>
+__device__ __forceinline__ unsigned long long rollout_slab(Tile& tile, const FastRolloutArgs& ra, const float* rd0, int row,
+                                                           int n_rows, unsigned long long run_key, bool first, int lane) {
+    const bool live = row < n_rows;
+    typename Tile::State st;
+    tile.init(st);
+#pragma unroll
+    for (int t = 0; t < H; ++t) tile.step(st, rd0 + t * D);
+    const float cost = tile.cost(st);
+    if (live && lane < 16) ra.costs[row] = cost;
+    if (ra.K > 0) {
+        const unsigned long long key = (lane < 16 && live && row < ra.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
+        run_key = topk_push16(run_key, key, first, ra.K, lane);
+    }
+    return run_key;
+}
+
 template <int H, int D, int O, int KIND, int ROUNDS, int RW, int KREG, bool REC>
 __global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64 + (KREG > 0 ? 64 : 0)) void sample_rollout_kernel(FastIterArgs a) {
     using Tile = Tile16<H, D, O, KIND>;
@@ -1163,43 +1221,13 @@ __global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64 + (KREG > 0 ? 64 : 0
     }
     if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[9] = wall_clock64();
     const int r_mine = base + nl;
-    if (has_row) {
-        if (r_mine < sa.n) {
-            if (PM) {  // mean / std are still being computed: park the raw colored samples
-                sample_row<H, ROUNDS>(sa.W, (unsigned)(sa.first_index + r_mine), (unsigned)jd, sa.off_lo, sa.off_hi,
-                                      sa.seed_lo, sa.seed_hi, [&](int t, float y) { trow[t * D] = y; }, sa.white != 0);
-            } else {
-                const float lo = sa.low[jd], hi = sa.high[jd];
-                sample_row<H, ROUNDS>(sa.W, (unsigned)(sa.first_index + r_mine), (unsigned)jd, sa.off_lo, sa.off_hi,
-                                      sa.seed_lo, sa.seed_hi, [&](int t, float y) {
-                                          const float v = __builtin_fmaf(y, mrow[HD + t * D], mrow[t * D]);
-                                          trow[t * D] = __builtin_amdgcn_fmed3f(v, lo, hi);
-                                      }, sa.white != 0);
-            }
-        } else if (r_mine < n_rows && !PM) {
-            // shifted elite e: elites[e, 1:, j] and a last action drawn from the full (n_shift, d, h) noise batch
-            // of stream off2 (only t = h-1 is used, icem.py:102); iteration 0 only, which has no merge prologue
-            const int e = r_mine - sa.n;
-            const float lo = sa.low[jd], hi = sa.high[jd];
-            float last = 0.f;
-            sample_row<H, ROUNDS>(sa.W, (unsigned)e, (unsigned)jd, sa.off2_lo, sa.off2_hi, sa.seed_lo, sa.seed_hi,
-                                  [&](int t, float y) {
-                                      if (t == H - 1) {
-                                          const float v = __builtin_fmaf(y, mrow[HD + t * D], mrow[t * D]);
-                                          last = __builtin_amdgcn_fmed3f(v, lo, hi);
-                                      }
-                                  }, sa.white != 0);
-            const float* src = sa.elites_src + (size_t)e * HD + jd;
-            for (int t = 0; t < H - 1; ++t) trow[t * D] = src[(t + 1) * D];
-            trow[(H - 1) * D] = last;
-        } else {
-            for (int t = 0; t < H; ++t) trow[t * D] = 0.f;  // past the end: rolled out, dropped
-        }
-    }
+    if (has_row) sample_into_tile<H, D, ROUNDS, PM>(sa, n_rows, r_mine, jd, trow, mrow);
     if constexpr (PM) {
         if (tid >= NT) {
             if constexpr (REC)
                 merge_select_records(a.m, lane, cand, sel, slot);
+            else if constexpr (RW >= 8)  // 13 waves share the register file: the low-register selection
+                merge_select_stream(a.m, lane, cand, sel);
             else
                 merge_select<KREG>(a.m, lane, cand, sel);
         }
@@ -1262,19 +1290,8 @@ __global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64 + (KREG > 0 ? 64 : 0
     unsigned long long run_key = KEY_SENTINEL;
     if (wave < RW) {
         tile.load_obs(obs_stage);
-        const int row = base + wave * 16 + (lane & 15);
-        const bool live = row < n_rows;
-        typename Tile::State st;
-        tile.init(st);
-#pragma unroll
-        for (int t = 0; t < H; ++t) tile.step(st, rd0 + t * D);
-        const float cost = tile.cost(st);
+        run_key = rollout_slab<Tile, H, D>(tile, ra, rd0, base + wave * 16 + (lane & 15), n_rows, run_key, true, lane);
         if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[12] = wall_clock64();
-        if (live && lane < 16) ra.costs[row] = cost;
-        if (ra.K > 0) {
-            const unsigned long long key = (lane < 16 && live && row < ra.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
-            run_key = topk_push16(run_key, key, true, ra.K, lane);
-        }
     }
     if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[13] = wall_clock64();
     if (ra.K > 0) wg_merge_emit<RW>(wg_keys, run_key, ra.K, lane, wave, ra);
@@ -1344,9 +1361,12 @@ void launch_rollout16(const FastRolloutArgs& a, int h, int d, int O, int kind, h
 #undef XW
 }
 
-// single-launch iteration: compiled for the default generator (10 Philox rounds) and up to 8 rollout waves per
-// workgroup.  sample_rollout_lists: workgroups (= candidate lists) of the launch, 0 when the shape or size is
-// outside that (use the two-kernel path).
+// single-launch iteration: compiled for the default generator (10 Philox rounds) and 1, 2, 4 or 8 rollout waves per
+// workgroup, one slab of 16 * rw trajectories each, at most FAST_MAX_LISTS workgroups (= candidate lists).
+// sample_rollout_lists: workgroups of the launch, 0 when the shape or size is outside that (use the two-kernel
+// path).  (Several slabs per workgroup through the same LDS tile were tried for larger populations: with one
+// 92 KB tile per CU the sampling and rollout phases of a workgroup run back to back at 2-3 waves per SIMD, and
+// N=65 536 took 297 instead of 220 us per MPC step -- the two full-occupancy kernels win there.)
 static bool sample_rollout_shape(int h, int d, int O, int rounds, int n_rows, int* grid_out, int* rw_out) {
     static const int max_rw = [] { const char* e = getenv("ICEM_FUSE_MAX_RW"); return e ? atoi(e) : 8; }();
     int grid, rw;
@@ -1364,11 +1384,12 @@ int sample_rollout_lists(int h, int d, int O, int rounds, int n_rows) {
     return sample_rollout_shape(h, d, O, rounds, n_rows, &grid, &rw) ? grid : 0;
 }
 
-// merge prologue: selection wavefront + sampling waves must fit the register budget -> up to 4 rollout waves
+// merge prologue: the selection wavefront joins the sampling waves (8 rollout waves: 13 waves share the register
+// file, the selection runs in its low-register form)
 bool sample_rollout_merge_ok(int h, int d, int O, int rounds, int n_rows, int K) {
     static const int on = [] { const char* e = getenv("ICEM_MERGE_PROLOGUE"); return e ? atoi(e) : 1; }();
     int grid, rw;
-    return on && K + 1 <= 12 && sample_rollout_shape(h, d, O, rounds, n_rows, &grid, &rw) && rw <= 4;
+    return on && K + 1 <= 12 && sample_rollout_shape(h, d, O, rounds, n_rows, &grid, &rw);
 }
 
 void launch_sample_rollout(const FastIterArgs& a, int h, int d, int O, int kind, bool merge_prologue, hipStream_t st) {
@@ -1386,10 +1407,8 @@ void launch_sample_rollout(const FastIterArgs& a, int h, int d, int O, int kind,
 #define XW(HH, DD, OO, WW)                                                   \
     if constexpr (WW <= single_launch_max_rw(HH, DD)) {                      \
         if (rw == WW) {                                                      \
-            if constexpr (WW <= 4) {                                         \
-                if (merge_prologue && a.m.records) XK(HH, DD, OO, WW, 12, true)  \
-                if (merge_prologue) XK(HH, DD, OO, WW, 12, false)            \
-            }                                                                \
+            if (merge_prologue && a.m.records) XK(HH, DD, OO, WW, 12, true)  \
+            if (merge_prologue) XK(HH, DD, OO, WW, 12, false)                \
             XK(HH, DD, OO, WW, 0, false)                                     \
         }                                                                    \
     }
