@@ -116,18 +116,20 @@ KERNEL_FAMILY = {"sample_clip": ("sample_folded_kernel", "sample_folded_merge_ke
 def measured_traffic(kernel_class, workload):
     """HBM bytes per launch of that kernel class from the committed rocprofv3 PMC passes over this same command
     (profiles/rNN_<workload>_hbm_traffic.json, written by tools/summarize_profile.py: separate --pmc FETCH_SIZE /
-    WRITE_SIZE runs, reads with the gfx950 x2 correction).  None if no such profile is in the tree."""
+    WRITE_SIZE runs, reads with the gfx950 x2 correction), and the average duration the kernel trace of that
+    command shows for it.  None if no such profile is in the tree."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_hbm_traffic.json")))
     if not files:
-        return None, None
+        return None, None, None
     tab = json.load(open(files[-1]))
-    tot, n = 0.0, 0
+    tot, n, dur = 0.0, 0, 0.0
     for name in KERNEL_FAMILY.get(kernel_class, ()):
         if name in tab:
             tot += (tab[name]["read_bytes_per_launch"] + tab[name]["write_bytes_per_launch"]) * tab[name]["launches"]
+            dur += (tab[name].get("trace_avg_duration_ns") or 0.0) * tab[name]["launches"]
             n += tab[name]["launches"]
-    return (tot / n, os.path.relpath(files[-1], ROOT)) if n else (None, None)
+    return (tot / n, os.path.relpath(files[-1], ROOT), dur / n * 1e-3 or None) if n else (None, None, None)
 
 
 def roofline_of(prof, w, workload=None):
@@ -137,9 +139,12 @@ def roofline_of(prof, w, workload=None):
     if bpu is None or ms <= 0:
         return None
     achieved = units * bpu / (ms * 1e-3) / 1e9
-    traffic, src = measured_traffic(dom, workload) if workload else (None, None)
+    traffic, src, trace_us = measured_traffic(dom, workload) if workload else (None, None, None)
+    # avg_launch_us: HIP events around every launch on the launch stream (kernel + its dispatch, ~2.5 us more than the
+    # kernel alone); rocprof_trace_avg_us: the committed kernel trace's figure for the same kernels, for comparison
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_source": src, "kernel": dom, "avg_launch_us": 1e3 * ms / launches, "launches": launches,
+            "traffic": traffic, "traffic_source": src, "kernel": dom, "avg_launch_us": 1e3 * ms / launches,
+            "rocprof_trace_avg_us": trace_us, "launches": launches,
             "algorithmic_bytes_per_launch": units * bpu / launches, "bytes_per_traj_step": bpu}
 
 

@@ -49,6 +49,14 @@ for k in set(fetch) | set(write):
     fam[name][0] += 2 * fv * 1024 / max(fn, 1) * n
     fam[name][1] += wv * 1024 / max(wn, 1) * n
     fam[name][2] += n
-json.dump({name: {"read_bytes_per_launch": v[0] / v[2], "write_bytes_per_launch": v[1] / v[2], "launches": v[2]}
+# ... and its average duration in the kernel trace (calls-weighted over the template instances of the family)
+dur = defaultdict(lambda: [0.0, 0])
+for row in csv.DictReader(open(dst + "_kernel_stats.csv")):
+    nm = row["Name"].replace("void ", "").replace("(anonymous namespace)::", "").replace("icem::", "")
+    name = nm.split("<")[0].split("(")[0]
+    dur[name][0] += float(row["AverageNs"]) * int(row["Calls"])
+    dur[name][1] += int(row["Calls"])
+json.dump({name: {"read_bytes_per_launch": v[0] / v[2], "write_bytes_per_launch": v[1] / v[2], "launches": v[2],
+                  "trace_avg_duration_ns": (dur[name][0] / dur[name][1]) if dur[name][1] else None}
            for name, v in fam.items() if v[2]}, open(dst + "_hbm_traffic.json", "w"), indent=1)
 print(open(dst + "_hbm_traffic.md").read())
