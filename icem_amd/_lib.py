@@ -42,14 +42,22 @@ class IcemCostSpecC(C.Structure):
                 ("flip_thresh", C.c_double), ("lin_idx", C.c_int32), ("flip_idx", C.c_int32)]
 
 
+MAX_COST_TERMS = 8
+TERM_NORM, TERM_NORM_GT, TERM_NORM_LT, TERM_SQ_OFFSET, TERM_SUMSQ, TERM_STEP_GT = range(6)
+
+
+class IcemCostTermC(C.Structure):
+    """include/icem_hip.h: struct icem_cost_term."""
+    _fields_ = [("weight", C.c_double), ("thresh", C.c_double), ("gate_thresh", C.c_double), ("kind", C.c_int32),
+                ("a", C.c_int32), ("b", C.c_int32), ("len", C.c_int32), ("gate_idx", C.c_int32), ("reserved", C.c_int32)]
+
+
 class IcemCostTermsC(C.Structure):
     """include/icem_hip.h: struct icem_cost_terms."""
     _fields_ = [("diff_weight", C.c_double), ("health_penalty", C.c_double), ("health_lo", C.c_double),
                 ("health_hi", C.c_double), ("box_lo", C.c_double), ("box_hi", C.c_double),
-                ("dist_weight", C.c_double * 2), ("dist_thresh", C.c_double * 2),
                 ("diff_idx", C.c_int32), ("health_idx", C.c_int32), ("health_closed", C.c_int32), ("box_from", C.c_int32),
-                ("dist_a", C.c_int32 * 2), ("dist_b", C.c_int32 * 2), ("dist_len", C.c_int32 * 2),
-                ("dist_sparse", C.c_int32 * 2)]
+                ("n_terms", C.c_int32), ("reserved", C.c_int32), ("terms", IcemCostTermC * MAX_COST_TERMS)]
 
 
 class IcemPlanBuffersC(C.Structure):

@@ -244,8 +244,12 @@ struct CostArgs {
     T ctrl_w, lin_w, flip_pen, flip_th;
     int lin_idx, flip_idx;
     // icem_cost_terms (include/icem_hip.h); ext = any of them on
-    T diff_w, health_pen, health_lo, health_hi, box_lo, box_hi, dist_w[2], dist_th[2];
-    int ext, diff_idx, health_idx, health_closed, box_from, dist_a[2], dist_b[2], dist_len[2], dist_sparse[2];
+    T diff_w, health_pen, health_lo, health_hi, box_lo, box_hi;
+    int ext, diff_idx, health_idx, health_closed, box_from, n_terms;
+    struct Term {
+        T w, th, gate_th;
+        int kind, a, b, len, gate_idx;
+    } terms[ICEM_MAX_COST_TERMS];
 };
 
 __device__ __forceinline__ bool finite_val(float x) { return fabsf(x) <= FLT_MAX; }    // false for NaN / inf
@@ -264,17 +268,33 @@ __device__ __forceinline__ T cost_terms(const CostArgs<T>& cs, bool bad, Obs obs
         const bool in = cs.health_closed ? (cs.health_lo <= z && z <= cs.health_hi) : (cs.health_lo < z && z < cs.health_hi);
         c += (in && !bad) ? (T)0 : cs.health_pen;
     }
-    for (int j = 0; j < 2; ++j) {
-        if (cs.dist_len[j] <= 0) continue;
-        T acc = (T)0;
-        for (int m = 0; m < cs.dist_len[j]; ++m) {
-            T v = obs(cs.dist_a[j] + m);
-            if (cs.dist_b[j] >= 0) v -= obs(cs.dist_b[j] + m);
-            acc = fmad(v, v, acc);
+    // static term indices: a runtime index into the by-value argument block would move it to scratch
+#pragma unroll
+    for (int j = 0; j < ICEM_MAX_COST_TERMS; ++j) {
+        if (j >= cs.n_terms) break;
+        const typename CostArgs<T>::Term& tm = cs.terms[j];
+        if (tm.gate_idx >= 0 && !(obs(tm.gate_idx) > tm.gate_th)) continue;
+        T f;
+        if (tm.kind == ICEM_TERM_STEP_GT) {
+            f = obs(tm.a) > tm.th ? (T)1 : (T)0;
+        } else if (tm.kind == ICEM_TERM_SQ_OFFSET) {
+            const T v = obs(tm.a) - tm.th;
+            f = v * v;
+        } else {
+            T acc = (T)0;
+            for (int m = 0; m < tm.len; ++m) {
+                T v = obs(tm.a + m);
+                if (tm.b >= 0) v -= obs(tm.b + m);
+                acc = fmad(v, v, acc);
+            }
+            if (tm.kind == ICEM_TERM_SUMSQ) {
+                f = acc;
+            } else {
+                const T r = sqrt_val(acc);
+                f = tm.kind == ICEM_TERM_NORM ? r : tm.kind == ICEM_TERM_NORM_GT ? (r > tm.th ? (T)1 : (T)0) : (r < tm.th ? (T)1 : (T)0);
+            }
         }
-        T r = sqrt_val(acc);
-        if (cs.dist_sparse[j]) r = r > cs.dist_th[j] ? (T)1 : (T)0;
-        c += cs.dist_w[j] * r;
+        c += tm.w * f;
     }
     return c;
 }
@@ -335,7 +355,7 @@ __global__ __launch_bounds__(WG) void rollout_cost_kernel(RolloutArgs<T> a) {
             c += (ang < -a.cs.flip_th) ? a.cs.flip_pen : (T)0;
         }
         c += a.cs.ctrl_w * ctrl;
-        c += a.cs.lin_w * lin;
+        if (a.cs.lin_w != (T)0) c += a.cs.lin_w * lin;
         if (a.cs.ext) {
             bool bad = false;
 #pragma unroll
@@ -459,7 +479,7 @@ __global__ __launch_bounds__(WG) void trajectory_cost_kernel(TrajCostArgs<T> a) 
             c += (ang < -a.cs.flip_th) ? a.cs.flip_pen : (T)0;
         }
         c += a.cs.ctrl_w * ctrl;
-        c += a.cs.lin_w * row[a.cs.lin_idx];
+        if (a.cs.lin_w != (T)0) c += a.cs.lin_w * row[a.cs.lin_idx];
         if (a.cs.ext) {
             const T* __restrict__ nrow = a.nxt ? a.nxt + (long long)n * a.ts + (long long)t * a.ss : row;
             bool bad = (bad_steps >> t) & 1ull;
@@ -1030,13 +1050,17 @@ void fill_cost_args(const icem_handle* h, CostArgs<T>& cs) {
     cs.health_idx = h->has_terms ? t.health_idx : -1;
     cs.health_closed = t.health_closed;
     cs.box_from = (h->has_terms && t.health_idx >= 0) ? t.box_from : -1;
-    for (int j = 0; j < 2; ++j) {
-        cs.dist_w[j] = (T)t.dist_weight[j];
-        cs.dist_th[j] = (T)t.dist_thresh[j];
-        cs.dist_a[j] = t.dist_a[j];
-        cs.dist_b[j] = t.dist_b[j];
-        cs.dist_len[j] = h->has_terms ? t.dist_len[j] : 0;
-        cs.dist_sparse[j] = t.dist_sparse[j];
+    cs.n_terms = h->has_terms ? t.n_terms : 0;
+    for (int j = 0; j < ICEM_MAX_COST_TERMS; ++j) {
+        const icem_cost_term& tm = t.terms[j];
+        cs.terms[j].w = (T)tm.weight;
+        cs.terms[j].th = (T)tm.thresh;
+        cs.terms[j].gate_th = (T)tm.gate_thresh;
+        cs.terms[j].kind = tm.kind;
+        cs.terms[j].a = tm.a;
+        cs.terms[j].b = tm.b;
+        cs.terms[j].len = tm.len;
+        cs.terms[j].gate_idx = tm.gate_idx;
     }
 }
 
@@ -1046,10 +1070,10 @@ const char* cost_indices_error(const icem_handle* h, int o) {
     if (!h->has_terms) return nullptr;
     const icem_cost_terms& t = h->terms;
     if (t.diff_idx >= o || t.health_idx >= o || t.box_from >= o) return "cost term index outside the observation";
-    for (int j = 0; j < 2; ++j) {
-        if (t.dist_len[j] <= 0) continue;
-        if (t.dist_a[j] < 0 || t.dist_a[j] + t.dist_len[j] > o || (t.dist_b[j] >= 0 && t.dist_b[j] + t.dist_len[j] > o))
-            return "distance term slice outside the observation";
+    for (int j = 0; j < t.n_terms; ++j) {
+        const icem_cost_term& tm = t.terms[j];
+        if (tm.a < 0 || tm.a + tm.len > o || (tm.b >= 0 && tm.b + tm.len > o) || tm.gate_idx >= o)
+            return "cost term slice outside the observation";
     }
     return nullptr;
 }
@@ -1165,6 +1189,7 @@ int ensure_fast_model(icem_handle* h) {
 
 bool fast_rollout_ok(const icem_handle* h, int K) {
     if (h->has_terms) return false;  // the extra cost terms live in the general kernel
+    if (h->cost.lin_weight == 0.0) return false;  // ... and so does a cost without the linear term (dropped, not 0 * obs)
     return h->use_fast && h->cfg.dtype == ICEM_F32 && h->has_model && h->has_cost &&
            fast_rollout_supported(h->cfg.horizon, h->cfg.act_dim, h->O, K);
 }
@@ -1717,12 +1742,16 @@ int icem_set_cost_terms(icem_handle* h, const icem_cost_terms* terms) {
         h->has_terms = false;
         return ICEM_OK;
     }
-    for (int j = 0; j < 2; ++j)
-        if (terms->dist_len[j] < 0 || terms->dist_len[j] > 16) return fail(ICEM_E_INVALID, "dist_len must be in [0, 16]");
+    if (terms->n_terms < 0 || terms->n_terms > ICEM_MAX_COST_TERMS) return fail(ICEM_E_INVALID, "n_terms must be in [0, 8]");
+    for (int j = 0; j < terms->n_terms; ++j) {
+        const icem_cost_term& tm = terms->terms[j];
+        if (tm.kind < ICEM_TERM_NORM || tm.kind > ICEM_TERM_STEP_GT) return fail(ICEM_E_INVALID, "unknown cost term kind");
+        if (tm.len < 1 || tm.len > ICEM_MAX_TERM_LEN) return fail(ICEM_E_INVALID, "cost term len must be in [1, 64]");
+    }
     if (terms->box_from >= 0 && terms->health_idx < 0)
         return fail(ICEM_E_INVALID, "box_from is part of the health term: health_idx must be set");
     h->terms = *terms;
-    h->has_terms = terms->diff_idx >= 0 || terms->health_idx >= 0 || terms->dist_len[0] > 0 || terms->dist_len[1] > 0;
+    h->has_terms = terms->diff_idx >= 0 || terms->health_idx >= 0 || terms->n_terms > 0;
     return ICEM_OK;
 }
 

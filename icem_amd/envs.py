@@ -31,11 +31,29 @@ class Discrete:
         self.n = n
 
 
+TERM_NORM, TERM_NORM_GT, TERM_NORM_LT, TERM_SQ_OFFSET, TERM_SUMSQ, TERM_STEP_GT = range(6)
+
+
+@dataclass(frozen=True)
+class CostTerm:
+    """One ``icem_cost_term``: ``weight * [obs[gate_idx] > gate_thresh] * f`` with ``r = ||obs[a:a+len] - obs[b:b+len]||``
+    (``b < 0``: the slice itself) and ``f`` = ``r`` (NORM), ``[r > thresh]`` (NORM_GT), ``[r < thresh]`` (NORM_LT),
+    ``(obs[a] - thresh)^2`` (SQ_OFFSET), ``sum obs[a:a+len]^2`` (SUMSQ), ``[obs[a] > thresh]`` (STEP_GT)."""
+    kind: int
+    a: int
+    b: int = -1
+    len: int = 1
+    weight: float = 1.0
+    thresh: float = 0.0
+    gate_idx: int = -1
+    gate_thresh: float = 0.0
+
+
 @dataclass
 class CostSpec:
     """The parametric cost the device evaluates (``icem_cost_spec`` + ``icem_cost_terms``, include/icem_hip.h):
     ``flip penalties + ctrl_weight*sum(a^2) + lin_weight*obs[lin_idx] + diff_weight*(next_obs[diff_idx] - obs[diff_idx])
-    + health_penalty*unhealthy(obs) + sum_j dist_weight[j]*f_j(||obs[a_j:a_j+len_j] - obs[b_j:b_j+len_j]||)``."""
+    + health_penalty*unhealthy(obs) + sum of the terms``."""
     ctrl_weight: float = 0.1
     lin_idx: int = 8
     lin_weight: float = -1.0
@@ -52,16 +70,11 @@ class CostSpec:
     box_from: int = -1
     box_lo: float = -100.0
     box_hi: float = 100.0
-    dist_a: tuple = (0, 0)
-    dist_b: tuple = (-1, -1)
-    dist_len: tuple = (0, 0)
-    dist_sparse: tuple = (False, False)
-    dist_weight: tuple = (0.0, 0.0)
-    dist_thresh: tuple = (0.0, 0.0)
+    terms: tuple = ()
 
     @property
     def extended(self) -> bool:
-        return self.diff_idx >= 0 or self.health_idx >= 0 or any(n > 0 for n in self.dist_len)
+        return self.diff_idx >= 0 or self.health_idx >= 0 or len(self.terms) > 0
 
 
 class SyntheticEnv:
@@ -94,20 +107,30 @@ class SyntheticEnv:
             scores = scores + (ang > c.flip_thresh) * c.flip_penalty
             scores = scores + (ang < -c.flip_thresh) * c.flip_penalty
         scores = scores + c.ctrl_weight * np.sum(action ** 2, axis=-1)
-        scores = scores + c.lin_weight * observation[..., c.lin_idx]
+        if c.lin_weight != 0:
+            scores = scores + c.lin_weight * observation[..., c.lin_idx]
         if c.diff_idx >= 0:
             scores = scores + c.diff_weight * (np.asarray(next_obs)[..., c.diff_idx] - observation[..., c.diff_idx])
         if c.health_idx >= 0:
             scores = scores + c.health_penalty * self.unhealthy_states(observation)
-        for j in range(2):
-            if c.dist_len[j] > 0:
-                v = observation[..., c.dist_a[j]:c.dist_a[j] + c.dist_len[j]]
-                if c.dist_b[j] >= 0:
-                    v = v - observation[..., c.dist_b[j]:c.dist_b[j] + c.dist_len[j]]
-                r = np.linalg.norm(v, axis=-1)
-                if c.dist_sparse[j]:
-                    r = np.asarray(r > c.dist_thresh[j], dtype=np.float64)
-                scores = scores + c.dist_weight[j] * r
+        for tm in c.terms:
+            if tm.kind == TERM_STEP_GT:
+                f = np.asarray(observation[..., tm.a] > tm.thresh, dtype=np.float64)
+            elif tm.kind == TERM_SQ_OFFSET:
+                f = (observation[..., tm.a] - tm.thresh) ** 2
+            else:
+                v = observation[..., tm.a:tm.a + tm.len]
+                if tm.b >= 0:
+                    v = v - observation[..., tm.b:tm.b + tm.len]
+                if tm.kind == TERM_SUMSQ:
+                    f = np.sum(v ** 2, axis=-1)
+                else:
+                    r = np.linalg.norm(v, axis=-1)
+                    f = r if tm.kind == TERM_NORM else np.asarray(r > tm.thresh if tm.kind == TERM_NORM_GT else r < tm.thresh,
+                                                                  dtype=np.float64)
+            if tm.gate_idx >= 0:
+                f = f * (observation[..., tm.gate_idx] > tm.gate_thresh)
+            scores = scores + tm.weight * f
         return scores
 
     def reward_fn(self, observation, action, next_obs=None):
@@ -166,7 +189,7 @@ def humanoid_env(obs_dim: int = 376, nq: int = 24, exclude_current_positions: bo
 
 def reacher_env(obs_dim: int = 11) -> SyntheticEnv:
     """Reacher shapes (d=2): ``||obs[-3:]||`` (icem/environments/mujoco.py:366-368)."""
-    spec = CostSpec(0.0, 0, 0.0, -1, 0.0, 0.0, dist_a=(obs_dim - 3, 0), dist_len=(3, 0), dist_weight=(1.0, 0.0))
+    spec = CostSpec(0.0, 0, 0.0, -1, 0.0, 0.0, terms=(CostTerm(TERM_NORM, obs_dim - 3, -1, 3),))
     return SyntheticEnv("Reacher", obs_dim, -np.ones(2), np.ones(2), spec)
 
 
@@ -174,14 +197,42 @@ def fetch_pick_and_place_env(orig_obs_len: int = 25, sparse: bool = False, thres
                              shaped_reward: bool = True) -> SyntheticEnv:
     """FetchPickAndPlace shapes (o = 25 + 3 goal entries, d=4): ``||goal - obs[3:6]|| + 0.1*||obs[0:3] - obs[3:6]||``
     or the ``[. > threshold]`` indicators (icem/environments/robotics.py:150-164)."""
-    spec = CostSpec(0.0, 0, 0.0, -1, 0.0, 0.0, dist_a=(orig_obs_len, 0), dist_b=(3, 3),
-                    dist_len=(3, 3 if shaped_reward else 0), dist_sparse=(sparse, sparse), dist_weight=(1.0, 0.1),
-                    dist_thresh=(threshold, threshold))
+    kind = TERM_NORM_GT if sparse else TERM_NORM
+    terms = (CostTerm(kind, orig_obs_len, 3, 3, 1.0, threshold),)
+    if shaped_reward:
+        terms += (CostTerm(kind, 0, 3, 3, 0.1, threshold),)
+    spec = CostSpec(0.0, 0, 0.0, -1, 0.0, 0.0, terms=terms)
     return SyntheticEnv("FetchPickAndPlace", orig_obs_len + 3, -np.ones(4), np.ones(4), spec)
 
 
 def fetch_reach_env(orig_obs_len: int = 10, sparse: bool = False, threshold: float = 0.05) -> SyntheticEnv:
     """FetchReach shapes (o = 10 + 3, d=4): ``||goal - obs[0:3]||`` or ``[. > threshold]`` (robotics.py:286-295)."""
-    spec = CostSpec(0.0, 0, 0.0, -1, 0.0, 0.0, dist_a=(orig_obs_len, 0), dist_b=(0, -1), dist_len=(3, 0),
-                    dist_sparse=(sparse, False), dist_weight=(1.0, 0.0), dist_thresh=(threshold, 0.0))
+    spec = CostSpec(0.0, 0, 0.0, -1, 0.0, 0.0,
+                    terms=(CostTerm(TERM_NORM_GT if sparse else TERM_NORM, orig_obs_len, 0, 3, 1.0, threshold),))
     return SyntheticEnv("FetchReach", orig_obs_len + 3, -np.ones(4), np.ones(4), spec)
+
+
+def door_env(obs_dim: int = 39, nq: int = 30, nv: int = 30, shaped_reward: bool = True, add_bonus_rewards: bool = True) -> SyntheticEnv:
+    """Door (hand manipulation suite) shapes (o=39, d=28): ``0.1*||palm - handle|| + 0.1*(door - 1.57)^2
+    + 1e-5*sum(obs[-nv:]^2) - 2[door > 0.2] - 8[door > 1.0] - 10[door > 1.35]`` with door = obs[nq-2], palm =
+    obs[nq-1:nq+2], handle = obs[nq+2:nq+5] (icem/environments/mjenvs.py:26-31, 57-78)."""
+    door, palm, handle = nq - 2, nq - 1, nq + 2
+    tail = min(nv, obs_dim)
+    terms = ((CostTerm(TERM_NORM, palm, handle, 3, 0.1),) if shaped_reward else ()) + (
+        CostTerm(TERM_SQ_OFFSET, door, -1, 1, 0.1, 1.57), CostTerm(TERM_SUMSQ, obs_dim - tail, -1, tail, 1e-5))
+    if add_bonus_rewards:
+        terms += (CostTerm(TERM_STEP_GT, door, -1, 1, -2.0, 0.2), CostTerm(TERM_STEP_GT, door, -1, 1, -8.0, 1.0),
+                  CostTerm(TERM_STEP_GT, door, -1, 1, -10.0, 1.35))
+    return SyntheticEnv("Door", obs_dim, -np.ones(28), np.ones(28), CostSpec(0.0, 0, 0.0, -1, 0.0, 0.0, terms=terms))
+
+
+def relocate_env(obs_dim: int = 39, nq: int = 36, add_bonus_rewards: bool = True) -> SyntheticEnv:
+    """Relocate shapes (o=39, d=30): ``0.1*||palm - obj|| - [obj_z > 0.04] + 0.5*||obj - target||*[obj_z > 0.04]
+    - 10[||obj - target|| < 0.1] - 20[||obj - target|| < 0.05]`` with the three difference vectors at obs[nq-6:nq+3]
+    and obj_z = obs[-1] (icem/environments/mjenvs.py:112-115, 155-174)."""
+    po, ot, z = nq - 6, nq, obs_dim - 1
+    terms = (CostTerm(TERM_NORM, po, -1, 3, 0.1), CostTerm(TERM_STEP_GT, z, -1, 1, -1.0, 0.04),
+             CostTerm(TERM_NORM, ot, -1, 3, 0.5, 0.0, z, 0.04))
+    if add_bonus_rewards:
+        terms += (CostTerm(TERM_NORM_LT, ot, -1, 3, -10.0, 0.1), CostTerm(TERM_NORM_LT, ot, -1, 3, -20.0, 0.05))
+    return SyntheticEnv("Relocate", obs_dim, -np.ones(30), np.ones(30), CostSpec(0.0, 0, 0.0, -1, 0.0, 0.0, terms=terms))

@@ -139,13 +139,16 @@ class IcemPlanner:
         if not getattr(spec, "extended", False):
             L.check(self.lib.icem_set_cost_terms(self._h, None))
             return
+        if len(spec.terms) > L.MAX_COST_TERMS:
+            raise ValueError(f"at most {L.MAX_COST_TERMS} cost terms")
         t = L.IcemCostTermsC(
             diff_weight=spec.diff_weight, health_penalty=spec.health_penalty, health_lo=spec.health_lo,
-            health_hi=spec.health_hi, box_lo=spec.box_lo, box_hi=spec.box_hi,
-            dist_weight=(C.c_double * 2)(*spec.dist_weight), dist_thresh=(C.c_double * 2)(*spec.dist_thresh),
-            diff_idx=spec.diff_idx, health_idx=spec.health_idx, health_closed=int(spec.health_closed),
-            box_from=spec.box_from, dist_a=(C.c_int32 * 2)(*spec.dist_a), dist_b=(C.c_int32 * 2)(*spec.dist_b),
-            dist_len=(C.c_int32 * 2)(*spec.dist_len), dist_sparse=(C.c_int32 * 2)(*[int(x) for x in spec.dist_sparse]))
+            health_hi=spec.health_hi, box_lo=spec.box_lo, box_hi=spec.box_hi, diff_idx=spec.diff_idx,
+            health_idx=spec.health_idx, health_closed=int(spec.health_closed), box_from=spec.box_from,
+            n_terms=len(spec.terms))
+        for j, tm in enumerate(spec.terms):
+            t.terms[j] = L.IcemCostTermC(weight=tm.weight, thresh=tm.thresh, gate_thresh=tm.gate_thresh, kind=tm.kind,
+                                         a=tm.a, b=tm.b, len=tm.len, gate_idx=tm.gate_idx)
         L.check(self.lib.icem_set_cost_terms(self._h, C.byref(t)))
 
     def trajectory_cost(self, observations, actions, next_observations=None) -> torch.Tensor:

@@ -79,7 +79,8 @@ typedef struct icem_config {
  * :259-277 HumanoidStandup):
  *   cost_t = ctrl_weight*sum_j a_j^2 + lin_weight*obs[lin_idx]
  *            + flip_penalty*([obs[flip_idx] > flip_thresh] + [obs[flip_idx] < -flip_thresh])
- * with the flip term dropped when flip_idx < 0.  `obs` is the PRE-action observation. */
+ * with the flip term dropped when flip_idx < 0 and the linear term when lin_weight == 0 (lin_idx must still be a
+ * valid index).  `obs` is the PRE-action observation. */
 typedef struct icem_cost_spec {
     double ctrl_weight;
     double lin_weight;
@@ -90,26 +91,47 @@ typedef struct icem_cost_spec {
 } icem_cost_spec;
 
 /* The remaining parametric cost functions of the reference's environments, as extra terms on top of
- * icem_cost_spec (all off in a zero-initialised struct with the idx fields at -1 / dist_len at 0):
+ * icem_cost_spec (a zero-initialised struct with diff_idx = health_idx = box_from = -1 and n_terms = 0 is "off"):
  *   + diff_weight * (next_obs[diff_idx] - obs[diff_idx])            Ant, Hopper: -x_velocity = -(x' - x)/dt
  *                                                                    (environments/mujoco.py:164, 218)
  *   + health_penalty * unhealthy(obs),  unhealthy = 1 - all_finite(obs) * [lo <(=) obs[health_idx] <(=) hi]
  *                                                   * [box_lo < obs[k] < box_hi for all k >= box_from]
  *       Ant :146-149,166 (closed range), Hopper :189-203,221 (open range + healthy_state_range over obs[2:];
  *       its healthy_angle is dropped by the reference itself, :199), Humanoid :302-315,338 (open range)
- *   + dist_weight[j] * f(|| obs[dist_a[j] .. +dist_len[j]) - obs[dist_b[j] .. +dist_len[j]) ||),  j = 0, 1
- *       f = identity, or [. > dist_thresh[j]] when dist_sparse[j]; dist_b[j] < 0: norm of the slice itself
- *       Reacher :366-368; FetchPickAndPlace / FetchReach environments/robotics.py:150-164, 286-295. */
+ *   + sum over terms[0 .. n_terms) of  weight * gate * f,  gate = [obs[gate_idx] > gate_thresh] (1 if gate_idx < 0),
+ *     with r = || obs[a .. a+len) - obs[b .. b+len) ||  (b < 0: the norm of the slice itself) and f by kind:
+ *       ICEM_TERM_NORM       r                    Reacher :366-368, FetchPickAndPlace / FetchReach
+ *                                                 environments/robotics.py:150-164, 286-295, Door / Relocate
+ *                                                 environments/mjenvs.py:64, 161, 166 (the latter gated on the lift)
+ *       ICEM_TERM_NORM_GT    [r > thresh]         the sparse robotics costs robotics.py:159-161, 291-292
+ *       ICEM_TERM_NORM_LT    [r < thresh]         Relocate's closeness bonuses mjenvs.py:170-172
+ *       ICEM_TERM_SQ_OFFSET  (obs[a] - thresh)^2  Door's hinge target mjenvs.py:68
+ *       ICEM_TERM_SUMSQ      sum_k obs[a+k]^2     Door's velocity cost mjenvs.py:70
+ *       ICEM_TERM_STEP_GT    [obs[a] > thresh]    Door's opening bonuses :74-76, Relocate's lift bonus :162 */
+enum { ICEM_TERM_NORM = 0, ICEM_TERM_NORM_GT = 1, ICEM_TERM_NORM_LT = 2, ICEM_TERM_SQ_OFFSET = 3, ICEM_TERM_SUMSQ = 4,
+       ICEM_TERM_STEP_GT = 5 };
+#define ICEM_MAX_COST_TERMS 8
+#define ICEM_MAX_TERM_LEN 64
+
+typedef struct icem_cost_term {
+    double weight, thresh, gate_thresh;
+    int32_t kind;
+    int32_t a, b, len;      /* b = -1: no second slice; len <= ICEM_MAX_TERM_LEN (1 for the scalar kinds) */
+    int32_t gate_idx;       /* -1: not gated */
+    int32_t reserved;
+} icem_cost_term;
+
 typedef struct icem_cost_terms {
     double diff_weight;
     double health_penalty, health_lo, health_hi;
     double box_lo, box_hi;
-    double dist_weight[2], dist_thresh[2];
     int32_t diff_idx;        /* -1: off */
     int32_t health_idx;      /* -1: off */
     int32_t health_closed;   /* 1: lo <= z <= hi, 0: lo < z < hi */
     int32_t box_from;        /* -1: off */
-    int32_t dist_a[2], dist_b[2], dist_len[2], dist_sparse[2];   /* dist_len 0: off; at most 16 */
+    int32_t n_terms;
+    int32_t reserved;
+    icem_cost_term terms[ICEM_MAX_COST_TERMS];
 } icem_cost_terms;
 
 typedef struct icem_handle icem_handle;

@@ -321,6 +321,24 @@ def sample_via_matrices(mean, std, low, high, beta, z_r, z_i, dtype=np.float64) 
 # --------------------------------------------------------------------------
 
 
+TERM_NORM, TERM_NORM_GT, TERM_NORM_LT, TERM_SQ_OFFSET, TERM_SUMSQ, TERM_STEP_GT = range(6)
+
+
+@dataclass(frozen=True)
+class CostTerm:
+    """``weight * [obs[gate_idx] > gate_thresh] * f`` with ``r = ||obs[a:a+len] - obs[b:b+len]||`` (``b < 0``: the
+    slice itself); ``f`` by kind: NORM ``r``, NORM_GT ``[r > thresh]``, NORM_LT ``[r < thresh]``, SQ_OFFSET
+    ``(obs[a] - thresh)^2``, SUMSQ ``sum obs[a:a+len]^2``, STEP_GT ``[obs[a] > thresh]``."""
+    kind: int
+    a: int
+    b: int = -1
+    len: int = 1
+    weight: float = 1.0
+    thresh: float = 0.0
+    gate_idx: int = -1
+    gate_thresh: float = 0.0
+
+
 @dataclass
 class CostSpec:
     """Parametric restatement of the shipped cost functions.
@@ -329,15 +347,15 @@ class CostSpec:
                + ctrl_weight*sum_d a^2 + lin_weight*obs[lin_idx]
                + diff_weight*(next_obs[diff_idx] - obs[diff_idx])
                + health_penalty*unhealthy(obs)
-               + sum_j dist_weight[j]*f_j(||obs[a_j:a_j+len_j] - obs[b_j:b_j+len_j]||)``
-    added in that order (each group only when switched on: ``flip_idx/diff_idx/health_idx >= 0``,
-    ``dist_len[j] > 0``).  ``unhealthy = 1 - isfinite(obs).all() * [lo <(=) obs[health_idx] <(=) hi]
+               + sum_j terms[j]``  (see :class:`CostTerm`)
+    added in that order (each group only when switched on: ``flip_idx/diff_idx/health_idx >= 0``;
+    the linear term only when ``lin_weight != 0``).  ``unhealthy = 1 - isfinite(obs).all() * [lo <(=) obs[health_idx] <(=) hi]
     * [box_lo < obs[k] < box_hi for all k >= box_from]`` (``health_closed``: ``<=`` as in Ant,
     mujoco.py:146-149; open as in Hopper :189-203 / Humanoid :302-315; the box is Hopper's
     ``healthy_state_range`` over ``obs[2:]``; Hopper's ``healthy_angle`` never enters the result:
-    it is passed as ``out=`` of ``np.logical_and``, :199).  ``f_j`` is the identity, or ``[. > thresh]``
-    for the sparse robotics costs (robotics.py:159-161, 291-292); ``b_j < 0`` takes the plain norm
-    of the slice (Reacher, mujoco.py:366-368).  HalfCheetah (:67-99) and HumanoidStandup (:259-277)
+    it is passed as ``out=`` of ``np.logical_and``, :199).  The terms cover Reacher (mujoco.py:366-368),
+    FetchPickAndPlace / FetchReach dense and sparse (robotics.py:150-164, 286-295), Door and Relocate
+    (mjenvs.py:57-78, 155-174).  HalfCheetah (:67-99) and HumanoidStandup (:259-277)
     reproduce the reference bit for bit in float64; the others to rounding (the reference adds its
     terms in a different order per env).
     """
@@ -357,16 +375,11 @@ class CostSpec:
     box_from: int = -1
     box_lo: float = -100.0
     box_hi: float = 100.0
-    dist_a: tuple = (0, 0)
-    dist_b: tuple = (-1, -1)
-    dist_len: tuple = (0, 0)
-    dist_sparse: tuple = (False, False)
-    dist_weight: tuple = (0.0, 0.0)
-    dist_thresh: tuple = (0.0, 0.0)
+    terms: tuple = ()
 
     @property
     def extended(self) -> bool:
-        return self.diff_idx >= 0 or self.health_idx >= 0 or any(n > 0 for n in self.dist_len)
+        return self.diff_idx >= 0 or self.health_idx >= 0 or len(self.terms) > 0
 
     @property
     def needs_next_obs(self) -> bool:
@@ -414,21 +427,48 @@ class CostSpec:
     @staticmethod
     def reacher(obs_dim: int = 11) -> "CostSpec":
         # mujoco.py:366-368: ||obs[-3:]||
-        return CostSpec(0.0, 0, 0.0, -1, 0.0, 0.0, dist_a=(obs_dim - 3, 0), dist_len=(3, 0), dist_weight=(1.0, 0.0))
+        return CostSpec(0.0, 0, 0.0, -1, 0.0, 0.0, terms=(CostTerm(TERM_NORM, obs_dim - 3, -1, 3),))
 
     @staticmethod
     def fetch_pick_and_place(orig_obs_len: int = 25, sparse: bool = False, threshold: float = 0.05,
                              shaped_reward: bool = True) -> "CostSpec":
         # robotics.py:150-164: ||goal - obs[3:6]|| (+ 0.1*||obs[0:3] - obs[3:6]||), or the [. > threshold] indicators
-        return CostSpec(0.0, 0, 0.0, -1, 0.0, 0.0, dist_a=(orig_obs_len, 0), dist_b=(3, 3),
-                        dist_len=(3, 3 if shaped_reward else 0), dist_sparse=(sparse, sparse),
-                        dist_weight=(1.0, 0.1), dist_thresh=(threshold, threshold))
+        kind = TERM_NORM_GT if sparse else TERM_NORM
+        terms = (CostTerm(kind, orig_obs_len, 3, 3, 1.0, threshold),)
+        if shaped_reward:
+            terms += (CostTerm(kind, 0, 3, 3, 0.1, threshold),)
+        return CostSpec(0.0, 0, 0.0, -1, 0.0, 0.0, terms=terms)
 
     @staticmethod
     def fetch_reach(orig_obs_len: int = 10, sparse: bool = False, threshold: float = 0.05) -> "CostSpec":
         # robotics.py:286-295: ||goal - obs[0:3]|| or [. > threshold]
-        return CostSpec(0.0, 0, 0.0, -1, 0.0, 0.0, dist_a=(orig_obs_len, 0), dist_b=(0, -1), dist_len=(3, 0),
-                        dist_sparse=(sparse, False), dist_weight=(1.0, 0.0), dist_thresh=(threshold, 0.0))
+        return CostSpec(0.0, 0, 0.0, -1, 0.0, 0.0,
+                        terms=(CostTerm(TERM_NORM_GT if sparse else TERM_NORM, orig_obs_len, 0, 3, 1.0, threshold),))
+
+    @staticmethod
+    def door(obs_dim: int = 39, nq: int = 30, nv: int = 30, shaped_reward: bool = True,
+             add_bonus_rewards: bool = True) -> "CostSpec":
+        # mjenvs.py:26-31 (index layout), 57-78: 0.1*||palm - handle|| + 0.1*(door - 1.57)^2 + 1e-5*sum(obs[-nv:]^2)
+        #                                        - 2[door > 0.2] - 8[door > 1.0] - 10[door > 1.35]
+        door, palm, handle = nq - 2, nq - 1, nq + 2
+        tail = min(nv, obs_dim)
+        terms = ((CostTerm(TERM_NORM, palm, handle, 3, 0.1),) if shaped_reward else ()) + (
+            CostTerm(TERM_SQ_OFFSET, door, -1, 1, 0.1, 1.57), CostTerm(TERM_SUMSQ, obs_dim - tail, -1, tail, 1e-5))
+        if add_bonus_rewards:
+            terms += (CostTerm(TERM_STEP_GT, door, -1, 1, -2.0, 0.2), CostTerm(TERM_STEP_GT, door, -1, 1, -8.0, 1.0),
+                      CostTerm(TERM_STEP_GT, door, -1, 1, -10.0, 1.35))
+        return CostSpec(0.0, 0, 0.0, -1, 0.0, 0.0, terms=terms)
+
+    @staticmethod
+    def relocate(obs_dim: int = 39, nq: int = 36, add_bonus_rewards: bool = True) -> "CostSpec":
+        # mjenvs.py:112-115 (index layout), 155-174: 0.1*||palm - obj|| - [obj_z > 0.04]
+        #     + 0.5*||obj - target||*[obj_z > 0.04] - 10[||obj - target|| < 0.1] - 20[||obj - target|| < 0.05]
+        po, ot, z = nq - 6, nq, obs_dim - 1
+        terms = (CostTerm(TERM_NORM, po, -1, 3, 0.1), CostTerm(TERM_STEP_GT, z, -1, 1, -1.0, 0.04),
+                 CostTerm(TERM_NORM, ot, -1, 3, 0.5, 0.0, z, 0.04))
+        if add_bonus_rewards:
+            terms += (CostTerm(TERM_NORM_LT, ot, -1, 3, -10.0, 0.1), CostTerm(TERM_NORM_LT, ot, -1, 3, -20.0, 0.05))
+        return CostSpec(0.0, 0, 0.0, -1, 0.0, 0.0, terms=terms)
 
     def unhealthy(self, obs: np.ndarray) -> np.ndarray:
         z = obs[..., self.health_idx]
@@ -441,19 +481,32 @@ class CostSpec:
             ok = np.logical_and(np.all(np.logical_and(self.box_lo < st, st < self.box_hi), axis=-1), ok)
         return 1 - np.isfinite(obs).all(axis=-1) * ok
 
-    def dist_term(self, j: int, obs: np.ndarray) -> np.ndarray:
-        """Term j's norm, accumulated element by element in index order (the order the kernels use)."""
+    def term_value(self, tm: CostTerm, obs: np.ndarray) -> np.ndarray:
+        """One term; sums of squares accumulated element by element in index order (the order the kernels use)."""
         dt = obs.dtype.type
-        acc = np.zeros(obs.shape[:-1], dtype=obs.dtype)
-        for m in range(self.dist_len[j]):
-            v = obs[..., self.dist_a[j] + m]
-            if self.dist_b[j] >= 0:
-                v = v - obs[..., self.dist_b[j] + m]
-            acc = acc + v * v
-        r = np.sqrt(acc)
-        if self.dist_sparse[j]:
-            r = (r > dt(self.dist_thresh[j])).astype(obs.dtype)
-        return dt(self.dist_weight[j]) * r
+        if tm.kind == TERM_STEP_GT:
+            f = (obs[..., tm.a] > dt(tm.thresh)).astype(obs.dtype)
+        elif tm.kind == TERM_SQ_OFFSET:
+            v = obs[..., tm.a] - dt(tm.thresh)
+            f = v * v
+        else:
+            acc = np.zeros(obs.shape[:-1], dtype=obs.dtype)
+            for m in range(tm.len):
+                v = obs[..., tm.a + m]
+                if tm.b >= 0:
+                    v = v - obs[..., tm.b + m]
+                acc = acc + v * v
+            if tm.kind == TERM_SUMSQ:
+                f = acc
+            else:
+                r = np.sqrt(acc)
+                if tm.kind == TERM_NORM:
+                    f = r
+                else:
+                    f = (r > dt(tm.thresh) if tm.kind == TERM_NORM_GT else r < dt(tm.thresh)).astype(obs.dtype)
+        if tm.gate_idx >= 0:
+            f = f * (obs[..., tm.gate_idx] > dt(tm.gate_thresh)).astype(obs.dtype)
+        return dt(tm.weight) * f
 
     def __call__(self, obs: np.ndarray, act: np.ndarray, next_obs=None) -> np.ndarray:
         scores = np.zeros(act.shape[:-1], dtype=act.dtype)
@@ -462,7 +515,8 @@ class CostSpec:
             scores = scores + (ang > self.flip_thresh) * self.flip_penalty
             scores = scores + (ang < -self.flip_thresh) * self.flip_penalty
         scores = scores + self.ctrl_weight * np.sum(act ** 2, axis=-1)
-        scores = scores + self.lin_weight * obs[..., self.lin_idx]
+        if self.lin_weight != 0:
+            scores = scores + self.lin_weight * obs[..., self.lin_idx]
         return scores + self.extended_terms(obs, next_obs)
 
     def extended_terms(self, obs: np.ndarray, next_obs) -> np.ndarray:
@@ -472,9 +526,8 @@ class CostSpec:
             ext = ext + dt(self.diff_weight) * (next_obs[..., self.diff_idx] - obs[..., self.diff_idx])
         if self.health_idx >= 0:
             ext = ext + dt(self.health_penalty) * self.unhealthy(obs).astype(obs.dtype)
-        for j in range(2):
-            if self.dist_len[j] > 0:
-                ext = ext + self.dist_term(j, obs)
+        for tm in self.terms:
+            ext = ext + self.term_value(tm, obs)
         return ext
 
 
@@ -502,7 +555,8 @@ def _step_cost(cost: CostSpec, obs, a, nxt, dt):
         c = c + (ang > dt(cost.flip_thresh)).astype(dt) * dt(cost.flip_penalty)
         c = c + (ang < dt(-cost.flip_thresh)).astype(dt) * dt(cost.flip_penalty)
     c = c + dt(cost.ctrl_weight) * ctrl
-    c = c + dt(cost.lin_weight) * obs[:, cost.lin_idx]
+    if cost.lin_weight != 0:
+        c = c + dt(cost.lin_weight) * obs[:, cost.lin_idx]
     if cost.extended:
         c = c + cost.extended_terms(obs, nxt)
     return c

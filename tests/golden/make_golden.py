@@ -512,6 +512,38 @@ def env_cost_vectors():
                           "goal_from_observation", "achieved_goal_from_observation")
                 key = f"{tag}_{'sparse' if sparse else 'dense'}{'_shaped' if shaped else ''}"
                 data[key] = np.asarray(cls.cost_fn(ns, o, a, None))
+    # Door / Relocate (hand manipulation suite): environments/mjenvs.py imports the un-vendored mj_envs submodule at
+    # module level -> stand-in modules for those four imports, then the cost functions are called unbound, one
+    # trajectory at a time as trajectory_cost_fn does (Door flattens door_pos: 2-D input only)
+    pk = "environments.mj_envs"
+    for name, attrs in ((pk, {}), (pk + ".mj_envs", {}), (pk + ".mj_envs.hand_manipulation_suite", {}),
+                        (pk + ".mj_envs.hand_manipulation_suite.door_v0", dict(DoorEnvV0=object, ADD_BONUS_REWARDS=True)),
+                        (pk + ".mj_envs.hand_manipulation_suite.relocate_v0", dict(RelocateEnvV0=object, ADD_BONUS_REWARDS=True)),
+                        (pk + ".mj_envs.hand_manipulation_suite.hammer_v0", dict(HammerEnvV0=object, ADD_BONUS_REWARDS=True))):
+        mod = types.ModuleType(name)
+        mod.__path__ = []
+        mod.__dict__.update(attrs)
+        sys.modules[name] = mod
+    import environments.mjenvs as ref_mjenvs
+    o_dim = 39
+    for tag, shaped, bonus in (("door", True, True), ("door_plain", False, False)):
+        door = types.SimpleNamespace(door_pos_idx=np.arange(28, 29), palm_pos_idx=np.arange(29, 32),
+                                     handle_pos_idx=np.arange(32, 35), qv_start_idx=30, shaped_reward=shaped,
+                                     add_bonus_rewards=bonus)
+        o = 0.3 * rs.randn(n, h, o_dim)
+        o[..., 28] = rs.uniform(-0.2, 1.7, (n, h))    # hinge angle across the 0.2 / 1.0 / 1.35 bonus steps
+        a = rs.uniform(-1, 1, (n, h, 28))
+        data.update({tag + "_obs": o, tag + "_act": a,
+                     tag: np.stack([ref_mjenvs.Door.cost_fn(door, o[i], a[i], None) for i in range(n)])})
+    for tag, bonus in (("relocate", True), ("relocate_plain", False)):
+        rel = types.SimpleNamespace(palm_pos_minus_obj_pos_idx=np.arange(30, 33), palm_pos_minus_target_pos_idx=np.arange(33, 36),
+                                    obj_pos_minus_target_pos_idx=np.arange(36, 39), add_bonus_rewards=bonus)
+        o = 0.2 * rs.randn(n, h, o_dim)
+        o[::2, :, 36:39] = 0.04 * rs.randn(n // 2, h, 3)   # object near the target (both closeness bonuses) ...
+        o[1::3, :, 38] = rs.uniform(0.03, 0.08, (len(range(1, n, 3)), h))   # ... and just lifted / not lifted
+        a = rs.uniform(-1, 1, (n, h, 30))
+        data.update({tag + "_obs": o, tag + "_act": a,
+                     tag: np.stack([ref_mjenvs.Relocate.cost_fn(rel, o[i], a[i], None) for i in range(n)])})
     path = os.path.join(OUT, "env_cost_vectors.npz")
     np.savez_compressed(path, **data)
     print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB")

@@ -42,6 +42,24 @@ def test_struct_sizes_match_header():
     assert C.sizeof(L.IcemConfigC) == 104
     assert C.sizeof(L.IcemCostSpecC) == 40
     assert C.sizeof(L.IcemPlanBuffersC) == 16 * 8
+    # icem_cost_term: 3 double + 6 int32 = 48; icem_cost_terms: 6 double + 6 int32 + 8 terms = 48 + 24 + 384 = 456
+    # (checked against `gcc sizeof` of include/icem_hip.h below when a C compiler is around)
+    assert C.sizeof(L.IcemCostTermC) == 48 and C.sizeof(L.IcemCostTermsC) == 456
+
+
+def test_struct_sizes_match_c_compiler(tmp_path):
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "icem_hip.h")
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu", sizeof(icem_config), '
+                   'sizeof(icem_cost_spec), sizeof(icem_plan_buffers), sizeof(icem_cost_term), sizeof(icem_cost_terms));return 0;}' % hdr)
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-o", str(exe), str(src)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert got == [C.sizeof(x) for x in (L.IcemConfigC, L.IcemCostSpecC, L.IcemPlanBuffersC, L.IcemCostTermC, L.IcemCostTermsC)]
 
 
 def test_create_rejects_bad_config_like_the_reference(lib):

@@ -939,9 +939,11 @@ def _env_cost_cases():
 
 def _device_spec(spec):
     """oracle CostSpec -> the product's CostSpec (same fields)."""
-    from icem_amd.envs import CostSpec
+    from icem_amd.envs import CostSpec, CostTerm
     import dataclasses
-    return CostSpec(**dataclasses.asdict(spec))
+    d = dataclasses.asdict(spec)
+    d["terms"] = tuple(CostTerm(**t) for t in d["terms"])
+    return CostSpec(**d)
 
 
 @pytest.mark.parametrize("mode", ["sum", "best", "final"])

@@ -128,11 +128,13 @@ def env_cost_specs():
         ("fpp_sparse_shaped", O.CostSpec.fetch_pick_and_place(25, True, 0.05, True), False),
         ("freach_dense", O.CostSpec.fetch_reach(10, False, 0.05), False),
         ("freach_sparse", O.CostSpec.fetch_reach(10, True, 0.05), False),
+        ("door", O.CostSpec.door(39, 30, 30, True, True), False), ("door_plain", O.CostSpec.door(39, 30, 30, False, False), False),
+        ("relocate", O.CostSpec.relocate(39, 36, True), False), ("relocate_plain", O.CostSpec.relocate(39, 36, False), False),
     ]
 
 
 def env_cost_inputs(z, tag):
-    base = tag.split("_")[0] if tag.startswith(("fpp", "freach")) else tag
+    base = tag.split("_")[0] if tag.startswith(("fpp", "freach")) else tag   # fpp / freach variants share inputs
     obs, act = z[base + "_obs"], z[base + "_act"]
     nxt = z[base + "_next"] if base + "_next" in z.files else None
     return obs, act, nxt
@@ -140,9 +142,10 @@ def env_cost_inputs(z, tag):
 
 @pytest.mark.parametrize("tag,spec,has_next", env_cost_specs(), ids=[t for t, _, _ in env_cost_specs()])
 def test_env_cost_functions_match_reference(tag, spec, has_next):
-    """f-4: Ant / Hopper / Humanoid / Reacher (environments/mujoco.py:151-171, 205-225, 317-343, 366-368) and
-    FetchPickAndPlace / FetchReach (environments/robotics.py:150-164, 286-295) as parametric cost terms: indicator
-    terms exact, floats to 1e-12 (the reference adds its terms in an env-specific order)."""
+    """f-4: Ant / Hopper / Humanoid / Reacher (environments/mujoco.py:151-171, 205-225, 317-343, 366-368),
+    FetchPickAndPlace / FetchReach (environments/robotics.py:150-164, 286-295) and Door / Relocate
+    (environments/mjenvs.py:57-78, 155-174) as parametric cost terms: indicator terms exact, floats to 1e-12 (the
+    reference adds its terms in an env-specific order)."""
     z = np.load(os.path.join(GOLDEN, "env_cost_vectors.npz"))
     obs, act, nxt = env_cost_inputs(z, tag)
     assert (nxt is not None) == has_next and spec.needs_next_obs == has_next
