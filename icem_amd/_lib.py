@@ -82,6 +82,7 @@ SYMBOLS = [
     ("icem_set_cost_terms", C.c_int, [_H, C.POINTER(IcemCostTermsC)]),
     ("icem_trajectory_cost", C.c_int, [_H, _I32, _I32, _VP, _VP, _I64, _I64, _VP, _VP, _VP]),
     ("icem_sample_clip", C.c_int, [_H, _I32, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _U64, _I32, _I32, _VP, _VP]),
+    ("icem_sample_piecewise", C.c_int, [_H, _I32, _I64, _I32, _I64, _VP, _VP, _VP, _VP, _VP]),
     ("icem_philox_normals", C.c_int, [_H, _I32, _I64, _U64, _VP, _VP, _VP]),
     ("icem_rollout_cost", C.c_int, [_H, _I32, _VP, _VP, _VP, _VP, _VP]),
     ("icem_cost_reduce", C.c_int, [_H, _I32, _VP, _VP, _VP]),

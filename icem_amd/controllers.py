@@ -584,6 +584,88 @@ class MpcCemStdHip(MpcController):
 
 
 # ---------------------------------------------------------------------------------------------
+# the random-shooting baseline
+# ---------------------------------------------------------------------------------------------
+
+class MpcRandomHip(MpcController):
+    """``controllers.mpc.MpcRandom`` (icem/controllers/mpc.py:86-138): uniform action sequences held for
+    ``action_change_frequency`` steps, rolled out, the first action of the cheapest one executed -- sampling, rollout,
+    cost and argmin on the device.  ``action_sampler_params`` needs ``action_change_frequency`` (attribute or key).
+    Extra optional keywords: ``dtype``, ``seed``, ``rng_rounds``, ``device``, ``noise_source`` ("philox": device
+    uniforms keyed by the block index; "action_space": ``env.action_space``-style draws ``np.random.random_sample(d)``
+    in the reference's call order, two of them at construction -- parity mode; or a callable
+    ``uniforms(first_block, n_blocks) -> [n_blocks, d]``)."""
+
+    def __init__(self, *, action_sampler_params, dtype="f32", seed=0, rng_rounds=10, device="cuda:0",
+                 noise_source: Union[str, Callable] = "philox", **kwargs):
+        super().__init__(**kwargs)
+        asp = action_sampler_params
+        self.action_change_frequency = int(asp["action_change_frequency"] if isinstance(asp, Mapping)
+                                           else asp.action_change_frequency)
+        assert self.action_change_frequency < self.horizon  # mpc.py:92
+        space = self.env.action_space
+        if isinstance(space, Discrete) or type(space).__name__ == "Discrete":
+            raise NotImplementedError("discrete action spaces are not supported by the device sampler")
+        if self.cost_along_trajectory not in ("sum", "best", "final"):
+            raise NotImplementedError(
+                "Implement method {} to compute cost along trajectory".format(self.cost_along_trajectory))
+        self.noise_source = noise_source
+        d = int(np.prod(space.shape))
+        cfg = IcemConfig(horizon=self.horizon, act_dim=d, num_traj=self.num_sim_traj, elites_size=2, opt_iters=1,
+                         cost_mode=self.cost_along_trajectory, dtype=dtype, rng_rounds=rng_rounds, seed=seed)
+        self.planner = IcemPlanner(cfg, space.low, space.high, device=device)
+        self._bind_models()
+        self.calls = 0            # MpcRandom.sample() calls so far (its counter runs on across MPC steps)
+        self._draws = []          # parity mode: the unit draws of blocks 0, 1, ... as they are consumed
+        if noise_source == "action_space":
+            # RndController.__init__ draws previous_action (unused by MpcRandom), then MpcRandom its current_action
+            np.random.random_sample(d)
+            self._draws.append(np.random.random_sample(d))
+        self.last_min_cost = None
+        self.best_traj_idx = None
+
+    def beginning_of_rollout(self, *, observation, state=None, mode):
+        super().beginning_of_rollout(observation=observation, state=state, mode=mode)
+
+    def _block_uniforms(self, first_block: int, n_blocks: int):
+        if callable(self.noise_source):
+            return np.asarray(self.noise_source(first_block, n_blocks))
+        if self.noise_source == "action_space":
+            d = self.planner.d
+            while len(self._draws) < first_block + n_blocks:
+                self._draws.append(np.random.random_sample(d))
+            return np.stack(self._draws[first_block:first_block + n_blocks])
+        if self.noise_source == "philox":
+            return None
+        raise ValueError(f"unknown noise_source {self.noise_source!r}")
+
+    def sample_action_sequences(self, obs, num_traj, time_slice=None) -> torch.Tensor:  # mpc.py:104-109
+        p, f = self.planner, self.action_change_frequency
+        block = lambda c: 0 if c < f else 1 + (c - f) // (f + 1)  # noqa: E731
+        first, last = block(self.calls), block(self.calls + num_traj * p.h - 1)
+        u = self._block_uniforms(first, last - first + 1)
+        actions = p.sample_piecewise(num_traj, self.calls, f, u, first)
+        self.calls += num_traj * p.h
+        return actions
+
+    def get_action(self, obs, state, mode="train"):  # mpc.py:114-138
+        self.forward_model_state = self.forward_model.got_actual_observation_and_env_state(
+            observation=obs, env_state=state, model_state=self.forward_model_state)
+        p = self.planner
+        actions = self.sample_action_sequences(obs, self.num_sim_traj)
+        costs = self._costs_of(obs, actions)
+        best_cost, idx = p.topk_sorted(costs, 1)                         # np.argmin(costs), mpc.py:122
+        self.best_traj_idx = int(idx[0])
+        self.last_min_cost = float(best_cost[0])
+        self._last_actions, self._last_costs = actions, costs
+        executed_action = actions[self.best_traj_idx, 0].cpu().numpy().astype(np.float64)
+        if self.forward_model_state is not None:
+            _, self.forward_model_state, _ = self.forward_model.predict(
+                observations=obs, states=self.forward_model_state, actions=executed_action)
+        return executed_action
+
+
+# ---------------------------------------------------------------------------------------------
 # registry: icem/controllers/__init__.py:6-31
 # ---------------------------------------------------------------------------------------------
 
@@ -597,6 +679,8 @@ class ControllerFactory:
         "mpc-icem": (".controllers", "MpcICemHip"),
         "mpc-cem-std-hip": (".controllers", "MpcCemStdHip"),
         "mpc-cem-std": (".controllers", "MpcCemStdHip"),
+        "mpc-random-hip": (".controllers", "MpcRandomHip"),
+        "mpc-random": (".controllers", "MpcRandomHip"),
     }
     controller = None
 

@@ -189,6 +189,30 @@ __global__ __launch_bounds__(WG) void sample_truncnorm_kernel(int n, int h, int 
     }
 }
 
+// MpcRandom.sample_action_sequences (mpc.py:96-109): uniform actions held for a number of consecutive calls of
+// sample() -- a call counter that runs over (trajectory, step) pairs and on across MPC steps.  Call c uses block
+// 0 (the action drawn at construction) while c < freq, then block 1 + (c - freq) / (freq + 1).  u: the caller's
+// uniforms [*, d] for blocks first_block.. (parity), or null: word 0 of block (b, j)'s Philox / xoshiro stream.
+template <typename T, int ROUNDS>
+__global__ __launch_bounds__(WG) void sample_piecewise_kernel(long long total, int d, long long call_offset, int freq,
+                                                             long long first_block, const T* low, const T* high, const T* u,
+                                                             uint32_t seed_lo, uint32_t seed_hi, T* out) {
+    const long long e = (long long)blockIdx.x * WG + threadIdx.x;
+    if (e >= total) return;
+    const long long call = call_offset + e / d;
+    const int j = (int)(e % d);
+    const long long b = call < freq ? 0 : 1 + (call - freq) / (freq + 1);
+    T uu;
+    if (u) {
+        uu = u[(b - first_block) * d + j];
+    } else {
+        Xoshiro128pp rng = row_stream<ROUNDS>((uint32_t)b, (uint32_t)j, (uint32_t)((unsigned long long)b >> 32), 0x52414E44u /* "RAND" */,
+                                              seed_lo, seed_hi);
+        uu = ((T)rng.next() + (T)0.5) * (T)2.3283064365386963e-10;
+    }
+    out[e] = fmad(high[j] - low[j], uu, low[j]);
+}
+
 // MpcCemStd._update_bounds (mpc.py:290-301), in place on std (like_levine) and into lower / upper [h, d]
 template <typename T>
 __global__ __launch_bounds__(WG) void cem_bounds_kernel(int hd, int d, int like_levine, const T* mean, T* std, const T* low,
@@ -1806,6 +1830,31 @@ int icem_sample_truncnorm(icem_handle* h, int32_t n, int64_t first_index, const 
         if (c.rng_rounds == 7) ICEM_TN(float, 7); else ICEM_TN(float, 10);
     }
 #undef ICEM_TN
+    ICEM_HIP_TRY(hipGetLastError());
+    return ICEM_OK;
+}
+
+int icem_sample_piecewise(icem_handle* h, int32_t n, int64_t call_offset, int32_t change_freq, int64_t first_block,
+                          const void* low, const void* high, const void* u, void* actions, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (n < 0 || call_offset < 0 || change_freq < 0 || !low || !high || !actions)
+        return fail(ICEM_E_INVALID, "null tensor / negative n, call_offset or change_freq");
+    if (n == 0) return ICEM_OK;
+    const icem_config& c = h->cfg;
+    hipStream_t st = (hipStream_t)stream;
+    const long long total = (long long)n * c.horizon * c.act_dim;
+    const int grid = (int)((total + WG - 1) / WG);
+    const uint32_t sl = (uint32_t)c.seed, sh = (uint32_t)(c.seed >> 32);
+#define ICEM_PW(T, R)                                                                                              \
+    hipLaunchKernelGGL((sample_piecewise_kernel<T, R>), dim3(grid), dim3(WG), 0, st, total, c.act_dim,             \
+                       (long long)call_offset, change_freq, (long long)first_block, (const T*)low, (const T*)high, \
+                       (const T*)u, sl, sh, (T*)actions)
+    if (c.dtype == ICEM_F64) {
+        if (c.rng_rounds == 7) ICEM_PW(double, 7); else ICEM_PW(double, 10);
+    } else {
+        if (c.rng_rounds == 7) ICEM_PW(float, 7); else ICEM_PW(float, 10);
+    }
+#undef ICEM_PW
     ICEM_HIP_TRY(hipGetLastError());
     return ICEM_OK;
 }

@@ -132,6 +132,16 @@ class IcemPlanner:
         spec = L.IcemCostSpecC(ctrl_weight, lin_weight, flip_penalty, flip_thresh, lin_idx, flip_idx)
         L.check(self.lib.icem_set_cost(self._h, C.byref(spec)))
 
+    def sample_piecewise(self, n: int, call_offset: int, change_freq: int, u=None, first_block: int = 0) -> torch.Tensor:
+        """``MpcRandom.sample_action_sequences`` (icem/controllers/mpc.py:96-109): ``[n, h, d]`` uniform actions held
+        over consecutive ``sample()`` calls (``icem_sample_piecewise``).  ``u``: the draws ``[*, d]`` of blocks
+        ``first_block..`` (parity), or None for the device's Philox streams."""
+        actions = torch.empty((n, self.h, self.d), dtype=self.dt, device=self.device)
+        u_t = None if u is None else self._t(u)
+        L.check(self.lib.icem_sample_piecewise(self._h, n, int(call_offset), int(change_freq), int(first_block),
+                                               _ptr(self.low), _ptr(self.high), _ptr(u_t), _ptr(actions), self._stream()))
+        return actions
+
     def set_cost_spec(self, spec):
         """The whole parametric cost of an env (``envs.CostSpec``): the HalfCheetah / HumanoidStandup form plus the
         Ant / Hopper / Humanoid / Reacher / Fetch terms (``icem_set_cost_terms``)."""

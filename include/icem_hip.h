@@ -193,6 +193,15 @@ int icem_sample_truncnorm(icem_handle* h, int32_t n, int64_t first_index, const 
 int icem_cem_bounds(icem_handle* h, int32_t like_levine, const void* mean, void* std, const void* low, const void* high,
                     void* lower, void* upper, void* stream);
 
+/* MpcRandom.sample_action_sequences (icem/controllers/mpc.py:96-109, random shooting): actions[i, t, :] = low +
+ * (high - low) * U(block), uniform draws held for consecutive calls of MpcRandom.sample() (mpc.py:96-102) -- one call
+ * per (trajectory, step) pair in row-major order, the call counter running on across MPC steps: call c =
+ * call_offset + i*h + t uses block 0 (the action drawn at construction) while c < change_freq, then block
+ * 1 + (c - change_freq) / (change_freq + 1).  u: uniforms [*, d] for blocks first_block, first_block + 1, ...
+ * (parity mode: env.action_space.sample()'s draws), or NULL for the Philox path (keyed by the block index). */
+int icem_sample_piecewise(icem_handle* h, int32_t n, int64_t call_offset, int32_t change_freq, int64_t first_block,
+                          const void* low, const void* high, const void* u, void* actions, void* stream);
+
 /* Raw white noise of the Philox path (for RNG known-answer tests): z_r, z_i [n, d, F]. */
 int icem_philox_normals(icem_handle* h, int32_t n, int64_t first_index, uint64_t offset,
                         void* z_r, void* z_i, void* stream);

@@ -245,6 +245,47 @@ def philox_uniforms(seed: int, offset: int, num: int, d: int, h: int, first_inde
     return np.ascontiguousarray(u)
 
 
+RANDOM_STREAM_HI = 0x52414E44  # "RAND": high offset word of the random-shooting block streams (icem_sample_piecewise)
+
+
+def philox_block_uniforms(seed: int, first_block: int, n_blocks: int, d: int, rounds: int = 10, dtype=np.float64):
+    """Uniforms ``[n_blocks, d]`` of the device's random-shooting sampler: word 0 of block ``(b, j)``'s stream."""
+    return philox_uniforms(seed, RANDOM_STREAM_HI << 32, n_blocks, d, 1, first_index=first_block, rounds=rounds,
+                           dtype=dtype)[:, 0, :]
+
+
+def piecewise_blocks(call_offset: int, count: int, freq: int) -> np.ndarray:
+    """Block index of calls ``call_offset .. call_offset+count`` of ``MpcRandom.sample`` (mpc.py:96-102): the action
+    drawn at construction serves the first ``freq`` calls, every later draw ``freq + 1`` calls."""
+    c = call_offset + np.arange(count, dtype=np.int64)
+    return np.where(c < freq, 0, 1 + (c - freq) // (freq + 1))
+
+
+class RandomShootingOracle:
+    """``MpcRandom`` (icem/controllers/mpc.py:86-138): piecewise-constant uniform action sequences, rollout, argmin,
+    first action of the best.  ``uniforms(first_block, n_blocks) -> [n_blocks, d]`` supplies the draws."""
+
+    def __init__(self, *, horizon, num_traj, freq, low, high, rollout_cost, uniforms):
+        assert freq < horizon  # mpc.py:92
+        self.h, self.N, self.freq = horizon, num_traj, freq
+        self.low, self.high = np.asarray(low, dtype=np.float64), np.asarray(high, dtype=np.float64)
+        self.rollout_cost, self.uniforms = rollout_cost, uniforms
+        self.calls = 0
+
+    def sample_action_sequences(self, num_traj: int) -> np.ndarray:
+        b = piecewise_blocks(self.calls, num_traj * self.h, self.freq)
+        u = np.asarray(self.uniforms(int(b[0]), int(b[-1] - b[0] + 1)), dtype=np.float64)
+        self.calls += num_traj * self.h
+        acts = (self.high - self.low) * u[b - b[0]] + self.low
+        return acts.reshape(num_traj, self.h, -1)
+
+    def get_action(self, obs):
+        self.actions = self.sample_action_sequences(self.N)
+        self.costs = self.rollout_cost(np.asarray(obs, dtype=np.float64), self.actions)
+        self.best = int(np.argmin(self.costs))   # mpc.py:122
+        return self.actions[self.best, 0]
+
+
 class PhiloxNoiseSchedule:
     """Noise callback for :class:`IcemOracle` reproducing the device's Philox
     offsets: per MPC step ``s`` the main batch of iteration ``i`` uses offset

@@ -67,10 +67,15 @@ STUBS = {
     "gym/spaces.py": """
         import numpy as np
         class Space: pass
+        SAMPLE_LOG = []
         class Box(Space):
             def __init__(self, low, high, dtype=np.float32):
                 self.low = np.asarray(low, dtype=dtype); self.high = np.asarray(high, dtype=dtype)
                 self.shape = self.low.shape
+            def sample(self):   # bounded Box.sample: uniform(low, high); the unit draws are logged for replay
+                u = np.random.random_sample(self.shape)
+                SAMPLE_LOG.append(u)
+                return (self.high.astype(np.float64) - self.low) * u + self.low
         class Discrete(Space):
             def __init__(self, n): self.n = n
         class Dict(Space):
@@ -420,6 +425,74 @@ def run_cem_std_case(name, *, N, h, d, o, iters, seed, n_steps, kind, like_levin
     print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB, {len(calls)} sampling calls")
 
 
+def run_random_case(name, *, N, h, d, o, freq, seed, n_steps, kind, cost_mode="sum"):
+    """f-3: the random-shooting baseline MpcRandom (icem/controllers/mpc.py:86-138) with the synthetic model: records
+    the unit draws behind every env.action_space.sample() call (two at construction: RndController's, unused, then
+    MpcRandom's current_action), the sampled sequences, costs, argmin and executed action of every MPC step."""
+    from controllers.mpc import MpcRandom
+    from models.abstract_models import ForwardModelWithDefaults
+    from gym import spaces
+    import environments.mujoco as ref_mj
+    A, B = make_model_mats(o, d)
+
+    class Env:
+        name = "fake"
+        action_space = spaces.Box(-np.ones(d), np.ones(d))
+        observation_space = spaces.Box(-np.inf * np.ones(o), np.inf * np.ones(o))
+        penalise_flipping = True
+
+        def cost_fn(self, obs, act, next_obs):
+            return ref_mj.HalfCheetahMaybeWithPosition.cost_fn(self, obs, act, next_obs)
+
+    class Model(ForwardModelWithDefaults):
+        def train(self, buffer): pass
+        def save(self, path): pass
+        def load(self, path): pass
+
+        def predict(self, *, observations, states, actions):
+            nxt = np.zeros_like(observations)
+            for k in range(o):
+                nxt = nxt + observations[..., k:k + 1] * A[k]
+            for j in range(d):
+                nxt = nxt + actions[..., j:j + 1] * B[j]
+            if kind == 1:
+                nxt = np.tanh(nxt)
+            return nxt, None, np.zeros(observations.shape[:-1] + (1,))
+
+    del spaces.SAMPLE_LOG[:]
+    np.random.seed(seed)
+    env = Env()
+    params = types.SimpleNamespace(action_change_frequency=freq)
+
+    class Runnable(MpcRandom):   # the reference class leaves these two abstract (it cannot be instantiated as shipped)
+        def beginning_of_rollout(self, *, observation, state=None, mode): pass
+        def end_of_rollout(self, total_time, total_return, mode): pass
+
+    ctrl = Runnable(env=env, forward_model=Model(env=env), horizon=h, num_simulated_trajectories=N,
+                    cost_along_trajectory=cost_mode, action_sampler_params=params)
+    n_init = len(spaces.SAMPLE_LOG)
+    data = dict(N=N, h=h, d=d, o=o, freq=freq, kind=kind, A=A, B=B, n_steps=n_steps, cost_mode=cost_mode, n_init_draws=n_init)
+    orig = ctrl.trajectory_cost_fn
+    log = {}
+
+    def spy(cost_fn, paths):
+        c = orig(cost_fn, paths)
+        log["costs"], log["actions"] = np.array(c), np.array(paths.as_array("actions"))
+        return c
+    ctrl.trajectory_cost_fn = spy
+    rs = np.random.RandomState(seed + 1)
+    for sidx in range(n_steps):
+        obs = 0.1 * rs.randn(o)
+        a = ctrl.get_action(obs, None)
+        data[f"obs_{sidx}"], data[f"executed_{sidx}"] = obs, np.array(a)
+        data[f"actions_{sidx}"], data[f"costs_{sidx}"] = log["actions"], log["costs"]
+        data[f"best_{sidx}"] = int(np.argmin(log["costs"]))
+    data["u"] = np.array(spaces.SAMPLE_LOG)
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **data)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB, {len(spaces.SAMPLE_LOG)} draws ({n_init} at construction)")
+
+
 def cost_fn_vectors():
     """Direct input/output vectors of the reference's two cost functions."""
     import environments.mujoco as ref_mj
@@ -576,6 +649,7 @@ def main():
              n_steps=3, kind=0, env_kind="halfcheetah")
     # the CEM baseline MpcCemStd (truncated normal): bounds from the action space, and "like Levine" (+-2 sigma, std capped)
     run_cem_std_case("cemstd_bounds_n48", N=48, h=12, d=6, o=17, iters=3, seed=21, n_steps=3, kind=0, like_levine=False)
+    run_random_case("random_n24", N=24, h=10, d=4, o=17, freq=3, seed=31, n_steps=3, kind=1)
     run_cem_std_case("cemstd_levine_n40", N=40, h=10, d=4, o=17, iters=4, seed=22, n_steps=2, kind=1, like_levine=True,
                      execute_best=False, cost_mode="best")
 

@@ -7,7 +7,8 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 _ALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if not p.endswith("cost_vectors.npz") and not p.endswith("cost_fn_vectors.npz"))
-CASES = [n for n in _ALL if not n.startswith("cemstd_")]        # MpcICem runs
+CASES = [n for n in _ALL if not n.startswith(("cemstd_", "random_"))]        # MpcICem runs
+RANDOM_CASES = [n for n in _ALL if n.startswith("random_")]     # MpcRandom runs (random shooting baseline)
 CEMSTD_CASES = [n for n in _ALL if n.startswith("cemstd_")]     # MpcCemStd runs (truncated-normal CEM baseline)
 
 
@@ -54,3 +55,25 @@ class GoldenCemStd:
     def call(self, i):
         z = self.z
         return {k: z[f"{k}_{i}"] for k in ("u", "lower", "upper", "simact", "costs", "elite", "mean", "std", "lower_next", "upper_next")}
+
+
+class GoldenRandom:
+    """A recorded run of the reference's MpcRandom (tests/golden/make_golden.py::run_random_case)."""
+
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN, name + ".npz"))
+        self.z = z
+        for k in ("N", "h", "d", "o", "freq", "kind", "n_steps", "n_init_draws"):
+            setattr(self, k, int(z[k]))
+        self.cost_mode = str(z["cost_mode"])
+        self.A, self.B, self.u = z["A"], z["B"], z["u"]
+        self.low, self.high = -np.ones(self.d), np.ones(self.d)
+
+    def block_uniforms(self, first_block, n_blocks):
+        """Draws of blocks first_block.. : block 0 is the LAST construction-time draw (MpcRandom.current_action; the
+        one before it is RndController.previous_action, never used)."""
+        lo = self.n_init_draws - 1 + first_block
+        return self.u[lo:lo + n_blocks]
+
+    def step(self, s):
+        return {k: self.z[f"{k}_{s}"] for k in ("obs", "executed", "actions", "costs", "best")}

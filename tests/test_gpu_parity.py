@@ -1137,3 +1137,76 @@ def test_nan_costs_rank_last_with_index_tie_break(N, dtype):
     assert np.array_equal(np_(elite_actions), np_(pl.actions[:K])) and last_pool >= K
     assert np.array_equal(executed, np_(pl.actions[0, 0]))
     assert O.topk_sorted(np.full(last_pool, np.nan), K).tolist() == list(range(K))
+
+
+# ---------------------------------------------------------------------------------------------
+# f-3: the random-shooting baseline MpcRandom
+# ---------------------------------------------------------------------------------------------
+
+def _random_controller(g, dtype, noise_source, seed=0):
+    from icem_amd import DeviceSyntheticModel, MpcRandomHip
+    from icem_amd.envs import SyntheticEnv
+    spec = O.CostSpec.halfcheetah(g.o)
+    env = SyntheticEnv("fake", g.o, g.low, g.high, _device_spec(spec))
+    model = DeviceSyntheticModel(g.A, g.B, g.kind)
+    return MpcRandomHip(env=env, forward_model=model, horizon=g.h, num_simulated_trajectories=g.N,
+                        cost_along_trajectory=g.cost_mode, dtype=dtype, seed=seed, noise_source=noise_source,
+                        action_sampler_params=dict(action_change_frequency=g.freq))
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("name", __import__("golden_util").RANDOM_CASES)
+def test_random_shooting_controller_replays_reference_run(name, dtype):
+    """MpcRandomHip fed the recorded action_space.sample() draws reproduces the reference's MpcRandom run
+    (icem/controllers/mpc.py:86-138): the sampled sequences (f64: exactly), the argmin and the executed actions; and
+    does so too when it draws from the global np.random stream itself in the reference's call order."""
+    from golden_util import GoldenRandom
+    g = GoldenRandom(name)
+    for source in ("callable", "action_space"):
+        if source == "action_space":
+            np.random.seed(31)   # the seed of the recorded run (make_golden.py::main)
+            ctrl = _random_controller(g, dtype, "action_space")
+        else:
+            ctrl = _random_controller(g, dtype, g.block_uniforms)
+        assert ctrl.device_path
+        ctrl.beginning_of_rollout(observation=g.step(0)["obs"], state=None, mode="train")
+        for s in range(g.n_steps):
+            st = g.step(s)
+            a = ctrl.get_action(st["obs"], None)
+            if dtype == "f64":
+                assert np.array_equal(np_(ctrl._last_actions), st["actions"]) and np.array_equal(a, st["executed"])
+                np.testing.assert_allclose(np_(ctrl._last_costs), st["costs"], rtol=1e-10, atol=1e-12)
+            else:
+                np.testing.assert_allclose(np_(ctrl._last_actions), st["actions"], rtol=1e-6, atol=1e-7)
+                np.testing.assert_allclose(a, st["executed"], rtol=1e-6, atol=1e-7)
+                np.testing.assert_allclose(np_(ctrl._last_costs), st["costs"], **tol(dtype))
+            assert ctrl.best_traj_idx == int(st["best"])
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_random_shooting_device_rng_matches_oracle(dtype):
+    """Philox mode of the random-shooting sampler: block (b, j) -> word 0 of its stream; oracle driven by the same
+    counters.  Populations large enough for the matrix-pipe rollout (f32) and several MPC steps (the call counter and
+    the held blocks run on across steps)."""
+    from icem_amd import DeviceSyntheticModel, MpcRandomHip, halfcheetah_env
+    env = halfcheetah_env(17)
+    model = DeviceSyntheticModel.make(17, 6, kind=1)
+    N, h, freq, seed = 3000, 30, 4, 17
+    ctrl = MpcRandomHip(env=env, forward_model=model, horizon=h, num_simulated_trajectories=N, cost_along_trajectory="sum",
+                        dtype=dtype, seed=seed, action_sampler_params=dict(action_change_frequency=freq))
+    npdt = np.float64 if dtype == "f64" else np.float32
+    om, oc = O.SyntheticModel(model.A, model.B, model.kind), O.CostSpec.halfcheetah(17)
+    orc = O.RandomShootingOracle(horizon=h, num_traj=N, freq=freq, low=env.action_space.low, high=env.action_space.high,
+                                 rollout_cost=lambda ob, ac: O.rollout_costs(om, oc, ob, ac),
+                                 uniforms=lambda b0, nb: O.philox_block_uniforms(seed, b0, nb, 6, dtype=npdt))
+    ctrl.beginning_of_rollout(observation=np.zeros(17), state=None, mode="train")
+    t = dict(rtol=1e-12, atol=1e-13) if dtype == "f64" else dict(rtol=1e-6, atol=1e-6)
+    for s in range(3):
+        ob = 0.1 * np.random.RandomState(s).randn(17)
+        a, want = ctrl.get_action(ob, None), orc.get_action(ob)
+        np.testing.assert_allclose(np_(ctrl._last_actions), orc.actions, **t)
+        assert ctrl.best_traj_idx == orc.best
+        np.testing.assert_allclose(a, want, **t)
+        acts = np_(ctrl._last_actions).reshape(-1, 6)
+        n_blocks = N * h // (freq + 1)   # distinct held values per step (f32: a handful of the 18 000 draws collide)
+        assert (np.abs(acts) <= 1).all() and 0.995 * n_blocks <= len(np.unique(acts[:, 0])) <= n_blocks + 1

@@ -190,3 +190,24 @@ def test_cem_std_oracle_matches_reference(name):
             np.testing.assert_allclose(lower, ref["lower_next"], rtol=1e-12, atol=1e-9)
             np.testing.assert_allclose(upper, ref["upper_next"], rtol=1e-12, atol=1e-9)
             i += 1
+
+
+@pytest.mark.parametrize("name", __import__("golden_util").RANDOM_CASES)
+def test_random_shooting_oracle_matches_reference(name):
+    """f-3: MpcRandom (icem/controllers/mpc.py:86-138): replaying the recorded action_space.sample() draws through the
+    oracle reproduces every sampled sequence (exactly: same affine map), cost, argmin and executed action."""
+    from golden_util import GoldenRandom
+    g = GoldenRandom(name)
+    om, oc = O.SyntheticModel(g.A, g.B, g.kind), O.CostSpec.halfcheetah(g.o)
+    orc = O.RandomShootingOracle(horizon=g.h, num_traj=g.N, freq=g.freq, low=g.low, high=g.high,
+                                 rollout_cost=lambda ob, ac: O.rollout_costs(om, oc, ob, ac, mode=g.cost_mode),
+                                 uniforms=g.block_uniforms)
+    for s in range(g.n_steps):
+        st = g.step(s)
+        a = orc.get_action(st["obs"])
+        assert np.array_equal(orc.actions, st["actions"])
+        np.testing.assert_allclose(orc.costs, st["costs"], rtol=1e-12, atol=1e-12)
+        assert orc.best == int(st["best"]) and np.array_equal(a, st["executed"])
+    # the held blocks: the construction-time action serves `freq` calls, every later draw `freq + 1`
+    b = O.piecewise_blocks(0, 3 * g.freq + 5, g.freq)
+    assert b[:g.freq].tolist() == [0] * g.freq and b[g.freq:2 * g.freq + 1].tolist() == [1] * (g.freq + 1) and b[2 * g.freq + 1] == 2
