@@ -148,7 +148,7 @@ def roofline_of(prof, w, workload=None):
             "algorithmic_bytes_per_launch": units * bpu / launches, "bytes_per_traj_step": bpu}
 
 
-def measure_also(name, steps=30, warmup=5):
+def measure_also(name, steps=200, warmup=20):
     """The large-population configuration the north-star roofline target is stated on (N=65536), measured
     in the same run: whole-loop traj-steps/s, ms per MPC step, dominant-kernel roofline, and the whole
     loop's algorithmic bytes (8d+8/h per traj-step) over the MPC-step time."""

@@ -479,10 +479,14 @@ __global__ __launch_bounds__(WG) void trajectory_cost_kernel(TrajCostArgs<T> a) 
                 const int k0 = min(base + lane, a.o - 1), k1 = min(base + 64 + lane, a.o - 1);
                 const T v00 = r0[k0], v01 = r0[k1], v10 = r1[k0], v11 = r1[k1];
                 const T v20 = r2[k0], v21 = r2[k1], v30 = r3[k0], v31 = r3[k1];
-                b0 |= bad_entry(a, v00, k0) | bad_entry(a, v01, k1);
-                b1 |= bad_entry(a, v10, k0) | bad_entry(a, v11, k1);
-                b2 |= bad_entry(a, v20, k0) | bad_entry(a, v21, k1);
-                b3 |= bad_entry(a, v30, k0) | bad_entry(a, v31, k1);
+                b0 |= bad_entry(a, v00, k0);
+                b0 |= bad_entry(a, v01, k1);
+                b1 |= bad_entry(a, v10, k0);
+                b1 |= bad_entry(a, v11, k1);
+                b2 |= bad_entry(a, v20, k0);
+                b2 |= bad_entry(a, v21, k1);
+                b3 |= bad_entry(a, v30, k0);
+                b3 |= bad_entry(a, v31, k1);
             }
             bad_steps |= (unsigned long long)(__ballot(b0) != 0) << (t & 63);
             bad_steps |= (unsigned long long)(__ballot(b1) != 0) << ((t + 1) & 63);   // rows past h repeat row h-1:
@@ -799,7 +803,7 @@ __global__ __launch_bounds__(WG) void merge_refit_kernel(MergeArgs<T> a) {
             new_mean[e] = nm;
         }
     }
-    if (threadIdx.x < a.K) a.elites_cost_next[threadIdx.x] = sel_c[threadIdx.x];
+    if ((int)threadIdx.x < a.K) a.elites_cost_next[threadIdx.x] = sel_c[threadIdx.x];
     if (a.last) {
         __syncthreads();
         for (int e = threadIdx.x; e < hd; e += WG) {
@@ -807,7 +811,7 @@ __global__ __launch_bounds__(WG) void merge_refit_kernel(MergeArgs<T> a) {
             a.mean[e] = (e + a.d < hd) ? new_mean[e + a.d] : new_mean[e];
             a.std[e] = (a.high[j] - a.low[j]) / (T)2 * a.init_std;
         }
-        if (threadIdx.x < a.d) a.executed[threadIdx.x] = src_row(0)[threadIdx.x];
+        if ((int)threadIdx.x < a.d) a.executed[threadIdx.x] = src_row(0)[threadIdx.x];
         if (threadIdx.x == 0) a.best_cost[0] = sel_c[0];
     }
 }
