@@ -25,10 +25,11 @@ for deferral in (0, 1):
     for s in range(10): step(s)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for s in range(10, 110): step(s)
+    t_host = (time.perf_counter() - t0) / 100   # enqueue time alone (the stream may still be draining)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 100
     pl.profile_enable(True)
     for s in range(110, 130): step(s)
     torch.cuda.synchronize()
     prof = pl.profile_read()
-    print(f"world={world} per-GPU N={per_gpu} deferral={deferral}: {dt * 1e6:.1f} us per MPC step on this rank (no all-gather); "
+    print(f"world={world} per-GPU N={per_gpu} deferral={deferral}: {dt * 1e6:.1f} us per MPC step on this rank (no all-gather; host enqueue {t_host * 1e6:.1f} us); "
           + ", ".join(f"{k} {1e3 * v[0] / v[1]:.1f} us x{v[1] // 20}" for k, v in prof.items()))
