@@ -213,6 +213,7 @@ class MpcController(ModelBasedController, StatefulController, ABC):
         elif world != 1:
             raise NotImplementedError("sharding over GPUs needs the device path (built-in model + cost_spec)")
         # a torch model without its own cost callable is scored by the env's parametric cost on the device
+        self._torch_rollouts = {}
         self.torch_spec_cost = (self.torch_path and getattr(self.forward_model, "cost", None) is None
                                 and getattr(self.env, "cost_spec", None) is not None)
         if self.torch_spec_cost:
@@ -225,30 +226,77 @@ class MpcController(ModelBasedController, StatefulController, ABC):
         if self.device_path:
             return p.rollout_cost(np.asarray(obs, dtype=np.float64), actions)
         if self.torch_path:
-            # device-resident torch model (learned dynamics): h batched steps on the GPU, step costs reduced by
-            # the HIP cost_reduce kernel; nothing leaves the device
+            # device-resident torch model (learned dynamics): h batched steps on the GPU, scored by the HIP cost
+            # kernels; nothing leaves the device.  The h * (model + cost) torch launches of one population size are
+            # captured in a HIP graph on first use and replayed (static input / output tensors per size).
             m = self.forward_model
-            o = torch.as_tensor(np.asarray(obs, dtype=np.float64), dtype=m.dtype, device=p.device)
-            o = o.expand(actions.shape[0], -1)
+            n = actions.shape[0]
+            o0 = torch.as_tensor(np.asarray(obs, dtype=np.float64), dtype=m.dtype, device=p.device)
+            r = self._torch_rollouts.get(n)
+            if r is None:
+                r = self._torch_rollouts[n] = _TorchRollout(m, p, n, self.torch_spec_cost)
+            r.run(o0, actions)
             if self.torch_spec_cost:
                 # the rollout stays in HBM step-major ([h+1, n, o]); icem_trajectory_cost scores it in one launch
-                buf = torch.empty((p.h + 1,) + tuple(o.shape), dtype=p.dt, device=p.device)
-                buf[0] = o
-                a_all = actions.to(m.dtype)
-                for t in range(p.h):
-                    o = m.torch_step(o, a_all[:, t])
-                    buf[t + 1] = o
-                return p.trajectory_cost(buf[:p.h].transpose(0, 1), actions, buf[1:].transpose(0, 1))
-            step_costs = torch.empty((actions.shape[0], p.h), dtype=p.dt, device=p.device)
-            a_all = actions.to(m.dtype)
-            for t in range(p.h):
-                step_costs[:, t] = m.torch_cost(o, a_all[:, t]).to(p.dt)
-                o = m.torch_step(o, a_all[:, t])
-            return p.cost_reduce(step_costs)
+                return p.trajectory_cost(r.buf[:p.h].transpose(0, 1), actions, r.buf[1:].transpose(0, 1))
+            return p.cost_reduce(r.step_costs)
         batch = self.simulate_trajectories(obs=obs, state=self.forward_model_state,
                                            action_sequences=actions.cpu().numpy().astype(np.float64))
         return torch.as_tensor(self.trajectory_cost_fn(self.cost_fn, batch), dtype=p.dt, device=p.device)
 
+
+
+class _TorchRollout:
+    """The h batched steps of a torch dynamics model for ONE population size, with static tensors so that the whole
+    chain of torch launches can be replayed as a HIP graph (``forward_model.use_graph``; a model whose step cannot be
+    captured -- data-dependent control flow, host syncs -- stays on eager launches)."""
+
+    def __init__(self, model, planner, n, spec_cost):
+        self.m, self.p, self.spec_cost = model, planner, spec_cost
+        dev = planner.device
+        self.o0 = torch.empty((n, model.obs_dim), dtype=model.dtype, device=dev)
+        self.actions = torch.empty((n, planner.h, planner.d), dtype=model.dtype, device=dev)
+        if spec_cost:
+            self.buf = torch.empty((planner.h + 1, n, model.obs_dim), dtype=planner.dt, device=dev)
+        else:
+            self.step_costs = torch.empty((n, planner.h), dtype=planner.dt, device=dev)
+        self.graph = None
+        self.use_graph = bool(getattr(model, "use_graph", True))
+
+    def _chain(self):
+        m, p, o = self.m, self.p, self.o0
+        if self.spec_cost:
+            self.buf[0] = o
+        for t in range(p.h):
+            a = self.actions[:, t]
+            if not self.spec_cost:
+                self.step_costs[:, t] = m.torch_cost(o, a).to(p.dt)
+            o = m.torch_step(o, a)
+            if self.spec_cost:
+                self.buf[t + 1] = o
+
+    def run(self, o0, actions):
+        self.o0.copy_(o0.expand_as(self.o0))
+        self.actions.copy_(actions)
+        if not self.use_graph:
+            return self._chain()
+        if self.graph is None:
+            try:
+                side = torch.cuda.Stream(device=self.p.device)
+                side.wait_stream(torch.cuda.current_stream(self.p.device))
+                with torch.cuda.stream(side):   # warm-up off the capture (lazy initialisations, workspace allocations)
+                    self._chain()
+                    self._chain()
+                torch.cuda.current_stream(self.p.device).wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._chain()
+                self.graph = g
+            except Exception:  # noqa: BLE001 -- not capturable: eager launches from here on
+                self.use_graph = False
+                torch.cuda.synchronize(self.p.device)
+                return self._chain()
+        self.graph.replay()
 
 
 # ---------------------------------------------------------------------------------------------

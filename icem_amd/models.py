@@ -142,9 +142,10 @@ class TorchForwardModel(ForwardModel):
     module is bf16); ``cost(obs, act) -> [N]`` is a torch callable.  ``MpcICemHip`` keeps the whole CEM loop on
     the device with it; ``predict`` serves the reference-style NumPy interface."""
 
-    def __init__(self, module, cost, obs_dim: int, act_dim: int, dtype=None, device="cuda:0", env=None):
+    def __init__(self, module, cost, obs_dim: int, act_dim: int, dtype=None, device="cuda:0", env=None, use_graph=True):
         super().__init__(env=env)
         import torch
+        self.use_graph = use_graph   # replay the h-step chain of torch launches as a HIP graph (MpcController._costs_of)
         self.module = module.to(device)
         self.cost = cost
         self.obs_dim, self.act_dim = obs_dim, act_dim
@@ -172,3 +173,46 @@ class TorchForwardModel(ForwardModel):
         if single:
             nxt = nxt[0]
         return nxt, None, np.zeros(nxt.shape[:-1] + (1,))
+
+
+def declared_rssm(act_dim: int = 6, det: int = 200, stoch: int = 30, hidden: int = 200, seed: int = 0, dtype=None,
+                  device="cuda:0", env=None) -> TorchForwardModel:
+    """The learned-dynamics stand-in declared for BASELINE config 5 (N=1024, h=12: "PlaNet learned dynamics" -- the
+    reference ships no such model, README.md:21-29 only quotes its results): a recurrent state-space model in the
+    PlaNet shape, rolled out on its prior mean.  Planner observation = ``[h (det) | z (stoch)]``;
+    ``x = relu(W1 [z, a])``, ``h' = GRUCell(x, h)``, ``z' = W3 relu(W2 h')`` and a two-layer reward head on
+    ``[h', z']``; cost of a step = minus the predicted reward of the state it starts from.  Random weights
+    (``seed``); ``dtype=torch.bfloat16`` runs the GEMMs on the bf16 matrix cores through hipBLASLt."""
+    import torch
+
+    class RSSM(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.det, self.stoch = det, stoch
+            self.inp = torch.nn.Linear(stoch + act_dim, hidden)
+            self.gru = torch.nn.GRUCell(hidden, det)
+            self.prior1 = torch.nn.Linear(det, hidden)
+            self.prior2 = torch.nn.Linear(hidden, stoch)
+            self.rew1 = torch.nn.Linear(det + stoch, hidden)
+            self.rew2 = torch.nn.Linear(hidden, hidden)
+            self.rew3 = torch.nn.Linear(hidden, 1)
+
+        def forward(self, obs, act):
+            h, z = obs[:, :self.det], obs[:, self.det:]
+            x = torch.relu(self.inp(torch.cat([z, act], dim=-1)))
+            h2 = self.gru(x, h)
+            z2 = self.prior2(torch.relu(self.prior1(h2)))
+            return torch.cat([h2, z2], dim=-1)
+
+        def reward(self, obs):
+            return self.rew3(torch.relu(self.rew2(torch.relu(self.rew1(obs))))).squeeze(-1)
+
+    gen = torch.Generator().manual_seed(seed)
+    net = RSSM()
+    with torch.no_grad():
+        for p in net.parameters():   # reproducible weights, independent of torch's global RNG state
+            bound = 1.0 / math.sqrt(p.shape[-1]) if p.ndim > 1 else 0.05
+            p.copy_((torch.rand(p.shape, generator=gen) * 2 - 1) * bound)
+    if dtype is not None:
+        net = net.to(dtype)
+    return TorchForwardModel(net, lambda o, a: -net.reward(o), det + stoch, act_dim, dtype=dtype, device=device, env=env)

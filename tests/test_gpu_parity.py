@@ -1210,3 +1210,88 @@ def test_random_shooting_device_rng_matches_oracle(dtype):
         acts = np_(ctrl._last_actions).reshape(-1, 6)
         n_blocks = N * h // (freq + 1)   # distinct held values per step (f32: a handful of the 18 000 draws collide)
         assert (np.abs(acts) <= 1).all() and 0.995 * n_blocks <= len(np.unique(acts[:, 0])) <= n_blocks + 1
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE config 5: learned-dynamics rollout (declared RSSM), N=1024, h=12
+# ---------------------------------------------------------------------------------------------
+
+def _rssm_numpy(net):
+    """Float64 NumPy restatement of icem_amd.models.declared_rssm's module (torch.nn.GRUCell gate order r, z, n)."""
+    P = {k: v.detach().cpu().double().numpy() for k, v in net.state_dict().items()}
+    det = net.det
+    sig = lambda x: 1.0 / (1.0 + np.exp(-x))  # noqa: E731
+
+    def step(obs, act):
+        h, z = obs[:, :det], obs[:, det:]
+        x = np.maximum(np.concatenate([z, act], -1) @ P["inp.weight"].T + P["inp.bias"], 0)
+        gi = x @ P["gru.weight_ih"].T + P["gru.bias_ih"]
+        gh = h @ P["gru.weight_hh"].T + P["gru.bias_hh"]
+        r = sig(gi[:, :det] + gh[:, :det])
+        u = sig(gi[:, det:2 * det] + gh[:, det:2 * det])
+        n = np.tanh(gi[:, 2 * det:] + r * gh[:, 2 * det:])
+        h2 = (1 - u) * n + u * h
+        z2 = np.maximum(h2 @ P["prior1.weight"].T + P["prior1.bias"], 0) @ P["prior2.weight"].T + P["prior2.bias"]
+        return np.concatenate([h2, z2], -1)
+
+    def reward(obs):
+        a = np.maximum(obs @ P["rew1.weight"].T + P["rew1.bias"], 0)
+        a = np.maximum(a @ P["rew2.weight"].T + P["rew2.bias"], 0)
+        return (a @ P["rew3.weight"].T + P["rew3.bias"])[:, 0]
+
+    return step, reward
+
+
+def test_config5_learned_dynamics_rollout():
+    """BASELINE configs[4]: N=1024, h=12, d=6, beta=0.25 with learned dynamics.  The declared RSSM (f32) behind
+    MpcICemHip -- sampling, cost reduction, top-K and refit in HIP, the recurrent model's GEMMs in torch on the GPU --
+    against the oracle loop driving a float64 NumPy restatement of the same network on the same Philox draws; then the
+    same weights in bf16 (matrix cores): costs of a fixed action batch within bf16 accuracy of the f32 ones, and the
+    planner deterministic."""
+    from icem_amd import MpcICemHip, declared_rssm, halfcheetah_env
+    N, h, d, iters, seed = 1024, 12, 6, 3, 5
+    env = halfcheetah_env(17)   # action space only (d=6, +-1); the cost is the model's reward head
+    asp = dict(alpha=0.1, elites_size=10, opt_iterations=iters, init_std=0.5, use_mean_actions=True,
+               keep_previous_elites=True, shift_elites_over_time=True, fraction_elites_reused=0.3, noise_beta=0.25)
+
+    def controller(model):
+        return MpcICemHip(env=env, forward_model=model, horizon=h, num_simulated_trajectories=N, factor_decrease_num=1.25,
+                          cost_along_trajectory="sum", dtype="f32", seed=seed, action_sampler_params=asp)
+
+    m32 = declared_rssm(seed=3)
+    ctrl = controller(m32)
+    assert ctrl.torch_path and not ctrl.torch_spec_cost
+    step, reward = _rssm_numpy(m32.module)
+
+    def rollout_cost(obs, actions):
+        ob = np.broadcast_to(obs, (actions.shape[0], obs.shape[0])).copy()
+        acc = np.zeros(actions.shape[0])
+        for t in range(h):
+            acc -= reward(ob)
+            ob = step(ob, actions[:, t])
+        return acc
+
+    noise = O.PhiloxNoiseSchedule(seed, iters, d, h, dtype=np.float32)
+    orc = O.IcemOracle(O.IcemParams(horizon=h, num_simulated_trajectories=N, opt_iterations=iters),
+                       env.action_space.low.astype(np.float64), env.action_space.high.astype(np.float64), rollout_cost,
+                       lambda num: tuple(z.astype(np.float64) for z in noise(num)))
+    obs = 0.3 * np.random.RandomState(1).randn(230)
+    ctrl.beginning_of_rollout(observation=obs, state=None, mode="train")
+    orc.beginning_of_rollout()
+    for s in range(2):
+        if s:
+            noise.begin_step()
+        np.testing.assert_allclose(ctrl.get_action(obs, None), orc.get_action(obs), rtol=5e-4, atol=5e-5)
+    # bf16 weights and activations: same planner, matrix-core GEMMs
+    m16 = declared_rssm(seed=3, dtype=torch.bfloat16)
+    acts = torch.as_tensor(np.random.RandomState(2).uniform(-1, 1, (N, h, d)), dtype=torch.float32, device="cuda")
+    c32 = np_(controller(m32)._costs_of(obs, acts))
+    c16_ctrl = controller(m16)
+    c16 = np_(c16_ctrl._costs_of(obs, acts))
+    assert np.abs(c16 - c32).max() <= 0.05 * (1 + np.abs(c32).max()), (np.abs(c16 - c32).max(), np.abs(c32).max())
+    assert np.corrcoef(c16, c32)[0, 1] > 0.99
+    outs = []
+    for _ in range(2):
+        c16_ctrl.beginning_of_rollout(observation=obs, state=None, mode="train")
+        outs.append(c16_ctrl.get_action(obs, None))
+    assert np.array_equal(outs[0], outs[1]) and np.all(np.abs(outs[0]) <= 1.0)
