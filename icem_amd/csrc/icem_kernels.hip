@@ -297,7 +297,6 @@ __device__ __forceinline__ T cost_terms(const CostArgs<T>& cs, bool bad, Obs obs
     for (int j = 0; j < ICEM_MAX_COST_TERMS; ++j) {
         if (j >= cs.n_terms) break;
         const typename CostArgs<T>::Term& tm = cs.terms[j];
-        if (tm.gate_idx >= 0 && !(obs(tm.gate_idx) > tm.gate_th)) continue;
         T f;
         if (tm.kind == ICEM_TERM_STEP_GT) {
             f = obs(tm.a) > tm.th ? (T)1 : (T)0;
@@ -318,6 +317,7 @@ __device__ __forceinline__ T cost_terms(const CostArgs<T>& cs, bool bad, Obs obs
                 f = tm.kind == ICEM_TERM_NORM ? r : tm.kind == ICEM_TERM_NORM_GT ? (r > tm.th ? (T)1 : (T)0) : (r < tm.th ? (T)1 : (T)0);
             }
         }
+        if (tm.gate_idx >= 0) f *= obs(tm.gate_idx) > tm.gate_th ? (T)1 : (T)0;  // a product, as in the reference (NaN * 0 = NaN)
         c += tm.w * f;
     }
     return c;
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(WG) void rollout_cost_kernel(RolloutArgs<T> a) {
         else if (a.cost_mode == ICEM_COST_SUM)
             acc += c;
         else
-            acc = c < acc ? c : acc;
+            acc = (c < acc || c != c) ? c : acc;  // np.amin: a NaN step cost makes the trajectory's cost NaN
         if (a.observations != nullptr) {
             T* dst = a.observations + ((size_t)n * a.h + t) * a.o;
 #pragma unroll
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(WG) void cost_reduce_kernel(int n, int h, int mode,
         if (mode == ICEM_COST_SUM)
             acc += c;
         else if (mode == ICEM_COST_BEST)
-            acc = c < acc ? c : acc;
+            acc = (c < acc || c != c) ? c : acc;  // np.amin: a NaN step cost makes the trajectory's cost NaN
         else
             acc = c;
     }
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(WG) void trajectory_cost_kernel(TrajCostArgs<T> a) 
         if (a.cost_mode == ICEM_COST_SUM)
             acc += ct;
         else if (a.cost_mode == ICEM_COST_BEST)
-            acc = ct < acc ? ct : acc;
+            acc = (ct < acc || ct != ct) ? ct : acc;  // np.amin: NaN propagates
         else
             acc = ct;
     }

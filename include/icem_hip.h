@@ -98,7 +98,8 @@ typedef struct icem_cost_spec {
  *                                                   * [box_lo < obs[k] < box_hi for all k >= box_from]
  *       Ant :146-149,166 (closed range), Hopper :189-203,221 (open range + healthy_state_range over obs[2:];
  *       its healthy_angle is dropped by the reference itself, :199), Humanoid :302-315,338 (open range)
- *   + sum over terms[0 .. n_terms) of  weight * gate * f,  gate = [obs[gate_idx] > gate_thresh] (1 if gate_idx < 0),
+ *   + sum over terms[0 .. n_terms) of  weight * gate * f,  gate = [obs[gate_idx] > gate_thresh] (1 if gate_idx < 0;
+ *     a product as in the reference, so a non-finite f is not masked by a closed gate),
  *     with r = || obs[a .. a+len) - obs[b .. b+len) ||  (b < 0: the norm of the slice itself) and f by kind:
  *       ICEM_TERM_NORM       r                    Reacher :366-368, FetchPickAndPlace / FetchReach
  *                                                 environments/robotics.py:150-164, 286-295, Door / Relocate

@@ -546,7 +546,8 @@ class CostSpec:
                 else:
                     f = (r > dt(tm.thresh) if tm.kind == TERM_NORM_GT else r < dt(tm.thresh)).astype(obs.dtype)
         if tm.gate_idx >= 0:
-            f = f * (obs[..., tm.gate_idx] > dt(tm.gate_thresh)).astype(obs.dtype)
+            with np.errstate(invalid="ignore"):   # inf * 0 -> NaN, as in the reference's products
+                f = f * (obs[..., tm.gate_idx] > dt(tm.gate_thresh)).astype(obs.dtype)
         return dt(tm.weight) * f
 
     def __call__(self, obs: np.ndarray, act: np.ndarray, next_obs=None) -> np.ndarray:

@@ -1295,3 +1295,43 @@ def test_config5_learned_dynamics_rollout():
         c16_ctrl.beginning_of_rollout(observation=obs, state=None, mode="train")
         outs.append(c16_ctrl.get_action(obs, None))
     assert np.array_equal(outs[0], outs[1]) and np.all(np.abs(outs[0]) <= 1.0)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_trajectory_cost_random_term_lists(seed):
+    """Property test of the cost-term evaluator: random term lists (every kind, gated and not, slices of random place
+    and length, plus random flip / linear / difference / health settings) on random rollouts, f64 device against the
+    oracle's restatement (1e-12), for the [n, h, o] layout and all three reductions."""
+    import dataclasses
+    from icem_amd import IcemConfig, IcemPlanner
+    rs = np.random.RandomState(100 + seed)
+    n, h, o, d = int(rs.randint(1, 40)), int(rs.randint(2, 20)), int(rs.randint(4, 90)), int(rs.randint(1, 9))
+    terms = []
+    for _ in range(rs.randint(0, 9)):
+        kind = int(rs.randint(6))
+        ln = 1 if kind in (O.TERM_STEP_GT, O.TERM_SQ_OFFSET) else int(rs.randint(1, min(o, 12) + 1))
+        a = int(rs.randint(0, o - ln + 1))
+        b = int(rs.randint(0, o - ln + 1)) if (kind in (0, 1, 2) and rs.randint(2)) else -1
+        gate = int(rs.randint(o)) if rs.randint(3) == 0 else -1
+        terms.append(O.CostTerm(kind, a, b, ln, float(rs.randn()), float(abs(rs.randn())), gate, float(0.3 * rs.randn())))
+    health = int(rs.randint(o)) if rs.randint(2) else -1
+    spec = O.CostSpec(float(rs.rand()), int(rs.randint(o)), float(rs.randn()) if rs.randint(3) else 0.0,
+                      int(rs.randint(o)) if rs.randint(2) else -1, 10.0, float(rs.rand()),
+                      diff_idx=int(rs.randint(o)) if rs.randint(2) else -1, diff_weight=float(rs.randn()),
+                      health_idx=health, health_penalty=float(50 * rs.rand()), health_lo=-0.5, health_hi=0.8,
+                      health_closed=bool(rs.randint(2)), box_from=int(rs.randint(o)) if (health >= 0 and rs.randint(2)) else -1,
+                      box_lo=-2.0, box_hi=2.0, terms=tuple(terms))
+    obs, nxt, act = rs.randn(n, h, o), rs.randn(n, h, o), rs.uniform(-1, 1, (n, h, d))
+    if health >= 0 and n > 2:
+        obs[0, 0, rs.randint(o)] = np.inf
+        obs[1, h - 1, rs.randint(o)] = np.nan
+    for mode in ("sum", "best", "final"):
+        pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=max(n, 2), elites_size=2, opt_iters=1, cost_mode=mode,
+                                    dtype="f64"), -np.ones(d), np.ones(d))
+        pl.set_cost_spec(_device_spec(spec))
+        to = lambda x: torch.as_tensor(x, dtype=pl.dt, device=pl.device)  # noqa: E731
+        got = np_(pl.trajectory_cost(to(obs), to(act), to(nxt) if spec.diff_idx >= 0 else None))
+        want = O.spec_trajectory_costs(spec, obs, act, nxt, mode=mode)
+        finite = np.isfinite(want)
+        np.testing.assert_allclose(got[finite], want[finite], rtol=1e-12, atol=1e-12)
+        assert np.array_equal(np.isnan(got), np.isnan(want))
