@@ -436,7 +436,9 @@ class MpcICemHip(MpcController):
         self.forward_model_state = self.forward_model.got_actual_observation_and_env_state(
             observation=obs, env_state=state, model_state=self.forward_model_state)
         noise = self._noise_fn()
-        if self.device_path:
+        if self.device_path and noise is None and self.planner.cfg.world == 1:
+            executed_action, self.last_min_cost = self.planner.get_action_host(obs)   # one call, one synchronisation
+        elif self.device_path:
             executed_dev = self.planner.plan_step(obs, noise=noise)
             host = torch.cat([executed_dev, self.planner.best_cost]).cpu().numpy().astype(np.float64)  # one D2H sync
             executed_action, self.last_min_cost = host[:-1], float(host[-1])

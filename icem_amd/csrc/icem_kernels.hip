@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -824,6 +825,17 @@ __global__ __launch_bounds__(WG) void merge_refit_kernel(MergeArgs<T> a) {
 
 using namespace icem;
 
+// icem_get_action: executed action + best cost -> the host-mapped block, then the sequence flag (system scope)
+__global__ void publish_result_kernel(const float* executed, const float* best_cost, int d, float* host_out, unsigned* flag,
+                                      unsigned seq) {
+    const int j = threadIdx.x;
+    if (j < d) host_out[j] = executed[j];
+    if (j == d) host_out[d] = best_cost[0];
+    __threadfence_system();
+    __syncthreads();
+    if (j == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 struct icem_handle {
     icem_config cfg;
     int F = 0, HMAX = 0, hd = 0;
@@ -836,6 +848,9 @@ struct icem_handle {
     icem_cost_spec cost;
     icem_cost_terms terms;
     bool has_terms = false;  // any term of icem_cost_terms switched on
+    void* host_stage = nullptr;  // pinned, device-mapped block of icem_get_action [obs | action, best cost | flag]
+    void* host_stage_dev = nullptr;
+    unsigned io_seq = 0;
     std::vector<int> pop;
     int n_reuse = 0;
     int n_local_max = 0;
@@ -1710,6 +1725,7 @@ int icem_destroy(icem_handle* h) {
     if (!h) return ICEM_OK;
     if (h->W_dev) (void)hipFree(h->W_dev);
     if (h->actions_alt) (void)hipFree(h->actions_alt);
+    if (h->host_stage) (void)hipHostFree(h->host_stage);
     if (h->ws_alt) (void)hipFree(h->ws_alt);
     if (h->pp_stats) (void)hipFree(h->pp_stats);
     if (h->A_dev) (void)hipFree(h->A_dev);
@@ -2206,6 +2222,72 @@ int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step,
             cur_mean = pp;
             cur_std = pp + h->hd;
         }
+    }
+    return ICEM_OK;
+}
+
+// MpcICem.get_action as one call for a host caller: observation in, executed action (+ its pool's best cost) out.
+// The handle owns a small pinned, device-mapped block [obs | action, best cost | flag].  On the f32 fast path the first
+// launch reads the observation straight from it (no H2D copy command in front of the step) and a one-thread kernel
+// behind the last merge writes the result and a sequence flag into it, which the host polls (no D2H copy commands,
+// no stream synchronisation wake-up).  Other configurations stage through the same block with copy commands.
+int icem_get_action(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, const double* obs_host,
+                    double* action_host, double* best_cost_host, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (!b || !obs_host || !action_host) return fail(ICEM_E_INVALID, "null argument");
+    if (!h->has_model) return fail(ICEM_E_STATE, "icem_set_model / icem_set_cost must be called first");
+    hipStream_t st = (hipStream_t)stream;
+    const int o = h->obs_dim, d = h->cfg.act_dim;
+    const size_t ts = h->tsize;
+    constexpr size_t OUT_OFF = ICEM_MAX_OBS_DIM * sizeof(double), FLAG_OFF = OUT_OFF + (ICEM_MAX_ACT_DIM + 1) * sizeof(double);
+    if (!h->host_stage) {
+        ICEM_HIP_TRY(hipHostMalloc(&h->host_stage, FLAG_OFF + 64, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(h->host_stage, 0, FLAG_OFF + 64);
+        ICEM_HIP_TRY(hipHostGetDevicePointer(&h->host_stage_dev, h->host_stage, 0));
+    }
+    unsigned char* stage = (unsigned char*)h->host_stage;
+    for (int k = 0; k < o; ++k) {
+        if (h->cfg.dtype == ICEM_F64) ((double*)stage)[k] = obs_host[k];
+        else ((float*)stage)[k] = (float)obs_host[k];
+    }
+    unsigned char* out = stage + OUT_OFF;
+    volatile unsigned* flag = (volatile unsigned*)(stage + FLAG_OFF);
+    const bool mapped = h->cfg.dtype == ICEM_F32 && h->use_fast && b->z_r == nullptr && fast_rollout_ok(h, h->cfg.num_elites) &&
+                        fast_sample_ok(h);
+    icem_plan_buffers bb = *b;
+    if (mapped) {
+        std::atomic_thread_fence(std::memory_order_release);
+        bb.obs0 = h->host_stage_dev;
+    } else {
+        ICEM_HIP_TRY(hipMemcpyAsync(b->obs0, stage, o * ts, hipMemcpyHostToDevice, st));
+    }
+    const int rc = icem_plan_step(h, &bb, mpc_step, stream);
+    if (rc) return rc;
+    if (mapped) {
+        // (publishing from inside the last merge kernel instead was tried: no faster than this one-wave launch)
+        const unsigned seq = ++h->io_seq;
+        unsigned char* dev = (unsigned char*)h->host_stage_dev;
+        hipLaunchKernelGGL(publish_result_kernel, dim3(1), dim3(64), 0, st, (const float*)b->executed, (const float*)b->best_cost, d,
+                           (float*)(dev + OUT_OFF), (unsigned*)(dev + FLAG_OFF), seq);
+        ICEM_HIP_TRY(hipGetLastError());
+        long long spins = 0;
+        while (*flag != seq) {
+            __builtin_ia32_pause();
+            if (++spins > (1ll << 26)) {  // ~ a second: something is wrong on the stream -- let the runtime report it
+                ICEM_HIP_TRY(hipStreamSynchronize(st));
+                if (*flag != seq) return fail(ICEM_E_HIP, "result flag never arrived");
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    } else {
+        ICEM_HIP_TRY(hipMemcpyAsync(out, b->executed, d * ts, hipMemcpyDeviceToHost, st));
+        ICEM_HIP_TRY(hipMemcpyAsync(out + (size_t)d * ts, b->best_cost, ts, hipMemcpyDeviceToHost, st));
+        ICEM_HIP_TRY(hipStreamSynchronize(st));
+    }
+    for (int j = 0; j <= d; ++j) {
+        const double v = h->cfg.dtype == ICEM_F64 ? ((const double*)out)[j] : (double)((const float*)out)[j];
+        if (j < d) action_host[j] = v;
+        else if (best_cost_host) *best_cost_host = v;
     }
     return ICEM_OK;
 }

@@ -312,6 +312,22 @@ class IcemPlanner:
         L.check(self.lib.icem_profile_read(self._h, ms, cnt, units))
         return {L.KERNEL_NAMES[i]: (ms[i], cnt[i], units[i]) for i in range(n) if cnt[i]}
 
+    def get_action_host(self, obs) -> Tuple[np.ndarray, float]:
+        """One MPC step for a host caller (``icem_get_action``): float64 observation in, ``(executed action [d] float64,
+        best cost of the last pool)`` out; one H2D copy, the step's launches, one D2H copy and one synchronisation, all
+        inside the library.  Device noise, world == 1."""
+        self._ensure_buffers()
+        self._cb.z_r = self._cb.z_i = self._cb.z_r_shift = self._cb.z_i_shift = None
+        ob = np.ascontiguousarray(obs, dtype=np.float64)
+        if ob.shape != (self.obs_dim,):
+            raise ValueError(f"expected an observation of shape ({self.obs_dim},)")
+        act = np.empty(self.d, dtype=np.float64)
+        best = C.c_double()
+        L.check(self.lib.icem_get_action(self._h, C.byref(self._cb), self.mpc_step, ob.ctypes.data_as(C.POINTER(C.c_double)),
+                                         act.ctypes.data_as(C.POINTER(C.c_double)), C.byref(best), self._stream()))
+        self.mpc_step += 1
+        return act, best.value
+
     def plan_step_resident(self):
         """plan_step with the observation already in ``self.obs0`` (Philox noise): no host work besides
         the launches (and, for world > 1, the one all-gather per iteration) -- the bench's timed region."""

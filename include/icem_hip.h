@@ -323,6 +323,13 @@ int icem_profile_read(icem_handle* h, double* total_ms, int64_t* launches, int64
  * actions[h*d] (T)}; all-gather moves K records per rank. */
 size_t icem_record_bytes(const icem_handle* h);
 
+/* MpcICem.get_action (icem/controllers/icem.py:106-189) as ONE call for a host caller: obs_host [obs_dim] float64
+ * goes to b->obs0 through a pinned staging buffer of the handle, icem_plan_step runs, and the executed action
+ * [act_dim] (+ the best cost of the last pool, if best_cost_host != NULL) comes back as float64 after ONE stream
+ * synchronisation.  world == 1, device noise (b->z_* must be NULL). */
+int icem_get_action(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, const double* obs_host,
+                    double* action_host, double* best_cost_host, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1335,3 +1335,40 @@ def test_trajectory_cost_random_term_lists(seed):
         finite = np.isfinite(want)
         np.testing.assert_allclose(got[finite], want[finite], rtol=1e-12, atol=1e-12)
         assert np.array_equal(np.isnan(got), np.isnan(want))
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_get_action_host_call_equals_plan_step(dtype):
+    """icem_get_action (host observation in, host action out, one synchronisation inside the library) returns exactly
+    what icem_plan_step leaves in the device buffers, over several MPC steps; the controller uses it."""
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, MpcICemHip, halfcheetah_env
+    env = halfcheetah_env(17)
+    model = DeviceSyntheticModel.make(17, 6, kind=1)
+
+    def mk():
+        pl = IcemPlanner(IcemConfig(horizon=30, act_dim=6, num_traj=2000, opt_iters=4, dtype=dtype, seed=9),
+                         env.action_space.low, env.action_space.high)
+        pl.set_model(model.kind, model.A, model.B)
+        pl.set_cost_spec(env.cost_spec)
+        pl.reset()
+        return pl
+
+    a, b = mk(), mk()
+    rs = np.random.RandomState(0)
+    for s in range(3):
+        ob = 0.1 * rs.randn(17)
+        act, best = a.get_action_host(ob)
+        want = np_(b.plan_step(ob))
+        assert np.array_equal(act, want) and best == float(np_(b.best_cost)[0])
+        assert np.array_equal(np_(a.mean), np_(b.mean))
+    with pytest.raises(ValueError):
+        a.get_action_host(np.zeros(5))
+    ctrl = MpcICemHip(env=env, forward_model=model, horizon=30, num_simulated_trajectories=2000, factor_decrease_num=1.25,
+                      cost_along_trajectory="sum", dtype=dtype, seed=9,
+                      action_sampler_params=dict(alpha=0.1, elites_size=10, opt_iterations=4, init_std=0.5,
+                                                 use_mean_actions=True, keep_previous_elites=True,
+                                                 shift_elites_over_time=True, fraction_elites_reused=0.3, noise_beta=0.25))
+    c = mk()
+    ob = 0.1 * np.random.RandomState(5).randn(17)
+    ctrl.beginning_of_rollout(observation=ob, state=None, mode="train")
+    assert np.array_equal(ctrl.get_action(ob, None), np_(c.plan_step(ob))) and ctrl.last_min_cost == float(np_(c.best_cost)[0])
