@@ -11,7 +11,7 @@ from ._lib import IcemError, lib_path, load_library  # noqa: F401
 from .planner import IcemConfig, IcemPlanner  # noqa: F401
 from .envs import (CostSpec, CostTerm, SyntheticEnv, door_env, relocate_env, halfcheetah_env, humanoid_standup_env, ant_env, hopper_env, humanoid_env,  # noqa: F401
                    reacher_env, fetch_pick_and_place_env, fetch_reach_env)
-from .models import DeviceSyntheticModel, TorchForwardModel, declared_rssm  # noqa: F401
+from .models import DeviceSyntheticModel, DeviceRSSMModel, TorchForwardModel, declared_rssm, pack_rssm  # noqa: F401
 from .controllers import (MpcICemHip, MpcCemStdHip, MpcRandomHip, controller_from_string, ControllerFactory)  # noqa: F401
 
 __version__ = "0.1.0"

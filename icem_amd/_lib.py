@@ -79,6 +79,8 @@ SYMBOLS = [
     ("icem_noise_tables_host", C.c_int, [_I32, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("icem_set_model", C.c_int, [_H, _I32, _I32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("icem_set_cost", C.c_int, [_H, C.POINTER(IcemCostSpecC)]),
+    ("icem_rssm_param_elems", _SZ, []),
+    ("icem_rssm_rollout_cost", C.c_int, [_I32, _I32, _I32, _VP, _VP, _VP, _VP, _VP]),
     ("icem_get_action", C.c_int, [_H, C.POINTER(IcemPlanBuffersC), _I32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double), _VP]),
     ("icem_set_cost_terms", C.c_int, [_H, C.POINTER(IcemCostTermsC)]),

@@ -4,9 +4,10 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = [os.path.join(HERE, "csrc", "icem_kernels.hip"), os.path.join(HERE, "csrc", "icem_fused.hip")]
+SRCS = [os.path.join(HERE, "csrc", "icem_kernels.hip"), os.path.join(HERE, "csrc", "icem_fused.hip"),
+        os.path.join(HERE, "csrc", "icem_rssm.hip")]
 OUT = os.path.join(HERE, "libicem_hip.so")
-DEPS = SRCS + [os.path.join(HERE, "csrc", "philox.h"), os.path.join(HERE, "csrc", "icem_fused.h"),
+DEPS = SRCS + [os.path.join(HERE, "csrc", "philox.h"), os.path.join(HERE, "csrc", "icem_fused.h"), os.path.join(HERE, "csrc", "icem_rssm.h"),
                os.path.join(os.path.dirname(HERE), "include", "icem_hip.h")]
 
 

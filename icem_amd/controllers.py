@@ -33,6 +33,7 @@ import torch
 from .envs import Box, Discrete
 from .models import DeviceSyntheticModel, TrajectoryBatch
 from .planner import IcemConfig, IcemPlanner
+from ._lib import COST_MODES as L_COST_MODES
 
 try:  # the reference logs through `allogger` (icem.py:28,177); optional here
     import allogger as _allogger
@@ -204,7 +205,8 @@ class MpcController(ModelBasedController, StatefulController, ABC):
         self.device_path = (isinstance(self.forward_model, DeviceSyntheticModel)
                             and getattr(self.env, "cost_spec", None) is not None
                             and not self.use_env_reward_as_cost)
-        self.torch_path = (not self.device_path and hasattr(self.forward_model, "torch_step")
+        self.rssm_path = hasattr(self.forward_model, "rollout_cost") and hasattr(self.forward_model, "params")
+        self.torch_path = (not self.device_path and not self.rssm_path and hasattr(self.forward_model, "torch_step")
                            and hasattr(self.forward_model, "torch_cost"))
         if self.device_path:
             m, c = self.forward_model, self.env.cost_spec
@@ -225,6 +227,8 @@ class MpcController(ModelBasedController, StatefulController, ABC):
         p = self.planner
         if self.device_path:
             return p.rollout_cost(np.asarray(obs, dtype=np.float64), actions)
+        if self.rssm_path:   # learned dynamics fused into one launch (icem_rssm_rollout_cost)
+            return self.forward_model.rollout_cost(obs, actions, L_COST_MODES[p.cfg.cost_mode]).to(p.dt)
         if self.torch_path:
             # device-resident torch model (learned dynamics): h batched steps on the GPU, scored by the HIP cost
             # kernels; nothing leaves the device.  The h * (model + cost) torch launches of one population size are

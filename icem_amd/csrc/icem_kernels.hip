@@ -26,6 +26,7 @@
 #include "../../include/icem_hip.h"
 #include "philox.h"
 #include "icem_fused.h"
+#include "icem_rssm.h"
 #include "refit.h"
 #include <type_traits>
 
@@ -2223,6 +2224,17 @@ int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step,
             cur_std = pp + h->hd;
         }
     }
+    return ICEM_OK;
+}
+
+size_t icem_rssm_param_elems(void) { return rssm::TOTAL; }
+
+int icem_rssm_rollout_cost(int32_t n, int32_t horizon, int32_t cost_mode, const void* params, const void* obs0,
+                           const void* actions, void* costs, void* stream) {
+    if (n < 0 || horizon < 1 || cost_mode < ICEM_COST_SUM || cost_mode > ICEM_COST_FINAL || !params || !obs0 || !actions || !costs)
+        return fail(ICEM_E_INVALID, "null tensor / bad n, horizon or cost_mode");
+    ICEM_HIP_TRY(launch_rssm_rollout(n, horizon, cost_mode, (const unsigned short*)params, (const float*)obs0,
+                                     (const float*)actions, (float*)costs, (hipStream_t)stream));
     return ICEM_OK;
 }
 

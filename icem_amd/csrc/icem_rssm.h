@@ -1,0 +1,35 @@
+// Fused rollout of the declared recurrent state-space model (BASELINE configs[4]: learned dynamics, N=1024, h=12) on
+// the bf16 matrix cores.  Architecture (icem_amd/models.py::declared_rssm): planner observation [h (200) | z (30)],
+//   x  = relu(W1 [z, a] + b1)                200
+//   h' = GRUCell(x, h)                       200      (torch gate order r, u, n)
+//   z' = W5 relu(W4 h' + b4) + b5            30
+//   reward(h, z) = W8 relu(W7 relu(W6 [h, z] + b6) + b7) + b8,   cost of a step = -reward of the state it starts from
+// All widths are padded to multiples of 16 (200 -> 208, 30 -> 32, 6 -> 16); the packed parameter buffer holds, per
+// layer, the weight as MFMA A-operand blocks [out block][k block][lane 64][4 bf16] followed by the f32 bias.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+
+namespace icem {
+namespace rssm {
+constexpr int DET = 200, STOCH = 30, HID = 200, ACT = 6;
+constexpr int DETB = 13, STB = 2, HIDB = 13, ACTB = 1;  // 16-wide blocks
+constexpr int K1B = STB + ACTB;                         // [z | a]
+constexpr int K6B = DETB + STB;                         // [h | z]
+constexpr int BLK = 64 * 4;                             // bf16 elements of one A-operand block
+// element offsets (in bf16 units; biases are f32 = 2 units each) of the packed parameter buffer
+constexpr size_t W1 = 0, B1 = W1 + (size_t)HIDB * K1B * BLK;
+constexpr size_t WGI = B1 + 2 * 16 * HIDB, BGI = WGI + (size_t)3 * DETB * HIDB * BLK;
+constexpr size_t WGH = BGI + 2 * 16 * 3 * DETB, BGH = WGH + (size_t)3 * DETB * DETB * BLK;
+constexpr size_t W4 = BGH + 2 * 16 * 3 * DETB, B4 = W4 + (size_t)HIDB * DETB * BLK;
+constexpr size_t W5 = B4 + 2 * 16 * HIDB, B5 = W5 + (size_t)STB * HIDB * BLK;
+constexpr size_t W6 = B5 + 2 * 16 * STB, B6 = W6 + (size_t)HIDB * K6B * BLK;
+constexpr size_t W7 = B6 + 2 * 16 * HIDB, B7 = W7 + (size_t)HIDB * HIDB * BLK;
+constexpr size_t W8 = B7 + 2 * 16 * HIDB, B8 = W8 + (size_t)1 * HIDB * BLK;
+constexpr size_t TOTAL = B8 + 2 * 16;  // bf16 units
+}  // namespace rssm
+
+// costs[i] = reduce_t -reward(state_t) along the rollout of actions[i] from obs0 (cost_mode: 0 sum, 1 best, 2 final)
+hipError_t launch_rssm_rollout(int n, int horizon, int cost_mode, const unsigned short* params, const float* obs0,
+                               const float* actions, float* costs, hipStream_t st);
+}  // namespace icem

@@ -1,0 +1,169 @@
+// See icem_rssm.h.  One workgroup (4 wavefronts) per 16 trajectories.  Every layer is D = W-block . X^T with
+// v_mfma_f32_16x16x16_bf16: the A operand is a 16 x 16 block of the weight (output row i = lane % 16, k = 4 * (lane / 16)
+// + 0..3), the B operand the activations (trajectory j = lane % 16, same k), and the result leaves lane (j, g) holding
+// outputs 4g .. 4g+3 of trajectory j -- exactly the slice that lane writes back (bias, activation, bf16) to the LDS
+// activation row it will later be read from as a B operand.  The four waves split a layer's output blocks; the
+// weights stream from L2 (760 KB of bf16 per step, shared by all workgroups), the recurrent state stays in LDS in f32.
+#include "icem_rssm.h"
+
+namespace icem {
+namespace {
+using namespace rssm;
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int RS = 212;   // bf16 row stride of the 208-wide activation rows (424 B: conflict-free 8-byte reads)
+constexpr int ZS = 52;    // ... of the [z | a] row (48 wide)
+constexpr int HS = 212;   // f32 row stride of the recurrent state
+
+__device__ __forceinline__ unsigned short to_bf16(float x) {   // round to nearest even
+    unsigned u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ v4s pack4(float a, float b, float c, float d) {
+    v4s r;
+    r[0] = (short)to_bf16(a); r[1] = (short)to_bf16(b); r[2] = (short)to_bf16(c); r[3] = (short)to_bf16(d);
+    return r;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// acc += W[ob][0 .. KB) . X : W points at this lane's 4 bf16 of block (ob, 0); X at the lane's 4 bf16 of k-block 0
+template <int KB>
+__device__ __forceinline__ v4f dot_blocks(const unsigned short* __restrict__ W, const unsigned short* X, v4f acc) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const v4s a = *reinterpret_cast<const v4s*>(W + (size_t)kb * BLK);
+        const v4s b = *reinterpret_cast<const v4s*>(X + kb * 16);
+        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+__device__ __forceinline__ v4f bias4(const unsigned short* params, size_t off, int idx) {
+    const float* b = reinterpret_cast<const float*>(params + off) + idx;
+    return v4f{b[0], b[1], b[2], b[3]};
+}
+
+__global__ __launch_bounds__(256) void rssm_rollout_kernel(int n, int horizon, int cost_mode, const unsigned short* __restrict__ P,
+                                                           const float* __restrict__ obs0, const float* __restrict__ actions,
+                                                           float* __restrict__ costs) {
+    __shared__ __attribute__((aligned(16))) unsigned short zA[16 * ZS];       // [z_t | a_t]
+    __shared__ __attribute__((aligned(16))) unsigned short hb[2][16 * RS];    // h_t in bf16 (operand), ping-pong
+    __shared__ __attribute__((aligned(16))) unsigned short xb[16 * RS];       // x, then p
+    __shared__ __attribute__((aligned(16))) unsigned short r1[16 * RS];
+    __shared__ __attribute__((aligned(16))) unsigned short r2[16 * RS];
+    __shared__ __attribute__((aligned(16))) float h32[16 * HS];               // h_t in f32 (the recurrence)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int base = blockIdx.x * 16;
+    const int row = base + j < n ? base + j : n - 1;   // padding trajectories repeat the last one, never stored
+    const float* __restrict__ act = actions + (size_t)row * horizon * ACT;
+    // ---- initial state: every trajectory starts from obs0 = [h (200) | z (30)] ----
+    for (int e = tid; e < 16 * RS; e += 256) {
+        const int k = e % RS;
+        const float v = k < DET ? obs0[k] : 0.f;
+        hb[0][e] = to_bf16(v);
+        hb[1][e] = 0;
+        h32[e] = v;
+        xb[e] = r1[e] = r2[e] = 0;
+    }
+    for (int e = tid; e < 16 * ZS; e += 256) {
+        const int k = e % ZS, jj = e / ZS;
+        float v = 0.f;
+        if (k < STOCH) v = obs0[DET + k];
+        else if (k >= 32 && k < 32 + ACT) v = actions[(size_t)(base + jj < n ? base + jj : n - 1) * horizon * ACT + (k - 32)];
+        zA[e] = to_bf16(v);
+    }
+    __syncthreads();
+    const unsigned short* Plane = P + lane * 4;   // this lane's 4 bf16 inside every A-operand block
+    const int xo = j * RS + 4 * g, zo = j * ZS + 4 * g, ho = j * HS + 4 * g;
+    float acc_cost = 0.f;
+    int cur = 0;
+    for (int t = 0; t < horizon; ++t) {
+        // ---- reward head on the state the step starts from: r1 = relu(W6 [h | z] + b6) ----
+        for (int ob = w; ob < HIDB; ob += 4) {
+            v4f a = bias4(P, B6, ob * 16 + 4 * g);
+            const unsigned short* W = Plane + W6 + (size_t)ob * K6B * BLK;
+            a = dot_blocks<DETB>(W, hb[cur] + xo, a);
+            a = dot_blocks<STB>(W + (size_t)DETB * BLK, zA + zo, a);
+            *reinterpret_cast<v4s*>(r1 + xo + ob * 16) = pack4(fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f));
+        }
+        // ---- x = relu(W1 [z | a] + b1) (independent of the reward head: same phase) ----
+        for (int ob = w; ob < HIDB; ob += 4) {
+            v4f a = bias4(P, B1, ob * 16 + 4 * g);
+            a = dot_blocks<K1B>(Plane + W1 + (size_t)ob * K1B * BLK, zA + zo, a);
+            *reinterpret_cast<v4s*>(xb + xo + ob * 16) = pack4(fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f));
+        }
+        __syncthreads();
+        // ---- r2 = relu(W7 r1 + b7);  GRU: h' = (1 - u) n + u h ----
+        for (int ob = w; ob < HIDB; ob += 4) {
+            v4f a = bias4(P, B7, ob * 16 + 4 * g);
+            a = dot_blocks<HIDB>(Plane + W7 + (size_t)ob * HIDB * BLK, r1 + xo, a);
+            *reinterpret_cast<v4s*>(r2 + xo + ob * 16) = pack4(fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f));
+        }
+        for (int ob = w; ob < DETB; ob += 4) {
+            const int bi = ob * 16 + 4 * g;
+            v4f ir = bias4(P, BGI, bi), iu = bias4(P, BGI, 16 * DETB + bi), in = bias4(P, BGI, 32 * DETB + bi);
+            v4f hr = bias4(P, BGH, bi), hu = bias4(P, BGH, 16 * DETB + bi), hn = bias4(P, BGH, 32 * DETB + bi);
+            ir = dot_blocks<HIDB>(Plane + WGI + (size_t)(ob) * HIDB * BLK, xb + xo, ir);
+            iu = dot_blocks<HIDB>(Plane + WGI + (size_t)(DETB + ob) * HIDB * BLK, xb + xo, iu);
+            in = dot_blocks<HIDB>(Plane + WGI + (size_t)(2 * DETB + ob) * HIDB * BLK, xb + xo, in);
+            hr = dot_blocks<DETB>(Plane + WGH + (size_t)(ob) * DETB * BLK, hb[cur] + xo, hr);
+            hu = dot_blocks<DETB>(Plane + WGH + (size_t)(DETB + ob) * DETB * BLK, hb[cur] + xo, hu);
+            hn = dot_blocks<DETB>(Plane + WGH + (size_t)(2 * DETB + ob) * DETB * BLK, hb[cur] + xo, hn);
+            float* hp = h32 + ho + ob * 16;
+            float nh[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float rg = sigmoidf_(ir[r] + hr[r]);
+                const float ug = sigmoidf_(iu[r] + hu[r]);
+                const float ng = tanhf(in[r] + rg * hn[r]);
+                nh[r] = (1.f - ug) * ng + ug * hp[r];
+                hp[r] = nh[r];
+            }
+            *reinterpret_cast<v4s*>(hb[cur ^ 1] + xo + ob * 16) = pack4(nh[0], nh[1], nh[2], nh[3]);
+        }
+        __syncthreads();
+        // ---- reward = W8 r2 + b8 (wave 0);  p = relu(W4 h' + b4) ----
+        if (w == 0) {
+            v4f a = bias4(P, B8, 4 * g);
+            a = dot_blocks<HIDB>(Plane + W8, r2 + xo, a);
+            const float c = -a[0];   // output 0 of trajectory j lives in lane (j, g = 0), register 0
+            if (t == 0 || cost_mode == 2) acc_cost = c;
+            else if (cost_mode == 0) acc_cost += c;
+            else acc_cost = (c < acc_cost || c != c) ? c : acc_cost;
+        }
+        for (int ob = w; ob < HIDB; ob += 4) {
+            v4f a = bias4(P, B4, ob * 16 + 4 * g);
+            a = dot_blocks<DETB>(Plane + W4 + (size_t)ob * DETB * BLK, hb[cur ^ 1] + xo, a);
+            *reinterpret_cast<v4s*>(xb + xo + ob * 16) = pack4(fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f));
+        }
+        __syncthreads();
+        // ---- z' = W5 p + b5 (waves 0, 1) and the next action (wave 3) -> [z | a] ----
+        if (w < STB) {
+            v4f a = bias4(P, B5, w * 16 + 4 * g);
+            a = dot_blocks<HIDB>(Plane + W5 + (size_t)w * HIDB * BLK, xb + xo, a);
+            *reinterpret_cast<v4s*>(zA + zo + w * 16) = pack4(a[0], a[1], a[2], a[3]);
+        } else if (w == 3 && t + 1 < horizon) {
+            const float* an = act + (size_t)(t + 1) * ACT;
+            if (g < 2) {   // lanes (j, 0): a[0..3]; lanes (j, 1): a[4], a[5], 0, 0
+                const float a0 = an[4 * g], a1 = an[4 * g + 1];
+                const float a2 = g == 0 ? an[2] : 0.f, a3 = g == 0 ? an[3] : 0.f;
+                *reinterpret_cast<v4s*>(zA + j * ZS + 32 + 4 * g) = pack4(a0, a1, a2, a3);
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (w == 0 && g == 0 && base + j < n) costs[base + j] = acc_cost;
+}
+}  // namespace
+
+hipError_t launch_rssm_rollout(int n, int horizon, int cost_mode, const unsigned short* params, const float* obs0,
+                               const float* actions, float* costs, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rssm_rollout_kernel, dim3((n + 15) / 16), dim3(256), 0, st, n, horizon, cost_mode, params, obs0, actions,
+                       costs);
+    return hipGetLastError();
+}
+}  // namespace icem

@@ -216,3 +216,82 @@ def declared_rssm(act_dim: int = 6, det: int = 200, stoch: int = 30, hidden: int
     if dtype is not None:
         net = net.to(dtype)
     return TorchForwardModel(net, lambda o, a: -net.reward(o), det + stoch, act_dim, dtype=dtype, device=device, env=env)
+
+
+def pack_rssm(module):
+    """The packed bf16 parameter buffer ``icem_rssm_rollout_cost`` reads (layout: icem_amd/csrc/icem_rssm.h) from a
+    ``declared_rssm`` module: every weight padded to multiples of 16, cut into 16 x 16 blocks stored as MFMA A operands
+    ``[out block][k block][lane = 16*g + i][v]`` = ``W[16*ob + i][16*kb + 4*g + v]``, each followed by its f32 bias."""
+    import torch
+    sd = {k: v.detach().float().cpu() for k, v in module.state_dict().items()}
+    det, st = module.det, module.stoch
+    assert (det, st) == (200, 30) and sd["inp.weight"].shape == (200, 36), "icem_rssm_rollout_cost is compiled for the declared sizes"
+
+    def pad(w, rows, cols, col_map=None):
+        out = torch.zeros(rows, cols)
+        if col_map is None:
+            out[:w.shape[0], :w.shape[1]] = w
+        else:
+            for (s0, s1, d0) in col_map:
+                out[:w.shape[0], d0:d0 + (s1 - s0)] = w[:, s0:s1]
+        return out
+
+    def gates(w, cols):   # [3*200, k] -> [3*208, cols]: each gate padded separately
+        return torch.cat([pad(w[i * det:(i + 1) * det], 208, cols) for i in range(3)], dim=0)
+
+    def gate_bias(b):
+        return torch.cat([pad(b[i * det:(i + 1) * det][None], 1, 208)[0] for i in range(3)])
+
+    layers = [
+        (pad(sd["inp.weight"], 208, 48, [(0, st, 0), (st, st + 6, 32)]), pad(sd["inp.bias"][None], 1, 208)[0]),
+        (gates(sd["gru.weight_ih"], 208), gate_bias(sd["gru.bias_ih"])),
+        (gates(sd["gru.weight_hh"], 208), gate_bias(sd["gru.bias_hh"])),
+        (pad(sd["prior1.weight"], 208, 208), pad(sd["prior1.bias"][None], 1, 208)[0]),
+        (pad(sd["prior2.weight"], 32, 208), pad(sd["prior2.bias"][None], 1, 32)[0]),
+        (pad(sd["rew1.weight"], 208, 240, [(0, det, 0), (det, det + st, 208)]), pad(sd["rew1.bias"][None], 1, 208)[0]),
+        (pad(sd["rew2.weight"], 208, 208), pad(sd["rew2.bias"][None], 1, 208)[0]),
+        (pad(sd["rew3.weight"], 16, 208), pad(sd["rew3.bias"][None], 1, 16)[0]),
+    ]
+    chunks = []
+    for w, b in layers:
+        ob, kb = w.shape[0] // 16, w.shape[1] // 16
+        blocks = w.reshape(ob, 16, kb, 4, 4).permute(0, 2, 3, 1, 4).contiguous()   # [ob, kb, g, i, v]
+        chunks.append(blocks.to(torch.bfloat16).view(torch.int16).reshape(-1))
+        chunks.append(b.contiguous().view(torch.int16).reshape(-1))                 # f32 bias as two 16-bit words each
+    return torch.cat(chunks)
+
+
+class DeviceRSSMModel(ForwardModel):
+    """The declared RSSM with its whole h-step rollout + cost fused into one HIP launch on the bf16 matrix cores
+    (``icem_rssm_rollout_cost``); ``MpcICemHip`` scores a population with it in a single kernel.  ``reference`` is the
+    f32 torch module the weights come from (``predict`` serves the reference-style NumPy interface through it)."""
+
+    def __init__(self, seed: int = 0, device="cuda:0", env=None):
+        super().__init__(env=env)
+        import torch
+        from . import _lib as L
+        self._tm = declared_rssm(seed=seed, device=device)
+        self.reference = self._tm.module
+        self.obs_dim, self.act_dim = 230, 6
+        self.device = torch.device(device)
+        self.params = pack_rssm(self.reference).to(self.device)
+        self.lib = L.load_library()
+        if self.params.numel() != self.lib.icem_rssm_param_elems():
+            raise RuntimeError("packed RSSM parameters do not match the library's layout")
+
+    def rollout_cost(self, obs, actions, cost_mode: int = 0):
+        """costs ``[n]`` (f32 device tensor) of f32 device action sequences ``[n, h, 6]`` from observation ``obs [230]``."""
+        import ctypes as C
+        import torch
+        from . import _lib as L
+        actions = actions.to(torch.float32).contiguous()
+        n, h, _ = actions.shape
+        o = torch.as_tensor(np.asarray(obs, dtype=np.float32), device=self.device)
+        costs = torch.empty((n,), dtype=torch.float32, device=self.device)
+        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        L.check(self.lib.icem_rssm_rollout_cost(n, h, cost_mode, C.c_void_p(self.params.data_ptr()), C.c_void_p(o.data_ptr()),
+                                                C.c_void_p(actions.data_ptr()), C.c_void_p(costs.data_ptr()), st))
+        return costs
+
+    def predict(self, *, observations, states, actions):
+        return self._tm.predict(observations=observations, states=states, actions=actions)

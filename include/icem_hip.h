@@ -323,6 +323,16 @@ int icem_profile_read(icem_handle* h, double* total_ms, int64_t* launches, int64
  * actions[h*d] (T)}; all-gather moves K records per rank. */
 size_t icem_record_bytes(const icem_handle* h);
 
+/* Learned-dynamics rollout (BASELINE configs[4]; the reference has no model code for it, README.md:21-29): the
+ * recurrent state-space model declared in icem_amd/models.py::declared_rssm, rolled out on its prior mean from
+ * obs0 = [h (200) | z (30)] (f32) along actions [n, horizon, 6] (f32) in ONE launch on the bf16 matrix cores
+ * (f32 accumulation, f32 recurrent state); costs[i] (f32) = reduce_t -reward(state_t) with cost_mode = ICEM_COST_*.
+ * params: the packed bf16 parameter buffer of icem_rssm_param_elems() elements (layout: icem_amd/csrc/icem_rssm.h;
+ * packer: icem_amd.models.pack_rssm).  Stateless: no handle. */
+size_t icem_rssm_param_elems(void);
+int icem_rssm_rollout_cost(int32_t n, int32_t horizon, int32_t cost_mode, const void* params, const void* obs0,
+                           const void* actions, void* costs, void* stream);
+
 /* MpcICem.get_action (icem/controllers/icem.py:106-189) as ONE call for a host caller: obs_host [obs_dim] float64
  * goes to b->obs0 through a pinned staging buffer of the handle, icem_plan_step runs, and the executed action
  * [act_dim] (+ the best cost of the last pool, if best_cost_host != NULL) comes back as float64 after ONE stream

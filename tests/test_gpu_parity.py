@@ -1372,3 +1372,81 @@ def test_get_action_host_call_equals_plan_step(dtype):
     ob = 0.1 * np.random.RandomState(5).randn(17)
     ctrl.beginning_of_rollout(observation=ob, state=None, mode="train")
     assert np.array_equal(ctrl.get_action(ob, None), np_(c.plan_step(ob))) and ctrl.last_min_cost == float(np_(c.best_cost)[0])
+
+
+@pytest.mark.parametrize("mode", ["sum", "best", "final"])
+def test_fused_rssm_rollout_kernel(mode):
+    """icem_rssm_rollout_cost (the declared RSSM's whole rollout + reward head in one launch, bf16 MFMA with f32
+    accumulation and f32 recurrent state) against (a) a float64 NumPy rollout of the same network with the weights and
+    the GEMM inputs rounded to bf16 exactly where the kernel rounds them -- tight; (b) the plain float64 network --
+    bf16 accuracy.  Ragged n (not a multiple of the 16-trajectory tile)."""
+    from icem_amd import DeviceRSSMModel
+    m = DeviceRSSMModel(seed=3)
+    n, h, d = 1000 + 7, 12, 6
+    rs = np.random.RandomState(4)
+    acts = rs.uniform(-1, 1, (n, h, d))
+    obs = 0.3 * rs.randn(230)
+    got = np_(m.rollout_cost(obs, torch.as_tensor(acts, dtype=torch.float32, device="cuda"), {"sum": 0, "best": 1, "final": 2}[mode]))
+
+    def bf(x):   # round to bf16 (nearest even), back to float64
+        return torch.as_tensor(np.asarray(x, dtype=np.float32)).to(torch.bfloat16).to(torch.float64).numpy()
+
+    P = {k: v.detach().cpu().double().numpy() for k, v in m.reference.state_dict().items()}
+    sig = lambda x: 1.0 / (1.0 + np.exp(-x))  # noqa: E731
+
+    def rollout(q):   # q: rounding applied to weights and to every GEMM input (identity = the exact network)
+        W = {k: (q(v) if k.endswith("weight") or "weight_" in k else v) for k, v in P.items()}
+        hh = np.broadcast_to(obs[:200].astype(np.float32).astype(np.float64), (n, 200)).copy()
+        z = np.broadcast_to(obs[200:].astype(np.float32).astype(np.float64), (n, 30)).copy()
+        steps = []
+        for t in range(h):
+            hq, zq, aq = q(hh), q(z), q(acts[:, t])
+            a1 = q(np.maximum(np.concatenate([hq, zq], -1) @ W["rew1.weight"].T + P["rew1.bias"], 0))
+            a2 = q(np.maximum(a1 @ W["rew2.weight"].T + P["rew2.bias"], 0))
+            steps.append(-(a2 @ W["rew3.weight"].T + P["rew3.bias"])[:, 0])
+            x = q(np.maximum(np.concatenate([zq, aq], -1) @ W["inp.weight"].T + P["inp.bias"], 0))
+            gi = x @ W["gru.weight_ih"].T + P["gru.bias_ih"]
+            gh = hq @ W["gru.weight_hh"].T + P["gru.bias_hh"]
+            r = sig(gi[:, :200] + gh[:, :200])
+            u = sig(gi[:, 200:400] + gh[:, 200:400])
+            nn = np.tanh(gi[:, 400:] + r * gh[:, 400:])
+            hh = (1 - u) * nn + u * hh
+            p = q(np.maximum(q(hh) @ W["prior1.weight"].T + P["prior1.bias"], 0))
+            z = p @ W["prior2.weight"].T + P["prior2.bias"]
+        s = np.stack(steps, 1)
+        return {"sum": s.sum(1), "best": s.min(1), "final": s[:, -1]}[mode]
+
+    emu, exact = rollout(bf), rollout(lambda x: x)
+    scale = 1 + np.abs(exact).max()
+    assert np.abs(got - emu).max() <= 2e-3 * scale, (np.abs(got - emu).max(), scale)
+    assert np.abs(got - exact).max() <= 5e-2 * scale and np.corrcoef(got, exact)[0, 1] > 0.99
+
+
+def test_config5_fused_rssm_behind_controller():
+    """BASELINE configs[4] with the fused kernel: MpcICemHip + DeviceRSSMModel (one launch per population) against the
+    oracle loop driving the bf16-exact... no: the float64 network; the planner's choice must agree up to bf16 cost noise:
+    the executed action's cost under the exact network is within bf16 accuracy of the oracle's best."""
+    from icem_amd import DeviceRSSMModel, MpcICemHip, declared_rssm, halfcheetah_env
+    N, h, d, iters, seed = 1024, 12, 6, 3, 5
+    env = halfcheetah_env(17)
+    asp = dict(alpha=0.1, elites_size=10, opt_iterations=iters, init_std=0.5, use_mean_actions=True,
+               keep_previous_elites=True, shift_elites_over_time=True, fraction_elites_reused=0.3, noise_beta=0.25)
+    fused = MpcICemHip(env=env, forward_model=DeviceRSSMModel(seed=3), horizon=h, num_simulated_trajectories=N,
+                       factor_decrease_num=1.25, cost_along_trajectory="sum", dtype="f32", seed=seed, action_sampler_params=asp)
+    torch32 = MpcICemHip(env=env, forward_model=declared_rssm(seed=3), horizon=h, num_simulated_trajectories=N,
+                         factor_decrease_num=1.25, cost_along_trajectory="sum", dtype="f32", seed=seed, action_sampler_params=asp)
+    assert fused.rssm_path and not fused.torch_path and torch32.torch_path
+    obs = 0.3 * np.random.RandomState(1).randn(230)
+    acts = torch.as_tensor(np.random.RandomState(2).uniform(-1, 1, (N, h, d)), dtype=torch.float32, device="cuda")
+    cf, ct = np_(fused._costs_of(obs, acts)), np_(torch32._costs_of(obs, acts))
+    assert np.abs(cf - ct).max() <= 0.05 * (1 + np.abs(ct).max()) and np.corrcoef(cf, ct)[0, 1] > 0.99
+    for c in (fused, torch32):
+        c.beginning_of_rollout(observation=obs, state=None, mode="train")
+    a_f, a_t = fused.get_action(obs, None), torch32.get_action(obs, None)
+    assert np.all(np.abs(a_f) <= 1.0)
+    # same Philox draws, costs equal up to bf16 noise: the two planners end on plans of (nearly) the same quality
+    assert abs(fused.last_min_cost - torch32.last_min_cost) <= 0.05 * (1 + abs(torch32.last_min_cost))
+    again = MpcICemHip(env=env, forward_model=DeviceRSSMModel(seed=3), horizon=h, num_simulated_trajectories=N,
+                       factor_decrease_num=1.25, cost_along_trajectory="sum", dtype="f32", seed=seed, action_sampler_params=asp)
+    again.beginning_of_rollout(observation=obs, state=None, mode="train")
+    assert np.array_equal(again.get_action(obs, None), a_f)   # deterministic

@@ -9,14 +9,14 @@ import numpy as np
 import torch
 
 sys.path.insert(0, ".")
-from icem_amd import MpcICemHip, declared_rssm, halfcheetah_env  # noqa: E402
+from icem_amd import DeviceRSSMModel, MpcICemHip, declared_rssm, halfcheetah_env  # noqa: E402
 
 N, h, d, iters = 1024, 12, 6, 5
 env = halfcheetah_env(17)
 asp = dict(alpha=0.1, elites_size=10, opt_iterations=iters, init_std=0.5, use_mean_actions=True, keep_previous_elites=True,
            shift_elites_over_time=True, fraction_elites_reused=0.3, noise_beta=0.25)
-for dtype in (None, torch.bfloat16):
-    m = declared_rssm(seed=3, dtype=dtype)
+for dtype in (None, torch.bfloat16, "fused"):
+    m = DeviceRSSMModel(seed=3) if dtype == "fused" else declared_rssm(seed=3, dtype=dtype)
     ctrl = MpcICemHip(env=env, forward_model=m, horizon=h, num_simulated_trajectories=N, factor_decrease_num=1.25,
                       cost_along_trajectory="sum", dtype="f32", seed=1, action_sampler_params=asp)
     obs = 0.3 * np.random.RandomState(1).randn(230)
@@ -30,9 +30,11 @@ for dtype in (None, torch.bfloat16):
         ctrl.get_action(obs, None)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    macs = sum(p.numel() for n_, p in m.module.named_parameters() if p.ndim == 2)   # one MAC per weight per trajectory-step
+    net = m.reference if dtype == "fused" else m.module
+    macs = sum(p.numel() for n_, p in net.named_parameters() if p.ndim == 2)   # one MAC per weight per trajectory-step
     pops = ctrl.planner.population_sizes
     flops = 2.0 * macs * sum(pops) * h
-    print(f"{'bf16' if dtype else 'f32 '}: {dt * 1e3:7.2f} ms per MPC step ({sum(pops)} trajectories x h={h}); "
+    label = {None: "torch f32 (graph)  ", torch.bfloat16: "torch bf16 (graph) ", "fused": "fused HIP bf16 MFMA"}[dtype]
+    print(f"{label}: {dt * 1e3:7.3f} ms per MPC step ({sum(pops)} trajectories x h={h}); "
           f"{flops / dt / 1e12:6.2f} TFLOP/s of model GEMMs = {100 * flops / dt / 2.5e15:.3f} % of the dense bf16 peak; "
           f"{sum(pops) * h / dt / 1e6:.2f} M traj-steps/s")
