@@ -28,23 +28,53 @@ __device__ __forceinline__ v4s pack4(float a, float b, float c, float d) {
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
-// acc += W[ob][0 .. KB) . X : W points at this lane's 4 bf16 of block (ob, 0); X at the lane's 4 bf16 of k-block 0
+// A wave owns output blocks w, w+4, w+8 and w+12 of a 13-block layer (the last one only exists for wave 0: the
+// others redo block 12 and drop the result -- cheaper than a divergent trip count, the matrix pipe is not the limit).
+// The weights come straight from L2, so what matters is how many loads are in flight: a layer first REQUESTS all of
+// the wave's A-operand blocks (NOB x KB 8-byte loads per lane), then runs the MFMAs.
+constexpr int NOB = 4;
+__device__ __forceinline__ int own_block(int w, int i) { const int ob = w + 4 * i; return ob < 13 ? ob : 12; }
+
 template <int KB>
-__device__ __forceinline__ v4f dot_blocks(const unsigned short* __restrict__ W, const unsigned short* X, v4f acc) {
+__device__ __forceinline__ void request(const unsigned short* __restrict__ W, v4s (&A)[KB]) {
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-        const v4s a = *reinterpret_cast<const v4s*>(W + (size_t)kb * BLK);
-        const v4s b = *reinterpret_cast<const v4s*>(X + kb * 16);
-        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc, 0, 0, 0);
-    }
+    for (int kb = 0; kb < KB; ++kb) A[kb] = *reinterpret_cast<const v4s*>(W + (size_t)kb * BLK);
+}
+template <int KB>
+__device__ __forceinline__ v4f mma(const v4s (&A)[KB], const unsigned short* X, v4f acc) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A[kb], *reinterpret_cast<const v4s*>(X + kb * 16), acc, 0, 0, 0);
     return acc;
 }
 __device__ __forceinline__ v4f bias4(const unsigned short* params, size_t off, int idx) {
     const float* b = reinterpret_cast<const float*>(params + off) + idx;
     return v4f{b[0], b[1], b[2], b[3]};
 }
+__device__ __forceinline__ v4s relu_pack(v4f a) { return pack4(fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f)); }
 
-__global__ __launch_bounds__(256) void rssm_rollout_kernel(int n, int horizon, int cost_mode, const unsigned short* __restrict__ P,
+// Y[:, own blocks] = relu(W X + b) for a 13-block layer with KB k-blocks; X: lane's row pointer, Y: likewise
+template <int KB, int BATCH = 4>
+__device__ __forceinline__ void dense13_relu(const unsigned short* __restrict__ P, const unsigned short* Plane, size_t woff,
+                                             size_t boff, const unsigned short* X, unsigned short* Y, int w, int g) {
+#pragma unroll
+    for (int half = 0; half < NOB; half += BATCH) {   // BATCH output blocks per batch: BATCH * KB 8-byte loads per lane in flight
+        v4s A[BATCH][KB];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) request<KB>(Plane + woff + (size_t)own_block(w, half + i) * KB * BLK, A[i]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+            const int ob = own_block(w, half + i);
+            const v4f a = mma<KB>(A[i], X, bias4(P, boff, ob * 16 + 4 * g));
+            if (w + 4 * (half + i) < 13) *reinterpret_cast<v4s*>(Y + ob * 16) = relu_pack(a);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__global__ __launch_bounds__(256) void rssm_rollout_kernel(int n, int horizon, int cost_mode, const unsigned short* __restrict__ Pg,
                                                            const float* __restrict__ obs0, const float* __restrict__ actions,
                                                            float* __restrict__ costs) {
     __shared__ __attribute__((aligned(16))) unsigned short zA[16 * ZS];       // [z_t | a_t]
@@ -53,7 +83,8 @@ __global__ __launch_bounds__(256) void rssm_rollout_kernel(int n, int horizon, i
     __shared__ __attribute__((aligned(16))) unsigned short r1[16 * RS];
     __shared__ __attribute__((aligned(16))) unsigned short r2[16 * RS];
     __shared__ __attribute__((aligned(16))) float h32[16 * HS];               // h_t in f32 (the recurrence)
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: block addresses stay scalar
     const int j = lane & 15, g = lane >> 4;
     const int base = blockIdx.x * 16;
     const int row = base + j < n ? base + j : n - 1;   // padding trajectories repeat the last one, never stored
@@ -75,74 +106,92 @@ __global__ __launch_bounds__(256) void rssm_rollout_kernel(int n, int horizon, i
         zA[e] = to_bf16(v);
     }
     __syncthreads();
-    const unsigned short* Plane = P + lane * 4;   // this lane's 4 bf16 inside every A-operand block
     const int xo = j * RS + 4 * g, zo = j * ZS + 4 * g, ho = j * HS + 4 * g;
     float acc_cost = 0.f;
     int cur = 0;
     for (int t = 0; t < horizon; ++t) {
-        // ---- reward head on the state the step starts from: r1 = relu(W6 [h | z] + b6) ----
-        for (int ob = w; ob < HIDB; ob += 4) {
-            v4f a = bias4(P, B6, ob * 16 + 4 * g);
-            const unsigned short* W = Plane + W6 + (size_t)ob * K6B * BLK;
-            a = dot_blocks<DETB>(W, hb[cur] + xo, a);
-            a = dot_blocks<STB>(W + (size_t)DETB * BLK, zA + zo, a);
-            *reinterpret_cast<v4s*>(r1 + xo + ob * 16) = pack4(fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f));
-        }
-        // ---- x = relu(W1 [z | a] + b1) (independent of the reward head: same phase) ----
-        for (int ob = w; ob < HIDB; ob += 4) {
-            v4f a = bias4(P, B1, ob * 16 + 4 * g);
-            a = dot_blocks<K1B>(Plane + W1 + (size_t)ob * K1B * BLK, zA + zo, a);
-            *reinterpret_cast<v4s*>(xb + xo + ob * 16) = pack4(fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f));
-        }
-        __syncthreads();
-        // ---- r2 = relu(W7 r1 + b7);  GRU: h' = (1 - u) n + u h ----
-        for (int ob = w; ob < HIDB; ob += 4) {
-            v4f a = bias4(P, B7, ob * 16 + 4 * g);
-            a = dot_blocks<HIDB>(Plane + W7 + (size_t)ob * HIDB * BLK, r1 + xo, a);
-            *reinterpret_cast<v4s*>(r2 + xo + ob * 16) = pack4(fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f));
-        }
-        for (int ob = w; ob < DETB; ob += 4) {
-            const int bi = ob * 16 + 4 * g;
-            v4f ir = bias4(P, BGI, bi), iu = bias4(P, BGI, 16 * DETB + bi), in = bias4(P, BGI, 32 * DETB + bi);
-            v4f hr = bias4(P, BGH, bi), hu = bias4(P, BGH, 16 * DETB + bi), hn = bias4(P, BGH, 32 * DETB + bi);
-            ir = dot_blocks<HIDB>(Plane + WGI + (size_t)(ob) * HIDB * BLK, xb + xo, ir);
-            iu = dot_blocks<HIDB>(Plane + WGI + (size_t)(DETB + ob) * HIDB * BLK, xb + xo, iu);
-            in = dot_blocks<HIDB>(Plane + WGI + (size_t)(2 * DETB + ob) * HIDB * BLK, xb + xo, in);
-            hr = dot_blocks<DETB>(Plane + WGH + (size_t)(ob) * DETB * BLK, hb[cur] + xo, hr);
-            hu = dot_blocks<DETB>(Plane + WGH + (size_t)(DETB + ob) * DETB * BLK, hb[cur] + xo, hu);
-            hn = dot_blocks<DETB>(Plane + WGH + (size_t)(2 * DETB + ob) * DETB * BLK, hb[cur] + xo, hn);
-            float* hp = h32 + ho + ob * 16;
-            float nh[4];
+        // the parameters do not depend on t, and the optimizer would gladly keep whatever fits of them in registers
+        // across steps (it filled all 512 and spilled): re-derive the pointer behind an opaque barrier every step
+        const unsigned short* P = Pg;
+        asm volatile("" : "+s"(P));
+        const unsigned short* Plane = P + lane * 4;   // this lane's 4 bf16 inside every A-operand block
+        // ---- phase 1 (reads h_t, z_t, a_t): r1 = relu(W6 [h | z] + b6) and x = relu(W1 [z | a] + b1) ----
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float rg = sigmoidf_(ir[r] + hr[r]);
-                const float ug = sigmoidf_(iu[r] + hu[r]);
-                const float ng = tanhf(in[r] + rg * hn[r]);
-                nh[r] = (1.f - ug) * ng + ug * hp[r];
-                hp[r] = nh[r];
+        for (int half = 0; half < NOB; half += 4) {
+            v4s Ah[4][DETB], Az[4][STB];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned short* W = Plane + W6 + (size_t)own_block(w, half + i) * K6B * BLK;
+                request<DETB>(W, Ah[i]);
+                request<STB>(W + (size_t)DETB * BLK, Az[i]);
             }
-            *reinterpret_cast<v4s*>(hb[cur ^ 1] + xo + ob * 16) = pack4(nh[0], nh[1], nh[2], nh[3]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ob = own_block(w, half + i);
+                v4f a = mma<DETB>(Ah[i], hb[cur] + xo, bias4(P, B6, ob * 16 + 4 * g));
+                a = mma<STB>(Az[i], zA + zo, a);
+                if (w + 4 * (half + i) < 13) *reinterpret_cast<v4s*>(r1 + xo + ob * 16) = relu_pack(a);
+            }
+        }
+        dense13_relu<K1B>(P, Plane, W1, B1, zA + zo, xb + xo, w, g);
+        __syncthreads();
+        // ---- phase 2: r2 = relu(W7 r1 + b7);  GRU h' = (1 - u) n + u h, one output block at a time ----
+        dense13_relu<HIDB>(P, Plane, W7, B7, r1 + xo, r2 + xo, w, g);
+#pragma unroll 1
+        for (int i = 0; i < NOB; ++i) {
+            const int ob = own_block(w, i), bi = ob * 16 + 4 * g;
+            v4f ir, iu, in, hr, hu, hn;
+            {   // all six gate matrices of this output block: 78 8-byte loads per lane in flight
+                v4s Ar[HIDB], Au[HIDB], An[HIDB], Br[DETB], Bu[DETB], Bn[DETB];
+                __builtin_amdgcn_sched_barrier(0);
+                request<HIDB>(Plane + WGI + (size_t)(ob) * HIDB * BLK, Ar);
+                request<HIDB>(Plane + WGI + (size_t)(DETB + ob) * HIDB * BLK, Au);
+                request<HIDB>(Plane + WGI + (size_t)(2 * DETB + ob) * HIDB * BLK, An);
+                request<DETB>(Plane + WGH + (size_t)(ob) * DETB * BLK, Br);
+                request<DETB>(Plane + WGH + (size_t)(DETB + ob) * DETB * BLK, Bu);
+                request<DETB>(Plane + WGH + (size_t)(2 * DETB + ob) * DETB * BLK, Bn);
+                __builtin_amdgcn_sched_barrier(0);
+                ir = mma<HIDB>(Ar, xb + xo, bias4(P, BGI, bi));
+                iu = mma<HIDB>(Au, xb + xo, bias4(P, BGI, 16 * DETB + bi));
+                in = mma<HIDB>(An, xb + xo, bias4(P, BGI, 32 * DETB + bi));
+                hr = mma<DETB>(Br, hb[cur] + xo, bias4(P, BGH, bi));
+                hu = mma<DETB>(Bu, hb[cur] + xo, bias4(P, BGH, 16 * DETB + bi));
+                hn = mma<DETB>(Bn, hb[cur] + xo, bias4(P, BGH, 32 * DETB + bi));
+            }
+            if (w + 4 * i < 13) {
+                float* hp = h32 + ho + ob * 16;
+                float nh[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float rg = sigmoidf_(ir[r] + hr[r]);
+                    const float ug = sigmoidf_(iu[r] + hu[r]);
+                    const float ng = tanhf(in[r] + rg * hn[r]);
+                    nh[r] = (1.f - ug) * ng + ug * hp[r];
+                    hp[r] = nh[r];
+                }
+                *reinterpret_cast<v4s*>(hb[cur ^ 1] + xo + ob * 16) = pack4(nh[0], nh[1], nh[2], nh[3]);
+            }
         }
         __syncthreads();
-        // ---- reward = W8 r2 + b8 (wave 0);  p = relu(W4 h' + b4) ----
+        // ---- phase 3: reward = W8 r2 + b8 (wave 0);  p = relu(W4 h' + b4) ----
         if (w == 0) {
-            v4f a = bias4(P, B8, 4 * g);
-            a = dot_blocks<HIDB>(Plane + W8, r2 + xo, a);
+            v4s A8[HIDB];
+            request<HIDB>(Plane + W8, A8);
+            const v4f a = mma<HIDB>(A8, r2 + xo, bias4(P, B8, 4 * g));
             const float c = -a[0];   // output 0 of trajectory j lives in lane (j, g = 0), register 0
             if (t == 0 || cost_mode == 2) acc_cost = c;
             else if (cost_mode == 0) acc_cost += c;
             else acc_cost = (c < acc_cost || c != c) ? c : acc_cost;
         }
-        for (int ob = w; ob < HIDB; ob += 4) {
-            v4f a = bias4(P, B4, ob * 16 + 4 * g);
-            a = dot_blocks<DETB>(Plane + W4 + (size_t)ob * DETB * BLK, hb[cur ^ 1] + xo, a);
-            *reinterpret_cast<v4s*>(xb + xo + ob * 16) = pack4(fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f));
-        }
+        dense13_relu<DETB>(P, Plane, W4, B4, hb[cur ^ 1] + xo, xb + xo, w, g);
         __syncthreads();
-        // ---- z' = W5 p + b5 (waves 0, 1) and the next action (wave 3) -> [z | a] ----
+        // ---- phase 4: z' = W5 p + b5 (waves 0, 1) and the next action (wave 3) -> [z | a] ----
         if (w < STB) {
-            v4f a = bias4(P, B5, w * 16 + 4 * g);
-            a = dot_blocks<HIDB>(Plane + W5 + (size_t)w * HIDB * BLK, xb + xo, a);
+            v4s A5[HIDB];
+            request<HIDB>(Plane + W5 + (size_t)w * HIDB * BLK, A5);
+            const v4f a = mma<HIDB>(A5, xb + xo, bias4(P, B5, w * 16 + 4 * g));
             *reinterpret_cast<v4s*>(zA + zo + w * 16) = pack4(a[0], a[1], a[2], a[3]);
         } else if (w == 3 && t + 1 < horizon) {
             const float* an = act + (size_t)(t + 1) * ACT;
