@@ -1,8 +1,8 @@
-// See icem_rssm.h.  One workgroup (4 wavefronts) per 16 trajectories.  Every layer is D = W-block . X^T with
+// See icem_rssm.h.  One workgroup (8 wavefronts) per 16 trajectories.  Every layer is D = W-block . X^T with
 // v_mfma_f32_16x16x16_bf16: the A operand is a 16 x 16 block of the weight (output row i = lane % 16, k = 4 * (lane / 16)
 // + 0..3), the B operand the activations (trajectory j = lane % 16, same k), and the result leaves lane (j, g) holding
 // outputs 4g .. 4g+3 of trajectory j -- exactly the slice that lane writes back (bias, activation, bf16) to the LDS
-// activation row it will later be read from as a B operand.  The four waves split a layer's output blocks; the
+// activation row it will later be read from as a B operand.  The waves split a layer's output blocks; the
 // weights stream from L2 (760 KB of bf16 per step, shared by all workgroups), the recurrent state stays in LDS in f32.
 #include "icem_rssm.h"
 
@@ -28,12 +28,14 @@ __device__ __forceinline__ v4s pack4(float a, float b, float c, float d) {
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
-// A wave owns output blocks w, w+4, w+8 and w+12 of a 13-block layer (the last one only exists for wave 0: the
-// others redo block 12 and drop the result -- cheaper than a divergent trip count, the matrix pipe is not the limit).
+// A wave owns output blocks w, w+WAVES, ... of a 13-block layer (waves without a last block redo block 12 and drop
+// the result -- cheaper than a divergent trip count, the matrix pipe is not the limit).
 // The weights come straight from L2, so what matters is how many loads are in flight: a layer first REQUESTS all of
 // the wave's A-operand blocks (NOB x KB 8-byte loads per lane), then runs the MFMAs.
-constexpr int NOB = 4;
-__device__ __forceinline__ int own_block(int w, int i) { const int ob = w + 4 * i; return ob < 13 ? ob : 12; }
+constexpr int WAVES = 8;                 // wavefronts per workgroup (two per SIMD: one's loads under the other's MFMAs)
+constexpr int NOB = (13 + WAVES - 1) / WAVES;
+constexpr int NTHR = 64 * WAVES;
+__device__ __forceinline__ int own_block(int w, int i) { const int ob = w + WAVES * i; return ob < 13 ? ob : 12; }
 
 template <int KB>
 __device__ __forceinline__ void request(const unsigned short* __restrict__ W, v4s (&A)[KB]) {
@@ -54,7 +56,7 @@ __device__ __forceinline__ v4f bias4(const unsigned short* params, size_t off, i
 __device__ __forceinline__ v4s relu_pack(v4f a) { return pack4(fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f)); }
 
 // Y[:, own blocks] = relu(W X + b) for a 13-block layer with KB k-blocks; X: lane's row pointer, Y: likewise
-template <int KB, int BATCH = 4>
+template <int KB, int BATCH = NOB>
 __device__ __forceinline__ void dense13_relu(const unsigned short* __restrict__ P, const unsigned short* Plane, size_t woff,
                                              size_t boff, const unsigned short* X, unsigned short* Y, int w, int g) {
 #pragma unroll
@@ -68,13 +70,13 @@ __device__ __forceinline__ void dense13_relu(const unsigned short* __restrict__ 
         for (int i = 0; i < BATCH; ++i) {
             const int ob = own_block(w, half + i);
             const v4f a = mma<KB>(A[i], X, bias4(P, boff, ob * 16 + 4 * g));
-            if (w + 4 * (half + i) < 13) *reinterpret_cast<v4s*>(Y + ob * 16) = relu_pack(a);
+            if (w + WAVES * (half + i) < 13) *reinterpret_cast<v4s*>(Y + ob * 16) = relu_pack(a);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
 }
 
-__global__ __launch_bounds__(256) void rssm_rollout_kernel(int n, int horizon, int cost_mode, const unsigned short* __restrict__ Pg,
+__global__ __launch_bounds__(NTHR) void rssm_rollout_kernel(int n, int horizon, int cost_mode, const unsigned short* __restrict__ Pg,
                                                            const float* __restrict__ obs0, const float* __restrict__ actions,
                                                            float* __restrict__ costs) {
     __shared__ __attribute__((aligned(16))) unsigned short zA[16 * ZS];       // [z_t | a_t]
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(256) void rssm_rollout_kernel(int n, int horizon, i
     const int row = base + j < n ? base + j : n - 1;   // padding trajectories repeat the last one, never stored
     const float* __restrict__ act = actions + (size_t)row * horizon * ACT;
     // ---- initial state: every trajectory starts from obs0 = [h (200) | z (30)] ----
-    for (int e = tid; e < 16 * RS; e += 256) {
+    for (int e = tid; e < 16 * RS; e += NTHR) {
         const int k = e % RS;
         const float v = k < DET ? obs0[k] : 0.f;
         hb[0][e] = to_bf16(v);
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) void rssm_rollout_kernel(int n, int horizon, i
         h32[e] = v;
         xb[e] = r1[e] = r2[e] = 0;
     }
-    for (int e = tid; e < 16 * ZS; e += 256) {
+    for (int e = tid; e < 16 * ZS; e += NTHR) {
         const int k = e % ZS, jj = e / ZS;
         float v = 0.f;
         if (k < STOCH) v = obs0[DET + k];
@@ -117,22 +119,22 @@ __global__ __launch_bounds__(256) void rssm_rollout_kernel(int n, int horizon, i
         const unsigned short* Plane = P + lane * 4;   // this lane's 4 bf16 inside every A-operand block
         // ---- phase 1 (reads h_t, z_t, a_t): r1 = relu(W6 [h | z] + b6) and x = relu(W1 [z | a] + b1) ----
 #pragma unroll
-        for (int half = 0; half < NOB; half += 4) {
-            v4s Ah[4][DETB], Az[4][STB];
+        for (int half = 0; half < NOB; half += NOB) {
+            v4s Ah[NOB][DETB], Az[NOB][STB];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NOB; ++i) {
                 const unsigned short* W = Plane + W6 + (size_t)own_block(w, half + i) * K6B * BLK;
                 request<DETB>(W, Ah[i]);
                 request<STB>(W + (size_t)DETB * BLK, Az[i]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NOB; ++i) {
                 const int ob = own_block(w, half + i);
                 v4f a = mma<DETB>(Ah[i], hb[cur] + xo, bias4(P, B6, ob * 16 + 4 * g));
                 a = mma<STB>(Az[i], zA + zo, a);
-                if (w + 4 * (half + i) < 13) *reinterpret_cast<v4s*>(r1 + xo + ob * 16) = relu_pack(a);
+                if (w + WAVES * (half + i) < 13) *reinterpret_cast<v4s*>(r1 + xo + ob * 16) = relu_pack(a);
             }
         }
         dense13_relu<K1B>(P, Plane, W1, B1, zA + zo, xb + xo, w, g);
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void rssm_rollout_kernel(int n, int horizon, i
                 hu = mma<DETB>(Bu, hb[cur] + xo, bias4(P, BGH, 16 * DETB + bi));
                 hn = mma<DETB>(Bn, hb[cur] + xo, bias4(P, BGH, 32 * DETB + bi));
             }
-            if (w + 4 * i < 13) {
+            if (w + WAVES * i < 13) {
                 float* hp = h32 + ho + ob * 16;
                 float nh[4];
 #pragma unroll
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256) void rssm_rollout_kernel(int n, int horizon, i
         }
         __syncthreads();
         // ---- phase 3: reward = W8 r2 + b8 (wave 0);  p = relu(W4 h' + b4) ----
-        if (w == 0) {
+        if (w == WAVES - 1) {   // the reward output block: a wave that owns one block less than wave 0
             v4s A8[HIDB];
             request<HIDB>(Plane + W8, A8);
             const v4f a = mma<HIDB>(A8, r2 + xo, bias4(P, B8, 4 * g));
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(256) void rssm_rollout_kernel(int n, int horizon, i
             request<HIDB>(Plane + W5 + (size_t)w * HIDB * BLK, A5);
             const v4f a = mma<HIDB>(A5, xb + xo, bias4(P, B5, w * 16 + 4 * g));
             *reinterpret_cast<v4s*>(zA + zo + w * 16) = pack4(a[0], a[1], a[2], a[3]);
-        } else if (w == 3 && t + 1 < horizon) {
+        } else if (w == STB && t + 1 < horizon) {
             const float* an = act + (size_t)(t + 1) * ACT;
             if (g < 2) {   // lanes (j, 0): a[0..3]; lanes (j, 1): a[4], a[5], 0, 0
                 const float a0 = an[4 * g], a1 = an[4 * g + 1];
@@ -204,14 +206,14 @@ __global__ __launch_bounds__(256) void rssm_rollout_kernel(int n, int horizon, i
         __syncthreads();
         cur ^= 1;
     }
-    if (w == 0 && g == 0 && base + j < n) costs[base + j] = acc_cost;
+    if (w == WAVES - 1 && g == 0 && base + j < n) costs[base + j] = acc_cost;
 }
 }  // namespace
 
 hipError_t launch_rssm_rollout(int n, int horizon, int cost_mode, const unsigned short* params, const float* obs0,
                                const float* actions, float* costs, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(rssm_rollout_kernel, dim3((n + 15) / 16), dim3(256), 0, st, n, horizon, cost_mode, params, obs0, actions,
+    hipLaunchKernelGGL(rssm_rollout_kernel, dim3((n + 15) / 16), dim3(NTHR), 0, st, n, horizon, cost_mode, params, obs0, actions,
                        costs);
     return hipGetLastError();
 }

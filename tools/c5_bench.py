@@ -8,7 +8,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from icem_amd import DeviceRSSMModel, MpcICemHip, declared_rssm, halfcheetah_env  # noqa: E402
 
 N, h, d, iters = 1024, 12, 6, 5
@@ -38,3 +38,24 @@ for dtype in (None, torch.bfloat16, "fused"):
     print(f"{label}: {dt * 1e3:7.3f} ms per MPC step ({sum(pops)} trajectories x h={h}); "
           f"{flops / dt / 1e12:6.2f} TFLOP/s of model GEMMs = {100 * flops / dt / 2.5e15:.3f} % of the dense bf16 peak; "
           f"{sum(pops) * h / dt / 1e6:.2f} M traj-steps/s")
+
+# the fused kernel alone: one launch = a whole population's 12-step rollout + reward head
+m = DeviceRSSMModel(seed=3)
+macs = sum(p.numel() for _, p in m.reference.named_parameters() if p.ndim == 2)
+obs = 0.3 * np.random.RandomState(1).randn(230)
+for n in (1024, 4096, 16384, 65536):
+    acts = torch.rand(n, h, d, device="cuda") * 2 - 1
+    for _ in range(3):
+        m.rollout_cost(obs, acts)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    reps = 20
+    for _ in range(reps):
+        m.rollout_cost(obs, acts)
+    ev[1].record()
+    torch.cuda.synchronize()
+    us = ev[0].elapsed_time(ev[1]) * 1e3 / reps
+    fl = 2.0 * macs * n * h
+    print(f"icem_rssm_rollout_cost n={n:6d}: {us:8.1f} us per launch, {fl / us / 1e6:7.1f} TFLOP/s = {100 * fl / us / 1e6 / 2500:.2f} % of the "
+          f"dense bf16 peak, {n * h / us:.1f} M traj-steps/s")

@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from icem_amd import IcemConfig, IcemPlanner  # noqa: E402
 from icem_amd import envs as E  # noqa: E402
 
