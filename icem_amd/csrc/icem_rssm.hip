@@ -55,44 +55,48 @@ __device__ __forceinline__ v4f bias4(const unsigned short* params, size_t off, i
 }
 __device__ __forceinline__ v4s relu_pack(v4f a) { return pack4(fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f)); }
 
-// Y[:, own blocks] = relu(W X + b) for a 13-block layer with KB k-blocks; X: lane's row pointer, Y: likewise
-template <int KB, int BATCH = NOB>
+// Y[:, own blocks] = relu(W X + b) for a 13-block layer with KB k-blocks, for TT tiles of 16 trajectories that share
+// every requested weight block; X / Y: the lane's row pointers in tile 0, xts: X's element stride between tiles
+template <int KB, int TT>
 __device__ __forceinline__ void dense13_relu(const unsigned short* __restrict__ P, const unsigned short* Plane, size_t woff,
-                                             size_t boff, const unsigned short* X, unsigned short* Y, int w, int g) {
+                                             size_t boff, const unsigned short* X, int xts, unsigned short* Y, int w, int g) {
+    v4s A[NOB][KB];
+    __builtin_amdgcn_sched_barrier(0);   // a layer's requests stay together, behind the previous layer's work
 #pragma unroll
-    for (int half = 0; half < NOB; half += BATCH) {   // BATCH output blocks per batch: BATCH * KB 8-byte loads per lane in flight
-        v4s A[BATCH][KB];
-        __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < NOB; ++i) request<KB>(Plane + woff + (size_t)own_block(w, i) * KB * BLK, A[i]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < BATCH; ++i) request<KB>(Plane + woff + (size_t)own_block(w, half + i) * KB * BLK, A[i]);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < NOB; ++i) {
+        const int ob = own_block(w, i);
+        const v4f b = bias4(P, boff, ob * 16 + 4 * g);
 #pragma unroll
-        for (int i = 0; i < BATCH; ++i) {
-            const int ob = own_block(w, half + i);
-            const v4f a = mma<KB>(A[i], X, bias4(P, boff, ob * 16 + 4 * g));
-            if (w + WAVES * (half + i) < 13) *reinterpret_cast<v4s*>(Y + ob * 16) = relu_pack(a);
+        for (int tt = 0; tt < TT; ++tt) {
+            const v4f a = mma<KB>(A[i], X + tt * xts, b);
+            if (w + WAVES * i < 13) *reinterpret_cast<v4s*>(Y + tt * 16 * RS + ob * 16) = relu_pack(a);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// TT tiles of 16 trajectories per workgroup: every weight block a wave requests feeds TT MFMAs (large populations are
+// bound by re-streaming the weights from L2 per tile; small ones want as many workgroups as possible: TT = 1)
+template <int TT>
 __global__ __launch_bounds__(NTHR) void rssm_rollout_kernel(int n, int horizon, int cost_mode, const unsigned short* __restrict__ Pg,
                                                            const float* __restrict__ obs0, const float* __restrict__ actions,
                                                            float* __restrict__ costs) {
-    __shared__ __attribute__((aligned(16))) unsigned short zA[16 * ZS];       // [z_t | a_t]
-    __shared__ __attribute__((aligned(16))) unsigned short hb[2][16 * RS];    // h_t in bf16 (operand), ping-pong
-    __shared__ __attribute__((aligned(16))) unsigned short xb[16 * RS];       // x, then p
-    __shared__ __attribute__((aligned(16))) unsigned short r1[16 * RS];
-    __shared__ __attribute__((aligned(16))) unsigned short r2[16 * RS];
-    __shared__ __attribute__((aligned(16))) float h32[16 * HS];               // h_t in f32 (the recurrence)
+    constexpr int NR = 16 * TT;   // trajectories (LDS rows) of the workgroup
+    __shared__ __attribute__((aligned(16))) unsigned short zA[NR * ZS];       // [z_t | a_t]
+    __shared__ __attribute__((aligned(16))) unsigned short hb[2][NR * RS];    // h_t in bf16 (operand), ping-pong
+    __shared__ __attribute__((aligned(16))) unsigned short xb[NR * RS];       // x, then p
+    __shared__ __attribute__((aligned(16))) unsigned short r1[NR * RS];
+    __shared__ __attribute__((aligned(16))) unsigned short r2[NR * RS];
+    __shared__ __attribute__((aligned(16))) float h32[NR * HS];               // h_t in f32 (the recurrence)
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: block addresses stay scalar
     const int j = lane & 15, g = lane >> 4;
-    const int base = blockIdx.x * 16;
-    const int row = base + j < n ? base + j : n - 1;   // padding trajectories repeat the last one, never stored
-    const float* __restrict__ act = actions + (size_t)row * horizon * ACT;
+    const int base = blockIdx.x * NR;
     // ---- initial state: every trajectory starts from obs0 = [h (200) | z (30)] ----
-    for (int e = tid; e < 16 * RS; e += NTHR) {
+    for (int e = tid; e < NR * RS; e += NTHR) {
         const int k = e % RS;
         const float v = k < DET ? obs0[k] : 0.f;
         hb[0][e] = to_bf16(v);
@@ -100,16 +104,18 @@ __global__ __launch_bounds__(NTHR) void rssm_rollout_kernel(int n, int horizon, 
         h32[e] = v;
         xb[e] = r1[e] = r2[e] = 0;
     }
-    for (int e = tid; e < 16 * ZS; e += NTHR) {
+    for (int e = tid; e < NR * ZS; e += NTHR) {
         const int k = e % ZS, jj = e / ZS;
         float v = 0.f;
         if (k < STOCH) v = obs0[DET + k];
         else if (k >= 32 && k < 32 + ACT) v = actions[(size_t)(base + jj < n ? base + jj : n - 1) * horizon * ACT + (k - 32)];
-        zA[e] = to_bf16(v);
+        zA[e] = to_bf16(v);   // padding trajectories repeat the last one, never stored
     }
     __syncthreads();
     const int xo = j * RS + 4 * g, zo = j * ZS + 4 * g, ho = j * HS + 4 * g;
-    float acc_cost = 0.f;
+    float acc_cost[TT];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) acc_cost[tt] = 0.f;
     int cur = 0;
     for (int t = 0; t < horizon; ++t) {
         // the parameters do not depend on t, and the optimizer would gladly keep whatever fits of them in registers
@@ -118,103 +124,127 @@ __global__ __launch_bounds__(NTHR) void rssm_rollout_kernel(int n, int horizon, 
         asm volatile("" : "+s"(P));
         const unsigned short* Plane = P + lane * 4;   // this lane's 4 bf16 inside every A-operand block
         // ---- phase 1 (reads h_t, z_t, a_t): r1 = relu(W6 [h | z] + b6) and x = relu(W1 [z | a] + b1) ----
-#pragma unroll
-        for (int half = 0; half < NOB; half += NOB) {
+        {
             v4s Ah[NOB][DETB], Az[NOB][STB];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < NOB; ++i) {
-                const unsigned short* W = Plane + W6 + (size_t)own_block(w, half + i) * K6B * BLK;
+                const unsigned short* W = Plane + W6 + (size_t)own_block(w, i) * K6B * BLK;
                 request<DETB>(W, Ah[i]);
                 request<STB>(W + (size_t)DETB * BLK, Az[i]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < NOB; ++i) {
-                const int ob = own_block(w, half + i);
-                v4f a = mma<DETB>(Ah[i], hb[cur] + xo, bias4(P, B6, ob * 16 + 4 * g));
-                a = mma<STB>(Az[i], zA + zo, a);
-                if (w + WAVES * (half + i) < 13) *reinterpret_cast<v4s*>(r1 + xo + ob * 16) = relu_pack(a);
+                const int ob = own_block(w, i);
+                const v4f b = bias4(P, B6, ob * 16 + 4 * g);
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) {
+                    v4f a = mma<DETB>(Ah[i], hb[cur] + tt * 16 * RS + xo, b);
+                    a = mma<STB>(Az[i], zA + tt * 16 * ZS + zo, a);
+                    if (w + WAVES * i < 13) *reinterpret_cast<v4s*>(r1 + tt * 16 * RS + xo + ob * 16) = relu_pack(a);
+                }
             }
         }
-        dense13_relu<K1B>(P, Plane, W1, B1, zA + zo, xb + xo, w, g);
+        dense13_relu<K1B, TT>(P, Plane, W1, B1, zA + zo, 16 * ZS, xb + xo, w, g);
         __syncthreads();
         // ---- phase 2: r2 = relu(W7 r1 + b7);  GRU h' = (1 - u) n + u h, one output block at a time ----
-        dense13_relu<HIDB>(P, Plane, W7, B7, r1 + xo, r2 + xo, w, g);
+        dense13_relu<HIDB, TT>(P, Plane, W7, B7, r1 + xo, 16 * RS, r2 + xo, w, g);
 #pragma unroll 1
         for (int i = 0; i < NOB; ++i) {
             const int ob = own_block(w, i), bi = ob * 16 + 4 * g;
-            v4f ir, iu, in, hr, hu, hn;
-            {   // all six gate matrices of this output block: 78 8-byte loads per lane in flight
-                v4s Ar[HIDB], Au[HIDB], An[HIDB], Br[DETB], Bu[DETB], Bn[DETB];
-                __builtin_amdgcn_sched_barrier(0);
-                request<HIDB>(Plane + WGI + (size_t)(ob) * HIDB * BLK, Ar);
-                request<HIDB>(Plane + WGI + (size_t)(DETB + ob) * HIDB * BLK, Au);
-                request<HIDB>(Plane + WGI + (size_t)(2 * DETB + ob) * HIDB * BLK, An);
-                request<DETB>(Plane + WGH + (size_t)(ob) * DETB * BLK, Br);
-                request<DETB>(Plane + WGH + (size_t)(DETB + ob) * DETB * BLK, Bu);
-                request<DETB>(Plane + WGH + (size_t)(2 * DETB + ob) * DETB * BLK, Bn);
-                __builtin_amdgcn_sched_barrier(0);
-                ir = mma<HIDB>(Ar, xb + xo, bias4(P, BGI, bi));
-                iu = mma<HIDB>(Au, xb + xo, bias4(P, BGI, 16 * DETB + bi));
-                in = mma<HIDB>(An, xb + xo, bias4(P, BGI, 32 * DETB + bi));
-                hr = mma<DETB>(Br, hb[cur] + xo, bias4(P, BGH, bi));
-                hu = mma<DETB>(Bu, hb[cur] + xo, bias4(P, BGH, 16 * DETB + bi));
-                hn = mma<DETB>(Bn, hb[cur] + xo, bias4(P, BGH, 32 * DETB + bi));
-            }
-            if (w + WAVES * i < 13) {
-                float* hp = h32 + ho + ob * 16;
-                float nh[4];
+            // all six gate matrices of this output block: 78 8-byte loads per lane in flight
+            v4s Ar[HIDB], Au[HIDB], An[HIDB], Br[DETB], Bu[DETB], Bn[DETB];
+            __builtin_amdgcn_sched_barrier(0);
+            request<HIDB>(Plane + WGI + (size_t)(ob) * HIDB * BLK, Ar);
+            request<HIDB>(Plane + WGI + (size_t)(DETB + ob) * HIDB * BLK, Au);
+            request<HIDB>(Plane + WGI + (size_t)(2 * DETB + ob) * HIDB * BLK, An);
+            request<DETB>(Plane + WGH + (size_t)(ob) * DETB * BLK, Br);
+            request<DETB>(Plane + WGH + (size_t)(DETB + ob) * DETB * BLK, Bu);
+            request<DETB>(Plane + WGH + (size_t)(2 * DETB + ob) * DETB * BLK, Bn);
+            __builtin_amdgcn_sched_barrier(0);
+            const v4f bir = bias4(P, BGI, bi), biu = bias4(P, BGI, 16 * DETB + bi), bin = bias4(P, BGI, 32 * DETB + bi);
+            const v4f bhr = bias4(P, BGH, bi), bhu = bias4(P, BGH, 16 * DETB + bi), bhn = bias4(P, BGH, 32 * DETB + bi);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float rg = sigmoidf_(ir[r] + hr[r]);
-                    const float ug = sigmoidf_(iu[r] + hu[r]);
-                    const float ng = tanhf(in[r] + rg * hn[r]);
-                    nh[r] = (1.f - ug) * ng + ug * hp[r];
-                    hp[r] = nh[r];
+            for (int tt = 0; tt < TT; ++tt) {
+                const unsigned short* X = xb + tt * 16 * RS + xo;
+                const unsigned short* H = hb[cur] + tt * 16 * RS + xo;
+                const v4f ir = mma<HIDB>(Ar, X, bir), iu = mma<HIDB>(Au, X, biu), in = mma<HIDB>(An, X, bin);
+                const v4f hr = mma<DETB>(Br, H, bhr), hu = mma<DETB>(Bu, H, bhu), hn = mma<DETB>(Bn, H, bhn);
+                if (w + WAVES * i < 13) {
+                    float* hp = h32 + tt * 16 * HS + ho + ob * 16;
+                    float nh[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float rg = sigmoidf_(ir[r] + hr[r]);
+                        const float ug = sigmoidf_(iu[r] + hu[r]);
+                        const float ng = tanhf(in[r] + rg * hn[r]);
+                        nh[r] = (1.f - ug) * ng + ug * hp[r];
+                        hp[r] = nh[r];
+                    }
+                    *reinterpret_cast<v4s*>(hb[cur ^ 1] + tt * 16 * RS + xo + ob * 16) = pack4(nh[0], nh[1], nh[2], nh[3]);
                 }
-                *reinterpret_cast<v4s*>(hb[cur ^ 1] + xo + ob * 16) = pack4(nh[0], nh[1], nh[2], nh[3]);
             }
         }
         __syncthreads();
-        // ---- phase 3: reward = W8 r2 + b8 (wave 0);  p = relu(W4 h' + b4) ----
+        // ---- phase 3: reward = W8 r2 + b8 (one wave);  p = relu(W4 h' + b4) ----
         if (w == WAVES - 1) {   // the reward output block: a wave that owns one block less than wave 0
             v4s A8[HIDB];
             request<HIDB>(Plane + W8, A8);
-            const v4f a = mma<HIDB>(A8, r2 + xo, bias4(P, B8, 4 * g));
-            const float c = -a[0];   // output 0 of trajectory j lives in lane (j, g = 0), register 0
-            if (t == 0 || cost_mode == 2) acc_cost = c;
-            else if (cost_mode == 0) acc_cost += c;
-            else acc_cost = (c < acc_cost || c != c) ? c : acc_cost;
+            const v4f b8 = bias4(P, B8, 4 * g);
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) {
+                const v4f a = mma<HIDB>(A8, r2 + tt * 16 * RS + xo, b8);
+                const float c = -a[0];   // output 0 of trajectory j lives in lane (j, g = 0), register 0
+                if (t == 0 || cost_mode == 2) acc_cost[tt] = c;
+                else if (cost_mode == 0) acc_cost[tt] += c;
+                else acc_cost[tt] = (c < acc_cost[tt] || c != c) ? c : acc_cost[tt];
+            }
         }
-        dense13_relu<DETB>(P, Plane, W4, B4, hb[cur ^ 1] + xo, xb + xo, w, g);
+        dense13_relu<DETB, TT>(P, Plane, W4, B4, hb[cur ^ 1] + xo, 16 * RS, xb + xo, w, g);
         __syncthreads();
-        // ---- phase 4: z' = W5 p + b5 (waves 0, 1) and the next action (wave 3) -> [z | a] ----
+        // ---- phase 4: z' = W5 p + b5 (waves 0, 1) and the next action (wave 2) -> [z | a] ----
         if (w < STB) {
             v4s A5[HIDB];
             request<HIDB>(Plane + W5 + (size_t)w * HIDB * BLK, A5);
-            const v4f a = mma<HIDB>(A5, xb + xo, bias4(P, B5, w * 16 + 4 * g));
-            *reinterpret_cast<v4s*>(zA + zo + w * 16) = pack4(a[0], a[1], a[2], a[3]);
+            const v4f b5 = bias4(P, B5, w * 16 + 4 * g);
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) {
+                const v4f a = mma<HIDB>(A5, xb + tt * 16 * RS + xo, b5);
+                *reinterpret_cast<v4s*>(zA + tt * 16 * ZS + zo + w * 16) = pack4(a[0], a[1], a[2], a[3]);
+            }
         } else if (w == STB && t + 1 < horizon) {
-            const float* an = act + (size_t)(t + 1) * ACT;
             if (g < 2) {   // lanes (j, 0): a[0..3]; lanes (j, 1): a[4], a[5], 0, 0
-                const float a0 = an[4 * g], a1 = an[4 * g + 1];
-                const float a2 = g == 0 ? an[2] : 0.f, a3 = g == 0 ? an[3] : 0.f;
-                *reinterpret_cast<v4s*>(zA + j * ZS + 32 + 4 * g) = pack4(a0, a1, a2, a3);
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) {
+                    const int rr = base + tt * 16 + j;
+                    const float* an = actions + ((size_t)(rr < n ? rr : n - 1) * horizon + (t + 1)) * ACT;
+                    const float a0 = an[4 * g], a1 = an[4 * g + 1];
+                    const float a2 = g == 0 ? an[2] : 0.f, a3 = g == 0 ? an[3] : 0.f;
+                    *reinterpret_cast<v4s*>(zA + (tt * 16 + j) * ZS + 32 + 4 * g) = pack4(a0, a1, a2, a3);
+                }
             }
         }
         __syncthreads();
         cur ^= 1;
     }
-    if (w == WAVES - 1 && g == 0 && base + j < n) costs[base + j] = acc_cost;
+    if (w == WAVES - 1 && g == 0) {
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt)
+            if (base + tt * 16 + j < n) costs[base + tt * 16 + j] = acc_cost[tt];
+    }
 }
 }  // namespace
 
 hipError_t launch_rssm_rollout(int n, int horizon, int cost_mode, const unsigned short* params, const float* obs0,
                                const float* actions, float* costs, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(rssm_rollout_kernel, dim3((n + 15) / 16), dim3(NTHR), 0, st, n, horizon, cost_mode, params, obs0, actions,
-                       costs);
+    if (n >= 8192)   // more tiles than CUs several times over: two tiles per workgroup share every weight load
+        hipLaunchKernelGGL(rssm_rollout_kernel<2>, dim3((n + 31) / 32), dim3(NTHR), 0, st, n, horizon, cost_mode, params, obs0,
+                           actions, costs);
+    else
+        hipLaunchKernelGGL(rssm_rollout_kernel<1>, dim3((n + 15) / 16), dim3(NTHR), 0, st, n, horizon, cost_mode, params, obs0,
+                           actions, costs);
     return hipGetLastError();
 }
 }  // namespace icem
