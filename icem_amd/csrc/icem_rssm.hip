@@ -26,7 +26,8 @@ __device__ __forceinline__ v4s pack4(float a, float b, float c, float d) {
     r[0] = (short)to_bf16(a); r[1] = (short)to_bf16(b); r[2] = (short)to_bf16(c); r[3] = (short)to_bf16(d);
     return r;
 }
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 2.f * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * x)) - 1.f; }  // ~1e-6: far inside bf16
 
 // A wave owns output blocks w, w+WAVES, ... of a 13-block layer (waves without a last block redo block 12 and drop
 // the result -- cheaper than a divergent trip count, the matrix pipe is not the limit).
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(NTHR) void rssm_rollout_kernel(int n, int horizon, 
                     for (int r = 0; r < 4; ++r) {
                         const float rg = sigmoidf_(ir[r] + hr[r]);
                         const float ug = sigmoidf_(iu[r] + hu[r]);
-                        const float ng = tanhf(in[r] + rg * hn[r]);
+                        const float ng = tanhf_(in[r] + rg * hn[r]);
                         nh[r] = (1.f - ug) * ng + ug * hp[r];
                         hp[r] = nh[r];
                     }
