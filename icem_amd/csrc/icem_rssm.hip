@@ -50,16 +50,26 @@ __device__ __forceinline__ v4f mma(const v4s (&A)[KB], const unsigned short* X, 
         acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A[kb], *reinterpret_cast<const v4s*>(X + kb * 16), acc, 0, 0, 0);
     return acc;
 }
-__device__ __forceinline__ v4f bias4(const unsigned short* params, size_t off, int idx) {
-    const float* b = reinterpret_cast<const float*>(params + off) + idx;
-    return v4f{b[0], b[1], b[2], b[3]};
+// The biases (2 128 floats) are copied to LDS once: read from global right in front of a layer's MFMAs they would put
+// an L2 round trip on every layer's critical path.
+constexpr int NBIAS = 16 * (HIDB + 3 * DETB + 3 * DETB + HIDB + STB + HIDB + HIDB + 1);
+__host__ __device__ constexpr int bias_slot(size_t off) {
+    return off == B1 ? 0 : off == BGI ? 16 * HIDB : off == BGH ? 16 * (HIDB + 3 * DETB) : off == B4 ? 16 * (HIDB + 6 * DETB)
+         : off == B5 ? 16 * (2 * HIDB + 6 * DETB) : off == B6 ? 16 * (2 * HIDB + 6 * DETB + STB)
+         : off == B7 ? 16 * (3 * HIDB + 6 * DETB + STB) : 16 * (4 * HIDB + 6 * DETB + STB);
+}
+constexpr int bias_len(size_t off) {
+    return off == B1 || off == B4 || off == B6 || off == B7 ? 16 * HIDB : off == BGI || off == BGH ? 48 * DETB : off == B5 ? 16 * STB : 16;
+}
+__device__ __forceinline__ v4f bias4(const float* bs, size_t off, int idx) {
+    return *reinterpret_cast<const v4f*>(bs + bias_slot(off) + idx);
 }
 __device__ __forceinline__ v4s relu_pack(v4f a) { return pack4(fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f)); }
 
 // Y[:, own blocks] = relu(W X + b) for a 13-block layer with KB k-blocks, for TT tiles of 16 trajectories that share
 // every requested weight block; X / Y: the lane's row pointers in tile 0, xts: X's element stride between tiles
 template <int KB, int TT>
-__device__ __forceinline__ void dense13_relu(const unsigned short* __restrict__ P, const unsigned short* Plane, size_t woff,
+__device__ __forceinline__ void dense13_relu(const float* P, const unsigned short* Plane, size_t woff,
                                              size_t boff, const unsigned short* X, int xts, unsigned short* Y, int w, int g) {
     v4s A[NOB][KB];
     __builtin_amdgcn_sched_barrier(0);   // a layer's requests stay together, behind the previous layer's work
@@ -92,6 +102,7 @@ __global__ __launch_bounds__(NTHR) void rssm_rollout_kernel(int n, int horizon, 
     __shared__ __attribute__((aligned(16))) unsigned short r1[NR * RS];
     __shared__ __attribute__((aligned(16))) unsigned short r2[NR * RS];
     __shared__ __attribute__((aligned(16))) float h32[NR * HS];               // h_t in f32 (the recurrence)
+    __shared__ __attribute__((aligned(16))) float bs[NBIAS];                  // all biases
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: block addresses stay scalar
     const int j = lane & 15, g = lane >> 4;
@@ -104,6 +115,13 @@ __global__ __launch_bounds__(NTHR) void rssm_rollout_kernel(int n, int horizon, 
         hb[1][e] = 0;
         h32[e] = v;
         xb[e] = r1[e] = r2[e] = 0;
+    }
+    {
+        constexpr size_t offs[8] = {B1, BGI, BGH, B4, B5, B6, B7, B8};
+#pragma unroll
+        for (int l = 0; l < 8; ++l)
+            for (int e = tid; e < bias_len(offs[l]); e += NTHR)
+                bs[bias_slot(offs[l]) + e] = reinterpret_cast<const float*>(Pg + offs[l])[e];
     }
     for (int e = tid; e < NR * ZS; e += NTHR) {
         const int k = e % ZS, jj = e / ZS;
@@ -138,7 +156,7 @@ __global__ __launch_bounds__(NTHR) void rssm_rollout_kernel(int n, int horizon, 
 #pragma unroll
             for (int i = 0; i < NOB; ++i) {
                 const int ob = own_block(w, i);
-                const v4f b = bias4(P, B6, ob * 16 + 4 * g);
+                const v4f b = bias4(bs, B6, ob * 16 + 4 * g);
 #pragma unroll
                 for (int tt = 0; tt < TT; ++tt) {
                     v4f a = mma<DETB>(Ah[i], hb[cur] + tt * 16 * RS + xo, b);
@@ -147,10 +165,10 @@ __global__ __launch_bounds__(NTHR) void rssm_rollout_kernel(int n, int horizon, 
                 }
             }
         }
-        dense13_relu<K1B, TT>(P, Plane, W1, B1, zA + zo, 16 * ZS, xb + xo, w, g);
+        dense13_relu<K1B, TT>(bs, Plane, W1, B1, zA + zo, 16 * ZS, xb + xo, w, g);
         __syncthreads();
         // ---- phase 2: r2 = relu(W7 r1 + b7);  GRU h' = (1 - u) n + u h, one output block at a time ----
-        dense13_relu<HIDB, TT>(P, Plane, W7, B7, r1 + xo, 16 * RS, r2 + xo, w, g);
+        dense13_relu<HIDB, TT>(bs, Plane, W7, B7, r1 + xo, 16 * RS, r2 + xo, w, g);
 #pragma unroll 1
         for (int i = 0; i < NOB; ++i) {
             const int ob = own_block(w, i), bi = ob * 16 + 4 * g;
@@ -164,8 +182,8 @@ __global__ __launch_bounds__(NTHR) void rssm_rollout_kernel(int n, int horizon, 
             request<DETB>(Plane + WGH + (size_t)(DETB + ob) * DETB * BLK, Bu);
             request<DETB>(Plane + WGH + (size_t)(2 * DETB + ob) * DETB * BLK, Bn);
             __builtin_amdgcn_sched_barrier(0);
-            const v4f bir = bias4(P, BGI, bi), biu = bias4(P, BGI, 16 * DETB + bi), bin = bias4(P, BGI, 32 * DETB + bi);
-            const v4f bhr = bias4(P, BGH, bi), bhu = bias4(P, BGH, 16 * DETB + bi), bhn = bias4(P, BGH, 32 * DETB + bi);
+            const v4f bir = bias4(bs, BGI, bi), biu = bias4(bs, BGI, 16 * DETB + bi), bin = bias4(bs, BGI, 32 * DETB + bi);
+            const v4f bhr = bias4(bs, BGH, bi), bhu = bias4(bs, BGH, 16 * DETB + bi), bhn = bias4(bs, BGH, 32 * DETB + bi);
 #pragma unroll
             for (int tt = 0; tt < TT; ++tt) {
                 const unsigned short* X = xb + tt * 16 * RS + xo;
@@ -192,7 +210,7 @@ __global__ __launch_bounds__(NTHR) void rssm_rollout_kernel(int n, int horizon, 
         if (w == WAVES - 1) {   // the reward output block: a wave that owns one block less than wave 0
             v4s A8[HIDB];
             request<HIDB>(Plane + W8, A8);
-            const v4f b8 = bias4(P, B8, 4 * g);
+            const v4f b8 = bias4(bs, B8, 4 * g);
 #pragma unroll
             for (int tt = 0; tt < TT; ++tt) {
                 const v4f a = mma<HIDB>(A8, r2 + tt * 16 * RS + xo, b8);
@@ -202,13 +220,13 @@ __global__ __launch_bounds__(NTHR) void rssm_rollout_kernel(int n, int horizon, 
                 else acc_cost[tt] = (c < acc_cost[tt] || c != c) ? c : acc_cost[tt];
             }
         }
-        dense13_relu<DETB, TT>(P, Plane, W4, B4, hb[cur ^ 1] + xo, 16 * RS, xb + xo, w, g);
+        dense13_relu<DETB, TT>(bs, Plane, W4, B4, hb[cur ^ 1] + xo, 16 * RS, xb + xo, w, g);
         __syncthreads();
         // ---- phase 4: z' = W5 p + b5 (waves 0, 1) and the next action (wave 2) -> [z | a] ----
         if (w < STB) {
             v4s A5[HIDB];
             request<HIDB>(Plane + W5 + (size_t)w * HIDB * BLK, A5);
-            const v4f b5 = bias4(P, B5, w * 16 + 4 * g);
+            const v4f b5 = bias4(bs, B5, w * 16 + 4 * g);
 #pragma unroll
             for (int tt = 0; tt < TT; ++tt) {
                 const v4f a = mma<HIDB>(A5, xb + tt * 16 * RS + xo, b5);
