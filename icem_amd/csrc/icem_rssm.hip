@@ -1,6 +1,6 @@
 // See icem_rssm.h.  One workgroup (8 wavefronts) per 16 trajectories.  Every layer is D = W-block . X^T with
-// v_mfma_f32_16x16x16_bf16: the A operand is a 16 x 16 block of the weight (output row i = lane % 16, k = 4 * (lane / 16)
-// + 0..3), the B operand the activations (trajectory j = lane % 16, same k), and the result leaves lane (j, g) holding
+// v_mfma_f32_16x16x32_bf16: the A operand is a 16 x 32 block of the weight (output row i = lane % 16, k = 8 * (lane / 16)
+// + 0..7), the B operand the activations (trajectory j = lane % 16, same k), and the result leaves lane (j, g) holding
 // outputs 4g .. 4g+3 of trajectory j -- exactly the slice that lane writes back (bias, activation, bf16) to the LDS
 // activation row it will later be read from as a B operand.  The waves split a layer's output blocks; the
 // weights stream from L2 (760 KB of bf16 per step, shared by all workgroups), the recurrent state stays in LDS in f32.
@@ -10,10 +10,12 @@ namespace icem {
 namespace {
 using namespace rssm;
 typedef short v4s __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-constexpr int RS = 212;   // bf16 row stride of the 208-wide activation rows (424 B: conflict-free 8-byte reads)
-constexpr int ZS = 52;    // ... of the [z | a] row (48 wide)
+constexpr int RS = 232;   // bf16 row stride of the 224-wide activation rows (208 used + zero padding to the K blocks)
+constexpr int ZS = 72;    // ... of the [z (32) | a (32)] row
 constexpr int HS = 212;   // f32 row stride of the recurrent state
 
 __device__ __forceinline__ unsigned short to_bf16(float x) {   // round to nearest even
@@ -39,15 +41,17 @@ constexpr int NTHR = 64 * WAVES;
 __device__ __forceinline__ int own_block(int w, int i) { const int ob = w + WAVES * i; return ob < 13 ? ob : 12; }
 
 template <int KB>
-__device__ __forceinline__ void request(const unsigned short* __restrict__ W, v4s (&A)[KB]) {
+__device__ __forceinline__ void request(const unsigned short* __restrict__ W, v4i (&A)[KB]) {
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) A[kb] = *reinterpret_cast<const v4s*>(W + (size_t)kb * BLK);
+    for (int kb = 0; kb < KB; ++kb) A[kb] = *reinterpret_cast<const v4i*>(W + (size_t)kb * BLK);
 }
+// X: the lane's 8 bf16 of k-block 0 (row j, column 8 * g)
 template <int KB>
-__device__ __forceinline__ v4f mma(const v4s (&A)[KB], const unsigned short* X, v4f acc) {
+__device__ __forceinline__ v4f mma(const v4i (&A)[KB], const unsigned short* X, v4f acc) {
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb)
-        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A[kb], *reinterpret_cast<const v4s*>(X + kb * 16), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, A[kb]),
+                                                      __builtin_bit_cast(v8bf, *reinterpret_cast<const v4i*>(X + kb * 32)), acc, 0, 0, 0);
     return acc;
 }
 // The biases (2 128 floats) are copied to LDS once: read from global right in front of a layer's MFMAs they would put
@@ -71,7 +75,7 @@ __device__ __forceinline__ v4s relu_pack(v4f a) { return pack4(fmaxf(a[0], 0.f),
 template <int KB, int TT>
 __device__ __forceinline__ void dense13_relu(const float* P, const unsigned short* Plane, size_t woff,
                                              size_t boff, const unsigned short* X, int xts, unsigned short* Y, int w, int g) {
-    v4s A[NOB][KB];
+    v4i A[NOB][KB];
     __builtin_amdgcn_sched_barrier(0);   // a layer's requests stay together, behind the previous layer's work
 #pragma unroll
     for (int i = 0; i < NOB; ++i) request<KB>(Plane + woff + (size_t)own_block(w, i) * KB * BLK, A[i]);
@@ -113,9 +117,9 @@ __global__ __launch_bounds__(NTHR) void rssm_rollout_kernel(int n, int horizon, 
         const float v = k < DET ? obs0[k] : 0.f;
         hb[0][e] = to_bf16(v);
         hb[1][e] = 0;
-        h32[e] = v;
         xb[e] = r1[e] = r2[e] = 0;
     }
+    for (int e = tid; e < NR * HS; e += NTHR) h32[e] = (e % HS) < DET ? obs0[e % HS] : 0.f;
     {
         constexpr size_t offs[8] = {B1, BGI, BGH, B4, B5, B6, B7, B8};
 #pragma unroll
@@ -131,7 +135,8 @@ __global__ __launch_bounds__(NTHR) void rssm_rollout_kernel(int n, int horizon, 
         zA[e] = to_bf16(v);   // padding trajectories repeat the last one, never stored
     }
     __syncthreads();
-    const int xo = j * RS + 4 * g, zo = j * ZS + 4 * g, ho = j * HS + 4 * g;
+    const int xr = j * RS + 8 * g, zr = j * ZS + 8 * g;   // operand reads: 8 bf16 of a 32-wide k-block
+    const int xo = j * RS + 4 * g, zo = j * ZS + 4 * g, ho = j * HS + 4 * g;   // result writes: 4 outputs of a 16-wide block
     float acc_cost[TT];
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) acc_cost[tt] = 0.f;
@@ -141,16 +146,16 @@ __global__ __launch_bounds__(NTHR) void rssm_rollout_kernel(int n, int horizon, 
         // across steps (it filled all 512 and spilled): re-derive the pointer behind an opaque barrier every step
         const unsigned short* P = Pg;
         asm volatile("" : "+s"(P));
-        const unsigned short* Plane = P + lane * 4;   // this lane's 4 bf16 inside every A-operand block
+        const unsigned short* Plane = P + lane * 8;   // this lane's 8 bf16 inside every A-operand block
         // ---- phase 1 (reads h_t, z_t, a_t): r1 = relu(W6 [h | z] + b6) and x = relu(W1 [z | a] + b1) ----
         {
-            v4s Ah[NOB][DETB], Az[NOB][STB];
+            v4i Ah[NOB][DETK], Az[NOB][STK];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < NOB; ++i) {
-                const unsigned short* W = Plane + W6 + (size_t)own_block(w, i) * K6B * BLK;
-                request<DETB>(W, Ah[i]);
-                request<STB>(W + (size_t)DETB * BLK, Az[i]);
+                const unsigned short* W = Plane + W6 + (size_t)own_block(w, i) * K6K * BLK;
+                request<DETK>(W, Ah[i]);
+                request<STK>(W + (size_t)DETK * BLK, Az[i]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -159,37 +164,37 @@ __global__ __launch_bounds__(NTHR) void rssm_rollout_kernel(int n, int horizon, 
                 const v4f b = bias4(bs, B6, ob * 16 + 4 * g);
 #pragma unroll
                 for (int tt = 0; tt < TT; ++tt) {
-                    v4f a = mma<DETB>(Ah[i], hb[cur] + tt * 16 * RS + xo, b);
-                    a = mma<STB>(Az[i], zA + tt * 16 * ZS + zo, a);
+                    v4f a = mma<DETK>(Ah[i], hb[cur] + tt * 16 * RS + xr, b);
+                    a = mma<STK>(Az[i], zA + tt * 16 * ZS + zr, a);
                     if (w + WAVES * i < 13) *reinterpret_cast<v4s*>(r1 + tt * 16 * RS + xo + ob * 16) = relu_pack(a);
                 }
             }
         }
-        dense13_relu<K1B, TT>(bs, Plane, W1, B1, zA + zo, 16 * ZS, xb + xo, w, g);
+        dense13_relu<K1K, TT>(bs, Plane, W1, B1, zA + zr, 16 * ZS, xb + xo, w, g);
         __syncthreads();
         // ---- phase 2: r2 = relu(W7 r1 + b7);  GRU h' = (1 - u) n + u h, one output block at a time ----
-        dense13_relu<HIDB, TT>(bs, Plane, W7, B7, r1 + xo, 16 * RS, r2 + xo, w, g);
+        dense13_relu<HIDK, TT>(bs, Plane, W7, B7, r1 + xr, 16 * RS, r2 + xo, w, g);
 #pragma unroll 1
         for (int i = 0; i < NOB; ++i) {
             const int ob = own_block(w, i), bi = ob * 16 + 4 * g;
             // all six gate matrices of this output block: 78 8-byte loads per lane in flight
-            v4s Ar[HIDB], Au[HIDB], An[HIDB], Br[DETB], Bu[DETB], Bn[DETB];
+            v4i Ar[HIDK], Au[HIDK], An[HIDK], Br[DETK], Bu[DETK], Bn[DETK];
             __builtin_amdgcn_sched_barrier(0);
-            request<HIDB>(Plane + WGI + (size_t)(ob) * HIDB * BLK, Ar);
-            request<HIDB>(Plane + WGI + (size_t)(DETB + ob) * HIDB * BLK, Au);
-            request<HIDB>(Plane + WGI + (size_t)(2 * DETB + ob) * HIDB * BLK, An);
-            request<DETB>(Plane + WGH + (size_t)(ob) * DETB * BLK, Br);
-            request<DETB>(Plane + WGH + (size_t)(DETB + ob) * DETB * BLK, Bu);
-            request<DETB>(Plane + WGH + (size_t)(2 * DETB + ob) * DETB * BLK, Bn);
+            request<HIDK>(Plane + WGI + (size_t)(ob) * HIDK * BLK, Ar);
+            request<HIDK>(Plane + WGI + (size_t)(DETB + ob) * HIDK * BLK, Au);
+            request<HIDK>(Plane + WGI + (size_t)(2 * DETB + ob) * HIDK * BLK, An);
+            request<DETK>(Plane + WGH + (size_t)(ob) * DETK * BLK, Br);
+            request<DETK>(Plane + WGH + (size_t)(DETB + ob) * DETK * BLK, Bu);
+            request<DETK>(Plane + WGH + (size_t)(2 * DETB + ob) * DETK * BLK, Bn);
             __builtin_amdgcn_sched_barrier(0);
             const v4f bir = bias4(bs, BGI, bi), biu = bias4(bs, BGI, 16 * DETB + bi), bin = bias4(bs, BGI, 32 * DETB + bi);
             const v4f bhr = bias4(bs, BGH, bi), bhu = bias4(bs, BGH, 16 * DETB + bi), bhn = bias4(bs, BGH, 32 * DETB + bi);
 #pragma unroll
             for (int tt = 0; tt < TT; ++tt) {
-                const unsigned short* X = xb + tt * 16 * RS + xo;
-                const unsigned short* H = hb[cur] + tt * 16 * RS + xo;
-                const v4f ir = mma<HIDB>(Ar, X, bir), iu = mma<HIDB>(Au, X, biu), in = mma<HIDB>(An, X, bin);
-                const v4f hr = mma<DETB>(Br, H, bhr), hu = mma<DETB>(Bu, H, bhu), hn = mma<DETB>(Bn, H, bhn);
+                const unsigned short* X = xb + tt * 16 * RS + xr;
+                const unsigned short* H = hb[cur] + tt * 16 * RS + xr;
+                const v4f ir = mma<HIDK>(Ar, X, bir), iu = mma<HIDK>(Au, X, biu), in = mma<HIDK>(An, X, bin);
+                const v4f hr = mma<DETK>(Br, H, bhr), hu = mma<DETK>(Bu, H, bhu), hn = mma<DETK>(Bn, H, bhn);
                 if (w + WAVES * i < 13) {
                     float* hp = h32 + tt * 16 * HS + ho + ob * 16;
                     float nh[4];
@@ -208,28 +213,28 @@ __global__ __launch_bounds__(NTHR) void rssm_rollout_kernel(int n, int horizon, 
         __syncthreads();
         // ---- phase 3: reward = W8 r2 + b8 (one wave);  p = relu(W4 h' + b4) ----
         if (w == WAVES - 1) {   // the reward output block: a wave that owns one block less than wave 0
-            v4s A8[HIDB];
-            request<HIDB>(Plane + W8, A8);
+            v4i A8[HIDK];
+            request<HIDK>(Plane + W8, A8);
             const v4f b8 = bias4(bs, B8, 4 * g);
 #pragma unroll
             for (int tt = 0; tt < TT; ++tt) {
-                const v4f a = mma<HIDB>(A8, r2 + tt * 16 * RS + xo, b8);
+                const v4f a = mma<HIDK>(A8, r2 + tt * 16 * RS + xr, b8);
                 const float c = -a[0];   // output 0 of trajectory j lives in lane (j, g = 0), register 0
                 if (t == 0 || cost_mode == 2) acc_cost[tt] = c;
                 else if (cost_mode == 0) acc_cost[tt] += c;
                 else acc_cost[tt] = (c < acc_cost[tt] || c != c) ? c : acc_cost[tt];
             }
         }
-        dense13_relu<DETB, TT>(bs, Plane, W4, B4, hb[cur ^ 1] + xo, 16 * RS, xb + xo, w, g);
+        dense13_relu<DETK, TT>(bs, Plane, W4, B4, hb[cur ^ 1] + xr, 16 * RS, xb + xo, w, g);
         __syncthreads();
         // ---- phase 4: z' = W5 p + b5 (waves 0, 1) and the next action (wave 2) -> [z | a] ----
         if (w < STB) {
-            v4s A5[HIDB];
-            request<HIDB>(Plane + W5 + (size_t)w * HIDB * BLK, A5);
+            v4i A5[HIDK];
+            request<HIDK>(Plane + W5 + (size_t)w * HIDK * BLK, A5);
             const v4f b5 = bias4(bs, B5, w * 16 + 4 * g);
 #pragma unroll
             for (int tt = 0; tt < TT; ++tt) {
-                const v4f a = mma<HIDB>(A5, xb + tt * 16 * RS + xo, b5);
+                const v4f a = mma<HIDK>(A5, xb + tt * 16 * RS + xr, b5);
                 *reinterpret_cast<v4s*>(zA + tt * 16 * ZS + zo + w * 16) = pack4(a[0], a[1], a[2], a[3]);
             }
         } else if (w == STB && t + 1 < horizon) {

@@ -220,8 +220,9 @@ def declared_rssm(act_dim: int = 6, det: int = 200, stoch: int = 30, hidden: int
 
 def pack_rssm(module):
     """The packed bf16 parameter buffer ``icem_rssm_rollout_cost`` reads (layout: icem_amd/csrc/icem_rssm.h) from a
-    ``declared_rssm`` module: every weight padded to multiples of 16, cut into 16 x 16 blocks stored as MFMA A operands
-    ``[out block][k block][lane = 16*g + i][v]`` = ``W[16*ob + i][16*kb + 4*g + v]``, each followed by its f32 bias."""
+    ``declared_rssm`` module: every weight padded (outputs to multiples of 16, contraction to multiples of 32), cut
+    into 16 x 32 blocks stored as ``v_mfma_f32_16x16x32_bf16`` A operands ``[out block][k block][lane = 16*g + i][v]``
+    = ``W[16*ob + i][32*kb + 8*g + v]``, each layer followed by its f32 bias."""
     import torch
     sd = {k: v.detach().float().cpu() for k, v in module.state_dict().items()}
     det, st = module.det, module.stoch
@@ -243,19 +244,19 @@ def pack_rssm(module):
         return torch.cat([pad(b[i * det:(i + 1) * det][None], 1, 208)[0] for i in range(3)])
 
     layers = [
-        (pad(sd["inp.weight"], 208, 48, [(0, st, 0), (st, st + 6, 32)]), pad(sd["inp.bias"][None], 1, 208)[0]),
-        (gates(sd["gru.weight_ih"], 208), gate_bias(sd["gru.bias_ih"])),
-        (gates(sd["gru.weight_hh"], 208), gate_bias(sd["gru.bias_hh"])),
-        (pad(sd["prior1.weight"], 208, 208), pad(sd["prior1.bias"][None], 1, 208)[0]),
-        (pad(sd["prior2.weight"], 32, 208), pad(sd["prior2.bias"][None], 1, 32)[0]),
-        (pad(sd["rew1.weight"], 208, 240, [(0, det, 0), (det, det + st, 208)]), pad(sd["rew1.bias"][None], 1, 208)[0]),
-        (pad(sd["rew2.weight"], 208, 208), pad(sd["rew2.bias"][None], 1, 208)[0]),
-        (pad(sd["rew3.weight"], 16, 208), pad(sd["rew3.bias"][None], 1, 16)[0]),
+        (pad(sd["inp.weight"], 208, 64, [(0, st, 0), (st, st + 6, 32)]), pad(sd["inp.bias"][None], 1, 208)[0]),
+        (gates(sd["gru.weight_ih"], 224), gate_bias(sd["gru.bias_ih"])),
+        (gates(sd["gru.weight_hh"], 224), gate_bias(sd["gru.bias_hh"])),
+        (pad(sd["prior1.weight"], 208, 224), pad(sd["prior1.bias"][None], 1, 208)[0]),
+        (pad(sd["prior2.weight"], 32, 224), pad(sd["prior2.bias"][None], 1, 32)[0]),
+        (pad(sd["rew1.weight"], 208, 256, [(0, det, 0), (det, det + st, 224)]), pad(sd["rew1.bias"][None], 1, 208)[0]),
+        (pad(sd["rew2.weight"], 208, 224), pad(sd["rew2.bias"][None], 1, 208)[0]),
+        (pad(sd["rew3.weight"], 16, 224), pad(sd["rew3.bias"][None], 1, 16)[0]),
     ]
     chunks = []
     for w, b in layers:
-        ob, kb = w.shape[0] // 16, w.shape[1] // 16
-        blocks = w.reshape(ob, 16, kb, 4, 4).permute(0, 2, 3, 1, 4).contiguous()   # [ob, kb, g, i, v]
+        ob, kb = w.shape[0] // 16, w.shape[1] // 32
+        blocks = w.reshape(ob, 16, kb, 4, 8).permute(0, 2, 3, 1, 4).contiguous()   # [ob, kb, g, i, v]
         chunks.append(blocks.to(torch.bfloat16).view(torch.int16).reshape(-1))
         chunks.append(b.contiguous().view(torch.int16).reshape(-1))                 # f32 bias as two 16-bit words each
     return torch.cat(chunks)
