@@ -1374,15 +1374,17 @@ def test_get_action_host_call_equals_plan_step(dtype):
     assert np.array_equal(ctrl.get_action(ob, None), np_(c.plan_step(ob))) and ctrl.last_min_cost == float(np_(c.best_cost)[0])
 
 
-@pytest.mark.parametrize("mode,n", [("sum", 1007), ("best", 1007), ("final", 1007), ("sum", 8200 + 5), ("best", 16384 + 21)])
-def test_fused_rssm_rollout_kernel(mode, n):
+@pytest.mark.parametrize("mode,n,h", [("sum", 1007, 12), ("best", 1007, 12), ("final", 1007, 12), ("sum", 8200 + 5, 12),
+                                      ("best", 16384 + 21, 12), ("sum", 1, 12), ("final", 17, 1), ("sum", 33, 30)])
+def test_fused_rssm_rollout_kernel(mode, n, h):
     """icem_rssm_rollout_cost (the declared RSSM's whole rollout + reward head in one launch, bf16 MFMA with f32
     accumulation and f32 recurrent state) against (a) a float64 NumPy rollout of the same network with the weights and
     the GEMM inputs rounded to bf16 exactly where the kernel rounds them -- tight; (b) the plain float64 network --
-    bf16 accuracy.  Ragged n (not a multiple of the 16-trajectory tile); n >= 8192 runs two tiles per workgroup."""
+    bf16 accuracy.  Ragged n (not a multiple of the 16-trajectory tile, a single trajectory), horizons 1 / 12 / 30;
+    n >= 8192 runs two tiles per workgroup."""
     from icem_amd import DeviceRSSMModel
     m = DeviceRSSMModel(seed=3)
-    h, d = 12, 6
+    d = 6
     rs = np.random.RandomState(4)
     acts = rs.uniform(-1, 1, (n, h, d))
     obs = 0.3 * rs.randn(230)
@@ -1420,7 +1422,7 @@ def test_fused_rssm_rollout_kernel(mode, n):
     scale = 1 + np.abs(exact).max()
     assert np.abs(got - emu).max() <= 2e-3 * scale, (np.abs(got - emu).max(), scale)
     assert np.abs(got - exact).max() <= 5e-2 * scale
-    if exact.std() > 1e-2 * scale:   # ('best' can pick the shared first step for every trajectory: a constant)
+    if n > 1 and exact.std() > 1e-2 * scale:   # ('best' can pick the shared first step for every trajectory: a constant)
         assert np.corrcoef(got, exact)[0, 1] > 0.99
 
 
