@@ -505,11 +505,12 @@ class MpcICemHip(MpcController):
             costs_dev, idx = p.topk_sorted(costs, K)
             self._elite_actions = p.gather_refit(pool, idx, p.mean, p.std)
             self._elite_costs = costs_dev
-        executed = self._elite_actions[0, 0].cpu().numpy().astype(np.float64)  # best of the last pool (icem.py:163)
-        self.last_min_cost = float(costs_dev[0])
         p.shift(p.mean, p.std)
         p.mpc_step += 1
-        return executed
+        # best of the last pool (icem.py:163) and its cost: one device-to-host copy, one synchronisation
+        host = torch.cat([self._elite_actions[0, 0], costs_dev[:1]]).cpu().numpy().astype(np.float64)
+        self.last_min_cost = float(host[-1])
+        return host[:-1]
 
 
 # ---------------------------------------------------------------------------------------------

@@ -277,6 +277,7 @@ class DeviceRSSMModel(ForwardModel):
         self.device = torch.device(device)
         self.params = pack_rssm(self.reference).to(self.device)
         self.lib = L.load_library()
+        self._obs_host = self._obs_dev = None
         if self.params.numel() != self.lib.icem_rssm_param_elems():
             raise RuntimeError("packed RSSM parameters do not match the library's layout")
 
@@ -287,7 +288,10 @@ class DeviceRSSMModel(ForwardModel):
         from . import _lib as L
         actions = actions.to(torch.float32).contiguous()
         n, h, _ = actions.shape
-        o = torch.as_tensor(np.asarray(obs, dtype=np.float32), device=self.device)
+        ob = np.asarray(obs, dtype=np.float32)
+        if self._obs_host is None or not np.array_equal(ob, self._obs_host):   # the CEM iterations of a step share it
+            self._obs_host, self._obs_dev = ob.copy(), torch.as_tensor(ob, device=self.device)
+        o = self._obs_dev
         costs = torch.empty((n,), dtype=torch.float32, device=self.device)
         st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         L.check(self.lib.icem_rssm_rollout_cost(n, h, cost_mode, C.c_void_p(self.params.data_ptr()), C.c_void_p(o.data_ptr()),
