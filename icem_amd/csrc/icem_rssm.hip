@@ -70,20 +70,24 @@ __device__ __forceinline__ v4f bias4(const float* bs, size_t off, int idx) {
 }
 __device__ __forceinline__ v4s relu_pack(v4f a) { return pack4(fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f)); }
 
-// Y[:, own blocks] = relu(W X + b) for a 13-block layer with KB k-blocks, for TT tiles of 16 trajectories that share
-// every requested weight block; X / Y: the lane's row pointers in tile 0, xts: X's element stride between tiles
-template <int KB, int TT>
-__device__ __forceinline__ void dense13_relu(const float* P, const unsigned short* Plane, size_t woff,
-                                             size_t boff, const unsigned short* X, int xts, unsigned short* Y, int w, int g) {
-    v4i A[NOB][KB];
-    __builtin_amdgcn_sched_barrier(0);   // a layer's requests stay together, behind the previous layer's work
+// A 13-block layer in two halves so that its weight requests can be issued early (they depend on nothing but the
+// parameters, so they may also sit in front of the barrier that ends the previous phase): req_own asks for the wave's
+// NOB blocks; fin_dense runs the MFMAs for TT tiles of 16 trajectories that share them and stores relu(W X + b).
+// X / Y: the lane's row pointers in tile 0, xts: X's element stride between tiles.
+template <int KB>
+__device__ __forceinline__ void req_own(const unsigned short* Plane, size_t woff, int w, v4i (&A)[NOB][KB]) {
+    __builtin_amdgcn_sched_barrier(0);   // requests stay where they are written
 #pragma unroll
     for (int i = 0; i < NOB; ++i) request<KB>(Plane + woff + (size_t)own_block(w, i) * KB * BLK, A[i]);
     __builtin_amdgcn_sched_barrier(0);
+}
+template <int KB, int TT>
+__device__ __forceinline__ void fin_dense(const float* bs, size_t boff, const v4i (&A)[NOB][KB], const unsigned short* X, int xts,
+                                          unsigned short* Y, int w, int g) {
 #pragma unroll
     for (int i = 0; i < NOB; ++i) {
         const int ob = own_block(w, i);
-        const v4f b = bias4(P, boff, ob * 16 + 4 * g);
+        const v4f b = bias4(bs, boff, ob * 16 + 4 * g);
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) {
             const v4f a = mma<KB>(A[i], X + tt * xts, b);
@@ -141,6 +145,23 @@ __global__ __launch_bounds__(NTHR) void rssm_rollout_kernel(int n, int horizon, 
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) acc_cost[tt] = 0.f;
     int cur = 0;
+    // The first layers' weight blocks of a step are requested at the end of the previous one (in front of its last
+    // barrier), W7's during phase 1 and W5's during phase 3: three of the four barriers of a step no longer have an L2
+    // round trip behind them.
+    // (Only with one tile per workgroup: with two, the extra live operands spill and the prefetch loses.)
+    constexpr bool AHEAD = TT == 1;
+    v4i Ah[NOB][DETK], Az[NOB][STK], A1[NOB][K1K];
+    if (AHEAD) {
+        const unsigned short* Plane = Pg + lane * 8;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NOB; ++i) {
+            const unsigned short* W = Plane + W6 + (size_t)own_block(w, i) * K6K * BLK;
+            request<DETK>(W, Ah[i]);
+            request<STK>(W + (size_t)DETK * BLK, Az[i]);
+        }
+        req_own<K1K>(Plane, W1, w, A1);
+    }
     for (int t = 0; t < horizon; ++t) {
         // the parameters do not depend on t, and the optimizer would gladly keep whatever fits of them in registers
         // across steps (it filled all 512 and spilled): re-derive the pointer behind an opaque barrier every step
@@ -148,8 +169,7 @@ __global__ __launch_bounds__(NTHR) void rssm_rollout_kernel(int n, int horizon, 
         asm volatile("" : "+s"(P));
         const unsigned short* Plane = P + lane * 8;   // this lane's 8 bf16 inside every A-operand block
         // ---- phase 1 (reads h_t, z_t, a_t): r1 = relu(W6 [h | z] + b6) and x = relu(W1 [z | a] + b1) ----
-        {
-            v4i Ah[NOB][DETK], Az[NOB][STK];
+        if (!AHEAD) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < NOB; ++i) {
@@ -157,23 +177,26 @@ __global__ __launch_bounds__(NTHR) void rssm_rollout_kernel(int n, int horizon, 
                 request<DETK>(W, Ah[i]);
                 request<STK>(W + (size_t)DETK * BLK, Az[i]);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            req_own<K1K>(Plane, W1, w, A1);
+        }
+        v4i A7[NOB][HIDK];
+        if (AHEAD) req_own<HIDK>(Plane, W7, w, A7);   // next phase's first layer: in flight across the barrier
 #pragma unroll
-            for (int i = 0; i < NOB; ++i) {
-                const int ob = own_block(w, i);
-                const v4f b = bias4(bs, B6, ob * 16 + 4 * g);
+        for (int i = 0; i < NOB; ++i) {
+            const int ob = own_block(w, i);
+            const v4f b = bias4(bs, B6, ob * 16 + 4 * g);
 #pragma unroll
-                for (int tt = 0; tt < TT; ++tt) {
-                    v4f a = mma<DETK>(Ah[i], hb[cur] + tt * 16 * RS + xr, b);
-                    a = mma<STK>(Az[i], zA + tt * 16 * ZS + zr, a);
-                    if (w + WAVES * i < 13) *reinterpret_cast<v4s*>(r1 + tt * 16 * RS + xo + ob * 16) = relu_pack(a);
-                }
+            for (int tt = 0; tt < TT; ++tt) {
+                v4f a = mma<DETK>(Ah[i], hb[cur] + tt * 16 * RS + xr, b);
+                a = mma<STK>(Az[i], zA + tt * 16 * ZS + zr, a);
+                if (w + WAVES * i < 13) *reinterpret_cast<v4s*>(r1 + tt * 16 * RS + xo + ob * 16) = relu_pack(a);
             }
         }
-        dense13_relu<K1K, TT>(bs, Plane, W1, B1, zA + zr, 16 * ZS, xb + xo, w, g);
+        fin_dense<K1K, TT>(bs, B1, A1, zA + zr, 16 * ZS, xb + xo, w, g);
         __syncthreads();
         // ---- phase 2: r2 = relu(W7 r1 + b7);  GRU h' = (1 - u) n + u h, one output block at a time ----
-        dense13_relu<HIDK, TT>(bs, Plane, W7, B7, r1 + xr, 16 * RS, r2 + xo, w, g);
+        if (!AHEAD) req_own<HIDK>(Plane, W7, w, A7);
+        fin_dense<HIDK, TT>(bs, B7, A7, r1 + xr, 16 * RS, r2 + xo, w, g);
 #pragma unroll 1
         for (int i = 0; i < NOB; ++i) {
             const int ob = own_block(w, i), bi = ob * 16 + 4 * g;
@@ -212,6 +235,9 @@ __global__ __launch_bounds__(NTHR) void rssm_rollout_kernel(int n, int horizon, 
         }
         __syncthreads();
         // ---- phase 3: reward = W8 r2 + b8 (one wave);  p = relu(W4 h' + b4) ----
+        v4i A5[HIDK];
+        if (AHEAD && w < STB) request<HIDK>(Plane + W5 + (size_t)w * HIDK * BLK, A5);   // next phase's layer, across the barrier
+        __builtin_amdgcn_sched_barrier(0);
         if (w == WAVES - 1) {   // the reward output block: a wave that owns one block less than wave 0
             v4i A8[HIDK];
             request<HIDK>(Plane + W8, A8);
@@ -225,12 +251,25 @@ __global__ __launch_bounds__(NTHR) void rssm_rollout_kernel(int n, int horizon, 
                 else acc_cost[tt] = (c < acc_cost[tt] || c != c) ? c : acc_cost[tt];
             }
         }
-        dense13_relu<DETK, TT>(bs, Plane, W4, B4, hb[cur ^ 1] + xr, 16 * RS, xb + xo, w, g);
+        {
+            v4i A4[NOB][DETK];
+            req_own<DETK>(Plane, W4, w, A4);
+            fin_dense<DETK, TT>(bs, B4, A4, hb[cur ^ 1] + xr, 16 * RS, xb + xo, w, g);
+        }
         __syncthreads();
         // ---- phase 4: z' = W5 p + b5 (waves 0, 1) and the next action (wave 2) -> [z | a] ----
+        if (AHEAD) {   // the next step's first layers (always: a request that is always made leaves nothing to keep alive)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NOB; ++i) {
+                const unsigned short* W = Plane + W6 + (size_t)own_block(w, i) * K6K * BLK;
+                request<DETK>(W, Ah[i]);
+                request<STK>(W + (size_t)DETK * BLK, Az[i]);
+            }
+            req_own<K1K>(Plane, W1, w, A1);
+        }
         if (w < STB) {
-            v4i A5[HIDK];
-            request<HIDK>(Plane + W5 + (size_t)w * HIDK * BLK, A5);
+            if (!AHEAD) request<HIDK>(Plane + W5 + (size_t)w * HIDK * BLK, A5);
             const v4f b5 = bias4(bs, B5, w * 16 + 4 * g);
 #pragma unroll
             for (int tt = 0; tt < TT; ++tt) {
