@@ -1,9 +1,10 @@
-// See icem_rssm.h.  One workgroup (8 wavefronts) per 16 trajectories.  Every layer is D = W-block . X^T with
+// See icem_rssm.h.  One workgroup (8 wavefronts) per 16 trajectories (two such tiles from N = 8192 on).  Every layer is D = W-block . X^T with
 // v_mfma_f32_16x16x32_bf16: the A operand is a 16 x 32 block of the weight (output row i = lane % 16, k = 8 * (lane / 16)
 // + 0..7), the B operand the activations (trajectory j = lane % 16, same k), and the result leaves lane (j, g) holding
 // outputs 4g .. 4g+3 of trajectory j -- exactly the slice that lane writes back (bias, activation, bf16) to the LDS
 // activation row it will later be read from as a B operand.  The waves split a layer's output blocks; the
-// weights stream from L2 (760 KB of bf16 per step, shared by all workgroups), the recurrent state stays in LDS in f32.
+// weights stream from L2 (0.9 MB of padded bf16 per step, the same for all workgroups), the recurrent state stays in LDS
+// in f32.
 #include "icem_rssm.h"
 
 namespace icem {
@@ -34,7 +35,7 @@ __device__ __forceinline__ float tanhf_(float x) { return 2.f * __builtin_amdgcn
 // A wave owns output blocks w, w+WAVES, ... of a 13-block layer (waves without a last block redo block 12 and drop
 // the result -- cheaper than a divergent trip count, the matrix pipe is not the limit).
 // The weights come straight from L2, so what matters is how many loads are in flight: a layer first REQUESTS all of
-// the wave's A-operand blocks (NOB x KB 8-byte loads per lane), then runs the MFMAs.
+// the wave's A-operand blocks (NOB x KB 16-byte loads per lane), then runs the MFMAs.
 constexpr int WAVES = 8;                 // wavefronts per workgroup (two per SIMD: one's loads under the other's MFMAs)
 constexpr int NOB = (13 + WAVES - 1) / WAVES;
 constexpr int NTHR = 64 * WAVES;
