@@ -38,6 +38,9 @@ WORKLOADS = {
     "c4": dict(N=65536, h=30, d=6, o=17, beta=0.25, iters=5, name="HalfCheetah-shaped synthetic, N=65536 h=30 d=6 o=17 beta=0.25, 5 CEM iters"),
     # BASELINE.json configs[2]: HumanoidStandup action shapes (d=17, bounds +-0.4, beta=2.0, 3 iterations); the real env
     # has o=378 MuJoCo observations, here a 24-dim tanh latent of which obs[2] enters the cost (not a default bench line)
+    # BASELINE configs[4]: learned dynamics (the declared RSSM, fused bf16-MFMA rollout), controller-driven MPC steps
+    "c5": dict(N=1024, h=12, d=6, o=230, beta=0.25, iters=5, env="rssm", kind=-1,
+               name="learned-dynamics (declared RSSM 200+30, GRU) N=1024 h=12 d=6 beta=0.25, 5 CEM iters, bf16 MFMA rollout"),
     "c3": dict(N=16384, h=30, d=17, o=24, beta=2.0, iters=3, env="humanoid", kind=1,
                name="HumanoidStandup-shaped synthetic, N=16384 h=30 d=17 o=24 (latent) beta=2.0, 3 CEM iters, tanh model"),
 }
@@ -173,6 +176,76 @@ def measure_also(name, steps=200, warmup=20):
             "whole_loop_frac_of_hbm_peak": loop_bytes * steps / el / 1e9 / HBM_PEAK_GBS}
 
 
+def run_c5(args, w):
+    """--workload c5: one step = MpcICemHip.get_action with DeviceRSSMModel (sampling / top-K / refit kernels + one fused
+    RSSM rollout launch per CEM iteration); roofline bound = the bf16 matrix cores for the rollout kernel; CPU baseline =
+    oracle/rssm_oracle.py (NumPy, float64) on the same populations."""
+    from icem_amd import DeviceRSSMModel, MpcICemHip, halfcheetah_env
+    env = halfcheetah_env(17)   # action space only (d=6, +-1)
+    model = DeviceRSSMModel(seed=3)
+    ctrl = MpcICemHip(env=env, forward_model=model, horizon=w["h"], num_simulated_trajectories=w["N"], factor_decrease_num=1.25,
+                      cost_along_trajectory="sum", dtype="f32", seed=1234,
+                      action_sampler_params=dict(alpha=0.1, elites_size=10, opt_iterations=w["iters"], init_std=0.5,
+                                                 use_mean_actions=True, keep_previous_elites=True, shift_elites_over_time=True,
+                                                 fraction_elites_reused=0.3, noise_beta=w["beta"]))
+    obs = 0.3 * np.random.RandomState(0).randn(w["o"])
+    ctrl.beginning_of_rollout(observation=obs, state=None, mode="train")
+    for _ in range(args.warmup):
+        ctrl.get_action(obs, None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctrl.get_action(obs, None)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    pops = ctrl.planner.population_sizes
+    ts = sum(pops) * w["h"]
+    # second pass: the rollout kernel alone, HIP events on the stream it is launched on (torch's current stream)
+    orig, spans = model.rollout_cost, []
+
+    def timed(o, a, mode=0):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig(o, a, mode)
+        e1.record()
+        spans.append((e0, e1, a.shape[0]))
+        return out
+    model.rollout_cost = timed
+    for _ in range(min(args.steps, 50)):
+        ctrl.get_action(obs, None)
+    torch.cuda.synchronize()
+    model.rollout_cost = orig
+    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in spans)
+    macs = sum(p.numel() for _, p in model.reference.named_parameters() if p.ndim == 2)
+    flops = 2.0 * macs * w["h"] * sum(n for _, _, n in spans)
+    achieved = flops / (ms * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0, "traffic": None,
+                "kernel": "rssm_rollout_kernel", "avg_launch_us": 1e3 * ms / len(spans), "launches": len(spans),
+                "algorithmic_flops_per_traj_step": 2.0 * macs, "dtype": "bf16 operands, f32 accumulation"}
+    out = {"metric": "traj-steps/sec (N x h), iCEM inner planning loop", "value": ts * args.steps / elapsed, "unit": "traj-steps/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": w["name"], "per_gpu_population": w["N"], "traj_per_mpc_step": sum(pops),
+                      "model": "declared RSSM, random weights (icem_amd.models.declared_rssm)", "cost": "-reward head",
+                      "rng": "Philox4x32-10-seeded xoshiro128++ + Box-Muller", "parallelism": "n-shard x1"},
+           "roofline": roofline, "cpu_baseline": None}
+    if not args.no_cpu_baseline:
+        from oracle import rssm_oracle as RO
+        P = RO.params_from_state_dict(model.reference.state_dict())
+        rs = np.random.RandomState(1)
+        done, reps, t0 = 0, 0, time.perf_counter()
+        while time.perf_counter() - t0 < 12.0:
+            for n_it in pops:
+                RO.rollout_costs(P, obs, rs.uniform(-1, 1, (n_it, w["h"], w["d"])))
+                done += n_it * w["h"]
+            reps += 1
+        el = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": done / el, "unit": "traj-steps/s", "cores": os.cpu_count(), "kind": "port",
+                               "sample": f"{reps} MPC step(s) worth of rollouts ({sum(pops)} trajectories x h={w['h']} each) in {el:.1f} s; "
+                                         "oracle/rssm_oracle.py, NumPy float64 (BLAS threads as configured on the host)"}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -207,6 +280,10 @@ def main():
         dist.barrier()
 
     w = WORKLOADS[args.workload]
+    if args.workload == "c5":
+        if world != 1:
+            sys.exit("--workload c5 is a single-GPU configuration")
+        return run_c5(args, w)
     pl, model, env = make_planner(w, rank, world, cost_mode=args.cost_mode)
     per_step_trajsteps = sum(pl.population_sizes) * w["h"]  # global (all ranks) traj-steps per MPC step
 
