@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """bench.py -- iCEM inner planning loop on MI355X: traj-steps/s of whole MPC steps.
 
-  python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4]
+  python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4|c5]
 
 A "step" is one MPC step = all CEM iterations (sample -> rollout -> cost -> top-k -> refit) of one
 `get_action`, on synthetic HalfCheetah-shaped input already resident in HBM.  Workload c2 (default;
 BASELINE.json's metric is quoted on it): N=4096, h=30, d=6, o=17, beta=0.25, 5 iterations with
 population decay (4096, 3276, 2620, 2096, 1676), K=10, f32.  Workload c4: N=65536, same otherwise.  Workload c3:
-HumanoidStandup action shapes (N=16384, d=17, beta=2.0, 3 iterations) on a 24-dim tanh latent model.
+HumanoidStandup action shapes (N=16384, d=17, beta=2.0, 3 iterations) on a 24-dim tanh latent model.  Workload c5
+(single GPU): the learned-dynamics configuration N=1024, h=12 -- controller-driven steps with the declared RSSM's rollout
+fused on the bf16 matrix cores; its `roofline` is bound "mfma" and its CPU baseline oracle/rssm_oracle.py.
 For --gpus G > 1 (launched by torch.distributed.run, one rank per GPU over RCCL) the per-GPU
 population is fixed (weak scaling): global N = G * N, sharded by global trajectory index, with one
 all-gather of the ranks' K candidate records per CEM iteration.
