@@ -107,3 +107,22 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "icem_oracle" not in src, f
+
+
+def test_rssm_parameter_packing_matches_the_library_layout(lib):
+    """The Python packer of the fused learned-dynamics kernel (icem_amd.models.pack_rssm) and the layout compiled into
+    the library (icem_amd/csrc/icem_rssm.h) agree on the buffer size; the packed blocks hold the weights where the
+    kernel's lane indexing expects them (block (ob, kb), lane 16*g + i, slot v  <-  W[16*ob + i][32*kb + 8*g + v])."""
+    import torch
+    from icem_amd.models import declared_rssm, pack_rssm
+    m = declared_rssm(seed=1, device="cpu")
+    packed = pack_rssm(m.module)
+    assert packed.dtype == torch.int16 and packed.numel() == lib.icem_rssm_param_elems()
+    # first layer (inp: [200, 36] -> padded [208, 64], z at columns 0..29, a at 32..37): spot-check three entries
+    W = m.module.inp.weight.detach()
+    blk = packed[:13 * 2 * 512].view(13, 2, 4, 16, 8)          # [ob, kb, g, i, v]
+    as_bf16 = lambda x: x.to(torch.bfloat16).view(torch.int16)  # noqa: E731
+    assert blk[0, 0, 0, 0, 0] == as_bf16(W[0, 0])               # z column 0 of output 0
+    assert blk[3, 0, 2, 5, 7] == as_bf16(W[3 * 16 + 5, 2 * 8 + 7])
+    assert blk[12, 1, 0, 7, 3] == as_bf16(W[12 * 16 + 7, 30 + 3])   # action column 3 sits at padded column 32 + 3
+    assert int(blk[12, 1, 3].abs().sum()) == 0                  # padded action columns 56..63 are zero
