@@ -103,6 +103,7 @@ SYMBOLS = [
     ("icem_profile_enable", C.c_int, [_H, _I32]),
     ("icem_debug_stamps", C.c_int, [_H, _VP]),
     ("icem_set_merge_deferral", C.c_int, [_H, C.c_int32]),
+    ("icem_set_episode", C.c_int, [_H, C.c_uint64]),
     ("icem_sample_truncnorm", C.c_int, [_H, C.c_int32, C.c_int64, _VP, _VP, _VP, _VP, _VP, C.c_uint64, _VP, _VP]),
     ("icem_cem_bounds", C.c_int, [_H, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     ("icem_profile_read", C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -1,30 +1,105 @@
-"""Build ``libicem_hip.so`` for gfx950 in-tree (``python -m icem_amd.build``)."""
+"""Build ``libicem_hip.so`` for gfx950 in-tree (``python -m icem_amd.build [--force]``).
+
+One object per translation unit, compiled in parallel; an object is rebuilt when the hash of (compile command, its
+source, every header under ``csrc/`` and ``include/icem_hip.h``) changes, the library when any object does.  The hash of
+all sources the library was linked from is kept next to it (``libicem_hip.so.json``) so that a stale binary is
+visible: ``build_info()`` is what ``bench.py`` prints as ``build``.
+"""
+import hashlib
+import json
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = [os.path.join(HERE, "csrc", "icem_kernels.hip"), os.path.join(HERE, "csrc", "icem_fused.hip"),
-        os.path.join(HERE, "csrc", "icem_rssm.hip")]
+CSRC = os.path.join(HERE, "csrc")
+UNITS = ["generic_kernels.hip", "plan.hip", "abi.hip", "exchange.hip", "k_sample.hip", "k_rollout.hip", "k_merge.hip",
+         "k_iter_small.hip", "k_iter_large.hip", "icem_rssm.hip", "k_rollout_wide.hip"]
 OUT = os.path.join(HERE, "libicem_hip.so")
-DEPS = SRCS + [os.path.join(HERE, "csrc", "philox.h"), os.path.join(HERE, "csrc", "icem_fused.h"), os.path.join(HERE, "csrc", "icem_rssm.h"),
-               os.path.join(os.path.dirname(HERE), "include", "icem_hip.h")]
+INFO = OUT + ".json"
+OBJ = os.path.join(CSRC, "_obj")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    return os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _units():
+    return [u for u in UNITS if os.path.exists(os.path.join(CSRC, u))]
+
+
+def _headers():
+    hs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    return hs + [os.path.join(os.path.dirname(HERE), "include", "icem_hip.h")]
+
+
+def _digest(paths, extra=""):
+    m = hashlib.sha256(extra.encode())
+    for p in paths:
+        m.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            m.update(f.read())
+    return m.hexdigest()[:16]
+
+
+def source_hash() -> str:
+    """Hash of everything the library is built from (sources, headers, flags)."""
+    return _digest([os.path.join(CSRC, u) for u in _units()] + _headers(), " ".join(FLAGS))
+
+
+def build_info() -> dict:
+    """{source_hash, built_from, stale}: ``stale`` is True when the library on disk was linked from other sources."""
+    info = {"source_hash": source_hash(), "built_from": None, "stale": True}
+    if os.path.exists(OUT) and os.path.exists(INFO):
+        try:
+            info["built_from"] = json.load(open(INFO)).get("source_hash")
+        except Exception:
+            pass
+        info["stale"] = info["built_from"] != info["source_hash"]
+    return info
 
 
 def up_to_date() -> bool:
-    return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(p) for p in DEPS)
+    return not build_info()["stale"]
+
+
+def _compile(unit, headers_digest, verbose):
+    src = os.path.join(CSRC, unit)
+    cmd = [_hipcc(), *FLAGS, "-I", CSRC, "-c", src]
+    key = _digest([src], " ".join(cmd[1:-1]) + headers_digest)
+    obj = os.path.join(OBJ, f"{os.path.splitext(unit)[0]}.{key}.o")
+    if not os.path.exists(obj):
+        for f in os.listdir(OBJ):  # drop older objects of this unit
+            if f.startswith(os.path.splitext(unit)[0] + ".") and f.endswith(".o"):
+                os.remove(os.path.join(OBJ, f))
+        if verbose:
+            print(" ".join(cmd + ["-o", obj]), flush=True)
+        subprocess.check_call(cmd + ["-o", obj + ".tmp"])
+        os.replace(obj + ".tmp", obj)
+    return obj
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and up_to_date():
         return OUT
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-parallel-jobs=4", *SRCS, "-o", OUT]
+    os.makedirs(OBJ, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ):
+            os.remove(os.path.join(OBJ, f))
+    hd = _digest(_headers())
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(lambda u: _compile(u, hd, verbose), _units()))
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", OUT]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(INFO, "w") as f:
+        json.dump({"source_hash": source_hash(), "forced": bool(force), "units": _units()}, f)
     return OUT
 
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    print(json.dumps(build_info()))

@@ -194,7 +194,12 @@ class MpcController(ModelBasedController, StatefulController, ABC):
                                                   policy=OpenLoopPolicy(action_sequences), horizon=self.horizon)[0]
 
     def beginning_of_rollout(self, *, observation, state=None, mode):
-        self.forward_model_state = self.forward_model.reset(observation)
+        # mpc.py:69-73: a ground-truth model starts from the env state the harness hands over
+        fm = self.forward_model
+        if state is not None and callable(getattr(fm, "set_state", None)) and callable(getattr(fm, "get_state", None)):
+            self.forward_model_state = state
+        else:
+            self.forward_model_state = fm.reset(observation)
 
     def end_of_rollout(self, total_time, total_return, mode):
         pass
@@ -318,13 +323,16 @@ class MpcICemHip(MpcController):
     """
 
     def __init__(self, *, action_sampler_params, dtype="f32", seed=0, rng_rounds=10, device="cuda:0",
-                 noise_source: Union[str, Callable] = "philox", process_group=None, rank=0, world=1, **kwargs):
+                 noise_source: Union[str, Callable] = "philox", process_group=None, rank=0, world=1,
+                 deterministic_replay=False, **kwargs):
         super().__init__(**kwargs)
         self._parse_action_sampler_params(**dict(action_sampler_params))
         self._check_validity_parameters()
         self.logger = _get_logger(self.__class__.__name__)
         self.was_reset = False
         self.noise_source = noise_source
+        # device noise: every episode gets its own streams unless the caller opts into replaying episode 0's
+        self.deterministic_replay = bool(deterministic_replay)
         cfg = IcemConfig(
             horizon=self.horizon, act_dim=self.dim_samples[1], num_traj=self.num_sim_traj,
             elites_size=self.elites_size, opt_iters=self.opt_iter, cost_mode=self.cost_along_trajectory,
@@ -395,6 +403,8 @@ class MpcICemHip(MpcController):
     # -- rollout hooks: icem.py:31-46 ----------------------------------------------------------
     def beginning_of_rollout(self, *, observation, state=None, mode):
         super().beginning_of_rollout(observation=observation, state=state, mode=mode)
+        if not self.deterministic_replay:
+            self.planner.new_episode()
         if self.device_path:
             self.planner.reset()
         else:
@@ -484,7 +494,7 @@ class MpcICemHip(MpcController):
     def _get_action_stagewise(self, obs, noise):
         p = self.planner
         K, it_n = self.num_elites, self.opt_iter
-        call_base = p.mpc_step * (it_n + 1)
+        call_base = p.noise_offset(p.mpc_step * (it_n + 1))
         pool = costs_dev = idx = None
         for i, n_i in enumerate(p.population_sizes):
             z = noise(n_i) if noise is not None else (None, None)
@@ -525,13 +535,14 @@ class MpcCemStdHip(MpcController):
     a callable ``uniforms(num) -> [num, h, d]``)."""
 
     def __init__(self, *, action_sampler_params, dtype="f32", seed=0, rng_rounds=10, device="cuda:0",
-                 noise_source: Union[str, Callable] = "philox", **kwargs):
+                 noise_source: Union[str, Callable] = "philox", deterministic_replay=False, **kwargs):
         super().__init__(**kwargs)
         self._parse_action_sampler_params(**dict(action_sampler_params))
         self._check_validity_parameters()
         self.logger = _get_logger(self.__class__.__name__)
         self.was_reset = False
         self.noise_source = noise_source
+        self.deterministic_replay = bool(deterministic_replay)
         if self.cost_along_trajectory not in ("sum", "best", "final"):
             raise NotImplementedError(
                 "Implement method {} to compute cost along trajectory".format(self.cost_along_trajectory))
@@ -580,6 +591,8 @@ class MpcCemStdHip(MpcController):
     def beginning_of_rollout(self, *, observation, state=None, mode):  # mpc.py:158-170
         super().beginning_of_rollout(observation=observation, state=state, mode=mode)
         p = self.planner
+        if not self.deterministic_replay:
+            p.new_episode()
         self._mean = torch.empty((p.h, p.d), dtype=p.dt, device=p.device)
         self._std = torch.empty_like(self._mean)
         p.reset_distribution(self._mean, self._std)
@@ -611,7 +624,7 @@ class MpcCemStdHip(MpcController):
         for i in range(self.opt_iter):
             u = uniforms(self.num_sim_traj) if uniforms is not None else None
             actions = p.sample_truncnorm(self.num_sim_traj, self._mean, self._std, self._lower, self._upper, u,
-                                         offset=p.mpc_step * self.opt_iter + i)
+                                         offset=p.noise_offset(p.mpc_step * self.opt_iter + i))
             costs = self._costs_of(obs, actions)
             costs_sorted, idx = p.topk_sorted(costs, self.num_elites)      # mpc.py:270
             self._elite_actions = p.gather_refit(actions, idx, self._mean, self._std)  # mpc.py:271-281

@@ -1,0 +1,406 @@
+// abi.hip -- handle life cycle and the stateless operators of include/icem_hip.h: argument checking (the reference's
+// ValueError / AttributeError / NotImplementedError cases as ICEM_E_* codes), the host-side colored-noise tables,
+// model / cost registration; the kernels behind the operators live in generic_kernels.hip (gk_*) and k_*.hip.
+#include "host_common.h"
+#include "icem_rssm.h"
+
+using namespace icem;
+
+namespace {
+
+void psd_scale_host(int h, double beta, std::vector<double>& s, double& sigma) {
+    // colorednoise.powerlaw_psd_gaussian (third-party, call site icem.py:73): f = rfftfreq(h),
+    // DC takes the first bin's value, s = f^(-beta/2), sigma = 2*sqrt(sum w^2)/h.
+    const int F = h / 2 + 1;
+    s.resize(F);
+    for (int k = 0; k < F; ++k) s[k] = (double)k * (1.0 / (double)h);
+    const double fmin = 1.0 / (double)h;
+    int ix = 0;
+    for (int k = 0; k < F; ++k) ix += s[k] < fmin ? 1 : 0;
+    if (ix && ix < F)
+        for (int k = 0; k < ix; ++k) s[k] = s[ix];
+    for (int k = 0; k < F; ++k) s[k] = std::pow(s[k], -beta / 2.0);
+    double acc = 0.0;
+    for (int k = 1; k < F; ++k) {
+        double w = s[k];
+        if (k == F - 1) w *= (1 + (h % 2)) / 2.0;
+        acc += w * w;
+    }
+    sigma = 2.0 * std::sqrt(acc) / (double)h;
+}
+
+void noise_tables(int h, double beta, std::vector<double>& cr, std::vector<double>& ci) {
+    std::vector<double> s;
+    double sigma;
+    psd_scale_host(h, beta, s, sigma);
+    const int F = h / 2 + 1;
+    cr.assign((size_t)F * h, 0.0);
+    ci.assign((size_t)F * h, 0.0);
+    for (int k = 0; k < F; ++k) {
+        double mult = 2.0;
+        if (k == 0 || (h % 2 == 0 && k == F - 1)) mult = 1.0;
+        const double amp = mult * s[k] / ((double)h * sigma);
+        const bool imag_dropped = (k == 0) || (h % 2 == 0 && k == F - 1);
+        for (int t = 0; t < h; ++t) {
+            const double ang = 2.0 * M_PI * (double)k * (double)t / (double)h;
+            cr[(size_t)k * h + t] = amp * std::cos(ang);
+            ci[(size_t)k * h + t] = imag_dropped ? 0.0 : -amp * std::sin(ang);
+        }
+    }
+}
+
+std::vector<int> population_sizes(const icem_config& c) {
+    std::vector<int> out;
+    int n = c.num_traj;
+    for (int i = 0; i < c.opt_iters; ++i) {
+        if (i > 0) n = std::max(c.elites_size * 2, (int)((double)n / c.factor_decrease));
+        out.push_back(n);
+    }
+    return out;
+}
+
+template <typename T>
+int upload(void** dev, const std::vector<double>& host) {
+    std::vector<T> tmp(host.size());
+    for (size_t i = 0; i < host.size(); ++i) tmp[i] = (T)host[i];
+    if (*dev) {
+        (void)hipFree(*dev);
+        *dev = nullptr;
+    }
+    ICEM_HIP_TRY(hipMalloc(dev, tmp.size() * sizeof(T)));
+    ICEM_HIP_TRY(hipMemcpy(*dev, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice));
+    return ICEM_OK;
+}
+
+int pick_O(int o) {
+    const int sizes[] = {8, 16, 17, 18, 24, 32};
+    for (int s : sizes)
+        if (o <= s) return s;
+    return -1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int icem_abi_version(void) { return ICEM_ABI_VERSION; }
+
+const char* icem_last_error(void) { return g_err.c_str(); }
+
+int icem_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int icem_noise_tables_host(int32_t horizon, double beta, double* cr_host, double* ci_host) {
+    if (horizon < 2 || !cr_host || !ci_host) return fail(ICEM_E_INVALID, "bad horizon / null output");
+    std::vector<double> cr, ci;
+    noise_tables(horizon, beta, cr, ci);
+    std::memcpy(cr_host, cr.data(), cr.size() * sizeof(double));
+    std::memcpy(ci_host, ci.data(), ci.size() * sizeof(double));
+    return ICEM_OK;
+}
+
+int icem_create(const icem_config* cfg, icem_handle** out) {
+    if (!cfg || !out) return fail(ICEM_E_INVALID, "null argument");
+    const icem_config& c = *cfg;
+    if (c.num_traj < 2) return fail(ICEM_E_INVALID, "At least two trajectories needed!");  // mpc.py:30-31
+    if (c.horizon < 2 || c.horizon > ICEM_MAX_HORIZON) return fail(ICEM_E_UNSUPPORTED, "horizon must be in [2, 64]");
+    if (c.act_dim < 1 || c.act_dim > ICEM_MAX_ACT_DIM) return fail(ICEM_E_UNSUPPORTED, "act_dim must be in [1, 64]");
+    if (c.num_elites < 1 || c.num_elites > ICEM_MAX_ELITES) return fail(ICEM_E_UNSUPPORTED, "num_elites must be in [1, 64]");
+    if (c.opt_iters < 1) return fail(ICEM_E_INVALID, "opt_iters < 1");
+    if (c.dtype != ICEM_F32 && c.dtype != ICEM_F64) return fail(ICEM_E_INVALID, "dtype");
+    if (c.rng_rounds != 10 && c.rng_rounds != 7) return fail(ICEM_E_INVALID, "rng_rounds must be 10 or 7");
+    if (c.world < 1 || c.rank < 0 || c.rank >= c.world) return fail(ICEM_E_INVALID, "rank/world");
+    if (c.noise_beta != c.noise_beta) return fail(ICEM_E_INVALID, "noise_beta is NaN");  // <= 0: white branch, icem.py:77
+    if (!(c.factor_decrease >= 1.0)) return fail(ICEM_E_INVALID, "factor_decrease must be >= 1");
+    if (c.cost_mode < 0 || c.cost_mode > 2)
+        return fail(ICEM_E_UNSUPPORTED, "Implement method to compute cost along trajectory");  // abstract_controller.py:88-91
+    if (icem_device_count() < 1) return fail(ICEM_E_NO_DEVICE, "no HIP device visible");
+    icem_handle* h = new icem_handle();
+    h->cfg = c;
+    h->F = c.horizon / 2 + 1;
+    h->HMAX = c.horizon <= 32 ? 32 : 64;
+    h->hd = c.horizon * c.act_dim;
+    h->tsize = c.dtype == ICEM_F64 ? 8 : 4;
+    h->pop = population_sizes(c);
+    h->n_reuse = (int)((double)c.num_elites * c.fraction_reused);  // int(len(elites)*xi), icem.py:98,145
+    // the population can GROW after iteration 0 when N < 2*elites_size (icem.py:127 floors N_i at 2*elites_size)
+    h->n_local_max = 0;
+    for (int n_it : h->pop) h->n_local_max = std::max(h->n_local_max, shard_chunk(n_it, c.world));
+    if (const char* e = getenv("ICEM_DISABLE_FAST")) h->use_fast = !(e[0] == '1');
+    // synthesis table W[t][m]: m < F real part of bin m, F <= m < h imaginary part of bin m-F+1
+    // noise_beta <= 0 is the reference's white branch (np.random.randn(N, h, d), icem.py:77): draw t of a row is
+    // its sample at step t, i.e. the identity table
+    std::vector<double> cr, ci, W((size_t)c.horizon * h->HMAX, 0.0);
+    if (c.noise_beta > 0) {
+        noise_tables(c.horizon, c.noise_beta, cr, ci);
+        for (int t = 0; t < c.horizon; ++t)
+            for (int m = 0; m < c.horizon; ++m)
+                W[(size_t)t * h->HMAX + m] = m < h->F ? cr[(size_t)m * c.horizon + t] : ci[(size_t)(m - h->F + 1) * c.horizon + t];
+    } else {
+        for (int t = 0; t < c.horizon; ++t) W[(size_t)t * h->HMAX + t] = 1.0;
+    }
+    int rc = c.dtype == ICEM_F64 ? upload<double>(&h->W_dev, W) : upload<float>(&h->W_dev, W);
+    if (rc) {
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return ICEM_OK;
+}
+
+int icem_destroy(icem_handle* h) {
+    if (!h) return ICEM_OK;
+    if (h->W_dev) (void)hipFree(h->W_dev);
+    if (h->actions_alt) (void)hipFree(h->actions_alt);
+    if (h->host_stage) (void)hipHostFree(h->host_stage);
+    if (h->ws_alt) (void)hipFree(h->ws_alt);
+    if (h->pp_stats) (void)hipFree(h->pp_stats);
+    if (h->A_dev) (void)hipFree(h->A_dev);
+    if (h->B_dev) (void)hipFree(h->B_dev);
+    if (h->Mp_dev) (void)hipFree(h->Mp_dev);
+    if (h->perm_dev) (void)hipFree(h->perm_dev);
+    for (auto& sp : h->spans) {
+        (void)hipEventDestroy(sp.a);
+        (void)hipEventDestroy(sp.b);
+    }
+    for (auto e : h->free_events) (void)hipEventDestroy(e);
+    delete h;
+    return ICEM_OK;
+}
+
+int icem_set_episode(icem_handle* h, uint64_t episode) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (episode >> 32) return fail(ICEM_E_INVALID, "episode must fit 32 bits");
+    h->episode = episode;
+    return ICEM_OK;
+}
+
+int icem_population_sizes(const icem_handle* h, int32_t* out_host) {
+    if (!h || !out_host) return fail(ICEM_E_INVALID, "null argument");
+    for (size_t i = 0; i < h->pop.size(); ++i) out_host[i] = h->pop[i];
+    return ICEM_OK;
+}
+
+int icem_set_model(icem_handle* h, int32_t kind, int32_t obs_dim, const double* A_host, const double* B_host) {
+    if (!h || !A_host || !B_host) return fail(ICEM_E_INVALID, "null argument");
+    if (kind != ICEM_MODEL_LINEAR && kind != ICEM_MODEL_TANH) return fail(ICEM_E_INVALID, "model kind");
+    const int O = pick_O(obs_dim);
+    if (obs_dim < 1 || O < 0) return fail(ICEM_E_UNSUPPORTED, "obs_dim must be in [1, 32] for the built-in models");
+    const int d = h->cfg.act_dim;
+    std::vector<double> A((size_t)O * O, 0.0), B((size_t)d * O, 0.0);
+    for (int k = 0; k < obs_dim; ++k)
+        for (int i = 0; i < obs_dim; ++i) A[(size_t)k * O + i] = A_host[(size_t)k * obs_dim + i];
+    for (int j = 0; j < d; ++j)
+        for (int i = 0; i < obs_dim; ++i) B[(size_t)j * O + i] = B_host[(size_t)j * obs_dim + i];
+    int rc = h->cfg.dtype == ICEM_F64 ? upload<double>(&h->A_dev, A) : upload<float>(&h->A_dev, A);
+    if (rc) return rc;
+    rc = h->cfg.dtype == ICEM_F64 ? upload<double>(&h->B_dev, B) : upload<float>(&h->B_dev, B);
+    if (rc) return rc;
+    h->model_kind = kind;
+    h->obs_dim = obs_dim;
+    h->O = O;
+    h->has_model = true;
+    h->A_host.assign(A_host, A_host + (size_t)obs_dim * obs_dim);
+    h->B_host.assign(B_host, B_host + (size_t)d * obs_dim);
+    h->fast_model_ready = false;
+    return ICEM_OK;
+}
+
+int icem_set_cost(icem_handle* h, const icem_cost_spec* spec) {
+    if (!h || !spec) return fail(ICEM_E_INVALID, "null argument");
+    h->cost = *spec;
+    h->has_cost = true;
+    h->fast_model_ready = false;
+    return ICEM_OK;
+}
+
+int icem_set_cost_terms(icem_handle* h, const icem_cost_terms* terms) {
+    if (!h) return fail(ICEM_E_INVALID, "null argument");
+    if (terms == nullptr) {
+        h->has_terms = false;
+        return ICEM_OK;
+    }
+    if (terms->n_terms < 0 || terms->n_terms > ICEM_MAX_COST_TERMS) return fail(ICEM_E_INVALID, "n_terms must be in [0, 8]");
+    for (int j = 0; j < terms->n_terms; ++j) {
+        const icem_cost_term& tm = terms->terms[j];
+        if (tm.kind < ICEM_TERM_NORM || tm.kind > ICEM_TERM_STEP_GT) return fail(ICEM_E_INVALID, "unknown cost term kind");
+        if (tm.len < 1 || tm.len > ICEM_MAX_TERM_LEN) return fail(ICEM_E_INVALID, "cost term len must be in [1, 64]");
+    }
+    if (terms->box_from >= 0 && terms->health_idx < 0)
+        return fail(ICEM_E_INVALID, "box_from is part of the health term: health_idx must be set");
+    h->terms = *terms;
+    h->has_terms = terms->diff_idx >= 0 || terms->health_idx >= 0 || terms->n_terms > 0;
+    return ICEM_OK;
+}
+
+int icem_trajectory_cost(icem_handle* h, int32_t n, int32_t obs_dim, const void* observations,
+                         const void* next_observations, int64_t traj_stride, int64_t step_stride, const void* actions,
+                         void* costs, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (!h->has_cost) return fail(ICEM_E_STATE, "icem_set_cost must be called first");
+    if (n < 0 || obs_dim < 1 || !observations || !actions || !costs) return fail(ICEM_E_INVALID, "null tensor / bad n or obs_dim");
+    if (const char* e = cost_indices_error(h, obs_dim)) return fail(ICEM_E_INVALID, e);
+    if (h->has_terms && h->terms.diff_idx >= 0 && !next_observations)
+        return fail(ICEM_E_INVALID, "the difference term needs next_observations");
+    if (n == 0) return ICEM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    return gk_trajectory_cost(h, n, obs_dim, observations, next_observations, traj_stride, step_stride, actions, costs, st);
+}
+
+int icem_sample_clip(icem_handle* h, int32_t n, int64_t first_index, const void* mean, const void* std,
+                     const void* low, const void* high, const void* z_r, const void* z_i, uint64_t offset,
+                     int32_t t_begin, int32_t row0_mean, void* actions, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (n < 0 || !mean || !std || !low || !high || !actions) return fail(ICEM_E_INVALID, "null tensor / negative n");
+    if (h->cfg.noise_beta > 0 && (z_r == nullptr) != (z_i == nullptr))
+        return fail(ICEM_E_INVALID, "z_r and z_i must both be given or both NULL");
+    if (t_begin < 0 || t_begin >= h->cfg.horizon) return fail(ICEM_E_INVALID, "t_begin out of range");
+    hipStream_t st = (hipStream_t)stream;
+    if (z_r == nullptr && t_begin == 0 && fast_sample_ok(h))
+        return launch_fast_sample(h, n, first_index, mean, std, low, high, offset, row0_mean, actions, st);
+    return gk_sample(h, n, first_index, mean, std, low, high, z_r, z_i, offset, t_begin, row0_mean, actions, st);
+}
+
+int icem_sample_truncnorm(icem_handle* h, int32_t n, int64_t first_index, const void* mean, const void* std,
+                          const void* lower, const void* upper, const void* u, uint64_t offset, void* actions,
+                          void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (n < 0 || !mean || !std || !lower || !upper || !actions) return fail(ICEM_E_INVALID, "null tensor / negative n");
+    if (n == 0) return ICEM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    return gk_sample_truncnorm(h, n, first_index, mean, std, lower, upper, u, offset, actions, st);
+}
+
+int icem_sample_piecewise(icem_handle* h, int32_t n, int64_t call_offset, int32_t change_freq, int64_t first_block,
+                          const void* low, const void* high, const void* u, void* actions, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (n < 0 || call_offset < 0 || change_freq < 0 || !low || !high || !actions)
+        return fail(ICEM_E_INVALID, "null tensor / negative n, call_offset or change_freq");
+    if (n == 0) return ICEM_OK;
+    return gk_sample_piecewise(h, n, call_offset, change_freq, first_block, low, high, u, actions, (hipStream_t)stream);
+}
+
+int icem_cem_bounds(icem_handle* h, int32_t like_levine, const void* mean, void* std, const void* low, const void* high,
+                    void* lower, void* upper, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (!mean || !std || !low || !high || !lower || !upper) return fail(ICEM_E_INVALID, "null tensor");
+    hipStream_t st = (hipStream_t)stream;
+    return gk_cem_bounds(h, like_levine, mean, std, low, high, lower, upper, st);
+}
+
+int icem_philox_normals(icem_handle* h, int32_t n, int64_t first_index, uint64_t offset, void* z_r, void* z_i,
+                        void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (n <= 0 || !z_r || !z_i) return fail(ICEM_E_INVALID, "null tensor / n <= 0");
+    hipStream_t st = (hipStream_t)stream;
+    return gk_philox_normals(h, n, first_index, offset, z_r, z_i, st);
+}
+
+int icem_rollout_cost(icem_handle* h, int32_t n, const void* obs0, const void* actions, void* costs,
+                      void* observations, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (!h->has_model || !h->has_cost) return fail(ICEM_E_STATE, "icem_set_model / icem_set_cost must be called first");
+    if (n < 0 || !obs0 || !actions || !costs) return fail(ICEM_E_INVALID, "null tensor / negative n");
+    if (const char* e = cost_indices_error(h, h->obs_dim)) return fail(ICEM_E_INVALID, e);
+    hipStream_t st = (hipStream_t)stream;
+    if (observations == nullptr && n > 0 && fast_rollout_ok(h, 0))
+        return launch_fast_rollout(h, n, 0, 0, obs0, actions, costs, nullptr, nullptr, st, nullptr);
+    return gk_rollout(h, n, obs0, actions, costs, observations, st);
+}
+
+int icem_cost_reduce(icem_handle* h, int32_t n, const void* step_costs, void* costs, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (n < 0 || !step_costs || !costs) return fail(ICEM_E_INVALID, "null tensor / negative n");
+    if (n == 0) return ICEM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    return gk_cost_reduce(h, n, step_costs, costs, st);
+}
+
+size_t icem_topk_workspace_bytes(const icem_handle* h, int32_t n, int32_t k) {
+    if (!h || n < 1 || k < 1) return 0;
+    return (size_t)topk_blocks(n) * (size_t)k * (h->tsize + sizeof(int));
+}
+
+int icem_topk_sorted(icem_handle* h, int32_t n, const void* costs, int32_t k, void* out_cost, int32_t* out_idx,
+                     void* workspace, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (n < 1 || k < 1 || k > ICEM_MAX_ELITES || !costs || !out_cost || !out_idx || !workspace)
+        return fail(ICEM_E_INVALID, "bad n/k or null tensor");
+    if (k > n) return fail(ICEM_E_INVALID, "k > n: fewer candidates than elites");
+    hipStream_t st = (hipStream_t)stream;
+    return gk_topk(h, n, k, costs, out_cost, out_idx, workspace, st);
+}
+
+int icem_gather_refit(icem_handle* h, const void* actions, const int32_t* idx, int32_t k, void* mean, void* std,
+                      void* elites_out, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (k < 1 || !actions || !idx || !mean || !std) return fail(ICEM_E_INVALID, "bad k or null tensor");
+    hipStream_t st = (hipStream_t)stream;
+    return gk_gather_refit(h, actions, idx, k, mean, std, elites_out, st);
+}
+
+int icem_shift(icem_handle* h, void* mean, void* std, const void* low, const void* high, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (!mean || !std || !low || !high) return fail(ICEM_E_INVALID, "null tensor");
+    hipStream_t st = (hipStream_t)stream;
+    return gk_shift(h, mean, std, low, high, st);
+}
+
+int icem_reset_distribution(icem_handle* h, void* mean, void* std, const void* low, const void* high, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (!mean || !std || !low || !high) return fail(ICEM_E_INVALID, "null tensor");
+    hipStream_t st = (hipStream_t)stream;
+    return gk_reset(h, mean, std, low, high, st);
+}
+
+int icem_debug_stamps(icem_handle* h, void* dev_ptr) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    h->dbg = (long long*)dev_ptr;
+    return ICEM_OK;
+}
+
+int icem_profile_enable(icem_handle* h, int32_t on) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    h->profiling = on != 0;
+    return ICEM_OK;
+}
+
+int icem_profile_read(icem_handle* h, double* total_ms, int64_t* launches, int64_t* units) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (!total_ms || !launches || !units) return fail(ICEM_E_INVALID, "null output");
+    for (int k = 0; k < ICEM_K_COUNT; ++k) {
+        total_ms[k] = 0.0;
+        launches[k] = 0;
+        units[k] = 0;
+    }
+    for (auto& sp : h->spans) {
+        ICEM_HIP_TRY(hipEventSynchronize(sp.b));
+        float ms = 0.f;
+        ICEM_HIP_TRY(hipEventElapsedTime(&ms, sp.a, sp.b));
+        total_ms[sp.kind] += ms;
+        launches[sp.kind] += 1;
+        units[sp.kind] += sp.units;
+        h->free_events.push_back(sp.a);
+        h->free_events.push_back(sp.b);
+    }
+    h->spans.clear();
+    return ICEM_OK;
+}
+
+size_t icem_record_bytes(const icem_handle* h) { return h ? (size_t)(h->hd + 2) * h->tsize : 0; }
+
+size_t icem_rssm_param_elems(void) { return rssm::TOTAL; }
+
+int icem_rssm_rollout_cost(int32_t n, int32_t horizon, int32_t cost_mode, const void* params, const void* obs0,
+                           const void* actions, void* costs, void* stream) {
+    if (n < 0 || horizon < 1 || cost_mode < ICEM_COST_SUM || cost_mode > ICEM_COST_FINAL || !params || !obs0 || !actions || !costs)
+        return fail(ICEM_E_INVALID, "null tensor / bad n, horizon or cost_mode");
+    ICEM_HIP_TRY(launch_rssm_rollout(n, horizon, cost_mode, (const unsigned short*)params, (const float*)obs0,
+                                     (const float*)actions, (float*)costs, (hipStream_t)stream));
+    return ICEM_OK;
+}
+
+}  // extern "C"

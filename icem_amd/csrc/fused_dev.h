@@ -1,31 +1,26 @@
-// icem_fused.hip -- the f32 throughput kernels for gfx950 (see icem_fused.h).
-//
-// sample_folded_kernel<H, ROUNDS>   (K1)
-//   one thread per (trajectory, action-dim) row: Philox4x32 -> Box-Muller -> the h white draws of
-//   the row in registers; inverse real DFT folded on its cos/sin symmetry (t and h-t share the even
-//   sum and negate the odd one: ~h*h/2 FMAs instead of h*h) with the table rows as wave-uniform
-//   scalar operands; affine (mean/std staged in LDS) + clip; samples parked in an LDS tile laid out
-//   like the [n, h, d] output so the slab leaves as coalesced stores.
-// rollout_mfma_kernel<H, D, O, KIND> (K2 + K3)
-//   one wavefront per 64 trajectories, lane = trajectory.  The model step [o | a] . [A ; B] runs on
-//   the matrix pipe as v_mfma_f32_4x4x1 (16 blocks of 4 trajectories, exact f32, the same k-ordered
-//   fmaf chain as scalar code): A-operand = 4 model output columns (resident in VGPRs), B-operand =
-//   the lane's own x_k, result register i of column tile ct = output 4*ct + i of THIS lane's
-//   trajectory -- no transposes, no LDS.  The cost runs on the VALU under the MFMAs; actions stream
-//   from HBM/L2 as 16-byte loads one group of steps ahead.  The wave then bitonic-sorts its 64
-//   (cost, index) keys and keeps a running sorted top-K: K candidates per wave.
-// merge_single_kernel: 1024 threads, one per candidate list; K tournament rounds over the list
-//   heads give the global sorted top-K; then gather + refit + epilogue (icem.py:163-211).
+// fused_dev.h -- device-side building blocks shared by the f32 throughput kernels (k_*.hip): packed (cost, index)
+// keys and the DPP / permlane bitonic sort, the per-row colored-noise sampler (sample_row), the 16-trajectory
+// matrix-pipe rollout tile (Tile16), per-workgroup candidate-list merging, and the global top-K selection
+// (merge_select*).  Everything here is __device__ __forceinline__ in an anonymous namespace: every translation unit
+// gets its own copy, and all of them produce the same bits for the same inputs (the shard- and path-invariance tests
+// rely on that).  Internal; not part of the public ABI.
+#pragma once
 #include "icem_fused.h"
 
 #include <climits>
 #include <cmath>
 #include <cstdlib>
+#include <algorithm>
 #include <type_traits>
 #include <utility>
 
 #include "philox.h"
 #include "refit.h"
+
+// shapes (H, D, O) with a compiled matrix-pipe rollout; anything else runs on the generic kernels
+#define ICEM_FAST_SHAPES(X) X(30, 6, 17) X(30, 6, 18) X(12, 6, 17) X(13, 4, 17) X(30, 17, 24)
+// horizons with a compiled folded sampler
+#define ICEM_FAST_HORIZONS(X) X(30) X(12) X(13) X(10)
 
 namespace icem {
 
@@ -169,73 +164,6 @@ __device__ __forceinline__ void sample_row(const float* __restrict__ W, unsigned
         const float e = e0 + e1, od = o0 + o1;
         emit(tp, e + od);
         if (H - tp != tp) emit(H - tp, e - od);
-    }
-}
-
-template <int H, int ROUNDS>
-__global__ __launch_bounds__(SWG) void sample_folded_kernel(FastSampleArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int d = a.d;
-    const int hd = H * d;
-    const int tpw = SWG / d;
-    float* ms = smem;            // mean | std
-    float* tile = smem + 2 * hd;  // [tpw, hd]
-    const int tid = threadIdx.x;
-    for (int e = tid; e < hd; e += SWG) {
-        ms[e] = a.mean[e];
-        ms[hd + e] = a.std[e];
-    }
-    const int n_base = blockIdx.x * tpw;
-    const int n_here = cmin(tpw, a.n - n_base);
-    __syncthreads();
-    if (a.n_shift > 0 && blockIdx.x == gridDim.x - 1) {
-        // the extra workgroup: shifted elites.  Row (e, j) keeps elites[e, 1:, j] and draws its last action
-        // from the full (n_shift, d, h) noise batch of stream off2 (only t = h-1 is used, icem.py:102)
-        if (tid < a.n_shift * d) {
-            const int e = tid / d;
-            const int j = tid - e * d;
-            const float lo = a.low[j], hi = a.high[j];
-            float last = 0.f;
-            sample_row<H, ROUNDS>(a.W, (unsigned)e, (unsigned)j, a.off2_lo, a.off2_hi, a.seed_lo, a.seed_hi,
-                                  [&](int t, float y) {
-                                      if (t == H - 1) {
-                                          float v = __builtin_fmaf(y, ms[hd + t * d + j], ms[t * d + j]);
-                                          v = v < lo ? lo : v;
-                                          last = v > hi ? hi : v;
-                                      }
-                                  }, a.white != 0);
-            float* dst = a.out + (size_t)(a.n + e) * hd + j;
-            const float* src = a.elites_src + (size_t)e * hd + j;
-            for (int t = 0; t < H - 1; ++t) dst[t * d] = src[(t + 1) * d];
-            dst[(H - 1) * d] = last;
-        }
-        return;
-    }
-    if (tid < n_here * d) {
-        const int nl = tid / d;
-        const int j = tid - nl * d;
-        const float lo = a.low[j], hi = a.high[j];
-        float* trow = tile + nl * hd + j;
-        const float* mrow = ms + j;
-        sample_row<H, ROUNDS>(a.W, (unsigned)(a.first_index + n_base + nl), (unsigned)j, a.off_lo, a.off_hi, a.seed_lo,
-                              a.seed_hi, [&](int t, float y) {
-                                  const float v = __builtin_fmaf(y, mrow[hd + t * d], mrow[t * d]);
-                                  trow[t * d] = __builtin_amdgcn_fmed3f(v, lo, hi);  // clip in one v_med3_f32
-                              }, a.white != 0);
-    }
-    __syncthreads();
-    if (a.row0_mean && a.first_index + n_base == 0) {  // icem.py:87-88
-        for (int e = tid; e < hd; e += SWG) tile[e] = ms[e];
-        __syncthreads();
-    }
-    float* gdst = a.out + (size_t)n_base * hd;
-    const int total = n_here * hd;
-    if ((hd & 3) == 0) {
-        const float4* t4 = reinterpret_cast<const float4*>(tile);
-        float4* g4 = reinterpret_cast<float4*>(gdst);
-        for (int e = tid; e < total / 4; e += SWG) g4[e] = t4[e];
-    } else {
-        for (int e = tid; e < total; e += SWG) gdst[e] = tile[e];
     }
 }
 
@@ -529,93 +457,6 @@ __device__ __forceinline__ void wg_merge_emit(unsigned long long (*wg_keys)[WAVE
     }
 }
 
-template <int H, int D, int O, int KIND, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void rollout16_kernel(FastRolloutArgs a) {
-    using Tile = Tile16<H, D, O, KIND>;
-    constexpr int HD = H * D;
-    constexpr int VW = HD % 4 == 0 ? 4 : 2;    // floats per load: rows are 16-byte aligned only if h*d % 4 == 0
-    static_assert(HD % 2 == 0, "8-byte aligned action rows");
-    using Vec = typename VecOf<VW>::type;
-    constexpr int TC = r16_chunk_steps(H, D, VW);  // steps per action chunk
-    static_assert(TC > 0, "no aligned action chunk for this (H, D)");
-    constexpr int CB = TC * D;                 // floats per row and chunk
-    constexpr int C4 = CB / VW;                // vectors per row and chunk
-    constexpr int CBP = (C4 % 2) ? CB : CB + VW;  // LDS row stride: odd number of vectors
-    constexpr int NCH = H / TC;
-    constexpr int F4 = 16 * C4;                // vectors per chunk of a 16-trajectory tile
-    constexpr int NLD = (F4 + 63) / 64;        // cooperative load instructions per chunk
-    constexpr int STG = Tile::SLACK + 16 * CBP + Tile::TAIL;
-    // the tile's actions are one contiguous 16 x H x D block of HBM: the wave fetches it with full-width coalesced
-    // loads, chunk by chunk, into its own LDS buffer; each lane then reads the one or two entries it feeds to the MFMAs
-    __shared__ __attribute__((aligned(16))) float stage[WAVES][STG];
-    __shared__ unsigned long long wg_keys[2][WAVES][32];
-    __shared__ float obs_stage[32];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    // model operands and start observation in flight together: one wait at the barrier
-    const float obs_reg = a.obs0[(threadIdx.x < 32 && (int)threadIdx.x < a.o) ? threadIdx.x : 0];
-    Tile tile;
-    tile.load(a, lane);
-    if (threadIdx.x < 32) obs_stage[threadIdx.x] = (int)threadIdx.x < a.o ? obs_reg : 0.f;
-    __syncthreads();
-    tile.load_obs(obs_stage);
-    const float* rd0 = tile.read_ptr(stage[wave], lane, CBP);
-    // cooperative loads: float4 number f = m * 64 + lane of a chunk is row f / C4, float4 f % C4 of that row
-    int ld_row[NLD], ld_c4[NLD];
-    bool ld_on[NLD];
-#pragma unroll
-    for (int m = 0; m < NLD; ++m) {
-        const int f = m * 64 + lane;
-        ld_on[m] = f < F4;
-        ld_row[m] = ld_on[m] ? f / C4 : 0;
-        ld_c4[m] = ld_on[m] ? f % C4 : 0;
-    }
-
-    unsigned long long run_key = KEY_SENTINEL;
-    bool first = true;
-    const int tiles = (a.n_rows + 15) / 16;
-    // tile t of the launch belongs to wave t / gridDim.x of workgroup t % gridDim.x: a short launch thins every CU
-    for (int tile_id = wave * gridDim.x + blockIdx.x; tile_id < tiles; tile_id += WAVES * gridDim.x) {
-        const int row = tile_id * 16 + (lane & 15);
-        const bool live = row < a.n_rows;
-        const Vec* src[NLD];
-#pragma unroll
-        for (int m = 0; m < NLD; ++m) {
-            const int r = tile_id * 16 + ld_row[m];
-            src[m] = reinterpret_cast<const Vec*>(a.actions + (size_t)(r < a.n_rows ? r : 0) * HD) + ld_c4[m];
-        }
-        Vec pre[NLD];
-#pragma unroll
-        for (int m = 0; m < NLD; ++m) pre[m] = src[m][0];
-        typename Tile::State st;
-        tile.init(st);
-#pragma unroll
-        for (int t = 0; t < H; ++t) {
-            if (t % TC == 0) {
-                // next chunk: registers -> this wave's LDS buffer (only this wave touches it and a wave's LDS
-                // operations execute in order: no barrier), then start fetching the one after
-#pragma unroll
-                for (int m = 0; m < NLD; ++m)
-                    if (ld_on[m])
-                        *reinterpret_cast<Vec*>(&stage[wave][Tile::SLACK + ld_row[m] * CBP + VW * ld_c4[m]]) = pre[m];
-                if (t / TC + 1 < NCH) {
-#pragma unroll
-                    for (int m = 0; m < NLD; ++m) pre[m] = src[m][(t / TC + 1) * C4];
-                }
-            }
-            tile.step(st, rd0 + (t % TC) * D);
-        }
-        const float cost = tile.cost(st);
-        if (live && lane < 16) a.costs[row] = cost;
-        if (a.K > 0) {
-            const unsigned long long key = (lane < 16 && live && row < a.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
-            run_key = topk_push16(run_key, key, first, a.K, lane);
-            first = false;
-        }
-    }
-    if (a.K > 0) wg_merge_emit<WAVES>(wg_keys, run_key, a.K, lane, wave, a);
-}
-
 // -------------------------------------------------------------------------------------------------
 // merge: global sorted top-K from <= 256 sorted candidate lists (+ kept elites)
 // -------------------------------------------------------------------------------------------------
@@ -896,225 +737,6 @@ __device__ __forceinline__ void merge_rows(const MergeSingleArgs& a, const unsig
     }
 }
 
-template <int KREG, bool REC>
-__global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs a) {
-    __shared__ unsigned long long sel[64];
-    __shared__ unsigned long long cand[64];
-    __shared__ int slot[64];
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float* new_mean = reinterpret_cast<float*>(smem_raw);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int hd = a.h * a.d;
-    if (a.dbg && threadIdx.x == 0) a.dbg[0] = wall_clock64();
-    // old mean/std of this thread's elements: issued now, consumed after the selection
-    constexpr int EPL = 4;
-    const bool pre = hd <= MERGE_WG * EPL;
-    float om[EPL], os[EPL];
-#pragma unroll
-    for (int i = 0; i < EPL; ++i) {
-        const int e = tid + i * MERGE_WG;
-        om[i] = (pre && e < hd) ? a.mean[e] : 0.f;
-        os[i] = (pre && e < hd) ? a.std[e] : 0.f;
-    }
-    if (tid < 64) {
-        if constexpr (REC)
-            merge_select_records(a, lane, cand, sel, slot);
-        else
-            merge_select<KREG>(a, lane, cand, sel);
-    }
-    if (a.dbg && threadIdx.x == 0) a.dbg[4] = wall_clock64();
-    __syncthreads();
-    // ---- all 4 waves: gather + refit (icem.py:201-211); row pointers first, then all K loads in flight ----
-    const float* rows[KREG];
-    merge_rows<KREG, REC>(a, sel, slot, rows);
-    auto finish_one = [&](int e, float old_mean, float old_std) {
-        float xs[KREG];
-#pragma unroll
-        for (int r = 0; r < KREG; ++r) xs[r] = rows[r][e];
-#pragma unroll
-        for (int r = 0; r < KREG; ++r)
-            if (r < a.K) a.elites_next[(size_t)r * hd + e] = xs[r];
-        float nm, ns;
-        refit_element_regs<float, KREG>(a.K, a.alpha, old_mean, old_std, xs, nm, ns);
-        if (!a.last) {
-            a.mean_out[e] = nm;
-            a.std_out[e] = ns;
-        } else {
-            new_mean[e] = nm;
-        }
-    };
-    if (pre) {
-#pragma unroll
-        for (int i = 0; i < EPL; ++i) {
-            const int e = tid + i * MERGE_WG;
-            if (e < hd) finish_one(e, om[i], os[i]);
-        }
-    } else {
-        for (int e = tid; e < hd; e += MERGE_WG) finish_one(e, a.mean[e], a.std[e]);
-    }
-    if (a.dbg && threadIdx.x == 0) a.dbg[5] = wall_clock64();
-    if (tid < a.K) a.elites_cost_next[tid] = key_cost(sel[tid]);
-    if (a.last) {
-        __syncthreads();
-        for (int e = tid; e < hd; e += MERGE_WG) {
-            const int j = e % a.d;
-            a.mean_out[e] = (e + a.d < hd) ? new_mean[e + a.d] : new_mean[e];
-            a.std_out[e] = (a.high[j] - a.low[j]) / 2.f * a.init_std;
-        }
-        if (tid < a.d) a.executed[tid] = rows[0][tid];
-        if (tid == 0) a.best_cost[0] = key_cost(sel[0]);
-    }
-    if (a.dbg && threadIdx.x == 0) a.dbg[6] = wall_clock64();
-}
-
-// Sharded runs: this rank's K best candidates (same selection) packed as records {cost, gidx, actions[h*d]} for
-// the all-gather.  Local pool row li is global trajectory shard_lo + li, or n_global + (li - n_loc) for the
-// replicated shifted elites behind the shard (icem_amd/distributed.py).
-template <int KREG>
-__global__ __launch_bounds__(MERGE_WG) void pack_records_kernel(MergeSingleArgs a, int n_loc, int shard_lo, float* records) {
-    __shared__ unsigned long long sel[64];
-    __shared__ unsigned long long cand[64];
-    const int tid = threadIdx.x;
-    const int hd = a.h * a.d;
-    const int rs = hd + 2;
-    if (tid < 64) merge_select<KREG>(a, tid, cand, sel);
-    __syncthreads();
-    // headers by the first K threads; rows: element e of all K rows per thread, every load in flight before a store
-    if (tid < a.K) {
-        const unsigned long long key = sel[tid];
-        float* rec = records + (size_t)tid * rs;
-        if (key == KEY_SENTINEL) {  // fewer than K candidates on this rank
-            rec[0] = INFINITY;
-            reinterpret_cast<int*>(rec + 1)[0] = INT_MAX;
-        } else {
-            const int li = key_idx(key);
-            rec[0] = key_cost(key);
-            reinterpret_cast<int*>(rec + 1)[0] = li < n_loc ? shard_lo + li : a.n_global + (li - n_loc);
-        }
-    }
-    const float* rows[KREG];
-    bool dead[KREG];
-#pragma unroll
-    for (int r = 0; r < KREG; ++r) {
-        const unsigned long long key = sel[r < a.K ? r : 0];
-        dead[r] = key == KEY_SENTINEL;
-        rows[r] = a.actions + (size_t)(dead[r] ? 0 : key_idx(key)) * hd;
-    }
-    for (int e = tid; e < hd; e += MERGE_WG) {
-        float xs[KREG];
-#pragma unroll
-        for (int r = 0; r < KREG; ++r) xs[r] = rows[r][e];
-#pragma unroll
-        for (int r = 0; r < KREG; ++r)
-            if (r < a.K) records[(size_t)r * rs + 2 + e] = dead[r] ? 0.f : xs[r];
-    }
-}
-
-// -------------------------------------------------------------------------------------------------
-// K1 with the PREVIOUS iteration's K3 + K4 in its prologue (populations too large for the single-launch kernel)
-// -------------------------------------------------------------------------------------------------
-// sample_folded_kernel plus one wavefront per workgroup that runs the low-register selection
-// (merge_select_stream) on the previous iteration's candidate lists while the 4 sampling waves draw their noise
-// into the LDS tile; then all 5 waves gather the K elite rows and refit, the affine map + clip is applied to the
-// tile and the tile leaves as before.  Every workgroup redoes the same merge (L2 serves the 20 KB of keys and 7 KB
-// of elite rows), workgroup 0 publishes it.  Saves the merge launch (8.6 + 2.6 us) for ~3 us more sampler time.
-template <int H, int ROUNDS, int KREG, bool REC>
-__global__ __launch_bounds__(SWG + 64) void sample_folded_merge_kernel(FastSampleMergeArgs args) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ unsigned long long sel[64];
-    __shared__ unsigned long long cand[64];
-    __shared__ int slot[64];
-    constexpr int NTT = SWG + 64;
-    const FastSampleArgs& a = args.s;
-    const MergeSingleArgs& m = args.m;
-    const int d = a.d;
-    const int hd = H * d;
-    const int tpw = SWG / d;
-    float* ms = smem;            // mean | std (computed here)
-    float* tile = smem + 2 * hd;  // [tpw, hd]
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int n_base = blockIdx.x * tpw;
-    const int n_here = cmin(tpw, a.n - n_base);
-    const bool has_row = tid < n_here * d;
-    const int nl = tid / d;
-    const int j = tid - nl * d;
-    float* trow = tile + nl * hd + j;
-    if (tid >= SWG) {
-        if constexpr (REC)
-            merge_select_records(m, lane, cand, sel, slot);
-        else
-            merge_select_stream(m, lane, cand, sel);
-    } else if (has_row) {
-        sample_row<H, ROUNDS>(a.W, (unsigned)(a.first_index + n_base + nl), (unsigned)j, a.off_lo, a.off_hi, a.seed_lo,
-                              a.seed_hi, [&](int t, float y) { trow[t * d] = y; }, a.white != 0);
-    }
-    __syncthreads();
-    {
-        const float* rows[KREG];
-        merge_rows<KREG, REC>(m, sel, slot, rows);
-        for (int e = tid; e < hd; e += NTT) {
-            float xs[KREG];
-#pragma unroll
-            for (int r = 0; r < KREG; ++r) xs[r] = rows[r][e];
-            float nm, ns;
-            refit_element_regs<float, KREG>(m.K, m.alpha, m.mean[e], m.std[e], xs, nm, ns);
-            ms[e] = nm;
-            ms[hd + e] = ns;
-            if (blockIdx.x == 0) {
-                m.mean_out[e] = nm;
-                m.std_out[e] = ns;
-#pragma unroll
-                for (int r = 0; r < KREG; ++r)
-                    if (r < m.K) m.elites_next[(size_t)r * hd + e] = xs[r];
-            }
-        }
-        if (blockIdx.x == 0 && tid < m.K) m.elites_cost_next[tid] = key_cost(sel[tid]);
-    }
-    __syncthreads();
-    if (has_row) {
-        const float lo = a.low[j], hi = a.high[j];
-        const float* mrow = ms + j;
-        for (int t = 0; t < H; ++t) {
-            const float v = __builtin_fmaf(trow[t * d], mrow[hd + t * d], mrow[t * d]);
-            trow[t * d] = __builtin_amdgcn_fmed3f(v, lo, hi);
-        }
-    }
-    __syncthreads();
-    if (a.row0_mean && a.first_index + n_base == 0) {  // icem.py:87-88
-        for (int e = tid; e < hd; e += NTT) tile[e] = ms[e];
-        __syncthreads();
-    }
-    float* gdst = a.out + (size_t)n_base * hd;
-    const int total = n_here * hd;
-    if ((hd & 3) == 0) {
-        const float4* t4 = reinterpret_cast<const float4*>(tile);
-        float4* g4 = reinterpret_cast<float4*>(gdst);
-        for (int e = tid; e < total / 4; e += NTT) g4[e] = t4[e];
-    } else {
-        for (int e = tid; e < total; e += NTT) gdst[e] = tile[e];
-    }
-}
-
-// -------------------------------------------------------------------------------------------------
-// K1 + K2 + K3 in one launch for small populations (+ the PREVIOUS iteration's K3 + K4 in its prologue)
-// -------------------------------------------------------------------------------------------------
-// With a few thousand trajectories the chip is mostly empty and an iteration is a chain of latencies: launch,
-// prologue, one thread's RNG -> DFT chain, HBM round trip of the actions, launch, prologue, 30 dependent model
-// steps, launch, merge.  Here a workgroup samples 16 * RW trajectories into an LDS tile (one thread per
-// (trajectory, dim) row, same code as sample_folded_kernel), writes the tile to HBM for the elite gather, and its
-// first RW waves roll the trajectories out straight from the tile (same code as rollout16_kernel): one launch, no
-// HBM round trip.
-// KREG > 0 ("merge prologue"): the distribution this iteration samples from is not in memory yet -- every
-// workgroup computes it itself from the previous iteration's candidate lists.  An extra wavefront runs the
-// selection (merge_select) WHILE the sampling waves draw their noise (which does not depend on mean / std: the
-// raw colored samples are parked in the tile); then all threads gather the K elite rows and refit (same
-// arithmetic as merge_single_kernel, so every workgroup gets the same bits), the affine map + clip is applied to
-// the tile, and the iteration proceeds as above.  Workgroup 0 also writes the new distribution and elite set for
-// the host / the next launch.  That removes the merge launch and hides its latency behind the sampling.  The
-// previous pool, lists and distribution are read while this launch writes new ones: all three are ping-pong
-// buffers (icem_plan_step).
 // The three kinds of rows of a single-launch slab.  RAW: the
 // distribution is still being computed -- park the raw colored samples (merge prologue, sampled rows only).
 template <int H, int D, int ROUNDS, bool RAW>
@@ -1173,156 +795,8 @@ __device__ __forceinline__ unsigned long long rollout_slab(Tile& tile, const Fas
     return run_key;
 }
 
-template <int H, int D, int O, int KIND, int ROUNDS, int RW, int KREG, bool REC>
-__global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64 + (KREG > 0 ? 64 : 0)) void sample_rollout_kernel(FastIterArgs a) {
-    using Tile = Tile16<H, D, O, KIND>;
-    constexpr bool PM = KREG > 0;
-    constexpr int HD = H * D;
-    constexpr int TPB = 16 * RW;                     // trajectories per workgroup
-    constexpr int ROWS = TPB * D;                    // (trajectory, dim) rows, one thread each
-    constexpr int NT = ((ROWS + 63) / 64) * 64;      // sampling threads
-    constexpr int NTT = NT + (PM ? 64 : 0);          // + the selection wavefront
-    static_assert(NTT <= 1024 && HD % 2 == 0, "workgroup shape");
-    constexpr int VW = HD % 4 == 0 ? 4 : 2;  // floats per vector of the tile -> HBM copy (rows are 4 * HD bytes)
-    using Vec = typename VecOf<VW>::type;
-    __shared__ __attribute__((aligned(16))) float ms[2 * HD];  // mean | std
-    __shared__ __attribute__((aligned(16))) float tilebuf[Tile::SLACK + TPB * HD + Tile::TAIL];
-    __shared__ unsigned long long wg_keys[2][RW][32];
-    __shared__ float obs_stage[32];
-    __shared__ unsigned long long sel[PM ? 64 : 1];
-    __shared__ unsigned long long cand[PM ? 64 : 1];
-    __shared__ int slot[PM ? 64 : 1];
-    float* tile_rows = tilebuf + Tile::SLACK;
-    const FastSampleArgs& sa = a.s;
-    const FastRolloutArgs& ra = a.r;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int n_rows = ra.n_rows;       // sa.n sampled rows, then sa.n_shift shifted elites
-    const int base = blockIdx.x * TPB;  // one slab of TPB trajectories per workgroup (launch_sample_rollout)
-    if (base >= n_rows) return;
-    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[8] = wall_clock64();
-    // Order matters at this size: kernel arguments arrive through serialized scalar loads, so everything the RNG
-    // chain does not need (start observation, model operands, bounds) is fetched AFTER the sampling got going.
-    const int nl = tid / D, jd = tid - nl * D;
-    const bool has_row = tid < ROWS;
-    float* trow = tile_rows + nl * HD + jd;
-    const float* mrow = ms + jd;
-    Tile tile;
-    float obs_reg = 0.f;
-    if (!PM) {  // iteration 0 of an MPC step: the distribution is in memory; the model operands ride the same wait
-        obs_reg = ra.obs0[(tid < 32 && tid < ra.o) ? tid : 0];
-        if (wave < RW) tile.load(ra, lane);
-        for (int e = tid; e < HD; e += NTT) {
-            ms[e] = sa.mean[e];
-            ms[HD + e] = sa.std[e];
-        }
-        __syncthreads();
-    }
-    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[9] = wall_clock64();
-    const int r_mine = base + nl;
-    if (has_row) sample_into_tile<H, D, ROUNDS, PM>(sa, n_rows, r_mine, jd, trow, mrow);
-    if constexpr (PM) {
-        if (tid >= NT) {
-            if constexpr (REC)
-                merge_select_records(a.m, lane, cand, sel, slot);
-            else if constexpr (RW >= 8)  // 13 waves share the register file: the low-register selection
-                merge_select_stream(a.m, lane, cand, sel);
-            else
-                merge_select<KREG>(a.m, lane, cand, sel);
-        }
-    }
-    if (PM) {  // now the rest of the inputs: in flight across the barriers below
-        obs_reg = ra.obs0[(tid < 32 && tid < ra.o) ? tid : 0];
-        if (wave < RW) tile.load(ra, lane);
-    }
-    const float* rd0 = tile.read_ptr(tilebuf + (wave < RW ? wave : 0) * 16 * HD, lane, HD);
-    if constexpr (PM) {
-        const MergeSingleArgs& m = a.m;
-        __syncthreads();
-        // all threads: gather the elite rows + refit (icem.py:201-211) -> this workgroup's mean / std
-        const float* rows[KREG > 0 ? KREG : 1];
-        merge_rows<KREG, REC>(m, sel, slot, rows);
-        for (int e = tid; e < HD; e += NTT) {
-            float xs[KREG > 0 ? KREG : 1];
-#pragma unroll
-            for (int r = 0; r < KREG; ++r) xs[r] = rows[r][e];
-            float nm, ns;
-            refit_element_regs<float, KREG>(m.K, m.alpha, m.mean[e], m.std[e], xs, nm, ns);
-            ms[e] = nm;
-            ms[HD + e] = ns;
-            if (blockIdx.x == 0) {
-                m.mean_out[e] = nm;
-                m.std_out[e] = ns;
-#pragma unroll
-                for (int r = 0; r < KREG; ++r)
-                    if (r < m.K) m.elites_next[(size_t)r * HD + e] = xs[r];
-            }
-        }
-        if (blockIdx.x == 0 && tid < m.K) m.elites_cost_next[tid] = key_cost(sel[tid]);
-        __syncthreads();
-        if (has_row && r_mine < sa.n) {  // y * std + mean, clipped (icem.py:79)
-            const float lo = sa.low[jd], hi = sa.high[jd];
-            for (int t = 0; t < H; ++t) {
-                const float v = __builtin_fmaf(trow[t * D], mrow[HD + t * D], mrow[t * D]);
-                trow[t * D] = __builtin_amdgcn_fmed3f(v, lo, hi);
-            }
-        }
-    }
-    if (tid < 32) {  // start observation -> LDS (consumed after the barrier)
-        float ov = obs_reg;
-        asm volatile("" : "+v"(ov));  // wait for the load here, not where it was issued
-        obs_stage[tid] = tid < ra.o ? ov : 0.f;
-    }
-    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[10] = wall_clock64();
-    __syncthreads();
-    if (sa.row0_mean && sa.first_index + base == 0) {  // icem.py:87-88
-        for (int e = tid; e < HD; e += NTT) tile_rows[e] = ms[e];
-        __syncthreads();
-    }
-    {   // the tile is a contiguous block of the action tensor
-        const int total4 = (n_rows - base < TPB ? n_rows - base : TPB) * (HD / VW);
-        const Vec* t4 = reinterpret_cast<const Vec*>(tile_rows);
-        Vec* g4 = reinterpret_cast<Vec*>(sa.out + (size_t)base * HD);
-        for (int e = tid; e < total4; e += NTT) g4[e] = t4[e];
-    }
-    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[11] = wall_clock64();
-    unsigned long long run_key = KEY_SENTINEL;
-    if (wave < RW) {
-        tile.load_obs(obs_stage);
-        run_key = rollout_slab<Tile, H, D>(tile, ra, rd0, base + wave * 16 + (lane & 15), n_rows, run_key, true, lane);
-        if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[12] = wall_clock64();
-    }
-    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[13] = wall_clock64();
-    if (ra.K > 0) wg_merge_emit<RW>(wg_keys, run_key, ra.K, lane, wave, ra);
-    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[14] = wall_clock64();
-}
-
-}  // namespace
-
-// shapes (H, D, O) with a compiled matrix-pipe rollout; anything else runs on the generic kernels
-#define ICEM_FAST_SHAPES(X) X(30, 6, 17) X(30, 6, 18) X(12, 6, 17) X(13, 4, 17) X(30, 17, 24)
-
-// rollout waves a single-launch workgroup can hold for this shape: 16 * RW * D sampling threads (+ 64) within 1024
-// threads, the [16 * RW, H, D] tile within ~120 KB of LDS
-constexpr int single_launch_max_rw(int h, int d) {
-    int best = 0;
-    for (int rw = 1; rw <= 8; rw *= 2)
-        if (((16 * rw * d + 63) / 64) * 64 + 64 <= 1024 && 16 * rw * h * d * 4 <= 120 * 1024) best = rw;
-    return best;
-}
-
-bool fast_rollout_supported(int h, int d, int O, int K) {
-    if (K > 32) return false;
-#define X(HH, DD, OO) \
-    if (h == HH && d == DD && O == OO) return true;
-    ICEM_FAST_SHAPES(X)
-#undef X
-    return false;
-}
-
 // rollout launch shape: one 16-trajectory tile per wave while they fit, at most FAST_MAX_LISTS workgroups (= lists)
-static void r16_shape(int n_rows, int* grid, int* waves) {
+inline void r16_shape(int n_rows, int* grid, int* waves) {
     const int tiles = std::max(1, (n_rows + 15) / 16);
     const int g = std::min(tiles, FAST_MAX_LISTS);
     int w = 1;
@@ -1331,168 +805,6 @@ static void r16_shape(int n_rows, int* grid, int* waves) {
     *waves = w;
 }
 
-int rollout_lists(int h, int d, int O, int n_rows) {
-    int g, w;
-    r16_shape(n_rows, &g, &w);
-    return g;
-}
-
-void launch_rollout16(const FastRolloutArgs& a, int h, int d, int O, int kind, hipStream_t st) {
-    int grid, waves;
-    r16_shape(a.n_rows, &grid, &waves);
-#define XW(HH, DD, OO, WW)                                                                                  \
-    if (waves == WW) {                                                                                      \
-        if (kind == 1)                                                                                      \
-            hipLaunchKernelGGL((rollout16_kernel<HH, DD, OO, 1, WW>), dim3(grid), dim3(64 * WW), 0, st, a); \
-        else                                                                                                \
-            hipLaunchKernelGGL((rollout16_kernel<HH, DD, OO, 0, WW>), dim3(grid), dim3(64 * WW), 0, st, a); \
-        return;                                                                                             \
-    }
-#define XR(HH, DD, OO)                   \
-    if (h == HH && d == DD && O == OO) { \
-        XW(HH, DD, OO, 1)                \
-        XW(HH, DD, OO, 2)                \
-        XW(HH, DD, OO, 4)                \
-        XW(HH, DD, OO, 8)                \
-        XW(HH, DD, OO, 16)               \
-    }
-    ICEM_FAST_SHAPES(XR)
-#undef XR
-#undef XW
-}
-
-// single-launch iteration: compiled for the default generator (10 Philox rounds) and 1, 2, 4 or 8 rollout waves per
-// workgroup, one slab of 16 * rw trajectories each, at most FAST_MAX_LISTS workgroups (= candidate lists).
-// sample_rollout_lists: workgroups of the launch, 0 when the shape or size is outside that (use the two-kernel
-// path).  (Several slabs per workgroup through the same LDS tile were tried for larger populations: with one
-// 92 KB tile per CU the sampling and rollout phases of a workgroup run back to back at 2-3 waves per SIMD, and
-// N=65 536 took 297 instead of 220 us per MPC step -- the two full-occupancy kernels win there.)
-static bool sample_rollout_shape(int h, int d, int O, int rounds, int n_rows, int* grid_out, int* rw_out) {
-    static const int max_rw = [] { const char* e = getenv("ICEM_FUSE_MAX_RW"); return e ? atoi(e) : 8; }();
-    int grid, rw;
-    r16_shape(n_rows, &grid, &rw);
-    if (rounds != 10 || rw > max_rw || n_rows <= 0 || !fast_rollout_supported(h, d, O, 1) || !fast_sample_supported(h, d))
-        return false;
-    if (rw > single_launch_max_rw(h, d)) return false;  // one slab of 16 * rw trajectories per workgroup
-    *grid_out = std::min(grid, (n_rows + 16 * rw - 1) / (16 * rw));
-    *rw_out = rw;
-    return true;
-}
-
-int sample_rollout_lists(int h, int d, int O, int rounds, int n_rows) {
-    int grid, rw;
-    return sample_rollout_shape(h, d, O, rounds, n_rows, &grid, &rw) ? grid : 0;
-}
-
-// merge prologue: the selection wavefront joins the sampling waves (8 rollout waves: 13 waves share the register
-// file, the selection runs in its low-register form)
-bool sample_rollout_merge_ok(int h, int d, int O, int rounds, int n_rows, int K) {
-    static const int on = [] { const char* e = getenv("ICEM_MERGE_PROLOGUE"); return e ? atoi(e) : 1; }();
-    int grid, rw;
-    return on && K + 1 <= 12 && sample_rollout_shape(h, d, O, rounds, n_rows, &grid, &rw);
-}
-
-void launch_sample_rollout(const FastIterArgs& a, int h, int d, int O, int kind, bool merge_prologue, hipStream_t st) {
-    int grid, rw;
-    if (!sample_rollout_shape(h, d, O, 10, a.r.n_rows, &grid, &rw)) return;
-#define XK(HH, DD, OO, WW, KR, RC)                                                                                      \
-    {                                                                                                                   \
-        constexpr int NT = ((16 * WW * DD + 63) / 64) * 64 + (KR > 0 ? 64 : 0);                                         \
-        if (kind == 1)                                                                                                  \
-            hipLaunchKernelGGL((sample_rollout_kernel<HH, DD, OO, 1, 10, WW, KR, RC>), dim3(grid), dim3(NT), 0, st, a); \
-        else                                                                                                            \
-            hipLaunchKernelGGL((sample_rollout_kernel<HH, DD, OO, 0, 10, WW, KR, RC>), dim3(grid), dim3(NT), 0, st, a); \
-        return;                                                                                                         \
-    }
-#define XW(HH, DD, OO, WW)                                                   \
-    if constexpr (WW <= single_launch_max_rw(HH, DD)) {                      \
-        if (rw == WW) {                                                      \
-            if (merge_prologue && a.m.records) XK(HH, DD, OO, WW, 12, true)  \
-            if (merge_prologue) XK(HH, DD, OO, WW, 12, false)                \
-            XK(HH, DD, OO, WW, 0, false)                                     \
-        }                                                                    \
-    }
-#define XR(HH, DD, OO)                   \
-    if (h == HH && d == DD && O == OO) { \
-        XW(HH, DD, OO, 1)                \
-        XW(HH, DD, OO, 2)                \
-        XW(HH, DD, OO, 4)                \
-        XW(HH, DD, OO, 8)                \
-    }
-    ICEM_FAST_SHAPES(XR)
-#undef XR
-#undef XW
-#undef XK
-}
-
-#define ICEM_FAST_HORIZONS(X) X(30) X(12) X(13) X(10)
-
-bool fast_sample_supported(int h, int d) {
-    if (d > SWG) return false;
-#define X(HH) \
-    if (h == HH) return true;
-    ICEM_FAST_HORIZONS(X)
-#undef X
-    return false;
-}
-
-// sampler with the previous iteration's merge in its prologue (default generator only, K <= 11, no shifted elites)
-bool sample_folded_merge_ok(int h, int d, int rounds, int K) {
-    static const int on = [] { const char* e = getenv("ICEM_MERGE_PROLOGUE"); return e ? atoi(e) : 1; }();
-    return on && rounds == 10 && K + 1 <= 12 && fast_sample_supported(h, d);
-}
-
-void launch_sample_folded_merge(const FastSampleMergeArgs& a, hipStream_t st) {
-    const int tpw = SWG / a.s.d;
-    const int grid = (a.s.n + tpw - 1) / tpw;
-    const size_t lds = ((size_t)2 * a.s.h * a.s.d + (size_t)tpw * a.s.h * a.s.d) * sizeof(float);
-#define X(HH)                                                                                                  \
-    if (a.s.h == HH) {                                                                                         \
-        if (a.m.records)                                                                                       \
-            hipLaunchKernelGGL((sample_folded_merge_kernel<HH, 10, 12, true>), dim3(grid), dim3(SWG + 64), lds, st, a);  \
-        else                                                                                                   \
-            hipLaunchKernelGGL((sample_folded_merge_kernel<HH, 10, 12, false>), dim3(grid), dim3(SWG + 64), lds, st, a); \
-        return;                                                                                                \
-    }
-    ICEM_FAST_HORIZONS(X)
-#undef X
-}
-
-void launch_sample_folded(const FastSampleArgs& a, int rounds, hipStream_t st) {
-    const int tpw = SWG / a.d;
-    const int grid = (a.n + tpw - 1) / tpw + (a.n_shift > 0 ? 1 : 0);
-    const size_t lds = ((size_t)2 * a.h * a.d + (size_t)tpw * a.h * a.d) * sizeof(float);
-#define X(HH)                                                                                        \
-    if (a.h == HH) {                                                                                 \
-        if (rounds == 7)                                                                             \
-            hipLaunchKernelGGL((sample_folded_kernel<HH, 7>), dim3(grid), dim3(SWG), lds, st, a);    \
-        else                                                                                         \
-            hipLaunchKernelGGL((sample_folded_kernel<HH, 10>), dim3(grid), dim3(SWG), lds, st, a);   \
-        return;                                                                                      \
-    }
-    ICEM_FAST_HORIZONS(X)
-#undef X
-}
-
-void launch_pack_records(const MergeSingleArgs& a, int n_loc, int shard_lo, float* records, hipStream_t st) {
-    if (a.K + 1 <= 12)
-        hipLaunchKernelGGL((pack_records_kernel<12>), dim3(1), dim3(MERGE_WG), 0, st, a, n_loc, shard_lo, records);
-    else
-        hipLaunchKernelGGL((pack_records_kernel<34>), dim3(1), dim3(MERGE_WG), 0, st, a, n_loc, shard_lo, records);
-}
-
-void launch_merge_single(const MergeSingleArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)a.h * a.d * sizeof(float);
-    if (a.records) {
-        if (a.K + 1 <= 12)
-            hipLaunchKernelGGL((merge_single_kernel<12, true>), dim3(1), dim3(MERGE_WG), lds, st, a);
-        else
-            hipLaunchKernelGGL((merge_single_kernel<34, true>), dim3(1), dim3(MERGE_WG), lds, st, a);
-    } else if (a.K + 1 <= 12) {
-        hipLaunchKernelGGL((merge_single_kernel<12, false>), dim3(1), dim3(MERGE_WG), lds, st, a);
-    } else {
-        hipLaunchKernelGGL((merge_single_kernel<34, false>), dim3(1), dim3(MERGE_WG), lds, st, a);
-    }
-}
+}  // namespace
 
 }  // namespace icem

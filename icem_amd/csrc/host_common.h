@@ -1,0 +1,211 @@
+// host_common.h -- what the host-side translation units of libicem_hip.so share: the handle, error plumbing,
+// per-kernel timing scopes, and the launcher interfaces between them.
+//   generic_kernels.hip  the generic (f32 / f64, any shape) kernels + their launchers (gk_*)
+//   plan.hip             the fused MPC step: icem_plan_* / icem_get_action and the f32 throughput-path orchestration
+//   exchange.hip         the in-library elite exchange between GPUs (icem_exchange_*)
+//   abi.hip              handle life cycle and the stateless operators of include/icem_hip.h
+// Internal; not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <atomic>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/icem_hip.h"
+#include "icem_fused.h"
+
+namespace icem {
+
+inline thread_local std::string g_err;
+
+inline int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define ICEM_HIP_TRY(expr)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return ::icem::fail(ICEM_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr int WG = 256;          // 4 wavefronts of 64
+constexpr int TOPK_CHUNK = 1024; // costs per workgroup in the block-level top-k
+
+struct Exchange;  // exchange.hip
+
+}  // namespace icem
+
+struct icem_handle {
+    icem_config cfg;
+    int F = 0, HMAX = 0, hd = 0;
+    size_t tsize = 4;
+    void* W_dev = nullptr;
+    int model_kind = 0, obs_dim = 0, O = 0;
+    void* A_dev = nullptr;
+    void* B_dev = nullptr;
+    bool has_model = false, has_cost = false;
+    icem_cost_spec cost;
+    icem_cost_terms terms;
+    bool has_terms = false;  // any term of icem_cost_terms switched on
+    void* host_stage = nullptr;  // pinned, device-mapped block of icem_get_action [obs | action, best cost | flag]
+    void* host_stage_dev = nullptr;
+    unsigned io_seq = 0;
+    std::vector<int> pop;
+    int n_reuse = 0;
+    int n_local_max = 0;
+    // optional per-kernel timing with HIP events on the caller's stream (bench.py roofline leg)
+    bool profiling = false;
+    struct Span {
+        int kind;
+        long long units;
+        hipEvent_t a, b;
+    };
+    bool use_fast = true;
+    long long* dbg = nullptr;
+    int fast_lists = 0;  // candidate lists written by the last matrix-pipe rollout (0 = generic path ran)
+    // icem_plan_step (world == 1): an iteration's merge can ride in the prologue of the next iteration's launch,
+    // which then reads the previous pool / lists / distribution while writing new ones -> ping-pong partners of
+    // the caller's actions / workspace buffers and of mean | std, owned by the handle
+    void* actions_alt = nullptr;
+    void* ws_alt = nullptr;
+    float* pp_stats = nullptr;          // [2][2 * hd]
+    bool defer_merge = false;           // plan_iter_merge: stash the merge instead of launching it
+    bool pm_pending = false;            // a stashed merge waits for the next local launch
+    icem::MergeSingleArgs pm_args;
+    float* merge_mean_out = nullptr;    // where the next merge writes mean / std (nullptr: in place)
+    float* merge_std_out = nullptr;
+    // world > 1 with icem_set_merge_deferral(on): the same folding across the split calls; the distribution of the
+    // running MPC step lives at cur_mean / cur_std (the caller's buffers or pp_stats)
+    bool deferral = false;
+    float* cur_mean = nullptr;
+    float* cur_std = nullptr;
+    // permuted, padded model of the matrix-pipe rollout: column 0 = obs[lin_idx], column 1 = obs[flip_idx]
+    void* Mp_dev = nullptr;
+    void* perm_dev = nullptr;
+    int flip_col = -1;
+    bool fast_model_ready = false;
+    std::vector<double> A_host, B_host;
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> free_events;
+    icem::Exchange* xchg = nullptr;  // in-library elite exchange (icem_exchange_*), world > 1
+    uint64_t episode = 0;            // folded into the noise stream offset (icem_set_episode)
+};
+
+namespace icem {
+
+struct ProfScope {
+    icem_handle* h;
+    hipStream_t st;
+    hipEvent_t a = nullptr, b = nullptr;
+    int kind;
+    long long units;
+    static hipEvent_t get(icem_handle* h) {
+        if (!h->free_events.empty()) {
+            hipEvent_t e = h->free_events.back();
+            h->free_events.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    ProfScope(const icem_handle* hc, int kind_, long long units_, hipStream_t st_)
+        : h(const_cast<icem_handle*>(hc)), st(st_), kind(kind_), units(units_) {
+        if (!h->profiling) return;
+        a = get(h);
+        b = get(h);
+        (void)hipEventRecord(a, st);
+    }
+    ~ProfScope() {
+        if (!a) return;
+        (void)hipEventRecord(b, st);
+        h->spans.push_back({kind, units, a, b});
+    }
+};
+
+inline int shard_chunk(int n_global, int world) { return (n_global + world - 1) / world; }
+inline int topk_blocks(int n) { return (n + TOPK_CHUNK - 1) / TOPK_CHUNK; }
+
+template <typename T>
+void split_partial_ws(void* ws, int nblk, int K, T** pc, int** pi) {
+    *pc = (T*)ws;
+    *pi = (int*)((unsigned char*)ws + (size_t)nblk * K * sizeof(T));
+}
+
+inline int check_handle(const icem_handle* h) {
+    if (!h) return fail(ICEM_E_INVALID, "null handle");
+    return ICEM_OK;
+}
+
+// ---- generic_kernels.hip: launchers of the generic kernels; pointers are of the handle's dtype ------------------
+int gk_sample(const icem_handle* h, int n, long long first_index, const void* mean, const void* std, const void* low,
+              const void* high, const void* zr, const void* zi, uint64_t offset, int t_begin, int row0_mean, void* out,
+              hipStream_t st);
+int gk_sample_truncnorm(const icem_handle* h, int n, long long first_index, const void* mean, const void* std,
+                        const void* lower, const void* upper, const void* u, uint64_t offset, void* actions, hipStream_t st);
+int gk_sample_piecewise(const icem_handle* h, int n, long long call_offset, int change_freq, long long first_block,
+                        const void* low, const void* high, const void* u, void* actions, hipStream_t st);
+int gk_cem_bounds(const icem_handle* h, int like_levine, const void* mean, void* std, const void* low, const void* high,
+                  void* lower, void* upper, hipStream_t st);
+int gk_philox_normals(const icem_handle* h, int n, long long first_index, uint64_t offset, void* z_r, void* z_i,
+                      hipStream_t st);
+int gk_rollout(const icem_handle* h, int n, const void* obs0, const void* actions, void* costs, void* observations,
+               hipStream_t st);
+int gk_trajectory_cost(const icem_handle* h, int n, int o, const void* obs, const void* nxt, long long ts, long long ss,
+                       const void* actions, void* costs, hipStream_t st);
+int gk_cost_reduce(const icem_handle* h, int n, const void* step_costs, void* costs, hipStream_t st);
+int gk_topk(const icem_handle* h, int n, int K, const void* costs, void* out_c, int* out_i, void* ws, hipStream_t st);
+int gk_topk_partial(const icem_handle* h, int n_cand, int K, const void* costs, void* ws, int nblk, hipStream_t st);
+int gk_local_pack(const icem_handle* h, int nblk, int K, int n_loc, int shard_lo, int n_global, const void* ws,
+                  const void* actions, void* records, hipStream_t st);
+int gk_gather_refit(const icem_handle* h, const void* actions, const int32_t* idx, int k, void* mean, void* std,
+                    void* elites_out, hipStream_t st);
+int gk_shift(const icem_handle* h, void* mean, void* std, const void* low, const void* high, hipStream_t st);
+int gk_reset(const icem_handle* h, void* mean, void* std, const void* low, const void* high, hipStream_t st);
+int gk_shift_elites(const icem_handle* h, int n_extra, const void* elites, void* dst, hipStream_t st);
+// merge of the all-gathered records (+ kept elites): arguments of merge_refit_kernel, dtype-erased
+struct MergeArgsV {
+    int n_rec, n_keep, K, h, d, n_global, last;
+    double alpha, init_std;
+    const void* records;
+    const void* elites_cur;
+    const void* elites_cost_cur;
+    void* elites_next;
+    void* elites_cost_next;
+    const void* mean_in;
+    const void* std_in;
+    void* mean;
+    void* std;
+    const void* low;
+    const void* high;
+    void* executed;
+    void* best_cost;
+};
+int gk_merge_refit(const icem_handle* h, const MergeArgsV& a, hipStream_t st);
+// every index a cost term reads lies inside an observation of width o (nullptr = fine)
+const char* cost_indices_error(const icem_handle* h, int o);
+
+// ---- plan.hip: the f32 throughput path ---------------------------------------------------------------------------
+bool fast_rollout_ok(const icem_handle* h, int K);
+bool fast_sample_ok(const icem_handle* h);
+int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const void* obs0, const void* actions,
+                        void* costs, float* part_c, int* part_i, hipStream_t st, int* lists_out,
+                        unsigned long long* part_k = nullptr);
+int launch_fast_sample(const icem_handle* h, int n, long long first_index, const void* mean, const void* std,
+                       const void* low, const void* high, uint64_t offset, int row0_mean, void* out, hipStream_t st,
+                       int n_shift = 0, const void* elites_src = nullptr, uint64_t offset2 = 0);
+
+}  // namespace icem
+
+#define ICEM_DISPATCH(h, expr_f32, expr_f64) ((h)->cfg.dtype == ICEM_F64 ? (expr_f64) : (expr_f32))

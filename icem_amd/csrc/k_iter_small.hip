@@ -1,0 +1,227 @@
+// k_iter_small.hip -- K1 + K2 + K3 in one launch for small populations (+ the PREVIOUS iteration's K3 + K4 in its
+// prologue): sample_rollout_kernel, one slab of 16 * RW trajectories per workgroup.
+#include "fused_dev.h"
+
+namespace icem {
+
+namespace {
+
+// -------------------------------------------------------------------------------------------------
+// K1 + K2 + K3 in one launch for small populations (+ the PREVIOUS iteration's K3 + K4 in its prologue)
+// -------------------------------------------------------------------------------------------------
+// With a few thousand trajectories the chip is mostly empty and an iteration is a chain of latencies: launch,
+// prologue, one thread's RNG -> DFT chain, HBM round trip of the actions, launch, prologue, 30 dependent model
+// steps, launch, merge.  Here a workgroup samples 16 * RW trajectories into an LDS tile (one thread per
+// (trajectory, dim) row, same code as sample_folded_kernel), writes the tile to HBM for the elite gather, and its
+// first RW waves roll the trajectories out straight from the tile (same code as rollout16_kernel): one launch, no
+// HBM round trip.
+// KREG > 0 ("merge prologue"): the distribution this iteration samples from is not in memory yet -- every
+// workgroup computes it itself from the previous iteration's candidate lists.  An extra wavefront runs the
+// selection (merge_select) WHILE the sampling waves draw their noise (which does not depend on mean / std: the
+// raw colored samples are parked in the tile); then all threads gather the K elite rows and refit (same
+// arithmetic as merge_single_kernel, so every workgroup gets the same bits), the affine map + clip is applied to
+// the tile, and the iteration proceeds as above.  Workgroup 0 also writes the new distribution and elite set for
+// the host / the next launch.  That removes the merge launch and hides its latency behind the sampling.  The
+// previous pool, lists and distribution are read while this launch writes new ones: all three are ping-pong
+// buffers (icem_plan_step).
+template <int H, int D, int O, int KIND, int ROUNDS, int RW, int KREG, bool REC>
+__global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64 + (KREG > 0 ? 64 : 0)) void sample_rollout_kernel(FastIterArgs a) {
+    using Tile = Tile16<H, D, O, KIND>;
+    constexpr bool PM = KREG > 0;
+    constexpr int HD = H * D;
+    constexpr int TPB = 16 * RW;                     // trajectories per workgroup
+    constexpr int ROWS = TPB * D;                    // (trajectory, dim) rows, one thread each
+    constexpr int NT = ((ROWS + 63) / 64) * 64;      // sampling threads
+    constexpr int NTT = NT + (PM ? 64 : 0);          // + the selection wavefront
+    static_assert(NTT <= 1024 && HD % 2 == 0, "workgroup shape");
+    constexpr int VW = HD % 4 == 0 ? 4 : 2;  // floats per vector of the tile -> HBM copy (rows are 4 * HD bytes)
+    using Vec = typename VecOf<VW>::type;
+    __shared__ __attribute__((aligned(16))) float ms[2 * HD];  // mean | std
+    __shared__ __attribute__((aligned(16))) float tilebuf[Tile::SLACK + TPB * HD + Tile::TAIL];
+    __shared__ unsigned long long wg_keys[2][RW][32];
+    __shared__ float obs_stage[32];
+    __shared__ unsigned long long sel[PM ? 64 : 1];
+    __shared__ unsigned long long cand[PM ? 64 : 1];
+    __shared__ int slot[PM ? 64 : 1];
+    float* tile_rows = tilebuf + Tile::SLACK;
+    const FastSampleArgs& sa = a.s;
+    const FastRolloutArgs& ra = a.r;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int n_rows = ra.n_rows;       // sa.n sampled rows, then sa.n_shift shifted elites
+    const int base = blockIdx.x * TPB;  // one slab of TPB trajectories per workgroup (launch_sample_rollout)
+    if (base >= n_rows) return;
+    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[8] = wall_clock64();
+    // Order matters at this size: kernel arguments arrive through serialized scalar loads, so everything the RNG
+    // chain does not need (start observation, model operands, bounds) is fetched AFTER the sampling got going.
+    const int nl = tid / D, jd = tid - nl * D;
+    const bool has_row = tid < ROWS;
+    float* trow = tile_rows + nl * HD + jd;
+    const float* mrow = ms + jd;
+    Tile tile;
+    float obs_reg = 0.f;
+    if (!PM) {  // iteration 0 of an MPC step: the distribution is in memory; the model operands ride the same wait
+        obs_reg = ra.obs0[(tid < 32 && tid < ra.o) ? tid : 0];
+        if (wave < RW) tile.load(ra, lane);
+        for (int e = tid; e < HD; e += NTT) {
+            ms[e] = sa.mean[e];
+            ms[HD + e] = sa.std[e];
+        }
+        __syncthreads();
+    }
+    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[9] = wall_clock64();
+    const int r_mine = base + nl;
+    if (has_row) sample_into_tile<H, D, ROUNDS, PM>(sa, n_rows, r_mine, jd, trow, mrow);
+    if constexpr (PM) {
+        if (tid >= NT) {
+            if constexpr (REC)
+                merge_select_records(a.m, lane, cand, sel, slot);
+            else if constexpr (RW >= 8)  // 13 waves share the register file: the low-register selection
+                merge_select_stream(a.m, lane, cand, sel);
+            else
+                merge_select<KREG>(a.m, lane, cand, sel);
+        }
+    }
+    if (PM) {  // now the rest of the inputs: in flight across the barriers below
+        obs_reg = ra.obs0[(tid < 32 && tid < ra.o) ? tid : 0];
+        if (wave < RW) tile.load(ra, lane);
+    }
+    const float* rd0 = tile.read_ptr(tilebuf + (wave < RW ? wave : 0) * 16 * HD, lane, HD);
+    if constexpr (PM) {
+        const MergeSingleArgs& m = a.m;
+        __syncthreads();
+        // all threads: gather the elite rows + refit (icem.py:201-211) -> this workgroup's mean / std
+        const float* rows[KREG > 0 ? KREG : 1];
+        merge_rows<KREG, REC>(m, sel, slot, rows);
+        for (int e = tid; e < HD; e += NTT) {
+            float xs[KREG > 0 ? KREG : 1];
+#pragma unroll
+            for (int r = 0; r < KREG; ++r) xs[r] = rows[r][e];
+            float nm, ns;
+            refit_element_regs<float, KREG>(m.K, m.alpha, m.mean[e], m.std[e], xs, nm, ns);
+            ms[e] = nm;
+            ms[HD + e] = ns;
+            if (blockIdx.x == 0) {
+                m.mean_out[e] = nm;
+                m.std_out[e] = ns;
+#pragma unroll
+                for (int r = 0; r < KREG; ++r)
+                    if (r < m.K) m.elites_next[(size_t)r * HD + e] = xs[r];
+            }
+        }
+        if (blockIdx.x == 0 && tid < m.K) m.elites_cost_next[tid] = key_cost(sel[tid]);
+        __syncthreads();
+        if (has_row && r_mine < sa.n) {  // y * std + mean, clipped (icem.py:79)
+            const float lo = sa.low[jd], hi = sa.high[jd];
+            for (int t = 0; t < H; ++t) {
+                const float v = __builtin_fmaf(trow[t * D], mrow[HD + t * D], mrow[t * D]);
+                trow[t * D] = __builtin_amdgcn_fmed3f(v, lo, hi);
+            }
+        }
+    }
+    if (tid < 32) {  // start observation -> LDS (consumed after the barrier)
+        float ov = obs_reg;
+        asm volatile("" : "+v"(ov));  // wait for the load here, not where it was issued
+        obs_stage[tid] = tid < ra.o ? ov : 0.f;
+    }
+    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[10] = wall_clock64();
+    __syncthreads();
+    if (sa.row0_mean && sa.first_index + base == 0) {  // icem.py:87-88
+        for (int e = tid; e < HD; e += NTT) tile_rows[e] = ms[e];
+        __syncthreads();
+    }
+    {   // the tile is a contiguous block of the action tensor
+        const int total4 = (n_rows - base < TPB ? n_rows - base : TPB) * (HD / VW);
+        const Vec* t4 = reinterpret_cast<const Vec*>(tile_rows);
+        Vec* g4 = reinterpret_cast<Vec*>(sa.out + (size_t)base * HD);
+        for (int e = tid; e < total4; e += NTT) g4[e] = t4[e];
+    }
+    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[11] = wall_clock64();
+    unsigned long long run_key = KEY_SENTINEL;
+    if (wave < RW) {
+        tile.load_obs(obs_stage);
+        run_key = rollout_slab<Tile, H, D>(tile, ra, rd0, base + wave * 16 + (lane & 15), n_rows, run_key, true, lane);
+        if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[12] = wall_clock64();
+    }
+    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[13] = wall_clock64();
+    if (ra.K > 0) wg_merge_emit<RW>(wg_keys, run_key, ra.K, lane, wave, ra);
+    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[14] = wall_clock64();
+}
+
+}  // namespace
+
+// rollout waves a single-launch workgroup can hold for this shape: 16 * RW * D sampling threads (+ 64) within 1024
+// threads, the [16 * RW, H, D] tile within ~120 KB of LDS
+constexpr int single_launch_max_rw(int h, int d) {
+    int best = 0;
+    for (int rw = 1; rw <= 8; rw *= 2)
+        if (((16 * rw * d + 63) / 64) * 64 + 64 <= 1024 && 16 * rw * h * d * 4 <= 120 * 1024) best = rw;
+    return best;
+}
+
+// single-launch iteration: compiled for the default generator (10 Philox rounds) and 1, 2, 4 or 8 rollout waves per
+// workgroup, one slab of 16 * rw trajectories each, at most FAST_MAX_LISTS workgroups (= candidate lists).
+// sample_rollout_lists: workgroups of the launch, 0 when the shape or size is outside that (use the two-kernel
+// path).  (Several slabs per workgroup through the same LDS tile were tried for larger populations: with one
+// 92 KB tile per CU the sampling and rollout phases of a workgroup run back to back at 2-3 waves per SIMD, and
+// N=65 536 took 297 instead of 220 us per MPC step -- the two full-occupancy kernels win there.)
+static bool sample_rollout_shape(int h, int d, int O, int rounds, int n_rows, int* grid_out, int* rw_out) {
+    static const int max_rw = [] { const char* e = getenv("ICEM_FUSE_MAX_RW"); return e ? atoi(e) : 8; }();
+    int grid, rw;
+    r16_shape(n_rows, &grid, &rw);
+    if (rounds != 10 || rw > max_rw || n_rows <= 0 || !fast_rollout_supported(h, d, O, 1) || !fast_sample_supported(h, d))
+        return false;
+    if (rw > single_launch_max_rw(h, d)) return false;  // one slab of 16 * rw trajectories per workgroup
+    *grid_out = std::min(grid, (n_rows + 16 * rw - 1) / (16 * rw));
+    *rw_out = rw;
+    return true;
+}
+
+int sample_rollout_lists(int h, int d, int O, int rounds, int n_rows) {
+    int grid, rw;
+    return sample_rollout_shape(h, d, O, rounds, n_rows, &grid, &rw) ? grid : 0;
+}
+
+// merge prologue: the selection wavefront joins the sampling waves (8 rollout waves: 13 waves share the register
+// file, the selection runs in its low-register form)
+bool sample_rollout_merge_ok(int h, int d, int O, int rounds, int n_rows, int K) {
+    static const int on = [] { const char* e = getenv("ICEM_MERGE_PROLOGUE"); return e ? atoi(e) : 1; }();
+    int grid, rw;
+    return on && K + 1 <= 12 && sample_rollout_shape(h, d, O, rounds, n_rows, &grid, &rw);
+}
+
+void launch_sample_rollout(const FastIterArgs& a, int h, int d, int O, int kind, bool merge_prologue, hipStream_t st) {
+    int grid, rw;
+    if (!sample_rollout_shape(h, d, O, 10, a.r.n_rows, &grid, &rw)) return;
+#define XK(HH, DD, OO, WW, KR, RC)                                                                                      \
+    {                                                                                                                   \
+        constexpr int NT = ((16 * WW * DD + 63) / 64) * 64 + (KR > 0 ? 64 : 0);                                         \
+        if (kind == 1)                                                                                                  \
+            hipLaunchKernelGGL((sample_rollout_kernel<HH, DD, OO, 1, 10, WW, KR, RC>), dim3(grid), dim3(NT), 0, st, a); \
+        else                                                                                                            \
+            hipLaunchKernelGGL((sample_rollout_kernel<HH, DD, OO, 0, 10, WW, KR, RC>), dim3(grid), dim3(NT), 0, st, a); \
+        return;                                                                                                         \
+    }
+#define XW(HH, DD, OO, WW)                                                   \
+    if constexpr (WW <= single_launch_max_rw(HH, DD)) {                      \
+        if (rw == WW) {                                                      \
+            if (merge_prologue && a.m.records) XK(HH, DD, OO, WW, 12, true)  \
+            if (merge_prologue) XK(HH, DD, OO, WW, 12, false)                \
+            XK(HH, DD, OO, WW, 0, false)                                     \
+        }                                                                    \
+    }
+#define XR(HH, DD, OO)                   \
+    if (h == HH && d == DD && O == OO) { \
+        XW(HH, DD, OO, 1)                \
+        XW(HH, DD, OO, 2)                \
+        XW(HH, DD, OO, 4)                \
+        XW(HH, DD, OO, 8)                \
+    }
+    ICEM_FAST_SHAPES(XR)
+#undef XR
+#undef XW
+#undef XK
+}
+
+}  // namespace icem

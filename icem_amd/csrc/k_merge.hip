@@ -1,0 +1,148 @@
+// k_merge.hip -- K3 + K4 as a launch of its own: merge_single_kernel (global sorted top-K of the candidate lists or
+// all-gathered records, elite gather, refit, last-iteration epilogue; one workgroup, wave 0 selects) and
+// pack_records_kernel (sharded runs: this rank's K best as records for the exchange).
+#include "fused_dev.h"
+
+namespace icem {
+
+namespace {
+
+template <int KREG, bool REC>
+__global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs a) {
+    __shared__ unsigned long long sel[64];
+    __shared__ unsigned long long cand[64];
+    __shared__ int slot[64];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* new_mean = reinterpret_cast<float*>(smem_raw);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int hd = a.h * a.d;
+    if (a.dbg && threadIdx.x == 0) a.dbg[0] = wall_clock64();
+    // old mean/std of this thread's elements: issued now, consumed after the selection
+    constexpr int EPL = 4;
+    const bool pre = hd <= MERGE_WG * EPL;
+    float om[EPL], os[EPL];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const int e = tid + i * MERGE_WG;
+        om[i] = (pre && e < hd) ? a.mean[e] : 0.f;
+        os[i] = (pre && e < hd) ? a.std[e] : 0.f;
+    }
+    if (tid < 64) {
+        if constexpr (REC)
+            merge_select_records(a, lane, cand, sel, slot);
+        else
+            merge_select<KREG>(a, lane, cand, sel);
+    }
+    if (a.dbg && threadIdx.x == 0) a.dbg[4] = wall_clock64();
+    __syncthreads();
+    // ---- all 4 waves: gather + refit (icem.py:201-211); row pointers first, then all K loads in flight ----
+    const float* rows[KREG];
+    merge_rows<KREG, REC>(a, sel, slot, rows);
+    auto finish_one = [&](int e, float old_mean, float old_std) {
+        float xs[KREG];
+#pragma unroll
+        for (int r = 0; r < KREG; ++r) xs[r] = rows[r][e];
+#pragma unroll
+        for (int r = 0; r < KREG; ++r)
+            if (r < a.K) a.elites_next[(size_t)r * hd + e] = xs[r];
+        float nm, ns;
+        refit_element_regs<float, KREG>(a.K, a.alpha, old_mean, old_std, xs, nm, ns);
+        if (!a.last) {
+            a.mean_out[e] = nm;
+            a.std_out[e] = ns;
+        } else {
+            new_mean[e] = nm;
+        }
+    };
+    if (pre) {
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) {
+            const int e = tid + i * MERGE_WG;
+            if (e < hd) finish_one(e, om[i], os[i]);
+        }
+    } else {
+        for (int e = tid; e < hd; e += MERGE_WG) finish_one(e, a.mean[e], a.std[e]);
+    }
+    if (a.dbg && threadIdx.x == 0) a.dbg[5] = wall_clock64();
+    if (tid < a.K) a.elites_cost_next[tid] = key_cost(sel[tid]);
+    if (a.last) {
+        __syncthreads();
+        for (int e = tid; e < hd; e += MERGE_WG) {
+            const int j = e % a.d;
+            a.mean_out[e] = (e + a.d < hd) ? new_mean[e + a.d] : new_mean[e];
+            a.std_out[e] = (a.high[j] - a.low[j]) / 2.f * a.init_std;
+        }
+        if (tid < a.d) a.executed[tid] = rows[0][tid];
+        if (tid == 0) a.best_cost[0] = key_cost(sel[0]);
+    }
+    if (a.dbg && threadIdx.x == 0) a.dbg[6] = wall_clock64();
+}
+
+// Sharded runs: this rank's K best candidates (same selection) packed as records {cost, gidx, actions[h*d]} for
+// the all-gather.  Local pool row li is global trajectory shard_lo + li, or n_global + (li - n_loc) for the
+// replicated shifted elites behind the shard (icem_amd/distributed.py).
+template <int KREG>
+__global__ __launch_bounds__(MERGE_WG) void pack_records_kernel(MergeSingleArgs a, int n_loc, int shard_lo, float* records) {
+    __shared__ unsigned long long sel[64];
+    __shared__ unsigned long long cand[64];
+    const int tid = threadIdx.x;
+    const int hd = a.h * a.d;
+    const int rs = hd + 2;
+    if (tid < 64) merge_select<KREG>(a, tid, cand, sel);
+    __syncthreads();
+    // headers by the first K threads; rows: element e of all K rows per thread, every load in flight before a store
+    if (tid < a.K) {
+        const unsigned long long key = sel[tid];
+        float* rec = records + (size_t)tid * rs;
+        if (key == KEY_SENTINEL) {  // fewer than K candidates on this rank
+            rec[0] = INFINITY;
+            reinterpret_cast<int*>(rec + 1)[0] = INT_MAX;
+        } else {
+            const int li = key_idx(key);
+            rec[0] = key_cost(key);
+            reinterpret_cast<int*>(rec + 1)[0] = li < n_loc ? shard_lo + li : a.n_global + (li - n_loc);
+        }
+    }
+    const float* rows[KREG];
+    bool dead[KREG];
+#pragma unroll
+    for (int r = 0; r < KREG; ++r) {
+        const unsigned long long key = sel[r < a.K ? r : 0];
+        dead[r] = key == KEY_SENTINEL;
+        rows[r] = a.actions + (size_t)(dead[r] ? 0 : key_idx(key)) * hd;
+    }
+    for (int e = tid; e < hd; e += MERGE_WG) {
+        float xs[KREG];
+#pragma unroll
+        for (int r = 0; r < KREG; ++r) xs[r] = rows[r][e];
+#pragma unroll
+        for (int r = 0; r < KREG; ++r)
+            if (r < a.K) records[(size_t)r * rs + 2 + e] = dead[r] ? 0.f : xs[r];
+    }
+}
+
+}  // namespace
+
+void launch_pack_records(const MergeSingleArgs& a, int n_loc, int shard_lo, float* records, hipStream_t st) {
+    if (a.K + 1 <= 12)
+        hipLaunchKernelGGL((pack_records_kernel<12>), dim3(1), dim3(MERGE_WG), 0, st, a, n_loc, shard_lo, records);
+    else
+        hipLaunchKernelGGL((pack_records_kernel<34>), dim3(1), dim3(MERGE_WG), 0, st, a, n_loc, shard_lo, records);
+}
+
+void launch_merge_single(const MergeSingleArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)a.h * a.d * sizeof(float);
+    if (a.records) {
+        if (a.K + 1 <= 12)
+            hipLaunchKernelGGL((merge_single_kernel<12, true>), dim3(1), dim3(MERGE_WG), lds, st, a);
+        else
+            hipLaunchKernelGGL((merge_single_kernel<34, true>), dim3(1), dim3(MERGE_WG), lds, st, a);
+    } else if (a.K + 1 <= 12) {
+        hipLaunchKernelGGL((merge_single_kernel<12, false>), dim3(1), dim3(MERGE_WG), lds, st, a);
+    } else {
+        hipLaunchKernelGGL((merge_single_kernel<34, false>), dim3(1), dim3(MERGE_WG), lds, st, a);
+    }
+}
+
+}  // namespace icem

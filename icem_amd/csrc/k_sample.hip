@@ -1,0 +1,215 @@
+// k_sample.hip -- K1 for populations too large for the single-launch kernel.
+// sample_folded_kernel<H, ROUNDS>: one thread per (trajectory, action-dim) row: per-row stream -> Box-Muller -> the h
+//   white draws in registers; inverse real DFT folded on its cos/sin symmetry with the table rows as wave-uniform
+//   scalar operands; affine (mean / std staged in LDS) + clip; samples parked in an LDS tile laid out like the
+//   [n, h, d] output so the slab leaves as coalesced stores.
+// sample_folded_merge_kernel: the same with the PREVIOUS iteration's top-K selection + refit in its prologue.
+#include "fused_dev.h"
+
+namespace icem {
+
+namespace {
+
+template <int H, int ROUNDS>
+__global__ __launch_bounds__(SWG) void sample_folded_kernel(FastSampleArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int d = a.d;
+    const int hd = H * d;
+    const int tpw = SWG / d;
+    float* ms = smem;            // mean | std
+    float* tile = smem + 2 * hd;  // [tpw, hd]
+    const int tid = threadIdx.x;
+    for (int e = tid; e < hd; e += SWG) {
+        ms[e] = a.mean[e];
+        ms[hd + e] = a.std[e];
+    }
+    const int n_base = blockIdx.x * tpw;
+    const int n_here = cmin(tpw, a.n - n_base);
+    __syncthreads();
+    if (a.n_shift > 0 && blockIdx.x == gridDim.x - 1) {
+        // the extra workgroup: shifted elites.  Row (e, j) keeps elites[e, 1:, j] and draws its last action
+        // from the full (n_shift, d, h) noise batch of stream off2 (only t = h-1 is used, icem.py:102)
+        if (tid < a.n_shift * d) {
+            const int e = tid / d;
+            const int j = tid - e * d;
+            const float lo = a.low[j], hi = a.high[j];
+            float last = 0.f;
+            sample_row<H, ROUNDS>(a.W, (unsigned)e, (unsigned)j, a.off2_lo, a.off2_hi, a.seed_lo, a.seed_hi,
+                                  [&](int t, float y) {
+                                      if (t == H - 1) {
+                                          float v = __builtin_fmaf(y, ms[hd + t * d + j], ms[t * d + j]);
+                                          v = v < lo ? lo : v;
+                                          last = v > hi ? hi : v;
+                                      }
+                                  }, a.white != 0);
+            float* dst = a.out + (size_t)(a.n + e) * hd + j;
+            const float* src = a.elites_src + (size_t)e * hd + j;
+            for (int t = 0; t < H - 1; ++t) dst[t * d] = src[(t + 1) * d];
+            dst[(H - 1) * d] = last;
+        }
+        return;
+    }
+    if (tid < n_here * d) {
+        const int nl = tid / d;
+        const int j = tid - nl * d;
+        const float lo = a.low[j], hi = a.high[j];
+        float* trow = tile + nl * hd + j;
+        const float* mrow = ms + j;
+        sample_row<H, ROUNDS>(a.W, (unsigned)(a.first_index + n_base + nl), (unsigned)j, a.off_lo, a.off_hi, a.seed_lo,
+                              a.seed_hi, [&](int t, float y) {
+                                  const float v = __builtin_fmaf(y, mrow[hd + t * d], mrow[t * d]);
+                                  trow[t * d] = __builtin_amdgcn_fmed3f(v, lo, hi);  // clip in one v_med3_f32
+                              }, a.white != 0);
+    }
+    __syncthreads();
+    if (a.row0_mean && a.first_index + n_base == 0) {  // icem.py:87-88
+        for (int e = tid; e < hd; e += SWG) tile[e] = ms[e];
+        __syncthreads();
+    }
+    float* gdst = a.out + (size_t)n_base * hd;
+    const int total = n_here * hd;
+    if ((hd & 3) == 0) {
+        const float4* t4 = reinterpret_cast<const float4*>(tile);
+        float4* g4 = reinterpret_cast<float4*>(gdst);
+        for (int e = tid; e < total / 4; e += SWG) g4[e] = t4[e];
+    } else {
+        for (int e = tid; e < total; e += SWG) gdst[e] = tile[e];
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// K1 with the PREVIOUS iteration's K3 + K4 in its prologue (populations too large for the single-launch kernel)
+// -------------------------------------------------------------------------------------------------
+// sample_folded_kernel plus one wavefront per workgroup that runs the low-register selection
+// (merge_select_stream) on the previous iteration's candidate lists while the 4 sampling waves draw their noise
+// into the LDS tile; then all 5 waves gather the K elite rows and refit, the affine map + clip is applied to the
+// tile and the tile leaves as before.  Every workgroup redoes the same merge (L2 serves the 20 KB of keys and 7 KB
+// of elite rows), workgroup 0 publishes it.  Saves the merge launch (8.6 + 2.6 us) for ~3 us more sampler time.
+template <int H, int ROUNDS, int KREG, bool REC>
+__global__ __launch_bounds__(SWG + 64) void sample_folded_merge_kernel(FastSampleMergeArgs args) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ unsigned long long sel[64];
+    __shared__ unsigned long long cand[64];
+    __shared__ int slot[64];
+    constexpr int NTT = SWG + 64;
+    const FastSampleArgs& a = args.s;
+    const MergeSingleArgs& m = args.m;
+    const int d = a.d;
+    const int hd = H * d;
+    const int tpw = SWG / d;
+    float* ms = smem;            // mean | std (computed here)
+    float* tile = smem + 2 * hd;  // [tpw, hd]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int n_base = blockIdx.x * tpw;
+    const int n_here = cmin(tpw, a.n - n_base);
+    const bool has_row = tid < n_here * d;
+    const int nl = tid / d;
+    const int j = tid - nl * d;
+    float* trow = tile + nl * hd + j;
+    if (tid >= SWG) {
+        if constexpr (REC)
+            merge_select_records(m, lane, cand, sel, slot);
+        else
+            merge_select_stream(m, lane, cand, sel);
+    } else if (has_row) {
+        sample_row<H, ROUNDS>(a.W, (unsigned)(a.first_index + n_base + nl), (unsigned)j, a.off_lo, a.off_hi, a.seed_lo,
+                              a.seed_hi, [&](int t, float y) { trow[t * d] = y; }, a.white != 0);
+    }
+    __syncthreads();
+    {
+        const float* rows[KREG];
+        merge_rows<KREG, REC>(m, sel, slot, rows);
+        for (int e = tid; e < hd; e += NTT) {
+            float xs[KREG];
+#pragma unroll
+            for (int r = 0; r < KREG; ++r) xs[r] = rows[r][e];
+            float nm, ns;
+            refit_element_regs<float, KREG>(m.K, m.alpha, m.mean[e], m.std[e], xs, nm, ns);
+            ms[e] = nm;
+            ms[hd + e] = ns;
+            if (blockIdx.x == 0) {
+                m.mean_out[e] = nm;
+                m.std_out[e] = ns;
+#pragma unroll
+                for (int r = 0; r < KREG; ++r)
+                    if (r < m.K) m.elites_next[(size_t)r * hd + e] = xs[r];
+            }
+        }
+        if (blockIdx.x == 0 && tid < m.K) m.elites_cost_next[tid] = key_cost(sel[tid]);
+    }
+    __syncthreads();
+    if (has_row) {
+        const float lo = a.low[j], hi = a.high[j];
+        const float* mrow = ms + j;
+        for (int t = 0; t < H; ++t) {
+            const float v = __builtin_fmaf(trow[t * d], mrow[hd + t * d], mrow[t * d]);
+            trow[t * d] = __builtin_amdgcn_fmed3f(v, lo, hi);
+        }
+    }
+    __syncthreads();
+    if (a.row0_mean && a.first_index + n_base == 0) {  // icem.py:87-88
+        for (int e = tid; e < hd; e += NTT) tile[e] = ms[e];
+        __syncthreads();
+    }
+    float* gdst = a.out + (size_t)n_base * hd;
+    const int total = n_here * hd;
+    if ((hd & 3) == 0) {
+        const float4* t4 = reinterpret_cast<const float4*>(tile);
+        float4* g4 = reinterpret_cast<float4*>(gdst);
+        for (int e = tid; e < total / 4; e += NTT) g4[e] = t4[e];
+    } else {
+        for (int e = tid; e < total; e += NTT) gdst[e] = tile[e];
+    }
+}
+
+}  // namespace
+
+bool fast_sample_supported(int h, int d) {
+    if (d > SWG) return false;
+#define X(HH) \
+    if (h == HH) return true;
+    ICEM_FAST_HORIZONS(X)
+#undef X
+    return false;
+}
+
+// sampler with the previous iteration's merge in its prologue (default generator only, K <= 11, no shifted elites)
+bool sample_folded_merge_ok(int h, int d, int rounds, int K) {
+    static const int on = [] { const char* e = getenv("ICEM_MERGE_PROLOGUE"); return e ? atoi(e) : 1; }();
+    return on && rounds == 10 && K + 1 <= 12 && fast_sample_supported(h, d);
+}
+
+void launch_sample_folded_merge(const FastSampleMergeArgs& a, hipStream_t st) {
+    const int tpw = SWG / a.s.d;
+    const int grid = (a.s.n + tpw - 1) / tpw;
+    const size_t lds = ((size_t)2 * a.s.h * a.s.d + (size_t)tpw * a.s.h * a.s.d) * sizeof(float);
+#define X(HH)                                                                                                  \
+    if (a.s.h == HH) {                                                                                         \
+        if (a.m.records)                                                                                       \
+            hipLaunchKernelGGL((sample_folded_merge_kernel<HH, 10, 12, true>), dim3(grid), dim3(SWG + 64), lds, st, a);  \
+        else                                                                                                   \
+            hipLaunchKernelGGL((sample_folded_merge_kernel<HH, 10, 12, false>), dim3(grid), dim3(SWG + 64), lds, st, a); \
+        return;                                                                                                \
+    }
+    ICEM_FAST_HORIZONS(X)
+#undef X
+}
+
+void launch_sample_folded(const FastSampleArgs& a, int rounds, hipStream_t st) {
+    const int tpw = SWG / a.d;
+    const int grid = (a.n + tpw - 1) / tpw + (a.n_shift > 0 ? 1 : 0);
+    const size_t lds = ((size_t)2 * a.h * a.d + (size_t)tpw * a.h * a.d) * sizeof(float);
+#define X(HH)                                                                                        \
+    if (a.h == HH) {                                                                                 \
+        if (rounds == 7)                                                                             \
+            hipLaunchKernelGGL((sample_folded_kernel<HH, 7>), dim3(grid), dim3(SWG), lds, st, a);    \
+        else                                                                                         \
+            hipLaunchKernelGGL((sample_folded_kernel<HH, 10>), dim3(grid), dim3(SWG), lds, st, a);   \
+        return;                                                                                      \
+    }
+    ICEM_FAST_HORIZONS(X)
+#undef X
+}
+
+}  // namespace icem

@@ -1,0 +1,710 @@
+// plan.hip -- the fused MPC step behind icem_plan_iter_local / icem_plan_iter_merge / icem_plan_step / icem_get_action
+// (the body of MpcICem.get_action, icem/controllers/icem.py:106-189): which kernels an iteration launches (generic
+// path, two-kernel f32 path, single-launch f32 paths), where a merge rides (own launch or the next launch's prologue),
+// and which of the ping-pong buffers each launch reads and writes.  No device code here except the result publisher.
+#include "host_common.h"
+
+using namespace icem;
+
+// icem_get_action: executed action + best cost -> the host-mapped block, then the sequence flag (system scope)
+__global__ void publish_result_kernel(const float* executed, const float* best_cost, int d, float* host_out, unsigned* flag,
+                                      unsigned seq) {
+    const int j = threadIdx.x;
+    if (j < d) host_out[j] = executed[j];
+    if (j == d) host_out[d] = best_cost[0];
+    __threadfence_system();
+    __syncthreads();
+    if (j == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+namespace icem {
+
+// Build the permuted, zero-padded [A ; B] operand of the matrix-pipe rollout (lazily: it depends on
+// both icem_set_model and icem_set_cost).  Observation entries are reordered so that the linear cost
+// term reads column 0 and the flip term column 0 or 1 -- static registers in the kernel.
+int ensure_fast_model(icem_handle* h) {
+    if (h->fast_model_ready) return ICEM_OK;
+    const int O = h->O, o = h->obs_dim, d = h->cfg.act_dim;
+    // layout of Tile16 (icem_fused.hip): O <= 20 -> one 16-column matrix-pipe tile + extra columns, Mp [O + d + 1, ceil4(O)];
+    // O > 20 -> two tiles, observation block padded to 32 rows / columns, Mp [32 + d + 1, 32]
+    const bool two = O > 20;
+    const int OP = two ? 32 : O;
+    const int CT4 = two ? 32 : ((O + 3) / 4) * 4;
+    std::vector<int> perm;
+    perm.push_back(h->cost.lin_idx);
+    h->flip_col = -1;
+    if (h->cost.flip_idx >= 0) {
+        if (h->cost.flip_idx == h->cost.lin_idx) {
+            h->flip_col = 0;
+        } else {
+            perm.push_back(h->cost.flip_idx);
+            h->flip_col = 1;
+        }
+    }
+    for (int k = 0; k < O; ++k)
+        if (std::find(perm.begin(), perm.end(), k) == perm.end()) perm.push_back(k);
+    std::vector<float> Mp((size_t)(OP + d + 1) * CT4, 0.f);  // + one zero row (contraction slots without an entry)
+    auto Aat = [&](int r, int c) { return (r < o && c < o) ? h->A_host[(size_t)r * o + c] : 0.0; };
+    auto Bat = [&](int j, int c) { return c < o ? h->B_host[(size_t)j * o + c] : 0.0; };
+    for (int k = 0; k < O; ++k)
+        for (int c = 0; c < O; ++c) Mp[(size_t)k * CT4 + c] = (float)Aat(perm[k], perm[c]);
+    for (int j = 0; j < d; ++j)
+        for (int c = 0; c < O; ++c) Mp[(size_t)(OP + j) * CT4 + c] = (float)Bat(j, perm[c]);
+    for (int k = 0; k < (int)perm.size(); ++k)
+        if (k >= o || perm[k] >= o) perm[k] = 31;  // padding columns start from the zero slot of the staged observation
+    perm.resize(32, 31);
+    if (h->Mp_dev) (void)hipFree(h->Mp_dev);
+    if (h->perm_dev) (void)hipFree(h->perm_dev);
+    ICEM_HIP_TRY(hipMalloc(&h->Mp_dev, Mp.size() * sizeof(float)));
+    ICEM_HIP_TRY(hipMalloc(&h->perm_dev, perm.size() * sizeof(int)));
+    ICEM_HIP_TRY(hipMemcpy(h->Mp_dev, Mp.data(), Mp.size() * sizeof(float), hipMemcpyHostToDevice));
+    ICEM_HIP_TRY(hipMemcpy(h->perm_dev, perm.data(), perm.size() * sizeof(int), hipMemcpyHostToDevice));
+    h->fast_model_ready = true;
+    return ICEM_OK;
+}
+
+bool fast_rollout_ok(const icem_handle* h, int K) {
+    if (h->has_terms) return false;  // the extra cost terms live in the general kernel
+    if (h->cost.lin_weight == 0.0) return false;  // ... and so does a cost without the linear term (dropped, not 0 * obs)
+    return h->use_fast && h->cfg.dtype == ICEM_F32 && h->has_model && h->has_cost &&
+           fast_rollout_supported(h->cfg.horizon, h->cfg.act_dim, h->O, K);
+}
+
+FastRolloutArgs fast_rollout_args(const icem_handle* h, int n_rows, int n_cand, int K, const void* obs0,
+                                  const void* actions, void* costs, float* part_c, int* part_i) {
+    FastRolloutArgs a;
+    a.n_rows = n_rows;
+    a.n_cand = n_cand;
+    a.K = K;
+    a.o = h->obs_dim;
+    a.cost_mode = h->cfg.cost_mode;
+    a.Mp = (const float*)h->Mp_dev;
+    a.perm = (const int*)h->perm_dev;
+    a.obs0 = (const float*)obs0;
+    a.ctrl_w = (float)h->cost.ctrl_weight;
+    a.lin_w = (float)h->cost.lin_weight;
+    a.flip_pen = (float)h->cost.flip_penalty;
+    a.flip_th = (float)h->cost.flip_thresh;
+    a.flip_col = h->flip_col;
+    a.actions = (const float*)actions;
+    a.costs = (float*)costs;
+    a.part_c = part_c;
+    a.part_i = part_i;
+    a.part_k = nullptr;
+    a.dbg = h->dbg;
+    return a;
+}
+
+// rows -> costs (+ one sorted candidate list per workgroup when K > 0); returns the number of candidate lists
+int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const void* obs0, const void* actions,
+                        void* costs, float* part_c, int* part_i, hipStream_t st, int* lists_out,
+                        unsigned long long* part_k) {
+    int rc = ensure_fast_model(h);
+    if (rc) return rc;
+    FastRolloutArgs a = fast_rollout_args(h, n_rows, n_cand, K, obs0, actions, costs, part_c, part_i);
+    a.part_k = part_k;
+    const int grid = rollout_lists(h->cfg.horizon, h->cfg.act_dim, h->O, n_rows);
+    {
+        ProfScope prof(h, ICEM_K_ROLLOUT, (long long)n_rows * h->cfg.horizon, st);
+        launch_rollout16(a, h->cfg.horizon, h->cfg.act_dim, h->O, h->model_kind, st);
+    }
+    ICEM_HIP_TRY(hipGetLastError());
+    if (lists_out) *lists_out = grid;
+    return ICEM_OK;
+}
+
+bool fast_sample_ok(const icem_handle* h) {
+    return h->use_fast && h->cfg.dtype == ICEM_F32 && fast_sample_supported(h->cfg.horizon, h->cfg.act_dim);
+}
+
+FastSampleArgs fast_sample_args(const icem_handle* h, int n, long long first_index, const void* mean, const void* std,
+                                const void* low, const void* high, uint64_t offset, int row0_mean, void* out,
+                                int n_shift, const void* elites_src, uint64_t offset2) {
+    FastSampleArgs a;
+    a.n = n;
+    a.h = h->cfg.horizon;
+    a.d = h->cfg.act_dim;
+    a.first_index = first_index;
+    a.W = (const float*)h->W_dev;
+    a.mean = (const float*)mean;
+    a.std = (const float*)std;
+    a.low = (const float*)low;
+    a.high = (const float*)high;
+    a.seed_lo = (uint32_t)h->cfg.seed;
+    a.seed_hi = (uint32_t)(h->cfg.seed >> 32);
+    a.off_lo = (uint32_t)offset;
+    a.off_hi = (uint32_t)(offset >> 32);
+    a.row0_mean = row0_mean;
+    a.out = (float*)out;
+    a.n_shift = n_shift;
+    a.elites_src = (const float*)elites_src;
+    a.off2_lo = (uint32_t)offset2;
+    a.off2_hi = (uint32_t)(offset2 >> 32);
+    a.white = h->cfg.noise_beta <= 0 ? 1 : 0;
+    return a;
+}
+
+int launch_fast_sample(const icem_handle* h, int n, long long first_index, const void* mean, const void* std,
+                       const void* low, const void* high, uint64_t offset, int row0_mean, void* out, hipStream_t st,
+                       int n_shift, const void* elites_src, uint64_t offset2) {
+    if (n <= 0 && n_shift <= 0) return ICEM_OK;
+    const FastSampleArgs a = fast_sample_args(h, n, first_index, mean, std, low, high, offset, row0_mean, out, n_shift,
+                                              elites_src, offset2);
+    {
+        ProfScope prof(h, ICEM_K_SAMPLE, (long long)n * a.h, st);
+        launch_sample_folded(a, h->cfg.rng_rounds, st);
+    }
+    ICEM_HIP_TRY(hipGetLastError());
+    return ICEM_OK;
+}
+
+// Can the f32 launch of an iteration with n_rows local rows (no shifted elites) carry a merge in its prologue?
+// (single-launch kernel with <= 4 rollout waves, or the sampler of the two-kernel path)
+bool prologue_possible(const icem_handle* h, int n_rows) {
+    const icem_config& c = h->cfg;
+    const int K = c.num_elites;
+    if (c.dtype != ICEM_F32 || !fast_rollout_ok(h, K) || !fast_sample_ok(h) || n_rows <= 0) return false;
+    if (sample_rollout_lists(c.horizon, c.act_dim, h->O, c.rng_rounds, n_rows) > 0)
+        return sample_rollout_merge_ok(c.horizon, c.act_dim, h->O, c.rng_rounds, n_rows, K);
+    return sample_folded_merge_ok(c.horizon, c.act_dim, c.rng_rounds, K);
+}
+
+// a stashed merge that found no launch to ride in
+int launch_pending_merge(icem_handle* h, hipStream_t st) {
+    const MergeSingleArgs& m = h->pm_args;
+    if (m.records == nullptr) {
+        ProfScope prof(h, ICEM_K_MERGE_REFIT, m.n_lists * m.K + m.n_keep, st);
+        launch_merge_single(m, st);
+    } else {
+        MergeArgsV a{};
+        a.n_rec = m.n_rec;
+        a.n_keep = m.n_keep;
+        a.K = m.K;
+        a.h = m.h;
+        a.d = m.d;
+        a.n_global = m.n_global;
+        a.last = 0;
+        a.alpha = m.alpha;
+        a.init_std = m.init_std;
+        a.records = m.records;
+        a.elites_cur = m.elites_cur;
+        a.elites_cost_cur = m.elites_cost_cur;
+        a.elites_next = m.elites_next;
+        a.elites_cost_next = m.elites_cost_next;
+        a.mean_in = m.mean;
+        a.std_in = m.std;
+        a.mean = m.mean_out;
+        a.std = m.std_out;
+        a.low = m.low;
+        a.high = m.high;
+        a.executed = m.executed;
+        a.best_cost = m.best_cost;
+        return gk_merge_refit(h, a, st);
+    }
+    ICEM_HIP_TRY(hipGetLastError());
+    return ICEM_OK;
+}
+
+template <typename T>
+int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, int it, hipStream_t st) {
+    const icem_config& c = h->cfg;
+    const int hd = h->hd, K = c.num_elites;
+    const int n_global = h->pop[it];
+    const int chunk = shard_chunk(n_global, c.world);
+    const int lo = std::min(n_global, c.rank * chunk);
+    const int n_loc = std::max(0, std::min(n_global - lo, chunk));
+    // noise stream offset of this call: episode in the high word (icem_set_episode; the reference's np.random stream
+    // runs on across episodes, icem.py:73), sampling call number of the episode in the low one
+    const uint64_t call_base = (h->episode << 32) + (uint64_t)mpc_step * (uint64_t)(c.opt_iters + 1);
+    const bool last = it == c.opt_iters - 1;
+    T* actions = (T*)b->actions;
+    // shifted elites, simulated at iteration 0 of every MPC step but the first (icem.py:131-137)
+    int n_extra = 0;
+    const T* shift_src = nullptr;
+    bool shift_in_sampler = false;
+    if (it == 0 && c.shift_elites && mpc_step > 0 && h->n_reuse > 0) {
+        n_extra = h->n_reuse;
+        const int g = (int)(((long long)mpc_step * c.opt_iters) & 1);  // elite buffer holding the previous step's set
+        shift_src = (const T*)b->elites + (size_t)g * K * hd;
+        // the fast sampler prepares them in an extra workgroup of its own launch
+        shift_in_sampler = std::is_same<T, float>::value && b->z_r == nullptr && b->z_r_shift == nullptr &&
+                           fast_rollout_ok(h, K) && fast_sample_ok(h) &&
+                           n_extra * c.act_dim <= 256;
+        if (!shift_in_sampler) {
+            T* dst = actions + (size_t)n_loc * hd;
+            int rc = gk_shift_elites(h, n_extra, shift_src, dst, st);
+            if (rc) return rc;
+            rc = gk_sample(h, n_extra, 0, b->mean, b->std, b->low, b->high, b->z_r_shift, b->z_i_shift,
+                           call_base + (uint64_t)c.opt_iters, c.horizon - 1, 0, dst, st);
+            if (rc) return rc;
+        }
+    }
+    // candidates: the shard, plus the shifted elites on rank 0 only (they are replicated)
+    const int n_cand = n_loc + (c.rank == 0 ? n_extra : 0);
+    const int row0 = (last && c.use_mean_actions) ? 1 : 0;
+    T* rec = (T*)b->records + (size_t)c.rank * K * (hd + 2);
+    h->fast_lists = 0;
+    if constexpr (std::is_same<T, float>::value) {
+        if (b->z_r == nullptr && fast_rollout_ok(h, K)) {
+            // f32 throughput path
+            const uint64_t off = call_base + (uint64_t)it;
+            int rc = ensure_fast_model(h);
+            if (rc) return rc;
+            int lists = 0;
+            float* pc;
+            int* pi;
+            const int n_rows = n_loc + n_extra;
+            const int one = (fast_sample_ok(h) && (n_extra == 0 || shift_in_sampler))
+                                ? sample_rollout_lists(c.horizon, c.act_dim, h->O, c.rng_rounds, n_rows) : 0;
+            // the merge finds the lists' indices behind `lists * K` costs
+            split_partial_ws<float>(b->workspace, one > 0 ? one : rollout_lists(c.horizon, c.act_dim, h->O, n_rows), K, &pc, &pi);
+            bool prologue = false;
+            if (h->pm_pending) {
+                prologue = n_extra == 0 && prologue_possible(h, n_rows);
+                if (!prologue) {  // cannot ride along after all: run it now
+                    rc = launch_pending_merge(h, st);
+                    if (rc) return rc;
+                }
+                h->pm_pending = false;
+            }
+            if (one > 0) {
+                // small populations: sample + rollout + top-K in one launch
+                FastIterArgs fa;
+                if (prologue) fa.m = h->pm_args;
+                fa.s = fast_sample_args(h, n_loc, lo, b->mean, b->std, b->low, b->high, off, row0, actions,
+                                        shift_in_sampler ? n_extra : 0, shift_src, call_base + (uint64_t)c.opt_iters);
+                fa.r = fast_rollout_args(h, n_rows, n_cand, K, b->obs0, actions, b->costs, pc, pi);
+                fa.r.part_k = (unsigned long long*)b->workspace;  // read by merge_single_kernel / pack_records_kernel
+                {
+                    ProfScope prof(h, ICEM_K_SAMPLE_ROLLOUT, (long long)n_rows * c.horizon, st);
+                    launch_sample_rollout(fa, c.horizon, c.act_dim, h->O, h->model_kind, prologue, st);
+                }
+                ICEM_HIP_TRY(hipGetLastError());
+                lists = one;
+            }
+            if (one == 0) {
+                if (prologue) {
+                    FastSampleMergeArgs sm;
+                    sm.s = fast_sample_args(h, n_loc, lo, b->mean, b->std, b->low, b->high, off, row0, actions, 0, nullptr, 0);
+                    sm.m = h->pm_args;
+                    {
+                        ProfScope prof(h, ICEM_K_SAMPLE, (long long)n_loc * c.horizon, st);
+                        launch_sample_folded_merge(sm, st);
+                    }
+                    ICEM_HIP_TRY(hipGetLastError());
+                    rc = ICEM_OK;
+                } else if (fast_sample_ok(h)) {
+                    rc = launch_fast_sample(h, n_loc, lo, b->mean, b->std, b->low, b->high, off, row0, actions, st,
+                                            shift_in_sampler ? n_extra : 0, shift_src, call_base + (uint64_t)c.opt_iters);
+                } else {
+                    rc = gk_sample(h, n_loc, lo, b->mean, b->std, b->low, b->high, nullptr, nullptr, off, 0, row0, actions, st);
+                }
+                if (rc) return rc;
+                rc = launch_fast_rollout(h, n_rows, n_cand, K, b->obs0, actions, b->costs, pc, pi, st, &lists,
+                                         (unsigned long long*)b->workspace);
+                if (rc) return rc;
+            }
+            h->fast_lists = lists;
+            if (c.world > 1) {
+                // this rank's K best -> records for the all-gather (same selection code as the merge)
+                MergeSingleArgs pk{};
+                pk.n_lists = lists;
+                pk.n_keep = 0;
+                pk.n_pool = n_rows;
+                pk.n_global = n_global;
+                pk.K = K;
+                pk.h = c.horizon;
+                pk.d = c.act_dim;
+                pk.part_k = (const unsigned long long*)b->workspace;
+                pk.actions = (const float*)actions;
+                ProfScope prof(h, ICEM_K_LOCAL_PACK, lists * K, st);
+                launch_pack_records(pk, n_loc, lo, (float*)rec, st);
+            }
+            ICEM_HIP_TRY(hipGetLastError());
+            return ICEM_OK;
+        }
+    }
+    // generic path (f64, external noise, shapes outside the fast list): one kernel per stage
+    int rc = gk_sample(h, n_loc, lo, b->mean, b->std, b->low, b->high, b->z_r, b->z_i, call_base + (uint64_t)it, 0, row0,
+                       actions, st);
+    if (rc) return rc;
+    rc = gk_rollout(h, n_loc + n_extra, b->obs0, actions, b->costs, nullptr, st);
+    if (rc) return rc;
+    const int nblk = std::max(1, topk_blocks(n_cand));
+    rc = gk_topk_partial(h, n_cand, K, b->costs, b->workspace, nblk, st);
+    if (rc) return rc;
+    return gk_local_pack(h, nblk, K, n_loc, lo, n_global, b->workspace, actions, rec, st);
+}
+
+template <typename T>
+int plan_iter_merge_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, int it, hipStream_t st) {
+    const icem_config& c = h->cfg;
+    const int hd = h->hd, K = c.num_elites;
+    const long long g = (long long)mpc_step * c.opt_iters + it;  // global iteration number
+    const int cur = (int)(g & 1), nxt = cur ^ 1;
+    T* el = (T*)b->elites;
+    T* elc = el + (size_t)2 * K * hd;
+    if constexpr (std::is_same<T, float>::value) {
+        if (c.world == 1 && h->fast_lists > 0) {
+            MergeSingleArgs m;
+            m.n_lists = h->fast_lists;
+            m.n_keep = (it > 0 && c.keep_previous_elites) ? h->n_reuse : 0;
+            const int n_extra = (it == 0 && c.shift_elites && mpc_step > 0) ? h->n_reuse : 0;
+            m.n_pool = h->pop[it] + n_extra;
+            m.n_global = h->pop[it];
+            m.K = K;
+            m.h = c.horizon;
+            m.d = c.act_dim;
+            m.last = it == c.opt_iters - 1;
+            m.alpha = (float)c.alpha;
+            m.init_std = (float)c.init_std;
+            m.part_k = (const unsigned long long*)b->workspace;
+            m.records = nullptr;
+            m.n_rec = 0;
+            m.actions = (const float*)b->actions;
+            m.elites_cur = (const float*)el + (size_t)cur * K * hd;
+            m.elites_cost_cur = (const float*)elc + (size_t)cur * K;
+            m.elites_next = (float*)el + (size_t)nxt * K * hd;
+            m.elites_cost_next = (float*)elc + (size_t)nxt * K;
+            m.mean = (const float*)b->mean;
+            m.std = (const float*)b->std;
+            m.mean_out = h->merge_mean_out ? h->merge_mean_out : (float*)b->mean;
+            m.std_out = h->merge_std_out ? h->merge_std_out : (float*)b->std;
+            m.low = (const float*)b->low;
+            m.high = (const float*)b->high;
+            m.executed = (float*)b->executed;
+            m.best_cost = (float*)b->best_cost;
+            m.dbg = h->dbg;
+            if (h->defer_merge && !m.last) {  // rides in the next iteration's launch (icem_plan_step)
+                h->pm_args = m;
+                h->pm_pending = true;
+                return ICEM_OK;
+            }
+            ProfScope prof(h, ICEM_K_MERGE_REFIT, h->fast_lists * K + m.n_keep, st);
+            launch_merge_single(m, st);
+            ICEM_HIP_TRY(hipGetLastError());
+            return ICEM_OK;
+        }
+    }
+    MergeArgsV a{};
+    a.n_rec = c.world * K;
+    a.n_keep = (it > 0 && c.keep_previous_elites) ? h->n_reuse : 0;
+    a.K = K;
+    a.h = c.horizon;
+    a.d = c.act_dim;
+    a.n_global = h->pop[it];
+    a.last = it == c.opt_iters - 1;
+    a.alpha = c.alpha;
+    a.init_std = c.init_std;
+    a.records = b->records;
+    a.elites_cur = el + (size_t)cur * K * hd;
+    a.elites_cost_cur = elc + (size_t)cur * K;
+    a.elites_next = el + (size_t)nxt * K * hd;
+    a.elites_cost_next = elc + (size_t)nxt * K;
+    a.mean_in = b->mean;
+    a.std_in = b->std;
+    a.mean = h->merge_mean_out ? (void*)h->merge_mean_out : b->mean;
+    a.std = h->merge_std_out ? (void*)h->merge_std_out : b->std;
+    a.low = b->low;
+    a.high = b->high;
+    a.executed = b->executed;
+    a.best_cost = b->best_cost;
+    if constexpr (std::is_same<T, float>::value) {
+        const bool fast_records = h->fast_lists > 0 && a.n_rec <= 128 && K <= 32;
+        if (fast_records) {  // f32 throughput path: the selection / refit code of the single-GPU merge on the records
+            MergeSingleArgs m{};
+            m.n_lists = 0;
+            m.n_keep = a.n_keep;
+            m.n_pool = 0;
+            m.n_global = a.n_global;
+            m.K = K;
+            m.h = a.h;
+            m.d = a.d;
+            m.last = 0;
+            m.alpha = (float)a.alpha;
+            m.init_std = (float)a.init_std;
+            m.part_k = nullptr;
+            m.records = (const float*)a.records;
+            m.n_rec = a.n_rec;
+            m.actions = nullptr;
+            m.elites_cur = (const float*)a.elites_cur;
+            m.elites_cost_cur = (const float*)a.elites_cost_cur;
+            m.elites_next = (float*)a.elites_next;
+            m.elites_cost_next = (float*)a.elites_cost_next;
+            m.mean = (const float*)a.mean_in;
+            m.std = (const float*)a.std_in;
+            m.mean_out = (float*)a.mean;
+            m.std_out = (float*)a.std;
+            m.low = (const float*)a.low;
+            m.high = (const float*)a.high;
+            m.executed = (float*)a.executed;
+            m.best_cost = (float*)a.best_cost;
+            m.dbg = nullptr;
+            if (h->defer_merge && !a.last) {  // rides in the next iteration's launch
+                h->pm_args = m;
+                h->pm_pending = true;
+                return ICEM_OK;
+            }
+            m.last = a.last;
+            ProfScope prof(h, ICEM_K_MERGE_REFIT, a.n_rec + a.n_keep, st);
+            launch_merge_single(m, st);
+            ICEM_HIP_TRY(hipGetLastError());
+            return ICEM_OK;
+        }
+    }
+    return gk_merge_refit(h, a, st);
+}
+
+}  // namespace icem
+
+extern "C" {
+
+size_t icem_plan_buffer_bytes(const icem_handle* h, int32_t which) {
+    if (!h) return 0;
+    const size_t ts = h->tsize, hd = (size_t)h->hd, K = (size_t)h->cfg.num_elites;
+    const size_t rows = (size_t)h->n_local_max + (size_t)h->n_reuse;
+    switch (which) {
+        case ICEM_BUF_MEAN:
+        case ICEM_BUF_STD:
+            return hd * ts;
+        case ICEM_BUF_LOW:
+        case ICEM_BUF_HIGH:
+        case ICEM_BUF_EXECUTED:
+            return (size_t)h->cfg.act_dim * ts;
+        case ICEM_BUF_OBS0:
+            return (size_t)std::max(1, h->obs_dim) * ts;
+        case ICEM_BUF_ACTIONS:
+            return rows * hd * ts;
+        case ICEM_BUF_COSTS:
+            return rows * ts;
+        case ICEM_BUF_ELITES:
+            return 2 * K * hd * ts + 2 * K * ts;
+        case ICEM_BUF_RECORDS:
+            return (size_t)h->cfg.world * K * (hd + 2) * ts;
+        case ICEM_BUF_WORKSPACE:
+            return (size_t)std::max(topk_blocks((int)rows), 1024) * K * (ts + sizeof(int));
+        case ICEM_BUF_BEST_COST:
+            return ts;
+        default:
+            return 0;
+    }
+}
+
+static int check_plan(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, int32_t it) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (!b) return fail(ICEM_E_INVALID, "null buffers");
+    if (!h->has_model || !h->has_cost) return fail(ICEM_E_STATE, "icem_set_model / icem_set_cost must be called first");
+    if (mpc_step < 0 || it < 0 || it >= h->cfg.opt_iters) return fail(ICEM_E_INVALID, "mpc_step / iteration out of range");
+    if (const char* e = cost_indices_error(h, h->obs_dim)) return fail(ICEM_E_INVALID, e);
+    if (!b->mean || !b->std || !b->low || !b->high || !b->obs0 || !b->actions || !b->costs || !b->elites || !b->records ||
+        !b->workspace || !b->executed || !b->best_cost)
+        return fail(ICEM_E_INVALID, "null plan buffer");
+    if (h->cfg.noise_beta > 0 &&
+        ((b->z_r == nullptr) != (b->z_i == nullptr) || (b->z_r_shift == nullptr) != (b->z_i_shift == nullptr)))
+        return fail(ICEM_E_INVALID, "z_r/z_i must be given in pairs");
+    return ICEM_OK;
+}
+
+// rows of this rank's shard at iteration `it`
+static int local_rows(const icem_handle* h, int it) {
+    const int n_global = h->pop[it];
+    const int chunk = shard_chunk(n_global, h->cfg.world);
+    const int lo = std::min(n_global, h->cfg.rank * chunk);
+    return std::max(0, std::min(n_global - lo, chunk));
+}
+
+static int ensure_pp_stats(icem_handle* h) {
+    if (!h->pp_stats) ICEM_HIP_TRY(hipMalloc((void**)&h->pp_stats, (size_t)4 * h->hd * sizeof(float)));
+    return ICEM_OK;
+}
+
+// world > 1 with merge deferral: the running step's distribution is at cur_mean / cur_std
+static bool deferral_active(const icem_handle* h, const icem_plan_buffers* b) {
+    return h->deferral && h->cfg.world > 1 && h->cfg.dtype == ICEM_F32 && b->z_r == nullptr && h->use_fast;
+}
+
+int icem_set_merge_deferral(icem_handle* h, int32_t on) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (h->pm_pending) return fail(ICEM_E_STATE, "a deferred merge is pending: finish the MPC step first");
+    h->deferral = on != 0;
+    return ICEM_OK;
+}
+
+int icem_plan_iter_local(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, int32_t it, void* stream) {
+    int rc = check_plan(h, b, mpc_step, it);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    icem_plan_buffers bb = *b;
+    if (deferral_active(h, b)) {
+        if (it == 0 || !h->cur_mean) {
+            h->cur_mean = (float*)b->mean;
+            h->cur_std = (float*)b->std;
+        }
+        bb.mean = h->cur_mean;
+        bb.std = h->cur_std;
+    }
+    return ICEM_DISPATCH(h, plan_iter_local_t<float>(h, &bb, mpc_step, it, st), plan_iter_local_t<double>(h, &bb, mpc_step, it, st));
+}
+
+int icem_plan_iter_merge(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, int32_t it, void* stream) {
+    int rc = check_plan(h, b, mpc_step, it);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (!deferral_active(h, b) || !h->cur_mean)
+        return ICEM_DISPATCH(h, plan_iter_merge_t<float>(h, b, mpc_step, it, st), plan_iter_merge_t<double>(h, b, mpc_step, it, st));
+    // sharded, deferral on: a non-last merge may ride in the next icem_plan_iter_local launch (mean / std / elites in
+    // the caller's buffers are then current again only after that launch; the last merge always runs here)
+    rc = ensure_pp_stats(h);
+    if (rc) return rc;
+    const bool last = it == h->cfg.opt_iters - 1;
+    const bool fold = !last && h->fast_lists > 0 && prologue_possible(h, local_rows(h, it + 1));
+    icem_plan_buffers bb = *b;
+    bb.mean = h->cur_mean;
+    bb.std = h->cur_std;
+    float* pp = h->pp_stats + (size_t)(it & 1) * 2 * h->hd;
+    h->defer_merge = fold;
+    if (last) {
+        h->merge_mean_out = (float*)b->mean;
+        h->merge_std_out = (float*)b->std;
+    } else if (fold) {
+        h->merge_mean_out = pp;
+        h->merge_std_out = pp + h->hd;
+    } else {
+        h->merge_mean_out = h->merge_std_out = nullptr;
+    }
+    rc = plan_iter_merge_t<float>(h, &bb, mpc_step, it, st);
+    h->defer_merge = false;
+    h->merge_mean_out = h->merge_std_out = nullptr;
+    if (rc) return rc;
+    if (fold && h->pm_pending) {
+        h->cur_mean = pp;
+        h->cur_std = pp + h->hd;
+    }
+    if (last) h->cur_mean = h->cur_std = nullptr;
+    return ICEM_OK;
+}
+
+int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (h->cfg.world != 1) return fail(ICEM_E_INVALID, "icem_plan_step is the world == 1 path; use iter_local/iter_merge");
+    int rc = check_plan(h, b, mpc_step, 0);
+    if (rc) return rc;
+    const icem_config& c = h->cfg;
+    const int iters = c.opt_iters;
+    // f32, device noise: iteration it's merge may ride in the prologue of iteration it+1's launch.  That launch
+    // reads pool / lists / distribution of iteration it while writing its own, so consecutive iterations alternate
+    // between the caller's buffers and the handle's partners (the last iteration always uses the caller's).
+    const bool pingpong = c.dtype == ICEM_F32 && b->z_r == nullptr && h->use_fast && iters > 1;
+    if (pingpong && !h->actions_alt) {
+        ICEM_HIP_TRY(hipMalloc(&h->actions_alt, icem_plan_buffer_bytes(h, ICEM_BUF_ACTIONS)));
+        ICEM_HIP_TRY(hipMalloc(&h->ws_alt, icem_plan_buffer_bytes(h, ICEM_BUF_WORKSPACE)));
+    }
+    if (pingpong) {
+        rc = ensure_pp_stats(h);
+        if (rc) return rc;
+    }
+    float* cur_mean = (float*)b->mean;  // where the current distribution lives
+    float* cur_std = (float*)b->std;
+    for (int it = 0; it < iters; ++it) {
+        icem_plan_buffers bb = *b;
+        if (pingpong) {
+            if ((iters - 1 - it) & 1) bb.actions = h->actions_alt;
+            if (it & 1) bb.workspace = h->ws_alt;
+            bb.mean = cur_mean;
+            bb.std = cur_std;
+        }
+        rc = icem_plan_iter_local(h, &bb, mpc_step, it, stream);
+        if (rc) return rc;
+        const bool last = it == iters - 1;
+        bool fold = false;
+        if (pingpong && !last && h->fast_lists > 0) fold = prologue_possible(h, h->pop[it + 1]);
+        h->defer_merge = fold;
+        float* pp = pingpong ? h->pp_stats + (size_t)(it & 1) * 2 * h->hd : nullptr;
+        if (last) {  // the final distribution goes to the caller's buffers
+            h->merge_mean_out = (float*)b->mean;
+            h->merge_std_out = (float*)b->std;
+        } else if (fold) {
+            h->merge_mean_out = pp;
+            h->merge_std_out = pp + h->hd;
+        } else {
+            h->merge_mean_out = h->merge_std_out = nullptr;  // in place
+        }
+        rc = icem_plan_iter_merge(h, &bb, mpc_step, it, stream);
+        h->defer_merge = false;
+        h->merge_mean_out = h->merge_std_out = nullptr;
+        if (rc) return rc;
+        if (fold && h->pm_pending) {
+            cur_mean = pp;
+            cur_std = pp + h->hd;
+        }
+    }
+    return ICEM_OK;
+}
+
+// MpcICem.get_action as one call for a host caller: observation in, executed action (+ its pool's best cost) out.
+// The handle owns a small pinned, device-mapped block [obs | action, best cost | flag].  On the f32 fast path the first
+// launch reads the observation straight from it (no H2D copy command in front of the step) and a one-thread kernel
+// behind the last merge writes the result and a sequence flag into it, which the host polls (no D2H copy commands,
+// no stream synchronisation wake-up).  Other configurations stage through the same block with copy commands.
+int icem_get_action(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, const double* obs_host,
+                    double* action_host, double* best_cost_host, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (!b || !obs_host || !action_host) return fail(ICEM_E_INVALID, "null argument");
+    if (!h->has_model) return fail(ICEM_E_STATE, "icem_set_model / icem_set_cost must be called first");
+    hipStream_t st = (hipStream_t)stream;
+    const int o = h->obs_dim, d = h->cfg.act_dim;
+    const size_t ts = h->tsize;
+    constexpr size_t OUT_OFF = ICEM_MAX_OBS_DIM * sizeof(double), FLAG_OFF = OUT_OFF + (ICEM_MAX_ACT_DIM + 1) * sizeof(double);
+    if (!h->host_stage) {
+        ICEM_HIP_TRY(hipHostMalloc(&h->host_stage, FLAG_OFF + 64, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(h->host_stage, 0, FLAG_OFF + 64);
+        ICEM_HIP_TRY(hipHostGetDevicePointer(&h->host_stage_dev, h->host_stage, 0));
+    }
+    unsigned char* stage = (unsigned char*)h->host_stage;
+    for (int k = 0; k < o; ++k) {
+        if (h->cfg.dtype == ICEM_F64) ((double*)stage)[k] = obs_host[k];
+        else ((float*)stage)[k] = (float)obs_host[k];
+    }
+    unsigned char* out = stage + OUT_OFF;
+    volatile unsigned* flag = (volatile unsigned*)(stage + FLAG_OFF);
+    const bool mapped = h->cfg.dtype == ICEM_F32 && h->use_fast && b->z_r == nullptr && fast_rollout_ok(h, h->cfg.num_elites) &&
+                        fast_sample_ok(h);
+    icem_plan_buffers bb = *b;
+    if (mapped) {
+        std::atomic_thread_fence(std::memory_order_release);
+        bb.obs0 = h->host_stage_dev;
+    } else {
+        ICEM_HIP_TRY(hipMemcpyAsync(b->obs0, stage, o * ts, hipMemcpyHostToDevice, st));
+    }
+    const int rc = icem_plan_step(h, &bb, mpc_step, stream);
+    if (rc) return rc;
+    if (mapped) {
+        // (publishing from inside the last merge kernel instead was tried: no faster than this one-wave launch)
+        const unsigned seq = ++h->io_seq;
+        unsigned char* dev = (unsigned char*)h->host_stage_dev;
+        hipLaunchKernelGGL(publish_result_kernel, dim3(1), dim3(64), 0, st, (const float*)b->executed, (const float*)b->best_cost, d,
+                           (float*)(dev + OUT_OFF), (unsigned*)(dev + FLAG_OFF), seq);
+        ICEM_HIP_TRY(hipGetLastError());
+        long long spins = 0;
+        while (*flag != seq) {
+            __builtin_ia32_pause();
+            if (++spins > (1ll << 26)) {  // ~ a second: something is wrong on the stream -- let the runtime report it
+                ICEM_HIP_TRY(hipStreamSynchronize(st));
+                if (*flag != seq) return fail(ICEM_E_HIP, "result flag never arrived");
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    } else {
+        ICEM_HIP_TRY(hipMemcpyAsync(out, b->executed, d * ts, hipMemcpyDeviceToHost, st));
+        ICEM_HIP_TRY(hipMemcpyAsync(out + (size_t)d * ts, b->best_cost, ts, hipMemcpyDeviceToHost, st));
+        ICEM_HIP_TRY(hipStreamSynchronize(st));
+    }
+    for (int j = 0; j <= d; ++j) {
+        const double v = h->cfg.dtype == ICEM_F64 ? ((const double*)out)[j] : (double)((const float*)out)[j];
+        if (j < d) action_host[j] = v;
+        else if (best_cost_host) *best_cost_host = v;
+    }
+    return ICEM_OK;
+}
+
+}  // extern "C"

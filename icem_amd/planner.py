@@ -102,6 +102,8 @@ class IcemPlanner:
         self.obs_dim = 0
         self._bufs = None
         self.mpc_step = 0
+        self.episode = 0           # folded into the device noise streams (icem_set_episode)
+        self._episodes_started = 0
         self._topk_ws = None
 
     def __del__(self):
@@ -403,6 +405,19 @@ class IcemPlanner:
         self._ensure_buffers()
         self.reset_distribution(self.mean, self.std)
         self.mpc_step = 0
+
+    def new_episode(self) -> int:
+        """Move the device noise streams on to the next episode (``icem_set_episode``): the reference's ``np.random``
+        stream runs on across episodes (icem/controllers/icem.py:73-77), so rollouts must not replay each other's
+        exploration noise.  The first call selects episode 0.  Returns the episode number."""
+        self.episode = self._episodes_started
+        self._episodes_started += 1
+        L.check(self.lib.icem_set_episode(self._h, self.episode))
+        return self.episode
+
+    def noise_offset(self, call: int) -> int:
+        """Stream offset of sampling call ``call`` of the current episode (what ``icem_plan_*`` use internally)."""
+        return (self.episode << 32) + int(call)
 
     def current_elites(self):
         """Elite actions [K,h,d] and costs [K] of the latest iteration (best first)."""

@@ -150,6 +150,12 @@ int icem_device_count(void);
 int icem_create(const icem_config* cfg, icem_handle** out);
 int icem_destroy(icem_handle* h);
 
+/* Episode number of the rollout being planned, folded into the device noise streams (high word of the stream offset,
+ * the sampling call number mpc_step*(opt_iters+1)+it is the low word): the reference draws from one np.random stream
+ * that runs on across episodes (icem.py:73-77), so consecutive episodes must not replay the same exploration noise.
+ * 0 after icem_create; the host mirror advances it in beginning_of_rollout (icem.py:31-43).  episode < 2^32. */
+int icem_set_episode(icem_handle* h, uint64_t episode);
+
 /* Sequence of population sizes N_i the loop will use (icem.py:123-127); out_host[opt_iters]. */
 int icem_population_sizes(const icem_handle* h, int32_t* out_host);
 

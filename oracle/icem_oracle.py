@@ -294,8 +294,9 @@ class PhiloxNoiseSchedule:
     main 1, ...); the shift batch is recognised by its position."""
 
     def __init__(self, seed: int, iters: int, d: int, h: int, shift: bool = True,
-                 rounds: int = 10, dtype=np.float64, white: bool = False):
+                 rounds: int = 10, dtype=np.float64, white: bool = False, episode: int = 0):
         self.seed, self.iters, self.d, self.h = seed, iters, d, h
+        self.episode = episode  # high word of every offset (the device's icem_set_episode)
         self.shift, self.rounds, self.dtype = shift, rounds, dtype
         self.white = white  # beta <= 0: return (randn[num, h, d], None)
         self.step = -1
@@ -307,7 +308,7 @@ class PhiloxNoiseSchedule:
         self.shift_done = False
 
     def __call__(self, num: int):
-        base = self.step * (self.iters + 1)
+        base = (self.episode << 32) + self.step * (self.iters + 1)
         if self.shift and self.step > 0 and self.it == 1 and not self.shift_done:
             self.shift_done = True
             off = base + self.iters

@@ -13,6 +13,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "soak: randomised many-seed runs (also marked gpu; ICEM_SOAK_SEEDS scales them)")
 
 
 def pytest_collection_modifyitems(config, items):
