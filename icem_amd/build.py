@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 UNITS = ["generic_kernels.hip", "plan.hip", "abi.hip", "exchange.hip", "k_sample.hip", "k_rollout.hip", "k_merge.hip",
-         "k_iter_small.hip", "k_iter_large.hip", "icem_rssm.hip", "k_rollout_wide.hip"]
+         "k_iter_small.hip", "icem_rssm.hip", "k_rollout_wide.hip"]
 OUT = os.path.join(HERE, "libicem_hip.so")
 INFO = OUT + ".json"
 OBJ = os.path.join(CSRC, "_obj")

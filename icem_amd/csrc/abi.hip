@@ -329,7 +329,6 @@ int icem_topk_sorted(icem_handle* h, int32_t n, const void* costs, int32_t k, vo
     if (check_handle(h)) return ICEM_E_INVALID;
     if (n < 1 || k < 1 || k > ICEM_MAX_ELITES || !costs || !out_cost || !out_idx || !workspace)
         return fail(ICEM_E_INVALID, "bad n/k or null tensor");
-    if (k > n) return fail(ICEM_E_INVALID, "k > n: fewer candidates than elites");
     hipStream_t st = (hipStream_t)stream;
     return gk_topk(h, n, k, costs, out_cost, out_idx, workspace, st);
 }

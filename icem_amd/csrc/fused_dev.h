@@ -118,14 +118,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // K1
 // -------------------------------------------------------------------------------------------------
 // The h colored samples of one (trajectory, action-dim) row: per-row RNG stream -> Box-Muller -> h white
-// draws in registers -> inverse real DFT folded on its symmetry; emit(t, y) receives sample y of step t.
-template <int H, int ROUNDS, typename Emit>
-__device__ __forceinline__ void sample_row(const float* __restrict__ W, unsigned gi, unsigned j, unsigned off_lo,
-                                           unsigned off_hi, unsigned seed_lo, unsigned seed_hi, Emit&& emit,
-                                           bool white = false) {
-    constexpr int F = H / 2 + 1;
+// draws in registers (row_normals) -> inverse real DFT folded on its symmetry (row_synth); emit(t, y) receives sample
+// y of step t.  sample_row is the two in sequence; kernels that have to wait for the distribution between the two
+// (merge prologue of k_iter_large.hip) call them separately -- same operations in the same order, same bits.
+template <int H, int ROUNDS>
+__device__ __forceinline__ void row_normals(unsigned gi, unsigned j, unsigned off_lo, unsigned off_hi, unsigned seed_lo,
+                                            unsigned seed_hi, float (&g)[HMAX]) {
     static_assert(H <= 32 && H >= 2, "white draws of a row live in 32 registers");
-    float g[HMAX];
     Xoshiro128pp rng = row_stream<ROUNDS>(gi, j, off_lo, off_hi, seed_lo, seed_hi);
 #pragma unroll
     for (int m = 0; m < H; m += 2) {
@@ -133,6 +132,11 @@ __device__ __forceinline__ void sample_row(const float* __restrict__ W, unsigned
         const uint32_t xb = rng.next();
         box_muller(xa, xb, g[m], g[m + 1]);
     }
+}
+
+template <int H, typename Emit>
+__device__ __forceinline__ void row_synth(const float* __restrict__ W, const float (&g)[HMAX], Emit&& emit, bool white) {
+    constexpr int F = H / 2 + 1;
     if (white) {  // wave-uniform: noise_beta <= 0, the draws are the samples (icem.py:77)
 #pragma unroll
         for (int t = 0; t < H; ++t) emit(t, g[t]);
@@ -167,9 +171,15 @@ __device__ __forceinline__ void sample_row(const float* __restrict__ W, unsigned
     }
 }
 
-// -------------------------------------------------------------------------------------------------
-// K2 + K3: rollout + cost + per-workgroup sorted top-K
-// -------------------------------------------------------------------------------------------------
+template <int H, int ROUNDS, typename Emit>
+__device__ __forceinline__ void sample_row(const float* __restrict__ W, unsigned gi, unsigned j, unsigned off_lo,
+                                           unsigned off_hi, unsigned seed_lo, unsigned seed_hi, Emit&& emit,
+                                           bool white = false) {
+    float g[HMAX];
+    row_normals<H, ROUNDS>(gi, j, off_lo, off_hi, seed_lo, seed_hi, g);
+    row_synth<H>(W, g, emit, white);
+}
+
 __device__ __forceinline__ float act_fn(float x, std::integral_constant<int, 0>) { return x; }
 // tanh in ~14 instructions (libm's tanhf is ~40, and a tanh model spends most of its step there): 1 - 2 / (e^2x + 1)
 // on the hardware exp2 / rcp, which loses relative accuracy near 0 to cancellation, so |x| < 0.1 takes the odd
@@ -794,6 +804,86 @@ __device__ __forceinline__ unsigned long long rollout_slab(Tile& tile, const Fas
     }
     return run_key;
 }
+
+// One wave rolls ONE 16-trajectory tile out of the action tensor in HBM / L2: the tile's actions are one contiguous
+// 16 x H x D block; the wave fetches it with full-width coalesced loads, chunk by chunk (one chunk prefetched in
+// registers), into its own LDS staging buffer; each lane then reads the one or two entries it feeds to the MFMAs.
+// Only this wave touches the buffer and a wave's LDS operations execute in order: no barriers.  Shared by
+// rollout16_kernel (k_rollout.hip) and iter_large_kernel (k_iter_large.hip).
+template <int H, int D, int O, int KIND>
+struct Stream16 {
+    using Tile = Tile16<H, D, O, KIND>;
+    static constexpr int HD = H * D;
+    static constexpr int VW = HD % 4 == 0 ? 4 : 2;    // floats per load: rows are 16-byte aligned only if h*d % 4 == 0
+    static_assert(HD % 2 == 0, "8-byte aligned action rows");
+    using Vec = typename VecOf<VW>::type;
+    static constexpr int TC = r16_chunk_steps(H, D, VW);  // steps per action chunk
+    static_assert(TC > 0, "no aligned action chunk for this (H, D)");
+    static constexpr int CB = TC * D;                 // floats per row and chunk
+    static constexpr int C4 = CB / VW;                // vectors per row and chunk
+    static constexpr int CBP = (C4 % 2) ? CB : CB + VW;  // LDS row stride: odd number of vectors
+    static constexpr int NCH = H / TC;
+    static constexpr int F4 = 16 * C4;                // vectors per chunk of a 16-trajectory tile
+    static constexpr int NLD = (F4 + 63) / 64;        // cooperative load instructions per chunk
+    static constexpr int STG = Tile::SLACK + 16 * CBP + Tile::TAIL;  // floats of staging per wave
+
+    // cooperative loads: vector number f = m * 64 + lane of a chunk is row f / C4, vector f % C4 of that row
+    int ld_row[NLD], ld_c4[NLD];
+    bool ld_on[NLD];
+    const float* rd0;
+    float* stage;
+
+    __device__ __forceinline__ void init(const Tile& tile, float* stage_buf, int lane) {
+        stage = stage_buf;
+        rd0 = tile.read_ptr(stage_buf, lane, CBP);
+#pragma unroll
+        for (int m = 0; m < NLD; ++m) {
+            const int f = m * 64 + lane;
+            ld_on[m] = f < F4;
+            ld_row[m] = ld_on[m] ? f / C4 : 0;
+            ld_c4[m] = ld_on[m] ? f % C4 : 0;
+        }
+    }
+
+    // costs[row] of the tile's live rows; the tile's keys join the wave's running sorted top-K
+    __device__ __forceinline__ unsigned long long run(const Tile& tile, const FastRolloutArgs& a, int tile_id, int lane,
+                                                      unsigned long long run_key, bool first) const {
+        const int row = tile_id * 16 + (lane & 15);
+        const bool live = row < a.n_rows;
+        const Vec* src[NLD];
+#pragma unroll
+        for (int m = 0; m < NLD; ++m) {
+            const int r = tile_id * 16 + ld_row[m];
+            src[m] = reinterpret_cast<const Vec*>(a.actions + (size_t)(r < a.n_rows ? r : 0) * HD) + ld_c4[m];
+        }
+        Vec pre[NLD];
+#pragma unroll
+        for (int m = 0; m < NLD; ++m) pre[m] = src[m][0];
+        typename Tile::State st;
+        tile.init(st);
+#pragma unroll
+        for (int t = 0; t < H; ++t) {
+            if (t % TC == 0) {
+                // next chunk: registers -> this wave's LDS buffer, then start fetching the one after
+#pragma unroll
+                for (int m = 0; m < NLD; ++m)
+                    if (ld_on[m]) *reinterpret_cast<Vec*>(&stage[Tile::SLACK + ld_row[m] * CBP + VW * ld_c4[m]]) = pre[m];
+                if (t / TC + 1 < NCH) {
+#pragma unroll
+                    for (int m = 0; m < NLD; ++m) pre[m] = src[m][(t / TC + 1) * C4];
+                }
+            }
+            tile.step(st, rd0 + (t % TC) * D);
+        }
+        const float cost = tile.cost(st);
+        if (live && lane < 16) a.costs[row] = cost;
+        if (a.K > 0) {
+            const unsigned long long key = (lane < 16 && live && row < a.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
+            run_key = topk_push16(run_key, key, first, a.K, lane);
+        }
+        return run_key;
+    }
+};
 
 // rollout launch shape: one 16-trajectory tile per wave while they fit, at most FAST_MAX_LISTS workgroups (= lists)
 inline void r16_shape(int n_rows, int* grid, int* waves) {

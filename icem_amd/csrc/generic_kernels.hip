@@ -621,11 +621,16 @@ __global__ __launch_bounds__(WG) void topk_final_kernel(int cnt, int K, const T*
 template <typename T>
 __global__ __launch_bounds__(WG) void gather_refit_kernel(int hd, int K, T alpha, const T* actions, const int* idx,
                                                           T* mean, T* std, T* elites_out) {
+    // an index list padded by icem_topk_sorted (k > n: entries INT_MAX) repeats its best row instead of reading out of bounds
+    auto row = [&](int r) -> size_t {
+        const int i = idx[r];
+        return (size_t)((i < 0 || i == INT_MAX) ? idx[0] : i);
+    };
     for (int e = blockIdx.x * WG + threadIdx.x; e < hd; e += gridDim.x * WG) {
         if (elites_out != nullptr)
-            for (int r = 0; r < K; ++r) elites_out[(size_t)r * hd + e] = actions[(size_t)idx[r] * hd + e];
+            for (int r = 0; r < K; ++r) elites_out[(size_t)r * hd + e] = actions[row(r) * hd + e];
         T nm, ns;
-        refit_element<T>(K, alpha, mean[e], std[e], [&](int r) { return actions[(size_t)idx[r] * hd + e]; }, nm, ns);
+        refit_element<T>(K, alpha, mean[e], std[e], [&](int r) { return actions[row(r) * hd + e]; }, nm, ns);
         mean[e] = nm;
         std[e] = ns;
     }

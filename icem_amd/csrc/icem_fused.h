@@ -108,5 +108,4 @@ int sample_rollout_lists(int h, int d, int O, int rounds, int n_rows);
 bool sample_rollout_merge_ok(int h, int d, int O, int rounds, int n_rows, int K);
 void launch_sample_rollout(const FastIterArgs& a, int h, int d, int O, int kind, bool merge_prologue, hipStream_t st);
 
-
 }  // namespace icem

@@ -235,14 +235,15 @@ int icem_trajectory_cost(icem_handle* h, int32_t n, int32_t obs_dim, const void*
 
 /* K3  costs.argsort()[:k] (icem.py:199) and argmin (icem.py:149): the k smallest (cost, index)
  * pairs in ascending order, ties broken by index, NaN treated as +inf.
- * out_cost [k] (handle dtype), out_idx [k] int32.  workspace: icem_topk_workspace_bytes(n, k). */
+ * out_cost [k] (handle dtype), out_idx [k] int32 (k > n: entries n.. are (+inf, INT_MAX)).  workspace:
+ * icem_topk_workspace_bytes(n, k). */
 size_t icem_topk_workspace_bytes(const icem_handle* h, int32_t n, int32_t k);
 int icem_topk_sorted(icem_handle* h, int32_t n, const void* costs, int32_t k, void* out_cost,
                      int32_t* out_idx, void* workspace, void* stream);
 
 /* K4  update_distributions (icem.py:201-211): gather the k elite rows of `actions` [*, h, d] in
  * `idx` order into elites_out [k, h, d]; mean <- (1-alpha)*mean_k + alpha*mean,
- * std <- (1-alpha)*std_k(ddof=0) + alpha*std (in place). */
+ * std <- (1-alpha)*std_k(ddof=0) + alpha*std (in place).  An entry INT_MAX (padding of icem_topk_sorted) repeats row idx[0]. */
 int icem_gather_refit(icem_handle* h, const void* actions, const int32_t* idx, int32_t k, void* mean,
                       void* std, void* elites_out, void* stream);
 

