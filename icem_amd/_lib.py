@@ -104,10 +104,19 @@ SYMBOLS = [
     ("icem_debug_stamps", C.c_int, [_H, _VP]),
     ("icem_set_merge_deferral", C.c_int, [_H, C.c_int32]),
     ("icem_set_episode", C.c_int, [_H, C.c_uint64]),
+    ("icem_exchange_create", C.c_int, [_H, _VP]),
+    ("icem_exchange_connect", C.c_int, [_H, _VP, C.POINTER(C.c_void_p)]),
+    ("icem_exchange_block", C.c_void_p, [_H]),
+    ("icem_exchange_status", C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("icem_plan_step_sharded", C.c_int, [_H, C.POINTER(IcemPlanBuffersC), _I32, _VP]),
+    ("icem_exchange_probe", C.c_int, [_H, C.c_int32, _VP, C.POINTER(C.c_double)]),
     ("icem_sample_truncnorm", C.c_int, [_H, C.c_int32, C.c_int64, _VP, _VP, _VP, _VP, _VP, C.c_uint64, _VP, _VP]),
     ("icem_cem_bounds", C.c_int, [_H, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     ("icem_profile_read", C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 ]
+
+
+IPC_HANDLE_BYTES = 64
 
 
 def lib_path() -> str:

@@ -14,6 +14,7 @@
 #include <type_traits>
 #include <utility>
 
+#include "exchange_dev.h"
 #include "philox.h"
 #include "refit.h"
 
@@ -677,6 +678,7 @@ __device__ __forceinline__ void merge_select_stream(const MergeSingleArgs& a, in
 __device__ __forceinline__ void merge_select_records(const MergeSingleArgs& a, int lane, unsigned long long* cand,
                                                      unsigned long long* sel, int* slot) {
     const int K = a.K, rs = a.h * a.d + 2;
+    xchg_wait(a.xw, lane);  // in-library exchange: the peers' records of this iteration have landed
     auto rec_key = [&](int e) -> unsigned long long {
         if (e >= a.n_rec) return KEY_SENTINEL;
         const float* rec = a.records + (size_t)e * rs;

@@ -13,6 +13,7 @@
 // Kernels (one section each): sample_clip (K1), rollout_cost (K2), block top-k (K3),
 // local_pack / merge_refit (K3+K4 of the fused step), small epilogue kernels.
 #include "host_common.h"
+#include "exchange_dev.h"
 #include "philox.h"
 #include "refit.h"
 
@@ -745,6 +746,7 @@ struct MergeArgs {
     const T* high;
     T* executed;
     T* best_cost;
+    XchgWait xw;  // in-library exchange: wait for the ranks' records first (flags == nullptr: they are in place)
 };
 
 // One workgroup: global sorted top-K over the gathered records (+ kept elites), new elite set,
@@ -763,6 +765,10 @@ __global__ __launch_bounds__(WG) void merge_refit_kernel(MergeArgs<T> a) {
     const int hd = a.h * a.d;
     const int rs = hd + 2;
     const int cnt = a.n_rec + a.n_keep;
+    if (a.xw.flags != nullptr) {  // in-library exchange: the peers' records of this iteration have landed
+        if (threadIdx.x < 64) xchg_wait(a.xw, threadIdx.x);
+        __syncthreads();
+    }
     block_select_sorted<T>(
         cnt, a.K,
         [&](int e) { return e < a.n_rec ? nan_to_inf(a.records[(size_t)e * rs]) : a.elites_cost_cur[e - a.n_rec]; },
@@ -1203,6 +1209,7 @@ static void merge_refit_t(const icem_handle* h, const MergeArgsV& v, hipStream_t
     a.high = (const T*)v.high;
     a.executed = (T*)v.executed;
     a.best_cost = (T*)v.best_cost;
+    a.xw = v.xw;
     ProfScope prof(h, ICEM_K_MERGE_REFIT, a.n_rec + a.n_keep, st);
     hipLaunchKernelGGL((merge_refit_kernel<T>), dim3(1), dim3(WG), (size_t)v.h * v.d * sizeof(T), st, a);
 }

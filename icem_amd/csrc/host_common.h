@@ -99,6 +99,7 @@ struct icem_handle {
     std::vector<Span> spans;
     std::vector<hipEvent_t> free_events;
     icem::Exchange* xchg = nullptr;  // in-library elite exchange (icem_exchange_*), world > 1
+    icem::XchgWait xw_last;          // ... and what the merge of the running iteration waits for (set by the push)
     uint64_t episode = 0;            // folded into the noise stream offset (icem_set_episode)
 };
 
@@ -191,10 +192,17 @@ struct MergeArgsV {
     const void* high;
     void* executed;
     void* best_cost;
+    XchgWait xw;
 };
 int gk_merge_refit(const icem_handle* h, const MergeArgsV& a, hipStream_t st);
 // every index a cost term reads lies inside an observation of width o (nullptr = fine)
 const char* cost_indices_error(const icem_handle* h, int o);
+
+// ---- exchange.hip: the in-library elite exchange --------------------------------------------------------------------
+bool xchg_connected(const icem_handle* h);
+// this rank's K records of the running iteration -> every rank's block (one launch); *wait_out: what the merge polls
+int xchg_push(icem_handle* h, const void* my_records, hipStream_t st, XchgWait* wait_out);
+void xchg_destroy(icem_handle* h);
 
 // ---- plan.hip: the f32 throughput path ---------------------------------------------------------------------------
 bool fast_rollout_ok(const icem_handle* h, int K);

@@ -8,6 +8,17 @@ namespace icem {
 
 constexpr int FAST_MAX_LISTS = 256;  // candidate lists (one per rollout workgroup) the merge accepts
 
+// In-library elite exchange (exchange.hip): what a merge needs to wait for the ranks' records of one exchange.
+constexpr int XCHG_MAX_WORLD = 16;
+struct XchgWait {
+    const unsigned* flags = nullptr;  // [world] sequence flags of the exchange's parity in THIS rank's block; nullptr: no wait
+    unsigned* status = nullptr;       // set to 1 when a wait times out
+    unsigned seq = 0;                 // the value every flag must reach
+    int world = 0;
+    unsigned max_polls = 0;           // bound of the wait (polls of ~0.5 us); then status = 1 and the wait gives up
+    const void* records = nullptr;    // [world * K] gathered records of that parity (handle dtype)
+};
+
 // K1 fast: colored-noise sampling with the inverse real DFT folded on its symmetry (f32, Philox).
 struct FastSampleArgs {
     int n, h, d;
@@ -69,6 +80,7 @@ struct MergeSingleArgs {
     // instead of lists + pool (part_k / actions / n_lists / n_pool unused)
     const float* records;  // [n_rec, 2 + h*d] or nullptr
     int n_rec;
+    XchgWait xw;           // records arrive through the in-library exchange: wait for them first (flags == nullptr: no)
     const float* actions;
     const float* elites_cur;
     const float* elites_cost_cur;

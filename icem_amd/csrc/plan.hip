@@ -199,6 +199,7 @@ int launch_pending_merge(icem_handle* h, hipStream_t st) {
         a.high = m.high;
         a.executed = m.executed;
         a.best_cost = m.best_cost;
+        a.xw = m.xw;
         return gk_merge_refit(h, a, st);
     }
     ICEM_HIP_TRY(hipGetLastError());
@@ -317,8 +318,12 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                 pk.d = c.act_dim;
                 pk.part_k = (const unsigned long long*)b->workspace;
                 pk.actions = (const float*)actions;
-                ProfScope prof(h, ICEM_K_LOCAL_PACK, lists * K, st);
-                launch_pack_records(pk, n_loc, lo, (float*)rec, st);
+                {
+                    ProfScope prof(h, ICEM_K_LOCAL_PACK, lists * K, st);
+                    launch_pack_records(pk, n_loc, lo, (float*)rec, st);
+                }
+                ICEM_HIP_TRY(hipGetLastError());
+                if (xchg_connected(h)) return xchg_push(h, rec, st, &h->xw_last);
             }
             ICEM_HIP_TRY(hipGetLastError());
             return ICEM_OK;
@@ -333,7 +338,10 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
     const int nblk = std::max(1, topk_blocks(n_cand));
     rc = gk_topk_partial(h, n_cand, K, b->costs, b->workspace, nblk, st);
     if (rc) return rc;
-    return gk_local_pack(h, nblk, K, n_loc, lo, n_global, b->workspace, actions, rec, st);
+    rc = gk_local_pack(h, nblk, K, n_loc, lo, n_global, b->workspace, actions, rec, st);
+    if (rc) return rc;
+    if (c.world > 1 && xchg_connected(h)) return xchg_push(h, rec, st, &h->xw_last);
+    return ICEM_OK;
 }
 
 template <typename T>
@@ -397,6 +405,10 @@ int plan_iter_merge_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
     a.alpha = c.alpha;
     a.init_std = c.init_std;
     a.records = b->records;
+    if (c.world > 1 && xchg_connected(h)) {  // the records of this iteration arrive in the exchange block
+        a.xw = h->xw_last;
+        a.records = h->xw_last.records;
+    }
     a.elites_cur = el + (size_t)cur * K * hd;
     a.elites_cost_cur = elc + (size_t)cur * K;
     a.elites_next = el + (size_t)nxt * K * hd;
@@ -425,6 +437,7 @@ int plan_iter_merge_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
             m.init_std = (float)a.init_std;
             m.part_k = nullptr;
             m.records = (const float*)a.records;
+            m.xw = a.xw;
             m.n_rec = a.n_rec;
             m.actions = nullptr;
             m.elites_cur = (const float*)a.elites_cur;
@@ -582,6 +595,22 @@ int icem_plan_iter_merge(icem_handle* h, const icem_plan_buffers* b, int32_t mpc
     }
     if (last) h->cur_mean = h->cur_std = nullptr;
     return ICEM_OK;
+}
+
+int icem_plan_step_sharded(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (h->cfg.world < 2) return icem_plan_step(h, b, mpc_step, stream);
+    if (!xchg_connected(h)) return fail(ICEM_E_STATE, "icem_exchange_create / icem_exchange_connect must be called first");
+    if (b && b->z_r != nullptr) return fail(ICEM_E_INVALID, "external noise goes through icem_plan_iter_local / _merge");
+    const bool was = h->deferral;
+    h->deferral = true;  // non-last merges ride in the next local launch
+    int rc = ICEM_OK;
+    for (int it = 0; it < h->cfg.opt_iters && rc == ICEM_OK; ++it) {
+        rc = icem_plan_iter_local(h, b, mpc_step, it, stream);
+        if (rc == ICEM_OK) rc = icem_plan_iter_merge(h, b, mpc_step, it, stream);
+    }
+    h->deferral = was;
+    return rc;
 }
 
 int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, void* stream) {

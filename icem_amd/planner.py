@@ -337,6 +337,9 @@ class IcemPlanner:
         st = self._stream()
         if self.cfg.world == 1:
             L.check(self.lib.icem_plan_step(self._h, C.byref(self._cb), self.mpc_step, st))
+        elif getattr(self, "_exchange", False):
+            # in-library exchange: one C call per MPC step, no host-side collective
+            L.check(self.lib.icem_plan_step_sharded(self._h, C.byref(self._cb), self.mpc_step, st))
         else:
             # non-last merges ride in the next iteration's launch (nobody looks at mean / std in between)
             self._set_deferral(True)
@@ -347,6 +350,48 @@ class IcemPlanner:
                 gather()
                 L.check(merge(h, cb, step, it, st))
         self.mpc_step += 1
+
+    # ------------------------------------------------------------------ in-library elite exchange (world > 1)
+    def connect_exchange(self, group=None):
+        """Set up the in-library elite exchange between the ranks' processes (``icem_exchange_create`` /
+        ``icem_exchange_connect``): every rank allocates its exchange block, the 64-byte IPC handles travel ONCE over
+        ``torch.distributed`` (any backend), and from then on an MPC step makes no host-side collective: the records
+        move as peer-to-peer stores issued by the library's own kernels (xGMI between GPUs)."""
+        import torch.distributed as dist
+        self._ensure_buffers()
+        group = self.group if group is None else group
+        mine = (C.c_ubyte * L.IPC_HANDLE_BYTES)()
+        L.check(self.lib.icem_exchange_create(self._h, mine))
+        handles = [None] * self.cfg.world
+        dist.all_gather_object(handles, bytes(mine), group=group)
+        blob = (C.c_ubyte * (L.IPC_HANDLE_BYTES * self.cfg.world)).from_buffer_copy(b"".join(handles))
+        L.check(self.lib.icem_exchange_connect(self._h, blob, None))
+        self._exchange = True
+
+    @staticmethod
+    def connect_exchange_local(planners: Sequence["IcemPlanner"]):
+        """The same for ranks that live in ONE process (tests, several GPUs driven by one host thread): the blocks are
+        handed over as device pointers, no IPC."""
+        for pl in planners:
+            pl._ensure_buffers()
+            scratch = (C.c_ubyte * L.IPC_HANDLE_BYTES)()
+            L.check(pl.lib.icem_exchange_create(pl._h, scratch))
+        blocks = (C.c_void_p * len(planners))(*[pl.lib.icem_exchange_block(pl._h) for pl in planners])
+        for pl in planners:
+            L.check(pl.lib.icem_exchange_connect(pl._h, None, blocks))
+            pl._exchange = True
+
+    def exchange_status(self) -> Tuple[int, bool]:
+        """(status, finegrained): status != 0 means a device-side wait for a peer timed out since the last call."""
+        s, f = C.c_int32(), C.c_int32()
+        L.check(self.lib.icem_exchange_status(self._h, C.byref(s), C.byref(f)))
+        return s.value, bool(f.value)
+
+    def exchange_probe(self, rounds: int = 200) -> float:
+        """Average latency [us] of one in-library exchange (collective: all ranks call it together)."""
+        us = C.c_double()
+        L.check(self.lib.icem_exchange_probe(self._h, rounds, self._stream(), C.byref(us)))
+        return us.value
 
     def _resident_gather(self):
         """The per-iteration all-gather of the bench loop with everything that does not change hoisted out: on RCCL
@@ -436,9 +481,10 @@ class IcemPlanner:
         self.obs0.copy_(torch.as_tensor(np.asarray(obs, dtype=np.float64), dtype=self.dt), non_blocking=False)
         cfg = self.cfg
         st = self._stream()
-        if noise is None and cfg.world == 1 and on_iteration is None:
+        xchg = getattr(self, "_exchange", False)
+        if noise is None and on_iteration is None and (cfg.world == 1 or xchg):
             self._cb.z_r = self._cb.z_i = self._cb.z_r_shift = self._cb.z_i_shift = None
-            L.check(self.lib.icem_plan_step(self._h, C.byref(self._cb), self.mpc_step, st))
+            L.check(self.lib.icem_plan_step_sharded(self._h, C.byref(self._cb), self.mpc_step, st))
         else:
             self._set_deferral(False)  # callers of this form look at the buffers between iterations
             keep = []
@@ -460,7 +506,7 @@ class IcemPlanner:
                         self._cb.z_r_shift = sr.data_ptr()
                         self._cb.z_i_shift = si.data_ptr() if si is not None else None
                 L.check(self.lib.icem_plan_iter_local(self._h, C.byref(self._cb), self.mpc_step, it, st))
-                if cfg.world > 1:
+                if cfg.world > 1 and not xchg:  # (connected exchange: the local call has pushed the records already)
                     exchange_records(self.records, self.K, cfg.rank, cfg.world, self.group)
                 L.check(self.lib.icem_plan_iter_merge(self._h, C.byref(self._cb), self.mpc_step, it, st))
                 if on_iteration is not None:

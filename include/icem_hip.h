@@ -307,6 +307,35 @@ int icem_plan_iter_merge(icem_handle* h, const icem_plan_buffers* b, int32_t mpc
  * buffers are current only after the LAST icem_plan_iter_merge of an MPC step.  Off by default. */
 int icem_set_merge_deferral(icem_handle* h, int32_t on);
 
+/* ---- in-library elite exchange (world > 1) ------------------------------------------------------------------
+ * The all-gather of every rank's K candidate records {cost, gidx, actions[h*d]} before the replicated refit (the
+ * reference's only data parallelism gathers its workers' results over pipes, icem/models/gt_par_model.py:77-94).
+ * Each rank owns an exchange block in its HBM and maps the blocks of all others (HIP IPC); a rank's records reach its
+ * peers as peer-to-peer stores over xGMI from ONE launch behind its local kernels, and every merge waits on flags in
+ * its own block -- no host call and no collective between icem_plan_iter_local and icem_plan_iter_merge.
+ *   1. icem_exchange_create on every rank: allocates the block, returns its IPC handle (ICEM_IPC_HANDLE_BYTES bytes);
+ *   2. the caller moves the handles between the ranks' processes once (any channel: torch.distributed, MPI, a file);
+ *   3. icem_exchange_connect with all `world` handles in rank order.  Ranks living in the CALLER'S process are passed
+ *      as device pointers instead (local_blocks[r] = icem_exchange_block(peer handle); NULL entries use the IPC handle;
+ *      handles_host may be NULL when every peer is local).
+ * From then on icem_plan_iter_local ends with the push and icem_plan_iter_merge reads the gathered records from the
+ * block (b->records then only receives this rank's own K records).  Every device-side wait is bounded (~seconds); a
+ * timeout sets the block's status word, which icem_exchange_status returns and clears (0 = fine). */
+#define ICEM_IPC_HANDLE_BYTES 64
+int icem_exchange_create(icem_handle* h, void* ipc_handle_out_host);
+int icem_exchange_connect(icem_handle* h, const void* handles_host, void* const* local_blocks);
+void* icem_exchange_block(icem_handle* h);
+/* finegrained_host (may be NULL): 1 if the block is fine-grained device memory (what multi-GPU runs want). */
+int icem_exchange_status(icem_handle* h, int32_t* status_host, int32_t* finegrained_host);
+/* Measurement only (collective: every rank calls it at the same time): average latency [us] of one exchange -- this
+ * rank's K records to every rank's block, then the wait for all ranks' -- over `rounds` back-to-back exchanges inside
+ * one launch.  Synchronises the stream. */
+int icem_exchange_probe(icem_handle* h, int32_t rounds, void* stream, double* us_out);
+/* Whole MPC step of one rank of a sharded run (world > 1, exchange connected, device noise): opt_iters x (local launch,
+ * pack + push, merge -- every merge but the last in the next local launch's prologue), no host synchronisation and no
+ * host-side collective.  world == 1: icem_plan_step. */
+int icem_plan_step_sharded(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, void* stream);
+
 /* Whole MPC step for world == 1: opt_iters x (local + merge), no host synchronisation
  * (the body of MpcICem.get_action, icem.py:123-175). */
 int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, void* stream);

@@ -1465,3 +1465,115 @@ def test_config5_fused_rssm_behind_controller():
                        factor_decrease_num=1.25, cost_along_trajectory="sum", dtype="f32", seed=seed, action_sampler_params=asp)
     again.beginning_of_rollout(observation=obs, state=None, mode="train")
     assert np.array_equal(again.get_action(obs, None), a_f)   # deterministic
+
+
+# ---------------------------------------------------------------------------------------------
+# in-library elite exchange (icem_exchange_*, csrc/exchange.hip)
+# ---------------------------------------------------------------------------------------------
+
+def _xchg_planner(rank, world, dtype, N=1000, iters=4, seed=99, kind=1):
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env
+    env = halfcheetah_env(17)
+    model = DeviceSyntheticModel.make(17, 6, kind=kind)
+    pl = IcemPlanner(IcemConfig(horizon=30, act_dim=6, num_traj=N, opt_iters=iters, dtype=dtype, seed=seed, rank=rank, world=world),
+                     env.action_space.low, env.action_space.high)
+    pl.set_model(model.kind, model.A, model.B)
+    pl.set_cost_spec(env.cost_spec)
+    pl.reset()
+    return pl
+
+
+@pytest.mark.parametrize("deferral", [False, True])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("world,N", [(2, 1000), (3, 1000), (8, 1000), (4, 40000), (16, 300)])
+def test_in_library_exchange_emulated_worlds(world, N, dtype, deferral):
+    """All ranks of a sharded run as planners of ONE process, connected through the in-library exchange (blocks handed
+    over as pointers): the records travel by exchange_push_kernel, the merges wait on the flags of their own block --
+    no host copy between icem_plan_iter_local and icem_plan_iter_merge.  Bit-equal to the single-GPU run, with the
+    merges as launches of their own and folded into the next local launch (deferral)."""
+    import ctypes as C
+    from icem_amd import IcemPlanner, _lib as L
+    iters = 4
+    obs_seq = [0.1 * np.random.RandomState(s).randn(17) for s in range(3)]
+    single = _xchg_planner(0, 1, dtype, N, iters)
+    want = [np_(single.plan_step(o)).copy() for o in obs_seq]
+    pls = [_xchg_planner(r, world, dtype, N, iters) for r in range(world)]
+    IcemPlanner.connect_exchange_local(pls)
+    st = pls[0]._stream()
+    for pl in pls:
+        L.check(pl.lib.icem_set_merge_deferral(pl._h, int(deferral)))
+    for s, o in enumerate(obs_seq):
+        for pl in pls:
+            pl.obs0.copy_(torch.as_tensor(o, dtype=pl.dt))
+        for it in range(iters):
+            for pl in pls:  # local launch + pack + push of every rank ...
+                L.check(pl.lib.icem_plan_iter_local(pl._h, C.byref(pl._cb), s, it, st))
+            for pl in pls:  # ... then the merges (or their stashing): they find every rank's records in their own block
+                L.check(pl.lib.icem_plan_iter_merge(pl._h, C.byref(pl._cb), s, it, st))
+        for pl in pls:
+            assert np.array_equal(np_(pl.executed), want[s])
+    for pl in pls:
+        assert np.array_equal(np_(pl.mean), np_(single.mean)) and np.array_equal(np_(pl.std), np_(single.std))
+        assert pl.exchange_status()[0] == 0
+
+
+def _xchg_worker(rank, world, port, out_dir, dtype):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pl = _xchg_planner(rank, world, dtype, 2000, 3, seed=21, kind=0)
+        pl.connect_exchange()
+        acts = []
+        for s in range(3):
+            acts.append(np_(pl.plan_step(0.1 * np.random.RandomState(s).randn(17))).copy())  # icem_plan_step_sharded
+        torch.cuda.synchronize()
+        status, fine = pl.exchange_status()
+        us = pl.exchange_probe(50)
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), acts=np.array(acts), mean=np_(pl.mean), status=status, fine=fine, us=us)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_in_library_exchange_two_processes_ipc(tmp_path, dtype):
+    """The real multi-process path: two processes share this GPU, exchange their IPC handles once over gloo, and run
+    whole MPC steps with icem_plan_step_sharded -- the records move through IPC-mapped peer blocks, the only
+    torch.distributed traffic is the handle exchange at construction.  Every rank ends with the single-process result."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_xchg_worker, args=(2, port, str(tmp_path), dtype), nprocs=2, join=True)
+    pl = _xchg_planner(0, 1, dtype, 2000, 3, seed=21, kind=0)
+    acts = np.array([np_(pl.plan_step(0.1 * np.random.RandomState(s).randn(17))).copy() for s in range(3)])
+    for r in range(2):
+        z = np.load(tmp_path / f"r{r}.npz")
+        assert int(z["status"]) == 0
+        assert np.array_equal(z["acts"], acts)
+        assert np.array_equal(z["mean"], np_(pl.mean))
+        assert 0 < float(z["us"]) < 1e5
+
+
+def test_in_library_exchange_wait_is_bounded(monkeypatch):
+    """A rank whose peer never pushes must not hang the GPU: the device-side wait gives up after its poll budget, sets
+    the block's status word, and the step finishes (with garbage)."""
+    import ctypes as C
+    from icem_amd import IcemPlanner, _lib as L
+    monkeypatch.setenv("ICEM_XCHG_MAX_POLLS", "2000")
+    pls = [_xchg_planner(r, 2, "f32") for r in range(2)]
+    IcemPlanner.connect_exchange_local(pls)
+    pl = pls[0]
+    pl.obs0.copy_(torch.as_tensor(0.1 * np.random.RandomState(0).randn(17), dtype=pl.dt))
+    st = pl._stream()
+    for it in range(pl.cfg.opt_iters):  # rank 1 never runs
+        L.check(pl.lib.icem_plan_iter_local(pl._h, C.byref(pl._cb), 0, it, st))
+        L.check(pl.lib.icem_plan_iter_merge(pl._h, C.byref(pl._cb), 0, it, st))
+    torch.cuda.synchronize()
+    assert pl.exchange_status()[0] == 1
+    assert pl.exchange_status()[0] == 0  # read clears
