@@ -10,13 +10,20 @@ population decay (4096, 3276, 2620, 2096, 1676), K=10, f32.  Workload c4: N=6553
 HumanoidStandup action shapes (N=16384, d=17, beta=2.0, 3 iterations) on a 24-dim tanh latent model.  Workload c5
 (single GPU): the learned-dynamics configuration N=1024, h=12 -- controller-driven steps with the declared RSSM's rollout
 fused on the bf16 matrix cores; its `roofline` is bound "mfma" and its CPU baseline oracle/rssm_oracle.py.
-For --gpus G > 1 (launched by torch.distributed.run, one rank per GPU over RCCL) the per-GPU
-population is fixed (weak scaling): global N = G * N, sharded by global trajectory index, with one
-all-gather of the ranks' K candidate records per CEM iteration.
+For --gpus G > 1 (launched by torch.distributed.run, one rank per GPU) the per-GPU population is fixed (weak
+scaling): global N = G * N, sharded by global trajectory index.  The ranks' K candidate records per CEM iteration
+move through the library's own exchange (icem_exchange_*: IPC-mapped peer blocks, peer-to-peer stores over xGMI,
+flags polled by the merge) -- torch.distributed carries the IPC handles once at set-up and the barriers around the
+timed region, nothing inside it.  The line then also carries the measured exchange latency and, under `also`, the
+N=65536-per-GPU weak-scaling run (the size north_star's multi-GPU target is stated on).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel, from HIP events recorded on
-the launch stream inside the library (icem_profile_*), in a second pass over the same steps;
-`cpu_baseline` times oracle/icem_oracle.c (a plain-C restatement, "port") on the host cores.
+the launch stream inside the library (icem_profile_*), in a second pass over the same steps: SURVEY 8(d)'s HBM
+definition (`bound`/`achieved`/`peak`/`frac`) plus the same launch priced against the f32 vector / matrix peak
+(`compute`) and which of the two roofs is nearer (`binding_roof`).  `cpu_baseline` times oracle/icem_oracle.c (a
+plain-C restatement, "port") on all host cores; `cpu_baselines` adds the NumPy restatement on one thread (what the
+reference's main.py:23 forces) and on the host's default threads, and the C port on one thread.  `build` says which
+sources the loaded library was built from.
 """
 import argparse
 import json
@@ -34,6 +41,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector = f32 matrix peak (they share the pipe)
 
 WORKLOADS = {
     "c2": dict(N=4096, h=30, d=6, o=17, beta=0.25, iters=5, name="HalfCheetah-shaped synthetic, N=4096 h=30 d=6 o=17 beta=0.25, 5 CEM iters"),
@@ -60,6 +68,8 @@ def make_planner(w, rank, world, seed=1234, cost_mode="sum"):
     pl.set_cost(c.ctrl_weight, c.lin_idx, c.lin_weight, c.flip_idx, c.flip_penalty, c.flip_thresh)
     pl.reset()
     pl.obs0.copy_(torch.as_tensor(0.1 * np.random.RandomState(0).randn(w["o"]), dtype=pl.dt))
+    if world > 1 and os.environ.get("ICEM_BENCH_EXCHANGE", "library") == "library":
+        pl.connect_exchange()  # the 64-byte IPC handles travel once; no collective in the timed loop
     return pl, model, env
 
 
@@ -72,6 +82,15 @@ def algorithmic_bytes_per_trajstep(kernel, d, h):
     """the whole loop moves 8d + 8/h bytes per traj-step in f32 (actions written once and
     read once, costs written once and read once).  A kernel is charged its own share of that."""
     return {"sample_clip": 4.0 * d, "rollout_cost": 4.0 * d + 4.0 / h, "sample_rollout": 8.0 * d + 8.0 / h}.get(kernel)
+
+
+def algorithmic_flops_per_trajstep(kernel, d, h, o):
+    """f32 operations the kernel's arithmetic needs per traj-step: rollout = the dense model step 2(o+d)o plus the
+    cost 2d+4; sampler = per (trajectory, dim) row the folded inverse DFT 2(h^2/2 + h) plus Box-Muller / affine / clip
+    ~6h, i.e. d(h + 8) per traj-step.  (The fused kernel does both.)"""
+    roll = 2.0 * (o + d) * o + 2.0 * d + 4.0
+    samp = d * (h + 8.0)
+    return {"sample_clip": samp, "rollout_cost": roll, "sample_rollout": samp + roll}.get(kernel)
 
 
 def cpu_baseline(w, model, env, budget_s=12.0):
@@ -114,6 +133,73 @@ def cpu_baseline(w, model, env, budget_s=12.0):
                       f"{el:.1f} s; oracle/icem_oracle.c, float64, OpenMP over trajectories"}
 
 
+def numpy_baseline_child(workload, budget_s):
+    """(child process) the NumPy restatement of the loop -- oracle/icem_oracle.py: vectorised sample -> clip -> rollout
+    with the same synthetic model -> cost -> argsort[:K] -> refit, float64, np.random's legacy normals like the
+    reference -- on whole MPC steps of the workload until ~budget_s; prints one JSON object."""
+    from oracle import icem_oracle as O
+    from icem_amd import halfcheetah_env, humanoid_standup_env
+    w = WORKLOADS[workload]
+    env = humanoid_standup_env(w["o"]) if w.get("env") == "humanoid" else halfcheetah_env(w["o"])
+    om = O.SyntheticModel.make(w["o"], w["d"], kind=w.get("kind", 0))
+    oc = O.CostSpec.humanoid_standup() if w.get("env") == "humanoid" else O.CostSpec.halfcheetah(w["o"])
+    np.random.seed(0)
+    orc = O.IcemOracle(O.IcemParams(horizon=w["h"], num_simulated_trajectories=w["N"], opt_iterations=w["iters"], noise_beta=w["beta"]),
+                       np.asarray(env.action_space.low, dtype=np.float64), np.asarray(env.action_space.high, dtype=np.float64),
+                       lambda ob, ac: O.rollout_costs(om, oc, ob, ac), lambda num: O.legacy_white_noise(num, w["d"], w["h"]))
+    orc.beginning_of_rollout()
+    obs = 0.1 * np.random.RandomState(0).randn(w["o"])
+    pops = O.population_sizes(w["N"], 10, 1.25, w["iters"])
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        orc.get_action(obs)
+        orc.trace.clear()
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s:
+            break
+    print(json.dumps({"value": reps * sum(pops) * w["h"] / el, "reps": reps, "seconds": el, "traj": sum(pops)}))
+
+
+def extra_cpu_baselines(workload, w, model, env):
+    """the NumPy restatement with OMP_NUM_THREADS=1 (what the reference's main.py:23 forces) and with the
+    host's default threads, and the C port on one thread -- each a bounded sample, in child processes so that the thread
+    counts are really what the label says."""
+    import subprocess
+    out = []
+
+    def child(extra_env, label, cores):
+        e = dict(os.environ)
+        e.update(extra_env)
+        e["HIP_VISIBLE_DEVICES"] = ""
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-numpy-child", workload, "6"], env=e,
+                               capture_output=True, text=True, timeout=180)
+            j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            out.append({"value": j["value"], "unit": "traj-steps/s", "cores": cores, "kind": "port", "what": label,
+                        "sample": f"{j['reps']} MPC step(s) ({j['traj']} trajectories x h={w['h']} each) in {j['seconds']:.1f} s; "
+                                  "oracle/icem_oracle.py, NumPy float64, legacy np.random normals"})
+        except Exception as ex:  # a baseline must never take the GPU numbers down with it
+            out.append({"value": None, "what": label, "error": repr(ex)[:200]})
+    one = {"OMP_NUM_THREADS": "1", "OPENBLAS_NUM_THREADS": "1", "MKL_NUM_THREADS": "1"}
+    child(one, "NumPy restatement, 1 thread (OMP_NUM_THREADS=1 as icem/main.py:23)", 1)
+    child({}, "NumPy restatement, host default threads (BLAS only; the rest of NumPy is single-threaded)", os.cpu_count())
+    try:
+        os.environ["OMP_NUM_THREADS"] = "1"
+        b = None
+        import subprocess as sp
+        r = sp.run([sys.executable, os.path.abspath(__file__), "--cpu-c-child", workload, "5"], env=dict(os.environ, HIP_VISIBLE_DEVICES=""),
+                   capture_output=True, text=True, timeout=180)
+        b = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        b["what"] = "C port (oracle/icem_oracle.c), 1 thread"
+        out.append(b)
+    except Exception as ex:
+        out.append({"value": None, "what": "C port, 1 thread", "error": repr(ex)[:200]})
+    finally:
+        os.environ.pop("OMP_NUM_THREADS", None)
+    return out
+
+
 KERNEL_FAMILY = {"sample_clip": ("sample_folded_kernel", "sample_folded_merge_kernel"), "rollout_cost": ("rollout16_kernel",),
                  "sample_rollout": ("sample_rollout_kernel",)}
 
@@ -144,41 +230,82 @@ def roofline_of(prof, w, workload=None):
     if bpu is None or ms <= 0:
         return None
     achieved = units * bpu / (ms * 1e-3) / 1e9
+    fpu = algorithmic_flops_per_trajstep(dom, w["d"], w["h"], w["o"])
+    tflops = units * fpu / (ms * 1e-3) / 1e12
+    compute = {"achieved": tflops, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / F32_PEAK_TFLOPS,
+               "flops_per_traj_step": fpu, "flops_per_launch": units * fpu / launches,
+               "note": "f32 vector and f32 MFMA share one pipe on gfx950 (155 TF measured): one compute roof"}
     traffic, src, trace_us = measured_traffic(dom, workload) if workload else (None, None, None)
     # avg_launch_us: HIP events around every launch on the launch stream (kernel + its dispatch, ~2.5 us more than the
     # kernel alone); rocprof_trace_avg_us: the committed kernel trace's figure for the same kernels, for comparison
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": src, "kernel": dom, "avg_launch_us": 1e3 * ms / launches,
             "rocprof_trace_avg_us": trace_us, "launches": launches,
-            "algorithmic_bytes_per_launch": units * bpu / launches, "bytes_per_traj_step": bpu}
+            "algorithmic_bytes_per_launch": units * bpu / launches, "bytes_per_traj_step": bpu,
+            "compute": compute, "binding_roof": "f32-alu" if compute["frac"] > achieved / HBM_PEAK_GBS else "hbm"}
 
 
-def measure_also(name, steps=200, warmup=20):
-    """The large-population configuration the north-star roofline target is stated on (N=65536), measured
-    in the same run: whole-loop traj-steps/s, ms per MPC step, dominant-kernel roofline, and the whole
-    loop's algorithmic bytes (8d+8/h per traj-step) over the MPC-step time."""
-    w = WORKLOADS[name]
-    pl, _, _ = make_planner(w, 0, 1)
-    run_steps(pl, warmup, 1)
-    torch.cuda.synchronize()
+def timed_steps(pl, steps, warmup, world):
+    """W untimed steps, then K timed ones between barrier + synchronize pairs; the MAX over ranks."""
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+    run_steps(pl, warmup, world)
+    sync()
     t0 = time.perf_counter()
-    run_steps(pl, steps, 1)
-    torch.cuda.synchronize()
+    run_steps(pl, steps, world)
+    sync()
     el = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    return el
+
+
+def measure_also(name, rank=0, world=1, steps=200, warmup=20):
+    """The large-population configuration the north-star targets are stated on (N=65536 per GPU), measured in the same
+    run (every rank takes part when world > 1: weak scaling at 65536 rows per GPU): whole-loop traj-steps/s, ms per MPC
+    step, dominant-kernel roofline, and the whole loop's algorithmic bytes (8d+8/h per traj-step) over the step time."""
+    w = WORKLOADS[name]
+    pl, _, _ = make_planner(w, rank, world)
+    el = timed_steps(pl, steps, warmup, world)
     pl.profile_enable(True)
-    run_steps(pl, 10, 1)
+    run_steps(pl, 10, world)
     torch.cuda.synchronize()
     prof = pl.profile_read()
     pl.profile_enable(False)
-    ts = sum(pl.population_sizes) * w["h"]
+    ts = sum(pl.population_sizes) * w["h"]  # global
     loop_bytes = ts * (8.0 * w["d"] + 8.0 / w["h"])
-    return {"workload": w["name"], "value": ts * steps / el, "unit": "traj-steps/s", "ms_per_mpc_step": 1e3 * el / steps,
-            "roofline": roofline_of(prof, w, name), "kernels_us": {k: round(1e3 * v[0] / v[1], 2) for k, v in prof.items()},
-            "whole_loop_algorithmic_GBps": loop_bytes * steps / el / 1e9,
-            "whole_loop_frac_of_hbm_peak": loop_bytes * steps / el / 1e9 / HBM_PEAK_GBS}
+    out = {"workload": w["name"], "per_gpu_population": w["N"], "global_population": w["N"] * world, "n_gpus": world,
+           "value": ts * steps / el, "unit": "traj-steps/s", "ms_per_mpc_step": 1e3 * el / steps,
+           "roofline": roofline_of(prof, w, name if world == 1 else None),
+           "kernels_us": {k: round(1e3 * v[0] / v[1], 2) for k, v in prof.items()},
+           "whole_loop_algorithmic_GBps": loop_bytes * steps / el / 1e9,
+           "whole_loop_frac_of_hbm_peak": loop_bytes * steps / el / 1e9 / (HBM_PEAK_GBS * world)}
+    if world > 1:
+        out["exchange"] = exchange_report(pl)
+    return out
 
 
-def run_c5(args, w):
+def exchange_report(pl):
+    """How the ranks' elite records travelled in this run, and what one exchange costs (probe: 200 back-to-back
+    exchanges inside one launch per rank, no launches around them)."""
+    if not getattr(pl, "_exchange", False):
+        return {"kind": "torch.distributed all_gather_into_tensor per CEM iteration (host-driven)", "latency_us": None,
+                "in_library_exchange_error": getattr(pl, "exchange_error", None)}
+    us = pl.exchange_probe(200)
+    status, fine = pl.exchange_status()
+    return {"kind": "in-library: P2P stores into IPC-mapped peer blocks + flags (csrc/exchange.hip)", "latency_us": us,
+            "records_bytes_per_rank": pl.K * (pl.h * pl.d + 2) * 4, "finegrained_block": fine, "timeouts": status,
+            "host_collectives_in_timed_loop": 0}
+
+
+def measure_c5(w, steps, warmup, cpu=True):
     """--workload c5: one step = MpcICemHip.get_action with DeviceRSSMModel (sampling / top-K / refit kernels + one fused
     RSSM rollout launch per CEM iteration); roofline bound = the bf16 matrix cores for the rollout kernel; CPU baseline =
     oracle/rssm_oracle.py (NumPy, float64) on the same populations."""
@@ -192,11 +319,11 @@ def run_c5(args, w):
                                                  fraction_elites_reused=0.3, noise_beta=w["beta"]))
     obs = 0.3 * np.random.RandomState(0).randn(w["o"])
     ctrl.beginning_of_rollout(observation=obs, state=None, mode="train")
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         ctrl.get_action(obs, None)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         ctrl.get_action(obs, None)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -213,7 +340,7 @@ def run_c5(args, w):
         spans.append((e0, e1, a.shape[0]))
         return out
     model.rollout_cost = timed
-    for _ in range(min(args.steps, 50)):
+    for _ in range(min(steps, 50)):
         ctrl.get_action(obs, None)
     torch.cuda.synchronize()
     model.rollout_cost = orig
@@ -224,14 +351,14 @@ def run_c5(args, w):
     roofline = {"bound": "mfma", "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0, "traffic": None,
                 "kernel": "rssm_rollout_kernel", "avg_launch_us": 1e3 * ms / len(spans), "launches": len(spans),
                 "algorithmic_flops_per_traj_step": 2.0 * macs, "dtype": "bf16 operands, f32 accumulation"}
-    out = {"metric": "traj-steps/sec (N x h), iCEM inner planning loop", "value": ts * args.steps / elapsed, "unit": "traj-steps/s",
-           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+    out = {"metric": "traj-steps/sec (N x h), iCEM inner planning loop", "value": ts * steps / elapsed, "unit": "traj-steps/s",
+           "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": w["name"], "per_gpu_population": w["N"], "traj_per_mpc_step": sum(pops),
                       "model": "declared RSSM, random weights (icem_amd.models.declared_rssm)", "cost": "-reward head",
                       "rng": "Philox4x32-10-seeded xoshiro128++ + Box-Muller", "parallelism": "n-shard x1"},
            "roofline": roofline, "cpu_baseline": None}
-    if not args.no_cpu_baseline:
+    if cpu:
         from oracle import rssm_oracle as RO
         P = RO.params_from_state_dict(model.reference.state_dict())
         rs = np.random.RandomState(1)
@@ -245,10 +372,19 @@ def run_c5(args, w):
         out["cpu_baseline"] = {"value": done / el, "unit": "traj-steps/s", "cores": os.cpu_count(), "kind": "port",
                                "sample": f"{reps} MPC step(s) worth of rollouts ({sum(pops)} trajectories x h={w['h']} each) in {el:.1f} s; "
                                          "oracle/rssm_oracle.py, NumPy float64 (BLAS threads as configured on the host)"}
-    print(json.dumps(out), flush=True)
+    return out
 
 
 def main():
+    if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-numpy-child":   # children of extra_cpu_baselines
+        return numpy_baseline_child(sys.argv[2], float(sys.argv[3]))
+    if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-c-child":
+        from icem_amd import DeviceSyntheticModel, halfcheetah_env, humanoid_standup_env
+        w = WORKLOADS[sys.argv[2]]
+        env = humanoid_standup_env(w["o"]) if w.get("env") == "humanoid" else halfcheetah_env(w["o"])
+        model = DeviceSyntheticModel.make(w["o"], w["d"], kind=w.get("kind", 0))
+        print(json.dumps(cpu_baseline(w, model, env, budget_s=float(sys.argv[3]))))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -257,7 +393,7 @@ def main():
     ap.add_argument("--cost-mode", default="sum", choices=["sum", "best", "final"],
                     help="cost_along_trajectory (abstract_controller.py:82-87); the metric is quoted on 'sum'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="skip the extra large-population (c4) measurement")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra measurements (c4 per GPU; c5 on one GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -276,35 +412,25 @@ def main():
                                 **({"device_id": torch.device(f"cuda:{local_rank}")} if backend == "nccl" else {}))
 
     import __graft_entry__ as ge
+    from icem_amd import build as B
+    stale_before = B.build_info()["stale"]
     if rank == 0:
         ge.build()
     if world > 1:
         dist.barrier()
+    build = dict(B.build_info(), rebuilt_in_this_run=bool(stale_before))
 
     w = WORKLOADS[args.workload]
     if args.workload == "c5":
         if world != 1:
             sys.exit("--workload c5 is a single-GPU configuration")
-        return run_c5(args, w)
+        out = measure_c5(w, args.steps, args.warmup, cpu=not args.no_cpu_baseline)
+        out["build"] = build
+        print(json.dumps(out), flush=True)
+        return
     pl, model, env = make_planner(w, rank, world, cost_mode=args.cost_mode)
     per_step_trajsteps = sum(pl.population_sizes) * w["h"]  # global (all ranks) traj-steps per MPC step
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    run_steps(pl, args.warmup, world)
-    sync()
-    t0 = time.perf_counter()
-    run_steps(pl, args.steps, world)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed_steps(pl, args.steps, args.warmup, world)
 
     # second pass: per-kernel durations from HIP events on the launch stream
     pl.profile_enable(True)
@@ -312,6 +438,11 @@ def main():
     torch.cuda.synchronize()
     prof = pl.profile_read()
     pl.profile_enable(False)
+    exchange = exchange_report(pl) if world > 1 else None   # collective: every rank
+    also = None
+    if args.workload == "c2" and not args.no_also:
+        del pl
+        also = measure_also("c4", rank, world)              # collective when world > 1
 
     if rank == 0:
         roofline = roofline_of(prof, w, args.workload if world == 1 else None)
@@ -321,19 +452,29 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": w["name"], "per_gpu_population": w["N"], "global_population": w["N"] * world,
-                       "traj_per_mpc_step": sum(pl.population_sizes),
+                       "traj_per_mpc_step": per_step_trajsteps // w["h"],
                        "model": "o' = tanh(o.A + a.B) dense (synthetic)" if model.kind == 1 else "o' = o.A + a.B dense linear (synthetic)",
                        "cost": "HumanoidStandup cost_fn" if w.get("env") == "humanoid" else "HalfCheetah cost_fn", "cost_along_trajectory": args.cost_mode, "rng": "Philox4x32-10-seeded xoshiro128++ + Box-Muller", "parallelism": f"n-shard x{world}"},
             "ms_per_mpc_step": 1e3 * elapsed / args.steps,
             "roofline": roofline,
             "kernels_us": {k: round(1e3 * v[0] / v[1], 2) for k, v in prof.items()},
+            "build": build,
         }
+        if exchange is not None:
+            out["exchange"] = exchange
         # GPU measurements first: the OpenMP team of the CPU baseline keeps spinning on the host cores for a
         # while after its last parallel region and would slow down kernel launches
+        if also is not None:
+            out["also"] = also
         if world == 1 and args.workload == "c2" and not args.no_also:
-            out["also"] = measure_also("c4")
+            try:   # BASELINE configs[4] in the default run: the learned-dynamics line, GPU part only
+                c5 = measure_c5(WORKLOADS["c5"], 200, 20, cpu=False)
+                out["also_c5"] = {k: c5[k] for k in ("value", "unit", "ms_per_step", "dtype", "config", "roofline")}
+            except Exception as ex:
+                out["also_c5"] = {"error": repr(ex)[:300]}
         if not args.no_cpu_baseline and world == 1 and args.cost_mode == "sum":   # the C oracle's loop reduces by sum
             out["cpu_baseline"] = cpu_baseline(w, model, env)
+            out["cpu_baselines"] = extra_cpu_baselines(args.workload, w, model, env)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

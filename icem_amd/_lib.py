@@ -107,6 +107,7 @@ SYMBOLS = [
     ("icem_exchange_create", C.c_int, [_H, _VP]),
     ("icem_exchange_connect", C.c_int, [_H, _VP, C.POINTER(C.c_void_p)]),
     ("icem_exchange_block", C.c_void_p, [_H]),
+    ("icem_exchange_disable", C.c_int, [_H]),
     ("icem_exchange_status", C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("icem_plan_step_sharded", C.c_int, [_H, C.POINTER(IcemPlanBuffersC), _I32, _VP]),
     ("icem_exchange_probe", C.c_int, [_H, C.c_int32, _VP, C.POINTER(C.c_double)]),

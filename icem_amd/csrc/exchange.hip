@@ -38,6 +38,7 @@ struct Exchange {
     unsigned seq = 0;                            // pushes so far (= sequence number of the last one)
     unsigned probe_seq = 0;
     long long* ticks_dev = nullptr;
+    bool loopback = false;                       // measurement: every "peer" is this rank's own block, waits look at rank 0 only
     unsigned max_polls = XCHG_MAX_POLLS;         // ICEM_XCHG_MAX_POLLS overrides (tests of the timeout path)
     bool connected = false;
 };
@@ -118,7 +119,29 @@ int xchg_push(icem_handle* h, const void* my_records, hipStream_t st, XchgWait* 
     wait_out->flags = reinterpret_cast<const unsigned*>(x->block) + parity * XCHG_MAX_WORLD;
     wait_out->status = reinterpret_cast<unsigned*>(x->block + xchg_status_off());
     wait_out->seq = seq;
-    wait_out->world = world;
+    wait_out->world = x->loopback ? 1 : world;
+    wait_out->max_polls = x->max_polls;
+    wait_out->records = x->block + x->rec_off + (size_t)parity * x->rec_slot;
+    return ICEM_OK;
+}
+
+// the same exchange with the push folded into the caller's own kernel (pack_records_kernel): arguments for it
+int xchg_begin(icem_handle* h, XchgPush* push_out, XchgWait* wait_out) {
+    Exchange* x = h->xchg;
+    if (!x || !x->connected) return fail(ICEM_E_STATE, "icem_exchange_connect has not been called");
+    const int world = h->cfg.world, K = h->cfg.num_elites;
+    const size_t rec_bytes = (size_t)K * (h->hd + 2) * h->tsize;
+    const unsigned seq = ++x->seq;
+    const int parity = (int)(seq & 1u);
+    push_out->peers = x->peers_dev;
+    push_out->rec_byte_off = x->rec_off + (size_t)parity * x->rec_slot + (size_t)h->cfg.rank * rec_bytes;
+    push_out->world = world;
+    push_out->flag_idx = parity * XCHG_MAX_WORLD + h->cfg.rank;
+    push_out->seq = seq;
+    wait_out->flags = reinterpret_cast<const unsigned*>(x->block) + parity * XCHG_MAX_WORLD;
+    wait_out->status = reinterpret_cast<unsigned*>(x->block + xchg_status_off());
+    wait_out->seq = seq;
+    wait_out->world = x->loopback ? 1 : world;
     wait_out->max_polls = x->max_polls;
     wait_out->records = x->block + x->rec_off + (size_t)parity * x->rec_slot;
     return ICEM_OK;
@@ -196,18 +219,29 @@ int icem_exchange_create(icem_handle* h, void* ipc_out_host) {
     return ICEM_OK;
 }
 
+int icem_exchange_disable(icem_handle* h) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (h->pm_pending) return fail(ICEM_E_STATE, "a deferred merge is pending: finish the MPC step first");
+    xchg_destroy(h);
+    return ICEM_OK;
+}
+
 void* icem_exchange_block(icem_handle* h) { return (h && h->xchg) ? h->xchg->block : nullptr; }
 
 int icem_exchange_connect(icem_handle* h, const void* handles_host, void* const* local_blocks) {
     if (check_handle(h)) return ICEM_E_INVALID;
     Exchange* x = h->xchg;
     if (!x) return fail(ICEM_E_STATE, "icem_exchange_create must be called first");
-    if (!handles_host && !local_blocks) return fail(ICEM_E_INVALID, "neither IPC handles nor local block pointers");
+    // ICEM_XCHG_LOOPBACK=1 (tools/sharded_rank_bench.py): time ONE rank of a sharded run without its peers -- every
+    // push lands in this rank's own block and the merges wait for this rank's flag only
+    const char* lb = getenv("ICEM_XCHG_LOOPBACK");
+    x->loopback = lb && atoi(lb) != 0 && h->cfg.rank == 0;
+    if (!handles_host && !local_blocks && !x->loopback) return fail(ICEM_E_INVALID, "neither IPC handles nor local block pointers");
     const int world = h->cfg.world, rank = h->cfg.rank;
     x->peers.assign(world, nullptr);
     x->opened.assign(world, false);
     for (int r = 0; r < world; ++r) {
-        if (r == rank) {
+        if (r == rank || x->loopback) {
             x->peers[r] = x->block;
         } else if (local_blocks && local_blocks[r]) {
             x->peers[r] = (unsigned char*)local_blocks[r];

@@ -202,6 +202,8 @@ const char* cost_indices_error(const icem_handle* h, int o);
 bool xchg_connected(const icem_handle* h);
 // this rank's K records of the running iteration -> every rank's block (one launch); *wait_out: what the merge polls
 int xchg_push(icem_handle* h, const void* my_records, hipStream_t st, XchgWait* wait_out);
+// ... or, where the caller's own kernel does the push (pack_records_kernel): the arguments for it
+int xchg_begin(icem_handle* h, XchgPush* push_out, XchgWait* wait_out);
 void xchg_destroy(icem_handle* h);
 
 // ---- plan.hip: the f32 throughput path ---------------------------------------------------------------------------

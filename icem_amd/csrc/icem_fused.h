@@ -18,6 +18,14 @@ struct XchgWait {
     unsigned max_polls = 0;           // bound of the wait (polls of ~0.5 us); then status = 1 and the wait gives up
     const void* records = nullptr;    // [world * K] gathered records of that parity (handle dtype)
 };
+// ... and what the producer needs to push its K records into every rank's block from inside the pack kernel
+struct XchgPush {
+    unsigned char* const* peers = nullptr;  // [world] device pointers of the ranks' blocks; nullptr: no push
+    size_t rec_byte_off = 0;                // byte offset of this rank's slot (parity applied) inside a block
+    int world = 0;
+    int flag_idx = 0;                       // flag word of (parity, this rank)
+    unsigned seq = 0;
+};
 
 // K1 fast: colored-noise sampling with the inverse real DFT folded on its symmetry (f32, Philox).
 struct FastSampleArgs {
@@ -98,7 +106,11 @@ struct MergeSingleArgs {
 };
 void launch_merge_single(const MergeSingleArgs& a, hipStream_t st);
 // sharded runs: the rank's K best of its candidate lists (part_k / actions / n_lists / n_keep = 0 of `a`) -> records [K, 2 + h*d]
-void launch_pack_records(const MergeSingleArgs& a, int n_loc, int shard_lo, float* records, hipStream_t st);
+// px.peers != nullptr (allowed when pack_can_push): the records also go into every rank's exchange block, followed by the
+// flags -- pack and push in one launch
+bool pack_can_push(int K, int h, int d);
+void launch_pack_records(const MergeSingleArgs& a, int n_loc, int shard_lo, float* records, hipStream_t st,
+                         const XchgPush& px = XchgPush());
 
 // K1 with the previous iteration's merge (last == 0) in its prologue, see sample_folded_merge_kernel
 struct FastSampleMergeArgs {

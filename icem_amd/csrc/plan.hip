@@ -318,12 +318,18 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                 pk.d = c.act_dim;
                 pk.part_k = (const unsigned long long*)b->workspace;
                 pk.actions = (const float*)actions;
+                XchgPush px;  // in-library exchange: the pack kernel pushes the records itself where they fit its LDS
+                const bool fold_push = xchg_connected(h) && pack_can_push(K, c.horizon, c.act_dim);
+                if (fold_push) {
+                    rc = xchg_begin(h, &px, &h->xw_last);
+                    if (rc) return rc;
+                }
                 {
                     ProfScope prof(h, ICEM_K_LOCAL_PACK, lists * K, st);
-                    launch_pack_records(pk, n_loc, lo, (float*)rec, st);
+                    launch_pack_records(pk, n_loc, lo, (float*)rec, st, px);
                 }
                 ICEM_HIP_TRY(hipGetLastError());
-                if (xchg_connected(h)) return xchg_push(h, rec, st, &h->xw_last);
+                if (xchg_connected(h) && !fold_push) return xchg_push(h, rec, st, &h->xw_last);
             }
             ICEM_HIP_TRY(hipGetLastError());
             return ICEM_OK;
@@ -570,7 +576,9 @@ int icem_plan_iter_merge(icem_handle* h, const icem_plan_buffers* b, int32_t mpc
     rc = ensure_pp_stats(h);
     if (rc) return rc;
     const bool last = it == h->cfg.opt_iters - 1;
-    const bool fold = !last && h->fast_lists > 0 && prologue_possible(h, local_rows(h, it + 1));
+    // (the prologue's record selection holds two records per lane: world * K <= 128)
+    const bool fold = !last && h->fast_lists > 0 && h->cfg.world * h->cfg.num_elites <= 128 && h->cfg.num_elites <= 32 &&
+                      prologue_possible(h, local_rows(h, it + 1));
     icem_plan_buffers bb = *b;
     bb.mean = h->cur_mean;
     bb.std = h->cur_std;

@@ -361,12 +361,31 @@ class IcemPlanner:
         self._ensure_buffers()
         group = self.group if group is None else group
         mine = (C.c_ubyte * L.IPC_HANDLE_BYTES)()
-        L.check(self.lib.icem_exchange_create(self._h, mine))
+        err = None
+        try:
+            L.check(self.lib.icem_exchange_create(self._h, mine))
+        except L.IcemError as e:
+            err = e
         handles = [None] * self.cfg.world
-        dist.all_gather_object(handles, bytes(mine), group=group)
-        blob = (C.c_ubyte * (L.IPC_HANDLE_BYTES * self.cfg.world)).from_buffer_copy(b"".join(handles))
-        L.check(self.lib.icem_exchange_connect(self._h, blob, None))
-        self._exchange = True
+        dist.all_gather_object(handles, None if err else bytes(mine), group=group)
+        if err is None and all(hd is not None for hd in handles):
+            blob = (C.c_ubyte * (L.IPC_HANDLE_BYTES * self.cfg.world)).from_buffer_copy(b"".join(handles))
+            try:
+                L.check(self.lib.icem_exchange_connect(self._h, blob, None))
+            except L.IcemError as e:
+                err = e
+        elif err is None:
+            err = L.IcemError(L.ICEM_E_HIP if hasattr(L, "ICEM_E_HIP") else -3, "a peer could not create its exchange block")
+        # all ranks or none: one rank that cannot map its peers sends everybody back to the host-driven all-gather
+        oks = [None] * self.cfg.world
+        dist.all_gather_object(oks, err is None, group=group)
+        if all(oks):
+            self._exchange = True
+            return True
+        self.lib.icem_exchange_disable(self._h)
+        self._exchange = False
+        self.exchange_error = str(err) if err is not None else "a peer failed to connect"
+        return False
 
     @staticmethod
     def connect_exchange_local(planners: Sequence["IcemPlanner"]):

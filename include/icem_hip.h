@@ -325,6 +325,8 @@ int icem_set_merge_deferral(icem_handle* h, int32_t on);
 int icem_exchange_create(icem_handle* h, void* ipc_handle_out_host);
 int icem_exchange_connect(icem_handle* h, const void* handles_host, void* const* local_blocks);
 void* icem_exchange_block(icem_handle* h);
+/* Back to caller-driven exchanges (frees the block, unmaps the peers'): every rank must do the same. */
+int icem_exchange_disable(icem_handle* h);
 /* finegrained_host (may be NULL): 1 if the block is fine-grained device memory (what multi-GPU runs want). */
 int icem_exchange_status(icem_handle* h, int32_t* status_host, int32_t* finegrained_host);
 /* Measurement only (collective: every rank calls it at the same time): average latency [us] of one exchange -- this
