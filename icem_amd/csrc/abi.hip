@@ -162,6 +162,7 @@ int icem_destroy(icem_handle* h) {
     if (h->A_dev) (void)hipFree(h->A_dev);
     if (h->B_dev) (void)hipFree(h->B_dev);
     if (h->Mp_dev) (void)hipFree(h->Mp_dev);
+    if (h->Mw_dev) (void)hipFree(h->Mw_dev);
     if (h->perm_dev) (void)hipFree(h->perm_dev);
     for (auto& sp : h->spans) {
         (void)hipEventDestroy(sp.a);
@@ -188,9 +189,27 @@ int icem_population_sizes(const icem_handle* h, int32_t* out_host) {
 int icem_set_model(icem_handle* h, int32_t kind, int32_t obs_dim, const double* A_host, const double* B_host) {
     if (!h || !A_host || !B_host) return fail(ICEM_E_INVALID, "null argument");
     if (kind != ICEM_MODEL_LINEAR && kind != ICEM_MODEL_TANH) return fail(ICEM_E_INVALID, "model kind");
-    const int O = pick_O(obs_dim);
-    if (obs_dim < 1 || O < 0) return fail(ICEM_E_UNSUPPORTED, "obs_dim must be in [1, 32] for the built-in models");
     const int d = h->cfg.act_dim;
+    if (obs_dim > 32) {
+        // wide observations (HumanoidStandup's real o = 378, mujoco.py:241-252): the f32 GEMM rollout only
+        if (h->cfg.dtype != ICEM_F32 || !wide_rollout_supported(obs_dim, d, 1))
+            return fail(ICEM_E_UNSUPPORTED, "obs_dim in (32, 384] needs dtype f32 (k_rollout_wide); beyond 384 is not compiled");
+        if (h->A_dev) (void)hipFree(h->A_dev);
+        if (h->B_dev) (void)hipFree(h->B_dev);
+        h->A_dev = h->B_dev = nullptr;
+        h->model_kind = kind;
+        h->obs_dim = obs_dim;
+        h->O = 0;
+        h->wide = true;
+        h->has_model = true;
+        h->A_host.assign(A_host, A_host + (size_t)obs_dim * obs_dim);
+        h->B_host.assign(B_host, B_host + (size_t)d * obs_dim);
+        h->fast_model_ready = false;
+        return ICEM_OK;
+    }
+    h->wide = false;
+    const int O = pick_O(obs_dim);
+    if (obs_dim < 1 || O < 0) return fail(ICEM_E_UNSUPPORTED, "obs_dim must be in [1, 384]");
     std::vector<double> A((size_t)O * O, 0.0), B((size_t)d * O, 0.0);
     for (int k = 0; k < obs_dim; ++k)
         for (int i = 0; i < obs_dim; ++i) A[(size_t)k * O + i] = A_host[(size_t)k * obs_dim + i];

@@ -91,6 +91,8 @@ struct icem_handle {
     float* cur_mean = nullptr;
     float* cur_std = nullptr;
     // permuted, padded model of the matrix-pipe rollout: column 0 = obs[lin_idx], column 1 = obs[flip_idx]
+    bool wide = false;           // obs_dim > 32: the rollout is k_rollout_wide.hip's GEMM kernel (f32 only)
+    void* Mw_dev = nullptr;      // its packed model
     void* Mp_dev = nullptr;
     void* perm_dev = nullptr;
     int flip_col = -1;

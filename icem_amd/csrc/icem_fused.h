@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 namespace icem {
 
@@ -73,6 +74,30 @@ bool fast_rollout_supported(int h, int d, int O, int K);
 void launch_rollout16(const FastRolloutArgs& a, int h, int d, int O, int kind, hipStream_t st);
 // workgroups (= candidate lists) the rollout of n_rows trajectories is launched with
 int rollout_lists(int h, int d, int O, int n_rows);
+
+// K2+K3 for wide observations (32 < o <= 384; k_rollout_wide.hip): the model step as an f32 matrix-pipe GEMM per
+// 16-trajectory tile, contraction vectors in LDS; same candidate-list outputs as the kernels above.
+struct WideRolloutArgs {
+    int n_rows, n_cand, K;
+    int o, d, h;
+    int kb, xs;           // contraction blocks of 4, LDS row stride (wide_kb / wide_xs)
+    int cost_mode;
+    int lin_idx, flip_idx;
+    float ctrl_w, lin_w, flip_pen, flip_th;
+    const float* Mp;      // pack_wide_model
+    const float* obs0;
+    const float* actions;
+    float* costs;
+    float* part_c;
+    int* part_i;
+    unsigned long long* part_k;
+};
+bool wide_rollout_supported(int o, int d, int K);
+int wide_rollout_lists(int n_rows);
+int wide_kb(int o, int d);
+int wide_xs(int o, int d);
+void pack_wide_model(int o, int d, const double* A, const double* B, std::vector<float>& Mp);
+void launch_rollout_wide(const WideRolloutArgs& a, int kind, hipStream_t st);
 
 // world == 1: global sorted top-K straight from the waves' candidate lists (+ kept elites), gather of
 // the elite rows from the pool, refit, and the last-iteration epilogue.

@@ -1,0 +1,190 @@
+// k_rollout_wide.hip -- K2 + K3 for WIDE observations (32 < o <= 384, e.g. HumanoidStandup's real o = 378, d = 17:
+// icem/environments/mujoco.py:241-277): rollout_wide_kernel.
+//
+// At this width the model step is a real GEMM: per step [n, o + d] x [o + d, o], 2 (o + d) o = 299 kflop per
+// trajectory-step at o = 378 against 68 bytes of actions -- compute bound by three orders of magnitude (SURVEY
+// 7.3-11), so the kernel is built around keeping the f32 matrix pipe fed, not around HBM:
+//   * one wavefront owns 16 trajectories; their contraction vectors [obs | action | 0-pad] live in the wave's own LDS
+//     rows X[16][XS] (f32; 25.6 KB at o = 378), the new observation of all NT = ceil(o / 16) column tiles in 4 * NT
+//     accumulator registers (96 at o = 378);
+//   * per 4-wide contraction block kb: ONE ds_read of the B operand (X[j][4 kb + g]: trajectory j = lane % 16, slot
+//     g = lane / 16), then NT v_mfma_f32_16x16x4_f32 (exact f32, same fmaf chain as scalar code) on independent
+//     accumulators, their A operands (the 16 x 4 blocks of the model) coming as 16-byte loads from a host-packed copy
+//     of [A ; B] in exactly that order: Mp[kb][ct / 4][lane][ct % 4] = M[4 kb + lane / 16][16 ct + lane % 16] -- 6
+//     coalesced dwordx4 loads per 24 MFMAs, shared by every wave of the chip through L2 (the 608 KB model stays
+//     L2-resident);
+//   * after the last block lane (j, g) holds columns 16 ct + 4 g .. + 3 of trajectory j in accumulator ct: activation,
+//     then one 16-byte LDS store per tile back into X (the wave's LDS traffic executes in order: no barrier);
+//   * the step cost (icem_cost_spec: control cost + linear + flip terms of the PRE-action observation) is read from X
+//     by lanes 0..15; costs and the wave's running sorted top-K as in k_rollout.hip; one candidate list per workgroup.
+// The arithmetic is exact f32, so the tolerance against the float64 oracle is the 1e-5 of every other f32 kernel.
+// A bf16 x 3 split on v_mfma_f32_16x16x32_bf16 (6 products per MAC at 16 x the rate) is the next step for this kernel.
+#include "fused_dev.h"
+
+namespace icem {
+
+namespace {
+
+constexpr int WIDE_WAVES = 4;
+
+template <int NT, int KIND, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void rollout_wide_kernel(WideRolloutArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float xs_all[];  // [WAVES][16][XS]
+    __shared__ unsigned long long wg_keys[2][WAVES][32];
+    constexpr int NQ = NT / 4;  // 16-byte model loads per contraction block
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int XS = a.xs, KB = a.kb, o = a.o, d = a.d, H = a.h;
+    float* X = xs_all + (size_t)wave * 16 * XS;
+    const float4* __restrict__ Mp = reinterpret_cast<const float4*>(a.Mp);
+    const float ksum = a.cost_mode == 0 ? 1.f : 0.f;  // sum: acc = acc + c; final: acc = c
+    const bool use_min = a.cost_mode == 1;
+    unsigned long long run_key = KEY_SENTINEL;
+    bool first = true;
+    const int tiles = (a.n_rows + 15) / 16;
+    for (int tile = wave * gridDim.x + blockIdx.x; tile < tiles; tile += WAVES * gridDim.x) {
+        const int row0 = tile * 16;
+        // contraction vectors: the start observation in every row, zeros behind
+        for (int e = lane; e < 16 * XS; e += 64) {
+            const int c = e % XS;
+            X[e] = c < o ? a.obs0[c] : 0.f;
+        }
+        float acc_s = 0.f, acc_b = INFINITY;
+        for (int t = 0; t < H; ++t) {
+            // this step's actions -> X[:, o .. o + d)
+            for (int e = lane; e < 16 * d; e += 64) {
+                const int r = e / d, c = e - r * d;
+                const int row = row0 + r;
+                X[r * XS + o + c] = row < a.n_rows ? a.actions[((size_t)row * H + t) * d + c] : 0.f;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < 16) {  // step cost of trajectory `lane` from the pre-action observation
+                const float* x = X + lane * XS;
+                float c = 0.f;
+                if (a.flip_idx >= 0) {
+                    const float ang = x[a.flip_idx];
+                    c += (ang > a.flip_th) ? a.flip_pen : 0.f;
+                    c += (ang < -a.flip_th) ? a.flip_pen : 0.f;
+                }
+                float u = 0.f;
+                for (int e = 0; e < d; ++e) u = __builtin_fmaf(x[o + e], x[o + e], u);
+                c = __builtin_fmaf(u, a.ctrl_w, c);
+                if (a.lin_w != 0.f) c = __builtin_fmaf(a.lin_w, x[a.lin_idx], c);  // a zero weight drops the term (icem_cost_spec)
+                acc_s = __builtin_fmaf(acc_s, ksum, c);
+                acc_b = c < acc_b ? c : acc_b;
+            }
+            f32x4 acc[NT];
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* xb = X + j * XS + g;
+            // model blocks one contraction block ahead of the MFMAs that consume them
+            float4 mcur[NQ], mnxt[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) mcur[q] = Mp[(size_t)q * 64 + lane];
+            float b = xb[0];
+#pragma unroll 1
+            for (int kb = 0; kb < KB; ++kb) {
+                const int kn = kb + 1 < KB ? kb + 1 : kb;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) mnxt[q] = Mp[((size_t)kn * NQ + q) * 64 + lane];
+                const float bn = xb[4 * kn];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    acc[4 * q + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(mcur[q].x, b, acc[4 * q + 0], 0, 0, 0);
+                    acc[4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(mcur[q].y, b, acc[4 * q + 1], 0, 0, 0);
+                    acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(mcur[q].z, b, acc[4 * q + 2], 0, 0, 0);
+                    acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(mcur[q].w, b, acc[4 * q + 3], 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) mcur[q] = mnxt[q];
+                b = bn;
+            }
+            // new observation: lane (j, g) holds columns 16 ct + 4 g .. + 3 of trajectory j (columns >= o: the model's
+            // zero padding, they stay 0 for the linear model and tanh(0) = 0)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+                f32x4 v = acc[ct];
+                if (KIND == 1) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = fast_tanh(v[k]);
+                }
+                const int col = 16 * ct + 4 * g;
+                if (col < o) *reinterpret_cast<f32x4*>(X + j * XS + col) = v;
+            }
+            // (a last column group that straddles o also zeroes the first action slots: they are reloaded next step)
+        }
+        const float cost = use_min ? acc_b : acc_s;
+        const int row = row0 + (lane & 15);
+        const bool live = row < a.n_rows;
+        if (live && lane < 16) a.costs[row] = cost;
+        if (a.K > 0) {
+            const unsigned long long key = (lane < 16 && live && row < a.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
+            run_key = topk_push16(run_key, key, first, a.K, lane);
+            first = false;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (a.K > 0) {
+        FastRolloutArgs fr{};  // wg_merge_emit only looks at the candidate outputs
+        fr.part_k = a.part_k;
+        fr.part_c = a.part_c;
+        fr.part_i = a.part_i;
+        wg_merge_emit<WAVES>(wg_keys, run_key, a.K, lane, wave, fr);
+    }
+}
+
+}  // namespace
+
+bool wide_rollout_supported(int o, int d, int K) { return o > 32 && o <= 384 && d >= 1 && d <= 64 && K <= 32; }
+
+int wide_rollout_lists(int n_rows) { return std::min(std::max(1, (n_rows + 15) / 16), FAST_MAX_LISTS); }
+
+// contraction rows of the packed model: [obs (o) | act (d)] padded to whole 4-blocks; X row stride in floats
+int wide_kb(int o, int d) { return (o + d + 3) / 4; }
+int wide_xs(int o, int d) { return 4 * wide_kb(o, d) + 4; }
+int wide_nt(int o) { const int nt = (o + 15) / 16; return nt <= 4 ? 4 : nt <= 8 ? 8 : nt <= 16 ? 16 : 24; }
+
+// Mp[kb][q][lane][v] = M[4 kb + lane / 16][16 (4 q + v) + lane % 16], M = [A ; B] ([o + d, o], zero padded)
+void pack_wide_model(int o, int d, const double* A, const double* B, std::vector<float>& Mp) {
+    const int KB = wide_kb(o, d), NT = wide_nt(o), NQ = NT / 4;
+    Mp.assign((size_t)KB * NQ * 64 * 4, 0.f);
+    auto M = [&](int r, int c) -> double {
+        if (c >= o) return 0.0;
+        if (r < o) return A[(size_t)r * o + c];
+        if (r < o + d) return B[(size_t)(r - o) * o + c];
+        return 0.0;
+    };
+    for (int kb = 0; kb < KB; ++kb)
+        for (int q = 0; q < NQ; ++q)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int v = 0; v < 4; ++v)
+                    Mp[(((size_t)kb * NQ + q) * 64 + lane) * 4 + v] = (float)M(4 * kb + lane / 16, 16 * (4 * q + v) + lane % 16);
+}
+
+void launch_rollout_wide(const WideRolloutArgs& a, int kind, hipStream_t st) {
+    const int grid = wide_rollout_lists(a.n_rows);
+    const size_t lds = (size_t)WIDE_WAVES * 16 * a.xs * sizeof(float);
+    const int NT = wide_nt(a.o);
+#define XW(NTV)                                                                                                       \
+    if (NT == NTV) {                                                                                                  \
+        if (kind == 1) {                                                                                              \
+            auto kfn = rollout_wide_kernel<NTV, 1, WIDE_WAVES>;                                                       \
+            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * WIDE_WAVES), lds, st, a);                                   \
+        } else {                                                                                                      \
+            auto kfn = rollout_wide_kernel<NTV, 0, WIDE_WAVES>;                                                       \
+            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * WIDE_WAVES), lds, st, a);                                   \
+        }                                                                                                             \
+        return;                                                                                                       \
+    }
+    XW(4) XW(8) XW(16) XW(24)
+#undef XW
+}
+
+}  // namespace icem

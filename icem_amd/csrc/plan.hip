@@ -24,6 +24,15 @@ namespace icem {
 // term reads column 0 and the flip term column 0 or 1 -- static registers in the kernel.
 int ensure_fast_model(icem_handle* h) {
     if (h->fast_model_ready) return ICEM_OK;
+    if (h->wide) {  // wide observations: the model packed in MFMA operand order (k_rollout_wide.hip)
+        std::vector<float> Mw;
+        pack_wide_model(h->obs_dim, h->cfg.act_dim, h->A_host.data(), h->B_host.data(), Mw);
+        if (h->Mw_dev) (void)hipFree(h->Mw_dev);
+        ICEM_HIP_TRY(hipMalloc(&h->Mw_dev, Mw.size() * sizeof(float)));
+        ICEM_HIP_TRY(hipMemcpy(h->Mw_dev, Mw.data(), Mw.size() * sizeof(float), hipMemcpyHostToDevice));
+        h->fast_model_ready = true;
+        return ICEM_OK;
+    }
     const int O = h->O, o = h->obs_dim, d = h->cfg.act_dim;
     // layout of Tile16 (icem_fused.hip): O <= 20 -> one 16-column matrix-pipe tile + extra columns, Mp [O + d + 1, ceil4(O)];
     // O > 20 -> two tiles, observation block padded to 32 rows / columns, Mp [32 + d + 1, 32]
@@ -65,7 +74,9 @@ int ensure_fast_model(icem_handle* h) {
 
 bool fast_rollout_ok(const icem_handle* h, int K) {
     if (h->has_terms) return false;  // the extra cost terms live in the general kernel
-    if (h->cost.lin_weight == 0.0) return false;  // ... and so does a cost without the linear term (dropped, not 0 * obs)
+    if (h->cost.lin_weight == 0.0 && !h->wide) return false;  // ... and so does a cost without the linear term (dropped, not 0 * obs)
+    if (h->wide)  // (the only rollout there is at this width: ICEM_DISABLE_FAST does not apply)
+        return h->cfg.dtype == ICEM_F32 && h->has_model && h->has_cost && wide_rollout_supported(h->obs_dim, h->cfg.act_dim, K);
     return h->use_fast && h->cfg.dtype == ICEM_F32 && h->has_model && h->has_cost &&
            fast_rollout_supported(h->cfg.horizon, h->cfg.act_dim, h->O, K);
 }
@@ -101,6 +112,38 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
                         unsigned long long* part_k) {
     int rc = ensure_fast_model(h);
     if (rc) return rc;
+    if (h->wide) {
+        WideRolloutArgs w{};
+        w.n_rows = n_rows;
+        w.n_cand = n_cand;
+        w.K = K;
+        w.o = h->obs_dim;
+        w.d = h->cfg.act_dim;
+        w.h = h->cfg.horizon;
+        w.kb = wide_kb(w.o, w.d);
+        w.xs = wide_xs(w.o, w.d);
+        w.cost_mode = h->cfg.cost_mode;
+        w.lin_idx = h->cost.lin_idx;
+        w.flip_idx = h->cost.flip_idx;
+        w.ctrl_w = (float)h->cost.ctrl_weight;
+        w.lin_w = (float)h->cost.lin_weight;
+        w.flip_pen = (float)h->cost.flip_penalty;
+        w.flip_th = (float)h->cost.flip_thresh;
+        w.Mp = (const float*)h->Mw_dev;
+        w.obs0 = (const float*)obs0;
+        w.actions = (const float*)actions;
+        w.costs = (float*)costs;
+        w.part_c = part_c;
+        w.part_i = part_i;
+        w.part_k = part_k;
+        {
+            ProfScope prof(h, ICEM_K_ROLLOUT, (long long)n_rows * h->cfg.horizon, st);
+            launch_rollout_wide(w, h->model_kind, st);
+        }
+        ICEM_HIP_TRY(hipGetLastError());
+        if (lists_out) *lists_out = wide_rollout_lists(n_rows);
+        return ICEM_OK;
+    }
     FastRolloutArgs a = fast_rollout_args(h, n_rows, n_cand, K, obs0, actions, costs, part_c, part_i);
     a.part_k = part_k;
     const int grid = rollout_lists(h->cfg.horizon, h->cfg.act_dim, h->O, n_rows);

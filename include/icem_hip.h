@@ -48,7 +48,7 @@ enum {
 
 #define ICEM_MAX_HORIZON 64
 #define ICEM_MAX_ACT_DIM 64
-#define ICEM_MAX_OBS_DIM 64
+#define ICEM_MAX_OBS_DIM 384
 #define ICEM_MAX_ELITES 64
 
 /* Constructor kwargs of MpcICem (icem.py:213-233, mpc.py:22, abstract_controller.py:64-65). */
@@ -165,7 +165,10 @@ int icem_noise_tables_host(int32_t horizon, double beta, double* cr_host, double
 
 /* Built-in batched forward model o' = act(o.A + a.B) (the `predict` contract of
  * models/abstract_models.py:17-26).  A [obs_dim, obs_dim], B [act_dim, obs_dim] are HOST float64
- * arrays; they are converted to the handle dtype and copied to the device.  `kind` = ICEM_MODEL_*. */
+ * arrays; they are converted to the handle dtype and copied to the device.  `kind` = ICEM_MODEL_*.
+ * obs_dim <= 32: every kernel family (f32 / f64).  32 < obs_dim <= 384 (HumanoidStandup's o = 378,
+ * environments/mujoco.py:241-252): dtype f32 only, the model step runs as an exact-f32 GEMM on the matrix pipe
+ * (icem_rollout_cost without `observations`, icem_plan_*); cost = icem_set_cost's form, no icem_set_cost_terms. */
 int icem_set_model(icem_handle* h, int32_t kind, int32_t obs_dim, const double* A_host, const double* B_host);
 int icem_set_cost(icem_handle* h, const icem_cost_spec* spec);
 /* Extra cost terms (NULL switches them off again).  With any of them on, icem_rollout_cost / icem_plan_* evaluate

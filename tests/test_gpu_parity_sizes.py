@@ -83,6 +83,8 @@ CASES = [
     pytest.param(65536, 5, 30, 6, 17, 0, 0.25, "halfcheetah", 1234, id="c4_N65536x5"),
     # BASELINE configs[2] (latent o=24): 17 action dims, beta = 2
     pytest.param(16384, 3, 30, 17, 24, 1, 2.0, "humanoid", 1234, id="c3_N16384x3_d17_beta2"),
+    # HumanoidStandup at its REAL observation width (icem/environments/mujoco.py:241-252): the GEMM rollout kernel
+    pytest.param(2048, 2, 30, 17, 378, 1, 2.0, "humanoid", 5, id="c3wide_o378_N2048x2"),
 ]
 
 
@@ -208,6 +210,34 @@ def test_humanoid_standup_cost_at_real_observation_width():
                                          torch.as_tensor(act, dtype=pl.dt, device=pl.device)))
             ref = {"sum": want.sum(1), "best": want.min(1), "final": want[:, -1]}[mode]
             np.testing.assert_allclose(got, ref, **t)
+
+
+@pytest.mark.parametrize("o,d,h,kind,mode,n", [(378, 17, 30, 0, "sum", 300), (378, 17, 30, 1, "sum", 100), (100, 6, 12, 1, "best", 1000),
+                                              (33, 4, 13, 0, "final", 77), (64, 6, 30, 1, "sum", 129), (384, 17, 30, 0, "sum", 40),
+                                              (200, 3, 10, 1, "sum", 4097)])
+def test_wide_observation_rollout_matches_oracle(o, d, h, kind, mode, n):
+    """rollout_wide_kernel (k_rollout_wide.hip): the model step at observation widths 33..384 as an exact-f32 GEMM on
+    the matrix pipe, against the float64 oracle rollout (predict_n_steps + trajectory_cost_fn,
+    icem/models/abstract_models.py:17-53, icem/controllers/abstract_controller.py:74-91) at 1e-5; o = 378, d = 17 is
+    HumanoidStandup's real shape (icem/environments/mujoco.py:241-277)."""
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner
+    model = DeviceSyntheticModel.make(o, d, kind=kind)
+    lo, hi = -0.4 * np.ones(d), 0.4 * np.ones(d)
+    pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=max(n, 4), elites_size=2, opt_iters=1, cost_mode=mode, dtype="f32"), lo, hi)
+    pl.set_model(model.kind, model.A, model.B)
+    flip_idx = 1 if kind == 0 else -1
+    pl.set_cost(0.1, 2, -1.0, flip_idx, 10.0, 0.05)
+    oc = O.CostSpec(0.1, 2, -1.0, flip_idx, 10.0, 0.05)
+    rs = np.random.RandomState(o + n)
+    obs = 0.1 * rs.randn(o)
+    act = rs.uniform(-0.4, 0.4, (n, h, d)).astype(np.float32)
+    got = np_(pl.rollout_cost(obs, torch.as_tensor(act, device=pl.device)))
+    want = O.rollout_costs(O.SyntheticModel(model.A, model.B, model.kind), oc, obs, act.astype(np.float64), mode=mode)
+    bad = np.abs(got - want) > 1e-5 * np.abs(want) + 2e-5
+    # a flip indicator may land on the other side of its threshold in f32: allow a handful of whole-penalty differences
+    assert bad.sum() <= (2 if flip_idx >= 0 else 0), (bad.sum(), np.abs(got - want).max())
+    if bad.any():
+        assert np.allclose(np.abs(got - want)[bad] % 10.0, 0.0, atol=1e-3) or np.allclose(np.abs(got - want)[bad] % 10.0, 10.0, atol=1e-3)
 
 
 @pytest.mark.soak

@@ -60,3 +60,42 @@ json.dump({name: {"read_bytes_per_launch": v[0] / v[2], "write_bytes_per_launch"
                   "trace_avg_duration_ns": (dur[name][0] / dur[name][1]) if dur[name][1] else None}
            for name, v in fam.items() if v[2]}, open(dst + "_hbm_traffic.json", "w"), indent=1)
 print(open(dst + "_hbm_traffic.md").read())
+
+# instruction mix: SQ counters of the two extra passes, per kernel family and launch (sums over all SEs / XCDs)
+SQ = {}
+for sub, stem in (("pmc_sq1", "s1"), ("pmc_sq2", "s2")):
+    path = os.path.join(src, sub, stem + "_counter_collection.csv")
+    if not os.path.exists(path):
+        continue
+    for row in csv.DictReader(open(path)):
+        nm = row["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").replace("icem::", "")
+        name = nm.split("<")[0].split("(")[0]
+        if "kernel" not in name:
+            continue
+        d = SQ.setdefault(name, defaultdict(lambda: [0.0, 0]))
+        d[row["Counter_Name"]][0] += float(row["Counter_Value"])
+        d[row["Counter_Name"]][1] += 1
+if SQ:
+    cols = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_INSTS_VALU_MFMA_MOPS_F32",
+            "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY",
+            "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_VALU_MFMA_BUSY_CYCLES"]
+    table = {name: {c: (d[c][0] / d[c][1] if d[c][1] else None) for c in cols} for name, d in SQ.items()}
+    for name, t in table.items():
+        w = t.get("SQ_WAVES") or 0
+        t["valu_per_wave"] = (t["SQ_INSTS_VALU"] / w) if w and t.get("SQ_INSTS_VALU") else None
+        t["salu_per_wave"] = (t["SQ_INSTS_SALU"] / w) if w and t.get("SQ_INSTS_SALU") else None
+        wc = t.get("SQ_WAVE_CYCLES") or 0
+        # SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_* count quad-cycles summed over waves (MI355X_MICROARCH.md)
+        t["frac_wave_cycles_issuing_valu"] = (t["SQ_ACTIVE_INST_VALU"] / wc) if wc and t.get("SQ_ACTIVE_INST_VALU") else None
+        t["frac_wave_cycles_issue_stalled"] = (t["SQ_WAIT_INST_ANY"] / wc) if wc and t.get("SQ_WAIT_INST_ANY") else None
+        t["frac_wave_cycles_parked"] = (t["SQ_WAIT_ANY"] / wc) if wc and t.get("SQ_WAIT_ANY") else None
+    json.dump(table, open(dst + "_instruction_mix.json", "w"), indent=1)
+    with open(dst + "_instruction_mix.md", "w") as f:
+        f.write("# Instruction mix per launch (rocprofv3 --pmc, SQ block, two passes; sums over the chip)\n\n")
+        f.write("| kernel | waves | VALU / wave | SALU / wave | SMEM | LDS | MFMA f32 MOPS | VALU-issuing share of wave cycles | issue-stalled | parked (waitcnt / barrier) | MFMA-busy cycles |\n|---|---|---|---|---|---|---|---|---|---|---|\n")
+        fmt = lambda v, p=0: "-" if v is None else (f"{v:.{p}f}")  # noqa: E731
+        for name, t in sorted(table.items()):
+            f.write(f"| `{name}` | {fmt(t['SQ_WAVES'])} | {fmt(t['valu_per_wave'])} | {fmt(t['salu_per_wave'])} | {fmt(t['SQ_INSTS_SMEM'])} | {fmt(t['SQ_INSTS_LDS'])} | "
+                    f"{fmt(t['SQ_INSTS_VALU_MFMA_MOPS_F32'])} | {fmt(t['frac_wave_cycles_issuing_valu'], 3)} | {fmt(t['frac_wave_cycles_issue_stalled'], 3)} | "
+                    f"{fmt(t['frac_wave_cycles_parked'], 3)} | {fmt(t['SQ_VALU_MFMA_BUSY_CYCLES'])} |\n")
+    print(open(dst + "_instruction_mix.md").read())
