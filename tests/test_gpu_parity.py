@@ -1517,14 +1517,14 @@ def test_in_library_exchange_emulated_worlds(world, N, dtype, deferral):
         assert pl.exchange_status()[0] == 0
 
 
-def _xchg_worker(rank, world, port, out_dir, dtype):
+def _xchg_worker(rank, world, port, out_dir, dtype, N=2000):
     import os
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        pl = _xchg_planner(rank, world, dtype, 2000, 3, seed=21, kind=0)
+        pl = _xchg_planner(rank, world, dtype, N, 3, seed=21, kind=0)
         pl.connect_exchange()
         acts = []
         for s in range(3):
@@ -1538,19 +1538,20 @@ def _xchg_worker(rank, world, port, out_dir, dtype):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f64"])
-def test_in_library_exchange_two_processes_ipc(tmp_path, dtype):
+@pytest.mark.parametrize("dtype,N", [("f32", 2000), ("f64", 2000), ("f32", 40000)])
+def test_in_library_exchange_two_processes_ipc(tmp_path, dtype, N):
     """The real multi-process path: two processes share this GPU, exchange their IPC handles once over gloo, and run
     whole MPC steps with icem_plan_step_sharded -- the records move through IPC-mapped peer blocks, the only
-    torch.distributed traffic is the handle exchange at construction.  Every rank ends with the single-process result."""
+    torch.distributed traffic is the handle exchange at construction (slab kernel at N = 2000, two-kernel path at
+    N = 40000).  Every rank ends with the single-process result."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_xchg_worker, args=(2, port, str(tmp_path), dtype), nprocs=2, join=True)
-    pl = _xchg_planner(0, 1, dtype, 2000, 3, seed=21, kind=0)
+    mp.spawn(_xchg_worker, args=(2, port, str(tmp_path), dtype, N), nprocs=2, join=True)
+    pl = _xchg_planner(0, 1, dtype, N, 3, seed=21, kind=0)
     acts = np.array([np_(pl.plan_step(0.1 * np.random.RandomState(s).randn(17))).copy() for s in range(3)])
     for r in range(2):
         z = np.load(tmp_path / f"r{r}.npz")
