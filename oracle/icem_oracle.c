@@ -161,7 +161,7 @@ void icem_c_rollout_cost(int n, int h, int d, int o, int kind, int mode, const d
                          int flip_idx, double flip_pen, double flip_th, double* costs) {
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < n; ++i) {
-        double obs[256], nxt[256];
+        double obs[512], nxt[512];  /* o <= 512 (HumanoidStandup: 378) */
         memcpy(obs, obs0, sizeof(double) * o);
         double acc = 0.0;
         for (int t = 0; t < h; ++t) {
