@@ -80,27 +80,39 @@ __global__ __launch_bounds__(64 * WAVES) void rollout_wide_kernel(WideRolloutArg
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
             const float* xb = X + j * XS + g;
-            // model blocks one contraction block ahead of the MFMAs that consume them
-            float4 mcur[NQ], mnxt[NQ];
+            // model blocks are requested ahead of the MFMAs that consume them: named register sets, the loop unrolled,
+            // and scheduling barriers so that the requests stay where they are written (left alone the compiler sinks
+            // them next to their first use and every block pays an L2 round trip: 2.19 instead of 1.70 ms per launch)
+            float4 mA[NQ], mB[NQ];
+            float bA, bB;
+            auto request = [&](float4 (&m)[NQ], float& b, int kb) {
+                kb = kb < KB ? kb : KB - 1;
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) mcur[q] = Mp[(size_t)q * 64 + lane];
-            float b = xb[0];
-#pragma unroll 1
-            for (int kb = 0; kb < KB; ++kb) {
-                const int kn = kb + 1 < KB ? kb + 1 : kb;
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) mnxt[q] = Mp[((size_t)kn * NQ + q) * 64 + lane];
-                const float bn = xb[4 * kn];
+                for (int q = 0; q < NQ; ++q) m[q] = Mp[((size_t)kb * NQ + q) * 64 + lane];
+                b = xb[4 * kb];
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto block = [&](const float4 (&m)[NQ], float b) {
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    acc[4 * q + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(mcur[q].x, b, acc[4 * q + 0], 0, 0, 0);
-                    acc[4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(mcur[q].y, b, acc[4 * q + 1], 0, 0, 0);
-                    acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(mcur[q].z, b, acc[4 * q + 2], 0, 0, 0);
-                    acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(mcur[q].w, b, acc[4 * q + 3], 0, 0, 0);
+                    acc[4 * q + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(m[q].x, b, acc[4 * q + 0], 0, 0, 0);
+                    acc[4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(m[q].y, b, acc[4 * q + 1], 0, 0, 0);
+                    acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(m[q].z, b, acc[4 * q + 2], 0, 0, 0);
+                    acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(m[q].w, b, acc[4 * q + 3], 0, 0, 0);
                 }
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) mcur[q] = mnxt[q];
-                b = bn;
+            };
+            // one block in flight ahead of the one being multiplied (two register sets, the loop unrolled by two; two
+            // blocks ahead with three sets measured slower: 1.90 ms)
+            request(mA, bA, 0);
+#pragma unroll 1
+            for (int kb = 0; kb < KB; kb += 2) {
+                request(mB, bB, kb + 1);
+                block(mA, bA);
+                if (kb + 1 < KB) {
+                    request(mA, bA, kb + 2);
+                    block(mB, bB);
+                }
             }
             // new observation: lane (j, g) holds columns 16 ct + 4 g .. + 3 of trajectory j (columns >= o: the model's
             // zero padding, they stay 0 for the linear model and tanh(0) = 0)
