@@ -113,6 +113,49 @@ __device__ __forceinline__ unsigned long long wave_sort64(unsigned long long k, 
     return k;
 }
 
+// the same network on 32-bit keys (half the moves): used where only the ORDER STATISTIC of the keys' cost halves matters
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned x) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, false);
+}
+template <int J>
+__device__ __forceinline__ unsigned xor_partner32(unsigned k, int lane) {
+    if constexpr (J == 1) {
+        return dpp_u32<0xB1>(k);
+    } else if constexpr (J == 2) {
+        return dpp_u32<0x4E>(k);
+    } else if constexpr (J == 4) {
+        const unsigned up = dpp_u32<0x12C>(k), down = dpp_u32<0x124>(k);
+        return (lane & 4) ? down : up;
+    } else if constexpr (J == 8) {
+        return dpp_u32<0x128>(k);
+    } else if constexpr (J == 16) {
+        auto l = __builtin_amdgcn_permlane16_swap(k, k, false, false);
+        return (lane & 16) ? l[0] : l[1];
+    } else {
+        static_assert(J == 32, "xor distance");
+        auto l = __builtin_amdgcn_permlane32_swap(k, k, false, false);
+        return (lane & 32) ? l[0] : l[1];
+    }
+}
+template <int SIZE, int J>
+__device__ __forceinline__ unsigned bitonic_merge32(unsigned k, int lane) {
+    const unsigned o = xor_partner32<J>(k, lane);
+    const bool take_min = ((lane & SIZE) == 0) == ((lane & J) == 0);
+    k = (take_min == (o < k)) ? o : k;
+    if constexpr (J > 1) k = bitonic_merge32<SIZE, J / 2>(k, lane);
+    return k;
+}
+__device__ __forceinline__ unsigned wave_sort64_u32(unsigned k, int lane) {
+    k = bitonic_merge32<2, 1>(k, lane);
+    k = bitonic_merge32<4, 2>(k, lane);
+    k = bitonic_merge32<8, 4>(k, lane);
+    k = bitonic_merge32<16, 8>(k, lane);
+    k = bitonic_merge32<32, 16>(k, lane);
+    k = bitonic_merge32<64, 32>(k, lane);
+    return k;
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // -------------------------------------------------------------------------------------------------
@@ -545,31 +588,35 @@ __device__ __forceinline__ void merge_select(const MergeSingleArgs& a, int lane,
             v = t;
         }
     }
-    // selection by threshold: the K-th smallest of the 64 lane minima bounds the K-th smallest key overall,
-    // so the global top-K is among the keys <= T; those (usually K..2K of them) are compacted into one key
-    // per lane and sorted.  Two 64-key sorts instead of K dependent tournament rounds.
+    // selection by threshold: the K-th smallest of the 64 lane minima bounds the K-th smallest key overall, so the
+    // global top-K is among the keys <= T; those (usually K..2K of them) are compacted into one key per lane and
+    // sorted.  The threshold only needs the minima's COST halves (32-bit sort; keys that tie with T in cost all
+    // survive), and every list is sorted, so a list's survivors are a prefix: the compaction walks the lists depth
+    // by depth and stops at the first depth without a survivor (usually the second).
     if (a.dbg && threadIdx.x == 0) a.dbg[2] = wall_clock64();
     unsigned long long mine = k[0][0];
 #pragma unroll
     for (int l = 1; l < LPL; ++l) mine = k[l][0] < mine ? k[l][0] : mine;
-    const unsigned long long srt = wave_sort64(mine, lane);
-    const unsigned long long T = __shfl(srt, a.K - 1, 64);
-    // compaction: every lane counts its keys <= T, an exclusive DPP scan over the lanes gives it a slot range
-    unsigned mine_n = 0;
+    const unsigned srt = wave_sort64_u32((unsigned)(mine >> 32), lane);
+    const unsigned T = __shfl(srt, a.K - 1, 64);
+    unsigned n_cand = 0;  // wave-uniform
 #pragma unroll
-    for (int l = 0; l < LPL; ++l)
+    for (int i = 0; i < KREG; ++i) {
+        bool p[LPL];
+        bool any_lane = false;
 #pragma unroll
-        for (int i = 0; i < KREG; ++i) mine_n += (k[l][i] <= T && k[l][i] != KEY_SENTINEL) ? 1u : 0u;
-    const unsigned incl = wave_incl_scan_u32(mine_n);
-    const unsigned n_cand = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-    unsigned pos = incl - mine_n;
+        for (int l = 0; l < LPL; ++l) {
+            p[l] = (unsigned)(k[l][i] >> 32) <= T && k[l][i] != KEY_SENTINEL;
+            any_lane |= p[l];
+        }
+        if (__ballot(any_lane) == 0) break;
 #pragma unroll
-    for (int l = 0; l < LPL; ++l) {
-#pragma unroll
-        for (int i = 0; i < KREG; ++i) {
-            if (k[l][i] <= T && k[l][i] != KEY_SENTINEL) {
-                if (pos < 64) cand[pos] = k[l][i];
-                ++pos;
+        for (int l = 0; l < LPL; ++l) {
+            const unsigned long long m = __ballot(p[l]);
+            if (m != 0) {
+                const unsigned pos = n_cand + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                if (p[l] && pos < 64) cand[pos] = k[l][i];
+                n_cand += (unsigned)__popcll(m);
             }
         }
     }
