@@ -224,6 +224,91 @@ __device__ __forceinline__ void sample_row(const float* __restrict__ W, unsigned
     row_synth<H>(W, g, emit, white);
 }
 
+// ---- one row on FOUR lanes (small populations) ---------------------------------------------------------------------
+// With fewer rows than lanes on the chip a row's ~1700 instructions are a latency chain (a lone wave issues one
+// instruction per ~5 cycles).  Here the four lanes of a quad share one (trajectory, dim) row: every lane runs the row's
+// word stream (the generator is serial), transforms only ITS Box-Muller pairs (pair 4k + q in group k), the quad
+// exchanges the draws through DPP quad broadcasts, and each lane synthesises a quarter of the outputs (t = 0 on lane 3,
+// the symmetric pairs tp = q + 1, q + 5, ... on lane q) with its table rows read from an LDS copy (per-lane row, so no
+// scalar loads).  Same operations per draw and per output as row_normals / row_synth: same bits.
+constexpr int WQ_STRIDE = HMAX + 4;  // floats per table row in LDS: the four rows a quad reads land in different banks
+
+template <int JQ>
+__device__ __forceinline__ float quad_bcast(float x) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), JQ * 0x55, 0xF, 0xF, false));
+}
+
+template <int H, int ROUNDS>
+__device__ __forceinline__ void row_normals_quad(unsigned gi, unsigned j, unsigned off_lo, unsigned off_hi, unsigned seed_lo,
+                                                 unsigned seed_hi, int q, float (&g)[HMAX]) {
+    constexpr int NP = (H + 1) / 2, NG = (NP + 3) / 4;
+    Xoshiro128pp rng = row_stream<ROUNDS>(gi, j, off_lo, off_hi, seed_lo, seed_hi);
+    float ga[NG], gb[NG];
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        uint32_t xa = 0, xb = 0;
+#pragma unroll
+        for (int jq = 0; jq < 4; ++jq) {
+            if (4 * k + jq < NP) {
+                const uint32_t wa = rng.next();
+                const uint32_t wb = rng.next();
+                xa = q == jq ? wa : xa;
+                xb = q == jq ? wb : xb;
+            }
+        }
+        box_muller(xa, xb, ga[k], gb[k]);  // (a lane without a pair in the last group transforms (0, 0): finite, unused)
+    }
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+#define ICEM_QB(JQ)                                                        \
+    if (4 * k + JQ < NP) {                                                 \
+        g[2 * (4 * k + JQ)] = quad_bcast<JQ>(ga[k]);                       \
+        if (2 * (4 * k + JQ) + 1 < HMAX) g[2 * (4 * k + JQ) + 1] = quad_bcast<JQ>(gb[k]); \
+    }
+        ICEM_QB(0) ICEM_QB(1) ICEM_QB(2) ICEM_QB(3)
+#undef ICEM_QB
+    }
+}
+
+// Wl: rows 0 .. H/2 of the synthesis table in LDS, WQ_STRIDE floats apart
+template <int H, typename Emit>
+__device__ __forceinline__ void row_synth_quad(const float* Wl, const float (&g)[HMAX], int q, Emit&& emit, bool white) {
+    constexpr int F = H / 2 + 1;
+    if (white) {  // wave-uniform: the draws are the samples (icem.py:77)
+#pragma unroll
+        for (int t = 0; t < H; ++t)
+            if ((t & 3) == q) emit(t, g[t]);
+        return;
+    }
+    if (q == 3) {  // t = 0: every sine is zero
+        float e0 = 0.f, e1 = 0.f;
+#pragma unroll
+        for (int m = 0; m < F; m += 2) {
+            e0 = __builtin_fmaf(g[m], Wl[m], e0);
+            if (m + 1 < F) e1 = __builtin_fmaf(g[m + 1], Wl[m + 1], e1);
+        }
+        emit(0, e0 + e1);
+    }
+#pragma unroll 1
+    for (int tp = q + 1; tp <= H / 2; tp += 4) {
+        const float* w = Wl + tp * WQ_STRIDE;
+        float e0 = 0.f, e1 = 0.f, o0 = 0.f, o1 = 0.f;
+#pragma unroll
+        for (int m = 0; m < F; m += 2) {
+            e0 = __builtin_fmaf(g[m], w[m], e0);
+            if (m + 1 < F) e1 = __builtin_fmaf(g[m + 1], w[m + 1], e1);
+        }
+#pragma unroll
+        for (int m = F; m < H; m += 2) {
+            o0 = __builtin_fmaf(g[m], w[m], o0);
+            if (m + 1 < H) o1 = __builtin_fmaf(g[m + 1], w[m + 1], o1);
+        }
+        const float e = e0 + e1, od = o0 + o1;
+        emit(tp, e + od);
+        if (H - tp != tp) emit(H - tp, e - od);
+    }
+}
+
 __device__ __forceinline__ float act_fn(float x, std::integral_constant<int, 0>) { return x; }
 // tanh in ~14 instructions (libm's tanhf is ~40, and a tanh model spends most of its step there): 1 - 2 / (e^2x + 1)
 // on the hardware exp2 / rcp, which loses relative accuracy near 0 to cancellation, so |x| < 0.1 takes the odd
@@ -832,6 +917,41 @@ __device__ __forceinline__ void sample_into_tile(const FastSampleArgs& sa, int n
         trow[(H - 1) * D] = last;
     } else {
         for (int t = 0; t < H; ++t) trow[t * D] = 0.f;  // past the end: rolled out, dropped
+    }
+}
+
+// sample_into_tile with the row on a quad of lanes (q = lane & 3), table from LDS (row_synth_quad)
+template <int H, int D, int ROUNDS, bool RAW>
+__device__ __forceinline__ void sample_into_tile_quad(const FastSampleArgs& sa, int n_rows, int r_mine, int jd, int q, float* trow,
+                                                      const float* mrow, const float* Wl) {
+    constexpr int HD = H * D;
+    float g[HMAX];
+    if (r_mine < sa.n) {
+        row_normals_quad<H, ROUNDS>((unsigned)(sa.first_index + r_mine), (unsigned)jd, sa.off_lo, sa.off_hi, sa.seed_lo, sa.seed_hi, q, g);
+        if (RAW) {
+            row_synth_quad<H>(Wl, g, q, [&](int t, float y) { trow[t * D] = y; }, sa.white != 0);
+        } else {
+            const float lo = sa.low[jd], hi = sa.high[jd];
+            row_synth_quad<H>(Wl, g, q, [&](int t, float y) {
+                const float v = __builtin_fmaf(y, mrow[HD + t * D], mrow[t * D]);
+                trow[t * D] = __builtin_amdgcn_fmed3f(v, lo, hi);
+            }, sa.white != 0);
+        }
+    } else if (r_mine < n_rows && !RAW) {
+        // shifted elite e (icem.py:91-104): elites[e, 1:, j] and a last action from stream off2 (only t = h-1 is used)
+        const int e = r_mine - sa.n;
+        const float lo = sa.low[jd], hi = sa.high[jd];
+        row_normals_quad<H, ROUNDS>((unsigned)e, (unsigned)jd, sa.off2_lo, sa.off2_hi, sa.seed_lo, sa.seed_hi, q, g);
+        row_synth_quad<H>(Wl, g, q, [&](int t, float y) {
+            if (t == H - 1) {
+                const float v = __builtin_fmaf(y, mrow[HD + t * D], mrow[t * D]);
+                trow[(H - 1) * D] = __builtin_amdgcn_fmed3f(v, lo, hi);
+            }
+        }, sa.white != 0);
+        const float* src = sa.elites_src + (size_t)e * HD + jd;
+        for (int t = q; t < H - 1; t += 4) trow[t * D] = src[(t + 1) * D];
+    } else {
+        for (int t = q; t < H; t += 4) trow[t * D] = 0.f;  // past the end: rolled out, dropped
     }
 }
 

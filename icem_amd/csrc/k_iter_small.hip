@@ -24,14 +24,20 @@ namespace {
 // the host / the next launch.  That removes the merge launch and hides its latency behind the sampling.  The
 // previous pool, lists and distribution are read while this launch writes new ones: all three are ping-pong
 // buffers (icem_plan_step).
+// QS ("quad sampling", RW <= 2): four lanes per (trajectory, dim) row (row_normals_quad / row_synth_quad): with at most
+// two tiles per CU the sampling phase is one thread's instruction chain, and a quarter of it is ~2.4x shorter.
+constexpr bool sr_quad(int d, int rw) { return rw <= 2 && ((4 * 16 * rw * d + 63) / 64) * 64 + 64 <= 1024; }
+constexpr int sr_threads(int d, int rw) { return (((sr_quad(d, rw) ? 4 : 1) * 16 * rw * d + 63) / 64) * 64; }
+
 template <int H, int D, int O, int KIND, int ROUNDS, int RW, int KREG, bool REC>
-__global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64 + (KREG > 0 ? 64 : 0)) void sample_rollout_kernel(FastIterArgs a) {
+__global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sample_rollout_kernel(FastIterArgs a) {
     using Tile = Tile16<H, D, O, KIND>;
     constexpr bool PM = KREG > 0;
+    constexpr bool QS = sr_quad(D, RW);
     constexpr int HD = H * D;
     constexpr int TPB = 16 * RW;                     // trajectories per workgroup
-    constexpr int ROWS = TPB * D;                    // (trajectory, dim) rows, one thread each
-    constexpr int NT = ((ROWS + 63) / 64) * 64;      // sampling threads
+    constexpr int ROWS = TPB * D;                    // (trajectory, dim) rows: one thread (QS: one quad) each
+    constexpr int NT = sr_threads(D, RW);            // sampling threads
     constexpr int NTT = NT + (PM ? 64 : 0);          // + the selection wavefront
     static_assert(NTT <= 1024 && HD % 2 == 0, "workgroup shape");
     constexpr int VW = HD % 4 == 0 ? 4 : 2;  // floats per vector of the tile -> HBM copy (rows are 4 * HD bytes)
@@ -40,6 +46,7 @@ __global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64 + (KREG > 0 ? 64 : 0
     __shared__ __attribute__((aligned(16))) float tilebuf[Tile::SLACK + TPB * HD + Tile::TAIL];
     __shared__ unsigned long long wg_keys[2][RW][32];
     __shared__ float obs_stage[32];
+    __shared__ __attribute__((aligned(16))) float Wl[QS ? (H / 2 + 1) * WQ_STRIDE : 4];  // QS: the synthesis table rows 0 .. H/2
     __shared__ unsigned long long sel[PM ? 64 : 1];
     __shared__ unsigned long long cand[PM ? 64 : 1];
     __shared__ int slot[PM ? 64 : 1];
@@ -55,12 +62,17 @@ __global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64 + (KREG > 0 ? 64 : 0
     if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[8] = wall_clock64();
     // Order matters at this size: kernel arguments arrive through serialized scalar loads, so everything the RNG
     // chain does not need (start observation, model operands, bounds) is fetched AFTER the sampling got going.
-    const int nl = tid / D, jd = tid - nl * D;
-    const bool has_row = tid < ROWS;
+    const int rowi = QS ? tid >> 2 : tid, q = tid & 3;  // QS: lane q of the row's quad
+    const int nl = rowi / D, jd = rowi - nl * D;
+    const bool has_row = rowi < ROWS;
     float* trow = tile_rows + nl * HD + jd;
     const float* mrow = ms + jd;
     Tile tile;
     float obs_reg = 0.f;
+    if constexpr (QS) {
+        for (int e = tid; e < (H / 2 + 1) * HMAX; e += NTT) Wl[(e / HMAX) * WQ_STRIDE + (e % HMAX)] = sa.W[e];
+        if (PM) __syncthreads();
+    }
     if (!PM) {  // iteration 0 of an MPC step: the distribution is in memory; the model operands ride the same wait
         obs_reg = ra.obs0[(tid < 32 && tid < ra.o) ? tid : 0];
         if (wave < RW) tile.load(ra, lane);
@@ -72,7 +84,12 @@ __global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64 + (KREG > 0 ? 64 : 0
     }
     if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[9] = wall_clock64();
     const int r_mine = base + nl;
-    if (has_row) sample_into_tile<H, D, ROUNDS, PM>(sa, n_rows, r_mine, jd, trow, mrow);
+    if (has_row) {
+        if constexpr (QS)
+            sample_into_tile_quad<H, D, ROUNDS, PM>(sa, n_rows, r_mine, jd, q, trow, mrow, Wl);
+        else
+            sample_into_tile<H, D, ROUNDS, PM>(sa, n_rows, r_mine, jd, trow, mrow);
+    }
     if constexpr (PM) {
         if (tid >= NT) {
             if constexpr (REC)
@@ -114,7 +131,7 @@ __global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64 + (KREG > 0 ? 64 : 0
         __syncthreads();
         if (has_row && r_mine < sa.n) {  // y * std + mean, clipped (icem.py:79)
             const float lo = sa.low[jd], hi = sa.high[jd];
-            for (int t = 0; t < H; ++t) {
+            for (int t = QS ? q : 0; t < H; t += QS ? 4 : 1) {
                 const float v = __builtin_fmaf(trow[t * D], mrow[HD + t * D], mrow[t * D]);
                 trow[t * D] = __builtin_amdgcn_fmed3f(v, lo, hi);
             }
@@ -156,7 +173,7 @@ __global__ __launch_bounds__(((16 * RW * D + 63) / 64) * 64 + (KREG > 0 ? 64 : 0
 constexpr int single_launch_max_rw(int h, int d) {
     int best = 0;
     for (int rw = 1; rw <= 8; rw *= 2)
-        if (((16 * rw * d + 63) / 64) * 64 + 64 <= 1024 && 16 * rw * h * d * 4 <= 120 * 1024) best = rw;
+        if (sr_threads(d, rw) + 64 <= 1024 && 16 * rw * h * d * 4 <= 120 * 1024) best = rw;
     return best;
 }
 
@@ -196,7 +213,7 @@ void launch_sample_rollout(const FastIterArgs& a, int h, int d, int O, int kind,
     if (!sample_rollout_shape(h, d, O, 10, a.r.n_rows, &grid, &rw)) return;
 #define XK(HH, DD, OO, WW, KR, RC)                                                                                      \
     {                                                                                                                   \
-        constexpr int NT = ((16 * WW * DD + 63) / 64) * 64 + (KR > 0 ? 64 : 0);                                         \
+        constexpr int NT = sr_threads(DD, WW) + (KR > 0 ? 64 : 0);                                                     \
         if (kind == 1)                                                                                                  \
             hipLaunchKernelGGL((sample_rollout_kernel<HH, DD, OO, 1, 10, WW, KR, RC>), dim3(grid), dim3(NT), 0, st, a); \
         else                                                                                                            \
