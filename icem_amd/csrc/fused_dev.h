@@ -551,6 +551,167 @@ struct Tile16 {
     }
 };
 
+// ---- Tile4: the same model step on the VALU, FOUR trajectories per wavefront ----------------------------------------
+// For small populations (fewer 16-trajectory tiles than SIMDs) the rollout is a latency chain, and Tile16's chain is
+// long: six DEPENDENT f32 MFMAs per step (40 cycles each) plus ~35 VALU for a lone wave = ~410 cycles.  Here a row of
+// 16 lanes is one trajectory and lane c holds observation column c: the contraction is 24 v_fmac_f32 whose x operand
+// arrives through the DPP row broadcast (v_fmac_f32_dpp ... row_newbcast:k: no move, no LDS), ~60 instructions per
+// step, and four wavefronts share a tile's work.  An f32 MFMA is bitwise an fmaf chain over its four slots, so the SAME
+// chain in the same order (k = 4g + s for s = 0..3, g = 0..3, then the extra entries) gives the SAME bits as Tile16:
+// costs, elites and every downstream buffer are identical whichever tile shape a launch uses (tested).  O <= 20.
+template <int K>
+__device__ __forceinline__ float fmac_row_bcast(float acc, float x, float m) {
+    // acc += x[lane K of this row of 16] * m   (fused)
+    asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(m), "n"(K));
+    return acc;
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float x) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), CTRL, 0xF, 0xF, false));
+}
+// (x_g + x_{g^2}) + (x_{g^1} + x_{g^3}) over the four quads g of a row -- Tile16's reduce_groups association
+// (floating-point addition commutes bitwise) -- the result in every lane of the row
+__device__ __forceinline__ float reduce_quads(float x) {
+    const float s = x + dpp_f32<0x128>(x);  // row_ror:8
+    return s + dpp_f32<0x124>(s);           // row_ror:4
+}
+
+template <int H, int D, int O, int KIND>
+struct Tile4 {
+    using T16 = Tile16<H, D, O, KIND>;
+    static_assert(T16::NT == 1, "one 16-column tile (O <= 20)");
+    static constexpr int REM = T16::REM, NKX = T16::NKX, NX = T16::NX, CT4 = T16::CT4, OP = T16::OP, ZROW = T16::ZROW;
+    static constexpr int NE = 4 * NKX;     // extra contraction entries incl. padding (columns >= 16, then the actions)
+    float mK[16];                          // M[k][c] for the 16 tile columns k, this lane's output column c
+    float mE[NE];                          // M[row(e)][c] for the extra entries
+    float wq[REM > 0 ? REM : 1][4];        // M[4g + s][16 + r]: this quad's share of extra output column r
+    float wx[REM > 0 ? REM : 1][NKX];      // M[row(4q + g)][16 + r]
+    float cw[NKX];
+    bool is_act[NKX];
+    float x_init, rem_init[REM > 0 ? REM : 1];
+    int perm_c, perm_rem[REM > 0 ? REM : 1];
+    float pen, lin_w, ksum, flip_th;
+    bool ang_is_col1, use_min;
+    int g, c;
+
+    static __device__ __forceinline__ int entry_row(int e) { return e >= NX ? ZROW : (e < REM ? 16 + e : OP + (e - REM)); }
+
+    __device__ __forceinline__ void load(const FastRolloutArgs& a, int lane) {
+        c = lane & 15;
+        g = c >> 2;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) mK[k] = a.Mp[k * CT4 + c];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) mE[e] = a.Mp[entry_row(e) * CT4 + c];
+#pragma unroll
+        for (int r = 0; r < REM; ++r) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) wq[r][s] = a.Mp[(4 * g + s) * CT4 + 16 + r];
+#pragma unroll
+            for (int q = 0; q < NKX; ++q) wx[r][q] = a.Mp[entry_row(4 * q + g) * CT4 + 16 + r];
+        }
+#pragma unroll
+        for (int q = 0; q < NKX; ++q) {
+            const int e = 4 * q + g;
+            is_act[q] = e < NX && e >= REM;
+            cw[q] = is_act[q] ? a.ctrl_w : 0.f;
+        }
+        perm_c = a.perm[c];
+#pragma unroll
+        for (int r = 0; r < REM; ++r) perm_rem[r] = a.perm[16 + r];
+        pen = (a.flip_col >= 0 && g == 0) ? a.flip_pen : 0.f;
+        lin_w = g == 0 ? a.lin_w : 0.f;
+        ang_is_col1 = a.flip_col == 1;
+        ksum = a.cost_mode == 0 ? 1.f : 0.f;
+        use_min = a.cost_mode == 1;
+        flip_th = a.flip_th;
+    }
+    __device__ __forceinline__ void load_obs(const float* obs) {
+        x_init = obs[perm_c];
+#pragma unroll
+        for (int r = 0; r < REM; ++r) rem_init[r] = obs[perm_rem[r]];
+    }
+    // this lane's read pointer for its quad's extra entries (entry 4q + g at rd[4q], as Tile16::read_ptr) and the
+    // trajectory's action row; row = the trajectory's row in an LDS tile of `stride` floats per trajectory
+    __device__ __forceinline__ const float* read_ptr(const float* buf, int row, int stride) const {
+        return buf + T16::SLACK + row * stride + (g - REM);
+    }
+    __device__ __forceinline__ const float* row_ptr(const float* buf, int row, int stride) const {
+        return buf + T16::SLACK + row * stride;
+    }
+    struct State {
+        float x;
+        float xr[REM > 0 ? REM : 1];
+        float acc_s, acc_b;
+    };
+    __device__ __forceinline__ void init(State& st) const {
+        st.x = x_init;
+#pragma unroll
+        for (int r = 0; r < REM; ++r) st.xr[r] = rem_init[r];
+        st.acc_s = 0.f;
+        st.acc_b = INFINITY;
+    }
+    // rd: this quad's entries of the step (rd[4q]); ar: the trajectory's D actions of the step
+    __device__ __forceinline__ void step(State& st, const float* rd, const float* ar) const {
+        float xv[NKX];
+#pragma unroll
+        for (int q = 0; q < NKX; ++q) {
+            const float ld = rd[4 * q];
+            float v = is_act[q] ? ld : 0.f;
+#pragma unroll
+            for (int r = 0; r < REM; ++r)
+                if (r / 4 == q) v = (g == r % 4) ? st.xr[r] : v;
+            xv[q] = v;
+        }
+        float ext[NE];  // the extra entries in contraction order, the same in every lane of the row
+#pragma unroll
+        for (int e = 0; e < NE; ++e) ext[e] = e < REM ? st.xr[e] : (e - REM < D ? ar[e - REM] : 0.f);
+        // step cost: this quad's share (the columns 4g .. 4g+3 live in the quad's four lanes), then the sum over quads
+        const float col0 = dpp_f32<0x00>(st.x);  // quad_perm [0,0,0,0]: column 4g
+        const float col1 = dpp_f32<0x55>(st.x);  // quad_perm [1,1,1,1]: column 4g + 1
+        const float ang = ang_is_col1 ? col1 : col0;
+        float cst = 0.f;
+        cst += (ang > flip_th) ? pen : 0.f;
+        cst += (ang < -flip_th) ? pen : 0.f;
+#pragma unroll
+        for (int q = 0; q < NKX; ++q) cst = __builtin_fmaf(xv[q] * xv[q], cw[q], cst);
+        cst = __builtin_fmaf(lin_w, col0, cst);
+        float pr[REM > 0 ? REM : 1];
+        if (REM > 0) {
+            const float col2 = dpp_f32<0xAA>(st.x), col3 = dpp_f32<0xFF>(st.x);
+            const float cq[4] = {col0, col1, col2, col3};
+#pragma unroll
+            for (int r = 0; r < REM; ++r) {
+                float p = 0.f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) p = __builtin_fmaf(cq[s], wq[r][s], p);
+#pragma unroll
+                for (int q = 0; q < NKX; ++q) p = __builtin_fmaf(xv[q], wx[r][q], p);
+                pr[r] = reduce_quads(p);
+            }
+        }
+        cst = reduce_quads(cst);
+        st.acc_s = __builtin_fmaf(st.acc_s, ksum, cst);
+        st.acc_b = cst < st.acc_b ? cst : st.acc_b;
+        // model step: one fmaf chain per output column in the matrix pipe's order: MFMA s (s = 0..3) contracts slots
+        // g = 0..3 = columns 4g + s; then the MFMAs of the extra entries
+        float nxt = 0.f;
+        asm volatile("s_nop 1" ::: "memory");  // st.x was written by VALU: keep the DPP read two slots behind it
+#define ICEM_T4(K) nxt = fmac_row_bcast<K>(nxt, st.x, mK[K]);
+        ICEM_T4(0) ICEM_T4(4) ICEM_T4(8) ICEM_T4(12)
+        ICEM_T4(1) ICEM_T4(5) ICEM_T4(9) ICEM_T4(13)
+        ICEM_T4(2) ICEM_T4(6) ICEM_T4(10) ICEM_T4(14)
+        ICEM_T4(3) ICEM_T4(7) ICEM_T4(11) ICEM_T4(15)
+#undef ICEM_T4
+#pragma unroll
+        for (int e = 0; e < NE; ++e) nxt = __builtin_fmaf(mE[e], ext[e], nxt);
+        st.x = act_fn(nxt, std::integral_constant<int, KIND>{});
+#pragma unroll
+        for (int r = 0; r < REM; ++r) st.xr[r] = act_fn(pr[r], std::integral_constant<int, KIND>{});
+    }
+    __device__ __forceinline__ float cost(const State& st) const { return use_min ? st.acc_b : st.acc_s; }
+};
+
 // a tile's 16 keys (lanes 0..15, the rest sentinels) join the wave's running sorted top-K: lanes 16..16+K-1 carry
 // the running list, one sort
 __device__ __forceinline__ unsigned long long topk_push16(unsigned long long run_key, unsigned long long key, bool first,

@@ -31,9 +31,15 @@ constexpr int sr_threads(int d, int rw) { return (((sr_quad(d, rw) ? 4 : 1) * 16
 
 template <int H, int D, int O, int KIND, int ROUNDS, int RW, int KREG, bool REC>
 __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sample_rollout_kernel(FastIterArgs a) {
-    using Tile = Tile16<H, D, O, KIND>;
     constexpr bool PM = KREG > 0;
     constexpr bool QS = sr_quad(D, RW);
+    // T4: with quad sampling there are >= 4 * RW wavefronts in the workgroup anyway: the rollout runs on Tile4 (VALU +
+    // DPP row broadcast, four trajectories per wave, 4 * RW waves) instead of Tile16 (RW waves): same bits, a shorter
+    // latency chain per model step
+    constexpr bool T4 = QS && O <= 20 && sr_threads(D, RW) >= 256 * RW;
+    using T16 = Tile16<H, D, O, KIND>;
+    using Tile = typename std::conditional<T4, Tile4<H, D, (O <= 20 ? O : 17), KIND>, T16>::type;
+    constexpr int RWV = T4 ? 4 * RW : RW;            // rollout wavefronts
     constexpr int HD = H * D;
     constexpr int TPB = 16 * RW;                     // trajectories per workgroup
     constexpr int ROWS = TPB * D;                    // (trajectory, dim) rows: one thread (QS: one quad) each
@@ -43,14 +49,14 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
     constexpr int VW = HD % 4 == 0 ? 4 : 2;  // floats per vector of the tile -> HBM copy (rows are 4 * HD bytes)
     using Vec = typename VecOf<VW>::type;
     __shared__ __attribute__((aligned(16))) float ms[2 * HD];  // mean | std
-    __shared__ __attribute__((aligned(16))) float tilebuf[Tile::SLACK + TPB * HD + Tile::TAIL];
+    __shared__ __attribute__((aligned(16))) float tilebuf[T16::SLACK + TPB * HD + T16::TAIL];
     __shared__ unsigned long long wg_keys[2][RW][32];
     __shared__ float obs_stage[32];
     __shared__ __attribute__((aligned(16))) float Wl[QS ? (H / 2 + 1) * WQ_STRIDE : 4];  // QS: the synthesis table rows 0 .. H/2
     __shared__ unsigned long long sel[PM ? 64 : 1];
     __shared__ unsigned long long cand[PM ? 64 : 1];
     __shared__ int slot[PM ? 64 : 1];
-    float* tile_rows = tilebuf + Tile::SLACK;
+    float* tile_rows = tilebuf + T16::SLACK;
     const FastSampleArgs& sa = a.s;
     const FastRolloutArgs& ra = a.r;
     const int tid = threadIdx.x;
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
     }
     if (!PM) {  // iteration 0 of an MPC step: the distribution is in memory; the model operands ride the same wait
         obs_reg = ra.obs0[(tid < 32 && tid < ra.o) ? tid : 0];
-        if (wave < RW) tile.load(ra, lane);
+        if (wave < RWV) tile.load(ra, lane);
         for (int e = tid; e < HD; e += NTT) {
             ms[e] = sa.mean[e];
             ms[HD + e] = sa.std[e];
@@ -102,9 +108,10 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
     }
     if (PM) {  // now the rest of the inputs: in flight across the barriers below
         obs_reg = ra.obs0[(tid < 32 && tid < ra.o) ? tid : 0];
-        if (wave < RW) tile.load(ra, lane);
+        if (wave < RWV) tile.load(ra, lane);
     }
-    const float* rd0 = tile.read_ptr(tilebuf + (wave < RW ? wave : 0) * 16 * HD, lane, HD);
+    const float* rd0 = nullptr;
+    if constexpr (!T4) rd0 = tile.read_ptr(tilebuf + (wave < RW ? wave : 0) * 16 * HD, lane, HD);
     if constexpr (PM) {
         const MergeSingleArgs& m = a.m;
         __syncthreads();
@@ -156,13 +163,49 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
     }
     if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[11] = wall_clock64();
     unsigned long long run_key = KEY_SENTINEL;
-    if (wave < RW) {
-        tile.load_obs(obs_stage);
-        run_key = rollout_slab<Tile, H, D>(tile, ra, rd0, base + wave * 16 + (lane & 15), n_rows, run_key, true, lane);
-        if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[12] = wall_clock64();
+    if constexpr (T4) {
+        // four trajectories per wave: row `wave * 4 + lane / 16` of the slab, lane % 16 = observation column
+        if (wave < RWV) {
+            tile.load_obs(obs_stage);
+            const int rs = wave * 4 + (lane >> 4);  // trajectory of this row of lanes inside the slab
+            const int row = base + rs;
+            const float* rd = tile.read_ptr(tilebuf, rs, HD);
+            const float* ar = tile.row_ptr(tilebuf, rs, HD);
+            typename Tile::State st;
+            tile.init(st);
+#pragma unroll
+            for (int t = 0; t < H; ++t) tile.step(st, rd + t * D, ar + t * D);
+            const float cost = tile.cost(st);
+            const bool live = row < n_rows;
+            if ((lane & 15) == 0) {
+                if (live) ra.costs[row] = cost;
+                wg_keys[0][0][rs] = (live && row < ra.n_cand) ? make_key(cost, row) : KEY_SENTINEL;  // TPB <= 32 keys
+            }
+        }
+        if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[13] = wall_clock64();
+        if (ra.K > 0) {   // the slab's keys -> one sorted list (one wave)
+            __syncthreads();
+            if (wave == 0) {
+                const unsigned long long key = wave_sort64(lane < TPB ? wg_keys[0][0][lane] : KEY_SENTINEL, lane);
+                if (lane < ra.K) {
+                    if (ra.part_k) {
+                        ra.part_k[(size_t)lane * gridDim.x + blockIdx.x] = key;
+                    } else {
+                        ra.part_c[(size_t)blockIdx.x * ra.K + lane] = key_cost(key);
+                        ra.part_i[(size_t)blockIdx.x * ra.K + lane] = key_idx(key);
+                    }
+                }
+            }
+        }
+    } else {
+        if (wave < RW) {
+            tile.load_obs(obs_stage);
+            run_key = rollout_slab<Tile, H, D>(tile, ra, rd0, base + wave * 16 + (lane & 15), n_rows, run_key, true, lane);
+            if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[12] = wall_clock64();
+        }
+        if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[13] = wall_clock64();
+        if (ra.K > 0) wg_merge_emit<RW>(wg_keys, run_key, ra.K, lane, wave, ra);
     }
-    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[13] = wall_clock64();
-    if (ra.K > 0) wg_merge_emit<RW>(wg_keys, run_key, ra.K, lane, wave, ra);
     if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[14] = wall_clock64();
 }
 
@@ -184,7 +227,8 @@ constexpr int single_launch_max_rw(int h, int d) {
 // 92 KB tile per CU the sampling and rollout phases of a workgroup run back to back at 2-3 waves per SIMD, and
 // N=65 536 took 297 instead of 220 us per MPC step -- the two full-occupancy kernels win there.)
 static bool sample_rollout_shape(int h, int d, int O, int rounds, int n_rows, int* grid_out, int* rw_out) {
-    static const int max_rw = [] { const char* e = getenv("ICEM_FUSE_MAX_RW"); return e ? atoi(e) : 8; }();
+    const char* env_rw = getenv("ICEM_FUSE_MAX_RW");  // read per call: the path-equivalence test flips it between planners
+    const int max_rw = env_rw ? atoi(env_rw) : 8;
     int grid, rw;
     r16_shape(n_rows, &grid, &rw);
     if (rounds != 10 || rw > max_rw || n_rows <= 0 || !fast_rollout_supported(h, d, O, 1) || !fast_sample_supported(h, d))

@@ -1590,3 +1590,37 @@ def test_in_library_exchange_wait_is_bounded(monkeypatch):
     torch.cuda.synchronize()
     assert pl.exchange_status()[0] == 1
     assert pl.exchange_status()[0] == 0  # read clears
+
+
+@pytest.mark.parametrize("h,d,o,kind,mode,N,iters", [(30, 6, 17, 0, "sum", 4096, 5), (30, 6, 17, 1, "best", 1000, 3), (30, 6, 18, 1, "sum", 8000, 3),
+                                                     (12, 6, 17, 0, "final", 300, 4), (13, 4, 17, 1, "sum", 5001, 3), (30, 6, 17, 0, "sum", 17, 2),
+                                                     (30, 17, 24, 1, "sum", 2000, 2)])
+def test_small_population_kernel_equals_two_kernel_path(h, d, o, kind, mode, N, iters, monkeypatch):
+    """The small-population launch (k_iter_small.hip: a row sampled by a quad of lanes with DPP exchange of its draws,
+    rollout on Tile4 = VALU + DPP row broadcast, four trajectories per wave) against the sampler + rollout16 kernels
+    (one thread per row, Tile16 = six dependent f32 MFMAs per step; ICEM_FUSE_MAX_RW=0): the same draws, the same fmaf
+    chains in the same order (an f32 MFMA is bitwise an fmaf chain over its slots) -- every buffer identical over three
+    MPC steps."""
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env, humanoid_standup_env
+    env = humanoid_standup_env(o) if d == 17 else halfcheetah_env(o)
+    model = DeviceSyntheticModel.make(o, d, kind=kind)
+
+    def run(max_rw):
+        monkeypatch.setenv("ICEM_FUSE_MAX_RW", str(max_rw))
+        pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=N, opt_iters=iters, dtype="f32", seed=11, cost_mode=mode),
+                         env.action_space.low[:d], env.action_space.high[:d])
+        pl.set_model(model.kind, model.A, model.B)
+        pl.set_cost_spec(env.cost_spec)
+        pl.reset()
+        out = []
+        for s in range(3):
+            a = np_(pl.plan_step(0.1 * np.random.RandomState(s).randn(o))).copy()
+            n_last = pl.population_sizes[-1]
+            ea, ec = pl.current_elites()
+            out.append((a, np_(pl.mean), np_(pl.std), np_(pl.costs[:n_last]), np_(pl.actions[:n_last]), np_(ea), np_(ec), np_(pl.best_cost)))
+        return out
+
+    ref, got = run(0), run(8)
+    for s, (r, g) in enumerate(zip(ref, got)):
+        for k, (x, y) in enumerate(zip(r, g)):
+            assert np.array_equal(x, y), (s, k, np.abs(x - y).max())
