@@ -1081,14 +1081,21 @@ __device__ __forceinline__ void sample_into_tile(const FastSampleArgs& sa, int n
     }
 }
 
-// sample_into_tile with the row on a quad of lanes (q = lane & 3), table from LDS (row_synth_quad)
-template <int H, int D, int ROUNDS, bool RAW>
-__device__ __forceinline__ void sample_into_tile_quad(const FastSampleArgs& sa, int n_rows, int r_mine, int jd, int q, float* trow,
-                                                      const float* mrow, const float* Wl) {
+// sample_into_tile with the row on a quad of lanes (q = lane & 3), table from LDS (row_synth_quad).  `publish()` runs
+// between the draws and the synthesis, in EVERY lane of the wave (live = false: a lane without a row): the caller
+// uses it to finish its wave's private copy of the table, whose global loads it issued in front of the draws.
+template <int H, int D, int ROUNDS, bool RAW, typename Publish>
+__device__ __forceinline__ void sample_into_tile_quad(const FastSampleArgs& sa, bool live, int n_rows, int r_mine, int jd, int q,
+                                                      float* trow, const float* mrow, const float* Wl, Publish&& publish) {
     constexpr int HD = H * D;
     float g[HMAX];
-    if (r_mine < sa.n) {
+    const int kind = !live ? 3 : (r_mine < sa.n ? 0 : ((r_mine < n_rows && !RAW) ? 1 : 2));
+    if (kind == 0)
         row_normals_quad<H, ROUNDS>((unsigned)(sa.first_index + r_mine), (unsigned)jd, sa.off_lo, sa.off_hi, sa.seed_lo, sa.seed_hi, q, g);
+    else if (kind == 1)  // shifted elite e = r_mine - sa.n: stream off2 (icem.py:91-104)
+        row_normals_quad<H, ROUNDS>((unsigned)(r_mine - sa.n), (unsigned)jd, sa.off2_lo, sa.off2_hi, sa.seed_lo, sa.seed_hi, q, g);
+    publish();
+    if (kind == 0) {
         if (RAW) {
             row_synth_quad<H>(Wl, g, q, [&](int t, float y) { trow[t * D] = y; }, sa.white != 0);
         } else {
@@ -1098,11 +1105,10 @@ __device__ __forceinline__ void sample_into_tile_quad(const FastSampleArgs& sa, 
                 trow[t * D] = __builtin_amdgcn_fmed3f(v, lo, hi);
             }, sa.white != 0);
         }
-    } else if (r_mine < n_rows && !RAW) {
-        // shifted elite e (icem.py:91-104): elites[e, 1:, j] and a last action from stream off2 (only t = h-1 is used)
+    } else if (kind == 1) {
+        // elites[e, 1:, j] and a last action from the full (n_shift, d, h) noise batch (only t = h-1 is used)
         const int e = r_mine - sa.n;
         const float lo = sa.low[jd], hi = sa.high[jd];
-        row_normals_quad<H, ROUNDS>((unsigned)e, (unsigned)jd, sa.off2_lo, sa.off2_hi, sa.seed_lo, sa.seed_hi, q, g);
         row_synth_quad<H>(Wl, g, q, [&](int t, float y) {
             if (t == H - 1) {
                 const float v = __builtin_fmaf(y, mrow[HD + t * D], mrow[t * D]);
@@ -1111,7 +1117,7 @@ __device__ __forceinline__ void sample_into_tile_quad(const FastSampleArgs& sa, 
         }, sa.white != 0);
         const float* src = sa.elites_src + (size_t)e * HD + jd;
         for (int t = q; t < H - 1; t += 4) trow[t * D] = src[(t + 1) * D];
-    } else {
+    } else if (kind == 2) {
         for (int t = q; t < H; t += 4) trow[t * D] = 0.f;  // past the end: rolled out, dropped
     }
 }

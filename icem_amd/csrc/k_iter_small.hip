@@ -52,7 +52,9 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
     __shared__ __attribute__((aligned(16))) float tilebuf[T16::SLACK + TPB * HD + T16::TAIL];
     __shared__ unsigned long long wg_keys[2][RW][32];
     __shared__ float obs_stage[32];
-    __shared__ __attribute__((aligned(16))) float Wl[QS ? (H / 2 + 1) * WQ_STRIDE : 4];  // QS: the synthesis table rows 0 .. H/2
+    constexpr int WROWS = H / 2 + 1;                 // table rows the folded synthesis reads
+    // QS: every sampling wave keeps its OWN copy of those rows (no workgroup barrier between filling and reading it)
+    __shared__ __attribute__((aligned(16))) float Wl[QS ? NT / 64 : 1][QS ? WROWS * WQ_STRIDE : 4];
     __shared__ unsigned long long sel[PM ? 64 : 1];
     __shared__ unsigned long long cand[PM ? 64 : 1];
     __shared__ int slot[PM ? 64 : 1];
@@ -75,9 +77,14 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
     const float* mrow = ms + jd;
     Tile tile;
     float obs_reg = 0.f;
+    // QS: this wave's table rows, requested now, parked in LDS behind the draws (sample_into_tile_quad's publish)
+    constexpr int WPL = (WROWS * HMAX + 63) / 64;
+    float wreg[QS ? WPL : 1];
     if constexpr (QS) {
-        for (int e = tid; e < (H / 2 + 1) * HMAX; e += NTT) Wl[(e / HMAX) * WQ_STRIDE + (e % HMAX)] = sa.W[e];
-        if (PM) __syncthreads();
+        if (tid < NT) {
+#pragma unroll
+            for (int i = 0; i < WPL; ++i) wreg[i] = sa.W[(i * 64 + lane) < WROWS * HMAX ? i * 64 + lane : 0];
+        }
     }
     if (!PM) {  // iteration 0 of an MPC step: the distribution is in memory; the model operands ride the same wait
         obs_reg = ra.obs0[(tid < 32 && tid < ra.o) ? tid : 0];
@@ -90,11 +97,22 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
     }
     if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[9] = wall_clock64();
     const int r_mine = base + nl;
-    if (has_row) {
-        if constexpr (QS)
-            sample_into_tile_quad<H, D, ROUNDS, PM>(sa, n_rows, r_mine, jd, q, trow, mrow, Wl);
-        else
-            sample_into_tile<H, D, ROUNDS, PM>(sa, n_rows, r_mine, jd, trow, mrow);
+    if constexpr (QS) {
+        if (tid < NT) {
+            float* wl = Wl[wave];
+            sample_into_tile_quad<H, D, ROUNDS, PM>(sa, has_row, n_rows, r_mine, jd, q, trow, mrow, wl, [&]() {
+#pragma unroll
+                for (int i = 0; i < WPL; ++i) {
+                    const int e = i * 64 + lane;
+                    if (e < WROWS * HMAX) wl[(e / HMAX) * WQ_STRIDE + (e % HMAX)] = wreg[i];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            });
+        }
+    } else if (has_row) {
+        sample_into_tile<H, D, ROUNDS, PM>(sa, n_rows, r_mine, jd, trow, mrow);
     }
     if constexpr (PM) {
         if (tid >= NT) {
