@@ -135,6 +135,8 @@ class ModelBasedController(Controller, ABC):
         """Per-trajectory cost of a batch of rollouts (abstract_controller.py:74-91)."""
         if self.use_env_reward_as_cost:
             costs_path = -np.asarray(rollout_buffer.as_array("rewards"))
+            if costs_path.ndim == 3 and costs_path.shape[-1] == 1:   # predict() reports rewards as [N, 1] per step
+                costs_path = costs_path[..., 0]
         else:
             costs_path = np.asarray([cost_fn(r["observations"], r["actions"], r["next_observations"])
                                      for r in rollout_buffer])
@@ -207,9 +209,13 @@ class MpcController(ModelBasedController, StatefulController, ABC):
     def _bind_models(self, world=1):
         """Which rollout path this controller's model allows: built-in device model + parametric cost (HIP rollout),
         a device torch model, or any host model through the reference's ``predict_n_steps`` interface."""
+        # use_env_reward_as_cost (abstract_controller.py:76-77: costs = -rewards of the rollouts): on the device when the
+        # model reports this very environment's reward, which is -cost_fn = -cost_spec -- the same kernels, the same
+        # numbers; any other reward source goes through the host-model path
+        reward_is_cost_spec = getattr(self.forward_model, "env", None) is self.env and hasattr(self.env, "reward_fn")
         self.device_path = (isinstance(self.forward_model, DeviceSyntheticModel)
                             and getattr(self.env, "cost_spec", None) is not None
-                            and not self.use_env_reward_as_cost)
+                            and (not self.use_env_reward_as_cost or reward_is_cost_spec))
         self.rssm_path = hasattr(self.forward_model, "rollout_cost") and hasattr(self.forward_model, "params")
         self.torch_path = (not self.device_path and not self.rssm_path and hasattr(self.forward_model, "torch_step")
                            and hasattr(self.forward_model, "torch_cost"))

@@ -132,7 +132,13 @@ class DeviceSyntheticModel(ForwardModel):
             nxt = nxt + actions[..., j:j + 1] * self.B[j]
         if self.kind == MODEL_TANH:
             nxt = np.tanh(nxt)
-        return nxt, None, np.zeros(observations.shape[:-1] + (1,))
+        # a model that carries its environment reports the environment's reward, like the reference's ground-truth
+        # models do (env.step's reward = -cost_fn); without one there is no reward to report
+        if self.env is not None and hasattr(self.env, "reward_fn"):
+            rew = np.asarray(self.env.reward_fn(observations, actions, nxt), dtype=np.float64)[..., None]
+        else:
+            rew = np.zeros(observations.shape[:-1] + (1,))
+        return nxt, None, rew
 
 
 class TorchForwardModel(ForwardModel):

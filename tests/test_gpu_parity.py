@@ -357,6 +357,30 @@ def test_controller_host_model_path(name):
         np.testing.assert_allclose(a, g.executed[s], rtol=F64_RTOL, atol=F64_ATOL)
 
 
+@pytest.mark.parametrize("on_device", [True, False])
+def test_controller_env_reward_as_cost(on_device):
+    """use_env_reward_as_cost (abstract_controller.py:76-77: costs = -rewards of the rollouts).  A synthetic model that
+    carries the controller's own environment reports that environment's reward = -cost_fn, so the device path serves
+    it with the same kernels; a model carrying another environment object goes through the host-model path, scored by
+    -rewards.  Both reproduce the reference's recorded actions."""
+    from icem_amd import DeviceSyntheticModel, MpcICemHip, halfcheetah_env
+    g = Golden("c1_halfcheetah_n128")
+    env = halfcheetah_env(g.o)
+    model_env = env if on_device else halfcheetah_env(g.o)
+    ctrl = MpcICemHip(env=env, forward_model=DeviceSyntheticModel(g.A, g.B, g.kind, env=model_env), horizon=g.h,
+                      num_simulated_trajectories=g.N, factor_decrease_num=g.gamma, cost_along_trajectory=g.cost_mode,
+                      dtype="f64", noise_source="numpy_legacy", use_env_reward_as_cost=True,
+                      action_sampler_params=dict(alpha=g.alpha, elites_size=g.K, opt_iterations=g.iters,
+                                                 init_std=g.init_std, use_mean_actions=g.use_mean,
+                                                 keep_previous_elites=g.keep, shift_elites_over_time=g.shift,
+                                                 fraction_elites_reused=g.xi, noise_beta=g.beta))
+    assert ctrl.device_path == on_device
+    np.random.seed(g.seed)
+    ctrl.beginning_of_rollout(observation=g.obs[0], state=None, mode="train")
+    for s in range(g.n_steps):
+        np.testing.assert_allclose(ctrl.get_action(g.obs[s], None), g.executed[s], rtol=F64_RTOL, atol=F64_ATOL)
+
+
 @pytest.mark.parametrize("deferral", [False, True])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_philox_plan_matches_oracle_and_is_shard_invariant(dtype, deferral):
