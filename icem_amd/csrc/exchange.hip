@@ -41,6 +41,9 @@ struct Exchange {
     bool loopback = false;                       // measurement: every "peer" is this rank's own block, waits look at rank 0 only
     unsigned max_polls = XCHG_MAX_POLLS;         // ICEM_XCHG_MAX_POLLS overrides (tests of the timeout path)
     bool connected = false;
+    // a peer connected by pointer lives in this process, possibly behind the same stream: its launches are ordered with
+    // ours, so nothing of ours may wait for something it has not launched yet (no riding pack)
+    bool local_peers = false;
 };
 
 namespace {
@@ -148,6 +151,7 @@ int xchg_begin(icem_handle* h, XchgPush* push_out, XchgWait* wait_out) {
 }
 
 bool xchg_connected(const icem_handle* h) { return h->xchg && h->xchg->connected; }
+bool xchg_concurrent_peers(const icem_handle* h) { return xchg_connected(h) && !h->xchg->local_peers; }
 
 void xchg_destroy(icem_handle* h) {
     Exchange* x = h->xchg;
@@ -240,11 +244,13 @@ int icem_exchange_connect(icem_handle* h, const void* handles_host, void* const*
     const int world = h->cfg.world, rank = h->cfg.rank;
     x->peers.assign(world, nullptr);
     x->opened.assign(world, false);
+    x->local_peers = false;
     for (int r = 0; r < world; ++r) {
         if (r == rank || x->loopback) {
             x->peers[r] = x->block;
         } else if (local_blocks && local_blocks[r]) {
             x->peers[r] = (unsigned char*)local_blocks[r];
+            x->local_peers = true;
         } else {
             if (!handles_host) return fail(ICEM_E_INVALID, "no IPC handle for a rank outside this process");
             hipIpcMemHandle_t ipc;

@@ -724,10 +724,11 @@ __device__ __forceinline__ unsigned long long topk_push16(unsigned long long run
 }
 
 // one sorted list per workgroup: tree merge of the first WAVES waves' lists through LDS (`fan` lists per sort),
-// wave 0 writes list blockIdx.x.  Every thread of the workgroup must call it.
+// wave 0 writes list `wg` of `n_wg`.  Every thread of the workgroup must call it.
 template <int WAVES>
 __device__ __forceinline__ void wg_merge_emit(unsigned long long (*wg_keys)[WAVES][32], unsigned long long run_key, int K,
-                                              int lane, int wave, const FastRolloutArgs& a) {
+                                              int lane, int wave, const FastRolloutArgs& a, int wg = blockIdx.x,
+                                              int n_wg = gridDim.x) {
     if (WAVES > 1) {
         const int fan = 4 * K <= 64 ? 4 : 2;
         int lists = WAVES, par = 0;
@@ -749,10 +750,10 @@ __device__ __forceinline__ void wg_merge_emit(unsigned long long (*wg_keys)[WAVE
     }
     if (wave == 0 && lane < K) {
         if (a.part_k) {
-            a.part_k[(size_t)lane * gridDim.x + blockIdx.x] = run_key;
+            a.part_k[(size_t)lane * n_wg + wg] = run_key;
         } else {
-            a.part_c[(size_t)blockIdx.x * K + lane] = key_cost(run_key);
-            a.part_i[(size_t)blockIdx.x * K + lane] = key_idx(run_key);
+            a.part_c[(size_t)wg * K + lane] = key_cost(run_key);
+            a.part_i[(size_t)wg * K + lane] = key_idx(run_key);
         }
     }
 }
@@ -1220,6 +1221,69 @@ struct Stream16 {
         return run_key;
     }
 };
+
+// Sharded runs: this rank's K best candidates (merge_select's selection, already in `sel`) packed as records
+// {cost, gidx, actions[h*d]} for the exchange.  Local pool row li is global trajectory shard_lo + li, or
+// n_global + (li - n_loc) for the replicated shifted elites behind the shard (icem_amd/distributed.py).  With
+// px.peers the records (staged in `stage`, [K, h*d + 2] floats of LDS) also go into this rank's slot of every rank's
+// exchange block as 16-byte peer-to-peer stores (xGMI between GPUs), the flags follow behind a system-scope fence.
+// Called by all `nthr` threads of ONE workgroup (pack_records_kernel, or workgroup 0 of a sample_rollout launch).
+template <int KREG>
+__device__ __forceinline__ void pack_records_body(const MergeSingleArgs& a, int n_loc, int shard_lo, float* records, const XchgPush& px,
+                                                  float* stage, const unsigned long long* sel, int tid, int nthr) {
+    const int hd = a.h * a.d;
+    const int rs = hd + 2;
+    const bool push = px.peers != nullptr;
+    auto put = [&](int off, float v) {
+        records[off] = v;
+        if (push) stage[off] = v;
+    };
+    // headers by the first K threads; rows: element e of all K rows per thread, every load in flight before a store
+    if (tid < a.K) {
+        const unsigned long long key = sel[tid];
+        float c = INFINITY;
+        int g = INT_MAX;
+        if (key != KEY_SENTINEL) {  // (else: fewer than K candidates on this rank)
+            const int li = key_idx(key);
+            c = key_cost(key);
+            g = li < n_loc ? shard_lo + li : a.n_global + (li - n_loc);
+        }
+        put(tid * rs, c);
+        put(tid * rs + 1, __int_as_float(g));
+    }
+    const float* rows[KREG];
+    bool dead[KREG];
+#pragma unroll
+    for (int r = 0; r < KREG; ++r) {
+        const unsigned long long key = sel[r < a.K ? r : 0];
+        dead[r] = key == KEY_SENTINEL;
+        rows[r] = a.actions + (size_t)(dead[r] ? 0 : key_idx(key)) * hd;
+    }
+    for (int e = tid; e < hd; e += nthr) {
+        float xs[KREG];
+#pragma unroll
+        for (int r = 0; r < KREG; ++r) xs[r] = rows[r][e];
+#pragma unroll
+        for (int r = 0; r < KREG; ++r)
+            if (r < a.K) put(r * rs + 2 + e, dead[r] ? 0.f : xs[r]);
+    }
+    if (push) {
+        __syncthreads();
+        const int words = a.K * rs;  // K * rs * 4 bytes: a multiple of 8; the tail goes out as dwords
+        const int vecs = words / 4;
+        for (int p = 0; p < px.world; ++p) {
+            float* dst = reinterpret_cast<float*>(px.peers[p] + px.rec_byte_off);
+            for (int v = tid; v < vecs; v += nthr) reinterpret_cast<float4*>(dst)[v] = reinterpret_cast<const float4*>(stage)[v];
+            for (int e = 4 * vecs + tid; e < words; e += nthr) dst[e] = stage[e];
+        }
+        __threadfence_system();
+        __syncthreads();
+        if (tid < px.world) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(reinterpret_cast<unsigned*>(px.peers[tid]) + px.flag_idx, px.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
 
 // rollout launch shape: one 16-trajectory tile per wave while they fit, at most FAST_MAX_LISTS workgroups (= lists)
 inline void r16_shape(int n_rows, int* grid, int* waves) {

@@ -103,6 +103,10 @@ struct icem_handle {
     icem::Exchange* xchg = nullptr;  // in-library elite exchange (icem_exchange_*), world > 1
     icem::XchgWait xw_last;          // ... and what the merge of the running iteration waits for (set by the push)
     uint64_t episode = 0;            // folded into the noise stream offset (icem_set_episode)
+    // sharded runs with merge deferral: an iteration's record pack + push can ride in the NEXT local launch too
+    // (workgroup 0 of sample_rollout_kernel) instead of being a launch of its own
+    bool pk_pending = false;
+    icem::PackPrev pk_args;
 };
 
 namespace icem {
@@ -203,6 +207,8 @@ const char* cost_indices_error(const icem_handle* h, int o);
 // ---- exchange.hip: the in-library elite exchange --------------------------------------------------------------------
 bool xchg_connected(const icem_handle* h);
 // this rank's K records of the running iteration -> every rank's block (one launch); *wait_out: what the merge polls
+// every peer runs in a process (stream) of its own: a launch of ours may wait for something a peer launches later
+bool xchg_concurrent_peers(const icem_handle* h);
 int xchg_push(icem_handle* h, const void* my_records, hipStream_t st, XchgWait* wait_out);
 // ... or, where the caller's own kernel does the push (pack_records_kernel): the arguments for it
 int xchg_begin(icem_handle* h, XchgPush* push_out, XchgWait* wait_out);

@@ -137,10 +137,28 @@ bool pack_can_push(int K, int h, int d);
 void launch_pack_records(const MergeSingleArgs& a, int n_loc, int shard_lo, float* records, hipStream_t st,
                          const XchgPush& px = XchgPush());
 
+// Sharded runs, "riding pack": the PREVIOUS iteration's record pack + push as one extra workgroup (index 0) of this
+// iteration's launch, running while the other workgroups draw their noise; their merge prologue then waits for the
+// exchange's flags (this rank's own among them) as always.  Reads the previous launch's lists and pool, which this
+// launch overwrites only behind those flags.
+struct PackPrev {
+    const unsigned long long* part_k = nullptr;  // previous launch's candidate lists; nullptr: no pack in this launch
+    const float* actions = nullptr;              // ... and pool
+    int n_lists = 0, n_pool = 0, n_global = 0, K = 0;
+    int n_loc = 0, shard_lo = 0;
+    float* records = nullptr;                    // this rank's [K, 2 + h*d] records
+    XchgPush px;
+};
+// may the merge-prologue launch of an iteration with n_rows local rows carry the previous iteration's pack? (the
+// single-launch kernel or the sampler of the two-kernel path; the records must fit the workgroup's tile)
+bool sample_rollout_pack_ok(int h, int d, int O, int rounds, int n_rows, int K);
+bool sample_folded_pack_ok(int h, int d, int rounds, int K);
+
 // K1 with the previous iteration's merge (last == 0) in its prologue, see sample_folded_merge_kernel
 struct FastSampleMergeArgs {
     FastSampleArgs s;  // n_shift must be 0
     MergeSingleArgs m;
+    PackPrev p;        // sharded runs: the previous iteration's pack rides as workgroup 0
 };
 bool sample_folded_merge_ok(int h, int d, int rounds, int K);
 void launch_sample_folded_merge(const FastSampleMergeArgs& a, hipStream_t st);
@@ -150,6 +168,7 @@ struct FastIterArgs {
     FastSampleArgs s;
     FastRolloutArgs r;
     MergeSingleArgs m;  // merge prologue only: the PREVIOUS iteration's merge (last == 0), see sample_rollout_kernel
+    PackPrev p;         // ... and its pack (sharded runs)
 };
 // workgroups (= candidate lists) of that launch; 0 if this shape / generator / size has no single-launch kernel
 int sample_rollout_lists(int h, int d, int O, int rounds, int n_rows);

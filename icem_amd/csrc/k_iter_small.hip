@@ -24,6 +24,8 @@ namespace {
 // the host / the next launch.  That removes the merge launch and hides its latency behind the sampling.  The
 // previous pool, lists and distribution are read while this launch writes new ones: all three are ping-pong
 // buffers (icem_plan_step).
+// REC + PackPrev ("riding pack", sharded runs): workgroup 0 of the launch is not a slab but the PREVIOUS iteration's
+// record pack + push (pack_records_body), running while the slabs' workgroups draw their noise; DESIGN section 6.
 // QS ("quad sampling", RW <= 2): four lanes per (trajectory, dim) row (row_normals_quad / row_synth_quad): with at most
 // two tiles per CU the sampling phase is one thread's instruction chain, and a quarter of it is ~2.4x shorter.
 constexpr bool sr_quad(int d, int rw) { return rw <= 2 && ((4 * 16 * rw * d + 63) / 64) * 64 + 64 <= 1024; }
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
     constexpr int WROWS = H / 2 + 1;                 // table rows the folded synthesis reads
     // QS: every sampling wave keeps its OWN copy of those rows (no workgroup barrier between filling and reading it)
     __shared__ __attribute__((aligned(16))) float Wl[QS ? NT / 64 : 1][QS ? WROWS * WQ_STRIDE : 4];
-    __shared__ unsigned long long sel[PM ? 64 : 1];
+    __shared__ unsigned long long sel[PM ? 64 : 1];   // prologue selection (workgroup 0 of a riding pack: the pack's)
     __shared__ unsigned long long cand[PM ? 64 : 1];
     __shared__ int slot[PM ? 64 : 1];
     float* tile_rows = tilebuf + T16::SLACK;
@@ -65,9 +67,37 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int n_rows = ra.n_rows;       // sa.n sampled rows, then sa.n_shift shifted elites
-    const int base = blockIdx.x * TPB;  // one slab of TPB trajectories per workgroup (launch_sample_rollout)
+    // riding pack (sharded runs, merge-prologue launches only): workgroup 0 packs + pushes the previous iteration's records
+    const bool has_pack = PM && REC && a.p.part_k != nullptr;
+    if constexpr (PM && REC) {
+        if (has_pack && blockIdx.x == 0) {
+            MergeSingleArgs pk{};
+            pk.n_lists = a.p.n_lists;
+            pk.n_pool = a.p.n_pool;
+            pk.n_global = a.p.n_global;
+            pk.K = a.p.K;
+            pk.h = H;
+            pk.d = D;
+            pk.part_k = a.p.part_k;
+            pk.actions = a.p.actions;
+            // everybody else's prologue waits for this workgroup's push: its waves go first on their SIMDs
+            __builtin_amdgcn_s_setprio(3);
+            // the register-resident selection (174 registers, 1 us faster) where at most two waves share a SIMD anyway
+            if (tid < 64) {
+                if constexpr (NTT <= 512)
+                    merge_select<12>(pk, lane, cand, sel);
+                else
+                    merge_select_stream(pk, lane, cand, sel);
+            }
+            __syncthreads();
+            pack_records_body<12>(pk, a.p.n_loc, a.p.shard_lo, a.p.records, a.p.px, tilebuf, sel, tid, NTT);
+            return;
+        }
+    }
+    const int wg = blockIdx.x - (has_pack ? 1 : 0), n_wg = gridDim.x - (has_pack ? 1 : 0);
+    const int base = wg * TPB;          // one slab of TPB trajectories per workgroup (launch_sample_rollout)
     if (base >= n_rows) return;
-    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[8] = wall_clock64();
+    if (ra.dbg && tid == 0 && wg == 0) ra.dbg[8] = wall_clock64();
     // Order matters at this size: kernel arguments arrive through serialized scalar loads, so everything the RNG
     // chain does not need (start observation, model operands, bounds) is fetched AFTER the sampling got going.
     const int rowi = QS ? tid >> 2 : tid, q = tid & 3;  // QS: lane q of the row's quad
@@ -95,7 +125,7 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
         }
         __syncthreads();
     }
-    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[9] = wall_clock64();
+    if (ra.dbg && tid == 0 && wg == 0) ra.dbg[9] = wall_clock64();
     const int r_mine = base + nl;
     if constexpr (QS) {
         if (tid < NT) {
@@ -144,7 +174,7 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
             refit_element_regs<float, KREG>(m.K, m.alpha, m.mean[e], m.std[e], xs, nm, ns);
             ms[e] = nm;
             ms[HD + e] = ns;
-            if (blockIdx.x == 0) {
+            if (wg == 0) {
                 m.mean_out[e] = nm;
                 m.std_out[e] = ns;
 #pragma unroll
@@ -152,7 +182,7 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
                     if (r < m.K) m.elites_next[(size_t)r * HD + e] = xs[r];
             }
         }
-        if (blockIdx.x == 0 && tid < m.K) m.elites_cost_next[tid] = key_cost(sel[tid]);
+        if (wg == 0 && tid < m.K) m.elites_cost_next[tid] = key_cost(sel[tid]);
         __syncthreads();
         if (has_row && r_mine < sa.n) {  // y * std + mean, clipped (icem.py:79)
             const float lo = sa.low[jd], hi = sa.high[jd];
@@ -167,7 +197,7 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
         asm volatile("" : "+v"(ov));  // wait for the load here, not where it was issued
         obs_stage[tid] = tid < ra.o ? ov : 0.f;
     }
-    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[10] = wall_clock64();
+    if (ra.dbg && tid == 0 && wg == 0) ra.dbg[10] = wall_clock64();
     __syncthreads();
     if (sa.row0_mean && sa.first_index + base == 0) {  // icem.py:87-88
         for (int e = tid; e < HD; e += NTT) tile_rows[e] = ms[e];
@@ -179,7 +209,7 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
         Vec* g4 = reinterpret_cast<Vec*>(sa.out + (size_t)base * HD);
         for (int e = tid; e < total4; e += NTT) g4[e] = t4[e];
     }
-    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[11] = wall_clock64();
+    if (ra.dbg && tid == 0 && wg == 0) ra.dbg[11] = wall_clock64();
     unsigned long long run_key = KEY_SENTINEL;
     if constexpr (T4) {
         // four trajectories per wave: row `wave * 4 + lane / 16` of the slab, lane % 16 = observation column
@@ -200,17 +230,17 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
                 wg_keys[0][0][rs] = (live && row < ra.n_cand) ? make_key(cost, row) : KEY_SENTINEL;  // TPB <= 32 keys
             }
         }
-        if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[13] = wall_clock64();
+        if (ra.dbg && tid == 0 && wg == 0) ra.dbg[13] = wall_clock64();
         if (ra.K > 0) {   // the slab's keys -> one sorted list (one wave)
             __syncthreads();
             if (wave == 0) {
                 const unsigned long long key = wave_sort64(lane < TPB ? wg_keys[0][0][lane] : KEY_SENTINEL, lane);
                 if (lane < ra.K) {
                     if (ra.part_k) {
-                        ra.part_k[(size_t)lane * gridDim.x + blockIdx.x] = key;
+                        ra.part_k[(size_t)lane * n_wg + wg] = key;
                     } else {
-                        ra.part_c[(size_t)blockIdx.x * ra.K + lane] = key_cost(key);
-                        ra.part_i[(size_t)blockIdx.x * ra.K + lane] = key_idx(key);
+                        ra.part_c[(size_t)wg * ra.K + lane] = key_cost(key);
+                        ra.part_i[(size_t)wg * ra.K + lane] = key_idx(key);
                     }
                 }
             }
@@ -219,12 +249,12 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
         if (wave < RW) {
             tile.load_obs(obs_stage);
             run_key = rollout_slab<Tile, H, D>(tile, ra, rd0, base + wave * 16 + (lane & 15), n_rows, run_key, true, lane);
-            if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[12] = wall_clock64();
+            if (ra.dbg && tid == 0 && wg == 0) ra.dbg[12] = wall_clock64();
         }
-        if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[13] = wall_clock64();
-        if (ra.K > 0) wg_merge_emit<RW>(wg_keys, run_key, ra.K, lane, wave, ra);
+        if (ra.dbg && tid == 0 && wg == 0) ra.dbg[13] = wall_clock64();
+        if (ra.K > 0) wg_merge_emit<RW>(wg_keys, run_key, ra.K, lane, wave, ra, wg, n_wg);
     }
-    if (ra.dbg && tid == 0 && blockIdx.x == 0) ra.dbg[14] = wall_clock64();
+    if (ra.dbg && tid == 0 && wg == 0) ra.dbg[14] = wall_clock64();
 }
 
 }  // namespace
@@ -270,9 +300,17 @@ bool sample_rollout_merge_ok(int h, int d, int O, int rounds, int n_rows, int K)
     return on && K + 1 <= 12 && sample_rollout_shape(h, d, O, rounds, n_rows, &grid, &rw);
 }
 
+bool sample_rollout_pack_ok(int h, int d, int O, int rounds, int n_rows, int K) {
+    static const int on = [] { const char* e = getenv("ICEM_RIDING_PACK"); return e ? atoi(e) : 1; }();
+    int grid, rw;
+    return on && sample_rollout_merge_ok(h, d, O, rounds, n_rows, K) && sample_rollout_shape(h, d, O, rounds, n_rows, &grid, &rw) &&
+           K * (h * d + 2) <= 16 * rw * h * d;
+}
+
 void launch_sample_rollout(const FastIterArgs& a, int h, int d, int O, int kind, bool merge_prologue, hipStream_t st) {
     int grid, rw;
     if (!sample_rollout_shape(h, d, O, 10, a.r.n_rows, &grid, &rw)) return;
+    if (merge_prologue && a.m.records && a.p.part_k) grid += 1;  // workgroup 0: the riding pack
 #define XK(HH, DD, OO, WW, KR, RC)                                                                                      \
     {                                                                                                                   \
         constexpr int NT = sr_threads(DD, WW) + (KR > 0 ? 64 : 0);                                                     \

@@ -79,9 +79,8 @@ __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs 
     if (a.dbg && threadIdx.x == 0) a.dbg[6] = wall_clock64();
 }
 
-// Sharded runs: this rank's K best candidates (same selection) packed as records {cost, gidx, actions[h*d]} for
-// the all-gather.  Local pool row li is global trajectory shard_lo + li, or n_global + (li - n_loc) for the
-// replicated shifted elites behind the shard (icem_amd/distributed.py).
+// Sharded runs: this rank's K best candidates (same selection) packed as records (pack_records_body) -- a launch of
+// its own where the pack cannot ride in the next iteration's launch (sample_rollout_kernel's workgroup 0).
 // bytes of LDS the pack kernel may use to stage the K records for the push (larger records: separate push launch)
 constexpr size_t PACK_STAGE_MAX = 48 * 1024;
 
@@ -91,63 +90,9 @@ __global__ __launch_bounds__(MERGE_WG) void pack_records_kernel(MergeSingleArgs 
     __shared__ unsigned long long cand[64];
     extern __shared__ __attribute__((aligned(16))) float stage[];  // [K, rs] when the kernel also pushes
     const int tid = threadIdx.x;
-    const int hd = a.h * a.d;
-    const int rs = hd + 2;
     if (tid < 64) merge_select<KREG>(a, tid, cand, sel);
     __syncthreads();
-    const bool push = px.peers != nullptr;
-    auto put = [&](int off, float v) {
-        records[off] = v;
-        if (push) stage[off] = v;
-    };
-    // headers by the first K threads; rows: element e of all K rows per thread, every load in flight before a store
-    if (tid < a.K) {
-        const unsigned long long key = sel[tid];
-        float c = INFINITY;
-        int g = INT_MAX;
-        if (key != KEY_SENTINEL) {  // (else: fewer than K candidates on this rank)
-            const int li = key_idx(key);
-            c = key_cost(key);
-            g = li < n_loc ? shard_lo + li : a.n_global + (li - n_loc);
-        }
-        put(tid * rs, c);
-        put(tid * rs + 1, __int_as_float(g));
-    }
-    const float* rows[KREG];
-    bool dead[KREG];
-#pragma unroll
-    for (int r = 0; r < KREG; ++r) {
-        const unsigned long long key = sel[r < a.K ? r : 0];
-        dead[r] = key == KEY_SENTINEL;
-        rows[r] = a.actions + (size_t)(dead[r] ? 0 : key_idx(key)) * hd;
-    }
-    for (int e = tid; e < hd; e += MERGE_WG) {
-        float xs[KREG];
-#pragma unroll
-        for (int r = 0; r < KREG; ++r) xs[r] = rows[r][e];
-#pragma unroll
-        for (int r = 0; r < KREG; ++r)
-            if (r < a.K) put(r * rs + 2 + e, dead[r] ? 0.f : xs[r]);
-    }
-    if (push) {
-        // in-library exchange (exchange.hip): the staged records go into this rank's slot of every rank's block as
-        // 16-byte peer-to-peer stores (xGMI between GPUs), the flags follow behind a system-scope fence -- no push
-        // launch of its own
-        __syncthreads();
-        const int words = a.K * rs;  // K * rs * 4 bytes: a multiple of 8; the tail goes out as dwords
-        const int vecs = words / 4;
-        for (int p = 0; p < px.world; ++p) {
-            float* dst = reinterpret_cast<float*>(px.peers[p] + px.rec_byte_off);
-            for (int v = tid; v < vecs; v += MERGE_WG) reinterpret_cast<float4*>(dst)[v] = reinterpret_cast<const float4*>(stage)[v];
-            for (int e = 4 * vecs + tid; e < words; e += MERGE_WG) dst[e] = stage[e];
-        }
-        __threadfence_system();
-        __syncthreads();
-        if (tid < px.world) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(reinterpret_cast<unsigned*>(px.peers[tid]) + px.flag_idx, px.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    pack_records_body<KREG>(a, n_loc, shard_lo, records, px, stage, sel, tid, MERGE_WG);
 }
 
 }  // namespace

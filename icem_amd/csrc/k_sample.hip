@@ -101,7 +101,30 @@ __global__ __launch_bounds__(SWG + 64) void sample_folded_merge_kernel(FastSampl
     float* tile = smem + 2 * hd;  // [tpw, hd]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int n_base = blockIdx.x * tpw;
+    // riding pack (sharded runs, PackPrev): workgroup 0 packs + pushes the previous iteration's records while the others
+    // draw their noise; the launch has one workgroup more
+    const bool has_pack = REC && args.p.part_k != nullptr;
+    if constexpr (REC) {
+        if (has_pack && blockIdx.x == 0) {
+            MergeSingleArgs pk{};
+            pk.n_lists = args.p.n_lists;
+            pk.n_pool = args.p.n_pool;
+            pk.n_global = args.p.n_global;
+            pk.K = args.p.K;
+            pk.h = H;
+            pk.d = d;
+            pk.part_k = args.p.part_k;
+            pk.actions = args.p.actions;
+            // everybody else's prologue waits for this workgroup's push: its waves go first on their SIMDs
+            __builtin_amdgcn_s_setprio(3);
+            if (tid >= SWG) merge_select_stream(pk, lane, cand, sel);
+            __syncthreads();
+            pack_records_body<KREG>(pk, args.p.n_loc, args.p.shard_lo, args.p.records, args.p.px, smem, sel, tid, NTT);
+            return;
+        }
+    }
+    const int wg = blockIdx.x - (has_pack ? 1 : 0);
+    const int n_base = wg * tpw;
     const int n_here = cmin(tpw, a.n - n_base);
     const bool has_row = tid < n_here * d;
     const int nl = tid / d;
@@ -128,7 +151,7 @@ __global__ __launch_bounds__(SWG + 64) void sample_folded_merge_kernel(FastSampl
             refit_element_regs<float, KREG>(m.K, m.alpha, m.mean[e], m.std[e], xs, nm, ns);
             ms[e] = nm;
             ms[hd + e] = ns;
-            if (blockIdx.x == 0) {
+            if (wg == 0) {
                 m.mean_out[e] = nm;
                 m.std_out[e] = ns;
 #pragma unroll
@@ -136,7 +159,7 @@ __global__ __launch_bounds__(SWG + 64) void sample_folded_merge_kernel(FastSampl
                     if (r < m.K) m.elites_next[(size_t)r * hd + e] = xs[r];
             }
         }
-        if (blockIdx.x == 0 && tid < m.K) m.elites_cost_next[tid] = key_cost(sel[tid]);
+        if (wg == 0 && tid < m.K) m.elites_cost_next[tid] = key_cost(sel[tid]);
     }
     __syncthreads();
     if (has_row) {
@@ -180,9 +203,15 @@ bool sample_folded_merge_ok(int h, int d, int rounds, int K) {
     return on && rounds == 10 && K + 1 <= 12 && fast_sample_supported(h, d);
 }
 
+bool sample_folded_pack_ok(int h, int d, int rounds, int K) {
+    static const int on = [] { const char* e = getenv("ICEM_RIDING_PACK"); return e ? atoi(e) : 1; }();
+    const int tpw = SWG / d;
+    return on && sample_folded_merge_ok(h, d, rounds, K) && K * (h * d + 2) <= (2 + tpw) * h * d;
+}
+
 void launch_sample_folded_merge(const FastSampleMergeArgs& a, hipStream_t st) {
     const int tpw = SWG / a.s.d;
-    const int grid = (a.s.n + tpw - 1) / tpw;
+    const int grid = (a.s.n + tpw - 1) / tpw + (a.m.records && a.p.part_k ? 1 : 0);  // + workgroup 0: the riding pack
     const size_t lds = ((size_t)2 * a.s.h * a.s.d + (size_t)tpw * a.s.h * a.s.d) * sizeof(float);
 #define X(HH)                                                                                                  \
     if (a.s.h == HH) {                                                                                         \

@@ -249,6 +249,43 @@ int launch_pending_merge(icem_handle* h, hipStream_t st) {
     return ICEM_OK;
 }
 
+// will the merge-prologue launch of an iteration with n_rows local rows take the previous iteration's pack along?
+static bool next_launch_takes_pack(const icem_handle* h, int n_rows) {
+    const icem_config& c = h->cfg;
+    if (sample_rollout_lists(c.horizon, c.act_dim, h->O, c.rng_rounds, n_rows) > 0)
+        return sample_rollout_pack_ok(c.horizon, c.act_dim, h->O, c.rng_rounds, n_rows, c.num_elites);
+    return sample_folded_pack_ok(c.horizon, c.act_dim, c.rng_rounds, c.num_elites);
+}
+
+// a stashed pack that found no launch to ride in
+int launch_pending_pack(icem_handle* h, hipStream_t st) {
+    const PackPrev& pp = h->pk_args;
+    MergeSingleArgs pk{};
+    pk.n_lists = pp.n_lists;
+    pk.n_pool = pp.n_pool;
+    pk.n_global = pp.n_global;
+    pk.K = pp.K;
+    pk.h = h->cfg.horizon;
+    pk.d = h->cfg.act_dim;
+    pk.part_k = pp.part_k;
+    pk.actions = pp.actions;
+    {
+        ProfScope prof(h, ICEM_K_LOCAL_PACK, pp.n_lists * pp.K, st);
+        launch_pack_records(pk, pp.n_loc, pp.shard_lo, pp.records, st, pp.px);
+    }
+    ICEM_HIP_TRY(hipGetLastError());
+    h->pk_pending = false;
+    return ICEM_OK;
+}
+
+// rows of this rank's shard at iteration `it`
+static int local_rows(const icem_handle* h, int it) {
+    const int n_global = h->pop[it];
+    const int chunk = shard_chunk(n_global, h->cfg.world);
+    const int lo = std::min(n_global, h->cfg.rank * chunk);
+    return std::max(0, std::min(n_global - lo, chunk));
+}
+
 template <typename T>
 int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, int it, hipStream_t st) {
     const icem_config& c = h->cfg;
@@ -302,19 +339,30 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                                 ? sample_rollout_lists(c.horizon, c.act_dim, h->O, c.rng_rounds, n_rows) : 0;
             // the merge finds the lists' indices behind `lists * K` costs
             split_partial_ws<float>(b->workspace, one > 0 ? one : rollout_lists(c.horizon, c.act_dim, h->O, n_rows), K, &pc, &pi);
-            bool prologue = false;
+            bool prologue = false, ride = false;
             if (h->pm_pending) {
                 prologue = n_extra == 0 && prologue_possible(h, n_rows);
+                // a stashed pack rides with the merge whose records it produces, or runs now -- in front of that merge
+                ride = prologue && h->pk_pending && next_launch_takes_pack(h, n_rows);
+                if (h->pk_pending && !ride) {
+                    rc = launch_pending_pack(h, st);
+                    if (rc) return rc;
+                }
                 if (!prologue) {  // cannot ride along after all: run it now
                     rc = launch_pending_merge(h, st);
                     if (rc) return rc;
                 }
                 h->pm_pending = false;
+            } else if (h->pk_pending) {
+                rc = launch_pending_pack(h, st);
+                if (rc) return rc;
             }
+            h->pk_pending = false;
             if (one > 0) {
                 // small populations: sample + rollout + top-K in one launch
                 FastIterArgs fa;
                 if (prologue) fa.m = h->pm_args;
+                if (ride) fa.p = h->pk_args;
                 fa.s = fast_sample_args(h, n_loc, lo, b->mean, b->std, b->low, b->high, off, row0, actions,
                                         shift_in_sampler ? n_extra : 0, shift_src, call_base + (uint64_t)c.opt_iters);
                 fa.r = fast_rollout_args(h, n_rows, n_cand, K, b->obs0, actions, b->costs, pc, pi);
@@ -331,6 +379,7 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                     FastSampleMergeArgs sm;
                     sm.s = fast_sample_args(h, n_loc, lo, b->mean, b->std, b->low, b->high, off, row0, actions, 0, nullptr, 0);
                     sm.m = h->pm_args;
+                    if (ride) sm.p = h->pk_args;
                     {
                         ProfScope prof(h, ICEM_K_SAMPLE, (long long)n_loc * c.horizon, st);
                         launch_sample_folded_merge(sm, st);
@@ -366,6 +415,27 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                 if (fold_push) {
                     rc = xchg_begin(h, &px, &h->xw_last);
                     if (rc) return rc;
+                }
+                // Riding pack: where this iteration's merge will ride in the next local launch (h->deferral, same
+                // conditions as icem_plan_iter_merge's fold) and that launch is a single-launch kernel, the pack rides
+                // there too, as its workgroup 0.  Stashed; the next icem_plan_iter_local consumes it (or launches it).
+                if (fold_push && xchg_concurrent_peers(h) && h->deferral && !last && lists > 0 && c.world * K <= 128 && K <= 32 && it + 1 < c.opt_iters) {
+                    const int n_next = local_rows(h, it + 1);
+                    if (prologue_possible(h, n_next) && next_launch_takes_pack(h, n_next)) {
+                        PackPrev& pp = h->pk_args;
+                        pp.part_k = pk.part_k;
+                        pp.actions = pk.actions;
+                        pp.n_lists = pk.n_lists;
+                        pp.n_pool = pk.n_pool;
+                        pp.n_global = pk.n_global;
+                        pp.K = K;
+                        pp.n_loc = n_loc;
+                        pp.shard_lo = lo;
+                        pp.records = (float*)rec;
+                        pp.px = px;
+                        h->pk_pending = true;
+                        return ICEM_OK;
+                    }
                 }
                 {
                     ProfScope prof(h, ICEM_K_LOCAL_PACK, lists * K, st);
@@ -436,6 +506,10 @@ int plan_iter_merge_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                 h->pm_args = m;
                 h->pm_pending = true;
                 return ICEM_OK;
+            }
+            if (h->pk_pending) {  // (cannot happen at world == 1; kept symmetrical)
+                const int rc = launch_pending_pack(h, st);
+                if (rc) return rc;
             }
             ProfScope prof(h, ICEM_K_MERGE_REFIT, h->fast_lists * K + m.n_keep, st);
             launch_merge_single(m, st);
@@ -508,11 +582,19 @@ int plan_iter_merge_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                 return ICEM_OK;
             }
             m.last = a.last;
+            if (h->pk_pending) {  // the merge runs now after all: so must the pack whose records it waits for
+                const int rc = launch_pending_pack(h, st);
+                if (rc) return rc;
+            }
             ProfScope prof(h, ICEM_K_MERGE_REFIT, a.n_rec + a.n_keep, st);
             launch_merge_single(m, st);
             ICEM_HIP_TRY(hipGetLastError());
             return ICEM_OK;
         }
+    }
+    if (h->pk_pending) {
+        const int rc = launch_pending_pack(h, st);
+        if (rc) return rc;
     }
     return gk_merge_refit(h, a, st);
 }
@@ -565,14 +647,6 @@ static int check_plan(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_st
         ((b->z_r == nullptr) != (b->z_i == nullptr) || (b->z_r_shift == nullptr) != (b->z_i_shift == nullptr)))
         return fail(ICEM_E_INVALID, "z_r/z_i must be given in pairs");
     return ICEM_OK;
-}
-
-// rows of this rank's shard at iteration `it`
-static int local_rows(const icem_handle* h, int it) {
-    const int n_global = h->pop[it];
-    const int chunk = shard_chunk(n_global, h->cfg.world);
-    const int lo = std::min(n_global, h->cfg.rank * chunk);
-    return std::max(0, std::min(n_global - lo, chunk));
 }
 
 static int ensure_pp_stats(icem_handle* h) {

@@ -1573,7 +1573,7 @@ def _xchg_worker(rank, world, port, out_dir, dtype, N=2000):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dtype,N", [("f32", 2000), ("f64", 2000), ("f32", 12000)])
+@pytest.mark.parametrize("dtype,N", [("f32", 2000), ("f64", 2000), ("f32", 12000), ("f32", 70000)])
 def test_in_library_exchange_two_processes_ipc(tmp_path, dtype, N):
     """The real multi-process path: two processes share this GPU, exchange their IPC handles once over gloo, and run
     whole MPC steps with icem_plan_step_sharded -- the records move through IPC-mapped peer blocks, the only
