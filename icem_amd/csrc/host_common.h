@@ -74,6 +74,7 @@ struct icem_handle {
     bool use_fast = true;
     long long* dbg = nullptr;
     int fast_lists = 0;  // candidate lists written by the last matrix-pipe rollout (0 = generic path ran)
+    int fast_tail_rows = 0;  // ... and shifted-elite rows behind them that the merge scores through the cost array
     // icem_plan_step (world == 1): an iteration's merge can ride in the prologue of the next iteration's launch,
     // which then reads the previous pool / lists / distribution while writing new ones -> ping-pong partners of
     // the caller's actions / workspace buffers and of mean | std, owned by the handle

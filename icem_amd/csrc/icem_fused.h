@@ -68,6 +68,7 @@ struct FastRolloutArgs {
     float* part_c;  // [grid, K] sorted candidate costs / row indices of every workgroup ...
     int* part_i;
     unsigned long long* part_k;  // ... or, if not null, their packed keys, key r of workgroup w at [r * grid + w]
+    int list_wgs = 0;   // > 0: only the first list_wgs workgroups emit a list (sample_rollout_lists' tail rows)
     long long* dbg;  // development: [waves, 8] cycle stamps, nullptr in production
 };
 bool fast_rollout_supported(int h, int d, int O, int K);
@@ -171,7 +172,8 @@ struct FastIterArgs {
     PackPrev p;         // ... and its pack (sharded runs)
 };
 // workgroups (= candidate lists) of that launch; 0 if this shape / generator / size has no single-launch kernel
-int sample_rollout_lists(int h, int d, int O, int rounds, int n_rows);
+// (n_tail trailing shifted-elite rows; *tail_out > 0: that many rows behind the lists are scored through the cost array)
+int sample_rollout_lists(int h, int d, int O, int rounds, int n_rows, int n_tail = 0, int* tail_out = nullptr);
 // may iteration `it >= 1` with n_rows rows fold the previous iteration's merge into its own launch?
 bool sample_rollout_merge_ok(int h, int d, int O, int rounds, int n_rows, int K);
 void launch_sample_rollout(const FastIterArgs& a, int h, int d, int O, int kind, bool merge_prologue, hipStream_t st);

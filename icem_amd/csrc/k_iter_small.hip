@@ -94,7 +94,9 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
             return;
         }
     }
-    const int wg = blockIdx.x - (has_pack ? 1 : 0), n_wg = gridDim.x - (has_pack ? 1 : 0);
+    const int wg = blockIdx.x - (has_pack ? 1 : 0);
+    // workgroups that emit a candidate list (behind them: shifted-elite rows scored through the cost array)
+    const int n_wg = ra.list_wgs > 0 ? ra.list_wgs : (int)gridDim.x - (has_pack ? 1 : 0);
     const int base = wg * TPB;          // one slab of TPB trajectories per workgroup (launch_sample_rollout)
     if (base >= n_rows) return;
     if (ra.dbg && tid == 0 && wg == 0) ra.dbg[8] = wall_clock64();
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
             }
         }
         if (ra.dbg && tid == 0 && wg == 0) ra.dbg[13] = wall_clock64();
-        if (ra.K > 0) {   // the slab's keys -> one sorted list (one wave)
+        if (ra.K > 0 && wg < n_wg) {   // the slab's keys -> one sorted list (one wave)
             __syncthreads();
             if (wave == 0) {
                 const unsigned long long key = wave_sort64(lane < TPB ? wg_keys[0][0][lane] : KEY_SENTINEL, lane);
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
             if (ra.dbg && tid == 0 && wg == 0) ra.dbg[12] = wall_clock64();
         }
         if (ra.dbg && tid == 0 && wg == 0) ra.dbg[13] = wall_clock64();
-        if (ra.K > 0) wg_merge_emit<RW>(wg_keys, run_key, ra.K, lane, wave, ra, wg, n_wg);
+        if (ra.K > 0 && wg < n_wg) wg_merge_emit<RW>(wg_keys, run_key, ra.K, lane, wave, ra, wg, n_wg);
     }
     if (ra.dbg && tid == 0 && wg == 0) ra.dbg[14] = wall_clock64();
 }
@@ -274,22 +276,40 @@ constexpr int single_launch_max_rw(int h, int d) {
 // path).  (Several slabs per workgroup through the same LDS tile were tried for larger populations: with one
 // 92 KB tile per CU the sampling and rollout phases of a workgroup run back to back at 2-3 waves per SIMD, and
 // N=65 536 took 297 instead of 220 us per MPC step -- the two full-occupancy kernels win there.)
-static bool sample_rollout_shape(int h, int d, int O, int rounds, int n_rows, int* grid_out, int* rw_out) {
+// n_tail: the last n_tail rows are shifted elites.  Where the sampled rows alone fill exactly FAST_MAX_LISTS slabs
+// (N = 4 096 at one tile per workgroup, 8 192 at two, ...) the shifted elites get workgroups of their own BEHIND the
+// list-writing ones: those roll their rows out and store the costs but emit no list -- the merge takes the rows as
+// extra candidates straight from the cost array (its kept-elite slot, free at iteration 0; *tail_out rows from pool row
+// n on).  Otherwise three shifted rows would push the launch over the list limit and onto twice the trajectories per
+// workgroup on half the CUs (N = 4 096: 15.5 instead of 12.5 us).
+static bool sample_rollout_shape(int h, int d, int O, int rounds, int n_rows, int n_tail, int* grid_out, int* rw_out,
+                                 int* tail_out = nullptr) {
     const char* env_rw = getenv("ICEM_FUSE_MAX_RW");  // read per call: the path-equivalence test flips it between planners
     const int max_rw = env_rw ? atoi(env_rw) : 8;
-    int grid, rw;
+    int grid, rw, tail = 0;
     r16_shape(n_rows, &grid, &rw);
+    if (n_tail > 0 && n_tail <= 64) {
+        int g2, w2;
+        r16_shape(n_rows - n_tail, &g2, &w2);
+        if (w2 < rw && g2 == FAST_MAX_LISTS && n_rows - n_tail == FAST_MAX_LISTS * 16 * w2) {
+            rw = w2;
+            tail = n_tail;
+        }
+    }
     if (rounds != 10 || rw > max_rw || n_rows <= 0 || !fast_rollout_supported(h, d, O, 1) || !fast_sample_supported(h, d))
         return false;
     if (rw > single_launch_max_rw(h, d)) return false;  // one slab of 16 * rw trajectories per workgroup
-    *grid_out = std::min(grid, (n_rows + 16 * rw - 1) / (16 * rw));
+    *grid_out = tail ? (n_rows + 16 * rw - 1) / (16 * rw) : std::min(grid, (n_rows + 16 * rw - 1) / (16 * rw));
     *rw_out = rw;
+    if (tail_out) *tail_out = tail;
     return true;
 }
 
-int sample_rollout_lists(int h, int d, int O, int rounds, int n_rows) {
-    int grid, rw;
-    return sample_rollout_shape(h, d, O, rounds, n_rows, &grid, &rw) ? grid : 0;
+int sample_rollout_lists(int h, int d, int O, int rounds, int n_rows, int n_tail, int* tail_out) {
+    int grid, rw, tail = 0;
+    if (!sample_rollout_shape(h, d, O, rounds, n_rows, n_tail, &grid, &rw, &tail)) return 0;
+    if (tail_out) *tail_out = tail;
+    return tail ? FAST_MAX_LISTS : grid;
 }
 
 // merge prologue: the selection wavefront joins the sampling waves (8 rollout waves: 13 waves share the register
@@ -297,19 +317,19 @@ int sample_rollout_lists(int h, int d, int O, int rounds, int n_rows) {
 bool sample_rollout_merge_ok(int h, int d, int O, int rounds, int n_rows, int K) {
     static const int on = [] { const char* e = getenv("ICEM_MERGE_PROLOGUE"); return e ? atoi(e) : 1; }();
     int grid, rw;
-    return on && K + 1 <= 12 && sample_rollout_shape(h, d, O, rounds, n_rows, &grid, &rw);
+    return on && K + 1 <= 12 && sample_rollout_shape(h, d, O, rounds, n_rows, 0, &grid, &rw);
 }
 
 bool sample_rollout_pack_ok(int h, int d, int O, int rounds, int n_rows, int K) {
     static const int on = [] { const char* e = getenv("ICEM_RIDING_PACK"); return e ? atoi(e) : 1; }();
     int grid, rw;
-    return on && sample_rollout_merge_ok(h, d, O, rounds, n_rows, K) && sample_rollout_shape(h, d, O, rounds, n_rows, &grid, &rw) &&
+    return on && sample_rollout_merge_ok(h, d, O, rounds, n_rows, K) && sample_rollout_shape(h, d, O, rounds, n_rows, 0, &grid, &rw) &&
            K * (h * d + 2) <= 16 * rw * h * d;
 }
 
 void launch_sample_rollout(const FastIterArgs& a, int h, int d, int O, int kind, bool merge_prologue, hipStream_t st) {
     int grid, rw;
-    if (!sample_rollout_shape(h, d, O, 10, a.r.n_rows, &grid, &rw)) return;
+    if (!sample_rollout_shape(h, d, O, 10, a.r.n_rows, a.s.n_shift, &grid, &rw)) return;
     if (merge_prologue && a.m.records && a.p.part_k) grid += 1;  // workgroup 0: the riding pack
 #define XK(HH, DD, OO, WW, KR, RC)                                                                                      \
     {                                                                                                                   \

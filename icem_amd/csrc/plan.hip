@@ -335,8 +335,11 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
             float* pc;
             int* pi;
             const int n_rows = n_loc + n_extra;
+            int tail_rows = 0;  // shifted-elite rows scored through the cost array instead of a list (world 1 only)
             const int one = (fast_sample_ok(h) && (n_extra == 0 || shift_in_sampler))
-                                ? sample_rollout_lists(c.horizon, c.act_dim, h->O, c.rng_rounds, n_rows) : 0;
+                                ? sample_rollout_lists(c.horizon, c.act_dim, h->O, c.rng_rounds, n_rows,
+                                                       (c.world == 1 && shift_in_sampler) ? n_extra : 0, &tail_rows) : 0;
+            h->fast_tail_rows = one > 0 ? tail_rows : 0;
             // the merge finds the lists' indices behind `lists * K` costs
             split_partial_ws<float>(b->workspace, one > 0 ? one : rollout_lists(c.horizon, c.act_dim, h->O, n_rows), K, &pc, &pi);
             bool prologue = false, ride = false;
@@ -367,6 +370,7 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                                         shift_in_sampler ? n_extra : 0, shift_src, call_base + (uint64_t)c.opt_iters);
                 fa.r = fast_rollout_args(h, n_rows, n_cand, K, b->obs0, actions, b->costs, pc, pi);
                 fa.r.part_k = (unsigned long long*)b->workspace;  // read by merge_single_kernel / pack_records_kernel
+                fa.r.list_wgs = tail_rows > 0 ? one : 0;
                 {
                     ProfScope prof(h, ICEM_K_SAMPLE_ROLLOUT, (long long)n_rows * c.horizon, st);
                     launch_sample_rollout(fa, c.horizon, c.act_dim, h->O, h->model_kind, prologue, st);
@@ -477,6 +481,10 @@ int plan_iter_merge_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
             m.n_lists = h->fast_lists;
             m.n_keep = (it > 0 && c.keep_previous_elites) ? h->n_reuse : 0;
             const int n_extra = (it == 0 && c.shift_elites && mpc_step > 0) ? h->n_reuse : 0;
+            // iteration 0: shifted elites that sit behind the list-writing workgroups (sample_rollout_lists) come in
+            // through the kept-elite slot: costs from the cost array, rows from the pool (index n_global + e < n_pool)
+            const bool tail = it == 0 && h->fast_tail_rows > 0;
+            if (tail) m.n_keep = h->fast_tail_rows;
             m.n_pool = h->pop[it] + n_extra;
             m.n_global = h->pop[it];
             m.K = K;
@@ -490,7 +498,7 @@ int plan_iter_merge_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
             m.n_rec = 0;
             m.actions = (const float*)b->actions;
             m.elites_cur = (const float*)el + (size_t)cur * K * hd;
-            m.elites_cost_cur = (const float*)elc + (size_t)cur * K;
+            m.elites_cost_cur = tail ? (const float*)b->costs + h->pop[it] : (const float*)elc + (size_t)cur * K;
             m.elites_next = (float*)el + (size_t)nxt * K * hd;
             m.elites_cost_next = (float*)elc + (size_t)nxt * K;
             m.mean = (const float*)b->mean;
