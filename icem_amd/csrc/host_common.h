@@ -220,7 +220,7 @@ bool fast_rollout_ok(const icem_handle* h, int K);
 bool fast_sample_ok(const icem_handle* h);
 int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const void* obs0, const void* actions,
                         void* costs, float* part_c, int* part_i, hipStream_t st, int* lists_out,
-                        unsigned long long* part_k = nullptr);
+                        unsigned long long* part_k = nullptr, int n_tail = 0, int* tail_out = nullptr);
 int launch_fast_sample(const icem_handle* h, int n, long long first_index, const void* mean, const void* std,
                        const void* low, const void* high, uint64_t offset, int row0_mean, void* out, hipStream_t st,
                        int n_shift = 0, const void* elites_src = nullptr, uint64_t offset2 = 0);

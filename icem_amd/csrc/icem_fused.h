@@ -99,6 +99,9 @@ int wide_kb(int o, int d);
 int wide_xs(int o, int d);
 void pack_wide_model(int o, int d, const double* A, const double* B, std::vector<float>& Mp);
 void launch_rollout_wide(const WideRolloutArgs& a, int kind, hipStream_t st);
+// rows [row0, row0 + n_tail) of the same pool one workgroup each, from the row-major f32 model (A [o, o], B [d, o]); costs only
+void launch_rollout_rows_wide(const WideRolloutArgs& a, int row0, int n_tail, const float* A, const float* B, int kind,
+                              hipStream_t st);
 
 // world == 1: global sorted top-K straight from the waves' candidate lists (+ kept elites), gather of
 // the elite rows from the pool, refit, and the last-iteration epilogue.

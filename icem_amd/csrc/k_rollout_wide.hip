@@ -83,8 +83,8 @@ __global__ __launch_bounds__(64 * WAVES) void rollout_wide_kernel(WideRolloutArg
             // model blocks are requested ahead of the MFMAs that consume them: named register sets, the loop unrolled,
             // and scheduling barriers so that the requests stay where they are written (left alone the compiler sinks
             // them next to their first use and every block pays an L2 round trip: 2.19 instead of 1.70 ms per launch)
-            float4 mA[NQ], mB[NQ];
-            float bA, bB;
+            float4 mA[NQ], mB[NQ], mC[NQ];
+            float bA, bB, bC;
             auto request = [&](float4 (&m)[NQ], float& b, int kb) {
                 kb = kb < KB ? kb : KB - 1;
                 __builtin_amdgcn_sched_barrier(0);
@@ -102,17 +102,21 @@ __global__ __launch_bounds__(64 * WAVES) void rollout_wide_kernel(WideRolloutArg
                     acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(m[q].w, b, acc[4 * q + 3], 0, 0, 0);
                 }
             };
-            // one block in flight ahead of the one being multiplied (two register sets, the loop unrolled by two; two
-            // blocks ahead with three sets measured slower: 1.90 ms)
+            // TWO blocks in flight ahead of the one being multiplied: with four waves per CU each pulling 6 KB per block
+            // through the CU's vector-memory port a request comes back after well over the 24 x 32 = 768 cycles a
+            // block's MFMAs take -- one block ahead left part of every round trip exposed (1.97 ms per launch, this:
+            // 1.67).  Three register sets, the loop unrolled by three and branch-free (KB is a multiple of 3: wide_kb
+            // pads the model with zero blocks, which add exact zeros); the accumulators stay in AGPRs throughout.
             request(mA, bA, 0);
+            request(mB, bB, 1);
 #pragma unroll 1
-            for (int kb = 0; kb < KB; kb += 2) {
-                request(mB, bB, kb + 1);
+            for (int kb = 0; kb < KB; kb += 3) {
+                request(mC, bC, kb + 2);
                 block(mA, bA);
-                if (kb + 1 < KB) {
-                    request(mA, bA, kb + 2);
-                    block(mB, bB);
-                }
+                request(mA, bA, kb + 3);
+                block(mB, bB);
+                request(mB, bB, kb + 4);
+                block(mC, bC);
             }
             // new observation: lane (j, g) holds columns 16 ct + 4 g .. + 3 of trajectory j (columns >= o: the model's
             // zero padding, they stay 0 for the linear model and tanh(0) = 0)
@@ -150,6 +154,62 @@ __global__ __launch_bounds__(64 * WAVES) void rollout_wide_kernel(WideRolloutArg
     }
 }
 
+// A few single rows at the same widths: one workgroup per trajectory, thread c owns observation column c and runs the
+// contraction as ONE fmaf chain over k = 0 .. o + d - 1 from the row-major model -- the chain an f32 MFMA executes over
+// its slots, blocks in rollout_wide_kernel's order, so the costs are the bits the tile kernel would produce for the row
+// (the zero padding blocks add exact zeros).  For the handful of shifted elites (icem.py:131-137) that would otherwise
+// open a 16-row tile of their own: at N = 16 384 that tile is number 1 025 on 1 024 wavefront slots and doubles the
+// launch (2.47 instead of 1.26 ms); these rows take ~0.1 ms.
+struct WideRowsArgs {
+    int row0, n_tail, o, d, h, cost_mode, lin_idx, flip_idx;
+    float ctrl_w, lin_w, flip_pen, flip_th;
+    const float* A;  // [o, o] row-major
+    const float* B;  // [d, o]
+    const float* obs0;
+    const float* actions;
+    float* costs;
+};
+
+template <int KIND>
+__global__ __launch_bounds__(384) void rollout_rows_wide_kernel(WideRowsArgs a) {
+    __shared__ float x[2][448];  // [obs | action], double buffered over the steps
+    const int c = threadIdx.x, o = a.o, d = a.d, H = a.h;
+    const int row = a.row0 + blockIdx.x;
+    x[0][c] = c < o ? a.obs0[c] : 0.f;
+    const float ksum = a.cost_mode == 0 ? 1.f : 0.f;
+    float acc_s = 0.f, acc_b = INFINITY;
+    for (int t = 0; t < H; ++t) {
+        float* xc = x[t & 1];
+        if (c < d) xc[o + c] = a.actions[((size_t)row * H + t) * d + c];
+        __syncthreads();
+        if (c == 0) {  // step cost from the pre-action observation, rollout_wide_kernel's expression
+            float cst = 0.f;
+            if (a.flip_idx >= 0) {
+                const float ang = xc[a.flip_idx];
+                cst += (ang > a.flip_th) ? a.flip_pen : 0.f;
+                cst += (ang < -a.flip_th) ? a.flip_pen : 0.f;
+            }
+            float u = 0.f;
+            for (int e = 0; e < d; ++e) u = __builtin_fmaf(xc[o + e], xc[o + e], u);
+            cst = __builtin_fmaf(u, a.ctrl_w, cst);
+            if (a.lin_w != 0.f) cst = __builtin_fmaf(a.lin_w, xc[a.lin_idx], cst);
+            acc_s = __builtin_fmaf(acc_s, ksum, cst);
+            acc_b = cst < acc_b ? cst : acc_b;
+        }
+        if (c < o) {
+            float acc = 0.f;
+            const float* Ac = a.A + c;
+#pragma unroll 8
+            for (int k = 0; k < o; ++k) acc = __builtin_fmaf(Ac[(size_t)k * o], xc[k], acc);
+            const float* Bc = a.B + c;
+#pragma unroll 4
+            for (int k = 0; k < d; ++k) acc = __builtin_fmaf(Bc[(size_t)k * o], xc[o + k], acc);
+            x[(t & 1) ^ 1][c] = KIND == 1 ? fast_tanh(acc) : acc;
+        }
+    }
+    if (c == 0) a.costs[row] = a.cost_mode == 1 ? acc_b : acc_s;
+}
+
 }  // namespace
 
 bool wide_rollout_supported(int o, int d, int K) { return o > 32 && o <= 384 && d >= 1 && d <= 64 && K <= 32; }
@@ -157,7 +217,8 @@ bool wide_rollout_supported(int o, int d, int K) { return o > 32 && o <= 384 && 
 int wide_rollout_lists(int n_rows) { return std::min(std::max(1, (n_rows + 15) / 16), FAST_MAX_LISTS); }
 
 // contraction rows of the packed model: [obs (o) | act (d)] padded to whole 4-blocks; X row stride in floats
-int wide_kb(int o, int d) { return (o + d + 3) / 4; }
+// (a multiple of 3: rollout_wide_kernel's block loop is unrolled by three; the padding blocks are zero)
+int wide_kb(int o, int d) { return ((o + d + 3) / 4 + 2) / 3 * 3; }
 int wide_xs(int o, int d) { return 4 * wide_kb(o, d) + 4; }
 int wide_nt(int o) { const int nt = (o + 15) / 16; return nt <= 4 ? 4 : nt <= 8 ? 8 : nt <= 16 ? 16 : 24; }
 
@@ -197,6 +258,17 @@ void launch_rollout_wide(const WideRolloutArgs& a, int kind, hipStream_t st) {
     }
     XW(4) XW(8) XW(16) XW(24)
 #undef XW
+}
+
+void launch_rollout_rows_wide(const WideRolloutArgs& w, int row0, int n_tail, const float* A, const float* B, int kind,
+                              hipStream_t st) {
+    if (n_tail <= 0) return;
+    WideRowsArgs a{row0, n_tail, w.o, w.d, w.h, w.cost_mode, w.lin_idx, w.flip_idx, w.ctrl_w, w.lin_w, w.flip_pen, w.flip_th,
+                   A, B, w.obs0, w.actions, w.costs};
+    if (kind == 1)
+        hipLaunchKernelGGL((rollout_rows_wide_kernel<1>), dim3(n_tail), dim3(384), 0, st, a);
+    else
+        hipLaunchKernelGGL((rollout_rows_wide_kernel<0>), dim3(n_tail), dim3(384), 0, st, a);
 }
 
 }  // namespace icem

@@ -30,6 +30,19 @@ int ensure_fast_model(icem_handle* h) {
         if (h->Mw_dev) (void)hipFree(h->Mw_dev);
         ICEM_HIP_TRY(hipMalloc(&h->Mw_dev, Mw.size() * sizeof(float)));
         ICEM_HIP_TRY(hipMemcpy(h->Mw_dev, Mw.data(), Mw.size() * sizeof(float), hipMemcpyHostToDevice));
+        // ... and row-major in f32 for the rows rolled out one by one (rollout_rows_wide_kernel)
+        auto upload_f32 = [](void** dev, const std::vector<double>& host) -> int {
+            std::vector<float> tmp(host.begin(), host.end());
+            if (*dev) (void)hipFree(*dev);
+            *dev = nullptr;
+            ICEM_HIP_TRY(hipMalloc(dev, tmp.size() * sizeof(float)));
+            ICEM_HIP_TRY(hipMemcpy(*dev, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice));
+            return ICEM_OK;
+        };
+        int rc = upload_f32(&h->A_dev, h->A_host);
+        if (rc) return rc;
+        rc = upload_f32(&h->B_dev, h->B_host);
+        if (rc) return rc;
         h->fast_model_ready = true;
         return ICEM_OK;
     }
@@ -109,10 +122,20 @@ FastRolloutArgs fast_rollout_args(const icem_handle* h, int n_rows, int n_cand, 
 // rows -> costs (+ one sorted candidate list per workgroup when K > 0); returns the number of candidate lists
 int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const void* obs0, const void* actions,
                         void* costs, float* part_c, int* part_i, hipStream_t st, int* lists_out,
-                        unsigned long long* part_k) {
+                        unsigned long long* part_k, int n_tail, int* tail_out) {
     int rc = ensure_fast_model(h);
     if (rc) return rc;
+    if (tail_out) *tail_out = 0;
     if (h->wide) {
+        // trailing shifted elites that would open a tile of their own: rolled out row by row (rollout_rows_wide_kernel),
+        // scored by the merge through the cost array (tail_out rows; the caller's merge takes them as extra candidates)
+        const bool split_tail = tail_out && n_tail > 0 && n_tail <= 64 && n_cand == n_rows && (n_rows - n_tail) % 16 == 0 &&
+                                n_rows - n_tail > 0 && h->cfg.dtype == ICEM_F32;
+        if (split_tail) {
+            n_rows -= n_tail;
+            n_cand = n_rows;
+            *tail_out = n_tail;
+        }
         WideRolloutArgs w{};
         w.n_rows = n_rows;
         w.n_cand = n_cand;
@@ -139,6 +162,7 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
         {
             ProfScope prof(h, ICEM_K_ROLLOUT, (long long)n_rows * h->cfg.horizon, st);
             launch_rollout_wide(w, h->model_kind, st);
+            if (split_tail) launch_rollout_rows_wide(w, n_rows, n_tail, (const float*)h->A_dev, (const float*)h->B_dev, h->model_kind, st);
         }
         ICEM_HIP_TRY(hipGetLastError());
         if (lists_out) *lists_out = wide_rollout_lists(n_rows);
@@ -397,9 +421,11 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                     rc = gk_sample(h, n_loc, lo, b->mean, b->std, b->low, b->high, nullptr, nullptr, off, 0, row0, actions, st);
                 }
                 if (rc) return rc;
+                int tail2 = 0;
                 rc = launch_fast_rollout(h, n_rows, n_cand, K, b->obs0, actions, b->costs, pc, pi, st, &lists,
-                                         (unsigned long long*)b->workspace);
+                                         (unsigned long long*)b->workspace, (c.world == 1 && it == 0) ? n_extra : 0, &tail2);
                 if (rc) return rc;
+                h->fast_tail_rows = tail2;
             }
             h->fast_lists = lists;
             if (c.world > 1) {

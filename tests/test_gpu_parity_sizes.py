@@ -160,6 +160,44 @@ def test_full_loop_at_benchmark_size_against_oracle_on_device_normals(N, iters, 
         assert np.array_equal(np_(fused.actions[:n_last]), np_(split.actions[:n_last]))
 
 
+@pytest.mark.parametrize("kind,mode", [(1, "sum"), (0, "best")])
+def test_wide_shifted_elite_rows_equal_the_tile_kernel_bit_for_bit(kind, mode):
+    """o = 378: the shifted elites of iteration 0 (icem.py:131-137) would open a 16-row tile of their own behind a
+    population that fills whole tiles; they are rolled out row by row instead (rollout_rows_wide_kernel: one fmaf chain
+    per observation column in the matrix pipe's order) and reach the merge through the cost array.  Their costs are the
+    bits the tile kernel produces for the same rows, and the step's result is the one the all-tiles path gives
+    (N not a multiple of 16: the same rows inside a tile)."""
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, humanoid_standup_env
+    o, d, h = 378, 17, 30
+    env = humanoid_standup_env(o)
+    model = DeviceSyntheticModel.make(o, d, kind=kind)
+
+    def mk(N):
+        pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=N, opt_iters=2, dtype="f32", seed=3, noise_beta=2.0,
+                                    cost_mode=mode), env.action_space.low, env.action_space.high)
+        pl.set_model(model.kind, model.A, model.B)
+        pl.set_cost_spec(env.cost_spec)
+        pl.reset()
+        return pl
+    pl = mk(64)
+    n_reuse = pl.n_reuse
+    assert n_reuse > 0
+    seen = {}
+
+    def on_iteration(it):
+        if it == 0:
+            seen["costs"] = pl.costs[:64 + n_reuse].clone()
+            seen["actions"] = pl.actions[:64 + n_reuse].clone()
+    for s in range(2):
+        obs = 0.1 * np.random.RandomState(s).randn(o)
+        pl.plan_step(obs, on_iteration=on_iteration)
+    tile = pl.rollout_cost(obs, seen["actions"])          # every row through rollout_wide_kernel's tiles
+    assert torch.equal(tile, seen["costs"])
+    # the elites of iteration 0 come out of pool costs either way: same selection as a host top-k of those costs
+    idx = O.topk_sorted(seen["costs"].cpu().numpy(), pl.K)
+    assert idx.max() < 64 + n_reuse
+
+
 def test_box_muller_residual_is_the_only_f32_term_the_oracle_cannot_restate():
     """The looser bounds of the Philox-mode tests in test_gpu_parity.py (rtol 2e-4 / 5e-4) are the RNG-only residual:
     the device's normals differ from the oracle's float32 Box-Muller by the hardware transcendentals (measured here,
