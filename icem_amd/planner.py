@@ -380,8 +380,19 @@ class IcemPlanner:
         oks = [None] * self.cfg.world
         dist.all_gather_object(oks, err is None, group=group)
         if all(oks):
+            # ... and it has to WORK, not only map: a few real exchanges (every rank pushes to every rank and waits for
+            # all of them); a rank whose waits time out (peer stores that never land) sends everybody back as well
             self._exchange = True
-            return True
+            try:
+                self.exchange_probe(rounds=4)
+                ok = self.exchange_status()[0] == 0
+            except L.IcemError as e:
+                ok, err = False, e
+            dist.all_gather_object(oks, ok, group=group)
+            if all(oks):
+                return True
+            if err is None:
+                err = L.IcemError(-3, "the exchange self-test timed out on a rank")
         self.lib.icem_exchange_disable(self._h)
         self._exchange = False
         self.exchange_error = str(err) if err is not None else "a peer failed to connect"
