@@ -1618,7 +1618,10 @@ def test_in_library_exchange_wait_is_bounded(monkeypatch):
 
 @pytest.mark.parametrize("h,d,o,kind,mode,N,iters", [(30, 6, 17, 0, "sum", 4096, 5), (30, 6, 17, 1, "best", 1000, 3), (30, 6, 18, 1, "sum", 8000, 3),
                                                      (12, 6, 17, 0, "final", 300, 4), (13, 4, 17, 1, "sum", 5001, 3), (30, 6, 17, 0, "sum", 17, 2),
-                                                     (30, 17, 24, 1, "sum", 2000, 2)])
+                                                     (30, 17, 24, 1, "sum", 2000, 2),
+                                                     # populations that fill the 256 slabs exactly: from the second MPC step on the
+                                                     # shifted elites sit in list-less workgroups behind them (2 and 4 tiles per slab)
+                                                     (30, 6, 17, 0, "sum", 8192, 2), (30, 6, 17, 1, "best", 16384, 2)])
 def test_small_population_kernel_equals_two_kernel_path(h, d, o, kind, mode, N, iters, monkeypatch):
     """The small-population launch (k_iter_small.hip: a row sampled by a quad of lanes with DPP exchange of its draws,
     rollout on Tile4 = VALU + DPP row broadcast, four trajectories per wave) against the sampler + rollout16 kernels
