@@ -18,7 +18,8 @@
 //   * the step cost (icem_cost_spec: control cost + linear + flip terms of the PRE-action observation) is read from X
 //     by lanes 0..15; costs and the wave's running sorted top-K as in k_rollout.hip; one candidate list per workgroup.
 // The arithmetic is exact f32, so the tolerance against the float64 oracle is the 1e-5 of every other f32 kernel.
-// A bf16 x 3 split on v_mfma_f32_16x16x32_bf16 (6 products per MAC at 16 x the rate) is the next step for this kernel.
+// (A bf16 x 3-plane split on v_mfma_f32_16x16x32_bf16 would need 94 B/clk of model operands per CU at this tiling --
+// more than the L2 port delivers: DESIGN.md section 4.)
 #include "fused_dev.h"
 
 namespace icem {
