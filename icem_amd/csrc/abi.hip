@@ -163,6 +163,7 @@ int icem_destroy(icem_handle* h) {
     if (h->B_dev) (void)hipFree(h->B_dev);
     if (h->Mp_dev) (void)hipFree(h->Mp_dev);
     if (h->Mw_dev) (void)hipFree(h->Mw_dev);
+    if (h->pub_dev) (void)hipFree(h->pub_dev);
     if (h->perm_dev) (void)hipFree(h->perm_dev);
     for (auto& sp : h->spans) {
         (void)hipEventDestroy(sp.a);

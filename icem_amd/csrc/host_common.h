@@ -108,6 +108,8 @@ struct icem_handle {
     // (workgroup 0 of sample_rollout_kernel) instead of being a launch of its own
     bool pk_pending = false;
     icem::PackPrev pk_args;
+    float* pub_dev = nullptr;        // published merge (PackPrev::pub): [2 * hd] floats, then the flag word
+    unsigned pub_seq = 0;
 };
 
 namespace icem {

@@ -152,6 +152,11 @@ struct PackPrev {
     int n_loc = 0, shard_lo = 0;
     float* records = nullptr;                    // this rank's [K, 2 + h*d] records
     XchgPush px;
+    // sample_folded_merge_kernel only ("published merge"): workgroup 0 also runs the launch's one records merge and
+    // publishes mean | std here (written through), then stores pub_seq to pub_flag; the other workgroups wait for that
+    float* pub = nullptr;                        // [2 * h*d]; nullptr: every workgroup merges for itself
+    unsigned* pub_flag = nullptr;
+    unsigned pub_seq = 0;
 };
 // may the merge-prologue launch of an iteration with n_rows local rows carry the previous iteration's pack? (the
 // single-launch kernel or the sampler of the two-kernel path; the records must fit the workgroup's tile)

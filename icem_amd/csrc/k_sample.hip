@@ -120,9 +120,39 @@ __global__ __launch_bounds__(SWG + 64) void sample_folded_merge_kernel(FastSampl
             if (tid >= SWG) merge_select_stream(pk, lane, cand, sel);
             __syncthreads();
             pack_records_body<KREG>(pk, args.p.n_loc, args.p.shard_lo, args.p.records, args.p.px, smem, sel, tid, NTT);
+            if (args.p.pub != nullptr) {
+                // Published merge: this workgroup also runs THE merge of the launch -- waits for every rank's records,
+                // selects, gathers, refits -- and publishes the new mean | std to all the others (written through: the
+                // XCDs' L2s are not coherent inside a launch; then one agent-scope flag).  Hundreds of workgroups each
+                // reading the same 7 KB of records from uncached memory was the slowest part of this launch.
+                __syncthreads();
+                if (tid >= SWG) merge_select_records(m, lane, cand, sel, slot);
+                __syncthreads();
+                const float* rows[KREG];
+                merge_rows<KREG, true>(m, sel, slot, rows);
+                for (int e = tid; e < hd; e += NTT) {
+                    float xs[KREG];
+#pragma unroll
+                    for (int r = 0; r < KREG; ++r) xs[r] = rows[r][e];
+                    float nm, ns;
+                    refit_element_regs<float, KREG>(m.K, m.alpha, m.mean[e], m.std[e], xs, nm, ns);
+                    __hip_atomic_store(args.p.pub + e, nm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(args.p.pub + hd + e, ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    m.mean_out[e] = nm;
+                    m.std_out[e] = ns;
+#pragma unroll
+                    for (int r = 0; r < KREG; ++r)
+                        if (r < m.K) m.elites_next[(size_t)r * hd + e] = xs[r];
+                }
+                if (tid < m.K) m.elites_cost_next[tid] = key_cost(sel[tid]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(args.p.pub_flag, args.p.pub_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             return;
         }
     }
+    const bool published = REC && has_pack && args.p.pub != nullptr;
     const int wg = blockIdx.x - (has_pack ? 1 : 0);
     const int n_base = wg * tpw;
     const int n_here = cmin(tpw, a.n - n_base);
@@ -131,16 +161,26 @@ __global__ __launch_bounds__(SWG + 64) void sample_folded_merge_kernel(FastSampl
     const int j = tid - nl * d;
     float* trow = tile + nl * hd + j;
     if (tid >= SWG) {
-        if constexpr (REC)
+        if (published) {  // workgroup 0 merges for everybody: wait for its flag (bounded like every exchange wait)
+            unsigned polls = 0;
+            while (__hip_atomic_load(args.p.pub_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != args.p.pub_seq &&
+                   ++polls <= args.m.xw.max_polls)
+                __builtin_amdgcn_s_sleep(16);
+            if (polls > args.m.xw.max_polls && lane == 0 && args.m.xw.status)
+                __hip_atomic_store(args.m.xw.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else if constexpr (REC) {
             merge_select_records(m, lane, cand, sel, slot);
-        else
+        } else {
             merge_select_stream(m, lane, cand, sel);
+        }
     } else if (has_row) {
         sample_row<H, ROUNDS>(a.W, (unsigned)(a.first_index + n_base + nl), (unsigned)j, a.off_lo, a.off_hi, a.seed_lo,
                               a.seed_hi, [&](int t, float y) { trow[t * d] = y; }, a.white != 0);
     }
     __syncthreads();
-    {
+    if (published) {
+        for (int e = tid; e < 2 * hd; e += NTT) ms[e] = __hip_atomic_load(args.p.pub + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
         const float* rows[KREG];
         merge_rows<KREG, REC>(m, sel, slot, rows);
         for (int e = tid; e < hd; e += NTT) {

@@ -407,7 +407,20 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                     FastSampleMergeArgs sm;
                     sm.s = fast_sample_args(h, n_loc, lo, b->mean, b->std, b->low, b->high, off, row0, actions, 0, nullptr, 0);
                     sm.m = h->pm_args;
-                    if (ride) sm.p = h->pk_args;
+                    if (ride) {
+                        sm.p = h->pk_args;
+                        // published merge: workgroup 0 merges the records once and publishes mean | std to the rest
+                        static const int pub_on = [] { const char* e = getenv("ICEM_PUBLISHED_MERGE"); return e ? atoi(e) : 1; }();
+                        if (pub_on && sm.m.records) {
+                            if (!h->pub_dev) {
+                                ICEM_HIP_TRY(hipMalloc((void**)&h->pub_dev, ((size_t)2 * hd + 16) * sizeof(float)));
+                                ICEM_HIP_TRY(hipMemsetAsync(h->pub_dev, 0, ((size_t)2 * hd + 16) * sizeof(float), st));
+                            }
+                            sm.p.pub = h->pub_dev;
+                            sm.p.pub_flag = reinterpret_cast<unsigned*>(h->pub_dev + 2 * hd);
+                            sm.p.pub_seq = ++h->pub_seq;
+                        }
+                    }
                     {
                         ProfScope prof(h, ICEM_K_SAMPLE, (long long)n_loc * c.horizon, st);
                         launch_sample_folded_merge(sm, st);
