@@ -31,8 +31,11 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# the host driver only supports dmabuf IPC: without this RCCL and the exchange's hipIpc handles fail (read at HSA start-up)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # CPU-baseline threads sleep between parallel regions
 

@@ -3,6 +3,9 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+
+# dmabuf IPC (hipIpcGetMemHandle of the exchange blocks, RCCL): must be in the environment before the HSA runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
