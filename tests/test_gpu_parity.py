@@ -1552,7 +1552,7 @@ def test_in_library_exchange_emulated_worlds(world, N, dtype, deferral):
         assert pl.exchange_status()[0] == 0
 
 
-def _xchg_worker(rank, world, port, out_dir, dtype, N=2000):
+def _xchg_worker(rank, world, port, out_dir, dtype, N=2000, steps=3):
     import os
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -1562,7 +1562,7 @@ def _xchg_worker(rank, world, port, out_dir, dtype, N=2000):
         pl = _xchg_planner(rank, world, dtype, N, 3, seed=21, kind=0)
         pl.connect_exchange()
         acts = []
-        for s in range(3):
+        for s in range(steps):
             acts.append(np_(pl.plan_step(0.1 * np.random.RandomState(s).randn(17))).copy())  # icem_plan_step_sharded
         torch.cuda.synchronize()
         status, fine = pl.exchange_status()
@@ -1595,6 +1595,31 @@ def test_in_library_exchange_two_processes_ipc(tmp_path, dtype, N):
         assert np.array_equal(z["acts"], acts)
         assert np.array_equal(z["mean"], np_(pl.mean))
         assert 0 < float(z["us"]) < 1e5
+
+
+@pytest.mark.soak
+@pytest.mark.parametrize("N", [12000, 70000])
+def test_soak_two_processes_ipc_many_steps(tmp_path, N):
+    """The two-process run over many MPC steps (ICEM_SOAK_STEPS, default 150): every step of every rank bit-equal to the
+    single-process run -- the riding pack, the published merge and their flags / written-through stores under
+    repetition (a stale read would show up as one differing step)."""
+    import os
+    import socket
+    import torch.multiprocessing as mp
+    steps = int(os.environ.get("ICEM_SOAK_STEPS", "150"))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_xchg_worker, args=(2, port, str(tmp_path), "f32", N, steps), nprocs=2, join=True)
+    pl = _xchg_planner(0, 1, "f32", N, 3, seed=21, kind=0)
+    acts = np.array([np_(pl.plan_step(0.1 * np.random.RandomState(s).randn(17))).copy() for s in range(steps)])
+    for r in range(2):
+        z = np.load(tmp_path / f"r{r}.npz")
+        assert int(z["status"]) == 0
+        bad = np.flatnonzero((z["acts"] != acts).any(axis=1))
+        assert bad.size == 0, f"rank {r}: steps {bad[:10]} differ"
+        assert np.array_equal(z["mean"], np_(pl.mean))
 
 
 def test_in_library_exchange_wait_is_bounded(monkeypatch):
