@@ -351,6 +351,11 @@ int icem_topk_sorted(icem_handle* h, int32_t n, const void* costs, int32_t k, vo
     if (n < 1 || k < 1 || k > ICEM_MAX_ELITES || !costs || !out_cost || !out_idx || !workspace)
         return fail(ICEM_E_INVALID, "bad n/k or null tensor");
     hipStream_t st = (hipStream_t)stream;
+    if (h->use_fast && h->cfg.dtype == ICEM_F32 && topk_small_ok(n, k)) {  // small f32 pools: one launch
+        launch_topk_small((const float*)costs, n, k, (float*)out_cost, out_idx, st);
+        ICEM_HIP_TRY(hipGetLastError());
+        return ICEM_OK;
+    }
     return gk_topk(h, n, k, costs, out_cost, out_idx, workspace, st);
 }
 

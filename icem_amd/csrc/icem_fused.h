@@ -134,6 +134,9 @@ struct MergeSingleArgs {
     long long* dbg;  // development: 8 wall_clock64 stamps (100 MHz) of thread 0, nullptr in production
 };
 void launch_merge_single(const MergeSingleArgs& a, hipStream_t st);
+// sorted top-K of a small f32 cost array in one launch (icem_topk_sorted's fast path)
+bool topk_small_ok(int n, int K);
+void launch_topk_small(const float* costs, int n, int K, float* out_c, int* out_i, hipStream_t st);
 // sharded runs: the rank's K best of its candidate lists (part_k / actions / n_lists / n_keep = 0 of `a`) -> records [K, 2 + h*d]
 // px.peers != nullptr (allowed when pack_can_push): the records also go into every rank's exchange block, followed by the
 // flags -- pack and push in one launch
