@@ -96,6 +96,7 @@ SYMBOLS = [
     ("icem_topk_workspace_bytes", _SZ, [_H, _I32, _I32]),
     ("icem_topk_sorted", C.c_int, [_H, _I32, _VP, _I32, _VP, _VP, _VP, _VP]),
     ("icem_gather_refit", C.c_int, [_H, _VP, _VP, _I32, _VP, _VP, _VP, _VP]),
+    ("icem_update_distribution", C.c_int, [_H, _I32, _VP, _VP, _I32, _VP, _VP, _I32, _VP, _VP, _VP, _VP, _VP, _VP]),
     ("icem_shift", C.c_int, [_H, _VP, _VP, _VP, _VP, _VP]),
     ("icem_reset_distribution", C.c_int, [_H, _VP, _VP, _VP, _VP, _VP]),
     ("icem_plan_buffer_bytes", _SZ, [_H, _I32]),

@@ -515,11 +515,18 @@ class MpcICemHip(MpcController):
                 actions = torch.cat([actions, shifted], dim=0)
             costs = self._costs_of(obs, actions)
             pool = actions
-            if i > 0 and self.keep_previous_elites:
-                pool = torch.cat([actions, self._elite_actions[:p.n_reuse]], dim=0)
-                costs = torch.cat([costs, self._elite_costs[:p.n_reuse]])
-            costs_dev, idx = p.topk_sorted(costs, K)
-            self._elite_actions = p.gather_refit(pool, idx, p.mean, p.std)
+            keep = i > 0 and self.keep_previous_elites and p.n_reuse > 0
+            if p.can_update_in_one_launch(actions.shape[0] + (p.n_reuse if keep else 0), K):
+                # top-K over [pool | kept elites] + gather + refit in one launch, nothing concatenated
+                costs_dev, idx, self._elite_actions = p.update_distribution(
+                    costs, actions, K, p.mean, p.std,
+                    self._elite_costs[:p.n_reuse] if keep else None, self._elite_actions[:p.n_reuse] if keep else None)
+            else:
+                if keep:
+                    pool = torch.cat([actions, self._elite_actions[:p.n_reuse]], dim=0)
+                    costs = torch.cat([costs, self._elite_costs[:p.n_reuse]])
+                costs_dev, idx = p.topk_sorted(costs, K)
+                self._elite_actions = p.gather_refit(pool, idx, p.mean, p.std)
             self._elite_costs = costs_dev
         p.shift(p.mean, p.std)
         p.mpc_step += 1
@@ -632,8 +639,11 @@ class MpcCemStdHip(MpcController):
             actions = p.sample_truncnorm(self.num_sim_traj, self._mean, self._std, self._lower, self._upper, u,
                                          offset=p.noise_offset(p.mpc_step * self.opt_iter + i))
             costs = self._costs_of(obs, actions)
-            costs_sorted, idx = p.topk_sorted(costs, self.num_elites)      # mpc.py:270
-            self._elite_actions = p.gather_refit(actions, idx, self._mean, self._std)  # mpc.py:271-281
+            if p.can_update_in_one_launch(actions.shape[0], self.num_elites):  # mpc.py:270-281 in one launch
+                costs_sorted, idx, self._elite_actions = p.update_distribution(costs, actions, self.num_elites, self._mean, self._std)
+            else:
+                costs_sorted, idx = p.topk_sorted(costs, self.num_elites)      # mpc.py:270
+                self._elite_actions = p.gather_refit(actions, idx, self._mean, self._std)  # mpc.py:271-281
             self._elite_costs = costs_sorted
             self._lower, self._upper = p.cem_bounds(self._mean, self._std, self.like_levine)
         if self.execute_best_elite:                                        # mpc.py:230-233

@@ -359,6 +359,23 @@ int icem_topk_sorted(icem_handle* h, int32_t n, const void* costs, int32_t k, vo
     return gk_topk(h, n, k, costs, out_cost, out_idx, workspace, st);
 }
 
+int icem_update_distribution(icem_handle* h, int32_t n, const void* costs, const void* pool, int32_t n_keep,
+                             const void* keep_costs, const void* keep_actions, int32_t k, void* mean, void* std,
+                             void* elites_out, void* elite_costs_out, int32_t* idx_out, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (n < 1 || k < 1 || n_keep < 0 || !costs || !pool || !mean || !std || !elites_out || !elite_costs_out || !idx_out ||
+        (n_keep > 0 && (!keep_costs || !keep_actions)))
+        return fail(ICEM_E_INVALID, "bad n / k / n_keep or null tensor");
+    if (elites_out == keep_actions) return fail(ICEM_E_INVALID, "elites_out must not alias keep_actions");
+    if (!h->use_fast || h->cfg.dtype != ICEM_F32 || !topk_small_ok(n + n_keep, k))
+        return fail(ICEM_E_UNSUPPORTED, "one-launch update: f32, n + n_keep <= 16384, k <= 32 (else icem_topk_sorted + icem_gather_refit)");
+    UpdateSmallArgs a{(const float*)costs, (const float*)pool, (const float*)keep_costs, (const float*)keep_actions, n, n_keep, k,
+                      h->hd, (float)h->cfg.alpha, (float*)mean, (float*)std, (float*)elites_out, (float*)elite_costs_out, idx_out};
+    launch_update_small(a, (hipStream_t)stream);
+    ICEM_HIP_TRY(hipGetLastError());
+    return ICEM_OK;
+}
+
 int icem_gather_refit(icem_handle* h, const void* actions, const int32_t* idx, int32_t k, void* mean, void* std,
                       void* elites_out, void* stream) {
     if (check_handle(h)) return ICEM_E_INVALID;

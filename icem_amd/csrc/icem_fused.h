@@ -134,6 +134,22 @@ struct MergeSingleArgs {
     long long* dbg;  // development: 8 wall_clock64 stamps (100 MHz) of thread 0, nullptr in production
 };
 void launch_merge_single(const MergeSingleArgs& a, hipStream_t st);
+// icem_update_distribution for small f32 pools (topk_small_ok(n + n_keep, K)): top-K over [costs | keep_costs], gather from
+// [pool | keep_actions], refit of mean / std in place -- one launch
+struct UpdateSmallArgs {
+    const float* costs;         // [n]
+    const float* pool;          // [n, hd]
+    const float* keep_costs;    // [n_keep] or nullptr
+    const float* keep_actions;  // [n_keep, hd]
+    int n, n_keep, K, hd;
+    float alpha;
+    float* mean;                // [hd], in place
+    float* std;
+    float* elites_out;          // [K, hd] (must not alias keep_actions)
+    float* elite_costs_out;     // [K]
+    int* idx_out;               // [K] indices into [pool | kept elites]
+};
+void launch_update_small(const UpdateSmallArgs& a, hipStream_t st);
 // sorted top-K of a small f32 cost array in one launch (icem_topk_sorted's fast path)
 bool topk_small_ok(int n, int K);
 void launch_topk_small(const float* costs, int n, int K, float* out_c, int* out_i, hipStream_t st);

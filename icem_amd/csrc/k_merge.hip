@@ -2,6 +2,7 @@
 // all-gathered records, elite gather, refit, last-iteration epilogue; one workgroup, wave 0 selects) and
 // pack_records_kernel (sharded runs: this rank's K best as records for the exchange).
 #include "fused_dev.h"
+#include "refit.h"
 
 namespace icem {
 
@@ -122,7 +123,58 @@ __global__ __launch_bounds__(1024) void topk_small_kernel(const float* costs, in
     wg_merge_emit<16>(wg_keys, run, K, lane, wave, fr, 0, 1);
 }
 
+// icem_update_distribution: the reference's update_distributions in ONE launch for small f32 pools -- the sorted top-K
+// over the pool's costs and the kept elites' (icem.py:143-145: appended behind the pool, index n + e), the gather of the
+// K elite rows from pool / kept elites, the refit (refit.h: the arithmetic of gather_refit_kernel).  Phase 1 + 2 are
+// topk_small_kernel's; the selection lands in LDS (wg_merge_emit's list 0 of 1, through a generic pointer).
+__global__ __launch_bounds__(1024) void update_small_kernel(UpdateSmallArgs a) {
+    __shared__ unsigned long long wg_keys[2][16][32];
+    __shared__ unsigned long long sel[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_all = a.n + a.n_keep;
+    unsigned long long run = KEY_SENTINEL;
+    bool first = true;
+    for (int base = wave * 64; base < n_all; base += 1024) {
+        const int i = base + lane;
+        unsigned long long key = KEY_SENTINEL;
+        if (i < n_all) key = make_key(i < a.n ? a.costs[i] : a.keep_costs[i - a.n], i);
+        key = wave_sort64(key, lane);
+        if (!first) {
+            const unsigned long long prev = __shfl(run, lane - 32, 64);
+            key = (lane >= 32 && lane < 32 + a.K) ? prev : (lane < a.K ? key : KEY_SENTINEL);
+            key = wave_sort64(key, lane);
+        }
+        run = key;
+        first = false;
+    }
+    FastRolloutArgs fr{};
+    fr.part_k = sel;
+    wg_merge_emit<16>(wg_keys, run, a.K, lane, wave, fr, 0, 1);
+    __syncthreads();
+    if (tid < a.K) {
+        a.elite_costs_out[tid] = key_cost(sel[tid]);
+        a.idx_out[tid] = key_idx(sel[tid]);
+    }
+    // a padded selection (fewer than K candidates: (+inf, INT_MAX)) repeats its best row, as icem_gather_refit does
+    auto row = [&](int r) -> const float* {
+        int i = key_idx(sel[r]);
+        if (i < 0 || i == INT_MAX) i = key_idx(sel[0]);
+        return i < a.n ? a.pool + (size_t)i * a.hd : a.keep_actions + (size_t)(i - a.n) * a.hd;
+    };
+    for (int e = tid; e < a.hd; e += 1024) {
+        for (int r = 0; r < a.K; ++r) a.elites_out[(size_t)r * a.hd + e] = row(r)[e];
+        float nm, ns;
+        refit_element<float>(a.K, a.alpha, a.mean[e], a.std[e], [&](int r) { return row(r)[e]; }, nm, ns);
+        a.mean[e] = nm;
+        a.std[e] = ns;
+    }
+}
+
 }  // namespace
+
+void launch_update_small(const UpdateSmallArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(update_small_kernel, dim3(1), dim3(1024), 0, st, a);
+}
 
 bool topk_small_ok(int n, int K) { return n >= 1 && n <= 16384 && K >= 1 && K <= 32; }
 

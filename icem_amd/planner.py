@@ -7,6 +7,7 @@ call site it replaces (paths relative to ``/root/reference``).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Callable, Optional, Sequence, Tuple
 
@@ -268,6 +269,29 @@ class IcemPlanner:
         L.check(self.lib.icem_gather_refit(self._h, _ptr(actions), _ptr(idx), k, _ptr(mean), _ptr(std), _ptr(elites),
                                            self._stream()))
         return elites
+
+    def can_update_in_one_launch(self, n_all: int, k: int) -> bool:
+        """``icem_update_distribution`` serves f32 handles, pools of at most 16 384 candidates and k <= 32."""
+        return self.cfg.dtype == "f32" and 1 <= n_all <= 16384 and 1 <= k <= 32 and not os.environ.get("ICEM_DISABLE_FAST")
+
+    def update_distribution(self, costs: torch.Tensor, pool: torch.Tensor, k: int, mean: torch.Tensor, std: torch.Tensor,
+                            keep_costs: Optional[torch.Tensor] = None, keep_actions: Optional[torch.Tensor] = None):
+        """``update_distributions`` (icem/controllers/icem.py:194-211) with the kept elites appended behind the pool
+        (icem.py:143-145) in ONE launch: -> (elite costs [k], indices [k] into [pool | kept], elites [k, h, d]); ``mean`` /
+        ``std`` refitted in place.  Same bits as ``topk_sorted`` over the concatenation + ``gather_refit``."""
+        assert mean.dtype == self.dt and std.dtype == self.dt and mean.is_contiguous() and std.is_contiguous()
+        n = costs.shape[0]
+        costs, pool = self._t(costs, (n,)), self._t(pool, (n, self.h, self.d))
+        n_keep = 0 if keep_costs is None else keep_costs.shape[0]
+        if n_keep:
+            keep_costs, keep_actions = self._t(keep_costs, (n_keep,)), self._t(keep_actions, (n_keep, self.h, self.d))
+        elites = torch.empty((k, self.h, self.d), dtype=self.dt, device=self.device)
+        ec = torch.empty(k, dtype=self.dt, device=self.device)
+        idx = torch.empty(k, dtype=torch.int32, device=self.device)
+        L.check(self.lib.icem_update_distribution(self._h, n, _ptr(costs), _ptr(pool), n_keep,
+                                                  _ptr(keep_costs) if n_keep else None, _ptr(keep_actions) if n_keep else None,
+                                                  k, _ptr(mean), _ptr(std), _ptr(elites), _ptr(ec), _ptr(idx), self._stream()))
+        return ec, idx, elites
 
     def sample_truncnorm(self, n: int, mean, std, lower, upper, u=None, offset: int = 0, first_index: int = 0,
                          out: Optional[torch.Tensor] = None) -> torch.Tensor:

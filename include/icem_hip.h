@@ -244,6 +244,17 @@ size_t icem_topk_workspace_bytes(const icem_handle* h, int32_t n, int32_t k);
 int icem_topk_sorted(icem_handle* h, int32_t n, const void* costs, int32_t k, void* out_cost,
                      int32_t* out_idx, void* workspace, void* stream);
 
+/* K3 + K4 in one launch for small pools (the stage-wise controller loop: learned dynamics, host models, the CEM
+ * baselines): update_distributions (icem.py:194-211) with the previous elites appended behind the pool
+ * (icem.py:143-145) -- the k best of [costs (n) | keep_costs (n_keep)] in (cost, index) order, index n + e = kept elite e;
+ * their rows from [pool | keep_actions] into elites_out [k, h, d] (must not alias keep_actions), elite_costs_out [k],
+ * idx_out [k]; mean / std refitted in place as icem_gather_refit does (same arithmetic, same bits as icem_topk_sorted
+ * over the concatenation + icem_gather_refit).  f32 handles, n + n_keep <= 16384, k <= 32; otherwise
+ * ICEM_E_UNSUPPORTED: use the two operators. */
+int icem_update_distribution(icem_handle* h, int32_t n, const void* costs, const void* pool, int32_t n_keep,
+                             const void* keep_costs, const void* keep_actions, int32_t k, void* mean, void* std,
+                             void* elites_out, void* elite_costs_out, int32_t* idx_out, void* stream);
+
 /* K4  update_distributions (icem.py:201-211): gather the k elite rows of `actions` [*, h, d] in
  * `idx` order into elites_out [k, h, d]; mean <- (1-alpha)*mean_k + alpha*mean,
  * std <- (1-alpha)*std_k(ddof=0) + alpha*std (in place).  An entry INT_MAX (padding of icem_topk_sorted) repeats row idx[0]. */

@@ -1622,6 +1622,43 @@ def test_soak_two_processes_ipc_many_steps(tmp_path, N):
         assert np.array_equal(z["mean"], np_(pl.mean))
 
 
+@pytest.mark.parametrize("n,n_keep,K,special", [(1024, 3, 10, "plain"), (819, 3, 10, "ties"), (300, 0, 10, "nan"), (5, 2, 10, "short"),
+                                                 (16381, 3, 32, "plain"), (64, 0, 1, "plain"), (1000, 10, 32, "ties")])
+def test_update_distribution_equals_topk_plus_gather_refit(n, n_keep, K, special):
+    """icem_update_distribution (top-K over [pool | kept elites] + gather + refit, one launch) against icem_topk_sorted
+    over the concatenation + icem_gather_refit: same costs, indices, elites, mean and std, bit for bit -- also with
+    ties (broken by index, kept elites behind the pool), NaN / inf costs and fewer candidates than K (padding)."""
+    from icem_amd import IcemConfig, IcemPlanner, halfcheetah_env
+    env = halfcheetah_env(17)
+    pl = IcemPlanner(IcemConfig(horizon=12, act_dim=6, num_traj=max(n, 2), opt_iters=1, dtype="f32", seed=1, elites_size=min(K, 32)),
+                     env.action_space.low, env.action_space.high)
+    rs = np.random.RandomState(n + K)
+    costs = rs.randn(n).astype(np.float32)
+    kc = rs.randn(n_keep).astype(np.float32)
+    if special == "ties":
+        costs = np.round(costs * 2) / 2
+        kc = np.round(kc * 2) / 2
+        if n_keep:
+            kc[0] = costs.min()
+    if special == "nan":
+        costs[::7] = np.nan
+        costs[3] = -np.inf
+        costs[5] = np.inf
+    pool = rs.randn(n, 12, 6).astype(np.float32)
+    ka = rs.randn(n_keep, 12, 6).astype(np.float32)
+    dev = lambda x: torch.as_tensor(x, device="cuda")  # noqa: E731
+    m1, s1 = dev(rs.randn(12, 6).astype(np.float32)), dev(np.abs(rs.randn(12, 6)).astype(np.float32))
+    m2, s2 = m1.clone(), s1.clone()
+    ec, idx, el = pl.update_distribution(dev(costs), dev(pool), K, m1, s1, dev(kc) if n_keep else None, dev(ka) if n_keep else None)
+    all_c = dev(np.concatenate([costs, kc]))
+    all_a = dev(np.concatenate([pool, ka]))
+    ec2, idx2 = pl.topk_sorted(all_c, K)
+    el2 = pl.gather_refit(all_a, idx2, m2, s2)
+    assert torch.equal(idx, idx2.to(idx.dtype))
+    assert np.array_equal(np_(ec), np_(ec2), equal_nan=True)
+    assert torch.equal(el, el2) and torch.equal(m1, m2) and torch.equal(s1, s2)
+
+
 def test_in_library_exchange_wait_is_bounded(monkeypatch):
     """A rank whose peer never pushes must not hang the GPU: the device-side wait gives up after its poll budget, sets
     the block's status word, and the step finishes (with garbage)."""
