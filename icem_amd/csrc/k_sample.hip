@@ -3,7 +3,9 @@
 //   white draws in registers; inverse real DFT folded on its cos/sin symmetry with the table rows as wave-uniform
 //   scalar operands; affine (mean / std staged in LDS) + clip; samples parked in an LDS tile laid out like the
 //   [n, h, d] output so the slab leaves as coalesced stores.
-// sample_folded_merge_kernel: the same with the PREVIOUS iteration's top-K selection + refit in its prologue.
+// sample_folded_merge_kernel: the same with the PREVIOUS iteration's top-K selection + refit in its prologue; in sharded
+//   runs (records variant) workgroup 0 can be the previous iteration's record pack + push ("riding pack") and run the
+//   launch's one records merge for everybody ("published merge"): DESIGN.md section 6.
 #include "fused_dev.h"
 
 namespace icem {

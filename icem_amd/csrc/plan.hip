@@ -1,7 +1,8 @@
 // plan.hip -- the fused MPC step behind icem_plan_iter_local / icem_plan_iter_merge / icem_plan_step / icem_get_action
 // (the body of MpcICem.get_action, icem/controllers/icem.py:106-189): which kernels an iteration launches (generic
 // path, two-kernel f32 path, single-launch f32 paths), where a merge rides (own launch or the next launch's prologue),
-// and which of the ping-pong buffers each launch reads and writes.  No device code here except the result publisher.
+// where a sharded rank's record pack rides (own launch or workgroup 0 of the next local launch), which trailing
+// shifted-elite rows go around the candidate lists, and which of the ping-pong buffers each launch reads and writes.  No device code here except the result publisher.
 #include "host_common.h"
 
 using namespace icem;
