@@ -148,6 +148,9 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
     }
     if constexpr (PM) {
         if (tid >= NT) {
+            // the selection is the longer of the two concurrent chains on its SIMD: it goes first (c2 74.5 -> 72.7 us; with 8
+            // rollout waves the sampling is the longer one and the priority costs 0.7 us)
+            if constexpr (RW <= 4) __builtin_amdgcn_s_setprio(3);
             if constexpr (REC)
                 merge_select_records(a.m, lane, cand, sel, slot);
             else if constexpr (RW >= 8)  // 13 waves share the register file: the low-register selection
