@@ -113,6 +113,20 @@ __device__ __forceinline__ unsigned long long wave_sort64(unsigned long long k, 
     return k;
 }
 
+// ... when only lanes < NKEYS (16 or 32) hold keys and every other lane holds KEY_SENTINEL (the maximum): block 0 of
+// every stage sorts ascending, so after the stages up to NKEYS the later ones would move nothing -- 10 or 15 steps
+template <int NKEYS>
+__device__ __forceinline__ unsigned long long wave_sort_first(unsigned long long k, int lane) {
+    static_assert(NKEYS == 16 || NKEYS == 32 || NKEYS == 64, "keys in the first 16 / 32 / 64 lanes");
+    k = bitonic_merge<2, 1>(k, lane);
+    k = bitonic_merge<4, 2>(k, lane);
+    k = bitonic_merge<8, 4>(k, lane);
+    k = bitonic_merge<16, 8>(k, lane);
+    if constexpr (NKEYS >= 32) k = bitonic_merge<32, 16>(k, lane);
+    if constexpr (NKEYS >= 64) k = bitonic_merge<64, 32>(k, lane);
+    return k;
+}
+
 // the same network on 32-bit keys (half the moves): used where only the ORDER STATISTIC of the keys' cost halves matters
 template <int CTRL>
 __device__ __forceinline__ unsigned dpp_u32(unsigned x) {

@@ -212,7 +212,10 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
         const int total4 = (n_rows - base < TPB ? n_rows - base : TPB) * (HD / VW);
         const Vec* t4 = reinterpret_cast<const Vec*>(tile_rows);
         Vec* g4 = reinterpret_cast<Vec*>(sa.out + (size_t)base * HD);
-        for (int e = tid; e < total4; e += NTT) g4[e] = t4[e];
+        // where the workgroup has at least two wavefronts besides the rollout waves, those copy and the rollout starts
+        constexpr int CP0 = (NTT - 64 * RWV >= 128) ? 64 * RWV : 0;
+        if (tid >= CP0)
+            for (int e = tid - CP0; e < total4; e += NTT - CP0) g4[e] = t4[e];
     }
     if (ra.dbg && tid == 0 && wg == 0) ra.dbg[11] = wall_clock64();
     unsigned long long run_key = KEY_SENTINEL;
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
         if (ra.K > 0 && wg < n_wg) {   // the slab's keys -> one sorted list (one wave)
             __syncthreads();
             if (wave == 0) {
-                const unsigned long long key = wave_sort64(lane < TPB ? wg_keys[0][0][lane] : KEY_SENTINEL, lane);
+                const unsigned long long key = wave_sort_first<(TPB <= 16 ? 16 : TPB <= 32 ? 32 : 64)>(lane < TPB ? wg_keys[0][0][lane] : KEY_SENTINEL, lane);
                 if (lane < ra.K) {
                     if (ra.part_k) {
                         ra.part_k[(size_t)lane * n_wg + wg] = key;
