@@ -127,6 +127,13 @@ __device__ __forceinline__ unsigned long long wave_sort_first(unsigned long long
     return k;
 }
 
+// n (wave-uniform) keys in the first lanes, sentinels behind: the shortest network that sorts them
+__device__ __forceinline__ unsigned long long wave_sort_n(unsigned long long k, int lane, unsigned n) {
+    if (n <= 16) return wave_sort_first<16>(k, lane);
+    if (n <= 32) return wave_sort_first<32>(k, lane);
+    return wave_sort64(k, lane);
+}
+
 // the same network on 32-bit keys (half the moves): used where only the ORDER STATISTIC of the keys' cost halves matters
 template <int CTRL>
 __device__ __forceinline__ unsigned dpp_u32(unsigned x) {
@@ -885,7 +892,7 @@ __device__ __forceinline__ void merge_select(const MergeSingleArgs& a, int lane,
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     if (n_cand <= 64) {
         unsigned long long key = lane < (int)n_cand ? *((volatile unsigned long long*)&cand[lane]) : KEY_SENTINEL;
-        key = wave_sort64(key, lane);
+        key = wave_sort_n(key, lane, n_cand);
         if (lane < a.K) sel[lane] = key;
     } else {
         // more than 64 keys tie at or below T: K tournament rounds over the list heads
@@ -954,7 +961,7 @@ __device__ __forceinline__ void merge_select_stream(const MergeSingleArgs& a, in
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     if (n_cand <= 64) {
         unsigned long long key = lane < (int)n_cand ? *((volatile unsigned long long*)&cand[lane]) : KEY_SENTINEL;
-        key = wave_sort64(key, lane);
+        key = wave_sort_n(key, lane, n_cand);
         if (lane < K) sel[lane] = key;
     } else {
         int cur[LPL];
@@ -1011,7 +1018,7 @@ __device__ __forceinline__ void merge_select_records(const MergeSingleArgs& a, i
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     if (n_cand <= 64) {
         unsigned long long key = lane < (int)n_cand ? *((volatile unsigned long long*)&cand[lane]) : KEY_SENTINEL;
-        key = wave_sort64(key, lane);
+        key = wave_sort_n(key, lane, n_cand);
         if (lane < K) sel[lane] = key;
     } else {
         for (int r = 0; r < K; ++r) {
