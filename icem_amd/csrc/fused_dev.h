@@ -832,6 +832,8 @@ template <int KREG>
 __device__ __forceinline__ void merge_select(const MergeSingleArgs& a, int lane, unsigned long long* cand,
                                              unsigned long long* sel) {
     unsigned long long k[LPL][KREG];
+    // (the kept elite's cost comes from another buffer: requested first, consumed behind the lists)
+    const float keep_cost = a.elites_cost_cur ? a.elites_cost_cur[lane < a.n_keep ? lane : 0] : 0.f;
 #pragma unroll
     for (int l = 0; l < LPL; ++l) {
         const int list = lane + l * 64;
@@ -847,7 +849,7 @@ __device__ __forceinline__ void merge_select(const MergeSingleArgs& a, int lane,
     }
     if (a.dbg && threadIdx.x == 0) a.dbg[1] = wall_clock64();
     if (lane < a.n_keep) {  // kept elite `lane` (icem.py:143-145) joins this lane's first list, order preserved
-        unsigned long long v = make_key(a.elites_cost_cur[lane], a.n_global + lane);
+        unsigned long long v = make_key(keep_cost, a.n_global + lane);
 #pragma unroll
         for (int i = 0; i < KREG; ++i) {
             const bool sw = v < k[0][i];
