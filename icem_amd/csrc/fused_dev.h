@@ -741,7 +741,8 @@ __device__ __forceinline__ unsigned long long topk_push16(unsigned long long run
         const unsigned long long prev = __shfl(run_key, lane - 16, 64);
         if (lane >= 16 && lane < 16 + K) key = prev;
     }
-    return wave_sort64(key, lane);
+    // keys in lanes 0..15 (first tile) or 0..15+K, sentinels behind: the shortest network that covers them
+    return wave_sort_n(key, lane, first ? 16u : 16u + (unsigned)K);
 }
 
 // one sorted list per workgroup: tree merge of the first WAVES waves' lists through LDS (`fan` lists per sort),
