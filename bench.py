@@ -206,7 +206,7 @@ def extra_cpu_baselines(workload, w, model, env):
     return out
 
 
-KERNEL_FAMILY = {"sample_clip": ("sample_folded_kernel", "sample_folded_merge_kernel"), "rollout_cost": ("rollout16_kernel",),
+KERNEL_FAMILY = {"sample_clip": ("sample_folded_kernel", "sample_folded_merge_kernel"), "rollout_cost": ("rollout16_kernel", "rollout_wide_kernel"),
                  "sample_rollout": ("sample_rollout_kernel",)}
 
 
