@@ -335,7 +335,8 @@ bool sample_rollout_pack_ok(int h, int d, int O, int rounds, int n_rows, int K) 
 
 void launch_sample_rollout(const FastIterArgs& a, int h, int d, int O, int kind, bool merge_prologue, hipStream_t st) {
     int grid, rw;
-    if (!sample_rollout_shape(h, d, O, 10, a.r.n_rows, a.s.n_shift, &grid, &rw)) return;
+    // (the tail shape only where the caller chose it -- it sets list_wgs then: the list count is the caller's contract)
+    if (!sample_rollout_shape(h, d, O, 10, a.r.n_rows, a.r.list_wgs > 0 ? a.s.n_shift : 0, &grid, &rw)) return;
     if (merge_prologue && a.m.records && a.p.part_k) grid += 1;  // workgroup 0: the riding pack
 #define XK(HH, DD, OO, WW, KR, RC)                                                                                      \
     {                                                                                                                   \

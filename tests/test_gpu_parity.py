@@ -1520,7 +1520,10 @@ def _xchg_planner(rank, world, dtype, N=1000, iters=4, seed=99, kind=1):
 
 @pytest.mark.parametrize("deferral", [False, True])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-@pytest.mark.parametrize("world,N", [(2, 1000), (3, 1000), (8, 1000), (4, 40000), (2, 80000), (16, 300)])
+@pytest.mark.parametrize("world,N", [(2, 1000), (3, 1000), (8, 1000), (4, 40000), (2, 80000), (16, 300),
+                                     # rank 0's shard fills the 256 slabs exactly (1 and 2 tiles per slab): its shifted
+                                     # elites of the later MPC steps must not change the launch shape behind the host's back
+                                     (2, 8192), (2, 16384), (8, 32768)])
 def test_in_library_exchange_emulated_worlds(world, N, dtype, deferral):
     """All ranks of a sharded run as planners of ONE process, connected through the in-library exchange (blocks handed
     over as pointers): the records travel by exchange_push_kernel, the merges wait on the flags of their own block --
@@ -1573,7 +1576,7 @@ def _xchg_worker(rank, world, port, out_dir, dtype, N=2000, steps=3):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dtype,N", [("f32", 2000), ("f64", 2000), ("f32", 12000), ("f32", 70000)])
+@pytest.mark.parametrize("dtype,N", [("f32", 2000), ("f64", 2000), ("f32", 12000), ("f32", 70000), ("f32", 8192)])
 def test_in_library_exchange_two_processes_ipc(tmp_path, dtype, N):
     """The real multi-process path: two processes share this GPU, exchange their IPC handles once over gloo, and run
     whole MPC steps with icem_plan_step_sharded -- the records move through IPC-mapped peer blocks, the only
