@@ -826,6 +826,10 @@ __device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned x) {
     return x;
 }
 
+// index the first kept candidate carries in its key: n_global (kept / shifted elites of the merges), or keep_base where
+// the caller indexes differently (a sharded rank's pack: its local pool row n_loc)
+__device__ __forceinline__ int keep_index0(const MergeSingleArgs& a) { return a.keep_base >= 0 ? a.keep_base : a.n_global; }
+
 // Global sorted top-K of the candidate lists (+ kept elites): ONE wavefront; sel[0..K) receives the keys.
 // Lane t owns lists t, t+64, t+128, t+192 (each sorted) in registers; key r of list w sits at
 // part_k[r * n_lists + w], so every load is one contiguous 512 bytes.
@@ -850,7 +854,7 @@ __device__ __forceinline__ void merge_select(const MergeSingleArgs& a, int lane,
     }
     if (a.dbg && threadIdx.x == 0) a.dbg[1] = wall_clock64();
     if (lane < a.n_keep) {  // kept elite `lane` (icem.py:143-145) joins this lane's first list, order preserved
-        unsigned long long v = make_key(keep_cost, a.n_global + lane);
+        unsigned long long v = make_key(keep_cost, keep_index0(a) + lane);
 #pragma unroll
         for (int i = 0; i < KREG; ++i) {
             const bool sw = v < k[0][i];
@@ -933,7 +937,7 @@ __device__ __forceinline__ void merge_select_stream(const MergeSingleArgs& a, in
         return (list < nl && i < K) ? v : KEY_SENTINEL;
     };
     // kept elite `lane` (icem.py:143-145): a one-key list of its own
-    const unsigned long long kept = lane < a.n_keep ? make_key(a.elites_cost_cur[lane], a.n_global + lane) : KEY_SENTINEL;
+    const unsigned long long kept = lane < a.n_keep ? make_key(a.elites_cost_cur[lane], keep_index0(a) + lane) : KEY_SENTINEL;
     unsigned long long mine = kept;
 #pragma unroll
     for (int l = 0; l < LPL; ++l) {

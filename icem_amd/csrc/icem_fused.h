@@ -108,6 +108,7 @@ void launch_rollout_rows_wide(const WideRolloutArgs& a, int row0, int n_tail, co
 struct MergeSingleArgs {
     int n_lists;   // candidate lists, each K long and sorted
     int n_keep;    // kept elites appended as candidates (icem.py:143-145), gidx = n_global + e
+    int keep_base = -1;  // >= 0: index of kept candidate 0 in its key instead of n_global (pack of a sharded rank: n_loc)
     int n_pool;    // sampled + shifted rows in `actions` this iteration (local == global, world 1)
     int n_global;  // N_it: index offset of shifted (it == 0) or kept (it > 0) elites
     int K, h, d, last;
@@ -169,6 +170,8 @@ struct PackPrev {
     const float* actions = nullptr;              // ... and pool
     int n_lists = 0, n_pool = 0, n_global = 0, K = 0;
     int n_loc = 0, shard_lo = 0;
+    int n_keep = 0;                              // shifted-elite rows behind the lists (rank 0, iteration 0), scored through
+    const float* keep_costs = nullptr;           // ... their costs (the cost array from row n_loc on)
     float* records = nullptr;                    // this rank's [K, 2 + h*d] records
     XchgPush px;
     // sample_folded_merge_kernel only ("published merge"): workgroup 0 also runs the launch's one records merge and

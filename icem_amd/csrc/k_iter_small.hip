@@ -80,6 +80,9 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
             pk.d = D;
             pk.part_k = a.p.part_k;
             pk.actions = a.p.actions;
+            pk.n_keep = a.p.n_keep;
+            pk.elites_cost_cur = a.p.keep_costs;
+            pk.keep_base = a.p.n_loc;
             // everybody else's prologue waits for this workgroup's push: its waves go first on their SIMDs
             __builtin_amdgcn_s_setprio(3);
             // the register-resident selection (174 registers, 1 us faster) where at most two waves share a SIMD anyway

@@ -117,6 +117,9 @@ __global__ __launch_bounds__(SWG + 64) void sample_folded_merge_kernel(FastSampl
             pk.d = d;
             pk.part_k = args.p.part_k;
             pk.actions = args.p.actions;
+            pk.n_keep = args.p.n_keep;
+            pk.elites_cost_cur = args.p.keep_costs;
+            pk.keep_base = args.p.n_loc;
             // everybody else's prologue waits for this workgroup's push: its waves go first on their SIMDs
             __builtin_amdgcn_s_setprio(3);
             if (tid >= SWG) merge_select_stream(pk, lane, cand, sel);

@@ -294,6 +294,9 @@ int launch_pending_pack(icem_handle* h, hipStream_t st) {
     pk.d = h->cfg.act_dim;
     pk.part_k = pp.part_k;
     pk.actions = pp.actions;
+    pk.n_keep = pp.n_keep;
+    pk.elites_cost_cur = pp.keep_costs;
+    pk.keep_base = pp.n_loc;
     {
         ProfScope prof(h, ICEM_K_LOCAL_PACK, pp.n_lists * pp.K, st);
         launch_pack_records(pk, pp.n_loc, pp.shard_lo, pp.records, st, pp.px);
@@ -363,7 +366,7 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
             int tail_rows = 0;  // shifted-elite rows scored through the cost array instead of a list (world 1 only)
             const int one = (fast_sample_ok(h) && (n_extra == 0 || shift_in_sampler))
                                 ? sample_rollout_lists(c.horizon, c.act_dim, h->O, c.rng_rounds, n_rows,
-                                                       (c.world == 1 && shift_in_sampler) ? n_extra : 0, &tail_rows) : 0;
+                                                       shift_in_sampler ? n_extra : 0, &tail_rows) : 0;
             h->fast_tail_rows = one > 0 ? tail_rows : 0;
             // the merge finds the lists' indices behind `lists * K` costs
             split_partial_ws<float>(b->workspace, one > 0 ? one : rollout_lists(c.horizon, c.act_dim, h->O, n_rows), K, &pc, &pi);
@@ -454,6 +457,13 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                 pk.d = c.act_dim;
                 pk.part_k = (const unsigned long long*)b->workspace;
                 pk.actions = (const float*)actions;
+                if (one > 0 && tail_rows > 0 && c.rank == 0) {
+                    // rank 0's shifted elites sit behind the list-writing workgroups: extra candidates of the pack, costs
+                    // from the cost array, key index = their local pool row
+                    pk.n_keep = tail_rows;
+                    pk.elites_cost_cur = (const float*)b->costs + n_loc;
+                    pk.keep_base = n_loc;
+                }
                 XchgPush px;  // in-library exchange: the pack kernel pushes the records itself where they fit its LDS
                 const bool fold_push = xchg_connected(h) && pack_can_push(K, c.horizon, c.act_dim);
                 if (fold_push) {
@@ -475,6 +485,8 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                         pp.K = K;
                         pp.n_loc = n_loc;
                         pp.shard_lo = lo;
+                        pp.n_keep = pk.n_keep;
+                        pp.keep_costs = pk.elites_cost_cur;
                         pp.records = (float*)rec;
                         pp.px = px;
                         h->pk_pending = true;
