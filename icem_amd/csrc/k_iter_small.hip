@@ -300,7 +300,10 @@ static bool sample_rollout_shape(int h, int d, int O, int rounds, int n_rows, in
     if (n_tail > 0 && n_tail <= 64) {
         int g2, w2;
         r16_shape(n_rows - n_tail, &g2, &w2);
-        if (w2 < rw && g2 == FAST_MAX_LISTS && n_rows - n_tail == FAST_MAX_LISTS * 16 * w2) {
+        // (only shapes whose workgroups fit a CU twice -- at most 512 threads: 1 or 4 tiles per workgroup at d = 6 -- so that
+        // the extra workgroups run beside the others; a 2-tile workgroup (832 threads with quad sampling) or an 8-tile one
+        // owns its CU, workgroup 257 would be a second round: N = 8 192 measured 23.5 us against 18.7 for the 4-tile shape)
+        if (w2 < rw && sr_threads(d, w2) + 64 <= 512 && g2 == FAST_MAX_LISTS && n_rows - n_tail == FAST_MAX_LISTS * 16 * w2) {
             rw = w2;
             tail = n_tail;
         }
