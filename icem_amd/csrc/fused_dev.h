@@ -207,6 +207,12 @@ __device__ __forceinline__ void row_synth(const float* __restrict__ W, const flo
         for (int t = 0; t < H; ++t) emit(t, g[t]);
         return;
     }
+    // Even H: the half-period shift t -> t + H/2 multiplies frequency k's cosine and sine by (-1)^k, and the partial sums
+    // over even and odd k are what the two accumulators of each part hold anyway (e0 / e1, o1 / o0).  So the table row of
+    // t' also yields the samples at H/2 - t' and H/2 + t': four outputs per row instead of two, half the rows (and half
+    // the scalar table loads).  t = H/2 comes with t = 0.
+    constexpr bool HALF = H % 2 == 0;
+    constexpr int Q = H / 2;
     {  // t = 0: every sine is zero
         float e0 = 0.f, e1 = 0.f;
 #pragma unroll
@@ -215,9 +221,9 @@ __device__ __forceinline__ void row_synth(const float* __restrict__ W, const flo
             if (m + 1 < F) e1 = __builtin_fmaf(g[m + 1], W[m + 1], e1);
         }
         emit(0, e0 + e1);
+        if (HALF) emit(Q, e0 - e1);
     }
-#pragma unroll 1
-    for (int tp = 1; tp <= H / 2; ++tp) {
+    auto row = [&](int tp, bool four) {
         const float* __restrict__ w = W + tp * HMAX;
         float e0 = 0.f, e1 = 0.f, o0 = 0.f, o1 = 0.f;
 #pragma unroll
@@ -233,6 +239,19 @@ __device__ __forceinline__ void row_synth(const float* __restrict__ W, const flo
         const float e = e0 + e1, od = o0 + o1;
         emit(tp, e + od);
         if (H - tp != tp) emit(H - tp, e - od);
+        if (four) {
+            const float ed = e0 - e1, dd = o0 - o1;
+            emit(Q - tp, ed + dd);
+            emit(Q + tp, ed - dd);
+        }
+    };
+    if constexpr (HALF) {
+#pragma unroll 1
+        for (int tp = 1; tp <= (Q - 1) / 2; ++tp) row(tp, true);
+        if (Q % 2 == 0) row(Q / 2, false);  // its own half-period partner
+    } else {
+#pragma unroll 1
+        for (int tp = 1; tp <= H / 2; ++tp) row(tp, false);
     }
 }
 
@@ -301,7 +320,9 @@ __device__ __forceinline__ void row_synth_quad(const float* Wl, const float (&g)
             if ((t & 3) == q) emit(t, g[t]);
         return;
     }
-    if (q == 3) {  // t = 0: every sine is zero
+    constexpr bool HALF = H % 2 == 0;   // four outputs per table row, as row_synth
+    constexpr int Q = H / 2;
+    if (q == 3) {  // t = 0 (and t = H/2): every sine is zero
         float e0 = 0.f, e1 = 0.f;
 #pragma unroll
         for (int m = 0; m < F; m += 2) {
@@ -309,9 +330,9 @@ __device__ __forceinline__ void row_synth_quad(const float* Wl, const float (&g)
             if (m + 1 < F) e1 = __builtin_fmaf(g[m + 1], Wl[m + 1], e1);
         }
         emit(0, e0 + e1);
+        if (HALF) emit(Q, e0 - e1);
     }
-#pragma unroll 1
-    for (int tp = q + 1; tp <= H / 2; tp += 4) {
+    auto row = [&](int tp, bool four) {
         const float* w = Wl + tp * WQ_STRIDE;
         float e0 = 0.f, e1 = 0.f, o0 = 0.f, o1 = 0.f;
 #pragma unroll
@@ -327,6 +348,19 @@ __device__ __forceinline__ void row_synth_quad(const float* Wl, const float (&g)
         const float e = e0 + e1, od = o0 + o1;
         emit(tp, e + od);
         if (H - tp != tp) emit(H - tp, e - od);
+        if (four) {
+            const float ed = e0 - e1, dd = o0 - o1;
+            emit(Q - tp, ed + dd);
+            emit(Q + tp, ed - dd);
+        }
+    };
+    if constexpr (HALF) {
+#pragma unroll 1
+        for (int tp = q + 1; tp <= (Q - 1) / 2; tp += 4) row(tp, true);
+        if (Q % 2 == 0 && q == ((Q - 1) / 2) % 4) row(Q / 2, false);  // the lane behind the last four-output row
+    } else {
+#pragma unroll 1
+        for (int tp = q + 1; tp <= H / 2; tp += 4) row(tp, false);
     }
 }
 
