@@ -74,6 +74,7 @@ _VP, _I32, _I64, _U64, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_s
 _H = C.c_void_p
 SYMBOLS = [
     ("icem_abi_version", C.c_int, []),
+    ("icem_build_hash", C.c_char_p, []),
     ("icem_last_error", C.c_char_p, []),
     ("icem_device_count", C.c_int, []),
     ("icem_create", C.c_int, [C.POINTER(IcemConfigC), C.POINTER(_H)]),
@@ -117,11 +118,13 @@ SYMBOLS = [
     ("icem_exchange_probe", C.c_int, [_H, C.c_int32, _VP, C.POINTER(C.c_double)]),
     ("icem_sample_truncnorm", C.c_int, [_H, C.c_int32, C.c_int64, _VP, _VP, _VP, _VP, _VP, C.c_uint64, _VP, _VP]),
     ("icem_cem_bounds", C.c_int, [_H, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    ("icem_update_distribution_ok", C.c_int, [_H, C.c_int32, C.c_int32]),
     ("icem_profile_read", C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 ]
 
 
 IPC_HANDLE_BYTES = 64
+ABI_VERSION = 2   # include/icem_hip.h: ICEM_ABI_VERSION
 
 
 def lib_path() -> str:
@@ -143,8 +146,8 @@ def load_library() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.icem_abi_version() != 1:
-        raise ImportError(f"{path}: ABI version {lib.icem_abi_version()} != 1")
+    if lib.icem_abi_version() != ABI_VERSION:
+        raise ImportError(f"{path}: ABI version {lib.icem_abi_version()} != {ABI_VERSION}: rebuild (python -m icem_amd.build)")
     _LIB = lib
     return lib
 

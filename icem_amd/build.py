@@ -2,8 +2,9 @@
 
 One object per translation unit, compiled in parallel; an object is rebuilt when the hash of (compile command, its
 source, every header under ``csrc/`` and ``include/icem_hip.h``) changes, the library when any object does.  The hash of
-all sources the library was linked from is kept next to it (``libicem_hip.so.json``) so that a stale binary is
-visible: ``build_info()`` is what ``bench.py`` prints as ``build``.
+all sources the library was linked from is compiled INTO it (``icem_build_hash()``, a marker string in ``abi.hip``'s
+object) so that a stale binary is visible whatever is lying next to it: ``build_info()`` reads the marker straight
+from the file (no dlopen) and is what ``bench.py`` prints as ``build``.
 """
 import hashlib
 import json
@@ -17,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 UNITS = ["generic_kernels.hip", "plan.hip", "abi.hip", "exchange.hip", "k_sample.hip", "k_rollout.hip", "k_merge.hip",
          "k_iter_small.hip", "icem_rssm.hip", "k_rollout_wide.hip"]
 OUT = os.path.join(HERE, "libicem_hip.so")
-INFO = OUT + ".json"
+MARK = b"ICEM_BUILD_HASH="  # abi.hip embeds MARK + the 16 hex digits of source_hash()
 OBJ = os.path.join(CSRC, "_obj")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function"]
 
@@ -49,15 +50,25 @@ def source_hash() -> str:
     return _digest([os.path.join(CSRC, u) for u in _units()] + _headers(), " ".join(FLAGS))
 
 
+def embedded_hash(path: str = OUT):
+    """The source hash compiled into a built library (None: no library, or one from before the marker existed)."""
+    try:
+        with open(path, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None
+    at = blob.find(MARK)
+    if at < 0:
+        return None
+    tag = blob[at + len(MARK):at + len(MARK) + 16]
+    return tag.decode() if len(tag) == 16 and all(c in b"0123456789abcdef" for c in tag) else None
+
+
 def build_info() -> dict:
-    """{source_hash, built_from, stale}: ``stale`` is True when the library on disk was linked from other sources."""
-    info = {"source_hash": source_hash(), "built_from": None, "stale": True}
-    if os.path.exists(OUT) and os.path.exists(INFO):
-        try:
-            info["built_from"] = json.load(open(INFO)).get("source_hash")
-        except Exception:
-            pass
-        info["stale"] = info["built_from"] != info["source_hash"]
+    """{source_hash, built_from, stale}: ``built_from`` is the hash embedded in the library on disk; ``stale`` is True
+    when that is not the hash of the sources in the tree."""
+    info = {"source_hash": source_hash(), "built_from": embedded_hash(), "stale": True}
+    info["stale"] = info["built_from"] != info["source_hash"]
     return info
 
 
@@ -67,7 +78,8 @@ def up_to_date() -> bool:
 
 def _compile(unit, headers_digest, verbose):
     src = os.path.join(CSRC, unit)
-    cmd = [_hipcc(), *FLAGS, "-I", CSRC, "-c", src]
+    extra = [f'-DICEM_BUILD_HASH="{source_hash()}"'] if unit == "abi.hip" else []  # the marker lives in one object
+    cmd = [_hipcc(), *FLAGS, *extra, "-I", CSRC, "-c", src]
     key = _digest([src], " ".join(cmd[1:-1]) + headers_digest)
     obj = os.path.join(OBJ, f"{os.path.splitext(unit)[0]}.{key}.o")
     if not os.path.exists(obj):
@@ -95,8 +107,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    with open(INFO, "w") as f:
-        json.dump({"source_hash": source_hash(), "forced": bool(force), "units": _units()}, f)
+    if embedded_hash() != source_hash():
+        raise RuntimeError("libicem_hip.so does not carry the hash of the sources it was just built from")
     return OUT
 
 

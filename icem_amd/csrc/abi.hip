@@ -85,6 +85,15 @@ extern "C" {
 
 int icem_abi_version(void) { return ICEM_ABI_VERSION; }
 
+#ifndef ICEM_BUILD_HASH
+#define ICEM_BUILD_HASH "0000000000000000"  // built by hand, not through icem_amd/build.py
+#endif
+// the marker icem_amd/build.py looks for in the file (no dlopen needed to tell a stale binary)
+const char* icem_build_hash(void) {
+    static const char tag[] = "ICEM_BUILD_HASH=" ICEM_BUILD_HASH;
+    return tag + 16;
+}
+
 const char* icem_last_error(void) { return g_err.c_str(); }
 
 int icem_device_count(void) {
@@ -195,6 +204,13 @@ int icem_set_model(icem_handle* h, int32_t kind, int32_t obs_dim, const double* 
         // wide observations (HumanoidStandup's real o = 378, mujoco.py:241-252): the f32 GEMM rollout only
         if (h->cfg.dtype != ICEM_F32 || !wide_rollout_supported(obs_dim, d, 1))
             return fail(ICEM_E_UNSUPPORTED, "obs_dim in (32, 384] needs dtype f32 (k_rollout_wide); beyond 384 is not compiled");
+        if (h->has_terms) {
+            h->wide = true;
+            const char* e = wide_unsupported(h, h->cfg.num_elites, false, false);
+            h->wide = false;
+            return fail(ICEM_E_UNSUPPORTED, e);
+        }
+        if (h->cfg.num_elites > 32) return fail(ICEM_E_UNSUPPORTED, "obs_dim > 32 needs num_elites <= 32 (candidate lists of k_rollout_wide)");
         if (h->A_dev) (void)hipFree(h->A_dev);
         if (h->B_dev) (void)hipFree(h->B_dev);
         h->A_dev = h->B_dev = nullptr;
@@ -252,8 +268,16 @@ int icem_set_cost_terms(icem_handle* h, const icem_cost_terms* terms) {
     }
     if (terms->box_from >= 0 && terms->health_idx < 0)
         return fail(ICEM_E_INVALID, "box_from is part of the health term: health_idx must be set");
+    const bool on = terms->diff_idx >= 0 || terms->health_idx >= 0 || terms->n_terms > 0;
+    if (on && h->wide && h->has_model) {  // (icem_trajectory_cost works without a built-in model: no conflict there)
+        const bool was = h->has_terms;
+        h->has_terms = true;
+        const char* e = wide_unsupported(h, h->cfg.num_elites, false, false);
+        h->has_terms = was;
+        return fail(ICEM_E_UNSUPPORTED, e);
+    }
     h->terms = *terms;
-    h->has_terms = terms->diff_idx >= 0 || terms->health_idx >= 0 || terms->n_terms > 0;
+    h->has_terms = on;
     return ICEM_OK;
 }
 
@@ -326,6 +350,7 @@ int icem_rollout_cost(icem_handle* h, int32_t n, const void* obs0, const void* a
     if (!h->has_model || !h->has_cost) return fail(ICEM_E_STATE, "icem_set_model / icem_set_cost must be called first");
     if (n < 0 || !obs0 || !actions || !costs) return fail(ICEM_E_INVALID, "null tensor / negative n");
     if (const char* e = cost_indices_error(h, h->obs_dim)) return fail(ICEM_E_INVALID, e);
+    if (const char* e = wide_unsupported(h, 0, false, observations != nullptr)) return fail(ICEM_E_UNSUPPORTED, e);
     hipStream_t st = (hipStream_t)stream;
     if (observations == nullptr && n > 0 && fast_rollout_ok(h, 0))
         return launch_fast_rollout(h, n, 0, 0, obs0, actions, costs, nullptr, nullptr, st, nullptr);
@@ -374,6 +399,10 @@ int icem_update_distribution(icem_handle* h, int32_t n, const void* costs, const
     launch_update_small(a, (hipStream_t)stream);
     ICEM_HIP_TRY(hipGetLastError());
     return ICEM_OK;
+}
+
+int icem_update_distribution_ok(const icem_handle* h, int32_t n_all, int32_t k) {
+    return (h && h->use_fast && h->cfg.dtype == ICEM_F32 && n_all >= 1 && k >= 1 && topk_small_ok(n_all, k)) ? 1 : 0;
 }
 
 int icem_gather_refit(icem_handle* h, const void* actions, const int32_t* idx, int32_t k, void* mean, void* std,

@@ -4,7 +4,9 @@
 //
 // Every rank owns ONE exchange block in its own HBM:
 //     flags   [2][XCHG_MAX_WORLD] u32   sequence number of the last push of rank r, per parity
-//     status  u32                        != 0: a wait for a peer timed out
+//     (status u32 -- superseded: the status word now lives in pinned, device-mapped HOST memory so that the host
+//      sees a timed-out wait without a copy or a synchronisation; bit 0: a wait timed out, bit 1: the probe's payload
+//      check failed)
 //     records [2][world][K][2 + h*d]     the gathered records, per parity -- the layout icem_plan_iter_merge reads
 // and maps the blocks of all other ranks (HIP IPC between processes, plain pointers inside one process).  A push is
 // ONE launch on the pushing rank's stream (exchange_push_kernel, `world` workgroups): workgroup r copies the rank's K
@@ -35,6 +37,8 @@ struct Exchange {
     std::vector<unsigned char*> peers;           // [world] device pointers of all blocks (own included)
     std::vector<bool> opened;                    // mapped through hipIpcOpenMemHandle
     unsigned char** peers_dev = nullptr;         // the same, on the device
+    unsigned* status_host = nullptr;             // pinned + mapped: the kernels' timeout / payload-check reports
+    unsigned* status_dev = nullptr;              // ... its device address
     unsigned seq = 0;                            // pushes so far (= sequence number of the last one)
     unsigned probe_seq = 0;
     long long* ticks_dev = nullptr;
@@ -73,39 +77,74 @@ __global__ __launch_bounds__(256) void exchange_push_kernel(const uint32_t* __re
     push_to_block(mine, words, peers[blockIdx.x], rec_byte_off, parity * XCHG_MAX_WORLD + rank, seq);
 }
 
-// Measurement only: `rounds` back-to-back exchanges (every rank pushes its K records to every block, then waits for
-// all of them) inside ONE launch per rank, timed with the 100 MHz wall clock: the latency of one exchange as the
-// planning loop sees it, without kernel launches around it.  Uses its own flag words (probe area) and parity slots.
-__global__ __launch_bounds__(256) void exchange_probe_kernel(const uint32_t* __restrict__ mine, int words, unsigned char* const* peers,
-                                                             size_t rec_off, size_t rec_slot, size_t rec_bytes, int rank, int world,
-                                                             unsigned base, int rounds, long long* ticks_out) {
+// the word the probe of rank `rank` writes at position e of its slot in round `seq`
+__device__ __forceinline__ uint32_t probe_word(unsigned seq, int rank, int e) {
+    return (seq * 0x9E3779B9u) ^ ((uint32_t)rank << 24) ^ (uint32_t)e;
+}
+
+// Self-test + measurement: `rounds` back-to-back exchanges (every rank pushes K records' worth of a round-stamped
+// pattern to every block, waits for all ranks' flags, then CHECKS every rank's payload in its own block) inside ONE
+// launch per rank, timed with the 100 MHz wall clock: the latency of one exchange as the planning loop sees it,
+// without kernel launches around it.  The payload check is what catches a block whose peer-written records are
+// shadowed by the owner's L2 (coarse-grained memory): the slots are rewritten every round with a different pattern,
+// so a stale line shows.  Uses its own flag words (probe area); the parity slots are free between MPC steps.
+__global__ __launch_bounds__(256) void exchange_probe_kernel(int words, unsigned char* const* peers, size_t rec_off, size_t rec_slot,
+                                                             size_t rec_bytes, int rank, int world, int n_wait, unsigned base,
+                                                             int rounds, unsigned max_polls, unsigned* status, long long* ticks_out) {
     unsigned char* own = peers[rank];
+    __shared__ unsigned bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
     const long long t0 = wall_clock64();
     for (int r = 1; r <= rounds; ++r) {
         const unsigned seq = base + (unsigned)r;
         const int parity = (int)(seq & 1u);
         for (int p = 0; p < world; ++p) {
-            push_to_block(mine, words, peers[p], rec_off + (size_t)parity * rec_slot + (size_t)rank * rec_bytes,
-                          XCHG_PROBE_FLAG0 + rank, seq);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(peers[p] + rec_off + (size_t)parity * rec_slot + (size_t)rank * rec_bytes);
+            if ((words & 3) == 0) {
+                for (int e = threadIdx.x; e < words / 4; e += blockDim.x)
+                    reinterpret_cast<uint4*>(dst)[e] = uint4{probe_word(seq, rank, 4 * e), probe_word(seq, rank, 4 * e + 1),
+                                                             probe_word(seq, rank, 4 * e + 2), probe_word(seq, rank, 4 * e + 3)};
+            } else {
+                for (int e = threadIdx.x; e < words; e += blockDim.x) dst[e] = probe_word(seq, rank, e);
+            }
+            __threadfence_system();
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(reinterpret_cast<unsigned*>(peers[p]) + XCHG_PROBE_FLAG0 + rank, seq, __ATOMIC_RELEASE,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             __syncthreads();
         }
         if (threadIdx.x < 64) {
             XchgWait w;
             w.flags = reinterpret_cast<const unsigned*>(own) + XCHG_PROBE_FLAG0;
-            w.status = reinterpret_cast<unsigned*>(own) + 2 * XCHG_MAX_WORLD;
+            w.status = status;
             w.seq = seq;
-            w.world = world;
-            w.max_polls = XCHG_MAX_POLLS;
+            w.world = n_wait;
+            w.max_polls = max_polls;
             xchg_wait_at_least(w, threadIdx.x);
         }
         __syncthreads();
+        // the payload every waited-for rank pushed into THIS rank's block in this round (plain loads, as the merges read it)
+        for (int q = 0; q < n_wait; ++q) {
+            const int src_rank = n_wait == world ? q : rank;   // loopback measurement: only this rank's own slot is live
+            const uint32_t* got = reinterpret_cast<const uint32_t*>(own + rec_off + (size_t)parity * rec_slot + (size_t)src_rank * rec_bytes);
+            for (int e = threadIdx.x; e < words; e += blockDim.x)
+                if (got[e] != probe_word(seq, src_rank, e)) bad = 1;
+        }
+        __syncthreads();   // (also: nobody overwrites a slot before every thread has checked it ... on THIS rank; a peer
+                           //  two rounds ahead cannot exist: its next push to this parity needs this rank's flag of round seq+1)
     }
-    if (threadIdx.x == 0) ticks_out[0] = wall_clock64() - t0;
+    if (threadIdx.x == 0) {
+        ticks_out[0] = wall_clock64() - t0;
+        if (bad) __hip_atomic_fetch_or(status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 }  // namespace
 
-size_t xchg_status_off() { return (size_t)2 * XCHG_MAX_WORLD * sizeof(unsigned); }
 
 // this rank's records of the running iteration -> every rank's block; returns the arguments the merge waits with
 int xchg_push(icem_handle* h, const void* my_records, hipStream_t st, XchgWait* wait_out) {
@@ -120,7 +159,7 @@ int xchg_push(icem_handle* h, const void* my_records, hipStream_t st, XchgWait* 
                        x->peers_dev, off, h->cfg.rank, parity, seq);
     ICEM_HIP_TRY(hipGetLastError());
     wait_out->flags = reinterpret_cast<const unsigned*>(x->block) + parity * XCHG_MAX_WORLD;
-    wait_out->status = reinterpret_cast<unsigned*>(x->block + xchg_status_off());
+    wait_out->status = x->status_dev;
     wait_out->seq = seq;
     wait_out->world = x->loopback ? 1 : world;
     wait_out->max_polls = x->max_polls;
@@ -142,7 +181,7 @@ int xchg_begin(icem_handle* h, XchgPush* push_out, XchgWait* wait_out) {
     push_out->flag_idx = parity * XCHG_MAX_WORLD + h->cfg.rank;
     push_out->seq = seq;
     wait_out->flags = reinterpret_cast<const unsigned*>(x->block) + parity * XCHG_MAX_WORLD;
-    wait_out->status = reinterpret_cast<unsigned*>(x->block + xchg_status_off());
+    wait_out->status = x->status_dev;
     wait_out->seq = seq;
     wait_out->world = x->loopback ? 1 : world;
     wait_out->max_polls = x->max_polls;
@@ -151,6 +190,10 @@ int xchg_begin(icem_handle* h, XchgPush* push_out, XchgWait* wait_out) {
 }
 
 bool xchg_connected(const icem_handle* h) { return h->xchg && h->xchg->connected; }
+// what the kernels have reported so far (bit 0: a wait for a peer timed out); a plain read of host memory, not cleared
+unsigned xchg_status_peek(const icem_handle* h) {
+    return (h->xchg && h->xchg->status_host) ? __atomic_load_n(h->xchg->status_host, __ATOMIC_ACQUIRE) : 0u;
+}
 bool xchg_concurrent_peers(const icem_handle* h) { return xchg_connected(h) && !h->xchg->local_peers; }
 
 void xchg_destroy(icem_handle* h) {
@@ -160,6 +203,7 @@ void xchg_destroy(icem_handle* h) {
         if (x->opened[r] && x->peers[r]) (void)hipIpcCloseMemHandle(x->peers[r]);
     if (x->peers_dev) (void)hipFree(x->peers_dev);
     if (x->ticks_dev) (void)hipFree(x->ticks_dev);
+    if (x->status_host) (void)hipHostFree(x->status_host);
     if (x->block) (void)hipFree(x->block);
     delete x;
     h->xchg = nullptr;
@@ -217,6 +261,16 @@ int icem_exchange_create(icem_handle* h, void* ipc_out_host) {
         return fail(ICEM_E_HIP, std::string("hipMemset(exchange block): ") + hipGetErrorString(e));
     }
     x->block = (unsigned char*)p;
+    // the status word: pinned host memory the kernels write on a timed-out wait (rare) and the host reads for free
+    e = hipHostMalloc((void**)&x->status_host, 64, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&x->status_dev, x->status_host, 0);
+    if (e != hipSuccess) {
+        if (x->status_host) (void)hipHostFree(x->status_host);
+        (void)hipFree(p);
+        delete x;
+        return fail(ICEM_E_HIP, std::string("hipHostMalloc(exchange status): ") + hipGetErrorString(e));
+    }
+    std::memset(x->status_host, 0, 64);
     std::memset(ipc_out_host, 0, ICEM_IPC_HANDLE_BYTES);
     std::memcpy(ipc_out_host, &ipc, sizeof(ipc));
     h->xchg = x;
@@ -271,14 +325,10 @@ int icem_exchange_connect(icem_handle* h, const void* handles_host, void* const*
 int icem_exchange_status(icem_handle* h, int32_t* status_host, int32_t* finegrained_host) {
     if (check_handle(h)) return ICEM_E_INVALID;
     if (!h->xchg || !status_host) return fail(ICEM_E_STATE, "no exchange block / null output");
-    unsigned s = 0;
-    ICEM_HIP_TRY(hipMemcpy(&s, h->xchg->block + xchg_status_off(), sizeof(s), hipMemcpyDeviceToHost));
+    // (read and clear: host-mapped memory, no copy command and no synchronisation -- kernels still in flight report later)
+    const unsigned s = __atomic_exchange_n(h->xchg->status_host, 0u, __ATOMIC_ACQ_REL);
     *status_host = (int32_t)s;
     if (finegrained_host) *finegrained_host = h->xchg->finegrained ? 1 : 0;
-    if (s) {
-        const unsigned zero = 0;
-        ICEM_HIP_TRY(hipMemcpy(h->xchg->block + xchg_status_off(), &zero, sizeof(zero), hipMemcpyHostToDevice));
-    }
     return ICEM_OK;
 }
 
@@ -292,10 +342,9 @@ int icem_exchange_probe(icem_handle* h, int32_t rounds, void* stream, double* us
     hipStream_t st = (hipStream_t)stream;
     const size_t rec_bytes = (size_t)h->cfg.num_elites * (h->hd + 2) * h->tsize;
     if (!x->ticks_dev) ICEM_HIP_TRY(hipMalloc((void**)&x->ticks_dev, sizeof(long long)));
-    // the payload: whatever sits in this rank's slot of its own block
-    const unsigned char* mine = x->block + x->rec_off + (size_t)h->cfg.rank * rec_bytes;
-    hipLaunchKernelGGL(exchange_probe_kernel, dim3(1), dim3(256), 0, st, (const uint32_t*)mine, (int)(rec_bytes / 4), x->peers_dev,
-                       x->rec_off, x->rec_slot, rec_bytes, h->cfg.rank, h->cfg.world, x->probe_seq, rounds, x->ticks_dev);
+    hipLaunchKernelGGL(exchange_probe_kernel, dim3(1), dim3(256), 0, st, (int)(rec_bytes / 4), x->peers_dev, x->rec_off, x->rec_slot,
+                       rec_bytes, h->cfg.rank, h->cfg.world, x->loopback ? 1 : h->cfg.world, x->probe_seq, rounds, x->max_polls,
+                       x->status_dev, x->ticks_dev);
     x->probe_seq += (unsigned)rounds;
     ICEM_HIP_TRY(hipGetLastError());
     ICEM_HIP_TRY(hipStreamSynchronize(st));

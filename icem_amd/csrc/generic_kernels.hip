@@ -877,7 +877,7 @@ int launch_rollout_k(const icem_handle* h, const RolloutArgs<T>& a, hipStream_t 
         ICEM_CASE(32)
 #undef ICEM_CASE
         default:
-            return fail(ICEM_E_UNSUPPORTED, "obs_dim not compiled");
+            return fail(ICEM_E_UNSUPPORTED, "the generic rollout is compiled for padded observation widths 8, 16, 17, 18, 24, 32 only");
     }
     ICEM_HIP_TRY(hipGetLastError());
     return ICEM_OK;

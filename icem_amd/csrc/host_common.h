@@ -209,6 +209,7 @@ const char* cost_indices_error(const icem_handle* h, int o);
 
 // ---- exchange.hip: the in-library elite exchange --------------------------------------------------------------------
 bool xchg_connected(const icem_handle* h);
+unsigned xchg_status_peek(const icem_handle* h);  // != 0: a device-side wait for a peer has timed out (not cleared)
 // this rank's K records of the running iteration -> every rank's block (one launch); *wait_out: what the merge polls
 // every peer runs in a process (stream) of its own: a launch of ours may wait for something a peer launches later
 bool xchg_concurrent_peers(const icem_handle* h);
@@ -216,6 +217,21 @@ int xchg_push(icem_handle* h, const void* my_records, hipStream_t st, XchgWait* 
 // ... or, where the caller's own kernel does the push (pack_records_kernel): the arguments for it
 int xchg_begin(icem_handle* h, XchgPush* push_out, XchgWait* wait_out);
 void xchg_destroy(icem_handle* h);
+
+// Observation widths in (32, 384] exist only in k_rollout_wide.hip (f32, built-in HalfCheetah / HumanoidStandup cost form,
+// device noise, K <= 32, costs only).  What a wide handle cannot do, spelled out (nullptr = fine) -- asked by
+// icem_set_model / icem_set_cost_terms up front and by icem_rollout_cost / check_plan at use.
+inline const char* wide_unsupported(const icem_handle* h, int K, bool external_noise, bool want_observations) {
+    if (!h->wide) return nullptr;
+    if (h->has_terms)
+        return "obs_dim > 32 with icem_set_cost_terms: the built-in-model rollout at this width (k_rollout_wide) scores the "
+               "HalfCheetah / HumanoidStandup cost form only; roll the model out as a torch module (TorchForwardModel) and score "
+               "it with icem_trajectory_cost, which takes every cost term at any width";
+    if (K > 32) return "obs_dim > 32 needs num_elites <= 32 (candidate lists of k_rollout_wide)";
+    if (external_noise) return "obs_dim > 32 has no external-noise (z_r / z_i) path: the wide rollout is f32 with device noise only";
+    if (want_observations) return "obs_dim > 32: icem_rollout_cost returns costs only at this width (observations == NULL)";
+    return nullptr;
+}
 
 // ---- plan.hip: the f32 throughput path ---------------------------------------------------------------------------
 bool fast_rollout_ok(const icem_handle* h, int K);

@@ -700,6 +700,7 @@ static int check_plan(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_st
     if (!h->has_model || !h->has_cost) return fail(ICEM_E_STATE, "icem_set_model / icem_set_cost must be called first");
     if (mpc_step < 0 || it < 0 || it >= h->cfg.opt_iters) return fail(ICEM_E_INVALID, "mpc_step / iteration out of range");
     if (const char* e = cost_indices_error(h, h->obs_dim)) return fail(ICEM_E_INVALID, e);
+    if (const char* e = wide_unsupported(h, h->cfg.num_elites, b->z_r != nullptr, false)) return fail(ICEM_E_UNSUPPORTED, e);
     if (!b->mean || !b->std || !b->low || !b->high || !b->obs0 || !b->actions || !b->costs || !b->elites || !b->records ||
         !b->workspace || !b->executed || !b->best_cost)
         return fail(ICEM_E_INVALID, "null plan buffer");
@@ -787,6 +788,11 @@ int icem_plan_step_sharded(icem_handle* h, const icem_plan_buffers* b, int32_t m
     if (h->cfg.world < 2) return icem_plan_step(h, b, mpc_step, stream);
     if (!xchg_connected(h)) return fail(ICEM_E_STATE, "icem_exchange_create / icem_exchange_connect must be called first");
     if (b && b->z_r != nullptr) return fail(ICEM_E_INVALID, "external noise goes through icem_plan_iter_local / _merge");
+    // A merge of an earlier step gave up waiting for a peer's records (bounded waits): that step's elites, mean and
+    // action are garbage and differ between ranks.  The status word is host memory -- this check costs one load.
+    if (xchg_status_peek(h) & 1u)
+        return fail(ICEM_E_STATE, "in-library exchange: a wait for a peer's elite records timed out in an earlier MPC step "
+                                  "(icem_exchange_status reads and clears the word); the plans since then are not valid");
     const bool was = h->deferral;
     h->deferral = true;  // non-last merges ride in the next local launch
     int rc = ICEM_OK;

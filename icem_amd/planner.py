@@ -271,8 +271,10 @@ class IcemPlanner:
         return elites
 
     def can_update_in_one_launch(self, n_all: int, k: int) -> bool:
-        """``icem_update_distribution`` serves f32 handles, pools of at most 16 384 candidates and k <= 32."""
-        return self.cfg.dtype == "f32" and 1 <= n_all <= 16384 and 1 <= k <= 32 and not os.environ.get("ICEM_DISABLE_FAST")
+        """Does this handle serve ``icem_update_distribution`` for ``n_all`` candidates and ``k`` elites?  (f32, pools of at
+        most 16 384 candidates, k <= 32 -- and the fast-path switch the HANDLE latched at ``icem_create``: asked of the
+        handle, not re-read from the environment.)"""
+        return bool(self.lib.icem_update_distribution_ok(self._h, int(n_all), int(k)))
 
     def update_distribution(self, costs: torch.Tensor, pool: torch.Tensor, k: int, mean: torch.Tensor, std: torch.Tensor,
                             keep_costs: Optional[torch.Tensor] = None, keep_actions: Optional[torch.Tensor] = None):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ICEM_ABI_VERSION 1
+#define ICEM_ABI_VERSION 2 /* 2: icem_build_hash, icem_allgather_elites / icem_rccl_*, noise-ahead planning; ICEM_MAX_OBS_DIM 384 */
 
 enum { ICEM_F32 = 0, ICEM_F64 = 1 };
 enum { ICEM_COST_SUM = 0, ICEM_COST_BEST = 1, ICEM_COST_FINAL = 2 }; /* abstract_controller.py:82-87 */
@@ -141,6 +141,9 @@ typedef struct icem_handle icem_handle;
 
 int icem_abi_version(void);
 const char* icem_last_error(void);
+/* Hash (16 hex digits) of the sources this binary was built from -- what `python -m icem_amd.build` compares with the
+ * tree to tell a stale library from a current one (no reference counterpart: the reference is interpreted Python). */
+const char* icem_build_hash(void);
 
 /* Number of visible HIP devices (0 on a CPU-only host); never fails. */
 int icem_device_count(void);
@@ -254,6 +257,9 @@ int icem_topk_sorted(icem_handle* h, int32_t n, const void* costs, int32_t k, vo
 int icem_update_distribution(icem_handle* h, int32_t n, const void* costs, const void* pool, int32_t n_keep,
                              const void* keep_costs, const void* keep_actions, int32_t k, void* mean, void* std,
                              void* elites_out, void* elite_costs_out, int32_t* idx_out, void* stream);
+/* 1 if THIS handle serves icem_update_distribution for a pool of n_all = n + n_keep candidates and k elites (the handle's
+ * dtype and the fast-path switch it latched at icem_create decide, not the caller's environment), else 0. */
+int icem_update_distribution_ok(const icem_handle* h, int32_t n_all, int32_t k);
 
 /* K4  update_distributions (icem.py:201-211): gather the k elite rows of `actions` [*, h, d] in
  * `idx` order into elites_out [k, h, d]; mean <- (1-alpha)*mean_k + alpha*mean,

@@ -33,8 +33,18 @@ def test_header_symbols_all_exported(lib):
 
 
 def test_abi_version_and_error_string(lib):
-    assert lib.icem_abi_version() == 1
+    assert lib.icem_abi_version() == L.ABI_VERSION == 2
     assert isinstance(lib.icem_last_error(), bytes)
+
+
+def test_build_hash_is_compiled_into_the_library(lib):
+    """A stale binary must be visible whatever stamp files lie around: the hash of the sources is a string inside the
+    .so (icem_build_hash), read by icem_amd.build.build_info() without loading it."""
+    from icem_amd import build as B
+    info = B.build_info()
+    assert info["built_from"] == info["source_hash"] and not info["stale"]
+    assert lib.icem_build_hash().decode() == info["source_hash"]
+    assert B.embedded_hash(os.path.join(ROOT, "include", "icem_hip.h")) is None   # a file without the marker
 
 
 def test_struct_sizes_match_header():

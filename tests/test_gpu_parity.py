@@ -1677,6 +1677,9 @@ def test_in_library_exchange_wait_is_bounded(monkeypatch):
         L.check(pl.lib.icem_plan_iter_local(pl._h, C.byref(pl._cb), 0, it, st))
         L.check(pl.lib.icem_plan_iter_merge(pl._h, C.byref(pl._cb), 0, it, st))
     torch.cuda.synchronize()
+    # the next sharded step refuses to plan on: the status word is host memory, checked without a copy or a sync
+    rc = pl.lib.icem_plan_step_sharded(pl._h, C.byref(pl._cb), 1, st)
+    assert rc != 0 and b"timed out" in pl.lib.icem_last_error()
     assert pl.exchange_status()[0] == 1
     assert pl.exchange_status()[0] == 0  # read clears
 
