@@ -10,12 +10,18 @@ population decay (4096, 3276, 2620, 2096, 1676), K=10, f32.  Workload c4: N=6553
 HumanoidStandup action shapes (N=16384, d=17, beta=2.0, 3 iterations) on a 24-dim tanh latent model.  Workload c5
 (single GPU): the learned-dynamics configuration N=1024, h=12 -- controller-driven steps with the declared RSSM's rollout
 fused on the bf16 matrix cores; its `roofline` is bound "mfma" and its CPU baseline oracle/rssm_oracle.py.
-For --gpus G > 1 (launched by torch.distributed.run, one rank per GPU) the per-GPU population is fixed (weak
-scaling): global N = G * N, sharded by global trajectory index.  The ranks' K candidate records per CEM iteration
-move through the library's own exchange (icem_exchange_*: IPC-mapped peer blocks, peer-to-peer stores over xGMI,
-flags polled by the merge) -- torch.distributed carries the IPC handles once at set-up and the barriers around the
-timed region, nothing inside it.  The line then also carries the measured exchange latency and, under `also`, the
-N=65536-per-GPU weak-scaling run (the size north_star's multi-GPU target is stated on).
+For --gpus G > 1 there is one rank per GPU: either the driver launches them (torch.distributed.run sets RANK /
+WORLD_SIZE) or, when WORLD_SIZE is unset, `python bench.py --gpus G` starts its own G rank processes (as the reference's
+ParallelGroundTruthModel forks its own workers, icem/models/gt_par_model.py:26-37) and rank 0 prints the line.  The
+headline of a multi-GPU line is weak scaling at the metric's population per GPU (global N = G * 4096, sharded by global
+trajectory index); `also` is weak scaling at N = 65536 per GPU (the size north_star's multi-GPU target is stated on) and
+`strong` is BASELINE configs[3] as written: N = 65536 GLOBAL sharded over the G GPUs (8192 per GPU at 8).  The ranks' K
+candidate records per CEM iteration move through the library's own exchange (icem_exchange_*: IPC-mapped peer blocks,
+peer-to-peer stores over xGMI, flags polled by the merge); where that cannot be connected, through the library's own
+ncclAllGather on the launch stream (icem_allgather_elites); only if neither works, through a host-driven
+torch.distributed all-gather -- every leg says which one ran (`exchange.kind`), its latency, whether the block is
+fine-grained and how many waits timed out.  torch.distributed carries handles / ids once at set-up and the barriers
+around the timed region, nothing inside it.
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel, from HIP events recorded on
 the launch stream inside the library (icem_profile_*), in a second pass over the same steps: SURVEY 8(d)'s HBM
@@ -37,7 +43,8 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # CPU-baseline threads sleep between parallel regions
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # this process's own OpenMP teams (torch) sleep between uses; the CPU
+                                                     # baselines run in child processes with teams of their own
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -62,11 +69,12 @@ WORKLOADS = {
 }
 
 
-def make_planner(w, rank, world, seed=1234, cost_mode="sum"):
+def make_planner(w, rank, world, seed=1234, cost_mode="sum", global_n=None):
+    """One rank's planner of a run over `world` GPUs; global population = global_n (strong scaling) or w["N"] per GPU."""
     from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env, humanoid_standup_env
     env = humanoid_standup_env(w["o"]) if w.get("env") == "humanoid" else halfcheetah_env(w["o"])
     model = DeviceSyntheticModel.make(w["o"], w["d"], kind=w.get("kind", 0))
-    cfg = IcemConfig(horizon=w["h"], act_dim=w["d"], num_traj=w["N"] * world, opt_iters=w["iters"],
+    cfg = IcemConfig(horizon=w["h"], act_dim=w["d"], num_traj=global_n if global_n else w["N"] * world, opt_iters=w["iters"],
                      noise_beta=w["beta"], dtype="f32", seed=seed, rank=rank, world=world, cost_mode=cost_mode)
     pl = IcemPlanner(cfg, env.action_space.low, env.action_space.high, device=f"cuda:{torch.cuda.current_device()}")
     pl.set_model(model.kind, model.A, model.B)
@@ -74,8 +82,13 @@ def make_planner(w, rank, world, seed=1234, cost_mode="sum"):
     pl.set_cost(c.ctrl_weight, c.lin_idx, c.lin_weight, c.flip_idx, c.flip_penalty, c.flip_thresh)
     pl.reset()
     pl.obs0.copy_(torch.as_tensor(0.1 * np.random.RandomState(0).randn(w["o"]), dtype=pl.dt))
-    if world > 1 and os.environ.get("ICEM_BENCH_EXCHANGE", "library") == "library":
-        pl.connect_exchange()  # the 64-byte IPC handles travel once; no collective in the timed loop
+    if world > 1:
+        # ICEM_BENCH_EXCHANGE = library (default: IPC peer-to-peer exchange, then the in-library RCCL all-gather, then the
+        # host-driven one) | rccl (skip the first) | host (skip both)
+        want = os.environ.get("ICEM_BENCH_EXCHANGE", "library")
+        ok = want == "library" and pl.connect_exchange()  # the 64-byte IPC handles travel once
+        if not ok and want in ("library", "rccl"):
+            pl.connect_rccl()                             # the 128-byte ncclUniqueId travels once
     return pl, model, env
 
 
@@ -99,9 +112,9 @@ def algorithmic_flops_per_trajstep(kernel, d, h, o):
     return {"sample_clip": samp, "rollout_cost": roll, "sample_rollout": samp + roll}.get(kernel)
 
 
-def cpu_baseline(w, model, env, budget_s=12.0):
-    """oracle/icem_oracle.c (float64, OpenMP over trajectories) on one MPC step's worth of
-    iterations of the same workload, repeated until ~budget_s of wall time."""
+def cpu_baseline_sample(w, model, env, budget_s=4.0, samples=3):
+    """(child process) oracle/icem_oracle.c (float64, OpenMP over trajectories) on whole MPC steps' worth of iterations
+    of the same workload: `samples` samples of ~budget_s each, the BEST one reported (the others ride along)."""
     from oracle import c_oracle as CO
     lib = CO.load()
     cores = lib.icem_c_num_threads()
@@ -120,23 +133,62 @@ def cpu_baseline(w, model, env, budget_s=12.0):
     costs = np.zeros(pops[0])
     idx = np.zeros(K, dtype=np.int32)
     ec = np.zeros(K)
-    done, t0 = 0, time.perf_counter()
-    reps = 0
-    while True:
-        mean = np.zeros((h, d)) + (high + low) / 2
-        std = np.ones((h, d)) * (high - low) / 2 * 0.5
-        for it, n_it in enumerate(pops):
-            lib.icem_c_iteration(n_it, h, d, o, K, w["beta"], 0.1, 1234, reps * 8 + it, 10, model.kind, A, B, obs0, low, high,
-                                 c.ctrl_weight, c.lin_idx, c.lin_weight, c.flip_idx, c.flip_penalty, c.flip_thresh,
-                                 mean, std, actions, costs, idx, ec)
-            done += n_it * h
-        reps += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or reps >= 4096:
-            break
-    return {"value": done / el, "unit": "traj-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} MPC step(s) of the same workload ({sum(pops)} trajectories x h={h} each) in "
-                      f"{el:.1f} s; oracle/icem_oracle.c, float64, OpenMP over trajectories"}
+    rates, reps_all, el_all = [], 0, 0.0
+    for _ in range(samples):
+        done, reps, t0 = 0, 0, time.perf_counter()
+        while True:
+            mean = np.zeros((h, d)) + (high + low) / 2
+            std = np.ones((h, d)) * (high - low) / 2 * 0.5
+            for it, n_it in enumerate(pops):
+                lib.icem_c_iteration(n_it, h, d, o, K, w["beta"], 0.1, 1234, reps * 8 + it, 10, model.kind, A, B, obs0, low, high,
+                                     c.ctrl_weight, c.lin_idx, c.lin_weight, c.flip_idx, c.flip_penalty, c.flip_thresh,
+                                     mean, std, actions, costs, idx, ec)
+                done += n_it * h
+            reps += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or reps >= 4096:
+                break
+        rates.append(done / el)
+        reps_all += reps
+        el_all += el
+    return {"value": max(rates), "unit": "traj-steps/s", "cores": cores, "kind": "port", "samples": [round(r) for r in rates],
+            "sample": f"best of {samples} samples of ~{budget_s:.0f} s ({reps_all} MPC steps of the same workload in {el_all:.1f} s, "
+                      f"{sum(pops)} trajectories x h={h} each); oracle/icem_oracle.c, float64, OpenMP over trajectories, "
+                      f"{cores} thread(s) bound to cores (OMP_PROC_BIND=close, OMP_PLACES=cores, active waits)"}
+
+
+def usable_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def c_port_threads(w):
+    """Threads the C port's parallel regions can use: one region is one population (1676..4096 rows at c2) split
+    statically over the team, so beyond ~32 rows per thread the fork / join of a region costs more than its share of the
+    work.  (SMT siblings do not help a float64 FMA loop: at most one thread per two logical CPUs beyond 16.)"""
+    K, n = 10, w["N"]
+    for i in range(1, w["iters"]):
+        n = max(2 * K, int(n / 1.25))
+    cpus = usable_cores()
+    phys = cpus if cpus <= 16 else cpus // 2
+    return max(1, min(phys, n // 32))
+
+
+def cpu_baseline(workload, threads, budget_s=4.0, samples=3):
+    """The C port in a CHILD process whose OpenMP team is sized and bound before libgomp starts: `threads` threads, one
+    per core, spinning between the (short) parallel regions.  The parent's environment is left alone -- its own OpenMP
+    teams (torch) keep sleeping between uses."""
+    import subprocess
+    e = dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_PLACES="cores",
+             OMP_WAIT_POLICY="active", OMP_DYNAMIC="false")
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-c-child", workload, str(budget_s), str(samples)], env=e,
+                           capture_output=True, text=True, timeout=240)
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    except Exception as ex:  # a baseline must never take the GPU numbers down with it
+        return {"value": None, "unit": "traj-steps/s", "cores": threads, "kind": "port", "error": repr(ex)[:200]}
 
 
 def numpy_baseline_child(workload, budget_s):
@@ -190,19 +242,9 @@ def extra_cpu_baselines(workload, w, model, env):
     one = {"OMP_NUM_THREADS": "1", "OPENBLAS_NUM_THREADS": "1", "MKL_NUM_THREADS": "1"}
     child(one, "NumPy restatement, 1 thread (OMP_NUM_THREADS=1 as icem/main.py:23)", 1)
     child({}, "NumPy restatement, host default threads (BLAS only; the rest of NumPy is single-threaded)", os.cpu_count())
-    try:
-        os.environ["OMP_NUM_THREADS"] = "1"
-        b = None
-        import subprocess as sp
-        r = sp.run([sys.executable, os.path.abspath(__file__), "--cpu-c-child", workload, "5"], env=dict(os.environ, HIP_VISIBLE_DEVICES=""),
-                   capture_output=True, text=True, timeout=180)
-        b = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-        b["what"] = "C port (oracle/icem_oracle.c), 1 thread"
-        out.append(b)
-    except Exception as ex:
-        out.append({"value": None, "what": "C port, 1 thread", "error": repr(ex)[:200]})
-    finally:
-        os.environ.pop("OMP_NUM_THREADS", None)
+    one_c = cpu_baseline(workload, 1, budget_s=4.0, samples=1)
+    one_c["what"] = "C port (oracle/icem_oracle.c), 1 thread"
+    out.append(one_c)
     return out
 
 
@@ -282,12 +324,13 @@ def timed_steps(pl, steps, warmup, world):
     return el
 
 
-def measure_also(name, rank=0, world=1, steps=200, warmup=20):
+def measure_also(name, rank=0, world=1, steps=200, warmup=20, global_n=None):
     """The large-population configuration the north-star targets are stated on (N=65536 per GPU), measured in the same
-    run (every rank takes part when world > 1: weak scaling at 65536 rows per GPU): whole-loop traj-steps/s, ms per MPC
-    step, dominant-kernel roofline, and the whole loop's algorithmic bytes (8d+8/h per traj-step) over the step time."""
+    run (every rank takes part when world > 1: weak scaling at 65536 rows per GPU; global_n: strong scaling, that many
+    rows over all GPUs): whole-loop traj-steps/s, ms per MPC step, dominant-kernel roofline, and the whole loop's
+    algorithmic bytes (8d+8/h per traj-step) over the step time."""
     w = WORKLOADS[name]
-    pl, _, _ = make_planner(w, rank, world)
+    pl, _, _ = make_planner(w, rank, world, global_n=global_n)
     el = timed_steps(pl, steps, warmup, world)
     pl.profile_enable(True)
     run_steps(pl, 10, world)
@@ -296,8 +339,10 @@ def measure_also(name, rank=0, world=1, steps=200, warmup=20):
     pl.profile_enable(False)
     ts = sum(pl.population_sizes) * w["h"]  # global
     loop_bytes = ts * (8.0 * w["d"] + 8.0 / w["h"])
-    out = {"workload": w["name"], "per_gpu_population": w["N"], "global_population": w["N"] * world, "n_gpus": world,
-           "value": ts * steps / el, "unit": "traj-steps/s", "ms_per_mpc_step": 1e3 * el / steps,
+    n_glob = global_n if global_n else w["N"] * world
+    out = {"workload": w["name"] if not global_n else w["name"].replace(f"N={w['N']}", f"N={n_glob} global"),
+           "scaling": "strong" if global_n else "weak", "per_gpu_population": -(-n_glob // world), "global_population": n_glob,
+           "n_gpus": world, "value": ts * steps / el, "unit": "traj-steps/s", "ms_per_mpc_step": 1e3 * el / steps,
            "roofline": roofline_of(prof, w, name if world == 1 else None),
            "kernels_us": {k: round(1e3 * v[0] / v[1], 2) for k, v in prof.items()},
            "whole_loop_algorithmic_GBps": loop_bytes * steps / el / 1e9,
@@ -311,11 +356,28 @@ def exchange_report(pl):
     """How the ranks' elite records travelled in this run, and what one exchange costs (probe: 200 back-to-back
     exchanges inside one launch per rank, no launches around them)."""
     if not getattr(pl, "_exchange", False):
-        return {"kind": "torch.distributed all_gather_into_tensor per CEM iteration (host-driven)", "latency_us": None,
-                "in_library_exchange_error": getattr(pl, "exchange_error", None)}
+        import torch.distributed as dist
+        if getattr(pl, "_rccl", False):
+            # in-library fallback: ncclAllGather on the launch stream; latency of one such call (200 back to back)
+            import ctypes as C
+            from icem_amd import _lib as L
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                L.check(pl.lib.icem_allgather_elites(pl._h, C.c_void_p(pl.records.data_ptr()), pl._stream()))
+            torch.cuda.synchronize()
+            us = (time.perf_counter() - t0) / 200 * 1e6
+            return {"kind": "in-library: ncclAllGather of the K records on the launch stream (csrc/collective.hip, icem_allgather_elites)",
+                    "ran": "rccl", "latency_us": us, "records_bytes_per_rank": pl.K * (pl.h * pl.d + 2) * 4, "finegrained_block": None,
+                    "timeouts": 0, "host_collectives_in_timed_loop": 0, "rccl_library": pl.lib.icem_rccl_library().decode(),
+                    "in_library_exchange_error": getattr(pl, "exchange_error", None)}
+        return {"kind": "torch.distributed all_gather_into_tensor per CEM iteration (host-driven)", "ran": "host", "latency_us": None,
+                "finegrained_block": None, "timeouts": None, "host_collectives_in_timed_loop": pl.cfg.opt_iters,
+                "in_library_exchange_error": getattr(pl, "exchange_error", None), "rccl_error": getattr(pl, "rccl_error", None)}
     us = pl.exchange_probe(200)
     status, fine = pl.exchange_status()
-    return {"kind": "in-library: P2P stores into IPC-mapped peer blocks + flags (csrc/exchange.hip)", "latency_us": us,
+    return {"kind": "in-library: P2P stores into IPC-mapped peer blocks + flags (csrc/exchange.hip)", "ran": "ipc", "latency_us": us,
             "records_bytes_per_rank": pl.K * (pl.h * pl.d + 2) * 4, "finegrained_block": fine, "timeouts": status,
             "host_collectives_in_timed_loop": 0}
 
@@ -390,6 +452,30 @@ def measure_c5(w, steps, warmup, cpu=True):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes of this command line (the
+    environment torch.distributed.run would give them: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), pass rank 0's output
+    through, fail if any rank fails.  Reference analogue: ParallelGroundTruthModel forks its own workers
+    (icem/models/gt_par_model.py:26-37)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        e = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ICEM_BENCH_LAUNCHER="bench.py (self-launched ranks)")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    if rc:
+        sys.exit(rc)
+
+
 def main():
     if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-numpy-child":   # children of extra_cpu_baselines
         return numpy_baseline_child(sys.argv[2], float(sys.argv[3]))
@@ -398,7 +484,8 @@ def main():
         w = WORKLOADS[sys.argv[2]]
         env = humanoid_standup_env(w["o"]) if w.get("env") == "humanoid" else halfcheetah_env(w["o"])
         model = DeviceSyntheticModel.make(w["o"], w["d"], kind=w.get("kind", 0))
-        print(json.dumps(cpu_baseline(w, model, env, budget_s=float(sys.argv[3]))))
+        print(json.dumps(cpu_baseline_sample(w, model, env, budget_s=float(sys.argv[3]),
+                                             samples=int(sys.argv[4]) if len(sys.argv) > 4 else 1)))
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -411,18 +498,37 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the extra measurements (c4 per GPU; c5 on one GPU)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # nobody launched the ranks for us: start them ourselves (one process per GPU, this command line in each)
+        return self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-    local_rank %= max(1, torch.cuda.device_count())   # more ranks than GPUs only in a debugging run
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running with the launcher's {world} rank(s)", file=sys.stderr)
+    if os.environ.get("ICEM_BENCH_DRYRUN"):   # CPU-side test of the launch plumbing (tests/test_distributed_gloo.py): no GPU work
+        import torch.distributed as dist
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+            dist.all_reduce(t)
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dryrun": True, "n_gpus": world, "rank_sum": float(t.item()) if world > 1 else 1.0,
+                              "launched_by": os.environ.get("ICEM_BENCH_LAUNCHER", "direct")}), flush=True)
+        return
+    n_dev = max(1, torch.cuda.device_count())
+    shared_gpu = world > n_dev                        # more ranks than GPUs: a debugging run, ranks share devices
+    local_rank %= n_dev
     torch.cuda.set_device(local_rank)
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("ICEM_BENCH_BACKEND", "nccl")   # "gloo": debugging runs with ranks sharing a GPU
+        # RCCL wants one GPU per rank; ranks that share a GPU rendezvous over gloo (set-up traffic and barriers only)
+        backend = os.environ.get("ICEM_BENCH_BACKEND", "gloo" if shared_gpu else "nccl")
         dist.init_process_group(backend, rank=rank, world_size=world,
                                 **({"device_id": torch.device(f"cuda:{local_rank}")} if backend == "nccl" else {}))
 
@@ -454,10 +560,17 @@ def main():
     prof = pl.profile_read()
     pl.profile_enable(False)
     exchange = exchange_report(pl) if world > 1 else None   # collective: every rank
-    also = None
+    also = strong = None
     if args.workload == "c2" and not args.no_also:
         del pl
-        also = measure_also("c4", rank, world)              # collective when world > 1
+        # (ranks that share ONE GPU cannot run 65536 rows each: a rank's launch fills the chip and spins on a peer that
+        #  cannot get a CU until the bounded waits give up -- DESIGN section 6; the debugging run skips that leg)
+        if not shared_gpu:
+            also = measure_also("c4", rank, world)          # collective when world > 1
+        if world > 1:   # BASELINE configs[3] as written: N = 65536 global, sharded (8192 per GPU at 8)
+            # (ranks sharing one GPU: a population both ranks' launches fit the chip with, for the code path only)
+            strong = measure_also("c4", rank, world, global_n=WORKLOADS["c4"]["N"] if not shared_gpu else 2048 * world)
+            strong["debug_population"] = shared_gpu
 
     if rank == 0:
         roofline = roofline_of(prof, w, args.workload if world == 1 else None)
@@ -465,6 +578,8 @@ def main():
             "metric": "traj-steps/sec (N x h), iCEM inner planning loop", "value": per_step_trajsteps * args.steps / elapsed,
             "unit": "traj-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "launched_by": os.environ.get("ICEM_BENCH_LAUNCHER", "torch.distributed.run" if world > 1 else "direct"),
+            "rendezvous_backend": backend, "ranks_share_a_gpu": shared_gpu,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": w["name"], "per_gpu_population": w["N"], "global_population": w["N"] * world,
                        "traj_per_mpc_step": per_step_trajsteps // w["h"],
@@ -481,14 +596,21 @@ def main():
         # while after its last parallel region and would slow down kernel launches
         if also is not None:
             out["also"] = also
+        if strong is not None:
+            out["strong"] = strong
         if world == 1 and args.workload == "c2" and not args.no_also:
+            try:   # BASELINE configs[2] at the env's real width o = 378 (the f32 GEMM rollout): 30 MPC steps
+                out["also_c3"] = measure_also("c3", 0, 1, steps=30, warmup=3)
+            except Exception as ex:
+                out["also_c3"] = {"error": repr(ex)[:300]}
             try:   # BASELINE configs[4] in the default run: the learned-dynamics line, GPU part only
                 c5 = measure_c5(WORKLOADS["c5"], 200, 20, cpu=False)
                 out["also_c5"] = {k: c5[k] for k in ("value", "unit", "ms_per_step", "dtype", "config", "roofline")}
             except Exception as ex:
                 out["also_c5"] = {"error": repr(ex)[:300]}
         if not args.no_cpu_baseline and world == 1 and args.cost_mode == "sum":   # the C oracle's loop reduces by sum
-            out["cpu_baseline"] = cpu_baseline(w, model, env)
+            out["cpu_baseline"] = cpu_baseline(args.workload, c_port_threads(w))
+            out["cpu_baseline"]["host_logical_cpus"] = usable_cores()
             out["cpu_baselines"] = extra_cpu_baselines(args.workload, w, model, env)
         else:
             out["cpu_baseline"] = None

@@ -19,6 +19,7 @@ MODEL_LINEAR, MODEL_TANH = 0, 1
 
 KERNEL_NAMES = ["sample_clip", "rollout_cost", "topk_partial", "local_pack", "merge_refit", "sample_rollout"]
 
+ICEM_E_INVALID, ICEM_E_UNSUPPORTED, ICEM_E_HIP, ICEM_E_NO_DEVICE, ICEM_E_STATE = -1, -2, -3, -4, -5
 ERR_NAMES = {-1: "ICEM_E_INVALID", -2: "ICEM_E_UNSUPPORTED", -3: "ICEM_E_HIP", -4: "ICEM_E_NO_DEVICE",
              -5: "ICEM_E_STATE"}
 
@@ -119,11 +120,19 @@ SYMBOLS = [
     ("icem_sample_truncnorm", C.c_int, [_H, C.c_int32, C.c_int64, _VP, _VP, _VP, _VP, _VP, C.c_uint64, _VP, _VP]),
     ("icem_cem_bounds", C.c_int, [_H, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     ("icem_update_distribution_ok", C.c_int, [_H, C.c_int32, C.c_int32]),
+    ("icem_rccl_load", C.c_int, [C.c_char_p]),
+    ("icem_rccl_library", C.c_char_p, []),
+    ("icem_rccl_unique_id", C.c_int, [_VP]),
+    ("icem_rccl_connect", C.c_int, [_H, _VP]),
+    ("icem_rccl_adopt", C.c_int, [_H, _VP]),
+    ("icem_rccl_disconnect", C.c_int, [_H]),
+    ("icem_allgather_elites", C.c_int, [_H, _VP, _VP]),
     ("icem_profile_read", C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 ]
 
 
 IPC_HANDLE_BYTES = 64
+RCCL_ID_BYTES = 128
 ABI_VERSION = 2   # include/icem_hip.h: ICEM_ABI_VERSION
 
 

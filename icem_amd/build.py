@@ -16,7 +16,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 UNITS = ["generic_kernels.hip", "plan.hip", "abi.hip", "exchange.hip", "k_sample.hip", "k_rollout.hip", "k_merge.hip",
-         "k_iter_small.hip", "icem_rssm.hip", "k_rollout_wide.hip"]
+         "k_iter_small.hip", "icem_rssm.hip", "k_rollout_wide.hip", "collective.hip"]
 OUT = os.path.join(HERE, "libicem_hip.so")
 MARK = b"ICEM_BUILD_HASH="  # abi.hip embeds MARK + the 16 hex digits of source_hash()
 OBJ = os.path.join(CSRC, "_obj")
@@ -103,7 +103,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hd = _digest(_headers())
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(lambda u: _compile(u, hd, verbose), _units()))
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", OUT]
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", OUT]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

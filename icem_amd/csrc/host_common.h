@@ -110,6 +110,8 @@ struct icem_handle {
     icem::PackPrev pk_args;
     float* pub_dev = nullptr;        // published merge (PackPrev::pub): [2 * hd] floats, then the flag word
     unsigned pub_seq = 0;
+    void* rccl_comm = nullptr;       // collective.hip: the RCCL communicator of icem_allgather_elites (world > 1)
+    bool rccl_owned = false;         // ... created by icem_rccl_connect (destroyed with the handle) or adopted
 };
 
 namespace icem {
@@ -232,6 +234,11 @@ inline const char* wide_unsupported(const icem_handle* h, int K, bool external_n
     if (want_observations) return "obs_dim > 32: icem_rollout_cost returns costs only at this width (observations == NULL)";
     return nullptr;
 }
+
+// ---- collective.hip: the RCCL form of the elite all-gather ----------------------------------------------------------
+bool rccl_connected(const icem_handle* h);
+int rccl_allgather_records(icem_handle* h, void* records, hipStream_t st);
+void rccl_release(icem_handle* h);
 
 // ---- plan.hip: the f32 throughput path ---------------------------------------------------------------------------
 bool fast_rollout_ok(const icem_handle* h, int K);

@@ -786,7 +786,9 @@ int icem_plan_iter_merge(icem_handle* h, const icem_plan_buffers* b, int32_t mpc
 int icem_plan_step_sharded(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, void* stream) {
     if (check_handle(h)) return ICEM_E_INVALID;
     if (h->cfg.world < 2) return icem_plan_step(h, b, mpc_step, stream);
-    if (!xchg_connected(h)) return fail(ICEM_E_STATE, "icem_exchange_create / icem_exchange_connect must be called first");
+    if (!xchg_connected(h) && !rccl_connected(h))
+        return fail(ICEM_E_STATE, "neither the in-library exchange (icem_exchange_create / _connect) nor an RCCL communicator "
+                                  "(icem_rccl_connect / _adopt) is connected");
     if (b && b->z_r != nullptr) return fail(ICEM_E_INVALID, "external noise goes through icem_plan_iter_local / _merge");
     // A merge of an earlier step gave up waiting for a peer's records (bounded waits): that step's elites, mean and
     // action are garbage and differ between ranks.  The status word is host memory -- this check costs one load.
@@ -796,8 +798,10 @@ int icem_plan_step_sharded(icem_handle* h, const icem_plan_buffers* b, int32_t m
     const bool was = h->deferral;
     h->deferral = true;  // non-last merges ride in the next local launch
     int rc = ICEM_OK;
+    const bool by_rccl = !xchg_connected(h);  // the pack left this rank's K records in b->records: gather them in place
     for (int it = 0; it < h->cfg.opt_iters && rc == ICEM_OK; ++it) {
         rc = icem_plan_iter_local(h, b, mpc_step, it, stream);
+        if (rc == ICEM_OK && by_rccl) rc = rccl_allgather_records(h, b->records, (hipStream_t)stream);
         if (rc == ICEM_OK) rc = icem_plan_iter_merge(h, b, mpc_step, it, stream);
     }
     h->deferral = was;

@@ -363,8 +363,9 @@ class IcemPlanner:
         st = self._stream()
         if self.cfg.world == 1:
             L.check(self.lib.icem_plan_step(self._h, C.byref(self._cb), self.mpc_step, st))
-        elif getattr(self, "_exchange", False):
-            # in-library exchange: one C call per MPC step, no host-side collective
+        elif getattr(self, "_exchange", False) or getattr(self, "_rccl", False):
+            # in-library exchange (or, failing that, the library's own RCCL all-gather on the launch stream): one C call
+            # per MPC step, no host-side collective
             L.check(self.lib.icem_plan_step_sharded(self._h, C.byref(self._cb), self.mpc_step, st))
         else:
             # non-last merges ride in the next iteration's launch (nobody looks at mean / std in between)
@@ -422,6 +423,46 @@ class IcemPlanner:
         self.lib.icem_exchange_disable(self._h)
         self._exchange = False
         self.exchange_error = str(err) if err is not None else "a peer failed to connect"
+        return False
+
+    def connect_rccl(self, group=None) -> bool:
+        """The fallback of :meth:`connect_exchange`: an RCCL communicator owned by the library (``icem_rccl_connect``) so
+        that ``icem_plan_step_sharded`` gathers the ranks' records with ``ncclAllGather`` on the launch stream
+        (``icem_allgather_elites``) -- still one C call per MPC step and no host-side collective.  The 128-byte
+        ``ncclUniqueId`` travels once over ``torch.distributed`` (any backend).  All ranks or none."""
+        import torch.distributed as dist
+        self._ensure_buffers()
+        group = self.group if group is None else group
+        err = None
+        ident = [None]
+        try:
+            # bind the copy of RCCL this process already carries (torch's), else torch's file, else the system's
+            L.check(self.lib.icem_rccl_load(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so").encode()))
+            if self.cfg.rank == 0:
+                buf = (C.c_ubyte * L.RCCL_ID_BYTES)()
+                L.check(self.lib.icem_rccl_unique_id(buf))
+                ident = [bytes(buf)]
+        except L.IcemError as e:
+            err = e
+        dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        oks = [None] * self.cfg.world
+        dist.all_gather_object(oks, err is None and ident[0] is not None, group=group)
+        if all(oks):   # (ncclCommInitRank blocks until every rank has called it: only enter it together)
+            try:
+                blob = (C.c_ubyte * L.RCCL_ID_BYTES).from_buffer_copy(ident[0])
+                L.check(self.lib.icem_rccl_connect(self._h, blob))
+                # ... and one real all-gather of the (zeroed) record buffer
+                L.check(self.lib.icem_allgather_elites(self._h, _ptr(self.records), self._stream()))
+                torch.cuda.current_stream(self.device).synchronize()
+            except (L.IcemError, RuntimeError) as e:
+                err = e
+            dist.all_gather_object(oks, err is None, group=group)
+            if all(oks):
+                self._rccl = True
+                return True
+        self.lib.icem_rccl_disconnect(self._h)
+        self._rccl = False
+        self.rccl_error = str(err) if err is not None else "a peer failed to create the communicator"
         return False
 
     @staticmethod
@@ -538,7 +579,7 @@ class IcemPlanner:
         cfg = self.cfg
         st = self._stream()
         xchg = getattr(self, "_exchange", False)
-        if noise is None and on_iteration is None and (cfg.world == 1 or xchg):
+        if noise is None and on_iteration is None and (cfg.world == 1 or xchg or getattr(self, "_rccl", False)):
             self._cb.z_r = self._cb.z_i = self._cb.z_r_shift = self._cb.z_i_shift = None
             L.check(self.lib.icem_plan_step_sharded(self._h, C.byref(self._cb), self.mpc_step, st))
         else:

@@ -353,9 +353,32 @@ int icem_exchange_status(icem_handle* h, int32_t* status_host, int32_t* finegrai
  * rank's K records to every rank's block, then the wait for all ranks' -- over `rounds` back-to-back exchanges inside
  * one launch.  Synchronises the stream. */
 int icem_exchange_probe(icem_handle* h, int32_t rounds, void* stream, double* us_out);
-/* Whole MPC step of one rank of a sharded run (world > 1, exchange connected, device noise): opt_iters x (local launch,
- * pack + push, merge -- every merge but the last in the next local launch's prologue), no host synchronisation and no
- * host-side collective.  world == 1: icem_plan_step. */
+/* ---- the same all-gather on RCCL (world > 1) -------------------------------------------------------------------
+ * SURVEY 8(b)'s icem_allgather_elites: ncclAllGather of the ranks' K records, in place in `records`
+ * [world*K, 2 + h*d] (this rank's slot written by icem_plan_iter_local), enqueued on the launch stream between the
+ * record pack and the merge.  It is the fallback of the exchange above -- for ranks whose peer blocks do not map or
+ * whose self-test fails -- and keeps an MPC step ONE C call with zero host-side collectives (icem_plan_step_sharded).
+ * Same reference analogue: the pipe gather of icem/models/gt_par_model.py:77-94.  RCCL is bound at run time (dlopen:
+ * the copy already loaded in the process, else icem_rccl_load's path / $ICEM_RCCL_LIB / librccl.so.1); nothing here is
+ * needed, or loaded, on one GPU.
+ *   icem_rccl_unique_id   rank 0: a fresh ncclUniqueId (ICEM_RCCL_ID_BYTES bytes) for the caller to hand to every rank
+ *   icem_rccl_connect     every rank, together: ncclCommInitRank(world, id, rank) -- the handle owns the communicator
+ *   icem_rccl_adopt       or: use a communicator the caller already has (an ncclComm_t; size / rank must match)
+ *   icem_allgather_elites the collective itself (every rank, same stream order)
+ *   icem_rccl_disconnect  destroys an owned communicator / forgets an adopted one */
+#define ICEM_RCCL_ID_BYTES 128
+int icem_rccl_load(const char* path_or_null);
+const char* icem_rccl_library(void); /* which library was bound ("" = none yet) */
+int icem_rccl_unique_id(void* id_out_host);
+int icem_rccl_connect(icem_handle* h, const void* id_host);
+int icem_rccl_adopt(icem_handle* h, void* nccl_comm);
+int icem_rccl_disconnect(icem_handle* h);
+int icem_allgather_elites(icem_handle* h, void* records, void* stream);
+
+/* Whole MPC step of one rank of a sharded run (world > 1, device noise) as ONE call, no host synchronisation and no
+ * host-side collective: opt_iters x (local launch, pack, exchange, merge -- every merge but the last in the next local
+ * launch's prologue).  The exchange is the in-library one when it is connected (pack + push in one launch), else
+ * icem_allgather_elites when a communicator is connected; neither: ICEM_E_STATE.  world == 1: icem_plan_step. */
 int icem_plan_step_sharded(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, void* stream);
 
 /* Whole MPC step for world == 1: opt_iters x (local + merge), no host synchronisation

@@ -709,6 +709,26 @@ def rollout_costs(model: SyntheticModel, cost: CostSpec, obs0, actions, mode="su
     return acc
 
 
+def rollout_cost_magnitudes(model: SyntheticModel, cost: CostSpec, obs0, actions):
+    """``sum_t sum |addend|`` of every trajectory's "sum"-mode cost (the HalfCheetah / HumanoidStandup form): the scale a
+    rounding-error bound on that cost has to be relative to -- a trajectory whose positive and negative terms cancel has
+    a small cost but not a small error.  Used by the at-size parity tests (north_star's 1e-5 relative, taken relative to
+    this magnitude instead of padded with an absolute floor); same rollout as :func:`rollout_costs`."""
+    actions = np.asarray(actions, dtype=np.float64)
+    P, h, _ = actions.shape
+    obs = np.broadcast_to(np.asarray(obs0, dtype=np.float64), (P, len(obs0))).copy()
+    mag = np.zeros(P)
+    for t in range(h):
+        a = actions[:, t]
+        if cost.flip_idx >= 0:
+            mag += (np.abs(obs[:, cost.flip_idx]) > cost.flip_thresh) * abs(cost.flip_penalty)
+        mag += abs(cost.ctrl_weight) * (a * a).sum(axis=1)
+        if cost.lin_weight != 0:
+            mag += abs(cost.lin_weight) * np.abs(obs[:, cost.lin_idx])
+        obs = model.predict(obs, a)
+    return mag
+
+
 # --------------------------------------------------------------------------
 # a-11  elite selection + refit (icem.py:194-211)
 # --------------------------------------------------------------------------

@@ -136,3 +136,17 @@ def test_rssm_parameter_packing_matches_the_library_layout(lib):
     assert blk[3, 0, 2, 5, 7] == as_bf16(W[3 * 16 + 5, 2 * 8 + 7])
     assert blk[12, 1, 0, 7, 3] == as_bf16(W[12 * 16 + 7, 30 + 3])   # action column 3 sits at padded column 32 + 3
     assert int(blk[12, 1, 3].abs().sum()) == 0                  # padded action columns 56..63 are zero
+
+
+def test_rccl_binding_is_lazy_and_reports(lib):
+    """collective.hip binds RCCL at run time: loading libicem_hip.so must not need librccl, icem_allgather_elites without a
+    handle is an argument error, and where an RCCL is present a unique id can be made without a GPU."""
+    import subprocess
+    out = subprocess.run(["readelf", "-d", L.lib_path()], capture_output=True, text=True).stdout
+    assert "rccl" not in out.lower()
+    assert lib.icem_allgather_elites(None, None, None) == L.ICEM_E_INVALID
+    ident = (C.c_ubyte * L.RCCL_ID_BYTES)()
+    rc = lib.icem_rccl_unique_id(ident)
+    assert rc in (0, L.ICEM_E_UNSUPPORTED, L.ICEM_E_HIP), lib.icem_last_error()
+    if rc == 0:
+        assert any(bytes(ident)) and b"rccl" in lib.icem_rccl_library()

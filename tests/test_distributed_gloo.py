@@ -86,3 +86,25 @@ def test_sharded_exchange_matches_single_process(tmp_path, world):
         assert np.array_equal(z["gidx"].astype(np.int64), idx)           # bit-exact global elite indices
         assert np.array_equal(z["cost"], costs[idx])
         assert np.array_equal(z["mean"], mean) and np.array_equal(z["std"], std)
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` without a launcher must start N ranks itself (the driver's multi-GPU command is exactly
+    that; the reference's ParallelGroundTruthModel forks its own workers, icem/models/gt_par_model.py:26-37): every rank
+    gets RANK / WORLD_SIZE / MASTER_*, rendezvous works, rank 0 alone prints ONE line.  (Dry run: no GPU work.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["ICEM_BENCH_DRYRUN"] = "1"
+    for n in (1, 2, 3):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        j = json.loads(lines[0])
+        assert j["n_gpus"] == n and j["rank_sum"] == n * (n + 1) / 2
+        assert (j["launched_by"] == "direct") == (n == 1)

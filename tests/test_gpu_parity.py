@@ -1523,7 +1523,9 @@ def _xchg_planner(rank, world, dtype, N=1000, iters=4, seed=99, kind=1):
 @pytest.mark.parametrize("world,N", [(2, 1000), (3, 1000), (8, 1000), (4, 40000), (2, 80000), (16, 300),
                                      # rank 0's shard fills the 256 slabs exactly (1 and 2 tiles per slab): its shifted
                                      # elites of the later MPC steps must not change the launch shape behind the host's back
-                                     (2, 8192), (2, 16384), (8, 32768)])
+                                     (2, 8192), (2, 16384), (8, 32768),
+                                     # BASELINE configs[3] as written: N = 65 536 global over 8 GPUs, 8 192 rows each
+                                     (8, 65536)])
 def test_in_library_exchange_emulated_worlds(world, N, dtype, deferral):
     """All ranks of a sharded run as planners of ONE process, connected through the in-library exchange (blocks handed
     over as pointers): the records travel by exchange_push_kernel, the merges wait on the flags of their own block --
@@ -1598,6 +1600,80 @@ def test_in_library_exchange_two_processes_ipc(tmp_path, dtype, N):
         assert np.array_equal(z["acts"], acts)
         assert np.array_equal(z["mean"], np_(pl.mean))
         assert 0 < float(z["us"]) < 1e5
+
+
+def test_rccl_allgather_elites_on_one_rank():
+    """icem_allgather_elites (collective.hip): RCCL bound at run time, a communicator owned by the handle
+    (icem_rccl_unique_id -> icem_rccl_connect), ncclAllGather of the K records in place on the launch stream.  With one
+    rank the gather must leave the records as they are; a second handle adopts the first one's communicator."""
+    import ctypes as C
+    from icem_amd import _lib as L
+    pl = _xchg_planner(0, 1, "f32", 1000, 2)
+    pl._ensure_buffers()
+    ident = (C.c_ubyte * L.RCCL_ID_BYTES)()
+    L.check(pl.lib.icem_rccl_unique_id(ident))
+    assert any(bytes(ident))
+    assert b"rccl" in pl.lib.icem_rccl_library()
+    L.check(pl.lib.icem_rccl_connect(pl._h, ident))
+    pl.plan_step(0.1 * np.random.RandomState(0).randn(17))
+    pl.records.copy_(torch.randn_like(pl.records))
+    before = pl.records.clone()
+    L.check(pl.lib.icem_allgather_elites(pl._h, C.c_void_p(pl.records.data_ptr()), pl._stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(pl.records, before)
+    # without a communicator: a state error, not a crash
+    other = _xchg_planner(0, 1, "f32", 1000, 2)
+    other._ensure_buffers()
+    assert other.lib.icem_allgather_elites(other._h, C.c_void_p(other.records.data_ptr()), other._stream()) == L.ICEM_E_STATE
+    L.check(pl.lib.icem_rccl_disconnect(pl._h))
+    assert pl.lib.icem_allgather_elites(pl._h, C.c_void_p(pl.records.data_ptr()), pl._stream()) == L.ICEM_E_STATE
+
+
+def _rccl_worker(rank, world, port, out_dir, N):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if torch.cuda.device_count() >= world:
+            torch.cuda.set_device(rank)
+        pl = _xchg_planner(rank, world, "f32", N, 3, seed=21, kind=0)
+        ok = pl.connect_rccl()
+        acts = []
+        if ok:
+            for s in range(3):
+                acts.append(np_(pl.plan_step(0.1 * np.random.RandomState(s).randn(17))).copy())  # icem_plan_step_sharded over RCCL
+            torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), ok=ok, acts=np.array(acts), mean=np_(pl.mean),
+                 err=str(getattr(pl, "rccl_error", "")))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_plan_step_sharded_over_rccl_two_processes(tmp_path):
+    """The fallback collective inside the library: two ranks, no in-library exchange connected, an RCCL communicator per
+    handle -- icem_plan_step_sharded gathers the records with ncclAllGather between pack and merge (one C call per MPC
+    step, no host collective) and every rank ends with the single-process result.  RCCL wants one GPU per rank: on a
+    one-GPU box the communicator cannot be created and the test says so."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    N = 12000
+    mp.spawn(_rccl_worker, args=(2, port, str(tmp_path), N), nprocs=2, join=True)
+    z = [np.load(tmp_path / f"r{r}.npz") for r in range(2)]
+    if not all(bool(x["ok"]) for x in z):
+        assert torch.cuda.device_count() < 2, [str(x["err"]) for x in z]   # with a GPU per rank it has to work
+        pytest.skip("RCCL refuses two ranks on one GPU (" + str(z[0]["err"])[:120] + "): needs >= 2 GPUs")
+    pl = _xchg_planner(0, 1, "f32", N, 3, seed=21, kind=0)
+    acts = np.array([np_(pl.plan_step(0.1 * np.random.RandomState(s).randn(17))).copy() for s in range(3)])
+    for x in z:
+        assert np.array_equal(x["acts"], acts)
+        assert np.array_equal(x["mean"], np_(pl.mean))
 
 
 @pytest.mark.soak
@@ -1719,3 +1795,33 @@ def test_small_population_kernel_equals_two_kernel_path(h, d, o, kind, mode, N, 
     for s, (r, g) in enumerate(zip(ref, got)):
         for k, (x, y) in enumerate(zip(r, g)):
             assert np.array_equal(x, y), (s, k, np.abs(x - y).max())
+
+
+def test_bench_two_ranks_without_a_launcher():
+    """The multi-GPU bench command exactly as the driver types it -- `python bench.py --gpus 2`, no torch.distributed.run
+    in front -- on whatever GPUs this box has (one: both ranks share it and rendezvous over gloo): bench.py starts its own
+    ranks, rank 0 prints ONE line with the weak-scaling headline, the strong-scaling leg of BASELINE configs[3] and, per
+    leg, which exchange ran, its latency, the block kind and the timeout count."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["config"]["global_population"] == 2 * 4096
+    assert j["launched_by"].startswith("bench.py")
+    for leg in (j, j["strong"]) + ((j["also"],) if "also" in j else ()):
+        ex = leg["exchange"]
+        assert ex["ran"] in ("ipc", "rccl", "host")
+        if ex["ran"] == "ipc":
+            assert ex["timeouts"] == 0 and ex["latency_us"] > 0 and ex["host_collectives_in_timed_loop"] == 0
+    assert j["strong"]["scaling"] == "strong" and j["strong"]["n_gpus"] == 2
+    if torch.cuda.device_count() >= 2:
+        assert j["strong"]["global_population"] == 65536 and "also" in j
