@@ -164,6 +164,7 @@ int icem_destroy(icem_handle* h) {
     if (!h) return ICEM_OK;
     xchg_destroy(h);
     rccl_release(h);
+    ahead_destroy(h);
     if (h->W_dev) (void)hipFree(h->W_dev);
     if (h->actions_alt) (void)hipFree(h->actions_alt);
     if (h->host_stage) (void)hipHostFree(h->host_stage);

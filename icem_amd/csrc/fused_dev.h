@@ -185,7 +185,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // The h colored samples of one (trajectory, action-dim) row: per-row RNG stream -> Box-Muller -> h white
 // draws in registers (row_normals) -> inverse real DFT folded on its symmetry (row_synth); emit(t, y) receives sample
 // y of step t.  sample_row is the two in sequence; kernels that have to wait for the distribution between the two
-// (merge prologue of k_iter_large.hip) call them separately -- same operations in the same order, same bits.
+// (merge prologue of k_sample.hip's sample_folded_merge_kernel) call them separately -- same operations in the same order, same bits.
 template <int H, int ROUNDS>
 __device__ __forceinline__ void row_normals(unsigned gi, unsigned j, unsigned off_lo, unsigned off_hi, unsigned seed_lo,
                                             unsigned seed_hi, float (&g)[HMAX]) {
@@ -1208,7 +1208,7 @@ __device__ __forceinline__ unsigned long long rollout_slab(Tile& tile, const Fas
 // 16 x H x D block; the wave fetches it with full-width coalesced loads, chunk by chunk (one chunk prefetched in
 // registers), into its own LDS staging buffer; each lane then reads the one or two entries it feeds to the MFMAs.
 // Only this wave touches the buffer and a wave's LDS operations execute in order: no barriers.  Shared by
-// rollout16_kernel (k_rollout.hip) and iter_large_kernel (k_iter_large.hip).
+// rollout16_kernel (k_rollout.hip) and rollout16_ahead_kernel (k_rollout_ahead.hip).
 template <int H, int D, int O, int KIND>
 struct Stream16 {
     using Tile = Tile16<H, D, O, KIND>;
@@ -1271,6 +1271,78 @@ struct Stream16 {
 #pragma unroll
                     for (int m = 0; m < NLD; ++m) pre[m] = src[m][(t / TC + 1) * C4];
                 }
+            }
+            tile.step(st, rd0 + (t % TC) * D);
+        }
+        const float cost = tile.cost(st);
+        if (live && lane < 16) a.costs[row] = cost;
+        if (a.K > 0) {
+            const unsigned long long key = (lane < 16 && live && row < a.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
+            run_key = topk_push16(run_key, key, first, a.K, lane);
+        }
+        return run_key;
+    }
+
+    // ---- noise-ahead form (k_rollout_ahead.hip) --------------------------------------------------------------------
+    // The tile's rows hold RAW colored noise y (written ahead of time by noise_rows_kernel: it needs no distribution,
+    // icem.py:73-75).  Every vector becomes an action on its way from the prefetch registers to the staging buffer --
+    // clip(y * std + mean, low, high) (icem.py:79), the same fmaf + v_med3 the samplers apply, so the same bits; row 0 <-
+    // mean on the last iteration (icem.py:87-88) -- and is written back in place: when the launch is over the pool holds
+    // the actions and everything downstream (elite gather, record pack, the caller) reads it as before.
+    //   dist    LDS [mean (HD) | std (HD)]
+    //   lo, hi  the action bounds, the same for every action dimension (wave-uniform scalars; environments with
+    //           per-dimension bounds stay on the sampler + rollout pair -- plan.hip checks)
+    // Rows >= n_xf are taken as they are (rows that already hold actions).  One load group at a time (the empty asm
+    // statements keep the compiler from batching all groups' LDS reads: 16 registers this kernel does not have).
+    __device__ __forceinline__ void first_loads(const float* pool, int n_rows, int tile_id, Vec (&pre)[NLD]) const {
+#pragma unroll
+        for (int m = 0; m < NLD; ++m) {
+            const int r = tile_id * 16 + ld_row[m];
+            pre[m] = (reinterpret_cast<const Vec*>(pool + (size_t)(r < n_rows ? r : 0) * HD) + ld_c4[m])[0];
+        }
+    }
+    __device__ __forceinline__ unsigned long long run_xf(const Tile& tile, const FastRolloutArgs& a, float* pool, int n_xf,
+                                                         bool row0_mean, const float* dist, float lo, float hi, int tile_id, int lane,
+                                                         unsigned long long run_key, bool first, Vec (&pre)[NLD]) const {
+        const int row = tile_id * 16 + (lane & 15);
+        const bool live = row < a.n_rows;
+        unsigned voff[NLD];  // float offset of this lane's vector of load group m inside the pool (chunk 0)
+        bool xf_on[NLD], is0[NLD];
+#pragma unroll
+        for (int m = 0; m < NLD; ++m) {
+            const int r = tile_id * 16 + ld_row[m];
+            voff[m] = (unsigned)(r < a.n_rows ? r : 0) * (unsigned)HD + (unsigned)(VW * ld_c4[m]);
+            xf_on[m] = ld_on[m] && r < a.n_rows && r < n_xf;
+            is0[m] = xf_on[m] && row0_mean && r == 0;
+        }
+        typename Tile::State st;
+        tile.init(st);
+#pragma unroll
+        for (int t = 0; t < H; ++t) {
+            if (t % TC == 0) {
+                const int ch = t / TC;
+#pragma unroll
+                for (int m = 0; m < NLD; ++m) {
+                    asm volatile("" ::: "memory");
+                    const int eo = ch * CB + VW * ld_c4[m];
+                    const Vec mu = *reinterpret_cast<const Vec*>(dist + eo);
+                    const Vec sg = *reinterpret_cast<const Vec*>(dist + HD + eo);
+                    float y[VW], vm[VW], vs[VW];
+                    __builtin_memcpy(y, &pre[m], sizeof(Vec));
+                    __builtin_memcpy(vm, &mu, sizeof(Vec));
+                    __builtin_memcpy(vs, &sg, sizeof(Vec));
+#pragma unroll
+                    for (int k = 0; k < VW; ++k) {
+                        const float v = __builtin_amdgcn_fmed3f(__builtin_fmaf(y[k], vs[k], vm[k]), lo, hi);
+                        y[k] = xf_on[m] ? (is0[m] ? vm[k] : v) : y[k];
+                    }
+                    Vec out;
+                    __builtin_memcpy(&out, y, sizeof(Vec));
+                    if (ld_on[m]) *reinterpret_cast<Vec*>(&stage[Tile::SLACK + ld_row[m] * CBP + VW * ld_c4[m]]) = out;
+                    if (xf_on[m]) *reinterpret_cast<Vec*>(pool + voff[m] + ch * CB) = out;
+                    if (ch + 1 < NCH) pre[m] = *reinterpret_cast<const Vec*>(pool + voff[m] + (ch + 1) * CB);
+                }
+                asm volatile("" ::: "memory");
             }
             tile.step(st, rd0 + (t % TC) * D);
         }

@@ -110,6 +110,30 @@ struct icem_handle {
     icem::PackPrev pk_args;
     float* pub_dev = nullptr;        // published merge (PackPrev::pub): [2 * hd] floats, then the flag word
     unsigned pub_seq = 0;
+    // noise-ahead pipeline (plan.hip::plan_step_ahead; world == 1, large populations): the raw colored noise of iteration
+    // i + 1 -- and of iteration 0 of the NEXT MPC step -- is drawn on `side` while iteration i rolls out on the caller's
+    // stream; `side2` prepares and rolls out the shifted elites of iteration 0.  Non-last iterations rotate through three
+    // pools owned by the handle (a pool is rewritten by the noise three launches after the merge that read it).
+    struct Ahead {
+        hipStream_t side = nullptr, side2 = nullptr;
+        void* pool[3] = {nullptr, nullptr, nullptr};
+        unsigned long long ctr = 0;          // non-last iterations so far: pool of (step, it) = pool[(ctr + it) % 3]
+        std::vector<hipEvent_t> ev_roll;     // [it] recorded on the caller's stream behind the rollout of iteration it
+        std::vector<hipEvent_t> ev_noise;    // [it] recorded on `side` behind the noise of iteration it
+        hipEvent_t ev_start = nullptr, ev_tail = nullptr, ev_next = nullptr;
+        // the noise drawn ahead for iteration 0 of the next MPC step
+        bool next_valid = false;
+        uint64_t next_episode = 0;
+        int next_step = -1;
+        void* next_pool = nullptr;
+        // host copy of the action bounds (the transform takes them as scalars: equal in every dimension or no pipeline)
+        const void* lo_ptr = nullptr;
+        const void* hi_ptr = nullptr;
+        bool uniform = false;
+        float lo = 0.f, hi = 0.f;
+        int disabled = -1;                   // ICEM_NOISE_AHEAD=0 (latched at first use)
+        int min_rows = 0;                    // ICEM_NOISE_AHEAD_MIN_ROWS
+    } ahead;
     void* rccl_comm = nullptr;       // collective.hip: the RCCL communicator of icem_allgather_elites (world > 1)
     bool rccl_owned = false;         // ... created by icem_rccl_connect (destroyed with the handle) or adopted
 };
@@ -246,6 +270,7 @@ bool fast_sample_ok(const icem_handle* h);
 int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const void* obs0, const void* actions,
                         void* costs, float* part_c, int* part_i, hipStream_t st, int* lists_out,
                         unsigned long long* part_k = nullptr, int n_tail = 0, int* tail_out = nullptr);
+void ahead_destroy(icem_handle* h);
 int launch_fast_sample(const icem_handle* h, int n, long long first_index, const void* mean, const void* std,
                        const void* low, const void* high, uint64_t offset, int row0_mean, void* out, hipStream_t st,
                        int n_shift = 0, const void* elites_src = nullptr, uint64_t offset2 = 0);

@@ -1,5 +1,6 @@
-// icem_fused.h -- interface between the C-ABI translation unit (icem_kernels.hip) and the f32
-// throughput kernels (icem_fused.hip).  Internal; not part of the public ABI.
+// icem_fused.h -- interface between the host-side translation units (plan.hip, abi.hip) and the f32 throughput
+// kernels (k_sample.hip, k_rollout.hip, k_rollout_ahead.hip, k_rollout_wide.hip, k_iter_small.hip, k_merge.hip):
+// argument blocks and launchers.  Internal; not part of the public ABI.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -184,6 +185,27 @@ struct PackPrev {
 // single-launch kernel or the sampler of the two-kernel path; the records must fit the workgroup's tile)
 bool sample_rollout_pack_ok(int h, int d, int O, int rounds, int n_rows, int K);
 bool sample_folded_pack_ok(int h, int d, int rounds, int K);
+
+// ---- noise-ahead pipeline (large populations, world == 1; plan.hip::plan_step_ahead) -------------------------------
+// The colored noise of an iteration does not depend on the distribution (icem.py:73-79: powerlaw_psd_gaussian first,
+// `* std + mean` after), so it is drawn AHEAD on a second stream while the previous iteration's rollout runs:
+// noise_rows_kernel writes raw y [n, h, d] into the next pool buffer; rollout16_ahead_kernel is the rollout with the
+// previous iteration's merge in its prologue and the affine map + clip applied to every vector it loads, written back
+// in place.  Same operations in the same order as the sampler + rollout pair: same bits in every buffer.
+void launch_noise_rows(const FastSampleArgs& a, int rounds, hipStream_t st);  // uses n, first_index, W, seed / offset, out, white
+struct RolloutAheadArgs {
+    FastRolloutArgs r;   // r.actions == pool
+    MergeSingleArgs m;   // has_merge: the PREVIOUS iteration's merge (last == 0, lists form) runs in the prologue
+    int has_merge;
+    int n_xf;            // rows [0, n_xf) of the pool hold raw noise
+    int row0_mean;       // icem.py:87-88
+    float* pool;         // [n_rows, h, d], read and rewritten in place
+    const float* mean;   // the distribution when has_merge == 0 (else the prologue computes it from m)
+    const float* std;
+    float lo, hi;        // the action bounds, equal in every action dimension (plan.hip checks before taking this path)
+};
+bool rollout_ahead_ok(int h, int d, int O, int K, int n_rows);
+void launch_rollout_ahead(const RolloutAheadArgs& a, int h, int d, int O, int kind, hipStream_t st);
 
 // K1 with the previous iteration's merge (last == 0) in its prologue, see sample_folded_merge_kernel
 struct FastSampleMergeArgs {

@@ -80,6 +80,44 @@ __global__ __launch_bounds__(SWG) void sample_folded_kernel(FastSampleArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// K1 without the distribution ("noise ahead"): the raw colored samples y [n, h, d] of one sampling call
+// -------------------------------------------------------------------------------------------------
+// powerlaw_psd_gaussian itself (icem.py:73-75) -- 95 % of the sampler's instructions -- needs only (seed, call offset,
+// global row): it runs on a second stream while the PREVIOUS iteration's rollout is still busy, and the rollout of
+// this iteration applies `* std + mean` and the clip to every vector it loads (Stream16::run_xf).  Same sample_row, so
+// the same y; no mean / std staging, no shifted-elite workgroup.
+// DT: the action dimension as a compile-time constant for the benchmark shapes (the tile offsets of the 30 stores of a
+// row become immediates, the row / dimension split a constant division), 0 = run-time d.
+template <int H, int ROUNDS, int DT>
+__global__ __launch_bounds__(SWG) void noise_rows_kernel(FastSampleArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int d = DT > 0 ? DT : a.d;
+    const int hd = H * d;
+    const int tpw = SWG / d;
+    float* tile = smem;  // [tpw, hd]
+    const int tid = threadIdx.x;
+    const int n_base = blockIdx.x * tpw;
+    const int n_here = cmin(tpw, a.n - n_base);
+    if (tid < n_here * d) {
+        const int nl = tid / d;
+        const int j = tid - nl * d;
+        float* trow = tile + nl * hd + j;
+        sample_row<H, ROUNDS>(a.W, (unsigned)(a.first_index + n_base + nl), (unsigned)j, a.off_lo, a.off_hi, a.seed_lo,
+                              a.seed_hi, [&](int t, float y) { trow[t * d] = y; }, a.white != 0);
+    }
+    __syncthreads();
+    float* gdst = a.out + (size_t)n_base * hd;
+    const int total = n_here * hd;
+    if ((hd & 3) == 0) {
+        const float4* t4 = reinterpret_cast<const float4*>(tile);
+        float4* g4 = reinterpret_cast<float4*>(gdst);
+        for (int e = tid; e < total / 4; e += SWG) g4[e] = t4[e];
+    } else {
+        for (int e = tid; e < total; e += SWG) gdst[e] = tile[e];
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // K1 with the PREVIOUS iteration's K3 + K4 in its prologue (populations too large for the single-launch kernel)
 // -------------------------------------------------------------------------------------------------
 // sample_folded_kernel plus one wavefront per workgroup that runs the low-register selection
@@ -265,6 +303,30 @@ void launch_sample_folded_merge(const FastSampleMergeArgs& a, hipStream_t st) {
         else                                                                                                   \
             hipLaunchKernelGGL((sample_folded_merge_kernel<HH, 10, 12, false>), dim3(grid), dim3(SWG + 64), lds, st, a); \
         return;                                                                                                \
+    }
+    ICEM_FAST_HORIZONS(X)
+#undef X
+}
+
+void launch_noise_rows(const FastSampleArgs& a, int rounds, hipStream_t st) {
+    if (a.n <= 0) return;
+    const int tpw = SWG / a.d;
+    const int grid = (a.n + tpw - 1) / tpw;
+    const size_t lds = (size_t)tpw * a.h * a.d * sizeof(float);
+#define XS(HH, DD, OO)                                                                                \
+    if (a.h == HH && a.d == DD && rounds == 10) {                                                     \
+        hipLaunchKernelGGL((noise_rows_kernel<HH, 10, DD>), dim3(grid), dim3(SWG), lds, st, a);       \
+        return;                                                                                       \
+    }
+    ICEM_FAST_SHAPES(XS)
+#undef XS
+#define X(HH)                                                                                         \
+    if (a.h == HH) {                                                                                  \
+        if (rounds == 7)                                                                              \
+            hipLaunchKernelGGL((noise_rows_kernel<HH, 7, 0>), dim3(grid), dim3(SWG), lds, st, a);     \
+        else                                                                                          \
+            hipLaunchKernelGGL((noise_rows_kernel<HH, 10, 0>), dim3(grid), dim3(SWG), lds, st, a);    \
+        return;                                                                                       \
     }
     ICEM_FAST_HORIZONS(X)
 #undef X

@@ -48,7 +48,7 @@ int ensure_fast_model(icem_handle* h) {
         return ICEM_OK;
     }
     const int O = h->O, o = h->obs_dim, d = h->cfg.act_dim;
-    // layout of Tile16 (icem_fused.hip): O <= 20 -> one 16-column matrix-pipe tile + extra columns, Mp [O + d + 1, ceil4(O)];
+    // layout of Tile16 (fused_dev.h): O <= 20 -> one 16-column matrix-pipe tile + extra columns, Mp [O + d + 1, ceil4(O)];
     // O > 20 -> two tiles, observation block padded to 32 rows / columns, Mp [32 + d + 1, 32]
     const bool two = O > 20;
     const int OP = two ? 32 : O;
@@ -659,6 +659,214 @@ int plan_iter_merge_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
     return gk_merge_refit(h, a, st);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Noise-ahead pipeline (world == 1, f32, device noise, every iteration's rollout launch >= 4 waves per workgroup)
+// ---------------------------------------------------------------------------------------------------------------------
+// icem.py:73-79 draws the colored noise first and applies `* std + mean` afterwards: only the affine map depends on the
+// previous iteration.  So the critical path of an MPC step is ONE launch per iteration -- rollout16_ahead_kernel: merge
+// prologue, affine + clip on load, rollout, candidate lists -- and the noise of iteration i + 1 (and of iteration 0 of the
+// next MPC step) is drawn by noise_rows_kernel on a low-priority side stream while iteration i rolls out.  The shifted
+// elites of iteration 0 (icem.py:131-137) are prepared and rolled out on a second side stream (the sampler's extra
+// workgroup + a one-wave rollout16 launch: the same code, the same bits) and reach the merge through the cost array, as
+// in the single-launch kernel's tail shape.  Buffers: the last iteration's pool is the caller's `actions`; the others
+// rotate through three pools of the handle.
+
+void ahead_destroy(icem_handle* h) {
+    icem_handle::Ahead& A = h->ahead;
+    if (A.side) (void)hipStreamSynchronize(A.side);
+    if (A.side2) (void)hipStreamSynchronize(A.side2);
+    for (hipEvent_t e : A.ev_roll) (void)hipEventDestroy(e);
+    for (hipEvent_t e : A.ev_noise) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {A.ev_start, A.ev_tail, A.ev_next})
+        if (e) (void)hipEventDestroy(e);
+    if (A.side) (void)hipStreamDestroy(A.side);
+    if (A.side2) (void)hipStreamDestroy(A.side2);
+    for (void*& p : A.pool) {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
+    A = icem_handle::Ahead();
+}
+
+static bool ahead_eligible(icem_handle* h, const icem_plan_buffers* b) {
+    icem_handle::Ahead& A = h->ahead;
+    const icem_config& c = h->cfg;
+    if (A.disabled < 0) {
+        const char* e = getenv("ICEM_NOISE_AHEAD");
+        A.disabled = (e && atoi(e) == 0) ? 1 : 0;
+        const char* m = getenv("ICEM_NOISE_AHEAD_MIN_ROWS");
+        A.min_rows = m ? atoi(m) : 0;
+    }
+    if (A.disabled || c.world != 1 || c.dtype != ICEM_F32 || b->z_r != nullptr || !h->use_fast || h->wide || c.opt_iters < 2 ||
+        h->dbg != nullptr)
+        return false;
+    if (!fast_rollout_ok(h, c.num_elites) || !fast_sample_ok(h)) return false;
+    for (int n : h->pop)
+        if (n < A.min_rows || !rollout_ahead_ok(c.horizon, c.act_dim, h->O, c.num_elites, n)) return false;
+    if (c.shift_elites && h->n_reuse * c.act_dim > 256) return false;  // (the sampler's shifted-elite workgroup)
+    // the transform takes the bounds as two scalars: fetch them once per (low, high) buffer pair
+    if (A.lo_ptr != b->low || A.hi_ptr != b->high) {
+        std::vector<float> lo(c.act_dim), hi(c.act_dim);
+        if (hipMemcpy(lo.data(), b->low, lo.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(hi.data(), b->high, hi.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        A.lo_ptr = b->low;
+        A.hi_ptr = b->high;
+        A.uniform = true;
+        for (int j = 1; j < c.act_dim; ++j) A.uniform = A.uniform && lo[j] == lo[0] && hi[j] == hi[0];
+        A.lo = lo[0];
+        A.hi = hi[0];
+    }
+    return A.uniform;
+}
+
+static int ahead_setup(icem_handle* h) {
+    icem_handle::Ahead& A = h->ahead;
+    if (A.side) return ICEM_OK;
+    int least = 0, greatest = 0;
+    ICEM_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    ICEM_HIP_TRY(hipStreamCreateWithPriority(&A.side, hipStreamNonBlocking, least));  // the rollouts go first
+    ICEM_HIP_TRY(hipStreamCreateWithPriority(&A.side2, hipStreamNonBlocking, least));
+    auto mk = [](hipEvent_t* e) { return hipEventCreateWithFlags(e, hipEventDisableTiming); };
+    A.ev_roll.assign(h->cfg.opt_iters, nullptr);
+    A.ev_noise.assign(h->cfg.opt_iters, nullptr);
+    for (auto& e : A.ev_roll) ICEM_HIP_TRY(mk(&e));
+    for (auto& e : A.ev_noise) ICEM_HIP_TRY(mk(&e));
+    ICEM_HIP_TRY(mk(&A.ev_start));
+    ICEM_HIP_TRY(mk(&A.ev_tail));
+    ICEM_HIP_TRY(mk(&A.ev_next));
+    for (void*& p : A.pool) ICEM_HIP_TRY(hipMalloc(&p, icem_plan_buffer_bytes(h, ICEM_BUF_ACTIONS)));
+    if (!h->ws_alt) ICEM_HIP_TRY(hipMalloc(&h->ws_alt, icem_plan_buffer_bytes(h, ICEM_BUF_WORKSPACE)));
+    if (!h->pp_stats) ICEM_HIP_TRY(hipMalloc((void**)&h->pp_stats, (size_t)4 * h->hd * sizeof(float)));
+    return ICEM_OK;
+}
+
+// raw noise of sampling call `off` for rows [0, n) -> pool, on `st`
+static int ahead_noise(icem_handle* h, int n, uint64_t off, void* pool, hipStream_t st) {
+    const FastSampleArgs a = fast_sample_args(h, n, 0, nullptr, nullptr, nullptr, nullptr, off, 0, pool, 0, nullptr, 0);
+    {
+        ProfScope prof(h, ICEM_K_SAMPLE, (long long)n * a.h, st);
+        launch_noise_rows(a, h->cfg.rng_rounds, st);
+    }
+    ICEM_HIP_TRY(hipGetLastError());
+    return ICEM_OK;
+}
+
+static int plan_step_ahead(icem_handle* h, const icem_plan_buffers* b, int mpc_step, hipStream_t main) {
+    icem_handle::Ahead& A = h->ahead;
+    const icem_config& c = h->cfg;
+    const int iters = c.opt_iters, K = c.num_elites, hd = h->hd;
+    int rc = ahead_setup(h);
+    if (rc) return rc;
+    rc = ensure_fast_model(h);
+    if (rc) return rc;
+    const uint64_t call_base = (h->episode << 32) + (uint64_t)mpc_step * (uint64_t)(iters + 1);
+    auto pool_of = [&](int it) -> float* { return it == iters - 1 ? (float*)b->actions : (float*)A.pool[(A.ctr + (unsigned)it) % 3]; };
+    ICEM_HIP_TRY(hipEventRecord(A.ev_start, main));  // everything of the previous step (its last merge above all)
+    float* cur_mean = (float*)b->mean;
+    float* cur_std = (float*)b->std;
+    const int n_extra = (c.shift_elites && mpc_step > 0 && h->n_reuse > 0) ? h->n_reuse : 0;
+    for (int it = 0; it < iters; ++it) {
+        const bool last = it == iters - 1;
+        const int n = h->pop[it];
+        float* pool = pool_of(it);
+        icem_plan_buffers bb = *b;
+        bb.actions = pool;
+        if (it & 1) bb.workspace = h->ws_alt;
+        bb.mean = cur_mean;
+        bb.std = cur_std;
+        // ---- this iteration's noise: drawn ahead (side stream) or, for a step nobody predicted, right here ----
+        if (it == 0) {
+            const bool hit = A.next_valid && A.next_episode == h->episode && A.next_step == mpc_step && A.next_pool == pool;
+            A.next_valid = false;
+            if (hit) {
+                ICEM_HIP_TRY(hipStreamWaitEvent(main, A.ev_next, 0));
+            } else {
+                rc = ahead_noise(h, n, call_base, pool, main);
+                if (rc) return rc;
+            }
+            if (n_extra > 0) {
+                // shifted elites (icem.py:91-104, 131-137): rows [n, n + n_extra) as actions, then their costs -- beside
+                // the main launch; the merge of iteration 0 takes them through the cost array (its kept-elite slot)
+                const int g = (int)(((long long)mpc_step * iters) & 1);  // elite buffer holding the previous step's set
+                const float* shift_src = (const float*)b->elites + (size_t)g * K * hd;
+                ICEM_HIP_TRY(hipStreamWaitEvent(A.side2, A.ev_start, 0));
+                const FastSampleArgs sa = fast_sample_args(h, 0, 0, cur_mean, cur_std, b->low, b->high, call_base, 0, pool + (size_t)n * hd,
+                                                           n_extra, shift_src, call_base + (uint64_t)iters);
+                launch_sample_folded(sa, c.rng_rounds, A.side2);
+                ICEM_HIP_TRY(hipGetLastError());
+                FastRolloutArgs ta = fast_rollout_args(h, n_extra, 0, 0, b->obs0, pool + (size_t)n * hd, (float*)b->costs + n, nullptr, nullptr);
+                launch_rollout16(ta, c.horizon, c.act_dim, h->O, h->model_kind, A.side2);
+                ICEM_HIP_TRY(hipGetLastError());
+                ICEM_HIP_TRY(hipEventRecord(A.ev_tail, A.side2));
+            }
+        } else {
+            ICEM_HIP_TRY(hipStreamWaitEvent(main, A.ev_noise[it], 0));
+        }
+        // ---- the next noise starts when this rollout does: side waits for the rollout BEFORE this one ----
+        {
+            ICEM_HIP_TRY(hipStreamWaitEvent(A.side, it == 0 ? A.ev_start : A.ev_roll[it - 1], 0));
+            if (!last) {
+                rc = ahead_noise(h, h->pop[it + 1], call_base + (uint64_t)(it + 1), pool_of(it + 1), A.side);
+                if (rc) return rc;
+                ICEM_HIP_TRY(hipEventRecord(A.ev_noise[it + 1], A.side));
+            } else {
+                // iteration 0 of the NEXT MPC step (same episode, step + 1 -- checked when it comes)
+                void* np = A.pool[(A.ctr + (unsigned)(iters - 1)) % 3];
+                rc = ahead_noise(h, h->pop[0], (h->episode << 32) + (uint64_t)(mpc_step + 1) * (uint64_t)(iters + 1), np, A.side);
+                if (rc) return rc;
+                ICEM_HIP_TRY(hipEventRecord(A.ev_next, A.side));
+                A.next_valid = true;
+                A.next_episode = h->episode;
+                A.next_step = mpc_step + 1;
+                A.next_pool = np;
+            }
+        }
+        // ---- the launch of this iteration ----
+        RolloutAheadArgs ra;
+        ra.r = fast_rollout_args(h, n, n, K, b->obs0, pool, b->costs, nullptr, nullptr);
+        ra.r.part_k = (unsigned long long*)bb.workspace;
+        ra.has_merge = h->pm_pending ? 1 : 0;
+        if (h->pm_pending) ra.m = h->pm_args;
+        h->pm_pending = false;
+        ra.n_xf = n;
+        ra.row0_mean = (last && c.use_mean_actions) ? 1 : 0;
+        ra.pool = pool;
+        ra.mean = cur_mean;
+        ra.std = cur_std;
+        ra.lo = A.lo;
+        ra.hi = A.hi;
+        {
+            ProfScope prof(h, ICEM_K_ROLLOUT, (long long)n * c.horizon, main);
+            launch_rollout_ahead(ra, c.horizon, c.act_dim, h->O, h->model_kind, main);
+        }
+        ICEM_HIP_TRY(hipGetLastError());
+        ICEM_HIP_TRY(hipEventRecord(A.ev_roll[it], main));
+        h->fast_lists = rollout_lists(c.horizon, c.act_dim, h->O, n);
+        h->fast_tail_rows = it == 0 ? n_extra : 0;
+        if (it == 0 && n_extra > 0) ICEM_HIP_TRY(hipStreamWaitEvent(main, A.ev_tail, 0));  // before whatever merges iteration 0
+        // ---- its merge: stashed for the next launch's prologue, or (last) a launch of its own ----
+        float* pp = h->pp_stats + (size_t)(it & 1) * 2 * hd;
+        h->defer_merge = !last;
+        h->merge_mean_out = last ? (float*)b->mean : pp;
+        h->merge_std_out = last ? (float*)b->std : pp + hd;
+        rc = ICEM_DISPATCH(h, plan_iter_merge_t<float>(h, &bb, mpc_step, it, main), ICEM_E_INVALID);
+        h->defer_merge = false;
+        h->merge_mean_out = h->merge_std_out = nullptr;
+        if (rc) return rc;
+        if (!last) {
+            if (!h->pm_pending) return fail(ICEM_E_STATE, "noise-ahead: the merge did not defer");
+            cur_mean = pp;
+            cur_std = pp + hd;
+        }
+    }
+    A.ctr += (unsigned long long)(iters - 1);
+    return ICEM_OK;
+}
+
 }  // namespace icem
 
 extern "C" {
@@ -815,6 +1023,7 @@ int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step,
     if (rc) return rc;
     const icem_config& c = h->cfg;
     const int iters = c.opt_iters;
+    if (ahead_eligible(h, b)) return plan_step_ahead(h, b, mpc_step, (hipStream_t)stream);
     // f32, device noise: iteration it's merge may ride in the prologue of iteration it+1's launch.  That launch
     // reads pool / lists / distribution of iteration it while writing its own, so consecutive iterations alternate
     // between the caller's buffers and the handle's partners (the last iteration always uses the caller's).

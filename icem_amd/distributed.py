@@ -17,7 +17,7 @@ import torch.distributed as dist
 
 def shard_range(n_global: int, rank: int, world: int) -> Tuple[int, int]:
     """Global trajectory indices ``[lo, hi)`` owned by ``rank`` (must match ``shard_chunk`` in
-    csrc/icem_kernels.hip): chunks of ceil(n/world), trailing ranks may be short or empty."""
+    csrc/host_common.h): chunks of ceil(n/world), trailing ranks may be short or empty."""
     chunk = -(-n_global // world)
     lo = min(n_global, rank * chunk)
     hi = min(n_global, lo + chunk)

@@ -435,6 +435,17 @@ class IcemPlanner:
         group = self.group if group is None else group
         err = None
         ident = [None]
+        # RCCL wants one GPU per rank (two ranks on one device: "duplicate GPU", or a hang inside ncclCommInitRank):
+        # find out BEFORE anybody enters the blocking call
+        import socket
+        where = [None] * self.cfg.world
+        mine = (socket.gethostname(), torch.cuda.current_device(),
+                tuple(os.environ.get(k, "") for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")))
+        dist.all_gather_object(where, mine, group=group)
+        if len(set(where)) < self.cfg.world:
+            self._rccl = False
+            self.rccl_error = "two ranks share a GPU: RCCL needs one device per rank"
+            return False
         try:
             # bind the copy of RCCL this process already carries (torch's), else torch's file, else the system's
             L.check(self.lib.icem_rccl_load(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so").encode()))

@@ -1659,6 +1659,9 @@ def test_plan_step_sharded_over_rccl_two_processes(tmp_path):
     one-GPU box the communicator cannot be created and the test says so."""
     import socket
     import torch.multiprocessing as mp
+    if torch.cuda.device_count() < 2:
+        pytest.skip("RCCL wants one GPU per rank and this box has one (two ranks on one device end in 'duplicate GPU' or hang "
+                    "inside ncclCommInitRank; IcemPlanner.connect_rccl refuses up front): needs >= 2 GPUs")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
