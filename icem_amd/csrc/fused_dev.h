@@ -1087,6 +1087,101 @@ __device__ __forceinline__ void merge_select_records(const MergeSingleArgs& a, i
     }
 }
 
+// The same selection spread over the NW wavefronts of a workgroup, for a merge prologue that has NOTHING to hide behind
+// (rollout16_ahead_kernel: every wave waits for the distribution).  merge_select_stream walks the lists with dependent
+// loads -- a dozen L2 round trips, 12-14 us when exposed (measured) -- and merge_select holds all 4 x K keys of a lane in
+// registers (174 VGPRs); here every wave takes n_lists / NW lists, ONE list per lane, all K keys of it requested at
+// once (24 registers), reduces them to its own K best (threshold on the lane minima, depth-wise compaction, one sort) and
+// parks those in LDS; behind a workgroup barrier wave 0 selects the K best of the NW x K (+ kept elites).  One cold
+// round trip + four sorts.  Same result: the K smallest keys overall, ascending (keys are unique: they embed the row).
+// Stage 1: call from EVERY wave (w = wave index); then __syncthreads(); stage 2: call from wave 0.
+template <int KREG>
+__device__ __forceinline__ void merge_select_split_stage1(const MergeSingleArgs& a, int lane, int w, int nw, unsigned long long* cand /* [64] of this wave */,
+                                                          unsigned long long* wsel /* [nw][16] */) {
+    const int per = (a.n_lists + nw - 1) / nw;  // <= 64 (n_lists <= 256, nw >= 4)
+    const int base = w * per;
+    const int cnt = base < a.n_lists ? (a.n_lists - base < per ? a.n_lists - base : per) : 0;
+    const bool has = lane < cnt;
+    const int list = has ? base + lane : 0;
+    unsigned long long k[KREG];
+#pragma unroll
+    for (int i = 0; i < KREG; ++i) k[i] = a.part_k[(size_t)(i < a.K ? i : 0) * a.n_lists + list];
+#pragma unroll
+    for (int i = 0; i < KREG; ++i) k[i] = (has && i < a.K) ? k[i] : KEY_SENTINEL;
+    const unsigned srt = wave_sort64_u32((unsigned)(k[0] >> 32), lane);
+    const unsigned T = __shfl(srt, a.K - 1, 64);  // (fewer lists than K: the sentinel's cost half -- everything survives)
+    unsigned n_cand = 0;
+#pragma unroll
+    for (int i = 0; i < KREG; ++i) {
+        const bool p = (unsigned)(k[i] >> 32) <= T && k[i] != KEY_SENTINEL;
+        const unsigned long long m = __ballot(p);
+        if (m == 0) break;
+        const unsigned pos = n_cand + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (p && pos < 64) cand[pos] = k[i];
+        n_cand += (unsigned)__popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    unsigned long long* out = wsel + w * 16;
+    if (n_cand <= 64) {
+        unsigned long long key = lane < (int)n_cand ? *((volatile unsigned long long*)&cand[lane]) : KEY_SENTINEL;
+        key = wave_sort_n(key, lane, n_cand);
+        if (lane < 16) out[lane] = lane < a.K ? key : KEY_SENTINEL;
+    } else {
+        // more than 64 keys tie at or below the threshold: K tournament rounds over the list heads
+        for (int r = 0; r < a.K; ++r) {
+            const unsigned long long best = wave_min_u64(k[0]);
+            if (best != KEY_SENTINEL && k[0] == best) {
+#pragma unroll
+                for (int i = 0; i + 1 < KREG; ++i) k[i] = k[i + 1];
+                k[KREG - 1] = KEY_SENTINEL;
+            }
+            if (lane == 0) out[r] = best;
+        }
+        if (lane >= a.K && lane < 16) out[lane] = KEY_SENTINEL;
+    }
+}
+__device__ __forceinline__ void merge_select_split_stage2(const MergeSingleArgs& a, int lane, int nw, const unsigned long long* wsel,
+                                                          unsigned long long* cand, unsigned long long* sel) {
+    // nw * 16 <= 256 slots (sentinels behind each wave's K keys): four per lane, + kept elite `lane` (icem.py:143-145)
+    unsigned long long k[5];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) k[j] = (lane + 64 * j < nw * 16) ? *((volatile const unsigned long long*)&wsel[lane + 64 * j]) : KEY_SENTINEL;
+    k[4] = (lane < a.n_keep && a.elites_cost_cur) ? make_key(a.elites_cost_cur[lane], keep_index0(a) + lane) : KEY_SENTINEL;
+    unsigned long long mine = k[0];
+#pragma unroll
+    for (int j = 1; j < 5; ++j) mine = k[j] < mine ? k[j] : mine;
+    const unsigned long long srt = wave_sort64(mine, lane);
+    const unsigned long long T = __shfl(srt, a.K - 1, 64);
+    unsigned n_cand = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const bool p = k[j] <= T && k[j] != KEY_SENTINEL;
+        const unsigned long long m = __ballot(p);
+        const unsigned pos = n_cand + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (p && pos < 64) cand[pos] = k[j];
+        n_cand += (unsigned)__popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    if (n_cand <= 64) {
+        unsigned long long key = lane < (int)n_cand ? *((volatile unsigned long long*)&cand[lane]) : KEY_SENTINEL;
+        key = wave_sort_n(key, lane, n_cand);
+        if (lane < a.K) sel[lane] = key;
+    } else {
+        for (int r = 0; r < a.K; ++r) {
+            unsigned long long head = k[0];
+#pragma unroll
+            for (int j = 1; j < 5; ++j) head = k[j] < head ? k[j] : head;
+            const unsigned long long best = wave_min_u64(head);
+            if (best != KEY_SENTINEL) {
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+                    if (k[j] == best) k[j] = KEY_SENTINEL;
+            }
+            if (lane == 0) sel[r] = best;
+        }
+    }
+}
+
 // pointers to the K selected rows (icem.py:201): pool rows, or kept elites behind index n_global
 template <int KREG, bool REC>
 __device__ __forceinline__ void merge_rows(const MergeSingleArgs& a, const unsigned long long* sel, const int* slot,
@@ -1302,18 +1397,19 @@ struct Stream16 {
         }
     }
     __device__ __forceinline__ unsigned long long run_xf(const Tile& tile, const FastRolloutArgs& a, float* pool, int n_xf,
-                                                         bool row0_mean, const float* dist, float lo, float hi, int tile_id, int lane,
-                                                         unsigned long long run_key, bool first, Vec (&pre)[NLD]) const {
+                                                         bool row0_mean, bool store_back, const float* dist, float lo, float hi, int tile_id,
+                                                         int lane, unsigned long long run_key, bool first, Vec (&pre)[NLD]) const {
         const int row = tile_id * 16 + (lane & 15);
         const bool live = row < a.n_rows;
         unsigned voff[NLD];  // float offset of this lane's vector of load group m inside the pool (chunk 0)
-        bool xf_on[NLD], is0[NLD];
+        bool xf_on[NLD], is0[NLD], st_on[NLD];
 #pragma unroll
         for (int m = 0; m < NLD; ++m) {
             const int r = tile_id * 16 + ld_row[m];
             voff[m] = (unsigned)(r < a.n_rows ? r : 0) * (unsigned)HD + (unsigned)(VW * ld_c4[m]);
             xf_on[m] = ld_on[m] && r < a.n_rows && r < n_xf;
             is0[m] = xf_on[m] && row0_mean && r == 0;
+            st_on[m] = xf_on[m] && store_back;
         }
         typename Tile::State st;
         tile.init(st);
@@ -1339,8 +1435,10 @@ struct Stream16 {
                     Vec out;
                     __builtin_memcpy(&out, y, sizeof(Vec));
                     if (ld_on[m]) *reinterpret_cast<Vec*>(&stage[Tile::SLACK + ld_row[m] * CBP + VW * ld_c4[m]]) = out;
-                    if (xf_on[m]) *reinterpret_cast<Vec*>(pool + voff[m] + ch * CB) = out;
+                    // (the next chunk's request goes out in front of this chunk's store: on this ISA one counter tracks
+                    //  loads and stores in order, and a wait for a load issued behind a store waits for the store as well)
                     if (ch + 1 < NCH) pre[m] = *reinterpret_cast<const Vec*>(pool + voff[m] + (ch + 1) * CB);
+                    if (st_on[m]) *reinterpret_cast<Vec*>(pool + voff[m] + ch * CB) = out;
                 }
                 asm volatile("" ::: "memory");
             }

@@ -199,6 +199,7 @@ struct RolloutAheadArgs {
     int has_merge;
     int n_xf;            // rows [0, n_xf) of the pool hold raw noise
     int row0_mean;       // icem.py:87-88
+    int store_back;      // write the actions back over the noise (0: timing experiments only)
     float* pool;         // [n_rows, h, d], read and rewritten in place
     const float* mean;   // the distribution when has_merge == 0 (else the prologue computes it from m)
     const float* std;

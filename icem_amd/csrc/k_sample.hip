@@ -312,7 +312,10 @@ void launch_noise_rows(const FastSampleArgs& a, int rounds, hipStream_t st) {
     if (a.n <= 0) return;
     const int tpw = SWG / a.d;
     const int grid = (a.n + tpw - 1) / tpw;
-    const size_t lds = (size_t)tpw * a.h * a.d * sizeof(float);
+    // The LDS request also bounds how many of these workgroups a CU takes (the tile is 30 KB at d = 6: five would fit and
+    // leave a rollout workgroup of the noise-ahead pipeline -- 37 KB -- no room): at least 40.5 KB, i.e. three per CU.
+    static const size_t min_lds = [] { const char* e = getenv("ICEM_AHEAD_NOISE_LDS_KB"); return (size_t)((e ? atof(e) : 40.5) * 1024.0); }();
+    const size_t lds = std::max((size_t)tpw * a.h * a.d * sizeof(float), min_lds);
 #define XS(HH, DD, OO)                                                                                \
     if (a.h == HH && a.d == DD && rounds == 10) {                                                     \
         hipLaunchKernelGGL((noise_rows_kernel<HH, 10, DD>), dim3(grid), dim3(SWG), lds, st, a);       \

@@ -693,8 +693,12 @@ static bool ahead_eligible(icem_handle* h, const icem_plan_buffers* b) {
     icem_handle::Ahead& A = h->ahead;
     const icem_config& c = h->cfg;
     if (A.disabled < 0) {
+        // OPT-IN (ICEM_NOISE_AHEAD=1): measured on MI355X the pipeline loses to the sampler + rollout pair at every
+        // population north_star names (N = 65 536: 245-256 vs 211 us per MPC step; EXPERIMENTS.md has the timeline) -- the
+        // cross-stream event waits cost 10-15 us each on the critical path and the rollout with merge prologue + affine
+        // map on load is 4-12 us longer than rollout16_kernel.  Kept tested (bit-equal to the default path) for the record.
         const char* e = getenv("ICEM_NOISE_AHEAD");
-        A.disabled = (e && atoi(e) == 0) ? 1 : 0;
+        A.disabled = (e && atoi(e) != 0) ? 0 : 1;
         const char* m = getenv("ICEM_NOISE_AHEAD_MIN_ROWS");
         A.min_rows = m ? atoi(m) : 0;
     }
@@ -728,9 +732,17 @@ static int ahead_setup(icem_handle* h) {
     if (A.side) return ICEM_OK;
     int least = 0, greatest = 0;
     ICEM_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    ICEM_HIP_TRY(hipStreamCreateWithPriority(&A.side, hipStreamNonBlocking, least));  // the rollouts go first
-    ICEM_HIP_TRY(hipStreamCreateWithPriority(&A.side2, hipStreamNonBlocking, least));
-    auto mk = [](hipEvent_t* e) { return hipEventCreateWithFlags(e, hipEventDisableTiming); };
+    // (ICEM_AHEAD_PRIO=1: lowest stream priority for the side streams -- measured: 750-800 instead of 245 us per MPC step
+    //  at N = 65 536; a low-priority queue is not "fills the gaps", it is starved and starves in turn)
+    const char* pe = getenv("ICEM_AHEAD_PRIO");
+    const int prio = (pe && atoi(pe) != 0) ? least : 0;
+    ICEM_HIP_TRY(hipStreamCreateWithPriority(&A.side, hipStreamNonBlocking, prio));
+    ICEM_HIP_TRY(hipStreamCreateWithPriority(&A.side2, hipStreamNonBlocking, prio));
+    // The events order launches of THIS device only: no system-scope release behind the recorded work (the default: a
+    // write-back + invalidate of the caches the next launch is about to read the pool from)
+    const char* fe = getenv("ICEM_AHEAD_FENCE");
+    const unsigned ev_flags = hipEventDisableTiming | ((fe && atoi(fe) != 0) ? 0u : hipEventDisableSystemFence);
+    auto mk = [ev_flags](hipEvent_t* e) { return hipEventCreateWithFlags(e, ev_flags); };
     A.ev_roll.assign(h->cfg.opt_iters, nullptr);
     A.ev_noise.assign(h->cfg.opt_iters, nullptr);
     for (auto& e : A.ev_roll) ICEM_HIP_TRY(mk(&e));
@@ -746,6 +758,8 @@ static int ahead_setup(icem_handle* h) {
 
 // raw noise of sampling call `off` for rows [0, n) -> pool, on `st`
 static int ahead_noise(icem_handle* h, int n, uint64_t off, void* pool, hipStream_t st) {
+    static const int dbg = [] { const char* e = getenv("ICEM_AHEAD_DBG"); return e ? atoi(e) : 0; }();
+    if (dbg & 4) return ICEM_OK;  // timing experiment: no noise at all (results are garbage)
     const FastSampleArgs a = fast_sample_args(h, n, 0, nullptr, nullptr, nullptr, nullptr, off, 0, pool, 0, nullptr, 0);
     {
         ProfScope prof(h, ICEM_K_SAMPLE, (long long)n * a.h, st);
@@ -804,7 +818,8 @@ static int plan_step_ahead(icem_handle* h, const icem_plan_buffers* b, int mpc_s
                 ICEM_HIP_TRY(hipEventRecord(A.ev_tail, A.side2));
             }
         } else {
-            ICEM_HIP_TRY(hipStreamWaitEvent(main, A.ev_noise[it], 0));
+            static const int dbg = [] { const char* e = getenv("ICEM_AHEAD_DBG"); return e ? atoi(e) : 0; }();
+            if (!(dbg & 1)) ICEM_HIP_TRY(hipStreamWaitEvent(main, A.ev_noise[it], 0));  // (1: timing experiment without the wait)
         }
         // ---- the next noise starts when this rollout does: side waits for the rollout BEFORE this one ----
         {
@@ -834,6 +849,10 @@ static int plan_step_ahead(icem_handle* h, const icem_plan_buffers* b, int mpc_s
         h->pm_pending = false;
         ra.n_xf = n;
         ra.row0_mean = (last && c.use_mean_actions) ? 1 : 0;
+        {
+            static const int dbg = [] { const char* e = getenv("ICEM_AHEAD_DBG"); return e ? atoi(e) : 0; }();
+            ra.store_back = (dbg & 8) ? 0 : 1;  // (8: timing experiment without the write-back; results are garbage)
+        }
         ra.pool = pool;
         ra.mean = cur_mean;
         ra.std = cur_std;

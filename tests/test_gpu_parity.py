@@ -1828,3 +1828,35 @@ def test_bench_two_ranks_without_a_launcher():
     assert j["strong"]["scaling"] == "strong" and j["strong"]["n_gpus"] == 2
     if torch.cuda.device_count() >= 2:
         assert j["strong"]["global_population"] == 65536 and "also" in j
+
+
+@pytest.mark.parametrize("h,d,o,kind,mode,N,iters", [(30, 6, 17, 0, "sum", 16384, 3), (30, 6, 17, 1, "best", 40000, 4), (30, 17, 24, 1, "sum", 16384, 2)])
+def test_noise_ahead_pipeline_equals_the_default_path(h, d, o, kind, mode, N, iters, monkeypatch):
+    """The opt-in noise-ahead pipeline (ICEM_NOISE_AHEAD=1; plan.hip::plan_step_ahead: raw colored noise drawn on a side
+    stream by noise_rows_kernel while the previous rollout runs, rollout16_ahead_kernel = merge prologue shared by all
+    waves + affine map / clip applied to every vector it loads and written back in place, shifted elites on a second side
+    stream) against the sampler + rollout pair: same draws, same fmaf / v_med3 per sample, same rollout code -- every
+    buffer identical over four MPC steps (the noise of step s + 1's first iteration is drawn during step s).  It is not
+    the default: measured slower on MI355X (EXPERIMENTS.md)."""
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env, humanoid_standup_env
+    env = humanoid_standup_env(o) if d == 17 else halfcheetah_env(o)
+    model = DeviceSyntheticModel.make(o, d, kind=kind)
+
+    def run(on):
+        monkeypatch.setenv("ICEM_NOISE_AHEAD", "1" if on else "0")
+        pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=N, opt_iters=iters, dtype="f32", seed=5, cost_mode=mode),
+                         env.action_space.low[:d], env.action_space.high[:d])
+        pl.set_model(model.kind, model.A, model.B)
+        pl.set_cost_spec(env.cost_spec)
+        pl.reset()
+        out = []
+        for s in range(4):
+            act = np_(pl.plan_step(0.1 * np.random.RandomState(s).randn(o))).copy()
+            torch.cuda.synchronize()
+            n_last = pl.population_sizes[-1]
+            ea, ec = pl.current_elites()
+            out.append([act, np_(pl.mean), np_(pl.std), np_(ea), np_(ec), np_(pl.costs[:n_last]), np_(pl.actions[:n_last]), np_(pl.best_cost)])
+        return out
+    for got, want in zip(run(True), run(False)):
+        for x, y in zip(got, want):
+            assert np.array_equal(x, y)

@@ -14,7 +14,7 @@ import bench  # noqa: E402
 
 
 def planner(N, on, iters=5):
-    os.environ["ICEM_NOISE_AHEAD"] = "1" if on else "0"   # latched by the handle at its first icem_plan_step
+    os.environ["ICEM_NOISE_AHEAD"] = "1" if on else "0"   # opt-in; latched by the handle at its first icem_plan_step
     w = dict(bench.WORKLOADS["c4"], N=N, iters=iters)
     pl, _, _ = bench.make_planner(w, 0, 1)
     pl.plan_step_resident()
@@ -34,6 +34,11 @@ def timed(pl, steps=200):
 
 def main():
     sizes = [int(x) for x in sys.argv[1:]] or [16384, 32768, 65536, 131072]
+    if os.environ.get("ICEM_AB_ONLY"):   # one mode only, for a kernel trace: ICEM_AB_ONLY=ahead|pair
+        for N in sizes:
+            pl = planner(N, os.environ["ICEM_AB_ONLY"] == "ahead")
+            print(f"N={N:7d}  {os.environ['ICEM_AB_ONLY']} {timed(pl, 100):8.1f} us/step", flush=True)
+        return
     for N in sizes:
         a, b = planner(N, True), planner(N, False)
         # same number of steps so far on both: compare the state after a few more
