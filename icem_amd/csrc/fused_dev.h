@@ -1339,9 +1339,11 @@ struct Stream16 {
         }
     }
 
-    // costs[row] of the tile's live rows; the tile's keys join the wave's running sorted top-K
+    // costs[row] of the tile's live rows; the tile's keys join the wave's running sorted top-K.  `pre`: the tile's first
+    // chunk, requested by the caller (first_loads) -- for a wave's first tile in front of the workgroup barrier that waits
+    // for the model operands, so that the two cold round trips overlap instead of following each other.
     __device__ __forceinline__ unsigned long long run(const Tile& tile, const FastRolloutArgs& a, int tile_id, int lane,
-                                                      unsigned long long run_key, bool first) const {
+                                                      unsigned long long run_key, bool first, Vec (&pre)[NLD]) const {
         const int row = tile_id * 16 + (lane & 15);
         const bool live = row < a.n_rows;
         const Vec* src[NLD];
@@ -1350,9 +1352,6 @@ struct Stream16 {
             const int r = tile_id * 16 + ld_row[m];
             src[m] = reinterpret_cast<const Vec*>(a.actions + (size_t)(r < a.n_rows ? r : 0) * HD) + ld_c4[m];
         }
-        Vec pre[NLD];
-#pragma unroll
-        for (int m = 0; m < NLD; ++m) pre[m] = src[m][0];
         typename Tile::State st;
         tile.init(st);
 #pragma unroll

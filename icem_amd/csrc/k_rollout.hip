@@ -19,17 +19,23 @@ __global__ __launch_bounds__(64 * WAVES) void rollout16_kernel(FastRolloutArgs a
     const float obs_reg = a.obs0[(threadIdx.x < 32 && (int)threadIdx.x < a.o) ? threadIdx.x : 0];
     Tile tile;
     tile.load(a, lane);
+    Stream stream;
+    stream.init(tile, stage[wave], lane);
+    // tile t of the launch belongs to wave t / gridDim.x of workgroup t % gridDim.x: a short launch thins every CU
+    const int tiles = (a.n_rows + 15) / 16;
+    const int tile0 = wave * gridDim.x + blockIdx.x;
+    // (requesting the first tile's actions HERE, next to the model operands, so that the two cold round trips overlap,
+    //  was measured and lost: 26.5 instead of 24.5 us per launch at N = 65 536 -- 4 096 waves asking HBM for their first
+    //  chunk in the same microsecond queue up behind each other, and the model loads behind them)
+    typename Stream::Vec pre[Stream::NLD];
     if (threadIdx.x < 32) obs_stage[threadIdx.x] = (int)threadIdx.x < a.o ? obs_reg : 0.f;
     __syncthreads();
     tile.load_obs(obs_stage);
-    Stream stream;
-    stream.init(tile, stage[wave], lane);
     unsigned long long run_key = KEY_SENTINEL;
     bool first = true;
-    const int tiles = (a.n_rows + 15) / 16;
-    // tile t of the launch belongs to wave t / gridDim.x of workgroup t % gridDim.x: a short launch thins every CU
-    for (int tile_id = wave * gridDim.x + blockIdx.x; tile_id < tiles; tile_id += WAVES * gridDim.x) {
-        run_key = stream.run(tile, a, tile_id, lane, run_key, first);
+    for (int tile_id = tile0; tile_id < tiles; tile_id += WAVES * gridDim.x) {
+        stream.first_loads(a.actions, a.n_rows, tile_id, pre);
+        run_key = stream.run(tile, a, tile_id, lane, run_key, first, pre);
         first = false;
     }
     if (a.K > 0) wg_merge_emit<WAVES>(wg_keys, run_key, a.K, lane, wave, a);

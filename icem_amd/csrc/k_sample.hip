@@ -21,47 +21,68 @@ __global__ __launch_bounds__(SWG) void sample_folded_kernel(FastSampleArgs a) {
     float* ms = smem;            // mean | std
     float* tile = smem + 2 * hd;  // [tpw, hd]
     const int tid = threadIdx.x;
-    for (int e = tid; e < hd; e += SWG) {
-        ms[e] = a.mean[e];
-        ms[hd + e] = a.std[e];
+    // mean / std are requested now and parked in LDS BEHIND the draws: the generator -- 60 % of a row's instructions --
+    // needs neither, so the cold round trip of these loads hides under it instead of standing in front of it
+    float mreg[2], sreg[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = tid + i * SWG;
+        mreg[i] = a.mean[e < hd ? e : 0];
+        sreg[i] = a.std[e < hd ? e : 0];
     }
     const int n_base = blockIdx.x * tpw;
     const int n_here = cmin(tpw, a.n - n_base);
+    const bool shift_wg = a.n_shift > 0 && blockIdx.x == gridDim.x - 1;
+    const bool has_row = !shift_wg && tid < n_here * d;
+    const int nl = tid / d;
+    const int j = tid - nl * d;
+    const float lo = a.low[j < d ? j : 0], hi = a.high[j < d ? j : 0];
+    float g[HMAX];
+    if (has_row)
+        row_normals<H, ROUNDS>((unsigned)(a.first_index + n_base + nl), (unsigned)j, a.off_lo, a.off_hi, a.seed_lo, a.seed_hi, g);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = tid + i * SWG;
+        if (e < hd) {
+            ms[e] = mreg[i];
+            ms[hd + e] = sreg[i];
+        }
+    }
+    for (int e = tid + 2 * SWG; e < hd; e += SWG) {
+        ms[e] = a.mean[e];
+        ms[hd + e] = a.std[e];
+    }
     __syncthreads();
-    if (a.n_shift > 0 && blockIdx.x == gridDim.x - 1) {
+    if (shift_wg) {
         // the extra workgroup: shifted elites.  Row (e, j) keeps elites[e, 1:, j] and draws its last action
         // from the full (n_shift, d, h) noise batch of stream off2 (only t = h-1 is used, icem.py:102)
         if (tid < a.n_shift * d) {
             const int e = tid / d;
-            const int j = tid - e * d;
-            const float lo = a.low[j], hi = a.high[j];
+            const int js = tid - e * d;
+            const float los = a.low[js], his = a.high[js];
             float last = 0.f;
-            sample_row<H, ROUNDS>(a.W, (unsigned)e, (unsigned)j, a.off2_lo, a.off2_hi, a.seed_lo, a.seed_hi,
+            sample_row<H, ROUNDS>(a.W, (unsigned)e, (unsigned)js, a.off2_lo, a.off2_hi, a.seed_lo, a.seed_hi,
                                   [&](int t, float y) {
                                       if (t == H - 1) {
-                                          float v = __builtin_fmaf(y, ms[hd + t * d + j], ms[t * d + j]);
-                                          v = v < lo ? lo : v;
-                                          last = v > hi ? hi : v;
+                                          float v = __builtin_fmaf(y, ms[hd + t * d + js], ms[t * d + js]);
+                                          v = v < los ? los : v;
+                                          last = v > his ? his : v;
                                       }
                                   }, a.white != 0);
-            float* dst = a.out + (size_t)(a.n + e) * hd + j;
-            const float* src = a.elites_src + (size_t)e * hd + j;
+            float* dst = a.out + (size_t)(a.n + e) * hd + js;
+            const float* src = a.elites_src + (size_t)e * hd + js;
             for (int t = 0; t < H - 1; ++t) dst[t * d] = src[(t + 1) * d];
             dst[(H - 1) * d] = last;
         }
         return;
     }
-    if (tid < n_here * d) {
-        const int nl = tid / d;
-        const int j = tid - nl * d;
-        const float lo = a.low[j], hi = a.high[j];
+    if (has_row) {
         float* trow = tile + nl * hd + j;
         const float* mrow = ms + j;
-        sample_row<H, ROUNDS>(a.W, (unsigned)(a.first_index + n_base + nl), (unsigned)j, a.off_lo, a.off_hi, a.seed_lo,
-                              a.seed_hi, [&](int t, float y) {
-                                  const float v = __builtin_fmaf(y, mrow[hd + t * d], mrow[t * d]);
-                                  trow[t * d] = __builtin_amdgcn_fmed3f(v, lo, hi);  // clip in one v_med3_f32
-                              }, a.white != 0);
+        row_synth<H>(a.W, g, [&](int t, float y) {
+            const float v = __builtin_fmaf(y, mrow[hd + t * d], mrow[t * d]);
+            trow[t * d] = __builtin_amdgcn_fmed3f(v, lo, hi);  // clip in one v_med3_f32
+        }, a.white != 0);
     }
     __syncthreads();
     if (a.row0_mean && a.first_index + n_base == 0) {  // icem.py:87-88

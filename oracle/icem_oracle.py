@@ -656,6 +656,11 @@ class SyntheticModel:
         dt = obs.dtype
         A = self.A.astype(dt)
         B = self.B.astype(dt)
+        if dt == np.float64 and A.shape[0] > 64:
+            # wide observations (HumanoidStandup's o = 378): one BLAS product per step instead of o passes over
+            # [P, o] -- in float64 the summation order is worth 1e-15, and the fixed order matters for float32 only
+            nxt = obs @ A + act @ B
+            return np.tanh(nxt) if self.kind == MODEL_TANH else nxt
         nxt = np.zeros_like(obs)
         for k in range(A.shape[0]):
             nxt = nxt + obs[..., k:k + 1] * A[k]
