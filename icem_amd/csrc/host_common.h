@@ -110,17 +110,12 @@ struct icem_handle {
     icem::PackPrev pk_args;
     float* pub_dev = nullptr;        // published merge (PackPrev::pub): [2 * hd] floats, then the flag word
     unsigned pub_seq = 0;
-    // noise-ahead pipeline (plan.hip::plan_step_ahead; world == 1, large populations): the raw colored noise of iteration
-    // i + 1 -- and of iteration 0 of the NEXT MPC step -- is drawn on `side` while iteration i rolls out on the caller's
-    // stream; `side2` prepares and rolls out the shifted elites of iteration 0.  Non-last iterations rotate through three
-    // pools owned by the handle (a pool is rewritten by the noise three launches after the merge that read it).
+    // noise-ahead pipeline (plan.hip::plan_step_ahead; world == 1, large populations): every iteration's launch
+    // also draws the raw noise of the NEXT sampling call into the next pool.  Non-last iterations rotate through three
+    // pools owned by the handle (a pool is rewritten by the noise role two launches after the merge that read it).
     struct Ahead {
-        hipStream_t side = nullptr, side2 = nullptr;
         void* pool[3] = {nullptr, nullptr, nullptr};
         unsigned long long ctr = 0;          // non-last iterations so far: pool of (step, it) = pool[(ctr + it) % 3]
-        std::vector<hipEvent_t> ev_roll;     // [it] recorded on the caller's stream behind the rollout of iteration it
-        std::vector<hipEvent_t> ev_noise;    // [it] recorded on `side` behind the noise of iteration it
-        hipEvent_t ev_start = nullptr, ev_tail = nullptr, ev_next = nullptr;
         // the noise drawn ahead for iteration 0 of the next MPC step
         bool next_valid = false;
         uint64_t next_episode = 0;
@@ -131,7 +126,10 @@ struct icem_handle {
         const void* hi_ptr = nullptr;
         bool uniform = false;
         float lo = 0.f, hi = 0.f;
-        int disabled = -1;                   // ICEM_NOISE_AHEAD=0 (latched at first use)
+        // part of that noise rides beside the step's LAST merge (the one launch that leaves the chip idle)
+        bool tail_pending = false;
+        icem::FastSampleArgs tail_args;
+        int disabled = -1;                   // ICEM_NOISE_AHEAD (latched at first use)
         int min_rows = 0;                    // ICEM_NOISE_AHEAD_MIN_ROWS
     } ahead;
     void* rccl_comm = nullptr;       // collective.hip: the RCCL communicator of icem_allgather_elites (world > 1)

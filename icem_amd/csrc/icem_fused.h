@@ -136,6 +136,9 @@ struct MergeSingleArgs {
     long long* dbg;  // development: 8 wall_clock64 stamps (100 MHz) of thread 0, nullptr in production
 };
 void launch_merge_single(const MergeSingleArgs& a, hipStream_t st);
+// ... with noise workgroups beside it (noise-ahead pipeline: z.n rows of raw colored noise -> z.out; see merge_noise_kernel)
+bool merge_noise_ok(const MergeSingleArgs& a, int rounds);
+void launch_merge_noise(const MergeSingleArgs& a, const FastSampleArgs& z, hipStream_t st);
 // icem_update_distribution for small f32 pools (topk_small_ok(n + n_keep, K)): top-K over [costs | keep_costs], gather from
 // [pool | keep_actions], refit of mean / std in place -- one launch
 struct UpdateSmallArgs {
@@ -186,27 +189,35 @@ struct PackPrev {
 bool sample_rollout_pack_ok(int h, int d, int O, int rounds, int n_rows, int K);
 bool sample_folded_pack_ok(int h, int d, int rounds, int K);
 
-// ---- noise-ahead pipeline (large populations, world == 1; plan.hip::plan_step_ahead) -------------------------------
+// ---- noise-ahead pipeline (large populations, world == 1; plan.hip::plan_step_ahead) -----------------------
 // The colored noise of an iteration does not depend on the distribution (icem.py:73-79: powerlaw_psd_gaussian first,
-// `* std + mean` after), so it is drawn AHEAD on a second stream while the previous iteration's rollout runs:
-// noise_rows_kernel writes raw y [n, h, d] into the next pool buffer; rollout16_ahead_kernel is the rollout with the
-// previous iteration's merge in its prologue and the affine map + clip applied to every vector it loads, written back
-// in place.  Same operations in the same order as the sampler + rollout pair: same bits in every buffer.
+// `* std + mean` after), so it is drawn AHEAD: every iteration is ONE launch (iter_ahead_kernel, k_rollout_ahead.hip)
+// whose workgroups split into a rollout role (previous iteration's merge in the prologue, affine map + clip applied to
+// every vector it loads from the raw-noise pool and written back in place), a noise role (the NEXT sampling call's raw
+// y [n, h, d] into the next pool) and, at iteration 0, a shifted-elites role.  Same operations in the same order as the
+// sampler + rollout pair: same bits in every buffer.
 void launch_noise_rows(const FastSampleArgs& a, int rounds, hipStream_t st);  // uses n, first_index, W, seed / offset, out, white
-struct RolloutAheadArgs {
+struct IterAheadArgs {
+    // rollout role
     FastRolloutArgs r;   // r.actions == pool
     MergeSingleArgs m;   // has_merge: the PREVIOUS iteration's merge (last == 0, lists form) runs in the prologue
     int has_merge;
     int n_xf;            // rows [0, n_xf) of the pool hold raw noise
     int row0_mean;       // icem.py:87-88
-    int store_back;      // write the actions back over the noise (0: timing experiments only)
     float* pool;         // [n_rows, h, d], read and rewritten in place
     const float* mean;   // the distribution when has_merge == 0 (else the prologue computes it from m)
     const float* std;
     float lo, hi;        // the action bounds, equal in every action dimension (plan.hip checks before taking this path)
+    // noise role: z.n rows of the sampling call (z.off_*) -> z.out (z.n == 0: no such workgroups)
+    FastSampleArgs z;
+    // shift role: s.n_shift shifted elites from s.elites_src (stream s.off2_*, distribution s.mean / s.std) -> rows
+    // [s.n, s.n + s.n_shift) of s.out (== pool) and their costs -> r.costs[s.n ...] (s.n_shift == 0: no such workgroup)
+    FastSampleArgs s;
+    int n_roll, n_noise;  // workgroups per role (filled by the launcher)
 };
 bool rollout_ahead_ok(int h, int d, int O, int K, int n_rows);
-void launch_rollout_ahead(const RolloutAheadArgs& a, int h, int d, int O, int kind, hipStream_t st);
+int ahead_roll_workgroups(int n_rows);  // = candidate lists of that launch
+void launch_iter_ahead(const IterAheadArgs& a, int h, int d, int O, int kind, hipStream_t st);
 
 // K1 with the previous iteration's merge (last == 0) in its prologue, see sample_folded_merge_kernel
 struct FastSampleMergeArgs {

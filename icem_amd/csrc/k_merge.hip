@@ -9,11 +9,10 @@ namespace icem {
 namespace {
 
 template <int KREG, bool REC>
-__global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs a) {
+__device__ __forceinline__ void merge_single_body(const MergeSingleArgs& a, unsigned char* smem_raw) {
     __shared__ unsigned long long sel[64];
     __shared__ unsigned long long cand[64];
     __shared__ int slot[64];
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* new_mean = reinterpret_cast<float*>(smem_raw);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -78,6 +77,45 @@ __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs 
         if (tid == 0) a.best_cost[0] = key_cost(sel[0]);
     }
     if (a.dbg && threadIdx.x == 0) a.dbg[6] = wall_clock64();
+}
+
+template <int KREG, bool REC>
+__global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    merge_single_body<KREG, REC>(a, smem_raw);
+}
+
+// The last merge of an MPC step with company (noise-ahead pipeline, plan.hip): workgroup 0 is merge_single_kernel, the
+// other workgroups draw raw colored noise (noise_rows_kernel's work: sample_row into an LDS tile, coalesced copy-out) for
+// iteration 0 of the NEXT MPC step -- the one launch of a step during which 255 of the 256 CUs had nothing to do.
+template <int H, int KREG>
+__global__ __launch_bounds__(MERGE_WG) void merge_noise_kernel(MergeSingleArgs a, FastSampleArgs z) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if (blockIdx.x == 0) {
+        merge_single_body<KREG, false>(a, smem_raw);
+        return;
+    }
+    float* tile = reinterpret_cast<float*>(smem_raw);
+    const int d = z.d, hd = H * d, tpw = MERGE_WG / d, tid = threadIdx.x;
+    const int n_base = ((int)blockIdx.x - 1) * tpw;
+    const int n_here = cmin(tpw, z.n - n_base);
+    if (tid < n_here * d) {
+        const int nl = tid / d;
+        const int j = tid - nl * d;
+        float* trow = tile + nl * hd + j;
+        sample_row<H, 10>(z.W, (unsigned)(z.first_index + n_base + nl), (unsigned)j, z.off_lo, z.off_hi, z.seed_lo, z.seed_hi,
+                          [&](int t, float y) { trow[t * d] = y; }, z.white != 0);
+    }
+    __syncthreads();
+    float* gdst = z.out + (size_t)n_base * hd;
+    const int total = n_here * hd;
+    if ((hd & 3) == 0) {
+        const float4* t4 = reinterpret_cast<const float4*>(tile);
+        float4* g4 = reinterpret_cast<float4*>(gdst);
+        for (int e = tid; e < total / 4; e += MERGE_WG) g4[e] = t4[e];
+    } else {
+        for (int e = tid; e < total; e += MERGE_WG) gdst[e] = tile[e];
+    }
 }
 
 // Sharded runs: this rank's K best candidates (same selection) packed as records (pack_records_body) -- a launch of
@@ -190,6 +228,24 @@ void launch_pack_records(const MergeSingleArgs& a, int n_loc, int shard_lo, floa
         hipLaunchKernelGGL((pack_records_kernel<12>), dim3(1), dim3(MERGE_WG), lds, st, a, n_loc, shard_lo, records, px);
     else
         hipLaunchKernelGGL((pack_records_kernel<34>), dim3(1), dim3(MERGE_WG), lds, st, a, n_loc, shard_lo, records, px);
+}
+
+// lists form, K <= 11, default generator, a compiled sampler horizon (else: launch_merge_single + launch_noise_rows)
+bool merge_noise_ok(const MergeSingleArgs& a, int rounds) {
+    return a.records == nullptr && a.K + 1 <= 12 && rounds == 10 && fast_sample_supported(a.h, a.d);
+}
+
+void launch_merge_noise(const MergeSingleArgs& a, const FastSampleArgs& z, hipStream_t st) {
+    const int tpw = MERGE_WG / z.d;
+    const int grid = 1 + (z.n + tpw - 1) / tpw;
+    const size_t lds = std::max((size_t)a.h * a.d, (size_t)tpw * z.h * z.d) * sizeof(float);
+#define X(HH)                                                                                          \
+    if (a.h == HH) {                                                                                   \
+        hipLaunchKernelGGL((merge_noise_kernel<HH, 12>), dim3(grid), dim3(MERGE_WG), lds, st, a, z);   \
+        return;                                                                                        \
+    }
+    ICEM_FAST_HORIZONS(X)
+#undef X
 }
 
 void launch_merge_single(const MergeSingleArgs& a, hipStream_t st) {

@@ -1,55 +1,177 @@
-// k_rollout_ahead.hip -- K2 + K3 of the noise-ahead pipeline (large populations, world == 1): rollout16_ahead_kernel =
-// rollout16_kernel (one wavefront per 16 trajectories on v_mfma_f32_16x16x4_f32, Tile16 / Stream16 of fused_dev.h) whose
-// pool holds RAW colored noise drawn ahead of time (noise_rows_kernel, k_sample.hip, on a second stream while the
-// previous rollout ran).  What the sampler used to do with the distribution happens here:
-//   * PM: the PREVIOUS iteration's K3 + K4 (top-K of its candidate lists, elite gather, refit; icem.py:194-211) in the
-//     prologue -- all wavefronts share the selection (merge_select_split: nothing hides it here), then all threads gather +
-//     refit (refit.h: every workgroup gets the same bits), workgroup 0 publishes;
-//   * every vector a wave loads becomes clip(y * std + mean) (icem.py:79) between the prefetch registers and its LDS
-//     staging buffer and is written back in place (Stream16::run_xf): after the launch the pool holds the actions.
-// One launch per CEM iteration on the critical path instead of two; same operations in the same order as
-// sample_folded(_merge)_kernel + rollout16_kernel, so the same bits in every buffer (tests: the at-size loops, the
-// plan_step == split-API checks).
+// k_rollout_ahead.hip -- the noise-ahead iteration launch (large populations, world == 1; plan.hip::plan_step_ahead): ONE launch
+// per CEM iteration whose workgroups play different roles,
+//   rollout  (the first `n_roll` workgroups)  rollout16_kernel's work (one wavefront per 16 trajectories on
+//            v_mfma_f32_16x16x4_f32, Tile16 / Stream16 of fused_dev.h) on a pool that holds RAW colored noise: the PREVIOUS
+//            iteration's K3 + K4 (top-K of its candidate lists, elite gather, refit; icem.py:194-211) in the prologue, the
+//            selection shared by all waves (merge_select_split: nothing hides it here), then every vector a wave loads
+//            becomes clip(y * std + mean) (icem.py:79) between the prefetch registers and its LDS staging buffer and is
+//            written back in place (Stream16::run_xf): after the launch the pool holds the actions;
+//   noise    (the next `n_noise` workgroups)  the raw colored noise of the NEXT sampling call (iteration i + 1, or
+//            iteration 0 of the next MPC step) into the next pool: powerlaw_psd_gaussian needs no distribution
+//            (icem.py:73-79), so it runs beside the rollout whose waves leave half of every SIMD's registers free;
+//   shift    (one more workgroup, iteration 0 of every MPC step but the first)  the shifted elites (icem.py:91-104,
+//            131-137): built like the sampler's extra workgroup builds them, rolled out by the workgroup's first wave, and
+//            handed to the merge through the cost array (its kept-elite slot), as the single-launch kernel's tail rows.
+// All roles in one launch on ONE stream: no events, no second queue (the two-stream form of this pipeline lost 10-15 us
+// per cross-stream wait; profiles/r03_noise_ahead_*).  Same operations in the same order as sample_folded(_merge)_kernel +
+// rollout16_kernel, so the same bits in every buffer (tests: test_noise_ahead_pipeline_equals_the_default_path).
 #include "fused_dev.h"
 
 namespace icem {
 
 namespace {
 
-// (at most 128 registers whatever the workgroup size: the waves share their SIMDs with the noise kernel's)
+constexpr int AHEAD_KREG = 12;
+
+// LDS of a workgroup (dynamic, one buffer overlaid by the three roles), in floats
+template <int H, int D, int O, int KIND, int WAVES>
+struct AheadLds {
+    using Stream = Stream16<H, D, O, KIND>;
+    using T16 = Tile16<H, D, O, KIND>;
+    static constexpr int HD = H * D, NT = 64 * WAVES;
+    // rollout role
+    static constexpr int STAGE = 0;                                   // [WAVES][STG]; the selection's scratch lies over it
+    static constexpr int KEYS = STAGE + WAVES * Stream::STG + (WAVES * Stream::STG) % 2;   // u64 [2][WAVES][32]
+    static constexpr int DIST = KEYS + 2 * (2 * WAVES * 32);          // [2 HD]
+    static constexpr int OBS = DIST + 2 * HD + (2 * HD) % 4;          // [32]
+    static constexpr int SEL = OBS + 32;                              // u64 [64]
+    static constexpr int WSEL = SEL + 2 * 64;                         // u64 [WAVES * 16]
+    static constexpr int SLOT = WSEL + 2 * WAVES * 16;                // int [64]
+    static constexpr int ROLL_END = SLOT + 64;
+    static_assert(WAVES * 64 * 2 <= WAVES * Stream::STG, "per-wave compaction scratch fits the staging buffers");
+    // noise role: [tpw, HD] tile of NT / D rows
+    static constexpr int TPW = NT / D;
+    static constexpr int NOISE_END = TPW * HD;
+    // shift role: mean | std, then a 16-row tile the first wave rolls out
+    static constexpr int SH_DIST = 0;
+    static constexpr int SH_TILE = 2 * HD + (2 * HD) % 4;
+    static constexpr int SHIFT_END = SH_TILE + T16::SLACK + 16 * HD + T16::TAIL + 32;
+    static constexpr int FLOATS = ROLL_END > NOISE_END ? (ROLL_END > SHIFT_END ? ROLL_END : SHIFT_END) : (NOISE_END > SHIFT_END ? NOISE_END : SHIFT_END);
+};
+
+// (at most 128 registers whatever the workgroup size: the rollout waves share their SIMDs with the noise role's.  96 -- a
+//  fifth wave per SIMD -- spills 32 registers in the rollout role: measured 220 instead of 185 us per MPC step at N = 65 536)
 template <int H, int D, int O, int KIND, int WAVES, bool PM>
-__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8))) void rollout16_ahead_kernel(RolloutAheadArgs args) {
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8))) void iter_ahead_kernel(IterAheadArgs args) {
     using Tile = Tile16<H, D, O, KIND>;
     using Stream = Stream16<H, D, O, KIND>;
-    constexpr int HD = H * D, NTT = 64 * WAVES, KREG = 12;
-    __shared__ __attribute__((aligned(16))) float stage[WAVES][Stream::STG];
-    __shared__ unsigned long long wg_keys[2][WAVES][32];
-    __shared__ float obs_stage[32];
-    __shared__ __attribute__((aligned(16))) float dist[2 * HD];  // mean | std this iteration samples from
-    __shared__ unsigned long long sel[PM ? 64 : 1];
-    __shared__ unsigned long long cand[PM ? WAVES : 1][PM ? 64 : 1];  // compaction scratch, one per wave
-    __shared__ unsigned long long wsel[PM ? WAVES * 16 : 1];         // every wave's K best (merge_select_split)
-    __shared__ int slot[PM ? 64 : 1];
-    const FastRolloutArgs& a = args.r;
+    using L = AheadLds<H, D, O, KIND, WAVES>;
+    constexpr int HD = H * D, NTT = 64 * WAVES, KREG = AHEAD_KREG;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    // model operands, start observation and this wave's first noise vectors in flight together, in front of the merge
+    const int n_roll = args.n_roll;
+    // ------------------------------------------------------------------------------------------------ noise role
+    if ((int)blockIdx.x >= n_roll && (int)blockIdx.x < n_roll + args.n_noise) {
+        const FastSampleArgs& z = args.z;
+        float* tile = smem;  // [TPW, HD]
+        const int n_base = ((int)blockIdx.x - n_roll) * L::TPW;
+        const int n_here = cmin(L::TPW, z.n - n_base);
+        if (tid < n_here * D) {
+            const int nl = tid / D;
+            const int j = tid - nl * D;
+            float* trow = tile + nl * HD + j;
+            sample_row<H, 10>(z.W, (unsigned)(z.first_index + n_base + nl), (unsigned)j, z.off_lo, z.off_hi, z.seed_lo, z.seed_hi,
+                              [&](int t, float y) { trow[t * D] = y; }, z.white != 0);
+        }
+        __syncthreads();
+        float* gdst = z.out + (size_t)n_base * HD;
+        const int total = n_here * HD;
+        if constexpr ((HD & 3) == 0) {
+            const float4* t4 = reinterpret_cast<const float4*>(tile);
+            float4* g4 = reinterpret_cast<float4*>(gdst);
+            for (int e = tid; e < total / 4; e += NTT) g4[e] = t4[e];
+        } else {
+            const float2* t2 = reinterpret_cast<const float2*>(tile);
+            float2* g2 = reinterpret_cast<float2*>(gdst);
+            for (int e = tid; e < total / 2; e += NTT) g2[e] = t2[e];
+        }
+        return;
+    }
+    const FastRolloutArgs& a = args.r;
+    // ------------------------------------------------------------------------------------------------ shift role
+    if ((int)blockIdx.x >= n_roll) {
+        // shifted elite e: elites[e, 1:, j] and a last action drawn from the full (n_shift, d, h) noise batch of stream off2
+        // (only t = h-1 is used, icem.py:102) -> pool rows [n, n + n_shift) and a 16-row LDS tile; then one wave rolls the
+        // tile out (Tile16: the bits the rollout role would produce for these rows) -> costs [n, n + n_shift)
+        const FastSampleArgs& s = args.s;
+        float* ms = smem + L::SH_DIST;
+        float* tilebuf = smem + L::SH_TILE;
+        float* obs_stage = tilebuf + Tile::SLACK + 16 * HD + Tile::TAIL;
+        float* rows = tilebuf + Tile::SLACK;
+        const float obs_reg = a.obs0[(tid < 32 && tid < a.o) ? tid : 0];
+        Tile tile;
+        if (wave == 0) tile.load(a, lane);
+        for (int e = tid; e < HD; e += NTT) {
+            ms[e] = s.mean[e];
+            ms[HD + e] = s.std[e];
+        }
+        for (int e = tid; e < 16 * HD; e += NTT) rows[e] = 0.f;
+        if (tid < 32) obs_stage[tid] = tid < a.o ? obs_reg : 0.f;
+        __syncthreads();
+        if (tid < s.n_shift * D) {
+            const int e = tid / D;
+            const int j = tid - e * D;
+            const float lo = s.low[j], hi = s.high[j];
+            float last = 0.f;
+            sample_row<H, 10>(s.W, (unsigned)e, (unsigned)j, s.off2_lo, s.off2_hi, s.seed_lo, s.seed_hi,
+                              [&](int t, float y) {
+                                  if (t == H - 1) {
+                                      float v = __builtin_fmaf(y, ms[HD + t * D + j], ms[t * D + j]);
+                                      v = v < lo ? lo : v;
+                                      last = v > hi ? hi : v;
+                                  }
+                              }, s.white != 0);
+            float* dst = s.out + (size_t)(s.n + e) * HD + j;
+            const float* src = s.elites_src + (size_t)e * HD + j;
+            float* trow = rows + e * HD + j;
+            for (int t = 0; t < H - 1; ++t) {
+                const float v = src[(t + 1) * D];
+                dst[t * D] = v;
+                trow[t * D] = v;
+            }
+            dst[(H - 1) * D] = last;
+            trow[(H - 1) * D] = last;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            tile.load_obs(obs_stage);
+            FastRolloutArgs ta = a;
+            ta.K = 0;
+            ta.costs = a.costs + s.n;
+            (void)rollout_slab<Tile, H, D>(tile, ta, tile.read_ptr(tilebuf, lane, HD), lane & 15, s.n_shift, KEY_SENTINEL, true, lane);
+        }
+        return;
+    }
+    // ------------------------------------------------------------------------------------------------ rollout role
+    // (s_setprio for this role's waves -- the longer chain -- measured: no effect, 185.0 vs 184.7 us per MPC step)
+    float* stage = smem + L::STAGE;
+    auto wg_keys = reinterpret_cast<unsigned long long(*)[WAVES][32]>(smem + L::KEYS);
+    float* dist = smem + L::DIST;  // mean | std this iteration samples from
+    float* obs_stage = smem + L::OBS;
+    unsigned long long* sel = reinterpret_cast<unsigned long long*>(smem + L::SEL);
+    unsigned long long* wsel = reinterpret_cast<unsigned long long*>(smem + L::WSEL);
+    int* slot = reinterpret_cast<int*>(smem + L::SLOT);
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(stage) + wave * 64;  // this wave's compaction scratch
+    // model operands and start observation in flight in front of the merge
     const float obs_reg = a.obs0[(tid < 32 && tid < a.o) ? tid : 0];
     Tile tile;
     tile.load(a, lane);
     Stream stream;
-    stream.init(tile, stage[wave], lane);
+    stream.init(tile, stage + wave * Stream::STG, lane);
     const int tiles = (a.n_rows + 15) / 16;
-    const int tile0 = wave * gridDim.x + blockIdx.x;
+    const int tile0 = wave * n_roll + (int)blockIdx.x;
     typename Stream::Vec pre[Stream::NLD];
-    if (tile0 < tiles) stream.first_loads(args.pool, a.n_rows, tile0, pre);
     if constexpr (PM) {
-        // nothing to hide the selection behind here: all waves share it (one cold round trip instead of a dozen)
-        merge_select_split_stage1<KREG>(args.m, lane, wave, WAVES, cand[wave], wsel);
+        // all waves share the selection: one cold round trip instead of a dozen dependent ones
+        merge_select_split_stage1<KREG>(args.m, lane, wave, WAVES, cand, wsel);
+        // (this wave's first noise vectors: requested behind its keys, in flight across the barriers below)
+        if (tile0 < tiles) stream.first_loads(args.pool, a.n_rows, tile0, pre);
         __syncthreads();
-        if (wave == 0) merge_select_split_stage2(args.m, lane, WAVES, wsel, cand[0], sel);
+        if (wave == 0) merge_select_split_stage2(args.m, lane, WAVES, wsel, cand, sel);
     } else {
+        if (tile0 < tiles) stream.first_loads(args.pool, a.n_rows, tile0, pre);
         for (int e = tid; e < HD; e += NTT) {
             dist[e] = args.mean[e];
             dist[HD + e] = args.std[e];
@@ -83,44 +205,51 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
     tile.load_obs(obs_stage);
     unsigned long long run_key = KEY_SENTINEL;
     bool first = true;
-    // tile t of the launch belongs to wave t / gridDim.x of workgroup t % gridDim.x (as rollout16_kernel)
-    for (int tile_id = tile0; tile_id < tiles; tile_id += WAVES * gridDim.x) {
+    // tile t of the launch belongs to wave t / n_roll of rollout workgroup t % n_roll (as rollout16_kernel)
+    for (int tile_id = tile0; tile_id < tiles; tile_id += WAVES * n_roll) {
         if (!first) stream.first_loads(args.pool, a.n_rows, tile_id, pre);
-        run_key = stream.run_xf(tile, a, args.pool, args.n_xf, args.row0_mean != 0, args.store_back != 0, dist, args.lo, args.hi, tile_id, lane, run_key, first, pre);
+        run_key = stream.run_xf(tile, a, args.pool, args.n_xf, args.row0_mean != 0, true, dist, args.lo, args.hi, tile_id, lane, run_key, first, pre);
         first = false;
     }
-    if (a.K > 0) wg_merge_emit<WAVES>(wg_keys, run_key, a.K, lane, wave, a);
+    if (a.K > 0) wg_merge_emit<WAVES>(wg_keys, run_key, a.K, lane, wave, a, (int)blockIdx.x, n_roll);
+}
+
+// Launch shape of the rollout role: rollout16's (one 16-trajectory tile per wave while they fit, at most FAST_MAX_LISTS
+// workgroups), but at most 8 wavefronts per workgroup -- two per SIMD, each taking its tiles one after the other: the
+// rollout leaves half of every SIMD's registers (and 100 of the CU's 160 KB of LDS) to a noise workgroup beside it.
+void ahead_shape(int n_rows, int* grid, int* waves) {
+    r16_shape(n_rows, grid, waves);
+    if (*waves > 8) *waves = 8;
 }
 
 }  // namespace
-
-// Launch shape: rollout16's (one 16-trajectory tile per wave while they fit, at most FAST_MAX_LISTS workgroups), but at
-// most AHEAD_MAX_WAVES wavefronts per workgroup -- two per SIMD, each taking its tiles one after the other: the rollout
-// must leave half of every SIMD's registers to the noise kernel that runs beside it (a 16-wave workgroup owns its CU, and
-// noise workgroups back-filling every freed slot then starve the rollout's: measured 751 us per MPC step at N = 65 536
-// against 214 for the sampler + rollout pair).
-static int ahead_max_waves() {
-    static const int w = [] { const char* e = getenv("ICEM_AHEAD_MAXW"); const int v = e ? atoi(e) : 8; return v >= 16 ? 16 : (v >= 8 ? 8 : 4); }();
-    return w;
-}
-static void ahead_shape(int n_rows, int* grid, int* waves) {
-    r16_shape(n_rows, grid, waves);
-    if (*waves > ahead_max_waves()) *waves = ahead_max_waves();
-}
 
 // populations whose rollout launch has at least 4 waves per workgroup (more than 512 tiles): below that the
 // single-launch kernel of k_iter_small.hip is the shorter chain
 bool rollout_ahead_ok(int h, int d, int O, int K, int n_rows) {
     int grid, waves;
     r16_shape(n_rows, &grid, &waves);
-    return K + 1 <= 12 && waves >= 4 && fast_rollout_supported(h, d, O, K) && fast_sample_supported(h, d);
+    return K + 1 <= AHEAD_KREG && waves >= 4 && fast_rollout_supported(h, d, O, K) && fast_sample_supported(h, d);
 }
 
-void launch_rollout_ahead(const RolloutAheadArgs& a, int h, int d, int O, int kind, hipStream_t st) {
+int ahead_roll_workgroups(int n_rows) {
+    int grid, waves;
+    ahead_shape(n_rows, &grid, &waves);
+    return grid;
+}
+
+void launch_iter_ahead(const IterAheadArgs& a_in, int h, int d, int O, int kind, hipStream_t st) {
+    IterAheadArgs a = a_in;
     int grid, waves;
     ahead_shape(a.r.n_rows, &grid, &waves);
-#define XK(HH, DD, OO, KK, WW, PP) \
-    hipLaunchKernelGGL((rollout16_ahead_kernel<HH, DD, OO, KK, WW, PP>), dim3(grid), dim3(64 * WW), 0, st, a);
+    a.n_roll = grid;
+#define XK(HH, DD, OO, KK, WW, PP)                                                                                         \
+    {                                                                                                                      \
+        using L = AheadLds<HH, DD, OO, KK, WW>;                                                                            \
+        a.n_noise = a.z.n > 0 ? (a.z.n + L::TPW - 1) / L::TPW : 0;                                                         \
+        const int total = grid + a.n_noise + (a.s.n_shift > 0 ? 1 : 0);                                                    \
+        hipLaunchKernelGGL((iter_ahead_kernel<HH, DD, OO, KK, WW, PP>), dim3(total), dim3(64 * WW), L::FLOATS * sizeof(float), st, a); \
+    }
 #define XW(HH, DD, OO, WW)                          \
     if (waves == WW) {                              \
         if (kind == 1) {                            \
@@ -142,7 +271,6 @@ void launch_rollout_ahead(const RolloutAheadArgs& a, int h, int d, int O, int ki
     if (h == HH && d == DD && O == OO) { \
         XW(HH, DD, OO, 4)                \
         XW(HH, DD, OO, 8)                \
-        XW(HH, DD, OO, 16)               \
     }
     ICEM_FAST_SHAPES(XR)
 #undef XR

@@ -572,7 +572,12 @@ int plan_iter_merge_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                 if (rc) return rc;
             }
             ProfScope prof(h, ICEM_K_MERGE_REFIT, h->fast_lists * K + m.n_keep, st);
-            launch_merge_single(m, st);
+            if (h->ahead.tail_pending && merge_noise_ok(m, c.rng_rounds)) {
+                launch_merge_noise(m, h->ahead.tail_args, st);  // + the rest of the next step's first noise
+                h->ahead.tail_pending = false;
+            } else {
+                launch_merge_single(m, st);
+            }
             ICEM_HIP_TRY(hipGetLastError());
             return ICEM_OK;
         }
@@ -664,24 +669,18 @@ int plan_iter_merge_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
 // Noise-ahead pipeline (world == 1, f32, device noise, every iteration's rollout launch >= 4 waves per workgroup)
 // ---------------------------------------------------------------------------------------------------------------------
 // icem.py:73-79 draws the colored noise first and applies `* std + mean` afterwards: only the affine map depends on the
-// previous iteration.  So the critical path of an MPC step is ONE launch per iteration -- rollout16_ahead_kernel: merge
-// prologue, affine + clip on load, rollout, candidate lists -- and the noise of iteration i + 1 (and of iteration 0 of the
-// next MPC step) is drawn by noise_rows_kernel on a low-priority side stream while iteration i rolls out.  The shifted
-// elites of iteration 0 (icem.py:131-137) are prepared and rolled out on a second side stream (the sampler's extra
-// workgroup + a one-wave rollout16 launch: the same code, the same bits) and reach the merge through the cost array, as
-// in the single-launch kernel's tail shape.  Buffers: the last iteration's pool is the caller's `actions`; the others
-// rotate through three pools of the handle.
+// previous iteration.  So an iteration is ONE launch (iter_ahead_kernel, k_rollout_ahead.hip): its rollout workgroups run
+// the previous iteration's merge in their prologue, map the raw noise of the pool to actions as they load it, roll out
+// and emit candidate lists; its noise workgroups draw the NEXT sampling call's noise (iteration i + 1, or iteration 0 of
+// the next MPC step) into the next pool beside them; at iteration 0 one more workgroup builds and rolls out the shifted
+// elites (icem.py:131-137), which reach the merge through the cost array as in the single-launch kernel's tail shape.
+// One stream, six launches per MPC step at five iterations (ten on the default path).  Buffers: the last iteration's
+// pool is the caller's `actions`; the others rotate through three pools of the handle.
+// The first form of this pipeline drew the noise on a second stream: every cross-stream event wait cost 10-15 us on the
+// critical path and a low-priority side stream starved the rollouts (profiles/r03_noise_ahead_*; EXPERIMENTS.md).
 
 void ahead_destroy(icem_handle* h) {
     icem_handle::Ahead& A = h->ahead;
-    if (A.side) (void)hipStreamSynchronize(A.side);
-    if (A.side2) (void)hipStreamSynchronize(A.side2);
-    for (hipEvent_t e : A.ev_roll) (void)hipEventDestroy(e);
-    for (hipEvent_t e : A.ev_noise) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {A.ev_start, A.ev_tail, A.ev_next})
-        if (e) (void)hipEventDestroy(e);
-    if (A.side) (void)hipStreamDestroy(A.side);
-    if (A.side2) (void)hipStreamDestroy(A.side2);
     for (void*& p : A.pool) {
         if (p) (void)hipFree(p);
         p = nullptr;
@@ -693,22 +692,20 @@ static bool ahead_eligible(icem_handle* h, const icem_plan_buffers* b) {
     icem_handle::Ahead& A = h->ahead;
     const icem_config& c = h->cfg;
     if (A.disabled < 0) {
-        // OPT-IN (ICEM_NOISE_AHEAD=1): measured on MI355X the pipeline loses to the sampler + rollout pair at every
-        // population north_star names (N = 65 536: 245-256 vs 211 us per MPC step; EXPERIMENTS.md has the timeline) -- the
-        // cross-stream event waits cost 10-15 us each on the critical path and the rollout with merge prologue + affine
-        // map on load is 4-12 us longer than rollout16_kernel.  Kept tested (bit-equal to the default path) for the record.
+        // on by default where it applies (measured 1.09-1.21x the sampler + rollout pair from N = 32 768 to 262 144;
+        // ICEM_NOISE_AHEAD=0 switches it off -- the equivalence test and tools/ahead_bench.py flip it per handle)
         const char* e = getenv("ICEM_NOISE_AHEAD");
-        A.disabled = (e && atoi(e) != 0) ? 0 : 1;
+        A.disabled = (e && atoi(e) == 0) ? 1 : 0;
         const char* m = getenv("ICEM_NOISE_AHEAD_MIN_ROWS");
         A.min_rows = m ? atoi(m) : 0;
     }
     if (A.disabled || c.world != 1 || c.dtype != ICEM_F32 || b->z_r != nullptr || !h->use_fast || h->wide || c.opt_iters < 2 ||
-        h->dbg != nullptr)
+        h->dbg != nullptr || c.rng_rounds != 10)
         return false;
     if (!fast_rollout_ok(h, c.num_elites) || !fast_sample_ok(h)) return false;
     for (int n : h->pop)
         if (n < A.min_rows || !rollout_ahead_ok(c.horizon, c.act_dim, h->O, c.num_elites, n)) return false;
-    if (c.shift_elites && h->n_reuse * c.act_dim > 256) return false;  // (the sampler's shifted-elite workgroup)
+    if (c.shift_elites && h->n_reuse > 16) return false;  // (the shift role rolls its rows out as one 16-row tile)
     // the transform takes the bounds as two scalars: fetch them once per (low, high) buffer pair
     if (A.lo_ptr != b->low || A.hi_ptr != b->high) {
         std::vector<float> lo(c.act_dim), hi(c.act_dim);
@@ -729,47 +726,14 @@ static bool ahead_eligible(icem_handle* h, const icem_plan_buffers* b) {
 
 static int ahead_setup(icem_handle* h) {
     icem_handle::Ahead& A = h->ahead;
-    if (A.side) return ICEM_OK;
-    int least = 0, greatest = 0;
-    ICEM_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    // (ICEM_AHEAD_PRIO=1: lowest stream priority for the side streams -- measured: 750-800 instead of 245 us per MPC step
-    //  at N = 65 536; a low-priority queue is not "fills the gaps", it is starved and starves in turn)
-    const char* pe = getenv("ICEM_AHEAD_PRIO");
-    const int prio = (pe && atoi(pe) != 0) ? least : 0;
-    ICEM_HIP_TRY(hipStreamCreateWithPriority(&A.side, hipStreamNonBlocking, prio));
-    ICEM_HIP_TRY(hipStreamCreateWithPriority(&A.side2, hipStreamNonBlocking, prio));
-    // The events order launches of THIS device only: no system-scope release behind the recorded work (the default: a
-    // write-back + invalidate of the caches the next launch is about to read the pool from)
-    const char* fe = getenv("ICEM_AHEAD_FENCE");
-    const unsigned ev_flags = hipEventDisableTiming | ((fe && atoi(fe) != 0) ? 0u : hipEventDisableSystemFence);
-    auto mk = [ev_flags](hipEvent_t* e) { return hipEventCreateWithFlags(e, ev_flags); };
-    A.ev_roll.assign(h->cfg.opt_iters, nullptr);
-    A.ev_noise.assign(h->cfg.opt_iters, nullptr);
-    for (auto& e : A.ev_roll) ICEM_HIP_TRY(mk(&e));
-    for (auto& e : A.ev_noise) ICEM_HIP_TRY(mk(&e));
-    ICEM_HIP_TRY(mk(&A.ev_start));
-    ICEM_HIP_TRY(mk(&A.ev_tail));
-    ICEM_HIP_TRY(mk(&A.ev_next));
+    if (A.pool[0]) return ICEM_OK;
     for (void*& p : A.pool) ICEM_HIP_TRY(hipMalloc(&p, icem_plan_buffer_bytes(h, ICEM_BUF_ACTIONS)));
     if (!h->ws_alt) ICEM_HIP_TRY(hipMalloc(&h->ws_alt, icem_plan_buffer_bytes(h, ICEM_BUF_WORKSPACE)));
     if (!h->pp_stats) ICEM_HIP_TRY(hipMalloc((void**)&h->pp_stats, (size_t)4 * h->hd * sizeof(float)));
     return ICEM_OK;
 }
 
-// raw noise of sampling call `off` for rows [0, n) -> pool, on `st`
-static int ahead_noise(icem_handle* h, int n, uint64_t off, void* pool, hipStream_t st) {
-    static const int dbg = [] { const char* e = getenv("ICEM_AHEAD_DBG"); return e ? atoi(e) : 0; }();
-    if (dbg & 4) return ICEM_OK;  // timing experiment: no noise at all (results are garbage)
-    const FastSampleArgs a = fast_sample_args(h, n, 0, nullptr, nullptr, nullptr, nullptr, off, 0, pool, 0, nullptr, 0);
-    {
-        ProfScope prof(h, ICEM_K_SAMPLE, (long long)n * a.h, st);
-        launch_noise_rows(a, h->cfg.rng_rounds, st);
-    }
-    ICEM_HIP_TRY(hipGetLastError());
-    return ICEM_OK;
-}
-
-static int plan_step_ahead(icem_handle* h, const icem_plan_buffers* b, int mpc_step, hipStream_t main) {
+static int plan_step_ahead(icem_handle* h, const icem_plan_buffers* b, int mpc_step, hipStream_t st) {
     icem_handle::Ahead& A = h->ahead;
     const icem_config& c = h->cfg;
     const int iters = c.opt_iters, K = c.num_elites, hd = h->hd;
@@ -779,7 +743,9 @@ static int plan_step_ahead(icem_handle* h, const icem_plan_buffers* b, int mpc_s
     if (rc) return rc;
     const uint64_t call_base = (h->episode << 32) + (uint64_t)mpc_step * (uint64_t)(iters + 1);
     auto pool_of = [&](int it) -> float* { return it == iters - 1 ? (float*)b->actions : (float*)A.pool[(A.ctr + (unsigned)it) % 3]; };
-    ICEM_HIP_TRY(hipEventRecord(A.ev_start, main));  // everything of the previous step (its last merge above all)
+    auto noise_args = [&](int n, uint64_t off, void* out) {
+        return fast_sample_args(h, n, 0, nullptr, nullptr, nullptr, nullptr, off, 0, out, 0, nullptr, 0);
+    };
     float* cur_mean = (float*)b->mean;
     float* cur_std = (float*)b->std;
     const int n_extra = (c.shift_elites && mpc_step > 0 && h->n_reuse > 0) ? h->n_reuse : 0;
@@ -792,90 +758,81 @@ static int plan_step_ahead(icem_handle* h, const icem_plan_buffers* b, int mpc_s
         if (it & 1) bb.workspace = h->ws_alt;
         bb.mean = cur_mean;
         bb.std = cur_std;
-        // ---- this iteration's noise: drawn ahead (side stream) or, for a step nobody predicted, right here ----
         if (it == 0) {
+            // this step's first noise: drawn by the previous step's last launch -- or, for a step nobody predicted, here
             const bool hit = A.next_valid && A.next_episode == h->episode && A.next_step == mpc_step && A.next_pool == pool;
             A.next_valid = false;
-            if (hit) {
-                ICEM_HIP_TRY(hipStreamWaitEvent(main, A.ev_next, 0));
-            } else {
-                rc = ahead_noise(h, n, call_base, pool, main);
-                if (rc) return rc;
+            if (!hit) {
+                const FastSampleArgs za = noise_args(n, call_base, pool);
+                ProfScope prof(h, ICEM_K_SAMPLE, (long long)n * c.horizon, st);
+                launch_noise_rows(za, c.rng_rounds, st);
             }
-            if (n_extra > 0) {
-                // shifted elites (icem.py:91-104, 131-137): rows [n, n + n_extra) as actions, then their costs -- beside
-                // the main launch; the merge of iteration 0 takes them through the cost array (its kept-elite slot)
-                const int g = (int)(((long long)mpc_step * iters) & 1);  // elite buffer holding the previous step's set
-                const float* shift_src = (const float*)b->elites + (size_t)g * K * hd;
-                ICEM_HIP_TRY(hipStreamWaitEvent(A.side2, A.ev_start, 0));
-                const FastSampleArgs sa = fast_sample_args(h, 0, 0, cur_mean, cur_std, b->low, b->high, call_base, 0, pool + (size_t)n * hd,
-                                                           n_extra, shift_src, call_base + (uint64_t)iters);
-                launch_sample_folded(sa, c.rng_rounds, A.side2);
-                ICEM_HIP_TRY(hipGetLastError());
-                FastRolloutArgs ta = fast_rollout_args(h, n_extra, 0, 0, b->obs0, pool + (size_t)n * hd, (float*)b->costs + n, nullptr, nullptr);
-                launch_rollout16(ta, c.horizon, c.act_dim, h->O, h->model_kind, A.side2);
-                ICEM_HIP_TRY(hipGetLastError());
-                ICEM_HIP_TRY(hipEventRecord(A.ev_tail, A.side2));
-            }
-        } else {
-            static const int dbg = [] { const char* e = getenv("ICEM_AHEAD_DBG"); return e ? atoi(e) : 0; }();
-            if (!(dbg & 1)) ICEM_HIP_TRY(hipStreamWaitEvent(main, A.ev_noise[it], 0));  // (1: timing experiment without the wait)
+            ICEM_HIP_TRY(hipGetLastError());
         }
-        // ---- the next noise starts when this rollout does: side waits for the rollout BEFORE this one ----
-        {
-            ICEM_HIP_TRY(hipStreamWaitEvent(A.side, it == 0 ? A.ev_start : A.ev_roll[it - 1], 0));
-            if (!last) {
-                rc = ahead_noise(h, h->pop[it + 1], call_base + (uint64_t)(it + 1), pool_of(it + 1), A.side);
-                if (rc) return rc;
-                ICEM_HIP_TRY(hipEventRecord(A.ev_noise[it + 1], A.side));
-            } else {
-                // iteration 0 of the NEXT MPC step (same episode, step + 1 -- checked when it comes)
-                void* np = A.pool[(A.ctr + (unsigned)(iters - 1)) % 3];
-                rc = ahead_noise(h, h->pop[0], (h->episode << 32) + (uint64_t)(mpc_step + 1) * (uint64_t)(iters + 1), np, A.side);
-                if (rc) return rc;
-                ICEM_HIP_TRY(hipEventRecord(A.ev_next, A.side));
-                A.next_valid = true;
-                A.next_episode = h->episode;
-                A.next_step = mpc_step + 1;
-                A.next_pool = np;
-            }
-        }
-        // ---- the launch of this iteration ----
-        RolloutAheadArgs ra;
-        ra.r = fast_rollout_args(h, n, n, K, b->obs0, pool, b->costs, nullptr, nullptr);
-        ra.r.part_k = (unsigned long long*)bb.workspace;
-        ra.has_merge = h->pm_pending ? 1 : 0;
-        if (h->pm_pending) ra.m = h->pm_args;
+        IterAheadArgs ia{};
+        ia.r = fast_rollout_args(h, n, n, K, b->obs0, pool, b->costs, nullptr, nullptr);
+        ia.r.part_k = (unsigned long long*)bb.workspace;
+        ia.has_merge = h->pm_pending ? 1 : 0;
+        if (h->pm_pending) ia.m = h->pm_args;
         h->pm_pending = false;
-        ra.n_xf = n;
-        ra.row0_mean = (last && c.use_mean_actions) ? 1 : 0;
-        {
-            static const int dbg = [] { const char* e = getenv("ICEM_AHEAD_DBG"); return e ? atoi(e) : 0; }();
-            ra.store_back = (dbg & 8) ? 0 : 1;  // (8: timing experiment without the write-back; results are garbage)
+        ia.n_xf = n;
+        ia.row0_mean = (last && c.use_mean_actions) ? 1 : 0;
+        ia.pool = pool;
+        ia.mean = cur_mean;
+        ia.std = cur_std;
+        ia.lo = A.lo;
+        ia.hi = A.hi;
+        // the noise role: the next sampling call
+        if (!last) {
+            ia.z = noise_args(h->pop[it + 1], call_base + (uint64_t)(it + 1), pool_of(it + 1));
+        } else {
+            // iteration 0 of the NEXT MPC step (same episode, step + 1 -- checked when it comes)
+            // -- split: what fits beside this launch's rollout here, the rest beside the step's last merge, a launch that
+            // leaves 255 of the 256 CUs idle (ICEM_AHEAD_TAIL_FRAC: share of the rows that goes there)
+            void* np = A.pool[(A.ctr + (unsigned)(iters - 1)) % 3];
+            const uint64_t off0 = (h->episode << 32) + (uint64_t)(mpc_step + 1) * (uint64_t)(iters + 1);
+            static const double tail_frac = [] { const char* e = getenv("ICEM_AHEAD_TAIL_FRAC"); return e ? atof(e) : 0.6; }();
+            int n_tail = (int)(tail_frac * h->pop[0]);
+            n_tail = std::max(0, std::min(h->pop[0], n_tail));
+            const int n_here = h->pop[0] - n_tail;
+            ia.z = noise_args(n_here, off0, np);
+            A.tail_pending = n_tail > 0;
+            if (n_tail > 0) {
+                A.tail_args = noise_args(n_tail, off0, (float*)np + (size_t)n_here * hd);
+                A.tail_args.first_index = n_here;
+            }
+            A.next_valid = true;
+            A.next_episode = h->episode;
+            A.next_step = mpc_step + 1;
+            A.next_pool = np;
         }
-        ra.pool = pool;
-        ra.mean = cur_mean;
-        ra.std = cur_std;
-        ra.lo = A.lo;
-        ra.hi = A.hi;
+        // the shift role (icem.py:91-104, 131-137): rows [n, n + n_extra) of this pool, costs behind costs[n]
+        if (it == 0 && n_extra > 0) {
+            const int g = (int)(((long long)mpc_step * iters) & 1);  // elite buffer holding the previous step's set
+            ia.s = fast_sample_args(h, n, 0, cur_mean, cur_std, b->low, b->high, call_base, 0, pool, n_extra,
+                                    (const float*)b->elites + (size_t)g * K * hd, call_base + (uint64_t)iters);
+        }
         {
-            ProfScope prof(h, ICEM_K_ROLLOUT, (long long)n * c.horizon, main);
-            launch_rollout_ahead(ra, c.horizon, c.act_dim, h->O, h->model_kind, main);
+            ProfScope prof(h, ICEM_K_SAMPLE_ROLLOUT, (long long)n * c.horizon, st);
+            launch_iter_ahead(ia, c.horizon, c.act_dim, h->O, h->model_kind, st);
         }
         ICEM_HIP_TRY(hipGetLastError());
-        ICEM_HIP_TRY(hipEventRecord(A.ev_roll[it], main));
-        h->fast_lists = rollout_lists(c.horizon, c.act_dim, h->O, n);
+        h->fast_lists = ahead_roll_workgroups(n);
         h->fast_tail_rows = it == 0 ? n_extra : 0;
-        if (it == 0 && n_extra > 0) ICEM_HIP_TRY(hipStreamWaitEvent(main, A.ev_tail, 0));  // before whatever merges iteration 0
         // ---- its merge: stashed for the next launch's prologue, or (last) a launch of its own ----
         float* pp = h->pp_stats + (size_t)(it & 1) * 2 * hd;
         h->defer_merge = !last;
         h->merge_mean_out = last ? (float*)b->mean : pp;
         h->merge_std_out = last ? (float*)b->std : pp + hd;
-        rc = ICEM_DISPATCH(h, plan_iter_merge_t<float>(h, &bb, mpc_step, it, main), ICEM_E_INVALID);
+        rc = plan_iter_merge_t<float>(h, &bb, mpc_step, it, st);
         h->defer_merge = false;
         h->merge_mean_out = h->merge_std_out = nullptr;
         if (rc) return rc;
+        if (last && A.tail_pending) {  // (the merge could not take it along: a launch of its own)
+            launch_noise_rows(A.tail_args, c.rng_rounds, st);
+            ICEM_HIP_TRY(hipGetLastError());
+            A.tail_pending = false;
+        }
         if (!last) {
             if (!h->pm_pending) return fail(ICEM_E_STATE, "noise-ahead: the merge did not defer");
             cur_mean = pp;

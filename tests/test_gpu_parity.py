@@ -1832,12 +1832,11 @@ def test_bench_two_ranks_without_a_launcher():
 
 @pytest.mark.parametrize("h,d,o,kind,mode,N,iters", [(30, 6, 17, 0, "sum", 16384, 3), (30, 6, 17, 1, "best", 40000, 4), (30, 17, 24, 1, "sum", 16384, 2)])
 def test_noise_ahead_pipeline_equals_the_default_path(h, d, o, kind, mode, N, iters, monkeypatch):
-    """The opt-in noise-ahead pipeline (ICEM_NOISE_AHEAD=1; plan.hip::plan_step_ahead: raw colored noise drawn on a side
-    stream by noise_rows_kernel while the previous rollout runs, rollout16_ahead_kernel = merge prologue shared by all
-    waves + affine map / clip applied to every vector it loads and written back in place, shifted elites on a second side
-    stream) against the sampler + rollout pair: same draws, same fmaf / v_med3 per sample, same rollout code -- every
-    buffer identical over four MPC steps (the noise of step s + 1's first iteration is drawn during step s).  It is not
-    the default: measured slower on MI355X (EXPERIMENTS.md)."""
+    """The noise-ahead pipeline of large populations (plan.hip::plan_step_ahead, k_rollout_ahead.hip: one launch per
+    iteration whose rollout workgroups run the previous merge in their prologue and map the pool's raw noise to actions as
+    they load it, beside noise workgroups that draw the NEXT sampling call and, at iteration 0, a shifted-elites workgroup)
+    against the sampler + rollout pair (ICEM_NOISE_AHEAD=0): same draws, same fmaf / v_med3 per sample, same rollout code --
+    every buffer identical over four MPC steps (the noise of step s + 1's first iteration is drawn during step s)."""
     from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env, humanoid_standup_env
     env = humanoid_standup_env(o) if d == 17 else halfcheetah_env(o)
     model = DeviceSyntheticModel.make(o, d, kind=kind)
