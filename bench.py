@@ -248,8 +248,10 @@ def extra_cpu_baselines(workload, w, model, env):
     return out
 
 
-KERNEL_FAMILY = {"sample_clip": ("sample_folded_kernel", "sample_folded_merge_kernel"), "rollout_cost": ("rollout16_kernel", "rollout_wide_kernel"),
-                 "sample_rollout": ("sample_rollout_kernel",)}
+KERNEL_FAMILY = {"sample_clip": ("sample_folded_kernel", "sample_folded_merge_kernel", "noise_rows_kernel"),
+                 "rollout_cost": ("rollout16_kernel", "rollout_wide_kernel"),
+                 # one launch per iteration: the small-population kernel, or the noise-ahead launch of large populations
+                 "sample_rollout": ("sample_rollout_kernel", "iter_ahead_kernel")}
 
 
 def measured_traffic(kernel_class, workload):

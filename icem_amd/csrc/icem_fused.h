@@ -134,6 +134,12 @@ struct MergeSingleArgs {
     float* executed;
     float* best_cost;
     long long* dbg;  // development: 8 wall_clock64 stamps (100 MHz) of thread 0, nullptr in production
+    // noise-ahead pipeline, non-last iterations (iter_ahead_kernel's prologue only): pool rows [0, n_raw) still hold the
+    // RAW colored noise y -- the launch that rolled them out did not write the actions back -- and an elite row among
+    // them is clip(y * std + mean, xf_lo, xf_hi) with THIS merge's input distribution (mean / std above: what the
+    // iteration sampled from).  0: the pool holds actions.
+    int n_raw = 0;
+    float xf_lo = 0.f, xf_hi = 0.f;
 };
 void launch_merge_single(const MergeSingleArgs& a, hipStream_t st);
 // ... with noise workgroups beside it (noise-ahead pipeline: z.n rows of raw colored noise -> z.out; see merge_noise_kernel)
@@ -204,7 +210,9 @@ struct IterAheadArgs {
     int has_merge;
     int n_xf;            // rows [0, n_xf) of the pool hold raw noise
     int row0_mean;       // icem.py:87-88
-    float* pool;         // [n_rows, h, d], read and rewritten in place
+    int store_back;      // write the actions back over the noise (the last iteration: the caller's pool; the others leave
+                         // the noise in place and the next prologue maps the K elite rows again, MergeSingleArgs::n_raw)
+    float* pool;         // [n_rows, h, d]
     const float* mean;   // the distribution when has_merge == 0 (else the prologue computes it from m)
     const float* std;
     float lo, hi;        // the action bounds, equal in every action dimension (plan.hip checks before taking this path)

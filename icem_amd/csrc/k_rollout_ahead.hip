@@ -4,8 +4,9 @@
 //            v_mfma_f32_16x16x4_f32, Tile16 / Stream16 of fused_dev.h) on a pool that holds RAW colored noise: the PREVIOUS
 //            iteration's K3 + K4 (top-K of its candidate lists, elite gather, refit; icem.py:194-211) in the prologue, the
 //            selection shared by all waves (merge_select_split: nothing hides it here), then every vector a wave loads
-//            becomes clip(y * std + mean) (icem.py:79) between the prefetch registers and its LDS staging buffer and is
-//            written back in place (Stream16::run_xf): after the launch the pool holds the actions;
+//            becomes clip(y * std + mean) (icem.py:79) between the prefetch registers and its LDS staging buffer
+//            (Stream16::run_xf).  The last iteration writes the actions back in place (the caller's pool); the others
+//            leave the noise where it is and the NEXT prologue maps the K elite rows once more (MergeSingleArgs::n_raw);
 //   noise    (the next `n_noise` workgroups)  the raw colored noise of the NEXT sampling call (iteration i + 1, or
 //            iteration 0 of the next MPC step) into the next pool: powerlaw_psd_gaussian needs no distribution
 //            (icem.py:73-79), so it runs beside the rollout whose waves leave half of every SIMD's registers free;
@@ -187,8 +188,16 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
             float xs[KREG];
 #pragma unroll
             for (int r = 0; r < KREG; ++r) xs[r] = rows[r][e];
+            const float om = m.mean[e], os = m.std[e];
+            // elite rows the previous launch left as raw noise: the action it rolled out (same fmaf + v_med3, same bits)
+#pragma unroll
+            for (int r = 0; r < KREG; ++r) {
+                const bool raw = key_idx(sel[r < m.K ? r : 0]) < m.n_raw;
+                const float v = __builtin_amdgcn_fmed3f(__builtin_fmaf(xs[r], os, om), m.xf_lo, m.xf_hi);
+                xs[r] = raw ? v : xs[r];
+            }
             float nm, ns;
-            refit_element_regs<float, KREG>(m.K, m.alpha, m.mean[e], m.std[e], xs, nm, ns);
+            refit_element_regs<float, KREG>(m.K, m.alpha, om, os, xs, nm, ns);
             dist[e] = nm;
             dist[HD + e] = ns;
             if (blockIdx.x == 0) {
@@ -208,7 +217,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
     // tile t of the launch belongs to wave t / n_roll of rollout workgroup t % n_roll (as rollout16_kernel)
     for (int tile_id = tile0; tile_id < tiles; tile_id += WAVES * n_roll) {
         if (!first) stream.first_loads(args.pool, a.n_rows, tile_id, pre);
-        run_key = stream.run_xf(tile, a, args.pool, args.n_xf, args.row0_mean != 0, true, dist, args.lo, args.hi, tile_id, lane, run_key, first, pre);
+        run_key = stream.run_xf(tile, a, args.pool, args.n_xf, args.row0_mean != 0, args.store_back != 0, dist, args.lo, args.hi, tile_id, lane, run_key, first, pre);
         first = false;
     }
     if (a.K > 0) wg_merge_emit<WAVES>(wg_keys, run_key, a.K, lane, wave, a, (int)blockIdx.x, n_roll);

@@ -777,6 +777,7 @@ static int plan_step_ahead(icem_handle* h, const icem_plan_buffers* b, int mpc_s
         h->pm_pending = false;
         ia.n_xf = n;
         ia.row0_mean = (last && c.use_mean_actions) ? 1 : 0;
+        ia.store_back = last ? 1 : 0;
         ia.pool = pool;
         ia.mean = cur_mean;
         ia.std = cur_std;
@@ -835,6 +836,9 @@ static int plan_step_ahead(icem_handle* h, const icem_plan_buffers* b, int mpc_s
         }
         if (!last) {
             if (!h->pm_pending) return fail(ICEM_E_STATE, "noise-ahead: the merge did not defer");
+            h->pm_args.n_raw = n;  // this pool keeps its noise: the next prologue maps the elite rows among rows [0, n)
+            h->pm_args.xf_lo = A.lo;
+            h->pm_args.xf_hi = A.hi;
             cur_mean = pp;
             cur_std = pp + hd;
         }
