@@ -1,0 +1,42 @@
+"""Throughput of the GENERIC kernels (generic_kernels.hip: any h <= 64, d <= 64, o <= 32, f32 / f64) on shapes outside the
+compiled fast list and on the f64 strict-parity mode -- what a settings/*.json with another horizon / action count gets.
+usage (GPU box): python tools/generic_bench.py"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner  # noqa: E402
+
+CASES = [  # (label, h, d, o, N, iters, dtype)
+    ("fast path, for reference (h=30 d=6 o=17 f32)", 30, 6, 17, 4096, 5, "f32"),
+    ("same shape, f64 strict-parity mode", 30, 6, 17, 4096, 5, "f64"),
+    ("h=20 d=8 o=12 f32 (no fast kernel for this shape)", 20, 8, 12, 4096, 5, "f32"),
+    ("h=20 d=8 o=12 f32", 20, 8, 12, 65536, 5, "f32"),
+    ("h=50 d=3 o=8 f32 (Reacher-sized)", 50, 3, 8, 4096, 5, "f32"),
+    ("h=30 d=6 o=17 f32 with ICEM_DISABLE_FAST=1", 30, 6, 17, 65536, 5, "f32"),
+]
+for label, h, d, o, N, iters, dtype in CASES:
+    if "DISABLE_FAST" in label:
+        os.environ["ICEM_DISABLE_FAST"] = "1"
+    model = DeviceSyntheticModel.make(o, d)
+    pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=N, opt_iters=iters, dtype=dtype, seed=1), -np.ones(d), np.ones(d))
+    pl.set_model(model.kind, model.A, model.B)
+    pl.set_cost(0.1, min(8, o - 1), -1.0, 1, 10.0, float(np.pi / 2))
+    pl.reset()
+    pl.obs0.copy_(torch.as_tensor(0.1 * np.random.RandomState(0).randn(o), dtype=pl.dt))
+    for _ in range(5):
+        pl.plan_step_resident()
+    torch.cuda.synchronize()
+    steps = 50
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pl.plan_step_resident()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ts = sum(pl.population_sizes) * h
+    print(f"{label:58s} N={N:6d}: {dt * 1e6:9.1f} us per MPC step, {ts / dt / 1e9:7.3f} G traj-steps/s", flush=True)
+    os.environ.pop("ICEM_DISABLE_FAST", None)
