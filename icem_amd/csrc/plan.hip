@@ -163,6 +163,9 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
         {
             ProfScope prof(h, ICEM_K_ROLLOUT, (long long)n_rows * h->cfg.horizon, st);
             launch_rollout_wide(w, h->model_kind, st);
+            // (the row-wise kernel BESIDE the tile kernel on a second stream instead of behind it was measured: 4.70
+            //  instead of 4.15 ms per MPC step -- the three CUs that host a row workgroup finish their tile workgroup
+            //  late, and the launch waits for its slowest workgroup; EXPERIMENTS.md R3.7)
             if (split_tail) launch_rollout_rows_wide(w, n_rows, n_tail, (const float*)h->A_dev, (const float*)h->B_dev, h->model_kind, st);
         }
         ICEM_HIP_TRY(hipGetLastError());
