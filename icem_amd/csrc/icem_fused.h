@@ -206,8 +206,8 @@ void launch_noise_rows(const FastSampleArgs& a, int rounds, hipStream_t st);  //
 struct IterAheadArgs {
     // rollout role
     FastRolloutArgs r;   // r.actions == pool
-    MergeSingleArgs m;   // has_merge: the PREVIOUS iteration's merge (last == 0, lists form) runs in the prologue
-    int has_merge;
+    MergeSingleArgs m;   // has_merge: the PREVIOUS iteration's merge (last == 0) -- 1: lists form, in every rollout
+    int has_merge;       // workgroup's prologue (world 1); 2: records form, once, by the pack role (sharded runs)
     int n_xf;            // rows [0, n_xf) of the pool hold raw noise
     int row0_mean;       // icem.py:87-88
     int store_back;      // write the actions back over the noise (the last iteration: the caller's pool; the others leave
@@ -221,6 +221,10 @@ struct IterAheadArgs {
     // shift role: s.n_shift shifted elites from s.elites_src (stream s.off2_*, distribution s.mean / s.std) -> rows
     // [s.n, s.n + s.n_shift) of s.out (== pool) and their costs -> r.costs[s.n ...] (s.n_shift == 0: no such workgroup)
     FastSampleArgs s;
+    // sharded runs (world > 1; has_merge == 2): the PREVIOUS iteration's record pack + push rides as workgroup 0, which
+    // then runs the launch's one records merge (m: records form) and publishes mean | std (p.pub / p.pub_flag / p.pub_seq,
+    // as in sample_folded_merge_kernel); the rollout workgroups wait for that flag instead of merging themselves
+    PackPrev p;
     int n_roll, n_noise;  // workgroups per role (filled by the launcher)
 };
 bool rollout_ahead_ok(int h, int d, int O, int K, int n_rows);

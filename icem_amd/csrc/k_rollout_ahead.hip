@@ -52,7 +52,9 @@ struct AheadLds {
 
 // (at most 128 registers whatever the workgroup size: the rollout waves share their SIMDs with the noise role's.  96 -- a
 //  fifth wave per SIMD -- spills 32 registers in the rollout role: measured 220 instead of 185 us per MPC step at N = 65 536)
-template <int H, int D, int O, int KIND, int WAVES, bool PM>
+// PM: 0 = no merge (iteration 0), 1 = lists merge in every rollout workgroup's prologue, 2 = sharded: pack role + published
+// records merge
+template <int H, int D, int O, int KIND, int WAVES, int PM>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8))) void iter_ahead_kernel(IterAheadArgs args) {
     using Tile = Tile16<H, D, O, KIND>;
     using Stream = Stream16<H, D, O, KIND>;
@@ -63,11 +65,69 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int n_roll = args.n_roll;
+    // ------------------------------------------------------------------------------------------------ pack role
+    // (sharded runs) workgroup 0: the previous iteration's K best of this rank's lists -> records, pushed into every rank's
+    // exchange block; then THE records merge of the launch for everybody (waits for all ranks' flags, selects, gathers,
+    // refits) and its publication (written through; one agent-scope flag).  sample_folded_merge_kernel's workgroup 0,
+    // with the local selection shared by all waves.
+    if constexpr (PM == 2) {
+        if (blockIdx.x == 0) {
+            unsigned long long* sel = reinterpret_cast<unsigned long long*>(smem + L::SEL);
+            unsigned long long* wsel = reinterpret_cast<unsigned long long*>(smem + L::WSEL);
+            int* slot = reinterpret_cast<int*>(smem + L::SLOT);
+            unsigned long long* cand = reinterpret_cast<unsigned long long*>(smem + L::STAGE) + wave * 64;
+            float* stage = smem + L::STAGE + WAVES * 128;  // behind the compaction scratch: [K, rs] floats of records
+            MergeSingleArgs pk{};
+            pk.n_lists = args.p.n_lists;
+            pk.n_pool = args.p.n_pool;
+            pk.n_global = args.p.n_global;
+            pk.K = args.p.K;
+            pk.h = H;
+            pk.d = D;
+            pk.part_k = args.p.part_k;
+            pk.actions = args.p.actions;
+            pk.n_keep = args.p.n_keep;
+            pk.elites_cost_cur = args.p.keep_costs;
+            pk.keep_base = args.p.n_loc;
+            __builtin_amdgcn_s_setprio(3);  // everybody else waits for this workgroup
+            merge_select_split_stage1<KREG>(pk, lane, wave, WAVES, cand, wsel);
+            __syncthreads();
+            if (wave == 0) merge_select_split_stage2(pk, lane, WAVES, wsel, cand, sel);
+            __syncthreads();
+            pack_records_body<KREG>(pk, args.p.n_loc, args.p.shard_lo, args.p.records, args.p.px, stage, sel, tid, NTT);
+            __syncthreads();
+            const MergeSingleArgs& m = args.m;
+            if (wave == 0) merge_select_records(m, lane, cand, sel, slot);
+            __syncthreads();
+            const float* rows[KREG];
+            merge_rows<KREG, true>(m, sel, slot, rows);
+            for (int e = tid; e < HD; e += NTT) {
+                float xs[KREG];
+#pragma unroll
+                for (int r = 0; r < KREG; ++r) xs[r] = rows[r][e];
+                float nm, ns;
+                refit_element_regs<float, KREG>(m.K, m.alpha, m.mean[e], m.std[e], xs, nm, ns);
+                __hip_atomic_store(args.p.pub + e, nm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(args.p.pub + HD + e, ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                m.mean_out[e] = nm;
+                m.std_out[e] = ns;
+#pragma unroll
+                for (int r = 0; r < KREG; ++r)
+                    if (r < m.K) m.elites_next[(size_t)r * HD + e] = xs[r];
+            }
+            if (tid < m.K) m.elites_cost_next[tid] = key_cost(sel[tid]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(args.p.pub_flag, args.p.pub_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
+    const int bid = (int)blockIdx.x - (PM == 2 ? 1 : 0);  // workgroup number behind the pack role
     // ------------------------------------------------------------------------------------------------ noise role
-    if ((int)blockIdx.x >= n_roll && (int)blockIdx.x < n_roll + args.n_noise) {
+    if (bid >= n_roll && bid < n_roll + args.n_noise) {
         const FastSampleArgs& z = args.z;
         float* tile = smem;  // [TPW, HD]
-        const int n_base = ((int)blockIdx.x - n_roll) * L::TPW;
+        const int n_base = (bid - n_roll) * L::TPW;
         const int n_here = cmin(L::TPW, z.n - n_base);
         if (tid < n_here * D) {
             const int nl = tid / D;
@@ -92,7 +152,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
     }
     const FastRolloutArgs& a = args.r;
     // ------------------------------------------------------------------------------------------------ shift role
-    if ((int)blockIdx.x >= n_roll) {
+    if (bid >= n_roll) {
         // shifted elite e: elites[e, 1:, j] and a last action drawn from the full (n_shift, d, h) noise batch of stream off2
         // (only t = h-1 is used, icem.py:102) -> pool rows [n, n + n_shift) and a 16-row LDS tile; then one wave rolls the
         // tile out (Tile16: the bits the rollout role would produce for these rows) -> costs [n, n + n_shift)
@@ -162,15 +222,26 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
     Stream stream;
     stream.init(tile, stage + wave * Stream::STG, lane);
     const int tiles = (a.n_rows + 15) / 16;
-    const int tile0 = wave * n_roll + (int)blockIdx.x;
+    const int tile0 = wave * n_roll + bid;
     typename Stream::Vec pre[Stream::NLD];
-    if constexpr (PM) {
+    if constexpr (PM == 1) {
         // all waves share the selection: one cold round trip instead of a dozen dependent ones
         merge_select_split_stage1<KREG>(args.m, lane, wave, WAVES, cand, wsel);
         // (this wave's first noise vectors: requested behind its keys, in flight across the barriers below)
         if (tile0 < tiles) stream.first_loads(args.pool, a.n_rows, tile0, pre);
         __syncthreads();
         if (wave == 0) merge_select_split_stage2(args.m, lane, WAVES, wsel, cand, sel);
+    } else if constexpr (PM == 2) {
+        // sharded: the pack role merges for everybody -- wait for its flag (bounded like every exchange wait)
+        if (tile0 < tiles) stream.first_loads(args.pool, a.n_rows, tile0, pre);
+        if (wave == 0) {
+            unsigned polls = 0;
+            while (__hip_atomic_load(args.p.pub_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != args.p.pub_seq &&
+                   ++polls <= args.m.xw.max_polls)
+                __builtin_amdgcn_s_sleep(16);
+            if (polls > args.m.xw.max_polls && lane == 0 && args.m.xw.status)
+                __hip_atomic_store(args.m.xw.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     } else {
         if (tile0 < tiles) stream.first_loads(args.pool, a.n_rows, tile0, pre);
         for (int e = tid; e < HD; e += NTT) {
@@ -180,7 +251,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
     }
     if (tid < 32) obs_stage[tid] = tid < a.o ? obs_reg : 0.f;
     __syncthreads();
-    if constexpr (PM) {
+    if constexpr (PM == 2) {
+        for (int e = tid; e < 2 * HD; e += NTT) dist[e] = __hip_atomic_load(args.p.pub + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+    }
+    if constexpr (PM == 1) {
         const MergeSingleArgs& m = args.m;
         const float* rows[KREG];
         merge_rows<KREG, false>(m, sel, slot, rows);
@@ -200,7 +275,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
             refit_element_regs<float, KREG>(m.K, m.alpha, om, os, xs, nm, ns);
             dist[e] = nm;
             dist[HD + e] = ns;
-            if (blockIdx.x == 0) {
+            if (bid == 0) {
                 m.mean_out[e] = nm;
                 m.std_out[e] = ns;
 #pragma unroll
@@ -208,7 +283,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
                     if (r < m.K) m.elites_next[(size_t)r * HD + e] = xs[r];
             }
         }
-        if (blockIdx.x == 0 && tid < m.K) m.elites_cost_next[tid] = key_cost(sel[tid]);
+        if (bid == 0 && tid < m.K) m.elites_cost_next[tid] = key_cost(sel[tid]);
         __syncthreads();
     }
     tile.load_obs(obs_stage);
@@ -220,7 +295,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
         run_key = stream.run_xf(tile, a, args.pool, args.n_xf, args.row0_mean != 0, args.store_back != 0, dist, args.lo, args.hi, tile_id, lane, run_key, first, pre);
         first = false;
     }
-    if (a.K > 0) wg_merge_emit<WAVES>(wg_keys, run_key, a.K, lane, wave, a, (int)blockIdx.x, n_roll);
+    if (a.K > 0) wg_merge_emit<WAVES>(wg_keys, run_key, a.K, lane, wave, a, bid, n_roll);
 }
 
 // Launch shape of the rollout role: rollout16's (one 16-trajectory tile per wave while they fit, at most FAST_MAX_LISTS
@@ -256,22 +331,26 @@ void launch_iter_ahead(const IterAheadArgs& a_in, int h, int d, int O, int kind,
     {                                                                                                                      \
         using L = AheadLds<HH, DD, OO, KK, WW>;                                                                            \
         a.n_noise = a.z.n > 0 ? (a.z.n + L::TPW - 1) / L::TPW : 0;                                                         \
-        const int total = grid + a.n_noise + (a.s.n_shift > 0 ? 1 : 0);                                                    \
+        const int total = grid + a.n_noise + (a.s.n_shift > 0 ? 1 : 0) + (PP == 2 ? 1 : 0);                                \
         hipLaunchKernelGGL((iter_ahead_kernel<HH, DD, OO, KK, WW, PP>), dim3(total), dim3(64 * WW), L::FLOATS * sizeof(float), st, a); \
     }
 #define XW(HH, DD, OO, WW)                          \
     if (waves == WW) {                              \
         if (kind == 1) {                            \
-            if (a.has_merge) {                      \
-                XK(HH, DD, OO, 1, WW, true)         \
+            if (a.has_merge == 2) {                 \
+                XK(HH, DD, OO, 1, WW, 2)            \
+            } else if (a.has_merge) {               \
+                XK(HH, DD, OO, 1, WW, 1)            \
             } else {                                \
-                XK(HH, DD, OO, 1, WW, false)        \
+                XK(HH, DD, OO, 1, WW, 0)            \
             }                                       \
         } else {                                    \
-            if (a.has_merge) {                      \
-                XK(HH, DD, OO, 0, WW, true)         \
+            if (a.has_merge == 2) {                 \
+                XK(HH, DD, OO, 0, WW, 2)            \
+            } else if (a.has_merge) {               \
+                XK(HH, DD, OO, 0, WW, 1)            \
             } else {                                \
-                XK(HH, DD, OO, 0, WW, false)        \
+                XK(HH, DD, OO, 0, WW, 0)            \
             }                                       \
         }                                           \
         return;                                     \

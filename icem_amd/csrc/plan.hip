@@ -691,7 +691,7 @@ void ahead_destroy(icem_handle* h) {
     A = icem_handle::Ahead();
 }
 
-static bool ahead_eligible(icem_handle* h, const icem_plan_buffers* b) {
+static bool ahead_eligible(icem_handle* h, const icem_plan_buffers* b, bool sharded = false) {
     icem_handle::Ahead& A = h->ahead;
     const icem_config& c = h->cfg;
     if (A.disabled < 0) {
@@ -702,12 +702,22 @@ static bool ahead_eligible(icem_handle* h, const icem_plan_buffers* b) {
         const char* m = getenv("ICEM_NOISE_AHEAD_MIN_ROWS");
         A.min_rows = m ? atoi(m) : 0;
     }
-    if (A.disabled || c.world != 1 || c.dtype != ICEM_F32 || b->z_r != nullptr || !h->use_fast || h->wide || c.opt_iters < 2 ||
-        h->dbg != nullptr || c.rng_rounds != 10)
+    if (A.disabled || (c.world != 1) != sharded || c.dtype != ICEM_F32 || b->z_r != nullptr || !h->use_fast || h->wide ||
+        c.opt_iters < 2 || h->dbg != nullptr || c.rng_rounds != 10)
         return false;
     if (!fast_rollout_ok(h, c.num_elites) || !fast_sample_ok(h)) return false;
-    for (int n : h->pop)
+    if (sharded) {
+        // peers in processes of their own (the pack rides in the next launch), records that fit the pack's LDS stage and
+        // the records merge's two-per-lane layout, the published merge switched on
+        static const int on = [] { const char* e = getenv("ICEM_NOISE_AHEAD_SHARDED"); return e ? atoi(e) : 1; }();
+        if (!on || !xchg_connected(h) || !xchg_concurrent_peers(h) || !pack_can_push(c.num_elites, c.horizon, c.act_dim) ||
+            c.world * c.num_elites > 128 || c.num_elites > 32)
+            return false;
+    }
+    for (size_t it = 0; it < h->pop.size(); ++it) {
+        const int n = sharded ? local_rows(h, (int)it) : h->pop[it];
         if (n < A.min_rows || !rollout_ahead_ok(c.horizon, c.act_dim, h->O, c.num_elites, n)) return false;
+    }
     if (c.shift_elites && h->n_reuse > 16) return false;  // (the shift role rolls its rows out as one 16-row tile)
     // the transform takes the bounds as two scalars: fetch them once per (low, high) buffer pair
     if (A.lo_ptr != b->low || A.hi_ptr != b->high) {
@@ -842,6 +852,167 @@ static int plan_step_ahead(icem_handle* h, const icem_plan_buffers* b, int mpc_s
             h->pm_args.n_raw = n;  // this pool keeps its noise: the next prologue maps the elite rows among rows [0, n)
             h->pm_args.xf_lo = A.lo;
             h->pm_args.xf_hi = A.hi;
+            cur_mean = pp;
+            cur_std = pp + hd;
+        }
+    }
+    A.ctr += (unsigned long long)(iters - 1);
+    return ICEM_OK;
+}
+
+// The same pipeline for one rank of a sharded run (world > 1, in-library exchange connected, peers in processes of their
+// own).  Per iteration ONE local launch: workgroup 0 packs + pushes the PREVIOUS iteration's K records and runs the
+// launch's one records merge for everybody (published mean | std), the rollout workgroups wait for that flag, map and
+// roll out this rank's shard, the noise workgroups draw the shard's next noise; rank 0 alone builds and rolls out the
+// (replicated) shifted elites.  Every pool is written back (the record pack gathers actions).  The last iteration's
+// pack and merge are launches of their own, as on the sampler + rollout path.
+static int plan_step_sharded_ahead(icem_handle* h, const icem_plan_buffers* b, int mpc_step, hipStream_t st) {
+    icem_handle::Ahead& A = h->ahead;
+    const icem_config& c = h->cfg;
+    const int iters = c.opt_iters, K = c.num_elites, hd = h->hd;
+    int rc = ahead_setup(h);
+    if (rc) return rc;
+    rc = ensure_fast_model(h);
+    if (rc) return rc;
+    if (!h->pub_dev) {
+        ICEM_HIP_TRY(hipMalloc((void**)&h->pub_dev, ((size_t)2 * hd + 16) * sizeof(float)));
+        ICEM_HIP_TRY(hipMemsetAsync(h->pub_dev, 0, ((size_t)2 * hd + 16) * sizeof(float), st));
+    }
+    const uint64_t call_base = (h->episode << 32) + (uint64_t)mpc_step * (uint64_t)(iters + 1);
+    auto pool_of = [&](int it) -> float* { return it == iters - 1 ? (float*)b->actions : (float*)A.pool[(A.ctr + (unsigned)it) % 3]; };
+    auto shard = [&](int it, int* lo_out) {
+        const int n_global = h->pop[it], chunk = shard_chunk(n_global, c.world);
+        const int lo = std::min(n_global, c.rank * chunk);
+        *lo_out = lo;
+        return std::max(0, std::min(n_global - lo, chunk));
+    };
+    auto noise_args = [&](int n, int lo, uint64_t off, void* out) {
+        return fast_sample_args(h, n, lo, nullptr, nullptr, nullptr, nullptr, off, 0, out, 0, nullptr, 0);
+    };
+    float* cur_mean = (float*)b->mean;
+    float* cur_std = (float*)b->std;
+    const int n_extra = (c.shift_elites && mpc_step > 0 && h->n_reuse > 0) ? h->n_reuse : 0;
+    float* rec = (float*)b->records + (size_t)c.rank * K * (hd + 2);
+    PackPrev pack{};        // the previous iteration's pack, riding in this iteration's launch
+    bool pack_pending = false;
+    for (int it = 0; it < iters; ++it) {
+        const bool last = it == iters - 1;
+        int lo = 0;
+        const int n_loc = shard(it, &lo);
+        const int n_global = h->pop[it];
+        float* pool = pool_of(it);
+        icem_plan_buffers bb = *b;
+        bb.actions = pool;
+        bb.mean = cur_mean;
+        bb.std = cur_std;
+        if (it == 0) {
+            const bool hit = A.next_valid && A.next_episode == h->episode && A.next_step == mpc_step && A.next_pool == pool;
+            A.next_valid = false;
+            if (!hit) {
+                const FastSampleArgs za = noise_args(n_loc, lo, call_base, pool);
+                ProfScope prof(h, ICEM_K_SAMPLE, (long long)n_loc * c.horizon, st);
+                launch_noise_rows(za, c.rng_rounds, st);
+            }
+            ICEM_HIP_TRY(hipGetLastError());
+        }
+        const int tail = (it == 0 && c.rank == 0) ? n_extra : 0;  // shifted elites: rank 0 submits them (they are replicated)
+        IterAheadArgs ia{};
+        ia.r = fast_rollout_args(h, n_loc, n_loc, K, b->obs0, pool, b->costs, nullptr, nullptr);
+        ia.r.part_k = (unsigned long long*)b->workspace;
+        ia.n_xf = n_loc;
+        ia.row0_mean = (last && c.use_mean_actions && lo == 0) ? 1 : 0;
+        ia.store_back = 1;
+        ia.pool = pool;
+        ia.mean = cur_mean;
+        ia.std = cur_std;
+        ia.lo = A.lo;
+        ia.hi = A.hi;
+        if (it > 0) {
+            if (!h->pm_pending || !pack_pending) return fail(ICEM_E_STATE, "noise-ahead (sharded): merge / pack not stashed");
+            ia.has_merge = 2;
+            ia.m = h->pm_args;
+            ia.p = pack;
+            ia.p.pub = h->pub_dev;
+            ia.p.pub_flag = reinterpret_cast<unsigned*>(h->pub_dev + 2 * hd);
+            ia.p.pub_seq = ++h->pub_seq;
+            h->pm_pending = false;
+            pack_pending = false;
+        }
+        if (!last) {
+            int lo1 = 0;
+            const int n1 = shard(it + 1, &lo1);
+            ia.z = noise_args(n1, lo1, call_base + (uint64_t)(it + 1), pool_of(it + 1));
+        } else {
+            int lo0 = 0;
+            const int n0 = shard(0, &lo0);
+            void* np = A.pool[(A.ctr + (unsigned)(iters - 1)) % 3];
+            ia.z = noise_args(n0, lo0, (h->episode << 32) + (uint64_t)(mpc_step + 1) * (uint64_t)(iters + 1), np);
+            A.next_valid = true;
+            A.next_episode = h->episode;
+            A.next_step = mpc_step + 1;
+            A.next_pool = np;
+        }
+        if (tail > 0) {
+            const int g = (int)(((long long)mpc_step * iters) & 1);
+            ia.s = fast_sample_args(h, n_loc, 0, cur_mean, cur_std, b->low, b->high, call_base, 0, pool, tail,
+                                    (const float*)b->elites + (size_t)g * K * hd, call_base + (uint64_t)iters);
+        }
+        {
+            ProfScope prof(h, ICEM_K_SAMPLE_ROLLOUT, (long long)n_loc * c.horizon, st);
+            launch_iter_ahead(ia, c.horizon, c.act_dim, h->O, h->model_kind, st);
+        }
+        ICEM_HIP_TRY(hipGetLastError());
+        const int lists = ahead_roll_workgroups(n_loc);
+        h->fast_lists = lists;
+        h->fast_tail_rows = 0;
+        // ---- this iteration's pack: stashed for the next launch's workgroup 0, or (last) a launch of its own ----
+        MergeSingleArgs pk{};
+        pk.n_lists = lists;
+        pk.n_pool = n_loc + tail;
+        pk.n_global = n_global;
+        pk.K = K;
+        pk.h = c.horizon;
+        pk.d = c.act_dim;
+        pk.part_k = (const unsigned long long*)b->workspace;
+        pk.actions = pool;
+        if (tail > 0) {  // rank 0's shifted elites: extra candidates of the pack, costs from the cost array
+            pk.n_keep = tail;
+            pk.elites_cost_cur = (const float*)b->costs + n_loc;
+            pk.keep_base = n_loc;
+        }
+        XchgPush px;
+        rc = xchg_begin(h, &px, &h->xw_last);
+        if (rc) return rc;
+        if (!last) {
+            pack.part_k = pk.part_k;
+            pack.actions = pk.actions;
+            pack.n_lists = pk.n_lists;
+            pack.n_pool = pk.n_pool;
+            pack.n_global = pk.n_global;
+            pack.K = K;
+            pack.n_loc = n_loc;
+            pack.shard_lo = lo;
+            pack.n_keep = pk.n_keep;
+            pack.keep_costs = pk.elites_cost_cur;
+            pack.records = rec;
+            pack.px = px;
+            pack_pending = true;
+        } else {
+            ProfScope prof(h, ICEM_K_LOCAL_PACK, lists * K, st);
+            launch_pack_records(pk, n_loc, lo, rec, st, px);
+            ICEM_HIP_TRY(hipGetLastError());
+        }
+        // ---- its merge (records form): stashed for the next launch's pack role, or (last) a launch of its own ----
+        float* pp = h->pp_stats + (size_t)(it & 1) * 2 * hd;
+        h->defer_merge = !last;
+        h->merge_mean_out = last ? (float*)b->mean : pp;
+        h->merge_std_out = last ? (float*)b->std : pp + hd;
+        rc = plan_iter_merge_t<float>(h, &bb, mpc_step, it, st);
+        h->defer_merge = false;
+        h->merge_mean_out = h->merge_std_out = nullptr;
+        if (rc) return rc;
+        if (!last) {
+            if (!h->pm_pending || h->pm_args.records == nullptr) return fail(ICEM_E_STATE, "noise-ahead (sharded): the merge did not defer");
             cur_mean = pp;
             cur_std = pp + hd;
         }
@@ -986,6 +1157,8 @@ int icem_plan_step_sharded(icem_handle* h, const icem_plan_buffers* b, int32_t m
     if (xchg_status_peek(h) & 1u)
         return fail(ICEM_E_STATE, "in-library exchange: a wait for a peer's elite records timed out in an earlier MPC step "
                                   "(icem_exchange_status reads and clears the word); the plans since then are not valid");
+    if (b && check_plan(h, b, mpc_step, 0) == ICEM_OK && !h->pm_pending && !h->pk_pending && ahead_eligible(h, b, true))
+        return plan_step_sharded_ahead(h, b, mpc_step, (hipStream_t)stream);
     const bool was = h->deferral;
     h->deferral = true;  // non-last merges ride in the next local launch
     int rc = ICEM_OK;
