@@ -128,7 +128,13 @@ struct icem_handle {
         float lo = 0.f, hi = 0.f;
         // part of that noise rides beside the step's LAST merge (the one launch that leaves the chip idle)
         bool tail_pending = false;
-        icem::FastSampleArgs tail_args;
+        icem::FastSampleArgs tail_args, tail2_args;   // tail2 (n > 0): the next step's shifted elites' noise as well
+        // small populations (single-launch kernel): the whole first noise of the next MPC step is drawn beside the last
+        // merge into `pre_raw` [pop[0] + n_reuse, h, d]; iteration 0 of that step only maps it (FastSampleArgs::raw_src)
+        void* pre_raw = nullptr;
+        bool pre_valid = false;
+        uint64_t pre_episode = 0;
+        int pre_step = -1;
         int disabled = -1;                   // ICEM_NOISE_AHEAD (latched at first use)
         int min_rows = 0;                    // ICEM_NOISE_AHEAD_MIN_ROWS
     } ahead;
@@ -269,6 +275,7 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
                         void* costs, float* part_c, int* part_i, hipStream_t st, int* lists_out,
                         unsigned long long* part_k = nullptr, int n_tail = 0, int* tail_out = nullptr);
 void ahead_destroy(icem_handle* h);
+void predraw_next_step(icem_handle* h, const icem_plan_buffers* b, int mpc_step);
 int launch_fast_sample(const icem_handle* h, int n, long long first_index, const void* mean, const void* std,
                        const void* low, const void* high, uint64_t offset, int row0_mean, void* out, hipStream_t st,
                        int n_shift = 0, const void* elites_src = nullptr, uint64_t offset2 = 0);

@@ -47,6 +47,10 @@ struct FastSampleArgs {
     const float* elites_src;  // [>= n_shift, h, d]
     uint32_t off2_lo, off2_hi;
     int white;  // noise_beta <= 0 (icem.py:77): normal t of a row is its sample at step t, no synthesis
+    // single-launch kernel, iteration 0 only: the raw colored noise of this call -- rows [0, n) and, behind them, the
+    // n_shift shifted elites' rows of stream off2 -- was drawn ahead (beside the previous MPC step's last merge,
+    // merge_noise_kernel) and only has to be mapped; nullptr: draw it here
+    const float* raw_src = nullptr;
 };
 bool fast_sample_supported(int h, int d);
 void launch_sample_folded(const FastSampleArgs& a, int rounds, hipStream_t st);
@@ -144,7 +148,8 @@ struct MergeSingleArgs {
 void launch_merge_single(const MergeSingleArgs& a, hipStream_t st);
 // ... with noise workgroups beside it (noise-ahead pipeline: z.n rows of raw colored noise -> z.out; see merge_noise_kernel)
 bool merge_noise_ok(const MergeSingleArgs& a, int rounds);
-void launch_merge_noise(const MergeSingleArgs& a, const FastSampleArgs& z, hipStream_t st);
+// z2 (z2.n > 0): a second, small sampling call in one more workgroup (the next step's shifted elites' noise)
+void launch_merge_noise(const MergeSingleArgs& a, const FastSampleArgs& z, const FastSampleArgs& z2, hipStream_t st);
 // icem_update_distribution for small f32 pools (topk_small_ok(n + n_keep, K)): top-K over [costs | keep_costs], gather from
 // [pool | keep_actions], refit of mean / std in place -- one launch
 struct UpdateSmallArgs {

@@ -115,8 +115,10 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
     // QS: this wave's table rows, requested now, parked in LDS behind the draws (sample_into_tile_quad's publish)
     constexpr int WPL = (WROWS * HMAX + 63) / 64;
     float wreg[QS ? WPL : 1];
+    // iteration 0 with its noise drawn ahead (beside the previous MPC step's last merge): nothing to sample here
+    const bool pre_drawn = !PM && sa.raw_src != nullptr;
     if constexpr (QS) {
-        if (tid < NT) {
+        if (tid < NT && !pre_drawn) {
 #pragma unroll
             for (int i = 0; i < WPL; ++i) wreg[i] = sa.W[(i * 64 + lane) < WROWS * HMAX ? i * 64 + lane : 0];
         }
@@ -132,6 +134,36 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
     }
     if (ra.dbg && tid == 0 && wg == 0) ra.dbg[9] = wall_clock64();
     const int r_mine = base + nl;
+    if (pre_drawn) {
+        // the slab's raw rows (sampled rows, then the shifted elites' rows of stream off2) are one contiguous block
+        {
+            const int total4 = (n_rows - base < TPB ? n_rows - base : TPB) * (HD / VW);
+            const Vec* g4 = reinterpret_cast<const Vec*>(sa.raw_src + (size_t)base * HD);
+            Vec* t4 = reinterpret_cast<Vec*>(tile_rows);
+            for (int e = tid; e < total4; e += NTT) t4[e] = g4[e];
+        }
+        __syncthreads();
+        if (has_row && tid < NT) {
+            const float lo = sa.low[jd], hi = sa.high[jd];
+            constexpr int QN = QS ? 4 : 1;
+            const int q0 = QS ? q : 0;
+            if (r_mine < sa.n) {  // y * std + mean, clipped (icem.py:79): the samplers' fmaf + v_med3
+                for (int t = q0; t < H; t += QN) {
+                    const float v = __builtin_fmaf(trow[t * D], mrow[HD + t * D], mrow[t * D]);
+                    trow[t * D] = __builtin_amdgcn_fmed3f(v, lo, hi);
+                }
+            } else if (r_mine < n_rows) {  // shifted elite: elites[e, 1:, j] ++ its freshly drawn last action (icem.py:91-104)
+                const float* src = sa.elites_src + (size_t)(r_mine - sa.n) * HD + jd;
+                if ((H - 1) % QN == q0) {
+                    const float v = __builtin_fmaf(trow[(H - 1) * D], mrow[HD + (H - 1) * D], mrow[(H - 1) * D]);
+                    trow[(H - 1) * D] = __builtin_amdgcn_fmed3f(v, lo, hi);
+                }
+                for (int t = q0; t < H - 1; t += QN) trow[t * D] = src[(t + 1) * D];
+            } else {
+                for (int t = q0; t < H; t += QN) trow[t * D] = 0.f;  // past the end: rolled out, dropped
+            }
+        }
+    } else
     if constexpr (QS) {
         if (tid < NT) {
             float* wl = Wl[wave];

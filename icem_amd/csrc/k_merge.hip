@@ -89,15 +89,18 @@ __global__ __launch_bounds__(MERGE_WG) void merge_single_kernel(MergeSingleArgs 
 // other workgroups draw raw colored noise (noise_rows_kernel's work: sample_row into an LDS tile, coalesced copy-out) for
 // iteration 0 of the NEXT MPC step -- the one launch of a step during which 255 of the 256 CUs had nothing to do.
 template <int H, int KREG>
-__global__ __launch_bounds__(MERGE_WG) void merge_noise_kernel(MergeSingleArgs a, FastSampleArgs z) {
+__global__ __launch_bounds__(MERGE_WG) void merge_noise_kernel(MergeSingleArgs a, FastSampleArgs z1, FastSampleArgs z2, int wgs1) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     if (blockIdx.x == 0) {
         merge_single_body<KREG, false>(a, smem_raw);
         return;
     }
+    // workgroups 1 .. wgs1: the sampling call z1; behind them: z2 (a few rows of another stream)
+    const bool second = (int)blockIdx.x > wgs1;
+    const FastSampleArgs& z = second ? z2 : z1;
     float* tile = reinterpret_cast<float*>(smem_raw);
     const int d = z.d, hd = H * d, tpw = MERGE_WG / d, tid = threadIdx.x;
-    const int n_base = ((int)blockIdx.x - 1) * tpw;
+    const int n_base = ((int)blockIdx.x - 1 - (second ? wgs1 : 0)) * tpw;
     const int n_here = cmin(tpw, z.n - n_base);
     if (tid < n_here * d) {
         const int nl = tid / d;
@@ -235,14 +238,15 @@ bool merge_noise_ok(const MergeSingleArgs& a, int rounds) {
     return a.records == nullptr && a.K + 1 <= 12 && rounds == 10 && fast_sample_supported(a.h, a.d);
 }
 
-void launch_merge_noise(const MergeSingleArgs& a, const FastSampleArgs& z, hipStream_t st) {
+void launch_merge_noise(const MergeSingleArgs& a, const FastSampleArgs& z, const FastSampleArgs& z2, hipStream_t st) {
     const int tpw = MERGE_WG / z.d;
-    const int grid = 1 + (z.n + tpw - 1) / tpw;
+    const int wgs1 = (z.n + tpw - 1) / tpw, wgs2 = z2.n > 0 ? (z2.n + tpw - 1) / tpw : 0;
+    const int grid = 1 + wgs1 + wgs2;
     const size_t lds = std::max((size_t)a.h * a.d, (size_t)tpw * z.h * z.d) * sizeof(float);
-#define X(HH)                                                                                          \
-    if (a.h == HH) {                                                                                   \
-        hipLaunchKernelGGL((merge_noise_kernel<HH, 12>), dim3(grid), dim3(MERGE_WG), lds, st, a, z);   \
-        return;                                                                                        \
+#define X(HH)                                                                                                    \
+    if (a.h == HH) {                                                                                             \
+        hipLaunchKernelGGL((merge_noise_kernel<HH, 12>), dim3(grid), dim3(MERGE_WG), lds, st, a, z, z2, wgs1);   \
+        return;                                                                                                  \
     }
     ICEM_FAST_HORIZONS(X)
 #undef X
