@@ -150,3 +150,12 @@ def test_rccl_binding_is_lazy_and_reports(lib):
     assert rc in (0, L.ICEM_E_UNSUPPORTED, L.ICEM_E_HIP), lib.icem_last_error()
     if rc == 0:
         assert any(bytes(ident)) and b"rccl" in lib.icem_rccl_library()
+
+
+def test_quoted_numbers_follow_from_the_tracked_profiles():
+    """Every figure DESIGN.md section 5 and profiles/README.md quote for the round is generated from the files under
+    profiles/ (tools/doc_numbers.py): the committed documents must be what the script generates, not hand copies."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "doc_numbers.py"), "r03", "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
