@@ -867,7 +867,11 @@ __device__ __forceinline__ int keep_index0(const MergeSingleArgs& a) { return a.
 // Global sorted top-K of the candidate lists (+ kept elites): ONE wavefront; sel[0..K) receives the keys.
 // Lane t owns lists t, t+64, t+128, t+192 (each sorted) in registers; key r of list w sits at
 // part_k[r * n_lists + w], so every load is one contiguous 512 bytes.
-template <int KREG>
+// KEPT_APART: the kept elites are offered as candidates of their own behind the lists' survivors instead of being
+// inserted into their lanes' first lists (a KREG-step compare-exchange chain, 0.56 us).  Measured per caller: the last
+// merge 6.52 -> 6.21 us and the one-tile single-launch kernel 10.07 -> 9.80 us with it, but the two- and four-tile
+// single-launch kernels +0.8 / +0.5 us per launch (N = 8192: 83.3 -> 87.7 us per MPC step) -- those keep the insertion.
+template <int KREG, bool KEPT_APART = false>
 __device__ __forceinline__ void merge_select(const MergeSingleArgs& a, int lane, unsigned long long* cand,
                                              unsigned long long* sel) {
     unsigned long long k[LPL][KREG];
@@ -887,7 +891,13 @@ __device__ __forceinline__ void merge_select(const MergeSingleArgs& a, int lane,
         for (int i = 0; i < KREG; ++i) k[l][i] = (has_list && i < a.K) ? k[l][i] : KEY_SENTINEL;
     }
     if (a.dbg && threadIdx.x == 0) a.dbg[1] = wall_clock64();
-    if (lane < a.n_keep) {  // kept elite `lane` (icem.py:143-145) joins this lane's first list, order preserved
+    // kept elite `lane` (icem.py:143-145): joins this lane's first list, order preserved -- or (KEPT_APART) stays one
+    // more candidate of this lane, offered behind the lists' survivors (the threshold below then comes from the lists
+    // alone: still an upper bound of the K-th smallest key overall)
+    unsigned long long kept = KEY_SENTINEL;
+    if constexpr (KEPT_APART) {
+        kept = lane < a.n_keep ? make_key(keep_cost, keep_index0(a) + lane) : KEY_SENTINEL;
+    } else if (lane < a.n_keep) {
         unsigned long long v = make_key(keep_cost, keep_index0(a) + lane);
 #pragma unroll
         for (int i = 0; i < KREG; ++i) {
@@ -929,6 +939,15 @@ __device__ __forceinline__ void merge_select(const MergeSingleArgs& a, int lane,
             }
         }
     }
+    if constexpr (KEPT_APART) {   // the kept elites at or below the threshold
+        const bool p = (unsigned)(kept >> 32) <= T && kept != KEY_SENTINEL;
+        const unsigned long long m = __ballot(p);
+        if (m != 0) {
+            const unsigned pos = n_cand + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (p && pos < 64) cand[pos] = kept;
+            n_cand += (unsigned)__popcll(m);
+        }
+    }
     if (a.dbg && threadIdx.x == 0) a.dbg[3] = wall_clock64();
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     if (n_cand <= 64) {
@@ -936,13 +955,17 @@ __device__ __forceinline__ void merge_select(const MergeSingleArgs& a, int lane,
         key = wave_sort_n(key, lane, n_cand);
         if (lane < a.K) sel[lane] = key;
     } else {
-        // more than 64 keys tie at or below T: K tournament rounds over the list heads
+        // more than 64 keys tie at or below T: K tournament rounds over the list heads (and the kept elites)
         for (int r = 0; r < a.K; ++r) {
             unsigned long long head = k[0][0];
 #pragma unroll
             for (int l = 1; l < LPL; ++l) head = k[l][0] < head ? k[l][0] : head;
+            if constexpr (KEPT_APART) head = kept < head ? kept : head;
             const unsigned long long best = wave_min_u64(head);
             if (best != KEY_SENTINEL) {  // keys embed the trajectory index: exactly one (lane, list) matches
+                if constexpr (KEPT_APART) {
+                    if (kept == best) kept = KEY_SENTINEL;
+                }
 #pragma unroll
                 for (int l = 0; l < LPL; ++l) {
                     if (k[l][0] == best) {

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
             else if constexpr (RW >= 8)  // 13 waves share the register file: the low-register selection
                 merge_select_stream(a.m, lane, cand, sel);
             else
-                merge_select<KREG>(a.m, lane, cand, sel);
+                merge_select<KREG, (RW == 1)>(a.m, lane, cand, sel);
         }
     }
     if (PM) {  // now the rest of the inputs: in flight across the barriers below

@@ -32,7 +32,7 @@ __device__ __forceinline__ void merge_single_body(const MergeSingleArgs& a, unsi
         if constexpr (REC)
             merge_select_records(a, lane, cand, sel, slot);
         else
-            merge_select<KREG>(a, lane, cand, sel);
+            merge_select<KREG, true>(a, lane, cand, sel);
     }
     if (a.dbg && threadIdx.x == 0) a.dbg[4] = wall_clock64();
     __syncthreads();
