@@ -430,6 +430,10 @@ int icem_reset_distribution(icem_handle* h, void* mean, void* std, const void* l
 }
 
 int icem_debug_stamps(icem_handle* h, void* dev_ptr) {
+    if (!h) {   // the stateless learned-dynamics rollout's stamps
+        rssm_set_stamps((long long*)dev_ptr);
+        return ICEM_OK;
+    }
     if (check_handle(h)) return ICEM_E_INVALID;
     h->dbg = (long long*)dev_ptr;
     return ICEM_OK;

@@ -29,9 +29,15 @@ constexpr size_t W6 = B5 + 2 * 16 * STB, B6 = W6 + (size_t)HIDB * K6K * BLK;
 constexpr size_t W7 = B6 + 2 * 16 * HIDB, B7 = W7 + (size_t)HIDB * HIDK * BLK;
 constexpr size_t W8 = B7 + 2 * 16 * HIDB, B8 = W8 + (size_t)1 * HIDK * BLK;
 constexpr size_t TOTAL = B8 + 2 * 16;  // bf16 units
+constexpr int SPLIT_MAX_TILES = 128;   // populations up to 2048: recurrence and reward head on separate CUs (icem_rssm_split.hip)
 }  // namespace rssm
 
 // costs[i] = reduce_t -reward(state_t) along the rollout of actions[i] from obs0 (cost_mode: 0 sum, 1 best, 2 final)
 hipError_t launch_rssm_rollout(int n, int horizon, int cost_mode, const unsigned short* params, const float* obs0,
                                const float* actions, float* costs, hipStream_t st);
+// n <= 16 * SPLIT_MAX_TILES: one launch of recurrence workgroups + reward-head workgroups (ICEM_RSSM_SPLIT=0 turns it off)
+bool rssm_split_ok(int n, int horizon);
+void rssm_set_stamps(long long* dev_ptr);   // development aid: 16 int64 of wall_clock64 phase stamps of tile 0 (NULL = off)
+hipError_t launch_rssm_split(int n, int horizon, int cost_mode, const unsigned short* params, const float* obs0,
+                             const float* actions, float* costs, hipStream_t st);
 }  // namespace icem

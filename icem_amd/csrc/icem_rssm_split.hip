@@ -1,0 +1,369 @@
+// Small populations of the recurrent state-space model rollout (icem_rssm.h), at most 128 tiles of 16 trajectories: the
+// fused kernel of icem_rssm.hip leaves three CUs in four idle there and every workgroup streams the reward head's
+// weights (W6, W7, W8: 0.2 of the 0.9 MB per model step) through its CU's L2 port on the recurrence's own critical path.
+// Here ONE launch holds two kinds of workgroups:
+//   * blocks [0, tiles): the RECURRENCE of one tile -- x, GRU, p, z' per model step, four barriers, nothing else; the
+//     last of the `horizon` transitions is never run (a step's cost is the reward of the state it STARTS from);
+//   * blocks [tiles, 2 tiles): the REWARD HEAD of one tile on another CU, its weights loaded ONCE into registers
+//     (148 per lane), consuming the states (h_t, z_t) as the recurrence publishes them.
+// State t of a tile travels through an 8 KB item in global memory: wave 7 of the recurrence workgroup -- which owns one
+// GRU output block where waves 0..4 own two -- copies [h_t | z_t] out of LDS during phase 2 of step t with written-through
+// stores, waits for them itself and raises the tile's flag to t + 1; no other wave ever waits for a store.  The reward
+// workgroup polls the flag, reads the item with agent-scope loads straight into B operands, and resets the flag to 0
+// behind the last item (so a captured launch can be replayed).  Producers have the lower block indices: they are all
+// resident before the first consumer is dispatched and they wait for nobody.
+// The arithmetic, its order and its rounding points are those of rssm_rollout_kernel<1>: costs are bit-identical.
+#include "rssm_dev.h"
+
+#include <cstdlib>
+#include <map>
+#include <mutex>
+
+namespace icem {
+namespace {
+using namespace rssm_dev;
+
+constexpr int SR = 256;              // bf16 row of an item: [h: 7 k-blocks (200 + zero padding) | z: 1 k-block]
+constexpr int ITEM = 16 * SR;        // elements
+constexpr unsigned MAX_POLLS = 1u << 22;   // x s_sleep(2): a few hundred ms, then the reward workgroup gives up (costs = NaN)
+
+struct ProducerLds {
+    unsigned short zA[16 * ZS];
+    unsigned short hb[2][16 * RS];
+    unsigned short xb[16 * RS];
+    float h32[16 * HS];
+    float bs[NBIAS];
+    unsigned short w1[HIDB * K1K * BLK];   // the two small layers' A-operand blocks, resident: no L2 round trip in phases 1 and 4
+    unsigned short w5[STB * HIDK * BLK];
+};
+struct ConsumerLds {
+    unsigned short r1[2][16 * RS];
+    unsigned short r2[2][16 * RS];
+};
+constexpr size_t LDS_BYTES = sizeof(ProducerLds) > sizeof(ConsumerLds) ? sizeof(ProducerLds) : sizeof(ConsumerLds);
+
+__device__ __forceinline__ void store_wt(unsigned short* p, unsigned long long v) {   // written through, 8 bytes
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long load_ag(const unsigned short* p) {     // past the non-coherent caches, 8 bytes
+    return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// wave-wide copy of state t out of LDS into its item, then the flag (called by ONE wave)
+__device__ __forceinline__ void publish(const ProducerLds& s, int cur, unsigned short* item, unsigned* flag, unsigned value, int lane) {
+    // h: 16 rows x 208 bf16 = 52 8-byte words per row; z: 16 rows x 32 bf16 = 8 words per row
+    asm volatile("" : "+v"(lane));   // (the 15 address pairs are step-invariant: hoisted out of the step loop they are spilled)
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+        const int e = lane + 64 * i, row = e / 52, c = e % 52;
+        store_wt(item + row * SR + 4 * c, *reinterpret_cast<const unsigned long long*>(s.hb[cur] + row * RS + 4 * c));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = lane + 64 * i, row = e / 8, c = e % 8;
+        store_wt(item + row * SR + 224 + 4 * c, *reinterpret_cast<const unsigned long long*>(s.zA + row * ZS + 4 * c));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void recurrence(ProducerLds& s, int tile, int n, int horizon, const unsigned short* __restrict__ Pg,
+                                           const float* __restrict__ obs0, const float* __restrict__ actions,
+                                           unsigned short* stage, unsigned* flags, long long* stamps) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int base = tile * 16;
+    const bool stamp = stamps && tile == 0 && tid == 0;   // development aid (icem_debug_stamps(NULL, buffer))
+    if (stamp) stamps[0] = wall_clock64();
+    unsigned short* items = stage + (size_t)tile * horizon * ITEM;
+    unsigned* flag = flags + tile;
+    for (int e = tid; e < 16 * RS; e += NTHR) {
+        const int k = e % RS;
+        s.hb[0][e] = to_bf16(k < DET ? obs0[k] : 0.f);
+        s.hb[1][e] = 0;
+        s.xb[e] = 0;
+    }
+    for (int e = tid; e < 16 * HS; e += NTHR) s.h32[e] = (e % HS) < DET ? obs0[e % HS] : 0.f;
+    {
+        constexpr size_t offs[5] = {B1, BGI, BGH, B4, B5};
+#pragma unroll
+        for (int l = 0; l < 5; ++l)
+            for (int e = tid; e < bias_len(offs[l]); e += NTHR)
+                s.bs[bias_slot(offs[l]) + e] = reinterpret_cast<const float*>(Pg + offs[l])[e];
+    }
+    for (int e = tid; e < 16 * ZS; e += NTHR) {
+        const int k = e % ZS, jj = e / ZS;
+        float v = 0.f;
+        if (k < STOCH) v = obs0[DET + k];
+        else if (k >= 32 && k < 32 + ACT) v = actions[(size_t)(base + jj < n ? base + jj : n - 1) * horizon * ACT + (k - 32)];
+        s.zA[e] = to_bf16(v);
+    }
+    for (int e = tid; e < HIDB * K1K * BLK / 8; e += NTHR)
+        reinterpret_cast<v4i*>(s.w1)[e] = reinterpret_cast<const v4i*>(Pg + W1)[e];
+    for (int e = tid; e < STB * HIDK * BLK / 8; e += NTHR)
+        reinterpret_cast<v4i*>(s.w5)[e] = reinterpret_cast<const v4i*>(Pg + W5)[e];
+    // A wave's GRU work: output block w and (waves 0..4) block w + 8.  A wave without a second block goes through the same
+    // instructions on one broadcast 16-byte word per request (every lane the same address: 64 bytes instead of 1 KB
+    // through the L2 port) and drops the result -- straight-line code keeps the compiler's vmcnt bookkeeping exact.
+    const bool two = w + WAVES < DETB;
+    const int ob0 = w, ob1 = two ? w + WAVES : w;
+    int l8 = lane * 8, l8b = two ? lane * 8 : 0;
+    v4i A4[NOB][DETK];
+    v4i Hd[3][DETK], In[3][HIDK];   // the hidden-side and the input-side gate matrices (r, u, n) of the block at hand
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) request<DETK>((gptr)Pg + l8 + WGH + (size_t)(q * DETB + ob0) * DETK * BLK, Hd[q]);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    if (stamp) stamps[1] = wall_clock64();
+    int cur = 0;
+    for (int t = 0; t + 1 < horizon; ++t) {
+        const bool st = stamp && t == 5;
+        if (st) stamps[2] = wall_clock64();
+        // (the parameters do not depend on t: re-derive the pointer behind an opaque barrier every step, or the optimizer
+        // keeps what fits of them in registers across steps and spills -- see icem_rssm.hip)
+        gptr P = (gptr)Pg;
+        asm volatile("" : "+s"(P));
+        // (and the lane's offsets are recomputed every step: carried across the loop they are spilled, and a scratch
+        // reload is a vmcnt(0) wait in the middle of the weight requests)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int j = ln & 15, g = ln >> 4;
+        const int xr = j * RS + 8 * g, zr = j * ZS + 8 * g;
+        const int xo = j * RS + 4 * g, zo = j * ZS + 4 * g, ho = j * HS + 4 * g;
+        l8 = ln * 8; l8b = two ? ln * 8 : 0;
+        gptr Plane = P + l8;
+        gptr Plane1 = P + l8b;
+        // The weights are requested in the order they are needed, as far ahead as the registers allow: at the end of
+        // phase 2 those of phase 3 and the hidden side of the next step's first block; here the input side of this
+        // step's first block (W1 and W5 live in LDS).  No phase but the GRU's second block waits for the L2.
+        // ---- phase 1 (reads z_t, a_t): x = relu(W1 [z | a] + b1) ----
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) request<HIDK>(Plane + WGI + (size_t)(q * DETB + ob0) * HIDK * BLK, In[q]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NOB; ++i) {
+            if (i == 1 && !two) break;   // (uniform)
+            const int ob = w + WAVES * i;
+            v4i A1[K1K];
+            request<K1K>(s.w1 + (size_t)ob * K1K * BLK + l8, A1);
+            const v4f a = mma<K1K>(A1, s.zA + zr, bias4(s.bs, B1, ob * 16 + 4 * g));
+            *reinterpret_cast<v4s*>(s.xb + xo + ob * 16) = relu_pack(a);
+        }
+        __syncthreads();
+        if (st) stamps[3] = wall_clock64();
+        // ---- phase 2: GRU h' = (1 - u) n + u h; wave 7 publishes state t ----
+        {
+            const unsigned short* X = s.xb + xr;
+            const unsigned short* H = s.hb[cur] + xr;
+            auto gates = [&](int ob, const v4f& ir, const v4f& iu, const v4f& in, const v4f& hr, const v4f& hu, const v4f& hn) {
+                float* hp = s.h32 + ho + ob * 16;
+                float nh[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    nh[r] = gru_out(ir[r], iu[r], in[r], hr[r], hu[r], hn[r], hp[r]);
+                    hp[r] = nh[r];
+                }
+                *reinterpret_cast<v4s*>(s.hb[cur ^ 1] + xo + ob * 16) = pack4(nh[0], nh[1], nh[2], nh[3]);
+            };
+            int bi = ob0 * 16 + 4 * g;
+            v4f hr = mma<DETK>(Hd[0], H, bias4(s.bs, BGH, bi)), hu = mma<DETK>(Hd[1], H, bias4(s.bs, BGH, 16 * DETB + bi)),
+                hn = mma<DETK>(Hd[2], H, bias4(s.bs, BGH, 32 * DETB + bi));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) request<DETK>(Plane1 + WGH + (size_t)(q * DETB + ob1) * DETK * BLK, Hd[q]);
+            __builtin_amdgcn_sched_barrier(0);
+            v4f ir = mma<HIDK>(In[0], X, bias4(s.bs, BGI, bi)), iu = mma<HIDK>(In[1], X, bias4(s.bs, BGI, 16 * DETB + bi)),
+                in = mma<HIDK>(In[2], X, bias4(s.bs, BGI, 32 * DETB + bi));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) request<HIDK>(Plane1 + WGI + (size_t)(q * DETB + ob1) * HIDK * BLK, In[q]);
+            __builtin_amdgcn_sched_barrier(0);
+            gates(ob0, ir, iu, in, hr, hu, hn);
+            if (w == WAVES - 1) publish(s, cur, items + (size_t)t * ITEM, flag, (unsigned)t + 1u, ln);
+            bi = ob1 * 16 + 4 * g;
+            hr = mma<DETK>(Hd[0], H, bias4(s.bs, BGH, bi)); hu = mma<DETK>(Hd[1], H, bias4(s.bs, BGH, 16 * DETB + bi));
+            hn = mma<DETK>(Hd[2], H, bias4(s.bs, BGH, 32 * DETB + bi));
+            ir = mma<HIDK>(In[0], X, bias4(s.bs, BGI, bi)); iu = mma<HIDK>(In[1], X, bias4(s.bs, BGI, 16 * DETB + bi));
+            in = mma<HIDK>(In[2], X, bias4(s.bs, BGI, 32 * DETB + bi));
+            if (two) gates(ob1, ir, iu, in, hr, hu, hn);
+            __builtin_amdgcn_sched_barrier(0);
+            // what phase 3 and the next step's first hidden-side MFMAs will read
+            req_own<DETK>(Plane, W4, w, A4);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) request<DETK>(Plane + WGH + (size_t)(q * DETB + ob0) * DETK * BLK, Hd[q]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        if (st) stamps[4] = wall_clock64();
+        // ---- phase 3: p = relu(W4 h' + b4) ----
+        fin_dense<DETK, 1>(s.bs, B4, A4, s.hb[cur ^ 1] + xr, 16 * RS, s.xb + xo, w, g);
+        __syncthreads();
+        if (st) stamps[5] = wall_clock64();
+        // ---- phase 4: z' = W5 p + b5 (waves 0, 1) and the next action (wave 2) -> [z | a] ----
+        if (w < STB) {
+            v4i A5[HIDK];
+            request<HIDK>(s.w5 + (size_t)w * HIDK * BLK + l8, A5);
+            const v4f b5 = bias4(s.bs, B5, w * 16 + 4 * g);
+            const v4f a = mma<HIDK>(A5, s.xb + xr, b5);
+            *reinterpret_cast<v4s*>(s.zA + zo + w * 16) = pack4(a[0], a[1], a[2], a[3]);
+        } else if (w == STB) {
+            if (g < 2) {   // lanes (j, 0): a[0..3]; lanes (j, 1): a[4], a[5], 0, 0
+                const int rr = base + j;
+                const float* an = actions + ((size_t)(rr < n ? rr : n - 1) * horizon + (t + 1)) * ACT;
+                const float a0 = an[4 * g], a1 = an[4 * g + 1];
+                const float a2 = g == 0 ? an[2] : 0.f, a3 = g == 0 ? an[3] : 0.f;
+                *reinterpret_cast<v4s*>(s.zA + j * ZS + 32 + 4 * g) = pack4(a0, a1, a2, a3);
+            }
+        }
+        __syncthreads();
+        if (st) stamps[6] = wall_clock64();
+        cur ^= 1;
+    }
+    // the state the last step starts from
+    if (stamp) stamps[7] = wall_clock64();
+    if (w == WAVES - 1) publish(s, cur, items + (size_t)(horizon - 1) * ITEM, flag, (unsigned)horizon, lane);
+}
+
+__device__ __forceinline__ void reward_head(ConsumerLds& s, int tile, int n, int horizon, int cost_mode,
+                                            const unsigned short* __restrict__ Pg, float* __restrict__ costs,
+                                            const unsigned short* stage, unsigned* flags, long long* stamps) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const bool stamp = stamps && tile == 0 && tid == 0;
+    if (stamp) stamps[8] = wall_clock64();
+    const unsigned short* items = stage + (size_t)tile * horizon * ITEM;
+    unsigned* flag = flags + tile;
+    gptr Plane = (gptr)Pg + lane * 8;
+    // the head's weights and biases, once
+    v4i A6[NOB][K6K], A7[NOB][HIDK], A8[HIDK];
+    v4f b6[NOB], b7[NOB];
+#pragma unroll
+    for (int i = 0; i < NOB; ++i) {
+        const int ob = own_block(w, i);
+        request<K6K>(Plane + W6 + (size_t)ob * K6K * BLK, A6[i]);
+        request<HIDK>(Plane + W7 + (size_t)ob * HIDK * BLK, A7[i]);
+        b6[i] = *reinterpret_cast<const v4f*>(reinterpret_cast<const float*>(Pg + B6) + ob * 16 + 4 * g);
+        b7[i] = *reinterpret_cast<const v4f*>(reinterpret_cast<const float*>(Pg + B7) + ob * 16 + 4 * g);
+    }
+    request<HIDK>(Plane + W8, A8);
+    const v4f b8 = *reinterpret_cast<const v4f*>(reinterpret_cast<const float*>(Pg + B8) + 4 * g);
+    for (int e = tid; e < 2 * 16 * RS; e += NTHR) { (&s.r1[0][0])[e] = 0; (&s.r2[0][0])[e] = 0; }   // the K padding of the rows
+    __syncthreads();
+    const int xr = j * RS + 8 * g, xo = j * RS + 4 * g;
+    float acc_cost = 0.f;
+    bool gave_up = false;
+    if (stamp) stamps[9] = wall_clock64();
+    for (int t = 0; t < horizon; ++t) {
+        const int par = t & 1;
+        if (!gave_up) {
+            unsigned polls = 0;
+            while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)(t + 1)) < 0) {
+                if (++polls > MAX_POLLS) { gave_up = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        asm volatile("" ::: "memory");
+        if (stamp && t == 5) stamps[10] = wall_clock64();
+        if (stamp && t == horizon - 1) stamps[12] = wall_clock64();
+        const unsigned short* it = items + (size_t)t * ITEM + j * SR + 8 * g;
+        v4i X[K6K];
+#pragma unroll
+        for (int kb = 0; kb < K6K; ++kb) {
+            const unsigned long long lo = load_ag(it + kb * 32), hi = load_ag(it + kb * 32 + 4);
+            X[kb][0] = (int)(unsigned)lo; X[kb][1] = (int)(unsigned)(lo >> 32);
+            X[kb][2] = (int)(unsigned)hi; X[kb][3] = (int)(unsigned)(hi >> 32);
+        }
+#pragma unroll
+        for (int i = 0; i < NOB; ++i) {
+            v4f a = b6[i];
+#pragma unroll
+            for (int kb = 0; kb < K6K; ++kb)
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, A6[i][kb]), __builtin_bit_cast(v8bf, X[kb]), a, 0, 0, 0);
+            if (w + WAVES * i < 13) *reinterpret_cast<v4s*>(s.r1[par] + xo + own_block(w, i) * 16) = relu_pack(a);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NOB; ++i) {
+            const v4f a = mma<HIDK>(A7[i], s.r1[par] + xr, b7[i]);
+            if (w + WAVES * i < 13) *reinterpret_cast<v4s*>(s.r2[par] + xo + own_block(w, i) * 16) = relu_pack(a);
+        }
+        __syncthreads();
+        if (w == WAVES - 1) {
+            const v4f a = mma<HIDK>(A8, s.r2[par] + xr, b8);
+            const float c = -a[0];   // output 0 of trajectory j lives in lane (j, g = 0), register 0
+            if (t == 0 || cost_mode == 2) acc_cost = c;
+            else if (cost_mode == 0) acc_cost += c;
+            else acc_cost = (c < acc_cost || c != c) ? c : acc_cost;
+        }
+        if (stamp && t == 5) stamps[11] = wall_clock64();
+    }
+    if (stamp) stamps[13] = wall_clock64();
+    if (tid == 0) __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    if (w == WAVES - 1 && g == 0 && tile * 16 + j < n)
+        costs[tile * 16 + j] = gave_up ? __builtin_nanf("") : acc_cost;
+}
+
+__global__ __launch_bounds__(NTHR) void rssm_split_kernel(int n, int horizon, int cost_mode, const unsigned short* __restrict__ Pg,
+                                                         const float* __restrict__ obs0, const float* __restrict__ actions,
+                                                         float* __restrict__ costs, unsigned short* stage, unsigned* flags, int tiles,
+                                                         long long* stamps) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    const int b = blockIdx.x;
+    if (b < tiles) recurrence(*reinterpret_cast<ProducerLds*>(smem), b, n, horizon, Pg, obs0, actions, stage, flags, stamps);
+    else reward_head(*reinterpret_cast<ConsumerLds*>(smem), b - tiles, n, horizon, cost_mode, Pg, costs, stage, flags, stamps);
+}
+
+// One staging area per (device, stream): launches on a stream are ordered, so they may share it.
+struct Staging {
+    unsigned short* stage = nullptr;
+    unsigned* flags = nullptr;
+    size_t items = 0;
+};
+std::mutex g_mu;
+long long* g_stamps = nullptr;
+std::map<std::pair<int, hipStream_t>, Staging> g_staging;
+}  // namespace
+
+void rssm_set_stamps(long long* dev_ptr) { g_stamps = dev_ptr; }
+
+bool rssm_split_ok(int n, int horizon) {
+    static const bool on = [] { const char* e = std::getenv("ICEM_RSSM_SPLIT"); return !(e && e[0] == '0'); }();
+    return on && n > 0 && horizon >= 1 && (n + 15) / 16 <= rssm::SPLIT_MAX_TILES;
+}
+
+hipError_t launch_rssm_split(int n, int horizon, int cost_mode, const unsigned short* params, const float* obs0,
+                             const float* actions, float* costs, hipStream_t st) {
+    const int tiles = (n + 15) / 16;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    Staging sg;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        Staging& s = g_staging[{dev, st}];
+        const size_t want = (size_t)rssm::SPLIT_MAX_TILES * horizon;
+        if (s.items < want) {   // (first call on this stream, or a longer horizon: not inside a capture)
+            if (s.stage) {
+                if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+                (void)hipFree(s.stage);
+                s.stage = nullptr; s.items = 0;
+            }
+            if ((e = hipMalloc(&s.stage, want * ITEM * sizeof(unsigned short))) != hipSuccess) return e;
+            if ((e = hipMemset(s.stage, 0, want * ITEM * sizeof(unsigned short))) != hipSuccess) return e;   // K padding stays zero
+            s.items = want;
+        }
+        if (!s.flags) {
+            if ((e = hipMalloc(&s.flags, rssm::SPLIT_MAX_TILES * sizeof(unsigned))) != hipSuccess) return e;
+            if ((e = hipMemset(s.flags, 0, rssm::SPLIT_MAX_TILES * sizeof(unsigned))) != hipSuccess) return e;
+        }
+        sg = s;
+    }
+    hipLaunchKernelGGL(rssm_split_kernel, dim3(2 * tiles), dim3(NTHR), 0, st, n, horizon, cost_mode, params, obs0, actions, costs,
+                       sg.stage, sg.flags, tiles, g_stamps);
+    return hipGetLastError();
+}
+}  // namespace icem

@@ -396,7 +396,8 @@ enum {
  * SAMPLE/ROLLOUT/SAMPLE_ROLLOUT, keys for the top-k kernels), and clears the log. */
 int icem_profile_enable(icem_handle* h, int32_t on);
 /* Development aid: [grid, 8] int64 device buffer a kernel under study may fill with per-workgroup phase
- * cycle stamps (NULL disables; no production kernel writes it). */
+ * cycle stamps (NULL disables; no production kernel writes it).  h = NULL addresses the stateless
+ * icem_rssm_rollout_cost instead: 16 int64 of wall_clock64 stamps of tile 0 (icem_rssm_split.hip). */
 int icem_debug_stamps(icem_handle* h, void* dev_ptr);
 int icem_profile_read(icem_handle* h, double* total_ms, int64_t* launches, int64_t* units);
 

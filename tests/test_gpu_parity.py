@@ -1421,13 +1421,14 @@ def test_get_action_host_call_equals_plan_step(dtype):
 
 
 @pytest.mark.parametrize("mode,n,h", [("sum", 1007, 12), ("best", 1007, 12), ("final", 1007, 12), ("sum", 8200 + 5, 12),
-                                      ("best", 16384 + 21, 12), ("sum", 1, 12), ("final", 17, 1), ("sum", 33, 30)])
+                                      ("best", 16384 + 21, 12), ("sum", 1, 12), ("final", 17, 1), ("sum", 33, 30),
+                                      ("sum", 2048, 12), ("best", 2049 + 30, 12)])
 def test_fused_rssm_rollout_kernel(mode, n, h):
     """icem_rssm_rollout_cost (the declared RSSM's whole rollout + reward head in one launch, bf16 MFMA with f32
     accumulation and f32 recurrent state) against (a) a float64 NumPy rollout of the same network with the weights and
     the GEMM inputs rounded to bf16 exactly where the kernel rounds them -- tight; (b) the plain float64 network --
     bf16 accuracy.  Ragged n (not a multiple of the 16-trajectory tile, a single trajectory), horizons 1 / 12 / 30;
-    n >= 8192 runs two tiles per workgroup."""
+    n <= 2048 runs the split launch of icem_rssm_split.hip, n >= 8192 two tiles per workgroup."""
     from icem_amd import DeviceRSSMModel
     m = DeviceRSSMModel(seed=3)
     d = 6
@@ -1470,6 +1471,26 @@ def test_fused_rssm_rollout_kernel(mode, n, h):
     assert np.abs(got - exact).max() <= 5e-2 * scale
     if n > 1 and exact.std() > 1e-2 * scale:   # ('best' can pick the shared first step for every trajectory: a constant)
         assert np.corrcoef(got, exact)[0, 1] > 0.99
+
+
+def test_split_rssm_launch_equals_the_fused_kernel(tmp_path):
+    """Populations up to 2 048 take icem_rssm_split.hip (recurrence workgroups + reward-head workgroups exchanging the
+    states through global memory, weights of the head resident in registers); ICEM_RSSM_SPLIT=0 keeps them on the
+    fused kernel.  Same arithmetic, same rounding points: the costs must be bit-identical -- ragged tiles, horizons
+    1 / 2 / 5 / 12 / 30, all three cost modes, the 128-tile limit, and every case three times in a row (the tile flags
+    must be back at zero behind every launch)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "dbg", "rssm_split_check.py")
+    f = str(tmp_path / "fused.npz")
+    env = dict(os.environ, ICEM_RSSM_SPLIT="0")
+    a = subprocess.run([sys.executable, tool, "write", f], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert a.returncode == 0, a.stdout + a.stderr
+    env.pop("ICEM_RSSM_SPLIT")
+    b = subprocess.run([sys.executable, tool, "check", f], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert b.returncode == 0 and "0 differ" in b.stdout, b.stdout + b.stderr
 
 
 def test_config5_fused_rssm_behind_controller():
