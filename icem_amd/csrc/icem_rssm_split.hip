@@ -33,8 +33,9 @@ struct ProducerLds {
     unsigned short xb[16 * RS];
     float h32[16 * HS];
     float bs[NBIAS];
-    unsigned short w1[HIDB * K1K * BLK];   // the two small layers' A-operand blocks, resident: no L2 round trip in phases 1 and 4
+    unsigned short w1[HIDB * K1K * BLK];   // A-operand blocks that stay here: W1, W5 and W4's 13th output block
     unsigned short w5[STB * HIDK * BLK];
+    unsigned short w4x[DETK * BLK];
 };
 struct ConsumerLds {
     unsigned short r1[2][16 * RS];
@@ -67,12 +68,167 @@ __device__ __forceinline__ void publish(const ProducerLds& s, int cur, unsigned 
     if (lane == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The model steps of the recurrence for one CLASS of waves.  The 0.65 MB of weights a step reads are cut into CHUNKS
+// (one output block of one matrix: 7 A-operand blocks = 28 registers per lane, 7 KB per wave) and every chunk has an owner:
+//   class A, waves 0..4:  the GRU's output blocks w and w + 8         12 chunks: H(w) r u n, I(w) r u n, H(w+8) .., I(w+8) ..
+//   class B, waves 5..7:  the GRU's block w and W4's blocks 4 (w - 5) .. + 3    10 chunks: H(w) r u n, I(w) r u n, 4 x W4
+// (H = hidden side, needs h_t only: phase 1; I = input side, needs x: phase 2; W4: phase 3).  W1, W5 and W4's 13th
+// block live in LDS.  A wave consumes its chunks in that order, every step.  The first RES of them stay in registers
+// for the whole rollout; the others go through a ring of RING register slots, chunk c + RING requested right behind the
+// MFMAs of chunk c.  The two classes are two instances of this function behind one wave-uniform branch: inside each
+// the code is straight-line, so the compiler's in-order vmcnt bookkeeping is exact (a wave only ever waits for the
+// chunk it is about to use), and nobody issues a load it does not need (a "dummy" broadcast load costs the L1 more
+// than a real one: measured).
+template <bool CLASS_A>
+__device__ __forceinline__ void recurrence_steps(ProducerLds& s, int w, int lane, int base, int n, int horizon,
+                                                 const unsigned short* __restrict__ Pg, const float* __restrict__ actions,
+                                                 unsigned short* items, unsigned* flag, long long* stamps, bool stamp) {
+    constexpr int NCH = CLASS_A ? 12 : 10;
+    constexpr int RES = CLASS_A ? 3 : 4;
+    constexpr int RING = CLASS_A ? 3 : 2;
+    static_assert((NCH - RES) % RING == 0, "a chunk's slot must not depend on the step");
+    const int ob0 = w, ob1 = w + WAVES, wb = 4 * (w - 5);
+    v4i slot[RES + RING][DETK];
+    auto chunk = [&](gptr P, int c, int l8) -> gptr {   // (c is a constant after unrolling)
+        if (c < 3) return P + WGH + (size_t)(c * DETB + ob0) * DETK * BLK + l8;
+        if (c < 6) return P + WGI + (size_t)((c - 3) * DETB + ob0) * HIDK * BLK + l8;
+        if (CLASS_A) return c < 9 ? P + WGH + (size_t)((c - 6) * DETB + ob1) * DETK * BLK + l8
+                                  : P + WGI + (size_t)((c - 9) * DETB + ob1) * HIDK * BLK + l8;
+        return P + W4 + (size_t)(wb + c - 6) * DETK * BLK + l8;
+    };
+    constexpr auto slot_of = [](int c) { return c < RES ? c : RES + (c - RES) % RING; };
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < RES + RING; ++c) request<DETK>(chunk((gptr)Pg, c, lane * 8), slot[c]);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    if (stamp) stamps[1] = wall_clock64();
+    int cur = 0;
+    for (int t = 0; t + 1 < horizon; ++t) {
+        const bool st = stamp && t == 5;
+        if (st) stamps[2] = wall_clock64();
+        // (the parameters do not depend on t: re-derive the pointer behind an opaque barrier every step, or the optimizer
+        // keeps what fits of them in registers across steps and spills -- see icem_rssm.hip)
+        gptr P = (gptr)Pg;
+        asm volatile("" : "+s"(P));
+        // (and the lane's offsets are recomputed every step: carried across the loop they are spilled, and a scratch
+        // reload is a vmcnt(0) wait in the middle of the weight requests)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int j = ln & 15, g = ln >> 4, l8 = ln * 8;
+        const int xr = j * RS + 8 * g, zr = j * ZS + 8 * g;
+        const int xo = j * RS + 4 * g, zo = j * ZS + 4 * g, ho = j * HS + 4 * g;
+        const unsigned short* X = s.xb + xr;
+        const unsigned short* H = s.hb[cur] + xr;
+        // the next action of the tile's trajectories (every wave asks, wave 2 stores: a load inside a branch would cost
+        // the waves behind the branch their exact vmcnt)
+        float an0, an1, an2, an3;
+        {
+            const int rr = base + j;
+            const float* an = actions + ((size_t)(rr < n ? rr : n - 1) * horizon + (t + 1)) * ACT;
+            const int o = g & 1 ? 4 : 0;
+            an0 = an[o]; an1 = an[o + 1]; an2 = an[g & 1 ? 5 : 2]; an3 = an[g & 1 ? 5 : 3];
+        }
+        // chunk c through the matrix pipe; if it is a streamed one, the request that refills its slot
+        auto use = [&](int c, const unsigned short* B, v4f bias) -> v4f {
+            const v4f a = mma<DETK>(slot[slot_of(c)], B, bias);
+            if (c >= RES) {
+                int nx = c + RING;
+                if (nx >= NCH) nx = RES + (nx - NCH);
+                __builtin_amdgcn_sched_barrier(0);
+                request<DETK>(chunk(P, nx, l8), slot[slot_of(c)]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return a;
+        };
+        auto gates = [&](int ob, const v4f& ir, const v4f& iu, const v4f& in, const v4f& hr, const v4f& hu, const v4f& hn) {
+            float* hp = s.h32 + ho + ob * 16;
+            float nh[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                nh[r] = gru_out(ir[r], iu[r], in[r], hr[r], hu[r], hn[r], hp[r]);
+                hp[r] = nh[r];
+            }
+            *reinterpret_cast<v4s*>(s.hb[cur ^ 1] + xo + ob * 16) = pack4(nh[0], nh[1], nh[2], nh[3]);
+        };
+        // ---- phase 1 (reads z_t, a_t, h_t): x = relu(W1 [z | a] + b1); the hidden side of the wave's first GRU block ----
+#pragma unroll
+        for (int i = 0; i < (CLASS_A ? 2 : 1); ++i) {
+            const int ob = w + WAVES * i;
+            v4i A1[K1K];
+            request<K1K>(s.w1 + (size_t)ob * K1K * BLK + l8, A1);
+            const v4f a = mma<K1K>(A1, s.zA + zr, bias4(s.bs, B1, ob * 16 + 4 * g));
+            *reinterpret_cast<v4s*>(s.xb + xo + ob * 16) = relu_pack(a);
+        }
+        int bi = ob0 * 16 + 4 * g;
+        v4f hr = use(0, H, bias4(s.bs, BGH, bi));
+        v4f hu = use(1, H, bias4(s.bs, BGH, 16 * DETB + bi));
+        v4f hn = use(2, H, bias4(s.bs, BGH, 32 * DETB + bi));
+        __syncthreads();
+        if (st) stamps[3] = wall_clock64();
+        // ---- phase 2: GRU h' = (1 - u) n + u h; wave 7 publishes state t ----
+        {
+            v4f ir = use(3, X, bias4(s.bs, BGI, bi));
+            v4f iu = use(4, X, bias4(s.bs, BGI, 16 * DETB + bi));
+            v4f in = use(5, X, bias4(s.bs, BGI, 32 * DETB + bi));
+            gates(ob0, ir, iu, in, hr, hu, hn);
+            if (CLASS_A) {
+                bi = ob1 * 16 + 4 * g;
+                hr = use(6, H, bias4(s.bs, BGH, bi));
+                hu = use(7, H, bias4(s.bs, BGH, 16 * DETB + bi));
+                hn = use(8, H, bias4(s.bs, BGH, 32 * DETB + bi));
+                ir = use(9, X, bias4(s.bs, BGI, bi));
+                iu = use(10, X, bias4(s.bs, BGI, 16 * DETB + bi));
+                in = use(11, X, bias4(s.bs, BGI, 32 * DETB + bi));
+                gates(ob1, ir, iu, in, hr, hu, hn);
+            } else if (w == WAVES - 1) {
+                publish(s, cur, items + (size_t)t * ITEM, flag, (unsigned)t + 1u, ln);
+            }
+        }
+        __syncthreads();
+        if (st) stamps[4] = wall_clock64();
+        // ---- phase 3 (class B): p = relu(W4 h' + b4) ----
+        if (!CLASS_A) {
+            const unsigned short* Hn = s.hb[cur ^ 1] + xr;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const v4f p = use(6 + q, Hn, bias4(s.bs, B4, (wb + q) * 16 + 4 * g));
+                *reinterpret_cast<v4s*>(s.xb + xo + (wb + q) * 16) = relu_pack(p);
+            }
+            if (w == 5) {   // the 13th block, from LDS
+                v4i A4[DETK];
+                request<DETK>(s.w4x + l8, A4);
+                const v4f p = mma<DETK>(A4, Hn, bias4(s.bs, B4, 12 * 16 + 4 * g));
+                *reinterpret_cast<v4s*>(s.xb + xo + 12 * 16) = relu_pack(p);
+            }
+        }
+        __syncthreads();
+        if (st) stamps[5] = wall_clock64();
+        // ---- phase 4: z' = W5 p + b5 (waves 0, 1, from LDS) and the next action (wave 2) -> [z | a] ----
+        if (CLASS_A) {
+            if (w < STB) {
+                v4i A5[HIDK];
+                request<HIDK>(s.w5 + (size_t)w * HIDK * BLK + l8, A5);
+                const v4f a = mma<HIDK>(A5, s.xb + xr, bias4(s.bs, B5, w * 16 + 4 * g));
+                *reinterpret_cast<v4s*>(s.zA + zo + w * 16) = pack4(a[0], a[1], a[2], a[3]);
+            } else if (w == STB && g < 2) {   // lanes (j, 0): a[0..3]; lanes (j, 1): a[4], a[5], 0, 0
+                *reinterpret_cast<v4s*>(s.zA + j * ZS + 32 + 4 * g) = pack4(an0, an1, g == 0 ? an2 : 0.f, g == 0 ? an3 : 0.f);
+            }
+        }
+        __syncthreads();
+        if (st) stamps[6] = wall_clock64();
+        cur ^= 1;
+    }
+    if (stamp) stamps[7] = wall_clock64();
+    // the state the last step starts from
+    if (w == WAVES - 1) publish(s, cur, items + (size_t)(horizon - 1) * ITEM, flag, (unsigned)horizon, lane);
+}
+
 __device__ __forceinline__ void recurrence(ProducerLds& s, int tile, int n, int horizon, const unsigned short* __restrict__ Pg,
                                            const float* __restrict__ obs0, const float* __restrict__ actions,
                                            unsigned short* stage, unsigned* flags, long long* stamps) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 15, g = lane >> 4;
     const int base = tile * 16;
     const bool stamp = stamps && tile == 0 && tid == 0;   // development aid (icem_debug_stamps(NULL, buffer))
     if (stamp) stamps[0] = wall_clock64();
@@ -103,128 +259,10 @@ __device__ __forceinline__ void recurrence(ProducerLds& s, int tile, int n, int 
         reinterpret_cast<v4i*>(s.w1)[e] = reinterpret_cast<const v4i*>(Pg + W1)[e];
     for (int e = tid; e < STB * HIDK * BLK / 8; e += NTHR)
         reinterpret_cast<v4i*>(s.w5)[e] = reinterpret_cast<const v4i*>(Pg + W5)[e];
-    // A wave's GRU work: output block w and (waves 0..4) block w + 8.  A wave without a second block goes through the same
-    // instructions on one broadcast 16-byte word per request (every lane the same address: 64 bytes instead of 1 KB
-    // through the L2 port) and drops the result -- straight-line code keeps the compiler's vmcnt bookkeeping exact.
-    const bool two = w + WAVES < DETB;
-    const int ob0 = w, ob1 = two ? w + WAVES : w;
-    int l8 = lane * 8, l8b = two ? lane * 8 : 0;
-    v4i A4[NOB][DETK];
-    v4i Hd[3][DETK], In[3][HIDK];   // the hidden-side and the input-side gate matrices (r, u, n) of the block at hand
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) request<DETK>((gptr)Pg + l8 + WGH + (size_t)(q * DETB + ob0) * DETK * BLK, Hd[q]);
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    if (stamp) stamps[1] = wall_clock64();
-    int cur = 0;
-    for (int t = 0; t + 1 < horizon; ++t) {
-        const bool st = stamp && t == 5;
-        if (st) stamps[2] = wall_clock64();
-        // (the parameters do not depend on t: re-derive the pointer behind an opaque barrier every step, or the optimizer
-        // keeps what fits of them in registers across steps and spills -- see icem_rssm.hip)
-        gptr P = (gptr)Pg;
-        asm volatile("" : "+s"(P));
-        // (and the lane's offsets are recomputed every step: carried across the loop they are spilled, and a scratch
-        // reload is a vmcnt(0) wait in the middle of the weight requests)
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        const int j = ln & 15, g = ln >> 4;
-        const int xr = j * RS + 8 * g, zr = j * ZS + 8 * g;
-        const int xo = j * RS + 4 * g, zo = j * ZS + 4 * g, ho = j * HS + 4 * g;
-        l8 = ln * 8; l8b = two ? ln * 8 : 0;
-        gptr Plane = P + l8;
-        gptr Plane1 = P + l8b;
-        // The weights are requested in the order they are needed, as far ahead as the registers allow: at the end of
-        // phase 2 those of phase 3 and the hidden side of the next step's first block; here the input side of this
-        // step's first block (W1 and W5 live in LDS).  No phase but the GRU's second block waits for the L2.
-        // ---- phase 1 (reads z_t, a_t): x = relu(W1 [z | a] + b1) ----
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) request<HIDK>(Plane + WGI + (size_t)(q * DETB + ob0) * HIDK * BLK, In[q]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < NOB; ++i) {
-            if (i == 1 && !two) break;   // (uniform)
-            const int ob = w + WAVES * i;
-            v4i A1[K1K];
-            request<K1K>(s.w1 + (size_t)ob * K1K * BLK + l8, A1);
-            const v4f a = mma<K1K>(A1, s.zA + zr, bias4(s.bs, B1, ob * 16 + 4 * g));
-            *reinterpret_cast<v4s*>(s.xb + xo + ob * 16) = relu_pack(a);
-        }
-        __syncthreads();
-        if (st) stamps[3] = wall_clock64();
-        // ---- phase 2: GRU h' = (1 - u) n + u h; wave 7 publishes state t ----
-        {
-            const unsigned short* X = s.xb + xr;
-            const unsigned short* H = s.hb[cur] + xr;
-            auto gates = [&](int ob, const v4f& ir, const v4f& iu, const v4f& in, const v4f& hr, const v4f& hu, const v4f& hn) {
-                float* hp = s.h32 + ho + ob * 16;
-                float nh[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    nh[r] = gru_out(ir[r], iu[r], in[r], hr[r], hu[r], hn[r], hp[r]);
-                    hp[r] = nh[r];
-                }
-                *reinterpret_cast<v4s*>(s.hb[cur ^ 1] + xo + ob * 16) = pack4(nh[0], nh[1], nh[2], nh[3]);
-            };
-            int bi = ob0 * 16 + 4 * g;
-            v4f hr = mma<DETK>(Hd[0], H, bias4(s.bs, BGH, bi)), hu = mma<DETK>(Hd[1], H, bias4(s.bs, BGH, 16 * DETB + bi)),
-                hn = mma<DETK>(Hd[2], H, bias4(s.bs, BGH, 32 * DETB + bi));
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) request<DETK>(Plane1 + WGH + (size_t)(q * DETB + ob1) * DETK * BLK, Hd[q]);
-            __builtin_amdgcn_sched_barrier(0);
-            v4f ir = mma<HIDK>(In[0], X, bias4(s.bs, BGI, bi)), iu = mma<HIDK>(In[1], X, bias4(s.bs, BGI, 16 * DETB + bi)),
-                in = mma<HIDK>(In[2], X, bias4(s.bs, BGI, 32 * DETB + bi));
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) request<HIDK>(Plane1 + WGI + (size_t)(q * DETB + ob1) * HIDK * BLK, In[q]);
-            __builtin_amdgcn_sched_barrier(0);
-            gates(ob0, ir, iu, in, hr, hu, hn);
-            if (w == WAVES - 1) publish(s, cur, items + (size_t)t * ITEM, flag, (unsigned)t + 1u, ln);
-            bi = ob1 * 16 + 4 * g;
-            hr = mma<DETK>(Hd[0], H, bias4(s.bs, BGH, bi)); hu = mma<DETK>(Hd[1], H, bias4(s.bs, BGH, 16 * DETB + bi));
-            hn = mma<DETK>(Hd[2], H, bias4(s.bs, BGH, 32 * DETB + bi));
-            ir = mma<HIDK>(In[0], X, bias4(s.bs, BGI, bi)); iu = mma<HIDK>(In[1], X, bias4(s.bs, BGI, 16 * DETB + bi));
-            in = mma<HIDK>(In[2], X, bias4(s.bs, BGI, 32 * DETB + bi));
-            if (two) gates(ob1, ir, iu, in, hr, hu, hn);
-            __builtin_amdgcn_sched_barrier(0);
-            // what phase 3 and the next step's first hidden-side MFMAs will read
-            req_own<DETK>(Plane, W4, w, A4);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) request<DETK>(Plane + WGH + (size_t)(q * DETB + ob0) * DETK * BLK, Hd[q]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();
-        if (st) stamps[4] = wall_clock64();
-        // ---- phase 3: p = relu(W4 h' + b4) ----
-        fin_dense<DETK, 1>(s.bs, B4, A4, s.hb[cur ^ 1] + xr, 16 * RS, s.xb + xo, w, g);
-        __syncthreads();
-        if (st) stamps[5] = wall_clock64();
-        // ---- phase 4: z' = W5 p + b5 (waves 0, 1) and the next action (wave 2) -> [z | a] ----
-        if (w < STB) {
-            v4i A5[HIDK];
-            request<HIDK>(s.w5 + (size_t)w * HIDK * BLK + l8, A5);
-            const v4f b5 = bias4(s.bs, B5, w * 16 + 4 * g);
-            const v4f a = mma<HIDK>(A5, s.xb + xr, b5);
-            *reinterpret_cast<v4s*>(s.zA + zo + w * 16) = pack4(a[0], a[1], a[2], a[3]);
-        } else if (w == STB) {
-            if (g < 2) {   // lanes (j, 0): a[0..3]; lanes (j, 1): a[4], a[5], 0, 0
-                const int rr = base + j;
-                const float* an = actions + ((size_t)(rr < n ? rr : n - 1) * horizon + (t + 1)) * ACT;
-                const float a0 = an[4 * g], a1 = an[4 * g + 1];
-                const float a2 = g == 0 ? an[2] : 0.f, a3 = g == 0 ? an[3] : 0.f;
-                *reinterpret_cast<v4s*>(s.zA + j * ZS + 32 + 4 * g) = pack4(a0, a1, a2, a3);
-            }
-        }
-        __syncthreads();
-        if (st) stamps[6] = wall_clock64();
-        cur ^= 1;
-    }
-    // the state the last step starts from
-    if (stamp) stamps[7] = wall_clock64();
-    if (w == WAVES - 1) publish(s, cur, items + (size_t)(horizon - 1) * ITEM, flag, (unsigned)horizon, lane);
+    for (int e = tid; e < DETK * BLK / 8; e += NTHR)
+        reinterpret_cast<v4i*>(s.w4x)[e] = reinterpret_cast<const v4i*>(Pg + W4 + (size_t)12 * DETK * BLK)[e];
+    if (w < 5) recurrence_steps<true>(s, w, lane, base, n, horizon, Pg, actions, items, flag, stamps, stamp);
+    else recurrence_steps<false>(s, w, lane, base, n, horizon, Pg, actions, items, flag, stamps, stamp);
 }
 
 __device__ __forceinline__ void reward_head(ConsumerLds& s, int tile, int n, int horizon, int cost_mode,
