@@ -424,11 +424,15 @@ def measure_c5(w, steps, warmup, cpu=True):
     torch.cuda.synchronize()
     model.rollout_cost = orig
     ms = sum(e0.elapsed_time(e1) for e0, e1, _ in spans)
-    macs = sum(p.numel() for _, p in model.reference.named_parameters() if p.ndim == 2)
+    # algorithmic work of a trajectory: the reward head on the h states its steps start from, the transition h - 1 times
+    # (the state behind the last step is never scored; the split launch does not compute it)
+    mac_rew = sum(p.numel() for k, p in model.reference.named_parameters() if p.ndim == 2 and k.startswith("rew"))
+    mac_tr = sum(p.numel() for k, p in model.reference.named_parameters() if p.ndim == 2 and not k.startswith("rew"))
+    macs = (w["h"] * mac_rew + (w["h"] - 1) * mac_tr) / w["h"]
     flops = 2.0 * macs * w["h"] * sum(n for _, _, n in spans)
     achieved = flops / (ms * 1e-3) / 1e12
     roofline = {"bound": "mfma", "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0, "traffic": None,
-                "kernel": "rssm_rollout_kernel", "avg_launch_us": 1e3 * ms / len(spans), "launches": len(spans),
+                "kernel": "rssm_split_kernel" if max(n for _, _, n in spans) <= 2048 else "rssm_rollout_kernel", "avg_launch_us": 1e3 * ms / len(spans), "launches": len(spans),
                 "algorithmic_flops_per_traj_step": 2.0 * macs, "dtype": "bf16 operands, f32 accumulation"}
     out = {"metric": "traj-steps/sec (N x h), iCEM inner planning loop", "value": ts * steps / elapsed, "unit": "traj-steps/s",
            "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,

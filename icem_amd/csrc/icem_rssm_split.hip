@@ -25,6 +25,10 @@ using namespace rssm_dev;
 
 constexpr int SR = 256;              // bf16 row of an item: [h: 7 k-blocks (200 + zero padding) | z: 1 k-block]
 constexpr int ITEM = 16 * SR;        // elements
+#ifndef RSSM_W4_ALL
+#define RSSM_W4_ALL 1
+#endif
+constexpr bool W4ALL = RSSM_W4_ALL;   // W4's 13 blocks over all 8 waves (1) or over the three class-B waves + LDS (0)
 constexpr unsigned MAX_POLLS = 1u << 22;   // x s_sleep(2): a few hundred ms, then the reward workgroup gives up (costs = NaN)
 
 struct ProducerLds {
@@ -36,6 +40,7 @@ struct ProducerLds {
     unsigned short w1[HIDB * K1K * BLK];   // A-operand blocks that stay here: W1, W5 and W4's 13th output block
     unsigned short w5[STB * HIDK * BLK];
     unsigned short w4x[DETK * BLK];
+    float ob[232];                         // obs0, parked once
 };
 struct ConsumerLds {
     unsigned short r1[2][16 * RS];
@@ -79,24 +84,26 @@ __device__ __forceinline__ void publish(const ProducerLds& s, int cur, unsigned 
 // the code is straight-line, so the compiler's in-order vmcnt bookkeeping is exact (a wave only ever waits for the
 // chunk it is about to use), and nobody issues a load it does not need (a "dummy" broadcast load costs the L1 more
 // than a real one: measured).
-template <bool CLASS_A>
+template <bool CLASS_A, bool W4_ALL>
 __device__ __forceinline__ void recurrence_steps(ProducerLds& s, int w, int lane, int base, int n, int horizon,
                                                  const unsigned short* __restrict__ Pg, const float* __restrict__ actions,
                                                  unsigned short* items, unsigned* flag, long long* stamps, bool stamp) {
-    constexpr int NCH = CLASS_A ? 12 : 10;
-    constexpr int RES = CLASS_A ? 3 : 4;
-    constexpr int RING = CLASS_A ? 3 : 2;
-    static_assert((NCH - RES) % RING == 0, "a chunk's slot must not depend on the step");
+    constexpr int NCH = W4_ALL ? (CLASS_A ? 14 : 7) : (CLASS_A ? 12 : 10);
+    constexpr int RES = W4_ALL ? (CLASS_A ? 2 : 7) : (CLASS_A ? 3 : 4);
+    constexpr int RING = W4_ALL ? (CLASS_A ? 4 : 0) : (CLASS_A ? 3 : 2);
+    static_assert(RING == 0 ? NCH == RES : (NCH - RES) % RING == 0, "a chunk's slot must not depend on the step");
     const int ob0 = w, ob1 = w + WAVES, wb = 4 * (w - 5);
     v4i slot[RES + RING][DETK];
     auto chunk = [&](gptr P, int c, int l8) -> gptr {   // (c is a constant after unrolling)
         if (c < 3) return P + WGH + (size_t)(c * DETB + ob0) * DETK * BLK + l8;
         if (c < 6) return P + WGI + (size_t)((c - 3) * DETB + ob0) * HIDK * BLK + l8;
-        if (CLASS_A) return c < 9 ? P + WGH + (size_t)((c - 6) * DETB + ob1) * DETK * BLK + l8
-                                  : P + WGI + (size_t)((c - 9) * DETB + ob1) * HIDK * BLK + l8;
+        if (W4_ALL && !CLASS_A) return P + W4 + (size_t)ob0 * DETK * BLK + l8;
+        if (CLASS_A && c < 12) return c < 9 ? P + WGH + (size_t)((c - 6) * DETB + ob1) * DETK * BLK + l8
+                                            : P + WGI + (size_t)((c - 9) * DETB + ob1) * HIDK * BLK + l8;
+        if (CLASS_A) return P + W4 + (size_t)(c == 12 ? ob0 : ob1) * DETK * BLK + l8;
         return P + W4 + (size_t)(wb + c - 6) * DETK * BLK + l8;
     };
-    constexpr auto slot_of = [](int c) { return c < RES ? c : RES + (c - RES) % RING; };
+    constexpr auto slot_of = [](int c) { return c < RES ? c : RES + (c - RES) % (RING ? RING : 1); };
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < RES + RING; ++c) request<DETK>(chunk((gptr)Pg, c, lane * 8), slot[c]);
@@ -187,8 +194,16 @@ __device__ __forceinline__ void recurrence_steps(ProducerLds& s, int w, int lane
         }
         __syncthreads();
         if (st) stamps[4] = wall_clock64();
-        // ---- phase 3 (class B): p = relu(W4 h' + b4) ----
-        if (!CLASS_A) {
+        // ---- phase 3: p = relu(W4 h' + b4) ----
+        if (W4_ALL) {
+            const unsigned short* Hn = s.hb[cur ^ 1] + xr;
+            const v4f p0 = use(CLASS_A ? 12 : 6, Hn, bias4(s.bs, B4, ob0 * 16 + 4 * g));
+            *reinterpret_cast<v4s*>(s.xb + xo + ob0 * 16) = relu_pack(p0);
+            if (CLASS_A) {
+                const v4f p1 = use(13, Hn, bias4(s.bs, B4, ob1 * 16 + 4 * g));
+                *reinterpret_cast<v4s*>(s.xb + xo + ob1 * 16) = relu_pack(p1);
+            }
+        } else if (!CLASS_A) {
             const unsigned short* Hn = s.hb[cur ^ 1] + xr;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -234,35 +249,63 @@ __device__ __forceinline__ void recurrence(ProducerLds& s, int tile, int n, int 
     if (stamp) stamps[0] = wall_clock64();
     unsigned short* items = stage + (size_t)tile * horizon * ITEM;
     unsigned* flag = flags + tile;
+    // Initial state: everything this workgroup reads from global memory before its first model step is requested at
+    // once (one round trip, not one per array), parked in LDS, and the activation rows are built from there.
+    {
+        const float ob = tid < DET + STOCH ? obs0[tid] : 0.f;
+        constexpr size_t boffs[5] = {B1, BGI, BGH, B4, B5};
+        float bv[5][2];
+#pragma unroll
+        for (int l = 0; l < 5; ++l)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int e = tid + NTHR * q;
+                bv[l][q] = e < bias_len(boffs[l]) ? reinterpret_cast<const float*>(Pg + boffs[l])[e] : 0.f;
+            }
+        constexpr int N1 = HIDB * K1K * BLK / 8, N5 = STB * HIDK * BLK / 8, N4 = DETK * BLK / 8;
+        v4i c1[(N1 + NTHR - 1) / NTHR], c5[(N5 + NTHR - 1) / NTHR], c4 = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < (N1 + NTHR - 1) / NTHR; ++q)
+            if (tid + NTHR * q < N1) c1[q] = reinterpret_cast<const v4i*>(Pg + W1)[tid + NTHR * q];
+#pragma unroll
+        for (int q = 0; q < (N5 + NTHR - 1) / NTHR; ++q)
+            if (tid + NTHR * q < N5) c5[q] = reinterpret_cast<const v4i*>(Pg + W5)[tid + NTHR * q];
+        if (!W4ALL && tid < N4) c4 = reinterpret_cast<const v4i*>(Pg + W4 + (size_t)12 * DETK * BLK)[tid];
+        float av = 0.f;
+        if (tid < 16 * ACT) {
+            const int jj = tid / ACT;
+            av = actions[(size_t)(base + jj < n ? base + jj : n - 1) * horizon * ACT + tid % ACT];
+        }
+        s.ob[tid < 232 ? tid : 231] = tid < 232 ? ob : 0.f;
+#pragma unroll
+        for (int l = 0; l < 5; ++l)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (tid + NTHR * q < bias_len(boffs[l])) s.bs[bias_slot(boffs[l]) + tid + NTHR * q] = bv[l][q];
+#pragma unroll
+        for (int q = 0; q < (N1 + NTHR - 1) / NTHR; ++q)
+            if (tid + NTHR * q < N1) reinterpret_cast<v4i*>(s.w1)[tid + NTHR * q] = c1[q];
+#pragma unroll
+        for (int q = 0; q < (N5 + NTHR - 1) / NTHR; ++q)
+            if (tid + NTHR * q < N5) reinterpret_cast<v4i*>(s.w5)[tid + NTHR * q] = c5[q];
+        if (!W4ALL && tid < N4) reinterpret_cast<v4i*>(s.w4x)[tid] = c4;
+        if (tid < 16 * ACT) s.zA[(tid / ACT) * ZS + 32 + tid % ACT] = to_bf16(av);
+    }
+    __syncthreads();
     for (int e = tid; e < 16 * RS; e += NTHR) {
         const int k = e % RS;
-        s.hb[0][e] = to_bf16(k < DET ? obs0[k] : 0.f);
+        s.hb[0][e] = to_bf16(k < DET ? s.ob[k] : 0.f);
         s.hb[1][e] = 0;
         s.xb[e] = 0;
     }
-    for (int e = tid; e < 16 * HS; e += NTHR) s.h32[e] = (e % HS) < DET ? obs0[e % HS] : 0.f;
-    {
-        constexpr size_t offs[5] = {B1, BGI, BGH, B4, B5};
-#pragma unroll
-        for (int l = 0; l < 5; ++l)
-            for (int e = tid; e < bias_len(offs[l]); e += NTHR)
-                s.bs[bias_slot(offs[l]) + e] = reinterpret_cast<const float*>(Pg + offs[l])[e];
-    }
+    for (int e = tid; e < 16 * HS; e += NTHR) s.h32[e] = (e % HS) < DET ? s.ob[e % HS] : 0.f;
     for (int e = tid; e < 16 * ZS; e += NTHR) {
-        const int k = e % ZS, jj = e / ZS;
-        float v = 0.f;
-        if (k < STOCH) v = obs0[DET + k];
-        else if (k >= 32 && k < 32 + ACT) v = actions[(size_t)(base + jj < n ? base + jj : n - 1) * horizon * ACT + (k - 32)];
-        s.zA[e] = to_bf16(v);
+        const int k = e % ZS;
+        if (k < 32) s.zA[e] = to_bf16(k < STOCH ? s.ob[DET + k] : 0.f);
+        else if (k >= 32 + ACT) s.zA[e] = 0;
     }
-    for (int e = tid; e < HIDB * K1K * BLK / 8; e += NTHR)
-        reinterpret_cast<v4i*>(s.w1)[e] = reinterpret_cast<const v4i*>(Pg + W1)[e];
-    for (int e = tid; e < STB * HIDK * BLK / 8; e += NTHR)
-        reinterpret_cast<v4i*>(s.w5)[e] = reinterpret_cast<const v4i*>(Pg + W5)[e];
-    for (int e = tid; e < DETK * BLK / 8; e += NTHR)
-        reinterpret_cast<v4i*>(s.w4x)[e] = reinterpret_cast<const v4i*>(Pg + W4 + (size_t)12 * DETK * BLK)[e];
-    if (w < 5) recurrence_steps<true>(s, w, lane, base, n, horizon, Pg, actions, items, flag, stamps, stamp);
-    else recurrence_steps<false>(s, w, lane, base, n, horizon, Pg, actions, items, flag, stamps, stamp);
+    if (w < 5) recurrence_steps<true, W4ALL>(s, w, lane, base, n, horizon, Pg, actions, items, flag, stamps, stamp);
+    else recurrence_steps<false, W4ALL>(s, w, lane, base, n, horizon, Pg, actions, items, flag, stamps, stamp);
 }
 
 __device__ __forceinline__ void reward_head(ConsumerLds& s, int tile, int n, int horizon, int cost_mode,
