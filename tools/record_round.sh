@@ -1,0 +1,44 @@
+#!/bin/bash
+# GPU box (via gpurun): everything the committed profiles/<tag>_* files of a round come from, in one call --
+#   the GPU test suite, the rocprofv3 passes of c2 / c4 / c3 (tools/profile_round.sh), the default bench line, the c5
+#   bench line, the tool lines and the soaks.  Summarise afterwards, here in the container:
+#     for w in c2 c4 c3; do python tools/summarize_profile.py gpurun_out/<tag>-$w profiles/<tag>_$w; done
+#     cp gpurun_out/<tag>-rec/*.json gpurun_out/<tag>-rec/*.txt -> profiles/<tag>_*   (tools/record_round.sh prints the list)
+#     python tools/doc_numbers.py <tag>
+# usage: tools/record_round.sh r03 [quick]
+TAG=${1:-r03}; QUICK=${2:-}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG-rec
+mkdir -p $OUT
+cd $ROOT
+timeout 1200 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.txt 2>&1; tail -1 $OUT/pytest_gpu.txt
+for w in c2 c4 c3; do timeout 900 bash tools/profile_round.sh $TAG $w > /dev/null 2>&1; done
+cd $ROOT
+timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 300 $OUT/bench_default.json
+timeout 300 python bench.py --workload c5 --steps 200 --warmup 20 > $OUT/c5_bench.json 2> /dev/null
+{
+  echo "# tools/controller_latency.py (MpcICemHip.get_action, host observation in, host action out)"
+  timeout 120 python tools/controller_latency.py 2>&1 | grep "N="
+  echo "# tools/sharded_rank_bench.py 8 <rows per GPU> (one rank of 8, peers absent: ICEM_XCHG_LOOPBACK -- everything but the wire)"
+  timeout 120 python tools/sharded_rank_bench.py 8 4096 2>&1 | grep "world="
+  timeout 120 python tools/sharded_rank_bench.py 8 65536 2>&1 | grep "world="
+  echo "# tools/dbg/step_time.py (us per MPC step, icem_plan_step, resident inputs)"
+  timeout 120 python tools/dbg/step_time.py 2048 4096 8192 16384 32768 65536 2>&1 | grep "N="
+  echo "# tools/dbg/rssm_sweep.py (icem_rssm_rollout_cost alone; TFLOP/s on the nominal 12-transition count)"
+  timeout 120 python tools/dbg/rssm_sweep.py 512 1024 2048 4096 16384 65536 2>&1 | grep "n="
+  echo "# tools/dbg/rssm_stamps.py 1024 (tile 0 of the split launch)"
+  timeout 120 python tools/dbg/rssm_stamps.py 1024 2>&1 | grep -v amdgpu.ids
+} > $OUT/tool_lines.txt 2>&1
+if [ -z "$QUICK" ]; then
+{
+  echo "# tools/dbg/soak_equiv.py 1000 1 (icem_plan_step vs split API, all population sizes)"
+  timeout 900 python tools/dbg/soak_equiv.py 1000 1 2>&1 | tail -1
+  echo "# tools/dbg/soak_equiv.py 300 2 large (noise-ahead launches vs the sampler + rollout pair)"
+  timeout 900 python tools/dbg/soak_equiv.py 300 2 large 2>&1 | tail -1
+  echo "# tools/dbg/soak_shards.py 600"
+  timeout 900 python tools/dbg/soak_shards.py 600 2>&1 | tail -1
+  echo "# tools/dbg/soak_oracle.py 100 3 (device vs float64 oracle, elite sets)"
+  timeout 600 python tools/dbg/soak_oracle.py 100 3 2>&1 | tail -1
+} > $OUT/soak.txt 2>&1
+fi
+ls $OUT
