@@ -77,7 +77,22 @@ __global__ __launch_bounds__(NTHR) void rssm_rollout_kernel(int n, int horizon, 
         }
         req_own<K1K>(Plane, W1, w, A1);
     }
-    for (int t = 0; t < horizon; ++t) {
+    // reward = W8 r2 + b8 of the state step t starts from, by the wave that owns one block less than wave 0
+    auto score = [&](gptr Plane, int t) {
+        v4i A8[HIDK];
+        request<HIDK>(Plane + W8, A8);
+        const v4f b8 = bias4(bs, B8, 4 * g);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            const v4f a = mma<HIDK>(A8, r2 + tt * 16 * RS + xr, b8);
+            const float c = -a[0];   // output 0 of trajectory j lives in lane (j, g = 0), register 0
+            if (t == 0 || cost_mode == 2) acc_cost[tt] = c;
+            else if (cost_mode == 0) acc_cost[tt] += c;
+            else acc_cost[tt] = (c < acc_cost[tt] || c != c) ? c : acc_cost[tt];
+        }
+    };
+    // horizon - 1 full steps; the state the LAST step starts from is only scored (the transition behind it never is)
+    for (int t = 0; t + 1 < horizon; ++t) {
         // the parameters do not depend on t, and the optimizer would gladly keep whatever fits of them in registers
         // across steps (it filled all 512 and spilled): re-derive the pointer behind an opaque barrier every step
         gptr P = (gptr)Pg;
@@ -150,19 +165,7 @@ __global__ __launch_bounds__(NTHR) void rssm_rollout_kernel(int n, int horizon, 
         v4i A5[HIDK];
         if (AHEAD && w < STB) request<HIDK>(Plane + W5 + (size_t)w * HIDK * BLK, A5);   // next phase's layer, across the barrier
         __builtin_amdgcn_sched_barrier(0);
-        if (w == WAVES - 1) {   // the reward output block: a wave that owns one block less than wave 0
-            v4i A8[HIDK];
-            request<HIDK>(Plane + W8, A8);
-            const v4f b8 = bias4(bs, B8, 4 * g);
-#pragma unroll
-            for (int tt = 0; tt < TT; ++tt) {
-                const v4f a = mma<HIDK>(A8, r2 + tt * 16 * RS + xr, b8);
-                const float c = -a[0];   // output 0 of trajectory j lives in lane (j, g = 0), register 0
-                if (t == 0 || cost_mode == 2) acc_cost[tt] = c;
-                else if (cost_mode == 0) acc_cost[tt] += c;
-                else acc_cost[tt] = (c < acc_cost[tt] || c != c) ? c : acc_cost[tt];
-            }
-        }
+        if (w == WAVES - 1) score(Plane, t);
         {
             v4i A4[NOB][DETK];
             req_own<DETK>(Plane, W4, w, A4);
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(NTHR) void rssm_rollout_kernel(int n, int horizon, 
                 const v4f a = mma<HIDK>(A5, xb + tt * 16 * RS + xr, b5);
                 *reinterpret_cast<v4s*>(zA + tt * 16 * ZS + zo + w * 16) = pack4(a[0], a[1], a[2], a[3]);
             }
-        } else if (w == STB && t + 1 < horizon) {
+        } else if (w == STB) {
             if (g < 2) {   // lanes (j, 0): a[0..3]; lanes (j, 1): a[4], a[5], 0, 0
 #pragma unroll
                 for (int tt = 0; tt < TT; ++tt) {
@@ -202,6 +205,35 @@ __global__ __launch_bounds__(NTHR) void rssm_rollout_kernel(int n, int horizon, 
         }
         __syncthreads();
         cur ^= 1;
+    }
+    {   // the last state: r1 = relu(W6 [h | z] + b6), r2 = relu(W7 r1 + b7), reward
+        gptr Plane = (gptr)Pg + lane * 8;
+        if (!AHEAD) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NOB; ++i) {
+                gptr W = Plane + W6 + (size_t)own_block(w, i) * K6K * BLK;
+                request<DETK>(W, Ah[i]);
+                request<STK>(W + (size_t)DETK * BLK, Az[i]);
+            }
+        }
+        v4i A7[NOB][HIDK];
+        req_own<HIDK>(Plane, W7, w, A7);
+#pragma unroll
+        for (int i = 0; i < NOB; ++i) {
+            const int ob = own_block(w, i);
+            const v4f b = bias4(bs, B6, ob * 16 + 4 * g);
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) {
+                v4f a = mma<DETK>(Ah[i], hb[cur] + tt * 16 * RS + xr, b);
+                a = mma<STK>(Az[i], zA + tt * 16 * ZS + zr, a);
+                if (w + WAVES * i < 13) *reinterpret_cast<v4s*>(r1 + tt * 16 * RS + xo + ob * 16) = relu_pack(a);
+            }
+        }
+        __syncthreads();
+        fin_dense<HIDK, TT>(bs, B7, A7, r1 + xr, 16 * RS, r2 + xo, w, g);
+        __syncthreads();
+        if (w == WAVES - 1) score(Plane, horizon - 1);
     }
     if (w == WAVES - 1 && g == 0) {
 #pragma unroll

@@ -25,28 +25,27 @@ using namespace rssm_dev;
 
 constexpr int SR = 256;              // bf16 row of an item: [h: 7 k-blocks (200 + zero padding) | z: 1 k-block]
 constexpr int ITEM = 16 * SR;        // elements
-#ifndef RSSM_W4_ALL
-#define RSSM_W4_ALL 1
-#endif
-constexpr bool W4ALL = RSSM_W4_ALL;   // W4's 13 blocks over all 8 waves (1) or over the three class-B waves + LDS (0)
+// two tiles per recurrence workgroup: resident chunks / ring slots of the two wave classes (accumulators take twice the room)
+constexpr int RES_A2 = 2, RING_A2 = 3, RES_B2 = 3, RING_B2 = 2;
 constexpr unsigned MAX_POLLS = 1u << 22;   // x s_sleep(2): a few hundred ms, then the reward workgroup gives up (costs = NaN)
 
-struct ProducerLds {
-    unsigned short zA[16 * ZS];
-    unsigned short hb[2][16 * RS];
-    unsigned short xb[16 * RS];
-    float h32[16 * HS];
+template <int TT>
+struct ProducerLds {                       // TT tiles of 16 trajectories: rows tt * 16 + j
+    unsigned short zA[TT * 16 * ZS];
+    unsigned short hb[2][TT * 16 * RS];
+    unsigned short xb[TT * 16 * RS];
+    float h32[TT * 16 * HS];
     float bs[NBIAS];
-    unsigned short w1[HIDB * K1K * BLK];   // A-operand blocks that stay here: W1, W5 and W4's 13th output block
+    unsigned short w1[HIDB * K1K * BLK];   // A-operand blocks that stay here: W1 and W5
     unsigned short w5[STB * HIDK * BLK];
-    unsigned short w4x[DETK * BLK];
     float ob[232];                         // obs0, parked once
 };
 struct ConsumerLds {
     unsigned short r1[2][16 * RS];
     unsigned short r2[2][16 * RS];
 };
-constexpr size_t LDS_BYTES = sizeof(ProducerLds) > sizeof(ConsumerLds) ? sizeof(ProducerLds) : sizeof(ConsumerLds);
+template <int TT>
+constexpr size_t lds_bytes() { return sizeof(ProducerLds<TT>) > sizeof(ConsumerLds) ? sizeof(ProducerLds<TT>) : sizeof(ConsumerLds); }
 
 __device__ __forceinline__ void store_wt(unsigned short* p, unsigned long long v) {   // written through, 8 bytes
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -55,53 +54,63 @@ __device__ __forceinline__ unsigned long long load_ag(const unsigned short* p) {
     return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// wave-wide copy of state t out of LDS into its item, then the flag (called by ONE wave)
-__device__ __forceinline__ void publish(const ProducerLds& s, int cur, unsigned short* item, unsigned* flag, unsigned value, int lane) {
+// wave-wide copy of state t of the workgroup's tiles out of LDS into their items, then the flags (called by ONE wave);
+// items / flags: those of the workgroup's first tile; ntl: how many of its TT tiles exist
+template <int TT>
+__device__ __forceinline__ void publish(const ProducerLds<TT>& s, int cur, unsigned short* items, size_t tile_stride, int t,
+                                        unsigned* flag, int ntl, int lane) {
     // h: 16 rows x 208 bf16 = 52 8-byte words per row; z: 16 rows x 32 bf16 = 8 words per row
     asm volatile("" : "+v"(lane));   // (the 15 address pairs are step-invariant: hoisted out of the step loop they are spilled)
 #pragma unroll
-    for (int i = 0; i < 13; ++i) {
-        const int e = lane + 64 * i, row = e / 52, c = e % 52;
-        store_wt(item + row * SR + 4 * c, *reinterpret_cast<const unsigned long long*>(s.hb[cur] + row * RS + 4 * c));
-    }
+    for (int tt = 0; tt < TT; ++tt) {
+        if (tt < ntl) {
+            unsigned short* item = items + tt * tile_stride + (size_t)t * ITEM;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int e = lane + 64 * i, row = e / 8, c = e % 8;
-        store_wt(item + row * SR + 224 + 4 * c, *reinterpret_cast<const unsigned long long*>(s.zA + row * ZS + 4 * c));
+            for (int i = 0; i < 13; ++i) {
+                const int e = lane + 64 * i, row = e / 52, c = e % 52;
+                store_wt(item + row * SR + 4 * c, *reinterpret_cast<const unsigned long long*>(s.hb[cur] + (tt * 16 + row) * RS + 4 * c));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = lane + 64 * i, row = e / 8, c = e % 8;
+                store_wt(item + row * SR + 224 + 4 * c, *reinterpret_cast<const unsigned long long*>(s.zA + (tt * 16 + row) * ZS + 4 * c));
+            }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane < ntl) __hip_atomic_store(flag + lane, (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // The model steps of the recurrence for one CLASS of waves.  The 0.65 MB of weights a step reads are cut into CHUNKS
 // (one output block of one matrix: 7 A-operand blocks = 28 registers per lane, 7 KB per wave) and every chunk has an owner:
-//   class A, waves 0..4:  the GRU's output blocks w and w + 8         12 chunks: H(w) r u n, I(w) r u n, H(w+8) .., I(w+8) ..
-//   class B, waves 5..7:  the GRU's block w and W4's blocks 4 (w - 5) .. + 3    10 chunks: H(w) r u n, I(w) r u n, 4 x W4
-// (H = hidden side, needs h_t only: phase 1; I = input side, needs x: phase 2; W4: phase 3).  W1, W5 and W4's 13th
-// block live in LDS.  A wave consumes its chunks in that order, every step.  The first RES of them stay in registers
-// for the whole rollout; the others go through a ring of RING register slots, chunk c + RING requested right behind the
-// MFMAs of chunk c.  The two classes are two instances of this function behind one wave-uniform branch: inside each
-// the code is straight-line, so the compiler's in-order vmcnt bookkeeping is exact (a wave only ever waits for the
-// chunk it is about to use), and nobody issues a load it does not need (a "dummy" broadcast load costs the L1 more
-// than a real one: measured).
-template <bool CLASS_A, bool W4_ALL>
-__device__ __forceinline__ void recurrence_steps(ProducerLds& s, int w, int lane, int base, int n, int horizon,
+//   class A, waves 0..4:  the GRU's output blocks w and w + 8, W4's blocks w and w + 8
+//                         14 chunks: H(w) r u n, I(w) r u n, H(w+8) r u n, I(w+8) r u n, W4(w), W4(w+8)
+//   class B, waves 5..7:  the GRU's block w, W4's block w          7 chunks: H(w) r u n, I(w) r u n, W4(w)
+// (H = hidden side, needs h_t only: phase 1; I = input side, needs x: phase 2; W4: phase 3).  W1 and W5 live in LDS.
+// A wave consumes its chunks in that order, every step.  The first RES of them stay in registers for the whole rollout;
+// the others go through a ring of RING register slots, chunk c + RING requested right behind the MFMAs of chunk c.
+// The two classes are two instances of this function behind one wave-uniform branch: inside each the code is
+// straight-line, so the compiler's in-order vmcnt bookkeeping is exact (a wave only ever waits for the chunk it is
+// about to use), and nobody issues a load it does not need (a "dummy" broadcast load costs the L1 more than a real
+// one: measured).  TT tiles per workgroup share every chunk (one request, TT accumulation chains).
+template <bool CLASS_A, int TT>
+__device__ __forceinline__ void recurrence_steps(ProducerLds<TT>& s, int w, int lane, int base, int n, int horizon,
                                                  const unsigned short* __restrict__ Pg, const float* __restrict__ actions,
-                                                 unsigned short* items, unsigned* flag, long long* stamps, bool stamp) {
-    constexpr int NCH = W4_ALL ? (CLASS_A ? 14 : 7) : (CLASS_A ? 12 : 10);
-    constexpr int RES = W4_ALL ? (CLASS_A ? 2 : 7) : (CLASS_A ? 3 : 4);
-    constexpr int RING = W4_ALL ? (CLASS_A ? 4 : 0) : (CLASS_A ? 3 : 2);
+                                                 unsigned short* items, size_t tile_stride, unsigned* flag, int ntl,
+                                                 long long* stamps, bool stamp) {
+    constexpr int NCH = CLASS_A ? 14 : 7;
+    constexpr int RES = TT == 1 ? (CLASS_A ? 2 : 7) : (CLASS_A ? RES_A2 : RES_B2);
+    constexpr int RING = TT == 1 ? (CLASS_A ? 4 : 0) : (CLASS_A ? RING_A2 : RING_B2);
     static_assert(RING == 0 ? NCH == RES : (NCH - RES) % RING == 0, "a chunk's slot must not depend on the step");
-    const int ob0 = w, ob1 = w + WAVES, wb = 4 * (w - 5);
+    const int ob0 = w, ob1 = w + WAVES;
     v4i slot[RES + RING][DETK];
     auto chunk = [&](gptr P, int c, int l8) -> gptr {   // (c is a constant after unrolling)
         if (c < 3) return P + WGH + (size_t)(c * DETB + ob0) * DETK * BLK + l8;
         if (c < 6) return P + WGI + (size_t)((c - 3) * DETB + ob0) * HIDK * BLK + l8;
-        if (W4_ALL && !CLASS_A) return P + W4 + (size_t)ob0 * DETK * BLK + l8;
-        if (CLASS_A && c < 12) return c < 9 ? P + WGH + (size_t)((c - 6) * DETB + ob1) * DETK * BLK + l8
-                                            : P + WGI + (size_t)((c - 9) * DETB + ob1) * HIDK * BLK + l8;
-        if (CLASS_A) return P + W4 + (size_t)(c == 12 ? ob0 : ob1) * DETK * BLK + l8;
-        return P + W4 + (size_t)(wb + c - 6) * DETK * BLK + l8;
+        if (!CLASS_A) return P + W4 + (size_t)ob0 * DETK * BLK + l8;
+        if (c < 9) return P + WGH + (size_t)((c - 6) * DETB + ob1) * DETK * BLK + l8;
+        if (c < 12) return P + WGI + (size_t)((c - 9) * DETB + ob1) * HIDK * BLK + l8;
+        return P + W4 + (size_t)(c == 12 ? ob0 : ob1) * DETK * BLK + l8;
     };
     constexpr auto slot_of = [](int c) { return c < RES ? c : RES + (c - RES) % (RING ? RING : 1); };
     __builtin_amdgcn_sched_barrier(0);
@@ -127,18 +136,28 @@ __device__ __forceinline__ void recurrence_steps(ProducerLds& s, int w, int lane
         const int xo = j * RS + 4 * g, zo = j * ZS + 4 * g, ho = j * HS + 4 * g;
         const unsigned short* X = s.xb + xr;
         const unsigned short* H = s.hb[cur] + xr;
-        // the next action of the tile's trajectories (every wave asks, wave 2 stores: a load inside a branch would cost
-        // the waves behind the branch their exact vmcnt)
-        float an0, an1, an2, an3;
-        {
-            const int rr = base + j;
-            const float* an = actions + ((size_t)(rr < n ? rr : n - 1) * horizon + (t + 1)) * ACT;
+        // the next action of the trajectories (every wave asks, wave 2 stores: a load inside a branch would cost the
+        // waves behind the branch their exact vmcnt)
+        float an[TT][4];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            const int rr = base + tt * 16 + j;
+            const float* ap = actions + ((size_t)(rr < n ? rr : n - 1) * horizon + (t + 1)) * ACT;
             const int o = g & 1 ? 4 : 0;
-            an0 = an[o]; an1 = an[o + 1]; an2 = an[g & 1 ? 5 : 2]; an3 = an[g & 1 ? 5 : 3];
+            an[tt][0] = ap[o]; an[tt][1] = ap[o + 1]; an[tt][2] = ap[g & 1 ? 5 : 2]; an[tt][3] = ap[g & 1 ? 5 : 3];
         }
-        // chunk c through the matrix pipe; if it is a streamed one, the request that refills its slot
-        auto use = [&](int c, const unsigned short* B, v4f bias) -> v4f {
-            const v4f a = mma<DETK>(slot[slot_of(c)], B, bias);
+        // chunk c through the matrix pipe for every tile (B: the lane's operand row in tile 0, bts: its stride between
+        // tiles); if it is a streamed chunk, the request that refills its slot
+        auto use = [&](int c, const unsigned short* B, int bts, v4f (&acc)[TT], v4f bias) {
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) acc[tt] = bias;
+#pragma unroll
+            for (int kb = 0; kb < DETK; ++kb)
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt)
+                    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(v8bf, slot[slot_of(c)][kb]),
+                        __builtin_bit_cast(v8bf, *reinterpret_cast<const v4i*>(B + tt * bts + kb * 32)), acc[tt], 0, 0, 0);
             if (c >= RES) {
                 int nx = c + RING;
                 if (nx >= NCH) nx = RES + (nx - NCH);
@@ -146,17 +165,20 @@ __device__ __forceinline__ void recurrence_steps(ProducerLds& s, int w, int lane
                 request<DETK>(chunk(P, nx, l8), slot[slot_of(c)]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            return a;
         };
-        auto gates = [&](int ob, const v4f& ir, const v4f& iu, const v4f& in, const v4f& hr, const v4f& hu, const v4f& hn) {
-            float* hp = s.h32 + ho + ob * 16;
-            float nh[4];
+        auto gates = [&](int ob, const v4f (&ir)[TT], const v4f (&iu)[TT], const v4f (&in)[TT], const v4f (&hr)[TT],
+                         const v4f (&hu)[TT], const v4f (&hn)[TT]) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                nh[r] = gru_out(ir[r], iu[r], in[r], hr[r], hu[r], hn[r], hp[r]);
-                hp[r] = nh[r];
+            for (int tt = 0; tt < TT; ++tt) {
+                float* hp = s.h32 + tt * 16 * HS + ho + ob * 16;
+                float nh[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    nh[r] = gru_out(ir[tt][r], iu[tt][r], in[tt][r], hr[tt][r], hu[tt][r], hn[tt][r], hp[r]);
+                    hp[r] = nh[r];
+                }
+                *reinterpret_cast<v4s*>(s.hb[cur ^ 1] + tt * 16 * RS + xo + ob * 16) = pack4(nh[0], nh[1], nh[2], nh[3]);
             }
-            *reinterpret_cast<v4s*>(s.hb[cur ^ 1] + xo + ob * 16) = pack4(nh[0], nh[1], nh[2], nh[3]);
         };
         // ---- phase 1 (reads z_t, a_t, h_t): x = relu(W1 [z | a] + b1); the hidden side of the wave's first GRU block ----
 #pragma unroll
@@ -164,57 +186,53 @@ __device__ __forceinline__ void recurrence_steps(ProducerLds& s, int w, int lane
             const int ob = w + WAVES * i;
             v4i A1[K1K];
             request<K1K>(s.w1 + (size_t)ob * K1K * BLK + l8, A1);
-            const v4f a = mma<K1K>(A1, s.zA + zr, bias4(s.bs, B1, ob * 16 + 4 * g));
-            *reinterpret_cast<v4s*>(s.xb + xo + ob * 16) = relu_pack(a);
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) {
+                const v4f a = mma<K1K>(A1, s.zA + tt * 16 * ZS + zr, bias4(s.bs, B1, ob * 16 + 4 * g));
+                *reinterpret_cast<v4s*>(s.xb + tt * 16 * RS + xo + ob * 16) = relu_pack(a);
+            }
         }
         int bi = ob0 * 16 + 4 * g;
-        v4f hr = use(0, H, bias4(s.bs, BGH, bi));
-        v4f hu = use(1, H, bias4(s.bs, BGH, 16 * DETB + bi));
-        v4f hn = use(2, H, bias4(s.bs, BGH, 32 * DETB + bi));
+        v4f hr[TT], hu[TT], hn[TT];
+        use(0, H, 16 * RS, hr, bias4(s.bs, BGH, bi));
+        use(1, H, 16 * RS, hu, bias4(s.bs, BGH, 16 * DETB + bi));
+        use(2, H, 16 * RS, hn, bias4(s.bs, BGH, 32 * DETB + bi));
         __syncthreads();
         if (st) stamps[3] = wall_clock64();
         // ---- phase 2: GRU h' = (1 - u) n + u h; wave 7 publishes state t ----
         {
-            v4f ir = use(3, X, bias4(s.bs, BGI, bi));
-            v4f iu = use(4, X, bias4(s.bs, BGI, 16 * DETB + bi));
-            v4f in = use(5, X, bias4(s.bs, BGI, 32 * DETB + bi));
+            v4f ir[TT], iu[TT], in[TT];
+            use(3, X, 16 * RS, ir, bias4(s.bs, BGI, bi));
+            use(4, X, 16 * RS, iu, bias4(s.bs, BGI, 16 * DETB + bi));
+            use(5, X, 16 * RS, in, bias4(s.bs, BGI, 32 * DETB + bi));
             gates(ob0, ir, iu, in, hr, hu, hn);
             if (CLASS_A) {
                 bi = ob1 * 16 + 4 * g;
-                hr = use(6, H, bias4(s.bs, BGH, bi));
-                hu = use(7, H, bias4(s.bs, BGH, 16 * DETB + bi));
-                hn = use(8, H, bias4(s.bs, BGH, 32 * DETB + bi));
-                ir = use(9, X, bias4(s.bs, BGI, bi));
-                iu = use(10, X, bias4(s.bs, BGI, 16 * DETB + bi));
-                in = use(11, X, bias4(s.bs, BGI, 32 * DETB + bi));
+                use(6, H, 16 * RS, hr, bias4(s.bs, BGH, bi));
+                use(7, H, 16 * RS, hu, bias4(s.bs, BGH, 16 * DETB + bi));
+                use(8, H, 16 * RS, hn, bias4(s.bs, BGH, 32 * DETB + bi));
+                use(9, X, 16 * RS, ir, bias4(s.bs, BGI, bi));
+                use(10, X, 16 * RS, iu, bias4(s.bs, BGI, 16 * DETB + bi));
+                use(11, X, 16 * RS, in, bias4(s.bs, BGI, 32 * DETB + bi));
                 gates(ob1, ir, iu, in, hr, hu, hn);
             } else if (w == WAVES - 1) {
-                publish(s, cur, items + (size_t)t * ITEM, flag, (unsigned)t + 1u, ln);
+                publish<TT>(s, cur, items, tile_stride, t, flag, ntl, ln);
             }
         }
         __syncthreads();
         if (st) stamps[4] = wall_clock64();
         // ---- phase 3: p = relu(W4 h' + b4) ----
-        if (W4_ALL) {
+        {
             const unsigned short* Hn = s.hb[cur ^ 1] + xr;
-            const v4f p0 = use(CLASS_A ? 12 : 6, Hn, bias4(s.bs, B4, ob0 * 16 + 4 * g));
-            *reinterpret_cast<v4s*>(s.xb + xo + ob0 * 16) = relu_pack(p0);
-            if (CLASS_A) {
-                const v4f p1 = use(13, Hn, bias4(s.bs, B4, ob1 * 16 + 4 * g));
-                *reinterpret_cast<v4s*>(s.xb + xo + ob1 * 16) = relu_pack(p1);
-            }
-        } else if (!CLASS_A) {
-            const unsigned short* Hn = s.hb[cur ^ 1] + xr;
+            v4f p0[TT];
+            use(CLASS_A ? 12 : 6, Hn, 16 * RS, p0, bias4(s.bs, B4, ob0 * 16 + 4 * g));
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const v4f p = use(6 + q, Hn, bias4(s.bs, B4, (wb + q) * 16 + 4 * g));
-                *reinterpret_cast<v4s*>(s.xb + xo + (wb + q) * 16) = relu_pack(p);
-            }
-            if (w == 5) {   // the 13th block, from LDS
-                v4i A4[DETK];
-                request<DETK>(s.w4x + l8, A4);
-                const v4f p = mma<DETK>(A4, Hn, bias4(s.bs, B4, 12 * 16 + 4 * g));
-                *reinterpret_cast<v4s*>(s.xb + xo + 12 * 16) = relu_pack(p);
+            for (int tt = 0; tt < TT; ++tt) *reinterpret_cast<v4s*>(s.xb + tt * 16 * RS + xo + ob0 * 16) = relu_pack(p0[tt]);
+            if (CLASS_A) {
+                v4f p1[TT];
+                use(13, Hn, 16 * RS, p1, bias4(s.bs, B4, ob1 * 16 + 4 * g));
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) *reinterpret_cast<v4s*>(s.xb + tt * 16 * RS + xo + ob1 * 16) = relu_pack(p1[tt]);
             }
         }
         __syncthreads();
@@ -224,10 +242,16 @@ __device__ __forceinline__ void recurrence_steps(ProducerLds& s, int w, int lane
             if (w < STB) {
                 v4i A5[HIDK];
                 request<HIDK>(s.w5 + (size_t)w * HIDK * BLK + l8, A5);
-                const v4f a = mma<HIDK>(A5, s.xb + xr, bias4(s.bs, B5, w * 16 + 4 * g));
-                *reinterpret_cast<v4s*>(s.zA + zo + w * 16) = pack4(a[0], a[1], a[2], a[3]);
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) {
+                    const v4f a = mma<HIDK>(A5, s.xb + tt * 16 * RS + xr, bias4(s.bs, B5, w * 16 + 4 * g));
+                    *reinterpret_cast<v4s*>(s.zA + tt * 16 * ZS + zo + w * 16) = pack4(a[0], a[1], a[2], a[3]);
+                }
             } else if (w == STB && g < 2) {   // lanes (j, 0): a[0..3]; lanes (j, 1): a[4], a[5], 0, 0
-                *reinterpret_cast<v4s*>(s.zA + j * ZS + 32 + 4 * g) = pack4(an0, an1, g == 0 ? an2 : 0.f, g == 0 ? an3 : 0.f);
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt)
+                    *reinterpret_cast<v4s*>(s.zA + (tt * 16 + j) * ZS + 32 + 4 * g) =
+                        pack4(an[tt][0], an[tt][1], g == 0 ? an[tt][2] : 0.f, g == 0 ? an[tt][3] : 0.f);
             }
         }
         __syncthreads();
@@ -236,19 +260,23 @@ __device__ __forceinline__ void recurrence_steps(ProducerLds& s, int w, int lane
     }
     if (stamp) stamps[7] = wall_clock64();
     // the state the last step starts from
-    if (w == WAVES - 1) publish(s, cur, items + (size_t)(horizon - 1) * ITEM, flag, (unsigned)horizon, lane);
+    if (w == WAVES - 1) publish<TT>(s, cur, items, tile_stride, horizon - 1, flag, ntl, lane);
 }
 
-__device__ __forceinline__ void recurrence(ProducerLds& s, int tile, int n, int horizon, const unsigned short* __restrict__ Pg,
+// wg: the workgroup's index among the recurrence workgroups (tiles wg * TT ..)
+template <int TT>
+__device__ __forceinline__ void recurrence(ProducerLds<TT>& s, int wg, int tiles, int n, int horizon, const unsigned short* __restrict__ Pg,
                                            const float* __restrict__ obs0, const float* __restrict__ actions,
                                            unsigned short* stage, unsigned* flags, long long* stamps) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int base = tile * 16;
-    const bool stamp = stamps && tile == 0 && tid == 0;   // development aid (icem_debug_stamps(NULL, buffer))
+    const int tile0 = wg * TT, base = tile0 * 16;
+    const int ntl = tiles - tile0 < TT ? tiles - tile0 : TT;
+    const bool stamp = stamps && wg == 0 && tid == 0;   // development aid (icem_debug_stamps(NULL, buffer))
     if (stamp) stamps[0] = wall_clock64();
-    unsigned short* items = stage + (size_t)tile * horizon * ITEM;
-    unsigned* flag = flags + tile;
+    const size_t tile_stride = (size_t)horizon * ITEM;
+    unsigned short* items = stage + (size_t)tile0 * tile_stride;
+    unsigned* flag = flags + tile0;
     // Initial state: everything this workgroup reads from global memory before its first model step is requested at
     // once (one round trip, not one per array), parked in LDS, and the activation rows are built from there.
     {
@@ -262,17 +290,16 @@ __device__ __forceinline__ void recurrence(ProducerLds& s, int tile, int n, int 
                 const int e = tid + NTHR * q;
                 bv[l][q] = e < bias_len(boffs[l]) ? reinterpret_cast<const float*>(Pg + boffs[l])[e] : 0.f;
             }
-        constexpr int N1 = HIDB * K1K * BLK / 8, N5 = STB * HIDK * BLK / 8, N4 = DETK * BLK / 8;
-        v4i c1[(N1 + NTHR - 1) / NTHR], c5[(N5 + NTHR - 1) / NTHR], c4 = {0, 0, 0, 0};
+        constexpr int N1 = HIDB * K1K * BLK / 8, N5 = STB * HIDK * BLK / 8;
+        v4i c1[(N1 + NTHR - 1) / NTHR], c5[(N5 + NTHR - 1) / NTHR];
 #pragma unroll
         for (int q = 0; q < (N1 + NTHR - 1) / NTHR; ++q)
             if (tid + NTHR * q < N1) c1[q] = reinterpret_cast<const v4i*>(Pg + W1)[tid + NTHR * q];
 #pragma unroll
         for (int q = 0; q < (N5 + NTHR - 1) / NTHR; ++q)
             if (tid + NTHR * q < N5) c5[q] = reinterpret_cast<const v4i*>(Pg + W5)[tid + NTHR * q];
-        if (!W4ALL && tid < N4) c4 = reinterpret_cast<const v4i*>(Pg + W4 + (size_t)12 * DETK * BLK)[tid];
         float av = 0.f;
-        if (tid < 16 * ACT) {
+        if (tid < TT * 16 * ACT) {
             const int jj = tid / ACT;
             av = actions[(size_t)(base + jj < n ? base + jj : n - 1) * horizon * ACT + tid % ACT];
         }
@@ -288,24 +315,23 @@ __device__ __forceinline__ void recurrence(ProducerLds& s, int tile, int n, int 
 #pragma unroll
         for (int q = 0; q < (N5 + NTHR - 1) / NTHR; ++q)
             if (tid + NTHR * q < N5) reinterpret_cast<v4i*>(s.w5)[tid + NTHR * q] = c5[q];
-        if (!W4ALL && tid < N4) reinterpret_cast<v4i*>(s.w4x)[tid] = c4;
-        if (tid < 16 * ACT) s.zA[(tid / ACT) * ZS + 32 + tid % ACT] = to_bf16(av);
+        if (tid < TT * 16 * ACT) s.zA[(tid / ACT) * ZS + 32 + tid % ACT] = to_bf16(av);
     }
     __syncthreads();
-    for (int e = tid; e < 16 * RS; e += NTHR) {
+    for (int e = tid; e < TT * 16 * RS; e += NTHR) {
         const int k = e % RS;
         s.hb[0][e] = to_bf16(k < DET ? s.ob[k] : 0.f);
         s.hb[1][e] = 0;
         s.xb[e] = 0;
     }
-    for (int e = tid; e < 16 * HS; e += NTHR) s.h32[e] = (e % HS) < DET ? s.ob[e % HS] : 0.f;
-    for (int e = tid; e < 16 * ZS; e += NTHR) {
+    for (int e = tid; e < TT * 16 * HS; e += NTHR) s.h32[e] = (e % HS) < DET ? s.ob[e % HS] : 0.f;
+    for (int e = tid; e < TT * 16 * ZS; e += NTHR) {
         const int k = e % ZS;
         if (k < 32) s.zA[e] = to_bf16(k < STOCH ? s.ob[DET + k] : 0.f);
         else if (k >= 32 + ACT) s.zA[e] = 0;
     }
-    if (w < 5) recurrence_steps<true, W4ALL>(s, w, lane, base, n, horizon, Pg, actions, items, flag, stamps, stamp);
-    else recurrence_steps<false, W4ALL>(s, w, lane, base, n, horizon, Pg, actions, items, flag, stamps, stamp);
+    if (w < 5) recurrence_steps<true, TT>(s, w, lane, base, n, horizon, Pg, actions, items, tile_stride, flag, ntl, stamps, stamp);
+    else recurrence_steps<false, TT>(s, w, lane, base, n, horizon, Pg, actions, items, tile_stride, flag, ntl, stamps, stamp);
 }
 
 __device__ __forceinline__ void reward_head(ConsumerLds& s, int tile, int n, int horizon, int cost_mode,
@@ -388,14 +414,16 @@ __device__ __forceinline__ void reward_head(ConsumerLds& s, int tile, int n, int
         costs[tile * 16 + j] = gave_up ? __builtin_nanf("") : acc_cost;
 }
 
+// blocks [0, prods): recurrence of TT tiles each; blocks [prods, prods + tiles): the reward head of one tile each
+template <int TT>
 __global__ __launch_bounds__(NTHR) void rssm_split_kernel(int n, int horizon, int cost_mode, const unsigned short* __restrict__ Pg,
                                                          const float* __restrict__ obs0, const float* __restrict__ actions,
                                                          float* __restrict__ costs, unsigned short* stage, unsigned* flags, int tiles,
-                                                         long long* stamps) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+                                                         int prods, long long* stamps) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[lds_bytes<TT>()];
     const int b = blockIdx.x;
-    if (b < tiles) recurrence(*reinterpret_cast<ProducerLds*>(smem), b, n, horizon, Pg, obs0, actions, stage, flags, stamps);
-    else reward_head(*reinterpret_cast<ConsumerLds*>(smem), b - tiles, n, horizon, cost_mode, Pg, costs, stage, flags, stamps);
+    if (b < prods) recurrence<TT>(*reinterpret_cast<ProducerLds<TT>*>(smem), b, tiles, n, horizon, Pg, obs0, actions, stage, flags, stamps);
+    else reward_head(*reinterpret_cast<ConsumerLds*>(smem), b - prods, n, horizon, cost_mode, Pg, costs, stage, flags, stamps);
 }
 
 // One staging area per (device, stream): launches on a stream are ordered, so they may share it.
@@ -443,8 +471,15 @@ hipError_t launch_rssm_split(int n, int horizon, int cost_mode, const unsigned s
         }
         sg = s;
     }
-    hipLaunchKernelGGL(rssm_split_kernel, dim3(2 * tiles), dim3(NTHR), 0, st, n, horizon, cost_mode, params, obs0, actions, costs,
-                       sg.stage, sg.flags, tiles, g_stamps);
+    static const int tt = [] { const char* e = std::getenv("ICEM_RSSM_SPLIT_TT"); return e && e[0] == '2' ? 2 : 1; }();
+    if (tt == 2) {
+        const int prods = (tiles + 1) / 2;
+        hipLaunchKernelGGL(rssm_split_kernel<2>, dim3(prods + tiles), dim3(NTHR), 0, st, n, horizon, cost_mode, params, obs0, actions,
+                           costs, sg.stage, sg.flags, tiles, prods, g_stamps);
+    } else {
+        hipLaunchKernelGGL(rssm_split_kernel<1>, dim3(2 * tiles), dim3(NTHR), 0, st, n, horizon, cost_mode, params, obs0, actions, costs,
+                           sg.stage, sg.flags, tiles, tiles, g_stamps);
+    }
     return hipGetLastError();
 }
 }  // namespace icem
