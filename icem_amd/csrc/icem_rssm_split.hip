@@ -25,6 +25,7 @@ using namespace rssm_dev;
 
 constexpr int SR = 256;              // bf16 row of an item: [h: 7 k-blocks (200 + zero padding) | z: 1 k-block]
 constexpr int ITEM = 16 * SR;        // elements
+constexpr int XS = SR + 8;           // its row stride in the reward head's LDS (conflict-free operand reads)
 // two tiles per recurrence workgroup: resident chunks / ring slots of the two wave classes (accumulators take twice the room)
 constexpr int RES_A2 = 2, RING_A2 = 3, RES_B2 = 3, RING_B2 = 2;
 constexpr unsigned MAX_POLLS = 1u << 22;   // x s_sleep(2): a few hundred ms, then the reward workgroup gives up (costs = NaN)
@@ -41,8 +42,10 @@ struct ProducerLds {                       // TT tiles of 16 trajectories: rows 
     float ob[232];                         // obs0, parked once
 };
 struct ConsumerLds {
+    unsigned short x[2][16 * XS];          // the state at hand (ping-pong)
     unsigned short r1[2][16 * RS];
     unsigned short r2[2][16 * RS];
+    int gave_up;
 };
 template <int TT>
 constexpr size_t lds_bytes() { return sizeof(ProducerLds<TT>) > sizeof(ConsumerLds) ? sizeof(ProducerLds<TT>) : sizeof(ConsumerLds); }
@@ -359,6 +362,7 @@ __device__ __forceinline__ void reward_head(ConsumerLds& s, int tile, int n, int
     request<HIDK>(Plane + W8, A8);
     const v4f b8 = *reinterpret_cast<const v4f*>(reinterpret_cast<const float*>(Pg + B8) + 4 * g);
     for (int e = tid; e < 2 * 16 * RS; e += NTHR) { (&s.r1[0][0])[e] = 0; (&s.r2[0][0])[e] = 0; }   // the K padding of the rows
+    if (tid == 0) s.gave_up = 0;
     __syncthreads();
     const int xr = j * RS + 8 * g, xo = j * RS + 4 * g;
     float acc_cost = 0.f;
@@ -366,30 +370,36 @@ __device__ __forceinline__ void reward_head(ConsumerLds& s, int tile, int n, int
     if (stamp) stamps[9] = wall_clock64();
     for (int t = 0; t < horizon; ++t) {
         const int par = t & 1;
-        if (!gave_up) {
+        // one wave polls (the flag is read past L2: eight waves of 64 workgroups polling the same 256 bytes of memory
+        // are traffic the recurrence workgroups' own requests queue behind); the others wait at the barrier
+        if (w == 0 && !gave_up) {
             unsigned polls = 0;
             while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)(t + 1)) < 0) {
                 if (++polls > MAX_POLLS) { gave_up = true; break; }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(4);
             }
+            if (gave_up && lane == 0) s.gave_up = 1;
         }
+        __syncthreads();
         asm volatile("" ::: "memory");
         if (stamp && t == 5) stamps[10] = wall_clock64();
         if (stamp && t == horizon - 1) stamps[12] = wall_clock64();
-        const unsigned short* it = items + (size_t)t * ITEM + j * SR + 8 * g;
-        v4i X[K6K];
-#pragma unroll
-        for (int kb = 0; kb < K6K; ++kb) {
-            const unsigned long long lo = load_ag(it + kb * 32), hi = load_ag(it + kb * 32 + 4);
-            X[kb][0] = (int)(unsigned)lo; X[kb][1] = (int)(unsigned)(lo >> 32);
-            X[kb][2] = (int)(unsigned)hi; X[kb][3] = (int)(unsigned)(hi >> 32);
+        // the item once per workgroup (the loads go past L2: eight waves fetching the same 8 KB each cost more than a
+        // trip through LDS): thread e fetches 16 bytes
+        {
+            const unsigned short* it = items + (size_t)t * ITEM + tid * 8;
+            const unsigned long long lo = load_ag(it), hi = load_ag(it + 4);
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(s.x[par] + (tid >> 5) * XS + (tid & 31) * 8);
+            dst[0] = lo; dst[1] = hi;
         }
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < NOB; ++i) {
             v4f a = b6[i];
 #pragma unroll
             for (int kb = 0; kb < K6K; ++kb)
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, A6[i][kb]), __builtin_bit_cast(v8bf, X[kb]), a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, A6[i][kb]),
+                                                            __builtin_bit_cast(v8bf, *reinterpret_cast<const v4i*>(s.x[par] + j * XS + 8 * g + kb * 32)), a, 0, 0, 0);
             if (w + WAVES * i < 13) *reinterpret_cast<v4s*>(s.r1[par] + xo + own_block(w, i) * 16) = relu_pack(a);
         }
         __syncthreads();
@@ -411,7 +421,7 @@ __device__ __forceinline__ void reward_head(ConsumerLds& s, int tile, int n, int
     if (stamp) stamps[13] = wall_clock64();
     if (tid == 0) __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     if (w == WAVES - 1 && g == 0 && tile * 16 + j < n)
-        costs[tile * 16 + j] = gave_up ? __builtin_nanf("") : acc_cost;
+        costs[tile * 16 + j] = s.gave_up ? __builtin_nanf("") : acc_cost;
 }
 
 // blocks [0, prods): recurrence of TT tiles each; blocks [prods, prods + tiles): the reward head of one tile each
