@@ -1,17 +1,19 @@
-// Small populations of the recurrent state-space model rollout (icem_rssm.h), at most 128 tiles of 16 trajectories: the
-// fused kernel of icem_rssm.hip leaves three CUs in four idle there and every workgroup streams the reward head's
-// weights (W6, W7, W8: 0.2 of the 0.9 MB per model step) through its CU's L2 port on the recurrence's own critical path.
-// Here ONE launch holds two kinds of workgroups:
+// Populations of up to 4 096 trajectories (256 tiles of 16) of the recurrent state-space model rollout (icem_rssm.h).  The
+// fused kernel of icem_rssm.hip puts one workgroup per tile on a CU and streams ALL weights (0.9 MB per model step)
+// through that CU's L1, reward head included, on the recurrence's own critical path.  Here ONE launch holds two kinds
+// of workgroups:
 //   * blocks [0, tiles): the RECURRENCE of one tile -- x, GRU, p, z' per model step, four barriers, nothing else; the
 //     last of the `horizon` transitions is never run (a step's cost is the reward of the state it STARTS from);
-//   * blocks [tiles, 2 tiles): the REWARD HEAD of one tile on another CU, its weights loaded ONCE into registers
-//     (148 per lane), consuming the states (h_t, z_t) as the recurrence publishes them.
+//   * blocks [tiles, 2 tiles): the REWARD HEAD of one tile, its weights loaded ONCE into registers (148 per lane),
+//     consuming the states (h_t, z_t) as the recurrence publishes them.
 // State t of a tile travels through an 8 KB item in global memory: wave 7 of the recurrence workgroup -- which owns one
 // GRU output block where waves 0..4 own two -- copies [h_t | z_t] out of LDS during phase 2 of step t with written-through
 // stores, waits for them itself and raises the tile's flag to t + 1; no other wave ever waits for a store.  The reward
-// workgroup polls the flag, reads the item with agent-scope loads straight into B operands, and resets the flag to 0
+// workgroup polls the flag (one wave), reads the item with agent-scope loads (once, into LDS), and resets the flag to 0
 // behind the last item (so a captured launch can be replayed).  Producers have the lower block indices: they are all
-// resident before the first consumer is dispatched and they wait for nobody.
+// dispatched before the first consumer and they wait for nobody -- up to 128 tiles both kinds are resident together
+// (a reward workgroup runs a few microseconds behind its recurrence); beyond that the reward workgroups take the CUs the
+// recurrence workgroups leave and find their states waiting.
 // The arithmetic, its order and its rounding points are those of rssm_rollout_kernel<1>: costs are bit-identical.
 #include "rssm_dev.h"
 
@@ -451,7 +453,12 @@ void rssm_set_stamps(long long* dev_ptr) { g_stamps = dev_ptr; }
 
 bool rssm_split_ok(int n, int horizon) {
     static const bool on = [] { const char* e = std::getenv("ICEM_RSSM_SPLIT"); return !(e && e[0] == '0'); }();
-    return on && n > 0 && horizon >= 1 && (n + 15) / 16 <= rssm::SPLIT_MAX_TILES;
+    static const int max_tiles = [] {   // (development: ICEM_RSSM_SPLIT_MAX_N moves the population limit)
+        const char* e = std::getenv("ICEM_RSSM_SPLIT_MAX_N");
+        const int v = e ? std::atoi(e) / 16 : rssm::SPLIT_MAX_TILES;
+        return v < 1 ? 1 : v > rssm::SPLIT_TILE_LIMIT ? rssm::SPLIT_TILE_LIMIT : v;
+    }();
+    return on && n > 0 && horizon >= 1 && (n + 15) / 16 <= max_tiles;
 }
 
 hipError_t launch_rssm_split(int n, int horizon, int cost_mode, const unsigned short* params, const float* obs0,
@@ -464,7 +471,7 @@ hipError_t launch_rssm_split(int n, int horizon, int cost_mode, const unsigned s
     {
         std::lock_guard<std::mutex> lk(g_mu);
         Staging& s = g_staging[{dev, st}];
-        const size_t want = (size_t)rssm::SPLIT_MAX_TILES * horizon;
+        const size_t want = (size_t)(tiles > rssm::SPLIT_MAX_TILES ? tiles : rssm::SPLIT_MAX_TILES) * horizon;
         if (s.items < want) {   // (first call on this stream, or a longer horizon: not inside a capture)
             if (s.stage) {
                 if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
@@ -476,8 +483,8 @@ hipError_t launch_rssm_split(int n, int horizon, int cost_mode, const unsigned s
             s.items = want;
         }
         if (!s.flags) {
-            if ((e = hipMalloc(&s.flags, rssm::SPLIT_MAX_TILES * sizeof(unsigned))) != hipSuccess) return e;
-            if ((e = hipMemset(s.flags, 0, rssm::SPLIT_MAX_TILES * sizeof(unsigned))) != hipSuccess) return e;
+            if ((e = hipMalloc(&s.flags, rssm::SPLIT_TILE_LIMIT * sizeof(unsigned))) != hipSuccess) return e;
+            if ((e = hipMemset(s.flags, 0, rssm::SPLIT_TILE_LIMIT * sizeof(unsigned))) != hipSuccess) return e;
         }
         sg = s;
     }
