@@ -2,6 +2,7 @@
 // ValueError / AttributeError / NotImplementedError cases as ICEM_E_* codes), the host-side colored-noise tables,
 // model / cost registration; the kernels behind the operators live in generic_kernels.hip (gk_*) and k_*.hip.
 #include "host_common.h"
+#include "cost_terms_dev.h"
 #include "icem_rssm.h"
 
 using namespace icem;
@@ -174,6 +175,7 @@ int icem_destroy(icem_handle* h) {
     if (h->B_dev) (void)hipFree(h->B_dev);
     if (h->Mp_dev) (void)hipFree(h->Mp_dev);
     if (h->Mw_dev) (void)hipFree(h->Mw_dev);
+    if (h->wide_cs_dev) (void)hipFree(h->wide_cs_dev);
     if (h->pub_dev) (void)hipFree(h->pub_dev);
     if (h->perm_dev) (void)hipFree(h->perm_dev);
     for (auto& sp : h->spans) {
@@ -206,12 +208,6 @@ int icem_set_model(icem_handle* h, int32_t kind, int32_t obs_dim, const double* 
         // wide observations (HumanoidStandup's real o = 378, mujoco.py:241-252): the f32 GEMM rollout only
         if (h->cfg.dtype != ICEM_F32 || !wide_rollout_supported(obs_dim, d, 1))
             return fail(ICEM_E_UNSUPPORTED, "obs_dim in (32, 384] needs dtype f32 (k_rollout_wide); beyond 384 is not compiled");
-        if (h->has_terms) {
-            h->wide = true;
-            const char* e = wide_unsupported(h, h->cfg.num_elites, false, false);
-            h->wide = false;
-            return fail(ICEM_E_UNSUPPORTED, e);
-        }
         if (h->cfg.num_elites > 32) return fail(ICEM_E_UNSUPPORTED, "obs_dim > 32 needs num_elites <= 32 (candidate lists of k_rollout_wide)");
         if (h->A_dev) (void)hipFree(h->A_dev);
         if (h->B_dev) (void)hipFree(h->B_dev);
@@ -248,12 +244,23 @@ int icem_set_model(icem_handle* h, int32_t kind, int32_t obs_dim, const double* 
     return ICEM_OK;
 }
 
+// the device copy of the cost the wide rollout kernels read when cost terms are on (by value in the argument block it
+// costs them 200 spilled scalar registers -- and 9 % of a launch -- whether a term is on or not)
+static int sync_wide_cost(icem_handle* h) {
+    if (!h->has_terms) return ICEM_OK;
+    CostArgs<float> cs;
+    fill_cost_args_f32(h, cs);
+    if (!h->wide_cs_dev) ICEM_HIP_TRY(hipMalloc(&h->wide_cs_dev, sizeof(cs)));
+    ICEM_HIP_TRY(hipMemcpy(h->wide_cs_dev, &cs, sizeof(cs), hipMemcpyHostToDevice));
+    return ICEM_OK;
+}
+
 int icem_set_cost(icem_handle* h, const icem_cost_spec* spec) {
     if (!h || !spec) return fail(ICEM_E_INVALID, "null argument");
     h->cost = *spec;
     h->has_cost = true;
     h->fast_model_ready = false;
-    return ICEM_OK;
+    return sync_wide_cost(h);
 }
 
 int icem_set_cost_terms(icem_handle* h, const icem_cost_terms* terms) {
@@ -271,16 +278,9 @@ int icem_set_cost_terms(icem_handle* h, const icem_cost_terms* terms) {
     if (terms->box_from >= 0 && terms->health_idx < 0)
         return fail(ICEM_E_INVALID, "box_from is part of the health term: health_idx must be set");
     const bool on = terms->diff_idx >= 0 || terms->health_idx >= 0 || terms->n_terms > 0;
-    if (on && h->wide && h->has_model) {  // (icem_trajectory_cost works without a built-in model: no conflict there)
-        const bool was = h->has_terms;
-        h->has_terms = true;
-        const char* e = wide_unsupported(h, h->cfg.num_elites, false, false);
-        h->has_terms = was;
-        return fail(ICEM_E_UNSUPPORTED, e);
-    }
     h->terms = *terms;
     h->has_terms = on;
-    return ICEM_OK;
+    return sync_wide_cost(h);
 }
 
 int icem_trajectory_cost(icem_handle* h, int32_t n, int32_t obs_dim, const void* observations,

@@ -13,15 +13,13 @@
 // Kernels (one section each): sample_clip (K1), rollout_cost (K2), block top-k (K3),
 // local_pack / merge_refit (K3+K4 of the fused step), small epilogue kernels.
 #include "host_common.h"
+#include "cost_terms_dev.h"
 #include "exchange_dev.h"
 #include "philox.h"
 #include "refit.h"
 
 namespace icem {
 
-// __builtin_fma is the DOUBLE fma: route by type so the f32 kernels stay in f32.
-__device__ __forceinline__ float fmad(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-__device__ __forceinline__ double fmad(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 template <typename T>
 __device__ __forceinline__ T inf_v() {
@@ -239,66 +237,6 @@ __global__ __launch_bounds__(WG) void philox_normals_kernel(SampleArgs<T> a, T* 
 // ---------------------------------------------------------------------------------------------
 // One thread per trajectory; the observation lives in registers (O compile-time, zero padded),
 // the model matrices are wave-uniform operands.  Cost is scored on the PRE-action observation.
-
-template <typename T>
-struct CostArgs {
-    T ctrl_w, lin_w, flip_pen, flip_th;
-    int lin_idx, flip_idx;
-    // icem_cost_terms (include/icem_hip.h); ext = any of them on
-    T diff_w, health_pen, health_lo, health_hi, box_lo, box_hi;
-    int ext, diff_idx, health_idx, health_closed, box_from, n_terms;
-    struct Term {
-        T w, th, gate_th;
-        int kind, a, b, len, gate_idx;
-    } terms[ICEM_MAX_COST_TERMS];
-};
-
-__device__ __forceinline__ bool finite_val(float x) { return fabsf(x) <= FLT_MAX; }    // false for NaN / inf
-__device__ __forceinline__ bool finite_val(double x) { return fabs(x) <= DBL_MAX; }
-__device__ __forceinline__ float sqrt_val(float x) { return sqrtf(x); }
-__device__ __forceinline__ double sqrt_val(double x) { return sqrt(x); }
-
-// The extra terms of one step given accessors for the pre- and post-action observation; `bad` = some observation
-// entry is non-finite or outside Hopper's state box (computed by the caller, who owns the sweep over the row).
-template <typename T, typename Obs, typename Nxt>
-__device__ __forceinline__ T cost_terms(const CostArgs<T>& cs, bool bad, Obs obs, Nxt nxt) {
-    T c = (T)0;
-    if (cs.diff_idx >= 0) c += cs.diff_w * (nxt(cs.diff_idx) - obs(cs.diff_idx));
-    if (cs.health_idx >= 0) {
-        const T z = obs(cs.health_idx);
-        const bool in = cs.health_closed ? (cs.health_lo <= z && z <= cs.health_hi) : (cs.health_lo < z && z < cs.health_hi);
-        c += (in && !bad) ? (T)0 : cs.health_pen;
-    }
-    // static term indices: a runtime index into the by-value argument block would move it to scratch
-#pragma unroll
-    for (int j = 0; j < ICEM_MAX_COST_TERMS; ++j) {
-        if (j >= cs.n_terms) break;
-        const typename CostArgs<T>::Term& tm = cs.terms[j];
-        T f;
-        if (tm.kind == ICEM_TERM_STEP_GT) {
-            f = obs(tm.a) > tm.th ? (T)1 : (T)0;
-        } else if (tm.kind == ICEM_TERM_SQ_OFFSET) {
-            const T v = obs(tm.a) - tm.th;
-            f = v * v;
-        } else {
-            T acc = (T)0;
-            for (int m = 0; m < tm.len; ++m) {
-                T v = obs(tm.a + m);
-                if (tm.b >= 0) v -= obs(tm.b + m);
-                acc = fmad(v, v, acc);
-            }
-            if (tm.kind == ICEM_TERM_SUMSQ) {
-                f = acc;
-            } else {
-                const T r = sqrt_val(acc);
-                f = tm.kind == ICEM_TERM_NORM ? r : tm.kind == ICEM_TERM_NORM_GT ? (r > tm.th ? (T)1 : (T)0) : (r < tm.th ? (T)1 : (T)0);
-            }
-        }
-        if (tm.gate_idx >= 0) f *= obs(tm.gate_idx) > tm.gate_th ? (T)1 : (T)0;  // a product, as in the reference (NaN * 0 = NaN)
-        c += tm.w * f;
-    }
-    return c;
-}
 
 template <typename T>
 struct RolloutArgs {
@@ -916,6 +854,8 @@ void fill_cost_args(const icem_handle* h, CostArgs<T>& cs) {
         cs.terms[j].gate_idx = tm.gate_idx;
     }
 }
+
+void fill_cost_args_f32(const icem_handle* h, CostArgs<float>& cs) { fill_cost_args<float>(h, cs); }
 
 // every index a cost term reads lies inside an observation of width o
 const char* cost_indices_error(const icem_handle* h, int o) {

@@ -94,6 +94,7 @@ struct icem_handle {
     // permuted, padded model of the matrix-pipe rollout: column 0 = obs[lin_idx], column 1 = obs[flip_idx]
     bool wide = false;           // obs_dim > 32: the rollout is k_rollout_wide.hip's GEMM kernel (f32 only)
     void* Mw_dev = nullptr;      // its packed model
+    void* wide_cs_dev = nullptr; // CostArgs<float> (cost spec + terms) for k_rollout_wide, refreshed by the cost setters
     void* Mp_dev = nullptr;
     void* perm_dev = nullptr;
     int flip_col = -1;
@@ -253,10 +254,6 @@ void xchg_destroy(icem_handle* h);
 // icem_set_model / icem_set_cost_terms up front and by icem_rollout_cost / check_plan at use.
 inline const char* wide_unsupported(const icem_handle* h, int K, bool external_noise, bool want_observations) {
     if (!h->wide) return nullptr;
-    if (h->has_terms)
-        return "obs_dim > 32 with icem_set_cost_terms: the built-in-model rollout at this width (k_rollout_wide) scores the "
-               "HalfCheetah / HumanoidStandup cost form only; roll the model out as a torch module (TorchForwardModel) and score "
-               "it with icem_trajectory_cost, which takes every cost term at any width";
     if (K > 32) return "obs_dim > 32 needs num_elites <= 32 (candidate lists of k_rollout_wide)";
     if (external_noise) return "obs_dim > 32 has no external-noise (z_r / z_i) path: the wide rollout is f32 with device noise only";
     if (want_observations) return "obs_dim > 32: icem_rollout_cost returns costs only at this width (observations == NULL)";

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <vector>
+#include "cost_args.h"
 
 namespace icem {
 
@@ -90,6 +91,7 @@ struct WideRolloutArgs {
     int cost_mode;
     int lin_idx, flip_idx;
     float ctrl_w, lin_w, flip_pen, flip_th;
+    const CostArgs<float>* cs;   // icem_cost_terms on: the same + the terms, in device memory (NULL: off)
     const float* Mp;      // pack_wide_model
     const float* obs0;
     const float* actions;

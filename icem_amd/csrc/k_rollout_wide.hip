@@ -21,6 +21,7 @@
 // (A bf16 x 3-plane split on v_mfma_f32_16x16x32_bf16 would need 94 B/clk of model operands per CU at this tiling --
 // more than the L2 port delivers: DESIGN.md section 4.)
 #include "fused_dev.h"
+#include "cost_terms_dev.h"
 
 namespace icem {
 
@@ -28,7 +29,64 @@ namespace {
 
 constexpr int WIDE_WAVES = 4;
 
-template <int NT, int KIND, int WAVES>
+// The step cost of one trajectory from its PRE-action contraction vector x = [obs (o) | action (d)], shared by the tile
+// kernel and the row kernel (the same expression, so a row costs the same bits whichever of them scores it):
+// icem_cost_spec, then -- cs.ext -- the icem_cost_terms that read the pre-action observation (health, the term list;
+// `bad` = some entry of the observation is non-finite or outside the state box: the caller owns that sweep).  The
+// difference term reads the NEXT observation, which these kernels write over x: `dold` takes obs[diff_idx] and the
+// caller adds wide_diff_cost() once the step is done, before it accumulates.  The icem_cost_spec part travels by value
+// (WideCost); the terms sit in device memory behind a pointer that is NULL when none is on and are copied to LDS once per
+// workgroup.  By value in the argument block they cost the tile kernel 200 spilled scalar registers, and read through
+// the pointer inside the step loop they left vector-memory loads pending on one path into the model loop, whose
+// two-blocks-ahead requests then sat behind a vmcnt(0): 9 % of a launch either way, terms on or not (measured).
+__device__ __forceinline__ void wide_stage_terms(CostArgs<float>& dst, const CostArgs<float>* src, int tid, int nthr) {
+    if (src != nullptr)
+        for (int e = tid; e < (int)(sizeof(CostArgs<float>) / 4); e += nthr)
+            reinterpret_cast<int*>(&dst)[e] = reinterpret_cast<const int*>(src)[e];
+    __syncthreads();
+}
+struct WideCost {
+    int lin_idx, flip_idx;
+    float ctrl_w, lin_w, flip_pen, flip_th;
+};
+__device__ __forceinline__ float wide_step_cost(const WideCost& b, bool ext, const CostArgs<float>& cs, const float* x, int o, int d,
+                                                bool bad, float& dold) {
+    float c = 0.f;
+    if (b.flip_idx >= 0) {
+        const float ang = x[b.flip_idx];
+        c += (ang > b.flip_th) ? b.flip_pen : 0.f;
+        c += (ang < -b.flip_th) ? b.flip_pen : 0.f;
+    }
+    float u = 0.f;
+    for (int e = 0; e < d; ++e) u = __builtin_fmaf(x[o + e], x[o + e], u);
+    c = __builtin_fmaf(u, b.ctrl_w, c);
+    if (b.lin_w != 0.f) c = __builtin_fmaf(b.lin_w, x[b.lin_idx], c);  // a zero weight drops the term (icem_cost_spec)
+    if (ext) {
+        c += cost_terms<float, false>(cs, bad, [&](int idx) { return x[idx]; }, [&](int idx) { return x[idx]; });
+        dold = cs.diff_idx >= 0 ? x[cs.diff_idx] : 0.f;
+    }
+    return c;
+}
+__device__ __forceinline__ float wide_diff_cost(const CostArgs<float>& cs, float next, float dold) {
+    return cs.diff_w * (next - dold);
+}
+__device__ __forceinline__ bool wide_bad_entry(const CostArgs<float>& cs, float v, int k) {
+    bool bad = !finite_val(v);
+    if (cs.box_from >= 0 && k >= cs.box_from) bad |= !(cs.box_lo < v && v < cs.box_hi);
+    return bad;
+}
+// sum / best / final over the steps (np.amin: a NaN step cost makes the trajectory's cost NaN)
+__device__ __forceinline__ float wide_accumulate(float acc, float c, int t, int cost_mode) {
+    if (t == 0 || cost_mode == 2) return c;
+    if (cost_mode == 0) return acc + c;
+    return (c < acc || c != c) ? c : acc;
+}
+
+// EXT: icem_cost_terms on.  Its own instantiation: the model loop below is scheduled to the register -- with the terms'
+// code merely PRESENT (never executed) the allocator moved an in-flight model operand, which is a wait for all requests
+// in flight, and every launch was 9 % slower (1 358 -> 1 466 us at o = 378, N = 16 384), whatever was tried to keep the
+// terms out of the loop's live set.
+template <int NT, int KIND, int WAVES, bool EXT>
 __global__ __launch_bounds__(64 * WAVES) void rollout_wide_kernel(WideRolloutArgs a) {
     extern __shared__ __attribute__((aligned(16))) float xs_all[];  // [WAVES][16][XS]
     __shared__ unsigned long long wg_keys[2][WAVES][32];
@@ -39,8 +97,11 @@ __global__ __launch_bounds__(64 * WAVES) void rollout_wide_kernel(WideRolloutArg
     const int XS = a.xs, KB = a.kb, o = a.o, d = a.d, H = a.h;
     float* X = xs_all + (size_t)wave * 16 * XS;
     const float4* __restrict__ Mp = reinterpret_cast<const float4*>(a.Mp);
-    const float ksum = a.cost_mode == 0 ? 1.f : 0.f;  // sum: acc = acc + c; final: acc = c
-    const bool use_min = a.cost_mode == 1;
+    const WideCost wc{a.lin_idx, a.flip_idx, a.ctrl_w, a.lin_w, a.flip_pen, a.flip_th};
+    __shared__ CostArgs<float> cs_s;
+    __shared__ float park[WAVES][32];
+    constexpr bool ext = EXT;
+    if (EXT) wide_stage_terms(cs_s, a.cs, threadIdx.x, 64 * WAVES);
     unsigned long long run_key = KEY_SENTINEL;
     bool first = true;
     const int tiles = (a.n_rows + 15) / 16;
@@ -51,7 +112,7 @@ __global__ __launch_bounds__(64 * WAVES) void rollout_wide_kernel(WideRolloutArg
             const int c = e % XS;
             X[e] = c < o ? a.obs0[c] : 0.f;
         }
-        float acc_s = 0.f, acc_b = INFINITY;
+        float acc_c = 0.f;
         for (int t = 0; t < H; ++t) {
             // this step's actions -> X[:, o .. o + d)
             for (int e = lane; e < 16 * d; e += 64) {
@@ -62,20 +123,28 @@ __global__ __launch_bounds__(64 * WAVES) void rollout_wide_kernel(WideRolloutArg
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (lane < 16) {  // step cost of trajectory `lane` from the pre-action observation
-                const float* x = X + lane * XS;
-                float c = 0.f;
-                if (a.flip_idx >= 0) {
-                    const float ang = x[a.flip_idx];
-                    c += (ang > a.flip_th) ? a.flip_pen : 0.f;
-                    c += (ang < -a.flip_th) ? a.flip_pen : 0.f;
+            // step cost of trajectory `lane` (lanes 0..15) from the pre-action observation; with cost terms that need the
+            // whole row (finite check / state box) lane (j, g) sweeps entries g, g + 4, .. of row j first
+            bool bad = false;
+            if (ext && cs_s.health_idx >= 0) {
+                const float* xj = X + j * XS;
+                bool b = false;
+                for (int k = g; k < o; k += 4) b |= wide_bad_entry(cs_s, xj[k], k);
+                const unsigned long long m = __ballot(b);
+                bad = ((m >> (lane & 15)) & 0x0001000100010001ull) != 0ull;
+            }
+            // (nothing of the cost may stay in registers across the model loop below: two more live values and the
+            // register allocator moves an in-flight model operand, i.e. waits for ALL requests -- 9 % of a launch.  With a
+            // difference term the step's partial cost and obs[diff_idx] are parked in LDS instead.)
+            const bool diff = ext && cs_s.diff_idx >= 0;
+            {
+                float c_step = 0.f, dold = 0.f;
+                if (lane < 16) c_step = wide_step_cost(wc, ext, cs_s, X + lane * XS, o, d, bad, dold);
+                if (diff) {
+                    if (lane < 16) { park[wave][lane] = c_step; park[wave][16 + lane] = dold; }
+                } else {
+                    acc_c = wide_accumulate(acc_c, c_step, t, a.cost_mode);
                 }
-                float u = 0.f;
-                for (int e = 0; e < d; ++e) u = __builtin_fmaf(x[o + e], x[o + e], u);
-                c = __builtin_fmaf(u, a.ctrl_w, c);
-                if (a.lin_w != 0.f) c = __builtin_fmaf(a.lin_w, x[a.lin_idx], c);  // a zero weight drops the term (icem_cost_spec)
-                acc_s = __builtin_fmaf(acc_s, ksum, c);
-                acc_b = c < acc_b ? c : acc_b;
             }
             f32x4 acc[NT];
 #pragma unroll
@@ -134,8 +203,16 @@ __global__ __launch_bounds__(64 * WAVES) void rollout_wide_kernel(WideRolloutArg
                 if (col < o) *reinterpret_cast<f32x4*>(X + j * XS + col) = v;
             }
             // (a last column group that straddles o also zeroes the first action slots: they are reloaded next step)
+            if (diff) {   // the term that reads the observation just written
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                float c_step = 0.f;
+                if (lane < 16) c_step = park[wave][lane] + wide_diff_cost(cs_s, X[lane * XS + cs_s.diff_idx], park[wave][16 + lane]);
+                acc_c = wide_accumulate(acc_c, c_step, t, a.cost_mode);
+            }
         }
-        const float cost = use_min ? acc_b : acc_s;
+        const float cost = acc_c;
         const int row = row0 + (lane & 15);
         const bool live = row < a.n_rows;
         if (live && lane < 16) a.costs[row] = cost;
@@ -162,8 +239,9 @@ __global__ __launch_bounds__(64 * WAVES) void rollout_wide_kernel(WideRolloutArg
 // open a 16-row tile of their own: at N = 16 384 that tile is number 1 025 on 1 024 wavefront slots and doubles the
 // launch (2.47 instead of 1.26 ms); these rows take ~0.1 ms.
 struct WideRowsArgs {
-    int row0, n_tail, o, d, h, cost_mode, lin_idx, flip_idx;
-    float ctrl_w, lin_w, flip_pen, flip_th;
+    int row0, n_tail, o, d, h, cost_mode;
+    WideCost wc;
+    const CostArgs<float>* cs;
     const float* A;  // [o, o] row-major
     const float* B;  // [d, o]
     const float* obs0;
@@ -177,26 +255,22 @@ __global__ __launch_bounds__(384) void rollout_rows_wide_kernel(WideRowsArgs a) 
     const int c = threadIdx.x, o = a.o, d = a.d, H = a.h;
     const int row = a.row0 + blockIdx.x;
     x[0][c] = c < o ? a.obs0[c] : 0.f;
-    const float ksum = a.cost_mode == 0 ? 1.f : 0.f;
-    float acc_s = 0.f, acc_b = INFINITY;
+    __shared__ CostArgs<float> cs_s;
+    const bool ext = a.cs != nullptr;
+    wide_stage_terms(cs_s, a.cs, threadIdx.x, 384);
+    const bool sweep = ext && cs_s.health_idx >= 0, diff = ext && cs_s.diff_idx >= 0;
+    float acc_c = 0.f, c_step = 0.f, dold = 0.f;
     for (int t = 0; t < H; ++t) {
         float* xc = x[t & 1];
         if (c < d) xc[o + c] = a.actions[((size_t)row * H + t) * d + c];
         __syncthreads();
-        if (c == 0) {  // step cost from the pre-action observation, rollout_wide_kernel's expression
-            float cst = 0.f;
-            if (a.flip_idx >= 0) {
-                const float ang = xc[a.flip_idx];
-                cst += (ang > a.flip_th) ? a.flip_pen : 0.f;
-                cst += (ang < -a.flip_th) ? a.flip_pen : 0.f;
-            }
-            float u = 0.f;
-            for (int e = 0; e < d; ++e) u = __builtin_fmaf(xc[o + e], xc[o + e], u);
-            cst = __builtin_fmaf(u, a.ctrl_w, cst);
-            if (a.lin_w != 0.f) cst = __builtin_fmaf(a.lin_w, xc[a.lin_idx], cst);
-            acc_s = __builtin_fmaf(acc_s, ksum, cst);
-            acc_b = cst < acc_b ? cst : acc_b;
+        if (c == 0 && t > 0) {   // the previous step's cost is complete now that its next observation is visible
+            if (diff) c_step += wide_diff_cost(cs_s, xc[cs_s.diff_idx], dold);
+            acc_c = wide_accumulate(acc_c, c_step, t - 1, a.cost_mode);
         }
+        bool bad = false;
+        if (sweep) bad = __syncthreads_or(c < o && wide_bad_entry(cs_s, xc[c], c)) != 0;
+        if (c == 0) c_step = wide_step_cost(a.wc, ext, cs_s, xc, o, d, bad, dold);   // rollout_wide_kernel's expression
         if (c < o) {
             float acc = 0.f;
             const float* Ac = a.A + c;
@@ -208,7 +282,11 @@ __global__ __launch_bounds__(384) void rollout_rows_wide_kernel(WideRowsArgs a) 
             x[(t & 1) ^ 1][c] = KIND == 1 ? fast_tanh(acc) : acc;
         }
     }
-    if (c == 0) a.costs[row] = a.cost_mode == 1 ? acc_b : acc_s;
+    __syncthreads();
+    if (c == 0) {
+        if (diff) c_step += wide_diff_cost(cs_s, x[H & 1][cs_s.diff_idx], dold);
+        a.costs[row] = wide_accumulate(acc_c, c_step, H - 1, a.cost_mode);
+    }
 }
 
 }  // namespace
@@ -244,28 +322,31 @@ void launch_rollout_wide(const WideRolloutArgs& a, int kind, hipStream_t st) {
     const int grid = wide_rollout_lists(a.n_rows);
     const size_t lds = (size_t)WIDE_WAVES * 16 * a.xs * sizeof(float);
     const int NT = wide_nt(a.o);
+#define XW1(NTV, KINDV, EXTV)                                                                                         \
+    {                                                                                                                 \
+        auto kfn = rollout_wide_kernel<NTV, KINDV, WIDE_WAVES, EXTV>;                                                 \
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * WIDE_WAVES), lds, st, a);                                       \
+    }
 #define XW(NTV)                                                                                                       \
     if (NT == NTV) {                                                                                                  \
         if (kind == 1) {                                                                                              \
-            auto kfn = rollout_wide_kernel<NTV, 1, WIDE_WAVES>;                                                       \
-            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-            hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * WIDE_WAVES), lds, st, a);                                   \
+            if (a.cs) XW1(NTV, 1, true) else XW1(NTV, 1, false)                                                       \
         } else {                                                                                                      \
-            auto kfn = rollout_wide_kernel<NTV, 0, WIDE_WAVES>;                                                       \
-            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-            hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * WIDE_WAVES), lds, st, a);                                   \
+            if (a.cs) XW1(NTV, 0, true) else XW1(NTV, 0, false)                                                       \
         }                                                                                                             \
         return;                                                                                                       \
     }
     XW(4) XW(8) XW(16) XW(24)
 #undef XW
+#undef XW1
 }
 
 void launch_rollout_rows_wide(const WideRolloutArgs& w, int row0, int n_tail, const float* A, const float* B, int kind,
                               hipStream_t st) {
     if (n_tail <= 0) return;
-    WideRowsArgs a{row0, n_tail, w.o, w.d, w.h, w.cost_mode, w.lin_idx, w.flip_idx, w.ctrl_w, w.lin_w, w.flip_pen, w.flip_th,
-                   A, B, w.obs0, w.actions, w.costs};
+    WideRowsArgs a{row0, n_tail, w.o, w.d, w.h, w.cost_mode, WideCost{w.lin_idx, w.flip_idx, w.ctrl_w, w.lin_w, w.flip_pen, w.flip_th},
+                   w.cs, A, B, w.obs0, w.actions, w.costs};
     if (kind == 1)
         hipLaunchKernelGGL((rollout_rows_wide_kernel<1>), dim3(n_tail), dim3(384), 0, st, a);
     else

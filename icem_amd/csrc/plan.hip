@@ -4,6 +4,7 @@
 // where a sharded rank's record pack rides (own launch or workgroup 0 of the next local launch), which trailing
 // shifted-elite rows go around the candidate lists, and which of the ping-pong buffers each launch reads and writes.  No device code here except the result publisher.
 #include "host_common.h"
+#include "cost_terms_dev.h"
 
 using namespace icem;
 
@@ -87,7 +88,7 @@ int ensure_fast_model(icem_handle* h) {
 }
 
 bool fast_rollout_ok(const icem_handle* h, int K) {
-    if (h->has_terms) return false;  // the extra cost terms live in the general kernel
+    if (h->has_terms && !h->wide) return false;  // o <= 32: the extra cost terms live in the general kernel (k_rollout_wide has them)
     if (h->cost.lin_weight == 0.0 && !h->wide) return false;  // ... and so does a cost without the linear term (dropped, not 0 * obs)
     if (h->wide)  // (the only rollout there is at this width: ICEM_DISABLE_FAST does not apply)
         return h->cfg.dtype == ICEM_F32 && h->has_model && h->has_cost && wide_rollout_supported(h->obs_dim, h->cfg.act_dim, K);
@@ -153,6 +154,7 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
         w.lin_w = (float)h->cost.lin_weight;
         w.flip_pen = (float)h->cost.flip_penalty;
         w.flip_th = (float)h->cost.flip_thresh;
+        w.cs = h->has_terms ? (const CostArgs<float>*)h->wide_cs_dev : nullptr;
         w.Mp = (const float*)h->Mw_dev;
         w.obs0 = (const float*)obs0;
         w.actions = (const float*)actions;

@@ -171,11 +171,13 @@ int icem_noise_tables_host(int32_t horizon, double beta, double* cr_host, double
  * arrays; they are converted to the handle dtype and copied to the device.  `kind` = ICEM_MODEL_*.
  * obs_dim <= 32: every kernel family (f32 / f64).  32 < obs_dim <= 384 (HumanoidStandup's o = 378,
  * environments/mujoco.py:241-252): dtype f32 only, the model step runs as an exact-f32 GEMM on the matrix pipe
- * (icem_rollout_cost without `observations`, icem_plan_*); cost = icem_set_cost's form, no icem_set_cost_terms. */
+ * (icem_rollout_cost without `observations`, icem_plan_*); cost = icem_set_cost's form + icem_set_cost_terms
+ * (Ant's o = 111/113, Humanoid's 376, Door / Relocate's 39: mujoco.py:151-171, 317-343, mjenvs.py:57-78, 155-174). */
 int icem_set_model(icem_handle* h, int32_t kind, int32_t obs_dim, const double* A_host, const double* B_host);
 int icem_set_cost(icem_handle* h, const icem_cost_spec* spec);
 /* Extra cost terms (NULL switches them off again).  With any of them on, icem_rollout_cost / icem_plan_* evaluate
- * the cost in the general rollout kernel (one thread per trajectory, obs_dim <= 32). */
+ * the cost in the general rollout kernel (one thread per trajectory) for obs_dim <= 32 and inside the matrix-pipe
+ * rollout of k_rollout_wide.hip for 32 < obs_dim <= 384. */
 int icem_set_cost_terms(icem_handle* h, const icem_cost_terms* terms);
 
 /* ---- stateless operators (each replaces one NumPy call site) ------------------------------ */

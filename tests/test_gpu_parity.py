@@ -1092,6 +1092,73 @@ def test_rollout_and_plan_with_cost_terms(env_name, dtype):
     np.testing.assert_allclose(np_(pl.mean), orc.mean, rtol=1e-9, atol=1e-11)
 
 
+@pytest.mark.parametrize("env_name", ["ant", "humanoid", "door", "relocate"])
+def test_wide_rollout_with_cost_terms(env_name):
+    """The built-in model at observation widths 32 < o <= 384 WITH the extra cost terms (k_rollout_wide.hip: the tile kernel
+    on the f32 matrix pipe and the row kernel that scores trailing shifted elites): Ant (o = 113: difference term read
+    from the NEXT observation, closed health range, finite check over the whole row), Humanoid (o = 376: open health
+    range), Door and Relocate (o = 39: norms, gated norms, offsets, step bonuses).  icem_rollout_cost against the float64
+    oracle rollout; then whole MPC steps, whose last pool -- tile rows and row-kernel rows -- is re-scored by the oracle."""
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner
+    from icem_amd import envs as E
+    if env_name == "ant":   # ranges moved to where the synthetic latent lives: healthy and unhealthy steps both occur
+        env, spec = E.ant_env(healthy_z_range=(-0.05, 1.0)), O.CostSpec.ant(healthy_z_range=(-0.05, 1.0))
+    elif env_name == "humanoid":
+        env, spec = E.humanoid_env(healthy_z_range=(-0.05, 2.0)), O.CostSpec.humanoid(healthy_z_range=(-0.05, 2.0))
+    elif env_name == "door":
+        env, spec = E.door_env(), O.CostSpec.door()
+    else:
+        env, spec = E.relocate_env(), O.CostSpec.relocate()
+    o, d = env.obs_dim, env.action_space.shape[0]
+    assert o > 32
+    h, N, iters = 12, 16 * 40, 3
+    model = DeviceSyntheticModel.make(o, d, kind=1)
+    pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=N, opt_iters=iters, dtype="f32", seed=7),
+                     env.action_space.low, env.action_space.high)
+    pl.set_model(model.kind, model.A, model.B)
+    pl.set_cost_spec(env.cost_spec)
+    pl.reset()
+    om = O.SyntheticModel(model.A, model.B, model.kind)
+    rs = np.random.RandomState(3)
+    obs0 = 0.2 * rs.randn(o)
+    acts = rs.uniform(-1, 1, (257, h, d)) * env.action_space.high
+    got = np_(pl.rollout_cost(obs0, torch.as_tensor(acts, dtype=pl.dt, device=pl.device)))
+    want = O.rollout_costs(om, spec, obs0, acts).astype(np.float64)
+
+    def close(a, b):   # an f32 tanh one ulp off can move a step across a threshold: a few whole-penalty mismatches
+        return np.abs(a - b) <= 1e-4 * (1 + np.abs(b))
+    assert close(got, want).mean() > 0.98, (np.abs(got - want).max(), close(got, want).mean())
+    if env_name in ("ant", "humanoid"):   # no, some and many unhealthy steps are all in the batch
+        import dataclasses
+        count = O.rollout_costs(om, dataclasses.replace(spec, diff_idx=-1, ctrl_weight=0.0, lin_weight=0.0, health_penalty=1.0), obs0, acts)
+        assert (count == 0).any() and (count > 0).any()
+    for s_ in range(2):   # whole MPC steps: the pool of the last iteration holds sampled rows and shifted-elite rows
+        ob = 0.2 * np.random.RandomState(20 + s_).randn(o)
+        a0 = np_(pl.plan_step(ob))
+        assert np.all(np.isfinite(a0))
+        n_last = pl.population_sizes[-1]
+        pool = np_(pl.actions[:n_last]).astype(np.float64)
+        rescored = O.rollout_costs(om, spec, ob.astype(np.float32).astype(np.float64), pool).astype(np.float64)
+        dev = np_(pl.costs[:n_last]).astype(np.float64)
+        assert close(dev, rescored).mean() > 0.98, (np.abs(dev - rescored).max(), close(dev, rescored).mean())
+    # one iteration per MPC step: from the second step on the pool is N sampled rows (whole tiles) + the shifted elites,
+    # which rollout_rows_wide_kernel scores row by row
+    p1 = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=N, opt_iters=1, dtype="f32", seed=9),
+                     env.action_space.low, env.action_space.high)
+    p1.set_model(model.kind, model.A, model.B)
+    p1.set_cost_spec(env.cost_spec)
+    p1.reset()
+    n_shift = int(p1.cfg.num_elites * p1.cfg.fraction_reused)
+    assert n_shift >= 1
+    for s_ in range(2):
+        ob = 0.2 * np.random.RandomState(30 + s_).randn(o)
+        p1.plan_step(ob)
+    pool = np_(p1.actions[:N + n_shift]).astype(np.float64)
+    rescored = O.rollout_costs(om, spec, ob.astype(np.float32).astype(np.float64), pool).astype(np.float64)
+    dev = np_(p1.costs[:N + n_shift]).astype(np.float64)
+    assert close(dev[N:], rescored[N:]).all() or close(dev, rescored).mean() > 0.995, (dev[N:], rescored[N:])
+
+
 def test_torch_model_with_env_cost_spec_uses_trajectory_cost():
     """f-2 + f-4: a torch dynamics model without its own cost callable is scored by the env's parametric cost through
     icem_trajectory_cost (Ant-shaped: o=113, difference and health terms); checked against the oracle loop."""
