@@ -64,12 +64,11 @@ __device__ __forceinline__ void push_to_block(const uint32_t* __restrict__ mine,
     } else {
         for (int e = threadIdx.x; e < words; e += blockDim.x) dst[e] = mine[e];
     }
-    __threadfence_system();
+    // (every thread waits for its stores, the workgroup meets, ONE thread releases at system scope: pack_records_body)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0)
         __hip_atomic_store(reinterpret_cast<unsigned*>(blk) + flag_idx, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
 }
 
 __global__ __launch_bounds__(256) void exchange_push_kernel(const uint32_t* __restrict__ mine, int words, unsigned char* const* peers,

@@ -1530,12 +1530,14 @@ __device__ __forceinline__ void pack_records_body(const MergeSingleArgs& a, int 
             for (int v = tid; v < vecs; v += nthr) reinterpret_cast<float4*>(dst)[v] = reinterpret_cast<const float4*>(stage)[v];
             for (int e = 4 * vecs + tid; e < words; e += nthr) dst[e] = stage[e];
         }
-        __threadfence_system();
+        // Every thread waits for ITS record stores to be acknowledged, the workgroup meets, then the ONE wave that
+        // raises the flags releases at system scope (L2 write-back + the flag stores).  (A system-scope fence in every
+        // wave of the workgroup, as it used to be, is 7..13 write-backs of the whole L2 where one is needed: the
+        // barrier alone does not wait for outstanding global stores on this target, hence the explicit wait.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid < px.world) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid < px.world)
             __hip_atomic_store(reinterpret_cast<unsigned*>(px.peers[tid]) + px.flag_idx, px.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
     }
 }
 

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
             pk.keep_base = a.p.n_loc;
             // everybody else's prologue waits for this workgroup's push: its waves go first on their SIMDs
             __builtin_amdgcn_s_setprio(3);
+            if (ra.dbg && tid == 0) ra.dbg[0] = wall_clock64();
             // the register-resident selection (174 registers, 1 us faster) where at most two waves share a SIMD anyway
             if (tid < 64) {
                 if constexpr (NTT <= 512)
@@ -93,7 +94,9 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
                     merge_select_stream(pk, lane, cand, sel);
             }
             __syncthreads();
+            if (ra.dbg && tid == 0) ra.dbg[1] = wall_clock64();
             pack_records_body<12>(pk, a.p.n_loc, a.p.shard_lo, a.p.records, a.p.px, tilebuf, sel, tid, NTT);
+            if (ra.dbg && tid == 0) ra.dbg[2] = wall_clock64();
             return;
         }
     }
@@ -186,8 +189,11 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
             // the selection is the longer of the two concurrent chains on its SIMD: it goes first (c2 74.5 -> 72.7 us; with 8
             // rollout waves the sampling is the longer one and the priority costs 0.7 us)
             if constexpr (RW <= 4) __builtin_amdgcn_s_setprio(3);
-            if constexpr (REC)
+            if constexpr (REC) {
+                if (ra.dbg && lane == 0 && wg == 0) ra.dbg[3] = wall_clock64();
                 merge_select_records(a.m, lane, cand, sel, slot);
+                if (ra.dbg && lane == 0 && wg == 0) ra.dbg[4] = wall_clock64();
+            }
             else if constexpr (RW >= 8)  // 13 waves share the register file: the low-register selection
                 merge_select_stream(a.m, lane, cand, sel);
             else
@@ -203,6 +209,7 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
     if constexpr (PM) {
         const MergeSingleArgs& m = a.m;
         __syncthreads();
+        if (ra.dbg && tid == 0 && wg == 0) ra.dbg[5] = wall_clock64();
         // all threads: gather the elite rows + refit (icem.py:201-211) -> this workgroup's mean / std
         const float* rows[KREG > 0 ? KREG : 1];
         merge_rows<KREG, REC>(m, sel, slot, rows);
@@ -224,6 +231,7 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
         }
         if (wg == 0 && tid < m.K) m.elites_cost_next[tid] = key_cost(sel[tid]);
         __syncthreads();
+        if (ra.dbg && tid == 0 && wg == 0) ra.dbg[6] = wall_clock64();
         if (has_row && r_mine < sa.n) {  // y * std + mean, clipped (icem.py:79)
             const float lo = sa.low[jd], hi = sa.high[jd];
             for (int t = QS ? q : 0; t < H; t += QS ? 4 : 1) {
