@@ -844,6 +844,35 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long x)
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// The same minimum for (cost | index) keys in a fraction of the dependent instructions: the 32-bit cost halves first
+// (one v_min_u32 with a DPP operand per step), then the index among the lanes that hold that cost -- one lane in all
+// but tied costs (ballot), where a second 32-bit reduction over the indices decides, as the 64-bit compare would.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned min_dpp32(unsigned x) {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, ROW_MASK, 0xF, false);
+    return o < x ? o : x;
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned x) {
+    x = min_dpp32<0xB1, 0xF>(x);
+    x = min_dpp32<0x4E, 0xF>(x);
+    x = min_dpp32<0x141, 0xF>(x);
+    x = min_dpp32<0x140, 0xF>(x);
+    x = min_dpp32<0x142, 0xA>(x);
+    x = min_dpp32<0x143, 0xC>(x);
+    return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
+__device__ __forceinline__ unsigned long long wave_min_key(unsigned long long x) {
+    const unsigned hi = (unsigned)(x >> 32), lo = (unsigned)x;
+    const unsigned mh = wave_min_u32(hi);
+    const unsigned long long tie = __ballot(hi == mh);
+    unsigned ml;
+    if (__popcll(tie) == 1)   // (wave-uniform)
+        ml = (unsigned)__builtin_amdgcn_readlane((int)lo, __ffsll((long long)tie) - 1);
+    else
+        ml = wave_min_u32(hi == mh ? lo : 0xFFFFFFFFu);
+    return ((unsigned long long)mh << 32) | ml;
+}
+
 // inclusive prefix sum over the 64 lanes: Hillis-Steele inside each row of 16 (row_shr 1, 2, 4, 8, zero fill), then
 // row_bcast:15 into rows 1 / 3 and row_bcast:31 into rows 2 / 3
 template <int CTRL, int ROW_MASK>
@@ -1055,9 +1084,10 @@ __device__ __forceinline__ void merge_select_stream(const MergeSingleArgs& a, in
 // records and one kept elite per lane; same threshold selection; slot[r] receives the record number of selected key
 // r (n_rec + e for kept elite e).  Ties cannot occur: keys embed the global trajectory index.
 __device__ __forceinline__ void merge_select_records(const MergeSingleArgs& a, int lane, unsigned long long* cand,
-                                                     unsigned long long* sel, int* slot) {
+                                                     unsigned long long* sel, int* slot, long long* stamp = nullptr) {
     const int K = a.K, rs = a.h * a.d + 2;
     xchg_wait(a.xw, lane);  // in-library exchange: the peers' records of this iteration have landed
+    if (stamp && lane == 0) *stamp = wall_clock64();
     auto rec_key = [&](int e) -> unsigned long long {
         if (e >= a.n_rec) return KEY_SENTINEL;
         const float* rec = a.records + (size_t)e * rs;
@@ -1065,49 +1095,24 @@ __device__ __forceinline__ void merge_select_records(const MergeSingleArgs& a, i
     };
     unsigned long long k[3] = {rec_key(lane), rec_key(lane + 64),
                                lane < a.n_keep ? make_key(a.elites_cost_cur[lane], a.n_global + lane) : KEY_SENTINEL};
+    // K rounds of "the smallest key of the wave" (wave_min_key).  The selected key is wave-uniform, so the lane that holds
+    // it records its slot on the spot.  (The earlier form -- sort the lane minima for a threshold, compact through LDS,
+    // sort again, look every selected key up -- took the same 2.5 us beside the sampling waves: EXPERIMENTS.md R3.14.)
     const unsigned long long k0 = k[0], k1 = k[1], k2 = k[2];
-    unsigned long long mine = k0 < k1 ? k0 : k1;
-    mine = k2 < mine ? k2 : mine;
-    const unsigned long long srt = wave_sort64(mine, lane);
-    const unsigned long long T = __shfl(srt, K - 1, 64);
-    unsigned n_cand = 0;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const bool p = k[i] <= T && k[i] != KEY_SENTINEL;
-        const unsigned long long m = __ballot(p);
-        const unsigned pos = n_cand + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-        if (p && pos < 64) cand[pos] = k[i];
-        n_cand += (unsigned)__popcll(m);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    if (n_cand <= 64) {
-        unsigned long long key = lane < (int)n_cand ? *((volatile unsigned long long*)&cand[lane]) : KEY_SENTINEL;
-        key = wave_sort_n(key, lane, n_cand);
-        if (lane < K) sel[lane] = key;
-    } else {
-        for (int r = 0; r < K; ++r) {
-            unsigned long long head = k[0] < k[1] ? k[0] : k[1];
-            head = k[2] < head ? k[2] : head;
-            const unsigned long long best = wave_min_u64(head);
-            if (best != KEY_SENTINEL) {
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-                    if (k[i] == best) k[i] = KEY_SENTINEL;
-            }
-            if (lane == 0) sel[r] = best;
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     for (int r = 0; r < K; ++r) {
-        const unsigned long long s = *((volatile unsigned long long*)&sel[r]);
-        if (s != KEY_SENTINEL) {
-            if (k0 == s) slot[r] = lane;
-            if (k1 == s) slot[r] = lane + 64;
-            if (k2 == s) slot[r] = a.n_rec + lane;
+        unsigned long long head = k[0] < k[1] ? k[0] : k[1];
+        head = k[2] < head ? k[2] : head;
+        const unsigned long long best = wave_min_key(head);
+        if (best != KEY_SENTINEL) {   // (keys embed the global trajectory index: exactly one lane and slot matches)
+            if (k0 == best) { slot[r] = lane; k[0] = KEY_SENTINEL; }
+            if (k1 == best) { slot[r] = lane + 64; k[1] = KEY_SENTINEL; }
+            if (k2 == best) { slot[r] = a.n_rec + lane; k[2] = KEY_SENTINEL; }
         } else if (lane == 0) {
             slot[r] = 0;  // fewer than K live candidates: reference behaviour undefined, stay in bounds
         }
+        if (lane == 0) sel[r] = best;
     }
+    (void)cand;
 }
 
 // The same selection spread over the NW wavefronts of a workgroup, for a merge prologue that has NOTHING to hide behind

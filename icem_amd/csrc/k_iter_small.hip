@@ -191,7 +191,7 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
             if constexpr (RW <= 4) __builtin_amdgcn_s_setprio(3);
             if constexpr (REC) {
                 if (ra.dbg && lane == 0 && wg == 0) ra.dbg[3] = wall_clock64();
-                merge_select_records(a.m, lane, cand, sel, slot);
+                merge_select_records(a.m, lane, cand, sel, slot, (ra.dbg && wg == 0) ? ra.dbg + 7 : nullptr);
                 if (ra.dbg && lane == 0 && wg == 0) ra.dbg[4] = wall_clock64();
             }
             else if constexpr (RW >= 8)  // 13 waves share the register file: the low-register selection

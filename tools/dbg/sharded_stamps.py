@@ -32,5 +32,5 @@ for _ in range(R):
     acc += (d - t0) / 100.0
 acc /= R
 print("pack workgroup: entry %.2f  selected %.2f  packed+pushed %.2f" % (acc[0], acc[1], acc[2]))
-print("slab workgroup 0, selection wave: starts waiting %.2f  records selected %.2f | all threads: past the barrier %.2f  gathered + refitted %.2f" % tuple(acc[3:7]))
+print("slab workgroup 0, selection wave: starts waiting %.2f  flags seen + acquire %.2f  records selected %.2f | all threads: past the barrier %.2f  gathered + refitted %.2f" % (acc[3], acc[7], acc[4], acc[5], acc[6]))
 print("slab workgroup 0: entry %.2f  [9] %.2f  [10] %.2f  [11] %.2f  rollout done [12] %.2f  [13] %.2f  end [14] %.2f" % tuple(acc[8:15]))
