@@ -1132,6 +1132,16 @@ def test_wide_rollout_with_cost_terms(env_name):
         import dataclasses
         count = O.rollout_costs(om, dataclasses.replace(spec, diff_idx=-1, ctrl_weight=0.0, lin_weight=0.0, health_penalty=1.0), obs0, acts)
         assert (count == 0).any() and (count > 0).any()
+    if env_name == "door":   # the other reductions over the steps (np.amin / last step), same kernels
+        for mode in ("best", "final"):
+            pm = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=N, opt_iters=1, dtype="f32", seed=7, cost_mode=mode),
+                             env.action_space.low, env.action_space.high)
+            pm.set_model(model.kind, model.A, model.B)
+            pm.set_cost_spec(env.cost_spec)
+            pm.reset()
+            gm = np_(pm.rollout_cost(obs0, torch.as_tensor(acts, dtype=pm.dt, device=pm.device)))
+            wm = O.rollout_costs(om, spec, obs0, acts, mode=mode).astype(np.float64)
+            assert close(gm, wm).mean() > 0.98, (mode, np.abs(gm - wm).max())
     for s_ in range(2):   # whole MPC steps: the pool of the last iteration holds sampled rows and shifted-elite rows
         ob = 0.2 * np.random.RandomState(20 + s_).randn(o)
         a0 = np_(pl.plan_step(ob))
@@ -1559,6 +1569,35 @@ def test_split_rssm_launch_equals_the_fused_kernel(tmp_path):
     env.pop("ICEM_RSSM_SPLIT")
     b = subprocess.run([sys.executable, tool, "check", f], env=env, capture_output=True, text=True, timeout=300, cwd=root)
     assert b.returncode == 0 and "0 differ" in b.stdout, b.stdout + b.stderr
+
+
+def test_split_rssm_launch_replays_in_a_hip_graph():
+    """The split learned-dynamics launch keeps per-(device, stream) staging and per-tile flags that every launch must
+    leave as it found them: captured once (after a first call on the capture stream -- the staging area is allocated
+    there, include/icem_hip.h) it is replayed on fresh actions and must give what a direct call gives, bit for bit."""
+    from icem_amd import DeviceRSSMModel
+    m = DeviceRSSMModel(seed=3)
+    n, h = 1000, 12
+    obs = 0.3 * np.random.RandomState(1).randn(230)
+    acts = torch.empty((n, h, 6), dtype=torch.float32, device="cuda")
+    rs = np.random.RandomState(2)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        acts.copy_(torch.as_tensor(rs.uniform(-1, 1, (n, h, 6)), dtype=torch.float32))
+        m.rollout_cost(obs, acts)          # first call on this stream: allocates the staging area
+        side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        out = m.rollout_cost(obs, acts)
+    for rep in range(3):
+        fresh = torch.as_tensor(rs.uniform(-1, 1, (n, h, 6)), dtype=torch.float32, device="cuda")
+        acts.copy_(fresh)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        direct = m.rollout_cost(obs, fresh)
+        torch.cuda.synchronize()
+        assert np.array_equal(np_(out), np_(direct)), rep
 
 
 def test_config5_fused_rssm_behind_controller():
