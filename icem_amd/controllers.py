@@ -504,15 +504,17 @@ class MpcICemHip(MpcController):
         pool = costs_dev = idx = None
         for i, n_i in enumerate(p.population_sizes):
             z = noise(n_i) if noise is not None else (None, None)
-            actions = p.sample_clip(n_i, p.mean, p.std, z[0], z[1], offset=call_base + i,
-                                    row0_mean=bool(self.use_mean_actions and i == it_n - 1))
-            if i == 0 and self.shift_elites_over_time and self._elite_actions is not None and p.n_reuse > 0:
+            with_shift = i == 0 and self.shift_elites_over_time and self._elite_actions is not None and p.n_reuse > 0
+            # (the shifted elites are sampled into the tail of the same buffer: nothing is concatenated)
+            actions = torch.empty((n_i + (p.n_reuse if with_shift else 0), p.h, p.d), dtype=p.dt, device=p.device)
+            p.sample_clip(n_i, p.mean, p.std, z[0], z[1], offset=call_base + i,
+                          row0_mean=bool(self.use_mean_actions and i == it_n - 1), out=actions[:n_i])
+            if with_shift:
                 zs = noise(p.n_reuse) if noise is not None else (None, None)
-                shifted = torch.empty((p.n_reuse, p.h, p.d), dtype=p.dt, device=p.device)
+                shifted = actions[n_i:]
                 shifted[:, :-1] = self._elite_actions[:p.n_reuse, 1:]
                 p.sample_clip(p.n_reuse, p.mean, p.std, zs[0], zs[1], offset=call_base + it_n, t_begin=p.h - 1,
                               out=shifted)
-                actions = torch.cat([actions, shifted], dim=0)
             costs = self._costs_of(obs, actions)
             pool = actions
             keep = i > 0 and self.keep_previous_elites and p.n_reuse > 0
