@@ -432,7 +432,7 @@ def measure_c5(w, steps, warmup, cpu=True):
     flops = 2.0 * macs * w["h"] * sum(n for _, _, n in spans)
     achieved = flops / (ms * 1e-3) / 1e12
     roofline = {"bound": "mfma", "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0, "traffic": None,
-                "kernel": "rssm_split_kernel" if max(n for _, _, n in spans) <= 4096 else "rssm_rollout_kernel", "avg_launch_us": 1e3 * ms / len(spans), "launches": len(spans),
+                "kernel": "rssm_split_kernel" if max(n for _, _, n in spans) <= 65536 else "rssm_rollout_kernel", "avg_launch_us": 1e3 * ms / len(spans), "launches": len(spans),
                 "algorithmic_flops_per_traj_step": 2.0 * macs, "dtype": "bf16 operands, f32 accumulation"}
     out = {"metric": "traj-steps/sec (N x h), iCEM inner planning loop", "value": ts * steps / elapsed, "unit": "traj-steps/s",
            "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,

@@ -30,7 +30,8 @@ constexpr size_t W7 = B6 + 2 * 16 * HIDB, B7 = W7 + (size_t)HIDB * HIDK * BLK;
 constexpr size_t W8 = B7 + 2 * 16 * HIDB, B8 = W8 + (size_t)1 * HIDK * BLK;
 constexpr size_t TOTAL = B8 + 2 * 16;  // bf16 units
 constexpr int SPLIT_TILE_LIMIT = 8192;  // what the staging bookkeeping is sized for
-constexpr int SPLIT_MAX_TILES = 256;   // populations up to 4096: recurrence and reward head as separate workgroups (icem_rssm_split.hip)
+constexpr int SPLIT_TT1_TILES = 256;    // up to here one tile per recurrence workgroup, two beyond
+constexpr int SPLIT_MAX_TILES = 4096;  // populations up to 65 536: recurrence and reward head as separate workgroups (icem_rssm_split.hip)
 }  // namespace rssm
 
 // costs[i] = reduce_t -reward(state_t) along the rollout of actions[i] from obs0 (cost_mode: 0 sum, 1 best, 2 final)

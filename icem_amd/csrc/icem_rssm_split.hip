@@ -1,11 +1,12 @@
-// Populations of up to 4 096 trajectories (256 tiles of 16) of the recurrent state-space model rollout (icem_rssm.h).  The
+// Populations of up to 65 536 trajectories (4 096 tiles of 16) of the recurrent state-space model rollout (icem_rssm.h).  The
 // fused kernel of icem_rssm.hip puts one workgroup per tile on a CU and streams ALL weights (0.9 MB per model step)
 // through that CU's L1, reward head included, on the recurrence's own critical path.  Here ONE launch holds two kinds
 // of workgroups:
 //   * blocks [0, tiles): the RECURRENCE of one tile -- x, GRU, p, z' per model step, four barriers, nothing else; the
 //     last of the `horizon` transitions is never run (a step's cost is the reward of the state it STARTS from);
 //   * blocks [tiles, 2 tiles): the REWARD HEAD of one tile, its weights loaded ONCE into registers (148 per lane),
-//     consuming the states (h_t, z_t) as the recurrence publishes them.
+//     consuming the states (h_t, z_t) as the recurrence publishes them.  (Above 256 tiles: two tiles per recurrence
+//     workgroup, which share every weight chunk, and 512 reward workgroups that walk the tiles.)
 // State t of a tile travels through an 8 KB item in global memory: wave 7 of the recurrence workgroup -- which owns one
 // GRU output block where waves 0..4 own two -- copies [h_t | z_t] out of LDS during phase 2 of step t with written-through
 // stores, waits for them itself and raises the tile's flag to t + 1; no other wave ever waits for a store.  The reward
@@ -17,6 +18,7 @@
 // The arithmetic, its order and its rounding points are those of rssm_rollout_kernel<1>: costs are bit-identical.
 #include "rssm_dev.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -47,7 +49,7 @@ struct ConsumerLds {
     unsigned short x[2][16 * XS];          // the state at hand (ping-pong)
     unsigned short r1[2][16 * RS];
     unsigned short r2[2][16 * RS];
-    int gave_up;
+    int gave_up, avail[2];
 };
 template <int TT>
 constexpr size_t lds_bytes() { return sizeof(ProducerLds<TT>) > sizeof(ConsumerLds) ? sizeof(ProducerLds<TT>) : sizeof(ConsumerLds); }
@@ -339,16 +341,16 @@ __device__ __forceinline__ void recurrence(ProducerLds<TT>& s, int wg, int tiles
     else recurrence_steps<false, TT>(s, w, lane, base, n, horizon, Pg, actions, items, tile_stride, flag, ntl, stamps, stamp);
 }
 
-__device__ __forceinline__ void reward_head(ConsumerLds& s, int tile, int n, int horizon, int cost_mode,
+// tiles first, first + stride, ...: one tile per workgroup while both workgroup kinds fit the chip together, several for
+// the large populations whose reward workgroups run behind the recurrence workgroups (the head's weights are loaded once)
+__device__ __forceinline__ void reward_head(ConsumerLds& s, int first, int stride, int tiles, int n, int horizon, int cost_mode,
                                             const unsigned short* __restrict__ Pg, float* __restrict__ costs,
                                             const unsigned short* stage, unsigned* flags, long long* stamps) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
-    const bool stamp = stamps && tile == 0 && tid == 0;
+    const bool stamp = stamps && first == 0 && tid == 0;
     if (stamp) stamps[8] = wall_clock64();
-    const unsigned short* items = stage + (size_t)tile * horizon * ITEM;
-    unsigned* flag = flags + tile;
     gptr Plane = (gptr)Pg + lane * 8;
     // the head's weights and biases, once
     v4i A6[NOB][K6K], A7[NOB][HIDK], A8[HIDK];
@@ -367,32 +369,54 @@ __device__ __forceinline__ void reward_head(ConsumerLds& s, int tile, int n, int
     if (tid == 0) s.gave_up = 0;
     __syncthreads();
     const int xr = j * RS + 8 * g, xo = j * RS + 4 * g;
-    float acc_cost = 0.f;
-    bool gave_up = false;
     if (stamp) stamps[9] = wall_clock64();
+    for (int tile = first; tile < tiles; tile += stride) {
+    const unsigned short* items = stage + (size_t)tile * horizon * ITEM;
+    unsigned* flag = flags + tile;
+    float acc_cost = 0.f;
+    // how many of the tile's states are published: read once (behind the recurrence workgroups' launch-wide lead --
+    // large populations -- it already says `horizon`, and no state of the tile costs a poll of its own any more)
+    if (tid == 0) s.avail[1] = (int)__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    int avail = s.avail[1];   // (slot 1: the polls of states 0, 1, .. use slots 0, 1, ..: a slot is rewritten two barriers after its last read)
+    unsigned long long nlo = 0, nhi = 0;   // the next state, requested while this one is scored
+    bool have_next = false;
     for (int t = 0; t < horizon; ++t) {
         const int par = t & 1;
-        // one wave polls (the flag is read past L2: eight waves of 64 workgroups polling the same 256 bytes of memory
-        // are traffic the recurrence workgroups' own requests queue behind); the others wait at the barrier
-        if (w == 0 && !gave_up) {
-            unsigned polls = 0;
-            while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)(t + 1)) < 0) {
-                if (++polls > MAX_POLLS) { gave_up = true; break; }
-                __builtin_amdgcn_s_sleep(4);
+        if (avail < t + 1) {   // (uniform) one wave polls (the flag is read past L2: eight waves of 64 workgroups polling
+            // the same 256 bytes of memory are traffic the recurrence workgroups' own requests queue behind)
+            if (w == 0) {
+                unsigned polls = 0;
+                unsigned v;
+                while ((int)((v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - (unsigned)(t + 1)) < 0) {
+                    if (++polls > MAX_POLLS) { if (lane == 0) s.gave_up = 1; v = (unsigned)horizon; break; }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                if (lane == 0) s.avail[par] = (int)v;
             }
-            if (gave_up && lane == 0) s.gave_up = 1;
+            __syncthreads();
+            avail = s.avail[par];
         }
-        __syncthreads();
         asm volatile("" ::: "memory");
-        if (stamp && t == 5) stamps[10] = wall_clock64();
-        if (stamp && t == horizon - 1) stamps[12] = wall_clock64();
+        if (stamp && tile == 0 && t == 5) stamps[10] = wall_clock64();
+        if (stamp && tile == 0 && t == horizon - 1) stamps[12] = wall_clock64();
         // the item once per workgroup (the loads go past L2: eight waves fetching the same 8 KB each cost more than a
         // trip through LDS): thread e fetches 16 bytes
         {
-            const unsigned short* it = items + (size_t)t * ITEM + tid * 8;
-            const unsigned long long lo = load_ag(it), hi = load_ag(it + 4);
+            unsigned long long lo, hi;
+            if (have_next) {
+                lo = nlo; hi = nhi;
+            } else {
+                const unsigned short* it = items + (size_t)t * ITEM + tid * 8;
+                lo = load_ag(it); hi = load_ag(it + 4);
+            }
             unsigned long long* dst = reinterpret_cast<unsigned long long*>(s.x[par] + (tid >> 5) * XS + (tid & 31) * 8);
             dst[0] = lo; dst[1] = hi;
+            have_next = t + 1 < horizon && avail >= t + 2;
+            if (have_next) {
+                const unsigned short* it = items + (size_t)(t + 1) * ITEM + tid * 8;
+                nlo = load_ag(it); nhi = load_ag(it + 4);
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -418,12 +442,13 @@ __device__ __forceinline__ void reward_head(ConsumerLds& s, int tile, int n, int
             else if (cost_mode == 0) acc_cost += c;
             else acc_cost = (c < acc_cost || c != c) ? c : acc_cost;
         }
-        if (stamp && t == 5) stamps[11] = wall_clock64();
+        if (stamp && tile == 0 && t == 5) stamps[11] = wall_clock64();
     }
-    if (stamp) stamps[13] = wall_clock64();
+    if (stamp && tile == 0) stamps[13] = wall_clock64();
     if (tid == 0) __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     if (w == WAVES - 1 && g == 0 && tile * 16 + j < n)
-        costs[tile * 16 + j] = s.gave_up ? __builtin_nanf("") : acc_cost;
+        costs[tile * 16 + j] = s.gave_up ? __builtin_nanf("") : acc_cost;   // (a workgroup that gave up once reports NaN from there on)
+    }
 }
 
 // blocks [0, prods): recurrence of TT tiles each; blocks [prods, prods + tiles): the reward head of one tile each
@@ -435,7 +460,8 @@ __global__ __launch_bounds__(NTHR) void rssm_split_kernel(int n, int horizon, in
     __shared__ __attribute__((aligned(16))) unsigned char smem[lds_bytes<TT>()];
     const int b = blockIdx.x;
     if (b < prods) recurrence<TT>(*reinterpret_cast<ProducerLds<TT>*>(smem), b, tiles, n, horizon, Pg, obs0, actions, stage, flags, stamps);
-    else reward_head(*reinterpret_cast<ConsumerLds*>(smem), b - prods, n, horizon, cost_mode, Pg, costs, stage, flags, stamps);
+    else reward_head(*reinterpret_cast<ConsumerLds*>(smem), b - prods, (int)gridDim.x - prods, tiles, n, horizon, cost_mode, Pg, costs, stage,
+                     flags, stamps);
 }
 
 // One staging area per (device, stream): launches on a stream are ordered, so they may share it.
@@ -471,7 +497,8 @@ hipError_t launch_rssm_split(int n, int horizon, int cost_mode, const unsigned s
     {
         std::lock_guard<std::mutex> lk(g_mu);
         Staging& s = g_staging[{dev, st}];
-        const size_t want = (size_t)(tiles > rssm::SPLIT_MAX_TILES ? tiles : rssm::SPLIT_MAX_TILES) * horizon;
+        // (8 KB per tile and step: 25 MB cover the populations up to 4096 at h = 12; larger ones grow it, to 403 MB at 65 536)
+        const size_t want = (size_t)(tiles > rssm::SPLIT_TT1_TILES ? tiles : rssm::SPLIT_TT1_TILES) * horizon;
         if (s.items < want) {   // (first call on this stream, or a longer horizon: not inside a capture)
             if (s.stage) {
                 if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
@@ -488,13 +515,18 @@ hipError_t launch_rssm_split(int n, int horizon, int cost_mode, const unsigned s
         }
         sg = s;
     }
-    static const int tt = [] { const char* e = std::getenv("ICEM_RSSM_SPLIT_TT"); return e && e[0] == '2' ? 2 : 1; }();
+    // Up to 256 tiles: one tile per recurrence workgroup and one reward workgroup per tile (up to 128 tiles both kinds are
+    // resident together).  Beyond: two tiles per recurrence workgroup (they share every weight chunk) and 512 reward
+    // workgroups that walk the tiles behind them.  (ICEM_RSSM_SPLIT_TT = 1 | 2 overrides the tiles per workgroup.)
+    static const int tt_env = [] { const char* e = std::getenv("ICEM_RSSM_SPLIT_TT"); return e && (e[0] == '1' || e[0] == '2') ? e[0] - '0' : 0; }();
+    const int tt = tt_env ? tt_env : (tiles > rssm::SPLIT_TT1_TILES ? 2 : 1);
+    const int heads = tiles > rssm::SPLIT_TT1_TILES ? std::min(tiles, 512) : tiles;
     if (tt == 2) {
         const int prods = (tiles + 1) / 2;
-        hipLaunchKernelGGL(rssm_split_kernel<2>, dim3(prods + tiles), dim3(NTHR), 0, st, n, horizon, cost_mode, params, obs0, actions,
+        hipLaunchKernelGGL(rssm_split_kernel<2>, dim3(prods + heads), dim3(NTHR), 0, st, n, horizon, cost_mode, params, obs0, actions,
                            costs, sg.stage, sg.flags, tiles, prods, g_stamps);
     } else {
-        hipLaunchKernelGGL(rssm_split_kernel<1>, dim3(2 * tiles), dim3(NTHR), 0, st, n, horizon, cost_mode, params, obs0, actions, costs,
+        hipLaunchKernelGGL(rssm_split_kernel<1>, dim3(tiles + heads), dim3(NTHR), 0, st, n, horizon, cost_mode, params, obs0, actions, costs,
                            sg.stage, sg.flags, tiles, tiles, g_stamps);
     }
     return hipGetLastError();

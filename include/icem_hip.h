@@ -412,9 +412,10 @@ size_t icem_record_bytes(const icem_handle* h);
  * obs0 = [h (200) | z (30)] (f32) along actions [n, horizon, 6] (f32) in ONE launch on the bf16 matrix cores
  * (f32 accumulation, f32 recurrent state); costs[i] (f32) = reduce_t -reward(state_t) with cost_mode = ICEM_COST_*.
  * params: the packed bf16 parameter buffer of icem_rssm_param_elems() elements (layout: icem_amd/csrc/icem_rssm.h;
- * packer: icem_amd.models.pack_rssm).  No handle.  Populations of up to 4096 rows take a launch in which the
+ * packer: icem_amd.models.pack_rssm).  No handle.  Populations of up to 65 536 rows take a launch in which the
  * recurrence and the reward head are separate workgroups exchanging the states through a staging area in device
- * memory (8 KB per 16 trajectories and step); the library keeps one such area per (device, stream), allocated at the
+ * memory (8 KB per 16 trajectories and step: 25 MB up to 4096 rows at h = 12, grown on demand to 403 MB at 65 536); the
+ * library keeps one such area per (device, stream), allocated at the
  * first call on that stream -- which therefore must not be inside a stream capture (later ones may be: the launch
  * leaves its flags as it found them). */
 size_t icem_rssm_param_elems(void);

@@ -1505,7 +1505,8 @@ def test_fused_rssm_rollout_kernel(mode, n, h):
     accumulation and f32 recurrent state) against (a) a float64 NumPy rollout of the same network with the weights and
     the GEMM inputs rounded to bf16 exactly where the kernel rounds them -- tight; (b) the plain float64 network --
     bf16 accuracy.  Ragged n (not a multiple of the 16-trajectory tile, a single trajectory), horizons 1 / 12 / 30;
-    n <= 4096 runs the split launch of icem_rssm_split.hip, n >= 8192 two tiles per workgroup."""
+    every n here runs the split launch of icem_rssm_split.hip (two tiles per recurrence workgroup above 4096 rows); the fused
+    kernel is held to the same costs bit for bit by test_split_rssm_launch_equals_the_fused_kernel."""
     from icem_amd import DeviceRSSMModel
     m = DeviceRSSMModel(seed=3)
     d = 6
@@ -1551,11 +1552,12 @@ def test_fused_rssm_rollout_kernel(mode, n, h):
 
 
 def test_split_rssm_launch_equals_the_fused_kernel(tmp_path):
-    """Populations up to 4 096 take icem_rssm_split.hip (recurrence workgroups + reward-head workgroups exchanging the
+    """Populations up to 65 536 take icem_rssm_split.hip (recurrence workgroups + reward-head workgroups exchanging the
     states through global memory, weights of the head resident in registers); ICEM_RSSM_SPLIT=0 keeps them on the
     fused kernel.  Same arithmetic, same rounding points: the costs must be bit-identical -- ragged tiles, horizons
-    1 / 2 / 5 / 12 / 30, all three cost modes, 128 tiles (both workgroup kinds resident together) and 256 (the limit),
-    and every case three times in a row (the tile flags
+    1 / 2 / 3 / 5 / 12 / 30, all three cost modes, 128 tiles (both workgroup kinds resident together), 256 (the last size with
+    one tile per recurrence workgroup), 257 and up to 4 096 tiles (two tiles per recurrence workgroup, reward workgroups
+    walking the tiles behind them), and every case three times in a row (the tile flags
     must be back at zero behind every launch)."""
     import os
     import subprocess

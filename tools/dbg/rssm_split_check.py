@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from icem_amd import DeviceRSSMModel  # noqa: E402
 
 CASES = [(1, 12, 0), (15, 1, 2), (16, 2, 0), (17, 12, 1), (1007, 12, 0), (1024, 12, 1), (1024, 12, 2), (2048, 12, 0), (2033, 30, 0),
-         (640, 5, 1), (4096, 12, 0), (3001, 12, 1)]
+         (640, 5, 1), (4096, 12, 0), (3001, 12, 1), (4097, 12, 0), (8192 + 21, 12, 1), (20000, 12, 0), (65536, 12, 0), (40001, 3, 2)]
 m = DeviceRSSMModel(seed=3)
 out = {}
 for rep in range(3):   # (repeats: the flags must come back to 0 behind every launch)
