@@ -1602,6 +1602,30 @@ def test_split_rssm_launch_replays_in_a_hip_graph():
         assert np.array_equal(np_(out), np_(direct)), rep
 
 
+def test_split_rssm_launches_on_two_streams_at_once():
+    """Two split learned-dynamics launches in flight on two streams (each stream has its own staging area and flags; both
+    launches' recurrence workgroups are dispatched ahead of their reward workgroups, so neither can starve the other):
+    same costs as one at a time, bit for bit -- with both workgroup kinds resident together (n = 1000) and with the
+    reward workgroups walking the tiles behind two-tile recurrence workgroups (n = 9000)."""
+    from icem_amd import DeviceRSSMModel
+    m = DeviceRSSMModel(seed=3)
+    obs = 0.3 * np.random.RandomState(1).randn(230)
+    rs = np.random.RandomState(5)
+    for n in (1000, 9000):
+        a1 = torch.as_tensor(rs.uniform(-1, 1, (n, 12, 6)), dtype=torch.float32, device="cuda")
+        a2 = torch.as_tensor(rs.uniform(-1, 1, (n, 12, 6)), dtype=torch.float32, device="cuda")
+        r1, r2 = m.rollout_cost(obs, a1).clone(), m.rollout_cost(obs, a2).clone()
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        for _ in range(6):
+            with torch.cuda.stream(s1):
+                o1 = m.rollout_cost(obs, a1)
+            with torch.cuda.stream(s2):
+                o2 = m.rollout_cost(obs, a2)
+            torch.cuda.synchronize()
+            assert torch.equal(o1, r1) and torch.equal(o2, r2)
+
+
 def test_config5_fused_rssm_behind_controller():
     """BASELINE configs[4] with the fused kernel: MpcICemHip + DeviceRSSMModel (one launch per population) against the
     oracle loop driving the bf16-exact... no: the float64 network; the planner's choice must agree up to bf16 cost noise:
