@@ -1,4 +1,5 @@
-"""Would replaying an MPC step as a HIP graph shorten it?  Captures two icem_plan_step calls (the ping-pong buffers come back\nafter two) and replays them -- with stale RNG offsets, so a timing probe only -- against the same steps enqueued on a stream."""
+"""Would replaying an MPC step as a HIP graph shorten it?  Captures two icem_plan_step calls (the ping-pong buffers come back
+after two) and replays them -- with stale RNG offsets, so a timing probe only -- against the same steps enqueued on a stream."""
 import sys, time, numpy as np, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from icem_amd import IcemConfig, IcemPlanner, DeviceSyntheticModel, halfcheetah_env
