@@ -273,6 +273,35 @@ def measured_traffic(kernel_class, workload):
     return (tot / n, os.path.relpath(files[-1], ROOT), dur / n * 1e-3 or None) if n else (None, None, None)
 
 
+def event_bracket_us(pl):
+    """The share of a ``profile_read`` span that is the event pair and the launch's dispatch, not the kernel: an event pair
+    around ONE empty launch minus what a SECOND empty launch adds (``icem_profile_overhead``; the median of 200 each, on the
+    launch stream).  Subtracted from every span so that the per-kernel times are the ones the launches contribute to the
+    step they were taken from (a time that sums to more than ms_per_step is not evidence of anything)."""
+    pair, marginal = pl.profile_overhead(200)
+    return {"pair_us": round(pair, 3), "marginal_launch_us": round(marginal, 3), "subtracted_us": round(max(0.0, pair - marginal), 3)}
+
+
+def without_bracket(prof, bracket):
+    """{kernel: (ms, launches, units)} with the event bracket taken out of every span (never below a fifth of the span)."""
+    sub = bracket["subtracted_us"] * 1e-3
+    return {k: (max(ms - sub * n, 0.2 * ms), n, u) for k, (ms, n, u) in prof.items()}
+
+
+def fit_to_step(prof, profiled_steps, ms_per_step):
+    """Do the per-kernel times fit the step they claim to make up?  sum(kernel time) per MPC step against the timed
+    ms_per_step; above 1.05 x the times are scaled down to the step (and the line says so)."""
+    per_step_ms = sum(ms for ms, _, _ in prof.values()) / max(1, profiled_steps)
+    ratio = per_step_ms / ms_per_step if ms_per_step > 0 else float("inf")
+    fit = {"sum_of_kernel_times_ms_per_step": per_step_ms, "ms_per_step": ms_per_step, "ratio": ratio, "fits": ratio <= 1.05,
+           "scaled_to_step": False}
+    if ratio > 1.05:
+        print(f"bench.py: per-kernel event times sum to {ratio:.2f} x the timed step; scaling them to the step", file=sys.stderr)
+        prof = {k: (ms / ratio, n, u) for k, (ms, n, u) in prof.items()}
+        fit["scaled_to_step"] = True
+    return prof, fit
+
+
 def roofline_of(prof, w, workload=None):
     dom = max(prof, key=lambda k: prof[k][0])
     ms, launches, units = prof[dom]
@@ -286,8 +315,9 @@ def roofline_of(prof, w, workload=None):
                "flops_per_traj_step": fpu, "flops_per_launch": units * fpu / launches,
                "note": "f32 vector and f32 MFMA share one pipe on gfx950 (155 TF measured): one compute roof"}
     traffic, src, trace_us = measured_traffic(dom, workload) if workload else (None, None, None)
-    # avg_launch_us: HIP events around every launch on the launch stream (kernel + its dispatch, ~2.5 us more than the
-    # kernel alone); rocprof_trace_avg_us: the committed kernel trace's figure for the same kernels, for comparison
+    # avg_launch_us: HIP events around every launch on the launch stream with the calibrated event bracket taken out
+    # (event_bracket_us; the caller checks that the times sum to the step: fit_to_step); rocprof_trace_avg_us: the
+    # committed kernel trace's figure for the same kernels, for comparison
     if w["o"] > 32 and dom == "rollout_cost":
         # wide observations: the rollout is a GEMM three orders of magnitude above the f32 ridge ("declare
         # that stage compute-bound"); the roof is the f32 matrix pipe, the HBM view rides along
@@ -337,8 +367,10 @@ def measure_also(name, rank=0, world=1, steps=200, warmup=20, global_n=None):
     pl.profile_enable(True)
     run_steps(pl, 10, world)
     torch.cuda.synchronize()
-    prof = pl.profile_read()
+    raw = pl.profile_read()
     pl.profile_enable(False)
+    bracket = event_bracket_us(pl)
+    prof, fit = fit_to_step(without_bracket(raw, bracket), 10, 1e3 * el / steps)
     ts = sum(pl.population_sizes) * w["h"]  # global
     loop_bytes = ts * (8.0 * w["d"] + 8.0 / w["h"])
     n_glob = global_n if global_n else w["N"] * world
@@ -347,6 +379,8 @@ def measure_also(name, rank=0, world=1, steps=200, warmup=20, global_n=None):
            "n_gpus": world, "value": ts * steps / el, "unit": "traj-steps/s", "ms_per_mpc_step": 1e3 * el / steps,
            "roofline": roofline_of(prof, w, name if world == 1 else None),
            "kernels_us": {k: round(1e3 * v[0] / v[1], 2) for k, v in prof.items()},
+           "kernels_us_with_event_bracket": {k: round(1e3 * v[0] / v[1], 2) for k, v in raw.items()},
+           "event_bracket": bracket, "kernel_times_vs_step": fit,
            "whole_loop_algorithmic_GBps": loop_bytes * steps / el / 1e9,
            "whole_loop_frac_of_hbm_peak": loop_bytes * steps / el / 1e9 / (HBM_PEAK_GBS * world)}
     if world > 1:
@@ -561,10 +595,13 @@ def main():
 
     # second pass: per-kernel durations from HIP events on the launch stream
     pl.profile_enable(True)
-    run_steps(pl, min(args.steps, 50), world)
+    n_prof = min(args.steps, 50)
+    run_steps(pl, n_prof, world)
     torch.cuda.synchronize()
-    prof = pl.profile_read()
+    raw_prof = pl.profile_read()
     pl.profile_enable(False)
+    bracket = event_bracket_us(pl)
+    prof, fit = fit_to_step(without_bracket(raw_prof, bracket), n_prof, 1e3 * elapsed / args.steps)
     exchange = exchange_report(pl) if world > 1 else None   # collective: every rank
     also = strong = None
     if args.workload == "c2" and not args.no_also:
@@ -594,6 +631,8 @@ def main():
             "ms_per_mpc_step": 1e3 * elapsed / args.steps,
             "roofline": roofline,
             "kernels_us": {k: round(1e3 * v[0] / v[1], 2) for k, v in prof.items()},
+            "kernels_us_with_event_bracket": {k: round(1e3 * v[0] / v[1], 2) for k, v in raw_prof.items()},
+            "event_bracket": bracket, "kernel_times_vs_step": fit,
             "build": build,
         }
         if exchange is not None:

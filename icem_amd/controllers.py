@@ -150,26 +150,67 @@ class ModelBasedController(Controller, ABC):
             "Implement method {} to compute cost along trajectory".format(self.cost_along_trajectory))
 
 
+class _RowwiseCursor:
+    """Walks ``sequences [p,h,...]`` the way ``ArrayIteratorParallelRowwise`` does (controllers/utils.py:18-51), with
+    a (first row, time) cursor instead of re-slicing the array at every block:
+
+    * ``k == 1``: one trajectory at a time -- ``[row, t]`` for t = 0..h-1, then the next row.  This is how
+      ``GroundTruthModel.predict_n_steps`` consumes a policy (gt_model.py:84-90: 1-D observation, h calls per start state).
+    * ``1 < k < rows left``: ``k`` rows at a time -- ``[row:row+k, t]`` for t = 0..h-1, then the next ``k`` rows.
+    * ``k == rows left`` (also the last block of the case above): one column of all of them per call; when the columns
+      are used up the next call raises.
+
+    Error behaviour as upstream: more parallel rows than sequences -> AttributeError at construction; nothing left ->
+    AttributeError (column-wise walk) or IndexError (``k == 1`` walk past the last row, upstream's ``array[0, t]`` on an
+    empty array); a remainder smaller than ``k`` -> AssertionError.  Returned arrays are views of ``sequences``."""
+
+    def __init__(self, sequences, k: int):
+        if k > sequences.shape[0]:
+            raise AttributeError("too many parallel rows requested!")
+        self.sequences, self.k = sequences, k
+        self.row = self.t = 0
+        self.columns_used_up = sequences.shape[1] == 0
+
+    def next(self):
+        s, k = self.sequences, self.k
+        if self.columns_used_up:
+            raise AttributeError("I don't have any item(s) left.")
+        left = s.shape[0] - self.row
+        if k == 1 or k < left:
+            if left <= 0:
+                raise IndexError("index 0 is out of bounds for axis 0 with size 0")
+            out = s[self.row, self.t] if k == 1 else s[self.row:self.row + k, self.t]
+            self.t += 1
+            if self.t >= s.shape[1]:        # this block of rows is done
+                self.t = 0
+                self.row += k
+            return out
+        assert k == left                    # fully parallel from here on
+        out = s[self.row:, self.t]
+        self.t += 1
+        self.columns_used_up = self.t >= s.shape[1]
+        return out
+
+
 class OpenLoopPolicy(ParallelController):
-    """Feeds column ``t`` of ``action_sequences [p,h,d]`` at the t-th call
-    (abstract_controller.py:153-184 with the fully-parallel iterator of controllers/utils.py:47-50)."""
+    """Replays ``action_sequences [p,h,d]`` (abstract_controller.py:153-184).  The number of rows served per call is
+    fixed by the FIRST observation it is asked with -- 1-D: one trajectory at a time (the reference's
+    ``GroundTruthModel``), ``[k,o]``: k at a time, ``[p,o]``: one column per call (batched models) -- see
+    ``_RowwiseCursor``."""
 
     def __init__(self, action_sequences, *, env=None):
         super().__init__(env=env)
         self.action_sequences = action_sequences
-        self._t = 0
+        self.action_sequence_iterator = None
+
+    @staticmethod
+    def get_num_parallel(obs):
+        return 1 if np.ndim(obs) == 1 else np.shape(obs)[0]
 
     def get_action(self, obs, state=None, mode="train"):
-        n_par = 1 if np.ndim(obs) == 1 else np.shape(obs)[0]
-        if n_par > self.action_sequences.shape[0]:
-            raise AttributeError("too many parallel rows requested!")
-        if self._t >= self.action_sequences.shape[1]:
-            raise AttributeError("I don't have any item(s) left.")
-        if n_par != self.action_sequences.shape[0]:
-            raise NotImplementedError("OpenLoopPolicy here serves the fully parallel case only")
-        col = self.action_sequences[:, self._t]
-        self._t += 1
-        return col if np.ndim(obs) > 1 else col[0]
+        if self.action_sequence_iterator is None:
+            self.action_sequence_iterator = _RowwiseCursor(self.action_sequences, self.get_num_parallel(obs))
+        return self.action_sequence_iterator.next()
 
     def get_parallel_policy_copy(self, indices):
         return OpenLoopPolicy(self.action_sequences[indices], env=self.env)

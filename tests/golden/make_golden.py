@@ -622,12 +622,57 @@ def env_cost_vectors():
     print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB")
 
 
+def open_loop_policy_vectors():
+    """The order in which the reference's ``OpenLoopPolicy`` (abstract_controller.py:153-184 over
+    ``ArrayIteratorParallelRowwise``, controllers/utils.py:18-51) hands out a ``[p,h,d]`` array, for every way a forward
+    model asks: 1-D observations (``GroundTruthModel.predict_n_steps``, gt_model.py:84-90), ``k < p`` rows, all rows, the
+    sub-policies of ``get_parallel_policy_copy`` (gt_par_model.py:77-80) -- each walked until the reference raises; the
+    exception's type name is recorded too."""
+    from controllers.abstract_controller import OpenLoopPolicy
+    data, cases = {}, []
+    for (p, h, d, k) in [(5, 4, 2, 1), (6, 3, 2, 2), (6, 3, 2, 6), (4, 3, 1, 3), (1, 3, 2, 1), (3, 1, 2, 2), (7, 5, 3, 7),
+                         (2, 3, 2, 3)]:
+        seq = np.arange(p * h * d, dtype=np.float64).reshape(p, h, d)
+        obs = np.zeros(4) if k == 1 else np.zeros((k, 4))
+        outs, err = [], "none"
+        try:
+            pol = OpenLoopPolicy(seq)
+            for _ in range(p * h + 2):
+                outs.append(np.array(pol.get_action(obs, None), dtype=np.float64))
+        except Exception as e:  # noqa: BLE001 -- the type IS the datum
+            err = type(e).__name__
+        name = f"olp_p{p}_h{h}_d{d}_k{k}"
+        cases.append(name)
+        data[name + "_cfg"] = np.array([p, h, d, k], dtype=np.int64)
+        data[name + "_ndim"] = np.array([o.ndim for o in outs], dtype=np.int64)
+        data[name + "_rows"] = np.array([1 if o.ndim == 1 else o.shape[0] for o in outs], dtype=np.int64)
+        data[name + "_flat"] = np.concatenate([o.reshape(-1) for o in outs]) if outs else np.zeros(0)
+        data[name + "_err"] = np.array(err)
+    # sub-policies as ParallelGroundTruthModel builds them: array_split chunks, each walked one row at a time
+    p, h, d, workers = 11, 4, 2, 4
+    seq = np.arange(p * h * d, dtype=np.float64).reshape(p, h, d)
+    pol = OpenLoopPolicy(seq)
+    chunks = [c for c in np.array_split(range(p), workers) if len(c) > 0]
+    flat = []
+    for c in chunks:
+        sub = pol.get_parallel_policy_copy(c)
+        for _ in range(len(c) * h):
+            flat.append(np.array(sub.get_action(np.zeros(4), None)))
+    data["olp_chunks_cfg"] = np.array([p, h, d, workers], dtype=np.int64)
+    data["olp_chunks_flat"] = np.concatenate(flat)
+    data["cases"] = np.array(cases)
+    path = os.path.join(OUT, "open_loop_policy_vectors.npz")
+    np.savez_compressed(path, **data)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference (build container only)")
     install_stubs()
     cost_fn_vectors()
     env_cost_vectors()
+    open_loop_policy_vectors()
     # C1-shaped: HalfCheetah shapes, beta=0.25, 3 iterations (BASELINE.json configs[0])
     run_case("c1_halfcheetah_n128", N=128, h=30, d=6, o=17, beta=0.25, iters=3, seed=11,
              n_steps=3, kind=0, env_kind="halfcheetah")

@@ -6,7 +6,7 @@ import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-_ALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if not p.endswith("cost_vectors.npz") and not p.endswith("cost_fn_vectors.npz"))
+_ALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if not p.endswith(("cost_vectors.npz", "cost_fn_vectors.npz", "open_loop_policy_vectors.npz")))
 CASES = [n for n in _ALL if not n.startswith(("cemstd_", "random_"))]        # MpcICem runs
 RANDOM_CASES = [n for n in _ALL if n.startswith("random_")]     # MpcRandom runs (random shooting baseline)
 CEMSTD_CASES = [n for n in _ALL if n.startswith("cemstd_")]     # MpcCemStd runs (truncated-normal CEM baseline)

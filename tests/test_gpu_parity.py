@@ -357,6 +357,92 @@ def test_controller_host_model_path(name):
         np.testing.assert_allclose(a, g.executed[s], rtol=F64_RTOL, atol=F64_ATOL)
 
 
+class _SerialGtStyleModel:
+    """A host forward model whose ``predict_n_steps`` walks the policy the way the reference's ``GroundTruthModel`` does
+    (gt_model.py:76-102): one start state after the other, ``policy.get_action(obs[o], None)`` h times each, one
+    rollout per trajectory -- the ROW-WISE branch of ``OpenLoopPolicy``.  Built inside the tests from the icem_amd
+    ``ForwardModel`` base."""
+
+    @staticmethod
+    def make(env, om, workers=0):
+        from icem_amd.models import ForwardModel, TrajectoryBatch
+
+        class Model(ForwardModel):
+            calls = []
+
+            def predict(self, *, observations, states, actions):
+                return om.predict(observations, actions), None, np.zeros(np.shape(observations)[:-1] + (1,))
+
+            def _serial(self, start_observations, start_states, policy, horizon):
+                obs_l, nxt_l, act_l = [], [], []
+                for start_obs, _state in zip(start_observations, start_states):
+                    o, ro, rn, ra = start_obs, [], [], []
+                    for _ in range(horizon):
+                        a = policy.get_action(o, None)
+                        assert a.ndim == 1
+                        n = om.predict(o, a)
+                        ro.append(o), rn.append(n), ra.append(a)
+                        o = n
+                    obs_l.append(ro), nxt_l.append(rn), act_l.append(ra)
+                return np.asarray(obs_l), np.asarray(nxt_l), np.asarray(act_l)
+
+            def predict_n_steps(self, *, start_observations, start_states, policy, horizon):
+                if start_observations.ndim != 2:
+                    raise AttributeError("call predict_n_steps with a batch of states")
+                n = start_observations.shape[0]
+                self.calls.append(n)
+                if not workers:
+                    o, nx, a = self._serial(start_observations, start_states, policy, horizon)
+                else:
+                    # gt_par_model.py:77-94: array_split chunks, one sub-policy per worker, results chained in order
+                    chunks = [c for c in np.array_split(range(n), workers) if len(c) > 0]
+                    policies = [policy.get_parallel_policy_copy(c) for c in chunks]
+                    parts = [self._serial(start_observations[c], [start_states[i] for i in c], sub, horizon)
+                             for c, sub in zip(chunks, policies)]
+                    o, nx, a = (np.concatenate([p[j] for p in parts]) for j in range(3))
+                return TrajectoryBatch(observations=o, next_observations=nx, actions=a,
+                                       rewards=np.zeros(a.shape[:2] + (1,))), [None] * n
+        return Model(env=env)
+
+
+@pytest.mark.parametrize("workers", [0, 5])
+@pytest.mark.parametrize("name", ["c1_halfcheetah_n128", "h13_odd_n48"])
+def test_controller_rowwise_host_models(name, workers):
+    """The reference's shipped forward models consume the controller's policy one trajectory at a time
+    (``GroundTruthModel``) or as per-worker sub-policies (``ParallelGroundTruthModel``); every settings/*.json goes
+    through one of them.  MpcICemHip behind such a model, fed the reference's draws, returns the reference's actions."""
+    from icem_amd import MpcICemHip, halfcheetah_env
+    g = Golden(name)
+    env = halfcheetah_env(g.o)
+    if g.d != 6:
+        from icem_amd.envs import Box
+        env.action_space = Box(-g.bounds * np.ones(g.d), g.bounds * np.ones(g.d))
+    model = _SerialGtStyleModel.make(env, O.SyntheticModel(g.A, g.B, g.kind), workers)
+    ctrl = MpcICemHip(env=env, forward_model=model, horizon=g.h, num_simulated_trajectories=g.N,
+                      factor_decrease_num=g.gamma, cost_along_trajectory=g.cost_mode, dtype="f64",
+                      noise_source="numpy_legacy",
+                      action_sampler_params=dict(alpha=g.alpha, elites_size=g.K, opt_iterations=g.iters,
+                                                 init_std=g.init_std, use_mean_actions=g.use_mean,
+                                                 keep_previous_elites=g.keep, shift_elites_over_time=g.shift,
+                                                 fraction_elites_reused=g.xi, noise_beta=g.beta))
+    assert not ctrl.device_path
+    np.random.seed(g.seed)
+    ctrl.beginning_of_rollout(observation=g.obs[0], state=None, mode="train")
+    for s in range(g.n_steps):
+        a = ctrl.get_action(g.obs[s], None)
+        assert a.dtype == np.float64 and a.shape == (g.d,)
+        np.testing.assert_allclose(a, g.executed[s], rtol=F64_RTOL, atol=F64_ATOL)
+    # population bookkeeping seen by the model: N (+3 shifted elites from the 2nd step on), then the decayed sizes
+    sizes = [g.N]
+    for _ in range(g.iters - 1):
+        sizes.append(max(2 * g.K, int(sizes[-1] / g.gamma)))
+    reuse = int(g.K * g.xi) if g.shift else 0
+    want = []
+    for s in range(g.n_steps):
+        want += [sizes[0] + (reuse if s > 0 else 0)] + sizes[1:]
+    assert type(model).calls == want
+
+
 @pytest.mark.parametrize("on_device", [True, False])
 def test_controller_env_reward_as_cost(on_device):
     """use_env_reward_as_cost (abstract_controller.py:76-77: costs = -rewards of the rollouts).  A synthetic model that
