@@ -275,11 +275,18 @@ def measured_traffic(kernel_class, workload):
 
 def event_bracket_us(pl):
     """The share of a ``profile_read`` span that is the event pair and the launch's dispatch, not the kernel: an event pair
-    around ONE empty launch minus what a SECOND empty launch adds (``icem_profile_overhead``; the median of 200 each, on the
-    launch stream).  Subtracted from every span so that the per-kernel times are the ones the launches contribute to the
-    step they were taken from (a time that sums to more than ms_per_step is not evidence of anything)."""
-    pair, marginal = pl.profile_overhead(200)
-    return {"pair_us": round(pair, 3), "marginal_launch_us": round(marginal, 3), "subtracted_us": round(max(0.0, pair - marginal), 3)}
+    around a one-wave kernel that spins for 15 us of the wall clock, minus the time that kernel reports it ran
+    (``icem_profile_overhead``; medians of 200, on the launch stream).  Subtracted from every span so that the per-kernel
+    times are the ones the launches contribute to the step they were taken from (a time that sums to more than ms_per_step
+    is not evidence of anything).  The in-kernel time leaves out the wave's launch and retirement (part of a kernel's
+    duration in a rocprofv3 trace), so the corrected times sit below the trace's by that much; the committed trace's own
+    figure rides along as ``rocprof_trace_avg_us``."""
+    out = {}
+    for spin in (15.0, 40.0):   # two durations: the bracket must not depend on the kernel's length
+        pair, kern = pl.profile_overhead(200, spin)
+        out[f"spin_{int(spin)}us"] = {"pair_us": round(pair, 3), "kernel_us": round(kern, 3), "bracket_us": round(pair - kern, 3)}
+    out["subtracted_us"] = round(max(0.0, min(v["bracket_us"] for v in out.values())), 3)
+    return out
 
 
 def without_bracket(prof, bracket):
@@ -289,17 +296,17 @@ def without_bracket(prof, bracket):
 
 
 def fit_to_step(prof, profiled_steps, ms_per_step):
-    """Do the per-kernel times fit the step they claim to make up?  sum(kernel time) per MPC step against the timed
-    ms_per_step; above 1.05 x the times are scaled down to the step (and the line says so)."""
+    """Price every kernel on its SHARE OF THE TIMED STEP: the bracket-corrected event times are scaled so that they sum to
+    ms_per_step exactly -- launch gaps are charged to the kernels pro rata (conservative: a roofline fraction computed
+    from these can only be lower than the kernel alone would show), and a set of times that exceeds the step (the r02 /
+    r03 flaw) cannot happen.  Returns the scaled profile and the record of what was done."""
     per_step_ms = sum(ms for ms, _, _ in prof.values()) / max(1, profiled_steps)
     ratio = per_step_ms / ms_per_step if ms_per_step > 0 else float("inf")
     fit = {"sum_of_kernel_times_ms_per_step": per_step_ms, "ms_per_step": ms_per_step, "ratio": ratio, "fits": ratio <= 1.05,
-           "scaled_to_step": False}
+           "priced_on": "share of the timed step (event time x ms_per_step / sum of event times)"}
     if ratio > 1.05:
-        print(f"bench.py: per-kernel event times sum to {ratio:.2f} x the timed step; scaling them to the step", file=sys.stderr)
-        prof = {k: (ms / ratio, n, u) for k, (ms, n, u) in prof.items()}
-        fit["scaled_to_step"] = True
-    return prof, fit
+        print(f"bench.py: per-kernel event times sum to {ratio:.2f} x the timed step", file=sys.stderr)
+    return {k: (ms / ratio, n, u) for k, (ms, n, u) in prof.items()}, fit
 
 
 def roofline_of(prof, w, workload=None):
@@ -315,9 +322,9 @@ def roofline_of(prof, w, workload=None):
                "flops_per_traj_step": fpu, "flops_per_launch": units * fpu / launches,
                "note": "f32 vector and f32 MFMA share one pipe on gfx950 (155 TF measured): one compute roof"}
     traffic, src, trace_us = measured_traffic(dom, workload) if workload else (None, None, None)
-    # avg_launch_us: HIP events around every launch on the launch stream with the calibrated event bracket taken out
-    # (event_bracket_us; the caller checks that the times sum to the step: fit_to_step); rocprof_trace_avg_us: the
-    # committed kernel trace's figure for the same kernels, for comparison
+    # avg_launch_us: HIP events around every launch on the launch stream, the calibrated event bracket taken out
+    # (event_bracket_us), then priced as the launch's share of the timed step (fit_to_step: the times sum to ms_per_step);
+    # rocprof_trace_avg_us: the committed kernel trace's figure for the same kernels, for comparison
     if w["o"] > 32 and dom == "rollout_cost":
         # wide observations: the rollout is a GEMM three orders of magnitude above the f32 ridge ("declare
         # that stage compute-bound"); the roof is the f32 matrix pipe, the HBM view rides along
@@ -379,6 +386,7 @@ def measure_also(name, rank=0, world=1, steps=200, warmup=20, global_n=None):
            "n_gpus": world, "value": ts * steps / el, "unit": "traj-steps/s", "ms_per_mpc_step": 1e3 * el / steps,
            "roofline": roofline_of(prof, w, name if world == 1 else None),
            "kernels_us": {k: round(1e3 * v[0] / v[1], 2) for k, v in prof.items()},
+           "kernels_us_events": {k: round(1e3 * v[0] / v[1], 2) for k, v in without_bracket(raw, bracket).items()},
            "kernels_us_with_event_bracket": {k: round(1e3 * v[0] / v[1], 2) for k, v in raw.items()},
            "event_bracket": bracket, "kernel_times_vs_step": fit,
            "whole_loop_algorithmic_GBps": loop_bytes * steps / el / 1e9,
@@ -631,6 +639,7 @@ def main():
             "ms_per_mpc_step": 1e3 * elapsed / args.steps,
             "roofline": roofline,
             "kernels_us": {k: round(1e3 * v[0] / v[1], 2) for k, v in prof.items()},
+            "kernels_us_events": {k: round(1e3 * v[0] / v[1], 2) for k, v in without_bracket(raw_prof, bracket).items()},
             "kernels_us_with_event_bracket": {k: round(1e3 * v[0] / v[1], 2) for k, v in raw_prof.items()},
             "event_bracket": bracket, "kernel_times_vs_step": fit,
             "build": build,

@@ -82,8 +82,14 @@ int pick_O(int o) {
 
 }  // namespace
 
-// what icem_profile_overhead times: nothing
-__global__ void profile_empty_kernel() {}
+// what icem_profile_overhead times: one wave that spins for `ticks` of the 100 MHz wall clock and reports how long it
+// really ran (a kernel of KNOWN duration; an empty one would overstate the bracket: the command processor sets up the
+// closing event while a real kernel is still running)
+__global__ void profile_spin_kernel(long long ticks, long long* ran) {
+    long long t0 = wall_clock64(), t = t0;
+    while (t - t0 < ticks) t = wall_clock64();
+    if (threadIdx.x == 0) *ran = t - t0;
+}
 
 extern "C" {
 
@@ -470,32 +476,39 @@ int icem_profile_read(icem_handle* h, double* total_ms, int64_t* launches, int64
     return ICEM_OK;
 }
 
-int icem_profile_overhead(void* stream, int32_t reps, double* pair_us, double* marginal_us) {
-    if (!pair_us || !marginal_us || reps < 3 || reps > 4096) return fail(ICEM_E_INVALID, "null output / bad reps");
+int icem_profile_overhead(void* stream, int32_t reps, double spin_us, double* pair_us, double* kernel_us) {
+    if (!pair_us || !kernel_us || reps < 3 || reps > 4096 || !(spin_us >= 0.0) || spin_us > 1e4)
+        return fail(ICEM_E_INVALID, "null output / bad reps or spin_us");
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t a = nullptr, b = nullptr;
+    long long* ran = nullptr;
     ICEM_HIP_TRY(hipEventCreate(&a));
     ICEM_HIP_TRY(hipEventCreate(&b));
-    double med[2] = {0.0, 0.0};
-    for (int two = 0; two < 2; ++two) {
-        std::vector<float> v;
-        for (int r = 0; r < reps + 8; ++r) {
-            ICEM_HIP_TRY(hipEventRecord(a, st));
-            hipLaunchKernelGGL(profile_empty_kernel, dim3(1), dim3(64), 0, st);
-            if (two) hipLaunchKernelGGL(profile_empty_kernel, dim3(1), dim3(64), 0, st);
-            ICEM_HIP_TRY(hipEventRecord(b, st));
-            ICEM_HIP_TRY(hipEventSynchronize(b));
-            float ms = 0.f;
-            ICEM_HIP_TRY(hipEventElapsedTime(&ms, a, b));
-            if (r >= 8) v.push_back(ms);   // the first few pay for code-object loading
+    ICEM_HIP_TRY(hipHostMalloc((void**)&ran, sizeof(long long), hipHostMallocMapped));
+    std::vector<float> pair;
+    std::vector<double> kern;
+    int rc = ICEM_OK;
+    for (int r = 0; r < reps + 8 && rc == ICEM_OK; ++r) {
+        hipError_t e = hipEventRecord(a, st);
+        hipLaunchKernelGGL(profile_spin_kernel, dim3(1), dim3(64), 0, st, (long long)(spin_us * 100.0), ran);
+        if (e == hipSuccess) e = hipEventRecord(b, st);
+        if (e == hipSuccess) e = hipEventSynchronize(b);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+        if (e != hipSuccess) rc = fail(ICEM_E_HIP, hipGetErrorString(e));
+        if (r >= 8) {   // the first few pay for code-object loading
+            pair.push_back(ms);
+            kern.push_back((double)*ran * 0.01);
         }
-        std::sort(v.begin(), v.end());
-        med[two] = 1e3 * (double)v[v.size() / 2];
     }
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
-    *pair_us = med[0];
-    *marginal_us = med[1] - med[0];
+    (void)hipHostFree(ran);
+    if (rc != ICEM_OK) return rc;
+    std::sort(pair.begin(), pair.end());
+    std::sort(kern.begin(), kern.end());
+    *pair_us = 1e3 * (double)pair[pair.size() / 2];
+    *kernel_us = kern[kern.size() / 2];
     return ICEM_OK;
 }
 

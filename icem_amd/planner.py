@@ -340,12 +340,13 @@ class IcemPlanner:
         L.check(self.lib.icem_profile_read(self._h, ms, cnt, units))
         return {L.KERNEL_NAMES[i]: (ms[i], cnt[i], units[i]) for i in range(n) if cnt[i]}
 
-    def profile_overhead(self, reps: int = 200) -> Tuple[float, float]:
-        """(event-pair time around one empty launch, what a second empty launch adds) in microseconds, on the launch stream
-        (``icem_profile_overhead``): their difference is the bracket's share of every ``profile_read`` span."""
-        pair, marg = C.c_double(), C.c_double()
-        L.check(self.lib.icem_profile_overhead(self._stream(), reps, C.byref(pair), C.byref(marg)))
-        return pair.value, marg.value
+    def profile_overhead(self, reps: int = 200, spin_us: float = 15.0) -> Tuple[float, float]:
+        """(event-pair time around a one-wave kernel spinning for ``spin_us``, how long that kernel really ran) in
+        microseconds, on the launch stream (``icem_profile_overhead``): their difference is the bracket's share of every
+        ``profile_read`` span."""
+        pair, kern = C.c_double(), C.c_double()
+        L.check(self.lib.icem_profile_overhead(self._stream(), reps, spin_us, C.byref(pair), C.byref(kern)))
+        return pair.value, kern.value
 
     def get_action_host(self, obs) -> Tuple[np.ndarray, float]:
         """One MPC step for a host caller (``icem_get_action``): float64 observation in, ``(executed action [d] float64,

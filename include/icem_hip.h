@@ -402,12 +402,12 @@ int icem_profile_enable(icem_handle* h, int32_t on);
  * icem_rssm_rollout_cost instead: 16 int64 of wall_clock64 stamps of tile 0 (icem_rssm_split.hip). */
 int icem_debug_stamps(icem_handle* h, void* dev_ptr);
 int icem_profile_read(icem_handle* h, double* total_ms, int64_t* launches, int64_t* units);
-/* What an event pair adds to the kernel it brackets (measurement only; stateless).  Times `reps` event pairs around ONE
- * empty launch and `reps` around TWO on `stream`: *pair_us = median of the first, *marginal_us = what the second empty
- * launch added (a launch's cost inside a chain of dependent launches).  pair_us - marginal_us is the part of every
- * icem_profile_read span that is the bracket, not the kernel: bench.py subtracts it so that the per-kernel times sum to
- * the step they were taken from. */
-int icem_profile_overhead(void* stream, int32_t reps, double* pair_us, double* marginal_us);
+/* What an event pair adds to the kernel it brackets (measurement only; stateless).  Times `reps` event pairs on `stream`
+ * around a one-wave kernel that spins for spin_us of the 100 MHz wall clock and reports how long it really ran:
+ * *pair_us = median event-pair time, *kernel_us = median in-kernel duration.  pair_us - kernel_us is the part of every
+ * icem_profile_read span that is the bracket (dispatch in front, the closing event behind), not the kernel; bench.py
+ * subtracts it so that the per-kernel times sum to the step they were taken from. */
+int icem_profile_overhead(void* stream, int32_t reps, double spin_us, double* pair_us, double* kernel_us);
 
 /* Byte size / layout of one candidate record: {cost (T), gidx (int32, padded to sizeof(T)),
  * actions[h*d] (T)}; all-gather moves K records per rank. */
