@@ -516,12 +516,22 @@ size_t icem_record_bytes(const icem_handle* h) { return h ? (size_t)(h->hd + 2) 
 
 size_t icem_rssm_param_elems(void) { return rssm::TOTAL; }
 
+int icem_rssm_trim(void) {
+    rssm_split_trim();
+    return ICEM_OK;
+}
+
 int icem_rssm_rollout_cost(int32_t n, int32_t horizon, int32_t cost_mode, const void* params, const void* obs0,
                            const void* actions, void* costs, void* stream) {
     if (n < 0 || horizon < 1 || cost_mode < ICEM_COST_SUM || cost_mode > ICEM_COST_FINAL || !params || !obs0 || !actions || !costs)
         return fail(ICEM_E_INVALID, "null tensor / bad n, horizon or cost_mode");
-    ICEM_HIP_TRY(launch_rssm_rollout(n, horizon, cost_mode, (const unsigned short*)params, (const float*)obs0,
-                                     (const float*)actions, (float*)costs, (hipStream_t)stream));
+    const hipError_t e = launch_rssm_rollout(n, horizon, cost_mode, (const unsigned short*)params, (const float*)obs0,
+                                             (const float*)actions, (float*)costs, (hipStream_t)stream);
+    if (e == hipErrorLaunchTimeOut)
+        return fail(ICEM_E_STATE, "learned-dynamics rollout: a reward workgroup of an EARLIER launch on this stream gave up waiting "
+                                  "for its recurrence (that launch's costs are NaN); the staging flags were reset, nothing was "
+                                  "launched by this call -- call again");
+    ICEM_HIP_TRY(e);
     return ICEM_OK;
 }
 

@@ -122,6 +122,7 @@ struct icem_handle {
         uint64_t next_episode = 0;
         int next_step = -1;
         void* next_pool = nullptr;
+        hipStream_t next_stream = nullptr;   // the stream that noise was enqueued on: consumed only by a step on the SAME stream
         // host copy of the action bounds (the transform takes them as scalars: equal in every dimension or no pipeline)
         const void* lo_ptr = nullptr;
         const void* hi_ptr = nullptr;
@@ -136,6 +137,7 @@ struct icem_handle {
         bool pre_valid = false;
         uint64_t pre_episode = 0;
         int pre_step = -1;
+        hipStream_t pre_stream = nullptr;    // (as next_stream)
         int disabled = -1;                   // ICEM_NOISE_AHEAD (latched at first use)
         int min_rows = 0;                    // ICEM_NOISE_AHEAD_MIN_ROWS
     } ahead;
@@ -272,7 +274,7 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
                         void* costs, float* part_c, int* part_i, hipStream_t st, int* lists_out,
                         unsigned long long* part_k = nullptr, int n_tail = 0, int* tail_out = nullptr);
 void ahead_destroy(icem_handle* h);
-void predraw_next_step(icem_handle* h, const icem_plan_buffers* b, int mpc_step);
+void predraw_next_step(icem_handle* h, const icem_plan_buffers* b, int mpc_step, hipStream_t st);
 int launch_fast_sample(const icem_handle* h, int n, long long first_index, const void* mean, const void* std,
                        const void* low, const void* high, uint64_t offset, int row0_mean, void* out, hipStream_t st,
                        int n_shift = 0, const void* elites_src = nullptr, uint64_t offset2 = 0);

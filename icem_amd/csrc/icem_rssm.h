@@ -39,6 +39,7 @@ hipError_t launch_rssm_rollout(int n, int horizon, int cost_mode, const unsigned
                                const float* actions, float* costs, hipStream_t st);
 // n <= 16 * SPLIT_MAX_TILES: one launch of recurrence workgroups + reward-head workgroups (ICEM_RSSM_SPLIT=0 turns it off)
 bool rssm_split_ok(int n, int horizon);
+void rssm_split_trim();                     // frees the split launch's per-(device, stream) staging areas
 void rssm_set_stamps(long long* dev_ptr);   // development aid: 16 int64 of wall_clock64 phase stamps of tile 0 (NULL = off)
 hipError_t launch_rssm_split(int n, int horizon, int cost_mode, const unsigned short* params, const float* obs0,
                              const float* actions, float* costs, hipStream_t st);

@@ -345,7 +345,7 @@ __device__ __forceinline__ void recurrence(ProducerLds<TT>& s, int wg, int tiles
 // the large populations whose reward workgroups run behind the recurrence workgroups (the head's weights are loaded once)
 __device__ __forceinline__ void reward_head(ConsumerLds& s, int first, int stride, int tiles, int n, int horizon, int cost_mode,
                                             const unsigned short* __restrict__ Pg, float* __restrict__ costs,
-                                            const unsigned short* stage, unsigned* flags, long long* stamps) {
+                                            const unsigned short* stage, unsigned* flags, unsigned* status, long long* stamps) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
@@ -366,7 +366,10 @@ __device__ __forceinline__ void reward_head(ConsumerLds& s, int first, int strid
     request<HIDK>(Plane + W8, A8);
     const v4f b8 = *reinterpret_cast<const v4f*>(reinterpret_cast<const float*>(Pg + B8) + 4 * g);
     for (int e = tid; e < 2 * 16 * RS; e += NTHR) { (&s.r1[0][0])[e] = 0; (&s.r2[0][0])[e] = 0; }   // the K padding of the rows
-    if (tid == 0) s.gave_up = 0;
+    // A reward workgroup that gave up in an EARLIER launch left this staging area's flags in an unknown state (its stalled
+    // producer kept storing behind the reset): the status word stays raised until the host has zeroed the flags
+    // (launch_rssm_split), and until then every launch reports NaN instead of scoring stale states.
+    if (tid == 0) s.gave_up = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
     __syncthreads();
     const int xr = j * RS + 8 * g, xo = j * RS + 4 * g;
     if (stamp) stamps[9] = wall_clock64();
@@ -389,7 +392,14 @@ __device__ __forceinline__ void reward_head(ConsumerLds& s, int first, int strid
                 unsigned polls = 0;
                 unsigned v;
                 while ((int)((v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - (unsigned)(t + 1)) < 0) {
-                    if (++polls > MAX_POLLS) { if (lane == 0) s.gave_up = 1; v = (unsigned)horizon; break; }
+                    if (++polls > MAX_POLLS) {
+                        if (lane == 0) {
+                            s.gave_up = 1;
+                            __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-visible
+                        }
+                        v = (unsigned)horizon;
+                        break;
+                    }
                     __builtin_amdgcn_s_sleep(4);
                 }
                 if (lane == 0) s.avail[par] = (int)v;
@@ -455,19 +465,22 @@ __device__ __forceinline__ void reward_head(ConsumerLds& s, int first, int strid
 template <int TT>
 __global__ __launch_bounds__(NTHR) void rssm_split_kernel(int n, int horizon, int cost_mode, const unsigned short* __restrict__ Pg,
                                                          const float* __restrict__ obs0, const float* __restrict__ actions,
-                                                         float* __restrict__ costs, unsigned short* stage, unsigned* flags, int tiles,
-                                                         int prods, long long* stamps) {
+                                                         float* __restrict__ costs, unsigned short* stage, unsigned* flags,
+                                                         unsigned* status, int tiles, int prods, long long* stamps) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[lds_bytes<TT>()];
     const int b = blockIdx.x;
     if (b < prods) recurrence<TT>(*reinterpret_cast<ProducerLds<TT>*>(smem), b, tiles, n, horizon, Pg, obs0, actions, stage, flags, stamps);
     else reward_head(*reinterpret_cast<ConsumerLds*>(smem), b - prods, (int)gridDim.x - prods, tiles, n, horizon, cost_mode, Pg, costs, stage,
-                     flags, stamps);
+                     flags, status, stamps);
 }
 
-// One staging area per (device, stream): launches on a stream are ordered, so they may share it.
+// One staging area per (device, stream): launches on a stream are ordered, so they may share it.  (Areas live until
+// rssm_split_trim(): 25 MB for populations up to 4096, up to 403 MB at 65 536 rows, per stream ever used.)
 struct Staging {
     unsigned short* stage = nullptr;
     unsigned* flags = nullptr;
+    unsigned* status = nullptr;      // pinned, device-mapped word: raised by a reward workgroup whose wait timed out
+    unsigned* status_dev = nullptr;  // (its device address)
     size_t items = 0;
 };
 std::mutex g_mu;
@@ -476,6 +489,17 @@ std::map<std::pair<int, hipStream_t>, Staging> g_staging;
 }  // namespace
 
 void rssm_set_stamps(long long* dev_ptr) { g_stamps = dev_ptr; }
+
+// free every staging area (the caller has no launch of this path in flight)
+void rssm_split_trim() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& kv : g_staging) {
+        if (kv.second.stage) (void)hipFree(kv.second.stage);
+        if (kv.second.flags) (void)hipFree(kv.second.flags);
+        if (kv.second.status) (void)hipHostFree(kv.second.status);
+    }
+    g_staging.clear();
+}
 
 bool rssm_split_ok(int n, int horizon) {
     static const bool on = [] { const char* e = std::getenv("ICEM_RSSM_SPLIT"); return !(e && e[0] == '0'); }();
@@ -493,28 +517,41 @@ hipError_t launch_rssm_split(int n, int horizon, int cost_mode, const unsigned s
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    Staging sg;
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        Staging& s = g_staging[{dev, st}];
-        // (8 KB per tile and step: 25 MB cover the populations up to 4096 at h = 12; larger ones grow it, to 403 MB at 65 536)
-        const size_t want = (size_t)(tiles > rssm::SPLIT_TT1_TILES ? tiles : rssm::SPLIT_TT1_TILES) * horizon;
-        if (s.items < want) {   // (first call on this stream, or a longer horizon: not inside a capture)
-            if (s.stage) {
-                if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
-                (void)hipFree(s.stage);
-                s.stage = nullptr; s.items = 0;
-            }
-            if ((e = hipMalloc(&s.stage, want * ITEM * sizeof(unsigned short))) != hipSuccess) return e;
-            if ((e = hipMemset(s.stage, 0, want * ITEM * sizeof(unsigned short))) != hipSuccess) return e;   // K padding stays zero
-            s.items = want;
-        }
-        if (!s.flags) {
-            if ((e = hipMalloc(&s.flags, rssm::SPLIT_TILE_LIMIT * sizeof(unsigned))) != hipSuccess) return e;
-            if ((e = hipMemset(s.flags, 0, rssm::SPLIT_TILE_LIMIT * sizeof(unsigned))) != hipSuccess) return e;
-        }
-        sg = s;
+    // The launch stays inside the lock: another host thread that grows this stream's staging synchronises the stream and
+    // frees the old area, which must not happen between reading the pointers and enqueuing the kernel that uses them.
+    std::lock_guard<std::mutex> lk(g_mu);
+    Staging& s = g_staging[{dev, st}];
+    if (!s.status) {
+        if ((e = hipHostMalloc((void**)&s.status, sizeof(unsigned), hipHostMallocMapped)) != hipSuccess) return e;
+        *s.status = 0u;
+        if ((e = hipHostGetDevicePointer((void**)&s.status_dev, s.status, 0)) != hipSuccess) return e;
     }
+    if (__atomic_load_n(s.status, __ATOMIC_RELAXED) != 0u) {
+        // a reward workgroup of an earlier launch on this stream gave up waiting: that launch returned NaN costs and its
+        // flags are in an unknown state.  Quiesce, reset, and tell the caller (once) instead of launching on top of it.
+        (void)hipStreamSynchronize(st);
+        if (s.flags) (void)hipMemsetAsync(s.flags, 0, rssm::SPLIT_TILE_LIMIT * sizeof(unsigned), st);
+        (void)hipStreamSynchronize(st);
+        __atomic_store_n(s.status, 0u, __ATOMIC_RELAXED);
+        return hipErrorLaunchTimeOut;
+    }
+    // (8 KB per tile and step: 25 MB cover the populations up to 4096 at h = 12; larger ones grow it, to 403 MB at 65 536)
+    const size_t want = (size_t)(tiles > rssm::SPLIT_TT1_TILES ? tiles : rssm::SPLIT_TT1_TILES) * horizon;
+    if (s.items < want) {   // (first call on this stream, or a longer horizon: not inside a capture)
+        if (s.stage) {
+            if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+            (void)hipFree(s.stage);
+            s.stage = nullptr; s.items = 0;
+        }
+        if ((e = hipMalloc(&s.stage, want * ITEM * sizeof(unsigned short))) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(s.stage, 0, want * ITEM * sizeof(unsigned short), st)) != hipSuccess) return e;   // K padding stays zero
+        s.items = want;
+    }
+    if (!s.flags) {
+        if ((e = hipMalloc(&s.flags, rssm::SPLIT_TILE_LIMIT * sizeof(unsigned))) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(s.flags, 0, rssm::SPLIT_TILE_LIMIT * sizeof(unsigned), st)) != hipSuccess) return e;
+    }
+    const Staging& sg = s;
     // Up to 256 tiles: one tile per recurrence workgroup and one reward workgroup per tile (up to 128 tiles both kinds are
     // resident together).  Beyond: two tiles per recurrence workgroup (they share every weight chunk) and 512 reward
     // workgroups that walk the tiles behind them.  (ICEM_RSSM_SPLIT_TT = 1 | 2 overrides the tiles per workgroup.)
@@ -524,10 +561,10 @@ hipError_t launch_rssm_split(int n, int horizon, int cost_mode, const unsigned s
     if (tt == 2) {
         const int prods = (tiles + 1) / 2;
         hipLaunchKernelGGL(rssm_split_kernel<2>, dim3(prods + heads), dim3(NTHR), 0, st, n, horizon, cost_mode, params, obs0, actions,
-                           costs, sg.stage, sg.flags, tiles, prods, g_stamps);
+                           costs, sg.stage, sg.flags, sg.status_dev, tiles, prods, g_stamps);
     } else {
         hipLaunchKernelGGL(rssm_split_kernel<1>, dim3(tiles + heads), dim3(NTHR), 0, st, n, horizon, cost_mode, params, obs0, actions, costs,
-                           sg.stage, sg.flags, tiles, tiles, g_stamps);
+                           sg.stage, sg.flags, sg.status_dev, tiles, tiles, g_stamps);
     }
     return hipGetLastError();
 }

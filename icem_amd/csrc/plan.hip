@@ -403,8 +403,9 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                 fa.s = fast_sample_args(h, n_loc, lo, b->mean, b->std, b->low, b->high, off, row0, actions,
                                         shift_in_sampler ? n_extra : 0, shift_src, call_base + (uint64_t)c.opt_iters);
                 if (it == 0 && c.world == 1 && h->ahead.pre_valid) {
-                    // this step's first noise (and the shifted elites') was drawn beside the previous step's last merge
-                    if (h->ahead.pre_episode == h->episode && h->ahead.pre_step == mpc_step) fa.s.raw_src = (const float*)h->ahead.pre_raw;
+                    // this step's first noise (and the shifted elites') was drawn beside the previous step's last merge -- on
+                    // pre_stream: a step enqueued on another stream is not ordered behind that launch and redraws instead
+                    if (h->ahead.pre_episode == h->episode && h->ahead.pre_step == mpc_step && h->ahead.pre_stream == st) fa.s.raw_src = (const float*)h->ahead.pre_raw;
                     h->ahead.pre_valid = false;
                 }
                 fa.r = fast_rollout_args(h, n_rows, n_cand, K, b->obs0, actions, b->costs, pc, pi);
@@ -782,7 +783,8 @@ static int plan_step_ahead(icem_handle* h, const icem_plan_buffers* b, int mpc_s
         bb.std = cur_std;
         if (it == 0) {
             // this step's first noise: drawn by the previous step's last launch -- or, for a step nobody predicted, here
-            const bool hit = A.next_valid && A.next_episode == h->episode && A.next_step == mpc_step && A.next_pool == pool;
+            const bool hit = A.next_valid && A.next_episode == h->episode && A.next_step == mpc_step && A.next_pool == pool &&
+                             A.next_stream == st;   // (another stream is not ordered behind the launch that drew it: a miss)
             A.next_valid = false;
             if (!hit) {
                 const FastSampleArgs za = noise_args(n, call_base, pool);
@@ -830,6 +832,7 @@ static int plan_step_ahead(icem_handle* h, const icem_plan_buffers* b, int mpc_s
             A.next_episode = h->episode;
             A.next_step = mpc_step + 1;
             A.next_pool = np;
+            A.next_stream = st;
         }
         // the shift role (icem.py:91-104, 131-137): rows [n, n + n_extra) of this pool, costs behind costs[n]
         if (it == 0 && n_extra > 0) {
@@ -917,7 +920,8 @@ static int plan_step_sharded_ahead(icem_handle* h, const icem_plan_buffers* b, i
         bb.mean = cur_mean;
         bb.std = cur_std;
         if (it == 0) {
-            const bool hit = A.next_valid && A.next_episode == h->episode && A.next_step == mpc_step && A.next_pool == pool;
+            const bool hit = A.next_valid && A.next_episode == h->episode && A.next_step == mpc_step && A.next_pool == pool &&
+                             A.next_stream == st;   // (another stream is not ordered behind the launch that drew it: a miss)
             A.next_valid = false;
             if (!hit) {
                 const FastSampleArgs za = noise_args(n_loc, lo, call_base, pool);
@@ -962,6 +966,7 @@ static int plan_step_sharded_ahead(icem_handle* h, const icem_plan_buffers* b, i
             A.next_episode = h->episode;
             A.next_step = mpc_step + 1;
             A.next_pool = np;
+            A.next_stream = st;
         }
         if (tail > 0) {
             const int g = (int)(((long long)mpc_step * iters) & 1);
@@ -1037,7 +1042,7 @@ static int plan_step_sharded_ahead(icem_handle* h, const icem_plan_buffers* b, i
 // so it is drawn beside THIS step's last merge, the one launch that leaves 255 CUs idle (merge_noise_kernel), into a
 // buffer of the handle; iteration 0 of the next step then only maps it (FastSampleArgs::raw_src).  Same sample_row, same
 // map: same bits as sampling in place.  Arms h->ahead.tail_args for plan_iter_merge_t's last launch.
-void predraw_next_step(icem_handle* h, const icem_plan_buffers* b, int mpc_step) {
+void predraw_next_step(icem_handle* h, const icem_plan_buffers* b, int mpc_step, hipStream_t st) {
     icem_handle::Ahead& A = h->ahead;
     const icem_config& c = h->cfg;
     static const int on = [] { const char* e = getenv("ICEM_PREDRAW"); return e ? atoi(e) : 1; }();
@@ -1066,6 +1071,7 @@ void predraw_next_step(icem_handle* h, const icem_plan_buffers* b, int mpc_step)
     A.pre_valid = true;
     A.pre_episode = h->episode;
     A.pre_step = mpc_step + 1;
+    A.pre_stream = st;
 }
 
 }  // namespace icem
@@ -1192,8 +1198,19 @@ int icem_plan_iter_merge(icem_handle* h, const icem_plan_buffers* b, int32_t mpc
     return ICEM_OK;
 }
 
-int icem_plan_step_sharded(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, void* stream) {
-    if (check_handle(h)) return ICEM_E_INVALID;
+// A step that failed half way must not leave arguments armed for a later step's launches (stale merge / pack / noise
+// arguments would reach kernels with buffers of a step that never completed).
+static int disarm_on_error(icem_handle* h, int rc) {
+    if (rc != ICEM_OK) {
+        h->ahead.tail_pending = h->ahead.next_valid = h->ahead.pre_valid = false;
+        h->pm_pending = h->pk_pending = false;
+        h->defer_merge = false;
+        h->merge_mean_out = h->merge_std_out = nullptr;
+    }
+    return rc;
+}
+
+static int plan_step_sharded_body(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, void* stream) {
     if (h->cfg.world < 2) return icem_plan_step(h, b, mpc_step, stream);
     if (!xchg_connected(h) && !rccl_connected(h))
         return fail(ICEM_E_STATE, "neither the in-library exchange (icem_exchange_create / _connect) nor an RCCL communicator "
@@ -1219,8 +1236,12 @@ int icem_plan_step_sharded(icem_handle* h, const icem_plan_buffers* b, int32_t m
     return rc;
 }
 
-int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, void* stream) {
+int icem_plan_step_sharded(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, void* stream) {
     if (check_handle(h)) return ICEM_E_INVALID;
+    return disarm_on_error(h, plan_step_sharded_body(h, b, mpc_step, stream));
+}
+
+static int plan_step_body(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, void* stream) {
     if (h->cfg.world != 1) return fail(ICEM_E_INVALID, "icem_plan_step is the world == 1 path; use iter_local/iter_merge");
     int rc = check_plan(h, b, mpc_step, 0);
     if (rc) return rc;
@@ -1231,10 +1252,8 @@ int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step,
     // reads pool / lists / distribution of iteration it while writing its own, so consecutive iterations alternate
     // between the caller's buffers and the handle's partners (the last iteration always uses the caller's).
     const bool pingpong = c.dtype == ICEM_F32 && b->z_r == nullptr && h->use_fast && iters > 1;
-    if (pingpong && !h->actions_alt) {
-        ICEM_HIP_TRY(hipMalloc(&h->actions_alt, icem_plan_buffer_bytes(h, ICEM_BUF_ACTIONS)));
-        ICEM_HIP_TRY(hipMalloc(&h->ws_alt, icem_plan_buffer_bytes(h, ICEM_BUF_WORKSPACE)));
-    }
+    if (pingpong && !h->actions_alt) ICEM_HIP_TRY(hipMalloc(&h->actions_alt, icem_plan_buffer_bytes(h, ICEM_BUF_ACTIONS)));
+    if (pingpong && !h->ws_alt) ICEM_HIP_TRY(hipMalloc(&h->ws_alt, icem_plan_buffer_bytes(h, ICEM_BUF_WORKSPACE)));   // (ahead_setup may own one already)
     if (pingpong) {
         rc = ensure_pp_stats(h);
         if (rc) return rc;
@@ -1252,7 +1271,7 @@ int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step,
         rc = icem_plan_iter_local(h, &bb, mpc_step, it, stream);
         if (rc) return rc;
         const bool last = it == iters - 1;
-        if (last) predraw_next_step(h, b, mpc_step);  // small populations: the next step's first noise rides with the last merge
+        if (last) predraw_next_step(h, b, mpc_step, (hipStream_t)stream);  // small populations: the next step's first noise rides with the last merge
         bool fold = false;
         if (pingpong && !last && h->fast_lists > 0) fold = prologue_possible(h, h->pop[it + 1]);
         h->defer_merge = fold;
@@ -1280,6 +1299,11 @@ int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step,
         }
     }
     return ICEM_OK;
+}
+
+int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    return disarm_on_error(h, plan_step_body(h, b, mpc_step, stream));
 }
 
 // MpcICem.get_action as one call for a host caller: observation in, executed action (+ its pool's best cost) out.

@@ -447,7 +447,8 @@ class IcemPlanner:
         # find out BEFORE anybody enters the blocking call
         import socket
         where = [None] * self.cfg.world
-        mine = (socket.gethostname(), torch.cuda.current_device(),
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        mine = (socket.gethostname(), dev_index,
                 tuple(os.environ.get(k, "") for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")))
         dist.all_gather_object(where, mine, group=group)
         if len(set(where)) < self.cfg.world:
@@ -469,10 +470,11 @@ class IcemPlanner:
         if all(oks):   # (ncclCommInitRank blocks until every rank has called it: only enter it together)
             try:
                 blob = (C.c_ubyte * L.RCCL_ID_BYTES).from_buffer_copy(ident[0])
-                L.check(self.lib.icem_rccl_connect(self._h, blob))
-                # ... and one real all-gather of the (zeroed) record buffer
-                L.check(self.lib.icem_allgather_elites(self._h, _ptr(self.records), self._stream()))
-                torch.cuda.current_stream(self.device).synchronize()
+                with torch.cuda.device(self.device):   # ncclCommInitRank binds the CURRENT device: the planner's, not torch's default
+                    L.check(self.lib.icem_rccl_connect(self._h, blob))
+                    # ... and one real all-gather of the (zeroed) record buffer
+                    L.check(self.lib.icem_allgather_elites(self._h, _ptr(self.records), self._stream()))
+                    torch.cuda.current_stream(self.device).synchronize()
             except (L.IcemError, RuntimeError) as e:
                 err = e
             dist.all_gather_object(oks, err is None, group=group)

@@ -423,8 +423,12 @@ size_t icem_record_bytes(const icem_handle* h);
  * memory (8 KB per 16 trajectories and step: 25 MB up to 4096 rows at h = 12, grown on demand to 403 MB at 65 536); the
  * library keeps one such area per (device, stream), allocated at the
  * first call on that stream -- which therefore must not be inside a stream capture (later ones may be: the launch
- * leaves its flags as it found them). */
+ * leaves its flags as it found them).  A reward workgroup whose bounded wait for its recurrence times out reports NaN
+ * costs and raises a host-visible word: every later launch on that stream reports NaN too until the NEXT call of this
+ * function, which resets the flags, launches nothing and returns ICEM_E_STATE once.  icem_rssm_trim() frees the staging
+ * areas (no launch of this path may be in flight). */
 size_t icem_rssm_param_elems(void);
+int icem_rssm_trim(void);
 int icem_rssm_rollout_cost(int32_t n, int32_t horizon, int32_t cost_mode, const void* params, const void* obs0,
                            const void* actions, void* costs, void* stream);
 
