@@ -19,7 +19,9 @@
 #include "refit.h"
 
 // shapes (H, D, O) with a compiled matrix-pipe rollout; anything else runs on the generic kernels
+#ifndef ICEM_FAST_SHAPES   // (a development build may narrow the list: ICEM_DEV_SHAPES=30,6,17 python -m icem_amd.build)
 #define ICEM_FAST_SHAPES(X) X(30, 6, 17) X(30, 6, 18) X(12, 6, 17) X(13, 4, 17) X(30, 17, 24)
+#endif
 // horizons with a compiled folded sampler
 #define ICEM_FAST_HORIZONS(X) X(30) X(12) X(13) X(10)
 
@@ -1168,13 +1170,18 @@ __device__ __forceinline__ void merge_select_split_stage1(const MergeSingleArgs&
         if (lane >= a.K && lane < 16) out[lane] = KEY_SENTINEL;
     }
 }
+// the kept elite's cost of lane `lane` (icem.py:143-145) for stage 2: a cold load of its own -- callers request it in front
+// of stage 1 so that it travels with the lists' keys instead of behind the workgroup barrier
+__device__ __forceinline__ float merge_keep_cost(const MergeSingleArgs& a, int lane) {
+    return a.elites_cost_cur ? a.elites_cost_cur[lane < a.n_keep ? lane : 0] : 0.f;
+}
 __device__ __forceinline__ void merge_select_split_stage2(const MergeSingleArgs& a, int lane, int nw, const unsigned long long* wsel,
-                                                          unsigned long long* cand, unsigned long long* sel) {
+                                                          unsigned long long* cand, unsigned long long* sel, float keep_cost) {
     // nw * 16 <= 256 slots (sentinels behind each wave's K keys): four per lane, + kept elite `lane` (icem.py:143-145)
     unsigned long long k[5];
 #pragma unroll
     for (int j = 0; j < 4; ++j) k[j] = (lane + 64 * j < nw * 16) ? *((volatile const unsigned long long*)&wsel[lane + 64 * j]) : KEY_SENTINEL;
-    k[4] = (lane < a.n_keep && a.elites_cost_cur) ? make_key(a.elites_cost_cur[lane], keep_index0(a) + lane) : KEY_SENTINEL;
+    k[4] = (lane < a.n_keep && a.elites_cost_cur) ? make_key(keep_cost, keep_index0(a) + lane) : KEY_SENTINEL;
     unsigned long long mine = k[0];
 #pragma unroll
     for (int j = 1; j < 5; ++j) mine = k[j] < mine ? k[j] : mine;

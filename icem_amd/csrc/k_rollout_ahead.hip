@@ -90,9 +90,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
             pk.elites_cost_cur = args.p.keep_costs;
             pk.keep_base = args.p.n_loc;
             __builtin_amdgcn_s_setprio(3);  // everybody else waits for this workgroup
+            const float pk_keep = merge_keep_cost(pk, lane);
             merge_select_split_stage1<KREG>(pk, lane, wave, WAVES, cand, wsel);
             __syncthreads();
-            if (wave == 0) merge_select_split_stage2(pk, lane, WAVES, wsel, cand, sel);
+            if (wave == 0) merge_select_split_stage2(pk, lane, WAVES, wsel, cand, sel, pk_keep);
             __syncthreads();
             pack_records_body<KREG>(pk, args.p.n_loc, args.p.shard_lo, args.p.records, args.p.px, stage, sel, tid, NTT);
             __syncthreads();
@@ -225,12 +226,14 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
     const int tile0 = wave * n_roll + bid;
     typename Stream::Vec pre[Stream::NLD];
     if constexpr (PM == 1) {
-        // all waves share the selection: one cold round trip instead of a dozen dependent ones
+        // all waves share the selection: one cold round trip instead of a dozen dependent ones (the kept elites' costs,
+        // stage 2's other input, travel with it)
+        const float keep_cost = merge_keep_cost(args.m, lane);
         merge_select_split_stage1<KREG>(args.m, lane, wave, WAVES, cand, wsel);
         // (this wave's first noise vectors: requested behind its keys, in flight across the barriers below)
         if (tile0 < tiles) stream.first_loads(args.pool, a.n_rows, tile0, pre);
         __syncthreads();
-        if (wave == 0) merge_select_split_stage2(args.m, lane, WAVES, wsel, cand, sel);
+        if (wave == 0) merge_select_split_stage2(args.m, lane, WAVES, wsel, cand, sel, keep_cost);
     } else if constexpr (PM == 2) {
         // sharded: the pack role merges for everybody -- wait for its flag (bounded like every exchange wait)
         if (tile0 < tiles) stream.first_loads(args.pool, a.n_rows, tile0, pre);
