@@ -129,6 +129,7 @@ SYMBOLS = [
     ("icem_allgather_elites", C.c_int, [_H, _VP, _VP]),
     ("icem_profile_read", C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("icem_rssm_trim", C.c_int, []),
+    ("icem_set_wide_exact", C.c_int, [_H, _I32]),
     ("icem_profile_overhead", C.c_int, [_VP, _I32, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 ]
 

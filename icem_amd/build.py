@@ -16,7 +16,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 UNITS = ["generic_kernels.hip", "plan.hip", "abi.hip", "exchange.hip", "k_sample.hip", "k_rollout.hip", "k_merge.hip",
-         "k_iter_small.hip", "icem_rssm.hip", "icem_rssm_split.hip", "k_rollout_wide.hip", "collective.hip", "k_rollout_ahead.hip"]
+         "k_iter_small.hip", "icem_rssm.hip", "icem_rssm_split.hip", "k_rollout_wide.hip", "collective.hip", "k_rollout_ahead.hip",
+         "k_rollout_wide_split.hip"]
 OUT = os.path.join(HERE, "libicem_hip.so")
 MARK = b"ICEM_BUILD_HASH="  # abi.hip embeds MARK + the 16 hex digits of source_hash()
 OBJ = os.path.join(CSRC, "_obj")

@@ -184,6 +184,7 @@ int icem_destroy(icem_handle* h) {
     if (h->B_dev) (void)hipFree(h->B_dev);
     if (h->Mp_dev) (void)hipFree(h->Mp_dev);
     if (h->Mw_dev) (void)hipFree(h->Mw_dev);
+    if (h->Mws_dev) (void)hipFree(h->Mws_dev);
     if (h->wide_cs_dev) (void)hipFree(h->wide_cs_dev);
     if (h->pub_dev) (void)hipFree(h->pub_dev);
     if (h->perm_dev) (void)hipFree(h->perm_dev);
@@ -445,6 +446,12 @@ int icem_debug_stamps(icem_handle* h, void* dev_ptr) {
     }
     if (check_handle(h)) return ICEM_E_INVALID;
     h->dbg = (long long*)dev_ptr;
+    return ICEM_OK;
+}
+
+int icem_set_wide_exact(icem_handle* h, int32_t on) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    h->wide_exact = on != 0;
     return ICEM_OK;
 }
 

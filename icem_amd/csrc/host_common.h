@@ -94,6 +94,8 @@ struct icem_handle {
     // permuted, padded model of the matrix-pipe rollout: column 0 = obs[lin_idx], column 1 = obs[flip_idx]
     bool wide = false;           // obs_dim > 32: the rollout is k_rollout_wide.hip's GEMM kernel (f32 only)
     void* Mw_dev = nullptr;      // its packed model
+    void* Mws_dev = nullptr;     // ... and as three bf16 planes (k_rollout_wide_split.hip), the default wide rollout
+    bool wide_exact = false;     // icem_set_wide_exact: the exact-f32 matrix pipe instead (k_rollout_wide.hip + its row kernel)
     void* wide_cs_dev = nullptr; // CostArgs<float> (cost spec + terms) for k_rollout_wide, refreshed by the cost setters
     void* Mp_dev = nullptr;
     void* perm_dev = nullptr;

@@ -92,7 +92,8 @@ struct WideRolloutArgs {
     int lin_idx, flip_idx;
     float ctrl_w, lin_w, flip_pen, flip_th;
     const CostArgs<float>* cs;   // icem_cost_terms on: the same + the terms, in device memory (NULL: off)
-    const float* Mp;      // pack_wide_model
+    long long* dbg;       // development: 8 wall_clock64 phase stamps of one wave (rollout_wide_split_kernel; tools/dbg/split_stamps.py), nullptr in production
+    const float* Mp;      // pack_wide_model / pack_wide_model_split
     const float* obs0;
     const float* actions;
     float* costs;
@@ -106,6 +107,13 @@ int wide_kb(int o, int d);
 int wide_xs(int o, int d);
 void pack_wide_model(int o, int d, const double* A, const double* B, std::vector<float>& Mp);
 void launch_rollout_wide(const WideRolloutArgs& a, int kind, hipStream_t st);
+// ... the same on the bf16 matrix cores (k_rollout_wide_split.hip): every f32 operand as three bf16 planes, six products
+// per MAC, up to 80 trajectories per workgroup; a.Mp = pack_wide_model_split's planes, a.kb / a.xs = wide_split_kb / _xs
+int wide_split_kb(int o, int d);
+int wide_split_xs(int o, int d);
+int wide_split_lists(int n_rows);
+void pack_wide_model_split(int o, int d, const double* A, const double* B, std::vector<unsigned short>& Mb);
+void launch_rollout_wide_split(const WideRolloutArgs& a, int kind, hipStream_t st);
 // rows [row0, row0 + n_tail) of the same pool one workgroup each, from the row-major f32 model (A [o, o], B [d, o]); costs only
 void launch_rollout_rows_wide(const WideRolloutArgs& a, int row0, int n_tail, const float* A, const float* B, int kind,
                               hipStream_t st);

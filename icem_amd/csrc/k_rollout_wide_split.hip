@@ -1,0 +1,378 @@
+// k_rollout_wide_split.hip -- K2 + K3 for WIDE observations (32 < o <= 384; HumanoidStandup's o = 378, d = 17:
+// icem/environments/mujoco.py:241-277) with the model step on the bf16 matrix cores: rollout_wide_split_kernel.
+//
+// The step [n, o + d] x [o + d, o] is a GEMM three orders of magnitude above the f32 ridge, and the exact-f32 MFMA of
+// k_rollout_wide.hip runs at 1/16 of the bf16 rate.  Here every f32 value is the exact sum of three bf16 numbers
+// (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): 3 x 8 significant bits) and a product x * m is the six
+// bf16 x bf16 products whose weight is above 2^-24 of it -- hi*Hi, hi*Mid, mid*Hi, hi*Lo, lo*Hi, mid*Mid -- each EXACT in
+// the f32 accumulator's format, summed smallest first on v_mfma_f32_16x16x32_bf16.  What is dropped (mid*Lo, lo*Mid,
+// lo*Lo) is below 2^-31 of a product: the result is an f32 dot product with f32-class rounding, not the bits of an fmaf
+// chain (error analysis: DESIGN.md section 4).  Six K = 32 MFMAs of 16 cycles replace eight K = 4 MFMAs of 32.
+//
+// Tiling.  A 16-row tile per wave (k_rollout_wide.hip) streams the whole model through every wave every step; in three
+// bf16 planes that is 958 KB per 16 rows and step -- more than a CU's L2 port delivers.  So a WORKGROUP owns up to 80
+// trajectories (five 16-row tiles; four is the regular batch, the fifth takes the few rows a population leaves behind
+// whole batches -- the shifted elites of iteration 0, icem.py:131-137 -- instead of a second round of workgroups):
+//   * their contraction vectors [obs | action | 0-pad] live in LDS as f32 rows X[80][XS] (134 KB: one workgroup per CU);
+//   * wave w of 8 (two per SIMD) owns the output column tiles NCT w .. NCT w + NCT - 1 for ALL the workgroup's
+//     trajectories -- NCT x 5 accumulator tiles (60 registers at o = 378) -- and streams only ITS eighth of the model: per
+//     32-deep contraction block 3 planes x NCT 16-byte loads per lane, one block requested ahead in a second register set;
+//   * per block and trajectory tile: 32 bytes of X per lane (the B operand's 8 contraction entries), split into the three
+//     planes in registers (every wave splits the same values: 36 VALU per 6 NCT MFMAs), then NCT x 6 MFMAs, product by
+//     product over the column tiles so that consecutive MFMAs write different accumulators.  Two waves per SIMD because
+//     a lone wave runs its split and its MFMAs one after the other (tools/ubench/mfma_bf16_shadow.hip: a VALU burst behind
+//     36 MFMAs costs 6-8 cycles per MFMA, one VALU instruction behind EACH MFMA costs nothing, a v_pk_add_f32 behind each
+//     doubles it -- and the compiler emits the burst, packed, whatever the source order or sched_group_barrier ask for;
+//     the hand-ordered asm stream that fixes this is tools/experiments/r04_wide_split_asm_stream.hip.txt, EXPERIMENTS R4.4);
+//   * the step's actions are requested one step ahead and held in registers across the model loop;
+//   * two workgroup barriers per step (X read by everybody -> X rewritten column block by column block);
+//   * step cost, candidate lists and the running top-K as in k_rollout_wide.hip (trajectory tile tt is scored by wave tt's
+//     lanes 0..15 from X); icem_cost_terms included (EXT).
+// Model operand layout (pack_wide_model_split): Mb[kb][wave][ct][plane][lane] = 8 bf16 = M[32 kb + 8 (lane / 16) + v]
+// [16 (NCT wave + ct) + lane % 16], planes in the order lo, mid, hi.
+#include "fused_dev.h"
+#include "wide_dev.h"
+
+namespace icem {
+
+namespace {
+
+constexpr int SPLIT_TT = 5;      // trajectory tiles per workgroup batch (regular batches take 4)
+constexpr int SPLIT_WAVES = 8;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// x -> (hi, residual): hi = bf16(x) round-to-nearest-even, both of a pair in one v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned split_pair(float& a, float& b) {
+    const bf16x2 h = __builtin_convertvector(f32x2{a, b}, bf16x2);
+    const unsigned u = __builtin_bit_cast(unsigned, h);
+    // exact: the residual has at most 16 significant bits.  (Spelled as two v_sub_f32: the compiler's v_pk_add_f32 is
+    // an expensive neighbour of MFMAs -- MI355X guide, "price of one filler beside MFMAs".)
+    const float fa = __uint_as_float(u << 16), fb = __uint_as_float(u & 0xFFFF0000u);
+    asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a) : "v"(fa));
+    asm volatile("v_sub_f32 %0, %0, %1" : "+v"(b) : "v"(fb));
+    return u;
+}
+
+struct Planes {
+    u32x4 hi, mid, lo;
+};
+// the three bf16 planes of 8 f32 values (a lane's share of one 32-deep contraction block)
+__device__ __forceinline__ Planes split8(float4 p, float4 q) {
+    float x[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
+    Planes r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.hi[i] = split_pair(x[2 * i], x[2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.mid[i] = split_pair(x[2 * i], x[2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bf16x2 h = __builtin_convertvector(f32x2{x[2 * i], x[2 * i + 1]}, bf16x2);
+        r.lo[i] = __builtin_bit_cast(unsigned, h);
+    }
+    return r;
+}
+
+__device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// One batch of NTT trajectory tiles (rows [row0, row0 + 16 ntt), ntt <= NTT: tiles beyond ntt are computed on whatever their
+// LDS rows hold and dropped -- no predicate inside the model loop) through all H steps.  m0 holds contraction block 0 of the
+// wave's share of the model on entry and on exit.
+template <int NCT, int NTT, int KIND, bool EXT, typename Req>
+__device__ __forceinline__ void split_batch(const WideRolloutArgs& a, float* X, const CostArgs<float>& cs_s, int row0, int ntt, int tid, int lane,
+                                            int wave, u32x4 (&m0)[NCT * 3], u32x4 (&m1)[NCT * 3], Req&& request,
+                                            unsigned long long& run_key, bool& first) {
+    const int j = lane & 15, g = lane >> 4;
+    const int XS = a.xs, KB = a.kb, o = a.o, d = a.d, H = a.h;
+    const WideCost wc{a.lin_idx, a.flip_idx, a.ctrl_w, a.lin_w, a.flip_pen, a.flip_th};
+    const bool sweep = EXT && cs_s.health_idx >= 0, diff = EXT && cs_s.diff_idx >= 0;
+    const int nrow = 16 * ntt;
+    __syncthreads();   // (the previous batch's readers are done with X)
+    for (int e = tid; e < 16 * NTT * XS; e += 64 * SPLIT_WAVES) {
+        const int c = e % XS;
+        X[e] = c < o ? a.obs0[c] : 0.f;
+    }
+    // cost bookkeeping of the trajectory tile this wave scores (tt = wave), in lanes 0..15
+    constexpr int NS = (SPLIT_TT + SPLIT_WAVES - 1) / SPLIT_WAVES;
+    float acc_c[NS] = {}, c_prev[NS] = {}, dold[NS] = {};
+    auto score = [&](int t) {   // finish step t - 1 (its difference term reads the observation now in X), start step t
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int tt = wave + SPLIT_WAVES * s;
+            if (tt >= ntt) continue;   // (wave-uniform)
+            const float* xt = X + (size_t)(16 * tt) * XS;
+            if (t > 0 && lane < 16) {
+                float c = c_prev[s];
+                if (diff) c += wide_diff_cost(cs_s, xt[lane * XS + cs_s.diff_idx], dold[s]);
+                acc_c[s] = wide_accumulate(acc_c[s], c, t - 1, a.cost_mode);
+            }
+            if (t < H) {
+                bool bad = false;
+                if (sweep) {   // lane (j, g) sweeps entries g, g + 4, .. of row j
+                    const float* xj = xt + j * XS;
+                    bool b = false;
+                    for (int k = g; k < o; k += 4) b |= wide_bad_entry(cs_s, xj[k], k);
+                    const unsigned long long mk = __ballot(b);
+                    bad = ((mk >> (lane & 15)) & 0x0001000100010001ull) != 0ull;
+                }
+                if (lane < 16) c_prev[s] = wide_step_cost(wc, EXT, cs_s, xt + lane * XS, o, d, bad, dold[s]);
+            }
+        }
+    };
+    const float* xb = X + j * XS + 8 * g;
+    // The step's actions -> X[:, o .. o + d): element e = tid + 256 i of the batch's [nrow, d] block.  Step t + 1's are
+    // requested at the top of step t and stay in registers across the model loop (a load -> LDS store -> barrier sequence
+    // per step would expose one global round trip per step and element: measured, a third of the launch).
+    constexpr int AE = 4;   // elements per thread held ahead: covers d <= 25 at 80 rows, d <= 32 at 64
+    const bool ahead = nrow * d <= 64 * SPLIT_WAVES * AE;
+    int aoff[AE], xoff[AE];
+    float an[AE];
+#pragma unroll
+    for (int i = 0; i < AE; ++i) {
+        const int e = tid + 64 * SPLIT_WAVES * i;
+        const int r = e / d, c = e - r * d;
+        const bool in = e < nrow * d;
+        xoff[i] = in ? r * XS + o + c : -1;
+        aoff[i] = (in && row0 + r < a.n_rows) ? (r * H) * d + c : -1;   // relative to the batch's first row
+    }
+    const float* abase = a.actions + (size_t)row0 * H * d;
+    auto load_actions = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < AE; ++i) an[i] = aoff[i] >= 0 ? abase[aoff[i] + t * d] : 0.f;
+    };
+    auto store_actions = [&](int t) {
+        if (ahead) {
+#pragma unroll
+            for (int i = 0; i < AE; ++i)
+                if (xoff[i] >= 0) X[xoff[i]] = an[i];
+        } else {
+            for (int e = tid; e < nrow * d; e += 64 * SPLIT_WAVES) {
+                const int r = e / d, c = e - r * d;
+                const int row = row0 + r;
+                X[r * XS + o + c] = row < a.n_rows ? a.actions[((size_t)row * H + t) * d + c] : 0.f;
+            }
+        }
+    };
+    if (ahead) load_actions(0);
+    store_actions(0);
+    long long* st = (a.dbg && blockIdx.x == 3 && tid == 64) ? a.dbg : nullptr;   // development: phase stamps of step 5 (tools/dbg/split_stamps.py)
+    for (int t = 0; t < H; ++t) {
+        if (st && t == 5) st[0] = wall_clock64();
+        __syncthreads();
+        if (st && t == 5) st[1] = wall_clock64();
+        score(t);
+        if (st && t == 5) st[2] = wall_clock64();
+        if (ahead && t + 1 < H) load_actions(t + 1);
+        f32x4 acc[NCT][NTT];
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int tt = 0; tt < NTT; ++tt) acc[c][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto block = [&](const u32x4 (&m)[NCT * 3], int kb) {
+#pragma unroll
+            for (int tt = 0; tt < NTT; ++tt) {
+                const float* xp = xb + (size_t)(16 * tt) * XS + 32 * kb;
+                const Planes b = split8(*reinterpret_cast<const float4*>(xp), *reinterpret_cast<const float4*>(xp + 4));
+                // product by product over the wave's column tiles: consecutive MFMAs write different accumulators
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) acc[c][tt] = mma(m[3 * c + 0], b.hi, acc[c][tt]);    // Lo  * hi
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) acc[c][tt] = mma(m[3 * c + 2], b.lo, acc[c][tt]);    // Hi  * lo
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) acc[c][tt] = mma(m[3 * c + 1], b.mid, acc[c][tt]);   // Mid * mid
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) acc[c][tt] = mma(m[3 * c + 1], b.hi, acc[c][tt]);    // Mid * hi
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) acc[c][tt] = mma(m[3 * c + 2], b.mid, acc[c][tt]);   // Hi  * mid
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) acc[c][tt] = mma(m[3 * c + 2], b.hi, acc[c][tt]);    // Hi  * hi
+            }
+        };
+        // two register sets, one block requested ahead; the request behind the last block is block 0 of the NEXT step
+        int kb = 0;
+#pragma unroll 1
+        for (; kb + 1 < KB; kb += 2) {
+            request(m1, kb + 1);
+            block(m0, kb);
+            request(m0, kb + 2 < KB ? kb + 2 : 0);
+            block(m1, kb + 1);
+        }
+        if (kb < KB) {   // odd block count: the last one (outside the loop: a conditional block inside it costs a copy of every accumulator per trip)
+            block(m0, kb);
+            request(m0, 0);
+        }
+        if (st && t == 5) st[3] = wall_clock64();
+        __syncthreads();   // everybody has read X: the new observation may go in
+        if (st && t == 5) st[4] = wall_clock64();
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            const int col = 16 * (NCT * wave + c) + 4 * g;
+#pragma unroll
+            for (int tt = 0; tt < NTT; ++tt) {
+                f32x4 v = acc[c][tt];
+                if (KIND == 1) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = fast_tanh(v[k]);
+                }
+                float* dst = X + (size_t)(16 * tt + j) * XS + col;
+                if (col + 3 < o) {
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                } else {   // the column group that straddles o: the action slots behind it belong to other threads
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (col + k < o) dst[k] = v[k];
+                }
+            }
+        }
+        if (st && t == 5) st[5] = wall_clock64();
+        if (t + 1 < H) store_actions(t + 1);
+        if (st && t == 5) st[6] = wall_clock64();
+        if (st && t == 6) st[7] = wall_clock64();
+    }
+    __syncthreads();
+    score(H);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int tt = wave + SPLIT_WAVES * s;
+        if (tt >= ntt) continue;
+        const int row = row0 + 16 * tt + (lane & 15);
+        const bool live = row < a.n_rows;
+        if (live && lane < 16) a.costs[row] = acc_c[s];
+        if (a.K > 0) {
+            const unsigned long long key = (lane < 16 && live && row < a.n_cand) ? make_key(acc_c[s], row) : KEY_SENTINEL;
+            run_key = topk_push16(run_key, key, first, a.K, lane);
+            first = false;
+        }
+    }
+}
+
+template <int NCT, int KIND, bool EXT>
+__global__ __launch_bounds__(64 * SPLIT_WAVES) void rollout_wide_split_kernel(WideRolloutArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float X[];  // [16 * SPLIT_TT][XS]
+    __shared__ unsigned long long wg_keys[2][SPLIT_WAVES][32];
+    __shared__ CostArgs<float> cs_s;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (EXT) wide_stage_terms(cs_s, a.cs, tid, 64 * SPLIT_WAVES);
+    // this wave's share of the model: [kb][wave][ct][plane][lane] 16-byte vectors
+    typedef const __attribute__((address_space(1))) u32x4* gvec;
+    gvec Mw = (gvec)a.Mp + (size_t)wave * NCT * 3 * 64 + lane;
+    const size_t kb_stride = (size_t)SPLIT_WAVES * NCT * 3 * 64;
+    auto request = [&](u32x4 (&m)[NCT * 3], int kb) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < NCT * 3; ++e) m[e] = Mw[(size_t)kb * kb_stride + (size_t)e * 64];
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // tiles of this workgroup: T tiles over the grid, the remainder one each to the first workgroups
+    const int tiles = (a.n_rows + 15) / 16;
+    const int base = tiles / (int)gridDim.x, extra = tiles % (int)gridDim.x;
+    int t_begin = (int)blockIdx.x * base + ((int)blockIdx.x < extra ? (int)blockIdx.x : extra);
+    int cnt = base + ((int)blockIdx.x < extra ? 1 : 0);
+    unsigned long long run_key = KEY_SENTINEL;
+    bool first = true;
+    u32x4 m0[NCT * 3], m1[NCT * 3];
+    request(m0, 0);
+    while (cnt > 0) {   // batches of four tiles; a remainder of five is one batch
+        const int ntt = cnt <= SPLIT_TT ? (cnt == SPLIT_TT || cnt < SPLIT_TT - 1 ? cnt : SPLIT_TT - 1) : SPLIT_TT - 1;
+        if (ntt == SPLIT_TT)
+            split_batch<NCT, SPLIT_TT, KIND, EXT>(a, X, cs_s, t_begin * 16, ntt, tid, lane, wave, m0, m1, request, run_key, first);
+        else
+            split_batch<NCT, SPLIT_TT - 1, KIND, EXT>(a, X, cs_s, t_begin * 16, ntt, tid, lane, wave, m0, m1, request, run_key, first);
+        cnt -= ntt;
+        t_begin += ntt;
+    }
+    if (a.K > 0) {
+        FastRolloutArgs fr{};  // wg_merge_emit only looks at the candidate outputs
+        fr.part_k = a.part_k;
+        fr.part_c = a.part_c;
+        fr.part_i = a.part_i;
+        wg_merge_emit<SPLIT_WAVES>(wg_keys, run_key, a.K, lane, wave, fr);
+    }
+}
+
+__host__ unsigned short bf16_rne(float x) {
+    unsigned u;
+    std::memcpy(&u, &x, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__host__ float bf16_f32(unsigned short b) {
+    const unsigned u = (unsigned)b << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+}  // namespace
+
+int wide_split_kb(int o, int d) { return (o + d + 31) / 32; }
+int wide_split_xs(int o, int d) { return 32 * wide_split_kb(o, d) + 4; }
+static int wide_split_nct(int o) { const int nt = (o + 15) / 16; return nt <= 8 ? 1 : nt <= 16 ? 2 : 3; }
+
+// workgroups (= candidate lists): whole batches of four tiles, at most FAST_MAX_LISTS
+int wide_split_lists(int n_rows) {
+    const int tiles = std::max(1, (n_rows + 15) / 16);
+    return std::min(std::max(1, tiles / (SPLIT_TT - 1)), FAST_MAX_LISTS);
+}
+
+// Mb[kb][wave][ct][plane (lo, mid, hi)][lane][v] = plane of (float)M[32 kb + 8 (lane / 16) + v][16 (NCT wave + ct) + lane % 16],
+// M = [A ; B] ([o + d, o], zero padded)
+void pack_wide_model_split(int o, int d, const double* A, const double* B, std::vector<unsigned short>& Mb) {
+    const int KB = wide_split_kb(o, d), NCT = wide_split_nct(o);
+    Mb.assign((size_t)KB * SPLIT_WAVES * NCT * 3 * 64 * 8, 0);
+    auto M = [&](int r, int c) -> double {
+        if (c >= o) return 0.0;
+        if (r < o) return A[(size_t)r * o + c];
+        if (r < o + d) return B[(size_t)(r - o) * o + c];
+        return 0.0;
+    };
+    for (int kb = 0; kb < KB; ++kb)
+        for (int w = 0; w < SPLIT_WAVES; ++w)
+            for (int ct = 0; ct < NCT; ++ct)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int v = 0; v < 8; ++v) {
+                        const float m = (float)M(32 * kb + 8 * (lane / 16) + v, 16 * (NCT * w + ct) + lane % 16);
+                        const unsigned short hi = bf16_rne(m);
+                        const float r1 = m - bf16_f32(hi);
+                        const unsigned short mid = bf16_rne(r1);
+                        const float r2 = r1 - bf16_f32(mid);
+                        const unsigned short lo = bf16_rne(r2);
+                        const size_t at = ((((size_t)kb * SPLIT_WAVES + w) * NCT + ct) * 3) * 64 * 8 + (size_t)lane * 8 + v;
+                        Mb[at] = lo;
+                        Mb[at + 64 * 8] = mid;
+                        Mb[at + 2 * 64 * 8] = hi;
+                    }
+}
+
+void launch_rollout_wide_split(const WideRolloutArgs& a, int kind, hipStream_t st) {
+    const int grid = wide_split_lists(a.n_rows);
+    const size_t lds = (size_t)16 * SPLIT_TT * a.xs * sizeof(float);
+    const int NCT = wide_split_nct(a.o);
+#define XW1(NV, KINDV, EXTV)                                                                                \
+    {                                                                                                       \
+        auto kfn = rollout_wide_split_kernel<NV, KINDV, EXTV>;                                              \
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * SPLIT_WAVES), lds, st, a);                            \
+    }
+#define XW(NV)                                                     \
+    if (NCT == NV) {                                               \
+        if (kind == 1) {                                           \
+            if (a.cs) XW1(NV, 1, true) else XW1(NV, 1, false)      \
+        } else {                                                   \
+            if (a.cs) XW1(NV, 0, true) else XW1(NV, 0, false)      \
+        }                                                          \
+        return;                                                    \
+    }
+    XW(1) XW(2) XW(3)
+#undef XW
+#undef XW1
+}
+
+}  // namespace icem

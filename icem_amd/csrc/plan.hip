@@ -32,6 +32,11 @@ int ensure_fast_model(icem_handle* h) {
         if (h->Mw_dev) (void)hipFree(h->Mw_dev);
         ICEM_HIP_TRY(hipMalloc(&h->Mw_dev, Mw.size() * sizeof(float)));
         ICEM_HIP_TRY(hipMemcpy(h->Mw_dev, Mw.data(), Mw.size() * sizeof(float), hipMemcpyHostToDevice));
+        std::vector<unsigned short> Mb;
+        pack_wide_model_split(h->obs_dim, h->cfg.act_dim, h->A_host.data(), h->B_host.data(), Mb);
+        if (h->Mws_dev) (void)hipFree(h->Mws_dev);
+        ICEM_HIP_TRY(hipMalloc(&h->Mws_dev, Mb.size() * sizeof(unsigned short)));
+        ICEM_HIP_TRY(hipMemcpy(h->Mws_dev, Mb.data(), Mb.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
         // ... and row-major in f32 for the rows rolled out one by one (rollout_rows_wide_kernel)
         auto upload_f32 = [](void** dev, const std::vector<double>& host) -> int {
             std::vector<float> tmp(host.begin(), host.end());
@@ -131,7 +136,8 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
     if (h->wide) {
         // trailing shifted elites that would open a tile of their own: rolled out row by row (rollout_rows_wide_kernel),
         // scored by the merge through the cost array (tail_out rows; the caller's merge takes them as extra candidates)
-        const bool split_tail = tail_out && n_tail > 0 && n_tail <= 64 && n_cand == n_rows && (n_rows - n_tail) % 16 == 0 &&
+        // (exact-f32 tile kernel only: the bf16-split kernel's workgroups take a fifth tile instead)
+        const bool split_tail = h->wide_exact && tail_out && n_tail > 0 && n_tail <= 64 && n_cand == n_rows && (n_rows - n_tail) % 16 == 0 &&
                                 n_rows - n_tail > 0 && h->cfg.dtype == ICEM_F32;
         if (split_tail) {
             n_rows -= n_tail;
@@ -145,8 +151,8 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
         w.o = h->obs_dim;
         w.d = h->cfg.act_dim;
         w.h = h->cfg.horizon;
-        w.kb = wide_kb(w.o, w.d);
-        w.xs = wide_xs(w.o, w.d);
+        w.kb = h->wide_exact ? wide_kb(w.o, w.d) : wide_split_kb(w.o, w.d);
+        w.xs = h->wide_exact ? wide_xs(w.o, w.d) : wide_split_xs(w.o, w.d);
         w.cost_mode = h->cfg.cost_mode;
         w.lin_idx = h->cost.lin_idx;
         w.flip_idx = h->cost.flip_idx;
@@ -155,7 +161,8 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
         w.flip_pen = (float)h->cost.flip_penalty;
         w.flip_th = (float)h->cost.flip_thresh;
         w.cs = h->has_terms ? (const CostArgs<float>*)h->wide_cs_dev : nullptr;
-        w.Mp = (const float*)h->Mw_dev;
+        w.Mp = h->wide_exact ? (const float*)h->Mw_dev : (const float*)h->Mws_dev;
+        w.dbg = h->dbg;
         w.obs0 = (const float*)obs0;
         w.actions = (const float*)actions;
         w.costs = (float*)costs;
@@ -164,14 +171,15 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
         w.part_k = part_k;
         {
             ProfScope prof(h, ICEM_K_ROLLOUT, (long long)n_rows * h->cfg.horizon, st);
-            launch_rollout_wide(w, h->model_kind, st);
+            if (h->wide_exact) launch_rollout_wide(w, h->model_kind, st);
+            else launch_rollout_wide_split(w, h->model_kind, st);
             // (the row-wise kernel BESIDE the tile kernel on a second stream instead of behind it was measured: 4.70
             //  instead of 4.15 ms per MPC step -- the three CUs that host a row workgroup finish their tile workgroup
             //  late, and the launch waits for its slowest workgroup; EXPERIMENTS.md R3.7)
             if (split_tail) launch_rollout_rows_wide(w, n_rows, n_tail, (const float*)h->A_dev, (const float*)h->B_dev, h->model_kind, st);
         }
         ICEM_HIP_TRY(hipGetLastError());
-        if (lists_out) *lists_out = wide_rollout_lists(n_rows);
+        if (lists_out) *lists_out = h->wide_exact ? wide_rollout_lists(n_rows) : wide_split_lists(n_rows);
         return ICEM_OK;
     }
     FastRolloutArgs a = fast_rollout_args(h, n_rows, n_cand, K, obs0, actions, costs, part_c, part_i);

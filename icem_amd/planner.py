@@ -329,6 +329,11 @@ class IcemPlanner:
         L.check(self.lib.icem_reset_distribution(self._h, _ptr(mean), _ptr(std), _ptr(self.low), _ptr(self.high),
                                                  self._stream()))
 
+    def set_wide_exact(self, on: bool = True):
+        """obs_dim > 32: the model step on the exact-f32 matrix pipe (bitwise an fmaf chain) instead of the default 3-way bf16
+        split on the bf16 matrix cores (``icem_set_wide_exact``)."""
+        L.check(self.lib.icem_set_wide_exact(self._h, int(on)))
+
     # ------------------------------------------------------------------ measurement
     def profile_enable(self, on: bool = True):
         L.check(self.lib.icem_profile_enable(self._h, int(on)))

@@ -387,6 +387,14 @@ int icem_plan_step_sharded(icem_handle* h, const icem_plan_buffers* b, int32_t m
  * (the body of MpcICem.get_action, icem.py:123-175). */
 int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, void* stream);
 
+/* Wide observations (32 < obs_dim <= 384; HumanoidStandup's o = 378, environments/mujoco.py:241-277): which matrix-pipe
+ * arithmetic the rollout's model step (the GEMM of abstract_models.py:31-53's predict at this width) runs in.
+ * 0 (default): every f32 operand as the exact sum of three bf16 numbers, six bf16 products per multiply-add with f32
+ * accumulation on v_mfma_f32_16x16x32_bf16 -- f32-class rounding (each product to 2^-24 of its magnitude), not the bits
+ * of an f32 fmaf chain; 1: v_mfma_f32_16x16x4_f32, bitwise an fmaf chain, at a third of the speed.  Takes effect at the
+ * next rollout; no effect at obs_dim <= 32. */
+int icem_set_wide_exact(icem_handle* h, int32_t on);
+
 /* ---- per-kernel timing (measurement only) ------------------------------------------------- */
 enum {
     ICEM_K_SAMPLE = 0, ICEM_K_ROLLOUT, ICEM_K_TOPK_PARTIAL, ICEM_K_LOCAL_PACK, ICEM_K_MERGE_REFIT,

@@ -63,14 +63,14 @@ class DeviceNormals:
         return z_r, z_i
 
 
-def _make(N, iters, h, d, o, kind, beta, seed, env_kind):
+def _make(N, iters, h, d, o, kind, beta, seed, env_kind, cost_mode="sum"):
     from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env, humanoid_standup_env
     env = halfcheetah_env(o) if env_kind == "halfcheetah" else humanoid_standup_env(o)
     model = DeviceSyntheticModel.make(o, d, kind=kind)
 
     def mk():
         pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=N, opt_iters=iters, dtype="f32", seed=seed,
-                                    noise_beta=beta), env.action_space.low, env.action_space.high)
+                                    noise_beta=beta, cost_mode=cost_mode), env.action_space.low, env.action_space.high)
         pl.set_model(model.kind, model.A, model.B)
         pl.set_cost_spec(env.cost_spec)
         pl.reset()
@@ -90,20 +90,32 @@ CASES = [
     # HumanoidStandup at its REAL observation width (icem/environments/mujoco.py:241-252): the GEMM rollout kernel
     pytest.param(2048, 2, 30, 17, 378, 1, 2.0, "humanoid", 5, id="c3wide_o378_N2048x2"),
     # ... and at the size `bench.py --workload c3` / `also_c3` times it: 16 384 rows x 3 iterations; from the second MPC
-    # step on rows 16 384..16 386 (the shifted elites) go through rollout_rows_wide_kernel
+    # step on rows 16 384..16 386 (the shifted elites) are the fifth tile of the launch's first workgroup
     pytest.param(16384, 3, 30, 17, 378, 1, 2.0, "humanoid", 1234, id="c3wide_o378_N16384x3"),
 ]
 
 
 @pytest.mark.parametrize("N,iters,h,d,o,kind,beta,env_kind,seed", CASES)
 def test_full_loop_at_benchmark_size_against_oracle_on_device_normals(N, iters, h, d, o, kind, beta, env_kind, seed):
-    env, model, oc, mk = _make(N, iters, h, d, o, kind, beta, seed, env_kind)
+    _full_loop(N, iters, h, d, o, kind, beta, env_kind, seed, "sum")
+
+
+@pytest.mark.parametrize("cost_mode", ["best", "final"])
+def test_full_loop_at_benchmark_size_best_and_final(cost_mode):
+    """cost_along_trajectory = "best" / "final" (abstract_controller.py:82-87) through the WHOLE loop at the headline
+    population (N = 4096 x 5 iterations), held to the same bar as "sum": elite index sets identical to the float64
+    oracle's in every iteration, costs to 1e-5 of their magnitude."""
+    _full_loop(4096, 5, 30, 6, 17, 1, 0.25, "halfcheetah", 21, cost_mode)
+
+
+def _full_loop(N, iters, h, d, o, kind, beta, env_kind, seed, cost_mode):
+    env, model, oc, mk = _make(N, iters, h, d, o, kind, beta, seed, env_kind, cost_mode)
     om = O.SyntheticModel(model.A, model.B, model.kind)
     split, fused, rng = mk(), mk(), mk()
     noise = DeviceNormals(rng, iters)
     low, high = env.action_space.low.astype(np.float64), env.action_space.high.astype(np.float64)
     orc = O.IcemOracle(O.IcemParams(horizon=h, num_simulated_trajectories=N, opt_iterations=iters, noise_beta=beta),
-                       low, high, lambda ob, ac: O.rollout_costs(om, oc, ob, ac), noise)
+                       low, high, lambda ob, ac: O.rollout_costs(om, oc, ob, ac, mode=cost_mode), noise)
     orc.beginning_of_rollout()
     K, n_reuse = split.K, split.n_reuse
     n_steps = 2
@@ -174,13 +186,15 @@ def test_full_loop_at_benchmark_size_against_oracle_on_device_normals(N, iters, 
         assert np.array_equal(np_(fused.actions[:n_last]), np_(split.actions[:n_last]))
 
 
+@pytest.mark.parametrize("exact", [False, True])
 @pytest.mark.parametrize("kind,mode", [(1, "sum"), (0, "best")])
-def test_wide_shifted_elite_rows_equal_the_tile_kernel_bit_for_bit(kind, mode):
-    """o = 378: the shifted elites of iteration 0 (icem.py:131-137) would open a 16-row tile of their own behind a
-    population that fills whole tiles; they are rolled out row by row instead (rollout_rows_wide_kernel: one fmaf chain
-    per observation column in the matrix pipe's order) and reach the merge through the cost array.  Their costs are the
-    bits the tile kernel produces for the same rows, and the step's result is the one the all-tiles path gives
-    (N not a multiple of 16: the same rows inside a tile)."""
+def test_wide_shifted_elite_rows_equal_the_tile_kernel_bit_for_bit(kind, mode, exact):
+    """o = 378: the shifted elites of iteration 0 (icem.py:131-137) would open a tile of their own behind a population
+    that fills whole tiles.  Exact-f32 path: they are rolled out row by row instead (rollout_rows_wide_kernel: one fmaf
+    chain per observation column in the matrix pipe's order) and reach the merge through the cost array.  bf16-split path
+    (default): the launch's first workgroup takes them as a fifth tile of its batch.  Either way their costs are the
+    bits the tile kernel produces for the same rows wherever they sit in a launch, and the step's result is the one the
+    all-tiles path gives."""
     from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, humanoid_standup_env
     o, d, h = 378, 17, 30
     env = humanoid_standup_env(o)
@@ -189,6 +203,7 @@ def test_wide_shifted_elite_rows_equal_the_tile_kernel_bit_for_bit(kind, mode):
     def mk(N):
         pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=N, opt_iters=2, dtype="f32", seed=3, noise_beta=2.0,
                                     cost_mode=mode), env.action_space.low, env.action_space.high)
+        pl.set_wide_exact(exact)
         pl.set_model(model.kind, model.A, model.B)
         pl.set_cost_spec(env.cost_spec)
         pl.reset()
@@ -267,15 +282,19 @@ def test_humanoid_standup_cost_at_real_observation_width():
 @pytest.mark.parametrize("o,d,h,kind,mode,n", [(378, 17, 30, 0, "sum", 300), (378, 17, 30, 1, "sum", 100), (100, 6, 12, 1, "best", 1000),
                                               (33, 4, 13, 0, "final", 77), (64, 6, 30, 1, "sum", 129), (384, 17, 30, 0, "sum", 40),
                                               (200, 3, 10, 1, "sum", 4097)])
-def test_wide_observation_rollout_matches_oracle(o, d, h, kind, mode, n):
-    """rollout_wide_kernel (k_rollout_wide.hip): the model step at observation widths 33..384 as an exact-f32 GEMM on
-    the matrix pipe, against the float64 oracle rollout (predict_n_steps + trajectory_cost_fn,
-    icem/models/abstract_models.py:17-53, icem/controllers/abstract_controller.py:74-91) at 1e-5; o = 378, d = 17 is
-    HumanoidStandup's real shape (icem/environments/mujoco.py:241-277)."""
+@pytest.mark.parametrize("exact", [False, True])
+def test_wide_observation_rollout_matches_oracle(o, d, h, kind, mode, n, exact):
+    """The model step at observation widths 33..384 as a GEMM on the matrix cores -- rollout_wide_split_kernel (default:
+    every f32 operand as three bf16 planes, six products per multiply-add; k_rollout_wide_split.hip) and
+    rollout_wide_kernel (icem_set_wide_exact: exact f32; k_rollout_wide.hip) -- against the float64 oracle rollout
+    (predict_n_steps + trajectory_cost_fn, icem/models/abstract_models.py:17-53,
+    icem/controllers/abstract_controller.py:74-91) at the SAME 1e-5; o = 378, d = 17 is HumanoidStandup's real shape
+    (icem/environments/mujoco.py:241-277).  n = 300 / 129 / 4097 leave a fifth tile to a workgroup's batch."""
     from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner
     model = DeviceSyntheticModel.make(o, d, kind=kind)
     lo, hi = -0.4 * np.ones(d), 0.4 * np.ones(d)
     pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=max(n, 4), elites_size=2, opt_iters=1, cost_mode=mode, dtype="f32"), lo, hi)
+    pl.set_wide_exact(exact)
     pl.set_model(model.kind, model.A, model.B)
     flip_idx = 1 if kind == 0 else -1
     pl.set_cost(0.1, 2, -1.0, flip_idx, 10.0, 0.05)
