@@ -61,13 +61,18 @@ int rollout_lists(int h, int d, int O, int n_rows) {
 void launch_rollout16(const FastRolloutArgs& a, int h, int d, int O, int kind, hipStream_t st) {
     int grid, waves;
     r16_shape(a.n_rows, &grid, &waves);
-#define XW(HH, DD, OO, WW)                                                                                  \
-    if (waves == WW) {                                                                                      \
-        if (kind == 1)                                                                                      \
-            hipLaunchKernelGGL((rollout16_kernel<HH, DD, OO, 1, WW>), dim3(grid), dim3(64 * WW), 0, st, a); \
-        else                                                                                                \
-            hipLaunchKernelGGL((rollout16_kernel<HH, DD, OO, 0, WW>), dim3(grid), dim3(64 * WW), 0, st, a); \
-        return;                                                                                             \
+    // two output tiles (O > 20): a 16-wave workgroup's 128 registers spill ~100 of the two-tile step's; at most 8 waves per
+    // workgroup (256 registers, no spills), each taking its tiles one after the other (EXPERIMENTS.md R4.6)
+    if (O > 20 && waves > 8) waves = 8;
+#define XW(HH, DD, OO, WW)                                                                                      \
+    if constexpr (OO <= 20 || WW <= 8) {                                                                        \
+        if (waves == WW) {                                                                                      \
+            if (kind == 1)                                                                                      \
+                hipLaunchKernelGGL((rollout16_kernel<HH, DD, OO, 1, WW>), dim3(grid), dim3(64 * WW), 0, st, a); \
+            else                                                                                                \
+                hipLaunchKernelGGL((rollout16_kernel<HH, DD, OO, 0, WW>), dim3(grid), dim3(64 * WW), 0, st, a); \
+            return;                                                                                             \
+        }                                                                                                       \
     }
 #define XR(HH, DD, OO)                   \
     if (h == HH && d == DD && O == OO) { \

@@ -313,10 +313,14 @@ void ahead_shape(int n_rows, int* grid, int* waves) {
 
 // populations whose rollout launch has at least 4 waves per workgroup (more than 512 tiles): below that the
 // single-launch kernel of k_iter_small.hip is the shorter chain
+// ... and one-tile observation widths (O <= 20) only: with two output tiles (O = 24: 26 MFMAs and twice the state per
+// step) the rollout role does not fit the 128 registers it shares its SIMDs on -- 112-158 spilled VGPRs, and the launch
+// LOSES to the sampler + rollout16 pair: 236.1 vs 171.4 us per MPC step at N = 16 384 (d = 17, 3 iterations), 657.7 vs
+// 473.7 at 65 536 (EXPERIMENTS.md R4.6).  Those shapes are not instantiated.
 bool rollout_ahead_ok(int h, int d, int O, int K, int n_rows) {
     int grid, waves;
     r16_shape(n_rows, &grid, &waves);
-    return K + 1 <= AHEAD_KREG && waves >= 4 && fast_rollout_supported(h, d, O, K) && fast_sample_supported(h, d);
+    return O <= 20 && K + 1 <= AHEAD_KREG && waves >= 4 && fast_rollout_supported(h, d, O, K) && fast_sample_supported(h, d);
 }
 
 int ahead_roll_workgroups(int n_rows) {
@@ -358,10 +362,12 @@ void launch_iter_ahead(const IterAheadArgs& a_in, int h, int d, int O, int kind,
         }                                           \
         return;                                     \
     }
-#define XR(HH, DD, OO)                   \
-    if (h == HH && d == DD && O == OO) { \
-        XW(HH, DD, OO, 4)                \
-        XW(HH, DD, OO, 8)                \
+#define XR(HH, DD, OO)                       \
+    if constexpr (OO <= 20) {                \
+        if (h == HH && d == DD && O == OO) { \
+            XW(HH, DD, OO, 4)                \
+            XW(HH, DD, OO, 8)                \
+        }                                    \
     }
     ICEM_FAST_SHAPES(XR)
 #undef XR
