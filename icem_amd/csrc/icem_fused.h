@@ -185,6 +185,9 @@ void launch_topk_small(const float* costs, int n, int K, float* out_c, int* out_
 bool pack_can_push(int K, int h, int d);
 void launch_pack_records(const MergeSingleArgs& a, int n_loc, int shard_lo, float* records, hipStream_t st,
                          const XchgPush& px = XchgPush());
+// the same + the records merge `m` that waits for this pack's records (the step's last iteration), one launch
+void launch_pack_merge(const MergeSingleArgs& pk, int n_loc, int shard_lo, float* records, const XchgPush& px, const MergeSingleArgs& m,
+                       hipStream_t st);
 
 // Sharded runs, "riding pack": the PREVIOUS iteration's record pack + push as one extra workgroup (index 0) of this
 // iteration's launch, running while the other workgroups draw their noise; their merge prologue then waits for the

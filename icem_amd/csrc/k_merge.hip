@@ -137,6 +137,23 @@ __global__ __launch_bounds__(MERGE_WG) void pack_records_kernel(MergeSingleArgs 
     pack_records_body<KREG>(a, n_loc, shard_lo, records, px, stage, sel, tid, MERGE_WG);
 }
 
+// ... and the step's LAST pack together with the records merge that waits for it (sharded runs): one launch instead of two
+// one-workgroup launches back to back -- pack + push, then the wait for every rank's flag, selection over the gathered
+// records, refit and the epilogue.  The dynamic LDS is the pack's stage first, the merge's new mean afterwards.
+template <int KREG>
+__global__ __launch_bounds__(MERGE_WG) void pack_merge_kernel(MergeSingleArgs pk, int n_loc, int shard_lo, float* records, XchgPush px,
+                                                               MergeSingleArgs m) {
+    __shared__ unsigned long long sel[64];
+    __shared__ unsigned long long cand[64];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x;
+    if (tid < 64) merge_select<KREG>(pk, tid, cand, sel);
+    __syncthreads();
+    pack_records_body<KREG>(pk, n_loc, shard_lo, records, px, reinterpret_cast<float*>(smem_raw), sel, tid, MERGE_WG);
+    __syncthreads();
+    merge_single_body<KREG, true>(m, smem_raw);
+}
+
 // icem_topk_sorted for small f32 pools (the stage-wise controller paths: learned dynamics, host models, the CEM
 // baselines) in ONE launch of one workgroup instead of the generic partial + final pair (12.4 + 9.2 us at n = 1 024):
 // every wave keeps a running sorted top-K over its 64-key batches (batch sort, running list parked in lanes 32.., one
@@ -231,6 +248,15 @@ void launch_pack_records(const MergeSingleArgs& a, int n_loc, int shard_lo, floa
         hipLaunchKernelGGL((pack_records_kernel<12>), dim3(1), dim3(MERGE_WG), lds, st, a, n_loc, shard_lo, records, px);
     else
         hipLaunchKernelGGL((pack_records_kernel<34>), dim3(1), dim3(MERGE_WG), lds, st, a, n_loc, shard_lo, records, px);
+}
+
+void launch_pack_merge(const MergeSingleArgs& pk, int n_loc, int shard_lo, float* records, const XchgPush& px, const MergeSingleArgs& m,
+                       hipStream_t st) {
+    const size_t lds = std::max(px.peers ? (size_t)pk.K * (pk.h * pk.d + 2) : (size_t)0, (size_t)m.h * m.d) * sizeof(float);
+    if (pk.K + 1 <= 12)
+        hipLaunchKernelGGL((pack_merge_kernel<12>), dim3(1), dim3(MERGE_WG), lds, st, pk, n_loc, shard_lo, records, px, m);
+    else
+        hipLaunchKernelGGL((pack_merge_kernel<34>), dim3(1), dim3(MERGE_WG), lds, st, pk, n_loc, shard_lo, records, px, m);
 }
 
 // lists form, K <= 11, default generator, a compiled sampler horizon (else: launch_merge_single + launch_noise_rows)

@@ -493,9 +493,12 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                 // Riding pack: where this iteration's merge will ride in the next local launch (h->deferral, same
                 // conditions as icem_plan_iter_merge's fold) and that launch is a single-launch kernel, the pack rides
                 // there too, as its workgroup 0.  Stashed; the next icem_plan_iter_local consumes it (or launches it).
-                if (fold_push && xchg_concurrent_peers(h) && h->deferral && !last && lists > 0 && c.world * K <= 128 && K <= 32 && it + 1 < c.opt_iters) {
-                    const int n_next = local_rows(h, it + 1);
-                    if (prologue_possible(h, n_next) && next_launch_takes_pack(h, n_next)) {
+                // (the step's LAST pack: stashed for the merge that waits for its records -- pack_merge_kernel, one launch)
+                static const int fuse_last = [] { const char* e = getenv("ICEM_PACK_MERGE"); return e ? atoi(e) : 1; }();
+                const bool rides_next = !last && it + 1 < c.opt_iters;
+                if (fold_push && xchg_concurrent_peers(h) && h->deferral && (rides_next || (last && fuse_last)) && lists > 0 && c.world * K <= 128 && K <= 32) {
+                    const int n_next = rides_next ? local_rows(h, it + 1) : 0;
+                    if (!rides_next || (prologue_possible(h, n_next) && next_launch_takes_pack(h, n_next))) {
                         PackPrev& pp = h->pk_args;
                         pp.part_k = pk.part_k;
                         pp.actions = pk.actions;
@@ -667,7 +670,29 @@ int plan_iter_merge_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                 return ICEM_OK;
             }
             m.last = a.last;
-            if (h->pk_pending) {  // the merge runs now after all: so must the pack whose records it waits for
+            static const int fuse_on = [] { const char* e = getenv("ICEM_PACK_MERGE"); return e ? atoi(e) : 1; }();
+            if (h->pk_pending && fuse_on && m.records != nullptr && xchg_connected(h)) {
+                // the merge runs now, and so must the pack whose records it waits for: ONE launch for the two
+                const PackPrev& pp = h->pk_args;
+                MergeSingleArgs pk{};
+                pk.n_lists = pp.n_lists;
+                pk.n_pool = pp.n_pool;
+                pk.n_global = pp.n_global;
+                pk.K = pp.K;
+                pk.h = h->cfg.horizon;
+                pk.d = h->cfg.act_dim;
+                pk.part_k = pp.part_k;
+                pk.actions = pp.actions;
+                pk.n_keep = pp.n_keep;
+                pk.elites_cost_cur = pp.keep_costs;
+                pk.keep_base = pp.n_loc;
+                ProfScope prof(h, ICEM_K_MERGE_REFIT, a.n_rec + a.n_keep, st);
+                launch_pack_merge(pk, pp.n_loc, pp.shard_lo, pp.records, pp.px, m, st);
+                ICEM_HIP_TRY(hipGetLastError());
+                h->pk_pending = false;
+                return ICEM_OK;
+            }
+            if (h->pk_pending) {  // (records gathered by a collective between the two: separate launches)
                 const int rc = launch_pending_pack(h, st);
                 if (rc) return rc;
             }
