@@ -250,7 +250,7 @@ def extra_cpu_baselines(workload, w, model, env):
 
 
 KERNEL_FAMILY = {"sample_clip": ("sample_folded_kernel", "sample_folded_merge_kernel", "noise_rows_kernel"),
-                 "rollout_cost": ("rollout16_kernel", "rollout_wide_kernel"),
+                 "rollout_cost": ("rollout16_kernel", "rollout_wide_kernel", "rollout_wide_split_kernel"),
                  # one launch per iteration: the small-population kernel, or the noise-ahead launch of large populations
                  "sample_rollout": ("sample_rollout_kernel", "iter_ahead_kernel")}
 

@@ -210,6 +210,15 @@ int icem_population_sizes(const icem_handle* h, int32_t* out_host) {
     return ICEM_OK;
 }
 
+// which kernel family serves this handle's f32 rollout (icem_handle::Of)
+static void update_paths(icem_handle* h) {
+    const bool tile = !h->wide && h->has_model && !h->has_terms && !(h->has_cost && h->cost.lin_weight == 0.0) &&
+                      fast_rollout_supported(h->cfg.horizon, h->cfg.act_dim, h->O, 1);
+    const int of = tile ? h->O : 0;
+    if (of != h->Of) h->fast_model_ready = false;
+    h->Of = of;
+}
+
 int icem_set_model(icem_handle* h, int32_t kind, int32_t obs_dim, const double* A_host, const double* B_host) {
     if (!h || !A_host || !B_host) return fail(ICEM_E_INVALID, "null argument");
     if (kind != ICEM_MODEL_LINEAR && kind != ICEM_MODEL_TANH) return fail(ICEM_E_INVALID, "model kind");
@@ -230,6 +239,7 @@ int icem_set_model(icem_handle* h, int32_t kind, int32_t obs_dim, const double* 
         h->A_host.assign(A_host, A_host + (size_t)obs_dim * obs_dim);
         h->B_host.assign(B_host, B_host + (size_t)d * obs_dim);
         h->fast_model_ready = false;
+        update_paths(h);
         return ICEM_OK;
     }
     h->wide = false;
@@ -251,6 +261,7 @@ int icem_set_model(icem_handle* h, int32_t kind, int32_t obs_dim, const double* 
     h->A_host.assign(A_host, A_host + (size_t)obs_dim * obs_dim);
     h->B_host.assign(B_host, B_host + (size_t)d * obs_dim);
     h->fast_model_ready = false;
+    update_paths(h);
     return ICEM_OK;
 }
 
@@ -270,6 +281,7 @@ int icem_set_cost(icem_handle* h, const icem_cost_spec* spec) {
     h->cost = *spec;
     h->has_cost = true;
     h->fast_model_ready = false;
+    update_paths(h);
     return sync_wide_cost(h);
 }
 
@@ -277,6 +289,7 @@ int icem_set_cost_terms(icem_handle* h, const icem_cost_terms* terms) {
     if (!h) return fail(ICEM_E_INVALID, "null argument");
     if (terms == nullptr) {
         h->has_terms = false;
+        update_paths(h);
         return ICEM_OK;
     }
     if (terms->n_terms < 0 || terms->n_terms > ICEM_MAX_COST_TERMS) return fail(ICEM_E_INVALID, "n_terms must be in [0, 8]");
@@ -290,6 +303,7 @@ int icem_set_cost_terms(icem_handle* h, const icem_cost_terms* terms) {
     const bool on = terms->diff_idx >= 0 || terms->health_idx >= 0 || terms->n_terms > 0;
     h->terms = *terms;
     h->has_terms = on;
+    update_paths(h);
     return sync_wide_cost(h);
 }
 

@@ -93,6 +93,10 @@ struct icem_handle {
     float* cur_std = nullptr;
     // permuted, padded model of the matrix-pipe rollout: column 0 = obs[lin_idx], column 1 = obs[flip_idx]
     bool wide = false;           // obs_dim > 32: the rollout is k_rollout_wide.hip's GEMM kernel (f32 only)
+    int Of = 0;                  // O of the 16-trajectory tile kernels (Tile16 / Tile4), or 0 where they do not serve this handle's
+                                 // model + cost (wide observations; icem_cost_terms; a cost without its linear term; a shape
+                                 // (h, d, O) that is not compiled): the f32 rollout is then the GEMM kernel at ANY width.
+                                 // Kept current by update_paths() (abi.hip) behind every model / cost setter.
     void* Mw_dev = nullptr;      // its packed model
     void* Mws_dev = nullptr;     // ... and as three bf16 planes (k_rollout_wide_split.hip), the default wide rollout
     bool wide_exact = false;     // icem_set_wide_exact: the exact-f32 matrix pipe instead (k_rollout_wide.hip + its row kernel)
@@ -271,6 +275,8 @@ void rccl_release(icem_handle* h);
 
 // ---- plan.hip: the f32 throughput path ---------------------------------------------------------------------------
 bool fast_rollout_ok(const icem_handle* h, int K);
+// the f32 rollout of this handle is k_rollout_wide*.hip's GEMM kernel (obs_dim > 32, or a narrow model the tile kernels do not serve)
+inline bool gemm_rollout(const icem_handle* h) { return h->wide || h->Of == 0; }
 bool fast_sample_ok(const icem_handle* h);
 int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const void* obs0, const void* actions,
                         void* costs, float* part_c, int* part_i, hipStream_t st, int* lists_out,

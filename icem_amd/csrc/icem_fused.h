@@ -102,6 +102,7 @@ struct WideRolloutArgs {
     unsigned long long* part_k;
 };
 bool wide_rollout_supported(int o, int d, int K);
+bool gemm_rollout_supported(int o, int d, int K);   // the same kernels at ANY observation width 1..384 (narrow models the tile kernels do not serve)
 int wide_rollout_lists(int n_rows);
 int wide_kb(int o, int d);
 int wide_xs(int o, int d);

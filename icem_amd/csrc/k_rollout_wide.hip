@@ -239,6 +239,7 @@ __global__ __launch_bounds__(384) void rollout_rows_wide_kernel(WideRowsArgs a) 
 }  // namespace
 
 bool wide_rollout_supported(int o, int d, int K) { return o > 32 && o <= 384 && d >= 1 && d <= 64 && K <= 32; }
+bool gemm_rollout_supported(int o, int d, int K) { return o >= 1 && o <= 384 && d >= 1 && d <= 64 && K <= 32; }
 
 int wide_rollout_lists(int n_rows) { return std::min(std::max(1, (n_rows + 15) / 16), FAST_MAX_LISTS); }
 

@@ -26,7 +26,7 @@ namespace icem {
 // term reads column 0 and the flip term column 0 or 1 -- static registers in the kernel.
 int ensure_fast_model(icem_handle* h) {
     if (h->fast_model_ready) return ICEM_OK;
-    if (h->wide) {  // wide observations: the model packed in MFMA operand order (k_rollout_wide.hip)
+    if (gemm_rollout(h)) {  // the GEMM kernels' model, packed in MFMA operand order (k_rollout_wide.hip, k_rollout_wide_split.hip)
         std::vector<float> Mw;
         pack_wide_model(h->obs_dim, h->cfg.act_dim, h->A_host.data(), h->B_host.data(), Mw);
         if (h->Mw_dev) (void)hipFree(h->Mw_dev);
@@ -37,6 +37,10 @@ int ensure_fast_model(icem_handle* h) {
         if (h->Mws_dev) (void)hipFree(h->Mws_dev);
         ICEM_HIP_TRY(hipMalloc(&h->Mws_dev, Mb.size() * sizeof(unsigned short)));
         ICEM_HIP_TRY(hipMemcpy(h->Mws_dev, Mb.data(), Mb.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+        if (!h->wide) {   // a narrow model on the GEMM kernel: A_dev / B_dev keep the generic kernels' padded layout
+            h->fast_model_ready = true;
+            return ICEM_OK;
+        }
         // ... and row-major in f32 for the rows rolled out one by one (rollout_rows_wide_kernel)
         auto upload_f32 = [](void** dev, const std::vector<double>& host) -> int {
             std::vector<float> tmp(host.begin(), host.end());
@@ -93,12 +97,15 @@ int ensure_fast_model(icem_handle* h) {
 }
 
 bool fast_rollout_ok(const icem_handle* h, int K) {
-    if (h->has_terms && !h->wide) return false;  // o <= 32: the extra cost terms live in the general kernel (k_rollout_wide has them)
-    if (h->cost.lin_weight == 0.0 && !h->wide) return false;  // ... and so does a cost without the linear term (dropped, not 0 * obs)
+    if (h->cfg.dtype != ICEM_F32 || !h->has_model || !h->has_cost) return false;
     if (h->wide)  // (the only rollout there is at this width: ICEM_DISABLE_FAST does not apply)
-        return h->cfg.dtype == ICEM_F32 && h->has_model && h->has_cost && wide_rollout_supported(h->obs_dim, h->cfg.act_dim, K);
-    return h->use_fast && h->cfg.dtype == ICEM_F32 && h->has_model && h->has_cost &&
-           fast_rollout_supported(h->cfg.horizon, h->cfg.act_dim, h->O, K);
+        return wide_rollout_supported(h->obs_dim, h->cfg.act_dim, K);
+    if (!h->use_fast) return false;
+    // o <= 32: the tile kernels where they serve the model + cost (no icem_cost_terms, a linear term, a compiled shape);
+    // otherwise the exact-f32 GEMM kernel with its smallest column count -- FetchPickAndPlace (settings/fpp: o = 28, d = 4,
+    // a norm cost), Hopper, Reacher, FetchReach ... run at matrix-pipe speed instead of one thread per trajectory
+    if (h->Of == 0) return gemm_rollout_supported(h->obs_dim, h->cfg.act_dim, K);
+    return fast_rollout_supported(h->cfg.horizon, h->cfg.act_dim, h->Of, K);
 }
 
 FastRolloutArgs fast_rollout_args(const icem_handle* h, int n_rows, int n_cand, int K, const void* obs0,
@@ -133,11 +140,13 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
     int rc = ensure_fast_model(h);
     if (rc) return rc;
     if (tail_out) *tail_out = 0;
-    if (h->wide) {
+    if (gemm_rollout(h)) {
+        // narrow observations always take the exact-f32 kernel (two workgroup barriers per step buy nothing at o <= 32)
+        const bool exact = h->wide_exact || !h->wide;
         // trailing shifted elites that would open a tile of their own: rolled out row by row (rollout_rows_wide_kernel),
         // scored by the merge through the cost array (tail_out rows; the caller's merge takes them as extra candidates)
         // (exact-f32 tile kernel only: the bf16-split kernel's workgroups take a fifth tile instead)
-        const bool split_tail = h->wide_exact && tail_out && n_tail > 0 && n_tail <= 64 && n_cand == n_rows && (n_rows - n_tail) % 16 == 0 &&
+        const bool split_tail = h->wide && h->wide_exact && tail_out && n_tail > 0 && n_tail <= 64 && n_cand == n_rows && (n_rows - n_tail) % 16 == 0 &&
                                 n_rows - n_tail > 0 && h->cfg.dtype == ICEM_F32;
         if (split_tail) {
             n_rows -= n_tail;
@@ -151,8 +160,8 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
         w.o = h->obs_dim;
         w.d = h->cfg.act_dim;
         w.h = h->cfg.horizon;
-        w.kb = h->wide_exact ? wide_kb(w.o, w.d) : wide_split_kb(w.o, w.d);
-        w.xs = h->wide_exact ? wide_xs(w.o, w.d) : wide_split_xs(w.o, w.d);
+        w.kb = exact ? wide_kb(w.o, w.d) : wide_split_kb(w.o, w.d);
+        w.xs = exact ? wide_xs(w.o, w.d) : wide_split_xs(w.o, w.d);
         w.cost_mode = h->cfg.cost_mode;
         w.lin_idx = h->cost.lin_idx;
         w.flip_idx = h->cost.flip_idx;
@@ -161,7 +170,7 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
         w.flip_pen = (float)h->cost.flip_penalty;
         w.flip_th = (float)h->cost.flip_thresh;
         w.cs = h->has_terms ? (const CostArgs<float>*)h->wide_cs_dev : nullptr;
-        w.Mp = h->wide_exact ? (const float*)h->Mw_dev : (const float*)h->Mws_dev;
+        w.Mp = exact ? (const float*)h->Mw_dev : (const float*)h->Mws_dev;
         w.dbg = h->dbg;
         w.obs0 = (const float*)obs0;
         w.actions = (const float*)actions;
@@ -171,7 +180,7 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
         w.part_k = part_k;
         {
             ProfScope prof(h, ICEM_K_ROLLOUT, (long long)n_rows * h->cfg.horizon, st);
-            if (h->wide_exact) launch_rollout_wide(w, h->model_kind, st);
+            if (exact) launch_rollout_wide(w, h->model_kind, st);
             else launch_rollout_wide_split(w, h->model_kind, st);
             // (the row-wise kernel BESIDE the tile kernel on a second stream instead of behind it was measured: 4.70
             //  instead of 4.15 ms per MPC step -- the three CUs that host a row workgroup finish their tile workgroup
@@ -179,15 +188,15 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
             if (split_tail) launch_rollout_rows_wide(w, n_rows, n_tail, (const float*)h->A_dev, (const float*)h->B_dev, h->model_kind, st);
         }
         ICEM_HIP_TRY(hipGetLastError());
-        if (lists_out) *lists_out = h->wide_exact ? wide_rollout_lists(n_rows) : wide_split_lists(n_rows);
+        if (lists_out) *lists_out = exact ? wide_rollout_lists(n_rows) : wide_split_lists(n_rows);
         return ICEM_OK;
     }
     FastRolloutArgs a = fast_rollout_args(h, n_rows, n_cand, K, obs0, actions, costs, part_c, part_i);
     a.part_k = part_k;
-    const int grid = rollout_lists(h->cfg.horizon, h->cfg.act_dim, h->O, n_rows);
+    const int grid = rollout_lists(h->cfg.horizon, h->cfg.act_dim, h->Of, n_rows);
     {
         ProfScope prof(h, ICEM_K_ROLLOUT, (long long)n_rows * h->cfg.horizon, st);
-        launch_rollout16(a, h->cfg.horizon, h->cfg.act_dim, h->O, h->model_kind, st);
+        launch_rollout16(a, h->cfg.horizon, h->cfg.act_dim, h->Of, h->model_kind, st);
     }
     ICEM_HIP_TRY(hipGetLastError());
     if (lists_out) *lists_out = grid;
@@ -246,8 +255,8 @@ bool prologue_possible(const icem_handle* h, int n_rows) {
     const icem_config& c = h->cfg;
     const int K = c.num_elites;
     if (c.dtype != ICEM_F32 || !fast_rollout_ok(h, K) || !fast_sample_ok(h) || n_rows <= 0) return false;
-    if (sample_rollout_lists(c.horizon, c.act_dim, h->O, c.rng_rounds, n_rows) > 0)
-        return sample_rollout_merge_ok(c.horizon, c.act_dim, h->O, c.rng_rounds, n_rows, K);
+    if (sample_rollout_lists(c.horizon, c.act_dim, h->Of, c.rng_rounds, n_rows) > 0)
+        return sample_rollout_merge_ok(c.horizon, c.act_dim, h->Of, c.rng_rounds, n_rows, K);
     return sample_folded_merge_ok(c.horizon, c.act_dim, c.rng_rounds, K);
 }
 
@@ -291,8 +300,8 @@ int launch_pending_merge(icem_handle* h, hipStream_t st) {
 // will the merge-prologue launch of an iteration with n_rows local rows take the previous iteration's pack along?
 static bool next_launch_takes_pack(const icem_handle* h, int n_rows) {
     const icem_config& c = h->cfg;
-    if (sample_rollout_lists(c.horizon, c.act_dim, h->O, c.rng_rounds, n_rows) > 0)
-        return sample_rollout_pack_ok(c.horizon, c.act_dim, h->O, c.rng_rounds, n_rows, c.num_elites);
+    if (sample_rollout_lists(c.horizon, c.act_dim, h->Of, c.rng_rounds, n_rows) > 0)
+        return sample_rollout_pack_ok(c.horizon, c.act_dim, h->Of, c.rng_rounds, n_rows, c.num_elites);
     return sample_folded_pack_ok(c.horizon, c.act_dim, c.rng_rounds, c.num_elites);
 }
 
@@ -379,11 +388,11 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
             const int n_rows = n_loc + n_extra;
             int tail_rows = 0;  // shifted-elite rows scored through the cost array instead of a list (world 1 only)
             const int one = (fast_sample_ok(h) && (n_extra == 0 || shift_in_sampler))
-                                ? sample_rollout_lists(c.horizon, c.act_dim, h->O, c.rng_rounds, n_rows,
+                                ? sample_rollout_lists(c.horizon, c.act_dim, h->Of, c.rng_rounds, n_rows,
                                                        shift_in_sampler ? n_extra : 0, &tail_rows) : 0;
             h->fast_tail_rows = one > 0 ? tail_rows : 0;
             // the merge finds the lists' indices behind `lists * K` costs
-            split_partial_ws<float>(b->workspace, one > 0 ? one : rollout_lists(c.horizon, c.act_dim, h->O, n_rows), K, &pc, &pi);
+            split_partial_ws<float>(b->workspace, one > 0 ? one : rollout_lists(c.horizon, c.act_dim, h->Of, n_rows), K, &pc, &pi);
             bool prologue = false, ride = false;
             if (h->pm_pending) {
                 prologue = n_extra == 0 && prologue_possible(h, n_rows);
@@ -421,7 +430,7 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                 fa.r.list_wgs = tail_rows > 0 ? one : 0;
                 {
                     ProfScope prof(h, ICEM_K_SAMPLE_ROLLOUT, (long long)n_rows * c.horizon, st);
-                    launch_sample_rollout(fa, c.horizon, c.act_dim, h->O, h->model_kind, prologue, st);
+                    launch_sample_rollout(fa, c.horizon, c.act_dim, h->Of, h->model_kind, prologue, st);
                 }
                 ICEM_HIP_TRY(hipGetLastError());
                 lists = one;
@@ -745,7 +754,7 @@ static bool ahead_eligible(icem_handle* h, const icem_plan_buffers* b, bool shar
         const char* m = getenv("ICEM_NOISE_AHEAD_MIN_ROWS");
         A.min_rows = m ? atoi(m) : 0;
     }
-    if (A.disabled || (c.world != 1) != sharded || c.dtype != ICEM_F32 || b->z_r != nullptr || !h->use_fast || h->wide ||
+    if (A.disabled || (c.world != 1) != sharded || c.dtype != ICEM_F32 || b->z_r != nullptr || !h->use_fast || gemm_rollout(h) ||
         c.opt_iters < 2 || h->dbg != nullptr || c.rng_rounds != 10)
         return false;
     if (!fast_rollout_ok(h, c.num_elites) || !fast_sample_ok(h)) return false;
@@ -759,7 +768,7 @@ static bool ahead_eligible(icem_handle* h, const icem_plan_buffers* b, bool shar
     }
     for (size_t it = 0; it < h->pop.size(); ++it) {
         const int n = sharded ? local_rows(h, (int)it) : h->pop[it];
-        if (n < A.min_rows || !rollout_ahead_ok(c.horizon, c.act_dim, h->O, c.num_elites, n)) return false;
+        if (n < A.min_rows || !rollout_ahead_ok(c.horizon, c.act_dim, h->Of, c.num_elites, n)) return false;
     }
     if (c.shift_elites && h->n_reuse > 16) return false;  // (the shift role rolls its rows out as one 16-row tile)
     // the transform takes the bounds as two scalars: fetch them once per (low, high) buffer pair
@@ -875,7 +884,7 @@ static int plan_step_ahead(icem_handle* h, const icem_plan_buffers* b, int mpc_s
         }
         {
             ProfScope prof(h, ICEM_K_SAMPLE_ROLLOUT, (long long)n * c.horizon, st);
-            launch_iter_ahead(ia, c.horizon, c.act_dim, h->O, h->model_kind, st);
+            launch_iter_ahead(ia, c.horizon, c.act_dim, h->Of, h->model_kind, st);
         }
         ICEM_HIP_TRY(hipGetLastError());
         h->fast_lists = ahead_roll_workgroups(n);
@@ -1008,7 +1017,7 @@ static int plan_step_sharded_ahead(icem_handle* h, const icem_plan_buffers* b, i
         }
         {
             ProfScope prof(h, ICEM_K_SAMPLE_ROLLOUT, (long long)n_loc * c.horizon, st);
-            launch_iter_ahead(ia, c.horizon, c.act_dim, h->O, h->model_kind, st);
+            launch_iter_ahead(ia, c.horizon, c.act_dim, h->Of, h->model_kind, st);
         }
         ICEM_HIP_TRY(hipGetLastError());
         const int lists = ahead_roll_workgroups(n_loc);
@@ -1080,7 +1089,7 @@ void predraw_next_step(icem_handle* h, const icem_plan_buffers* b, int mpc_step,
     const icem_config& c = h->cfg;
     static const int on = [] { const char* e = getenv("ICEM_PREDRAW"); return e ? atoi(e) : 1; }();
     A.pre_valid = false;
-    if (!on || c.world != 1 || c.dtype != ICEM_F32 || b->z_r != nullptr || !h->use_fast || h->wide || c.rng_rounds != 10 ||
+    if (!on || c.world != 1 || c.dtype != ICEM_F32 || b->z_r != nullptr || !h->use_fast || gemm_rollout(h) || c.rng_rounds != 10 ||
         h->dbg != nullptr || h->fast_lists <= 0 || c.num_elites + 1 > 12 || !fast_rollout_ok(h, c.num_elites) || !fast_sample_ok(h))
         return;
     const int n0 = h->pop[0];
@@ -1090,7 +1099,7 @@ void predraw_next_step(icem_handle* h, const icem_plan_buffers* b, int mpc_step,
     const int n_shift = (c.shift_elites && h->n_reuse > 0) ? h->n_reuse : 0;   // (mpc_step + 1 > 0: the next step shifts)
     if (n_shift * c.act_dim > 256) return;
     int tail_rows = 0;
-    if (sample_rollout_lists(c.horizon, c.act_dim, h->O, c.rng_rounds, n0 + n_shift, n_shift, &tail_rows) <= 0) return;
+    if (sample_rollout_lists(c.horizon, c.act_dim, h->Of, c.rng_rounds, n0 + n_shift, n_shift, &tail_rows) <= 0) return;
     if (!A.pre_raw && hipMalloc(&A.pre_raw, (size_t)(n0 + h->n_reuse + 16) * h->hd * sizeof(float)) != hipSuccess) {
         (void)hipGetLastError();
         A.pre_raw = nullptr;
