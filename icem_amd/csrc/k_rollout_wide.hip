@@ -60,12 +60,42 @@ __global__ __launch_bounds__(64 * WAVES) void rollout_wide_kernel(WideRolloutArg
             X[e] = c < o ? a.obs0[c] : 0.f;
         }
         float acc_c = 0.f;
+        // Narrow observations (NT <= 8: a step is a few hundred cycles): the NEXT step's actions are requested while this step
+        // runs and held in registers -- a load -> LDS store per step would expose a global round trip that outweighs the step.
+        // (At NT = 24 a step is 40 us and the kernel has no register to spare: EXPERIMENTS.md R3.12.)
+        constexpr int AE = NT <= 8 ? 4 : 0;   // elements per lane held ahead: d <= 16
+        const bool ahead = AE > 0 && 16 * d <= 64 * AE;
+        float an[AE > 0 ? AE : 1];
+        int aoff[AE > 0 ? AE : 1], xoff[AE > 0 ? AE : 1];
+        if (ahead) {
+#pragma unroll
+            for (int i = 0; i < AE; ++i) {
+                const int e = lane + 64 * i;
+                const int r = e / d, c = e - r * d;
+                const bool in = e < 16 * d;
+                xoff[i] = in ? r * XS + o + c : -1;
+                aoff[i] = (in && row0 + r < a.n_rows) ? (r * H) * d + c : -1;
+            }
+        }
+        const float* abase = a.actions + (size_t)row0 * H * d;
+        auto request_actions = [&](int t) {
+#pragma unroll
+            for (int i = 0; i < AE; ++i) an[i] = aoff[i] >= 0 ? abase[aoff[i] + t * d] : 0.f;
+        };
+        if (ahead) request_actions(0);
         for (int t = 0; t < H; ++t) {
             // this step's actions -> X[:, o .. o + d)
-            for (int e = lane; e < 16 * d; e += 64) {
-                const int r = e / d, c = e - r * d;
-                const int row = row0 + r;
-                X[r * XS + o + c] = row < a.n_rows ? a.actions[((size_t)row * H + t) * d + c] : 0.f;
+            if (ahead) {
+#pragma unroll
+                for (int i = 0; i < AE; ++i)
+                    if (xoff[i] >= 0) X[xoff[i]] = an[i];
+                if (t + 1 < H) request_actions(t + 1);
+            } else {
+                for (int e = lane; e < 16 * d; e += 64) {
+                    const int r = e / d, c = e - r * d;
+                    const int row = row0 + r;
+                    X[r * XS + o + c] = row < a.n_rows ? a.actions[((size_t)row * H + t) * d + c] : 0.f;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
