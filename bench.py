@@ -70,13 +70,13 @@ WORKLOADS = {
 }
 
 
-def make_planner(w, rank, world, seed=1234, cost_mode="sum", global_n=None):
+def make_planner(w, rank, world, seed=1234, cost_mode="sum", global_n=None, dtype="f32"):
     """One rank's planner of a run over `world` GPUs; global population = global_n (strong scaling) or w["N"] per GPU."""
     from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env, humanoid_standup_env
     env = humanoid_standup_env(w["o"]) if w.get("env") == "humanoid" else halfcheetah_env(w["o"])
     model = DeviceSyntheticModel.make(w["o"], w["d"], kind=w.get("kind", 0))
     cfg = IcemConfig(horizon=w["h"], act_dim=w["d"], num_traj=global_n if global_n else w["N"] * world, opt_iters=w["iters"],
-                     noise_beta=w["beta"], dtype="f32", seed=seed, rank=rank, world=world, cost_mode=cost_mode)
+                     noise_beta=w["beta"], dtype=dtype, seed=seed, rank=rank, world=world, cost_mode=cost_mode)
     pl = IcemPlanner(cfg, env.action_space.low, env.action_space.high, device=f"cuda:{torch.cuda.current_device()}")
     pl.set_model(model.kind, model.A, model.B)
     c = env.cost_spec
@@ -403,6 +403,19 @@ def measure_also(name, rank=0, world=1, steps=200, warmup=20, global_n=None):
     return out
 
 
+def measure_f64(name="c2", steps=40, warmup=4):
+    """The reference's own arithmetic (float64 throughout, icem.py) on the device: the strict-parity mode of the same
+    workload (generic kernels, one per stage: sample_clip / rollout_cost / top-K partial + final / gather + refit) -- the
+    mode the golden fixtures of tests/golden are replayed in at 1e-10.  One timed number per round so that it is seen."""
+    w = WORKLOADS[name]
+    pl, _, _ = make_planner(w, 0, 1, dtype="f64")
+    el = timed_steps(pl, steps, warmup, 1)
+    ts = sum(pl.population_sizes) * w["h"]
+    return {"workload": w["name"], "dtype": "f64", "kernels": "generic_kernels.hip (strict-parity mode)", "steps": steps,
+            "value": ts * steps / el, "unit": "traj-steps/s", "ms_per_mpc_step": 1e3 * el / steps,
+            "algorithmic_GBps": ts * 2 * (8.0 * w["d"] + 8.0 / w["h"]) * steps / el / 1e9}
+
+
 def exchange_report(pl):
     """How the ranks' elite records travelled in this run, and what one exchange costs (probe: 200 back-to-back
     exchanges inside one launch per rank, no launches around them)."""
@@ -664,6 +677,10 @@ def main():
                 out["also_c3"] = measure_also("c3", 0, 1, steps=30, warmup=3)
             except Exception as ex:
                 out["also_c3"] = {"error": repr(ex)[:300]}
+            try:   # the reference's float64 arithmetic on the same workload (strict-parity mode, generic kernels)
+                out["also_f64"] = measure_f64("c2")
+            except Exception as ex:
+                out["also_f64"] = {"error": repr(ex)[:300]}
             try:   # BASELINE configs[4] in the default run: the learned-dynamics line, GPU part only
                 c5 = measure_c5(WORKLOADS["c5"], 200, 20, cpu=False)
                 out["also_c5"] = {k: c5[k] for k in ("value", "unit", "ms_per_step", "dtype", "config", "roofline")}
