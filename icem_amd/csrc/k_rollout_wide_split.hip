@@ -207,6 +207,7 @@ __device__ __forceinline__ void split_batch(const WideRolloutArgs& a, float* X, 
             request(m0, 0);
         }
         if (st && t == 5) st[3] = wall_clock64();
+        if (a.dbg && blockIdx.x == 3 && lane == 0 && t == 5) a.dbg[8 + wave] = wall_clock64();   // every wave's loop end
         __syncthreads();   // everybody has read X: the new observation may go in
         if (st && t == 5) st[4] = wall_clock64();
 #pragma unroll

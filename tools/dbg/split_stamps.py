@@ -14,9 +14,10 @@ dbg = torch.zeros(16, dtype=torch.int64, device="cuda")
 L.check(pl.lib.icem_debug_stamps(pl._h, dbg.data_ptr()))
 for _ in range(3): pl.rollout_cost(obs, acts)
 torch.cuda.synchronize()
-acc = np.zeros(8)
+acc = np.zeros(16)
 for _ in range(10):
     pl.rollout_cost(obs, acts); torch.cuda.synchronize()
-    v = dbg.cpu().numpy().astype(np.float64); acc += (v[:8] - v[0]) / 100.0
+    v = dbg.cpu().numpy().astype(np.float64); acc += (v[:16] - v[0]) / 100.0
 acc /= 10
+print("model loop end of waves 0..7 [us from wave 1's step top]:", " ".join("%.2f" % x for x in acc[8:16]))
 print("step 5 of wg 3, wave 1 [us]: barrier A %.2f | score %.2f | k-loop %.2f | barrier B %.2f | tanh + state write %.2f | action store %.2f | next step top %.2f" % tuple(acc[1:8]))
