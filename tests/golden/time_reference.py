@@ -71,9 +71,10 @@ def main():
     if not os.path.isdir(M.REF):
         sys.exit("needs /root/reference (build container only)")
     M.install_stubs()
+    cpu_model = next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "unknown")
     out = {"what": "reference MpcICem.get_action (icem/controllers/icem.py:106-189) imported from /root/reference, synthetic "
                    "linear model + the reference's HalfCheetah cost_fn, single thread",
-           "host": {"cpus": os.cpu_count(), "python": sys.version.split()[0], "numpy": np.__version__},
+           "host": {"cpu_model": cpu_model, "cpus": os.cpu_count(), "python": sys.version.split()[0], "numpy": np.__version__},
            "c1": run(128, 30, 6, 17, 0.25, 3, 3), "c2": run(4096, 30, 6, 17, 0.25, 5, 2)}
     path = sys.argv[1] if len(sys.argv) > 1 else "reference_cpu_walltime.json"
     json.dump(out, open(path, "w"), indent=1)
