@@ -17,6 +17,33 @@ __device__ __forceinline__ bool finite_val(double x) { return fabs(x) <= DBL_MAX
 __device__ __forceinline__ float sqrt_val(float x) { return sqrtf(x); }
 __device__ __forceinline__ double sqrt_val(double x) { return sqrt(x); }
 
+// one entry of the term list: weight * f(obs) (times its gate)
+template <typename T, typename Obs>
+__device__ __forceinline__ T cost_term_value(const typename CostArgs<T>::Term& tm, Obs obs) {
+    T f;
+    if (tm.kind == ICEM_TERM_STEP_GT) {
+        f = obs(tm.a) > tm.th ? (T)1 : (T)0;
+    } else if (tm.kind == ICEM_TERM_SQ_OFFSET) {
+        const T v = obs(tm.a) - tm.th;
+        f = v * v;
+    } else {
+        T acc = (T)0;
+        for (int m = 0; m < tm.len; ++m) {
+            T v = obs(tm.a + m);
+            if (tm.b >= 0) v -= obs(tm.b + m);
+            acc = fmad(v, v, acc);
+        }
+        if (tm.kind == ICEM_TERM_SUMSQ) {
+            f = acc;
+        } else {
+            const T r = sqrt_val(acc);
+            f = tm.kind == ICEM_TERM_NORM ? r : tm.kind == ICEM_TERM_NORM_GT ? (r > tm.th ? (T)1 : (T)0) : (r < tm.th ? (T)1 : (T)0);
+        }
+    }
+    if (tm.gate_idx >= 0) f *= obs(tm.gate_idx) > tm.gate_th ? (T)1 : (T)0;  // a product, as in the reference (NaN * 0 = NaN)
+    return tm.w * f;
+}
+
 // The extra terms of one step given accessors for the pre- and post-action observation; `bad` = some observation
 // entry is non-finite or outside Hopper's state box (computed by the caller, who owns the sweep over the row).
 // WITH_DIFF = false leaves the difference term to the caller (a kernel that overwrites the observation in place adds
@@ -34,29 +61,7 @@ __device__ __forceinline__ T cost_terms(const CostArgs<T>& cs, bool bad, Obs obs
 #pragma unroll
     for (int j = 0; j < ICEM_MAX_COST_TERMS; ++j) {
         if (j >= cs.n_terms) break;
-        const typename CostArgs<T>::Term& tm = cs.terms[j];
-        T f;
-        if (tm.kind == ICEM_TERM_STEP_GT) {
-            f = obs(tm.a) > tm.th ? (T)1 : (T)0;
-        } else if (tm.kind == ICEM_TERM_SQ_OFFSET) {
-            const T v = obs(tm.a) - tm.th;
-            f = v * v;
-        } else {
-            T acc = (T)0;
-            for (int m = 0; m < tm.len; ++m) {
-                T v = obs(tm.a + m);
-                if (tm.b >= 0) v -= obs(tm.b + m);
-                acc = fmad(v, v, acc);
-            }
-            if (tm.kind == ICEM_TERM_SUMSQ) {
-                f = acc;
-            } else {
-                const T r = sqrt_val(acc);
-                f = tm.kind == ICEM_TERM_NORM ? r : tm.kind == ICEM_TERM_NORM_GT ? (r > tm.th ? (T)1 : (T)0) : (r < tm.th ? (T)1 : (T)0);
-            }
-        }
-        if (tm.gate_idx >= 0) f *= obs(tm.gate_idx) > tm.gate_th ? (T)1 : (T)0;  // a product, as in the reference (NaN * 0 = NaN)
-        c += tm.w * f;
+        c += cost_term_value<T>(cs.terms[j], obs);
     }
     return c;
 }

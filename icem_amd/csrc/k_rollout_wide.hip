@@ -116,7 +116,11 @@ __global__ __launch_bounds__(64 * WAVES) void rollout_wide_kernel(WideRolloutArg
             const bool diff = ext && cs_s.diff_idx >= 0;
             {
                 float c_step = 0.f, dold = 0.f;
-                if (lane < 16) c_step = wide_step_cost(wc, ext, cs_s, X + lane * XS, o, d, bad, dold);
+                if (ext && NT <= 8) {   // narrow widths: the step is short, the term list walked by one lane is not
+                    c_step = reduce_groups(wide_step_cost_lanes(wc, cs_s, X + j * XS, o, d, bad, g, dold));
+                } else if (lane < 16) {
+                    c_step = wide_step_cost(wc, ext, cs_s, X + lane * XS, o, d, bad, dold);
+                }
                 if (diff) {
                     if (lane < 16) { park[wave][lane] = c_step; park[wave][16 + lane] = dold; }
                 } else {

@@ -45,6 +45,39 @@ __device__ __forceinline__ float wide_step_cost(const WideCost& b, bool ext, con
     }
     return c;
 }
+// The same cost with the icem_cost_terms spread over the FOUR lanes (j, g) of a trajectory (rollout_wide_kernel's B-operand
+// layout): the icem_cost_spec part, the health term and `dold` in lane g = 0, term t of the list in lane t % 4 -- the
+// caller sums the four shares (reduce_groups).  One lane walking the whole list is a chain of dependent LDS reads: 1.5 us
+// of a 2.9 us step at o = 28 with two norm terms (FetchPickAndPlace; EXPERIMENTS.md R4.8).  Same terms, summed in another
+// order: an f32 rounding apart from wide_step_cost.
+__device__ __forceinline__ float wide_step_cost_lanes(const WideCost& b, const CostArgs<float>& cs, const float* x, int o, int d,
+                                                      bool bad, int g, float& dold) {
+    float c = 0.f;
+    auto obs = [&](int idx) { return x[idx]; };
+    if (g == 0) {
+        if (b.flip_idx >= 0) {
+            const float ang = x[b.flip_idx];
+            c += (ang > b.flip_th) ? b.flip_pen : 0.f;
+            c += (ang < -b.flip_th) ? b.flip_pen : 0.f;
+        }
+        float u = 0.f;
+        for (int e = 0; e < d; ++e) u = __builtin_fmaf(x[o + e], x[o + e], u);
+        c = __builtin_fmaf(u, b.ctrl_w, c);
+        if (b.lin_w != 0.f) c = __builtin_fmaf(b.lin_w, x[b.lin_idx], c);
+        if (cs.health_idx >= 0) {
+            const float z = x[cs.health_idx];
+            const bool in = cs.health_closed ? (cs.health_lo <= z && z <= cs.health_hi) : (cs.health_lo < z && z < cs.health_hi);
+            c += (in && !bad) ? 0.f : cs.health_pen;
+        }
+        dold = cs.diff_idx >= 0 ? x[cs.diff_idx] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < ICEM_MAX_COST_TERMS / 4; ++t) {
+        const int j = 4 * t + g;
+        if (j < cs.n_terms) c += cost_term_value<float>(cs.terms[j], obs);
+    }
+    return c;
+}
 __device__ __forceinline__ float wide_diff_cost(const CostArgs<float>& cs, float next, float dold) {
     return cs.diff_w * (next - dold);
 }

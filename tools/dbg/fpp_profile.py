@@ -1,3 +1,5 @@
+"""Per-kernel-class times of the FetchPickAndPlace-shaped workload (h = 30, d = 4, o = 28, the env's norm cost: settings/fpp,
+environments/robotics.py:150-164) -- a narrow model the tile kernels do not serve, rolled out by the exact-f32 GEMM kernel."""
 import sys, numpy as np, torch
 sys.path.insert(0, "/root/repo")
 from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner
@@ -17,3 +19,4 @@ pl.profile_enable(True)
 for _ in range(10): pl.plan_step_resident()
 torch.cuda.synchronize()
 print({k: (round(1e3 * v[0] / v[1], 1), v[1] // 10) for k, v in pl.profile_read().items()})
+
