@@ -1637,6 +1637,28 @@ def test_fused_rssm_rollout_kernel(mode, n, h):
         assert np.corrcoef(got, exact)[0, 1] > 0.99
 
 
+def test_rssm_staging_can_be_trimmed_and_comes_back():
+    """icem_rssm_trim frees the split launch's per-(device, stream) staging areas; the next rollout on that stream
+    allocates a new one and returns the same costs (and a second stream gets an area of its own)."""
+    from icem_amd import DeviceRSSMModel
+    m = DeviceRSSMModel(seed=3)
+    rs = np.random.RandomState(8)
+    acts = torch.as_tensor(rs.uniform(-1, 1, (300, 12, 6)), dtype=torch.float32, device="cuda")
+    obs = 0.3 * rs.randn(230)
+    first = np_(m.rollout_cost(obs, acts))
+    torch.cuda.synchronize()
+    assert m.lib.icem_rssm_trim() == 0
+    again = np_(m.rollout_cost(obs, acts))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        other = m.rollout_cost(obs, acts)
+    side.synchronize()
+    assert np.array_equal(first, again) and np.array_equal(first, np_(other))
+    torch.cuda.synchronize()
+    assert m.lib.icem_rssm_trim() == 0
+
+
 def test_split_rssm_launch_equals_the_fused_kernel(tmp_path):
     """Populations up to 65 536 take icem_rssm_split.hip (recurrence workgroups + reward-head workgroups exchanging the
     states through global memory, weights of the head resident in registers); ICEM_RSSM_SPLIT=0 keeps them on the
@@ -2070,13 +2092,70 @@ def test_bench_two_ranks_without_a_launcher():
         assert j["strong"]["global_population"] == 65536 and "also" in j
 
 
-@pytest.mark.parametrize("h,d,o,kind,mode,N,iters", [(30, 6, 17, 0, "sum", 16384, 3), (30, 6, 17, 1, "best", 40000, 4), (30, 17, 24, 1, "sum", 16384, 2)])
+@pytest.mark.parametrize("N", [4096, 40000])
+def test_noise_drawn_ahead_is_tied_to_its_stream(N):
+    """The first noise of MPC step s + 1 is drawn by a launch of step s (beside the last merge at small populations, beside
+    the last rollout at large ones).  A caller that enqueues step s + 1 on ANOTHER stream is not ordered behind that launch:
+    the library treats the stashed noise as a miss and redraws it on the new stream -- same counters, same bits -- instead
+    of reading a half-written buffer.  Steps alternate between two streams (the caller orders the streams
+    for the buffers it shares between them, as it must); every result equals the single-stream run's."""
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env
+    env = halfcheetah_env(17)
+    model = DeviceSyntheticModel.make(17, 6, kind=1)
+
+    def mk():
+        pl = IcemPlanner(IcemConfig(horizon=30, act_dim=6, num_traj=N, opt_iters=3, dtype="f32", seed=11),
+                         env.action_space.low, env.action_space.high)
+        pl.set_model(model.kind, model.A, model.B)
+        pl.set_cost_spec(env.cost_spec)
+        pl.reset()
+        return pl
+    obs = [0.1 * np.random.RandomState(40 + s).randn(17) for s in range(5)]
+    ref = mk()
+    want = []
+    for ob in obs:
+        want.append((np_(ref.plan_step(ob)).copy(), np_(ref.mean).copy(), np_(ref.std).copy()))
+    torch.cuda.synchronize()
+    pl = mk()
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    prev = torch.cuda.current_stream()
+    for s, ob in enumerate(obs):
+        st = streams[s & 1]
+        st.wait_stream(prev)
+        with torch.cuda.stream(st):
+            act = pl.plan_step(ob)
+        prev = st
+        st.synchronize()
+        assert np.array_equal(np_(act), want[s][0]), s
+        assert np.array_equal(np_(pl.mean), want[s][1]) and np.array_equal(np_(pl.std), want[s][2]), s
+
+
+def test_profile_overhead_calibration():
+    """icem_profile_overhead: the event pair around a kernel of known duration costs more than the kernel, by a few
+    microseconds that do not depend on the kernel's length (what bench.py subtracts from every per-kernel time)."""
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env
+    env = halfcheetah_env(17)
+    pl = IcemPlanner(IcemConfig(horizon=30, act_dim=6, num_traj=64, opt_iters=2, dtype="f32"), env.action_space.low, env.action_space.high)
+    brackets = []
+    for spin in (10.0, 30.0):
+        pair, kern = pl.profile_overhead(50, spin)
+        assert spin <= kern < spin + 1.0, (spin, kern)
+        assert kern < pair < kern + 20.0, (pair, kern)
+        brackets.append(pair - kern)
+    assert abs(brackets[0] - brackets[1]) < 1.5, brackets
+
+
+@pytest.mark.parametrize("h,d,o,kind,mode,N,iters", [(30, 6, 17, 0, "sum", 16384, 3), (30, 6, 17, 1, "best", 40000, 4), (30, 6, 18, 1, "sum", 16384, 2),
+                                                     (30, 17, 24, 1, "sum", 16384, 2)])
 def test_noise_ahead_pipeline_equals_the_default_path(h, d, o, kind, mode, N, iters, monkeypatch):
     """The noise-ahead pipeline of large populations (plan.hip::plan_step_ahead, k_rollout_ahead.hip: one launch per
     iteration whose rollout workgroups run the previous merge in their prologue and map the pool's raw noise to actions as
     they load it, beside noise workgroups that draw the NEXT sampling call and, at iteration 0, a shifted-elites workgroup)
     against the sampler + rollout pair (ICEM_NOISE_AHEAD=0): same draws, same fmaf / v_med3 per sample, same rollout code --
-    every buffer identical over four MPC steps (the noise of step s + 1's first iteration is drawn during step s)."""
+    every buffer identical over four MPC steps (the noise of step s + 1's first iteration is drawn during step s).  (The
+    two-tile shape d = 17, o = 24 is routed to the pair whatever the switch says -- its launch spilled and lost, EXPERIMENTS
+    R4.6 -- and stays here as the check that the routing leaves its results alone.)"""
     from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env, humanoid_standup_env
     env = humanoid_standup_env(o) if d == 17 else halfcheetah_env(o)
     model = DeviceSyntheticModel.make(o, d, kind=kind)
