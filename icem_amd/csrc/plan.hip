@@ -921,7 +921,7 @@ static int plan_step_ahead(icem_handle* h, const icem_plan_buffers* b, int mpc_s
 // launch's one records merge for everybody (published mean | std), the rollout workgroups wait for that flag, map and
 // roll out this rank's shard, the noise workgroups draw the shard's next noise; rank 0 alone builds and rolls out the
 // (replicated) shifted elites.  Every pool is written back (the record pack gathers actions).  The last iteration's
-// pack and merge are launches of their own, as on the sampler + rollout path.
+// pack and merge share one launch of their own, as on the sampler + rollout path.
 static int plan_step_sharded_ahead(icem_handle* h, const icem_plan_buffers* b, int mpc_step, hipStream_t st) {
     icem_handle::Ahead& A = h->ahead;
     const icem_config& c = h->cfg;
@@ -1056,11 +1056,23 @@ static int plan_step_sharded_ahead(icem_handle* h, const icem_plan_buffers* b, i
             pack.px = px;
             pack_pending = true;
         } else {
-            ProfScope prof(h, ICEM_K_LOCAL_PACK, lists * K, st);
-            launch_pack_records(pk, n_loc, lo, rec, st, px);
-            ICEM_HIP_TRY(hipGetLastError());
+            // the step's last pack: stashed for the merge below, which takes it along in its own launch (pack_merge_kernel)
+            PackPrev& pp = h->pk_args;
+            pp.part_k = pk.part_k;
+            pp.actions = pk.actions;
+            pp.n_lists = pk.n_lists;
+            pp.n_pool = pk.n_pool;
+            pp.n_global = pk.n_global;
+            pp.K = K;
+            pp.n_loc = n_loc;
+            pp.shard_lo = lo;
+            pp.n_keep = pk.n_keep;
+            pp.keep_costs = pk.elites_cost_cur;
+            pp.records = rec;
+            pp.px = px;
+            h->pk_pending = true;
         }
-        // ---- its merge (records form): stashed for the next launch's pack role, or (last) a launch of its own ----
+        // ---- its merge (records form): stashed for the next launch's pack role, or (last) a launch with the pack ----
         float* pp = h->pp_stats + (size_t)(it & 1) * 2 * hd;
         h->defer_merge = !last;
         h->merge_mean_out = last ? (float*)b->mean : pp;
