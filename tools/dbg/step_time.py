@@ -12,9 +12,10 @@ ap.add_argument("--o", type=int, default=17)
 ap.add_argument("--kind", type=int, default=0)
 ap.add_argument("--beta", type=float, default=0.25)
 ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--band", type=int, default=-1, help="0: diagonal A (SURVEY 7.3-11's cheap dynamics), -1: dense")
 a = ap.parse_args()
 env = halfcheetah_env(a.o) if a.d == 6 else humanoid_standup_env(a.o)
-model = DeviceSyntheticModel.make(a.o, a.d, kind=a.kind)
+model = DeviceSyntheticModel.make(a.o, a.d, kind=a.kind, band=a.band)
 for N in a.N:
     pl = IcemPlanner(IcemConfig(horizon=30, act_dim=a.d, num_traj=N, opt_iters=a.iters, dtype="f32", seed=1, noise_beta=a.beta),
                      env.action_space.low, env.action_space.high)
@@ -28,4 +29,4 @@ for N in a.N:
     for _ in range(200):
         pl.plan_step_resident()
     torch.cuda.synchronize()
-    print(f"N={N} d={a.d} o={a.o} kind={a.kind}: {(time.perf_counter() - t0) / 200 * 1e6:.1f} us per MPC step", flush=True)
+    print(f"N={N} d={a.d} o={a.o} kind={a.kind} band={a.band}: {(time.perf_counter() - t0) / 200 * 1e6:.1f} us per MPC step", flush=True)
