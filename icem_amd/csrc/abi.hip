@@ -450,6 +450,9 @@ int icem_reset_distribution(icem_handle* h, void* mean, void* std, const void* l
     if (check_handle(h)) return ICEM_E_INVALID;
     if (!mean || !std || !low || !high) return fail(ICEM_E_INVALID, "null tensor");
     hipStream_t st = (hipStream_t)stream;
+    // the large-population path keeps a host copy of the action bounds per (low, high) buffer pair: an episode start is
+    // where a caller may have rewritten them in place, so the copy is fetched again at the next step
+    h->ahead.lo_ptr = h->ahead.hi_ptr = nullptr;
     return gk_reset(h, mean, std, low, high, st);
 }
 

@@ -273,7 +273,9 @@ int icem_gather_refit(icem_handle* h, const void* actions, const int32_t* idx, i
  * std = (high-low)/2*init_std. */
 int icem_shift(icem_handle* h, void* mean, void* std, const void* low, const void* high, void* stream);
 
-/* beginning_of_rollout (icem.py:31-59): mean = (high+low)/2, std = (high-low)/2*init_std. */
+/* beginning_of_rollout (icem.py:31-59): mean = (high+low)/2, std = (high-low)/2*init_std.  The action bounds are
+ * read when this is called and, on the f32 large-population path, once more per (low, high) buffer pair at the next
+ * step: a caller that rewrites the bounds IN PLACE does so between episodes, in front of this call. */
 int icem_reset_distribution(icem_handle* h, void* mean, void* std, const void* low, const void* high,
                             void* stream);
 
