@@ -15,21 +15,28 @@
 // whole batches -- the shifted elites of iteration 0, icem.py:131-137 -- instead of a second round of workgroups):
 //   * their contraction vectors [obs | action | 0-pad] live in LDS as f32 rows X[80][XS] (134 KB: one workgroup per CU);
 //   * wave w of 8 (two per SIMD) owns the output column tiles NCT w .. NCT w + NCT - 1 for ALL the workgroup's
-//     trajectories -- NCT x 5 accumulator tiles (60 registers at o = 378) -- and streams only ITS eighth of the model: per
-//     32-deep contraction block 3 planes x NCT 16-byte loads per lane, one block requested ahead in a second register set;
-//   * per block and trajectory tile: 32 bytes of X per lane (the B operand's 8 contraction entries), split into the three
-//     planes in registers (every wave splits the same values: 36 VALU per 6 NCT MFMAs), then NCT x 6 MFMAs, product by
-//     product over the column tiles so that consecutive MFMAs write different accumulators.  Two waves per SIMD because
-//     a lone wave runs its split and its MFMAs one after the other (tools/ubench/mfma_bf16_shadow.hip: a VALU burst behind
-//     36 MFMAs costs 6-8 cycles per MFMA, one VALU instruction behind EACH MFMA costs nothing, a v_pk_add_f32 behind each
-//     doubles it -- and the compiler emits the burst, packed, whatever the source order or sched_group_barrier ask for;
-//     the hand-ordered asm stream that fixes this is tools/experiments/r04_wide_split_asm_stream.hip.txt, EXPERIMENTS R4.4);
+//     trajectories -- NCT x 4 (5) accumulator tiles -- and streams only ITS eighth of the model: per 32-deep contraction
+//     block 3 planes x NCT 16-byte loads per lane into a second register set, requested BETWEEN the MFMAs of the block
+//     before, one load per 8 MFMAs (all nine at the block's top queue up in front of the CU's one texture path, ~21 cycles
+//     per 1 KB, and a wave whose load is not accepted yet does not issue the MFMAs behind it: 900 -> 823 us per launch);
+//   * the B operand's bf16 planes are made ONCE per block for the whole workgroup -- thread u of the first 4 x rows splits
+//     the 8 contraction entries (row u / 4, slot u % 4) -- and shared through a double-buffered 24 KB of LDS behind X: block
+//     kb + 1 is split beside block kb's MFMAs, one barrier per block.  (Every wave splitting the same values for itself, the
+//     first form of this kernel, asked the issue port for 3.3 VALU per MFMA where 3 fit: EXPERIMENTS R4.4.)
+//   * per block a wave reads the planes of all its tiles (12 ds_read_b128) and runs column tile by column tile, 6 products x
+//     4 tiles, consecutive MFMAs on different accumulators; per accumulator the order of the six products never changes
+//     (Lo*hi, Hi*lo, Mid*mid, Mid*hi, Hi*mid, Hi*hi), so every form of this kernel returned the same bits;
+//   * a launch in which some workgroup is left with FIVE tiles runs the FIVE instantiation: the five-tile batch in two tile
+//     groups (3 + 2) with ONE operand set (requests over the operands just used).  Kept out of the regular kernel because
+//     its 60 accumulators set the whole kernel's register allocation (+14 % on launches that never see a fifth tile), and
+//     kept to one set because two spill > 100 VGPRs at 256 (11 with one);
 //   * the step's actions are requested one step ahead and held in registers across the model loop;
-//   * two workgroup barriers per step (X read by everybody -> X rewritten column block by column block);
+//   * two workgroup barriers per step around the model loop's (X read by everybody -> X rewritten column block by column block);
 //   * step cost, candidate lists and the running top-K as in k_rollout_wide.hip (trajectory tile tt is scored by wave tt's
 //     lanes 0..15 from X); icem_cost_terms included (EXT).
 // Model operand layout (pack_wide_model_split): Mb[kb][wave][ct][plane][lane] = 8 bf16 = M[32 kb + 8 (lane / 16) + v]
 // [16 (NCT wave + ct) + lane % 16], planes in the order lo, mid, hi.
+#include <type_traits>
 #include "fused_dev.h"
 #include "wide_dev.h"
 
@@ -39,6 +46,9 @@ namespace {
 
 constexpr int SPLIT_TT = 5;      // trajectory tiles per workgroup batch (regular batches take 4)
 constexpr int SPLIT_WAVES = 8;
+// the shared planes: two buffers of 3 planes x 64 rows x 32 bf16 for the regular batches (one of 80 rows for the five-tile batch fits inside)
+constexpr size_t SPLIT_PLANE_BYTES = (size_t)2 * 3 * 16 * (SPLIT_TT - 1) * 64;
+static_assert(SPLIT_PLANE_BYTES >= (size_t)3 * 16 * SPLIT_TT * 64 && SPLIT_PLANE_BYTES >= 2 * SPLIT_WAVES * 32 * sizeof(unsigned long long), "planes buffer");
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -83,9 +93,9 @@ __device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
 // One batch of NTT trajectory tiles (rows [row0, row0 + 16 ntt), ntt <= NTT: tiles beyond ntt are computed on whatever their
 // LDS rows hold and dropped -- no predicate inside the model loop) through all H steps.  m0 holds contraction block 0 of the
 // wave's share of the model on entry and on exit.
-template <int NCT, int NTT, int KIND, bool EXT, typename Req>
-__device__ __forceinline__ void split_batch(const WideRolloutArgs& a, float* X, const CostArgs<float>& cs_s, int row0, int ntt, int tid, int lane,
-                                            int wave, u32x4 (&m0)[NCT * 3], u32x4 (&m1)[NCT * 3], Req&& request,
+template <int NCT, int NTT, int KIND, bool EXT, bool ONESET, typename Req>
+__device__ __forceinline__ void split_batch(const WideRolloutArgs& a, float* X, unsigned char* P, const CostArgs<float>& cs_s, int row0, int ntt, int tid, int lane,
+                                            int wave, u32x4 (&m0)[NCT * 3], u32x4 (&m1)[NCT * 3], Req&& request1,
                                             unsigned long long& run_key, bool& first) {
     const int j = lane & 15, g = lane >> 4;
     const int XS = a.xs, KB = a.kb, o = a.o, d = a.d, H = a.h;
@@ -124,7 +134,6 @@ __device__ __forceinline__ void split_batch(const WideRolloutArgs& a, float* X, 
             }
         }
     };
-    const float* xb = X + j * XS + 8 * g;
     // The step's actions -> X[:, o .. o + d): element e = tid + 256 i of the batch's [nrow, d] block.  Step t + 1's are
     // requested at the top of step t and stay in registers across the model loop (a load -> LDS store -> barrier sequence
     // per step would expose one global round trip per step and element: measured, a third of the launch).
@@ -159,6 +168,7 @@ __device__ __forceinline__ void split_batch(const WideRolloutArgs& a, float* X, 
         }
     };
     if (ahead) load_actions(0);
+    __syncthreads();   // the zeros above and the actions below meet in X's action slots, written by different threads
     store_actions(0);
     long long* st = (a.dbg && blockIdx.x == 3 && tid == 64) ? a.dbg : nullptr;   // development: phase stamps of step 5 (tools/dbg/split_stamps.py)
     for (int t = 0; t < H; ++t) {
@@ -173,38 +183,103 @@ __device__ __forceinline__ void split_batch(const WideRolloutArgs& a, float* X, 
         for (int c = 0; c < NCT; ++c)
 #pragma unroll
             for (int tt = 0; tt < NTT; ++tt) acc[c][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        auto block = [&](const u32x4 (&m)[NCT * 3], int kb) {
-#pragma unroll
-            for (int tt = 0; tt < NTT; ++tt) {
-                const float* xp = xb + (size_t)(16 * tt) * XS + 32 * kb;
+        // the shared planes P[buffer][plane][row][32 bf16]: regular batches double-buffer (block kb + 1 is split while block kb
+        // is multiplied, one barrier per block); the five-tile batch has room for one buffer (two barriers per block)
+        constexpr bool DB = NTT < SPLIT_TT;
+        constexpr int ROWS = 16 * NTT;
+        auto splitn = [&](int kbn, int buf) {
+            if (tid < 4 * ROWS) {
+                const int r = tid >> 2, gg = tid & 3;
+                const float* xp = X + (size_t)r * XS + 32 * kbn + 8 * gg;
                 const Planes b = split8(*reinterpret_cast<const float4*>(xp), *reinterpret_cast<const float4*>(xp + 4));
-                // product by product over the wave's column tiles: consecutive MFMAs write different accumulators
-#pragma unroll
-                for (int c = 0; c < NCT; ++c) acc[c][tt] = mma(m[3 * c + 0], b.hi, acc[c][tt]);    // Lo  * hi
-#pragma unroll
-                for (int c = 0; c < NCT; ++c) acc[c][tt] = mma(m[3 * c + 2], b.lo, acc[c][tt]);    // Hi  * lo
-#pragma unroll
-                for (int c = 0; c < NCT; ++c) acc[c][tt] = mma(m[3 * c + 1], b.mid, acc[c][tt]);   // Mid * mid
-#pragma unroll
-                for (int c = 0; c < NCT; ++c) acc[c][tt] = mma(m[3 * c + 1], b.hi, acc[c][tt]);    // Mid * hi
-#pragma unroll
-                for (int c = 0; c < NCT; ++c) acc[c][tt] = mma(m[3 * c + 2], b.mid, acc[c][tt]);   // Hi  * mid
-#pragma unroll
-                for (int c = 0; c < NCT; ++c) acc[c][tt] = mma(m[3 * c + 2], b.hi, acc[c][tt]);    // Hi  * hi
+                unsigned char* q = P + ((size_t)(buf * 3) * ROWS + r) * 64 + gg * 16;
+                *reinterpret_cast<u32x4*>(q) = b.hi;
+                *reinterpret_cast<u32x4*>(q + (size_t)ROWS * 64) = b.mid;
+                *reinterpret_cast<u32x4*>(q + (size_t)2 * ROWS * 64) = b.lo;
             }
         };
-        // two register sets, one block requested ahead; the request behind the last block is block 0 of the NEXT step
+        // A block: the planes of all NTT tiles are read once, then column tile by column tile -- 6 products x NTT tiles on NTT
+        // different accumulators -- with the NEXT block's operands of that column tile requested between its MFMAs (two sets:
+        // every operand is asked for exactly one block before its use; one set: over itself, behind its last use).
+        auto block = [&](const u32x4 (&m)[NCT * 3], int buf, u32x4 (&mn)[NCT * 3], int kbn) {
+            const unsigned char* q0 = P + ((size_t)(buf * 3) * ROWS + j) * 64 + g * 16;
+            auto feed = [&](int e) {
+                __builtin_amdgcn_sched_barrier(0);
+                mn[e] = request1(kbn, e);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            // (the five-tile batch in two groups of tiles, 3 + 2: see the head of the file)
+            constexpr int T0 = NTT < SPLIT_TT ? NTT : 3;
+            auto group = [&](auto t_lo, auto t_n, bool first, bool last) {
+                constexpr int TL = decltype(t_lo)::value, TN = decltype(t_n)::value;
+                u32x4 bh[TN], bm[TN], bl[TN];
+                if (!first) __builtin_amdgcn_sched_barrier(0);   // (or the second group's planes are read beside the first's)
+#pragma unroll
+                for (int tt = 0; tt < TN; ++tt) bh[tt] = *reinterpret_cast<const u32x4*>(q0 + (size_t)(16 * (TL + tt)) * 64);
+#pragma unroll
+                for (int tt = 0; tt < TN; ++tt) bl[tt] = *reinterpret_cast<const u32x4*>(q0 + (size_t)(16 * (TL + tt) + 2 * ROWS) * 64);
+#pragma unroll
+                for (int tt = 0; tt < TN; ++tt) bm[tt] = *reinterpret_cast<const u32x4*>(q0 + (size_t)(16 * (TL + tt) + ROWS) * 64);
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) {
+                    // product by product over the group's tiles: consecutive MFMAs write different accumulators
+#pragma unroll
+                    for (int tt = 0; tt < TN; ++tt) acc[c][TL + tt] = mma(m[3 * c + 0], bh[tt], acc[c][TL + tt]);    // Lo  * hi
+#pragma unroll
+                    for (int tt = 0; tt < TN; ++tt) acc[c][TL + tt] = mma(m[3 * c + 2], bl[tt], acc[c][TL + tt]);    // Hi  * lo
+                    if (!ONESET && first) feed(3 * c + 0);
+#pragma unroll
+                    for (int tt = 0; tt < TN; ++tt) acc[c][TL + tt] = mma(m[3 * c + 1], bm[tt], acc[c][TL + tt]);    // Mid * mid
+#pragma unroll
+                    for (int tt = 0; tt < TN; ++tt) acc[c][TL + tt] = mma(m[3 * c + 1], bh[tt], acc[c][TL + tt]);    // Mid * hi
+                    if (!ONESET && first == last) feed(3 * c + 1);   // one group: here; two groups: behind the first one's last product
+#pragma unroll
+                    for (int tt = 0; tt < TN; ++tt) acc[c][TL + tt] = mma(m[3 * c + 2], bm[tt], acc[c][TL + tt]);    // Hi  * mid
+#pragma unroll
+                    for (int tt = 0; tt < TN; ++tt) acc[c][TL + tt] = mma(m[3 * c + 2], bh[tt], acc[c][TL + tt]);    // Hi  * hi
+                    if (!ONESET && first && !last) feed(3 * c + 1);
+                    if (ONESET && last) {   // over the operands just used for the last time
+                        feed(3 * c + 0);
+                        feed(3 * c + 1);
+                    }
+                    if (last) feed(3 * c + 2);
+                }
+            };
+            group(std::integral_constant<int, 0>{}, std::integral_constant<int, T0>{}, true, T0 == NTT);
+            if constexpr (T0 < NTT) group(std::integral_constant<int, T0>{}, std::integral_constant<int, NTT - T0>{}, false, true);
+        };
+        // behind a block: everybody is done with its planes (and the next block's are complete, if they were made beside it)
+        auto behind = [&](int kbn) {
+            __syncthreads();
+            if (!DB && kbn >= 0) {
+                splitn(kbn, 0);
+                __syncthreads();
+            }
+        };
+        splitn(0, 0);
+        __syncthreads();
         int kb = 0;
+        if constexpr (!ONESET) {
+            // two register sets of model operands, a block's requested while the block before it runs; beside the last block: block 0 of the NEXT step
 #pragma unroll 1
-        for (; kb + 1 < KB; kb += 2) {
-            request(m1, kb + 1);
-            block(m0, kb);
-            request(m0, kb + 2 < KB ? kb + 2 : 0);
-            block(m1, kb + 1);
-        }
-        if (kb < KB) {   // odd block count: the last one (outside the loop: a conditional block inside it costs a copy of every accumulator per trip)
-            block(m0, kb);
-            request(m0, 0);
+            for (; kb + 1 < KB; kb += 2) {
+                splitn(kb + 1, 1);
+                block(m0, 0, m1, kb + 1);
+                behind(kb + 1);
+                if (kb + 2 < KB) splitn(kb + 2, 0);
+                block(m1, 1, m0, kb + 2 < KB ? kb + 2 : 0);
+                behind(kb + 2 < KB ? kb + 2 : -1);
+            }
+            if (kb < KB) {   // odd block count: the last one (outside the loop: a conditional block inside it costs a copy of every accumulator per trip)
+                block(m0, 0, m1, 0);   // (the next step's block 0 lands in m1: moved to m0 at the step's end, when it has long arrived)
+            }
+        } else {
+#pragma unroll 1
+            for (; kb < KB; ++kb) {
+                if (DB && kb + 1 < KB) splitn(kb + 1, (kb + 1) & 1);
+                block(m0, DB ? (kb & 1) : 0, m0, kb + 1 < KB ? kb + 1 : 0);
+                behind(kb + 1 < KB ? kb + 1 : -1);
+            }
         }
         if (st && t == 5) st[3] = wall_clock64();
         if (a.dbg && blockIdx.x == 3 && lane == 0 && t == 5) a.dbg[8 + wave] = wall_clock64();   // every wave's loop end
@@ -232,6 +307,10 @@ __device__ __forceinline__ void split_batch(const WideRolloutArgs& a, float* X, 
         }
         if (st && t == 5) st[5] = wall_clock64();
         if (t + 1 < H) store_actions(t + 1);
+        if (!ONESET && (KB & 1)) {
+#pragma unroll
+            for (int e = 0; e < NCT * 3; ++e) m0[e] = m1[e];
+        }
         if (st && t == 5) st[6] = wall_clock64();
         if (st && t == 6) st[7] = wall_clock64();
     }
@@ -252,11 +331,16 @@ __device__ __forceinline__ void split_batch(const WideRolloutArgs& a, float* X, 
     }
 }
 
-template <int NCT, int KIND, bool EXT>
+// FIVE: some workgroup's tile count leaves a remainder of five (one batch instead of 4 + 1).  Its own instantiation: the
+// five-tile batch's 60 accumulators set the register allocation of the whole kernel, and the four-tile batches of a launch
+// that never sees one were 14 % slower for carrying it.
+template <int NCT, int KIND, bool EXT, bool FIVE>
 __global__ __launch_bounds__(64 * SPLIT_WAVES) void rollout_wide_split_kernel(WideRolloutArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float X[];  // [16 * SPLIT_TT][XS]
-    __shared__ unsigned long long wg_keys[2][SPLIT_WAVES][32];
+    extern __shared__ __attribute__((aligned(16))) float X[];  // [16 * SPLIT_TT][XS] f32 rows, then the planes' buffers
     __shared__ CostArgs<float> cs_s;
+    unsigned char* P = reinterpret_cast<unsigned char*>(X + (size_t)16 * SPLIT_TT * a.xs);   // SPLIT_PLANE_BYTES
+    // (the workgroup's candidate-list scratch lies over the planes: used behind the last batch only)
+    auto wg_keys = reinterpret_cast<unsigned long long(*)[SPLIT_WAVES][32]>(P);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -265,10 +349,11 @@ __global__ __launch_bounds__(64 * SPLIT_WAVES) void rollout_wide_split_kernel(Wi
     typedef const __attribute__((address_space(1))) u32x4* gvec;
     gvec Mw = (gvec)a.Mp + (size_t)wave * NCT * 3 * 64 + lane;
     const size_t kb_stride = (size_t)SPLIT_WAVES * NCT * 3 * 64;
+    auto request1 = [&](int kb, int e) -> u32x4 { return Mw[(size_t)kb * kb_stride + (size_t)e * 64]; };
     auto request = [&](u32x4 (&m)[NCT * 3], int kb) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int e = 0; e < NCT * 3; ++e) m[e] = Mw[(size_t)kb * kb_stride + (size_t)e * 64];
+        for (int e = 0; e < NCT * 3; ++e) m[e] = request1(kb, e);
         __builtin_amdgcn_sched_barrier(0);
     };
     // tiles of this workgroup: T tiles over the grid, the remainder one each to the first workgroups
@@ -281,14 +366,22 @@ __global__ __launch_bounds__(64 * SPLIT_WAVES) void rollout_wide_split_kernel(Wi
     u32x4 m0[NCT * 3], m1[NCT * 3];
     request(m0, 0);
     while (cnt > 0) {   // batches of four tiles; a remainder of five is one batch
-        const int ntt = cnt <= SPLIT_TT ? (cnt == SPLIT_TT || cnt < SPLIT_TT - 1 ? cnt : SPLIT_TT - 1) : SPLIT_TT - 1;
-        if (ntt == SPLIT_TT)
-            split_batch<NCT, SPLIT_TT, KIND, EXT>(a, X, cs_s, t_begin * 16, ntt, tid, lane, wave, m0, m1, request, run_key, first);
-        else
-            split_batch<NCT, SPLIT_TT - 1, KIND, EXT>(a, X, cs_s, t_begin * 16, ntt, tid, lane, wave, m0, m1, request, run_key, first);
+        int ntt = cnt < SPLIT_TT - 1 ? cnt : SPLIT_TT - 1;
+        if constexpr (FIVE) {
+            if (cnt == SPLIT_TT) ntt = SPLIT_TT;
+        }
+        if constexpr (FIVE) {
+            if (ntt == SPLIT_TT)
+                split_batch<NCT, SPLIT_TT, KIND, EXT, true>(a, X, P, cs_s, t_begin * 16, ntt, tid, lane, wave, m0, m1, request1, run_key, first);
+            else
+                split_batch<NCT, SPLIT_TT - 1, KIND, EXT, true>(a, X, P, cs_s, t_begin * 16, ntt, tid, lane, wave, m0, m1, request1, run_key, first);
+        } else {
+            split_batch<NCT, SPLIT_TT - 1, KIND, EXT, false>(a, X, P, cs_s, t_begin * 16, ntt, tid, lane, wave, m0, m1, request1, run_key, first);
+        }
         cnt -= ntt;
         t_begin += ntt;
     }
+    __syncthreads();   // (the planes are dead: their LDS becomes the list scratch)
     if (a.K > 0) {
         FastRolloutArgs fr{};  // wg_merge_emit only looks at the candidate outputs
         fr.part_k = a.part_k;
@@ -354,14 +447,19 @@ void pack_wide_model_split(int o, int d, const double* A, const double* B, std::
 
 void launch_rollout_wide_split(const WideRolloutArgs& a, int kind, hipStream_t st) {
     const int grid = wide_split_lists(a.n_rows);
-    const size_t lds = (size_t)16 * SPLIT_TT * a.xs * sizeof(float);
+    const size_t lds = (size_t)16 * SPLIT_TT * a.xs * sizeof(float) + SPLIT_PLANE_BYTES;
     const int NCT = wide_split_nct(a.o);
-#define XW1(NV, KINDV, EXTV)                                                                                \
+    // a batch of five: some workgroup holds 4 q + 1 tiles, q >= 1
+    const int tiles = (a.n_rows + 15) / 16, base = tiles / grid, extra = tiles % grid;
+    const bool five = (base >= SPLIT_TT && base % (SPLIT_TT - 1) == 1) || (extra > 0 && base + 1 >= SPLIT_TT && (base + 1) % (SPLIT_TT - 1) == 1);
+#define XW2(NV, KINDV, EXTV, FV)                                                                            \
     {                                                                                                       \
-        auto kfn = rollout_wide_split_kernel<NV, KINDV, EXTV>;                                              \
+        auto kfn = rollout_wide_split_kernel<NV, KINDV, EXTV, FV>;                                          \
         (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * SPLIT_WAVES), lds, st, a);                            \
     }
+#define XW1(NV, KINDV, EXTV) \
+    if (five) XW2(NV, KINDV, EXTV, true) else XW2(NV, KINDV, EXTV, false)
 #define XW(NV)                                                     \
     if (NCT == NV) {                                               \
         if (kind == 1) {                                           \
@@ -374,6 +472,7 @@ void launch_rollout_wide_split(const WideRolloutArgs& a, int kind, hipStream_t s
     XW(1) XW(2) XW(3)
 #undef XW
 #undef XW1
+#undef XW2
 }
 
 }  // namespace icem

@@ -1178,6 +1178,44 @@ def test_rollout_and_plan_with_cost_terms(env_name, dtype):
     np.testing.assert_allclose(np_(pl.mean), orc.mean, rtol=1e-9, atol=1e-11)
 
 
+@pytest.mark.parametrize("n", [80, 257, 409, 640])
+def test_wide_split_is_the_same_every_launch(n):
+    """rollout_wide_split_kernel at o = 376 with the Humanoid cost terms, the same launch 40 times with other kernels in
+    between (they leave LDS and registers dirty): every launch returns the bits of the first, and every cost is the
+    exact-f32 kernel's to 1e-4 or a whole health penalty away (a tanh one ulp off across a threshold).  The batch
+    prologue once zeroed X and stored step 0's actions into it with no barrier between -- different threads, same words:
+    whether a trajectory's first actions survived was a matter of timing, in the rows the LAST elements of the action
+    block map to (60-63 of a 64-row batch, 60-79 of a five-tile one), and only builds in which wave 0 ran ahead of the
+    zeroing waves showed it (EXPERIMENTS R4.9).  n = 80, 257 and 409 leave some workgroup FIVE tiles; 640 is regular
+    batches only."""
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner
+    from icem_amd import envs as E
+    env = E.humanoid_env(healthy_z_range=(-0.05, 2.0))
+    o, d, h = env.obs_dim, env.action_space.shape[0], 12
+    model = DeviceSyntheticModel.make(o, d, kind=1)
+    pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=max(n, 64), opt_iters=1, dtype="f32", seed=7),
+                     env.action_space.low, env.action_space.high)
+    pl.set_model(model.kind, model.A, model.B)
+    pl.set_cost_spec(env.cost_spec)
+    pl.reset()
+    rs = np.random.RandomState(3)
+    obs0 = 0.2 * rs.randn(o)
+    acts = torch.as_tensor(rs.uniform(-1, 1, (n, h, d)) * env.action_space.high, dtype=pl.dt, device=pl.device)
+    pl.set_wide_exact(True)
+    exact = np_(pl.rollout_cost(obs0, acts)).astype(np.float64)
+    pl.set_wide_exact(False)
+    first = pl.rollout_cost(obs0, acts).clone()
+    junk = torch.empty(16 << 20, device=pl.device)
+    for i in range(40):
+        if i % 3 == 0:
+            junk.normal_()
+        got = pl.rollout_cost(obs0, acts)
+        assert torch.equal(got, first), (i, (got != first).nonzero().flatten().tolist()[:8])
+    got = np_(first).astype(np.float64)
+    far = np.abs(got - exact) > 1e-4 * (1 + np.abs(exact))
+    assert far.mean() <= 0.02, (np.nonzero(far)[0][:8], got[far][:4], exact[far][:4])
+
+
 @pytest.mark.parametrize("env_name", ["ant", "humanoid", "door", "relocate"])
 def test_wide_rollout_with_cost_terms(env_name):
     """The built-in model at observation widths 32 < o <= 384 WITH the extra cost terms (k_rollout_wide.hip: the tile kernel
