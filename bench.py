@@ -52,7 +52,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector = f32 matrix peak (they share the pipe)
-BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (never the 2:1-sparsity headline)
+BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA (never the 2:1-sparsity headline)
 
 WORKLOADS = {
     "c2": dict(N=4096, h=30, d=6, o=17, beta=0.25, iters=5, name="HalfCheetah-shaped synthetic, N=4096 h=30 d=6 o=17 beta=0.25, 5 CEM iters"),
@@ -328,19 +328,20 @@ def roofline_of(prof, w, workload=None):
     # rocprof_trace_avg_us: the committed kernel trace's figure for the same kernels, for comparison
     if w["o"] > 32 and dom == "rollout_cost":
         # wide observations: the rollout is a GEMM three orders of magnitude above the ridge ("declare that
-        # stage compute-bound").  It runs on the bf16 matrix cores with every f32 operand split in three bf16 planes: SIX
-        # bf16 products per algorithmic multiply-add (k_rollout_wide_split.hip), so the roof is the dense bf16 peak and
-        # `achieved` the EXECUTED bf16 rate = 6 x the algorithmic f32 rate (padding of the 32-deep blocks not counted)
-        executed = 6.0 * tflops
+        # stage compute-bound").  It runs on the fp16 matrix cores with every f32 operand x 2^k split in two fp16 planes:
+        # THREE fp16 products per algorithmic multiply-add (k_rollout_wide_split.hip), so the roof is the dense fp16 peak
+        # (= the bf16 one) and `achieved` the EXECUTED fp16 rate = 3 x the algorithmic f32 rate (padding of the 32-deep
+        # blocks not counted).  (Round 4's first form, three bf16 planes and six products: icem_set_wide_exact(h, 2).)
+        executed = 3.0 * tflops
         return {"bound": "mfma", "achieved": executed, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": executed / BF16_PEAK_TFLOPS,
                 "traffic": traffic, "traffic_source": src, "kernel": dom, "avg_launch_us": 1e3 * ms / launches,
                 "rocprof_trace_avg_us": trace_us, "launches": launches, "flops_per_traj_step": fpu,
                 "algorithmic_flops_per_launch": units * fpu / launches, "algorithmic_TFLOPs": tflops,
-                "products_per_multiply_add": 6,
-                "dtype": "3-way bf16 split of f32 operands, six products per multiply-add, f32 accumulation (v_mfma_f32_16x16x32_bf16)",
+                "products_per_multiply_add": 3,
+                "dtype": "2-way fp16 split of f32 operands x 2^k, three products per multiply-add, f32 accumulation (v_mfma_f32_16x16x32_f16)",
                 "vs_exact_f32_matrix_peak": tflops / F32_PEAK_TFLOPS,
                 "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "bytes_per_traj_step": bpu}, "binding_roof": "bf16-mfma"}
+                        "bytes_per_traj_step": bpu}, "binding_roof": "fp16-mfma"}
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": src, "kernel": dom, "avg_launch_us": 1e3 * ms / launches,
             "rocprof_trace_avg_us": trace_us, "launches": launches,

@@ -185,6 +185,7 @@ int icem_destroy(icem_handle* h) {
     if (h->Mp_dev) (void)hipFree(h->Mp_dev);
     if (h->Mw_dev) (void)hipFree(h->Mw_dev);
     if (h->Mws_dev) (void)hipFree(h->Mws_dev);
+    if (h->Mwh_dev) (void)hipFree(h->Mwh_dev);
     if (h->wide_cs_dev) (void)hipFree(h->wide_cs_dev);
     if (h->pub_dev) (void)hipFree(h->pub_dev);
     if (h->perm_dev) (void)hipFree(h->perm_dev);
@@ -468,7 +469,8 @@ int icem_debug_stamps(icem_handle* h, void* dev_ptr) {
 
 int icem_set_wide_exact(icem_handle* h, int32_t on) {
     if (check_handle(h)) return ICEM_E_INVALID;
-    h->wide_exact = on != 0;
+    if (on < 0 || on > 2) return fail(ICEM_E_INVALID, "icem_set_wide_exact: 0 (fp16 planes), 1 (exact f32) or 2 (bf16 planes)");
+    h->wide_mode = on;
     return ICEM_OK;
 }
 

@@ -98,8 +98,11 @@ struct icem_handle {
                                  // (h, d, O) that is not compiled): the f32 rollout is then the GEMM kernel at ANY width.
                                  // Kept current by update_paths() (abi.hip) behind every model / cost setter.
     void* Mw_dev = nullptr;      // its packed model
-    void* Mws_dev = nullptr;     // ... and as three bf16 planes (k_rollout_wide_split.hip), the default wide rollout
-    bool wide_exact = false;     // icem_set_wide_exact: the exact-f32 matrix pipe instead (k_rollout_wide.hip + its row kernel)
+    void* Mws_dev = nullptr;     // ... as three bf16 planes (k_rollout_wide_split.hip) ...
+    void* Mwh_dev = nullptr;     // ... and as two fp16 planes of the model x 2^k, Mwh_inv = 2^-k: the default wide rollout
+    float Mwh_inv = 1.f;
+    int wide_mode = 0;           // icem_set_wide_exact: 0 = fp16 planes (3 products per multiply-add), 1 = the exact-f32 matrix pipe
+                                 // (k_rollout_wide.hip + its row kernel), 2 = bf16 planes (6 products)
     void* wide_cs_dev = nullptr; // CostArgs<float> (cost spec + terms) for k_rollout_wide, refreshed by the cost setters
     void* Mp_dev = nullptr;
     void* perm_dev = nullptr;

@@ -2,15 +2,27 @@
 // icem/environments/mujoco.py:241-277) with the model step on the bf16 matrix cores: rollout_wide_split_kernel.
 //
 // The step [n, o + d] x [o + d, o] is a GEMM three orders of magnitude above the f32 ridge, and the exact-f32 MFMA of
-// k_rollout_wide.hip runs at 1/16 of the bf16 rate.  Here every f32 value is the exact sum of three bf16 numbers
-// (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): 3 x 8 significant bits) and a product x * m is the six
-// bf16 x bf16 products whose weight is above 2^-24 of it -- hi*Hi, hi*Mid, mid*Hi, hi*Lo, lo*Hi, mid*Mid -- each EXACT in
-// the f32 accumulator's format, summed smallest first on v_mfma_f32_16x16x32_bf16.  What is dropped (mid*Lo, lo*Mid,
-// lo*Lo) is below 2^-31 of a product: the result is an f32 dot product with f32-class rounding, not the bits of an fmaf
-// chain (error analysis: DESIGN.md section 4).  Six K = 32 MFMAs of 16 cycles replace eight K = 4 MFMAs of 32.
+// k_rollout_wide.hip runs at 1/16 of the 16-bit rate.  Two splits of the f32 operands onto the 16-bit matrix cores, one
+// kernel template (F16):
+//   * fp16, two planes, THREE products (the default; icem_set_wide_exact 0).  x S = hi + lo with hi = f16(x S), lo =
+//     f16(x S - hi), both round-to-nearest-even: 11 + 11 significant bits and lo's sign, x S to 2^-24 relative.  S is a
+//     power of two per TRAJECTORY ROW and step, taken from the row's largest entry so that |x| S < 2^15 (fp16 ends at
+//     65 504; found by four threads per row at the step's top), and one per model (pack_wide_model_split); both are taken
+//     out of the accumulators again at the write-back, exactly.  A product x m = hi Hi + hi Lo + lo Hi (+ lo Lo, dropped:
+//     below 2^-22 of hi Hi, i.e. 2^-24-class like the operands' own rounding), each of the three EXACT in the f32
+//     accumulator's format (22 significant bits), summed smallest first on v_mfma_f32_16x16x32_f16.  Entries more than 2^13
+//     below their row's largest have a subnormal lo: an absolute error below 2^-40 of that largest entry.  Measured against
+//     the float64 oracle over 30 tanh steps at o = 378: 1-4 x 10^-6 relative, the exact-f32 kernel's own distance
+//     (tools/dbg/split_tile_errors.py; tests: observations from 1e-30 to 1e9 in test_wide_fp16_planes_follow_the_magnitudes).
+//   * bf16, three planes, SIX products (icem_set_wide_exact 2; round 4's first form).  x = hi + mid + lo EXACTLY (3 x 8
+//     significant bits, no scale needed: bf16 has f32's exponent), products hi*Hi, hi*Mid, mid*Hi, hi*Lo, lo*Hi, mid*Mid
+//     on v_mfma_f32_16x16x32_bf16; what is dropped is below 2^-31 of a product.  Two thirds of the fp16 form's speed.
+// Either way the result is an f32 dot product with f32-class rounding, not the bits of an fmaf chain (error analysis:
+// DESIGN.md section 4); a row's result depends on that row and the model only, wherever the row sits in a launch.
 //
-// Tiling.  A 16-row tile per wave (k_rollout_wide.hip) streams the whole model through every wave every step; in three
-// bf16 planes that is 958 KB per 16 rows and step -- more than a CU's L2 port delivers.  So a WORKGROUP owns up to 80
+// Tiling (numbers for the bf16 form; the fp16 one has two planes where it has three, three products where it has six).  A
+// 16-row tile per wave (k_rollout_wide.hip) streams the whole model through every wave every step; in three bf16 planes
+// that is 958 KB per 16 rows and step -- more than a CU's L2 port delivers.  So a WORKGROUP owns up to 80
 // trajectories (five 16-row tiles; four is the regular batch, the fifth takes the few rows a population leaves behind
 // whole batches -- the shifted elites of iteration 0, icem.py:131-137 -- instead of a second round of workgroups):
 //   * their contraction vectors [obs | action | 0-pad] live in LDS as f32 rows X[80][XS] (134 KB: one workgroup per CU);
@@ -19,7 +31,7 @@
 //     block 3 planes x NCT 16-byte loads per lane into a second register set, requested BETWEEN the MFMAs of the block
 //     before, one load per 8 MFMAs (all nine at the block's top queue up in front of the CU's one texture path, ~21 cycles
 //     per 1 KB, and a wave whose load is not accepted yet does not issue the MFMAs behind it: 900 -> 823 us per launch);
-//   * the B operand's bf16 planes are made ONCE per block for the whole workgroup -- thread u of the first 4 x rows splits
+//   * the B operand's planes are made ONCE per block for the whole workgroup -- thread u of the first 4 x rows splits
 //     the 8 contraction entries (row u / 4, slot u % 4) -- and shared through a double-buffered 24 KB of LDS behind X: block
 //     kb + 1 is split beside block kb's MFMAs, one barrier per block.  (Every wave splitting the same values for itself, the
 //     first form of this kernel, asked the issue port for 3.3 VALU per MFMA where 3 fit: EXPERIMENTS R4.4.)
@@ -34,8 +46,9 @@
 //   * two workgroup barriers per step around the model loop's (X read by everybody -> X rewritten column block by column block);
 //   * step cost, candidate lists and the running top-K as in k_rollout_wide.hip (trajectory tile tt is scored by wave tt's
 //     lanes 0..15 from X); icem_cost_terms included (EXT).
-// Model operand layout (pack_wide_model_split): Mb[kb][wave][ct][plane][lane] = 8 bf16 = M[32 kb + 8 (lane / 16) + v]
-// [16 (NCT wave + ct) + lane % 16], planes in the order lo, mid, hi.
+// Model operand layout (pack_wide_model_split): Mb[kb][wave][ct][plane][lane] = 8 x 16 bits = M[32 kb + 8 (lane / 16) + v]
+// [16 (NCT wave + ct) + lane % 16], planes in the order lo, (mid,) hi.
+#include <cmath>
 #include <type_traits>
 #include "fused_dev.h"
 #include "wide_dev.h"
@@ -46,7 +59,7 @@ namespace {
 
 constexpr int SPLIT_TT = 5;      // trajectory tiles per workgroup batch (regular batches take 4)
 constexpr int SPLIT_WAVES = 8;
-// the shared planes: two buffers of 3 planes x 64 rows x 32 bf16 for the regular batches (one of 80 rows for the five-tile batch fits inside)
+// the shared planes: two buffers of (up to) 3 planes x 64 rows x 32 x 16 bits for the regular batches (one of 80 rows for the five-tile batch fits inside)
 constexpr size_t SPLIT_PLANE_BYTES = (size_t)2 * 3 * 16 * (SPLIT_TT - 1) * 64;
 static_assert(SPLIT_PLANE_BYTES >= (size_t)3 * 16 * SPLIT_TT * 64 && SPLIT_PLANE_BYTES >= 2 * SPLIT_WAVES * 32 * sizeof(unsigned long long), "planes buffer");
 
@@ -86,17 +99,39 @@ __device__ __forceinline__ Planes split8(float4 p, float4 q) {
     return r;
 }
 
+// The two fp16 planes of 8 f32 values scaled by S (a power of two chosen per trajectory row so that |x| S < 2^15):
+// hi = f16(x S), lo = f16(x S - hi), both round-to-nearest-even (v_cvt_pk_f16_f32).  hi + lo is x S to 2^-24 relative
+// (11 + 11 significant bits and lo's sign), lo is a normal fp16 number for every entry within 2^-13 of the row's largest
+// and carries an absolute error below 2^-40 of that largest entry otherwise.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split8h(float4 p, float4 q, float S, u32x4& hi, u32x4& lo) {
+    const float x[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2 v = {x[2 * i] * S, x[2 * i + 1] * S};
+        const f16x2 h = __builtin_convertvector(v, f16x2);
+        const f32x2 b = __builtin_convertvector(h, f32x2);
+        const f16x2 l = __builtin_convertvector(f32x2{v[0] - b[0], v[1] - b[1]}, f16x2);
+        hi[i] = __builtin_bit_cast(unsigned, h);
+        lo[i] = __builtin_bit_cast(unsigned, l);
+    }
+}
+
+template <bool F16>
 __device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 // One batch of NTT trajectory tiles (rows [row0, row0 + 16 ntt), ntt <= NTT: tiles beyond ntt are computed on whatever their
 // LDS rows hold and dropped -- no predicate inside the model loop) through all H steps.  m0 holds contraction block 0 of the
 // wave's share of the model on entry and on exit.
-template <int NCT, int NTT, int KIND, bool EXT, bool ONESET, typename Req>
-__device__ __forceinline__ void split_batch(const WideRolloutArgs& a, float* X, unsigned char* P, const CostArgs<float>& cs_s, int row0, int ntt, int tid, int lane,
-                                            int wave, u32x4 (&m0)[NCT * 3], u32x4 (&m1)[NCT * 3], Req&& request1,
-                                            unsigned long long& run_key, bool& first) {
+template <int NCT, int NTT, int KIND, bool EXT, bool ONESET, bool F16, typename Req>
+__device__ __forceinline__ void split_batch(const WideRolloutArgs& a, float* X, unsigned char* P, float* rscale, float* rinv, const CostArgs<float>& cs_s,
+                                            int row0, int ntt, int tid, int lane, int wave, u32x4 (&m0)[NCT * (F16 ? 2 : 3)],
+                                            u32x4 (&m1)[NCT * (F16 ? 2 : 3)], Req&& request1, unsigned long long& run_key, bool& first) {
+    constexpr int NPL = F16 ? 2 : 3;   // planes per operand: fp16 (hi, lo) / bf16 (hi, mid, lo)
     const int j = lane & 15, g = lane >> 4;
     const int XS = a.xs, KB = a.kb, o = a.o, d = a.d, H = a.h;
     const WideCost wc{a.lin_idx, a.flip_idx, a.ctrl_w, a.lin_w, a.flip_pen, a.flip_th};
@@ -187,22 +222,67 @@ __device__ __forceinline__ void split_batch(const WideRolloutArgs& a, float* X, 
         // is multiplied, one barrier per block); the five-tile batch has room for one buffer (two barriers per block)
         constexpr bool DB = NTT < SPLIT_TT;
         constexpr int ROWS = 16 * NTT;
-        auto splitn = [&](int kbn, int buf) {
-            if (tid < 4 * ROWS) {
-                const int r = tid >> 2, gg = tid & 3;
-                const float* xp = X + (size_t)r * XS + 32 * kbn + 8 * gg;
+        float S = 1.f;   // (fp16 planes) the power of two of this splitter thread's row
+        auto split_row = [&](int r, int gg, int kbn, int buf) {
+            const float* xp = X + (size_t)r * XS + 32 * kbn + 8 * gg;
+            unsigned char* q = P + ((size_t)(buf * NPL) * ROWS + r) * 64 + gg * 16;
+            if constexpr (F16) {
+                u32x4 hi, lo;
+                split8h(*reinterpret_cast<const float4*>(xp), *reinterpret_cast<const float4*>(xp + 4), S, hi, lo);
+                *reinterpret_cast<u32x4*>(q) = hi;
+                *reinterpret_cast<u32x4*>(q + (size_t)ROWS * 64) = lo;
+            } else {
                 const Planes b = split8(*reinterpret_cast<const float4*>(xp), *reinterpret_cast<const float4*>(xp + 4));
-                unsigned char* q = P + ((size_t)(buf * 3) * ROWS + r) * 64 + gg * 16;
                 *reinterpret_cast<u32x4*>(q) = b.hi;
                 *reinterpret_cast<u32x4*>(q + (size_t)ROWS * 64) = b.mid;
                 *reinterpret_cast<u32x4*>(q + (size_t)2 * ROWS * 64) = b.lo;
             }
         };
+        auto splitn = [&](int kbn, int buf) {
+            if (tid < 4 * ROWS) split_row(tid >> 2, tid & 3, kbn, buf);
+        };
+        // Block 0 of a step.  bf16 planes: like every block.  fp16 planes: by the threads four waves on (the waves that
+        // score nothing at the step's top), which first find the row's scale -- four threads per row scan it, S = 2^(141 - e)
+        // for a largest entry 1.m x 2^(e - 127), so |x| S < 2^15 (fp16 holds 65 504), exact powers of two throughout;
+        // 1 / (S x the model's scale) waits in rinv[] for the write-back.  A NaN entry does not move the maximum and poisons
+        // its own trajectory only (one B-operand row = one output column); an infinite one makes S 2^-114 and stays infinite.
+        auto split_first = [&]() {
+            if constexpr (!F16) {
+                splitn(0, 0);
+            } else {
+                const int u = (tid + 4 * 64) & (64 * SPLIT_WAVES - 1);
+                if (u < 4 * ROWS) {
+                    const int r = u >> 2, gg = u & 3;
+                    const float* xr = X + (size_t)r * XS + 4 * gg;
+                    float mx = 0.f;
+                    for (int k = 0; k < 8 * KB; k += 4) {   // float4s gg, gg + 4, ..: the row's 32 KB entries, a quarter each
+                        if (4 * (gg + k) < 32 * KB) {
+                            const float4 v = *reinterpret_cast<const float4*>(xr + 4 * k);
+                            mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(v.x)), __builtin_fmaxf(__builtin_fabsf(v.y), __builtin_fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w))));
+                        }
+                    }
+                    mx = __builtin_fmaxf(mx, __shfl_xor(mx, 1));
+                    mx = __builtin_fmaxf(mx, __shfl_xor(mx, 2));
+                    int e = (int)(__float_as_uint(mx) >> 23);
+                    e = e < 40 ? 40 : e;   // (an all-zero row: any scale)
+                    const float Sr = __uint_as_float((unsigned)(268 - e) << 23);
+                    if (gg == 0) {
+                        rscale[r] = Sr;
+                        rinv[r] = __uint_as_float((unsigned)(e - 14) << 23) * a.minv;
+                    }
+                    const float keep = S;
+                    S = Sr;
+                    split_row(r, gg, 0, 0);
+                    S = keep;
+                }
+            }
+        };
         // A block: the planes of all NTT tiles are read once, then column tile by column tile -- 6 products x NTT tiles on NTT
         // different accumulators -- with the NEXT block's operands of that column tile requested between its MFMAs (two sets:
         // every operand is asked for exactly one block before its use; one set: over itself, behind its last use).
-        auto block = [&](const u32x4 (&m)[NCT * 3], int buf, u32x4 (&mn)[NCT * 3], int kbn) {
-            const unsigned char* q0 = P + ((size_t)(buf * 3) * ROWS + j) * 64 + g * 16;
+        static_assert(ONESET || NTT < SPLIT_TT, "the two-set form has one tile group");
+        auto block = [&](const u32x4 (&m)[NCT * NPL], int buf, u32x4 (&mn)[NCT * NPL], int kbn) {
+            const unsigned char* q0 = P + ((size_t)(buf * NPL) * ROWS + j) * 64 + g * 16;
             auto feed = [&](int e) {
                 __builtin_amdgcn_sched_barrier(0);
                 mn[e] = request1(kbn, e);
@@ -212,37 +292,36 @@ __device__ __forceinline__ void split_batch(const WideRolloutArgs& a, float* X, 
             constexpr int T0 = NTT < SPLIT_TT ? NTT : 3;
             auto group = [&](auto t_lo, auto t_n, bool first, bool last) {
                 constexpr int TL = decltype(t_lo)::value, TN = decltype(t_n)::value;
-                u32x4 bh[TN], bm[TN], bl[TN];
+                // planes of the group's tiles: [0] hi, [1] mid (bf16) / lo (fp16), [2] lo (bf16)
+                u32x4 bp[NPL][TN];
                 if (!first) __builtin_amdgcn_sched_barrier(0);   // (or the second group's planes are read beside the first's)
 #pragma unroll
-                for (int tt = 0; tt < TN; ++tt) bh[tt] = *reinterpret_cast<const u32x4*>(q0 + (size_t)(16 * (TL + tt)) * 64);
+                for (int pl = 0; pl < NPL; ++pl) {
+                    const int src = pl == 0 ? 0 : (NPL - pl);   // read order hi, lo, (mid): the order the products want them in
 #pragma unroll
-                for (int tt = 0; tt < TN; ++tt) bl[tt] = *reinterpret_cast<const u32x4*>(q0 + (size_t)(16 * (TL + tt) + 2 * ROWS) * 64);
-#pragma unroll
-                for (int tt = 0; tt < TN; ++tt) bm[tt] = *reinterpret_cast<const u32x4*>(q0 + (size_t)(16 * (TL + tt) + ROWS) * 64);
+                    for (int tt = 0; tt < TN; ++tt) bp[src][tt] = *reinterpret_cast<const u32x4*>(q0 + (size_t)(16 * (TL + tt) + src * ROWS) * 64);
+                }
+                // products, smallest first; model operands m[NPL c + ..]: planes in the order lo, (mid), hi
+                constexpr int NPROD = F16 ? 3 : 6;
+                constexpr int PA[6] = {0, NPL - 1, F16 ? 1 : 1, 1, 2, 2};          // A: Lo, Hi, [Hi] | Mid, Mid, Hi, Hi
+                constexpr int PB[6] = {0, NPL - 1, F16 ? 0 : 1, 0, 1, 0};          // B: hi, lo, [hi] | mid, hi, mid, hi
 #pragma unroll
                 for (int c = 0; c < NCT; ++c) {
-                    // product by product over the group's tiles: consecutive MFMAs write different accumulators
 #pragma unroll
-                    for (int tt = 0; tt < TN; ++tt) acc[c][TL + tt] = mma(m[3 * c + 0], bh[tt], acc[c][TL + tt]);    // Lo  * hi
+                    for (int p = 0; p < NPROD; ++p) {
+                        // product by product over the group's tiles: consecutive MFMAs write different accumulators
 #pragma unroll
-                    for (int tt = 0; tt < TN; ++tt) acc[c][TL + tt] = mma(m[3 * c + 2], bl[tt], acc[c][TL + tt]);    // Hi  * lo
-                    if (!ONESET && first) feed(3 * c + 0);
+                        for (int tt = 0; tt < TN; ++tt) acc[c][TL + tt] = mma<F16>(m[NPL * c + PA[p]], bp[PB[p]][tt], acc[c][TL + tt]);
+                        if (!ONESET && first && last) {   // the next block's operands of this column tile, spread over its products
 #pragma unroll
-                    for (int tt = 0; tt < TN; ++tt) acc[c][TL + tt] = mma(m[3 * c + 1], bm[tt], acc[c][TL + tt]);    // Mid * mid
-#pragma unroll
-                    for (int tt = 0; tt < TN; ++tt) acc[c][TL + tt] = mma(m[3 * c + 1], bh[tt], acc[c][TL + tt]);    // Mid * hi
-                    if (!ONESET && first == last) feed(3 * c + 1);   // one group: here; two groups: behind the first one's last product
-#pragma unroll
-                    for (int tt = 0; tt < TN; ++tt) acc[c][TL + tt] = mma(m[3 * c + 2], bm[tt], acc[c][TL + tt]);    // Hi  * mid
-#pragma unroll
-                    for (int tt = 0; tt < TN; ++tt) acc[c][TL + tt] = mma(m[3 * c + 2], bh[tt], acc[c][TL + tt]);    // Hi  * hi
-                    if (!ONESET && first && !last) feed(3 * c + 1);
-                    if (ONESET && last) {   // over the operands just used for the last time
-                        feed(3 * c + 0);
-                        feed(3 * c + 1);
+                            for (int i = 0; i < NPL; ++i)
+                                if (p == (i + 1) * NPROD / NPL - 1) feed(NPL * c + i);
+                        }
                     }
-                    if (last) feed(3 * c + 2);
+                    if (ONESET && last) {   // over the operands just used for the last time
+#pragma unroll
+                        for (int i = 0; i < NPL; ++i) feed(NPL * c + i);
+                    }
                 }
             };
             group(std::integral_constant<int, 0>{}, std::integral_constant<int, T0>{}, true, T0 == NTT);
@@ -256,8 +335,9 @@ __device__ __forceinline__ void split_batch(const WideRolloutArgs& a, float* X, 
                 __syncthreads();
             }
         };
-        splitn(0, 0);
+        split_first();
         __syncthreads();
+        if (F16 && tid < 4 * ROWS) S = rscale[tid >> 2];
         int kb = 0;
         if constexpr (!ONESET) {
             // two register sets of model operands, a block's requested while the block before it runs; beside the last block: block 0 of the NEXT step
@@ -291,6 +371,11 @@ __device__ __forceinline__ void split_batch(const WideRolloutArgs& a, float* X, 
 #pragma unroll
             for (int tt = 0; tt < NTT; ++tt) {
                 f32x4 v = acc[c][tt];
+                if constexpr (F16) {   // the row's and the model's powers of two taken out again (exact)
+                    const float iv = rinv[16 * tt + j];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] *= iv;
+                }
                 if (KIND == 1) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = fast_tanh(v[k]);
@@ -309,7 +394,7 @@ __device__ __forceinline__ void split_batch(const WideRolloutArgs& a, float* X, 
         if (t + 1 < H) store_actions(t + 1);
         if (!ONESET && (KB & 1)) {
 #pragma unroll
-            for (int e = 0; e < NCT * 3; ++e) m0[e] = m1[e];
+            for (int e = 0; e < NCT * NPL; ++e) m0[e] = m1[e];
         }
         if (st && t == 5) st[6] = wall_clock64();
         if (st && t == 6) st[7] = wall_clock64();
@@ -334,10 +419,12 @@ __device__ __forceinline__ void split_batch(const WideRolloutArgs& a, float* X, 
 // FIVE: some workgroup's tile count leaves a remainder of five (one batch instead of 4 + 1).  Its own instantiation: the
 // five-tile batch's 60 accumulators set the register allocation of the whole kernel, and the four-tile batches of a launch
 // that never sees one were 14 % slower for carrying it.
-template <int NCT, int KIND, bool EXT, bool FIVE>
+template <int NCT, int KIND, bool EXT, bool FIVE, bool F16>
 __global__ __launch_bounds__(64 * SPLIT_WAVES) void rollout_wide_split_kernel(WideRolloutArgs a) {
+    constexpr int NPL = F16 ? 2 : 3;
     extern __shared__ __attribute__((aligned(16))) float X[];  // [16 * SPLIT_TT][XS] f32 rows, then the planes' buffers
     __shared__ CostArgs<float> cs_s;
+    __shared__ float rscale[F16 ? 16 * SPLIT_TT : 1], rinv[F16 ? 16 * SPLIT_TT : 1];   // fp16 planes: the rows' powers of two
     unsigned char* P = reinterpret_cast<unsigned char*>(X + (size_t)16 * SPLIT_TT * a.xs);   // SPLIT_PLANE_BYTES
     // (the workgroup's candidate-list scratch lies over the planes: used behind the last batch only)
     auto wg_keys = reinterpret_cast<unsigned long long(*)[SPLIT_WAVES][32]>(P);
@@ -347,13 +434,13 @@ __global__ __launch_bounds__(64 * SPLIT_WAVES) void rollout_wide_split_kernel(Wi
     if (EXT) wide_stage_terms(cs_s, a.cs, tid, 64 * SPLIT_WAVES);
     // this wave's share of the model: [kb][wave][ct][plane][lane] 16-byte vectors
     typedef const __attribute__((address_space(1))) u32x4* gvec;
-    gvec Mw = (gvec)a.Mp + (size_t)wave * NCT * 3 * 64 + lane;
-    const size_t kb_stride = (size_t)SPLIT_WAVES * NCT * 3 * 64;
+    gvec Mw = (gvec)a.Mp + (size_t)wave * NCT * NPL * 64 + lane;
+    const size_t kb_stride = (size_t)SPLIT_WAVES * NCT * NPL * 64;
     auto request1 = [&](int kb, int e) -> u32x4 { return Mw[(size_t)kb * kb_stride + (size_t)e * 64]; };
-    auto request = [&](u32x4 (&m)[NCT * 3], int kb) {
+    auto request = [&](u32x4 (&m)[NCT * NPL], int kb) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int e = 0; e < NCT * 3; ++e) m[e] = request1(kb, e);
+        for (int e = 0; e < NCT * NPL; ++e) m[e] = request1(kb, e);
         __builtin_amdgcn_sched_barrier(0);
     };
     // tiles of this workgroup: T tiles over the grid, the remainder one each to the first workgroups
@@ -363,7 +450,7 @@ __global__ __launch_bounds__(64 * SPLIT_WAVES) void rollout_wide_split_kernel(Wi
     int cnt = base + ((int)blockIdx.x < extra ? 1 : 0);
     unsigned long long run_key = KEY_SENTINEL;
     bool first = true;
-    u32x4 m0[NCT * 3], m1[NCT * 3];
+    u32x4 m0[NCT * NPL], m1[NCT * NPL];
     request(m0, 0);
     while (cnt > 0) {   // batches of four tiles; a remainder of five is one batch
         int ntt = cnt < SPLIT_TT - 1 ? cnt : SPLIT_TT - 1;
@@ -372,11 +459,11 @@ __global__ __launch_bounds__(64 * SPLIT_WAVES) void rollout_wide_split_kernel(Wi
         }
         if constexpr (FIVE) {
             if (ntt == SPLIT_TT)
-                split_batch<NCT, SPLIT_TT, KIND, EXT, true>(a, X, P, cs_s, t_begin * 16, ntt, tid, lane, wave, m0, m1, request1, run_key, first);
+                split_batch<NCT, SPLIT_TT, KIND, EXT, true, F16>(a, X, P, rscale, rinv, cs_s, t_begin * 16, ntt, tid, lane, wave, m0, m1, request1, run_key, first);
             else
-                split_batch<NCT, SPLIT_TT - 1, KIND, EXT, true>(a, X, P, cs_s, t_begin * 16, ntt, tid, lane, wave, m0, m1, request1, run_key, first);
+                split_batch<NCT, SPLIT_TT - 1, KIND, EXT, true, F16>(a, X, P, rscale, rinv, cs_s, t_begin * 16, ntt, tid, lane, wave, m0, m1, request1, run_key, first);
         } else {
-            split_batch<NCT, SPLIT_TT - 1, KIND, EXT, false>(a, X, P, cs_s, t_begin * 16, ntt, tid, lane, wave, m0, m1, request1, run_key, first);
+            split_batch<NCT, SPLIT_TT - 1, KIND, EXT, false, F16>(a, X, P, rscale, rinv, cs_s, t_begin * 16, ntt, tid, lane, wave, m0, m1, request1, run_key, first);
         }
         cnt -= ntt;
         t_begin += ntt;
@@ -416,23 +503,49 @@ int wide_split_lists(int n_rows) {
     return std::min(std::max(1, tiles / (SPLIT_TT - 1)), FAST_MAX_LISTS);
 }
 
-// Mb[kb][wave][ct][plane (lo, mid, hi)][lane][v] = plane of (float)M[32 kb + 8 (lane / 16) + v][16 (NCT wave + ct) + lane % 16],
-// M = [A ; B] ([o + d, o], zero padded)
-void pack_wide_model_split(int o, int d, const double* A, const double* B, std::vector<unsigned short>& Mb) {
+// Mb[kb][wave][ct][plane][lane][v] = plane of (float)M[32 kb + 8 (lane / 16) + v][16 (NCT wave + ct) + lane % 16],
+// M = [A ; B] ([o + d, o], zero padded).  planes = 3: bf16 lo, mid, hi.  planes = 2: fp16 lo, hi of M x 2^k, k such that the
+// largest entry stays below 2^15; *minv = 2^-k.
+void pack_wide_model_split(int o, int d, const double* A, const double* B, int planes, std::vector<unsigned short>& Mb, float* minv) {
     const int KB = wide_split_kb(o, d), NCT = wide_split_nct(o);
-    Mb.assign((size_t)KB * SPLIT_WAVES * NCT * 3 * 64 * 8, 0);
+    Mb.assign((size_t)KB * SPLIT_WAVES * NCT * planes * 64 * 8, 0);
     auto M = [&](int r, int c) -> double {
         if (c >= o) return 0.0;
         if (r < o) return A[(size_t)r * o + c];
         if (r < o + d) return B[(size_t)(r - o) * o + c];
         return 0.0;
     };
+    float SM = 1.f;
+    if (planes == 2) {
+        float mx = 0.f;
+        for (int r = 0; r < o + d; ++r)
+            for (int c = 0; c < o; ++c) {
+                const float m = std::fabs((float)M(r, c));
+                if (m > mx) mx = m;   // (a NaN / infinite entry: the scale of the finite ones, the entry stays what it is)
+            }
+        int e = 0;
+        if (mx > 0.f && std::isfinite(mx)) (void)std::frexp(mx, &e);   // mx = f x 2^e, f in [0.5, 1)
+        else e = 1;
+        SM = std::ldexp(1.f, 15 - e);
+        if (minv) *minv = std::ldexp(1.f, e - 15);
+    } else if (minv) {
+        *minv = 1.f;
+    }
     for (int kb = 0; kb < KB; ++kb)
         for (int w = 0; w < SPLIT_WAVES; ++w)
             for (int ct = 0; ct < NCT; ++ct)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int v = 0; v < 8; ++v) {
                         const float m = (float)M(32 * kb + 8 * (lane / 16) + v, 16 * (NCT * w + ct) + lane % 16);
+                        if (planes == 2) {
+                            const float ms = m * SM;
+                            const _Float16 hi = (_Float16)ms;
+                            const _Float16 lo = (_Float16)(ms - (float)hi);
+                            const size_t at = ((((size_t)kb * SPLIT_WAVES + w) * NCT + ct) * 2) * 64 * 8 + (size_t)lane * 8 + v;
+                            std::memcpy(&Mb[at], &lo, 2);
+                            std::memcpy(&Mb[at + 64 * 8], &hi, 2);
+                            continue;
+                        }
                         const unsigned short hi = bf16_rne(m);
                         const float r1 = m - bf16_f32(hi);
                         const unsigned short mid = bf16_rne(r1);
@@ -452,12 +565,14 @@ void launch_rollout_wide_split(const WideRolloutArgs& a, int kind, hipStream_t s
     // a batch of five: some workgroup holds 4 q + 1 tiles, q >= 1
     const int tiles = (a.n_rows + 15) / 16, base = tiles / grid, extra = tiles % grid;
     const bool five = (base >= SPLIT_TT && base % (SPLIT_TT - 1) == 1) || (extra > 0 && base + 1 >= SPLIT_TT && (base + 1) % (SPLIT_TT - 1) == 1);
-#define XW2(NV, KINDV, EXTV, FV)                                                                            \
+#define XW3(NV, KINDV, EXTV, FV, HV)                                                                        \
     {                                                                                                       \
-        auto kfn = rollout_wide_split_kernel<NV, KINDV, EXTV, FV>;                                          \
+        auto kfn = rollout_wide_split_kernel<NV, KINDV, EXTV, FV, HV>;                                      \
         (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * SPLIT_WAVES), lds, st, a);                            \
     }
+#define XW2(NV, KINDV, EXTV, FV) \
+    if (a.planes == 2) XW3(NV, KINDV, EXTV, FV, true) else XW3(NV, KINDV, EXTV, FV, false)
 #define XW1(NV, KINDV, EXTV) \
     if (five) XW2(NV, KINDV, EXTV, true) else XW2(NV, KINDV, EXTV, false)
 #define XW(NV)                                                     \
@@ -473,6 +588,7 @@ void launch_rollout_wide_split(const WideRolloutArgs& a, int kind, hipStream_t s
 #undef XW
 #undef XW1
 #undef XW2
+#undef XW3
 }
 
 }  // namespace icem

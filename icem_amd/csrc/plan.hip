@@ -32,11 +32,17 @@ int ensure_fast_model(icem_handle* h) {
         if (h->Mw_dev) (void)hipFree(h->Mw_dev);
         ICEM_HIP_TRY(hipMalloc(&h->Mw_dev, Mw.size() * sizeof(float)));
         ICEM_HIP_TRY(hipMemcpy(h->Mw_dev, Mw.data(), Mw.size() * sizeof(float), hipMemcpyHostToDevice));
-        std::vector<unsigned short> Mb;
-        pack_wide_model_split(h->obs_dim, h->cfg.act_dim, h->A_host.data(), h->B_host.data(), Mb);
-        if (h->Mws_dev) (void)hipFree(h->Mws_dev);
-        ICEM_HIP_TRY(hipMalloc(&h->Mws_dev, Mb.size() * sizeof(unsigned short)));
-        ICEM_HIP_TRY(hipMemcpy(h->Mws_dev, Mb.data(), Mb.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+        for (int planes = 2; planes <= 3; ++planes) {   // fp16 (hi, lo) x 2^k and bf16 (hi, mid, lo) planes: k_rollout_wide_split.hip
+            std::vector<unsigned short> Mb;
+            void*& dev = planes == 2 ? h->Mwh_dev : h->Mws_dev;
+            float minv = 1.f;
+            pack_wide_model_split(h->obs_dim, h->cfg.act_dim, h->A_host.data(), h->B_host.data(), planes, Mb, &minv);
+            if (planes == 2) h->Mwh_inv = minv;
+            if (dev) (void)hipFree(dev);
+            dev = nullptr;
+            ICEM_HIP_TRY(hipMalloc(&dev, Mb.size() * sizeof(unsigned short)));
+            ICEM_HIP_TRY(hipMemcpy(dev, Mb.data(), Mb.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+        }
         if (!h->wide) {   // a narrow model on the GEMM kernel: A_dev / B_dev keep the generic kernels' padded layout
             h->fast_model_ready = true;
             return ICEM_OK;
@@ -142,11 +148,11 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
     if (tail_out) *tail_out = 0;
     if (gemm_rollout(h)) {
         // narrow observations always take the exact-f32 kernel (two workgroup barriers per step buy nothing at o <= 32)
-        const bool exact = h->wide_exact || !h->wide;
+        const bool exact = h->wide_mode == 1 || !h->wide;
         // trailing shifted elites that would open a tile of their own: rolled out row by row (rollout_rows_wide_kernel),
         // scored by the merge through the cost array (tail_out rows; the caller's merge takes them as extra candidates)
         // (exact-f32 tile kernel only: the bf16-split kernel's workgroups take a fifth tile instead)
-        const bool split_tail = h->wide && h->wide_exact && tail_out && n_tail > 0 && n_tail <= 64 && n_cand == n_rows && (n_rows - n_tail) % 16 == 0 &&
+        const bool split_tail = h->wide && h->wide_mode == 1 && tail_out && n_tail > 0 && n_tail <= 64 && n_cand == n_rows && (n_rows - n_tail) % 16 == 0 &&
                                 n_rows - n_tail > 0 && h->cfg.dtype == ICEM_F32;
         if (split_tail) {
             n_rows -= n_tail;
@@ -170,7 +176,9 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
         w.flip_pen = (float)h->cost.flip_penalty;
         w.flip_th = (float)h->cost.flip_thresh;
         w.cs = h->has_terms ? (const CostArgs<float>*)h->wide_cs_dev : nullptr;
-        w.Mp = exact ? (const float*)h->Mw_dev : (const float*)h->Mws_dev;
+        w.planes = h->wide_mode == 2 ? 3 : 2;   // (split kernel) fp16 planes unless the bf16 ones were asked for
+        w.minv = w.planes == 2 ? h->Mwh_inv : 1.f;
+        w.Mp = exact ? (const float*)h->Mw_dev : (const float*)(w.planes == 2 ? h->Mwh_dev : h->Mws_dev);
         w.dbg = h->dbg;
         w.obs0 = (const float*)obs0;
         w.actions = (const float*)actions;

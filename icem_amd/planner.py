@@ -329,9 +329,10 @@ class IcemPlanner:
         L.check(self.lib.icem_reset_distribution(self._h, _ptr(mean), _ptr(std), _ptr(self.low), _ptr(self.high),
                                                  self._stream()))
 
-    def set_wide_exact(self, on: bool = True):
-        """obs_dim > 32: the model step on the exact-f32 matrix pipe (bitwise an fmaf chain) instead of the default 3-way bf16
-        split on the bf16 matrix cores (``icem_set_wide_exact``)."""
+    def set_wide_exact(self, on=True):
+        """obs_dim > 32: which arithmetic the model step's GEMM runs in (``icem_set_wide_exact``): ``False`` / 0 the default
+        two-way fp16 split on the fp16 matrix cores, ``True`` / 1 the exact-f32 matrix pipe (bitwise an fmaf chain), 2 the
+        three-way bf16 split."""
         L.check(self.lib.icem_set_wide_exact(self._h, int(on)))
 
     # ------------------------------------------------------------------ measurement

@@ -391,10 +391,12 @@ int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step,
 
 /* Wide observations (32 < obs_dim <= 384; HumanoidStandup's o = 378, environments/mujoco.py:241-277): which matrix-pipe
  * arithmetic the rollout's model step (the GEMM of abstract_models.py:31-53's predict at this width) runs in.
- * 0 (default): every f32 operand as the exact sum of three bf16 numbers, six bf16 products per multiply-add with f32
- * accumulation on v_mfma_f32_16x16x32_bf16 -- f32-class rounding (each product to 2^-24 of its magnitude), not the bits
- * of an f32 fmaf chain; 1: v_mfma_f32_16x16x4_f32, bitwise an fmaf chain, at a third of the speed.  Takes effect at the
- * next rollout; no effect at obs_dim <= 32. */
+ * 0 (default): every f32 operand x 2^k (k per trajectory row / per model, so that nothing exceeds 2^15) as the sum of two
+ * fp16 numbers, three fp16 products per multiply-add with f32 accumulation on v_mfma_f32_16x16x32_f16 -- f32-class
+ * rounding (operands to 2^-24 relative, the dropped lo x lo product below 2^-24 of a product), not the bits of an f32 fmaf
+ * chain; 2: the same with three bf16 numbers and six products (operands exact, dropped products below 2^-31), at two
+ * thirds of the speed; 1: v_mfma_f32_16x16x4_f32, bitwise an fmaf chain, at a quarter of the speed.  Takes effect at the
+ * next rollout; no effect at obs_dim <= 32.  Other values: ICEM_E_INVALID. */
 int icem_set_wide_exact(icem_handle* h, int32_t on);
 
 /* ---- per-kernel timing (measurement only) ------------------------------------------------- */

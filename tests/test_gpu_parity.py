@@ -1178,8 +1178,9 @@ def test_rollout_and_plan_with_cost_terms(env_name, dtype):
     np.testing.assert_allclose(np_(pl.mean), orc.mean, rtol=1e-9, atol=1e-11)
 
 
+@pytest.mark.parametrize("planes", [0, 2])   # icem_set_wide_exact: fp16 planes (default) / bf16 planes
 @pytest.mark.parametrize("n", [80, 257, 409, 640])
-def test_wide_split_is_the_same_every_launch(n):
+def test_wide_split_is_the_same_every_launch(n, planes):
     """rollout_wide_split_kernel at o = 376 with the Humanoid cost terms, the same launch 40 times with other kernels in
     between (they leave LDS and registers dirty): every launch returns the bits of the first, and every cost is the
     exact-f32 kernel's to 1e-4 or a whole health penalty away (a tanh one ulp off across a threshold).  The batch
@@ -1203,7 +1204,7 @@ def test_wide_split_is_the_same_every_launch(n):
     acts = torch.as_tensor(rs.uniform(-1, 1, (n, h, d)) * env.action_space.high, dtype=pl.dt, device=pl.device)
     pl.set_wide_exact(True)
     exact = np_(pl.rollout_cost(obs0, acts)).astype(np.float64)
-    pl.set_wide_exact(False)
+    pl.set_wide_exact(planes)
     first = pl.rollout_cost(obs0, acts).clone()
     junk = torch.empty(16 << 20, device=pl.device)
     for i in range(40):

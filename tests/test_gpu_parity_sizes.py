@@ -186,7 +186,7 @@ def _full_loop(N, iters, h, d, o, kind, beta, env_kind, seed, cost_mode):
         assert np.array_equal(np_(fused.actions[:n_last]), np_(split.actions[:n_last]))
 
 
-@pytest.mark.parametrize("exact", [False, True])
+@pytest.mark.parametrize("exact", [0, 1, 2])   # icem_set_wide_exact: fp16 planes (default) / exact f32 / bf16 planes
 @pytest.mark.parametrize("kind,mode", [(1, "sum"), (0, "best")])
 def test_wide_shifted_elite_rows_equal_the_tile_kernel_bit_for_bit(kind, mode, exact):
     """o = 378: the shifted elites of iteration 0 (icem.py:131-137) would open a tile of their own behind a population
@@ -282,7 +282,7 @@ def test_humanoid_standup_cost_at_real_observation_width():
 @pytest.mark.parametrize("o,d,h,kind,mode,n", [(378, 17, 30, 0, "sum", 300), (378, 17, 30, 1, "sum", 100), (100, 6, 12, 1, "best", 1000),
                                               (33, 4, 13, 0, "final", 77), (64, 6, 30, 1, "sum", 129), (384, 17, 30, 0, "sum", 40),
                                               (200, 3, 10, 1, "sum", 4097)])
-@pytest.mark.parametrize("exact", [False, True])
+@pytest.mark.parametrize("exact", [0, 1, 2])   # icem_set_wide_exact: fp16 planes (default) / exact f32 / bf16 planes
 def test_wide_observation_rollout_matches_oracle(o, d, h, kind, mode, n, exact):
     """The model step at observation widths 33..384 as a GEMM on the matrix cores -- rollout_wide_split_kernel (default:
     every f32 operand as three bf16 planes, six products per multiply-add; k_rollout_wide_split.hip) and
@@ -309,6 +309,42 @@ def test_wide_observation_rollout_matches_oracle(o, d, h, kind, mode, n, exact):
     assert bad.sum() <= (2 if flip_idx >= 0 else 0), (bad.sum(), np.abs(got - want).max())
     if bad.any():
         assert np.allclose(np.abs(got - want)[bad] % 10.0, 0.0, atol=1e-3) or np.allclose(np.abs(got - want)[bad] % 10.0, 10.0, atol=1e-3)
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("scale", [1e-30, 1e-6, 1.0, 7e4, 1e9])
+def test_wide_fp16_planes_follow_the_magnitudes(scale, kind):
+    """The fp16 planes of rollout_wide_split_kernel hold x 2^k with k chosen per trajectory row and per step from the row's
+    largest entry (and once for the model): observations far outside fp16's range (65 504) or far below its normal
+    numbers cost no accuracy -- the costs stay within 1e-5 of the float64 oracle's like the exact-f32 kernel's, for the
+    linear model (whose state keeps the observation's magnitude) and the tanh one, actions of ordinary size beside
+    observations 10^9 times larger included.  A NaN observation entry poisons every trajectory (they all start from it),
+    like the exact kernel; a model with a NaN weight likewise."""
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner
+    o, d, h, n = 200, 6, 10, 129
+    model = DeviceSyntheticModel.make(o, d, kind=kind)
+    lo, hi = -0.4 * np.ones(d), 0.4 * np.ones(d)
+    rs = np.random.RandomState(11)
+    obs = scale * rs.randn(o)
+    act = rs.uniform(-0.4, 0.4, (n, h, d)).astype(np.float32)
+    oc = O.CostSpec(0.1, 2, -1.0, -1, 0.0, 0.0)
+    want = O.rollout_costs(O.SyntheticModel(model.A, model.B, model.kind), oc, obs.astype(np.float32).astype(np.float64), act.astype(np.float64))
+    got = {}
+    for m in (0, 1):
+        pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=n, elites_size=2, opt_iters=1, dtype="f32"), lo, hi)
+        pl.set_wide_exact(m)
+        pl.set_model(model.kind, model.A, model.B)
+        pl.set_cost(0.1, 2, -1.0, -1, 0.0, 0.0)
+        got[m] = np_(pl.rollout_cost(obs, torch.as_tensor(act, device=pl.device))).astype(np.float64)
+        assert np.all(np.isfinite(got[m])), m
+        # the linear term reads one state entry: the bar is relative to the state's magnitude, not to a cancelling sum
+        tol = 1e-5 * np.abs(want) + 2e-5 * max(1.0, float(np.abs(obs).max()) if kind == 0 else 1.0)
+        assert np.all(np.abs(got[m] - want) <= tol), (m, np.abs(got[m] - want).max(), np.abs(want).max())
+    bad_obs = obs.copy()
+    bad_obs[5] = np.nan
+    assert np.all(np.isnan(np_(pl.rollout_cost(bad_obs, torch.as_tensor(act, device=pl.device)))))   # (exact kernel)
+    pl.set_wide_exact(0)
+    assert np.all(np.isnan(np_(pl.rollout_cost(bad_obs, torch.as_tensor(act, device=pl.device)))))
 
 
 @pytest.mark.soak

@@ -21,9 +21,9 @@ ALLOWED = [
     (r"iter_ahead_kernel<30, 6, 18, [01], [48], [012]>", 32,
      "o = 18 (HalfCheetah with x position): 4-26 spills, and the launch still wins -- 268.5 vs 299.9 us per MPC step at "
      "N = 65 536 with the tanh model, 181.9 vs 239.0 with the linear one (EXPERIMENTS R4.6)"),
-    (r"rollout_wide_split_kernel<3, [01], true, (true|false)>", 16,
-     "o = 378 on the bf16 matrix cores with icem_cost_terms: 4-11 spills at 256 registers, all in the batch prologue "
-     "(EXPERIMENTS R4.9)"),
+    (r"rollout_wide_split_kernel<3, [01], true, (true|false), false>", 16,
+     "o = 378 on the bf16 matrix cores (icem_set_wide_exact 2) with icem_cost_terms: 4-11 spills at 256 registers, all in "
+     "the batch prologue (EXPERIMENTS R4.9); the default fp16 form spills nothing"),
     (r"rollout_cost_kernel<double, 32, 1>", 56, "the generic float64 kernel at its widest observation: strict-parity path, not a throughput kernel"),
     (r"rssm_rollout_kernel<2>", 48, "the fused learned-dynamics kernel, populations above 65 536 only (the split launch serves the rest)"),
 ]

@@ -6,11 +6,14 @@ o, d = 378, 17
 h = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 model = DeviceSyntheticModel.make(o, d, kind=1)
 low, high = -0.4 * np.ones(d), 0.4 * np.ones(d)
+import os
+MODE = int(os.environ.get("WIDE_MODE", "0"))   # icem_set_wide_exact: 0 fp16 planes, 1 exact f32, 2 bf16 planes
+SCALE = float(os.environ.get("OBS_SCALE", "0.2"))
 for n in (64, 80, 96, 144):
     pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=max(n, 64), opt_iters=1, noise_beta=2.0, dtype="f32", seed=1), low, high)
-    pl.set_model(model.kind, model.A, model.B); pl.set_cost(0.1, 2, -1.0, -1, 0.0, 0.0); pl.reset()
+    pl.set_model(model.kind, model.A, model.B); pl.set_cost(0.1, 2, -1.0, -1, 0.0, 0.0); pl.set_wide_exact(MODE); pl.reset()
     rs = np.random.RandomState(3)
-    obs = 0.2 * rs.randn(o)
+    obs = SCALE * rs.randn(o)
     acts = rs.uniform(-0.4, 0.4, (n, h, d))
     got = pl.rollout_cost(obs, torch.as_tensor(acts, dtype=pl.dt, device="cuda")).cpu().numpy().astype(np.float64)
     om = O.SyntheticModel(model.A, model.B, model.kind)

@@ -11,12 +11,14 @@ from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner  # noqa: E402
 
 h, d, o = 30, 17, 378
 KIND = int(os.environ.get("WIDE_KIND", "1"))
+MODE = int(os.environ.get("WIDE_MODE", "0"))   # icem_set_wide_exact: 0 fp16 planes, 1 exact f32, 2 bf16 planes
 model = DeviceSyntheticModel.make(o, d, kind=KIND)
 low, high = -0.4 * np.ones(d), 0.4 * np.ones(d)
 for n in [int(a) for a in sys.argv[1:]] or (4096, 8192, 16384, 32768):
     pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=n, opt_iters=1, noise_beta=2.0, dtype="f32", seed=1), low, high)
     pl.set_model(model.kind, model.A, model.B)
     pl.set_cost(0.1, 2, -1.0, -1, 0.0, 0.0)
+    pl.set_wide_exact(MODE)
     pl.reset()
     obs = 0.1 * np.random.RandomState(0).randn(o)
     acts = (torch.rand(n, h, d, device="cuda") * 0.8 - 0.4).to(pl.dt)
