@@ -186,6 +186,7 @@ int icem_destroy(icem_handle* h) {
     if (h->Mw_dev) (void)hipFree(h->Mw_dev);
     if (h->Mws_dev) (void)hipFree(h->Mws_dev);
     if (h->Mwh_dev) (void)hipFree(h->Mwh_dev);
+    if (h->Mwh_ksc_dev) (void)hipFree(h->Mwh_ksc_dev);
     if (h->wide_cs_dev) (void)hipFree(h->wide_cs_dev);
     if (h->pub_dev) (void)hipFree(h->pub_dev);
     if (h->perm_dev) (void)hipFree(h->perm_dev);

@@ -101,6 +101,8 @@ struct icem_handle {
     void* Mws_dev = nullptr;     // ... as three bf16 planes (k_rollout_wide_split.hip) ...
     void* Mwh_dev = nullptr;     // ... and as two fp16 planes of the model x 2^k, Mwh_inv = 2^-k: the default wide rollout
     float Mwh_inv = 1.f;
+    void* Mwh_ksc_dev = nullptr; // ... and the contraction entries' and output columns' powers of two (the model equilibrated): [Mwh_nk | columns]
+    int Mwh_nk = 0;
     int wide_mode = 0;           // icem_set_wide_exact: 0 = fp16 planes (3 products per multiply-add), 1 = the exact-f32 matrix pipe
                                  // (k_rollout_wide.hip + its row kernel), 2 = bf16 planes (6 products)
     void* wide_cs_dev = nullptr; // CostArgs<float> (cost spec + terms) for k_rollout_wide, refreshed by the cost setters

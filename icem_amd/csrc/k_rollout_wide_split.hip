@@ -10,8 +10,16 @@
 //     65 504; found by four threads per row at the step's top), and one per model (pack_wide_model_split); both are taken
 //     out of the accumulators again at the write-back, exactly.  A product x m = hi Hi + hi Lo + lo Hi (+ lo Lo, dropped:
 //     below 2^-22 of hi Hi, i.e. 2^-24-class like the operands' own rounding), each of the three EXACT in the f32
-//     accumulator's format (22 significant bits), summed smallest first on v_mfma_f32_16x16x32_f16.  Entries more than 2^13
-//     below their row's largest have a subnormal lo: an absolute error below 2^-40 of that largest entry.  Measured against
+//     accumulator's format (22 significant bits), summed smallest first on v_mfma_f32_16x16x32_f16.  The model is carried
+//     EQUILIBRATED (pack_wide_model_split): row k as M[k][:] 2^-e_k with entry k as x_k 2^e_k, column j as M[:][j] 2^-f_j with
+//     the accumulators x 2^f_j at the write-back -- rows, then columns, peak in [0.5, 1): one sweep of a matrix balancing,
+//     exact (powers of two).  S therefore follows a row's largest CONTRIBUTION, and what fp16's subnormals cost -- an
+//     entry 2^-r of the largest keeps 2^-24 relative up to r = 13, beyond that an ABSOLUTE 2^-40 of the largest -- is
+//     relative to each output column's own scale: the same dynamics in other units (D^-1 A D: observation entries 10^6 apart
+//     with weights to match) come out as they went in (test_wide_split_planes_in_mixed_units), and an entry the model
+//     ignores takes no part.  What is left outside: contributions that differ by more than 2^13 inside a BALANCED model
+//     (one state entry of 10^6 feeding a column beside entries of 1 feeding others): there the small columns see 1e-6
+//     relative per step instead of 6e-8 -- the bf16 planes below (exact operands) are for such a model.  Measured against
 //     the float64 oracle over 30 tanh steps at o = 378: 1-4 x 10^-6 relative, the exact-f32 kernel's own distance
 //     (tools/dbg/split_tile_errors.py; tests: observations from 1e-30 to 1e9 in test_wide_fp16_planes_follow_the_magnitudes).
 //   * bf16, three planes, SIX products (icem_set_wide_exact 2; round 4's first form).  x = hi + mid + lo EXACTLY (3 x 8
@@ -59,6 +67,7 @@ namespace {
 
 constexpr int SPLIT_TT = 5;      // trajectory tiles per workgroup batch (regular batches take 4)
 constexpr int SPLIT_WAVES = 8;
+constexpr int SPLIT_KMAX = 416;   // contraction length (o + d, padded to 32) the fp16 form's per-entry scales have LDS for
 // the shared planes: two buffers of (up to) 3 planes x 64 rows x 32 x 16 bits for the regular batches (one of 80 rows for the five-tile batch fits inside)
 constexpr size_t SPLIT_PLANE_BYTES = (size_t)2 * 3 * 16 * (SPLIT_TT - 1) * 64;
 static_assert(SPLIT_PLANE_BYTES >= (size_t)3 * 16 * SPLIT_TT * 64 && SPLIT_PLANE_BYTES >= 2 * SPLIT_WAVES * 32 * sizeof(unsigned long long), "planes buffer");
@@ -105,8 +114,8 @@ __device__ __forceinline__ Planes split8(float4 p, float4 q) {
 // and carries an absolute error below 2^-40 of that largest entry otherwise.
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void split8h(float4 p, float4 q, float S, u32x4& hi, u32x4& lo) {
-    const float x[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
+__device__ __forceinline__ void split8h(float4 p, float4 q, float4 cp, float4 cq, float S, u32x4& hi, u32x4& lo) {
+    const float x[8] = {p.x * cp.x, p.y * cp.y, p.z * cp.z, p.w * cp.w, q.x * cq.x, q.y * cq.y, q.z * cq.z, q.w * cq.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const f32x2 v = {x[2 * i] * S, x[2 * i + 1] * S};
@@ -128,7 +137,8 @@ __device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
 // LDS rows hold and dropped -- no predicate inside the model loop) through all H steps.  m0 holds contraction block 0 of the
 // wave's share of the model on entry and on exit.
 template <int NCT, int NTT, int KIND, bool EXT, bool ONESET, bool F16, typename Req>
-__device__ __forceinline__ void split_batch(const WideRolloutArgs& a, float* X, unsigned char* P, float* rscale, float* rinv, const CostArgs<float>& cs_s,
+__device__ __forceinline__ void split_batch(const WideRolloutArgs& a, float* X, unsigned char* P, float* rscale, float* rinv, const float* ksc, const float* csc,
+                                            const CostArgs<float>& cs_s,
                                             int row0, int ntt, int tid, int lane, int wave, u32x4 (&m0)[NCT * (F16 ? 2 : 3)],
                                             u32x4 (&m1)[NCT * (F16 ? 2 : 3)], Req&& request1, unsigned long long& run_key, bool& first) {
     constexpr int NPL = F16 ? 2 : 3;   // planes per operand: fp16 (hi, lo) / bf16 (hi, mid, lo)
@@ -228,7 +238,9 @@ __device__ __forceinline__ void split_batch(const WideRolloutArgs& a, float* X, 
             unsigned char* q = P + ((size_t)(buf * NPL) * ROWS + r) * 64 + gg * 16;
             if constexpr (F16) {
                 u32x4 hi, lo;
-                split8h(*reinterpret_cast<const float4*>(xp), *reinterpret_cast<const float4*>(xp + 4), S, hi, lo);
+                const float* cp = ksc + 32 * kbn + 8 * gg;
+                split8h(*reinterpret_cast<const float4*>(xp), *reinterpret_cast<const float4*>(xp + 4), *reinterpret_cast<const float4*>(cp),
+                        *reinterpret_cast<const float4*>(cp + 4), S, hi, lo);
                 *reinterpret_cast<u32x4*>(q) = hi;
                 *reinterpret_cast<u32x4*>(q + (size_t)ROWS * 64) = lo;
             } else {
@@ -254,10 +266,13 @@ __device__ __forceinline__ void split_batch(const WideRolloutArgs& a, float* X, 
                 if (u < 4 * ROWS) {
                     const int r = u >> 2, gg = u & 3;
                     const float* xr = X + (size_t)r * XS + 4 * gg;
+                    const float* cr = ksc + 4 * gg;
                     float mx = 0.f;
                     for (int k = 0; k < 8 * KB; k += 4) {   // float4s gg, gg + 4, ..: the row's 32 KB entries, a quarter each
                         if (4 * (gg + k) < 32 * KB) {
-                            const float4 v = *reinterpret_cast<const float4*>(xr + 4 * k);
+                            float4 v = *reinterpret_cast<const float4*>(xr + 4 * k);
+                            const float4 c = *reinterpret_cast<const float4*>(cr + 4 * k);
+                            v.x *= c.x; v.y *= c.y; v.z *= c.z; v.w *= c.w;
                             mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(v.x)), __builtin_fmaxf(__builtin_fabsf(v.y), __builtin_fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w))));
                         }
                     }
@@ -371,10 +386,13 @@ __device__ __forceinline__ void split_batch(const WideRolloutArgs& a, float* X, 
 #pragma unroll
             for (int tt = 0; tt < NTT; ++tt) {
                 f32x4 v = acc[c][tt];
-                if constexpr (F16) {   // the row's and the model's powers of two taken out again (exact)
+                if constexpr (F16) {   // the row's, the model's and the column's powers of two taken out again (exact)
                     const float iv = rinv[16 * tt + j];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] *= iv;
+                    const float4 cs4 = *reinterpret_cast<const float4*>(csc + col);
+                    v[0] *= iv * cs4.x;
+                    v[1] *= iv * cs4.y;
+                    v[2] *= iv * cs4.z;
+                    v[3] *= iv * cs4.w;
                 }
                 if (KIND == 1) {
 #pragma unroll
@@ -425,6 +443,12 @@ __global__ __launch_bounds__(64 * SPLIT_WAVES) void rollout_wide_split_kernel(Wi
     extern __shared__ __attribute__((aligned(16))) float X[];  // [16 * SPLIT_TT][XS] f32 rows, then the planes' buffers
     __shared__ CostArgs<float> cs_s;
     __shared__ float rscale[F16 ? 16 * SPLIT_TT : 1], rinv[F16 ? 16 * SPLIT_TT : 1];   // fp16 planes: the rows' powers of two
+    __shared__ __attribute__((aligned(16))) float ksc_s[F16 ? SPLIT_KMAX : 4];       // ... the contraction entries' ...
+    __shared__ __attribute__((aligned(16))) float csc_s[F16 ? 16 * SPLIT_WAVES * NCT : 4];   // ... and the output columns' (pack_wide_model_split)
+    if (F16) {   // (split_batch opens with a barrier)
+        for (int e = threadIdx.x; e < 32 * a.kb; e += 64 * SPLIT_WAVES) ksc_s[e] = a.ksc[e];
+        for (int e = threadIdx.x; e < 16 * SPLIT_WAVES * NCT; e += 64 * SPLIT_WAVES) csc_s[e] = a.csc[e];
+    }
     unsigned char* P = reinterpret_cast<unsigned char*>(X + (size_t)16 * SPLIT_TT * a.xs);   // SPLIT_PLANE_BYTES
     // (the workgroup's candidate-list scratch lies over the planes: used behind the last batch only)
     auto wg_keys = reinterpret_cast<unsigned long long(*)[SPLIT_WAVES][32]>(P);
@@ -459,11 +483,11 @@ __global__ __launch_bounds__(64 * SPLIT_WAVES) void rollout_wide_split_kernel(Wi
         }
         if constexpr (FIVE) {
             if (ntt == SPLIT_TT)
-                split_batch<NCT, SPLIT_TT, KIND, EXT, true, F16>(a, X, P, rscale, rinv, cs_s, t_begin * 16, ntt, tid, lane, wave, m0, m1, request1, run_key, first);
+                split_batch<NCT, SPLIT_TT, KIND, EXT, true, F16>(a, X, P, rscale, rinv, ksc_s, csc_s, cs_s, t_begin * 16, ntt, tid, lane, wave, m0, m1, request1, run_key, first);
             else
-                split_batch<NCT, SPLIT_TT - 1, KIND, EXT, true, F16>(a, X, P, rscale, rinv, cs_s, t_begin * 16, ntt, tid, lane, wave, m0, m1, request1, run_key, first);
+                split_batch<NCT, SPLIT_TT - 1, KIND, EXT, true, F16>(a, X, P, rscale, rinv, ksc_s, csc_s, cs_s, t_begin * 16, ntt, tid, lane, wave, m0, m1, request1, run_key, first);
         } else {
-            split_batch<NCT, SPLIT_TT - 1, KIND, EXT, false, F16>(a, X, P, rscale, rinv, cs_s, t_begin * 16, ntt, tid, lane, wave, m0, m1, request1, run_key, first);
+            split_batch<NCT, SPLIT_TT - 1, KIND, EXT, false, F16>(a, X, P, rscale, rinv, ksc_s, csc_s, cs_s, t_begin * 16, ntt, tid, lane, wave, m0, m1, request1, run_key, first);
         }
         cnt -= ntt;
         t_begin += ntt;
@@ -495,6 +519,8 @@ __host__ float bf16_f32(unsigned short b) {
 
 int wide_split_kb(int o, int d) { return (o + d + 31) / 32; }
 int wide_split_xs(int o, int d) { return 32 * wide_split_kb(o, d) + 4; }
+// the workgroup's LDS: 80 rows of 32 kb + 4 floats, the planes' buffers and ~3 KB of static arrays in 160 KB: o + d <= 416
+bool wide_split_fits(int o, int d) { return (size_t)16 * SPLIT_TT * wide_split_xs(o, d) * sizeof(float) + SPLIT_PLANE_BYTES + 4608 <= 160 * 1024 && 32 * wide_split_kb(o, d) <= SPLIT_KMAX; }
 static int wide_split_nct(int o) { const int nt = (o + 15) / 16; return nt <= 8 ? 1 : nt <= 16 ? 2 : 3; }
 
 // workgroups (= candidate lists): whole batches of four tiles, at most FAST_MAX_LISTS
@@ -506,7 +532,8 @@ int wide_split_lists(int n_rows) {
 // Mb[kb][wave][ct][plane][lane][v] = plane of (float)M[32 kb + 8 (lane / 16) + v][16 (NCT wave + ct) + lane % 16],
 // M = [A ; B] ([o + d, o], zero padded).  planes = 3: bf16 lo, mid, hi.  planes = 2: fp16 lo, hi of M x 2^k, k such that the
 // largest entry stays below 2^15; *minv = 2^-k.
-void pack_wide_model_split(int o, int d, const double* A, const double* B, int planes, std::vector<unsigned short>& Mb, float* minv) {
+void pack_wide_model_split(int o, int d, const double* A, const double* B, int planes, std::vector<unsigned short>& Mb, float* minv,
+                           std::vector<float>* ksc, std::vector<float>* csc) {
     const int KB = wide_split_kb(o, d), NCT = wide_split_nct(o);
     Mb.assign((size_t)KB * SPLIT_WAVES * NCT * planes * 64 * 8, 0);
     auto M = [&](int r, int c) -> double {
@@ -516,12 +543,62 @@ void pack_wide_model_split(int o, int d, const double* A, const double* B, int p
         return 0.0;
     };
     float SM = 1.f;
+    // fp16 planes: contraction entry k (an observation / action entry) is carried as x_k 2^e_k and the model's row k as
+    // M[k][:] 2^-e_k, 2^e_k the power of two of the row's largest weight -- every row of the scaled model peaks in [0.5, 1),
+    // and the planes' per-trajectory scale follows the largest CONTRIBUTION x_k max|M[k][:]|, not the largest entry: an
+    // observation in mixed units (positions of 1, forces of 10^4 with weights of 10^-4) keeps its small entries' bits, and an
+    // entry the model ignores (a zero row: 2^e_k = 0) takes no part.  Exact: powers of two.
+    std::vector<int> ek((size_t)32 * KB, 0);
+    std::vector<char> dead((size_t)32 * KB, 1);
+    if (planes == 2) {
+        if (ksc) ksc->assign((size_t)32 * KB, 0.f);
+        for (int r = 0; r < o + d; ++r) {
+            float wmax = 0.f;
+            for (int c = 0; c < o; ++c) {
+                const float m = std::fabs((float)M(r, c));
+                if (std::isfinite(m) && m > wmax) wmax = m;   // (a NaN / infinite weight: the scale of the finite ones, the weight stays what it is)
+            }
+            bool any = false;
+            for (int c = 0; c < o; ++c) any = any || M(r, c) != 0.0;   // (NaN != 0: a row with a NaN weight is not dead)
+            if (!any) continue;
+            int e = 0;
+            if (wmax > 0.f) (void)std::frexp(wmax, &e);
+            e = e < -100 ? -100 : (e > 100 ? 100 : e);
+            ek[r] = e;
+            dead[r] = 0;
+            if (ksc) (*ksc)[r] = std::ldexp(1.f, e);
+        }
+    }
+    // ... and output column j as (sum) 2^f_j, 2^f_j the power of two of the column's largest (row-scaled) weight: the planes'
+    // absolute accuracy (2^-40 of the row's largest contribution) is then relative to every COLUMN's own scale.  Rows, then
+    // columns: the first sweep of a matrix balancing -- the same dynamics in other units (D^-1 A D) come out as A.
+    std::vector<int> fj((size_t)o, 0);
+    if (planes == 2) {
+        if (csc) csc->assign((size_t)16 * SPLIT_WAVES * NCT, 1.f);
+        for (int c = 0; c < o; ++c) {
+            float cmax = 0.f;
+            for (int r = 0; r < o + d; ++r) {
+                if (dead[r]) continue;
+                const float m = std::fabs(std::ldexp((float)M(r, c), -ek[r]));
+                if (std::isfinite(m) && m > cmax) cmax = m;
+            }
+            int f = 0;
+            if (cmax > 0.f) (void)std::frexp(cmax, &f);
+            f = f < -100 ? -100 : (f > 100 ? 100 : f);
+            fj[c] = f;
+            if (csc) (*csc)[c] = std::ldexp(1.f, f);
+        }
+    }
+    auto Ms = [&](int r, int c) -> float {   // the model as the fp16 planes see it
+        if (r >= o + d || c >= o || dead[r]) return 0.f;
+        return std::ldexp((float)M(r, c), -ek[r] - fj[c]);
+    };
     if (planes == 2) {
         float mx = 0.f;
         for (int r = 0; r < o + d; ++r)
             for (int c = 0; c < o; ++c) {
-                const float m = std::fabs((float)M(r, c));
-                if (m > mx) mx = m;   // (a NaN / infinite entry: the scale of the finite ones, the entry stays what it is)
+                const float m = std::fabs(Ms(r, c));
+                if (std::isfinite(m) && m > mx) mx = m;
             }
         int e = 0;
         if (mx > 0.f && std::isfinite(mx)) (void)std::frexp(mx, &e);   // mx = f x 2^e, f in [0.5, 1)
@@ -538,7 +615,7 @@ void pack_wide_model_split(int o, int d, const double* A, const double* B, int p
                     for (int v = 0; v < 8; ++v) {
                         const float m = (float)M(32 * kb + 8 * (lane / 16) + v, 16 * (NCT * w + ct) + lane % 16);
                         if (planes == 2) {
-                            const float ms = m * SM;
+                            const float ms = Ms(32 * kb + 8 * (lane / 16) + v, 16 * (NCT * w + ct) + lane % 16) * SM;
                             const _Float16 hi = (_Float16)ms;
                             const _Float16 lo = (_Float16)(ms - (float)hi);
                             const size_t at = ((((size_t)kb * SPLIT_WAVES + w) * NCT + ct) * 2) * 64 * 8 + (size_t)lane * 8 + v;

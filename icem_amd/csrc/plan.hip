@@ -36,8 +36,17 @@ int ensure_fast_model(icem_handle* h) {
             std::vector<unsigned short> Mb;
             void*& dev = planes == 2 ? h->Mwh_dev : h->Mws_dev;
             float minv = 1.f;
-            pack_wide_model_split(h->obs_dim, h->cfg.act_dim, h->A_host.data(), h->B_host.data(), planes, Mb, &minv);
-            if (planes == 2) h->Mwh_inv = minv;
+            std::vector<float> ksc, csc;
+            pack_wide_model_split(h->obs_dim, h->cfg.act_dim, h->A_host.data(), h->B_host.data(), planes, Mb, &minv, &ksc, &csc);
+            if (planes == 2) {   // the scales of the equilibrated model: [ksc | csc] in one allocation
+                h->Mwh_inv = minv;
+                h->Mwh_nk = (int)ksc.size();
+                ksc.insert(ksc.end(), csc.begin(), csc.end());
+                if (h->Mwh_ksc_dev) (void)hipFree(h->Mwh_ksc_dev);
+                h->Mwh_ksc_dev = nullptr;
+                ICEM_HIP_TRY(hipMalloc(&h->Mwh_ksc_dev, ksc.size() * sizeof(float)));
+                ICEM_HIP_TRY(hipMemcpy(h->Mwh_ksc_dev, ksc.data(), ksc.size() * sizeof(float), hipMemcpyHostToDevice));
+            }
             if (dev) (void)hipFree(dev);
             dev = nullptr;
             ICEM_HIP_TRY(hipMalloc(&dev, Mb.size() * sizeof(unsigned short)));
@@ -148,11 +157,11 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
     if (tail_out) *tail_out = 0;
     if (gemm_rollout(h)) {
         // narrow observations always take the exact-f32 kernel (two workgroup barriers per step buy nothing at o <= 32)
-        const bool exact = h->wide_mode == 1 || !h->wide;
+        const bool exact = h->wide_mode == 1 || !h->wide || !wide_split_fits(h->obs_dim, h->cfg.act_dim);
         // trailing shifted elites that would open a tile of their own: rolled out row by row (rollout_rows_wide_kernel),
         // scored by the merge through the cost array (tail_out rows; the caller's merge takes them as extra candidates)
         // (exact-f32 tile kernel only: the bf16-split kernel's workgroups take a fifth tile instead)
-        const bool split_tail = h->wide && h->wide_mode == 1 && tail_out && n_tail > 0 && n_tail <= 64 && n_cand == n_rows && (n_rows - n_tail) % 16 == 0 &&
+        const bool split_tail = h->wide && exact && tail_out && n_tail > 0 && n_tail <= 64 && n_cand == n_rows && (n_rows - n_tail) % 16 == 0 &&
                                 n_rows - n_tail > 0 && h->cfg.dtype == ICEM_F32;
         if (split_tail) {
             n_rows -= n_tail;
@@ -178,6 +187,8 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
         w.cs = h->has_terms ? (const CostArgs<float>*)h->wide_cs_dev : nullptr;
         w.planes = h->wide_mode == 2 ? 3 : 2;   // (split kernel) fp16 planes unless the bf16 ones were asked for
         w.minv = w.planes == 2 ? h->Mwh_inv : 1.f;
+        w.ksc = (const float*)h->Mwh_ksc_dev;
+        w.csc = w.ksc ? w.ksc + h->Mwh_nk : nullptr;
         w.Mp = exact ? (const float*)h->Mw_dev : (const float*)(w.planes == 2 ? h->Mwh_dev : h->Mws_dev);
         w.dbg = h->dbg;
         w.obs0 = (const float*)obs0;

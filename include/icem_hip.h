@@ -394,8 +394,10 @@ int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step,
  * 0 (default): every f32 operand x 2^k (k per trajectory row / per model, so that nothing exceeds 2^15) as the sum of two
  * fp16 numbers, three fp16 products per multiply-add with f32 accumulation on v_mfma_f32_16x16x32_f16 -- f32-class
  * rounding (operands to 2^-24 relative, the dropped lo x lo product below 2^-24 of a product), not the bits of an f32 fmaf
- * chain; 2: the same with three bf16 numbers and six products (operands exact, dropped products below 2^-31), at two
- * thirds of the speed; 1: v_mfma_f32_16x16x4_f32, bitwise an fmaf chain, at a quarter of the speed.  Takes effect at the
+ * chain.  (The model is carried equilibrated -- rows and columns scaled by powers of two -- so observations in mixed units
+ * keep their accuracy; contributions more than 2^13 apart inside the balanced model keep an absolute, not a relative,
+ * accuracy: 2^-40 of a row's largest.  A model like that should use 2.)  2: the same with three bf16 numbers and six products (operands exact whatever their
+ * magnitudes, dropped products below 2^-31), at two thirds of the speed; 1: v_mfma_f32_16x16x4_f32, bitwise an fmaf chain, at a quarter of the speed.  Takes effect at the
  * next rollout; no effect at obs_dim <= 32.  Other values: ICEM_E_INVALID. */
 int icem_set_wide_exact(icem_handle* h, int32_t on);
 

@@ -347,6 +347,39 @@ def test_wide_fp16_planes_follow_the_magnitudes(scale, kind):
     assert np.all(np.isnan(np_(pl.rollout_cost(bad_obs, torch.as_tensor(act, device=pl.device)))))
 
 
+@pytest.mark.parametrize("mode", [0, 2])   # fp16 planes / bf16 planes
+def test_wide_split_planes_in_mixed_units(mode):
+    """The same linear dynamics in other units: x' = x D with D = diag(10^-4 .. 10^6) turns (A, B) into (D^-1 A D, B D) --
+    observation entries a million times larger than their neighbours, multiplied by weights a million times smaller.  The
+    fp16 planes carry entry k as x_k 2^e_k and the model's row k as M[k][:] 2^-e_k (pack_wide_model_split: the rows
+    equilibrated), so a trajectory row's scale follows its largest CONTRIBUTION and the small entries keep their bits: costs
+    within 1e-5 of the float64 oracle on the transformed problem, like the bf16 planes (exact operands) and the exact-f32
+    kernel.  Three observation entries the model ignores (zero rows of A) hold 1e9: they take no part."""
+    from icem_amd import IcemConfig, IcemPlanner, DeviceSyntheticModel
+    o, d, h, n = 120, 5, 12, 96
+    base = DeviceSyntheticModel.make(o, d, kind=0)
+    rs = np.random.RandomState(5)
+    D = 10.0 ** rs.uniform(-4, 6, o)
+    D[2] = 1.0   # (the cost's linear term reads entry 2: keep its unit)
+    A = np.asarray(base.A, np.float64).reshape(o, o) / D[:, None] * D[None, :]
+    B = np.asarray(base.B, np.float64).reshape(d, o) * D[None, :]
+    ignored = [7, 50, 99]
+    A[ignored, :] = 0.0
+    obs = 0.3 * rs.randn(o) * D
+    obs[ignored] = 1e9
+    act = rs.uniform(-0.4, 0.4, (n, h, d)).astype(np.float32)
+    oc = O.CostSpec(0.1, 2, -1.0, -1, 0.0, 0.0)
+    want = O.rollout_costs(O.SyntheticModel(A, B, 0), oc, obs.astype(np.float32).astype(np.float64), act.astype(np.float64))
+    lo, hi = -0.4 * np.ones(d), 0.4 * np.ones(d)
+    pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=n, elites_size=2, opt_iters=1, dtype="f32"), lo, hi)
+    pl.set_wide_exact(mode)
+    pl.set_model(0, A, B)
+    pl.set_cost(0.1, 2, -1.0, -1, 0.0, 0.0)
+    got = np_(pl.rollout_cost(obs, torch.as_tensor(act, device=pl.device))).astype(np.float64)
+    assert np.all(np.isfinite(got))
+    assert np.all(np.abs(got - want) <= 1e-5 * np.abs(want) + 2e-5), (np.abs(got - want).max(), np.abs(want).max())
+
+
 @pytest.mark.soak
 @pytest.mark.parametrize("N", [4096, 16384])
 def test_soak_elite_sets_against_float64_oracle(N):
