@@ -103,6 +103,7 @@ struct icem_handle {
     float Mwh_inv = 1.f;
     void* Mwh_ksc_dev = nullptr; // ... and the contraction entries' and output columns' powers of two (the model equilibrated): [Mwh_nk | columns]
     int Mwh_nk = 0;
+    float Mwh_sbound = 0.f;
     int wide_mode = 0;           // icem_set_wide_exact: 0 = fp16 planes (3 products per multiply-add), 1 = the exact-f32 matrix pipe
                                  // (k_rollout_wide.hip + its row kernel), 2 = bf16 planes (6 products)
     void* wide_cs_dev = nullptr; // CostArgs<float> (cost spec + terms) for k_rollout_wide, refreshed by the cost setters

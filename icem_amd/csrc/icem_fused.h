@@ -92,6 +92,7 @@ struct WideRolloutArgs {
     float minv;           // ... fp16 planes: 1 / the model's power-of-two scale (pack_wide_model_split)
     const float* ksc;     // ... the contraction entries' powers of two, [32 kb] (device memory)
     const float* csc;     // ... and the output columns', [16 x 8 x NCT]
+    float sbound;         // ... the largest scaled state entry of a tanh model (max over the observation entries of their power of two)
     int cost_mode;
     int lin_idx, flip_idx;
     float ctrl_w, lin_w, flip_pen, flip_th;
@@ -119,7 +120,7 @@ int wide_split_xs(int o, int d);
 int wide_split_lists(int n_rows);
 bool wide_split_fits(int o, int d);   // the workgroup's rows + planes in 160 KB of LDS (o + d <= 416); else the exact-f32 kernel
 void pack_wide_model_split(int o, int d, const double* A, const double* B, int planes, std::vector<unsigned short>& Mb, float* minv,
-                           std::vector<float>* ksc, std::vector<float>* csc);
+                           std::vector<float>* ksc, std::vector<float>* csc, float* sbound);
 void launch_rollout_wide_split(const WideRolloutArgs& a, int kind, hipStream_t st);
 // rows [row0, row0 + n_tail) of the same pool one workgroup each, from the row-major f32 model (A [o, o], B [d, o]); costs only
 void launch_rollout_rows_wide(const WideRolloutArgs& a, int row0, int n_tail, const float* A, const float* B, int kind,

@@ -250,15 +250,40 @@ __device__ __forceinline__ void split_batch(const WideRolloutArgs& a, float* X, 
                 *reinterpret_cast<u32x4*>(q + (size_t)2 * ROWS * 64) = b.lo;
             }
         };
+        // blocks 1 .. : bf16 planes by the first 4 x ROWS threads, 8 entries each; fp16 planes by ALL threads, 4 entries each
+        // (EIGHT per row) -- with the entries' scales to read and apply, four waves splitting for eight made the block's
+        // critical path: their MFMAs began when their SIMD partners' had ended (k-loop 13.3 -> 15.3 us per step)
+        float S8[F16 ? (NTT < SPLIT_TT ? 1 : 2) : 1] = {};   // the power of two of this thread's row (rows: one per 512 threads' pass)
         auto splitn = [&](int kbn, int buf) {
-            if (tid < 4 * ROWS) split_row(tid >> 2, tid & 3, kbn, buf);
+            if constexpr (!F16) {
+                if (tid < 4 * ROWS) split_row(tid >> 2, tid & 3, kbn, buf);
+            } else {
+#pragma unroll
+                for (int ps = 0; ps < (NTT < SPLIT_TT ? 1 : 2); ++ps) {
+                    const int u = tid + 64 * SPLIT_WAVES * ps;
+                    if (u < 8 * ROWS) {
+                        const int r = u >> 3, g8 = u & 7;
+                        const float4 x4 = *reinterpret_cast<const float4*>(X + (size_t)r * XS + 32 * kbn + 4 * g8);
+                        const float4 c4 = *reinterpret_cast<const float4*>(ksc + 32 * kbn + 4 * g8);
+                        const float sc = S8[ps];
+                        const f32x2 v0 = {x4.x * c4.x * sc, x4.y * c4.y * sc}, v1 = {x4.z * c4.z * sc, x4.w * c4.w * sc};
+                        const f16x2 h0 = __builtin_convertvector(v0, f16x2), h1 = __builtin_convertvector(v1, f16x2);
+                        const f32x2 b0 = __builtin_convertvector(h0, f32x2), b1 = __builtin_convertvector(h1, f32x2);
+                        const f16x2 l0 = __builtin_convertvector(f32x2{v0[0] - b0[0], v0[1] - b0[1]}, f16x2);
+                        const f16x2 l1 = __builtin_convertvector(f32x2{v1[0] - b1[0], v1[1] - b1[1]}, f16x2);
+                        unsigned char* q = P + ((size_t)(buf * NPL) * ROWS + r) * 64 + g8 * 8;
+                        *reinterpret_cast<uint2*>(q) = uint2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
+                        *reinterpret_cast<uint2*>(q + (size_t)ROWS * 64) = uint2{__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1)};
+                    }
+                }
+            }
         };
         // Block 0 of a step.  bf16 planes: like every block.  fp16 planes: by the threads four waves on (the waves that
         // score nothing at the step's top), which first find the row's scale -- four threads per row scan it, S = 2^(141 - e)
         // for a largest entry 1.m x 2^(e - 127), so |x| S < 2^15 (fp16 holds 65 504), exact powers of two throughout;
         // 1 / (S x the model's scale) waits in rinv[] for the write-back.  A NaN entry does not move the maximum and poisons
         // its own trajectory only (one B-operand row = one output column); an infinite one makes S 2^-114 and stays infinite.
-        auto split_first = [&]() {
+        auto split_first = [&](int t) {
             if constexpr (!F16) {
                 splitn(0, 0);
             } else {
@@ -267,8 +292,11 @@ __device__ __forceinline__ void split_batch(const WideRolloutArgs& a, float* X, 
                     const int r = u >> 2, gg = u & 3;
                     const float* xr = X + (size_t)r * XS + 4 * gg;
                     const float* cr = ksc + 4 * gg;
-                    float mx = 0.f;
-                    for (int k = 0; k < 8 * KB; k += 4) {   // float4s gg, gg + 4, ..: the row's 32 KB entries, a quarter each
+                    // (tanh model, t > 0: the state entries are below 1 -- their scaled bound a.sbound stands in for them, only
+                    //  the actions behind them are scanned: an upper bound of the largest contribution is all S needs)
+                    const bool bounded = KIND == 1 && t > 0;
+                    float mx = bounded ? a.sbound : 0.f;
+                    for (int k = bounded ? ((o / 4) & ~3) : 0; k < 8 * KB; k += 4) {   // float4s gg, gg + 4, ..: the row's 32 KB entries, a quarter each
                         if (4 * (gg + k) < 32 * KB) {
                             float4 v = *reinterpret_cast<const float4*>(xr + 4 * k);
                             const float4 c = *reinterpret_cast<const float4*>(cr + 4 * k);
@@ -350,9 +378,13 @@ __device__ __forceinline__ void split_batch(const WideRolloutArgs& a, float* X, 
                 __syncthreads();
             }
         };
-        split_first();
+        split_first(t);
         __syncthreads();
-        if (F16 && tid < 4 * ROWS) S = rscale[tid >> 2];
+        if constexpr (F16) {
+#pragma unroll
+            for (int ps = 0; ps < (NTT < SPLIT_TT ? 1 : 2); ++ps)
+                if (tid + 64 * SPLIT_WAVES * ps < 8 * ROWS) S8[ps] = rscale[(tid + 64 * SPLIT_WAVES * ps) >> 3];
+        }
         int kb = 0;
         if constexpr (!ONESET) {
             // two register sets of model operands, a block's requested while the block before it runs; beside the last block: block 0 of the NEXT step
@@ -533,7 +565,7 @@ int wide_split_lists(int n_rows) {
 // M = [A ; B] ([o + d, o], zero padded).  planes = 3: bf16 lo, mid, hi.  planes = 2: fp16 lo, hi of M x 2^k, k such that the
 // largest entry stays below 2^15; *minv = 2^-k.
 void pack_wide_model_split(int o, int d, const double* A, const double* B, int planes, std::vector<unsigned short>& Mb, float* minv,
-                           std::vector<float>* ksc, std::vector<float>* csc) {
+                           std::vector<float>* ksc, std::vector<float>* csc, float* sbound) {
     const int KB = wide_split_kb(o, d), NCT = wide_split_nct(o);
     Mb.assign((size_t)KB * SPLIT_WAVES * NCT * planes * 64 * 8, 0);
     auto M = [&](int r, int c) -> double {
@@ -568,6 +600,12 @@ void pack_wide_model_split(int o, int d, const double* A, const double* B, int p
             dead[r] = 0;
             if (ksc) (*ksc)[r] = std::ldexp(1.f, e);
         }
+    }
+    if (sbound) {   // the largest scaled state entry a tanh model can hand on: max over the observation entries of 2^e_k x 1
+        *sbound = 0.f;
+        if (planes == 2)
+            for (int r = 0; r < o; ++r)
+                if (!dead[r]) *sbound = std::max(*sbound, std::ldexp(1.f, ek[r]));
     }
     // ... and output column j as (sum) 2^f_j, 2^f_j the power of two of the column's largest (row-scaled) weight: the planes'
     // absolute accuracy (2^-40 of the row's largest contribution) is then relative to every COLUMN's own scale.  Rows, then

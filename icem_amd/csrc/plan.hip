@@ -37,9 +37,11 @@ int ensure_fast_model(icem_handle* h) {
             void*& dev = planes == 2 ? h->Mwh_dev : h->Mws_dev;
             float minv = 1.f;
             std::vector<float> ksc, csc;
-            pack_wide_model_split(h->obs_dim, h->cfg.act_dim, h->A_host.data(), h->B_host.data(), planes, Mb, &minv, &ksc, &csc);
+            float sb = 0.f;
+            pack_wide_model_split(h->obs_dim, h->cfg.act_dim, h->A_host.data(), h->B_host.data(), planes, Mb, &minv, &ksc, &csc, &sb);
             if (planes == 2) {   // the scales of the equilibrated model: [ksc | csc] in one allocation
                 h->Mwh_inv = minv;
+                h->Mwh_sbound = sb;
                 h->Mwh_nk = (int)ksc.size();
                 ksc.insert(ksc.end(), csc.begin(), csc.end());
                 if (h->Mwh_ksc_dev) (void)hipFree(h->Mwh_ksc_dev);
@@ -189,6 +191,7 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
         w.minv = w.planes == 2 ? h->Mwh_inv : 1.f;
         w.ksc = (const float*)h->Mwh_ksc_dev;
         w.csc = w.ksc ? w.ksc + h->Mwh_nk : nullptr;
+        w.sbound = h->Mwh_sbound;
         w.Mp = exact ? (const float*)h->Mw_dev : (const float*)(w.planes == 2 ? h->Mwh_dev : h->Mws_dev);
         w.dbg = h->dbg;
         w.obs0 = (const float*)obs0;
