@@ -32,6 +32,79 @@ constexpr int ITEM = 16 * SR;        // elements
 constexpr int XS = SR + 8;           // its row stride in the reward head's LDS (conflict-free operand reads)
 // two tiles per recurrence workgroup: resident chunks / ring slots of the two wave classes (accumulators take twice the room)
 constexpr int RES_A2 = 2, RING_A2 = 3, RES_B2 = 3, RING_B2 = 2;
+constexpr int LDS_CHUNKS = 10;       // chunks parked in LDS (one tile per workgroup): two per class-A wave
+// Where each of a wave's chunks lives, in the order the wave consumes them every step (recurrence_steps):
+//   REG  in registers for the whole rollout;  LDS  in ProducerLds::wl for the whole rollout;
+//   STR  streamed: the streamed chunks rotate through a ring of RING register slots, the i-th one's slot refilled with
+//        the (i + RING)-th right behind its MFMAs.
+// Every ring slot is refilled (streamed chunks / RING) times per step and a refill is one loaded L2 round trip (1.2 us with
+// 70 KB in flight per CU, 1.7 with 105), so a step cannot be shorter than that many round trips: WHERE the streamed
+// chunks sit in the order matters as much as how many they are.  With all of them in phase 2 that phase was two exposed
+// round trips long (3.7 us of a 5.3 us step); spread two by two between the resident ones, over all four phases, a
+// request is a quarter of a step ahead of its use (EXPERIMENTS R4.11: six placements measured).
+enum { REG = 0, STR = 1, LDS = 2 };
+#ifndef ICEM_RSSM_PLAN
+#define ICEM_RSSM_PLAN 0   // (development: other placements, measured in EXPERIMENTS R4.11)
+#endif
+// element offset of chunk c of the class-A wave that owns GRU / W4 blocks ob0 and ob1 (the order the wave consumes them in)
+__host__ __device__ constexpr size_t class_a_chunk(int c, int ob0, int ob1) {
+    return c < 3 ? WGH + (size_t)(c * DETB + ob0) * DETK * BLK
+         : c < 6 ? WGH + (size_t)((c - 3) * DETB + ob1) * DETK * BLK
+         : c < 9 ? WGI + (size_t)((c - 6) * DETB + ob0) * HIDK * BLK
+         : c < 12 ? WGI + (size_t)((c - 9) * DETB + ob1) * HIDK * BLK
+         : W4 + (size_t)(c == 12 ? ob0 : ob1) * DETK * BLK;
+}
+template <bool CLASS_A, int TT>
+struct ChunkPlan {
+    static constexpr int NCH = CLASS_A ? 14 : 7;
+    static constexpr int RING = TT == 1 ? (CLASS_A ? (ICEM_RSSM_PLAN >= 1 && ICEM_RSSM_PLAN <= 3 ? 3 : 2) : 0) : (CLASS_A ? RING_A2 : RING_B2);
+    static constexpr int kind(int c) {
+        if (TT == 1) {
+            if (!CLASS_A) return REG;
+            // H(w) r u n | H(w+8) r u n | I(w) r u n | I(w+8) r u n | W4(w) W4(w+8)   (class_a_chunk)
+#if ICEM_RSSM_PLAN == 1     // three ring slots, the two LDS chunks where the first form stalled
+            return c == 4 || c == 7 ? LDS : c == 2 || c == 5 || c == 8 ? REG : STR;
+#elif ICEM_RSSM_PLAN == 2   // three ring slots, every gate's n chunk resident
+            return c == 11 || c == 13 ? LDS : c == 2 || c == 5 || c == 8 ? REG : STR;
+#elif ICEM_RSSM_PLAN == 3
+            return c == 4 || c == 10 ? LDS : c == 2 || c == 7 || c == 12 ? REG : STR;
+#elif ICEM_RSSM_PLAN == 4   // two ring slots, the streamed pairs a quarter of a step apart
+            return c == 8 || c == 11 ? LDS : c == 2 || c == 3 || c == 6 || c == 7 ? REG : STR;
+#elif ICEM_RSSM_PLAN == 5
+            return c == 10 || c == 11 ? LDS : c == 2 || c == 3 || c == 6 || c == 7 ? REG : STR;
+#else                       // two ring slots: four chunks in registers, eight streamed
+            return c == 11 || c == 13 ? LDS : c == 2 || c == 5 || c == 8 || c == 12 ? REG : STR;
+#endif
+        }
+        return c < (CLASS_A ? RES_A2 : RES_B2) ? REG : STR;
+    }
+    static constexpr int count(int k, int upto) {
+        int n = 0;
+        for (int c = 0; c < upto; ++c) n += kind(c) == k;
+        return n;
+    }
+    static constexpr int RES = count(REG, NCH), NSTR = count(STR, NCH);
+    static_assert(count(LDS, NCH) == (TT == 1 && CLASS_A ? 2 : 0), "two LDS chunks per class-A wave (ProducerLds::wl)");
+    static_assert(RING == 0 ? NSTR == 0 : NSTR % RING == 0, "a chunk's slot must not depend on the step");
+    static constexpr int nth_streamed(int i) {
+        for (int c = 0, n = 0; c < NCH; ++c)
+            if (kind(c) == STR && n++ == i) return c;
+        return -1;
+    }
+    struct Tab { int kind[NCH], slot[NCH], next[NCH], first[RING ? RING : 1], lds[2]; };
+    static constexpr Tab make() {
+        Tab t{};
+        for (int c = 0; c < NCH; ++c) {
+            t.kind[c] = kind(c);
+            t.slot[c] = kind(c) == REG ? count(REG, c) : kind(c) == STR ? RES + count(STR, c) % (RING ? RING : 1) : count(LDS, c);
+            if (kind(c) == LDS) t.lds[count(LDS, c)] = c;
+            t.next[c] = kind(c) == STR ? nth_streamed((count(STR, c) + RING) % (NSTR ? NSTR : 1)) : -1;
+        }
+        for (int i = 0; i < RING; ++i) t.first[i] = nth_streamed(i);
+        return t;
+    }
+    static constexpr Tab tab = make();
+};
 constexpr unsigned MAX_POLLS = 1u << 22;   // x s_sleep(2): a few hundred ms, then the reward workgroup gives up (costs = NaN)
 
 template <int TT>
@@ -44,6 +117,9 @@ struct ProducerLds {                       // TT tiles of 16 trajectories: rows 
     unsigned short w1[HIDB * K1K * BLK];   // A-operand blocks that stay here: W1 and W5
     unsigned short w5[STB * HIDK * BLK];
     float ob[232];                         // obs0, parked once
+    // One tile per workgroup leaves 73 KB of the CU's LDS free: two chunks of every class-A wave (ChunkPlan: the n gate's
+    // input side and W4, both of block w + 8) stay here for the whole rollout -- 70 KB less to stream every model step.
+    unsigned short wl[TT == 1 ? LDS_CHUNKS * DETK * BLK : 8];
 };
 struct ConsumerLds {
     unsigned short x[2][16 * XS];          // the state at hand (ping-pong)
@@ -90,12 +166,12 @@ __device__ __forceinline__ void publish(const ProducerLds<TT>& s, int cur, unsig
 
 // The model steps of the recurrence for one CLASS of waves.  The 0.65 MB of weights a step reads are cut into CHUNKS
 // (one output block of one matrix: 7 A-operand blocks = 28 registers per lane, 7 KB per wave) and every chunk has an owner:
-//   class A, waves 0..4:  the GRU's output blocks w and w + 8, W4's blocks w and w + 8
-//                         14 chunks: H(w) r u n, I(w) r u n, H(w+8) r u n, I(w+8) r u n, W4(w), W4(w+8)
+//   class A, waves 0..4:  the GRU's output blocks w and w + 8, W4's blocks w and w + 8                  14 chunks
 //   class B, waves 5..7:  the GRU's block w, W4's block w          7 chunks: H(w) r u n, I(w) r u n, W4(w)
-// (H = hidden side, needs h_t only: phase 1; I = input side, needs x: phase 2; W4: phase 3).  W1 and W5 live in LDS.
-// A wave consumes its chunks in that order, every step.  The first RES of them stay in registers for the whole rollout;
-// the others go through a ring of RING register slots, chunk c + RING requested right behind the MFMAs of chunk c.
+// (H = hidden side, needs h_t only; I = input side, needs x: phase 2; W4: phase 3).  W1 and W5 live in LDS.
+// A wave consumes its chunks in a fixed order every step; ChunkPlan says where each one lives: in registers for the
+// whole rollout, in LDS for the whole rollout (one tile per workgroup: 70 KB of the CU's LDS are free), or streamed
+// through a ring of RING register slots, a slot's next chunk requested right behind the MFMAs of the one it held.
 // The two classes are two instances of this function behind one wave-uniform branch: inside each the code is
 // straight-line, so the compiler's in-order vmcnt bookkeeping is exact (a wave only ever waits for the chunk it is
 // about to use), and nobody issues a load it does not need (a "dummy" broadcast load costs the L1 more than a real
@@ -105,89 +181,129 @@ __device__ __forceinline__ void recurrence_steps(ProducerLds<TT>& s, int w, int 
                                                  const unsigned short* __restrict__ Pg, const float* __restrict__ actions,
                                                  unsigned short* items, size_t tile_stride, unsigned* flag, int ntl,
                                                  long long* stamps, bool stamp) {
-    constexpr int NCH = CLASS_A ? 14 : 7;
-    constexpr int RES = TT == 1 ? (CLASS_A ? 2 : 7) : (CLASS_A ? RES_A2 : RES_B2);
-    constexpr int RING = TT == 1 ? (CLASS_A ? 4 : 0) : (CLASS_A ? RING_A2 : RING_B2);
-    static_assert(RING == 0 ? NCH == RES : (NCH - RES) % RING == 0, "a chunk's slot must not depend on the step");
+    using CP = ChunkPlan<CLASS_A, TT>;
+    constexpr int NCH = CP::NCH, RES = CP::RES, RING = CP::RING;
+    // one tile per workgroup: the hidden side runs ahead of the step (see hidden0 below); two tiles: as written in the
+    // header comment (their accumulators take twice the room, and what is bound there is the matrix pipe)
+    constexpr bool EARLY = TT == 1;
     const int ob0 = w, ob1 = w + WAVES;
     v4i slot[RES + RING][DETK];
-    auto chunk = [&](gptr P, int c, int l8) -> gptr {   // (c is a constant after unrolling)
+    // (c is a constant after unrolling)   class A: H(w) r u n | H(w+8) r u n | I(w) r u n | I(w+8) r u n | W4(w) W4(w+8)
+    //                                      class B: H(w) r u n | I(w) r u n | W4(w)
+    auto chunk = [&](gptr P, int cpos, int l8) -> gptr {
+        const int c = EARLY || !CLASS_A ? cpos : cpos < 3 ? cpos : cpos < 6 ? cpos + 3 : cpos < 9 ? cpos - 3 : cpos;   // (not EARLY: H I H I W4 W4)
         if (c < 3) return P + WGH + (size_t)(c * DETB + ob0) * DETK * BLK + l8;
-        if (c < 6) return P + WGI + (size_t)((c - 3) * DETB + ob0) * HIDK * BLK + l8;
-        if (!CLASS_A) return P + W4 + (size_t)ob0 * DETK * BLK + l8;
-        if (c < 9) return P + WGH + (size_t)((c - 6) * DETB + ob1) * DETK * BLK + l8;
+        if (!CLASS_A) {
+            if (c < 6) return P + WGI + (size_t)((c - 3) * DETB + ob0) * HIDK * BLK + l8;
+            return P + W4 + (size_t)ob0 * DETK * BLK + l8;
+        }
+        if (c < 6) return P + WGH + (size_t)((c - 3) * DETB + ob1) * DETK * BLK + l8;
+        if (c < 9) return P + WGI + (size_t)((c - 6) * DETB + ob0) * HIDK * BLK + l8;
         if (c < 12) return P + WGI + (size_t)((c - 9) * DETB + ob1) * HIDK * BLK + l8;
-        return P + W4 + (size_t)(c == 12 ? ob0 : ob1) * DETK * BLK + l8;
+        return P + W4 + (size_t)(c == 12 ? ob0 : ob1) * DETK * BLK + l8;   // (class_a_chunk, spelled out: through the function one register more is live, and spilled)
     };
-    constexpr auto slot_of = [](int c) { return c < RES ? c : RES + (c - RES) % (RING ? RING : 1); };
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int c = 0; c < RES + RING; ++c) request<DETK>(chunk((gptr)Pg, c, lane * 8), slot[c]);
+    for (int c = 0; c < NCH; ++c)
+        if (CP::tab.kind[c] == REG) request<DETK>(chunk((gptr)Pg, c, lane * 8), slot[CP::tab.slot[c]]);
+#pragma unroll
+    for (int i = 0; i < RING; ++i) request<DETK>(chunk((gptr)Pg, CP::tab.first[i], lane * 8), slot[RES + i]);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     if (stamp) stamps[1] = wall_clock64();
     int cur = 0;
+    // (the parameters do not depend on t: re-derive the pointer behind an opaque barrier every step, or the optimizer
+    // keeps what fits of them in registers across steps and spills -- see icem_rssm.hip; and the lane's offsets are
+    // recomputed every step: carried across the loop they are spilled, and a scratch reload is a vmcnt(0) wait in the
+    // middle of the weight requests)
+    gptr P;
+    int j, g, l8, xr, zr, xo, zo, ho;
+    auto derive = [&]() {
+        P = (gptr)Pg;
+        asm volatile("" : "+s"(P));
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        j = ln & 15; g = ln >> 4; l8 = ln * 8;
+        xr = j * RS + 8 * g; zr = j * ZS + 8 * g;
+        xo = j * RS + 4 * g; zo = j * ZS + 4 * g; ho = j * HS + 4 * g;
+    };
+    // chunk c through the matrix pipe for every tile (B: the lane's operand row in tile 0, bts: its stride between
+    // tiles); if it is a streamed chunk, the request that refills its slot
+    auto use = [&](int c, const unsigned short* B, int bts, v4f (&acc)[TT], v4f bias) {
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) acc[tt] = bias;
+        if (CP::tab.kind[c] == LDS) {   // (one tile per workgroup) both operands from LDS; the same chain in the same order
+            const unsigned short* A = s.wl + (size_t)(2 * w + CP::tab.slot[c]) * DETK * BLK + l8;
+#pragma unroll
+            for (int kb = 0; kb < DETK; ++kb)
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(v8bf, *reinterpret_cast<const v4i*>(A + (size_t)kb * BLK)),
+                    __builtin_bit_cast(v8bf, *reinterpret_cast<const v4i*>(B + kb * 32)), acc[0], 0, 0, 0);
+            return;
+        }
+#pragma unroll
+        for (int kb = 0; kb < DETK; ++kb)
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt)
+                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(v8bf, slot[CP::tab.slot[c]][kb]),
+                    __builtin_bit_cast(v8bf, *reinterpret_cast<const v4i*>(B + tt * bts + kb * 32)), acc[tt], 0, 0, 0);
+        if (CP::tab.kind[c] == STR) {
+            __builtin_amdgcn_sched_barrier(0);
+            request<DETK>(chunk(P, CP::tab.next[c], l8), slot[CP::tab.slot[c]]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto gates = [&](int ob, const v4f (&ir)[TT], const v4f (&iu)[TT], const v4f (&in)[TT], const v4f (&hr)[TT],
+                     const v4f (&hu)[TT], const v4f (&hn)[TT]) {
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            float* hp = s.h32 + tt * 16 * HS + ho + ob * 16;
+            float nh[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                nh[r] = gru_out(ir[tt][r], iu[tt][r], in[tt][r], hr[tt][r], hu[tt][r], hn[tt][r], hp[r]);
+                hp[r] = nh[r];
+            }
+            *reinterpret_cast<v4s*>(s.hb[cur ^ 1] + tt * 16 * RS + xo + ob * 16) = pack4(nh[0], nh[1], nh[2], nh[3]);
+        }
+    };
+    // The hidden side of the GRU needs h_t only and is off the step's dependency chain (z -> x -> input side -> gates -> h'
+    // -> p -> z'): block w's runs beside z' at the END of the step before (phase 4), block w + 8's beside x (phase 1) --
+    // the two phases that are otherwise a barrier's latency long, so that phase 2 keeps the input side and the gates only
+    // and the streamed chunks' uses are spread over the whole step.
+    v4f hr[TT], hu[TT], hn[TT];
+    auto hidden0 = [&]() {
+        const unsigned short* H = s.hb[cur] + xr;
+        const int bi = ob0 * 16 + 4 * g;
+        use(0, H, 16 * RS, hr, bias4(s.bs, BGH, bi));
+        use(1, H, 16 * RS, hu, bias4(s.bs, BGH, 16 * DETB + bi));
+        use(2, H, 16 * RS, hn, bias4(s.bs, BGH, 32 * DETB + bi));
+    };
+    derive();
+    if (EARLY) hidden0();
     for (int t = 0; t + 1 < horizon; ++t) {
         const bool st = stamp && t == 5;
         if (st) stamps[2] = wall_clock64();
-        // (the parameters do not depend on t: re-derive the pointer behind an opaque barrier every step, or the optimizer
-        // keeps what fits of them in registers across steps and spills -- see icem_rssm.hip)
-        gptr P = (gptr)Pg;
-        asm volatile("" : "+s"(P));
-        // (and the lane's offsets are recomputed every step: carried across the loop they are spilled, and a scratch
-        // reload is a vmcnt(0) wait in the middle of the weight requests)
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        const int j = ln & 15, g = ln >> 4, l8 = ln * 8;
-        const int xr = j * RS + 8 * g, zr = j * ZS + 8 * g;
-        const int xo = j * RS + 4 * g, zo = j * ZS + 4 * g, ho = j * HS + 4 * g;
+        derive();
         const unsigned short* X = s.xb + xr;
         const unsigned short* H = s.hb[cur] + xr;
         // the next action of the trajectories (every wave asks, wave 2 stores: a load inside a branch would cost the
-        // waves behind the branch their exact vmcnt)
+        // waves behind the branch their exact vmcnt).  One tile: asked for in phase 3, a phase ahead of its use (four
+        // registers less across phase 2, where the wave's pressure peaks -- and a spilled register is a scratch reload,
+        // a vmcnt(0) wait among the weight requests); two tiles: at the step's top (measured: 3 % faster there)
         float an[TT][4];
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt) {
-            const int rr = base + tt * 16 + j;
-            const float* ap = actions + ((size_t)(rr < n ? rr : n - 1) * horizon + (t + 1)) * ACT;
-            const int o = g & 1 ? 4 : 0;
-            an[tt][0] = ap[o]; an[tt][1] = ap[o + 1]; an[tt][2] = ap[g & 1 ? 5 : 2]; an[tt][3] = ap[g & 1 ? 5 : 3];
-        }
-        // chunk c through the matrix pipe for every tile (B: the lane's operand row in tile 0, bts: its stride between
-        // tiles); if it is a streamed chunk, the request that refills its slot
-        auto use = [&](int c, const unsigned short* B, int bts, v4f (&acc)[TT], v4f bias) {
-#pragma unroll
-            for (int tt = 0; tt < TT; ++tt) acc[tt] = bias;
-#pragma unroll
-            for (int kb = 0; kb < DETK; ++kb)
-#pragma unroll
-                for (int tt = 0; tt < TT; ++tt)
-                    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(v8bf, slot[slot_of(c)][kb]),
-                        __builtin_bit_cast(v8bf, *reinterpret_cast<const v4i*>(B + tt * bts + kb * 32)), acc[tt], 0, 0, 0);
-            if (c >= RES) {
-                int nx = c + RING;
-                if (nx >= NCH) nx = RES + (nx - NCH);
-                __builtin_amdgcn_sched_barrier(0);
-                request<DETK>(chunk(P, nx, l8), slot[slot_of(c)]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        auto gates = [&](int ob, const v4f (&ir)[TT], const v4f (&iu)[TT], const v4f (&in)[TT], const v4f (&hr)[TT],
-                         const v4f (&hu)[TT], const v4f (&hn)[TT]) {
+        auto ask_actions = [&]() {
 #pragma unroll
             for (int tt = 0; tt < TT; ++tt) {
-                float* hp = s.h32 + tt * 16 * HS + ho + ob * 16;
-                float nh[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    nh[r] = gru_out(ir[tt][r], iu[tt][r], in[tt][r], hr[tt][r], hu[tt][r], hn[tt][r], hp[r]);
-                    hp[r] = nh[r];
-                }
-                *reinterpret_cast<v4s*>(s.hb[cur ^ 1] + tt * 16 * RS + xo + ob * 16) = pack4(nh[0], nh[1], nh[2], nh[3]);
+                const int rr = base + tt * 16 + j;
+                const float* ap = actions + ((size_t)(rr < n ? rr : n - 1) * horizon + (t + 1)) * ACT;
+                const int o = g & 1 ? 4 : 0;
+                an[tt][0] = ap[o]; an[tt][1] = ap[o + 1]; an[tt][2] = ap[g & 1 ? 5 : 2]; an[tt][3] = ap[g & 1 ? 5 : 3];
             }
         };
-        // ---- phase 1 (reads z_t, a_t, h_t): x = relu(W1 [z | a] + b1); the hidden side of the wave's first GRU block ----
+        if (!EARLY) ask_actions();
+        // ---- phase 1 (reads z_t, a_t, h_t): x = relu(W1 [z | a] + b1); class A: the hidden side of its second GRU block ----
 #pragma unroll
         for (int i = 0; i < (CLASS_A ? 2 : 1); ++i) {
             const int ob = w + WAVES * i;
@@ -199,36 +315,43 @@ __device__ __forceinline__ void recurrence_steps(ProducerLds<TT>& s, int w, int 
                 *reinterpret_cast<v4s*>(s.xb + tt * 16 * RS + xo + ob * 16) = relu_pack(a);
             }
         }
-        int bi = ob0 * 16 + 4 * g;
-        v4f hr[TT], hu[TT], hn[TT];
-        use(0, H, 16 * RS, hr, bias4(s.bs, BGH, bi));
-        use(1, H, 16 * RS, hu, bias4(s.bs, BGH, 16 * DETB + bi));
-        use(2, H, 16 * RS, hn, bias4(s.bs, BGH, 32 * DETB + bi));
+        if (!EARLY) hidden0();
+        v4f hr1[TT], hu1[TT], hn1[TT];   // (class A)
+        auto hidden1 = [&](int c0) {
+            const int bi = ob1 * 16 + 4 * g;
+            use(c0, H, 16 * RS, hr1, bias4(s.bs, BGH, bi));
+            use(c0 + 1, H, 16 * RS, hu1, bias4(s.bs, BGH, 16 * DETB + bi));
+            use(c0 + 2, H, 16 * RS, hn1, bias4(s.bs, BGH, 32 * DETB + bi));
+        };
+        if constexpr (CLASS_A && EARLY) hidden1(3);
         __syncthreads();
         if (st) stamps[3] = wall_clock64();
-        // ---- phase 2: GRU h' = (1 - u) n + u h; wave 7 publishes state t ----
+        // ---- phase 2: the input side, GRU h' = (1 - u) n + u h; wave 7 publishes state t ----
         {
             v4f ir[TT], iu[TT], in[TT];
-            use(3, X, 16 * RS, ir, bias4(s.bs, BGI, bi));
-            use(4, X, 16 * RS, iu, bias4(s.bs, BGI, 16 * DETB + bi));
-            use(5, X, 16 * RS, in, bias4(s.bs, BGI, 32 * DETB + bi));
+            int bi = ob0 * 16 + 4 * g;
+            constexpr int i0 = CLASS_A && EARLY ? 6 : 3;
+            use(i0, X, 16 * RS, ir, bias4(s.bs, BGI, bi));
+            use(i0 + 1, X, 16 * RS, iu, bias4(s.bs, BGI, 16 * DETB + bi));
+            use(i0 + 2, X, 16 * RS, in, bias4(s.bs, BGI, 32 * DETB + bi));
             gates(ob0, ir, iu, in, hr, hu, hn);
-            if (CLASS_A) {
+            if constexpr (CLASS_A) {
+                if constexpr (!EARLY) hidden1(6);
                 bi = ob1 * 16 + 4 * g;
-                use(6, H, 16 * RS, hr, bias4(s.bs, BGH, bi));
-                use(7, H, 16 * RS, hu, bias4(s.bs, BGH, 16 * DETB + bi));
-                use(8, H, 16 * RS, hn, bias4(s.bs, BGH, 32 * DETB + bi));
                 use(9, X, 16 * RS, ir, bias4(s.bs, BGI, bi));
                 use(10, X, 16 * RS, iu, bias4(s.bs, BGI, 16 * DETB + bi));
                 use(11, X, 16 * RS, in, bias4(s.bs, BGI, 32 * DETB + bi));
-                gates(ob1, ir, iu, in, hr, hu, hn);
+                gates(ob1, ir, iu, in, hr1, hu1, hn1);
             } else if (w == WAVES - 1) {
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
                 publish<TT>(s, cur, items, tile_stride, t, flag, ntl, ln);
             }
         }
         __syncthreads();
         if (st) stamps[4] = wall_clock64();
         // ---- phase 3: p = relu(W4 h' + b4) ----
+        if (EARLY) ask_actions();
         {
             const unsigned short* Hn = s.hb[cur ^ 1] + xr;
             v4f p0[TT];
@@ -244,7 +367,9 @@ __device__ __forceinline__ void recurrence_steps(ProducerLds<TT>& s, int w, int 
         }
         __syncthreads();
         if (st) stamps[5] = wall_clock64();
-        // ---- phase 4: z' = W5 p + b5 (waves 0, 1, from LDS) and the next action (wave 2) -> [z | a] ----
+        // ---- phase 4: z' = W5 p + b5 (waves 0, 1, from LDS) and the next action (wave 2) -> [z | a]; every wave: the
+        //      hidden side of its first GRU block for step t + 1 (behind the last step: computed and dropped, the ring
+        //      of streamed chunks keeps its order) ----
         if (CLASS_A) {
             if (w < STB) {
                 v4i A5[HIDK];
@@ -261,9 +386,10 @@ __device__ __forceinline__ void recurrence_steps(ProducerLds<TT>& s, int w, int 
                         pack4(an[tt][0], an[tt][1], g == 0 ? an[tt][2] : 0.f, g == 0 ? an[tt][3] : 0.f);
             }
         }
+        cur ^= 1;
+        if (EARLY) hidden0();
         __syncthreads();
         if (st) stamps[6] = wall_clock64();
-        cur ^= 1;
     }
     if (stamp) stamps[7] = wall_clock64();
     // the state the last step starts from
@@ -323,6 +449,22 @@ __device__ __forceinline__ void recurrence(ProducerLds<TT>& s, int wg, int tiles
         for (int q = 0; q < (N5 + NTHR - 1) / NTHR; ++q)
             if (tid + NTHR * q < N5) reinterpret_cast<v4i*>(s.w5)[tid + NTHR * q] = c5[q];
         if (tid < TT * 16 * ACT) s.zA[(tid / ACT) * ZS + 32 + tid % ACT] = to_bf16(av);
+        if constexpr (TT == 1) {   // the class-A waves' two LDS chunks (ChunkPlan)
+            constexpr int PC = DETK * BLK / 8, NP = LDS_CHUNKS * PC;   // 16-byte pieces per chunk, in all
+            v4i cl[(NP + NTHR - 1) / NTHR];
+#pragma unroll
+            for (int q = 0; q < (NP + NTHR - 1) / NTHR; ++q) {
+                const int e = tid + NTHR * q;
+                if (e < NP) {
+                    const int ci = e / PC, wv = ci >> 1;
+                    const size_t src = class_a_chunk(ChunkPlan<true, 1>::tab.lds[ci & 1], wv, wv + WAVES);
+                    cl[q] = reinterpret_cast<const v4i*>(Pg + src)[e % PC];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < (NP + NTHR - 1) / NTHR; ++q)
+                if (tid + NTHR * q < NP) reinterpret_cast<v4i*>(s.wl)[tid + NTHR * q] = cl[q];
+        }
     }
     __syncthreads();
     for (int e = tid; e < TT * 16 * RS; e += NTHR) {
@@ -337,6 +479,10 @@ __device__ __forceinline__ void recurrence(ProducerLds<TT>& s, int wg, int tiles
         if (k < 32) s.zA[e] = to_bf16(k < STOCH ? s.ob[DET + k] : 0.f);
         else if (k >= 32 + ACT) s.zA[e] = 0;
     }
+#ifdef ICEM_RSSM_ROT   // (development: the class-A waves' blocks rotated per workgroup -- do CUs in lockstep on the same lines cost?)
+    if (w < 5) recurrence_steps<true, TT>(s, __builtin_amdgcn_readfirstlane((w + wg) % 5), lane, base, n, horizon, Pg, actions, items, tile_stride, flag, ntl, stamps, stamp);
+    else
+#endif
     if (w < 5) recurrence_steps<true, TT>(s, w, lane, base, n, horizon, Pg, actions, items, tile_stride, flag, ntl, stamps, stamp);
     else recurrence_steps<false, TT>(s, w, lane, base, n, horizon, Pg, actions, items, tile_stride, flag, ntl, stamps, stamp);
 }
