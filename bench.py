@@ -533,9 +533,18 @@ def self_launch(n):
     port = s.getsockname()[1]
     s.close()
     procs = []
+    n_dev = max(1, torch.cuda.device_count())
+    per_dev = -(-n // n_dev)
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count if (per_dev > 1 and torch.cuda.is_available()) else 0
     for r in range(n):
         e = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                  MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ICEM_BENCH_LAUNCHER="bench.py (self-launched ranks)")
+        if n_cu and "HSA_CU_MASK" not in e:
+            # more ranks than GPUs (a debugging run): the ranks of a GPU each get their own slice of its CUs -- a rank's
+            # launch spins on its peers' records, and a peer that cannot get a CU meanwhile is a wait for the poll budget
+            # (on a node every rank has a GPU of its own and nothing is masked)
+            cus = n_cu // per_dev
+            e["HSA_CU_MASK"] = f"{r % n_dev}:{(r // n_dev) * cus}-{(r // n_dev + 1) * cus - 1}"
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0

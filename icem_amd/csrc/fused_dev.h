@@ -1217,6 +1217,49 @@ __device__ __forceinline__ void merge_select_split_stage2(const MergeSingleArgs&
     }
 }
 
+// Stage 2 without a sort, spread over ALL waves of the workgroup.  Behind stage 1 the candidates are the NW x 16 slots of
+// wsel: every wave's K best and, in the slots behind them, the kept elites (icem.py:143-145; wave w parks elites w,
+// w + NW, ..: merge_select_split_keep, in front of the workgroup barrier) -- at most NW x 16 keys, all different (a key
+// embeds its row).  A key's place in the ascending order is the number of smaller keys: wave w counts that for the 16
+// slots of its row (lane = slot + 16 x the quarter of the comparands it reads, two per ds_read_b128) and writes the key
+// to sel[place] if place < K.  32 independent compare-and-adds per lane where stage 2 is one wave's ~600-instruction
+// dependent chain (two bitonic networks on 64-bit keys).  Same result: the K smallest keys, ascending.
+// Needs n_keep <= (16 - K) x NW (merge_select_split_by_rank; callers fall back to stage 2 otherwise).
+template <int NW>
+__device__ __forceinline__ bool merge_select_split_by_rank(const MergeSingleArgs& a) { return a.n_keep <= (16 - a.K) * NW; }
+// the cost of the kept elite lane `lane` of wave w parks (requested in front of stage 1: it travels with the lists' keys)
+template <int NW>
+__device__ __forceinline__ float merge_keep_cost_split(const MergeSingleArgs& a, int lane, int w) {
+    const int j = w + NW * (lane - a.K);
+    return a.elites_cost_cur ? a.elites_cost_cur[(lane >= a.K && lane < 16 && j < a.n_keep) ? j : 0] : 0.f;
+}
+template <int NW>
+__device__ __forceinline__ void merge_select_split_keep(const MergeSingleArgs& a, int lane, int w, unsigned long long* wsel,
+                                                        unsigned long long* sel, float keep_cost) {
+    if (lane >= a.K && lane < 16) {   // (behind stage 1's own writes of these slots: same wave, program order)
+        const int j = w + NW * (lane - a.K);
+        wsel[w * 16 + lane] = (j < a.n_keep && a.elites_cost_cur) ? make_key(keep_cost, keep_index0(a) + j) : KEY_SENTINEL;
+    }
+    if (w == 0 && lane < 16) sel[lane] = KEY_SENTINEL;   // (fewer than K candidates: the places behind them)
+}
+template <int NW>
+__device__ __forceinline__ void merge_select_split_rank(const MergeSingleArgs& a, int lane, int w, const unsigned long long* wsel,
+                                                        unsigned long long* sel) {
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const int i = lane & 15, q = lane >> 4;
+    const unsigned long long mine = wsel[w * 16 + i];
+    const u64x2* pairs = reinterpret_cast<const u64x2*>(wsel) + q;
+    unsigned place = 0;
+#pragma unroll
+    for (int c = 0; c < 2 * NW; ++c) {
+        const u64x2 b = pairs[4 * c];
+        place += (b[0] < mine ? 1u : 0u) + (b[1] < mine ? 1u : 0u);
+    }
+    place += (unsigned)__shfl_xor((int)place, 16, 64);
+    place += (unsigned)__shfl_xor((int)place, 32, 64);
+    if (q == 0 && mine != KEY_SENTINEL && place < (unsigned)a.K) sel[place] = mine;
+}
+
 // pointers to the K selected rows (icem.py:201): pool rows, or kept elites behind index n_global
 template <int KREG, bool REC>
 __device__ __forceinline__ void merge_rows(const MergeSingleArgs& a, const unsigned long long* sel, const int* slot,

@@ -36,8 +36,9 @@ struct AheadLds {
     static constexpr int DIST = KEYS + 2 * (2 * WAVES * 32);          // [2 HD]
     static constexpr int OBS = DIST + 2 * HD + (2 * HD) % 4;          // [32]
     static constexpr int SEL = OBS + 32;                              // u64 [64]
-    static constexpr int WSEL = SEL + 2 * 64;                         // u64 [WAVES * 16]
+    static constexpr int WSEL = SEL + 2 * 64;                         // u64 [WAVES * 16]: every wave's K best, the kept elites behind them
     static constexpr int SLOT = WSEL + 2 * WAVES * 16;                // int [64]
+    static_assert(WSEL % 4 == 0, "wsel is read two keys at a time");
     static constexpr int ROLL_END = SLOT + 64;
     static_assert(WAVES * 64 * 2 <= WAVES * Stream::STG, "per-wave compaction scratch fits the staging buffers");
     // noise role: [tpw, HD] tile of NT / D rows
@@ -90,10 +91,13 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
             pk.elites_cost_cur = args.p.keep_costs;
             pk.keep_base = args.p.n_loc;
             __builtin_amdgcn_s_setprio(3);  // everybody else waits for this workgroup
-            const float pk_keep = merge_keep_cost(pk, lane);
+            const bool by_rank = merge_select_split_by_rank<WAVES>(pk);   // (uniform) the K best by counting, all waves
+            const float pk_keep = by_rank ? merge_keep_cost_split<WAVES>(pk, lane, wave) : merge_keep_cost(pk, lane);
             merge_select_split_stage1<KREG>(pk, lane, wave, WAVES, cand, wsel);
+            if (by_rank) merge_select_split_keep<WAVES>(pk, lane, wave, wsel, sel, pk_keep);
             __syncthreads();
-            if (wave == 0) merge_select_split_stage2(pk, lane, WAVES, wsel, cand, sel, pk_keep);
+            if (by_rank) merge_select_split_rank<WAVES>(pk, lane, wave, wsel, sel);
+            else if (wave == 0) merge_select_split_stage2(pk, lane, WAVES, wsel, cand, sel, pk_keep);
             __syncthreads();
             pack_records_body<KREG>(pk, args.p.n_loc, args.p.shard_lo, args.p.records, args.p.px, stage, sel, tid, NTT);
             __syncthreads();
@@ -228,12 +232,15 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
     if constexpr (PM == 1) {
         // all waves share the selection: one cold round trip instead of a dozen dependent ones (the kept elites' costs,
         // stage 2's other input, travel with it)
-        const float keep_cost = merge_keep_cost(args.m, lane);
+        const bool by_rank = merge_select_split_by_rank<WAVES>(args.m);   // (uniform) the K best by counting, all waves
+        const float keep_cost = by_rank ? merge_keep_cost_split<WAVES>(args.m, lane, wave) : merge_keep_cost(args.m, lane);
         merge_select_split_stage1<KREG>(args.m, lane, wave, WAVES, cand, wsel);
+        if (by_rank) merge_select_split_keep<WAVES>(args.m, lane, wave, wsel, sel, keep_cost);
         // (this wave's first noise vectors: requested behind its keys, in flight across the barriers below)
         if (tile0 < tiles) stream.first_loads(args.pool, a.n_rows, tile0, pre);
         __syncthreads();
-        if (wave == 0) merge_select_split_stage2(args.m, lane, WAVES, wsel, cand, sel, keep_cost);
+        if (by_rank) merge_select_split_rank<WAVES>(args.m, lane, wave, wsel, sel);
+        else if (wave == 0) merge_select_split_stage2(args.m, lane, WAVES, wsel, cand, sel, keep_cost);
     } else if constexpr (PM == 2) {
         // sharded: the pack role merges for everybody -- wait for its flag (bounded like every exchange wait)
         if (tile0 < tiles) stream.first_loads(args.pool, a.n_rows, tile0, pre);

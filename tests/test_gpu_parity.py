@@ -1858,6 +1858,39 @@ def test_in_library_exchange_emulated_worlds(world, N, dtype, deferral):
         assert pl.exchange_status()[0] == 0
 
 
+def _spawn_ranks(fn, world, args, timeout=900):
+    """torch.multiprocessing.spawn for ranks that may have to SHARE a GPU (this box has one): every rank of a shared GPU
+    gets its own slice of the CUs (HSA_CU_MASK, read when the child's HSA runtime starts).  A rank's launch spins on its
+    peers' records; without the slices a peer whose launch finds no free CU meanwhile is only released by the exchange's
+    poll budget (seconds) -- a property of two processes on one device, not of the exchange: on a node every rank has a
+    GPU of its own and nothing is masked."""
+    import multiprocessing as pymp
+    import os
+    ctx = pymp.get_context("spawn")
+    n_dev = max(1, torch.cuda.device_count())
+    per_dev = -(-world // n_dev)
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    old = os.environ.get("HSA_CU_MASK")
+    procs = []
+    try:
+        for r in range(world):
+            if per_dev > 1 and old is None:
+                cus = n_cu // per_dev
+                os.environ["HSA_CU_MASK"] = f"{r % n_dev}:{(r // n_dev) * cus}-{(r // n_dev + 1) * cus - 1}"
+            p = ctx.Process(target=fn, args=(r, world) + tuple(args))
+            p.start()
+            procs.append(p)
+    finally:
+        if old is None:
+            os.environ.pop("HSA_CU_MASK", None)
+    for p in procs:
+        p.join(timeout)
+    hung = [p for p in procs if p.is_alive()]
+    for p in hung:
+        p.kill()
+    assert not hung and all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+
+
 def _xchg_worker(rank, world, port, out_dir, dtype, N=2000, steps=3):
     import os
     import torch.distributed as dist
@@ -1883,16 +1916,16 @@ def _xchg_worker(rank, world, port, out_dir, dtype, N=2000, steps=3):
 def test_in_library_exchange_two_processes_ipc(tmp_path, dtype, N):
     """The real multi-process path: two processes share this GPU, exchange their IPC handles once over gloo, and run
     whole MPC steps with icem_plan_step_sharded -- the records move through IPC-mapped peer blocks, the only
-    torch.distributed traffic is the handle exchange at construction.  (Populations small enough that both processes'
-    launches are resident on the one GPU at once: a rank spinning on a peer that cannot get a CU would only ever be
-    released by its poll budget.)  Every rank ends with the single-process result."""
+    torch.distributed traffic is the handle exchange at construction.  (Sharing one GPU, each process gets half of its CUs:
+    _spawn_ranks -- a rank spinning on a peer that cannot get a CU would only ever be released by its poll budget.)
+    Every rank ends with the single-process result."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_xchg_worker, args=(2, port, str(tmp_path), dtype, N), nprocs=2, join=True)
+    _spawn_ranks(_xchg_worker, 2, (port, str(tmp_path), dtype, N))
     pl = _xchg_planner(0, 1, dtype, N, 3, seed=21, kind=0)
     acts = np.array([np_(pl.plan_step(0.1 * np.random.RandomState(s).randn(17))).copy() for s in range(3)])
     for r in range(2):
@@ -1994,7 +2027,7 @@ def test_soak_two_processes_ipc_many_steps(tmp_path, N):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_xchg_worker, args=(2, port, str(tmp_path), "f32", N, steps), nprocs=2, join=True)
+    _spawn_ranks(_xchg_worker, 2, (port, str(tmp_path), "f32", N, steps))
     pl = _xchg_planner(0, 1, "f32", N, 3, seed=21, kind=0)
     acts = np.array([np_(pl.plan_step(0.1 * np.random.RandomState(s).randn(17))).copy() for s in range(steps)])
     for r in range(2):
