@@ -781,37 +781,61 @@ __device__ __forceinline__ unsigned long long topk_push16(unsigned long long run
     return wave_sort_n(key, lane, first ? 16u : 16u + (unsigned)K);
 }
 
-// one sorted list per workgroup: tree merge of the first WAVES waves' lists through LDS (`fan` lists per sort),
-// wave 0 writes list `wg` of `n_wg`.  Every thread of the workgroup must call it.
+// one sorted list per workgroup out of the first WAVES waves' running lists (K <= 32 keys each, ascending in lanes 0..K-1):
+// list `wg` of `n_wg`.  Every thread of the workgroup must call it.
+// No sort: the lists go to LDS once, and the place of a key in the merged order is the number of smaller keys among the
+// WAVES x K -- real keys are all different (a key embeds its row), and the empty slots are filled with keys that are all
+// different too and lie behind every real one ((+inf, INT_MAX - 511 ..): they come out as the (+inf, INT_MAX) padding
+// again).  Every wave counts for its own keys (lane = key + 16 x the quarter of the comparands it reads) and the keys
+// with place < K go straight to the output.  One barrier and a few dozen independent compares per lane where the tree
+// of 64-lane bitonic networks on 64-bit keys (8 -> 2 -> 1 lists) was two dependent sorts and three barriers -- at the
+// end of EVERY rollout launch (EXPERIMENTS R4.13).
+constexpr unsigned KEY_FILL_LO = 0x7FFFFE00u;   // fillers: (+inf, KEY_FILL_LO + slot), slot < 512 (16 waves x 32)
 template <int WAVES>
 __device__ __forceinline__ void wg_merge_emit(unsigned long long (*wg_keys)[WAVES][32], unsigned long long run_key, int K,
                                               int lane, int wave, const FastRolloutArgs& a, int wg = blockIdx.x,
                                               int n_wg = gridDim.x) {
-    if (WAVES > 1) {
-        const int fan = 4 * K <= 64 ? 4 : 2;
-        int lists = WAVES, par = 0;
-        if (wave < WAVES && lane < K) wg_keys[0][wave][lane] = run_key;
-        __syncthreads();
-        while (lists > 1) {
-            const int f = lists < fan ? lists : fan;
-            const int out = lists / f;
-            if (wave < out) {
-                unsigned long long k2 = KEY_SENTINEL;
-                if (lane < f * K) k2 = wg_keys[par][wave * f + lane / K][lane % K];
-                run_key = wave_sort64(k2, lane);
-                if (lane < K) wg_keys[par ^ 1][wave][lane] = run_key;
-            }
-            __syncthreads();
-            par ^= 1;
-            lists = out;
-        }
-    }
-    if (wave == 0 && lane < K) {
+    static_assert(WAVES * 32 <= 512, "filler keys: one per slot");
+    auto emit = [&](unsigned long long key, int place) {
         if (a.part_k) {
-            a.part_k[(size_t)lane * n_wg + wg] = run_key;
+            a.part_k[(size_t)place * n_wg + wg] = key;
         } else {
-            a.part_c[(size_t)wg * K + lane] = key_cost(run_key);
-            a.part_i[(size_t)wg * K + lane] = key_idx(run_key);
+            a.part_c[(size_t)wg * K + place] = key_cost(key);
+            a.part_i[(size_t)wg * K + place] = key_idx(key);
+        }
+    };
+    if (WAVES == 1) {
+        if (wave == 0 && lane < K) emit(run_key, lane);
+        return;
+    }
+    // candidates and comparands: slots 0 .. K-1 of every row (WAVES x K >= K keys, all different: places 0 .. K-1 are all
+    // taken); comparands are read in pairs, so an odd K also reads slot K -- a filler behind its row's candidates, whose
+    // own place would be >= K
+    const int kp = (K + 1) & ~1, half = kp >> 1;
+    unsigned long long* keys = &wg_keys[0][0][0];
+    if (wave < WAVES && lane < kp) {
+        unsigned long long v = lane < K ? run_key : KEY_SENTINEL;
+        if (v == KEY_SENTINEL) v = (KEY_SENTINEL & 0xFFFFFFFF00000000ull) | (KEY_FILL_LO + (unsigned)(wave * 32 + lane));
+        keys[wave * 32 + lane] = v;
+    }
+    __syncthreads();
+    if (wave < WAVES) {
+        const int q = lane >> 4;   // rows q, q + 4, ..
+        for (int s0 = 0; s0 < K; s0 += 16) {
+            const int i = s0 + (lane & 15);
+            const unsigned long long mine = keys[wave * 32 + (i < 32 ? i : 31)];
+            unsigned place = 0;
+            for (int r = q; r < WAVES; r += 4) {
+                const unsigned long long* b = keys + r * 32;
+#pragma unroll 4
+                for (int c = 0; c < half; ++c) place += (b[2 * c] < mine ? 1u : 0u) + (b[2 * c + 1] < mine ? 1u : 0u);
+            }
+            place += (unsigned)__shfl_xor((int)place, 16, 64);
+            place += (unsigned)__shfl_xor((int)place, 32, 64);
+            if (q == 0 && i < K && place < (unsigned)K) {
+                const bool filler = (mine >> 32) == (KEY_SENTINEL >> 32) && (unsigned)mine >= KEY_FILL_LO;
+                emit(filler ? KEY_SENTINEL : mine, (int)place);
+            }
         }
     }
 }
