@@ -278,20 +278,49 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
             const bool live = row < n_rows;
             if ((lane & 15) == 0) {
                 if (live) ra.costs[row] = cost;
-                wg_keys[0][0][rs] = (live && row < ra.n_cand) ? make_key(cost, row) : KEY_SENTINEL;  // TPB <= 32 keys
+                // TPB <= 32 keys; two-tile slabs (counted, below): a row that is no candidate leaves a filler -- (+inf, INT_MAX - 511
+                // + rs), all different, behind every real key (wg_merge_emit's)
+                wg_keys[0][0][rs] = (live && row < ra.n_cand) ? make_key(cost, row)
+                                    : TPB <= 16 ? KEY_SENTINEL : ((KEY_SENTINEL & 0xFFFFFFFF00000000ull) | (KEY_FILL_LO + (unsigned)rs));
             }
         }
         if (ra.dbg && tid == 0 && wg == 0) ra.dbg[13] = wall_clock64();
         if (ra.K > 0 && wg < n_wg) {   // the slab's keys -> one sorted list (one wave)
             __syncthreads();
-            if (wave == 0) {
-                const unsigned long long key = wave_sort_first<(TPB <= 16 ? 16 : TPB <= 32 ? 32 : 64)>(lane < TPB ? wg_keys[0][0][lane] : KEY_SENTINEL, lane);
+            if (wave == 0 && TPB <= 16) {   // 16 keys: the 10-stage network is shorter than counting + two cross-row adds (measured)
+                const unsigned long long key = wave_sort_first<16>(lane < TPB ? wg_keys[0][0][lane] : KEY_SENTINEL, lane);
                 if (lane < ra.K) {
                     if (ra.part_k) {
                         ra.part_k[(size_t)lane * n_wg + wg] = key;
                     } else {
                         ra.part_c[(size_t)wg * ra.K + lane] = key_cost(key);
                         ra.part_i[(size_t)wg * ra.K + lane] = key_idx(key);
+                    }
+                }
+            } else if (wave == 0) {
+                // 32 keys: the K best, ascending, by counting (no sort: the keys are all different, a key's place is the
+                // number of smaller ones -- EXPERIMENTS R4.13): lane = key + NK x the part of the keys it reads
+                constexpr int NK = TPB <= 16 ? 16 : 32, PARTS = 64 / NK, PER = NK / PARTS;
+                static_assert(TPB <= 32 && PER % 2 == 0, "one wave counts for the slab");
+                const unsigned long long* keys = &wg_keys[0][0][0];
+                const int i = lane & (NK - 1), part = lane / NK;
+                const unsigned long long mine = i < TPB ? keys[i] : KEY_SENTINEL;
+                unsigned place = 0;
+#pragma unroll
+                for (int c = 0; c < PER; ++c) {
+                    const int e = part * PER + c;
+                    place += (e < TPB && keys[e < TPB ? e : 0] < mine) ? 1u : 0u;
+                }
+                if (NK == 16) place += (unsigned)__shfl_xor((int)place, 16, 64);
+                place += (unsigned)__shfl_xor((int)place, 32, 64);
+                if (part == 0 && i < TPB && place < (unsigned)ra.K) {
+                    const bool filler = (mine >> 32) == (KEY_SENTINEL >> 32) && (unsigned)mine >= KEY_FILL_LO;
+                    const unsigned long long key = filler ? KEY_SENTINEL : mine;
+                    if (ra.part_k) {
+                        ra.part_k[(size_t)place * n_wg + wg] = key;
+                    } else {
+                        ra.part_c[(size_t)wg * ra.K + place] = key_cost(key);
+                        ra.part_i[(size_t)wg * ra.K + place] = key_idx(key);
                     }
                 }
             }
