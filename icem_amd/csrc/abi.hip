@@ -219,7 +219,47 @@ static void update_paths(icem_handle* h) {
     const int of = tile ? h->O : 0;
     if (of != h->Of) h->fast_model_ready = false;
     h->Of = of;
+    // the tile's arithmetic (icem_set_tile_arith).  The fp16-plane tile exists for one-tile widths (O <= 20) and a flip
+    // threshold >= 0, carries the model's planes scaled by one power of two for A and one for B (largest |entry| into
+    // [64, 128): Tile16H) and is what large populations roll out with by default -- decided from the GLOBAL populations of
+    // the configuration, so every rank and every launch of a handle computes in one arithmetic.
+    bool split_ok = of >= 16 && of <= 20 && h->cfg.dtype == ICEM_F32 && !(h->cost.flip_idx >= 0 && h->cost.flip_thresh < 0.0);
+    auto lift = [](const std::vector<double>& m, bool* finite) {
+        double mx = 0.0;
+        for (double v : m) {
+            mx = std::max(mx, std::fabs(v));
+            if (!(std::fabs(v) < 1e30)) *finite = false;
+        }
+        if (!(mx > 1e-30)) return 1.f;
+        int e = 0;
+        (void)std::frexp(mx, &e);            // mx = f 2^e, f in [0.5, 1)
+        return (float)std::ldexp(1.0, 7 - e);  // mx x scale in [64, 128)
+    };
+    bool finite = true;
+    h->tile_m_scale = lift(h->A_host, &finite);
+    h->tile_b_scale = lift(h->B_host, &finite);
+    split_ok = split_ok && finite;
+    static const int env_mode = [] { const char* e = getenv("ICEM_TILE_ARITH"); return e ? atoi(e) : -1; }();
+    const int mode = h->tile_arith_mode >= 0 ? h->tile_arith_mode : env_mode;
+    // by configuration: where EVERY iteration's global population is one the noise-ahead launches serve (more than 8192 rows:
+    // the launches bound by the f32 pipe) -- smaller populations are latency chains that the exact tile's VALU twin serves best
+    bool big = !h->pop.empty();
+    for (int n_it : h->pop) big = big && n_it > ICEM_TILE_SPLIT_MIN_ROWS;
+    const bool want = mode == 1 || (mode < 0 && big);
+    h->tile_arith = (split_ok && want) ? 1 : 0;
 }
+
+int icem_set_tile_arith(icem_handle* h, int32_t mode) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (mode < -1 || mode > 1) return fail(ICEM_E_INVALID, "tile arithmetic: -1 (by configuration), 0 (exact f32) or 1 (fp16 planes)");
+    if (h->pm_pending || h->pk_pending) return fail(ICEM_E_STATE, "a deferred merge is pending: finish the MPC step first");
+    h->tile_arith_mode = mode;
+    update_paths(h);
+    h->ahead.next_valid = h->ahead.pre_valid = false;   // (noise drawn ahead for the other launch shapes is redrawn)
+    return ICEM_OK;
+}
+
+int icem_tile_arith(const icem_handle* h) { return h ? h->tile_arith : 0; }
 
 int icem_set_model(icem_handle* h, int32_t kind, int32_t obs_dim, const double* A_host, const double* B_host) {
     if (!h || !A_host || !B_host) return fail(ICEM_E_INVALID, "null argument");

@@ -608,6 +608,268 @@ struct Tile16 {
     }
 };
 
+// ---- Tile16H: the same tile with the model step on the 16-BIT matrix cores ------------------------------------------
+// (EXPERIMENTS R5.1.)  Tile16's six v_mfma_f32_16x16x4_f32 are 192 cycles of the one pipe f32 MFMA and f32 VALU share
+// (64 flop / clk / SIMD); v_mfma_f32_16x16x32_f16 runs at sixteen times that rate.  Every f32 operand x is carried as two
+// fp16 numbers, x S = hi + lo with hi = f16(x S), lo = f16(x S - hi), both round-to-nearest-even (22 significant bits
+// and lo's sign: x S to 2^-24 relative while lo is a normal fp16 number, i.e. |x S| >= 2^-3; to 2^-25 absolute below),
+// and a multiply-add is the three products hi.Hi + hi.Lo + lo.Hi -- each exact in the f32 accumulator's format -- summed
+// smallest first; lo.Lo (< 2^-22 of hi.Hi) is dropped.  The whole contraction of a step (16 tile columns + the extra
+// entries: columns >= 16 and the actions, <= 32 in all) is ONE 32-deep MFMA per product: 3 x 16 cycles.
+//   Layout: A = M^T (output column i = lane % 16, contraction slots 8g .. 8g+7 of lane group g = lane / 16), B = X^T
+// (trajectory j = lane % 16, the same slots).  Slots 8g .. 8g+3 are the tile columns 4g .. 4g+3 -- the lane's own four
+// accumulator registers of the previous step, as in Tile16: no cross-lane traffic -- and slots 8g+4 .. 8g+7 the extra
+// entries e = 4q + g, q = 0 .. 3 (Tile16's assignment: entry e of a step sits at rd[4q] of lane group g).
+//   S is ONE power of two per launch, the same in every wave, rank and tile: 2^(4 - e) with 2^e <= m < 2^(e+1),
+// m = max(|obs0| entries, FastRolloutArgs::act_mag (the action bound's magnitude), 1 for a tanh model) -- from the start
+// observation every trajectory shares, so a trajectory's bits do not depend on which tile, launch or GPU rolls it out.
+// The model's planes are made at load time from A sM and B sB, sM / sB the powers of two (FastRolloutArgs::m_scale / b_scale,
+// from the host: plan.hip) that put the largest |entry| of A / of B into [64, 128): entries down to 2^-10 of the largest keep
+// normal lo planes (an UNSCALED model's small entries -- 0.05 beside 0.95 -- sit in fp16's subnormals, a systematic 3e-8
+// per entry and step that adds up linearly over the horizon: measured 1e-5 of a cost at h = 30 where the actions dominate the
+// state).  B's scale is free (the actions enter at T / sB); A's costs the four v_mul that bring the accumulators (T = S sM
+// times the state) back to the B operand's scale S.  The state is KEPT at T (powers of two commute with every f32 operation
+// here; the cost's constants are scaled once instead); states growing beyond 2^11 m overflow fp16's range and the
+// trajectory's cost becomes NaN -> +inf in its key (it is dropped; an f32 chain would report a huge finite cost).  Output
+// columns >= 16 stay on the VALU (f32 fmaf chain over the lane's entries + permlane reduction, as Tile16).  NOT the bits of Tile16 / Tile4: a handle rolls out in ONE
+// arithmetic (FastRolloutArgs::arith), chosen from its configuration, never from a launch's row count.
+__device__ __forceinline__ unsigned wave_min_u32(unsigned x);   // (below, with the merge's reductions)
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+// (a, b) -> packed fp16 (hi_a | hi_b << 16) and the packed residuals: v_cvt_pk_f16_f32, 2 x v_fma_mix_f32 (the f32 value minus
+// one half of the packed pair, no unpacking), v_cvt_pk_f16_f32.  The residual x - f16(x) is exact in f32.
+__device__ __forceinline__ void split_pair_f16(float a, float b, unsigned& hi, unsigned& lo) {
+    const f16x2_t h = __builtin_convertvector(f32x2_t{a, b}, f16x2_t);
+    hi = __builtin_bit_cast(unsigned, h);
+    float r0, r1;
+    const float one = 1.f;
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(a), "v"(one), "v"(hi));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(b), "v"(one), "v"(hi));
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{r0, r1}, f16x2_t));
+}
+// the same for (a sa, b sb), sa / sb powers of two (or 0): two v_mul_f32 in front of the conversion (v_fma_mixlo / mixhi_f16
+// would fold the scale into it, but issue at a THIRD of v_mul's rate: tools/ubench/tile_ops_rates.hip), the residual's
+// v_fma_mix_f32 takes the scale into its own multiply
+__device__ __forceinline__ void split_pair_f16_scaled(float a, float sa, float b, float sb, unsigned& hi, unsigned& lo) {
+    const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a * sa, b * sb}, f16x2_t));
+    hi = h;
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(a), "v"(sa), "v"(h));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(b), "v"(sb), "v"(h));
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{r0, r1}, f16x2_t));
+}
+__device__ __forceinline__ f32x4 mfma_f16_32(const unsigned (&a)[4], const unsigned (&b)[4], f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, u32x4_t{a[0], a[1], a[2], a[3]}),
+                                                  __builtin_bit_cast(f16x8_t, u32x4_t{b[0], b[1], b[2], b[3]}), c, 0, 0, 0);
+}
+
+template <int H, int D, int O, int KIND>
+struct Tile16H {
+    static constexpr int NT = 1;
+    static constexpr int OP = O;
+    static constexpr int REM = O > 16 ? O - 16 : 0;
+    static constexpr int NX = REM + D;
+    static constexpr int NKX = (NX + 3) / 4;           // extra entries per lane (slots 8g+4 ..)
+    static constexpr int CT4 = ((O + 3) / 4) * 4;
+    static constexpr int SLACK = 4, TAIL = 8;
+    static constexpr int ZROW = OP + D;
+    static_assert(O >= 16 && O <= 20 && NKX <= 4, "one 16-column tile, at most 16 extra contraction entries");
+
+    unsigned aH[4], aL[4];              // model operand planes: slots 8g .. 8g+7 as four fp16 pairs
+    float wR[REM > 0 ? REM : 1][4 + NKX];   // f32 weights of this lane's entries into output column 16 + r (the extras' scaled in load_obs)
+    float cw[NKX], sc[NKX];             // ctrl_w where the extra entry is an action, else 0; the entry's scale into the B operand:
+                                        // S (an action), 1 (a state entry: kept scaled) or 0 (padding)
+    bool is_act[NKX];
+    int xoff[NKX];                      // where this lane reads extra entry q of a step, relative to its read pointer: 4q, or -- a
+                                        // padding entry (zero weight, zero scale) -- the step's first action: always staged, always finite
+    f32x4 obs_init;
+    float rem_init[REM > 0 ? REM : 1];
+    int perm_base[4], perm_rem[REM > 0 ? REM : 1];
+    float pen, lin_w, ksum, flip_th, T, invT, invM, sM, sB, act_mag;
+    bool ang_is_col1, use_min;
+    int g;
+
+    __device__ __forceinline__ void load(const FastRolloutArgs& a, int lane) {
+        const int j = lane & 15;
+        g = lane >> 4;
+        sM = a.m_scale;
+        sB = a.b_scale;
+        float m[8];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = 4 * g + s;
+            m[s] = a.Mp[k * CT4 + j] * sM;
+#pragma unroll
+            for (int r = 0; r < REM; ++r) wR[r][s] = a.Mp[k * CT4 + 16 + r];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = 4 * q + g;
+            const bool valid = q < NKX && e < NX;
+            const int k = !valid ? ZROW : (e < REM ? 16 + e : OP + (e - REM));
+            m[4 + q] = a.Mp[k * CT4 + j] * ((valid && e >= REM) ? sB : sM);   // an action's row of B, or a state row of A
+            if (q < NKX) {
+#pragma unroll
+                for (int r = 0; r < REM; ++r) wR[r][4 + q] = a.Mp[k * CT4 + 16 + r];
+                is_act[q] = valid && e >= REM;
+                cw[q] = is_act[q] ? a.ctrl_w : 0.f;
+                sc[q] = valid ? (is_act[q] ? 0.f : 1.f / sM) : 0.f;   // (actions: set in load_obs)
+                xoff[q] = valid ? 4 * q : REM - g;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) split_pair_f16(m[2 * p], m[2 * p + 1], aH[p], aL[p]);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) perm_base[v] = a.perm[4 * g + v];
+#pragma unroll
+        for (int r = 0; r < REM; ++r) perm_rem[r] = a.perm[16 + r];
+        pen = (a.flip_col >= 0 && g == 0) ? a.flip_pen : 0.f;
+        lin_w = g == 0 ? a.lin_w : 0.f;
+        ang_is_col1 = a.flip_col == 1;
+        ksum = a.cost_mode == 0 ? 1.f : 0.f;
+        use_min = a.cost_mode == 1;
+        flip_th = a.flip_th;
+        act_mag = a.act_mag;
+    }
+
+    // obs: 32 floats in LDS (natural order, zeros behind).  Also fixes the launch's power-of-two scale S.
+    __device__ __forceinline__ void load_obs(const float* obs) {
+        const int lane = (int)(threadIdx.x & 63);
+        float mx = __builtin_fabsf(obs[lane & 31]);
+        mx = mx != mx ? 0.f : mx;   // (a NaN observation poisons every cost anyway: keep S finite)
+        // max over the wave: non-negative floats order like their bit patterns
+        const unsigned mb = ~wave_min_u32(~__float_as_uint(mx));
+        float mm = __uint_as_float(mb);
+        mm = mm > act_mag ? mm : act_mag;
+        if (KIND == 1) mm = mm > 1.f ? mm : 1.f;
+        int ex = (int)((__float_as_uint(mm) >> 23) & 0xFF) - 127;   // 2^ex <= mm < 2^(ex+1); mm == 0 or subnormal: -127
+        ex = ex < -100 ? -100 : (ex > 100 ? 100 : ex);
+        // (wave-uniform values: pinned to scalar registers -- this tile lives on the 128 registers a wave has at four per SIMD)
+        auto uni = [](float x) { return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(x))); };
+        const float S = __uint_as_float((unsigned)(127 + 4 - ex) << 23);   // the B operand's scale: S x in [16, 32) at most
+        T = uni(S * sM);                                                    // the accumulators' (and the kept state's): S sM x
+        invT = uni(__uint_as_float((unsigned)(127 - 4 + ex) << 23) / sM);
+        invM = uni(1.f / sM);
+        flip_th = uni(flip_th);
+        ksum = uni(ksum);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            int pb = perm_base[v];
+            asm volatile("" : "+v"(pb));
+            obs_init[v] = obs[pb] * T;
+        }
+#pragma unroll
+        for (int r = 0; r < REM; ++r) {
+            int pb = perm_rem[r];
+            asm volatile("" : "+v"(pb));
+            rem_init[r] = obs[pb] * T;
+        }
+        flip_th *= T;
+        lin_w *= invT;
+#pragma unroll
+        for (int q = 0; q < NKX; ++q) {
+            if (is_act[q]) {
+                sc[q] = T / sB;   // (B sB) x (a T / sB) = T B a: the action's contribution at the accumulators' scale
+#pragma unroll
+                for (int r = 0; r < REM; ++r) wR[r][4 + q] *= T;
+            }
+        }
+    }
+
+    __device__ __forceinline__ const float* read_ptr(const float* buf, int lane, int stride) const {
+        return buf + SLACK + (lane & 15) * stride + ((lane >> 4) - REM);
+    }
+
+    struct State {
+        f32x4 cur[1];                    // T x the lane's four tile columns (T = S sM, the accumulators' scale)
+        float xr[REM > 0 ? REM : 1];     // T x column 16 + r
+        float acc_s, acc_b;
+    };
+    __device__ __forceinline__ void init(State& st) const {
+        st.cur[0] = obs_init;
+#pragma unroll
+        for (int r = 0; r < REM; ++r) st.xr[r] = rem_init[r];
+        st.acc_s = 0.f;
+        st.acc_b = INFINITY;
+    }
+    __device__ __forceinline__ void step(State& st, const float* rd) const {
+        float xv[NKX];
+#pragma unroll
+        for (int q = 0; q < NKX; ++q) {
+            float v = rd[xoff[q]];   // an action, a padding entry's finite stand-in, or (a state entry's lane) anything: replaced
+#pragma unroll
+            for (int r = 0; r < REM; ++r)
+                if (r / 4 == q) v = (g == r % 4) ? st.xr[r] : v;
+            xv[q] = v;
+        }
+        // step cost (Tile16's, on the scaled state: flip_th and lin_w carry S).  [ang > th] + [ang < -th] = [|ang| > th]
+        // for th >= 0 (update_paths keeps handles with a negative threshold on the exact tile)
+        const float ang = ang_is_col1 ? st.cur[0][1] : st.cur[0][0];
+        float c = (__builtin_fabsf(ang) > flip_th) ? pen : 0.f;
+#pragma unroll
+        for (int q = 0; q < NKX; ++q) c = __builtin_fmaf(xv[q] * xv[q], cw[q], c);
+        c = __builtin_fmaf(lin_w, st.cur[0][0], c);
+        float pr[REM > 0 ? REM : 1];
+#pragma unroll
+        for (int r = 0; r < REM; ++r) {
+            float p = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) p = __builtin_fmaf(st.cur[0][s], wR[r][s], p);
+#pragma unroll
+            for (int q = 0; q < NKX; ++q) p = __builtin_fmaf(xv[q], wR[r][4 + q], p);
+            pr[r] = p;
+        }
+        if (REM >= 1)
+            reduce_groups_pair(pr[0], c);
+        else
+            c = reduce_groups(c);
+#pragma unroll
+        for (int r = 1; r < REM; ++r) pr[r] = reduce_groups(pr[r]);
+        st.acc_s = __builtin_fmaf(st.acc_s, ksum, c);
+        st.acc_b = __builtin_fminf(c, st.acc_b);   // (a NaN step cost is skipped, as by Tile16's compare)
+        // the B operand planes: own columns, then the extras (x their scale)
+        unsigned bH[4], bL[4];
+        split_pair_f16_scaled(st.cur[0][0], invM, st.cur[0][1], invM, bH[0], bL[0]);
+        split_pair_f16_scaled(st.cur[0][2], invM, st.cur[0][3], invM, bH[1], bL[1]);
+        if (NKX >= 2) split_pair_f16_scaled(xv[0], sc[0], xv[NKX >= 2 ? 1 : 0], sc[NKX >= 2 ? 1 : 0], bH[2], bL[2]);
+        else split_pair_f16_scaled(xv[0], sc[0], 0.f, 0.f, bH[2], bL[2]);
+        if (NKX == 4) split_pair_f16_scaled(xv[NKX > 2 ? 2 : 0], sc[NKX > 2 ? 2 : 0], xv[NKX > 3 ? 3 : 0], sc[NKX > 3 ? 3 : 0], bH[3], bL[3]);
+        else if (NKX == 3) split_pair_f16_scaled(xv[NKX > 2 ? 2 : 0], sc[NKX > 2 ? 2 : 0], 0.f, 0.f, bH[3], bL[3]);
+        else bH[3] = bL[3] = 0u;
+        f32x4 nxt = f32x4{0.f, 0.f, 0.f, 0.f};
+        nxt = mfma_f16_32(aL, bH, nxt);
+        nxt = mfma_f16_32(aH, bL, nxt);
+        nxt = mfma_f16_32(aH, bH, nxt);
+        if (KIND == 1) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) st.cur[0][v] = fast_tanh(nxt[v] * invT) * T;
+#pragma unroll
+            for (int r = 0; r < REM; ++r) st.xr[r] = fast_tanh(pr[r] * invT) * T;
+        } else {
+            st.cur[0] = nxt;
+#pragma unroll
+            for (int r = 0; r < REM; ++r) st.xr[r] = pr[r];
+        }
+    }
+    __device__ __forceinline__ float cost(const State& st) const {
+        const float v = use_min ? st.acc_b : st.acc_s;
+        if (REM == 0) return v;
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return __uint_as_float(r[1]);
+    }
+};
+
+// which tile a kernel instantiation rolls out with: ARITH 0 = Tile16 (exact f32), 1 = Tile16H where it exists (one output tile)
+template <int H, int D, int O, int KIND, int ARITH>
+struct TileSel { using type = Tile16<H, D, O, KIND>; };
+template <int H, int D, int O, int KIND>
+struct TileSel<H, D, O, KIND, 1> {
+    using type = typename std::conditional<(O <= 20), Tile16H<H, D, (O <= 20 ? O : 17), KIND>, Tile16<H, D, O, KIND>>::type;
+};
+
 // ---- Tile4: the same model step on the VALU, FOUR trajectories per wavefront ----------------------------------------
 // For small populations (fewer 16-trajectory tiles than SIMDs) the rollout is a latency chain, and Tile16's chain is
 // long: six DEPENDENT f32 MFMAs per step (40 cycles each) plus ~35 VALU for a lone wave = ~410 cycles.  Here a row of
@@ -1406,9 +1668,9 @@ __device__ __forceinline__ unsigned long long rollout_slab(Tile& tile, const Fas
 // registers), into its own LDS staging buffer; each lane then reads the one or two entries it feeds to the MFMAs.
 // Only this wave touches the buffer and a wave's LDS operations execute in order: no barriers.  Shared by
 // rollout16_kernel (k_rollout.hip) and rollout16_ahead_kernel (k_rollout_ahead.hip).
-template <int H, int D, int O, int KIND>
+template <int H, int D, int O, int KIND, int ARITH = 0>
 struct Stream16 {
-    using Tile = Tile16<H, D, O, KIND>;
+    using Tile = typename TileSel<H, D, O, KIND, ARITH>::type;
     static constexpr int HD = H * D;
     static constexpr int VW = HD % 4 == 0 ? 4 : 2;    // floats per load: rows are 16-byte aligned only if h*d % 4 == 0
     static_assert(HD % 2 == 0, "8-byte aligned action rows");

@@ -97,6 +97,14 @@ struct icem_handle {
                                  // model + cost (wide observations; icem_cost_terms; a cost without its linear term; a shape
                                  // (h, d, O) that is not compiled): the f32 rollout is then the GEMM kernel at ANY width.
                                  // Kept current by update_paths() (abi.hip) behind every model / cost setter.
+    // arithmetic of the tile kernels' model step (icem_set_tile_arith): mode -1 = by configuration, 0 = exact f32, 1 = fp16 planes;
+    // tile_arith = what the handle's launches use (update_paths: mode + whether Tile16H serves this model)
+    int tile_arith_mode = -1;
+    int tile_arith = 0;
+    float tile_m_scale = 1.f, tile_b_scale = 1.f;   // FastRolloutArgs::m_scale / b_scale (update_paths)
+    float act_mag = 1.f;         // max(|low|, |high|) of the action bounds last seen (FastRolloutArgs::act_mag), from ...
+    const void* am_lo = nullptr; // ... this (low, high) buffer pair
+    const void* am_hi = nullptr;
     void* Mw_dev = nullptr;      // its packed model
     void* Mws_dev = nullptr;     // ... as three bf16 planes (k_rollout_wide_split.hip) ...
     void* Mwh_dev = nullptr;     // ... and as two fp16 planes of the model x 2^k, Mwh_inv = 2^-k: the default wide rollout

@@ -76,6 +76,12 @@ struct FastRolloutArgs {
     unsigned long long* part_k;  // ... or, if not null, their packed keys, key r of workgroup w at [r * grid + w]
     int list_wgs = 0;   // > 0: only the first list_wgs workgroups emit a list (sample_rollout_lists' tail rows)
     long long* dbg;  // development: [waves, 8] cycle stamps, nullptr in production
+    // which arithmetic the model step of the 16-trajectory tile runs in (icem_set_tile_arith; fused_dev.h):
+    // 0 = v_mfma_f32_16x16x4_f32, bitwise an fmaf chain (Tile16; Tile4 is its VALU twin); 1 = two fp16 planes of every f32
+    // operand, three products per multiply-add on v_mfma_f32_16x16x32_f16 (Tile16H; one-tile observation widths only)
+    int arith = 0;
+    float act_mag = 1.f;   // arith 1: magnitude of the action bounds, max(|low|, |high|) -- with |obs0| it fixes the launch's scale
+    float m_scale = 1.f, b_scale = 1.f;   // arith 1: powers of two that put the largest |entry| of A / of B into [64, 128)
 };
 bool fast_rollout_supported(int h, int d, int O, int K);
 void launch_rollout16(const FastRolloutArgs& a, int h, int d, int O, int kind, hipStream_t st);
@@ -252,6 +258,7 @@ struct IterAheadArgs {
     // as in sample_folded_merge_kernel); the rollout workgroups wait for that flag instead of merging themselves
     PackPrev p;
     int n_roll, n_noise;  // workgroups per role (filled by the launcher)
+    int dbg_slot = 0;     // development: which 16-word block of r.dbg this launch stamps (the iteration)
 };
 bool rollout_ahead_ok(int h, int d, int O, int K, int n_rows);
 int ahead_roll_workgroups(int n_rows);  // = candidate lists of that launch

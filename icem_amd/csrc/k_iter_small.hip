@@ -31,15 +31,17 @@ namespace {
 constexpr bool sr_quad(int d, int rw) { return rw <= 2 && ((4 * 16 * rw * d + 63) / 64) * 64 + 64 <= 1024; }
 constexpr int sr_threads(int d, int rw) { return (((sr_quad(d, rw) ? 4 : 1) * 16 * rw * d + 63) / 64) * 64; }
 
-template <int H, int D, int O, int KIND, int ROUNDS, int RW, int KREG, bool REC>
+// ARITH (FastRolloutArgs::arith): 1 = the model step on the 16-bit matrix cores (Tile16H) -- there is no VALU twin of
+// that arithmetic, so the slab is rolled out by RW waves of Tile16H whatever the sampling shape.
+template <int H, int D, int O, int KIND, int ROUNDS, int RW, int KREG, bool REC, int ARITH>
 __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sample_rollout_kernel(FastIterArgs a) {
     constexpr bool PM = KREG > 0;
     constexpr bool QS = sr_quad(D, RW);
     // T4: with quad sampling there are >= 4 * RW wavefronts in the workgroup anyway: the rollout runs on Tile4 (VALU +
     // DPP row broadcast, four trajectories per wave, 4 * RW waves) instead of Tile16 (RW waves): same bits, a shorter
     // latency chain per model step
-    constexpr bool T4 = QS && O <= 20 && sr_threads(D, RW) >= 256 * RW;
-    using T16 = Tile16<H, D, O, KIND>;
+    constexpr bool T4 = QS && O <= 20 && sr_threads(D, RW) >= 256 * RW && ARITH == 0;
+    using T16 = typename TileSel<H, D, O, KIND, ARITH>::type;
     using Tile = typename std::conditional<T4, Tile4<H, D, (O <= 20 ? O : 17), KIND>, T16>::type;
     constexpr int RWV = T4 ? 4 * RW : RW;            // rollout wavefronts
     constexpr int HD = H * D;
@@ -416,10 +418,19 @@ void launch_sample_rollout(const FastIterArgs& a, int h, int d, int O, int kind,
 #define XK(HH, DD, OO, WW, KR, RC)                                                                                      \
     {                                                                                                                   \
         constexpr int NT = sr_threads(DD, WW) + (KR > 0 ? 64 : 0);                                                     \
+        if constexpr (OO <= 20) {                                                                                       \
+            if (a.r.arith == 1) {                                                                                       \
+                if (kind == 1)                                                                                          \
+                    hipLaunchKernelGGL((sample_rollout_kernel<HH, DD, OO, 1, 10, WW, KR, RC, 1>), dim3(grid), dim3(NT), 0, st, a); \
+                else                                                                                                    \
+                    hipLaunchKernelGGL((sample_rollout_kernel<HH, DD, OO, 0, 10, WW, KR, RC, 1>), dim3(grid), dim3(NT), 0, st, a); \
+                return;                                                                                                 \
+            }                                                                                                           \
+        }                                                                                                               \
         if (kind == 1)                                                                                                  \
-            hipLaunchKernelGGL((sample_rollout_kernel<HH, DD, OO, 1, 10, WW, KR, RC>), dim3(grid), dim3(NT), 0, st, a); \
+            hipLaunchKernelGGL((sample_rollout_kernel<HH, DD, OO, 1, 10, WW, KR, RC, 0>), dim3(grid), dim3(NT), 0, st, a); \
         else                                                                                                            \
-            hipLaunchKernelGGL((sample_rollout_kernel<HH, DD, OO, 0, 10, WW, KR, RC>), dim3(grid), dim3(NT), 0, st, a); \
+            hipLaunchKernelGGL((sample_rollout_kernel<HH, DD, OO, 0, 10, WW, KR, RC, 0>), dim3(grid), dim3(NT), 0, st, a); \
         return;                                                                                                         \
     }
 #define XW(HH, DD, OO, WW)                                                   \

@@ -6,10 +6,10 @@ namespace icem {
 
 namespace {
 
-template <int H, int D, int O, int KIND, int WAVES>
+template <int H, int D, int O, int KIND, int WAVES, int ARITH>
 __global__ __launch_bounds__(64 * WAVES) void rollout16_kernel(FastRolloutArgs a) {
-    using Tile = Tile16<H, D, O, KIND>;
-    using Stream = Stream16<H, D, O, KIND>;
+    using Stream = Stream16<H, D, O, KIND, ARITH>;
+    using Tile = typename Stream::Tile;
     __shared__ __attribute__((aligned(16))) float stage[WAVES][Stream::STG];
     __shared__ unsigned long long wg_keys[2][WAVES][32];
     __shared__ float obs_stage[32];
@@ -64,15 +64,23 @@ void launch_rollout16(const FastRolloutArgs& a, int h, int d, int O, int kind, h
     // two output tiles (O > 20): a 16-wave workgroup's 128 registers spill ~100 of the two-tile step's; at most 8 waves per
     // workgroup (256 registers, no spills), each taking its tiles one after the other (EXPERIMENTS.md R4.6)
     if (O > 20 && waves > 8) waves = 8;
-#define XW(HH, DD, OO, WW)                                                                                      \
-    if constexpr (OO <= 20 || WW <= 8) {                                                                        \
-        if (waves == WW) {                                                                                      \
-            if (kind == 1)                                                                                      \
-                hipLaunchKernelGGL((rollout16_kernel<HH, DD, OO, 1, WW>), dim3(grid), dim3(64 * WW), 0, st, a); \
-            else                                                                                                \
-                hipLaunchKernelGGL((rollout16_kernel<HH, DD, OO, 0, WW>), dim3(grid), dim3(64 * WW), 0, st, a); \
-            return;                                                                                             \
+#define XA(HH, DD, OO, KK, WW)                                                                                  \
+    {                                                                                                           \
+        if constexpr (OO <= 20) {                                                                               \
+            if (a.arith == 1) {                                                                                 \
+                hipLaunchKernelGGL((rollout16_kernel<HH, DD, OO, KK, WW, 1>), dim3(grid), dim3(64 * WW), 0, st, a); \
+                return;                                                                                         \
+            }                                                                                                   \
         }                                                                                                       \
+        hipLaunchKernelGGL((rollout16_kernel<HH, DD, OO, KK, WW, 0>), dim3(grid), dim3(64 * WW), 0, st, a);     \
+        return;                                                                                                 \
+    }
+#define XW(HH, DD, OO, WW)                     \
+    if constexpr (OO <= 20 || WW <= 8) {       \
+        if (waves == WW) {                     \
+            if (kind == 1) XA(HH, DD, OO, 1, WW) \
+            else XA(HH, DD, OO, 0, WW)         \
+        }                                      \
     }
 #define XR(HH, DD, OO)                   \
     if (h == HH && d == DD && O == OO) { \
@@ -85,6 +93,7 @@ void launch_rollout16(const FastRolloutArgs& a, int h, int d, int O, int kind, h
     ICEM_FAST_SHAPES(XR)
 #undef XR
 #undef XW
+#undef XA
 }
 
 }  // namespace icem

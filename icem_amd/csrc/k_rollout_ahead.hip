@@ -27,7 +27,7 @@ constexpr int AHEAD_KREG = 12;
 // LDS of a workgroup (dynamic, one buffer overlaid by the three roles), in floats
 template <int H, int D, int O, int KIND, int WAVES>
 struct AheadLds {
-    using Stream = Stream16<H, D, O, KIND>;
+    using Stream = Stream16<H, D, O, KIND>;   // (the staging layout is the same for every tile arithmetic)
     using T16 = Tile16<H, D, O, KIND>;
     static constexpr int HD = H * D, NT = 64 * WAVES;
     // rollout role
@@ -55,10 +55,11 @@ struct AheadLds {
 //  fifth wave per SIMD -- spills 32 registers in the rollout role: measured 220 instead of 185 us per MPC step at N = 65 536)
 // PM: 0 = no merge (iteration 0), 1 = lists merge in every rollout workgroup's prologue, 2 = sharded: pack role + published
 // records merge
-template <int H, int D, int O, int KIND, int WAVES, int PM>
+template <int H, int D, int O, int KIND, int WAVES, int PM, int ARITH>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8))) void iter_ahead_kernel(IterAheadArgs args) {
-    using Tile = Tile16<H, D, O, KIND>;
-    using Stream = Stream16<H, D, O, KIND>;
+    using Stream = Stream16<H, D, O, KIND, ARITH>;
+    using Tile = typename Stream::Tile;
+    static_assert(Tile::SLACK == Tile16<H, D, O, KIND>::SLACK && Tile::TAIL == Tile16<H, D, O, KIND>::TAIL, "one staging layout");
     using L = AheadLds<H, D, O, KIND, WAVES>;
     constexpr int HD = H * D, NTT = 64 * WAVES, KREG = AHEAD_KREG;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -127,10 +128,20 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
             return;
         }
     }
-    const int bid = (int)blockIdx.x - (PM == 2 ? 1 : 0);  // workgroup number behind the pack role
+    // workgroup order: [pack (PM == 2)] [shift (iteration 0)] [rollout x n_roll] [noise x n_noise].  The shift workgroup is
+    // the launch's longest chain of ONE wave (three rows sampled by single lanes, then 30 steps of a lone wave: ~12 us) and
+    // used to be dispatched LAST, behind every noise workgroup -- it started 22 us into the launch and ended 10 us after the
+    // last rollout workgroup (stamps: EXPERIMENTS R5.2).  First in line it ends long before them.
+    const bool has_shift = args.s.n_shift > 0;
+    const int raw = (int)blockIdx.x - (PM == 2 ? 1 : 0);
+    const bool is_shift = has_shift && raw == 0;
+    const int bid = is_shift ? n_roll + args.n_noise : raw - (has_shift ? 1 : 0);  // workgroup number within [rollout | noise | shift]
     // ------------------------------------------------------------------------------------------------ noise role
     if (bid >= n_roll && bid < n_roll + args.n_noise) {
         const FastSampleArgs& z = args.z;
+        long long* zs = (args.r.dbg && tid == 0 && (bid == n_roll || bid == n_roll + args.n_noise - 1))
+                            ? args.r.dbg + 16 + 32 * args.dbg_slot + (bid == n_roll ? 20 : 24) : nullptr;
+        if (zs) zs[0] = wall_clock64();
         float* tile = smem;  // [TPW, HD]
         const int n_base = (bid - n_roll) * L::TPW;
         const int n_here = cmin(L::TPW, z.n - n_base);
@@ -141,7 +152,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
             sample_row<H, 10>(z.W, (unsigned)(z.first_index + n_base + nl), (unsigned)j, z.off_lo, z.off_hi, z.seed_lo, z.seed_hi,
                               [&](int t, float y) { trow[t * D] = y; }, z.white != 0);
         }
+        if (zs) zs[2] = wall_clock64();
         __syncthreads();
+        if (zs) zs[3] = wall_clock64();
         float* gdst = z.out + (size_t)n_base * HD;
         const int total = n_here * HD;
         if constexpr ((HD & 3) == 0) {
@@ -153,6 +166,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
             float2* g2 = reinterpret_cast<float2*>(gdst);
             for (int e = tid; e < total / 2; e += NTT) g2[e] = t2[e];
         }
+        if (zs) zs[1] = wall_clock64();
         return;
     }
     const FastRolloutArgs& a = args.r;
@@ -162,6 +176,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
         // (only t = h-1 is used, icem.py:102) -> pool rows [n, n + n_shift) and a 16-row LDS tile; then one wave rolls the
         // tile out (Tile16: the bits the rollout role would produce for these rows) -> costs [n, n + n_shift)
         const FastSampleArgs& s = args.s;
+        long long* ss = (a.dbg && tid == 0) ? a.dbg + 16 + 32 * args.dbg_slot + 16 : nullptr;
+        if (ss) ss[0] = wall_clock64();
         float* ms = smem + L::SH_DIST;
         float* tilebuf = smem + L::SH_TILE;
         float* obs_stage = tilebuf + Tile::SLACK + 16 * HD + Tile::TAIL;
@@ -208,6 +224,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
             ta.costs = a.costs + s.n;
             (void)rollout_slab<Tile, H, D>(tile, ta, tile.read_ptr(tilebuf, lane, HD), lane & 15, s.n_shift, KEY_SENTINEL, true, lane);
         }
+        if (ss) ss[1] = wall_clock64();
         return;
     }
     // ------------------------------------------------------------------------------------------------ rollout role
@@ -220,6 +237,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
     unsigned long long* wsel = reinterpret_cast<unsigned long long*>(smem + L::WSEL);
     int* slot = reinterpret_cast<int*>(smem + L::SLOT);
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(stage) + wave * 64;  // this wave's compaction scratch
+    // development (icem_debug_stamps + ICEM_AHEAD_STAMPS=1; tools/dbg/ahead_stamps.py): wall_clock64 phase stamps of thread 0
+    // of the first and the last rollout workgroup, [16 + 32 x iteration]: [2][8], then entry / exit of the shift workgroup and of the last and the first noise workgroup; a.dbg == nullptr in production
+    // (slots 16 + 32 x iteration: the merge kernels stamp the first eight words)
+    long long* stamps = (a.dbg && tid == 0 && (bid == 0 || bid == n_roll - 1)) ? a.dbg + 16 + 32 * args.dbg_slot + (bid == 0 ? 0 : 8) : nullptr;
+    if (stamps) stamps[0] = wall_clock64();
     // model operands and start observation in flight in front of the merge
     const float obs_reg = a.obs0[(tid < 32 && tid < a.o) ? tid : 0];
     Tile tile;
@@ -238,7 +260,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
         if (by_rank) merge_select_split_keep<WAVES>(args.m, lane, wave, wsel, sel, keep_cost);
         // (this wave's first noise vectors: requested behind its keys, in flight across the barriers below)
         if (tile0 < tiles) stream.first_loads(args.pool, a.n_rows, tile0, pre);
+        if (stamps) stamps[1] = wall_clock64();
         __syncthreads();
+        if (stamps) stamps[2] = wall_clock64();
         if (by_rank) merge_select_split_rank<WAVES>(args.m, lane, wave, wsel, sel);
         else if (wave == 0) merge_select_split_stage2(args.m, lane, WAVES, wsel, cand, sel, keep_cost);
     } else if constexpr (PM == 2) {
@@ -261,6 +285,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
     }
     if (tid < 32) obs_stage[tid] = tid < a.o ? obs_reg : 0.f;
     __syncthreads();
+    if (stamps) stamps[3] = wall_clock64();
     if constexpr (PM == 2) {
         for (int e = tid; e < 2 * HD; e += NTT) dist[e] = __hip_atomic_load(args.p.pub + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
@@ -296,6 +321,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
         if (bid == 0 && tid < m.K) m.elites_cost_next[tid] = key_cost(sel[tid]);
         __syncthreads();
     }
+    if (stamps) stamps[4] = wall_clock64();
     tile.load_obs(obs_stage);
     unsigned long long run_key = KEY_SENTINEL;
     bool first = true;
@@ -303,9 +329,12 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
     for (int tile_id = tile0; tile_id < tiles; tile_id += WAVES * n_roll) {
         if (!first) stream.first_loads(args.pool, a.n_rows, tile_id, pre);
         run_key = stream.run_xf(tile, a, args.pool, args.n_xf, args.row0_mean != 0, args.store_back != 0, dist, args.lo, args.hi, tile_id, lane, run_key, first, pre);
+        if (stamps && first) stamps[5] = wall_clock64();
         first = false;
     }
+    if (stamps) stamps[6] = wall_clock64();
     if (a.K > 0) wg_merge_emit<WAVES>(wg_keys, run_key, a.K, lane, wave, a, bid, n_roll);
+    if (stamps) stamps[7] = wall_clock64();
 }
 
 // Launch shape of the rollout role: rollout16's (one 16-trajectory tile per wave while they fit, at most FAST_MAX_LISTS
@@ -346,7 +375,10 @@ void launch_iter_ahead(const IterAheadArgs& a_in, int h, int d, int O, int kind,
         using L = AheadLds<HH, DD, OO, KK, WW>;                                                                            \
         a.n_noise = a.z.n > 0 ? (a.z.n + L::TPW - 1) / L::TPW : 0;                                                         \
         const int total = grid + a.n_noise + (a.s.n_shift > 0 ? 1 : 0) + (PP == 2 ? 1 : 0);                                \
-        hipLaunchKernelGGL((iter_ahead_kernel<HH, DD, OO, KK, WW, PP>), dim3(total), dim3(64 * WW), L::FLOATS * sizeof(float), st, a); \
+        if (a.r.arith == 1)                                                                                                \
+            hipLaunchKernelGGL((iter_ahead_kernel<HH, DD, OO, KK, WW, PP, 1>), dim3(total), dim3(64 * WW), L::FLOATS * sizeof(float), st, a); \
+        else                                                                                                               \
+            hipLaunchKernelGGL((iter_ahead_kernel<HH, DD, OO, KK, WW, PP, 0>), dim3(total), dim3(64 * WW), L::FLOATS * sizeof(float), st, a); \
     }
 #define XW(HH, DD, OO, WW)                          \
     if (waves == WW) {                              \

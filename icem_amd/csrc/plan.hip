@@ -147,7 +147,20 @@ FastRolloutArgs fast_rollout_args(const icem_handle* h, int n_rows, int n_cand, 
     a.part_i = part_i;
     a.part_k = nullptr;
     a.dbg = h->dbg;
+    a.arith = h->tile_arith;
+    a.act_mag = h->act_mag;
+    a.m_scale = h->tile_m_scale;
+    a.b_scale = h->tile_b_scale;
     return a;
+}
+
+// workgroups (= candidate lists) of the single-launch kernel for this handle, 0 where it has none.  (Its small slabs roll out on
+// Tile4, the VALU twin of the EXACT tile; a handle whose tile arithmetic is the fp16 planes gets the kernel's Tile16H
+// instantiation instead -- one arithmetic per handle, whatever a launch's row count.)
+static int one_launch_lists(const icem_handle* h, int n_rows, int n_tail = 0, int* tail_out = nullptr) {
+    if (tail_out) *tail_out = 0;
+    const icem_config& c = h->cfg;
+    return sample_rollout_lists(c.horizon, c.act_dim, h->Of, c.rng_rounds, n_rows, n_tail, tail_out);
 }
 
 // rows -> costs (+ one sorted candidate list per workgroup when K > 0); returns the number of candidate lists
@@ -277,7 +290,7 @@ bool prologue_possible(const icem_handle* h, int n_rows) {
     const icem_config& c = h->cfg;
     const int K = c.num_elites;
     if (c.dtype != ICEM_F32 || !fast_rollout_ok(h, K) || !fast_sample_ok(h) || n_rows <= 0) return false;
-    if (sample_rollout_lists(c.horizon, c.act_dim, h->Of, c.rng_rounds, n_rows) > 0)
+    if (one_launch_lists(h, n_rows) > 0)
         return sample_rollout_merge_ok(c.horizon, c.act_dim, h->Of, c.rng_rounds, n_rows, K);
     return sample_folded_merge_ok(c.horizon, c.act_dim, c.rng_rounds, K);
 }
@@ -322,7 +335,7 @@ int launch_pending_merge(icem_handle* h, hipStream_t st) {
 // will the merge-prologue launch of an iteration with n_rows local rows take the previous iteration's pack along?
 static bool next_launch_takes_pack(const icem_handle* h, int n_rows) {
     const icem_config& c = h->cfg;
-    if (sample_rollout_lists(c.horizon, c.act_dim, h->Of, c.rng_rounds, n_rows) > 0)
+    if (one_launch_lists(h, n_rows) > 0)
         return sample_rollout_pack_ok(c.horizon, c.act_dim, h->Of, c.rng_rounds, n_rows, c.num_elites);
     return sample_folded_pack_ok(c.horizon, c.act_dim, c.rng_rounds, c.num_elites);
 }
@@ -410,8 +423,7 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
             const int n_rows = n_loc + n_extra;
             int tail_rows = 0;  // shifted-elite rows scored through the cost array instead of a list (world 1 only)
             const int one = (fast_sample_ok(h) && (n_extra == 0 || shift_in_sampler))
-                                ? sample_rollout_lists(c.horizon, c.act_dim, h->Of, c.rng_rounds, n_rows,
-                                                       shift_in_sampler ? n_extra : 0, &tail_rows) : 0;
+                                ? one_launch_lists(h, n_rows, shift_in_sampler ? n_extra : 0, &tail_rows) : 0;
             h->fast_tail_rows = one > 0 ? tail_rows : 0;
             // the merge finds the lists' indices behind `lists * K` costs
             split_partial_ws<float>(b->workspace, one > 0 ? one : rollout_lists(c.horizon, c.act_dim, h->Of, n_rows), K, &pc, &pi);
@@ -777,8 +789,10 @@ static bool ahead_eligible(icem_handle* h, const icem_plan_buffers* b, bool shar
         A.min_rows = m ? atoi(m) : 0;
     }
     if (A.disabled || (c.world != 1) != sharded || c.dtype != ICEM_F32 || b->z_r != nullptr || !h->use_fast || gemm_rollout(h) ||
-        c.opt_iters < 2 || h->dbg != nullptr || c.rng_rounds != 10)
+        c.opt_iters < 2 || c.rng_rounds != 10)
         return false;
+    static const int stamps_on = [] { const char* e = getenv("ICEM_AHEAD_STAMPS"); return e ? atoi(e) : 0; }();
+    if (h->dbg != nullptr && !stamps_on) return false;   // (another kernel is under study; ICEM_AHEAD_STAMPS=1: this path's phase stamps)
     if (!fast_rollout_ok(h, c.num_elites) || !fast_sample_ok(h)) return false;
     if (sharded) {
         // peers in processes of their own (the pack rides in the next launch), records that fit the pack's LDS stage and
@@ -860,6 +874,7 @@ static int plan_step_ahead(icem_handle* h, const icem_plan_buffers* b, int mpc_s
         IterAheadArgs ia{};
         ia.r = fast_rollout_args(h, n, n, K, b->obs0, pool, b->costs, nullptr, nullptr);
         ia.r.part_k = (unsigned long long*)bb.workspace;
+        ia.dbg_slot = it;
         ia.has_merge = h->pm_pending ? 1 : 0;
         if (h->pm_pending) ia.m = h->pm_args;
         h->pm_pending = false;
@@ -1133,7 +1148,7 @@ void predraw_next_step(icem_handle* h, const icem_plan_buffers* b, int mpc_step,
     const int n_shift = (c.shift_elites && h->n_reuse > 0) ? h->n_reuse : 0;   // (mpc_step + 1 > 0: the next step shifts)
     if (n_shift * c.act_dim > 256) return;
     int tail_rows = 0;
-    if (sample_rollout_lists(c.horizon, c.act_dim, h->Of, c.rng_rounds, n0 + n_shift, n_shift, &tail_rows) <= 0) return;
+    if (one_launch_lists(h, n0 + n_shift, n_shift, &tail_rows) <= 0) return;
     if (!A.pre_raw && hipMalloc(&A.pre_raw, (size_t)(n0 + h->n_reuse + 16) * h->hd * sizeof(float)) != hipSuccess) {
         (void)hipGetLastError();
         A.pre_raw = nullptr;
@@ -1198,6 +1213,18 @@ static int check_plan(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_st
     if (h->cfg.noise_beta > 0 &&
         ((b->z_r == nullptr) != (b->z_i == nullptr) || (b->z_r_shift == nullptr) != (b->z_i_shift == nullptr)))
         return fail(ICEM_E_INVALID, "z_r/z_i must be given in pairs");
+    // fp16-plane tile arithmetic: the launch's scale needs the action bounds' magnitude -- fetched once per (low, high) pair
+    if (h->tile_arith && (h->am_lo != b->low || h->am_hi != b->high)) {
+        const int d = h->cfg.act_dim;
+        std::vector<float> lo(d), hi(d);
+        ICEM_HIP_TRY(hipMemcpy(lo.data(), b->low, d * sizeof(float), hipMemcpyDeviceToHost));
+        ICEM_HIP_TRY(hipMemcpy(hi.data(), b->high, d * sizeof(float), hipMemcpyDeviceToHost));
+        float m = 0.f;
+        for (int j = 0; j < d; ++j) m = std::max(m, std::max(std::fabs(lo[j]), std::fabs(hi[j])));
+        h->act_mag = (m == m && m < 1e30f) ? m : 1.f;
+        h->am_lo = b->low;
+        h->am_hi = b->high;
+    }
     return ICEM_OK;
 }
 

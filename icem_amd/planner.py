@@ -329,6 +329,18 @@ class IcemPlanner:
         L.check(self.lib.icem_reset_distribution(self._h, _ptr(mean), _ptr(std), _ptr(self.low), _ptr(self.high),
                                                  self._stream()))
 
+    def set_tile_arith(self, mode="auto"):
+        """16 <= padded obs_dim <= 20: the arithmetic of the tile kernels' model step (``icem_set_tile_arith``): ``"f32"`` / 0
+        the exact fmaf chain, ``"f16x2"`` / 1 two fp16 planes per operand on the 16-bit matrix cores, ``"auto"`` / -1 by the
+        configuration's global population.  Returns the arithmetic now in effect (0 / 1)."""
+        m = {"auto": -1, "f32": 0, "f16x2": 1}.get(mode, mode)
+        L.check(self.lib.icem_set_tile_arith(self._h, int(m)))
+        return self.tile_arith
+
+    @property
+    def tile_arith(self):
+        return int(self.lib.icem_tile_arith(self._h))
+
     def set_wide_exact(self, on=True):
         """obs_dim > 32: which arithmetic the model step's GEMM runs in (``icem_set_wide_exact``): ``False`` / 0 the default
         two-way fp16 split on the fp16 matrix cores, ``True`` / 1 the exact-f32 matrix pipe (bitwise an fmaf chain), 2 the

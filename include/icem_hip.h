@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ICEM_ABI_VERSION 2 /* 2: icem_build_hash, icem_allgather_elites / icem_rccl_*, noise-ahead planning; ICEM_MAX_OBS_DIM 384 */
+#define ICEM_ABI_VERSION 3 /* 2: icem_build_hash, icem_allgather_elites / icem_rccl_*, noise-ahead planning; ICEM_MAX_OBS_DIM 384; 3: icem_set_tile_arith */
 
 enum { ICEM_F32 = 0, ICEM_F64 = 1 };
 enum { ICEM_COST_SUM = 0, ICEM_COST_BEST = 1, ICEM_COST_FINAL = 2 }; /* abstract_controller.py:82-87 */
@@ -400,6 +400,27 @@ int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step,
  * magnitudes, dropped products below 2^-31), at two thirds of the speed; 1: v_mfma_f32_16x16x4_f32, bitwise an fmaf chain, at a quarter of the speed.  Takes effect at the
  * next rollout; no effect at obs_dim <= 32.  Other values: ICEM_E_INVALID. */
 int icem_set_wide_exact(icem_handle* h, int32_t on);
+
+/* Narrow observations (the 16-trajectory tile kernels, 16 <= padded obs_dim <= 20: HalfCheetah's o = 17 / 18): which
+ * arithmetic the model step (abstract_models.py:17-26's predict) runs in.
+ *   ICEM_TILE_F32 (0): v_mfma_f32_16x16x4_f32 -- bitwise an f32 fmaf chain; the single-launch kernel of small populations
+ *     runs the same chain on the VALU, so every launch shape gives the same bits.
+ *   ICEM_TILE_F16X2 (1): every f32 operand x S (S one power of two per launch, from max(|obs0|, action bound)) as the sum
+ *     of two fp16 numbers, three fp16 products per multiply-add with f32 accumulation on v_mfma_f32_16x16x32_f16 -- f32-class
+ *     rounding (operands to 2^-24 relative down to 2^-7 of the largest, 2^-29 of the largest below), a quarter of the
+ *     matrix-pipe time of the exact form; NOT the bits of an fmaf chain.  A state that grows beyond 2^11 x max(|obs0|,
+ *     action bound) inside the horizon leaves fp16's range: that trajectory's cost is reported as NaN and ranks last.
+ *     Served for models whose largest |entry| lies in [2^-4, 2^4]; other models silently keep the exact form
+ *     (icem_tile_arith tells which one a handle's launches use).
+ *   ICEM_TILE_AUTO (-1, the default): F16X2 where it is served and EVERY iteration's GLOBAL population (icem_population_sizes)
+ *     exceeds ICEM_TILE_SPLIT_MIN_ROWS -- the populations whose rollout is bound by the f32 pipe; F32 below.  Decided from
+ *     the configuration alone: every rank of a sharded run and every iteration of a decaying population computes in
+ *     the same arithmetic.  Strict-parity callers pass ICEM_TILE_F32.
+ * Takes effect at the next launch (not between icem_plan_iter_local and its merge).  No reference counterpart. */
+enum { ICEM_TILE_AUTO = -1, ICEM_TILE_F32 = 0, ICEM_TILE_F16X2 = 1 };
+#define ICEM_TILE_SPLIT_MIN_ROWS 8192
+int icem_set_tile_arith(icem_handle* h, int32_t mode);
+int icem_tile_arith(const icem_handle* h); /* the arithmetic in effect: ICEM_TILE_F32 or ICEM_TILE_F16X2 */
 
 /* ---- per-kernel timing (measurement only) ------------------------------------------------- */
 enum {

@@ -63,7 +63,7 @@ class DeviceNormals:
         return z_r, z_i
 
 
-def _make(N, iters, h, d, o, kind, beta, seed, env_kind, cost_mode="sum"):
+def _make(N, iters, h, d, o, kind, beta, seed, env_kind, cost_mode="sum", arith=None):
     from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env, humanoid_standup_env
     env = halfcheetah_env(o) if env_kind == "halfcheetah" else humanoid_standup_env(o)
     model = DeviceSyntheticModel.make(o, d, kind=kind)
@@ -73,6 +73,8 @@ def _make(N, iters, h, d, o, kind, beta, seed, env_kind, cost_mode="sum"):
                                     noise_beta=beta, cost_mode=cost_mode), env.action_space.low, env.action_space.high)
         pl.set_model(model.kind, model.A, model.B)
         pl.set_cost_spec(env.cost_spec)
+        if arith is not None:   # icem_set_tile_arith: 0 = the exact f32 tile, 1 = fp16 planes (None: by the configuration)
+            assert pl.set_tile_arith(arith) == arith
         pl.reset()
         return pl
     oc = O.CostSpec.halfcheetah(o) if env_kind == "halfcheetah" else O.CostSpec.humanoid_standup()
@@ -100,6 +102,20 @@ def test_full_loop_at_benchmark_size_against_oracle_on_device_normals(N, iters, 
     _full_loop(N, iters, h, d, o, kind, beta, env_kind, seed, "sum")
 
 
+# The tile arithmetic (icem_set_tile_arith) at the same bar.  c4 above runs on the fp16 planes by default (every global
+# population > 8192 rows); here: c4 on the exact tile, the tanh model and the o = 18 shape on the planes at that size, and
+# the headline population forced onto the planes (its single-launch kernel then rolls out on Tile16H).
+@pytest.mark.parametrize("N,iters,o,kind,arith,mode,seed", [
+    pytest.param(65536, 5, 17, 0, 0, "sum", 1234, id="c4_exact_tile"),
+    pytest.param(65536, 3, 17, 1, 1, "sum", 11, id="c4_tanh_fp16_planes"),
+    pytest.param(40000, 3, 18, 0, 1, "best", 12, id="o18_fp16_planes_best"),
+    pytest.param(4096, 5, 17, 0, 1, "sum", 1234, id="c2_fp16_planes"),
+    pytest.param(4096, 3, 17, 1, 1, "final", 13, id="c2_tanh_fp16_planes_final"),
+])
+def test_full_loop_in_each_tile_arithmetic(N, iters, o, kind, arith, mode, seed):
+    _full_loop(N, iters, 30, 6, o, kind, 0.25, "halfcheetah", seed, mode, arith=arith)
+
+
 @pytest.mark.parametrize("cost_mode", ["best", "final"])
 def test_full_loop_at_benchmark_size_best_and_final(cost_mode):
     """cost_along_trajectory = "best" / "final" (abstract_controller.py:82-87) through the WHOLE loop at the headline
@@ -108,8 +124,8 @@ def test_full_loop_at_benchmark_size_best_and_final(cost_mode):
     _full_loop(4096, 5, 30, 6, 17, 1, 0.25, "halfcheetah", 21, cost_mode)
 
 
-def _full_loop(N, iters, h, d, o, kind, beta, env_kind, seed, cost_mode):
-    env, model, oc, mk = _make(N, iters, h, d, o, kind, beta, seed, env_kind, cost_mode)
+def _full_loop(N, iters, h, d, o, kind, beta, env_kind, seed, cost_mode, arith=None):
+    env, model, oc, mk = _make(N, iters, h, d, o, kind, beta, seed, env_kind, cost_mode, arith)
     om = O.SyntheticModel(model.A, model.B, model.kind)
     split, fused, rng = mk(), mk(), mk()
     noise = DeviceNormals(rng, iters)

@@ -15,10 +15,14 @@ LIMIT = 8
 
 # pattern of the demangled kernel name -> (spilled VGPRs allowed, why)
 ALLOWED = [
-    (r"sample_rollout_kernel<\d+, \d+, \d+, [01], 10, 2, 12, false>", 60,
+    (r"sample_rollout_kernel<\d+, \d+, \d+, [01], 10, 2, 12, false, [01]>", 60,
      "two-tile slabs of the single-launch kernel (8k-16k rows): its selection wave spills; measured and left alone in "
      "EXPERIMENTS R3.13 -- 89-90 us per MPC step at N = 12 000-16 000, no faster path for those populations"),
-    (r"iter_ahead_kernel<30, 6, 18, [01], [48], [012]>", 32,
+    (r"iter_ahead_kernel<30, 6, 17, [01], [48], [012], 1>", 16,
+     "the fp16-plane tile (Tile16H: two operand planes of the model and of the state) on the 128 registers of the noise-ahead "
+     "launch: 9-14 spills, at the staging points every ten steps -- and the launch wins by 11-14 %: 140.8 vs 157.2 us per MPC "
+     "step at N = 65 536, 102.5 vs 116.4 at 32 768 on the same box (EXPERIMENTS R5.1)"),
+    (r"iter_ahead_kernel<30, 6, 18, [01], [48], [012], [01]>", 32,
      "o = 18 (HalfCheetah with x position): 4-26 spills, and the launch still wins -- 268.5 vs 299.9 us per MPC step at "
      "N = 65 536 with the tanh model, 181.9 vs 239.0 with the linear one (EXPERIMENTS R4.6)"),
     (r"rollout_wide_split_kernel<3, [01], true, (true|false), false>", 16,
@@ -85,14 +89,17 @@ def test_every_kernel_is_accounted_for(spills):
 
 
 def test_the_benchmarked_instantiations_do_not_spill(spills):
-    """The instantiations the bench lines run (c2, c4, c3, c5) stay at <= 4 spilled registers."""
-    for pat in (r"iter_ahead_kernel<30, 6, 17, 0, 8, [01]>", r"sample_rollout_kernel<30, 6, 17, 0, 10, 1, (0|12), false>",
-                r"rssm_split_kernel<1>", r"merge_noise_kernel", r"merge_single_kernel"):
+    """The instantiations the bench lines run (c2, c4, c3, c5) stay at <= 4 spilled registers -- c4's noise-ahead launch on the
+    fp16-plane tile at <= 12, none of them between the MFMAs of a tile's step chain (the spilled values belong to the merge
+    prologue and the noise role, which share the launch's 128 registers: tools/dbg/kernel_isa.py)."""
+    for pat, cap in ((r"iter_ahead_kernel<30, 6, 17, 0, 8, [01], 0>", 4), (r"iter_ahead_kernel<30, 6, 17, 0, 8, [01], 1>", 12),
+                     (r"sample_rollout_kernel<30, 6, 17, 0, 10, 1, (0|12), false, 0>", 4),
+                     (r"rssm_split_kernel<1>", 4), (r"merge_noise_kernel", 4), (r"merge_single_kernel", 4)):
         hit = {k: v for k, v in spills.items() if re.search(pat, k)}
         assert hit, pat
-        assert max(hit.values()) <= 4, hit
+        assert max(hit.values()) <= cap, hit
 
 
 def test_the_two_tile_shapes_are_not_on_the_noise_ahead_path(spills):
     assert not [k for k in spills if re.search(r"iter_ahead_kernel<\d+, \d+, 2[0-9],", k)]
-    assert not [k for k in spills if re.search(r"rollout16_kernel<\d+, \d+, 2[0-9], [01], 16>", k)]
+    assert not [k for k in spills if re.search(r"rollout16_kernel<\d+, \d+, 2[0-9], [01], 16, [01]>", k)]
