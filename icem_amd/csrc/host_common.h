@@ -151,6 +151,10 @@ struct icem_handle {
         // part of that noise rides beside the step's LAST merge (the one launch that leaves the chip idle)
         bool tail_pending = false;
         icem::FastSampleArgs tail_args, tail2_args;   // tail2 (n > 0): the next step's shifted elites' noise as well
+        // ... and the head of the next step's iteration-1 noise (rows [0, next1_rows) of next1_pool): iteration 0's launch has
+        // no merge prologue for its noise role to hide behind, its noise role outlasts its rollout (EXPERIMENTS R5.2)
+        int next1_rows = 0;
+        void* next1_pool = nullptr;
         // small populations (single-launch kernel): the whole first noise of the next MPC step is drawn beside the last
         // merge into `pre_raw` [pop[0] + n_reuse, h, d]; iteration 0 of that step only maps it (FastSampleArgs::raw_src)
         void* pre_raw = nullptr;

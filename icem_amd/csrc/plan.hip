@@ -850,6 +850,7 @@ static int plan_step_ahead(icem_handle* h, const icem_plan_buffers* b, int mpc_s
     float* cur_mean = (float*)b->mean;
     float* cur_std = (float*)b->std;
     const int n_extra = (c.shift_elites && mpc_step > 0 && h->n_reuse > 0) ? h->n_reuse : 0;
+    int n1_done = 0;   // rows of iteration 1's noise that are there already
     for (int it = 0; it < iters; ++it) {
         const bool last = it == iters - 1;
         const int n = h->pop[it];
@@ -870,6 +871,9 @@ static int plan_step_ahead(icem_handle* h, const icem_plan_buffers* b, int mpc_s
                 launch_noise_rows(za, c.rng_rounds, st);
             }
             ICEM_HIP_TRY(hipGetLastError());
+            // the head of iteration 1's noise may have been drawn beside the previous step's last merge as well
+            n1_done = (hit && iters > 1 && A.next1_pool == pool_of(1)) ? std::min(A.next1_rows, h->pop[1]) : 0;
+            A.next1_rows = 0;
         }
         IterAheadArgs ia{};
         ia.r = fast_rollout_args(h, n, n, K, b->obs0, pool, b->costs, nullptr, nullptr);
@@ -888,7 +892,9 @@ static int plan_step_ahead(icem_handle* h, const icem_plan_buffers* b, int mpc_s
         ia.hi = A.hi;
         // the noise role: the next sampling call
         if (!last) {
-            ia.z = noise_args(h->pop[it + 1], call_base + (uint64_t)(it + 1), pool_of(it + 1));
+            const int skip = it == 0 ? n1_done : 0;
+            ia.z = noise_args(h->pop[it + 1] - skip, call_base + (uint64_t)(it + 1), pool_of(it + 1) + (size_t)skip * hd);
+            ia.z.first_index = skip;
         } else {
             // iteration 0 of the NEXT MPC step (same episode, step + 1 -- checked when it comes)
             // -- split: what fits beside this launch's rollout here, the rest beside the step's last merge, a launch that
@@ -906,6 +912,16 @@ static int plan_step_ahead(icem_handle* h, const icem_plan_buffers* b, int mpc_s
             if (n_tail > 0) {
                 A.tail_args = noise_args(n_tail, off0, (float*)np + (size_t)n_here * hd);
                 A.tail_args.first_index = n_here;
+                // ... and the head of the next step's iteration-1 noise, into the pool that step will find at pool_of(1)
+                // (this step's iteration-2 pool: its last reader was iteration 3's prologue) -- ICEM_AHEAD_NEXT1_FRAC of it
+                static const double frac1 = [] { const char* e = getenv("ICEM_AHEAD_NEXT1_FRAC"); return e ? atof(e) : 0.3; }();
+                const int n1 = iters > 2 ? std::max(0, std::min(h->pop[1], (int)(frac1 * h->pop[1]))) : 0;
+                if (n1 > 0) {
+                    void* np1 = A.pool[(A.ctr + (unsigned)(iters - 1) + 1u) % 3];
+                    A.tail2_args = noise_args(n1, off0 + 1u, np1);
+                    A.next1_rows = n1;
+                    A.next1_pool = np1;
+                }
             }
             A.next_valid = true;
             A.next_episode = h->episode;
@@ -935,8 +951,9 @@ static int plan_step_ahead(icem_handle* h, const icem_plan_buffers* b, int mpc_s
         h->defer_merge = false;
         h->merge_mean_out = h->merge_std_out = nullptr;
         if (rc) return rc;
-        if (last && A.tail_pending) {  // (the merge could not take it along: a launch of its own)
+        if (last && A.tail_pending) {  // (the merge could not take it along: launches of their own)
             launch_noise_rows(A.tail_args, c.rng_rounds, st);
+            if (A.tail2_args.n > 0) launch_noise_rows(A.tail2_args, c.rng_rounds, st);
             ICEM_HIP_TRY(hipGetLastError());
             A.tail_pending = false;
         }
@@ -1306,6 +1323,7 @@ int icem_plan_iter_merge(icem_handle* h, const icem_plan_buffers* b, int32_t mpc
 static int disarm_on_error(icem_handle* h, int rc) {
     if (rc != ICEM_OK) {
         h->ahead.tail_pending = h->ahead.next_valid = h->ahead.pre_valid = false;
+        h->ahead.next1_rows = 0;
         h->pm_pending = h->pk_pending = false;
         h->defer_merge = false;
         h->merge_mean_out = h->merge_std_out = nullptr;
