@@ -17,11 +17,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 UNITS = ["generic_kernels.hip", "plan.hip", "abi.hip", "exchange.hip", "k_sample.hip", "k_rollout.hip", "k_merge.hip",
          "k_iter_small.hip", "icem_rssm.hip", "icem_rssm_split.hip", "k_rollout_wide.hip", "collective.hip", "k_rollout_ahead.hip",
-         "k_rollout_wide_split.hip"]
+         "k_rollout_wide_split.hip", "k_rollout_hn.hip"]
 OUT = os.path.join(HERE, "libicem_hip.so")
 MARK = b"ICEM_BUILD_HASH="  # abi.hip embeds MARK + the 16 hex digits of source_hash()
 OBJ = os.path.join(CSRC, "_obj")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function"]
+# per-unit flags (-mllvm -amdgpu-mfma-vgpr-form would keep TileHN's accumulators out of the AGPRs and save its 16-36
+# v_accvgpr_read per step)
+UNIT_FLAGS = {}   # (measured for TileHN: no gain, 30 more registers)
 if os.environ.get("ICEM_DEV_SHAPES"):   # development builds: compile the matrix-pipe kernels for ONE shape, e.g. "30,6,17" (4x faster)
     FLAGS.append(f"-DICEM_FAST_SHAPES(X)=X({os.environ['ICEM_DEV_SHAPES']})")
 
@@ -50,7 +53,7 @@ def _digest(paths, extra=""):
 
 def source_hash() -> str:
     """Hash of everything the library is built from (sources, headers, flags)."""
-    return _digest([os.path.join(CSRC, u) for u in _units()] + _headers(), " ".join(FLAGS))
+    return _digest([os.path.join(CSRC, u) for u in _units()] + _headers(), " ".join(FLAGS) + repr(sorted(UNIT_FLAGS.items())))
 
 
 def embedded_hash(path: str = OUT):
@@ -82,7 +85,7 @@ def up_to_date() -> bool:
 def _compile(unit, headers_digest, verbose):
     src = os.path.join(CSRC, unit)
     extra = [f'-DICEM_BUILD_HASH="{source_hash()}"'] if unit == "abi.hip" else []  # the marker lives in one object
-    cmd = [_hipcc(), *FLAGS, *extra, "-I", CSRC, "-c", src]
+    cmd = [_hipcc(), *FLAGS, *UNIT_FLAGS.get(unit, []), *extra, "-I", CSRC, "-c", src]
     key = _digest([src], " ".join(cmd[1:-1]) + headers_digest)
     obj = os.path.join(OBJ, f"{os.path.splitext(unit)[0]}.{key}.o")
     if not os.path.exists(obj):

@@ -188,6 +188,7 @@ int icem_destroy(icem_handle* h) {
     if (h->Mwh_dev) (void)hipFree(h->Mwh_dev);
     if (h->Mwh_ksc_dev) (void)hipFree(h->Mwh_ksc_dev);
     if (h->wide_cs_dev) (void)hipFree(h->wide_cs_dev);
+    if (h->hn_cs_dev) (void)hipFree(h->hn_cs_dev);
     if (h->pub_dev) (void)hipFree(h->pub_dev);
     if (h->perm_dev) (void)hipFree(h->perm_dev);
     for (auto& sp : h->spans) {
@@ -247,7 +248,30 @@ static void update_paths(icem_handle* h) {
     for (int n_it : h->pop) big = big && n_it > ICEM_TILE_SPLIT_MIN_ROWS;
     const bool want = mode == 1 || (mode < 0 && big);
     h->tile_arith = (split_ok && want) ? 1 : 0;
+    // the reference's other narrow shapes (Door, Relocate, FetchPickAndPlace) have ONE fast rollout, and it computes in the
+    // fp16 planes: theirs unless the exact arithmetic is asked for (icem_set_tile_arith 0: the exact-f32 GEMM kernel)
+    // (the term list must fit one of the kernel's compiled programs: slices of at most 32 entries)
+    int n32 = 0, n4 = 0, np = 0;
+    bool terms_ok = true;
+    if (h->has_terms && (h->terms.diff_idx >= 0 || h->terms.health_idx >= 0)) terms_ok = false;   // (Ant / Hopper / Humanoid: the GEMM kernel)
+    if (h->has_terms)
+        for (int j = 0; j < h->terms.n_terms; ++j) {
+            const icem_cost_term& tm = h->terms.terms[j];
+            if (tm.kind == ICEM_TERM_STEP_GT || tm.kind == ICEM_TERM_SQ_OFFSET) ++np;
+            else if (tm.len <= 4) ++n4;
+            else if (tm.len <= 32) ++n32;
+            else terms_ok = false;
+        }
+    int prog[3] = {0, 0, 0};
+    const bool hn = of == 0 && h->has_model && h->has_cost && h->cfg.dtype == ICEM_F32 && finite && mode != 0 && terms_ok &&
+                    hn_cost_program(n32, n4, np, prog) &&
+                    hn_rollout_supported(h->cfg.horizon, h->cfg.act_dim, h->obs_dim, h->cfg.num_elites);
+    for (int k = 0; k < 3; ++k) h->hn_prog[k] = hn ? prog[k] : 0;
+    if (hn != h->hn_tile) h->fast_model_ready = false;
+    h->hn_tile = hn;
 }
+
+static int sync_wide_cost(icem_handle* h);
 
 int icem_set_tile_arith(icem_handle* h, int32_t mode) {
     if (check_handle(h)) return ICEM_E_INVALID;
@@ -256,10 +280,10 @@ int icem_set_tile_arith(icem_handle* h, int32_t mode) {
     h->tile_arith_mode = mode;
     update_paths(h);
     h->ahead.next_valid = h->ahead.pre_valid = false;   // (noise drawn ahead for the other launch shapes is redrawn)
-    return ICEM_OK;
+    return sync_wide_cost(h);
 }
 
-int icem_tile_arith(const icem_handle* h) { return h ? h->tile_arith : 0; }
+int icem_tile_arith(const icem_handle* h) { return h ? ((h->tile_arith || h->hn_tile) ? 1 : 0) : 0; }
 
 int icem_set_model(icem_handle* h, int32_t kind, int32_t obs_dim, const double* A_host, const double* B_host) {
     if (!h || !A_host || !B_host) return fail(ICEM_E_INVALID, "null argument");
@@ -282,7 +306,7 @@ int icem_set_model(icem_handle* h, int32_t kind, int32_t obs_dim, const double* 
         h->B_host.assign(B_host, B_host + (size_t)d * obs_dim);
         h->fast_model_ready = false;
         update_paths(h);
-        return ICEM_OK;
+        return sync_wide_cost(h);
     }
     h->wide = false;
     const int O = pick_O(obs_dim);
@@ -304,7 +328,7 @@ int icem_set_model(icem_handle* h, int32_t kind, int32_t obs_dim, const double* 
     h->B_host.assign(B_host, B_host + (size_t)d * obs_dim);
     h->fast_model_ready = false;
     update_paths(h);
-    return ICEM_OK;
+    return sync_wide_cost(h);
 }
 
 // the device copy of the cost the wide rollout kernels read when cost terms are on (by value in the argument block it
@@ -313,6 +337,22 @@ static int sync_wide_cost(icem_handle* h) {
     if (!h->has_terms) return ICEM_OK;
     CostArgs<float> cs;
     fill_cost_args_f32(h, cs);
+    if (h->hn_tile) {   // TileHN's copy: the terms sorted into its program's slots (long slices, short slices, points), null-padded
+        CostArgs<float> hs = cs;
+        const int cap[3] = {h->hn_prog[0], h->hn_prog[1], h->hn_prog[2]}, base[3] = {0, cap[0], cap[0] + cap[1]};
+        int used[3] = {0, 0, 0};
+        for (int j = 0; j < ICEM_MAX_COST_TERMS; ++j) {
+            hs.terms[j] = CostArgs<float>::Term{0.f, 0.f, 0.f, -1, 0, -1, 1, -1};
+        }
+        for (int j = 0; j < cs.n_terms; ++j) {
+            const auto& tm = cs.terms[j];
+            const int cls = (tm.kind == ICEM_TERM_STEP_GT || tm.kind == ICEM_TERM_SQ_OFFSET) ? 2 : (tm.len <= 4 ? 1 : 0);
+            if (used[cls] < cap[cls]) hs.terms[base[cls] + used[cls]++] = tm;
+        }
+        hs.n_terms = cap[0] + cap[1] + cap[2];
+        if (!h->hn_cs_dev) ICEM_HIP_TRY(hipMalloc(&h->hn_cs_dev, sizeof(hs)));
+        ICEM_HIP_TRY(hipMemcpy(h->hn_cs_dev, &hs, sizeof(hs), hipMemcpyHostToDevice));
+    }
     if (!h->wide_cs_dev) ICEM_HIP_TRY(hipMalloc(&h->wide_cs_dev, sizeof(cs)));
     ICEM_HIP_TRY(hipMemcpy(h->wide_cs_dev, &cs, sizeof(cs), hipMemcpyHostToDevice));
     return ICEM_OK;

@@ -1668,9 +1668,9 @@ __device__ __forceinline__ unsigned long long rollout_slab(Tile& tile, const Fas
 // registers), into its own LDS staging buffer; each lane then reads the one or two entries it feeds to the MFMAs.
 // Only this wave touches the buffer and a wave's LDS operations execute in order: no barriers.  Shared by
 // rollout16_kernel (k_rollout.hip) and rollout16_ahead_kernel (k_rollout_ahead.hip).
-template <int H, int D, int O, int KIND, int ARITH = 0>
-struct Stream16 {
-    using Tile = typename TileSel<H, D, O, KIND, ARITH>::type;
+template <typename TileT, int H, int D>
+struct StreamT {
+    using Tile = TileT;
     static constexpr int HD = H * D;
     static constexpr int VW = HD % 4 == 0 ? 4 : 2;    // floats per load: rows are 16-byte aligned only if h*d % 4 == 0
     static_assert(HD % 2 == 0, "8-byte aligned action rows");
@@ -1816,6 +1816,8 @@ struct Stream16 {
         return run_key;
     }
 };
+template <int H, int D, int O, int KIND, int ARITH = 0>
+using Stream16 = StreamT<typename TileSel<H, D, O, KIND, ARITH>::type, H, D>;
 
 // Sharded runs: this rank's K best candidates (merge_select's selection, already in `sel`) packed as records
 // {cost, gidx, actions[h*d]} for the exchange.  Local pool row li is global trajectory shard_lo + li, or

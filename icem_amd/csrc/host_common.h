@@ -101,6 +101,9 @@ struct icem_handle {
     // tile_arith = what the handle's launches use (update_paths: mode + whether Tile16H serves this model)
     int tile_arith_mode = -1;
     int tile_arith = 0;
+    int hn_prog[3] = {0, 0, 0};  // ... its term program (N32, N4, NP) and the device copy of the terms sorted into it
+    void* hn_cs_dev = nullptr;
+    bool hn_tile = false;        // the f32 rollout is k_rollout_hn.hip's TileHN kernel (Door / Relocate / FetchPickAndPlace shapes; fp16 planes)
     float tile_m_scale = 1.f, tile_b_scale = 1.f;   // FastRolloutArgs::m_scale / b_scale (update_paths)
     float act_mag = 1.f;         // max(|low|, |high|) of the action bounds last seen (FastRolloutArgs::act_mag), from ...
     const void* am_lo = nullptr; // ... this (low, high) buffer pair

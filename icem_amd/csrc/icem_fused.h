@@ -88,6 +88,20 @@ void launch_rollout16(const FastRolloutArgs& a, int h, int d, int O, int kind, h
 // workgroups (= candidate lists) the rollout of n_rows trajectories is launched with
 int rollout_lists(int h, int d, int O, int n_rows);
 
+// K2+K3 for the narrow shapes beside HalfCheetah that the reference ships (Door, Relocate, FetchPickAndPlace: k_rollout_hn.hip):
+// TileHN -- up to three output tiles on the 16-bit matrix cores (the fp16-plane arithmetic of Tile16H), icem_cost_terms
+// evaluated across the four lanes of a trajectory.  A [o, lda], B [d, ldb]: the row-major f32 model; cs: device copy of the
+// cost terms (nullptr: none).  r: n_rows / n_cand / K / o / cost_mode / obs0 / actions / costs / part_* / the cost spec's
+// weights / act_mag, m_scale, b_scale.
+template <typename T> struct CostArgs;
+bool hn_rollout_supported(int h, int d, int o, int K);
+int hn_rollout_lists(int n_rows);
+// cs: terms sorted into the program prog = (N32, N4, NP) and padded with null terms (kind -1): hn_cost_program says whether a
+// list of n32 long slices (5 .. 32 entries), n4 short ones and np point terms has a compiled program, and which
+bool hn_cost_program(int n32, int n4, int np, int* prog);
+void launch_rollout_hn(const FastRolloutArgs& r, int h, int d, int o, int kind, const float* A, int lda, const float* B, int ldb,
+                       int lin_idx, int flip_idx, const CostArgs<float>* cs, const int* prog, hipStream_t st);
+
 // K2+K3 for wide observations (32 < o <= 384; k_rollout_wide.hip): the model step as an f32 matrix-pipe GEMM per
 // 16-trajectory tile, contraction vectors in LDS; same candidate-list outputs as the kernels above.
 struct WideRolloutArgs {

@@ -170,6 +170,20 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
     int rc = ensure_fast_model(h);
     if (rc) return rc;
     if (tail_out) *tail_out = 0;
+    if (h->hn_tile) {   // Door / Relocate / FetchPickAndPlace shapes: TileHN (k_rollout_hn.hip)
+        FastRolloutArgs a = fast_rollout_args(h, n_rows, n_cand, K, obs0, actions, costs, part_c, part_i);
+        a.part_k = part_k;
+        a.arith = 1;
+        const int ld = h->wide ? h->obs_dim : h->O;   // A_dev / B_dev: row-major f32, unpadded at o > 32, padded to O below
+        {
+            ProfScope prof(h, ICEM_K_ROLLOUT, (long long)n_rows * h->cfg.horizon, st);
+            launch_rollout_hn(a, h->cfg.horizon, h->cfg.act_dim, h->obs_dim, h->model_kind, (const float*)h->A_dev, ld, (const float*)h->B_dev, ld,
+                              h->cost.lin_idx, h->cost.flip_idx, h->has_terms ? (const CostArgs<float>*)h->hn_cs_dev : nullptr, h->hn_prog, st);
+        }
+        ICEM_HIP_TRY(hipGetLastError());
+        if (lists_out) *lists_out = hn_rollout_lists(n_rows);
+        return ICEM_OK;
+    }
     if (gemm_rollout(h)) {
         // narrow observations always take the exact-f32 kernel (two workgroup barriers per step buy nothing at o <= 32)
         const bool exact = h->wide_mode == 1 || !h->wide || !wide_split_fits(h->obs_dim, h->cfg.act_dim);
@@ -1231,7 +1245,7 @@ static int check_plan(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_st
         ((b->z_r == nullptr) != (b->z_i == nullptr) || (b->z_r_shift == nullptr) != (b->z_i_shift == nullptr)))
         return fail(ICEM_E_INVALID, "z_r/z_i must be given in pairs");
     // fp16-plane tile arithmetic: the launch's scale needs the action bounds' magnitude -- fetched once per (low, high) pair
-    if (h->tile_arith && (h->am_lo != b->low || h->am_hi != b->high)) {
+    if ((h->tile_arith || h->hn_tile) && (h->am_lo != b->low || h->am_hi != b->high)) {
         const int d = h->cfg.act_dim;
         std::vector<float> lo(d), hi(d);
         ICEM_HIP_TRY(hipMemcpy(lo.data(), b->low, d * sizeof(float), hipMemcpyDeviceToHost));

@@ -730,6 +730,8 @@ def rollout_cost_magnitudes(model: SyntheticModel, cost: CostSpec, obs0, actions
         mag += abs(cost.ctrl_weight) * (a * a).sum(axis=1)
         if cost.lin_weight != 0:
             mag += abs(cost.lin_weight) * np.abs(obs[:, cost.lin_idx])
+        for tm in getattr(cost, "terms", ()):   # the term list (icem_cost_terms): |weight x f x gate| of every term
+            mag += np.abs(cost.term_value(tm, obs))
         obs = model.predict(obs, a)
     return mag
 

@@ -65,7 +65,14 @@ class DeviceNormals:
 
 def _make(N, iters, h, d, o, kind, beta, seed, env_kind, cost_mode="sum", arith=None):
     from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env, humanoid_standup_env
-    env = halfcheetah_env(o) if env_kind == "halfcheetah" else humanoid_standup_env(o)
+    from icem_amd import envs as E
+    shipped = {"door": (E.door_env, O.CostSpec.door), "relocate": (E.relocate_env, O.CostSpec.relocate),
+               "fpp": (E.fetch_pick_and_place_env, O.CostSpec.fetch_pick_and_place)}
+    if env_kind in shipped:
+        env = shipped[env_kind][0]()
+        assert (env.obs_dim, env.action_space.shape[0]) == (o, d)
+    else:
+        env = halfcheetah_env(o) if env_kind == "halfcheetah" else humanoid_standup_env(o)
     model = DeviceSyntheticModel.make(o, d, kind=kind)
 
     def mk():
@@ -77,7 +84,10 @@ def _make(N, iters, h, d, o, kind, beta, seed, env_kind, cost_mode="sum", arith=
             assert pl.set_tile_arith(arith) == arith
         pl.reset()
         return pl
-    oc = O.CostSpec.halfcheetah(o) if env_kind == "halfcheetah" else O.CostSpec.humanoid_standup()
+    if env_kind in shipped:
+        oc = shipped[env_kind][1]()
+    else:
+        oc = O.CostSpec.halfcheetah(o) if env_kind == "halfcheetah" else O.CostSpec.humanoid_standup()
     return env, model, oc, mk
 
 
@@ -124,10 +134,25 @@ def test_full_loop_at_benchmark_size_best_and_final(cost_mode):
     _full_loop(4096, 5, 30, 6, 17, 1, 0.25, "halfcheetah", 21, cost_mode)
 
 
-def _full_loop(N, iters, h, d, o, kind, beta, env_kind, seed, cost_mode, arith=None):
+# The reference's other shipped settings (settings/{door,relocate,fpp}: icem/environments/mjenvs.py:57-78, 155-174,
+# robotics.py:150-164; beta from README.md:21-29) at the headline population, on the TileHN kernel (k_rollout_hn.hip: the model
+# step on the 16-bit matrix cores, the term list across the four lanes of a trajectory): the same bar -- every cost within
+# 1e-5 of its magnitude, the float64 oracle's elite sets -- with the indicator terms (opening / closeness bonuses) in play.
+@pytest.mark.parametrize("env_kind,d,o,beta,kind,seed", [
+    pytest.param("door", 28, 39, 2.5, 1, 31, id="door_N4096x3"),
+    pytest.param("relocate", 30, 39, 3.5, 1, 32, id="relocate_N4096x3"),
+    pytest.param("fpp", 4, 28, 3.0, 0, 33, id="fpp_N4096x3"),
+])
+def test_full_loop_on_the_shipped_door_relocate_fpp_shapes(env_kind, d, o, beta, kind, seed):
+    _full_loop(4096, 3, 30, d, o, kind, beta, env_kind, seed, "sum", expect_arith=1)
+
+
+def _full_loop(N, iters, h, d, o, kind, beta, env_kind, seed, cost_mode, arith=None, expect_arith=None):
     env, model, oc, mk = _make(N, iters, h, d, o, kind, beta, seed, env_kind, cost_mode, arith)
     om = O.SyntheticModel(model.A, model.B, model.kind)
     split, fused, rng = mk(), mk(), mk()
+    if expect_arith is not None:
+        assert split.tile_arith == expect_arith
     noise = DeviceNormals(rng, iters)
     low, high = env.action_space.low.astype(np.float64), env.action_space.high.astype(np.float64)
     orc = O.IcemOracle(O.IcemParams(horizon=h, num_simulated_trajectories=N, opt_iterations=iters, noise_beta=beta),
