@@ -249,7 +249,8 @@ def extra_cpu_baselines(workload, w, model, env):
     return out
 
 
-KERNEL_FAMILY = {"sample_clip": ("sample_folded_kernel", "sample_folded_merge_kernel", "noise_rows_kernel"),
+KERNEL_FAMILY = {"rssm_rollout": ("rssm_split_kernel", "rssm_rollout_kernel"),
+                 "sample_clip": ("sample_folded_kernel", "sample_folded_merge_kernel", "noise_rows_kernel"),
                  "rollout_cost": ("rollout16_kernel", "rollout_wide_kernel", "rollout_wide_split_kernel"),
                  # one launch per iteration: the small-population kernel, or the noise-ahead launch of large populations
                  "sample_rollout": ("sample_rollout_kernel", "iter_ahead_kernel")}
@@ -291,37 +292,70 @@ def event_bracket_us(pl):
 
 
 def without_bracket(prof, bracket):
-    """{kernel: (ms, launches, units)} with the event bracket taken out of every span (never below a fifth of the span)."""
+    """{kernel: (ms, launches, units)} with the event bracket taken out of every span (the bracket is the SMALLEST one the
+    calibration kernel showed, so a span cannot be shorter; a class that came out non-positive is dropped by roofline_of)."""
     sub = bracket["subtracted_us"] * 1e-3
-    return {k: (max(ms - sub * n, 0.2 * ms), n, u) for k, (ms, n, u) in prof.items()}
+    return {k: (max(ms - sub * n, 0.0), n, u) for k, (ms, n, u) in prof.items()}
 
 
 def fit_to_step(prof, profiled_steps, ms_per_step):
-    """Price every kernel on its SHARE OF THE TIMED STEP: the bracket-corrected event times are scaled so that they sum to
-    ms_per_step exactly -- launch gaps are charged to the kernels pro rata (conservative: a roofline fraction computed
-    from these can only be lower than the kernel alone would show), and a set of times that exceeds the step (the r02 /
-    r03 flaw) cannot happen.  Returns the scaled profile and the record of what was done."""
+    """Price every kernel on its SHARE OF THE TIMED STEP: the bracket-corrected event times are scaled UP so that they sum
+    to ms_per_step exactly -- launch gaps are charged to the kernels pro rata (conservative: a roofline fraction computed
+    from these can only be lower than the kernel alone would show).  Times that sum to more than 1.05 x the step are left
+    as they are and flagged (`fits` false): the line then carries `roofline.valid` = false instead of fractions inflated
+    by a scale-down.  Returns the profile and the record of what was done."""
     per_step_ms = sum(ms for ms, _, _ in prof.values()) / max(1, profiled_steps)
     ratio = per_step_ms / ms_per_step if ms_per_step > 0 else float("inf")
     fit = {"sum_of_kernel_times_ms_per_step": per_step_ms, "ms_per_step": ms_per_step, "ratio": ratio, "fits": ratio <= 1.05,
            "priced_on": "share of the timed step (event time x ms_per_step / sum of event times)"}
     if ratio > 1.05:
-        print(f"bench.py: per-kernel event times sum to {ratio:.2f} x the timed step", file=sys.stderr)
+        # event times that exceed the step they were taken from are not evidence of anything: they are NOT scaled down (that
+        # would inflate every fraction computed from them) -- the caller prints the line with `roofline.valid` false
+        print(f"bench.py: per-kernel event times sum to {ratio:.2f} x the timed step: roofline fractions marked invalid", file=sys.stderr)
+        fit["priced_on"] = "raw event times (they exceed the timed step: fractions invalid)"
+        return dict(prof), fit
     return {k: (ms / ratio, n, u) for k, (ms, n, u) in prof.items()}, fit
 
 
-def roofline_of(prof, w, workload=None):
+def attainable(w, units, launches, tile_arith, kernel):
+    """The floor of ONE launch of `kernel` on this chip at its own operation count: max(HBM floor at the algorithmic bytes,
+    ALU floor).  ALU floor = the model step's multiply-adds on the pipe they run on -- the exact-f32 pipe (vector and
+    v_mfma_f32_16x16x4_f32 share it: 157.3 TFLOP/s), or, in fp16 planes, THREE fp16 products per multiply-add at the dense
+    fp16 peak -- plus the sampler's and the cost's f32 vector operations at the f32 peak (they do not overlap the matrix
+    pipe's issue slot on gfx950: one VALU/MFMA issue per cycle and SIMD)."""
+    d, h, o = w["d"], w["h"], w["o"]
+    per = units / launches
+    model = 2.0 * (o + d) * o
+    rest = algorithmic_flops_per_trajstep(kernel, d, h, o) - (model if kernel != "sample_clip" else 0.0)
+    hbm_us = per * algorithmic_bytes_per_trajstep(kernel, d, h) / (HBM_PEAK_GBS * 1e9) * 1e6
+    if kernel == "sample_clip":
+        alu_us = per * rest / (F32_PEAK_TFLOPS * 1e12) * 1e6
+    elif tile_arith:
+        alu_us = per * (3.0 * model / (BF16_PEAK_TFLOPS * 1e12) + rest / (F32_PEAK_TFLOPS * 1e12)) * 1e6
+    else:
+        alu_us = per * (model + rest) / (F32_PEAK_TFLOPS * 1e12) * 1e6
+    return {"hbm_floor_us": hbm_us, "alu_floor_us": alu_us, "attainable_us": max(hbm_us, alu_us),
+            "model_step_arithmetic": "two fp16 planes, 3 products per multiply-add on v_mfma_f32_16x16x32_f16" if tile_arith
+                                     else "exact f32 (v_mfma_f32_16x16x4_f32 / v_fmac_f32: one shared pipe)"}
+
+
+def roofline_of(prof, w, workload=None, fit=None, tile_arith=0):
+    prof = {k: v for k, v in prof.items() if v[0] > 0}
+    if not prof:
+        return None
     dom = max(prof, key=lambda k: prof[k][0])
     ms, launches, units = prof[dom]
     bpu = algorithmic_bytes_per_trajstep(dom, w["d"], w["h"])
     if bpu is None or ms <= 0:
         return None
+    valid = bool(fit["fits"]) if fit else True
     achieved = units * bpu / (ms * 1e-3) / 1e9
     fpu = algorithmic_flops_per_trajstep(dom, w["d"], w["h"], w["o"])
     tflops = units * fpu / (ms * 1e-3) / 1e12
     compute = {"achieved": tflops, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / F32_PEAK_TFLOPS,
                "flops_per_traj_step": fpu, "flops_per_launch": units * fpu / launches,
-               "note": "f32 vector and f32 MFMA share one pipe on gfx950 (155 TF measured): one compute roof"}
+               "note": "algorithmic f32 operations over the EXACT-f32 peak (f32 vector and f32 MFMA share one pipe on gfx950: 155 TF "
+                       "measured); in fp16 planes the model step's share runs on the 16-bit matrix cores -- see attainable"}
     traffic, src, trace_us = measured_traffic(dom, workload) if workload else (None, None, None)
     # avg_launch_us: HIP events around every launch on the launch stream, the calibrated event bracket taken out
     # (event_bracket_us), then priced as the launch's share of the timed step (fit_to_step: the times sum to ms_per_step);
@@ -329,46 +363,74 @@ def roofline_of(prof, w, workload=None):
     if w["o"] > 32 and dom == "rollout_cost":
         # wide observations: the rollout is a GEMM three orders of magnitude above the ridge ("declare that
         # stage compute-bound").  It runs on the fp16 matrix cores with every f32 operand x 2^k split in two fp16 planes:
-        # THREE fp16 products per algorithmic multiply-add (k_rollout_wide_split.hip), so the roof is the dense fp16 peak
-        # (= the bf16 one) and `achieved` the EXECUTED fp16 rate = 3 x the algorithmic f32 rate (padding of the 32-deep
-        # blocks not counted).  (Round 4's first form, three bf16 planes and six products: icem_set_wide_exact(h, 2).)
+        # THREE fp16 products per algorithmic multiply-add (k_rollout_wide_split.hip).  `frac` is the ALGORITHMIC rate
+        # (one multiply-add = 2 flop, whatever executes it) over the peak of the pipe used; the executed products'
+        # utilisation of that pipe and the algorithmic rate over the exact-f32 matrix peak ride beside it.
         executed = 3.0 * tflops
-        return {"bound": "mfma", "achieved": executed, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": executed / BF16_PEAK_TFLOPS,
+        return {"bound": "mfma", "achieved": tflops, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / BF16_PEAK_TFLOPS,
+                "valid": valid, "what": "algorithmic flops per launch / launch time / dense fp16 peak (the pipe the kernel runs on)",
+                "executed_TFLOPs": executed, "executed_frac": executed / BF16_PEAK_TFLOPS,
+                "vs_exact_f32_matrix_peak": tflops / F32_PEAK_TFLOPS,
                 "traffic": traffic, "traffic_source": src, "kernel": dom, "avg_launch_us": 1e3 * ms / launches,
                 "rocprof_trace_avg_us": trace_us, "launches": launches, "flops_per_traj_step": fpu,
-                "algorithmic_flops_per_launch": units * fpu / launches, "algorithmic_TFLOPs": tflops,
+                "algorithmic_flops_per_launch": units * fpu / launches,
                 "products_per_multiply_add": 3,
                 "dtype": "2-way fp16 split of f32 operands x 2^k, three products per multiply-add, f32 accumulation (v_mfma_f32_16x16x32_f16)",
-                "vs_exact_f32_matrix_peak": tflops / F32_PEAK_TFLOPS,
                 "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "bytes_per_traj_step": bpu}, "binding_roof": "fp16-mfma"}
+    att = attainable(w, units, launches, tile_arith, dom)
+    att["frac_of_attainable"] = att["attainable_us"] / (1e3 * ms / launches)
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_source": src, "kernel": dom, "avg_launch_us": 1e3 * ms / launches,
+            "valid": valid, "traffic": traffic, "traffic_source": src, "kernel": dom, "avg_launch_us": 1e3 * ms / launches,
             "rocprof_trace_avg_us": trace_us, "launches": launches,
             "algorithmic_bytes_per_launch": units * bpu / launches, "bytes_per_traj_step": bpu,
-            "compute": compute, "binding_roof": "f32-alu" if compute["frac"] > achieved / HBM_PEAK_GBS else "hbm"}
+            "compute": compute, "attainable": att,
+            "binding_roof": "hbm" if att["hbm_floor_us"] >= att["alu_floor_us"] else ("fp16-mfma + f32-alu" if tile_arith else "f32-alu")}
 
 
-def timed_steps(pl, steps, warmup, world):
-    """W untimed steps, then K timed ones between barrier + synchronize pairs; the MAX over ranks."""
+def timed_steps(pl, steps, warmup, world, spread=None):
+    """W untimed steps, then K timed ones between barrier + synchronize pairs; the MAX over ranks.  That first block of
+    exactly K steps is what `value` is computed from.  A block shorter than 10 ms says little about a box (clock ramps, a
+    neighbour's interrupt): when `spread` (a dict) is given, further blocks of K steps are timed the same way until 10 ms
+    have been covered, and their min / median / max ms per step are recorded in it."""
     def sync():
         torch.cuda.synchronize()
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
             torch.cuda.synchronize()
+
+    def block():
+        sync()
+        t0 = time.perf_counter()
+        run_steps(pl, steps, world)
+        sync()
+        el = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
     run_steps(pl, warmup, world)
-    sync()
-    t0 = time.perf_counter()
-    run_steps(pl, steps, world)
-    sync()
-    el = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    el = block()
+    if spread is not None:
+        blocks = [el]
+        while sum(blocks) < 10e-3 and len(blocks) < 64:   # (el is the max over ranks: every rank takes the same number)
+            blocks.append(block())
+        per = sorted(1e3 * b / steps for b in blocks)
+        spread.update({"blocks_of_k_steps": len(blocks), "covered_ms": 1e3 * sum(blocks), "ms_per_step_first_block": 1e3 * el / steps,
+                       "ms_per_step_min": per[0], "ms_per_step_median": per[len(per) // 2], "ms_per_step_max": per[-1]})
     return el
+
+
+def loop_floor_ms(w, pops_total, tile_arith):
+    """Whole MPC step: max(HBM floor at 8d + 8/h bytes per traj-step, ALU floor at the loop's own operation count) --
+    see attainable()."""
+    units = pops_total * w["h"]
+    a = attainable(w, units, 1, tile_arith, "sample_rollout")
+    return {"hbm_floor_ms": a["hbm_floor_us"] * 1e-3, "alu_floor_ms": a["alu_floor_us"] * 1e-3, "attainable_ms": a["attainable_us"] * 1e-3,
+            "model_step_arithmetic": a["model_step_arithmetic"]}
 
 
 def measure_also(name, rank=0, world=1, steps=200, warmup=20, global_n=None):
@@ -378,7 +440,8 @@ def measure_also(name, rank=0, world=1, steps=200, warmup=20, global_n=None):
     algorithmic bytes (8d+8/h per traj-step) over the step time."""
     w = WORKLOADS[name]
     pl, _, _ = make_planner(w, rank, world, global_n=global_n)
-    el = timed_steps(pl, steps, warmup, world)
+    spread = {}
+    el = timed_steps(pl, steps, warmup, world, spread)
     pl.profile_enable(True)
     run_steps(pl, 10, world)
     torch.cuda.synchronize()
@@ -392,13 +455,17 @@ def measure_also(name, rank=0, world=1, steps=200, warmup=20, global_n=None):
     out = {"workload": w["name"] if not global_n else w["name"].replace(f"N={w['N']}", f"N={n_glob} global"),
            "scaling": "strong" if global_n else "weak", "per_gpu_population": -(-n_glob // world), "global_population": n_glob,
            "n_gpus": world, "value": ts * steps / el, "unit": "traj-steps/s", "ms_per_mpc_step": 1e3 * el / steps,
-           "roofline": roofline_of(prof, w, name if world == 1 else None),
+           "timed_region": spread,
+           "roofline": roofline_of(prof, w, name if world == 1 else None, fit, pl.tile_arith if w["o"] <= 32 else 0),
            "kernels_us": {k: round(1e3 * v[0] / v[1], 2) for k, v in prof.items()},
            "kernels_us_events": {k: round(1e3 * v[0] / v[1], 2) for k, v in without_bracket(raw, bracket).items()},
            "kernels_us_with_event_bracket": {k: round(1e3 * v[0] / v[1], 2) for k, v in raw.items()},
            "event_bracket": bracket, "kernel_times_vs_step": fit,
            "whole_loop_algorithmic_GBps": loop_bytes * steps / el / 1e9,
            "whole_loop_frac_of_hbm_peak": loop_bytes * steps / el / 1e9 / (HBM_PEAK_GBS * world)}
+    if w["o"] <= 32:
+        out["attainable"] = loop_floor_ms(w, sum(pl.population_sizes) / world, pl.tile_arith)
+        out["attainable"]["frac_of_attainable"] = out["attainable"]["attainable_ms"] / out["ms_per_mpc_step"]
     if world > 1:
         out["exchange"] = exchange_report(pl)
     return out
@@ -494,7 +561,9 @@ def measure_c5(w, steps, warmup, cpu=True):
     macs = (w["h"] * mac_rew + (w["h"] - 1) * mac_tr) / w["h"]
     flops = 2.0 * macs * w["h"] * sum(n for _, _, n in spans)
     achieved = flops / (ms * 1e-3) / 1e12
-    roofline = {"bound": "mfma", "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0, "traffic": None,
+    traffic, src, trace_us = measured_traffic("rssm_rollout", "c5")
+    roofline = {"bound": "mfma", "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0, "traffic": traffic,
+                "traffic_source": src, "rocprof_trace_avg_us": trace_us,
                 "kernel": "rssm_split_kernel" if max(n for _, _, n in spans) <= 65536 else "rssm_rollout_kernel", "avg_launch_us": 1e3 * ms / len(spans), "launches": len(spans),
                 "algorithmic_flops_per_traj_step": 2.0 * macs, "dtype": "bf16 operands, f32 accumulation"}
     out = {"metric": "traj-steps/sec (N x h), iCEM inner planning loop", "value": ts * steps / elapsed, "unit": "traj-steps/s",
@@ -629,7 +698,9 @@ def main():
         return
     pl, model, env = make_planner(w, rank, world, cost_mode=args.cost_mode)
     per_step_trajsteps = sum(pl.population_sizes) * w["h"]  # global (all ranks) traj-steps per MPC step
-    elapsed = timed_steps(pl, args.steps, args.warmup, world)
+    spread = {}
+    elapsed = timed_steps(pl, args.steps, args.warmup, world, spread)
+    tile_arith = pl.tile_arith if w["o"] <= 32 else 0
 
     # second pass: per-kernel durations from HIP events on the launch stream
     pl.profile_enable(True)
@@ -654,7 +725,7 @@ def main():
             strong["debug_population"] = shared_gpu
 
     if rank == 0:
-        roofline = roofline_of(prof, w, args.workload if world == 1 else None)
+        roofline = roofline_of(prof, w, args.workload if world == 1 else None, fit, tile_arith)
         out = {
             "metric": "traj-steps/sec (N x h), iCEM inner planning loop", "value": per_step_trajsteps * args.steps / elapsed,
             "unit": "traj-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -666,7 +737,7 @@ def main():
                        "traj_per_mpc_step": per_step_trajsteps // w["h"],
                        "model": "o' = tanh(o.A + a.B) dense (synthetic)" if model.kind == 1 else "o' = o.A + a.B dense linear (synthetic)",
                        "cost": "HumanoidStandup cost_fn" if w.get("env") == "humanoid" else "HalfCheetah cost_fn", "cost_along_trajectory": args.cost_mode, "rng": "Philox4x32-10-seeded xoshiro128++ + Box-Muller", "parallelism": f"n-shard x{world}"},
-            "ms_per_mpc_step": 1e3 * elapsed / args.steps,
+            "ms_per_mpc_step": 1e3 * elapsed / args.steps, "timed_region": spread,
             "roofline": roofline,
             "kernels_us": {k: round(1e3 * v[0] / v[1], 2) for k, v in prof.items()},
             "kernels_us_events": {k: round(1e3 * v[0] / v[1], 2) for k, v in without_bracket(raw_prof, bracket).items()},
@@ -674,6 +745,9 @@ def main():
             "event_bracket": bracket, "kernel_times_vs_step": fit,
             "build": build,
         }
+        if w["o"] <= 32:
+            out["attainable"] = loop_floor_ms(w, per_step_trajsteps / w["h"] / world, tile_arith)
+            out["attainable"]["frac_of_attainable"] = out["attainable"]["attainable_ms"] / out["ms_per_step"]
         if exchange is not None:
             out["exchange"] = exchange
         # GPU measurements first: the OpenMP team of the CPU baseline keeps spinning on the host cores for a

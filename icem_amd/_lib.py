@@ -130,6 +130,9 @@ SYMBOLS = [
     ("icem_profile_read", C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("icem_rssm_trim", C.c_int, []),
     ("icem_set_wide_exact", C.c_int, [_H, _I32]),
+    ("icem_set_wide_arith", C.c_int, [_H, _I32]),
+    ("icem_wide_arith", C.c_int, [_H]),
+    ("icem_wide_imbalance_log2", C.c_int, [_H]),
     ("icem_set_tile_arith", C.c_int, [_H, _I32]),
     ("icem_tile_arith", C.c_int, [_H]),
     ("icem_profile_overhead", C.c_int, [_VP, _I32, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -138,7 +141,7 @@ SYMBOLS = [
 
 IPC_HANDLE_BYTES = 64
 RCCL_ID_BYTES = 128
-ABI_VERSION = 3   # include/icem_hip.h: ICEM_ABI_VERSION
+ABI_VERSION = 4   # include/icem_hip.h: ICEM_ABI_VERSION
 
 
 def lib_path() -> str:

@@ -269,6 +269,18 @@ static void update_paths(icem_handle* h) {
     for (int k = 0; k < 3; ++k) h->hn_prog[k] = hn ? prog[k] : 0;
     if (hn != h->hn_tile) h->fast_model_ready = false;
     h->hn_tile = hn;
+    // wide observations (icem_set_wide_arith): AUTO = the fp16 planes, unless one sweep of balancing leaves a row or column
+    // of the model more than 2^13 below its largest weight (wide_model_imbalance_log2) -- then the bf16 planes, whose
+    // operands are exact at any magnitude; a width the split kernel's LDS does not hold computes in exact f32 whatever is asked
+    int eff = 0;
+    if (h->wide && h->has_model) {
+        eff = h->wide_mode >= 0 ? h->wide_mode : (h->wide_imbalance > 13 ? 2 : 0);
+        if (!wide_split_fits(h->obs_dim, h->cfg.act_dim)) eff = 1;
+    } else if (gemm_rollout(h)) {
+        eff = 1;   // narrow models on the GEMM kernel: the exact-f32 form (two workgroup barriers per step buy nothing at o <= 32)
+    }
+    if (eff != h->wide_eff) h->fast_model_ready = false;
+    h->wide_eff = eff;
 }
 
 static int sync_wide_cost(icem_handle* h);
@@ -304,6 +316,7 @@ int icem_set_model(icem_handle* h, int32_t kind, int32_t obs_dim, const double* 
         h->has_model = true;
         h->A_host.assign(A_host, A_host + (size_t)obs_dim * obs_dim);
         h->B_host.assign(B_host, B_host + (size_t)d * obs_dim);
+        h->wide_imbalance = wide_model_imbalance_log2(obs_dim, d, h->A_host.data(), h->B_host.data());
         h->fast_model_ready = false;
         update_paths(h);
         return sync_wide_cost(h);
@@ -362,8 +375,11 @@ int icem_set_cost(icem_handle* h, const icem_cost_spec* spec) {
     if (!h || !spec) return fail(ICEM_E_INVALID, "null argument");
     h->cost = *spec;
     h->has_cost = true;
-    h->fast_model_ready = false;
+    // the tile kernels' packed model is permuted by the cost's columns; the GEMM kernels' is not: a cost-only change leaves
+    // their packing alone unless the kernel family flips (update_paths clears the flag itself then)
+    const bool was_gemm = gemm_rollout(h);
     update_paths(h);
+    if (!(was_gemm && gemm_rollout(h))) h->fast_model_ready = false;
     return sync_wide_cost(h);
 }
 
@@ -548,11 +564,24 @@ int icem_debug_stamps(icem_handle* h, void* dev_ptr) {
     return ICEM_OK;
 }
 
-int icem_set_wide_exact(icem_handle* h, int32_t on) {
+int icem_set_wide_arith(icem_handle* h, int32_t mode) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (mode < ICEM_WIDE_AUTO || mode > ICEM_WIDE_BF16X3)
+        return fail(ICEM_E_INVALID, "wide arithmetic: ICEM_WIDE_AUTO (-1), ICEM_WIDE_F16X2 (0), ICEM_WIDE_F32 (1) or ICEM_WIDE_BF16X3 (2)");
+    if (h->pm_pending || h->pk_pending) return fail(ICEM_E_STATE, "a deferred merge is pending: finish the MPC step first");
+    h->wide_mode = mode;
+    update_paths(h);
+    return ICEM_OK;
+}
+
+int icem_wide_arith(const icem_handle* h) { return h ? h->wide_eff : 0; }
+
+int icem_wide_imbalance_log2(const icem_handle* h) { return h ? h->wide_imbalance : 0; }
+
+int icem_set_wide_exact(icem_handle* h, int32_t on) {   // ABI <= 3 spelling of icem_set_wide_arith (0 / 1 / 2)
     if (check_handle(h)) return ICEM_E_INVALID;
     if (on < 0 || on > 2) return fail(ICEM_E_INVALID, "icem_set_wide_exact: 0 (fp16 planes), 1 (exact f32) or 2 (bf16 planes)");
-    h->wide_mode = on;
-    return ICEM_OK;
+    return icem_set_wide_arith(h, on);
 }
 
 int icem_profile_enable(icem_handle* h, int32_t on) {

@@ -115,7 +115,10 @@ struct icem_handle {
     void* Mwh_ksc_dev = nullptr; // ... and the contraction entries' and output columns' powers of two (the model equilibrated): [Mwh_nk | columns]
     int Mwh_nk = 0;
     float Mwh_sbound = 0.f;
-    int wide_mode = 0;           // icem_set_wide_exact: 0 = fp16 planes (3 products per multiply-add), 1 = the exact-f32 matrix pipe
+    int wide_mode = -1;          // icem_set_wide_arith: ICEM_WIDE_AUTO (-1) / F16X2 (0) / F32 (1) / BF16X3 (2) as asked for ...
+    int wide_eff = 0;            // ... and the one in effect (update_paths: AUTO = fp16 planes unless the balanced model is not)
+    int wide_imbalance = 0;      // wide_model_imbalance_log2 of the current model
+    int wide_packed = -2;        // which arithmetic Mw_dev / Mwh_dev / Mws_dev currently hold the model for (-2: none)
                                  // (k_rollout_wide.hip + its row kernel), 2 = bf16 planes (6 products)
     void* wide_cs_dev = nullptr; // CostArgs<float> (cost spec + terms) for k_rollout_wide, refreshed by the cost setters
     void* Mp_dev = nullptr;

@@ -139,6 +139,7 @@ int wide_split_kb(int o, int d);
 int wide_split_xs(int o, int d);
 int wide_split_lists(int n_rows);
 bool wide_split_fits(int o, int d);   // the workgroup's rows + planes in 160 KB of LDS (o + d <= 416); else the exact-f32 kernel
+int wide_model_imbalance_log2(int o, int d, const double* A, const double* B);   // ICEM_WIDE_AUTO's criterion (k_rollout_wide_split.hip)
 void pack_wide_model_split(int o, int d, const double* A, const double* B, int planes, std::vector<unsigned short>& Mb, float* minv,
                            std::vector<float>* ksc, std::vector<float>* csc, float* sbound);
 void launch_rollout_wide_split(const WideRolloutArgs& a, int kind, hipStream_t st);

@@ -561,6 +561,90 @@ int wide_split_lists(int n_rows) {
     return std::min(std::max(1, tiles / (SPLIT_TT - 1)), FAST_MAX_LISTS);
 }
 
+// How far the EQUILIBRATED model (rows, then columns scaled by powers of two as pack_wide_model_split does for the fp16
+// planes) stays from balanced: the largest log2(global max / line max) over its live rows and live columns.  0-1 for a
+// model one sweep balances; a row or column whose LARGEST weight sits 2^13 below the model's largest has every entry where
+// the fp16 pair no longer carries f32's 22+ bits relative to that line (the lo plane in fp16's subnormals) -- the model
+// ICEM_WIDE_AUTO hands to the bf16 planes, whose operands are exact at any magnitude.  Incidental small entries inside a
+// line that has a large one do not count (their error is absolute, 2^-40 of that line's largest; a dense random model has
+// some 0.05 % of its entries 2^13 below its largest) -- a STRUCTURAL spread does: where the 1 % quantile of the nonzero
+// |entries| lies that far down (a block of the model in other units than diagonal scaling can take out), the states that
+// exercise those weights carry 10^-6 relative per step.  Returned: the larger of the two measures.
+int wide_model_imbalance_log2(int o, int d, const double* A, const double* B) {
+    auto M = [&](int r, int c) -> double { return r < o ? A[(size_t)r * o + c] : B[(size_t)(r - o) * o + c]; };
+    std::vector<int> ek((size_t)o + d, 0), fj((size_t)o, 0);
+    std::vector<char> dead((size_t)o + d, 1);
+    for (int r = 0; r < o + d; ++r) {
+        float wmax = 0.f;
+        bool any = false;
+        for (int c = 0; c < o; ++c) {
+            const float m = std::fabs((float)M(r, c));
+            if (std::isfinite(m) && m > wmax) wmax = m;
+            any = any || M(r, c) != 0.0;
+        }
+        if (!any) continue;
+        int e = 0;
+        if (wmax > 0.f) (void)std::frexp(wmax, &e);
+        ek[r] = e < -100 ? -100 : (e > 100 ? 100 : e);
+        dead[r] = 0;
+    }
+    std::vector<float> cmax((size_t)o, 0.f), rmax((size_t)o + d, 0.f);
+    for (int c = 0; c < o; ++c) {
+        for (int r = 0; r < o + d; ++r) {
+            if (dead[r]) continue;
+            const float m = std::fabs(std::ldexp((float)M(r, c), -ek[r]));
+            if (std::isfinite(m) && m > cmax[c]) cmax[c] = m;
+        }
+        int f = 0;
+        if (cmax[c] > 0.f) (void)std::frexp(cmax[c], &f);
+        fj[c] = f < -100 ? -100 : (f > 100 ? 100 : f);
+    }
+    float gmax = 0.f;
+    std::fill(cmax.begin(), cmax.end(), 0.f);
+    for (int r = 0; r < o + d; ++r) {
+        if (dead[r]) continue;
+        for (int c = 0; c < o; ++c) {
+            const float m = std::fabs(std::ldexp((float)M(r, c), -ek[r] - fj[c]));
+            if (!std::isfinite(m)) continue;
+            rmax[r] = std::max(rmax[r], m);
+            cmax[c] = std::max(cmax[c], m);
+            gmax = std::max(gmax, m);
+        }
+    }
+    if (!(gmax > 0.f)) return 0;
+    int worst = 0;
+    {   // the structural spread: global max over the 1 % quantile of the nonzero entries
+        std::vector<float> mags;
+        mags.reserve((size_t)(o + d) * o);
+        for (int r = 0; r < o + d; ++r) {
+            if (dead[r]) continue;
+            for (int c = 0; c < o; ++c) {
+                const float m = std::fabs(std::ldexp((float)M(r, c), -ek[r] - fj[c]));
+                if (std::isfinite(m) && m > 0.f) mags.push_back(m);
+            }
+        }
+        if (!mags.empty()) {
+            const size_t q = mags.size() / 100;
+            std::nth_element(mags.begin(), mags.begin() + q, mags.end());
+            int eg = 0, eq = 0;
+            (void)std::frexp(gmax, &eg);
+            (void)std::frexp(mags[q], &eq);
+            worst = std::max(worst, eg - eq);
+        }
+    }
+    auto line = [&](float mx) {
+        if (!(mx > 0.f)) return;   // (a column nothing feeds: zero in every arithmetic)
+        int eg = 0, el = 0;
+        (void)std::frexp(gmax, &eg);
+        (void)std::frexp(mx, &el);
+        worst = std::max(worst, eg - el);
+    };
+    for (int r = 0; r < o + d; ++r)
+        if (!dead[r]) line(rmax[r]);
+    for (int c = 0; c < o; ++c) line(cmax[c]);
+    return worst;
+}
+
 // Mb[kb][wave][ct][plane][lane][v] = plane of (float)M[32 kb + 8 (lane / 16) + v][16 (NCT wave + ct) + lane % 16],
 // M = [A ; B] ([o + d, o], zero padded).  planes = 3: bf16 lo, mid, hi.  planes = 2: fp16 lo, hi of M x 2^k, k such that the
 // largest entry stays below 2^15; *minv = 2^-k.

@@ -27,50 +27,66 @@ namespace icem {
 int ensure_fast_model(icem_handle* h) {
     if (h->fast_model_ready) return ICEM_OK;
     if (gemm_rollout(h)) {  // the GEMM kernels' model, packed in MFMA operand order (k_rollout_wide.hip, k_rollout_wide_split.hip)
-        std::vector<float> Mw;
-        pack_wide_model(h->obs_dim, h->cfg.act_dim, h->A_host.data(), h->B_host.data(), Mw);
-        if (h->Mw_dev) (void)hipFree(h->Mw_dev);
-        ICEM_HIP_TRY(hipMalloc(&h->Mw_dev, Mw.size() * sizeof(float)));
-        ICEM_HIP_TRY(hipMemcpy(h->Mw_dev, Mw.data(), Mw.size() * sizeof(float), hipMemcpyHostToDevice));
-        for (int planes = 2; planes <= 3; ++planes) {   // fp16 (hi, lo) x 2^k and bf16 (hi, mid, lo) planes: k_rollout_wide_split.hip
-            std::vector<unsigned short> Mb;
-            void*& dev = planes == 2 ? h->Mwh_dev : h->Mws_dev;
-            float minv = 1.f;
-            std::vector<float> ksc, csc;
-            float sb = 0.f;
-            pack_wide_model_split(h->obs_dim, h->cfg.act_dim, h->A_host.data(), h->B_host.data(), planes, Mb, &minv, &ksc, &csc, &sb);
-            if (planes == 2) {   // the scales of the equilibrated model: [ksc | csc] in one allocation
-                h->Mwh_inv = minv;
-                h->Mwh_sbound = sb;
-                h->Mwh_nk = (int)ksc.size();
-                ksc.insert(ksc.end(), csc.begin(), csc.end());
-                if (h->Mwh_ksc_dev) (void)hipFree(h->Mwh_ksc_dev);
-                h->Mwh_ksc_dev = nullptr;
-                ICEM_HIP_TRY(hipMalloc(&h->Mwh_ksc_dev, ksc.size() * sizeof(float)));
-                ICEM_HIP_TRY(hipMemcpy(h->Mwh_ksc_dev, ksc.data(), ksc.size() * sizeof(float), hipMemcpyHostToDevice));
-            }
-            if (dev) (void)hipFree(dev);
-            dev = nullptr;
-            ICEM_HIP_TRY(hipMalloc(&dev, Mb.size() * sizeof(unsigned short)));
-            ICEM_HIP_TRY(hipMemcpy(dev, Mb.data(), Mb.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
-        }
-        if (!h->wide) {   // a narrow model on the GEMM kernel: A_dev / B_dev keep the generic kernels' padded layout
-            h->fast_model_ready = true;
-            return ICEM_OK;
-        }
-        // ... and row-major in f32 for the rows rolled out one by one (rollout_rows_wide_kernel)
-        auto upload_f32 = [](void** dev, const std::vector<double>& host) -> int {
-            std::vector<float> tmp(host.begin(), host.end());
-            if (*dev) (void)hipFree(*dev);
-            *dev = nullptr;
-            ICEM_HIP_TRY(hipMalloc(dev, tmp.size() * sizeof(float)));
-            ICEM_HIP_TRY(hipMemcpy(*dev, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice));
+        // ONE packing, the one of the arithmetic in effect (icem_handle::wide_eff): exact f32, two fp16 planes with the
+        // equilibrated model's scales, or three bf16 planes.  Everything is uploaded into fresh allocations first and the
+        // handle's pointers and scales change together, after the last upload succeeded.
+        struct Fresh {
+            void* p[4] = {nullptr, nullptr, nullptr, nullptr};
+            ~Fresh() { for (void* q : p) if (q) (void)hipFree(q); }
+        } fr;
+        auto up = [](void** dev, const void* src, size_t bytes) -> int {
+            ICEM_HIP_TRY(hipMalloc(dev, bytes));
+            ICEM_HIP_TRY(hipMemcpy(*dev, src, bytes, hipMemcpyHostToDevice));
             return ICEM_OK;
         };
-        int rc = upload_f32(&h->A_dev, h->A_host);
+        const int eff = h->wide_eff;
+        float minv = 1.f, sb = 0.f;
+        int nk = 0;
+        int rc = ICEM_OK;
+        if (eff == 1) {
+            std::vector<float> Mw;
+            pack_wide_model(h->obs_dim, h->cfg.act_dim, h->A_host.data(), h->B_host.data(), Mw);
+            rc = up(&fr.p[0], Mw.data(), Mw.size() * sizeof(float));
+        } else {
+            std::vector<unsigned short> Mb;
+            std::vector<float> ksc, csc;
+            pack_wide_model_split(h->obs_dim, h->cfg.act_dim, h->A_host.data(), h->B_host.data(), eff == 2 ? 3 : 2, Mb, &minv, &ksc, &csc, &sb);
+            rc = up(&fr.p[0], Mb.data(), Mb.size() * sizeof(unsigned short));
+            if (!rc && eff == 0) {   // the scales of the equilibrated model: [ksc | csc] in one allocation
+                nk = (int)ksc.size();
+                ksc.insert(ksc.end(), csc.begin(), csc.end());
+                rc = up(&fr.p[1], ksc.data(), ksc.size() * sizeof(float));
+            }
+        }
         if (rc) return rc;
-        rc = upload_f32(&h->B_dev, h->B_host);
-        if (rc) return rc;
+        if (h->wide) {   // ... and row-major in f32 for the rows rolled out one by one (rollout_rows_wide_kernel) and TileHN
+            std::vector<float> tmp(h->A_host.begin(), h->A_host.end());
+            rc = up(&fr.p[2], tmp.data(), tmp.size() * sizeof(float));
+            if (rc) return rc;
+            tmp.assign(h->B_host.begin(), h->B_host.end());
+            rc = up(&fr.p[3], tmp.data(), tmp.size() * sizeof(float));
+            if (rc) return rc;
+        }
+        // commit
+        void*& slot = eff == 1 ? h->Mw_dev : (eff == 0 ? h->Mwh_dev : h->Mws_dev);
+        for (void** old : {&h->Mw_dev, &h->Mwh_dev, &h->Mws_dev, &h->Mwh_ksc_dev}) {
+            if (*old) (void)hipFree(*old);
+            *old = nullptr;
+        }
+        slot = fr.p[0];
+        h->Mwh_ksc_dev = fr.p[1];
+        h->Mwh_inv = minv;
+        h->Mwh_sbound = sb;
+        h->Mwh_nk = nk;
+        fr.p[0] = fr.p[1] = nullptr;
+        if (h->wide) {   // (a narrow model on the GEMM kernel: A_dev / B_dev keep the generic kernels' padded layout)
+            if (h->A_dev) (void)hipFree(h->A_dev);
+            if (h->B_dev) (void)hipFree(h->B_dev);
+            h->A_dev = fr.p[2];
+            h->B_dev = fr.p[3];
+            fr.p[2] = fr.p[3] = nullptr;
+        }
+        h->wide_packed = eff;
         h->fast_model_ready = true;
         return ICEM_OK;
     }
@@ -186,7 +202,7 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
     }
     if (gemm_rollout(h)) {
         // narrow observations always take the exact-f32 kernel (two workgroup barriers per step buy nothing at o <= 32)
-        const bool exact = h->wide_mode == 1 || !h->wide || !wide_split_fits(h->obs_dim, h->cfg.act_dim);
+        const bool exact = h->wide_eff == 1;   // (update_paths: asked for, a narrow model, or a width the split kernel does not hold)
         // trailing shifted elites that would open a tile of their own: rolled out row by row (rollout_rows_wide_kernel),
         // scored by the merge through the cost array (tail_out rows; the caller's merge takes them as extra candidates)
         // (exact-f32 tile kernel only: the bf16-split kernel's workgroups take a fifth tile instead)
@@ -214,7 +230,7 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
         w.flip_pen = (float)h->cost.flip_penalty;
         w.flip_th = (float)h->cost.flip_thresh;
         w.cs = h->has_terms ? (const CostArgs<float>*)h->wide_cs_dev : nullptr;
-        w.planes = h->wide_mode == 2 ? 3 : 2;   // (split kernel) fp16 planes unless the bf16 ones were asked for
+        w.planes = h->wide_eff == 2 ? 3 : 2;    // (split kernel) fp16 planes, or the bf16 ones (asked for, or AUTO on an unbalanced model)
         w.minv = w.planes == 2 ? h->Mwh_inv : 1.f;
         w.ksc = (const float*)h->Mwh_ksc_dev;
         w.csc = w.ksc ? w.ksc + h->Mwh_nk : nullptr;
@@ -426,8 +442,12 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
     T* rec = (T*)b->records + (size_t)c.rank * K * (hd + 2);
     h->fast_lists = 0;
     if constexpr (std::is_same<T, float>::value) {
-        if (b->z_r == nullptr && fast_rollout_ok(h, K)) {
-            // f32 throughput path
+        if (fast_rollout_ok(h, K)) {
+            // f32 throughput path.  External white noise (b->z_r: the reference's own draws, tests/golden) takes it too: the
+            // generic sampler turns the caller's z into the pool (it is the only kernel that reads z), and from there on the
+            // tile rollout, the lists and the threshold merges are the ones device noise gets -- the reference's draws reach
+            // Tile16 / Tile16H and merge_select*, not only the generic kernels.
+            const bool ext_z = b->z_r != nullptr;
             const uint64_t off = call_base + (uint64_t)it;
             int rc = ensure_fast_model(h);
             if (rc) return rc;
@@ -436,14 +456,14 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
             int* pi;
             const int n_rows = n_loc + n_extra;
             int tail_rows = 0;  // shifted-elite rows scored through the cost array instead of a list (world 1 only)
-            const int one = (fast_sample_ok(h) && (n_extra == 0 || shift_in_sampler))
+            const int one = (!ext_z && fast_sample_ok(h) && (n_extra == 0 || shift_in_sampler))
                                 ? one_launch_lists(h, n_rows, shift_in_sampler ? n_extra : 0, &tail_rows) : 0;
             h->fast_tail_rows = one > 0 ? tail_rows : 0;
             // the merge finds the lists' indices behind `lists * K` costs
             split_partial_ws<float>(b->workspace, one > 0 ? one : rollout_lists(c.horizon, c.act_dim, h->Of, n_rows), K, &pc, &pi);
             bool prologue = false, ride = false;
             if (h->pm_pending) {
-                prologue = n_extra == 0 && prologue_possible(h, n_rows);
+                prologue = !ext_z && n_extra == 0 && prologue_possible(h, n_rows);
                 // a stashed pack rides with the merge whose records it produces, or runs now -- in front of that merge
                 ride = prologue && h->pk_pending && next_launch_takes_pack(h, n_rows);
                 if (h->pk_pending && !ride) {
@@ -508,6 +528,8 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                     }
                     ICEM_HIP_TRY(hipGetLastError());
                     rc = ICEM_OK;
+                } else if (ext_z) {
+                    rc = gk_sample(h, n_loc, lo, b->mean, b->std, b->low, b->high, b->z_r, b->z_i, off, 0, row0, actions, st);
                 } else if (fast_sample_ok(h)) {
                     rc = launch_fast_sample(h, n_loc, lo, b->mean, b->std, b->low, b->high, off, row0, actions, st,
                                             shift_in_sampler ? n_extra : 0, shift_src, call_base + (uint64_t)c.opt_iters);

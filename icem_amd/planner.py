@@ -341,10 +341,30 @@ class IcemPlanner:
     def tile_arith(self):
         return int(self.lib.icem_tile_arith(self._h))
 
+    WIDE_ARITH = {"auto": -1, "f16x2": 0, "fp16x2": 0, "f32": 1, "bf16x3": 2}
+
+    def set_wide_arith(self, mode="auto"):
+        """obs_dim > 32: which arithmetic the model step's GEMM runs in (``icem_set_wide_arith``), by NAME: ``"f32"`` the
+        exact-f32 matrix pipe (bitwise an fmaf chain -- strict parity), ``"f16x2"`` two fp16 planes per operand (three
+        products per multiply-add), ``"bf16x3"`` three bf16 planes (six products, operands exact at any magnitude),
+        ``"auto"`` (the library's default) f16x2 unless the balanced model keeps a row or column more than 2^13 below its
+        largest weight -- then bf16x3.  Returns the arithmetic now in effect (a name)."""
+        m = self.WIDE_ARITH.get(mode, mode)
+        L.check(self.lib.icem_set_wide_arith(self._h, int(m)))
+        return self.wide_arith
+
+    @property
+    def wide_arith(self):
+        """The wide arithmetic in effect for the current model: ``"f16x2"`` / ``"f32"`` / ``"bf16x3"``."""
+        return {0: "f16x2", 1: "f32", 2: "bf16x3"}[int(self.lib.icem_wide_arith(self._h))]
+
+    @property
+    def wide_imbalance_log2(self):
+        return int(self.lib.icem_wide_imbalance_log2(self._h))
+
     def set_wide_exact(self, on=True):
-        """obs_dim > 32: which arithmetic the model step's GEMM runs in (``icem_set_wide_exact``): ``False`` / 0 the default
-        two-way fp16 split on the fp16 matrix cores, ``True`` / 1 the exact-f32 matrix pipe (bitwise an fmaf chain), 2 the
-        three-way bf16 split."""
+        """ABI <= 3 spelling of :meth:`set_wide_arith`: ``False`` / 0 the fp16 planes, ``True`` / 1 exact f32, 2 the bf16
+        planes (``on`` defaults to exact f32; the LIBRARY's default is ``"auto"``)."""
         L.check(self.lib.icem_set_wide_exact(self._h, int(on)))
 
     # ------------------------------------------------------------------ measurement

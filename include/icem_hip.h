@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ICEM_ABI_VERSION 3 /* 2: icem_build_hash, icem_allgather_elites / icem_rccl_*, noise-ahead planning; ICEM_MAX_OBS_DIM 384; 3: icem_set_tile_arith */
+#define ICEM_ABI_VERSION 4 /* 2: icem_build_hash, icem_allgather_elites / icem_rccl_*, noise-ahead planning; ICEM_MAX_OBS_DIM 384; 3: icem_set_tile_arith; 4: icem_set_wide_arith (default AUTO) */
 
 enum { ICEM_F32 = 0, ICEM_F64 = 1 };
 enum { ICEM_COST_SUM = 0, ICEM_COST_BEST = 1, ICEM_COST_FINAL = 2 }; /* abstract_controller.py:82-87 */
@@ -390,15 +390,31 @@ int icem_plan_step_sharded(icem_handle* h, const icem_plan_buffers* b, int32_t m
 int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, void* stream);
 
 /* Wide observations (32 < obs_dim <= 384; HumanoidStandup's o = 378, environments/mujoco.py:241-277): which matrix-pipe
- * arithmetic the rollout's model step (the GEMM of abstract_models.py:31-53's predict at this width) runs in.
- * 0 (default): every f32 operand x 2^k (k per trajectory row / per model, so that nothing exceeds 2^15) as the sum of two
- * fp16 numbers, three fp16 products per multiply-add with f32 accumulation on v_mfma_f32_16x16x32_f16 -- f32-class
- * rounding (operands to 2^-24 relative, the dropped lo x lo product below 2^-24 of a product), not the bits of an f32 fmaf
- * chain.  (The model is carried equilibrated -- rows and columns scaled by powers of two -- so observations in mixed units
- * keep their accuracy; contributions more than 2^13 apart inside the balanced model keep an absolute, not a relative,
- * accuracy: 2^-40 of a row's largest.  A model like that should use 2.)  2: the same with three bf16 numbers and six products (operands exact whatever their
- * magnitudes, dropped products below 2^-31), at two thirds of the speed; 1: v_mfma_f32_16x16x4_f32, bitwise an fmaf chain, at a quarter of the speed.  Takes effect at the
- * next rollout; no effect at obs_dim <= 32.  Other values: ICEM_E_INVALID. */
+ * arithmetic the rollout's model step (the GEMM of abstract_models.py:31-53's predict at this width) runs in.  The modes
+ * are NAMES, not an accuracy order:
+ *   ICEM_WIDE_F32 (1): v_mfma_f32_16x16x4_f32 -- bitwise an f32 fmaf chain, a quarter of the speed.  What strict-parity
+ *     callers pass; the only arithmetic at widths the split kernel's LDS does not hold (o + d > 416).
+ *   ICEM_WIDE_F16X2 (0): every f32 operand x 2^k (k per trajectory row / per model, so that nothing exceeds 2^15) as the
+ *     sum of two fp16 numbers, three fp16 products per multiply-add with f32 accumulation on v_mfma_f32_16x16x32_f16 --
+ *     f32-class rounding (operands to 2^-24 relative, the dropped lo x lo product below 2^-24 of a product), NOT the bits
+ *     of an f32 fmaf chain; a tanh model's state is bounded by the equilibrated scales instead of scanned.  The model is
+ *     carried equilibrated -- rows and columns scaled by powers of two -- so observations in mixed units keep their
+ *     accuracy; contributions more than 2^13 apart inside the balanced model keep an absolute, not a relative, accuracy:
+ *     2^-40 of a row's largest.
+ *   ICEM_WIDE_BF16X3 (2): three bf16 numbers and six products (operands exact whatever their magnitudes, dropped products
+ *     below 2^-31), two thirds of F16X2's speed.
+ *   ICEM_WIDE_AUTO (-1, THE DEFAULT since ABI 4; ABI 3 defaulted to F16X2 unconditionally, ABI 2 to F32): F16X2 where one
+ *     sweep of balancing leaves every row and column of the model within 2^13 of its largest weight
+ *     (icem_wide_imbalance_log2 <= 13), BF16X3 otherwise -- decided per model at icem_set_model.  A caller that needs the
+ *     fmaf chain's bits (golden vectors recorded at this width in f32) must ask for ICEM_WIDE_F32; the parity bar of
+ *     north_star (1e-5 relative, identical elite sets) holds in all three (tests/test_gpu_parity_sizes.py).
+ * icem_wide_arith: the arithmetic in effect for the handle's current model (never AUTO).  Takes effect at the next
+ * rollout; no effect at obs_dim <= 32 (narrow models on the GEMM kernel always compute in exact f32: icem_wide_arith = 1).
+ * Other values: ICEM_E_INVALID.  icem_set_wide_exact(h, on) is the ABI <= 3 spelling of icem_set_wide_arith(h, on), on in {0, 1, 2}. */
+enum { ICEM_WIDE_AUTO = -1, ICEM_WIDE_F16X2 = 0, ICEM_WIDE_F32 = 1, ICEM_WIDE_BF16X3 = 2 };
+int icem_set_wide_arith(icem_handle* h, int32_t mode);
+int icem_wide_arith(const icem_handle* h);
+int icem_wide_imbalance_log2(const icem_handle* h); /* log2(largest weight / largest weight of the weakest row or column) of the balanced model */
 int icem_set_wide_exact(icem_handle* h, int32_t on);
 
 /* Narrow observations (the 16-trajectory tile kernels, 16 <= padded obs_dim <= 20: HalfCheetah's o = 17 / 18): which

@@ -33,7 +33,7 @@ def test_header_symbols_all_exported(lib):
 
 
 def test_abi_version_and_error_string(lib):
-    assert lib.icem_abi_version() == L.ABI_VERSION == 3
+    assert lib.icem_abi_version() == L.ABI_VERSION == 4
     assert isinstance(lib.icem_last_error(), bytes)
 
 

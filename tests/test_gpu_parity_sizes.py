@@ -421,6 +421,53 @@ def test_wide_split_planes_in_mixed_units(mode):
     assert np.all(np.abs(got - want) <= 1e-5 * np.abs(want) + 2e-5), (np.abs(got - want).max(), np.abs(want).max())
 
 
+def test_wide_auto_picks_the_arithmetic_from_the_balanced_model():
+    """icem_set_wide_arith's default (ICEM_WIDE_AUTO): the fp16 planes for a model one sweep of balancing brings within
+    2^13 of its largest weight -- a dense random model, the same dynamics in units ten decades apart -- and the bf16
+    planes (exact operands) for one it does not: a 10 x 10 block of A in units 2^20 larger than the rest, which no diagonal
+    scaling takes out.  The named modes override it; the ABI <= 3 spelling still works; costs stay within 1e-5 of the
+    float64 oracle in whatever AUTO picked, on a state that exercises the small weights."""
+    from icem_amd import IcemConfig, IcemPlanner, DeviceSyntheticModel
+    o, d, h, n = 120, 5, 12, 96
+    base = DeviceSyntheticModel.make(o, d, kind=0)
+    A0 = np.asarray(base.A, np.float64).reshape(o, o)
+    B0 = np.asarray(base.B, np.float64).reshape(d, o)
+    rs = np.random.RandomState(9)
+    lo, hi = -0.4 * np.ones(d), 0.4 * np.ones(d)
+
+    def planner(A, B):
+        pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=n, elites_size=2, opt_iters=1, dtype="f32"), lo, hi)
+        pl.set_model(0, A, B)
+        pl.set_cost(0.1, 2, -1.0, -1, 0.0, 0.0)
+        return pl
+    pl = planner(A0, B0)
+    assert pl.wide_arith == "f16x2" and pl.wide_imbalance_log2 <= 13, (pl.wide_arith, pl.wide_imbalance_log2)
+    D = 10.0 ** rs.uniform(-4, 6, o)
+    pl = planner(A0 / D[:, None] * D[None, :], B0 * D[None, :])
+    assert pl.wide_arith == "f16x2" and pl.wide_imbalance_log2 <= 13, (pl.wide_arith, pl.wide_imbalance_log2)
+    A = A0.copy()
+    A[10:20, 10:20] *= 2.0 ** 20 / 64   # (/ 64: keep the linear dynamics from blowing up over the horizon)
+    A[10:20, :10] *= 2.0 ** -6
+    A[10:20, 20:] *= 2.0 ** -6
+    pl = planner(A, B0)
+    assert pl.wide_imbalance_log2 > 13 and pl.wide_arith == "bf16x3", (pl.wide_arith, pl.wide_imbalance_log2)
+    obs = 0.3 * rs.randn(o)
+    obs[10:20] *= 2.0 ** -14   # small entries against large weights: every contribution of ordinary size
+    act = rs.uniform(-0.4, 0.4, (n, h, d)).astype(np.float32)
+    oc = O.CostSpec(0.1, 2, -1.0, -1, 0.0, 0.0)
+    want = O.rollout_costs(O.SyntheticModel(A, B0, 0), oc, obs.astype(np.float32).astype(np.float64), act.astype(np.float64))
+    got = np_(pl.rollout_cost(obs, torch.as_tensor(act, device=pl.device))).astype(np.float64)
+    assert np.all(np.isfinite(got))
+    assert np.all(np.abs(got - want) <= 1e-5 * np.abs(want) + 2e-5), (np.abs(got - want).max(), np.abs(want).max())
+    for name in ("f16x2", "f32", "bf16x3"):
+        assert pl.set_wide_arith(name) == name
+    pl.set_wide_exact(0)
+    assert pl.wide_arith == "f16x2"
+    assert pl.set_wide_arith("auto") == "bf16x3"
+    with pytest.raises(Exception, match="INVALID|wide arithmetic"):
+        pl.set_wide_arith(3)
+
+
 @pytest.mark.soak
 @pytest.mark.parametrize("N", [4096, 16384])
 def test_soak_elite_sets_against_float64_oracle(N):
