@@ -117,7 +117,18 @@ class ModelBasedController(Controller, ABC):
             return
         viz = getattr(self, "visualize_env", None)
         if viz is None:
-            viz = self.visualize_env = env.make_visualization_copy()
+            # abstract_controller.py:99-107: a second instance of the env by NAME, with rendering switched on where the env
+            # only enables it at construction; envs that bring their own copy constructor are asked for that instead
+            from copy import deepcopy
+            init_kwargs = deepcopy(getattr(env, "init_kwargs", {}) or {})
+            if getattr(env, "enable_rendering_at_init", False):
+                init_kwargs["enable_rendering"] = True
+            factory = getattr(self, "env_from_string", None) or globals().get("env_from_string")
+            if factory is not None and getattr(env, "name", None) is not None:
+                viz = factory(env.name, **init_kwargs)
+            else:
+                viz = env.make_visualization_copy()
+            self.visualize_env = viz
             viz.reset()
         if self.do_visualize_plan == "last":
             viz.set_state_from_observation(obs[-1])
@@ -226,6 +237,22 @@ class MpcController(ModelBasedController, StatefulController, ABC):
             raise ValueError("At least two trajectories needed!")
         self.verbose = verbose
         self.forward_model_state = None
+
+    def check_model_consistency(self):
+        """mpc.py:39-47: a ground-truth model's state against the actual environment's (verbose mode).  Ground-truth models
+        and envs are recognised by their interface (``get_GT_state`` / ``compute_state_difference``: the simulators
+        themselves are out of scope); for every other pair this is a no-op, as upstream."""
+        env, fm = self.env, self.forward_model
+        if not (callable(getattr(env, "get_GT_state", None)) and callable(getattr(env, "compute_state_difference", None))
+                and callable(getattr(fm, "set_state", None))):
+            return
+        model_state = self.forward_model_state
+        env_state = env.get_GT_state()
+        diff = env.compute_state_difference(model_state, env_state)
+        if diff > 1e-5:
+            print(f"Warning: internal GT model and actual env are not in sync: Difference: {diff}")
+            print("env state:", env_state)
+            print("model_state:", model_state)
 
     def simulate_trajectories(self, *, obs, state, action_sequences):
         """mpc.py:56-67: tile the start observation, wrap the actions in an open-loop policy and
@@ -494,10 +521,20 @@ class MpcICemHip(MpcController):
     def get_action(self, obs, state, mode="train"):
         if not self.was_reset:
             raise AttributeError("beginning_of_rollout() needs to be called before")
+        if self.verbose:   # icem.py:112-115
+            print(f"-------------------- {self.mean[0][0:6]}")
+            if mode != "expert":
+                self.check_model_consistency()
         self.forward_model_state = self.forward_model.got_actual_observation_and_env_state(
             observation=obs, env_state=state, model_state=self.forward_model_state)
         noise = self._noise_fn()
-        if self.device_path and noise is None and self.planner.cfg.world == 1:
+        if self.device_path and self.verbose:
+            # icem.py:151-158: best / mean / worst cost and the best first action of every iteration -- the per-iteration
+            # form of the step (one host synchronisation per iteration: a debugging mode, as upstream)
+            executed_dev = self.planner.plan_step(obs, noise=noise, on_iteration=self._print_iteration)
+            host = torch.cat([executed_dev, self.planner.best_cost]).cpu().numpy().astype(np.float64)
+            executed_action, self.last_min_cost = host[:-1], float(host[-1])
+        elif self.device_path and noise is None and self.planner.cfg.world == 1:
             executed_action, self.last_min_cost = self.planner.get_action_host(obs)   # one call, one synchronisation
         elif self.device_path:
             executed_dev = self.planner.plan_step(obs, noise=noise)
@@ -514,6 +551,24 @@ class MpcICemHip(MpcController):
                 observations=obs, states=self.forward_model_state, actions=executed_action)
         return executed_action
 
+    def _print_iteration(self, it):
+        """The reference's verbose line (icem.py:151-158) from the device buffers of iteration ``it``: costs of the simulated
+        pool (+ the kept elites behind it), the first action of the cheapest row."""
+        p = self.planner
+        n = p.population_sizes[it]
+        n_sim = n + (p.n_reuse if (it == 0 and self.shift_elites_over_time and p.mpc_step > 0) else 0)
+        costs = p.costs[:n_sim]
+        if it > 0 and self.keep_previous_elites and p.n_reuse > 0:
+            g = (p.mpc_step * p.cfg.opt_iters + it) & 1      # the set the merge of this iteration read
+            costs = torch.cat([costs, p.elites_costs[g][:p.n_reuse]])
+        c = costs.detach().cpu().numpy().astype(np.float64)
+        best = int(np.argmin(c))
+        first = (p.actions[best, 0] if best < n_sim else p.elites_actions[(p.mpc_step * p.cfg.opt_iters + it) & 1][best - n_sim, 0])
+        scale = self.horizon if self.cost_along_trajectory == "sum" else 1.0
+        print('iter {}:{} --- best cost: {:.2f} --- mean: {:.2f} --- worst: {:.2f}  best action: {}...'
+              .format(it, n, np.amin(c) / scale, np.mean(c) / scale, np.amax(c) / scale,
+                      first.detach().cpu().numpy().astype(np.float64)[0:6]))
+
     def best_trajectory(self, obs) -> TrajectoryBatch:
         """The best trajectory of the last CEM iteration as the reference hands it to ``visualize_plan`` and hooks
         (``simulated_paths[best_traj_idx]``, icem.py:180-183): a one-row batch with ``actions [1,h,d]``,
@@ -529,9 +584,15 @@ class MpcICemHip(MpcController):
             cost, o = p.rollout_cost(np.asarray(obs, dtype=np.float64), torch.as_tensor(acts, dtype=p.dt, device=p.device),
                                      return_observations=True)
             o = o.detach().cpu().numpy().astype(np.float64)          # [1, h, o]: observation BEFORE each action
-            m = self.forward_model
-            nxt = o[:, -1] @ np.asarray(m.A, dtype=np.float64) + acts[:, -1] @ np.asarray(m.B, dtype=np.float64)
-            nxt = np.tanh(nxt) if m.kind == 1 else nxt
+            # the state BEHIND the last action comes from the device too: a second rollout that starts from the last
+            # observation with that action first -- its observation before step 1 is the transition asked for
+            if p.h >= 2:
+                tail = np.zeros_like(acts)
+                tail[:, 0] = acts[:, -1]
+                _, o2 = p.rollout_cost(o[0, -1], torch.as_tensor(tail, dtype=p.dt, device=p.device), return_observations=True)
+                nxt = o2.detach().cpu().numpy().astype(np.float64)[:, 1]
+            else:   # (a one-step horizon has no second observation to read: the model's reference-style predict)
+                nxt, _, _ = self.forward_model.predict(observations=o[:, -1], states=None, actions=acts[:, -1])
             next_o = np.concatenate([o[:, 1:], nxt[:, None]], axis=1)
             return TrajectoryBatch(observations=o, next_observations=next_o, actions=acts,
                                    costs=cost.detach().cpu().numpy().astype(np.float64))

@@ -51,6 +51,41 @@ class TrajectoryBatch:
         for i in range(len(self)):
             yield self[i]
 
+    # -- the mutating half of RolloutBuffer's sequence interface (icem/misc/rolloutbuffer.py:112-123, 156-172, 277) ----------
+    @property
+    def is_empty(self):
+        return len(self) == 0
+
+    def extend(self, other):
+        """Add trajectories: another ``TrajectoryBatch`` (its arrays are concatenated along N) or an iterable of
+        per-trajectory dict views as ``self[i]`` hands them out.  An empty batch takes the other's fields; otherwise the
+        fields must be the same and of the same horizon -- the reference's "Rollouts of unequal length?" error."""
+        if not isinstance(other, TrajectoryBatch):
+            rows = list(other)
+            if not rows:
+                return
+            try:
+                other = TrajectoryBatch(**{k: np.stack([np.asarray(r[k]) for r in rows]) for k in rows[0]})
+            except (ValueError, KeyError) as e:
+                raise TypeError(f"Concatenating rollouts failed with error {e}")
+        if len(other) == 0:
+            return
+        if not self._a:
+            self._a = {k: np.array(v) for k, v in other._a.items()}
+            return
+        if set(other._a) != set(self._a) or any(other._a[k].shape[1:] != v.shape[1:] for k, v in self._a.items()):
+            raise TypeError("Turning rollout structure into numpy array failed. Rollouts of unequal length?")
+        self._a = {k: np.concatenate([v, other._a[k]], axis=0) for k, v in self._a.items()}
+
+    def append(self, item):
+        self.extend([item])
+
+    @property
+    def flat(self):
+        """All transitions of all trajectories, ``{field: [N * h, ...]}`` (``RolloutBuffer.flat``: the concatenation of the
+        rollouts' transition records); per-trajectory scalars such as ``costs`` are left out."""
+        return {k: v.reshape((-1,) + v.shape[2:]) for k, v in self._a.items() if v.ndim >= 2}
+
 
 class ForwardModel(ABC):
     supports_stochastic = False

@@ -1056,6 +1056,33 @@ def test_best_trajectory_view_matches_oracle_rollout():
     ctrl.get_action(obs, None)
 
 
+def test_verbose_mode_prints_the_reference_lines_and_plans_the_same(capsys):
+    """verbose=True (icem.py:112-115, 151-158): the mean's first row, then one line per CEM iteration with best / mean /
+    worst cost (per step for "sum") and the best first action -- from the device buffers, through the per-iteration form
+    of the step -- and the executed actions are the quiet controller's, bit for bit."""
+    from icem_amd import DeviceSyntheticModel, MpcICemHip, halfcheetah_env
+    kw = dict(horizon=30, num_simulated_trajectories=300, factor_decrease_num=1.25, cost_along_trajectory="sum", dtype="f32",
+              seed=4, action_sampler_params=dict(alpha=0.1, elites_size=10, opt_iterations=3, init_std=0.5, use_mean_actions=True,
+                                                 keep_previous_elites=True, shift_elites_over_time=True,
+                                                 fraction_elites_reused=0.3, noise_beta=0.25))
+    obs = 0.1 * np.random.RandomState(3).randn(17)
+    out = {}
+    for verbose in (False, True):
+        ctrl = MpcICemHip(env=halfcheetah_env(17), forward_model=DeviceSyntheticModel.make(17, 6, kind=1), verbose=verbose, **kw)
+        ctrl.beginning_of_rollout(observation=obs, state=None, mode="train")
+        out[verbose] = [ctrl.get_action(obs, None) for _ in range(2)]
+    text = capsys.readouterr().out
+    lines = [ln for ln in text.splitlines() if ln.startswith("iter ")]
+    assert len(lines) == 6 and lines[0].startswith("iter 0:300 --- best cost:") and lines[1].startswith("iter 1:240 ---")
+    assert text.count("--------------------") == 2 and "iCEM using" in text
+    best = [float(ln.split("best cost:")[1].split("---")[0]) for ln in lines]
+    worst = [float(ln.split("worst:")[1].split("best action")[0]) for ln in lines]
+    assert all(b <= w for b, w in zip(best, worst))
+    ctrl.check_model_consistency()    # a learned / synthetic model: nothing to compare, nothing printed
+    for a, b in zip(out[False], out[True]):
+        assert np.array_equal(a, b)
+
+
 # ---------------------------------------------------------------------------------------------
 # f-4: the remaining env cost functions as device cost terms
 # ---------------------------------------------------------------------------------------------
