@@ -133,6 +133,7 @@ SYMBOLS = [
     ("icem_set_wide_arith", C.c_int, [_H, _I32]),
     ("icem_wide_arith", C.c_int, [_H]),
     ("icem_wide_imbalance_log2", C.c_int, [_H]),
+    ("icem_wide_model_imbalance_log2", C.c_int, [_I32, _I32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("icem_set_tile_arith", C.c_int, [_H, _I32]),
     ("icem_tile_arith", C.c_int, [_H]),
     ("icem_profile_overhead", C.c_int, [_VP, _I32, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -578,6 +578,11 @@ int icem_wide_arith(const icem_handle* h) { return h ? h->wide_eff : 0; }
 
 int icem_wide_imbalance_log2(const icem_handle* h) { return h ? h->wide_imbalance : 0; }
 
+int icem_wide_model_imbalance_log2(int32_t obs_dim, int32_t act_dim, const double* A_host, const double* B_host) {
+    if (obs_dim < 1 || act_dim < 0 || !A_host || (act_dim > 0 && !B_host)) return -1;
+    return wide_model_imbalance_log2(obs_dim, act_dim, A_host, B_host);
+}
+
 int icem_set_wide_exact(icem_handle* h, int32_t on) {   // ABI <= 3 spelling of icem_set_wide_arith (0 / 1 / 2)
     if (check_handle(h)) return ICEM_E_INVALID;
     if (on < 0 || on > 2) return fail(ICEM_E_INVALID, "icem_set_wide_exact: 0 (fp16 planes), 1 (exact f32) or 2 (bf16 planes)");

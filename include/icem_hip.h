@@ -404,8 +404,9 @@ int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step,
  *   ICEM_WIDE_BF16X3 (2): three bf16 numbers and six products (operands exact whatever their magnitudes, dropped products
  *     below 2^-31), two thirds of F16X2's speed.
  *   ICEM_WIDE_AUTO (-1, THE DEFAULT since ABI 4; ABI 3 defaulted to F16X2 unconditionally, ABI 2 to F32): F16X2 where one
- *     sweep of balancing leaves every row and column of the model within 2^13 of its largest weight
- *     (icem_wide_imbalance_log2 <= 13), BF16X3 otherwise -- decided per model at icem_set_model.  A caller that needs the
+ *     sweep of balancing leaves every row and column of the model with its largest weight within 2^13 of the model's
+ *     largest AND its median nonzero weight within 2^13 of its own largest (icem_wide_imbalance_log2 <= 13: the larger of
+ *     the two measures over all lines), BF16X3 otherwise -- decided per model at icem_set_model.  A caller that needs the
  *     fmaf chain's bits (golden vectors recorded at this width in f32) must ask for ICEM_WIDE_F32; the parity bar of
  *     north_star (1e-5 relative, identical elite sets) holds in all three (tests/test_gpu_parity_sizes.py).
  * icem_wide_arith: the arithmetic in effect for the handle's current model (never AUTO).  Takes effect at the next
@@ -414,7 +415,9 @@ int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step,
 enum { ICEM_WIDE_AUTO = -1, ICEM_WIDE_F16X2 = 0, ICEM_WIDE_F32 = 1, ICEM_WIDE_BF16X3 = 2 };
 int icem_set_wide_arith(icem_handle* h, int32_t mode);
 int icem_wide_arith(const icem_handle* h);
-int icem_wide_imbalance_log2(const icem_handle* h); /* log2(largest weight / largest weight of the weakest row or column) of the balanced model */
+int icem_wide_imbalance_log2(const icem_handle* h); /* of the balanced model: max over rows / columns of log2(model max / line max) and log2(line max / line median) */
+/* the same measure for any model (host arrays as icem_set_model takes them; no handle, no device): -1 on bad arguments */
+int icem_wide_model_imbalance_log2(int32_t obs_dim, int32_t act_dim, const double* A_host, const double* B_host);
 int icem_set_wide_exact(icem_handle* h, int32_t on);
 
 /* Narrow observations (the 16-trajectory tile kernels, 16 <= padded obs_dim <= 20: HalfCheetah's o = 17 / 18): which

@@ -159,3 +159,31 @@ def test_quoted_numbers_follow_from_the_tracked_profiles():
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "doc_numbers.py"), "r04", "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_wide_auto_criterion_on_host_models(lib):
+    """ICEM_WIDE_AUTO's measure (icem_wide_model_imbalance_log2: host code, no device): small for the benchmark's model and
+    a dense Gaussian one, an entry's worth of decades for a block in other units and for a model whose rows' weights are
+    mostly far below their largest; an all-but-dead row alone does not trip it (the rows are equilibrated)."""
+    import ctypes as C
+    import math
+
+    def imb(A, B):
+        A, B = np.ascontiguousarray(A, np.float64), np.ascontiguousarray(B, np.float64)
+        return lib.icem_wide_model_imbalance_log2(A.shape[0], B.shape[0], A.ctypes.data_as(C.POINTER(C.c_double)),
+                                                  B.ctypes.data_as(C.POINTER(C.c_double)))
+    for o, d in ((40, 6), (120, 5), (378, 17)):
+        rs = np.random.RandomState(o)
+        A0 = 0.95 * np.eye(o) + 0.05 * rs.randn(o, o) / math.sqrt(o)
+        B0 = 0.1 * rs.randn(d, o)
+        assert imb(A0, B0) <= 10
+        assert imb(rs.randn(o, o), rs.randn(d, o)) <= 5
+        A = A0.copy()
+        A[10:20, 10:20] *= 2.0 ** 14
+        A[10:20, :10] *= 2.0 ** -6
+        A[10:20, 20:] *= 2.0 ** -6
+        assert imb(A, B0) > 20
+        A = A0.copy()
+        A[5, :] *= 1e-30
+        assert imb(A, B0) <= 10
+    assert lib.icem_wide_model_imbalance_log2(0, 1, None, None) == -1
