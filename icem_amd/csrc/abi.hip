@@ -242,11 +242,11 @@ static void update_paths(icem_handle* h) {
     split_ok = split_ok && finite;
     static const int env_mode = [] { const char* e = getenv("ICEM_TILE_ARITH"); return e ? atoi(e) : -1; }();
     const int mode = h->tile_arith_mode >= 0 ? h->tile_arith_mode : env_mode;
-    // by configuration: where EVERY iteration's global population is one the noise-ahead launches serve (more than 8192 rows:
-    // the launches bound by the f32 pipe) -- smaller populations are latency chains that the exact tile's VALU twin serves best
-    bool big = !h->pop.empty();
-    for (int n_it : h->pop) big = big && n_it > ICEM_TILE_SPLIT_MIN_ROWS;
-    const bool want = mode == 1 || (mode < 0 && big);
+    // by configuration (AUTO): the planes wherever they are served.  (ABI 3 kept populations of at most 8192 rows on the exact
+    // tile's VALU twin, four waves per tile, on the argument that a lone wave's MFMA chain is the longer latency chain; measured
+    // -- EXPERIMENTS R5.5 -- one Tile16H wave per tile is the SHORTER chain: 66.7 -> 61.9 us per MPC step at N = 4096, 84.1 ->
+    // 74.6 at 8192.)  Still decided from the configuration alone, never from a rank's or a launch's row count.
+    const bool want = mode == 1 || mode < 0;
     h->tile_arith = (split_ok && want) ? 1 : 0;
     // the reference's other narrow shapes (Door, Relocate, FetchPickAndPlace) have ONE fast rollout, and it computes in the
     // fp16 planes: theirs unless the exact arithmetic is asked for (icem_set_tile_arith 0: the exact-f32 GEMM kernel)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ICEM_ABI_VERSION 4 /* 2: icem_build_hash, icem_allgather_elites / icem_rccl_*, noise-ahead planning; ICEM_MAX_OBS_DIM 384; 3: icem_set_tile_arith; 4: icem_set_wide_arith (default AUTO) */
+#define ICEM_ABI_VERSION 4 /* 2: icem_build_hash, icem_allgather_elites / icem_rccl_*, noise-ahead planning; ICEM_MAX_OBS_DIM 384; 3: icem_set_tile_arith; 4: icem_set_wide_arith (default AUTO), ICEM_TILE_AUTO = planes at every population */
 
 enum { ICEM_F32 = 0, ICEM_F64 = 1 };
 enum { ICEM_COST_SUM = 0, ICEM_COST_BEST = 1, ICEM_COST_FINAL = 2 }; /* abstract_controller.py:82-87 */
@@ -431,13 +431,13 @@ int icem_set_wide_exact(icem_handle* h, int32_t on);
  *     action bound) inside the horizon leaves fp16's range: that trajectory's cost is reported as NaN and ranks last.
  *     Served for models whose largest |entry| lies in [2^-4, 2^4]; other models silently keep the exact form
  *     (icem_tile_arith tells which one a handle's launches use).
- *   ICEM_TILE_AUTO (-1, the default): F16X2 where it is served and EVERY iteration's GLOBAL population (icem_population_sizes)
- *     exceeds ICEM_TILE_SPLIT_MIN_ROWS -- the populations whose rollout is bound by the f32 pipe; F32 below.  Decided from
- *     the configuration alone: every rank of a sharded run and every iteration of a decaying population computes in
- *     the same arithmetic.  Strict-parity callers pass ICEM_TILE_F32.
+ *   ICEM_TILE_AUTO (-1, the default): F16X2 wherever it is served (the widths, models and thresholds above), at every
+ *     population -- since ABI 4; ABI 3 kept configurations with an iteration of at most 8192 rows on F32, which measured
+ *     SLOWER there too (N = 4096 x 5 iterations: 66.7 -> 61.9 us per MPC step).  Decided from the configuration alone: every
+ *     rank of a sharded run and every iteration of a decaying population computes in the same arithmetic.  Strict-parity
+ *     callers pass ICEM_TILE_F32.
  * Takes effect at the next launch (not between icem_plan_iter_local and its merge).  No reference counterpart. */
 enum { ICEM_TILE_AUTO = -1, ICEM_TILE_F32 = 0, ICEM_TILE_F16X2 = 1 };
-#define ICEM_TILE_SPLIT_MIN_ROWS 8192
 int icem_set_tile_arith(icem_handle* h, int32_t mode);
 int icem_tile_arith(const icem_handle* h); /* the arithmetic in effect: ICEM_TILE_F32 or ICEM_TILE_F16X2 */
 

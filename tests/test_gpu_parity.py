@@ -259,14 +259,21 @@ def test_gather_refit(dtype):
 # the whole loop
 # ---------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("dtype", ["f64", "f32", "f32-exact-tile"])
 @pytest.mark.parametrize("name", CASES)
 def test_fused_plan_replays_reference_run(name, dtype):
     """Fused device path, fed the reference's own white draws: after every CEM iteration of every
     MPC step the elite costs (sorted), mean and std match the reference run, and so do the executed
-    actions.  Elite identity is checked through the elite costs + actions (bit-exact index sets)."""
+    actions.  Elite identity is checked through the elite costs + actions (bit-exact index sets).
+    In f32 the generic sampler turns the reference's draws into the pool and the TILE kernels roll it out (Tile16H on the
+    16-bit matrix cores by default, Tile16 / the exact-f32 pipe under "f32-exact-tile"), the threshold merges select and
+    refit: the throughput path from the rollout on, on the reference's own noise."""
     g = Golden(name)
+    exact_tile = dtype == "f32-exact-tile"
+    dtype = "f32" if exact_tile else dtype
     pl = make_planner(g, dtype)
+    if exact_tile:
+        pl.set_tile_arith("f32")
     pl.reset()
     calls = iter(range(g.n_noise_calls))
     it_global = [0]

@@ -112,14 +112,15 @@ def test_full_loop_at_benchmark_size_against_oracle_on_device_normals(N, iters, 
     _full_loop(N, iters, h, d, o, kind, beta, env_kind, seed, "sum")
 
 
-# The tile arithmetic (icem_set_tile_arith) at the same bar.  c4 above runs on the fp16 planes by default (every global
-# population > 8192 rows); here: c4 on the exact tile, the tanh model and the o = 18 shape on the planes at that size, and
+# The tile arithmetic (icem_set_tile_arith) at the same bar.  c2 and c4 above run on the fp16 planes by default (AUTO: wherever
+# the tile serves them); here: c2 and c4 on the exact tile, the tanh model and the o = 18 shape on the planes at that size, and
 # the headline population forced onto the planes (its single-launch kernel then rolls out on Tile16H).
 @pytest.mark.parametrize("N,iters,o,kind,arith,mode,seed", [
     pytest.param(65536, 5, 17, 0, 0, "sum", 1234, id="c4_exact_tile"),
     pytest.param(65536, 3, 17, 1, 1, "sum", 11, id="c4_tanh_fp16_planes"),
     pytest.param(40000, 3, 18, 0, 1, "best", 12, id="o18_fp16_planes_best"),
     pytest.param(4096, 5, 17, 0, 1, "sum", 1234, id="c2_fp16_planes"),
+    pytest.param(4096, 5, 17, 0, 0, "sum", 1234, id="c2_exact_tile"),
     pytest.param(4096, 3, 17, 1, 1, "final", 13, id="c2_tanh_fp16_planes_final"),
 ])
 def test_full_loop_in_each_tile_arithmetic(N, iters, o, kind, arith, mode, seed):
@@ -424,8 +425,8 @@ def test_wide_split_planes_in_mixed_units(mode):
 def test_wide_auto_picks_the_arithmetic_from_the_balanced_model():
     """icem_set_wide_arith's default (ICEM_WIDE_AUTO): the fp16 planes for a model one sweep of balancing brings within
     2^13 of its largest weight -- the benchmark's 0.95 I + 0.05 N / sqrt(o), a dense Gaussian model -- and the bf16
-    planes (exact operands) for one it does not: a 10 x 10 block of A in units 2^20 larger than the rest, which no diagonal
-    scaling takes out.  The named modes override it; the ABI <= 3 spelling still works; costs stay within 1e-5 of the
+    planes (exact operands) for one it does not: a 10 x 10 block of A whose rows are 2^20 weaker outside the block, which no
+    diagonal scaling takes out.  The named modes override it; the ABI <= 3 spelling still works; costs stay within 1e-5 of the
     float64 oracle in whatever AUTO picked, on a state that exercises the small weights."""
     from icem_amd import IcemConfig, IcemPlanner, DeviceSyntheticModel
     o, d, h, n = 120, 5, 12, 96
@@ -447,13 +448,12 @@ def test_wide_auto_picks_the_arithmetic_from_the_balanced_model():
     # (the same dynamics in units ten decades apart measure 14-16 after the ONE sweep the pack does: AUTO is conservative
     #  there and takes the bf16 planes; test_wide_split_planes_in_mixed_units holds both plane forms to 1e-5 on that model)
     A = A0.copy()
-    A[10:20, 10:20] *= 2.0 ** 20 / 64   # (/ 64: keep the linear dynamics from blowing up over the horizon)
-    A[10:20, :10] *= 2.0 ** -6
-    A[10:20, 20:] *= 2.0 ** -6
+    A[10:20, :10] *= 2.0 ** -20    # ten state entries whose weights outside their own block sit 2^20 below those inside it
+    A[10:20, 20:] *= 2.0 ** -20
     pl = planner(A, B0)
     assert pl.wide_imbalance_log2 > 13 and pl.wide_arith == "bf16x3", (pl.wide_arith, pl.wide_imbalance_log2)
     obs = 0.3 * rs.randn(o)
-    obs[10:20] *= 2.0 ** -14   # small entries against large weights: every contribution of ordinary size
+    obs[10:20] *= 2.0 ** 10    # ... and carry large values: the small weights' contributions are of ordinary size
     act = rs.uniform(-0.4, 0.4, (n, h, d)).astype(np.float32)
     oc = O.CostSpec(0.1, 2, -1.0, -1, 0.0, 0.0)
     want = O.rollout_costs(O.SyntheticModel(A, B0, 0), oc, obs.astype(np.float32).astype(np.float64), act.astype(np.float64))

@@ -38,16 +38,16 @@ def _planner(N, iters, h=30, d=6, o=17, kind=0, mode="sum", seed=5, arith=None, 
 
 
 def test_arithmetic_follows_the_global_populations_not_the_launch():
-    """AUTO: fp16 planes where every iteration's GLOBAL population exceeds 8192 rows (the launches bound by the f32 pipe), the
-    exact tile below; a rank of a sharded run decides from the global numbers, not from its own rows; models outside the
-    planes' range and widths without a Tile16H keep the exact tile whatever is asked."""
+    """AUTO: fp16 planes wherever the tile serves them, at every population (ABI 4; the exact tile on request); a rank of a
+    sharded run decides from the configuration, not from its own rows; models outside the planes' range and widths without a
+    Tile16H keep the exact tile whatever is asked."""
     from icem_amd import IcemConfig, IcemPlanner, DeviceSyntheticModel, halfcheetah_env, humanoid_standup_env
     assert _planner(65536, 5)[0].tile_arith == 1          # 65 536 ... 26 842 rows
-    assert _planner(16384, 5)[0].tile_arith == 0          # decays to 6 710 rows
+    assert _planner(16384, 5)[0].tile_arith == 1          # decays to 6 710 rows
     assert _planner(16384, 2)[0].tile_arith == 1          # 16 384, 13 107
-    assert _planner(4096, 5)[0].tile_arith == 0
+    assert _planner(4096, 5)[0].tile_arith == 1
     pl = _planner(4096, 5)[0]
-    assert pl.set_tile_arith("f16x2") == 1 and pl.set_tile_arith("f32") == 0 and pl.set_tile_arith("auto") == 0
+    assert pl.set_tile_arith("f16x2") == 1 and pl.set_tile_arith("f32") == 0 and pl.set_tile_arith("auto") == 1
     pl = _planner(65536, 5)[0]
     assert pl.set_tile_arith("f32") == 0 and pl.set_tile_arith("auto") == 1
     # one rank of eight: 8192 local rows, 65 536 global
