@@ -249,6 +249,8 @@ struct RolloutArgs {
     T* observations;  // nullable [n, h, o]
     CostArgs<T> cs;
     int cost_mode;
+    int ch;  // (rows kernel) steps of actions staged in LDS at a time
+    long long* dbg;  // icem_debug_stamps: phase stamps [24..29] of workgroup 0 (tools/dbg/f64_stamps.py), else null
 };
 
 __device__ __forceinline__ float act_tanh(float x) { return tanhf(x); }
@@ -330,6 +332,149 @@ __global__ __launch_bounds__(WG) void rollout_cost_kernel(RolloutArgs<T> a) {
         for (int i = 0; i < O; ++i) obs[i] = (KIND == ICEM_MODEL_TANH) ? act_tanh(nxt[i]) : nxt[i];
     }
     a.costs[n] = acc;
+}
+
+// The same rollout with a trajectory spread over LPT lanes (lane = observation column) instead of one thread per trajectory:
+// in float64 a thread's horizon is 30 x (O + d) x O dependent 8-cycle FMAs -- 214 us per launch at N = 4096, three quarters
+// of a strict-parity MPC step -- while 250 of the chip's 256 CUs hold one wave each.  Here lane c of a trajectory's row keeps
+// column c of A in registers and accumulates output c over the SAME chain (k = 0 .. O - 1, then the actions, fused
+// multiply-adds in that order: bit-identical to the thread form), the state goes from step to step through two LDS rows per
+// trajectory (written by its lanes, read back as broadcasts by the same wave: no workgroup barrier in the loop), B sits in
+// LDS, a chunk of the row's actions is staged in LDS.  Costs (icem_cost_spec's form; a term list keeps the thread form) are
+// computed redundantly by every lane of the row (same instructions); lane 0 stores.  ICEM_GK_ROLLOUT=thread brings the thread
+// form back (A/B, tests).
+template <typename T, int O, int KIND>
+__global__ __launch_bounds__(WG) void rollout_cost_rows_kernel(RolloutArgs<T> a) {
+    constexpr int LPT = O <= 16 ? 16 : 32;   // lanes per trajectory
+    constexpr int TPW = WG / LPT;            // trajectories per workgroup
+    constexpr int OS = (O + 1) & ~1;         // LDS row stride: pairs of entries are read as one 2 x T vector
+    constexpr int BREG = 8;                  // action dims whose row of B stays in registers
+    typedef T T2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* xs = reinterpret_cast<T*>(smem_raw);  // [2][TPW][OS]: the state before / behind the running step
+    T* Bs = xs + 2 * TPW * OS;               // [d][OS]
+    const int ds = a.d <= BREG ? BREG : ((a.d + 1) & ~1);   // a step's actions in LDS, zero padded (to BREG: read whole, unconditionally)
+    T* As = Bs + a.d * OS;                   // [TPW][ch * ds]: the next `ch` steps' actions of every trajectory of the workgroup
+    const int tid = threadIdx.x, col = tid % LPT, tl = tid / LPT;
+    const bool live_col = col < O;
+    const int cc = live_col ? col : 0;
+    const int n = blockIdx.x * TPW + tl;
+    const bool live = n < a.n;
+    long long* const dbg = (blockIdx.x == 0 && tid == 0) ? a.dbg : nullptr;
+    if (dbg) dbg[24] = wall_clock64();
+    for (int e = tid; e < a.d * O; e += WG) Bs[(e / O) * OS + e % O] = a.B[e];
+    T Acol[O];
+#pragma unroll
+    for (int k = 0; k < O; ++k) Acol[k] = live_col ? a.A[k * O + cc] : (T)0;
+    T Bcol[BREG];
+#pragma unroll
+    for (int j = 0; j < BREG; ++j) Bcol[j] = (live_col && j < a.d) ? a.B[j * O + cc] : (T)0;
+    if (tid < TPW * OS) xs[tid] = (T)0;
+    __syncthreads();
+    if (live_col) xs[tl * OS + col] = col < a.o ? a.obs0[col] : (T)0;
+    if (O < OS && col == 0) xs[TPW * OS + tl * OS + O] = (T)0;   // (the pad entry of the second buffer: read, never written)
+    __syncthreads();
+    if (dbg) dbg[25] = wall_clock64();
+    const T* __restrict__ act_g = a.actions + (size_t)(live ? n : a.n - 1) * a.h * a.d;
+    const int lane = tid & 63;
+    const unsigned long long row_mask = (LPT == 64 ? ~0ull : ((1ull << LPT) - 1ull)) << ((lane / LPT) * LPT);
+    const int ch = a.ch;                     // steps per staged chunk (host: the whole horizon where it fits)
+    T* my_acts = As + (size_t)tl * ch * ds;
+    const bool b_regs = a.d <= BREG;
+    // (the cost's scalars as locals: the argument block's term list must not be live across the loop -- with it in reach the
+    //  step restored 600 spilled scalar registers through v_readlane, 1.1 us per step whatever the arithmetic.  Costs with a
+    //  term list -- cs.ext -- keep the thread form: launch_rollout_k)
+    const T flip_th = a.cs.flip_th, flip_pen = a.cs.flip_pen, ctrl_w = a.cs.ctrl_w, lin_w = a.cs.lin_w;
+    const int lin_idx = a.cs.lin_idx, flip_idx = a.cs.flip_idx, cost_mode = a.cost_mode, hh = a.h, dd = a.d, oo = a.o;
+    T* const obs_out = a.observations;
+    T acc = (T)0;
+    for (int t = 0; t < hh; ++t) {
+        if (t % ch == 0) {
+            // the row's lanes fetch their trajectory's next chunk (one coalesced span: a step's actions straight from HBM were
+            // a cold miss every other step -- 1.5 us per step, 44 us per launch); same wave writes and reads: no workgroup barrier
+            const int cnt = (hh - t < ch ? hh - t : ch) * dd;
+            // (eight loads in flight per lane: one at a time, each a cold miss, was 0.6 us per step of the horizon)
+            for (int e0 = col; e0 < cnt; e0 += 8 * LPT) {
+                T v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = act_g[t * dd + (e0 + u * LPT < cnt ? e0 + u * LPT : 0)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * LPT;
+                    if (e < cnt) my_acts[(e / dd) * ds + e % dd] = v[u];
+                }
+            }
+            for (int e = col; e < ch * (ds - dd); e += LPT) my_acts[(e / (ds - dd)) * ds + dd + e % (ds - dd)] = (T)0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (dbg && t < 3) dbg[26 + t] = wall_clock64();
+        const T* act = my_acts + (t % ch) * ds;
+        const T* pre = xs + ((t & 1) * TPW + tl) * OS;
+        T* post = xs + (((t + 1) & 1) * TPW + tl) * OS;
+        // the whole state and the step's actions in a few wide broadcast reads, THEN the chain (the LDS pipe of a CU that
+        // holds eight such waves was the bound with one read per entry: 0.4 us of every step)
+        T xk[OS], av[BREG];
+#pragma unroll
+        for (int k = 0; k < OS; k += 2) {
+            const T2 v = *reinterpret_cast<const T2*>(pre + k);
+            xk[k] = v[0];
+            xk[k + 1] = v[1];
+        }
+        if (b_regs) {   // the step's actions ride the same wait (the row is padded to BREG entries)
+#pragma unroll
+            for (int j = 0; j < BREG; j += 2) {
+                const T2 v = *reinterpret_cast<const T2*>(act + j);
+                av[j] = v[0];
+                av[j + 1] = v[1];
+            }
+        }
+        T nx = (T)0;
+#pragma unroll
+        for (int k = 0; k < O; ++k) nx = fmad(xk[k], Acol[k], nx);
+        T ctrl = (T)0;
+        if (b_regs) {
+#pragma unroll
+            for (int j = 0; j < BREG; ++j) {
+                if (j < dd) {   // (wave-uniform; the padding entries take no part: an exact zero keeps its sign)
+                    ctrl = fmad(av[j], av[j], ctrl);
+                    nx = fmad(av[j], Bcol[j], nx);
+                }
+            }
+        } else {
+            for (int j = 0; j < dd; ++j) {
+                const T aj = act[j];
+                ctrl = fmad(aj, aj, ctrl);
+                nx = fmad(aj, Bs[j * OS + cc], nx);
+            }
+        }
+        const T pv = (KIND == ICEM_MODEL_TANH) ? act_tanh(nx) : nx;
+        if (live_col) post[col] = pv;
+        // (two more LDS reads, not a select chain over the registers: 34 compare masks do not fit the scalar registers)
+        const T lin = (lin_idx >= 0 && lin_idx < O) ? pre[lin_idx] : (T)0;
+        const T ang = (flip_idx >= 0 && flip_idx < O) ? pre[flip_idx] : (T)0;
+        T c = (T)0;
+        if (flip_idx >= 0) {
+            c += (ang > flip_th) ? flip_pen : (T)0;
+            c += (ang < -flip_th) ? flip_pen : (T)0;
+        }
+        c += ctrl_w * ctrl;
+        if (lin_w != (T)0) c += lin_w * lin;
+        if (t == 0 || cost_mode == ICEM_COST_FINAL)
+            acc = c;
+        else if (cost_mode == ICEM_COST_SUM)
+            acc += c;
+        else
+            acc = (c < acc || c != c) ? c : acc;  // np.amin: a NaN step cost makes the trajectory's cost NaN
+        if (obs_out != nullptr && live && live_col && col < oo)
+            obs_out[((size_t)n * hh + t) * oo + col] = pre[col];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (live && col == 0) a.costs[n] = acc;
+    if (dbg) dbg[29] = wall_clock64();
 }
 
 template <typename T>
@@ -743,6 +888,222 @@ __global__ __launch_bounds__(WG) void merge_refit_kernel(MergeArgs<T> a) {
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// K3 + K4 of a single-GPU step in ONE launch: threshold selection + gather + refit
+// ---------------------------------------------------------------------------------------------
+// topk_partial -> local_pack -> merge_refit are three launches of K rounds of a workgroup-wide minimum each (two barriers
+// per round): 46 us per iteration in float64 for work that is a few hundred compares.  One workgroup, the selection by
+// THRESHOLD (as the f32 merges do): every thread's best key, the K-th smallest of a wave's 64 bests (K rounds of a wave
+// minimum over order-preserving 64-bit images of the costs) is an upper bound of the K-th smallest key overall, the tightest
+// of the waves' bounds is T; the keys at or below T (K .. a few dozen) are collected and PLACED by counting -- a key's place
+// is the number of smaller keys (cost, then global index: np.argsort's order on distinct indices) -- and the K rows are
+// gathered and refitted exactly as merge_refit_kernel does (same refit_element, same epilogue).  Same elites, same bits.
+template <typename T>
+struct SelectArgs {
+    int n_cand;   // pool rows with a cost: the sampled rows, then (iteration 0) the shifted elites
+    int n_loc;    // ... of which sampled rows (global index = pool row); the others: n_global + (row - n_loc)
+    int cap;      // candidate capacity (host: SELECT_CAP)
+    const T* costs;
+    const T* actions;
+    long long* dbg;   // icem_debug_stamps: phase stamps [16..22] (tools/dbg/f64_stamps.py), else null
+    MergeArgs<T> m;   // records / n_rec / xw unused: the rows come from the pool
+};
+
+constexpr int SELECT_NT = 256;
+constexpr int SELECT_CAP = 3072;
+
+__device__ __forceinline__ unsigned long long order_image(double c) {   // monotone: c1 < c2  <=>  image(c1) < image(c2); -0 == +0
+    c = c == 0.0 ? 0.0 : c;
+    const unsigned long long b = (unsigned long long)__double_as_longlong(c);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ unsigned long long order_image(float c) { return order_image((double)c); }   // (exact widening)
+
+__device__ __forceinline__ unsigned long long wave_min_u64_shfl(unsigned long long x) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const unsigned long long o = __shfl_xor(x, s, 64);
+        x = o < x ? o : x;
+    }
+    return x;
+}
+
+template <typename T>
+__global__ __launch_bounds__(SELECT_NT) void select_refit_kernel(SelectArgs<T> s) {
+    constexpr int NW = SELECT_NT / 64;
+    __shared__ unsigned long long wave_T[NW];
+    __shared__ unsigned long long wave_best[NW][64];
+    __shared__ T cand_c[SELECT_CAP];
+    __shared__ int cand_i[SELECT_CAP];
+    __shared__ int cand_e[SELECT_CAP];
+    __shared__ int n_c;
+    __shared__ T sel_c[ICEM_MAX_ELITES];
+    __shared__ int sel_i[ICEM_MAX_ELITES];
+    __shared__ int sel_e[ICEM_MAX_ELITES];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* new_mean = reinterpret_cast<T*>(smem_raw);  // [hd]
+    const MergeArgs<T>& a = s.m;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int total = s.n_cand + a.n_keep;
+    auto cost_of = [&](int e) -> T { return e < s.n_cand ? nan_to_inf(s.costs[e]) : a.elites_cost_cur[e - s.n_cand]; };
+    auto gidx_of = [&](int e) -> int { return e < s.n_loc ? e : a.n_global + (e < s.n_cand ? e - s.n_loc : e - s.n_cand); };
+    if (s.dbg && tid == 0) s.dbg[16] = wall_clock64();
+    if (tid == 0) n_c = 0;
+    if (tid < ICEM_MAX_ELITES) {
+        sel_c[tid] = inf_v<T>();
+        sel_i[tid] = INT_MAX;
+        sel_e[tid] = -1;
+    }
+    // every thread's best cost (image), then the K-th smallest of the wave's 64
+    // (loads in batches of eight, all requested before the first is used: one thread's keys are 2 KB apart -- a cold miss
+    //  each, and a loop of dependent misses was 16 us of this kernel)
+    unsigned long long best = ~0ull;
+    constexpr int KEEP = 16;             // a thread's first keys stay in registers for the second pass (all of them up to 4096 keys)
+    T kept[KEEP];
+#pragma unroll
+    for (int b = 0; b < KEEP / 8; ++b) {
+        const int e0 = tid + b * 8 * SELECT_NT;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * SELECT_NT;
+            kept[b * 8 + u] = cost_of(e < total ? e : 0);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < KEEP; ++q) {
+        const unsigned long long v = tid + q * SELECT_NT < total ? order_image(kept[q]) : ~0ull;
+        best = v < best ? v : best;
+    }
+    for (int e0 = tid + KEEP * SELECT_NT; e0 < total; e0 += 8 * SELECT_NT) {
+        T cv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * SELECT_NT;
+            cv[u] = cost_of(e < total ? e : tid);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned long long v = e0 + u * SELECT_NT < total ? order_image(cv[u]) : ~0ull;
+            best = v < best ? v : best;
+        }
+    }
+    if (s.dbg && tid == 0) s.dbg[17] = wall_clock64();
+    // ... by counting: a lane's rank among the wave's 64 (value, then lane) is the number of smaller ones -- 64 broadcast
+    // reads, no dependent cross-lane chain (K rounds of a shuffled 64-bit minimum cost 5 us)
+    wave_best[wave][lane] = best;
+    if (lane == 0) wave_T[wave] = ~0ull;   // fewer than K threads with a key: everything is a candidate
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int rank = 0;
+#pragma unroll 8
+    for (int j = 0; j < 64; ++j) {
+        const unsigned long long o = wave_best[wave][j];
+        rank += (o < best || (o == best && j < lane)) ? 1 : 0;
+    }
+    if (rank == a.K - 1 && best != ~0ull) wave_T[wave] = best;
+    __syncthreads();
+    if (s.dbg && tid == 0) s.dbg[18] = wall_clock64();
+    unsigned long long Tt = wave_T[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) Tt = wave_T[w] < Tt ? wave_T[w] : Tt;
+    // the keys at or below the threshold (costs that tie with it all survive)
+#pragma unroll
+    for (int q = 0; q < KEEP; ++q) {
+        const int e = tid + q * SELECT_NT;
+        if (e < total && order_image(kept[q]) <= Tt) {
+            const int pos = atomicAdd(&n_c, 1);
+            if (pos < s.cap) {
+                cand_c[pos] = kept[q];
+                cand_i[pos] = gidx_of(e);
+                cand_e[pos] = e;
+            }
+        }
+    }
+    for (int e0 = tid + KEEP * SELECT_NT; e0 < total; e0 += 8 * SELECT_NT) {
+        T cv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * SELECT_NT;
+            cv[u] = cost_of(e < total ? e : tid);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * SELECT_NT;
+            if (e < total && order_image(cv[u]) <= Tt) {
+                const int pos = atomicAdd(&n_c, 1);
+                if (pos < s.cap) {
+                    cand_c[pos] = cv[u];
+                    cand_i[pos] = gidx_of(e);
+                    cand_e[pos] = e;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (s.dbg && tid == 0) s.dbg[19] = wall_clock64();
+    const int nc = n_c < s.cap ? n_c : s.cap;   // (the host admits only sizes whose worst case fits: gk_select_ok)
+    for (int i = tid; i < nc; i += SELECT_NT) {
+        const T c = cand_c[i];
+        const int g = cand_i[i];
+        int place = 0;
+#pragma unroll 8
+        for (int j = 0; j < nc; ++j) place += key_less(cand_c[j], cand_i[j], c, g) ? 1 : 0;
+        if (place < a.K) {
+            sel_c[place] = c;
+            sel_i[place] = g;
+            sel_e[place] = cand_e[i];
+        }
+    }
+    __syncthreads();
+    if (s.dbg && tid == 0) {
+        s.dbg[20] = wall_clock64();
+        s.dbg[23] = nc;
+    }
+    const int hd = a.h * a.d;
+    auto src_row = [&](int r) -> const T* {
+        int e = sel_e[r];
+        if (e < 0) e = sel_e[0];  // fewer than K live candidates (cannot happen for K <= N / 2): repeat the best
+        return e < s.n_cand ? s.actions + (size_t)e * hd : a.elites_cur + (size_t)(e - s.n_cand) * hd;
+    };
+    constexpr int KR = 16;   // elite rows gathered into registers at once (K <= KR: every load requested before the first use)
+    for (int e = tid; e < hd; e += SELECT_NT) {
+        T nm, ns;
+        if (a.K <= KR) {
+            T xr[KR];
+#pragma unroll
+            for (int r = 0; r < KR; ++r) xr[r] = src_row(r < a.K ? r : 0)[e];
+            const T om = a.mean_in[e], os = a.std_in[e];
+#pragma unroll
+            for (int r = 0; r < KR; ++r)
+                if (r < a.K) a.elites_next[(size_t)r * hd + e] = xr[r];
+            refit_element_regs<T, KR>(a.K, a.alpha, om, os, xr, nm, ns);
+        } else {
+            for (int r = 0; r < a.K; ++r) a.elites_next[(size_t)r * hd + e] = src_row(r)[e];
+            refit_element<T>(a.K, a.alpha, a.mean_in[e], a.std_in[e], [&](int r) { return src_row(r)[e]; }, nm, ns);
+        }
+        if (!a.last) {
+            a.mean[e] = nm;
+            a.std[e] = ns;
+        } else {
+            new_mean[e] = nm;
+        }
+    }
+    if (tid < a.K) a.elites_cost_next[tid] = sel_c[tid];
+    if (s.dbg && tid == 0) s.dbg[21] = wall_clock64();
+    if (a.last) {
+        __syncthreads();
+        for (int e = tid; e < hd; e += SELECT_NT) {
+            const int j = e % a.d;
+            a.mean[e] = (e + a.d < hd) ? new_mean[e + a.d] : new_mean[e];
+            a.std[e] = (a.high[j] - a.low[j]) / (T)2 * a.init_std;
+        }
+        if (tid < a.d) a.executed[tid] = src_row(0)[tid];
+        if (tid == 0) a.best_cost[0] = sel_c[0];
+    }
+}
+
+
 // =============================================================================================
 // launchers
 // =============================================================================================
@@ -802,6 +1163,34 @@ template <typename T, int KIND>
 int launch_rollout_k(const icem_handle* h, const RolloutArgs<T>& a, hipStream_t st) {
     const int grid = (a.n + WG - 1) / WG;
     ProfScope prof(h, ICEM_K_ROLLOUT, (long long)a.n * a.h, st);
+    const char* env_form = getenv("ICEM_GK_ROLLOUT");   // read per call: the path-equivalence test flips it between planners
+    const bool thread_form = env_form && env_form[0] == 't';
+    if (!thread_form && !a.cs.ext) {   // a trajectory's row of lanes (rollout_cost_rows_kernel); term lists: the thread form
+        switch (h->O) {
+#define ICEM_CASE(OV)                                                                                                          \
+    case OV: {                                                                                                                 \
+        constexpr int TPW = WG / (OV <= 16 ? 16 : 32);                                                                         \
+        RolloutArgs<T> ar = a;                                                                                                 \
+        constexpr int OSV = (OV + 1) & ~1;                                                                                     \
+        const int dsv = a.d <= 8 ? 8 : ((a.d + 1) & ~1);                                                                       \
+        ar.ch = std::max(1, std::min(a.h, (int)(32768 / ((size_t)TPW * dsv * sizeof(T)))));   /* at most 32 KB of actions */   \
+        const size_t lds = ((size_t)2 * TPW * OSV + (size_t)a.d * OSV + (size_t)TPW * ar.ch * dsv) * sizeof(T);                \
+        hipLaunchKernelGGL((rollout_cost_rows_kernel<T, OV, KIND>), dim3((a.n + TPW - 1) / TPW), dim3(WG), lds, st, ar);      \
+        break;                                                                                                                 \
+    }
+            ICEM_CASE(8)
+            ICEM_CASE(16)
+            ICEM_CASE(17)
+            ICEM_CASE(18)
+            ICEM_CASE(24)
+            ICEM_CASE(32)
+#undef ICEM_CASE
+            default:
+                return fail(ICEM_E_UNSUPPORTED, "the generic rollout is compiled for padded observation widths 8, 16, 17, 18, 24, 32 only");
+        }
+        ICEM_HIP_TRY(hipGetLastError());
+        return ICEM_OK;
+    }
     switch (h->O) {
 #define ICEM_CASE(OV)                                                                                  \
     case OV:                                                                                           \
@@ -911,6 +1300,8 @@ int launch_rollout(const icem_handle* h, int n, const void* obs0, const void* ac
     a.observations = (T*)observations;
     fill_cost_args<T>(h, a.cs);
     a.cost_mode = h->cfg.cost_mode;
+    a.ch = 0;
+    a.dbg = h->dbg;
     return h->model_kind == ICEM_MODEL_TANH ? launch_rollout_k<T, ICEM_MODEL_TANH>(h, a, st)
                                             : launch_rollout_k<T, ICEM_MODEL_LINEAR>(h, a, st);
 }
@@ -1153,6 +1544,64 @@ static void merge_refit_t(const icem_handle* h, const MergeArgsV& v, hipStream_t
     ProfScope prof(h, ICEM_K_MERGE_REFIT, a.n_rec + a.n_keep, st);
     hipLaunchKernelGGL((merge_refit_kernel<T>), dim3(1), dim3(WG), (size_t)v.h * v.d * sizeof(T), st, a);
 }
+// world == 1: selection + gather + refit of an iteration in one launch (select_refit_kernel).  The worst case of the
+// threshold -- K threads of each of the workgroup's waves hold ALL their keys at or below it -- must fit the candidate
+// array; beyond that size the three-launch path runs.
+bool gk_select_ok(const icem_handle* h, int n_cand, int n_keep, int K) {
+    const char* env_sel = getenv("ICEM_GK_SELECT");     // read per call (path-equivalence test)
+    const bool off = env_sel && env_sel[0] == '0';
+    if (off || h->cfg.world != 1 || K < 1 || K > ICEM_MAX_ELITES) return false;
+    const long long per_thread = ((long long)n_cand + n_keep + SELECT_NT - 1) / SELECT_NT;
+    return (long long)(SELECT_NT / 64) * K * per_thread <= SELECT_CAP;
+}
+
+template <typename T>
+static void select_refit_t(const icem_handle* h, int n_cand, int n_loc, const void* costs, const void* actions, const MergeArgsV& v,
+                           hipStream_t st) {
+    SelectArgs<T> s;
+    s.n_cand = n_cand;
+    s.n_loc = n_loc;
+    s.cap = SELECT_CAP;
+    s.costs = (const T*)costs;
+    s.actions = (const T*)actions;
+    s.dbg = h->dbg;
+    MergeArgs<T>& a = s.m;
+    a.n_rec = 0;
+    a.n_keep = v.n_keep;
+    a.K = v.K;
+    a.h = v.h;
+    a.d = v.d;
+    a.n_global = v.n_global;
+    a.last = v.last;
+    a.alpha = (T)v.alpha;
+    a.init_std = (T)v.init_std;
+    a.records = nullptr;
+    a.elites_cur = (const T*)v.elites_cur;
+    a.elites_cost_cur = (const T*)v.elites_cost_cur;
+    a.elites_next = (T*)v.elites_next;
+    a.elites_cost_next = (T*)v.elites_cost_next;
+    a.mean_in = (const T*)v.mean_in;
+    a.std_in = (const T*)v.std_in;
+    a.mean = (T*)v.mean;
+    a.std = (T*)v.std;
+    a.low = (const T*)v.low;
+    a.high = (const T*)v.high;
+    a.executed = (T*)v.executed;
+    a.best_cost = (T*)v.best_cost;
+    a.xw = XchgWait{};
+    ProfScope prof(h, ICEM_K_MERGE_REFIT, n_cand + v.n_keep, st);
+    hipLaunchKernelGGL((select_refit_kernel<T>), dim3(1), dim3(SELECT_NT), (size_t)v.h * v.d * sizeof(T), st, s);
+}
+int gk_select_refit(const icem_handle* h, int n_cand, int n_loc, const void* costs, const void* actions, const MergeArgsV& a,
+                    hipStream_t st) {
+    if (h->cfg.dtype == ICEM_F64)
+        select_refit_t<double>(h, n_cand, n_loc, costs, actions, a, st);
+    else
+        select_refit_t<float>(h, n_cand, n_loc, costs, actions, a, st);
+    ICEM_HIP_TRY(hipGetLastError());
+    return ICEM_OK;
+}
+
 int gk_merge_refit(const icem_handle* h, const MergeArgsV& a, hipStream_t st) {
     if (h->cfg.dtype == ICEM_F64)
         merge_refit_t<double>(h, a, st);

@@ -118,6 +118,9 @@ struct icem_handle {
     int wide_mode = -1;          // icem_set_wide_arith: ICEM_WIDE_AUTO (-1) / F16X2 (0) / F32 (1) / BF16X3 (2) as asked for ...
     int wide_eff = 0;            // ... and the one in effect (update_paths: AUTO = fp16 planes unless the balanced model is not)
     int wide_imbalance = 0;      // wide_model_imbalance_log2 of the current model
+    // generic path, world == 1: the iteration's selection waits for the merge call (gk_select_refit: one launch for top-K +
+    // gather + refit); gen_sel_cand > 0 = rows with a cost in b->costs, gen_sel_loc of them sampled rows
+    int gen_sel_cand = 0, gen_sel_loc = 0;
     int wide_packed = -2;        // which arithmetic Mw_dev / Mwh_dev / Mws_dev currently hold the model for (-2: none)
                                  // (k_rollout_wide.hip + its row kernel), 2 = bf16 planes (6 products)
     void* wide_cs_dev = nullptr; // CostArgs<float> (cost spec + terms) for k_rollout_wide, refreshed by the cost setters
@@ -267,6 +270,10 @@ struct MergeArgsV {
     XchgWait xw;
 };
 int gk_merge_refit(const icem_handle* h, const MergeArgsV& a, hipStream_t st);
+// world == 1: top-K over the pool's costs (+ kept elites) + gather + refit in ONE launch (a.records / a.n_rec unused)
+bool gk_select_ok(const icem_handle* h, int n_cand, int n_keep, int K);
+int gk_select_refit(const icem_handle* h, int n_cand, int n_loc, const void* costs, const void* actions, const MergeArgsV& a,
+                    hipStream_t st);
 // every index a cost term reads lies inside an observation of width o (nullptr = fine)
 const char* cost_indices_error(const icem_handle* h, int o);
 

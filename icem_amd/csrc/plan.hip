@@ -441,6 +441,7 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
     const int row0 = (last && c.use_mean_actions) ? 1 : 0;
     T* rec = (T*)b->records + (size_t)c.rank * K * (hd + 2);
     h->fast_lists = 0;
+    h->gen_sel_cand = 0;
     if constexpr (std::is_same<T, float>::value) {
         if (fast_rollout_ok(h, K)) {
             // f32 throughput path.  External white noise (b->z_r: the reference's own draws, tests/golden) takes it too: the
@@ -612,6 +613,13 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
     if (rc) return rc;
     rc = gk_rollout(h, n_loc + n_extra, b->obs0, actions, b->costs, nullptr, st);
     if (rc) return rc;
+    h->gen_sel_cand = 0;
+    if (c.world == 1 && gk_select_ok(h, n_cand, h->n_reuse, K)) {
+        // one GPU: nothing to exchange -- the merge call selects straight from the cost array (select_refit_kernel)
+        h->gen_sel_cand = n_cand;
+        h->gen_sel_loc = n_loc;
+        return ICEM_OK;
+    }
     const int nblk = std::max(1, topk_blocks(n_cand));
     rc = gk_topk_partial(h, n_cand, K, b->costs, b->workspace, nblk, st);
     if (rc) return rc;
@@ -784,6 +792,11 @@ int plan_iter_merge_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
     if (h->pk_pending) {
         const int rc = launch_pending_pack(h, st);
         if (rc) return rc;
+    }
+    if (c.world == 1 && h->gen_sel_cand > 0 && h->fast_lists == 0) {
+        const int n_cand = h->gen_sel_cand;
+        h->gen_sel_cand = 0;
+        return gk_select_refit(h, n_cand, h->gen_sel_loc, b->costs, b->actions, a, st);
     }
     return gk_merge_refit(h, a, st);
 }

@@ -1090,6 +1090,46 @@ def test_verbose_mode_prints_the_reference_lines_and_plans_the_same(capsys):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("kind,mode,o,N", [(0, "sum", 17, 4096), (1, "best", 18, 1000), (1, "final", 8, 300), (0, "sum", 24, 700)])
+def test_generic_path_forms_compute_the_same_bits(dtype, kind, mode, o, N, monkeypatch):
+    """The strict-parity path's two forms of an iteration -- a trajectory's row of lanes + ONE selection / gather / refit
+    launch (rollout_cost_rows_kernel, select_refit_kernel) against one thread per trajectory + top-K partials, pack, merge
+    (ICEM_GK_ROLLOUT=thread, ICEM_GK_SELECT=0) -- give the same bits in every buffer over three MPC steps: costs, elite sets
+    and their costs, mean, std, executed action (same fused multiply-add chains, same key order, same refit)."""
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env
+    d = 6
+    env = halfcheetah_env(17)   # (action space; the cost is set per width below)
+    model = DeviceSyntheticModel.make(o, d, kind=kind)
+
+    def run(old):
+        if old:
+            monkeypatch.setenv("ICEM_GK_ROLLOUT", "thread")
+            monkeypatch.setenv("ICEM_GK_SELECT", "0")
+        else:
+            monkeypatch.delenv("ICEM_GK_ROLLOUT", raising=False)
+            monkeypatch.delenv("ICEM_GK_SELECT", raising=False)
+        if dtype == "f32":
+            monkeypatch.setenv("ICEM_DISABLE_FAST", "1")   # f32 on the generic kernels
+        pl = IcemPlanner(IcemConfig(horizon=30, act_dim=d, num_traj=N, opt_iters=3, dtype=dtype, seed=5, cost_mode=mode),
+                         env.action_space.low, env.action_space.high)
+        pl.set_model(model.kind, model.A, model.B)
+        pl.set_cost(0.1, min(8, o - 1), -1.0, 1, 10.0, 0.3)
+        pl.reset()
+        out = []
+        for s in range(3):
+            obs = 0.1 * np.random.RandomState(40 + s).randn(o)
+            a = pl.plan_step(obs).cpu().numpy().copy()
+            ea, ec = pl.current_elites()
+            out.append((a, pl.costs.cpu().numpy().copy(), ea.cpu().numpy().copy(), ec.cpu().numpy().copy(),
+                        pl.mean.cpu().numpy().copy(), pl.std.cpu().numpy().copy(), pl.best_cost.cpu().numpy().copy()))
+        return out
+    new, old = run(False), run(True)
+    for s, (x, y) in enumerate(zip(new, old)):
+        for k, (u, v) in enumerate(zip(x, y)):
+            assert np.array_equal(u, v, equal_nan=True), (s, k)
+
+
 # ---------------------------------------------------------------------------------------------
 # f-4: the remaining env cost functions as device cost terms
 # ---------------------------------------------------------------------------------------------
