@@ -388,11 +388,20 @@ def roofline_of(prof, w, workload=None, fit=None, tile_arith=0):
             "binding_roof": "hbm" if att["hbm_floor_us"] >= att["alu_floor_us"] else ("fp16-mfma + f32-alu" if tile_arith else "f32-alu")}
 
 
+class RecordsPathFailed(RuntimeError):
+    """Some rank's launches reported a failure of the path the ranks' elite records travel on (agreed on by all ranks)."""
+
+
 def timed_steps(pl, steps, warmup, world, spread=None):
     """W untimed steps, then K timed ones between barrier + synchronize pairs; the MAX over ranks.  That first block of
     exactly K steps is what `value` is computed from.  A block shorter than 10 ms says little about a box (clock ramps, a
     neighbour's interrupt): when `spread` (a dict) is given, further blocks of K steps are timed the same way until 10 ms
-    have been covered, and their min / median / max ms per step are recorded in it."""
+    have been covered, and their min / median / max ms per step are recorded in it.
+    world > 1: a rank whose step raises (a bounded wait for a peer's records ran out) does NOT leave the collective
+    pattern -- every block ends in the same all-reduce, which carries the ranks' failure flags; if any is set, every rank
+    raises RecordsPathFailed and the caller degrades the path on all of them (timed_with_fallback)."""
+    from icem_amd import _lib as L
+
     def sync():
         torch.cuda.synchronize()
         if world > 1:
@@ -400,28 +409,61 @@ def timed_steps(pl, steps, warmup, world, spread=None):
             dist.barrier()
             torch.cuda.synchronize()
 
-    def block():
+    def block(n):
         sync()
+        failed = 0.0
         t0 = time.perf_counter()
-        run_steps(pl, steps, world)
+        try:
+            run_steps(pl, n, world)
+        except L.IcemError as ex:
+            failed = 1.0
+            print(f"bench.py: rank {pl.cfg.rank}: {ex}", file=sys.stderr)
         sync()
         el = time.perf_counter() - t0
+        if world > 1 and getattr(pl, "_exchange", False):
+            # the steps are enqueued long before the device runs them: a wait that ran out in THIS block has raised nothing
+            # yet -- read (and clear) the status word the kernels report into
+            status = pl.exchange_status()[0]
+            if status & 1:
+                pl._xchg_status_seen = status
+                failed = 1.0
         if world > 1:
             import torch.distributed as dist
-            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            t = torch.tensor([el, failed], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
+            el, failed = float(t[0].item()), float(t[1].item())
+        if failed:
+            raise RecordsPathFailed()
         return el
-    run_steps(pl, warmup, world)
-    el = block()
+    block(warmup)
+    el = block(steps)
     if spread is not None:
         blocks = [el]
         while sum(blocks) < 10e-3 and len(blocks) < 64:   # (el is the max over ranks: every rank takes the same number)
-            blocks.append(block())
+            blocks.append(block(steps))
         per = sorted(1e3 * b / steps for b in blocks)
         spread.update({"blocks_of_k_steps": len(blocks), "covered_ms": 1e3 * sum(blocks), "ms_per_step_first_block": 1e3 * el / steps,
                        "ms_per_step_min": per[0], "ms_per_step_median": per[len(per) // 2], "ms_per_step_max": per[-1]})
     return el
+
+
+def timed_with_fallback(pl, steps, warmup, world, spread=None):
+    """timed_steps; where the records' path fails at run time, all ranks step down together (IcemPlanner.degrade_exchange:
+    in-library exchange -> in-library RCCL all-gather -> host-driven all-gather) and the measurement starts over."""
+    degraded = []
+    for _ in range(3):
+        try:
+            if spread is not None:
+                spread.clear()
+            el = timed_steps(pl, steps, warmup, world, spread)
+            if degraded and spread is not None:
+                spread["records_path_degraded_to"] = degraded
+            return el
+        except RecordsPathFailed:
+            degraded.append(pl.degrade_exchange())
+            if pl.cfg.rank == 0:
+                print(f"bench.py: the records' path failed at run time; all ranks now on: {degraded[-1]}", file=sys.stderr)
+    raise SystemExit("bench.py: the ranks' elite records do not get through on any path")
 
 
 def loop_floor_ms(w, pops_total, tile_arith):
@@ -441,7 +483,7 @@ def measure_also(name, rank=0, world=1, steps=200, warmup=20, global_n=None):
     w = WORKLOADS[name]
     pl, _, _ = make_planner(w, rank, world, global_n=global_n)
     spread = {}
-    el = timed_steps(pl, steps, warmup, world, spread)
+    el = timed_with_fallback(pl, steps, warmup, world, spread)
     pl.profile_enable(True)
     run_steps(pl, 10, world)
     torch.cuda.synchronize()
@@ -699,7 +741,7 @@ def main():
     pl, model, env = make_planner(w, rank, world, cost_mode=args.cost_mode)
     per_step_trajsteps = sum(pl.population_sizes) * w["h"]  # global (all ranks) traj-steps per MPC step
     spread = {}
-    elapsed = timed_steps(pl, args.steps, args.warmup, world, spread)
+    elapsed = timed_with_fallback(pl, args.steps, args.warmup, world, spread)
     tile_arith = pl.tile_arith if w["o"] <= 32 else 0
 
     # second pass: per-kernel durations from HIP events on the launch stream

@@ -48,7 +48,32 @@ struct Exchange {
     // a peer connected by pointer lives in this process, possibly behind the same stream: its launches are ordered with
     // ours, so nothing of ours may wait for something it has not launched yet (no riding pack)
     bool local_peers = false;
+    // fault injection (ICEM_XCHG_FAIL=connect|selftest|timeout[:rank[:pushes]], for first-contact drills on one GPU: bench.py
+    // must end every such run on a fallback path and say which -- tests/test_gpu_exchange_faults.py): 1 = this rank's
+    // icem_exchange_connect fails, 2 = its self-test reports a corrupted payload, 3 = after `fail_after` pushes it stops
+    // publishing its records: every rank's bounded wait for them runs out and the next MPC step reports it
+    int fail_mode = 0;
+    unsigned fail_after = 60;
 };
+
+static void parse_fault(Exchange* x, int rank, int world) {
+    x->fail_mode = 0;
+    const char* e = getenv("ICEM_XCHG_FAIL");
+    if (!e || !*e) return;
+    std::string s(e);
+    std::string mode = s.substr(0, s.find(':'));
+    int who = world - 1;
+    unsigned after = 60;
+    const size_t c1 = s.find(':');
+    if (c1 != std::string::npos) {
+        who = atoi(s.c_str() + c1 + 1);
+        const size_t c2 = s.find(':', c1 + 1);
+        if (c2 != std::string::npos) after = (unsigned)std::max(0, atoi(s.c_str() + c2 + 1));
+    }
+    if (who != rank) return;
+    x->fail_mode = mode == "connect" ? 1 : mode == "selftest" ? 2 : mode == "timeout" ? 3 : 0;
+    x->fail_after = after;
+}
 
 namespace {
 
@@ -154,8 +179,9 @@ int xchg_push(icem_handle* h, const void* my_records, hipStream_t st, XchgWait* 
     const unsigned seq = ++x->seq;
     const int parity = (int)(seq & 1u);
     const size_t off = x->rec_off + (size_t)parity * x->rec_slot + (size_t)h->cfg.rank * rec_bytes;
-    hipLaunchKernelGGL(exchange_push_kernel, dim3(world), dim3(256), 0, st, (const uint32_t*)my_records, (int)(rec_bytes / 4),
-                       x->peers_dev, off, h->cfg.rank, parity, seq);
+    if (!(x->fail_mode == 3 && seq > x->fail_after))   // (injected: a rank that stops publishing)
+        hipLaunchKernelGGL(exchange_push_kernel, dim3(world), dim3(256), 0, st, (const uint32_t*)my_records, (int)(rec_bytes / 4),
+                           x->peers_dev, off, h->cfg.rank, parity, seq);
     ICEM_HIP_TRY(hipGetLastError());
     wait_out->flags = reinterpret_cast<const unsigned*>(x->block) + parity * XCHG_MAX_WORLD;
     wait_out->status = x->status_dev;
@@ -176,7 +202,7 @@ int xchg_begin(icem_handle* h, XchgPush* push_out, XchgWait* wait_out) {
     const int parity = (int)(seq & 1u);
     push_out->peers = x->peers_dev;
     push_out->rec_byte_off = x->rec_off + (size_t)parity * x->rec_slot + (size_t)h->cfg.rank * rec_bytes;
-    push_out->world = world;
+    push_out->world = (x->fail_mode == 3 && seq > x->fail_after) ? 0 : world;   // (injected: a rank that stops publishing)
     push_out->flag_idx = parity * XCHG_MAX_WORLD + h->cfg.rank;
     push_out->seq = seq;
     wait_out->flags = reinterpret_cast<const unsigned*>(x->block) + parity * XCHG_MAX_WORLD;
@@ -260,6 +286,7 @@ int icem_exchange_create(icem_handle* h, void* ipc_out_host) {
         return fail(ICEM_E_HIP, std::string("hipMemset(exchange block): ") + hipGetErrorString(e));
     }
     x->block = (unsigned char*)p;
+    parse_fault(x, h->cfg.rank, h->cfg.world);
     // the status word: pinned host memory the kernels write on a timed-out wait (rare) and the host reads for free
     e = hipHostMalloc((void**)&x->status_host, 64, hipHostMallocMapped | hipHostMallocCoherent);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&x->status_dev, x->status_host, 0);
@@ -294,6 +321,7 @@ int icem_exchange_connect(icem_handle* h, const void* handles_host, void* const*
     const char* lb = getenv("ICEM_XCHG_LOOPBACK");
     x->loopback = lb && atoi(lb) != 0 && h->cfg.rank == 0;
     if (!handles_host && !local_blocks && !x->loopback) return fail(ICEM_E_INVALID, "neither IPC handles nor local block pointers");
+    if (x->fail_mode == 1) return fail(ICEM_E_HIP, "injected fault (ICEM_XCHG_FAIL=connect): mapping the peers' exchange blocks failed on this rank");
     const int world = h->cfg.world, rank = h->cfg.rank;
     x->peers.assign(world, nullptr);
     x->opened.assign(world, false);
@@ -347,6 +375,7 @@ int icem_exchange_probe(icem_handle* h, int32_t rounds, void* stream, double* us
     x->probe_seq += (unsigned)rounds;
     ICEM_HIP_TRY(hipGetLastError());
     ICEM_HIP_TRY(hipStreamSynchronize(st));
+    if (x->fail_mode == 2) __atomic_fetch_or(x->status_host, 2u, __ATOMIC_ACQ_REL);   // injected: "the payload check failed"
     long long ticks = 0;
     ICEM_HIP_TRY(hipMemcpy(&ticks, x->ticks_dev, sizeof(ticks), hipMemcpyDeviceToHost));
     *us_out = (double)ticks / 100.0 / (double)rounds;  // wall_clock64: 100 MHz

@@ -471,6 +471,29 @@ class IcemPlanner:
         self.exchange_error = str(err) if err is not None else "a peer failed to connect"
         return False
 
+    def degrade_exchange(self, group=None) -> str:
+        """COLLECTIVE, after a run-time failure of the records' path (a bounded wait for a peer ran out: the next
+        ``icem_plan_step_sharded`` raises): every rank leaves the path it was on and takes the next one in the order in-library
+        exchange -> the library's RCCL all-gather -> host-driven all-gather; the distribution is re-initialised (the steps
+        since the failure planned on garbage).  Returns the path now in use: ``"rccl"`` or ``"host"``."""
+        torch.cuda.synchronize(self.device)
+        was_exchange = bool(getattr(self, "_exchange", False))
+        if was_exchange:
+            status = self.exchange_status()[0] | int(getattr(self, "_xchg_status_seen", 0))   # read and clear
+            self._xchg_status_seen = 0
+            self.exchange_error = f"run time: a wait for a peer's elite records timed out (status word {status})"
+            L.check(self.lib.icem_exchange_disable(self._h))
+            self._exchange = False
+        elif getattr(self, "_rccl", False):
+            self.rccl_error = "run time: the in-library all-gather failed"
+            self.lib.icem_rccl_disconnect(self._h)
+            self._rccl = False
+        self._gather_fn = None
+        self.reset()
+        if was_exchange and self.connect_rccl(group):
+            return "rccl"
+        return "host"
+
     def connect_rccl(self, group=None) -> bool:
         """The fallback of :meth:`connect_exchange`: an RCCL communicator owned by the library (``icem_rccl_connect``) so
         that ``icem_plan_step_sharded`` gathers the ranks' records with ``ncclAllGather`` on the launch stream
