@@ -67,20 +67,38 @@ WORKLOADS = {
                name="HumanoidStandup-shaped synthetic at the env's real width, N=16384 h=30 d=17 o=378 beta=2.0, 3 CEM iters, dense tanh model"),
     "c3l": dict(N=16384, h=30, d=17, o=24, beta=2.0, iters=3, env="humanoid", kind=1,
                 name="HumanoidStandup-shaped synthetic, N=16384 h=30 d=17 o=24 (latent) beta=2.0, 3 CEM iters, tanh model"),
+    # the reference's other shipped settings (settings/{door,relocate,fpp}; beta from README.md:21-29) at the headline population:
+    # cost-term envs (icem_cost_terms) on the TileHN kernel -- recorded lines under profiles/, not default bench lines
+    "door": dict(N=4096, h=30, d=28, o=39, beta=2.5, iters=5, env="door", kind=1,
+                 name="Door-shaped synthetic (mjenvs.py:57-78 cost terms), N=4096 h=30 d=28 o=39 beta=2.5, 5 CEM iters, tanh model"),
+    "relocate": dict(N=4096, h=30, d=30, o=39, beta=3.5, iters=5, env="relocate", kind=1,
+                     name="Relocate-shaped synthetic (mjenvs.py:155-174 cost terms), N=4096 h=30 d=30 o=39 beta=3.5, 5 CEM iters, tanh model"),
+    "fpp": dict(N=4096, h=30, d=4, o=28, beta=3.0, iters=5, env="fpp", kind=0,
+                name="FetchPickAndPlace-shaped synthetic (robotics.py:150-164 cost), N=4096 h=30 d=4 o=28 beta=3.0, 5 CEM iters, linear model"),
 }
+
+
+def make_env(w):
+    from icem_amd import halfcheetah_env, humanoid_standup_env
+    from icem_amd import envs as E
+    kind = w.get("env")
+    if kind == "humanoid":
+        return humanoid_standup_env(w["o"])
+    if kind in ("door", "relocate", "fpp"):
+        return {"door": E.door_env, "relocate": E.relocate_env, "fpp": E.fetch_pick_and_place_env}[kind]()
+    return halfcheetah_env(w["o"])
 
 
 def make_planner(w, rank, world, seed=1234, cost_mode="sum", global_n=None, dtype="f32"):
     """One rank's planner of a run over `world` GPUs; global population = global_n (strong scaling) or w["N"] per GPU."""
-    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env, humanoid_standup_env
-    env = humanoid_standup_env(w["o"]) if w.get("env") == "humanoid" else halfcheetah_env(w["o"])
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner
+    env = make_env(w)
     model = DeviceSyntheticModel.make(w["o"], w["d"], kind=w.get("kind", 0))
     cfg = IcemConfig(horizon=w["h"], act_dim=w["d"], num_traj=global_n if global_n else w["N"] * world, opt_iters=w["iters"],
                      noise_beta=w["beta"], dtype=dtype, seed=seed, rank=rank, world=world, cost_mode=cost_mode)
     pl = IcemPlanner(cfg, env.action_space.low, env.action_space.high, device=f"cuda:{torch.cuda.current_device()}")
     pl.set_model(model.kind, model.A, model.B)
-    c = env.cost_spec
-    pl.set_cost(c.ctrl_weight, c.lin_idx, c.lin_weight, c.flip_idx, c.flip_penalty, c.flip_thresh)
+    pl.set_cost_spec(env.cost_spec)
     pl.reset()
     pl.obs0.copy_(torch.as_tensor(0.1 * np.random.RandomState(0).randn(w["o"]), dtype=pl.dt))
     if world > 1:
@@ -778,7 +796,8 @@ def main():
             "config": {"workload": w["name"], "per_gpu_population": w["N"], "global_population": w["N"] * world,
                        "traj_per_mpc_step": per_step_trajsteps // w["h"],
                        "model": "o' = tanh(o.A + a.B) dense (synthetic)" if model.kind == 1 else "o' = o.A + a.B dense linear (synthetic)",
-                       "cost": "HumanoidStandup cost_fn" if w.get("env") == "humanoid" else "HalfCheetah cost_fn", "cost_along_trajectory": args.cost_mode, "rng": "Philox4x32-10-seeded xoshiro128++ + Box-Muller", "parallelism": f"n-shard x{world}"},
+                       "cost": {"humanoid": "HumanoidStandup cost_fn", "door": "Door cost terms", "relocate": "Relocate cost terms",
+                     "fpp": "FetchPickAndPlace cost terms"}.get(w.get("env"), "HalfCheetah cost_fn"), "cost_along_trajectory": args.cost_mode, "rng": "Philox4x32-10-seeded xoshiro128++ + Box-Muller", "parallelism": f"n-shard x{world}"},
             "ms_per_mpc_step": 1e3 * elapsed / args.steps, "timed_region": spread,
             "roofline": roofline,
             "kernels_us": {k: round(1e3 * v[0] / v[1], 2) for k, v in prof.items()},
@@ -812,7 +831,7 @@ def main():
                 out["also_c5"] = {k: c5[k] for k in ("value", "unit", "ms_per_step", "dtype", "config", "roofline")}
             except Exception as ex:
                 out["also_c5"] = {"error": repr(ex)[:300]}
-        if not args.no_cpu_baseline and world == 1 and args.cost_mode == "sum":   # the C oracle's loop reduces by sum
+        if not args.no_cpu_baseline and world == 1 and args.cost_mode == "sum" and w.get("env") not in ("door", "relocate", "fpp"):   # the C oracle's loop: sum, HalfCheetah / HumanoidStandup form
             out["cpu_baseline"] = cpu_baseline(args.workload, c_port_threads(w))
             out["cpu_baseline"]["host_logical_cpus"] = usable_cores()
             out["cpu_baselines"] = extra_cpu_baselines(args.workload, w, model, env)

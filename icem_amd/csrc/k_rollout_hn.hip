@@ -63,13 +63,16 @@ struct TileHN {
     float sM, sB, act_mag;
 
     // A [o, lda] row-major (x' = x A + a B), B [d, ldb]
-    __device__ __forceinline__ void load(const FastRolloutArgs& a, const float* A, int lda, const float* B, int ldb, int o, int lane) {
+    // with_model = false: a wave that only evaluates costs (rollout_hn_pair_kernel) leaves the model's planes alone
+    __device__ __forceinline__ void load(const FastRolloutArgs& a, const float* A, int lda, const float* B, int ldb, int o, int lane,
+                                         bool with_model = true) {
         const int j = lane & 15;
         g = lane >> 4;
         sM = a.m_scale;
         sB = a.b_scale;
 #pragma unroll
         for (int c = 0; c < NT; ++c) {
+            if (!with_model) break;
             const int i = 16 * c + j;   // output column
 #pragma unroll
             for (int kb = 0; kb < NT; ++kb) {
@@ -153,9 +156,8 @@ struct TileHN {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    __device__ __forceinline__ void step(State& st, const float* rd) const {
-        // this step's action entries (entry 16 kb + 4 q + g at rd[16 kb + 4 q]) and the control cost's share
-        float xv[NT][4];
+    // this step's action entries (entry 16 kb + 4 q + g at rd[16 kb + 4 q]) and the control cost's share of this lane
+    __device__ __forceinline__ float actions_of(const float* rd, float (&xv)[NT][4]) const {
         float u = 0.f;
 #pragma unroll
         for (int kb = 0; kb < NT; ++kb)
@@ -171,22 +173,26 @@ struct TileHN {
                     u = __builtin_fmaf(xv[kb][q], xv[kb][q], u);
                 }
             }
-        // (the same block BEHIND the MFMAs -- in their shadow, the accumulators are not needed before the next step -- measured
-        //  slower: 71 instead of 57.5 us per Door launch at N = 4096)
-        // the pre-action observation in the row; the cost: the four lanes' shares (control cost, lane group 0's icem_cost_spec
-        // terms) summed by one reduction, the term list on top (the same value in all four lanes)
-        park(st);
+        return u;
+    }
+    // the step's cost from the pre-action observation in row `x` (this lane's trajectory) and the control cost's share u: the
+    // four lanes' shares (control cost, lane group 0's icem_cost_spec terms) summed by one reduction, the term list on top (the
+    // same value in all four lanes)
+    __device__ __forceinline__ void cost_step(State& st, float u, const float* x) const {
         float c = u * ctrl_w;
         {
-            const float ang = row[flip_i];
+            const float ang = x[flip_i];
             c += (ang > wc.flip_th) ? pen_g : 0.f;
             c += (ang < -wc.flip_th) ? pen_g : 0.f;
-            c = __builtin_fmaf(lin_g, row[wc.lin_idx], c);
+            c = __builtin_fmaf(lin_g, x[wc.lin_idx], c);
         }
-        c = reduce_groups(c) + terms_all(row);
+        c = reduce_groups(c) + terms_all(x);
         st.acc_s = __builtin_fmaf(st.acc_s, ksum, c);
         st.acc_b = (c < st.acc_b || c != c) ? c : st.acc_b;   // np.amin: a NaN step cost makes the trajectory's cost NaN
-        // B operand planes per contraction block: own columns (x 1 / sM: from the accumulators' scale to the operand's), actions
+    }
+    // the model step: B operand planes per contraction block -- own columns (x 1 / sM: from the accumulators' scale to the
+    // operand's), actions -- then 3 NT^2 MFMAs
+    __device__ __forceinline__ void model_step(State& st, const float (&xv)[NT][4]) const {
         unsigned bH[NT][4], bL[NT][4];
 #pragma unroll
         for (int kb = 0; kb < NT; ++kb) {
@@ -222,6 +228,26 @@ struct TileHN {
                 st.cur[c2] = nxt[c2];
             }
         }
+    }
+    // ... into another buffer of rows (rollout_hn_pair_kernel's two: `off` floats from the first), no wave-level fence: the
+    // reader is another wave, behind a workgroup barrier
+    __device__ __forceinline__ void park_to(const State& st, int off) const {
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            f32x4 v;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) v[s] = st.cur[c][s] * invT;
+            *reinterpret_cast<f32x4*>(row + off + 16 * c + 4 * g) = v;
+        }
+    }
+    __device__ __forceinline__ void step(State& st, const float* rd) const {
+        float xv[NT][4];
+        const float u = actions_of(rd, xv);
+        // (the cost block BEHIND the MFMAs -- in their shadow, the accumulators are not needed before the next step -- measured
+        //  slower: 71 instead of 57.5 us per Door launch at N = 4096)
+        park(st);
+        cost_step(st, u, row);
+        model_step(st, xv);
     }
     // The term parameters are read through the CONSTANT address space (scalar loads: wave-uniform values in scalar registers,
     // selects on them are scalar selects, nothing is exec-masked); x: the trajectory's observation row in LDS.
@@ -319,6 +345,113 @@ __global__ __launch_bounds__(64 * WAVES) void rollout_hn_kernel(HnArgs a) {
     if (a.r.K > 0) wg_merge_emit<WAVES>(wg_keys, run_key, a.r.K, lane, wave, a.r);
 }
 
+// The same rollout with TWO waves per tile for populations that leave the chip mostly empty (at most two tiles per CU): a lone
+// wave issues a step's 150-330 vector instructions and 12-27 MFMAs one after the other, 1.0-2.3 us per step.  Here wave 2p of
+// a workgroup is tile p's MODEL wave (actions -> operand planes -> MFMAs -> tanh -> the next observation parked in the pair's
+// LDS rows) and wave 2p + 1 its COST wave (control cost, icem_cost_spec part and the term list of the observation parked one
+// barrier earlier), one workgroup barrier per step, the observation rows and the staged action chunks double-buffered between
+// them.  Same operations in the same order on the same values as rollout_hn_kernel: the same bits (tested).
+template <int H, int D, int O, int KIND, int PAIRS, int N32, int N4, int NP>
+__global__ __launch_bounds__(128 * PAIRS) void rollout_hn_pair_kernel(HnArgs a) {
+    using Tile = TileHN<H, D, O, KIND, N32, N4, NP>;
+    using Stream = StreamT<Tile, H, D>;
+    constexpr int TC = Stream::TC, NCH = Stream::NCH, C4 = Stream::C4, CBP = Stream::CBP, VW = Stream::VW, NLD = Stream::NLD;
+    constexpr int ROWS = 16 * Tile::RS;
+    __shared__ __attribute__((aligned(16))) float stage[PAIRS][2][Stream::STG];
+    __shared__ __attribute__((aligned(16))) float rows[PAIRS][2][ROWS];
+    __shared__ unsigned long long wg_keys[2][PAIRS][32];
+    __shared__ __attribute__((aligned(16))) float obs_stage[Tile::OP];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int pair = wave >> 1;
+    const bool model = (wave & 1) == 0;
+    const float obs_reg = a.r.obs0[((int)threadIdx.x < Tile::OP && (int)threadIdx.x < a.r.o) ? threadIdx.x : 0];
+    Tile tile;
+    tile.load(a.r, a.A, a.lda, a.B, a.ldb, a.r.o, lane, model);
+    tile.set_cost(a.wc, a.cs);
+    Stream stream;
+    stream.init(tile, stage[pair][0], lane);
+    const int tiles = (a.r.n_rows + 15) / 16;
+    if ((int)threadIdx.x < Tile::OP) obs_stage[threadIdx.x] = (int)threadIdx.x < a.r.o ? obs_reg : 0.f;
+    __syncthreads();
+    tile.load_obs(obs_stage, rows[pair][0]);
+    unsigned long long run_key = KEY_SENTINEL;
+    bool first = true;
+    // (every pair of the workgroup walks the same number of tiles: the barriers are the workgroup's; a pair past the end rolls a
+    //  clamped tile out and drops it)
+    const int stride = PAIRS * (int)gridDim.x;
+    const int rounds = (tiles - (int)blockIdx.x + stride - 1) / stride;
+    for (int rnd = 0; rnd < rounds; ++rnd) {
+        const int tile_id = rnd * stride + pair * (int)gridDim.x + (int)blockIdx.x;
+        const bool tile_on = tile_id < tiles;
+        const int tid_c = tile_on ? tile_id : 0;
+        const int row = tid_c * 16 + (lane & 15);
+        const bool live = tile_on && row < a.r.n_rows;
+        typename Stream::Vec pre[NLD];
+        const typename Stream::Vec* src[NLD];
+        if (model) {
+#pragma unroll
+            for (int m = 0; m < NLD; ++m) {
+                const int r = tid_c * 16 + stream.ld_row[m];
+                src[m] = reinterpret_cast<const typename Stream::Vec*>(a.r.actions + (size_t)(r < a.r.n_rows ? r : 0) * (H * D)) + stream.ld_c4[m];
+                pre[m] = src[m][0];
+            }
+        }
+        typename Tile::State st;
+        tile.init(st);
+        if (model) {   // chunk 0 -> staging buffer 0, chunk 1 requested; the start observation -> rows buffer 0
+#pragma unroll
+            for (int m = 0; m < NLD; ++m)
+                if (stream.ld_on[m]) *reinterpret_cast<typename Stream::Vec*>(&stage[pair][0][Tile::SLACK + stream.ld_row[m] * CBP + VW * stream.ld_c4[m]]) = pre[m];
+            if (1 < NCH) {
+#pragma unroll
+                for (int m = 0; m < NLD; ++m) pre[m] = src[m][C4];
+            }
+            tile.park_to(st, 0);
+        }
+        __syncthreads();
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int cb = ch & 1;
+#pragma unroll
+            for (int ts = 0; ts < TC; ++ts) {
+                const int t = ch * TC + ts;
+                const float* rd = stream.rd0 + cb * Stream::STG + ts * D;
+                float xv[Tile::NT][4];
+                const float u = tile.actions_of(rd, xv);
+                if (model) {
+                    if (ts == TC - 1 && ch + 1 < NCH) {   // the next chunk -> the other staging buffer (read from the next step on)
+#pragma unroll
+                        for (int m = 0; m < NLD; ++m)
+                            if (stream.ld_on[m])
+                                *reinterpret_cast<typename Stream::Vec*>(&stage[pair][cb ^ 1][Tile::SLACK + stream.ld_row[m] * CBP + VW * stream.ld_c4[m]]) = pre[m];
+                        if (ch + 2 < NCH) {
+#pragma unroll
+                            for (int m = 0; m < NLD; ++m) pre[m] = src[m][(ch + 2) * C4];
+                        }
+                    }
+                    tile.model_step(st, xv);
+                    if (t + 1 < H) tile.park_to(st, ((t + 1) & 1) * ROWS);
+                } else {
+                    tile.cost_step(st, u, tile.row + (t & 1) * ROWS);
+                }
+                __syncthreads();
+            }
+        }
+        if (!model) {
+            const float cost = tile.cost(st);
+            if (live && lane < 16) a.r.costs[row] = cost;
+            if (a.r.K > 0) {
+                const unsigned long long key = (lane < 16 && live && row < a.r.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
+                run_key = topk_push16(run_key, key, first, a.r.K, lane);
+            }
+            first = false;
+        }
+    }
+    if (a.r.K > 0) wg_merge_emit<PAIRS>(wg_keys, run_key, a.r.K, lane, model ? PAIRS : pair, a.r);
+}
+
+constexpr int HN_PAIR_MAX_TILES = 512;   // two tiles per CU: beyond, four lone waves per CU fill the SIMDs as well
+
 void hn_shape(int n_rows, int* grid, int* waves) {
     r16_shape(n_rows, grid, waves);
     if (*waves > HN_MAX_WAVES) *waves = HN_MAX_WAVES;
@@ -335,8 +468,19 @@ bool hn_rollout_supported(int h, int d, int o, int K) {
     return false;
 }
 
+// the two-wave-per-tile form: populations of at most HN_PAIR_MAX_TILES tiles (ICEM_HN_PAIR=0: never -- A/B, tests; read per call)
+static bool hn_pair_shape(int n_rows, int* grid, int* pairs) {
+    const char* e = getenv("ICEM_HN_PAIR");
+    const int tiles = std::max(1, (n_rows + 15) / 16);
+    if ((e && e[0] == '0') || tiles > HN_PAIR_MAX_TILES) return false;
+    *pairs = tiles > FAST_MAX_LISTS ? 2 : 1;
+    *grid = std::min(FAST_MAX_LISTS, (tiles + *pairs - 1) / *pairs);
+    return true;
+}
+
 int hn_rollout_lists(int n_rows) {
     int g, w;
+    if (hn_pair_shape(n_rows, &g, &w)) return g;
     hn_shape(n_rows, &g, &w);
     return g;
 }
@@ -358,6 +502,35 @@ void launch_rollout_hn(const FastRolloutArgs& r, int h, int d, int o, int kind, 
                        int lin_idx, int flip_idx, const CostArgs<float>* cs, const int* prog, hipStream_t st) {
     HnArgs a{r, A, B, lda, ldb, WideCost{lin_idx, flip_idx, r.ctrl_w, r.lin_w, r.flip_pen, r.flip_th}, cs};
     int grid, waves;
+    if (hn_pair_shape(r.n_rows, &grid, &waves)) {
+        const int pairs = waves;
+#define PP(HH, DD, OO, KK, PPV, A32, A4, AP)                                                                                       \
+    if (prog[0] == A32 && prog[1] == A4 && prog[2] == AP) {                                                                        \
+        hipLaunchKernelGGL((rollout_hn_pair_kernel<HH, DD, OO, KK, PPV, A32, A4, AP>), dim3(grid), dim3(128 * PPV), 0, st, a);     \
+        return;                                                                                                                    \
+    }
+#define PK(HH, DD, OO, KK, PPV) PP(HH, DD, OO, KK, PPV, 0, 0, 0) PP(HH, DD, OO, KK, PPV, 0, 2, 0) PP(HH, DD, OO, KK, PPV, 0, 4, 1) PP(HH, DD, OO, KK, PPV, 1, 1, 4)
+#define PW(HH, DD, OO, PPV)                 \
+    if (pairs == PPV) {                     \
+        if (kind == 1) {                    \
+            PK(HH, DD, OO, 1, PPV)          \
+        } else {                            \
+            PK(HH, DD, OO, 0, PPV)          \
+        }                                   \
+        return;                             \
+    }
+#define PR(HH, DD, OO)                   \
+    if (h == HH && d == DD && o == OO) { \
+        PW(HH, DD, OO, 1)                \
+        PW(HH, DD, OO, 2)                \
+    }
+        ICEM_HN_SHAPES(PR)
+#undef PR
+#undef PW
+#undef PK
+#undef PP
+        return;
+    }
     hn_shape(r.n_rows, &grid, &waves);
 #define XP(HH, DD, OO, KK, WW, A32, A4, AP)                                                                                   \
     if (prog[0] == A32 && prog[1] == A4 && prog[2] == AP) {                                                                   \

@@ -111,3 +111,36 @@ def test_term_lists_outside_the_compiled_programs_keep_the_gemm_kernel():
     spec2 = dataclasses.replace(O.CostSpec.door(), terms=O.CostSpec.door().terms + (O.CostTerm(O.TERM_SUMSQ, 0, -1, 20, 1e-3),))
     want = O.rollout_costs(O.SyntheticModel(model.A, model.B, model.kind), spec2, obs0, acts).astype(np.float64)
     assert (np.abs(got - want) <= 1e-4 * (1 + np.abs(want))).mean() > 0.98
+
+
+@pytest.mark.parametrize("name,kind,mode", [("door", 1, "sum"), ("relocate", 1, "best"), ("fpp", 0, "final"), ("fpp", 1, "sum")])
+def test_two_waves_per_tile_compute_the_bits_of_one(name, kind, mode, monkeypatch):
+    """rollout_hn_pair_kernel (small populations: a model wave and a cost wave per 16-trajectory tile, one workgroup barrier per
+    step) against rollout_hn_kernel (one wave per tile; ICEM_HN_PAIR=0): the same operations on the same values -- every cost,
+    every elite, mean, std and executed action bit for bit over three MPC steps, at one tile per workgroup (N = 4096: 256 + 1
+    tiles from the second step on, one workgroup walks two) and at two (N = 6000), and for stand-alone rollouts with a ragged
+    last tile."""
+    from icem_amd import DeviceSyntheticModel
+    mk, _ = _env(name)
+    env = mk()
+    o, d = env.obs_dim, env.action_space.shape[0]
+    model = DeviceSyntheticModel.make(o, d, kind=kind)
+    rs = np.random.RandomState(11)
+    acts = rs.uniform(-1, 1, (16 * 9 + 5, 30, d)) * env.action_space.high
+    for N in (4096, 6000):
+        out = {}
+        for pair in ("1", "0"):
+            monkeypatch.setenv("ICEM_HN_PAIR", pair)
+            pl = _planner(env, model, N=N, iters=3, mode=mode)
+            res = []
+            for s in range(3):
+                obs = 0.2 * np.random.RandomState(50 + s).randn(o)
+                a = pl.plan_step(obs).cpu().numpy().copy()
+                ea, ec = pl.current_elites()
+                res.append((a, pl.costs.cpu().numpy().copy(), ea.cpu().numpy().copy(), ec.cpu().numpy().copy(),
+                            pl.mean.cpu().numpy().copy(), pl.std.cpu().numpy().copy()))
+            res.append((pl.rollout_cost(0.2 * rs.randn(o) * 0 + 0.1, torch.as_tensor(acts, dtype=pl.dt, device=pl.device)).cpu().numpy().copy(),))
+            out[pair] = res
+        for s, (x, y) in enumerate(zip(out["1"], out["0"])):
+            for k, (u, v) in enumerate(zip(x, y)):
+                assert np.array_equal(u, v, equal_nan=True), (N, s, k)
