@@ -29,6 +29,12 @@ namespace icem {
 
 namespace {
 
+// A workgroup barrier that orders LDS traffic ONLY: __syncthreads() carries a release / acquire fence that also waits for every
+// global load in flight (s_waitcnt vmcnt(0)) -- the staging wave's prefetch of the next action chunk, requested a moment
+// earlier: a cold HBM round trip at the barrier of every chunk, for every wave of the workgroup (half of a launch).  The step
+// loops below exchange through LDS alone; the prefetch's registers are waited for where they are used.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr int HN_MAX_WAVES = 4;   // one per SIMD: the tile's registers (model planes + two operand planes of the state + staging) reach 260-340 at d = 30
 
 // N32 / N4 / NP: the term list's compile-time shape (hn_cost_program, abi.hip sorts the handle's terms into it and pads with
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(128 * PAIRS) void rollout_hn_pair_kernel(HnArgs a) 
                 } else {
                     tile.cost_step(st, u, tile.row + (t & 1) * ROWS);
                 }
-                __syncthreads();
+                lds_barrier();
             }
         }
         if (!model) {
@@ -450,6 +456,226 @@ __global__ __launch_bounds__(128 * PAIRS) void rollout_hn_pair_kernel(HnArgs a) 
     if (a.r.K > 0) wg_merge_emit<PAIRS>(wg_keys, run_key, a.r.K, lane, model ? PAIRS : pair, a.r);
 }
 
+// ... and with the MODEL split over the output tiles as well: NT model waves + one cost wave per tile, for populations of at most
+// one tile per CU.  Model wave c owns output tile c: its planes of the model (a third of TileHN's operand registers), the
+// lane's four columns of that tile, their operand planes and those of action block c; the waves exchange the operand planes
+// through LDS (lane to SAME lane: 2 x 16 bytes per lane, block and step), one workgroup barrier per step; each runs its own
+// accumulator's 3 NT MFMAs in TileHN's order, so every accumulator sees the products it sees there: the same bits.
+template <int H, int D, int O, int KIND, int N32, int N4, int NP>
+struct TileHNc {
+    using Full = TileHN<H, D, O, KIND, N32, N4, NP>;
+    static constexpr int NT = Full::NT, OP = Full::OP, RS = Full::RS;
+    unsigned mH[NT][4], mL[NT][4];   // [contraction block]: planes of slots 8g .. 8g+7 of output tile c
+    f32x4 obs_init;
+    float T, invT, invM, sact, part_w;
+    int part_off, c, g;
+    float sM, sB, act_mag;
+    float* row;
+
+    __device__ __forceinline__ void load(const FastRolloutArgs& a, const float* A, int lda, const float* B, int ldb, int o, int lane, int tile_c) {
+        const int j = lane & 15;
+        g = lane >> 4;
+        c = tile_c;
+        sM = a.m_scale;
+        sB = a.b_scale;
+        const int i = 16 * c + j;   // output column
+#pragma unroll
+        for (int kb = 0; kb < NT; ++kb) {
+            float m[8];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int k = 16 * kb + 4 * g + s;
+                m[s] = (k < o && i < o) ? A[(size_t)k * lda + i] * sM : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = Full::EV(kb, q) + g;
+                m[4 + q] = (e < D && i < o) ? B[(size_t)e * ldb + i] * sB : 0.f;
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) split_pair_f16(m[2 * p], m[2 * p + 1], mH[kb][p], mL[kb][p]);
+        }
+        part_w = g < (D & 3) ? 1.f : 0.f;
+        part_off = g < (D & 3) ? 0 : -(4 * (D / 4) + g);
+        act_mag = a.act_mag;
+    }
+    __device__ __forceinline__ void load_obs(const float* obs, float* rows) {
+        const int lane = (int)(threadIdx.x & 63);
+        float mx = lane < OP ? __builtin_fabsf(obs[lane < OP ? lane : 0]) : 0.f;
+        mx = mx != mx ? 0.f : mx;
+        float mm = __uint_as_float(~wave_min_u32(~__float_as_uint(mx)));
+        mm = mm > act_mag ? mm : act_mag;
+        if (KIND == 1) mm = mm > 1.f ? mm : 1.f;
+        int ex = (int)((__float_as_uint(mm) >> 23) & 0xFF) - 127;
+        ex = ex < -100 ? -100 : (ex > 100 ? 100 : ex);
+        auto uni = [](float x) { return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(x))); };
+        const float S = __uint_as_float((unsigned)(127 + 4 - ex) << 23);
+        T = uni(S * sM);
+        invT = uni(__uint_as_float((unsigned)(127 - 4 + ex) << 23) / sM);
+        invM = uni(1.f / sM);
+        sact = uni(T / sB);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) obs_init[s] = obs[16 * c + 4 * g + s] * T;
+        row = rows + (lane & 15) * RS;
+    }
+    // this lane's operand planes of block c for the step whose actions are at rd: own columns, then the block's action entries
+    __device__ __forceinline__ void planes(const f32x4& cur, const float* rd, unsigned (&pH)[4], unsigned (&pL)[4]) const {
+        float xv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ev = 16 * c + 4 * q;
+            xv[q] = ev >= D ? 0.f : (ev + 3 < D ? rd[ev] : rd[ev + part_off] * part_w);
+        }
+        split_pair_f16_scaled(cur[0], invM, cur[1], invM, pH[0], pL[0]);
+        split_pair_f16_scaled(cur[2], invM, cur[3], invM, pH[1], pL[1]);
+        if (16 * c >= D) pH[2] = pL[2] = 0u;
+        else split_pair_f16_scaled(xv[0], sact, xv[1], sact, pH[2], pL[2]);
+        if (16 * c + 8 >= D) pH[3] = pL[3] = 0u;
+        else split_pair_f16_scaled(xv[2], sact, xv[3], sact, pH[3], pL[3]);
+    }
+    // the accumulator of output tile c: TileHN::model_step's order for it -- (lo x hi) over the blocks, (hi x lo), (hi x hi)
+    __device__ __forceinline__ f32x4 advance(const unsigned (&bH)[NT][4], const unsigned (&bL)[NT][4]) const {
+        f32x4 nxt = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < NT; ++kb) nxt = mfma_f16_32(mL[kb], bH[kb], nxt);
+#pragma unroll
+        for (int kb = 0; kb < NT; ++kb) nxt = mfma_f16_32(mH[kb], bL[kb], nxt);
+#pragma unroll
+        for (int kb = 0; kb < NT; ++kb) nxt = mfma_f16_32(mH[kb], bH[kb], nxt);
+        if (KIND == 1) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) nxt[s] = fast_tanh(nxt[s] * invT) * T;
+        }
+        return nxt;
+    }
+    __device__ __forceinline__ void park_to(const f32x4& cur, int off) const {
+        f32x4 v;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] = cur[s] * invT;
+        *reinterpret_cast<f32x4*>(row + off + 16 * c + 4 * g) = v;
+    }
+};
+
+template <int H, int D, int O, int KIND, int N32, int N4, int NP>
+__global__ __launch_bounds__(64 * (TileHN<H, D, O, KIND, N32, N4, NP>::NT + 1)) void rollout_hn_split_kernel(HnArgs a) {
+    using Tile = TileHN<H, D, O, KIND, N32, N4, NP>;
+    using TileC = TileHNc<H, D, O, KIND, N32, N4, NP>;
+    using Stream = StreamT<Tile, H, D>;
+    constexpr int NT = Tile::NT, TC = Stream::TC, NCH = Stream::NCH, C4 = Stream::C4, CBP = Stream::CBP, VW = Stream::VW, NLD = Stream::NLD;
+    static_assert(TC >= 2, "the next chunk is staged one barrier ahead of its first reader");
+    constexpr int ROWS = 16 * Tile::RS;
+    __shared__ __attribute__((aligned(16))) float stage[2][Stream::STG];
+    __shared__ __attribute__((aligned(16))) float rows[2][ROWS];
+    __shared__ __attribute__((aligned(16))) uint4 xch[2][NT][2][64];   // [step parity][block][hi | lo][lane]: the operand planes
+    __shared__ unsigned long long wg_keys[2][1][32];
+    __shared__ __attribute__((aligned(16))) float obs_stage[Tile::OP];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const bool model = wave < NT;
+    const float obs_reg = a.r.obs0[((int)threadIdx.x < Tile::OP && (int)threadIdx.x < a.r.o) ? threadIdx.x : 0];
+    Tile tile;      // the cost wave's (and the staging layout's): no model planes
+    TileC mt;       // a model wave's
+    tile.load(a.r, a.A, a.lda, a.B, a.ldb, a.r.o, lane, false);
+    tile.set_cost(a.wc, a.cs);
+    if (model) mt.load(a.r, a.A, a.lda, a.B, a.ldb, a.r.o, lane, wave);
+    Stream stream;
+    stream.init(tile, stage[0], lane);
+    const int tiles = (a.r.n_rows + 15) / 16;
+    if ((int)threadIdx.x < Tile::OP) obs_stage[threadIdx.x] = (int)threadIdx.x < a.r.o ? obs_reg : 0.f;
+    __syncthreads();
+    tile.load_obs(obs_stage, rows[0]);
+    if (model) mt.load_obs(obs_stage, rows[0]);
+    unsigned long long run_key = KEY_SENTINEL;
+    bool first = true;
+    for (int tile_id = blockIdx.x; tile_id < tiles; tile_id += gridDim.x) {
+        const int row = tile_id * 16 + (lane & 15);
+        const bool live = row < a.r.n_rows;
+        typename Stream::Vec pre[NLD];
+        const typename Stream::Vec* src[NLD];
+        const bool stager = wave == 0;
+        if (stager) {
+#pragma unroll
+            for (int m = 0; m < NLD; ++m) {
+                const int r = tile_id * 16 + stream.ld_row[m];
+                src[m] = reinterpret_cast<const typename Stream::Vec*>(a.r.actions + (size_t)(r < a.r.n_rows ? r : 0) * (H * D)) + stream.ld_c4[m];
+                pre[m] = src[m][0];
+            }
+#pragma unroll
+            for (int m = 0; m < NLD; ++m)
+                if (stream.ld_on[m]) *reinterpret_cast<typename Stream::Vec*>(&stage[0][Tile::SLACK + stream.ld_row[m] * CBP + VW * stream.ld_c4[m]]) = pre[m];
+            if (1 < NCH) {
+#pragma unroll
+                for (int m = 0; m < NLD; ++m) pre[m] = src[m][C4];
+            }
+        }
+        typename Tile::State st;   // (the cost wave's accumulators)
+        tile.init(st);
+        f32x4 cur = mt.obs_init;
+        __syncthreads();   // chunk 0 is staged
+        if (model) {       // the start observation -> rows buffer 0; step 0's operand planes -> exchange buffer 0
+            mt.park_to(cur, 0);
+            unsigned pH[4], pL[4];
+            mt.planes(cur, stream.rd0, pH, pL);
+            xch[0][wave][0][lane] = uint4{pH[0], pH[1], pH[2], pH[3]};
+            xch[0][wave][1][lane] = uint4{pL[0], pL[1], pL[2], pL[3]};
+        }
+        __syncthreads();
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int cb = ch & 1;
+#pragma unroll
+            for (int ts = 0; ts < TC; ++ts) {
+                const int t = ch * TC + ts;
+                if (model) {
+                    if (stager && ts == 0 && ch + 1 < NCH) {   // the next chunk -> the other staging buffer, one barrier ahead of its readers
+#pragma unroll
+                        for (int m = 0; m < NLD; ++m)
+                            if (stream.ld_on[m])
+                                *reinterpret_cast<typename Stream::Vec*>(&stage[cb ^ 1][Tile::SLACK + stream.ld_row[m] * CBP + VW * stream.ld_c4[m]]) = pre[m];
+                        if (ch + 2 < NCH) {
+#pragma unroll
+                            for (int m = 0; m < NLD; ++m) pre[m] = src[m][(ch + 2) * C4];
+                        }
+                    }
+                    unsigned bH[NT][4], bL[NT][4];
+#pragma unroll
+                    for (int kb = 0; kb < NT; ++kb) {
+                        const uint4 h4 = xch[t & 1][kb][0][lane], l4 = xch[t & 1][kb][1][lane];
+                        bH[kb][0] = h4.x; bH[kb][1] = h4.y; bH[kb][2] = h4.z; bH[kb][3] = h4.w;
+                        bL[kb][0] = l4.x; bL[kb][1] = l4.y; bL[kb][2] = l4.z; bL[kb][3] = l4.w;
+                    }
+                    cur = mt.advance(bH, bL);
+                    if (t + 1 < H) {
+                        mt.park_to(cur, ((t + 1) & 1) * ROWS);
+                        const int t1 = t + 1;
+                        const float* rd1 = stream.rd0 + ((t1 / TC) & 1) * Stream::STG + (t1 % TC) * D;
+                        unsigned pH[4], pL[4];
+                        mt.planes(cur, rd1, pH, pL);
+                        xch[t1 & 1][wave][0][lane] = uint4{pH[0], pH[1], pH[2], pH[3]};
+                        xch[t1 & 1][wave][1][lane] = uint4{pL[0], pL[1], pL[2], pL[3]};
+                    }
+                } else {
+                    const float* rd = stream.rd0 + cb * Stream::STG + ts * D;
+                    float xv[NT][4];
+                    const float u = tile.actions_of(rd, xv);
+                    tile.cost_step(st, u, tile.row + (t & 1) * ROWS);
+                }
+                lds_barrier();
+            }
+        }
+        if (!model) {
+            const float cost = tile.cost(st);
+            if (live && lane < 16) a.r.costs[row] = cost;
+            if (a.r.K > 0) {
+                const unsigned long long key = (lane < 16 && live && row < a.r.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
+                run_key = topk_push16(run_key, key, first, a.r.K, lane);
+            }
+            first = false;
+        }
+    }
+    if (a.r.K > 0) wg_merge_emit<1>(wg_keys, run_key, a.r.K, lane, model ? 1 : 0, a.r);
+}
+
+constexpr int HN_SPLIT_MAX_TILES = FAST_MAX_LISTS + 16;   // one tile per CU (+ a second round for a few shifted-elite rows)
 constexpr int HN_PAIR_MAX_TILES = 512;   // two tiles per CU: beyond, four lone waves per CU fill the SIMDs as well
 
 void hn_shape(int n_rows, int* grid, int* waves) {
@@ -478,8 +704,19 @@ static bool hn_pair_shape(int n_rows, int* grid, int* pairs) {
     return true;
 }
 
+// the split form (NT model waves + a cost wave per tile): at most HN_SPLIT_MAX_TILES tiles (ICEM_HN_SPLIT=0: never)
+static bool hn_split_shape(int n_rows, int* grid) {
+    const char* e = getenv("ICEM_HN_SPLIT");
+    const char* e2 = getenv("ICEM_HN_PAIR");
+    const int tiles = std::max(1, (n_rows + 15) / 16);
+    if ((e && e[0] == '0') || (e2 && e2[0] == '0') || tiles > HN_SPLIT_MAX_TILES) return false;
+    *grid = std::min(FAST_MAX_LISTS, tiles);
+    return true;
+}
+
 int hn_rollout_lists(int n_rows) {
     int g, w;
+    if (hn_split_shape(n_rows, &g)) return g;
     if (hn_pair_shape(n_rows, &g, &w)) return g;
     hn_shape(n_rows, &g, &w);
     return g;
@@ -502,6 +739,29 @@ void launch_rollout_hn(const FastRolloutArgs& r, int h, int d, int o, int kind, 
                        int lin_idx, int flip_idx, const CostArgs<float>* cs, const int* prog, hipStream_t st) {
     HnArgs a{r, A, B, lda, ldb, WideCost{lin_idx, flip_idx, r.ctrl_w, r.lin_w, r.flip_pen, r.flip_th}, cs};
     int grid, waves;
+    if (hn_split_shape(r.n_rows, &grid)) {
+#define SP(HH, DD, OO, KK, A32, A4, AP)                                                                                             \
+    if (prog[0] == A32 && prog[1] == A4 && prog[2] == AP) {                                                                         \
+        constexpr int NTV = (OO + 15) / 16;                                                                                         \
+        hipLaunchKernelGGL((rollout_hn_split_kernel<HH, DD, OO, KK, A32, A4, AP>), dim3(grid), dim3(64 * (NTV + 1)), 0, st, a);     \
+        return;                                                                                                                     \
+    }
+#define SK(HH, DD, OO, KK) SP(HH, DD, OO, KK, 0, 0, 0) SP(HH, DD, OO, KK, 0, 2, 0) SP(HH, DD, OO, KK, 0, 4, 1) SP(HH, DD, OO, KK, 1, 1, 4)
+#define SR(HH, DD, OO)                   \
+    if (h == HH && d == DD && o == OO) { \
+        if (kind == 1) {                 \
+            SK(HH, DD, OO, 1)            \
+        } else {                         \
+            SK(HH, DD, OO, 0)            \
+        }                                \
+        return;                          \
+    }
+        ICEM_HN_SHAPES(SR)
+#undef SR
+#undef SK
+#undef SP
+        return;
+    }
     if (hn_pair_shape(r.n_rows, &grid, &waves)) {
         const int pairs = waves;
 #define PP(HH, DD, OO, KK, PPV, A32, A4, AP)                                                                                       \

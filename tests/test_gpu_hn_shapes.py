@@ -114,12 +114,13 @@ def test_term_lists_outside_the_compiled_programs_keep_the_gemm_kernel():
 
 
 @pytest.mark.parametrize("name,kind,mode", [("door", 1, "sum"), ("relocate", 1, "best"), ("fpp", 0, "final"), ("fpp", 1, "sum")])
-def test_two_waves_per_tile_compute_the_bits_of_one(name, kind, mode, monkeypatch):
-    """rollout_hn_pair_kernel (small populations: a model wave and a cost wave per 16-trajectory tile, one workgroup barrier per
-    step) against rollout_hn_kernel (one wave per tile; ICEM_HN_PAIR=0): the same operations on the same values -- every cost,
-    every elite, mean, std and executed action bit for bit over three MPC steps, at one tile per workgroup (N = 4096: 256 + 1
-    tiles from the second step on, one workgroup walks two) and at two (N = 6000), and for stand-alone rollouts with a ragged
-    last tile."""
+def test_every_wave_arrangement_of_a_tile_computes_the_same_bits(name, kind, mode, monkeypatch):
+    """The three arrangements of TileHN's work -- rollout_hn_split_kernel (at most one tile per CU: a model wave per OUTPUT TILE
+    exchanging operand planes through LDS + a cost wave), rollout_hn_pair_kernel (at most two tiles per CU: a model wave and a
+    cost wave; ICEM_HN_SPLIT=0) and rollout_hn_kernel (one wave per tile; ICEM_HN_PAIR=0) -- run the same operations on the same
+    values: every cost, every elite, mean, std and executed action bit for bit over three MPC steps, at N = 4096 (256 + 1
+    tiles from the second step on: one workgroup walks two) and N = 6000 (the pair form at two tiles per workgroup), and for a
+    stand-alone rollout with a ragged last tile."""
     from icem_amd import DeviceSyntheticModel
     mk, _ = _env(name)
     env = mk()
@@ -127,10 +128,15 @@ def test_two_waves_per_tile_compute_the_bits_of_one(name, kind, mode, monkeypatc
     model = DeviceSyntheticModel.make(o, d, kind=kind)
     rs = np.random.RandomState(11)
     acts = rs.uniform(-1, 1, (16 * 9 + 5, 30, d)) * env.action_space.high
+    obs_r = 0.2 * rs.randn(o)
+    variants = {"split": {}, "pair": {"ICEM_HN_SPLIT": "0"}, "single": {"ICEM_HN_PAIR": "0"}}
     for N in (4096, 6000):
         out = {}
-        for pair in ("1", "0"):
-            monkeypatch.setenv("ICEM_HN_PAIR", pair)
+        for label, envs in variants.items():
+            monkeypatch.delenv("ICEM_HN_SPLIT", raising=False)
+            monkeypatch.delenv("ICEM_HN_PAIR", raising=False)
+            for k, v in envs.items():
+                monkeypatch.setenv(k, v)
             pl = _planner(env, model, N=N, iters=3, mode=mode)
             res = []
             for s in range(3):
@@ -139,8 +145,9 @@ def test_two_waves_per_tile_compute_the_bits_of_one(name, kind, mode, monkeypatc
                 ea, ec = pl.current_elites()
                 res.append((a, pl.costs.cpu().numpy().copy(), ea.cpu().numpy().copy(), ec.cpu().numpy().copy(),
                             pl.mean.cpu().numpy().copy(), pl.std.cpu().numpy().copy()))
-            res.append((pl.rollout_cost(0.2 * rs.randn(o) * 0 + 0.1, torch.as_tensor(acts, dtype=pl.dt, device=pl.device)).cpu().numpy().copy(),))
-            out[pair] = res
-        for s, (x, y) in enumerate(zip(out["1"], out["0"])):
-            for k, (u, v) in enumerate(zip(x, y)):
-                assert np.array_equal(u, v, equal_nan=True), (N, s, k)
+            res.append((pl.rollout_cost(obs_r, torch.as_tensor(acts, dtype=pl.dt, device=pl.device)).cpu().numpy().copy(),))
+            out[label] = res
+        for label in ("split", "pair"):
+            for s, (x, y) in enumerate(zip(out[label], out["single"])):
+                for k, (u, v) in enumerate(zip(x, y)):
+                    assert np.array_equal(u, v, equal_nan=True), (label, N, s, k)
