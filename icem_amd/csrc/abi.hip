@@ -87,7 +87,8 @@ int pick_O(int o) {
 // closing event while a real kernel is still running)
 __global__ void profile_spin_kernel(long long ticks, long long* ran) {
     long long t0 = wall_clock64(), t = t0;
-    while (t - t0 < ticks) t = wall_clock64();
+    // (bounded: a wall clock that does not advance must not hang the stream -- every read is at least a few clocks)
+    for (long long polls = 0; t - t0 < ticks && polls < (1ll << 26); ++polls) t = wall_clock64();
     if (threadIdx.x == 0) *ran = t - t0;
 }
 
@@ -621,17 +622,23 @@ int icem_profile_overhead(void* stream, int32_t reps, double spin_us, double* pa
     if (!pair_us || !kernel_us || reps < 3 || reps > 4096 || !(spin_us >= 0.0) || spin_us > 1e4)
         return fail(ICEM_E_INVALID, "null output / bad reps or spin_us");
     hipStream_t st = (hipStream_t)stream;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return fail(ICEM_E_STATE, "icem_profile_overhead synchronises: not on a capturing stream");
+    (void)hipGetLastError();
     hipEvent_t a = nullptr, b = nullptr;
     long long* ran = nullptr;
-    ICEM_HIP_TRY(hipEventCreate(&a));
-    ICEM_HIP_TRY(hipEventCreate(&b));
-    ICEM_HIP_TRY(hipHostMalloc((void**)&ran, sizeof(long long), hipHostMallocMapped));
+    // (one exit: whatever was created is destroyed there)
+    hipError_t e0 = hipEventCreate(&a);
+    if (e0 == hipSuccess) e0 = hipEventCreate(&b);
+    if (e0 == hipSuccess) e0 = hipHostMalloc((void**)&ran, sizeof(long long), hipHostMallocMapped);
     std::vector<float> pair;
     std::vector<double> kern;
-    int rc = ICEM_OK;
+    int rc = e0 == hipSuccess ? ICEM_OK : fail(ICEM_E_HIP, hipGetErrorString(e0));
     for (int r = 0; r < reps + 8 && rc == ICEM_OK; ++r) {
         hipError_t e = hipEventRecord(a, st);
         hipLaunchKernelGGL(profile_spin_kernel, dim3(1), dim3(64), 0, st, (long long)(spin_us * 100.0), ran);
+        if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess) e = hipEventRecord(b, st);
         if (e == hipSuccess) e = hipEventSynchronize(b);
         float ms = 0.f;
@@ -642,9 +649,9 @@ int icem_profile_overhead(void* stream, int32_t reps, double spin_us, double* pa
             kern.push_back((double)*ran * 0.01);
         }
     }
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
-    (void)hipHostFree(ran);
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    if (ran) (void)hipHostFree(ran);
     if (rc != ICEM_OK) return rc;
     std::sort(pair.begin(), pair.end());
     std::sort(kern.begin(), kern.end());

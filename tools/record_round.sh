@@ -12,10 +12,22 @@ OUT=$ROOT/gpurun_out/$TAG-rec
 mkdir -p $OUT
 cd $ROOT
 timeout 1200 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.txt 2>&1; tail -1 $OUT/pytest_gpu.txt
-for w in c2 c4 c3; do timeout 900 bash tools/profile_round.sh $TAG $w > /dev/null 2>&1; done
+for w in c2 c4 c3 c5; do timeout 900 bash tools/profile_round.sh $TAG $w > /dev/null 2>&1; done
 cd $ROOT
 timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 300 $OUT/bench_default.json
 timeout 300 python bench.py --workload c5 --steps 200 --warmup 20 > $OUT/c5_bench.json 2> /dev/null
+# cost_along_trajectory = best / final on the headline workload, and the reference's other shipped settings (cost-term envs)
+for m in best final; do timeout 300 python bench.py --cost-mode $m --no-also --no-cpu-baseline > $OUT/bench_c2_$m.json 2> /dev/null; done
+for w in door relocate fpp; do timeout 300 python bench.py --workload $w --no-also --no-cpu-baseline > $OUT/bench_$w.json 2> /dev/null; done
+# first-contact drills of the records' path: two ranks on this box's GPU(s), every injected failure must end on a fallback path
+{
+  for f in none connect selftest:0 timeout:1:40; do
+    if [ $f = none ]; then unset ICEM_XCHG_FAIL; else export ICEM_XCHG_FAIL=$f; fi
+    echo "# ICEM_XCHG_FAIL=$f python bench.py --gpus 2 --steps 30 --warmup 5 --no-cpu-baseline --no-also  ->  exchange / timed_region of the line"
+    ICEM_XCHG_MAX_POLLS=20000 timeout 300 python bench.py --gpus 2 --steps 30 --warmup 5 --no-cpu-baseline --no-also 2> /dev/null | grep '^{' | python -c "import sys, json; j = json.loads(sys.stdin.read()); print(json.dumps({'ms_per_step': j['ms_per_step'], 'exchange': j['exchange'], 'timed_region': j['timed_region']}))"
+  done
+  unset ICEM_XCHG_FAIL
+} > $OUT/exchange_fault_drills.txt 2>&1
 {
   echo "# tools/controller_latency.py (MpcICemHip.get_action, host observation in, host action out)"
   timeout 120 python tools/controller_latency.py 2>&1 | grep "N="
@@ -28,6 +40,21 @@ timeout 300 python bench.py --workload c5 --steps 200 --warmup 20 > $OUT/c5_benc
   timeout 120 python tools/dbg/rssm_sweep.py 512 1024 2048 4096 16384 65536 2>&1 | grep "n="
   echo "# tools/dbg/rssm_stamps.py 1024 (tile 0 of the split launch)"
   timeout 120 python tools/dbg/rssm_stamps.py 1024 2>&1 | grep -v amdgpu.ids
+  echo "# tools/dbg/stamps.py 4096 5 (the headline's last launch, workgroup 0; ICEM_TILE_ARITH=0: the exact tile's VALU twin)"
+  timeout 120 python tools/dbg/stamps.py 4096 5 2>&1 | grep "us from"
+  ICEM_TILE_ARITH=0 timeout 120 python tools/dbg/stamps.py 4096 5 2>&1 | grep "us from" | sed 's/^/[exact tile] /'
+  echo "# ICEM_TILE_ARITH=0 tools/dbg/step_time.py (the exact f32 tile at the same populations)"
+  ICEM_TILE_ARITH=0 timeout 120 python tools/dbg/step_time.py 2048 4096 8192 16384 2>&1 | grep "N="
+  echo "# tools/dbg/f64_profile.py / f64_stamps.py (the strict-parity path; ICEM_GK_ROLLOUT=thread ICEM_GK_SELECT=0: its round-4 form)"
+  timeout 120 python tools/dbg/f64_profile.py 2>&1 | grep "f64 N"
+  ICEM_GK_ROLLOUT=thread ICEM_GK_SELECT=0 timeout 120 python tools/dbg/f64_profile.py 4096 10 2>&1 | grep "f64 N" | sed 's/^/[round-4 form] /'
+  timeout 120 python tools/dbg/f64_stamps.py 2>&1 | grep "us from"
+  echo "# tools/dbg/hn_terms_time.py (TileHN launches at N = 4096, HIP events incl. the ~4 us bracket: wave arrangements, with / without the term list)"
+  timeout 300 python tools/dbg/hn_terms_time.py 2>&1 | grep "terms="
+  echo "# tools/dbg/hn_check.py (MPC step of the shipped shapes)"
+  timeout 300 python tools/dbg/hn_check.py 2>&1 | grep "MPC step"
+  echo "# tools/ubench/lds_ring (the learned-dynamics weight ring: registers vs LDS)"
+  (cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o lds_ring lds_ring.hip 2> /dev/null; timeout 120 ./lds_ring)
 } > $OUT/tool_lines.txt 2>&1
 if [ -z "$QUICK" ]; then
 {
