@@ -128,6 +128,125 @@ __global__ __launch_bounds__(WG) void sample_clip_kernel(SampleArgs<T> a) {
     }
 }
 
+// The same sampler with FOUR lanes per (trajectory, dim) row (WG / 4 rows per workgroup): in float64 a row is one thread's chain of
+// HMAX / 2 libm-grade Box-Muller transforms and h x HMAX dependent fused multiply-adds -- 19 us per launch at N = 4096 with the
+// chip all but empty.  Lane q of a row's quad runs the row's generator like the others (integer work: cheap), transforms only
+// the pairs p = q, q + 4, .. of its words (or loads only those entries of the caller's z), multiplies them into partial sums
+// over ITS table columns (W staged in LDS) and the quad adds the four partial sums (two DPP swaps).  Not the thread form's
+// summation order: results agree with it to rounding (a few 1e-16 relative), inside the strict-parity bar of 1e-10.
+template <int CTRL>
+__device__ __forceinline__ float quad_swap(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double quad_swap(double x) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, false);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
+}
+
+template <typename T, int HMAX, int ROUNDS>
+__global__ __launch_bounds__(WG) void sample_clip_quad_kernel(SampleArgs<T> a) {
+    constexpr int PAIRS = HMAX / 8;   // Box-Muller pairs per lane
+    typedef T T2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* tile = reinterpret_cast<T*>(smem_raw);              // [tpw][h * d]
+    const int hd = a.h * a.d;
+    T* Wl = tile + (((size_t)a.tpw * hd + 1) & ~(size_t)1);   // [h][HMAX]
+    const int tid = threadIdx.x;
+    const int q = tid & 3, rowi = tid >> 2;
+    const int n_base = blockIdx.x * a.tpw;
+    const int n_here = min(a.tpw, a.n - n_base);
+    const int rows = n_here * a.d;
+    for (int e = tid; e < a.h * HMAX; e += WG) Wl[e] = a.W[e];
+    const bool on = rowi < rows;
+    const int nl = on ? rowi / a.d : 0;
+    const int j = on ? rowi - nl * a.d : 0;
+    T g[2 * PAIRS];   // entries m = 8 i + 2 q, 8 i + 2 q + 1 of the row's white draws
+    {
+        const int row_local = n_base + nl;
+        if (a.zr != nullptr && a.white) {
+#pragma unroll
+            for (int i = 0; i < PAIRS; ++i)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int m = 8 * i + 2 * q + u;
+                    g[2 * i + u] = m < a.h ? a.zr[((size_t)row_local * a.h + m) * a.d + j] : (T)0;
+                }
+        } else if (a.zr != nullptr) {
+            const size_t base = ((size_t)row_local * a.d + j) * a.F;
+#pragma unroll
+            for (int i = 0; i < PAIRS; ++i)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int m = 8 * i + 2 * q + u;
+                    T v = (T)0;
+                    if (m < a.F)
+                        v = a.zr[base + m];
+                    else if (m < a.h)
+                        v = a.zi[base + (m - a.F + 1)];
+                    g[2 * i + u] = v;
+                }
+        } else {
+            Xoshiro128pp rng = row_stream<ROUNDS>((uint32_t)(a.first_index + row_local), (uint32_t)j, a.off_lo, a.off_hi, a.seed_lo, a.seed_hi);
+            // every lane of the quad walks the row's whole word stream (integer work) and KEEPS the words of its own pairs
+            // (selects, no branch); the transforms -- the float64 work -- then run on all lanes at once, a quarter each
+            uint32_t wa[PAIRS], wb[PAIRS];
+#pragma unroll
+            for (int p = 0; p < HMAX / 2; ++p) {
+                const uint32_t xa = rng.next();
+                const uint32_t xb = rng.next();
+                if ((p & 3) == 0) {   // (p is a constant of the unrolled loop) the group's first pair: lane 0's, a placeholder for the others
+                    wa[p >> 2] = xa;
+                    wb[p >> 2] = xb;
+                } else {
+                    const bool mine = (p & 3) == q;
+                    wa[p >> 2] = mine ? xa : wa[p >> 2];
+                    wb[p >> 2] = mine ? xb : wb[p >> 2];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < PAIRS; ++i) {
+                if (2 * (4 * i) < a.h)   // (wave-uniform up to the quad's offset: pairs past the horizon are zero)
+                    box_muller(wa[i], wb[i], g[2 * i], g[2 * i + 1]);
+                if (!(2 * (4 * i + q) < a.h)) g[2 * i] = g[2 * i + 1] = (T)0;
+            }
+        }
+    }
+    __syncthreads();
+    const T lo = a.low[j], hi = a.high[j];
+    for (int t = a.t_begin; t < a.h; ++t) {
+        const T* __restrict__ w = Wl + (size_t)t * HMAX + 2 * q;
+        T acc = (T)0;
+#pragma unroll
+        for (int i = 0; i < PAIRS; ++i) {
+            const T2 wv = *reinterpret_cast<const T2*>(w + 8 * i);
+            acc = fmad(g[2 * i], wv[0], acc);
+            acc = fmad(g[2 * i + 1], wv[1], acc);
+        }
+        acc = acc + quad_swap<0xB1>(acc);   // quad_perm [1, 0, 3, 2]
+        acc = acc + quad_swap<0x4E>(acc);   // quad_perm [2, 3, 0, 1]
+        if (on && (t & 3) == q) {
+            T v = fmad(acc, a.std[t * a.d + j], a.mean[t * a.d + j]);
+            v = v < lo ? lo : v;
+            v = v > hi ? hi : v;
+            tile[nl * hd + t * a.d + j] = v;
+        }
+    }
+    __syncthreads();
+    if (a.row0_mean && a.first_index + n_base == 0) {  // icem.py:87-88
+        for (int e = tid; e < hd; e += WG) tile[e] = a.mean[e];
+        __syncthreads();
+    }
+    const size_t base = (size_t)n_base * hd;
+    const int total = n_here * hd;
+    const int e_begin = a.t_begin * a.d;
+    for (int e = tid; e < total; e += WG) {
+        if (e_begin == 0 || (e % hd) >= e_begin) a.out[base + e] = tile[e];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // MpcCemStd (the CEM baseline, icem/controllers/mpc.py:142-327): truncated-normal sampling and its bounds
 // ---------------------------------------------------------------------------------------------
@@ -1138,12 +1257,35 @@ SampleArgs<T> make_sample_args(const icem_handle* h, int n, long long first_inde
 }
 
 template <typename T>
-int launch_sample(const icem_handle* h, const SampleArgs<T>& a, hipStream_t st) {
-    if (a.n <= 0) return ICEM_OK;
+int launch_sample(const icem_handle* h, const SampleArgs<T>& a_in, hipStream_t st) {
+    if (a_in.n <= 0) return ICEM_OK;
+    SampleArgs<T> a = a_in;
+    // four lanes per row where the population leaves the chip mostly empty (the one-thread-per-row form's 256 rows per
+    // workgroup are then a few long chains per CU); ICEM_GK_SAMPLE=thread: never (A/B, tests; read per call)
+    const char* env_s = getenv("ICEM_GK_SAMPLE");
+    // (decided from the handle's GLOBAL population, never from a call's or a shard's row count: one summation order per handle)
+    const bool quad = !(env_s && env_s[0] == 't') && a.d <= WG / 4 && (long long)h->cfg.num_traj * a.d <= 262144;
+    if (quad) a.tpw = std::max(1, (WG / 4) / a.d);
     const int grid = (a.n + a.tpw - 1) / a.tpw;
-    const size_t lds = (size_t)a.tpw * a.h * a.d * sizeof(T);
+    size_t lds = (size_t)a.tpw * a.h * a.d * sizeof(T);
     ProfScope prof(h, ICEM_K_SAMPLE, (long long)a.n * (a.h - a.t_begin), st);
     const bool r7 = h->cfg.rng_rounds == 7;
+    if (quad) {
+        lds = ((((size_t)a.tpw * a.h * a.d + 1) & ~(size_t)1) + (size_t)a.h * h->HMAX) * sizeof(T);
+        if (h->HMAX == 32) {
+            if (r7)
+                hipLaunchKernelGGL((sample_clip_quad_kernel<T, 32, 7>), dim3(grid), dim3(WG), lds, st, a);
+            else
+                hipLaunchKernelGGL((sample_clip_quad_kernel<T, 32, 10>), dim3(grid), dim3(WG), lds, st, a);
+        } else {
+            if (r7)
+                hipLaunchKernelGGL((sample_clip_quad_kernel<T, 64, 7>), dim3(grid), dim3(WG), lds, st, a);
+            else
+                hipLaunchKernelGGL((sample_clip_quad_kernel<T, 64, 10>), dim3(grid), dim3(WG), lds, st, a);
+        }
+        ICEM_HIP_TRY(hipGetLastError());
+        return ICEM_OK;
+    }
     if (h->HMAX == 32) {
         if (r7)
             hipLaunchKernelGGL((sample_clip_kernel<T, 32, 7>), dim3(grid), dim3(WG), lds, st, a);

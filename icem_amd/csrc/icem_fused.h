@@ -96,6 +96,7 @@ int rollout_lists(int h, int d, int O, int n_rows);
 template <typename T> struct CostArgs;
 bool hn_rollout_supported(int h, int d, int o, int K);
 int hn_rollout_lists(int n_rows);
+int hn_tail_rows(int n_rows, int n_tail);   // trailing shifted-elite rows scored through the cost array (0: none)
 // cs: terms sorted into the program prog = (N32, N4, NP) and padded with null terms (kind -1): hn_cost_program says whether a
 // list of n32 long slices (5 .. 32 entries), n4 short ones and np point terms has a compiled program, and which
 bool hn_cost_program(int n32, int n4, int np, int* prog);

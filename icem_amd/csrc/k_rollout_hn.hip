@@ -672,7 +672,10 @@ __global__ __launch_bounds__(64 * (TileHN<H, D, O, KIND, N32, N4, NP>::NT + 1)) 
             first = false;
         }
     }
-    if (a.r.K > 0) wg_merge_emit<1>(wg_keys, run_key, a.r.K, lane, model ? 1 : 0, a.r);
+    // (tail workgroups -- trailing shifted-elite rows that would have opened a second round of tiles -- roll out and store
+    //  costs but emit no list: the merge takes those rows through the cost array; a.r.list_wgs = the list-writing workgroups)
+    const int n_wg = a.r.list_wgs > 0 ? a.r.list_wgs : (int)gridDim.x;
+    if (a.r.K > 0 && (int)blockIdx.x < n_wg) wg_merge_emit<1>(wg_keys, run_key, a.r.K, lane, model ? 1 : 0, a.r, blockIdx.x, n_wg);
 }
 
 constexpr int HN_SPLIT_MAX_TILES = FAST_MAX_LISTS + 16;   // one tile per CU (+ a second round for a few shifted-elite rows)
@@ -714,6 +717,15 @@ static bool hn_split_shape(int n_rows, int* grid) {
     return true;
 }
 
+// trailing shifted-elite rows of a launch whose sampled rows fill whole tiles: with the split form they get workgroups of
+// their own BEHIND the list-writing ones (no list: scored through the cost array) instead of a second round on workgroup 0
+int hn_tail_rows(int n_rows, int n_tail) {
+    int g;
+    if (n_tail <= 0 || n_tail > 64 || n_rows - n_tail <= 0 || (n_rows - n_tail) % 16 != 0) return 0;
+    if (!hn_split_shape(n_rows - n_tail, &g) || (n_rows - n_tail) / 16 > FAST_MAX_LISTS) return 0;
+    return n_tail;
+}
+
 int hn_rollout_lists(int n_rows) {
     int g, w;
     if (hn_split_shape(n_rows, &g)) return g;
@@ -740,6 +752,7 @@ void launch_rollout_hn(const FastRolloutArgs& r, int h, int d, int o, int kind, 
     HnArgs a{r, A, B, lda, ldb, WideCost{lin_idx, flip_idx, r.ctrl_w, r.lin_w, r.flip_pen, r.flip_th}, cs};
     int grid, waves;
     if (hn_split_shape(r.n_rows, &grid)) {
+        if (r.list_wgs > 0) grid = (r.n_rows + 15) / 16;   // list workgroups + the tail's (hn_tail_rows)
 #define SP(HH, DD, OO, KK, A32, A4, AP)                                                                                             \
     if (prog[0] == A32 && prog[1] == A4 && prog[2] == AP) {                                                                         \
         constexpr int NTV = (OO + 15) / 16;                                                                                         \

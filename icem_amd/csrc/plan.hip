@@ -187,9 +187,14 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
     if (rc) return rc;
     if (tail_out) *tail_out = 0;
     if (h->hn_tile) {   // Door / Relocate / FetchPickAndPlace shapes: TileHN (k_rollout_hn.hip)
-        FastRolloutArgs a = fast_rollout_args(h, n_rows, n_cand, K, obs0, actions, costs, part_c, part_i);
+        // trailing shifted elites that would open a second round of tiles: workgroups of their own, no list (tail_out rows: the
+        // caller's merge takes them as extra candidates through the cost array)
+        const int tail = (tail_out && n_cand == n_rows && K > 0) ? hn_tail_rows(n_rows, n_tail) : 0;
+        FastRolloutArgs a = fast_rollout_args(h, n_rows, tail ? n_rows - tail : n_cand, K, obs0, actions, costs, part_c, part_i);
         a.part_k = part_k;
         a.arith = 1;
+        a.list_wgs = tail ? (n_rows - tail) / 16 : 0;
+        if (tail) *tail_out = tail;
         const int ld = h->wide ? h->obs_dim : h->O;   // A_dev / B_dev: row-major f32, unpadded at o > 32, padded to O below
         {
             ProfScope prof(h, ICEM_K_ROLLOUT, (long long)n_rows * h->cfg.horizon, st);
@@ -197,7 +202,7 @@ int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const voi
                               h->cost.lin_idx, h->cost.flip_idx, h->has_terms ? (const CostArgs<float>*)h->hn_cs_dev : nullptr, h->hn_prog, st);
         }
         ICEM_HIP_TRY(hipGetLastError());
-        if (lists_out) *lists_out = hn_rollout_lists(n_rows);
+        if (lists_out) *lists_out = tail ? a.list_wgs : hn_rollout_lists(n_rows);
         return ICEM_OK;
     }
     if (gemm_rollout(h)) {
