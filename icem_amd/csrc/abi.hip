@@ -675,6 +675,10 @@ int icem_rssm_rollout_cost(int32_t n, int32_t horizon, int32_t cost_mode, const 
         return fail(ICEM_E_INVALID, "null tensor / bad n, horizon or cost_mode");
     const hipError_t e = launch_rssm_rollout(n, horizon, cost_mode, (const unsigned short*)params, (const float*)obs0,
                                              (const float*)actions, (float*)costs, (hipStream_t)stream);
+    if (e == hipErrorStreamCaptureUnsupported)
+        return fail(ICEM_E_STATE, "learned-dynamics rollout: the stream is capturing and this call would have to synchronise it (a larger "
+                                  "population or horizon than the staging area holds, or recovery from a timed-out wait): make one call "
+                                  "of this size outside the capture first");
     if (e == hipErrorLaunchTimeOut)
         return fail(ICEM_E_STATE, "learned-dynamics rollout: a reward workgroup of an EARLIER launch on this stream gave up waiting "
                                   "for its recurrence (that launch's costs are NaN); the staging flags were reset, nothing was "

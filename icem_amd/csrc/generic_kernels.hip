@@ -1161,7 +1161,19 @@ __global__ __launch_bounds__(SELECT_NT) void select_refit_kernel(SelectArgs<T> s
     }
     __syncthreads();
     if (s.dbg && tid == 0) s.dbg[19] = wall_clock64();
-    const int nc = n_c < s.cap ? n_c : s.cap;   // (the host admits only sizes whose worst case fits: gk_select_ok)
+    // More keys at or below the threshold than the candidate array holds: costs that TIE with it in bulk (a collapsed
+    // distribution -- every trajectory the same --, a population of NaNs).  Which of them landed in the array is a race, and
+    // np.argsort's order among equal costs is by index: take the three-launch path's selection instead (K rounds of a
+    // workgroup-wide minimum over all keys: deterministic, slow, rare).
+    if (n_c > s.cap) {
+        __shared__ T red_c[SELECT_NT / 64];
+        __shared__ int red_i[SELECT_NT / 64];
+        __shared__ int red_e[SELECT_NT / 64];
+        static_assert(SELECT_NT == WG, "block_select_sorted strides by WG");
+        block_select_sorted<T>(total, a.K, cost_of, gidx_of, sel_c, sel_i, sel_e, red_c, red_i, red_e);
+        __syncthreads();
+    }
+    const int nc = n_c <= s.cap ? n_c : 0;   // (overflow: the selection above stands, nothing is placed)
     for (int i = tid; i < nc; i += SELECT_NT) {
         const T c = cand_c[i];
         const int g = cand_i[i];

@@ -623,6 +623,7 @@ __global__ __launch_bounds__(NTHR) void rssm_split_kernel(int n, int horizon, in
 // One staging area per (device, stream): launches on a stream are ordered, so they may share it.  (Areas live until
 // rssm_split_trim(): 25 MB for populations up to 4096, up to 403 MB at 65 536 rows, per stream ever used.)
 struct Staging {
+    std::mutex mu;                   // this area's own lock: a wedged stream holds up its own launches, nobody else's
     unsigned short* stage = nullptr;
     unsigned* flags = nullptr;
     unsigned* status = nullptr;      // pinned, device-mapped word: raised by a reward workgroup whose wait timed out
@@ -640,6 +641,7 @@ void rssm_set_stamps(long long* dev_ptr) { g_stamps = dev_ptr; }
 void rssm_split_trim() {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto& kv : g_staging) {
+        std::lock_guard<std::mutex> la(kv.second.mu);
         if (kv.second.stage) (void)hipFree(kv.second.stage);
         if (kv.second.flags) (void)hipFree(kv.second.flags);
         if (kv.second.status) (void)hipHostFree(kv.second.status);
@@ -663,28 +665,41 @@ hipError_t launch_rssm_split(int n, int horizon, int cost_mode, const unsigned s
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    // The launch stays inside the lock: another host thread that grows this stream's staging synchronises the stream and
-    // frees the old area, which must not happen between reading the pointers and enqueuing the kernel that uses them.
-    std::lock_guard<std::mutex> lk(g_mu);
-    Staging& s = g_staging[{dev, st}];
+    // The map's lock covers the look-up alone (nodes of a std::map do not move); the launch stays inside the AREA's lock:
+    // another host thread that grows this stream's staging synchronises the stream and frees the old area, which must not
+    // happen between reading the pointers and enqueuing the kernel that uses them.
+    Staging* sp;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        sp = &g_staging[{dev, st}];
+    }
+    Staging& s = *sp;
+    std::lock_guard<std::mutex> lk(s.mu);
+    // a capturing stream must not be synchronised (it would invalidate the capture): the two cases below that need to --
+    // recovery from a timed-out wait, growing the area -- report instead
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    (void)hipGetLastError();
     if (!s.status) {
         if ((e = hipHostMalloc((void**)&s.status, sizeof(unsigned), hipHostMallocMapped)) != hipSuccess) return e;
         *s.status = 0u;
         if ((e = hipHostGetDevicePointer((void**)&s.status_dev, s.status, 0)) != hipSuccess) return e;
     }
-    if (__atomic_load_n(s.status, __ATOMIC_RELAXED) != 0u) {
+    if (__atomic_load_n(s.status, __ATOMIC_ACQUIRE) != 0u) {
         // a reward workgroup of an earlier launch on this stream gave up waiting: that launch returned NaN costs and its
         // flags are in an unknown state.  Quiesce, reset, and tell the caller (once) instead of launching on top of it.
+        if (capturing) return hipErrorStreamCaptureUnsupported;
         (void)hipStreamSynchronize(st);
         if (s.flags) (void)hipMemsetAsync(s.flags, 0, rssm::SPLIT_TILE_LIMIT * sizeof(unsigned), st);
         (void)hipStreamSynchronize(st);
-        __atomic_store_n(s.status, 0u, __ATOMIC_RELAXED);
+        __atomic_store_n(s.status, 0u, __ATOMIC_RELEASE);   // (behind the synchronise: no kernel is storing to it any more)
         return hipErrorLaunchTimeOut;
     }
     // (8 KB per tile and step: 25 MB cover the populations up to 4096 at h = 12; larger ones grow it, to 403 MB at 65 536)
     const size_t want = (size_t)(tiles > rssm::SPLIT_TT1_TILES ? tiles : rssm::SPLIT_TT1_TILES) * horizon;
     if (s.items < want) {   // (first call on this stream, or a longer horizon: not inside a capture)
         if (s.stage) {
+            if (capturing) return hipErrorStreamCaptureUnsupported;   // (growing means synchronising: size the area with one launch outside the capture)
             if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
             (void)hipFree(s.stage);
             s.stage = nullptr; s.items = 0;

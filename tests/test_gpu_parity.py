@@ -1131,6 +1131,43 @@ def test_generic_path_forms_compute_the_same_bits(dtype, kind, mode, o, N, monke
                 assert np.array_equal(u, v, equal_nan=True), (form, s, k)
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_one_launch_selection_with_every_cost_tied(dtype, monkeypatch):
+    """A cost that is the same for every trajectory (all weights zero: 4096 keys tie with the threshold, more than the
+    selection's candidate array holds): np.argsort's order among equal costs is by index, and the one-launch selection falls
+    back to the deterministic rounds -- the elites are pool rows 0 .. K - 1, the kept elites behind them, exactly as the
+    three-launch path picks them, step after step."""
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env
+    env = halfcheetah_env(17)
+    model = DeviceSyntheticModel.make(17, 6, kind=0)
+
+    def run(old):
+        if old:
+            monkeypatch.setenv("ICEM_GK_SELECT", "0")
+        else:
+            monkeypatch.delenv("ICEM_GK_SELECT", raising=False)
+        if dtype == "f32":
+            monkeypatch.setenv("ICEM_DISABLE_FAST", "1")
+        pl = IcemPlanner(IcemConfig(horizon=30, act_dim=6, num_traj=4096, opt_iters=3, dtype=dtype, seed=9),
+                         env.action_space.low, env.action_space.high)
+        pl.set_model(model.kind, model.A, model.B)
+        pl.set_cost(0.0, 0, 0.0, -1, 0.0, 0.0)
+        pl.reset()
+        out = []
+        for s in range(2):
+            a = pl.plan_step(0.1 * np.random.RandomState(s).randn(17)).cpu().numpy().copy()
+            ea, ec = pl.current_elites()
+            out.append((a, ea.cpu().numpy().copy(), ec.cpu().numpy().copy(), pl.mean.cpu().numpy().copy(), pl.std.cpu().numpy().copy()))
+        return out, pl
+    new, pl = run(False)
+    old, _ = run(True)
+    assert np.all(new[-1][2] == 0.0)
+    assert np.array_equal(new[-1][1], pl.actions[:pl.K].cpu().numpy())     # the last pool's first K rows
+    for s, (x, y) in enumerate(zip(new, old)):
+        for k, (u, v) in enumerate(zip(x, y)):
+            assert np.array_equal(u, v), (s, k)
+
+
 # ---------------------------------------------------------------------------------------------
 # f-4: the remaining env cost functions as device cost terms
 # ---------------------------------------------------------------------------------------------
