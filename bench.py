@@ -419,13 +419,16 @@ def timed_steps(pl, steps, warmup, world, spread=None):
     pattern -- every block ends in the same all-reduce, which carries the ranks' failure flags; if any is set, every rank
     raises RecordsPathFailed and the caller degrades the path on all of them (timed_with_fallback)."""
     from icem_amd import _lib as L
+    on_gpu = torch.cuda.is_available()   # (the CPU test of the ranks' agreement drives this loop with a stand-in planner)
 
     def sync():
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
-            torch.cuda.synchronize()
+            if on_gpu:
+                torch.cuda.synchronize()
 
     def block(n):
         sync()
@@ -447,7 +450,7 @@ def timed_steps(pl, steps, warmup, world, spread=None):
                 failed = 1.0
         if world > 1:
             import torch.distributed as dist
-            t = torch.tensor([el, failed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([el, failed], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el, failed = float(t[0].item()), float(t[1].item())
         if failed:

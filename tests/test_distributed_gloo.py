@@ -108,3 +108,69 @@ def test_bench_starts_its_own_ranks(tmp_path):
         j = json.loads(lines[0])
         assert j["n_gpus"] == n and j["rank_sum"] == n * (n + 1) / 2
         assert (j["launched_by"] == "direct") == (n == 1)
+
+
+# ---------------------------------------------------------------------------------------------
+# bench.py's agreement on a failed records path (world 2, gloo, a stand-in planner: no GPU)
+# ---------------------------------------------------------------------------------------------
+
+class _StandInPlanner:
+    """What bench.timed_steps needs of a planner: plan_step_resident raises IcemError from a given step on while the
+    path is "ipc" (a bounded device-side wait that ran out), degrade_exchange steps down."""
+
+    def __init__(self, rank, fail_rank, fail_from):
+        from types import SimpleNamespace
+        self.cfg = SimpleNamespace(rank=rank, world=2)
+        self.path, self.calls, self.fail_rank, self.fail_from = "ipc", 0, fail_rank, fail_from
+        self._exchange = False    # (no status word to read: the failure shows as an exception)
+        self.degraded = []
+
+    def plan_step_resident(self):
+        from icem_amd import _lib as L
+        self.calls += 1
+        if self.path == "ipc" and self.cfg.rank == self.fail_rank and self.calls >= self.fail_from:
+            raise L.IcemError(-4, "in-library exchange: a wait for a peer's elite records timed out")
+
+    def degrade_exchange(self):
+        self.path = "host"
+        self.degraded.append(self.path)
+        return self.path
+
+
+def _agree_worker(rank, world, port, out_dir):
+    import importlib.util
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+        # rank 1 alone starts failing in the middle of the first timed block: BOTH ranks must see RecordsPathFailed ...
+        pl = _StandInPlanner(rank, fail_rank=1, fail_from=9)
+        raised = False
+        try:
+            bench.timed_steps(pl, 6, 5, world, {})
+        except bench.RecordsPathFailed:
+            raised = True
+        # ... and with the fallback loop both step down once and finish the measurement on the next path
+        pl2 = _StandInPlanner(rank, fail_rank=1, fail_from=9)
+        spread = {}
+        el = bench.timed_with_fallback(pl2, 6, 5, world, spread)
+        np.savez(os.path.join(out_dir, f"agree{rank}.npz"), raised=raised, degraded=len(pl2.degraded), path=pl2.path, el=el,
+                 noted=spread.get("records_path_degraded_to", []) == ["host"])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_ranks_agree_on_a_failed_records_path_and_step_down_together(tmp_path):
+    """A rank whose MPC step raises stays inside the collective pattern of bench.py's timed blocks: the all-reduce that closes
+    the block carries the failure to every rank, all of them step down (the healthy rank too) and the measurement starts over
+    -- the run-time leg of the records' path drills, on CPU (the GPU form: tests/test_gpu_exchange_faults.py)."""
+    port = _free_port()
+    mp.spawn(_agree_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        z = np.load(tmp_path / f"agree{r}.npz")
+        assert bool(z["raised"]) and int(z["degraded"]) == 1 and str(z["path"]) == "host" and bool(z["noted"])
+        assert float(z["el"]) > 0
