@@ -1168,6 +1168,42 @@ def test_one_launch_selection_with_every_cost_tied(dtype, monkeypatch):
             assert np.array_equal(u, v), (s, k)
 
 
+@pytest.mark.parametrize("h,d,o,K,N,kind,mode", [
+    (40, 9, 8, 20, 300, 1, "sum"),      # h > 32: the 64-column synthesis table; d > 8: B through LDS; K > 16: the looped gather
+    (50, 3, 24, 4, 90, 0, "best"),      # 32 lanes per trajectory row, a short elite list
+    (33, 12, 32, 17, 257, 1, "final"),  # odd horizon, the widest generic observation, ragged last workgroup
+])
+def test_strict_parity_path_at_unusual_shapes_against_the_oracle(h, d, o, K, N, kind, mode):
+    """The float64 path's kernels off the beaten shapes -- long horizons (HMAX = 64 in both samplers), more action dims than
+    the rollout keeps in registers, elite counts beyond the register-gathered 16 -- over two MPC steps of device (Philox)
+    noise against the NumPy oracle restating the same stream: executed action, mean and std to 1e-9 (icem.py:106-211)."""
+    from icem_amd import IcemConfig, IcemPlanner
+    iters, seed = 2, 17
+    rs = np.random.RandomState(h + d)
+    m = O.SyntheticModel.make(o, d, kind)
+    spec = O.CostSpec(0.1, o - 1, -1.0, min(1, o - 1), 10.0, 0.3)
+    low, high = -0.7 * np.ones(d), 0.9 * np.ones(d)
+    pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=N, elites_size=K, opt_iters=iters, dtype="f64", seed=seed,
+                                cost_mode=mode), low, high)
+    pl.set_model(kind, m.A, m.B)
+    pl.set_cost(spec.ctrl_weight, spec.lin_idx, spec.lin_weight, spec.flip_idx, spec.flip_penalty, spec.flip_thresh)
+    pl.reset()
+    sched = O.PhiloxNoiseSchedule(seed, iters, d, h, dtype=np.float64)
+    orc = O.IcemOracle(O.IcemParams(horizon=h, num_simulated_trajectories=N, opt_iterations=iters, elites_size=K), low, high,
+                       lambda ob, ac: O.rollout_costs(m, spec, ob, ac, mode=mode),
+                       lambda num: tuple(z.astype(np.float64) for z in sched(num)))
+    orc.beginning_of_rollout()
+    for step in range(2):
+        obs = 0.2 * rs.randn(o)
+        if step:
+            sched.begin_step()
+        got = np_(pl.plan_step(obs))
+        want = orc.get_action(obs)
+        np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(np_(pl.mean), orc.mean, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(np_(pl.std), orc.std, rtol=1e-9, atol=1e-11)
+
+
 # ---------------------------------------------------------------------------------------------
 # f-4: the remaining env cost functions as device cost terms
 # ---------------------------------------------------------------------------------------------
