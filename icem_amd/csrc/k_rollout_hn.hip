@@ -296,6 +296,28 @@ struct TileHN {
         f *= gate_of(tm, x);
         return kind < 0 ? 0.f : tm->w * f;
     }
+    // ---- the cost in pieces, for kernels that spread it over two waves (rollout_hn_split_kernel): the part in front of the term
+    // list, one term's value, the accumulation -- composed in cost_step's order they give cost_step's bits
+    static constexpr int NTERMS = N32 + N4 + NP;
+    static constexpr int NB = N32 > 0 ? N32 : N4 / 2;   // the terms a second cost wave takes: the long slices, else half of the short ones
+    __device__ __forceinline__ float base_cost(float u, const float* x) const {
+        float c = u * ctrl_w;
+        const float ang = x[flip_i];
+        c += (ang > wc.flip_th) ? pen_g : 0.f;
+        c += (ang < -wc.flip_th) ? pen_g : 0.f;
+        c = __builtin_fmaf(lin_g, x[wc.lin_idx], c);
+        return reduce_groups(c);
+    }
+    template <int J>
+    __device__ __forceinline__ float term_val(const float* x) const {
+        if constexpr (J < N32) return slice_term<8>(term(J), x);
+        else if constexpr (J < N32 + N4) return slice_term<1>(term(J), x);
+        else return point_term(term(J), x);
+    }
+    __device__ __forceinline__ void acc_step(State& st, float c) const {
+        st.acc_s = __builtin_fmaf(st.acc_s, ksum, c);
+        st.acc_b = (c < st.acc_b || c != c) ? c : st.acc_b;   // np.amin: a NaN step cost makes the trajectory's cost NaN
+    }
     // the term list, the same value in all four lanes of the trajectory
     __device__ __forceinline__ float terms_all(const float* x) const {
         float c = 0.f;
@@ -556,24 +578,42 @@ struct TileHNc {
     }
 };
 
+// compile-time loop over term numbers [J0, J1)
+template <int J0, int J1, typename F>
+__device__ __forceinline__ void hn_for_terms(F&& f) {
+    if constexpr (J0 < J1) {
+        f(std::integral_constant<int, J0>{});
+        hn_for_terms<J0 + 1, J1>(f);
+    }
+}
+
+// waves of a workgroup: NT model waves, cost wave A (control cost, icem_cost_spec part, the terms behind the first NB, the
+// accumulation) and -- where the env has a term list -- cost wave B (the first NB terms: Door's 30-entry slice, half of
+// Relocate's norms): with the model on NT waves the term list had become the launch's chain (1.4 us of a Door step against the
+// model's 1.0).  B parks its terms' values in LDS; A closes step t one barrier later, adding the values IN THE LIST'S ORDER
+// (B's, then its own): cost_step's sum, bit for bit.
 template <int H, int D, int O, int KIND, int N32, int N4, int NP>
-__global__ __launch_bounds__(64 * (TileHN<H, D, O, KIND, N32, N4, NP>::NT + 1)) void rollout_hn_split_kernel(HnArgs a) {
+__global__ __launch_bounds__(64 * (TileHN<H, D, O, KIND, N32, N4, NP>::NT + 1 + (TileHN<H, D, O, KIND, N32, N4, NP>::NB > 0 ? 1 : 0)))
+void rollout_hn_split_kernel(HnArgs a) {
     using Tile = TileHN<H, D, O, KIND, N32, N4, NP>;
     using TileC = TileHNc<H, D, O, KIND, N32, N4, NP>;
     using Stream = StreamT<Tile, H, D>;
     constexpr int NT = Tile::NT, TC = Stream::TC, NCH = Stream::NCH, C4 = Stream::C4, CBP = Stream::CBP, VW = Stream::VW, NLD = Stream::NLD;
+    constexpr int NB = Tile::NB, NA = Tile::NTERMS - NB;
     static_assert(TC >= 2, "the next chunk is staged one barrier ahead of its first reader");
     constexpr int ROWS = 16 * Tile::RS;
     __shared__ __attribute__((aligned(16))) float stage[2][Stream::STG];
     __shared__ __attribute__((aligned(16))) float rows[2][ROWS];
     __shared__ __attribute__((aligned(16))) uint4 xch[2][NT][2][64];   // [step parity][block][hi | lo][lane]: the operand planes
+    __shared__ float tb[2][NB > 0 ? NB : 1][16];                       // [step parity][term][trajectory]: cost wave B's values
     __shared__ unsigned long long wg_keys[2][1][32];
     __shared__ __attribute__((aligned(16))) float obs_stage[Tile::OP];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const bool model = wave < NT;
+    const bool cost_a = wave == NT;
     const float obs_reg = a.r.obs0[((int)threadIdx.x < Tile::OP && (int)threadIdx.x < a.r.o) ? threadIdx.x : 0];
-    Tile tile;      // the cost wave's (and the staging layout's): no model planes
+    Tile tile;      // the cost waves' (and the staging layout's): no model planes
     TileC mt;       // a model wave's
     tile.load(a.r, a.A, a.lda, a.B, a.ldb, a.r.o, lane, false);
     tile.set_cost(a.wc, a.cs);
@@ -608,9 +648,11 @@ __global__ __launch_bounds__(64 * (TileHN<H, D, O, KIND, N32, N4, NP>::NT + 1)) 
                 for (int m = 0; m < NLD; ++m) pre[m] = src[m][C4];
             }
         }
-        typename Tile::State st;   // (the cost wave's accumulators)
+        typename Tile::State st;   // (cost wave A's accumulators)
         tile.init(st);
         f32x4 cur = mt.obs_init;
+        float base_prev = 0.f;                 // cost wave A: the step that waits for B's values
+        float va_prev[NA > 0 ? NA : 1];
         __syncthreads();   // chunk 0 is staged
         if (model) {       // the start observation -> rows buffer 0; step 0's operand planes -> exchange buffer 0
             mt.park_to(cur, 0);
@@ -620,6 +662,13 @@ __global__ __launch_bounds__(64 * (TileHN<H, D, O, KIND, N32, N4, NP>::NT + 1)) 
             xch[0][wave][1][lane] = uint4{pL[0], pL[1], pL[2], pL[3]};
         }
         __syncthreads();
+        // cost wave A closes step `tp` (its own share kept in base_prev / va_prev, B's in tb[tp & 1]): the list's order
+        auto close_step = [&](int tp) {
+            float c_terms = 0.f;
+            hn_for_terms<0, NB>([&](auto J) { c_terms += tb[tp & 1][decltype(J)::value][lane & 15]; });
+            hn_for_terms<0, NA>([&](auto J) { c_terms += va_prev[decltype(J)::value]; });
+            tile.acc_step(st, base_prev + c_terms);
+        };
         for (int ch = 0; ch < NCH; ++ch) {
             const int cb = ch & 1;
 #pragma unroll
@@ -653,16 +702,37 @@ __global__ __launch_bounds__(64 * (TileHN<H, D, O, KIND, N32, N4, NP>::NT + 1)) 
                         xch[t1 & 1][wave][0][lane] = uint4{pH[0], pH[1], pH[2], pH[3]};
                         xch[t1 & 1][wave][1][lane] = uint4{pL[0], pL[1], pL[2], pL[3]};
                     }
-                } else {
+                } else if (cost_a) {
                     const float* rd = stream.rd0 + cb * Stream::STG + ts * D;
+                    const float* x = tile.row + (t & 1) * ROWS;
                     float xv[NT][4];
                     const float u = tile.actions_of(rd, xv);
-                    tile.cost_step(st, u, tile.row + (t & 1) * ROWS);
+                    const float base = tile.base_cost(u, x);
+                    float va[NA > 0 ? NA : 1];
+                    hn_for_terms<0, NA>([&](auto J) { va[decltype(J)::value] = tile.template term_val<NB + decltype(J)::value>(x); });
+                    if constexpr (NB > 0) {
+                        if (t > 0) close_step(t - 1);            // B's values of step t - 1 are behind the barrier that opened this step
+                        base_prev = base;
+                        hn_for_terms<0, NA>([&](auto J) { va_prev[decltype(J)::value] = va[decltype(J)::value]; });
+                    } else {                                      // (no second cost wave: the step closes on the spot)
+                        float c_terms = 0.f;
+                        hn_for_terms<0, NA>([&](auto J) { c_terms += va[decltype(J)::value]; });
+                        tile.acc_step(st, base + c_terms);
+                    }
+                } else {   // cost wave B: the first NB terms of this step's observation
+                    const float* x = tile.row + (t & 1) * ROWS;
+                    hn_for_terms<0, NB>([&](auto J) {
+                        const float v = tile.template term_val<decltype(J)::value>(x);
+                        if (lane < 16) tb[t & 1][decltype(J)::value][lane] = v;
+                    });
                 }
                 lds_barrier();
             }
         }
-        if (!model) {
+        if constexpr (NB > 0) {
+            if (cost_a) close_step(H - 1);
+        }
+        if (cost_a) {
             const float cost = tile.cost(st);
             if (live && lane < 16) a.r.costs[row] = cost;
             if (a.r.K > 0) {
@@ -675,7 +745,7 @@ __global__ __launch_bounds__(64 * (TileHN<H, D, O, KIND, N32, N4, NP>::NT + 1)) 
     // (tail workgroups -- trailing shifted-elite rows that would have opened a second round of tiles -- roll out and store
     //  costs but emit no list: the merge takes those rows through the cost array; a.r.list_wgs = the list-writing workgroups)
     const int n_wg = a.r.list_wgs > 0 ? a.r.list_wgs : (int)gridDim.x;
-    if (a.r.K > 0 && (int)blockIdx.x < n_wg) wg_merge_emit<1>(wg_keys, run_key, a.r.K, lane, model ? 1 : 0, a.r, blockIdx.x, n_wg);
+    if (a.r.K > 0 && (int)blockIdx.x < n_wg) wg_merge_emit<1>(wg_keys, run_key, a.r.K, lane, cost_a ? 0 : 1, a.r, blockIdx.x, n_wg);
 }
 
 constexpr int HN_SPLIT_MAX_TILES = FAST_MAX_LISTS + 16;   // one tile per CU (+ a second round for a few shifted-elite rows)
@@ -756,7 +826,8 @@ void launch_rollout_hn(const FastRolloutArgs& r, int h, int d, int o, int kind, 
 #define SP(HH, DD, OO, KK, A32, A4, AP)                                                                                             \
     if (prog[0] == A32 && prog[1] == A4 && prog[2] == AP) {                                                                         \
         constexpr int NTV = (OO + 15) / 16;                                                                                         \
-        hipLaunchKernelGGL((rollout_hn_split_kernel<HH, DD, OO, KK, A32, A4, AP>), dim3(grid), dim3(64 * (NTV + 1)), 0, st, a);     \
+        constexpr int NWV = NTV + 1 + ((A32 > 0 ? A32 : A4 / 2) > 0 ? 1 : 0);   /* model waves + cost wave A (+ B) */                \
+        hipLaunchKernelGGL((rollout_hn_split_kernel<HH, DD, OO, KK, A32, A4, AP>), dim3(grid), dim3(64 * NWV), 0, st, a);           \
         return;                                                                                                                     \
     }
 #define SK(HH, DD, OO, KK) SP(HH, DD, OO, KK, 0, 0, 0) SP(HH, DD, OO, KK, 0, 2, 0) SP(HH, DD, OO, KK, 0, 4, 1) SP(HH, DD, OO, KK, 1, 1, 4)
