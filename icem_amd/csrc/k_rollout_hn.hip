@@ -541,15 +541,29 @@ struct TileHNc {
         row = rows + (lane & 15) * RS;
     }
     // this lane's operand planes of block c for the step whose actions are at rd: own columns, then the block's action entries
-    __device__ __forceinline__ void planes(const f32x4& cur, const float* rd, unsigned (&pH)[4], unsigned (&pL)[4]) const {
-        float xv[4];
+    // block c's action entries of the step at rd (read early: they do not depend on the state)
+    __device__ __forceinline__ void actions_c(const float* rd, float (&xv)[4]) const {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int ev = 16 * c + 4 * q;
             xv[q] = ev >= D ? 0.f : (ev + 3 < D ? rd[ev] : rd[ev + part_off] * part_w);
         }
+    }
+    __device__ __forceinline__ void planes(const f32x4& cur, const float* rd, unsigned (&pH)[4], unsigned (&pL)[4]) const {
+        float xv[4];
+        actions_c(rd, xv);
+        planes_xv(cur, xv, pH, pL);
+    }
+    __device__ __forceinline__ void planes_xv(const f32x4& cur, const float (&xv)[4], unsigned (&pH)[4], unsigned (&pL)[4]) const {
+        planes_state(cur, pH, pL);
+        planes_actions(xv, pH, pL);
+    }
+    // the two halves of a lane's operand planes: slots 0-1 from the state (behind the MFMAs), slots 2-3 from the actions (any time)
+    __device__ __forceinline__ void planes_state(const f32x4& cur, unsigned (&pH)[4], unsigned (&pL)[4]) const {
         split_pair_f16_scaled(cur[0], invM, cur[1], invM, pH[0], pL[0]);
         split_pair_f16_scaled(cur[2], invM, cur[3], invM, pH[1], pL[1]);
+    }
+    __device__ __forceinline__ void planes_actions(const float (&xv)[4], unsigned (&pH)[4], unsigned (&pL)[4]) const {
         if (16 * c >= D) pH[2] = pL[2] = 0u;
         else split_pair_f16_scaled(xv[0], sact, xv[1], sact, pH[2], pL[2]);
         if (16 * c + 8 >= D) pH[3] = pL[3] = 0u;
@@ -685,6 +699,12 @@ void rollout_hn_split_kernel(HnArgs a) {
                             for (int m = 0; m < NLD; ++m) pre[m] = src[m][(ch + 2) * C4];
                         }
                     }
+                    // the NEXT step's actions ride the same LDS round trip as this step's operand planes (a dependent LDS read
+                    // behind the MFMAs cost a lone wave 100 ns of every step)
+                    const int t1 = t + 1 < H ? t + 1 : t;
+                    const float* rd1 = stream.rd0 + ((t1 / TC) & 1) * Stream::STG + (t1 % TC) * D;
+                    float xv1[4];
+                    mt.actions_c(rd1, xv1);
                     unsigned bH[NT][4], bL[NT][4];
 #pragma unroll
                     for (int kb = 0; kb < NT; ++kb) {
@@ -692,13 +712,12 @@ void rollout_hn_split_kernel(HnArgs a) {
                         bH[kb][0] = h4.x; bH[kb][1] = h4.y; bH[kb][2] = h4.z; bH[kb][3] = h4.w;
                         bL[kb][0] = l4.x; bL[kb][1] = l4.y; bL[kb][2] = l4.z; bL[kb][3] = l4.w;
                     }
+                    unsigned pH[4], pL[4];
+                    mt.planes_actions(xv1, pH, pL);   // (in front of the MFMAs: nothing of it waits for the state)
                     cur = mt.advance(bH, bL);
                     if (t + 1 < H) {
                         mt.park_to(cur, ((t + 1) & 1) * ROWS);
-                        const int t1 = t + 1;
-                        const float* rd1 = stream.rd0 + ((t1 / TC) & 1) * Stream::STG + (t1 % TC) * D;
-                        unsigned pH[4], pL[4];
-                        mt.planes(cur, rd1, pH, pL);
+                        mt.planes_state(cur, pH, pL);
                         xch[t1 & 1][wave][0][lane] = uint4{pH[0], pH[1], pH[2], pH[3]};
                         xch[t1 & 1][wave][1][lane] = uint4{pL[0], pL[1], pL[2], pL[3]};
                     }
