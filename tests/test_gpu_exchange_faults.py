@@ -58,3 +58,19 @@ def test_every_injected_failure_ends_on_a_fallback_path_and_says_so(fault):
         assert "timed out" in ex["in_library_exchange_error"]
     else:
         assert "records_path_degraded_to" not in j["timed_region"]
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_four_and_eight_processes_exchange_their_records_through_the_library(world):
+    """The in-library exchange between `world` real processes (one IPC handle per peer, world - 1 peer blocks mapped, flags of
+    every peer polled) -- on this box all of them on the same GPU, so at a population whose workgroups are resident together
+    (tools/dbg/shared_gpu_worlds.py): HalfCheetah and Door shapes, every rank bit for bit the single-process run, nobody
+    timed out.  Two ranks are what the other tests of this file and of test_gpu_parity.py run."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "ICEM_XCHG_FAIL", "ICEM_XCHG_MAX_POLLS")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dbg", "shared_gpu_worlds.py"), str(world)], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith(f"world {world} ")]
+    assert len(lines) == 2 and all("identical to" in ln for ln in lines), r.stdout[-2000:]
+    assert all(ln.count("(1, 0)") == world for ln in lines), lines   # connected, status word 0 on every rank
+    assert "all identical" in r.stdout
