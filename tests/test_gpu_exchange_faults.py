@@ -60,13 +60,18 @@ def test_every_injected_failure_ends_on_a_fallback_path_and_says_so(fault):
         assert "records_path_degraded_to" not in j["timed_region"]
 
 
-@pytest.mark.parametrize("world", [4, 8])
-def test_four_and_eight_processes_exchange_their_records_through_the_library(world):
+@pytest.mark.parametrize("world,scale", [(4, None), (8, None), (8, "32.768")])
+def test_four_and_eight_processes_exchange_their_records_through_the_library(world, scale):
     """The in-library exchange between `world` real processes (one IPC handle per peer, world - 1 peer blocks mapped, flags of
     every peer polled) -- on this box all of them on the same GPU, so at a population whose workgroups are resident together
     (tools/dbg/shared_gpu_worlds.py): HalfCheetah and Door shapes, every rank bit for bit the single-process run, nobody
-    timed out.  Two ranks are what the other tests of this file and of test_gpu_parity.py run."""
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "ICEM_XCHG_FAIL", "ICEM_XCHG_MAX_POLLS")}
+    timed out.  Two ranks are what the other tests of this file and of test_gpu_parity.py run.
+    scale 32.768: BASELINE.json configs[3] as written -- N = 65 536 global over 8 ranks (and Door at 49 152) -- with every
+    rank on its own eighth of the CUs (HSA_CU_MASK), so that the ranks' launches are resident side by side as on a node."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "ICEM_XCHG_FAIL", "ICEM_XCHG_MAX_POLLS",
+                                                            "HSA_CU_MASK", "ICEM_SHARED_SCALE", "ICEM_SHARED_SLICES")}
+    if scale:
+        env.update(ICEM_SHARED_SCALE=scale, ICEM_SHARED_SLICES="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dbg", "shared_gpu_worlds.py"), str(world)], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]

@@ -1,7 +1,8 @@
 """The in-library exchange (IPC-mapped peer blocks + flags, csrc/exchange.hip) between `world` PROCESSES that share the one
 GPU of a box, at a global population small enough that every rank's workgroups are resident together (a rank's spinning wait
 cannot keep a peer's pack workgroup off the chip): every rank's actions, mean and elites of a few MPC steps against the
-single-process run, bit for bit, and the path each rank ended on.  (At bench.py's populations 4+ ranks on one GPU do not fit
+single-process run, bit for bit, and the path each rank ended on.  ICEM_SHARED_SCALE=<x> scales the populations,
+ICEM_SHARED_SLICES=1 gives every rank its own slice of the CUs (HSA_CU_MASK) -- larger populations then fit side by side.  (At bench.py's populations 4+ ranks on one GPU do not fit
 together: the bounded waits run out and the ranks step down -- profiles/r05_exchange_fault_drills.txt.)
 usage (GPU box): python tools/dbg/shared_gpu_worlds.py [world ...]"""
 import os, socket, sys
@@ -37,6 +38,9 @@ def run(pl, o, steps=4):
 
 
 def worker(rank, world, port, out_dir):
+    if os.environ.get("ICEM_SHARED_SLICES"):   # every rank its own slice of the 256 CUs (before HSA starts in this process)
+        cus = 256 // world
+        os.environ["HSA_CU_MASK"] = f"0:{rank * cus}-{(rank + 1) * cus - 1}"
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

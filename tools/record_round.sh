@@ -29,6 +29,9 @@ for w in door relocate fpp; do timeout 300 python bench.py --workload $w --no-al
   unset ICEM_XCHG_FAIL
   echo "# tools/dbg/shared_gpu_worlds.py 2 4 8: the exchange between 2 / 4 / 8 PROCESSES sharing this GPU, at a population whose workgroups are resident together"
   timeout 300 python tools/dbg/shared_gpu_worlds.py 2 4 8 2>&1 | grep "^world\|^shared"
+  echo "# ... every rank on its own slice of the CUs (ICEM_SHARED_SLICES=1), 8 processes: N = 65 536 global (BASELINE configs[3]; Door 49 152), then 65 536 PER RANK (N = 524 288 global; Door 393 216)"
+  ICEM_SHARED_SLICES=1 ICEM_SHARED_SCALE=32.768 timeout 300 python tools/dbg/shared_gpu_worlds.py 8 2>&1 | grep "^world\|^shared"
+  ICEM_SHARED_SLICES=1 ICEM_SHARED_SCALE=262.144 timeout 600 python tools/dbg/shared_gpu_worlds.py 8 2>&1 | grep "^world\|^shared"
   echo "# python -m torch.distributed.run --nproc-per-node {4,8} bench.py at the bench's population on ONE GPU: the ranks' launches do not fit on the chip together, a rank's bounded wait keeps a peer's pack workgroup off it -> the waits run out, all ranks step down together (a GPU per rank has no such tenant)"
   echo "# python bench.py --gpus {4,8} (self-launched ranks: each rank of a shared GPU gets its own slice of the CUs, HSA_CU_MASK): the same population, the in-library exchange carries the records"
   for n in 4 8; do
