@@ -33,6 +33,8 @@ for w in door relocate fpp; do timeout 300 python bench.py --workload $w --no-al
   ICEM_SHARED_SLICES=1 ICEM_SHARED_SCALE=32.768 timeout 300 python tools/dbg/shared_gpu_worlds.py 8 2>&1 | grep "^world\|^shared"
   ICEM_SHARED_SLICES=1 ICEM_SHARED_SCALE=262.144 timeout 600 python tools/dbg/shared_gpu_worlds.py 8 2>&1 | grep "^world\|^shared"
   echo "# python -m torch.distributed.run --nproc-per-node {4,8} bench.py at the bench's population on ONE GPU: the ranks' launches do not fit on the chip together, a rank's bounded wait keeps a peer's pack workgroup off it -> the waits run out, all ranks step down together (a GPU per rank has no such tenant)"
+  echo "# tools/dbg/shared_gpu_rank_time.py 2 4 8: real peers against absent ones, one tile per CU on every rank's slice; control = the same processes unsharded side by side"
+  timeout 600 python tools/dbg/shared_gpu_rank_time.py 2 4 8 2>&1 | grep "^world"
   echo "# python bench.py --gpus {4,8} (self-launched ranks: each rank of a shared GPU gets its own slice of the CUs, HSA_CU_MASK): the same population, the in-library exchange carries the records"
   for n in 4 8; do
     timeout 600 python bench.py --gpus $n --steps 20 --warmup 5 --no-cpu-baseline --no-also 2> /dev/null | grep '^{' | python -c "import sys, json; j = json.loads(sys.stdin.read()); print(json.dumps({'n_gpus': j['n_gpus'], 'ranks_share_a_gpu': j['ranks_share_a_gpu'], 'launched_by': j['launched_by'], 'ms_per_step': j['ms_per_step'], 'exchange': j['exchange'], 'timed_region': j['timed_region']}))"
