@@ -406,6 +406,16 @@ def roofline_of(prof, w, workload=None, fit=None, tile_arith=0):
             "binding_roof": "hbm" if att["hbm_floor_us"] >= att["alu_floor_us"] else ("fp16-mfma + f32-alu" if tile_arith else "f32-alu")}
 
 
+def distribution_checksum(pl):
+    """A float64-exact checksum of the bits of a planner's mean | std (low 24 bits of every element's image, summed)."""
+    mean, std = getattr(pl, "mean", None), getattr(pl, "std", None)
+    if mean is None or std is None:
+        return 0.0
+    x = torch.cat([torch.as_tensor(mean).flatten(), torch.as_tensor(std).flatten()]).contiguous()
+    bits = x.view(torch.int32 if x.element_size() == 4 else torch.int64).to(torch.int64)
+    return float((bits & 0xFFFFFF).sum().item())
+
+
 class RecordsPathFailed(RuntimeError):
     """Some rank's launches reported a failure of the path the ranks' elite records travel on (agreed on by all ranks)."""
 
@@ -450,9 +460,19 @@ def timed_steps(pl, steps, warmup, world, spread=None):
                 failed = 1.0
         if world > 1:
             import torch.distributed as dist
-            t = torch.tensor([el, failed], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+            # every rank refits the same distribution from the same records: a checksum of its bits rides in the same
+            # all-reduce (max of h and of -h), so records that arrive stale or torn on some rank -- nothing raises then --
+            # end the block like a failure of the path
+            h = distribution_checksum(pl)
+            t = torch.tensor([el, failed, h, -h], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el, failed = float(t[0].item()), float(t[1].item())
+            if not failed and float(t[2].item()) != -float(t[3].item()):
+                failed = 1.0
+                if spread is not None:
+                    spread["_ranks_disagreed"] = spread.get("_ranks_disagreed", 0) + 1
+                if pl.cfg.rank == 0:
+                    print("bench.py: the ranks' distributions differ after a block (records stale or torn on some rank)", file=sys.stderr)
         if failed:
             raise RecordsPathFailed()
         return el
@@ -471,16 +491,22 @@ def timed_steps(pl, steps, warmup, world, spread=None):
 def timed_with_fallback(pl, steps, warmup, world, spread=None):
     """timed_steps; where the records' path fails at run time, all ranks step down together (IcemPlanner.degrade_exchange:
     in-library exchange -> in-library RCCL all-gather -> host-driven all-gather) and the measurement starts over."""
-    degraded = []
+    degraded, disagreed = [], 0
     for _ in range(3):
         try:
             if spread is not None:
                 spread.clear()
             el = timed_steps(pl, steps, warmup, world, spread)
-            if degraded and spread is not None:
-                spread["records_path_degraded_to"] = degraded
+            if spread is not None:
+                if degraded:
+                    spread["records_path_degraded_to"] = degraded
+                if world > 1:
+                    spread["ranks_agree_after_every_block"] = True   # (a block that ended otherwise raised)
+                    if disagreed:
+                        spread["blocks_the_ranks_disagreed_after"] = disagreed
             return el
         except RecordsPathFailed:
+            disagreed += (spread or {}).get("_ranks_disagreed", 0)
             degraded.append(pl.degrade_exchange())
             if pl.cfg.rank == 0:
                 print(f"bench.py: the records' path failed at run time; all ranks now on: {degraded[-1]}", file=sys.stderr)

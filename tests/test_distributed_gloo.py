@@ -174,3 +174,66 @@ def test_bench_ranks_agree_on_a_failed_records_path_and_step_down_together(tmp_p
         z = np.load(tmp_path / f"agree{r}.npz")
         assert bool(z["raised"]) and int(z["degraded"]) == 1 and str(z["path"]) == "host" and bool(z["noted"])
         assert float(z["el"]) > 0
+
+
+class _DivergingPlanner(_StandInPlanner):
+    """Nothing raises, but while the path is "ipc" one rank's refit comes out different (a stale record): the checksum of
+    mean | std that rides in the block's all-reduce is what notices."""
+
+    def __init__(self, rank, diverge_rank):
+        super().__init__(rank, fail_rank=-1, fail_from=1 << 30)
+        self.diverge_rank = diverge_rank
+        self.mean = torch.zeros(30, 6)
+        self.std = torch.full((30, 6), 0.5)
+
+    def plan_step_resident(self):
+        self.calls += 1
+        self.mean = torch.full((30, 6), 0.001 * self.calls)
+        if self.path == "ipc" and self.cfg.rank == self.diverge_rank:
+            self.mean[3, 2] += 1e-7
+
+    def degrade_exchange(self):
+        self.calls = 0
+        return super().degrade_exchange()
+
+
+def _checksum_worker(rank, world, port, out_dir):
+    import importlib.util
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+        pl = _DivergingPlanner(rank, diverge_rank=1)
+        raised = False
+        try:
+            bench.timed_steps(pl, 6, 5, world, {})
+        except bench.RecordsPathFailed:
+            raised = True
+        pl2 = _DivergingPlanner(rank, diverge_rank=1)
+        spread = {}
+        el = bench.timed_with_fallback(pl2, 6, 5, world, spread)
+        same = _DivergingPlanner(rank, diverge_rank=-1)   # ranks that agree: no failure, the field says so
+        spread_ok = {}
+        bench.timed_with_fallback(same, 6, 5, world, spread_ok)
+        np.savez(os.path.join(out_dir, f"sum{rank}.npz"), raised=raised, path=pl2.path, el=el,
+                 noted=spread.get("records_path_degraded_to", []) == ["host"], disagreed=spread.get("blocks_the_ranks_disagreed_after", 0),
+                 agree=bool(spread.get("ranks_agree_after_every_block")), clean=bool(spread_ok.get("ranks_agree_after_every_block")) and
+                 "records_path_degraded_to" not in spread_ok and same.path == "ipc")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_notices_ranks_whose_distributions_differ_and_steps_down(tmp_path):
+    """Records that arrive stale or torn on one rank raise nothing: the block's all-reduce also carries a checksum of every
+    rank's mean | std (bench.distribution_checksum); ranks that differ end the block like a failed path -- all step down, the
+    measurement starts over, the line says how often (`timed_region.blocks_the_ranks_disagreed_after`)."""
+    port = _free_port()
+    mp.spawn(_checksum_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        z = np.load(tmp_path / f"sum{r}.npz")
+        assert bool(z["raised"]) and str(z["path"]) == "host" and bool(z["noted"]) and int(z["disagreed"]) == 1
+        assert bool(z["agree"]) and bool(z["clean"]) and float(z["el"]) > 0
