@@ -533,9 +533,16 @@ class IcemPlanner:
                 blob = (C.c_ubyte * L.RCCL_ID_BYTES).from_buffer_copy(ident[0])
                 with torch.cuda.device(self.device):   # ncclCommInitRank binds the CURRENT device: the planner's, not torch's default
                     L.check(self.lib.icem_rccl_connect(self._h, blob))
-                    # ... and one real all-gather of the (zeroed) record buffer
+                    # ... and one real all-gather, checked: every rank's K record slots marked with its number
+                    K, r = self.K, self.cfg.rank
+                    self.records.zero_()
+                    self.records[r * K:(r + 1) * K] = float(r + 1)
                     L.check(self.lib.icem_allgather_elites(self._h, _ptr(self.records), self._stream()))
-                    torch.cuda.current_stream(self.device).synchronize()
+                    torch.cuda.synchronize(self.device)
+                    want = torch.arange(1, self.cfg.world + 1, device=self.device, dtype=self.dt).repeat_interleave(K)
+                    if not bool((self.records == want[:, None]).all().item()):
+                        raise RuntimeError("the in-library all-gather returned other ranks' records in the wrong slots or not at all")
+                    self.records.zero_()
             except (L.IcemError, RuntimeError) as e:
                 err = e
             dist.all_gather_object(oks, err is None, group=group)
