@@ -712,6 +712,12 @@ def self_launch(n):
         sys.exit(rc)
 
 
+def dtype_name(tile_arith):
+    """The arithmetic the path computes in, by name: storage is f32 everywhere; the model step of the
+    tile kernels runs either as an exact f32 fmaf chain or on two fp16 planes per operand with f32 accumulation."""
+    return "f32 storage; model step 2xfp16 planes (3 products), f32 accumulate" if tile_arith else "f32"
+
+
 def main():
     if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-numpy-child":   # children of extra_cpu_baselines
         return numpy_baseline_child(sys.argv[2], float(sys.argv[3]))
@@ -776,6 +782,9 @@ def main():
     if world > 1:
         dist.barrier()
     build = dict(B.build_info(), rebuilt_in_this_run=bool(stale_before))
+    # development options: the library reads no environment variable; this tool maps ICEM_<NAME> onto icem_set_option
+    from icem_amd import _lib as _L
+    build["options_from_environment"] = _L.apply_env_options()
 
     w = WORKLOADS[args.workload]
     if args.workload == "c5":
@@ -821,7 +830,7 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "launched_by": os.environ.get("ICEM_BENCH_LAUNCHER", "torch.distributed.run" if world > 1 else "direct"),
             "rendezvous_backend": backend, "ranks_share_a_gpu": shared_gpu,
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": dtype_name(tile_arith), "data": "synthetic",
             "config": {"workload": w["name"], "per_gpu_population": w["N"], "global_population": w["N"] * world,
                        "traj_per_mpc_step": per_step_trajsteps // w["h"],
                        "model": "o' = tanh(o.A + a.B) dense (synthetic)" if model.kind == 1 else "o' = o.A + a.B dense linear (synthetic)",

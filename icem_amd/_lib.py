@@ -19,9 +19,9 @@ MODEL_LINEAR, MODEL_TANH = 0, 1
 
 KERNEL_NAMES = ["sample_clip", "rollout_cost", "topk_partial", "local_pack", "merge_refit", "sample_rollout"]
 
-ICEM_E_INVALID, ICEM_E_UNSUPPORTED, ICEM_E_HIP, ICEM_E_NO_DEVICE, ICEM_E_STATE = -1, -2, -3, -4, -5
+ICEM_E_INVALID, ICEM_E_UNSUPPORTED, ICEM_E_HIP, ICEM_E_NO_DEVICE, ICEM_E_STATE, ICEM_E_RANGE = -1, -2, -3, -4, -5, -6
 ERR_NAMES = {-1: "ICEM_E_INVALID", -2: "ICEM_E_UNSUPPORTED", -3: "ICEM_E_HIP", -4: "ICEM_E_NO_DEVICE",
-             -5: "ICEM_E_STATE"}
+             -5: "ICEM_E_STATE", -6: "ICEM_E_RANGE"}
 
 
 class IcemError(RuntimeError):
@@ -137,12 +137,18 @@ SYMBOLS = [
     ("icem_set_tile_arith", C.c_int, [_H, _I32]),
     ("icem_tile_arith", C.c_int, [_H]),
     ("icem_profile_overhead", C.c_int, [_VP, _I32, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("icem_tile_growth", C.c_double, [_H]),
+    ("icem_nonfinite_costs", C.c_int, [_H, C.POINTER(C.c_int64), _VP]),
+    ("icem_set_option", C.c_int, [C.c_char_p, C.c_double]),
+    ("icem_get_option", C.c_int, [C.c_char_p, C.POINTER(C.c_double)]),
+    ("icem_reset_options", C.c_int, []),
+    ("icem_option_name", C.c_char_p, [_I32]),
 ]
 
 
 IPC_HANDLE_BYTES = 64
 RCCL_ID_BYTES = 128
-ABI_VERSION = 4   # include/icem_hip.h: ICEM_ABI_VERSION
+ABI_VERSION = 5   # include/icem_hip.h: ICEM_ABI_VERSION
 
 
 def lib_path() -> str:
@@ -168,6 +174,75 @@ def load_library() -> C.CDLL:
         raise ImportError(f"{path}: ABI version {lib.icem_abi_version()} != {ABI_VERSION}: rebuild (python -m icem_amd.build)")
     _LIB = lib
     return lib
+
+
+# ---- development options (include/icem_hip.h: icem_set_option; icem_amd/csrc/options.h) ----------------------------------
+def option_names():
+    lib = load_library()
+    out, i = [], 0
+    while True:
+        n = lib.icem_option_name(i)
+        if n is None:
+            return out
+        out.append(n.decode())
+        i += 1
+
+
+def set_option(name: str, value: float):
+    check(load_library().icem_set_option(name.encode(), float(value)))
+
+
+def get_option(name: str) -> float:
+    v = C.c_double()
+    check(load_library().icem_get_option(name.encode(), C.byref(v)))
+    return v.value
+
+
+def reset_options():
+    check(load_library().icem_reset_options())
+
+
+# spellings the environment variables of rounds 3-5 used for options that are numbers now
+_ENV_WORDS = {"thread": 0.0, "rows": 1.0}
+
+
+def apply_env_options(environ=None) -> dict:
+    """Map ``ICEM_<NAME>`` environment variables onto the library's options -- for TOOLS (bench.py, tools/, test child
+    processes), called explicitly: neither the library nor ``load_library()`` reads the environment.  Returns what was
+    set.  (``ICEM_GK_ROLLOUT=thread`` is option ``gk_rollout_thread`` = 1, ``ICEM_GK_SAMPLE=thread`` is ``gk_sample`` = 0.)"""
+    environ = os.environ if environ is None else environ
+    done = {}
+    for name in option_names():
+        key = "ICEM_" + name.upper()
+        if key in environ and environ[key] != "":
+            raw = environ[key]
+            val = _ENV_WORDS[raw] if raw in _ENV_WORDS else float(raw)
+            set_option(name, val)
+            done[name] = val
+    if environ.get("ICEM_GK_ROLLOUT", "") == "thread":
+        set_option("gk_rollout_thread", 1.0)
+        done["gk_rollout_thread"] = 1.0
+    return done
+
+
+_FOLLOW_ENV = False
+
+
+def follow_environment(on: bool = True):
+    """TOOLS ONLY (tools/, the soaks): from now on every new ``IcemPlanner`` / learned-dynamics model first resets the
+    options and applies the ``ICEM_<NAME>`` variables of the moment (:func:`apply_env_options`) -- the scripts of rounds 3-5
+    flip ``os.environ`` between planners.  Off by default: product code never looks at the environment."""
+    global _FOLLOW_ENV
+    _FOLLOW_ENV = bool(on)
+    if on:
+        reset_options()
+        apply_env_options()
+
+
+def maybe_follow_environment():
+    if _FOLLOW_ENV:
+        reset_options()
+        apply_env_options()
 
 
 def check(rc: int):

@@ -19,6 +19,10 @@ UNITS = ["generic_kernels.hip", "plan.hip", "abi.hip", "exchange.hip", "k_sample
          "k_iter_small.hip", "icem_rssm.hip", "icem_rssm_split.hip", "k_rollout_wide.hip", "collective.hip", "k_rollout_ahead.hip",
          "k_rollout_wide_split.hip", "k_rollout_hn.hip"]
 OUT = os.path.join(HERE, "libicem_hip.so")
+# the same objects with exchange.hip compiled under -DICEM_FAULT_INJECTION (ICEM_XCHG_FAIL drills: tests/test_gpu_exchange_faults.py
+# loads it through ICEM_HIP_LIB); the product library carries no fault injection
+OUT_FAULTS = os.path.join(HERE, "libicem_hip_faults.so")
+FAULT_UNIT = "exchange.hip"
 MARK = b"ICEM_BUILD_HASH="  # abi.hip embeds MARK + the 16 hex digits of source_hash()
 OBJ = os.path.join(CSRC, "_obj")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function"]
@@ -82,15 +86,18 @@ def up_to_date() -> bool:
     return not build_info()["stale"]
 
 
-def _compile(unit, headers_digest, verbose):
+def _compile(unit, headers_digest, verbose, faults=False):
     src = os.path.join(CSRC, unit)
     extra = [f'-DICEM_BUILD_HASH="{source_hash()}"'] if unit == "abi.hip" else []  # the marker lives in one object
+    if faults:
+        extra.append("-DICEM_FAULT_INJECTION")
     cmd = [_hipcc(), *FLAGS, *UNIT_FLAGS.get(unit, []), *extra, "-I", CSRC, "-c", src]
     key = _digest([src], " ".join(cmd[1:-1]) + headers_digest)
-    obj = os.path.join(OBJ, f"{os.path.splitext(unit)[0]}.{key}.o")
+    stem = os.path.splitext(unit)[0] + ("_faults" if faults else "")
+    obj = os.path.join(OBJ, f"{stem}.{key}.o")
     if not os.path.exists(obj):
         for f in os.listdir(OBJ):  # drop older objects of this unit
-            if f.startswith(os.path.splitext(unit)[0] + ".") and f.endswith(".o"):
+            if f.startswith(stem + ".") and f.endswith(".o"):
                 os.remove(os.path.join(OBJ, f))
         if verbose:
             print(" ".join(cmd + ["-o", obj]), flush=True)
@@ -100,7 +107,7 @@ def _compile(unit, headers_digest, verbose):
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and up_to_date():
+    if not force and up_to_date() and embedded_hash(OUT_FAULTS) == source_hash():
         return OUT
     os.makedirs(OBJ, exist_ok=True)
     if force:
@@ -108,11 +115,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
             os.remove(os.path.join(OBJ, f))
     hd = _digest(_headers())
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        fut_faults = ex.submit(_compile, FAULT_UNIT, hd, verbose, True)
         objs = list(ex.map(lambda u: _compile(u, hd, verbose), _units()))
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", OUT]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+        obj_faults = fut_faults.result()
+    objs_f = [obj_faults if os.path.basename(o).startswith(os.path.splitext(FAULT_UNIT)[0] + ".") else o for o in objs]
+    for out, oo in ((OUT, objs), (OUT_FAULTS, objs_f)):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *oo, "-ldl", "-o", out]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     if embedded_hash() != source_hash():
         raise RuntimeError("libicem_hip.so does not carry the hash of the sources it was just built from")
     return OUT

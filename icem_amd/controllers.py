@@ -274,6 +274,23 @@ class MpcController(ModelBasedController, StatefulController, ABC):
     def end_of_rollout(self, total_time, total_return, mode):
         pass
 
+    # -- compute_new_mean (icem.py:168-171, 191-192; mpc.py:241-243, 265-269) ---------------------------------------
+    def _new_mean_is_overridden(self, base) -> bool:
+        return getattr(type(self), "compute_new_mean", None) is not getattr(base, "compute_new_mean", None)
+
+    def _last_predicted_observation(self, obs, best_actions: np.ndarray) -> np.ndarray:
+        """``simulated_paths[best_traj_idx]["observations"][-1]`` (icem.py:170, mpc.py:242): the observation in front of the
+        best trajectory's last action.  The N rollouts of the step are never materialised: this one row is re-rolled on
+        demand -- only when a subclass overrides ``compute_new_mean``."""
+        acts = np.asarray(best_actions, dtype=np.float64)[None]
+        if self.device_path:
+            p = self.planner
+            _, o = p.rollout_cost(np.asarray(obs, dtype=np.float64), torch.as_tensor(acts, dtype=p.dt, device=p.device),
+                                  return_observations=True)
+            return o.detach().cpu().numpy().astype(np.float64)[0, -1]
+        batch = self.simulate_trajectories(obs=obs, state=self.forward_model_state, action_sequences=acts)
+        return np.asarray(batch.as_array("observations"), dtype=np.float64)[0, -1]
+
     def _bind_models(self, world=1):
         """Which rollout path this controller's model allows: built-in device model + parametric cost (HIP rollout),
         a device torch model, or any host model through the reference's ``predict_n_steps`` interface."""
@@ -542,6 +559,13 @@ class MpcICemHip(MpcController):
             executed_action, self.last_min_cost = host[:-1], float(host[-1])
         else:
             executed_action = self._get_action_stagewise(obs, noise)
+        if self._new_mean_is_overridden(MpcICemHip):
+            # icem.py:168-171: the device epilogue has shifted the mean and KEPT its last row (the default
+            # compute_new_mean); a subclass decides that row from the best trajectory's last predicted observation
+            best = self.elite_samples.as_array("actions")[0]
+            new_last = np.asarray(self.compute_new_mean(obs=self._last_predicted_observation(obs, best)), dtype=np.float64)
+            p = self.planner
+            p.mean[-1].copy_(torch.as_tensor(new_last.reshape(p.d), dtype=p.dt, device=p.device))
         self.logger.log(self.last_min_cost, key="Expected_trajectory_cost")
         if self.do_visualize_plan:  # icem.py:180-183
             bt = self.best_trajectory(obs)
@@ -550,6 +574,13 @@ class MpcICemHip(MpcController):
             _, self.forward_model_state, _ = self.forward_model.predict(
                 observations=obs, states=self.forward_model_state, actions=executed_action)
         return executed_action
+
+    def compute_new_mean(self, obs):
+        """icem.py:191-192: the last row of the shifted mean (``obs``: the best trajectory's last predicted observation).
+        The default keeps the last row -- which is what the device epilogue (``icem_shift``) computes, so nothing is
+        fetched; a subclass that overrides this is called once per ``get_action`` with that observation (re-rolled on
+        demand) and its row is written into the device-resident mean."""
+        return self.mean[-1]
 
     def _print_iteration(self, it):
         """The reference's verbose line (icem.py:151-158) from the device buffers of iteration ``it``: costs of the simulated
@@ -699,6 +730,10 @@ class MpcCemStdHip(MpcController):
         return TrajectoryBatch(actions=self._elite_actions.detach().cpu().numpy().astype(np.float64),
                                costs=self._elite_costs.detach().cpu().numpy().astype(np.float64))
 
+    def compute_new_mean(self, obs):
+        """mpc.py:265-269: zeros under ``like_levine``, else the (already shifted) mean's last row."""
+        return self.mean[-1] * 0 if self.like_levine else self.mean[-1]
+
     def _reset_std(self):  # get_init_std(True), mpc.py:180-185, then _update_bounds
         p = self.planner
         scratch = torch.empty_like(self._mean)
@@ -754,10 +789,14 @@ class MpcCemStdHip(MpcController):
             executed_action = self._elite_actions[0, 0].cpu().numpy().astype(np.float64)
         else:
             executed_action = self._mean[0].cpu().numpy().astype(np.float64)
-        if self.shift_means:                                               # mpc.py:236-241
+        if self.shift_means:                                               # mpc.py:236-243
             last = torch.zeros_like(self._mean[-1]) if self.like_levine else self._mean[-1].clone()
             self._mean[:-1] = self._mean[1:].clone()
-            self._mean[-1] = last
+            self._mean[-1] = last                                          # the default compute_new_mean (mpc.py:265-269)
+            if self._new_mean_is_overridden(MpcCemStdHip):
+                best = self._elite_actions[0].detach().cpu().numpy().astype(np.float64)
+                new_last = np.asarray(self.compute_new_mean(obs=self._last_predicted_observation(obs, best)), dtype=np.float64)
+                self._mean[-1].copy_(torch.as_tensor(new_last.reshape(p.d), dtype=p.dt, device=p.device))
         else:
             self._mean.zero_()
         self._reset_std()                                                  # mpc.py:244-245

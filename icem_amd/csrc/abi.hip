@@ -73,6 +73,57 @@ int upload(void** dev, const std::vector<double>& host) {
     return ICEM_OK;
 }
 
+// ---- development options: one process-wide table (options.h) -----------------------------------------------------------
+struct OptRow {
+    const char* name;
+    double def;
+};
+const OptRow OPT_ROWS[OPT_COUNT] = {
+#define X(id, name, def) {name, def},
+    ICEM_OPTIONS(X)
+#undef X
+};
+std::atomic<double> g_opt[OPT_COUNT] = {
+#define X(id, name, def) {def},
+    ICEM_OPTIONS(X)
+#undef X
+};
+
+// Worst case, over every start observation with |entries| <= m and every action sequence with |entries| <= m, of
+// |state entry| / m inside `horizon` steps of the LINEAR model x' = x A + a B (A [o, o], B [d, o], row vectors):
+//   x_t = x_0 A^t + sum_{s < t} a_s B A^(t-1-s)   =>   |x_t[j]| <= m (sum_k |A^t[k][j]| + sum_{s < t} sum_k |(B A^s)[k][j]|),
+// attained for every (t, j) by a sign pattern of x_0 and bang-bang actions: the bound is the reachable maximum, not an
+// estimate.  What the fp16-plane tiles need to know: their operands are x S with S m in [16, 32), fp16 ends at 65 504.
+double linear_growth_bound(int o, int d, int horizon, const std::vector<double>& A, const std::vector<double>& B) {
+    std::vector<double> P((size_t)o * o, 0.0), Q((size_t)d * o), T2, colB(o, 0.0);
+    for (int k = 0; k < o; ++k) P[(size_t)k * o + k] = 1.0;
+    Q.assign(B.begin(), B.begin() + (size_t)d * o);
+    double worst = 1.0;
+    auto times_A = [&](std::vector<double>& M, int rows) {
+        T2.assign((size_t)rows * o, 0.0);
+        for (int r = 0; r < rows; ++r)
+            for (int k = 0; k < o; ++k) {
+                const double v = M[(size_t)r * o + k];
+                if (v == 0.0) continue;
+                for (int j = 0; j < o; ++j) T2[(size_t)r * o + j] += v * A[(size_t)k * o + j];
+            }
+        M.swap(T2);
+    };
+    for (int t = 1; t <= horizon; ++t) {
+        for (int j = 0; j < o; ++j)
+            for (int k = 0; k < d; ++k) colB[j] += std::fabs(Q[(size_t)k * o + j]);   // += |B A^(t-1)| column sums
+        times_A(P, o);   // A^t
+        times_A(Q, d);   // B A^t
+        for (int j = 0; j < o; ++j) {
+            double g = colB[j];
+            for (int k = 0; k < o; ++k) g += std::fabs(P[(size_t)k * o + j]);
+            if (!(g < 1e300)) return INFINITY;
+            worst = std::max(worst, g);
+        }
+    }
+    return worst;
+}
+
 int pick_O(int o) {
     const int sizes[] = {8, 16, 17, 18, 24, 32};
     for (int s : sizes)
@@ -81,6 +132,32 @@ int pick_O(int o) {
 }
 
 }  // namespace
+
+namespace icem {
+double opt(Opt k) { return g_opt[k].load(std::memory_order_relaxed); }
+
+// fp16-plane tile arithmetic: the launch's scale needs the action bounds' magnitude -- fetched once per (low, high) buffer
+// pair (check_plan) and again at every icem_reset_distribution (where a caller may have rewritten the bounds in place)
+int refresh_act_mag(icem_handle* h, const void* low, const void* high, hipStream_t st, bool force) {
+    if (h->cfg.dtype != ICEM_F32 || !low || !high) return ICEM_OK;
+    if (!force && h->am_lo == low && h->am_hi == high) return ICEM_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return fail(ICEM_E_STATE, "the action bounds are fetched at the first call with a (low, high) buffer pair: make one call outside the "
+                                  "stream capture first");
+    const int d = h->cfg.act_dim;
+    std::vector<float> lo(d), hi(d);
+    ICEM_HIP_TRY(hipMemcpyAsync(lo.data(), low, d * sizeof(float), hipMemcpyDeviceToHost, st));
+    ICEM_HIP_TRY(hipMemcpyAsync(hi.data(), high, d * sizeof(float), hipMemcpyDeviceToHost, st));
+    ICEM_HIP_TRY(hipStreamSynchronize(st));
+    float m = 0.f;
+    for (int j = 0; j < d; ++j) m = std::max(m, std::max(std::fabs(lo[j]), std::fabs(hi[j])));
+    h->act_mag = (m == m && m < 1e30f) ? m : 1.f;
+    h->am_lo = low;
+    h->am_hi = high;
+    return ICEM_OK;
+}
+}  // namespace icem
 
 // what icem_profile_overhead times: one wave that spins for `ticks` of the 100 MHz wall clock and reports how long it
 // really ran (a kernel of KNOWN duration; an empty one would overstate the bracket: the command processor sets up the
@@ -149,7 +226,7 @@ int icem_create(const icem_config* cfg, icem_handle** out) {
     // the population can GROW after iteration 0 when N < 2*elites_size (icem.py:127 floors N_i at 2*elites_size)
     h->n_local_max = 0;
     for (int n_it : h->pop) h->n_local_max = std::max(h->n_local_max, shard_chunk(n_it, c.world));
-    if (const char* e = getenv("ICEM_DISABLE_FAST")) h->use_fast = !(e[0] == '1');
+    h->use_fast = opt_i(OPT_DISABLE_FAST) == 0;
     // synthesis table W[t][m]: m < F real part of bin m, F <= m < h imaginary part of bin m-F+1
     // noise_beta <= 0 is the reference's white branch (np.random.randn(N, h, d), icem.py:77): draw t of a row is
     // its sample at step t, i.e. the identity table
@@ -163,7 +240,12 @@ int icem_create(const icem_config* cfg, icem_handle** out) {
         for (int t = 0; t < c.horizon; ++t) W[(size_t)t * h->HMAX + t] = 1.0;
     }
     int rc = c.dtype == ICEM_F64 ? upload<double>(&h->W_dev, W) : upload<float>(&h->W_dev, W);
+    if (!rc && (hipMalloc((void**)&h->nonfinite_dev, 2 * sizeof(unsigned)) != hipSuccess ||
+                hipMemset(h->nonfinite_dev, 0, 2 * sizeof(unsigned)) != hipSuccess))
+        rc = fail(ICEM_E_HIP, "hipMalloc of the handle's status word failed");
     if (rc) {
+        if (h->W_dev) (void)hipFree(h->W_dev);
+        if (h->nonfinite_dev) (void)hipFree(h->nonfinite_dev);
         delete h;
         return rc;
     }
@@ -177,6 +259,7 @@ int icem_destroy(icem_handle* h) {
     rccl_release(h);
     ahead_destroy(h);
     if (h->W_dev) (void)hipFree(h->W_dev);
+    if (h->nonfinite_dev) (void)hipFree(h->nonfinite_dev);
     if (h->actions_alt) (void)hipFree(h->actions_alt);
     if (h->host_stage) (void)hipHostFree(h->host_stage);
     if (h->ws_alt) (void)hipFree(h->ws_alt);
@@ -240,9 +323,31 @@ static void update_paths(icem_handle* h) {
     bool finite = true;
     h->tile_m_scale = lift(h->A_host, &finite);
     h->tile_b_scale = lift(h->B_host, &finite);
-    split_ok = split_ok && finite;
-    static const int env_mode = [] { const char* e = getenv("ICEM_TILE_ARITH"); return e ? atoi(e) : -1; }();
-    const int mode = h->tile_arith_mode >= 0 ? h->tile_arith_mode : env_mode;
+    // ... and the planes are served only where the model cannot take a state out of fp16's range, whatever the actions: the
+    // operands are x S with S max(|obs0|, action bound) in [16, 32), so a state may grow to 2^11 times that magnitude before
+    // f16(x S) is infinite -- and an infinite operand is a NaN cost where the reference ranks a finite one (icem.py:147-159,
+    // 199).  linear_growth_bound is the REACHABLE maximum over the horizon (a tanh model's state is bounded by 1); beyond
+    // 2^10 (a factor of two in hand) the handle computes on the exact tile.  The action operand a S sM / sB overflows where
+    // B's largest entry is more than 2^10 x A's (a small B only costs ABSOLUTE accuracy, 2^-28 of the state's scale).
+    const bool narrow_f32 = !h->wide && h->has_model && h->cfg.dtype == ICEM_F32 && finite;
+    const bool hn_shape = h->has_model && h->cfg.dtype == ICEM_F32 && finite && h->obs_dim <= 48;
+    h->tile_growth = 1.0;
+    h->tile_ratio_log2 = 0;
+    if ((narrow_f32 || hn_shape) && !h->A_host.empty()) {
+        if (h->model_kind == ICEM_MODEL_LINEAR)
+            h->tile_growth = linear_growth_bound(h->obs_dim, h->cfg.act_dim, h->cfg.horizon, h->A_host, h->B_host);
+        int ea = 0, eb = 0;
+        (void)std::frexp((double)h->tile_m_scale, &ea);   // scale = 2^(7 - e_max): log2(sM / sB) = e_max(B) - e_max(A)
+        (void)std::frexp((double)h->tile_b_scale, &eb);
+        double bmax = 0.0;
+        for (double v : h->B_host) bmax = std::max(bmax, std::fabs(v));
+        h->tile_ratio_log2 = bmax > 1e-30 ? ea - eb : 0;   // (a model without actions: nothing to scale)
+    }
+    const bool range_ok = finite && h->tile_growth <= 1024.0 && h->tile_ratio_log2 <= 10;
+    split_ok = split_ok && range_ok;
+    // (the arithmetic is the HANDLE's: no environment variable takes part -- the ranks of a sharded run are separate
+    //  processes and must agree on it from the configuration alone)
+    const int mode = h->tile_arith_mode;
     // by configuration (AUTO): the planes wherever they are served.  (ABI 3 kept populations of at most 8192 rows on the exact
     // tile's VALU twin, four waves per tile, on the argument that a lone wave's MFMA chain is the longer latency chain; measured
     // -- EXPERIMENTS R5.5 -- one Tile16H wave per tile is the SHORTER chain: 66.7 -> 61.9 us per MPC step at N = 4096, 84.1 ->
@@ -264,7 +369,10 @@ static void update_paths(icem_handle* h) {
             else terms_ok = false;
         }
     int prog[3] = {0, 0, 0};
-    const bool hn = of == 0 && h->has_model && h->has_cost && h->cfg.dtype == ICEM_F32 && finite && mode != 0 && terms_ok &&
+    // (o = 39 is a WIDE observation: a caller that asked for the exact arithmetic there -- icem_set_wide_arith(ICEM_WIDE_F32),
+    //  icem_set_wide_exact(1) -- gets the exact-f32 GEMM kernel, like one that passed ICEM_TILE_F32)
+    const bool hn = of == 0 && h->has_model && h->has_cost && h->cfg.dtype == ICEM_F32 && range_ok && mode != 0 && terms_ok &&
+                    !(h->wide && h->wide_mode == ICEM_WIDE_F32) &&
                     hn_cost_program(n32, n4, np, prog) &&
                     hn_rollout_supported(h->cfg.horizon, h->cfg.act_dim, h->obs_dim, h->cfg.num_elites);
     for (int k = 0; k < 3; ++k) h->hn_prog[k] = hn ? prog[k] : 0;
@@ -297,6 +405,49 @@ int icem_set_tile_arith(icem_handle* h, int32_t mode) {
 }
 
 int icem_tile_arith(const icem_handle* h) { return h ? ((h->tile_arith || h->hn_tile) ? 1 : 0) : 0; }
+
+double icem_tile_growth(const icem_handle* h) { return h ? h->tile_growth : 0.0; }
+
+int icem_set_option(const char* name, double value) {
+    if (!name || !(value == value)) return fail(ICEM_E_INVALID, "null option name / NaN value");
+    for (int k = 0; k < OPT_COUNT; ++k)
+        if (std::strcmp(name, OPT_ROWS[k].name) == 0) {
+            g_opt[k].store(value, std::memory_order_relaxed);
+            return ICEM_OK;
+        }
+    return fail(ICEM_E_INVALID, std::string("unknown option: ") + name);
+}
+
+int icem_get_option(const char* name, double* value_out) {
+    if (!name || !value_out) return fail(ICEM_E_INVALID, "null argument");
+    for (int k = 0; k < OPT_COUNT; ++k)
+        if (std::strcmp(name, OPT_ROWS[k].name) == 0) {
+            *value_out = g_opt[k].load(std::memory_order_relaxed);
+            return ICEM_OK;
+        }
+    return fail(ICEM_E_INVALID, std::string("unknown option: ") + name);
+}
+
+int icem_reset_options(void) {
+    for (int k = 0; k < OPT_COUNT; ++k) g_opt[k].store(OPT_ROWS[k].def, std::memory_order_relaxed);
+    return ICEM_OK;
+}
+
+const char* icem_option_name(int32_t index) { return (index >= 0 && index < OPT_COUNT) ? OPT_ROWS[index].name : nullptr; }
+
+int icem_nonfinite_costs(icem_handle* h, int64_t* count_out, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (!count_out) return fail(ICEM_E_INVALID, "null output");
+    hipStream_t st = (hipStream_t)stream;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return fail(ICEM_E_STATE, "icem_nonfinite_costs synchronises: not on a capturing stream");
+    unsigned v = 0;
+    ICEM_HIP_TRY(hipMemcpyAsync(&v, h->nonfinite_dev, sizeof(v), hipMemcpyDeviceToHost, st));
+    ICEM_HIP_TRY(hipStreamSynchronize(st));
+    *count_out = (int64_t)v;
+    return ICEM_OK;
+}
 
 int icem_set_model(icem_handle* h, int32_t kind, int32_t obs_dim, const double* A_host, const double* B_host) {
     if (!h || !A_host || !B_host) return fail(ICEM_E_INVALID, "null argument");
@@ -552,6 +703,10 @@ int icem_reset_distribution(icem_handle* h, void* mean, void* std, const void* l
     // the large-population path keeps a host copy of the action bounds per (low, high) buffer pair: an episode start is
     // where a caller may have rewritten them in place, so the copy is fetched again at the next step
     h->ahead.lo_ptr = h->ahead.hi_ptr = nullptr;
+    if (h->tile_arith || h->hn_tile) {   // ... and so does the fp16-plane tiles' scale (FastRolloutArgs::act_mag)
+        const int rc = refresh_act_mag(h, low, high, st, true);
+        if (rc) return rc;
+    }
     return gk_reset(h, mean, std, low, high, st);
 }
 
@@ -575,7 +730,8 @@ int icem_set_wide_arith(icem_handle* h, int32_t mode) {
     return ICEM_OK;
 }
 
-int icem_wide_arith(const icem_handle* h) { return h ? h->wide_eff : 0; }
+// (a TileHN handle -- Door / Relocate at o = 39 -- launches the fp16 planes of icem_set_tile_arith, whatever wide_eff says)
+int icem_wide_arith(const icem_handle* h) { return h ? (h->hn_tile ? ICEM_WIDE_F16X2 : h->wide_eff) : 0; }
 
 int icem_wide_imbalance_log2(const icem_handle* h) { return h ? h->wide_imbalance : 0; }
 

@@ -50,7 +50,6 @@ int rccl_bind(const char* path_or_null) {
     tries.push_back({"librccl.so.1", RTLD_NOW | RTLD_NOLOAD});  // the copy this process already carries (torch's)
     tries.push_back({"librccl.so", RTLD_NOW | RTLD_NOLOAD});
     if (path_or_null && *path_or_null) tries.push_back({path_or_null, RTLD_NOW | RTLD_GLOBAL});
-    if (const char* e = getenv("ICEM_RCCL_LIB")) tries.push_back({e, RTLD_NOW | RTLD_GLOBAL});
     tries.push_back({"librccl.so.1", RTLD_NOW | RTLD_GLOBAL});
     tries.push_back({"/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL});
     std::string errs;

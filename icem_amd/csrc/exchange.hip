@@ -58,6 +58,13 @@ struct Exchange {
 
 static void parse_fault(Exchange* x, int rank, int world) {
     x->fail_mode = 0;
+#ifndef ICEM_FAULT_INJECTION
+    // the product library carries no fault injection: libicem_hip_faults.so (icem_amd/build.py: this unit compiled with
+    // -DICEM_FAULT_INJECTION, everything else the same objects) is what tests/test_gpu_exchange_faults.py loads
+    (void)rank;
+    (void)world;
+    return;
+#else
     const char* e = getenv("ICEM_XCHG_FAIL");
     if (!e || !*e) return;
     std::string s(e);
@@ -73,6 +80,7 @@ static void parse_fault(Exchange* x, int rank, int world) {
     if (who != rank) return;
     x->fail_mode = mode == "connect" ? 1 : mode == "selftest" ? 2 : mode == "timeout" ? 3 : 0;
     x->fail_after = after;
+#endif
 }
 
 namespace {
@@ -316,10 +324,9 @@ int icem_exchange_connect(icem_handle* h, const void* handles_host, void* const*
     if (check_handle(h)) return ICEM_E_INVALID;
     Exchange* x = h->xchg;
     if (!x) return fail(ICEM_E_STATE, "icem_exchange_create must be called first");
-    // ICEM_XCHG_LOOPBACK=1 (tools/sharded_rank_bench.py): time ONE rank of a sharded run without its peers -- every
+    // option xchg_loopback = 1 (tools/sharded_rank_bench.py): time ONE rank of a sharded run without its peers -- every
     // push lands in this rank's own block and the merges wait for this rank's flag only
-    const char* lb = getenv("ICEM_XCHG_LOOPBACK");
-    x->loopback = lb && atoi(lb) != 0 && h->cfg.rank == 0;
+    x->loopback = opt_i(OPT_XCHG_LOOPBACK) != 0 && h->cfg.rank == 0;
     if (!handles_host && !local_blocks && !x->loopback) return fail(ICEM_E_INVALID, "neither IPC handles nor local block pointers");
     if (x->fail_mode == 1) return fail(ICEM_E_HIP, "injected fault (ICEM_XCHG_FAIL=connect): mapping the peers' exchange blocks failed on this rank");
     const int world = h->cfg.world, rank = h->cfg.rank;
@@ -344,7 +351,7 @@ int icem_exchange_connect(icem_handle* h, const void* handles_host, void* const*
     }
     if (!x->peers_dev) ICEM_HIP_TRY(hipMalloc((void**)&x->peers_dev, (size_t)XCHG_MAX_WORLD * sizeof(unsigned char*)));
     ICEM_HIP_TRY(hipMemcpy(x->peers_dev, x->peers.data(), (size_t)world * sizeof(unsigned char*), hipMemcpyHostToDevice));
-    if (const char* e = getenv("ICEM_XCHG_MAX_POLLS")) x->max_polls = (unsigned)std::max(1, atoi(e));
+    if (opt(OPT_XCHG_MAX_POLLS) >= 1.0) x->max_polls = (unsigned)opt(OPT_XCHG_MAX_POLLS);
     x->connected = true;
     return ICEM_OK;
 }

@@ -1644,6 +1644,12 @@ __device__ __forceinline__ void sample_into_tile_quad(const FastSampleArgs& sa, 
     }
 }
 
+// A trajectory whose cost came out NaN (a state left the arithmetic's range, or the inputs were not finite): ranked last by
+// its key as always -- and counted in the handle's status word (icem_nonfinite_costs; icem_get_action reports it)
+__device__ __forceinline__ void note_nonfinite(const FastRolloutArgs& a, float cost, bool stored) {
+    if (stored && cost != cost) atomicAdd(a.nonfinite, 1u);
+}
+
 // One wave rolls its 16 trajectories of the slab out of the LDS tile, stores the costs and folds them into its
 // running candidate list.
 template <typename Tile, int H, int D>
@@ -1656,6 +1662,7 @@ __device__ __forceinline__ unsigned long long rollout_slab(Tile& tile, const Fas
     for (int t = 0; t < H; ++t) tile.step(st, rd0 + t * D);
     const float cost = tile.cost(st);
     if (live && lane < 16) ra.costs[row] = cost;
+    note_nonfinite(ra, cost, live && lane < 16);
     if (ra.K > 0) {
         const unsigned long long key = (lane < 16 && live && row < ra.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
         run_key = topk_push16(run_key, key, first, ra.K, lane);
@@ -1734,6 +1741,7 @@ struct StreamT {
         }
         const float cost = tile.cost(st);
         if (live && lane < 16) a.costs[row] = cost;
+        note_nonfinite(a, cost, live && lane < 16);
         if (a.K > 0) {
             const unsigned long long key = (lane < 16 && live && row < a.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
             run_key = topk_push16(run_key, key, first, a.K, lane);
@@ -1809,6 +1817,7 @@ struct StreamT {
         }
         const float cost = tile.cost(st);
         if (live && lane < 16) a.costs[row] = cost;
+        note_nonfinite(a, cost, live && lane < 16);
         if (a.K > 0) {
             const unsigned long long key = (lane < 16 && live && row < a.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
             run_key = topk_push16(run_key, key, first, a.K, lane);

@@ -1273,10 +1273,9 @@ int launch_sample(const icem_handle* h, const SampleArgs<T>& a_in, hipStream_t s
     if (a_in.n <= 0) return ICEM_OK;
     SampleArgs<T> a = a_in;
     // four lanes per row where the population leaves the chip mostly empty (the one-thread-per-row form's 256 rows per
-    // workgroup are then a few long chains per CU); ICEM_GK_SAMPLE=thread: never (A/B, tests; read per call)
-    const char* env_s = getenv("ICEM_GK_SAMPLE");
+    // workgroup are then a few long chains per CU); option gk_sample = 0: never (A/B, tests; read per call)
     // (decided from the handle's GLOBAL population, never from a call's or a shard's row count: one summation order per handle)
-    const bool quad = !(env_s && env_s[0] == 't') && a.d <= WG / 4 && (long long)h->cfg.num_traj * a.d <= 262144;
+    const bool quad = opt_i(OPT_GK_SAMPLE) != 0 && a.d <= WG / 4 && (long long)h->cfg.num_traj * a.d <= 262144;
     if (quad) a.tpw = std::max(1, (WG / 4) / a.d);
     const int grid = (a.n + a.tpw - 1) / a.tpw;
     size_t lds = (size_t)a.tpw * a.h * a.d * sizeof(T);
@@ -1317,8 +1316,7 @@ template <typename T, int KIND>
 int launch_rollout_k(const icem_handle* h, const RolloutArgs<T>& a, hipStream_t st) {
     const int grid = (a.n + WG - 1) / WG;
     ProfScope prof(h, ICEM_K_ROLLOUT, (long long)a.n * a.h, st);
-    const char* env_form = getenv("ICEM_GK_ROLLOUT");   // read per call: the path-equivalence test flips it between planners
-    const bool thread_form = env_form && env_form[0] == 't';
+    const bool thread_form = opt_i(OPT_GK_ROLLOUT_THREAD) != 0;   // read per call: the path-equivalence test flips it between planners
     if (!thread_form && !a.cs.ext) {   // a trajectory's row of lanes (rollout_cost_rows_kernel); term lists: the thread form
         switch (h->O) {
 #define ICEM_CASE(OV)                                                                                                          \
@@ -1702,8 +1700,7 @@ static void merge_refit_t(const icem_handle* h, const MergeArgsV& v, hipStream_t
 // threshold -- K threads of each of the workgroup's waves hold ALL their keys at or below it -- must fit the candidate
 // array; beyond that size the three-launch path runs.
 bool gk_select_ok(const icem_handle* h, int n_cand, int n_keep, int K) {
-    const char* env_sel = getenv("ICEM_GK_SELECT");     // read per call (path-equivalence test)
-    const bool off = env_sel && env_sel[0] == '0';
+    const bool off = opt_i(OPT_GK_SELECT) == 0;     // read per call (path-equivalence test)
     if (off || h->cfg.world != 1 || K < 1 || K > ICEM_MAX_ELITES) return false;
     const long long per_thread = ((long long)n_cand + n_keep + SELECT_NT - 1) / SELECT_NT;
     return (long long)(SELECT_NT / 64) * K * per_thread <= SELECT_CAP;

@@ -22,6 +22,7 @@
 
 #include "../../include/icem_hip.h"
 #include "icem_fused.h"
+#include "options.h"
 
 namespace icem {
 
@@ -106,8 +107,15 @@ struct icem_handle {
     bool hn_tile = false;        // the f32 rollout is k_rollout_hn.hip's TileHN kernel (Door / Relocate / FetchPickAndPlace shapes; fp16 planes)
     float tile_m_scale = 1.f, tile_b_scale = 1.f;   // FastRolloutArgs::m_scale / b_scale (update_paths)
     float act_mag = 1.f;         // max(|low|, |high|) of the action bounds last seen (FastRolloutArgs::act_mag), from ...
-    const void* am_lo = nullptr; // ... this (low, high) buffer pair
+    const void* am_lo = nullptr; // ... this (low, high) buffer pair (refreshed by icem_reset_distribution and the plan calls)
     const void* am_hi = nullptr;
+    // fp16-plane tiles (Tile16H / TileHN): served only where no state can leave fp16's range inside the horizon
+    double tile_growth = 1.0;    // worst case of |state entry| / max(|obs0|, action bound) over the horizon (update_paths; 1 for tanh)
+    int tile_ratio_log2 = 0;     // log2(largest |B entry| / largest |A entry|) (the action operand's scale relative to the state's)
+    // trajectories whose cost left a tile kernel non-finite (FastRolloutArgs::nonfinite): a device word, and the value
+    // icem_get_action saw at its last call
+    unsigned* nonfinite_dev = nullptr;
+    unsigned nonfinite_seen = 0;
     void* Mw_dev = nullptr;      // its packed model
     void* Mws_dev = nullptr;     // ... as three bf16 planes (k_rollout_wide_split.hip) ...
     void* Mwh_dev = nullptr;     // ... and as two fp16 planes of the model x 2^k, Mwh_inv = 2^-k: the default wide rollout
@@ -312,6 +320,7 @@ bool fast_sample_ok(const icem_handle* h);
 int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const void* obs0, const void* actions,
                         void* costs, float* part_c, int* part_i, hipStream_t st, int* lists_out,
                         unsigned long long* part_k = nullptr, int n_tail = 0, int* tail_out = nullptr);
+int refresh_act_mag(icem_handle* h, const void* low, const void* high, hipStream_t st, bool force);   // abi.hip
 void ahead_destroy(icem_handle* h);
 void predraw_next_step(icem_handle* h, const icem_plan_buffers* b, int mpc_step, hipStream_t st);
 int launch_fast_sample(const icem_handle* h, int n, long long first_index, const void* mean, const void* std,

@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <vector>
 #include "cost_args.h"
+#include "options.h"
 
 namespace icem {
 
@@ -82,6 +83,7 @@ struct FastRolloutArgs {
     int arith = 0;
     float act_mag = 1.f;   // arith 1: magnitude of the action bounds, max(|low|, |high|) -- with |obs0| it fixes the launch's scale
     float m_scale = 1.f, b_scale = 1.f;   // arith 1: powers of two that put the largest |entry| of A / of B into [64, 128)
+    unsigned* nonfinite = nullptr;        // counts the trajectories whose cost came out NaN (icem_nonfinite_costs); never NULL in a launch
 };
 bool fast_rollout_supported(int h, int d, int O, int K);
 void launch_rollout16(const FastRolloutArgs& a, int h, int d, int O, int kind, hipStream_t st);

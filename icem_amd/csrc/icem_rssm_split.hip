@@ -650,10 +650,9 @@ void rssm_split_trim() {
 }
 
 bool rssm_split_ok(int n, int horizon) {
-    static const bool on = [] { const char* e = std::getenv("ICEM_RSSM_SPLIT"); return !(e && e[0] == '0'); }();
-    static const int max_tiles = [] {   // (development: ICEM_RSSM_SPLIT_MAX_N moves the population limit)
-        const char* e = std::getenv("ICEM_RSSM_SPLIT_MAX_N");
-        const int v = e ? std::atoi(e) / 16 : rssm::SPLIT_MAX_TILES;
+    const bool on = icem::opt_i(icem::OPT_RSSM_SPLIT) != 0;
+    const int max_tiles = [] {   // (development: option rssm_split_max_n moves the population limit)
+        const int v = icem::opt_i(icem::OPT_RSSM_SPLIT_MAX_N) / 16;
         return v < 1 ? 1 : v > rssm::SPLIT_TILE_LIMIT ? rssm::SPLIT_TILE_LIMIT : v;
     }();
     return on && n > 0 && horizon >= 1 && (n + 15) / 16 <= max_tiles;
@@ -715,8 +714,9 @@ hipError_t launch_rssm_split(int n, int horizon, int cost_mode, const unsigned s
     const Staging& sg = s;
     // Up to 256 tiles: one tile per recurrence workgroup and one reward workgroup per tile (up to 128 tiles both kinds are
     // resident together).  Beyond: two tiles per recurrence workgroup (they share every weight chunk) and 512 reward
-    // workgroups that walk the tiles behind them.  (ICEM_RSSM_SPLIT_TT = 1 | 2 overrides the tiles per workgroup.)
-    static const int tt_env = [] { const char* e = std::getenv("ICEM_RSSM_SPLIT_TT"); return e && (e[0] == '1' || e[0] == '2') ? e[0] - '0' : 0; }();
+    // workgroups that walk the tiles behind them.  (option rssm_split_tt = 1 | 2 overrides the tiles per workgroup.)
+    const int tt_opt = icem::opt_i(icem::OPT_RSSM_SPLIT_TT);
+    const int tt_env = (tt_opt == 1 || tt_opt == 2) ? tt_opt : 0;
     const int tt = tt_env ? tt_env : (tiles > rssm::SPLIT_TT1_TILES ? 2 : 1);
     const int heads = tiles > rssm::SPLIT_TT1_TILES ? std::min(tiles, 512) : tiles;
     if (tt == 2) {

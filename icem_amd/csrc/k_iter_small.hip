@@ -280,6 +280,7 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
             const bool live = row < n_rows;
             if ((lane & 15) == 0) {
                 if (live) ra.costs[row] = cost;
+                note_nonfinite(ra, cost, live);
                 // TPB <= 32 keys; two-tile slabs (counted, below): a row that is no candidate leaves a filler -- (+inf, INT_MAX - 511
                 // + rs), all different, behind every real key (wg_merge_emit's)
                 wg_keys[0][0][rs] = (live && row < ra.n_cand) ? make_key(cost, row)
@@ -364,8 +365,7 @@ constexpr int single_launch_max_rw(int h, int d) {
 // workgroup on half the CUs (N = 4 096: 15.5 instead of 12.5 us).
 static bool sample_rollout_shape(int h, int d, int O, int rounds, int n_rows, int n_tail, int* grid_out, int* rw_out,
                                  int* tail_out = nullptr) {
-    const char* env_rw = getenv("ICEM_FUSE_MAX_RW");  // read per call: the path-equivalence test flips it between planners
-    const int max_rw = env_rw ? atoi(env_rw) : 8;
+    const int max_rw = opt_i(OPT_FUSE_MAX_RW);  // read per call: the path-equivalence test flips it between planners
     int grid, rw, tail = 0;
     r16_shape(n_rows, &grid, &rw);
     if (n_tail > 0 && n_tail <= 64) {
@@ -398,13 +398,13 @@ int sample_rollout_lists(int h, int d, int O, int rounds, int n_rows, int n_tail
 // merge prologue: the selection wavefront joins the sampling waves (8 rollout waves: 13 waves share the register
 // file, the selection runs in its low-register form)
 bool sample_rollout_merge_ok(int h, int d, int O, int rounds, int n_rows, int K) {
-    static const int on = [] { const char* e = getenv("ICEM_MERGE_PROLOGUE"); return e ? atoi(e) : 1; }();
+    const int on = opt_i(OPT_MERGE_PROLOGUE);
     int grid, rw;
     return on && K + 1 <= 12 && sample_rollout_shape(h, d, O, rounds, n_rows, 0, &grid, &rw);
 }
 
 bool sample_rollout_pack_ok(int h, int d, int O, int rounds, int n_rows, int K) {
-    static const int on = [] { const char* e = getenv("ICEM_RIDING_PACK"); return e ? atoi(e) : 1; }();
+    const int on = opt_i(OPT_RIDING_PACK);
     int grid, rw;
     return on && sample_rollout_merge_ok(h, d, O, rounds, n_rows, K) && sample_rollout_shape(h, d, O, rounds, n_rows, 0, &grid, &rw) &&
            K * (h * d + 2) <= 16 * rw * h * d;

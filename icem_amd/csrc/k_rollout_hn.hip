@@ -468,6 +468,7 @@ __global__ __launch_bounds__(128 * PAIRS) void rollout_hn_pair_kernel(HnArgs a) 
         if (!model) {
             const float cost = tile.cost(st);
             if (live && lane < 16) a.r.costs[row] = cost;
+            note_nonfinite(a.r, cost, live && lane < 16);
             if (a.r.K > 0) {
                 const unsigned long long key = (lane < 16 && live && row < a.r.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
                 run_key = topk_push16(run_key, key, first, a.r.K, lane);
@@ -754,6 +755,7 @@ void rollout_hn_split_kernel(HnArgs a) {
         if (cost_a) {
             const float cost = tile.cost(st);
             if (live && lane < 16) a.r.costs[row] = cost;
+            note_nonfinite(a.r, cost, live && lane < 16);
             if (a.r.K > 0) {
                 const unsigned long long key = (lane < 16 && live && row < a.r.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
                 run_key = topk_push16(run_key, key, first, a.r.K, lane);
@@ -786,22 +788,19 @@ bool hn_rollout_supported(int h, int d, int o, int K) {
     return false;
 }
 
-// the two-wave-per-tile form: populations of at most HN_PAIR_MAX_TILES tiles (ICEM_HN_PAIR=0: never -- A/B, tests; read per call)
+// the two-wave-per-tile form: populations of at most HN_PAIR_MAX_TILES tiles (option hn_pair = 0: never -- A/B, tests; read per call)
 static bool hn_pair_shape(int n_rows, int* grid, int* pairs) {
-    const char* e = getenv("ICEM_HN_PAIR");
     const int tiles = std::max(1, (n_rows + 15) / 16);
-    if ((e && e[0] == '0') || tiles > HN_PAIR_MAX_TILES) return false;
+    if (!opt_i(OPT_HN_PAIR) || tiles > HN_PAIR_MAX_TILES) return false;
     *pairs = tiles > FAST_MAX_LISTS ? 2 : 1;
     *grid = std::min(FAST_MAX_LISTS, (tiles + *pairs - 1) / *pairs);
     return true;
 }
 
-// the split form (NT model waves + a cost wave per tile): at most HN_SPLIT_MAX_TILES tiles (ICEM_HN_SPLIT=0: never)
+// the split form (NT model waves + a cost wave per tile): at most HN_SPLIT_MAX_TILES tiles (option hn_split = 0: never)
 static bool hn_split_shape(int n_rows, int* grid) {
-    const char* e = getenv("ICEM_HN_SPLIT");
-    const char* e2 = getenv("ICEM_HN_PAIR");
     const int tiles = std::max(1, (n_rows + 15) / 16);
-    if ((e && e[0] == '0') || (e2 && e2[0] == '0') || tiles > HN_SPLIT_MAX_TILES) return false;
+    if (!opt_i(OPT_HN_SPLIT) || !opt_i(OPT_HN_PAIR) || tiles > HN_SPLIT_MAX_TILES) return false;
     *grid = std::min(FAST_MAX_LISTS, tiles);
     return true;
 }

@@ -303,12 +303,12 @@ bool fast_sample_supported(int h, int d) {
 
 // sampler with the previous iteration's merge in its prologue (default generator only, K <= 11, no shifted elites)
 bool sample_folded_merge_ok(int h, int d, int rounds, int K) {
-    static const int on = [] { const char* e = getenv("ICEM_MERGE_PROLOGUE"); return e ? atoi(e) : 1; }();
+    const int on = opt_i(OPT_MERGE_PROLOGUE);
     return on && rounds == 10 && K + 1 <= 12 && fast_sample_supported(h, d);
 }
 
 bool sample_folded_pack_ok(int h, int d, int rounds, int K) {
-    static const int on = [] { const char* e = getenv("ICEM_RIDING_PACK"); return e ? atoi(e) : 1; }();
+    const int on = opt_i(OPT_RIDING_PACK);
     const int tpw = SWG / d;
     return on && sample_folded_merge_ok(h, d, rounds, K) && K * (h * d + 2) <= (2 + tpw) * h * d;
 }
@@ -335,7 +335,7 @@ void launch_noise_rows(const FastSampleArgs& a, int rounds, hipStream_t st) {
     const int grid = (a.n + tpw - 1) / tpw;
     // The LDS request also bounds how many of these workgroups a CU takes (the tile is 30 KB at d = 6: five would fit and
     // leave a rollout workgroup of the noise-ahead pipeline -- 37 KB -- no room): at least 40.5 KB, i.e. three per CU.
-    static const size_t min_lds = [] { const char* e = getenv("ICEM_AHEAD_NOISE_LDS_KB"); return (size_t)((e ? atof(e) : 40.5) * 1024.0); }();
+    const size_t min_lds = (size_t)((opt(OPT_AHEAD_NOISE_LDS_KB) >= 0.0 ? opt(OPT_AHEAD_NOISE_LDS_KB) : 40.5) * 1024.0);   // (option ahead_noise_lds_kb: development)
     const size_t lds = std::max((size_t)tpw * a.h * a.d * sizeof(float), min_lds);
 #define XS(HH, DD, OO)                                                                                \
     if (a.h == HH && a.d == DD && rounds == 10) {                                                     \

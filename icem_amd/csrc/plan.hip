@@ -9,11 +9,12 @@
 using namespace icem;
 
 // icem_get_action: executed action + best cost -> the host-mapped block, then the sequence flag (system scope)
-__global__ void publish_result_kernel(const float* executed, const float* best_cost, int d, float* host_out, unsigned* flag,
-                                      unsigned seq) {
+__global__ void publish_result_kernel(const float* executed, const float* best_cost, const unsigned* nonfinite, int d, float* host_out,
+                                      unsigned* flag, unsigned seq) {
     const int j = threadIdx.x;
     if (j < d) host_out[j] = executed[j];
     if (j == d) host_out[d] = best_cost[0];
+    if (j == d + 1) reinterpret_cast<unsigned*>(host_out)[d + 1] = nonfinite[0];   // the handle's status word (icem_nonfinite_costs)
     __threadfence_system();
     __syncthreads();
     if (j == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -167,6 +168,7 @@ FastRolloutArgs fast_rollout_args(const icem_handle* h, int n_rows, int n_cand, 
     a.act_mag = h->act_mag;
     a.m_scale = h->tile_m_scale;
     a.b_scale = h->tile_b_scale;
+    a.nonfinite = h->nonfinite_dev;
     return a;
 }
 
@@ -517,7 +519,7 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                     if (ride) {
                         sm.p = h->pk_args;
                         // published merge: workgroup 0 merges the records once and publishes mean | std to the rest
-                        static const int pub_on = [] { const char* e = getenv("ICEM_PUBLISHED_MERGE"); return e ? atoi(e) : 1; }();
+                        const int pub_on = opt_i(OPT_PUBLISHED_MERGE);
                         if (pub_on && sm.m.records) {
                             if (!h->pub_dev) {
                                 ICEM_HIP_TRY(hipMalloc((void**)&h->pub_dev, ((size_t)2 * hd + 16) * sizeof(float)));
@@ -579,7 +581,7 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                 // conditions as icem_plan_iter_merge's fold) and that launch is a single-launch kernel, the pack rides
                 // there too, as its workgroup 0.  Stashed; the next icem_plan_iter_local consumes it (or launches it).
                 // (the step's LAST pack: stashed for the merge that waits for its records -- pack_merge_kernel, one launch)
-                static const int fuse_last = [] { const char* e = getenv("ICEM_PACK_MERGE"); return e ? atoi(e) : 1; }();
+                const int fuse_last = opt_i(OPT_PACK_MERGE);
                 const bool rides_next = !last && it + 1 < c.opt_iters;
                 if (fold_push && xchg_concurrent_peers(h) && h->deferral && (rides_next || (last && fuse_last)) && lists > 0 && c.world * K <= 128 && K <= 32) {
                     const int n_next = rides_next ? local_rows(h, it + 1) : 0;
@@ -762,7 +764,7 @@ int plan_iter_merge_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
                 return ICEM_OK;
             }
             m.last = a.last;
-            static const int fuse_on = [] { const char* e = getenv("ICEM_PACK_MERGE"); return e ? atoi(e) : 1; }();
+            const int fuse_on = opt_i(OPT_PACK_MERGE);
             if (h->pk_pending && fuse_on && m.records != nullptr && xchg_connected(h)) {
                 // the merge runs now, and so must the pack whose records it waits for: ONE launch for the two
                 const PackPrev& pp = h->pk_args;
@@ -836,22 +838,21 @@ static bool ahead_eligible(icem_handle* h, const icem_plan_buffers* b, bool shar
     const icem_config& c = h->cfg;
     if (A.disabled < 0) {
         // on by default where it applies (measured 1.09-1.21x the sampler + rollout pair from N = 32 768 to 262 144;
-        // ICEM_NOISE_AHEAD=0 switches it off -- the equivalence test and tools/ahead_bench.py flip it per handle)
-        const char* e = getenv("ICEM_NOISE_AHEAD");
-        A.disabled = (e && atoi(e) == 0) ? 1 : 0;
-        const char* m = getenv("ICEM_NOISE_AHEAD_MIN_ROWS");
-        A.min_rows = m ? atoi(m) : 0;
+        // option noise_ahead = 0 switches it off -- latched per handle at its first step: the equivalence test and
+        // tools/ahead_bench.py flip it between planners)
+        A.disabled = opt_i(OPT_NOISE_AHEAD) == 0 ? 1 : 0;
+        A.min_rows = opt_i(OPT_NOISE_AHEAD_MIN_ROWS);
     }
     if (A.disabled || (c.world != 1) != sharded || c.dtype != ICEM_F32 || b->z_r != nullptr || !h->use_fast || gemm_rollout(h) ||
         c.opt_iters < 2 || c.rng_rounds != 10)
         return false;
-    static const int stamps_on = [] { const char* e = getenv("ICEM_AHEAD_STAMPS"); return e ? atoi(e) : 0; }();
-    if (h->dbg != nullptr && !stamps_on) return false;   // (another kernel is under study; ICEM_AHEAD_STAMPS=1: this path's phase stamps)
+    const int stamps_on = opt_i(OPT_AHEAD_STAMPS);
+    if (h->dbg != nullptr && !stamps_on) return false;   // (another kernel is under study; option ahead_stamps = 1: this path's phase stamps)
     if (!fast_rollout_ok(h, c.num_elites) || !fast_sample_ok(h)) return false;
     if (sharded) {
         // peers in processes of their own (the pack rides in the next launch), records that fit the pack's LDS stage and
         // the records merge's two-per-lane layout, the published merge switched on
-        static const int on = [] { const char* e = getenv("ICEM_NOISE_AHEAD_SHARDED"); return e ? atoi(e) : 1; }();
+        const int on = opt_i(OPT_NOISE_AHEAD_SHARDED);
         if (!on || !xchg_connected(h) || !xchg_concurrent_peers(h) || !pack_can_push(c.num_elites, c.horizon, c.act_dim) ||
             c.world * c.num_elites > 128 || c.num_elites > 32)
             return false;
@@ -955,7 +956,7 @@ static int plan_step_ahead(icem_handle* h, const icem_plan_buffers* b, int mpc_s
             // leaves 255 of the 256 CUs idle (ICEM_AHEAD_TAIL_FRAC: share of the rows that goes there)
             void* np = A.pool[(A.ctr + (unsigned)(iters - 1)) % 3];
             const uint64_t off0 = (h->episode << 32) + (uint64_t)(mpc_step + 1) * (uint64_t)(iters + 1);
-            static const double tail_frac = [] { const char* e = getenv("ICEM_AHEAD_TAIL_FRAC"); return e ? atof(e) : 0.6; }();
+            const double tail_frac = opt(OPT_AHEAD_TAIL_FRAC);
             int n_tail = (int)(tail_frac * h->pop[0]);
             n_tail = std::max(0, std::min(h->pop[0], n_tail));
             const int n_here = h->pop[0] - n_tail;
@@ -968,7 +969,7 @@ static int plan_step_ahead(icem_handle* h, const icem_plan_buffers* b, int mpc_s
                 A.tail_args.first_index = n_here;
                 // ... and the head of the next step's iteration-1 noise, into the pool that step will find at pool_of(1)
                 // (this step's iteration-2 pool: its last reader was iteration 3's prologue) -- ICEM_AHEAD_NEXT1_FRAC of it
-                static const double frac1 = [] { const char* e = getenv("ICEM_AHEAD_NEXT1_FRAC"); return e ? atof(e) : 0.3; }();
+                const double frac1 = opt(OPT_AHEAD_NEXT1_FRAC);
                 const int n1 = iters > 2 ? std::max(0, std::min(h->pop[1], (int)(frac1 * h->pop[1]))) : 0;
                 if (n1 > 0) {
                     void* np1 = A.pool[(A.ctr + (unsigned)(iters - 1) + 1u) % 3];
@@ -1207,7 +1208,7 @@ static int plan_step_sharded_ahead(icem_handle* h, const icem_plan_buffers* b, i
 void predraw_next_step(icem_handle* h, const icem_plan_buffers* b, int mpc_step, hipStream_t st) {
     icem_handle::Ahead& A = h->ahead;
     const icem_config& c = h->cfg;
-    static const int on = [] { const char* e = getenv("ICEM_PREDRAW"); return e ? atoi(e) : 1; }();
+    const int on = opt_i(OPT_PREDRAW);
     A.pre_valid = false;
     if (!on || c.world != 1 || c.dtype != ICEM_F32 || b->z_r != nullptr || !h->use_fast || gemm_rollout(h) || c.rng_rounds != 10 ||
         h->dbg != nullptr || h->fast_lists <= 0 || c.num_elites + 1 > 12 || !fast_rollout_ok(h, c.num_elites) || !fast_sample_ok(h))
@@ -1271,7 +1272,7 @@ size_t icem_plan_buffer_bytes(const icem_handle* h, int32_t which) {
     }
 }
 
-static int check_plan(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, int32_t it) {
+static int check_plan(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, int32_t it, hipStream_t st = nullptr) {
     if (check_handle(h)) return ICEM_E_INVALID;
     if (!b) return fail(ICEM_E_INVALID, "null buffers");
     if (!h->has_model || !h->has_cost) return fail(ICEM_E_STATE, "icem_set_model / icem_set_cost must be called first");
@@ -1285,17 +1286,8 @@ static int check_plan(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_st
         ((b->z_r == nullptr) != (b->z_i == nullptr) || (b->z_r_shift == nullptr) != (b->z_i_shift == nullptr)))
         return fail(ICEM_E_INVALID, "z_r/z_i must be given in pairs");
     // fp16-plane tile arithmetic: the launch's scale needs the action bounds' magnitude -- fetched once per (low, high) pair
-    if ((h->tile_arith || h->hn_tile) && (h->am_lo != b->low || h->am_hi != b->high)) {
-        const int d = h->cfg.act_dim;
-        std::vector<float> lo(d), hi(d);
-        ICEM_HIP_TRY(hipMemcpy(lo.data(), b->low, d * sizeof(float), hipMemcpyDeviceToHost));
-        ICEM_HIP_TRY(hipMemcpy(hi.data(), b->high, d * sizeof(float), hipMemcpyDeviceToHost));
-        float m = 0.f;
-        for (int j = 0; j < d; ++j) m = std::max(m, std::max(std::fabs(lo[j]), std::fabs(hi[j])));
-        h->act_mag = (m == m && m < 1e30f) ? m : 1.f;
-        h->am_lo = b->low;
-        h->am_hi = b->high;
-    }
+    // (and at every icem_reset_distribution: abi.hip::refresh_act_mag)
+    if (h->tile_arith || h->hn_tile) return refresh_act_mag(h, b->low, b->high, st, false);
     return ICEM_OK;
 }
 
@@ -1317,7 +1309,7 @@ int icem_set_merge_deferral(icem_handle* h, int32_t on) {
 }
 
 int icem_plan_iter_local(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, int32_t it, void* stream) {
-    int rc = check_plan(h, b, mpc_step, it);
+    int rc = check_plan(h, b, mpc_step, it, (hipStream_t)stream);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     icem_plan_buffers bb = *b;
@@ -1333,7 +1325,7 @@ int icem_plan_iter_local(icem_handle* h, const icem_plan_buffers* b, int32_t mpc
 }
 
 int icem_plan_iter_merge(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, int32_t it, void* stream) {
-    int rc = check_plan(h, b, mpc_step, it);
+    int rc = check_plan(h, b, mpc_step, it, (hipStream_t)stream);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (!deferral_active(h, b) || !h->cur_mean)
@@ -1396,7 +1388,7 @@ static int plan_step_sharded_body(icem_handle* h, const icem_plan_buffers* b, in
     if (xchg_status_peek(h) & 1u)
         return fail(ICEM_E_STATE, "in-library exchange: a wait for a peer's elite records timed out in an earlier MPC step "
                                   "(icem_exchange_status reads and clears the word); the plans since then are not valid");
-    if (b && check_plan(h, b, mpc_step, 0) == ICEM_OK && !h->pm_pending && !h->pk_pending && ahead_eligible(h, b, true))
+    if (b && check_plan(h, b, mpc_step, 0, (hipStream_t)stream) == ICEM_OK && !h->pm_pending && !h->pk_pending && ahead_eligible(h, b, true))
         return plan_step_sharded_ahead(h, b, mpc_step, (hipStream_t)stream);
     const bool was = h->deferral;
     h->deferral = true;  // non-last merges ride in the next local launch
@@ -1418,7 +1410,7 @@ int icem_plan_step_sharded(icem_handle* h, const icem_plan_buffers* b, int32_t m
 
 static int plan_step_body(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, void* stream) {
     if (h->cfg.world != 1) return fail(ICEM_E_INVALID, "icem_plan_step is the world == 1 path; use iter_local/iter_merge");
-    int rc = check_plan(h, b, mpc_step, 0);
+    int rc = check_plan(h, b, mpc_step, 0, (hipStream_t)stream);
     if (rc) return rc;
     const icem_config& c = h->cfg;
     const int iters = c.opt_iters;
@@ -1522,8 +1514,8 @@ int icem_get_action(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step
         // (publishing from inside the last merge kernel instead was tried: no faster than this one-wave launch)
         const unsigned seq = ++h->io_seq;
         unsigned char* dev = (unsigned char*)h->host_stage_dev;
-        hipLaunchKernelGGL(publish_result_kernel, dim3(1), dim3(64), 0, st, (const float*)b->executed, (const float*)b->best_cost, d,
-                           (float*)(dev + OUT_OFF), (unsigned*)(dev + FLAG_OFF), seq);
+        hipLaunchKernelGGL(publish_result_kernel, dim3(1), dim3(128), 0, st, (const float*)b->executed, (const float*)b->best_cost,
+                           (const unsigned*)h->nonfinite_dev, d, (float*)(dev + OUT_OFF), (unsigned*)(dev + FLAG_OFF), seq);
         ICEM_HIP_TRY(hipGetLastError());
         long long spins = 0;
         while (*flag != seq) {
@@ -1537,12 +1529,28 @@ int icem_get_action(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step
     } else {
         ICEM_HIP_TRY(hipMemcpyAsync(out, b->executed, d * ts, hipMemcpyDeviceToHost, st));
         ICEM_HIP_TRY(hipMemcpyAsync(out + (size_t)d * ts, b->best_cost, ts, hipMemcpyDeviceToHost, st));
+        ICEM_HIP_TRY(hipMemcpyAsync(out + (size_t)(d + 1) * ts, h->nonfinite_dev, sizeof(unsigned), hipMemcpyDeviceToHost, st));
         ICEM_HIP_TRY(hipStreamSynchronize(st));
     }
+    unsigned nonfinite_now = 0;
+    std::memcpy(&nonfinite_now, out + (size_t)(d + 1) * ts, sizeof(unsigned));
     for (int j = 0; j <= d; ++j) {
         const double v = h->cfg.dtype == ICEM_F64 ? ((const double*)out)[j] : (double)((const float*)out)[j];
         if (j < d) action_host[j] = v;
         else if (best_cost_host) *best_cost_host = v;
+    }
+    // Trajectories of THIS step whose cost left a tile kernel non-finite although the observation was finite: a state left
+    // the arithmetic's range (f32's, or -- actions outside the bounds the scale was taken from -- the fp16 planes'), where
+    // the reference's float64 ranks a finite cost (icem.py:147-159, 199).  The action is returned, and so is the fact.
+    const unsigned fresh = nonfinite_now - h->nonfinite_seen;
+    h->nonfinite_seen = nonfinite_now;
+    if (fresh != 0) {
+        bool obs_finite = true;
+        for (int k = 0; k < o; ++k) obs_finite = obs_finite && std::isfinite(obs_host[k]);
+        if (obs_finite)
+            return fail(ICEM_E_RANGE, std::to_string(fresh) + " trajectories of this MPC step came back with a non-finite cost from a finite "
+                        "observation: a state left the range of the rollout's arithmetic (icem_tile_arith / icem_tile_growth); the "
+                        "reference's float64 ranks finite costs there -- use ICEM_TILE_F32 / dtype f64 for this model");
     }
     return ICEM_OK;
 }

@@ -2,6 +2,7 @@
 // bf16 packing, the A-operand requests, the 16x16x32 MFMA chains, the LDS bias table.
 #pragma once
 #include "icem_rssm.h"
+#include "options.h"
 
 namespace icem {
 namespace rssm_dev {

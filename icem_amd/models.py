@@ -318,6 +318,7 @@ class DeviceRSSMModel(ForwardModel):
         self.device = torch.device(device)
         self.params = pack_rssm(self.reference).to(self.device)
         self.lib = L.load_library()
+        L.maybe_follow_environment()   # (tools only: icem_amd._lib.follow_environment)
         self._obs_host = self._obs_dev = None
         if self.params.numel() != self.lib.icem_rssm_param_elems():
             raise RuntimeError("packed RSSM parameters do not match the library's layout")

@@ -79,6 +79,7 @@ class IcemPlanner:
 
     def __init__(self, cfg: IcemConfig, low, high, device="cuda:0", process_group=None):
         self.lib = L.load_library()
+        L.maybe_follow_environment()   # (tools only: icem_amd._lib.follow_environment)
         if not torch.cuda.is_available():
             raise RuntimeError("icem_amd needs a HIP device (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
@@ -90,6 +91,8 @@ class IcemPlanner:
         self._h = C.c_void_p()
         ccfg = cfg.to_c()
         L.check(self.lib.icem_create(C.byref(ccfg), C.byref(self._h)))
+        if L._FOLLOW_ENV and os.environ.get("ICEM_TILE_ARITH", "") != "":   # (tools only; the arithmetic is the HANDLE's)
+            L.check(self.lib.icem_set_tile_arith(self._h, int(os.environ["ICEM_TILE_ARITH"])))
         self.h, self.d, self.K = cfg.horizon, cfg.act_dim, cfg.num_elites
         self.F = self.h // 2 + 1
         self.low = torch.as_tensor(np.asarray(low, dtype=np.float64), dtype=self.dt, device=self.device).contiguous()
@@ -341,6 +344,19 @@ class IcemPlanner:
     def tile_arith(self):
         return int(self.lib.icem_tile_arith(self._h))
 
+    @property
+    def tile_growth(self) -> float:
+        """Reachable maximum of |state entry| / max(|obs0|, action bound) over the horizon for the handle's model
+        (``icem_tile_growth``): what decides whether the fp16-plane tiles are served (<= 2^10)."""
+        return float(self.lib.icem_tile_growth(self._h))
+
+    def nonfinite_costs(self) -> int:
+        """Trajectories since the planner was made whose cost left a tile kernel NaN (``icem_nonfinite_costs``;
+        synchronises the launch stream)."""
+        n = C.c_int64()
+        L.check(self.lib.icem_nonfinite_costs(self._h, C.byref(n), self._stream()))
+        return int(n.value)
+
     WIDE_ARITH = {"auto": -1, "f16x2": 0, "fp16x2": 0, "f32": 1, "bf16x3": 2}
 
     def set_wide_arith(self, mode="auto"):
@@ -397,9 +413,11 @@ class IcemPlanner:
             raise ValueError(f"expected an observation of shape ({self.obs_dim},)")
         act = np.empty(self.d, dtype=np.float64)
         best = C.c_double()
-        L.check(self.lib.icem_get_action(self._h, C.byref(self._cb), self.mpc_step, ob.ctypes.data_as(C.POINTER(C.c_double)),
-                                         act.ctypes.data_as(C.POINTER(C.c_double)), C.byref(best), self._stream()))
-        self.mpc_step += 1
+        rc = self.lib.icem_get_action(self._h, C.byref(self._cb), self.mpc_step, ob.ctypes.data_as(C.POINTER(C.c_double)),
+                                      act.ctypes.data_as(C.POINTER(C.c_double)), C.byref(best), self._stream())
+        if rc in (0, L.ICEM_E_RANGE):
+            self.mpc_step += 1   # (ICEM_E_RANGE: the step ran and its outputs are filled -- but they are not the reference's)
+        L.check(rc)
         return act, best.value
 
     def plan_step_resident(self):
@@ -518,7 +536,9 @@ class IcemPlanner:
             return False
         try:
             # bind the copy of RCCL this process already carries (torch's), else torch's file, else the system's
-            L.check(self.lib.icem_rccl_load(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so").encode()))
+            # (ICEM_RCCL_LIB names another one: read HERE, in the tooling -- the library reads no environment variable)
+            L.check(self.lib.icem_rccl_load((os.environ.get("ICEM_RCCL_LIB") or
+                                             os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")).encode()))
             if self.cfg.rank == 0:
                 buf = (C.c_ubyte * L.RCCL_ID_BYTES)()
                 L.check(self.lib.icem_rccl_unique_id(buf))

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ICEM_ABI_VERSION 4 /* 2: icem_build_hash, icem_allgather_elites / icem_rccl_*, noise-ahead planning; ICEM_MAX_OBS_DIM 384; 3: icem_set_tile_arith; 4: icem_set_wide_arith (default AUTO), ICEM_TILE_AUTO = planes at every population */
+#define ICEM_ABI_VERSION 5 /* 5: ICEM_TILE_AUTO serves the fp16 planes only where no state can leave their range (icem_tile_growth), icem_nonfinite_costs / ICEM_E_RANGE, icem_set_option (the library reads no environment variable), icem_plan_step_batch; 2: icem_build_hash, icem_allgather_elites / icem_rccl_*, noise-ahead planning; ICEM_MAX_OBS_DIM 384; 3: icem_set_tile_arith; 4: icem_set_wide_arith (default AUTO), ICEM_TILE_AUTO = planes at every population */
 
 enum { ICEM_F32 = 0, ICEM_F64 = 1 };
 enum { ICEM_COST_SUM = 0, ICEM_COST_BEST = 1, ICEM_COST_FINAL = 2 }; /* abstract_controller.py:82-87 */
@@ -43,7 +43,9 @@ enum {
     ICEM_E_UNSUPPORTED = -2,  /* shape outside the compiled kernels (NotImplementedError)          */
     ICEM_E_HIP = -3,          /* a HIP runtime call failed                                         */
     ICEM_E_NO_DEVICE = -4,    /* no gfx950 device visible                                          */
-    ICEM_E_STATE = -5         /* call order violated (e.g. rollout before icem_set_model)          */
+    ICEM_E_STATE = -5,        /* call order violated (e.g. rollout before icem_set_model)          */
+    ICEM_E_RANGE = -6         /* icem_get_action: the step's outputs are returned, but trajectories came back with a
+                                 non-finite cost from a finite observation (a state left the arithmetic's range)       */
 };
 
 #define ICEM_MAX_HORIZON 64
@@ -427,19 +429,46 @@ int icem_set_wide_exact(icem_handle* h, int32_t on);
  *   ICEM_TILE_F16X2 (1): every f32 operand x S (S one power of two per launch, from max(|obs0|, action bound)) as the sum
  *     of two fp16 numbers, three fp16 products per multiply-add with f32 accumulation on v_mfma_f32_16x16x32_f16 -- f32-class
  *     rounding (operands to 2^-24 relative down to 2^-7 of the largest, 2^-29 of the largest below), a quarter of the
- *     matrix-pipe time of the exact form; NOT the bits of an fmaf chain.  A state that grows beyond 2^11 x max(|obs0|,
- *     action bound) inside the horizon leaves fp16's range: that trajectory's cost is reported as NaN and ranks last.
- *     Served for models whose largest |entry| lies in [2^-4, 2^4]; other models silently keep the exact form
- *     (icem_tile_arith tells which one a handle's launches use).
+ *     matrix-pipe time of the exact form; NOT the bits of an fmaf chain.  fp16 ends at 65 504 = 2^11 x the scaled magnitude,
+ *     so the planes are SERVED ONLY WHERE NO STATE CAN GET THERE: for a linear model the reachable maximum of
+ *     |state entry| / max(|obs0|, action bound) over the horizon -- over every start observation and every action sequence
+ *     inside the bounds; icem_tile_growth returns it -- must not exceed 2^10 (a tanh model's state is bounded by 1), and the
+ *     largest |entry| of B must not exceed 2^10 x A's (the action operand's scale).  Every other model keeps the
+ *     exact form whatever is asked -- with A = 1.5 I over 30 steps the reference ranks finite costs of 1e5 (icem.py:147-159,
+ *     199) and so does this library -- and icem_tile_arith tells which arithmetic a handle's launches use.
  *   ICEM_TILE_AUTO (-1, the default): F16X2 wherever it is served (the widths, models and thresholds above), at every
  *     population -- since ABI 4; ABI 3 kept configurations with an iteration of at most 8192 rows on F32, which measured
- *     SLOWER there too (N = 4096 x 5 iterations: 66.7 -> 61.9 us per MPC step).  Decided from the configuration alone: every
- *     rank of a sharded run and every iteration of a decaying population computes in the same arithmetic.  Strict-parity
- *     callers pass ICEM_TILE_F32.
- * Takes effect at the next launch (not between icem_plan_iter_local and its merge).  No reference counterpart. */
+ *     SLOWER there too (N = 4096 x 5 iterations: 66.7 -> 61.9 us per MPC step).  Decided from the configuration alone -- the
+ *     handle's, never the process environment's: every rank of a sharded run and every iteration of a decaying population
+ *     computes in the same arithmetic.  Strict-parity callers pass ICEM_TILE_F32.
+ * The same setting governs the Door / Relocate / FetchPickAndPlace shapes' TileHN rollout (o = 28 / 39; k_rollout_hn.hip --
+ * fp16 planes by default under the same range rules; ICEM_TILE_F32, and at o = 39 also icem_set_wide_arith(ICEM_WIDE_F32),
+ * puts them on the exact-f32 GEMM kernel).
+ * Takes effect at the next launch (not between icem_plan_iter_local and its merge).  No reference counterpart.
+ * The scale S takes the action bound from the (low, high) buffers of the plan calls and of icem_reset_distribution (fetched
+ * once per buffer pair and again at every reset -- the first such call on a stream must not be inside a stream capture);
+ * icem_rollout_cost on actions OUTSIDE those bounds can still leave the planes' range: see icem_nonfinite_costs. */
 enum { ICEM_TILE_AUTO = -1, ICEM_TILE_F32 = 0, ICEM_TILE_F16X2 = 1 };
 int icem_set_tile_arith(icem_handle* h, int32_t mode);
 int icem_tile_arith(const icem_handle* h); /* the arithmetic in effect: ICEM_TILE_F32 or ICEM_TILE_F16X2 */
+double icem_tile_growth(const icem_handle* h); /* reachable max of |state| / max(|obs0|, action bound) over the horizon (1: tanh) */
+
+/* Status word of the tile rollouts (every launch of the o <= 48 kernels counts into it): the number of trajectories since
+ * icem_create whose cost came out NaN -- a state that left the arithmetic's range (f32's; the fp16 planes' for actions
+ * outside the bounds their scale was taken from) or non-finite inputs.  Such a trajectory ranks last, as a NaN does under
+ * icem.py:199's argsort; the reference's float64 would have ranked a finite cost, so a caller that fed finite inputs must
+ * not trust the step: icem_get_action returns ICEM_E_RANGE (outputs filled) when its own step raised the count from a finite
+ * observation; icem_plan_step callers read it here.  Copies one word back and synchronises `stream`. */
+int icem_nonfinite_costs(icem_handle* h, int64_t* count_out, void* stream);
+
+/* Development options: which of several BIT-IDENTICAL launch arrangements serves a call, tuning fractions, the bound of the
+ * exchange's device-side waits (names and defaults: icem_amd/csrc/options.h; icem_option_name(i) enumerates them, NULL
+ * behind the last).  One process-wide table; the library reads NO environment variable -- tools map ICEM_<NAME> variables
+ * onto it explicitly (icem_amd._lib.apply_env_options).  No option selects an arithmetic. */
+int icem_set_option(const char* name, double value);
+int icem_get_option(const char* name, double* value_out);
+int icem_reset_options(void);
+const char* icem_option_name(int32_t index);
 
 /* ---- per-kernel timing (measurement only) ------------------------------------------------- */
 enum {

@@ -821,7 +821,13 @@ class IcemOracle:
     """
 
     def __init__(self, params: IcemParams, low: np.ndarray, high: np.ndarray,
-                 rollout_cost: Callable[[np.ndarray, np.ndarray], np.ndarray], noise: NoiseFn):
+                 rollout_cost: Callable[[np.ndarray, np.ndarray], np.ndarray], noise: NoiseFn,
+                 compute_new_mean: Optional[Callable[[np.ndarray, np.ndarray], np.ndarray]] = None,
+                 rollout_obs: Optional[Callable[[np.ndarray, np.ndarray], np.ndarray]] = None):
+        # compute_new_mean(last_predicted_obs, kept_last_row) -> new last row: a subclass' override of icem.py:191-192
+        # (None: the default, keep the last row); rollout_obs(obs, actions [P,h,d]) -> pre-action observations [P,h,o]
+        self.compute_new_mean = compute_new_mean
+        self.rollout_obs = rollout_obs
         self.p = params
         self.low = np.asarray(low)
         self.high = np.asarray(high)
@@ -882,6 +888,9 @@ class IcemOracle:
                                              self.mean.copy(), self.std.copy(), best))
         executed = pool_actions[best][0].copy()                         # icem.py:163
         self.mean[:-1] = self.mean[1:]                                  # icem.py:167 (last kept: :171,191-192)
+        if self.compute_new_mean is not None:                           # icem.py:170-171 under an overriding subclass
+            last_predicted_ob = self.rollout_obs(obs, pool_actions[best][None])[0, -1]
+            self.mean[-1] = self.compute_new_mean(last_predicted_ob, self.mean[-1].copy())
         self.std = np.ones_like(self.std) * (self.high - self.low) / 2.0 * p.init_std  # icem.py:175
         self.last_min_cost = float(np.min(costs))                       # icem.py:177
         self.trace.append(step_trace)

@@ -16,6 +16,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "soak: randomised many-seed runs (also marked gpu; ICEM_SOAK_SEEDS scales them)")
 
 
+@pytest.fixture(autouse=True)
+def _library_options_back_to_defaults():
+    """The library's development options (icem_set_option) are process-wide: every test starts and ends on the defaults.
+    Tests flip them with ``icem_amd._lib.set_option`` -- the library itself reads no environment variable."""
+    from icem_amd import _lib as L
+    built = os.path.exists(L.lib_path())
+    if built:
+        L.reset_options()
+    yield
+    if built:
+        L.reset_options()
+
+
 def pytest_collection_modifyitems(config, items):
     try:
         import torch

@@ -174,9 +174,9 @@ def make_model_mats(o, d, seed_a=0, seed_b=1):
 
 def run_case(name, *, N, h, d, o, beta, iters, seed, n_steps, kind, env_kind,
              cost_mode="sum", K=10, xi=0.3, gamma=1.25, alpha=0.1, init_std=0.5,
-             use_mean=True, keep=True, shift=True, bounds=1.0):
+             use_mean=True, keep=True, shift=True, bounds=1.0, new_mean=False):
     import colorednoise
-    from controllers.icem import MpcICem
+    from controllers.icem import MpcICem as RefMpcICem
     from models.abstract_models import ForwardModelWithDefaults
     from gym import spaces
     import environments.mujoco as ref_mj
@@ -214,6 +214,13 @@ def run_case(name, *, N, h, d, o, beta, iters, seed, n_steps, kind, env_kind,
             r = np.zeros(observations.shape[:-1] + (1,))
             return nxt, None, r
 
+    class NewMeanICem(RefMpcICem):
+        # the override point icem.py:171,191-192: the new last row of the shifted mean from the best trajectory's last
+        # predicted observation AND the row the default would have kept (tests/golden_util.py::new_mean_rule is the same rule)
+        def compute_new_mean(self, obs):
+            return 0.5 * self.mean[-1] + 0.25 * np.tanh(obs[:d])
+
+    MpcICem = NewMeanICem if new_mean else RefMpcICem
     env = FakeEnv()
     ctrl = MpcICem(env=env, forward_model=FakeModel(env=env), horizon=h,
                    num_simulated_trajectories=N, factor_decrease_num=gamma,
@@ -258,12 +265,13 @@ def run_case(name, *, N, h, d, o, beta, iters, seed, n_steps, kind, env_kind,
     import io, contextlib
     with contextlib.redirect_stdout(io.StringIO()):
         ctrl.beginning_of_rollout(observation=obs, state=None, mode="train")
-    out = {"obs": [], "executed": []}
+    out = {"obs": [], "executed": [], "mean_after": []}
     for s in range(n_steps):
         out["obs"].append(obs.copy())
         a = ctrl.get_action(obs, None)
         assert a.dtype == np.float64 and a.shape == (d,)
         out["executed"].append(np.array(a))
+        out["mean_after"].append(ctrl.mean.copy())
         # advance the "real" system with the same fake dynamics
         nxt, _, _ = ctrl.forward_model.predict(observations=obs[None], states=None, actions=a[None])
         obs = nxt[0]
@@ -282,6 +290,9 @@ def run_case(name, *, N, h, d, o, beta, iters, seed, n_steps, kind, env_kind,
         obs=np.array(out["obs"]), executed=np.array(out["executed"]),
         n_noise_calls=np.array(len(colorednoise.CALLS)), n_iters_total=np.array(len(log["costs"])),
     )
+    if new_mean:
+        data["new_mean"] = np.array(1)
+        data["mean_after"] = np.array(out["mean_after"])
     for i, (zr, zi, y) in enumerate(colorednoise.CALLS):
         data[f"zr_{i}"] = zr
         data[f"zi_{i}"] = zi
@@ -670,6 +681,10 @@ def main():
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference (build container only)")
     install_stubs()
+    if "--new-mean-only" in sys.argv:   # (round 6: the one fixture added without rewriting the others)
+        run_case("newmean_n48", N=48, h=10, d=4, o=17, beta=1.0, iters=3, seed=17,
+                 n_steps=3, kind=1, env_kind="halfcheetah", new_mean=True)
+        return
     cost_fn_vectors()
     env_cost_vectors()
     open_loop_policy_vectors()
@@ -692,6 +707,9 @@ def main():
     # beta = 0: the white-noise branch (np.random.randn(N, h, d), icem.py:77), elites shifted and kept
     run_case("white_beta0_n64", N=64, h=30, d=6, o=17, beta=0.0, iters=3, seed=16,
              n_steps=3, kind=0, env_kind="halfcheetah")
+    # a subclass overriding compute_new_mean (icem.py:171,191-192): the last mean row from the last predicted observation
+    run_case("newmean_n48", N=48, h=10, d=4, o=17, beta=1.0, iters=3, seed=17,
+             n_steps=3, kind=1, env_kind="halfcheetah", new_mean=True)
     # the CEM baseline MpcCemStd (truncated normal): bounds from the action space, and "like Levine" (+-2 sigma, std capped)
     run_cem_std_case("cemstd_bounds_n48", N=48, h=12, d=6, o=17, iters=3, seed=21, n_steps=3, kind=0, like_levine=False)
     run_random_case("random_n24", N=24, h=10, d=4, o=17, freq=3, seed=31, n_steps=3, kind=1)

@@ -7,7 +7,15 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 _ALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if not p.endswith(("cost_vectors.npz", "cost_fn_vectors.npz", "open_loop_policy_vectors.npz")))
-CASES = [n for n in _ALL if not n.startswith(("cemstd_", "random_"))]        # MpcICem runs
+CASES = [n for n in _ALL if not n.startswith(("cemstd_", "random_", "newmean_"))]        # MpcICem runs
+NEWMEAN_CASES = [n for n in _ALL if n.startswith("newmean_")]   # MpcICem subclasses that override compute_new_mean (icem.py:171,191-192)
+
+
+def new_mean_rule(last_predicted_obs, kept_row):
+    """The override the ``newmean_*`` fixtures were recorded with (tests/golden/make_golden.py::NewMeanICem)."""
+    d = kept_row.shape[0]
+    return 0.5 * kept_row + 0.25 * np.tanh(np.asarray(last_predicted_obs)[:d])
+
 RANDOM_CASES = [n for n in _ALL if n.startswith("random_")]     # MpcRandom runs (random shooting baseline)
 CEMSTD_CASES = [n for n in _ALL if n.startswith("cemstd_")]     # MpcCemStd runs (truncated-normal CEM baseline)
 
@@ -27,6 +35,8 @@ class Golden:
         self.obs, self.executed = z["obs"], z["executed"]
         self.n_noise_calls = int(z["n_noise_calls"])
         self.n_iters_total = int(z["n_iters_total"])
+        self.new_mean = "new_mean" in z.files
+        self.mean_after = z["mean_after"] if self.new_mean else None   # [n_steps, h, d]: ctrl.mean behind every get_action
 
     def noise(self, i):
         return self.z[f"zr_{i}"], self.z[f"zi_{i}"]

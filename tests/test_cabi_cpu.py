@@ -33,7 +33,7 @@ def test_header_symbols_all_exported(lib):
 
 
 def test_abi_version_and_error_string(lib):
-    assert lib.icem_abi_version() == L.ABI_VERSION == 4
+    assert lib.icem_abi_version() == L.ABI_VERSION == 5
     assert isinstance(lib.icem_last_error(), bytes)
 
 
@@ -187,3 +187,37 @@ def test_wide_auto_criterion_on_host_models(lib):
         A[5, :] *= 1e-30
         assert imb(A, B0) <= 10
     assert lib.icem_wide_model_imbalance_log2(0, 1, None, None) == -1
+
+
+def test_options_are_set_through_the_abi_not_the_environment(lib, monkeypatch):
+    """kernel-path selection lives in one table behind icem_set_option; the library reads no
+    environment variable (its dynamic symbol table does not even import getenv); tools map ICEM_<NAME> explicitly."""
+    import shutil
+    import subprocess
+    names = L.option_names()
+    assert "fuse_max_rw" in names and "noise_ahead" in names and len(names) >= 20
+    assert not any("arith" in n for n in names)   # no option selects an arithmetic: that is per handle
+    L.reset_options()
+    assert L.get_option("fuse_max_rw") == 8.0 and L.get_option("ahead_tail_frac") == 0.6
+    L.set_option("fuse_max_rw", 0)
+    assert L.get_option("fuse_max_rw") == 0.0
+    with pytest.raises(L.IcemError):
+        L.set_option("no_such_option", 1)
+    with pytest.raises(L.IcemError):
+        L.set_option("fuse_max_rw", float("nan"))
+    # the environment alone changes nothing ...
+    monkeypatch.setenv("ICEM_FUSE_MAX_RW", "2")
+    monkeypatch.setenv("ICEM_GK_ROLLOUT", "thread")
+    L.reset_options()
+    assert L.get_option("fuse_max_rw") == 8.0 and L.get_option("gk_rollout_thread") == 0.0
+    # ... until a TOOL maps it
+    done = L.apply_env_options()
+    assert done == {"fuse_max_rw": 2.0, "gk_rollout_thread": 1.0}
+    assert L.get_option("fuse_max_rw") == 2.0 and L.get_option("gk_rollout_thread") == 1.0
+    L.reset_options()
+    if shutil.which("nm"):
+        syms = subprocess.check_output(["nm", "-D", "--undefined-only", L.lib_path()], text=True)
+        assert "getenv" not in syms
+        faults = os.path.join(os.path.dirname(L.lib_path()), "libicem_hip_faults.so")
+        if os.path.exists(faults):   # the fault-injection twin (tests/test_gpu_exchange_faults.py) is the one binary that does
+            assert "getenv" in subprocess.check_output(["nm", "-D", "--undefined-only", faults], text=True)

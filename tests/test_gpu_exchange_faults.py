@@ -27,8 +27,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _bench(fault):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "ICEM_XCHG_FAIL")}
     if fault:
+        # the product library carries no fault injection: the drills load its twin built with -DICEM_FAULT_INJECTION
+        # (icem_amd/build.py: exchange.hip compiled once more, everything else the same objects)
+        env["ICEM_HIP_LIB"] = os.path.join(ROOT, "icem_amd", "libicem_hip_faults.so")
         env["ICEM_XCHG_FAIL"] = fault
-        env["ICEM_XCHG_MAX_POLLS"] = "20000"   # a lost peer costs milliseconds, not the default's seconds
+        env["ICEM_XCHG_MAX_POLLS"] = "20000"   # a lost peer costs milliseconds, not the default's seconds (bench.py maps it onto icem_set_option)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5",
                         "--no-cpu-baseline", "--no-also"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]

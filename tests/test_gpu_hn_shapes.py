@@ -129,14 +129,14 @@ def test_every_wave_arrangement_of_a_tile_computes_the_same_bits(name, kind, mod
     rs = np.random.RandomState(11)
     acts = rs.uniform(-1, 1, (16 * 9 + 5, 30, d)) * env.action_space.high
     obs_r = 0.2 * rs.randn(o)
-    variants = {"split": {}, "pair": {"ICEM_HN_SPLIT": "0"}, "single": {"ICEM_HN_PAIR": "0"}}
+    from icem_amd import _lib as L
+    variants = {"split": {}, "pair": {"hn_split": 0}, "single": {"hn_pair": 0}}
     for N in (4096, 6000):
         out = {}
         for label, envs in variants.items():
-            monkeypatch.delenv("ICEM_HN_SPLIT", raising=False)
-            monkeypatch.delenv("ICEM_HN_PAIR", raising=False)
+            L.reset_options()
             for k, v in envs.items():
-                monkeypatch.setenv(k, v)
+                L.set_option(k, v)
             pl = _planner(env, model, N=N, iters=3, mode=mode)
             res = []
             for s in range(3):

@@ -372,6 +372,61 @@ def test_controller_host_model_path(name):
         np.testing.assert_allclose(a, g.executed[s], rtol=F64_RTOL, atol=F64_ATOL)
 
 
+@pytest.mark.parametrize("path,dtype", [("device", "f64"), ("device", "f32"), ("host", "f64")])
+def test_compute_new_mean_override_replays_the_reference_subclass(path, dtype):
+    """icem.py:168-171, 191-192: a subclass of MpcICem may set the last row of the shifted mean from the best trajectory's last
+    predicted observation.  The fixture is the run of such a subclass of the REFERENCE's class (tests/golden/make_golden.py::
+    NewMeanICem); the same override on MpcICemHip -- device path (the device epilogue keeps the last row; the override's row
+    is written behind it, the one observation it needs re-rolled on demand) and host-model path -- returns the reference's
+    actions and leaves the reference's mean behind every step."""
+    from golden_util import NEWMEAN_CASES, new_mean_rule
+    from icem_amd import DeviceSyntheticModel, MpcICemHip, halfcheetah_env
+    from icem_amd.envs import Box
+    from icem_amd.models import ForwardModel
+    g = Golden(NEWMEAN_CASES[0])
+    assert g.new_mean
+    env = halfcheetah_env(g.o)
+    env.action_space = Box(-g.bounds * np.ones(g.d), g.bounds * np.ones(g.d))
+    om = O.SyntheticModel(g.A, g.B, g.kind)
+    seen = []
+
+    class HostModel(ForwardModel):
+        def predict(self, *, observations, states, actions):
+            return om.predict(observations, actions), None, np.zeros(observations.shape[:-1] + (1,))
+
+    class NewMean(MpcICemHip):
+        def compute_new_mean(self, obs):
+            seen.append(np.array(obs))
+            return new_mean_rule(obs, self.mean[-1])
+
+    model = DeviceSyntheticModel(g.A, g.B, g.kind) if path == "device" else HostModel(env=env)
+    ctrl = NewMean(env=env, forward_model=model, horizon=g.h, num_simulated_trajectories=g.N, factor_decrease_num=g.gamma,
+                   cost_along_trajectory=g.cost_mode, dtype=dtype, noise_source="numpy_legacy",
+                   action_sampler_params=dict(alpha=g.alpha, elites_size=g.K, opt_iterations=g.iters, init_std=g.init_std,
+                                              use_mean_actions=g.use_mean, keep_previous_elites=g.keep,
+                                              shift_elites_over_time=g.shift, fraction_elites_reused=g.xi, noise_beta=g.beta))
+    assert ctrl.device_path == (path == "device")
+    t = tol(dtype)
+    np.random.seed(g.seed)
+    ctrl.beginning_of_rollout(observation=g.obs[0], state=None, mode="train")
+    for s in range(g.n_steps):
+        a = ctrl.get_action(g.obs[s], None)
+        np.testing.assert_allclose(a, g.executed[s], **t)
+        np.testing.assert_allclose(ctrl.mean, g.mean_after[s], **t)
+    assert len(seen) == g.n_steps and all(ob.shape == (g.o,) for ob in seen)
+    # the default keeps the last row: a controller that does not override never asks for the observation
+    plain = MpcICemHip(env=env, forward_model=DeviceSyntheticModel(g.A, g.B, g.kind), horizon=g.h, num_simulated_trajectories=g.N,
+                       factor_decrease_num=g.gamma, cost_along_trajectory=g.cost_mode, dtype="f64", noise_source="numpy_legacy",
+                       action_sampler_params=dict(alpha=g.alpha, elites_size=g.K, opt_iterations=g.iters, init_std=g.init_std,
+                                                  use_mean_actions=g.use_mean, keep_previous_elites=g.keep,
+                                                  shift_elites_over_time=g.shift, fraction_elites_reused=g.xi, noise_beta=g.beta))
+    assert not plain._new_mean_is_overridden(MpcICemHip)
+    np.random.seed(g.seed)
+    plain.beginning_of_rollout(observation=g.obs[0], state=None, mode="train")
+    np.testing.assert_allclose(plain.get_action(g.obs[0], None), g.executed[0], **tol("f64"))   # (step 0: same draws, same action)
+    assert np.abs(plain.mean[-1] - g.mean_after[0][-1]).max() > 1e-3                              # ... but the kept row behind it
+
+
 class _SerialGtStyleModel:
     """A host forward model whose ``predict_n_steps`` walks the policy the way the reference's ``GroundTruthModel`` does
     (gt_model.py:76-102): one start state after the other, ``policy.get_action(obs[o], None)`` h times each, one
@@ -1094,7 +1149,7 @@ def test_verbose_mode_prints_the_reference_lines_and_plans_the_same(capsys):
 @pytest.mark.parametrize("kind,mode,o,N", [(0, "sum", 17, 4096), (1, "best", 18, 1000), (1, "final", 8, 300), (0, "sum", 24, 700)])
 def test_generic_path_forms_compute_the_same_bits(dtype, kind, mode, o, N, monkeypatch):
     """The strict-parity path's forms of an iteration -- a trajectory's row of lanes (rollout_cost_rows_kernel) + ONE selection /
-    gather / refit launch (select_refit_kernel) against one thread per trajectory + top-K partials, pack, merge (ICEM_GK_ROLLOUT=thread, ICEM_GK_SELECT=0) -- give the same bits in every buffer over three MPC steps: costs, elite sets
+    gather / refit launch (select_refit_kernel) against one thread per trajectory + top-K partials, pack, merge (options gk_rollout_thread = 1, gk_select = 0) -- give the same bits in every buffer over three MPC steps: costs, elite sets
     and their costs, mean, std, executed action (same fused multiply-add chains, same key order, same refit)."""
     from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env
     d = 6
@@ -1102,14 +1157,13 @@ def test_generic_path_forms_compute_the_same_bits(dtype, kind, mode, o, N, monke
     model = DeviceSyntheticModel.make(o, d, kind=kind)
 
     def run(form):
+        from icem_amd import _lib as L
+        L.reset_options()
         if form == "round4":      # one thread per trajectory; top-K partials -> pack -> merge
-            monkeypatch.setenv("ICEM_GK_ROLLOUT", "thread")
-            monkeypatch.setenv("ICEM_GK_SELECT", "0")
-        else:                     # the default: a trajectory's row of lanes, one-launch selection
-            monkeypatch.delenv("ICEM_GK_ROLLOUT", raising=False)
-            monkeypatch.delenv("ICEM_GK_SELECT", raising=False)
+            L.set_option("gk_rollout_thread", 1)
+            L.set_option("gk_select", 0)
         if dtype == "f32":
-            monkeypatch.setenv("ICEM_DISABLE_FAST", "1")   # f32 on the generic kernels
+            L.set_option("disable_fast", 1)   # f32 on the generic kernels
         pl = IcemPlanner(IcemConfig(horizon=30, act_dim=d, num_traj=N, opt_iters=3, dtype=dtype, seed=5, cost_mode=mode),
                          env.action_space.low, env.action_space.high)
         pl.set_model(model.kind, model.A, model.B)
@@ -1142,12 +1196,12 @@ def test_one_launch_selection_with_every_cost_tied(dtype, monkeypatch):
     model = DeviceSyntheticModel.make(17, 6, kind=0)
 
     def run(old):
+        from icem_amd import _lib as L
+        L.reset_options()
         if old:
-            monkeypatch.setenv("ICEM_GK_SELECT", "0")
-        else:
-            monkeypatch.delenv("ICEM_GK_SELECT", raising=False)
+            L.set_option("gk_select", 0)
         if dtype == "f32":
-            monkeypatch.setenv("ICEM_DISABLE_FAST", "1")
+            L.set_option("disable_fast", 1)
         pl = IcemPlanner(IcemConfig(horizon=30, act_dim=6, num_traj=4096, opt_iters=3, dtype=dtype, seed=9),
                          env.action_space.low, env.action_space.high)
         pl.set_model(model.kind, model.A, model.B)
@@ -2236,7 +2290,7 @@ def test_in_library_exchange_wait_is_bounded(monkeypatch):
     the block's status word, and the step finishes (with garbage)."""
     import ctypes as C
     from icem_amd import IcemPlanner, _lib as L
-    monkeypatch.setenv("ICEM_XCHG_MAX_POLLS", "2000")
+    L.set_option("xchg_max_polls", 2000)
     pls = [_xchg_planner(r, 2, "f32") for r in range(2)]
     IcemPlanner.connect_exchange_local(pls)
     pl = pls[0]
@@ -2262,7 +2316,7 @@ def test_in_library_exchange_wait_is_bounded(monkeypatch):
 def test_small_population_kernel_equals_two_kernel_path(h, d, o, kind, mode, N, iters, monkeypatch):
     """The small-population launch (k_iter_small.hip: a row sampled by a quad of lanes with DPP exchange of its draws,
     rollout on Tile4 = VALU + DPP row broadcast, four trajectories per wave) against the sampler + rollout16 kernels
-    (one thread per row, Tile16 = six dependent f32 MFMAs per step; ICEM_FUSE_MAX_RW=0): the same draws, the same fmaf
+    (one thread per row, Tile16 = six dependent f32 MFMAs per step; option fuse_max_rw = 0): the same draws, the same fmaf
     chains in the same order (an f32 MFMA is bitwise an fmaf chain over its slots) -- every buffer identical over three
     MPC steps."""
     from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env, humanoid_standup_env
@@ -2270,7 +2324,8 @@ def test_small_population_kernel_equals_two_kernel_path(h, d, o, kind, mode, N, 
     model = DeviceSyntheticModel.make(o, d, kind=kind)
 
     def run(max_rw):
-        monkeypatch.setenv("ICEM_FUSE_MAX_RW", str(max_rw))
+        from icem_amd import _lib as L
+        L.set_option("fuse_max_rw", max_rw)
         pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=N, opt_iters=iters, dtype="f32", seed=11, cost_mode=mode),
                          env.action_space.low[:d], env.action_space.high[:d])
         pl.set_model(model.kind, model.A, model.B)
@@ -2380,7 +2435,7 @@ def test_noise_ahead_pipeline_equals_the_default_path(h, d, o, kind, mode, N, it
     """The noise-ahead pipeline of large populations (plan.hip::plan_step_ahead, k_rollout_ahead.hip: one launch per
     iteration whose rollout workgroups run the previous merge in their prologue and map the pool's raw noise to actions as
     they load it, beside noise workgroups that draw the NEXT sampling call and, at iteration 0, a shifted-elites workgroup)
-    against the sampler + rollout pair (ICEM_NOISE_AHEAD=0): same draws, same fmaf / v_med3 per sample, same rollout code --
+    against the sampler + rollout pair (option noise_ahead = 0): same draws, same fmaf / v_med3 per sample, same rollout code --
     every buffer identical over four MPC steps (the noise of step s + 1's first iteration is drawn during step s).  (The
     two-tile shape d = 17, o = 24 is routed to the pair whatever the switch says -- its launch spilled and lost, EXPERIMENTS
     R4.6 -- and stays here as the check that the routing leaves its results alone.)"""
@@ -2389,7 +2444,8 @@ def test_noise_ahead_pipeline_equals_the_default_path(h, d, o, kind, mode, N, it
     model = DeviceSyntheticModel.make(o, d, kind=kind)
 
     def run(on):
-        monkeypatch.setenv("ICEM_NOISE_AHEAD", "1" if on else "0")
+        from icem_amd import _lib as L
+        L.set_option("noise_ahead", 1 if on else 0)
         pl = IcemPlanner(IcemConfig(horizon=h, act_dim=d, num_traj=N, opt_iters=iters, dtype="f32", seed=5, cost_mode=mode),
                          env.action_space.low[:d], env.action_space.high[:d])
         pl.set_model(model.kind, model.A, model.B)

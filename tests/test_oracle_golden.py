@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from oracle import icem_oracle as O
-from golden_util import CASES, Golden, GOLDEN
+from golden_util import CASES, NEWMEAN_CASES, Golden, GOLDEN, new_mean_rule
 import os
 
 
@@ -20,6 +20,9 @@ def _oracle_for(g: Golden, noise_fn):
         observations = O.rollout_observations(model, obs, actions)
         return O.trajectory_costs(cost, observations, actions, g.cost_mode)
 
+    if g.new_mean:   # the run of a subclass that overrides compute_new_mean (icem.py:171,191-192)
+        return O.IcemOracle(p, g.low, g.high, rollout_cost, noise_fn, compute_new_mean=new_mean_rule,
+                            rollout_obs=lambda obs, actions: O.rollout_observations(model, obs, actions))
     return O.IcemOracle(p, g.low, g.high, rollout_cost, noise_fn)
 
 
@@ -46,7 +49,7 @@ def test_colored_noise_matches_reference_call(name):
         np.testing.assert_allclose(y2, y, rtol=0, atol=5e-14)
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + NEWMEAN_CASES)
 def test_full_loop_matches_reference(name):
     """Replay the recorded white noise through the oracle controller: every
     iteration's actions / costs / elites / mean / std and the executed actions
@@ -65,6 +68,9 @@ def test_full_loop_matches_reference(name):
     for s in range(g.n_steps):
         a = orc.get_action(g.obs[s])
         np.testing.assert_allclose(a, g.executed[s], rtol=1e-12, atol=1e-14)
+        if g.new_mean:   # the mean a subclass' compute_new_mean left behind (its last row is NOT the kept one)
+            np.testing.assert_allclose(orc.mean, g.mean_after[s], rtol=1e-12, atol=1e-14)
+            assert np.abs(orc.mean[-1] - orc.trace[s][-1].mean[-1]).max() > 1e-3
         for tr in orc.trace[s]:
             ref = g.it(it)
             assert tr.actions.shape == ref["simact"].shape

@@ -6,6 +6,8 @@ os.environ.setdefault("ICEM_AHEAD_STAMPS", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from icem_amd import IcemConfig, IcemPlanner, DeviceSyntheticModel, halfcheetah_env
 from icem_amd import _lib as L
+from icem_amd import _lib as _LENV  # noqa: E402
+_LENV.follow_environment()   # this tool flips ICEM_<NAME> variables: mapped onto icem_set_option per planner (the library reads no environment)
 env = halfcheetah_env(17)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 5

@@ -4,6 +4,8 @@ import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env
+from icem_amd import _lib as _LENV  # noqa: E402
+_LENV.follow_environment()   # this tool flips ICEM_<NAME> variables: mapped onto icem_set_option per planner (the library reads no environment)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 env = halfcheetah_env(17)
 model = DeviceSyntheticModel.make(17, 6)

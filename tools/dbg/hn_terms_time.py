@@ -5,6 +5,8 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner
 from icem_amd import envs as E
+from icem_amd import _lib as _LENV  # noqa: E402
+_LENV.follow_environment()   # this tool flips ICEM_<NAME> variables: mapped onto icem_set_option per planner (the library reads no environment)
 N = 4096
 for name, mk in (("door", E.door_env), ("relocate", E.relocate_env), ("fpp", E.fetch_pick_and_place_env)):
     env = mk()

@@ -9,6 +9,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from icem_amd import DeviceRSSMModel  # noqa: E402
+from icem_amd import _lib as _LENV  # noqa: E402
+_LENV.follow_environment()   # this tool flips ICEM_<NAME> variables: mapped onto icem_set_option per planner (the library reads no environment)
 
 CASES = [(1, 12, 0), (15, 1, 2), (16, 2, 0), (17, 12, 1), (1007, 12, 0), (1024, 12, 1), (1024, 12, 2), (2048, 12, 0), (2033, 30, 0),
          (640, 5, 1), (4096, 12, 0), (3001, 12, 1), (4097, 12, 0), (8192 + 21, 12, 1), (20000, 12, 0), (65536, 12, 0), (40001, 3, 2)]

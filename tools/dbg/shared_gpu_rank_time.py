@@ -62,6 +62,8 @@ def worker(rank, world, port, rows, out):
 def alone(world, rows, loopback):
     import ctypes as C, torch
     from icem_amd import _lib as L
+    from icem_amd import _lib as _LENV  # noqa: E402
+    _LENV.follow_environment()   # this tool flips ICEM_<NAME> variables: mapped onto icem_set_option per planner (the library reads no environment)
     pl = planner(0, world if loopback else 1, rows)
     if loopback:
         scratch = (C.c_ubyte * L.IPC_HANDLE_BYTES)()

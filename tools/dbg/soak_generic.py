@@ -10,6 +10,8 @@ import torch
 
 sys.path.insert(0, ".")
 from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner  # noqa: E402
+from icem_amd import _lib as _LENV  # noqa: E402
+_LENV.follow_environment()   # this tool flips ICEM_<NAME> variables: mapped onto icem_set_option per planner (the library reads no environment)
 
 
 def run(cfg_kw, model, cost, obs_seq, old):

@@ -10,6 +10,8 @@ import numpy as np
 sys.path.insert(0, ".")
 from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner  # noqa: E402
 from icem_amd import envs as E  # noqa: E402
+from icem_amd import _lib as _LENV  # noqa: E402
+_LENV.follow_environment()   # this tool flips ICEM_<NAME> variables: mapped onto icem_set_option per planner (the library reads no environment)
 
 ENVS = {"door": E.door_env, "relocate": E.relocate_env, "fpp": E.fetch_pick_and_place_env}
 

@@ -3,6 +3,8 @@ import sys, os, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from icem_amd import IcemConfig, IcemPlanner, DeviceSyntheticModel, halfcheetah_env
 from icem_amd import _lib as L
+from icem_amd import _lib as _LENV  # noqa: E402
+_LENV.follow_environment()   # ICEM_<NAME> variables (incl. ICEM_TILE_ARITH) are mapped per planner: the library reads no environment
 env = halfcheetah_env(17)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 1

@@ -5,6 +5,8 @@ import argparse, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from icem_amd import IcemConfig, IcemPlanner, DeviceSyntheticModel, halfcheetah_env, humanoid_standup_env
+from icem_amd import _lib as _LENV  # noqa: E402
+_LENV.follow_environment()   # ICEM_<NAME> variables (incl. ICEM_TILE_ARITH) are mapped per planner: the library reads no environment
 ap = argparse.ArgumentParser()
 ap.add_argument("N", type=int, nargs="*", default=[4096, 8192, 16384, 32768])
 ap.add_argument("--d", type=int, default=6)

@@ -12,6 +12,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner  # noqa: E402
+from icem_amd import _lib as _LENV  # noqa: E402
+_LENV.follow_environment()   # this tool flips ICEM_<NAME> variables: mapped onto icem_set_option per planner (the library reads no environment)
 
 CASES = [  # (label, h, d, o, N, iters, dtype)
     ("fast path, for reference (h=30 d=6 o=17 f32)", 30, 6, 17, 4096, 5, "f32"),
