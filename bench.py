@@ -560,6 +560,50 @@ def measure_also(name, rank=0, world=1, steps=200, warmup=20, global_n=None):
     return out
 
 
+def measure_batched(name="c2", batches=(2, 4, 8), steps=100, warmup=10, solo_ms=None):
+    """B independent planners of the headline configuration (different models' seeds, costs and observations; the reference's
+    parallel episodes, icem/misc/rollout_utils.py:46-58, 129-152) advanced by icem_plan_step_batch: every stage one launch for
+    all of them.  Per B: ms per (batched) MPC step, aggregate traj-steps/s over all problems, the whole loop's algorithmic
+    bytes over the step time as a fraction of the HBM line, and the aggregate relative to B solo steps of this run."""
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner
+    w = WORKLOADS[name]
+    env = make_env(w)
+    out = {"workload": w["name"], "what": "B independent planners, one launch per stage (icem_plan_step_batch)", "by_B": {}}
+    for B in batches:
+        pls = []
+        for i in range(B):
+            model = DeviceSyntheticModel.make(w["o"], w["d"], kind=w.get("kind", 0), seed_a=2 * i, seed_b=2 * i + 1)
+            cfg = IcemConfig(horizon=w["h"], act_dim=w["d"], num_traj=w["N"], opt_iters=w["iters"], noise_beta=w["beta"],
+                             dtype="f32", seed=1234 + i)
+            pl = IcemPlanner(cfg, env.action_space.low, env.action_space.high, device=f"cuda:{torch.cuda.current_device()}")
+            pl.set_model(model.kind, model.A, model.B)
+            pl.set_cost_spec(env.cost_spec)
+            pl.reset()
+            pl.obs0.copy_(torch.as_tensor(0.1 * np.random.RandomState(i).randn(w["o"]), dtype=pl.dt))
+            pls.append(pl)
+        for _ in range(warmup):
+            IcemPlanner.plan_step_batch(pls)
+        torch.cuda.synchronize()
+        up0 = pls[0].batch_uploads
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            IcemPlanner.plan_step_batch(pls)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        ts = B * sum(pls[0].population_sizes) * w["h"]
+        loop_bytes = ts * (8.0 * w["d"] + 8.0 / w["h"])
+        row = {"ms_per_batched_mpc_step": 1e3 * el / steps, "ms_per_problem_step": 1e3 * el / steps / B,
+               "value": ts * steps / el, "unit": "traj-steps/s (all problems)",
+               "whole_loop_algorithmic_GBps": loop_bytes * steps / el / 1e9,
+               "whole_loop_frac_of_hbm_peak": loop_bytes * steps / el / 1e9 / HBM_PEAK_GBS,
+               "argument_uploads_in_timed_steps": pls[0].batch_uploads - up0}
+        if solo_ms:
+            row["aggregate_vs_solo_steps"] = B * solo_ms / (1e3 * el / steps)
+        out["by_B"][str(B)] = row
+        del pls
+    return out
+
+
 def measure_f64(name="c2", steps=40, warmup=4):
     """The reference's own arithmetic (float64 throughout, icem.py) on the device: the strict-parity mode of the same
     workload (generic kernels, one per stage: sample_clip / rollout_cost / top-K partial + final / gather + refit) -- the
@@ -860,6 +904,10 @@ def main():
                 out["also_c3"] = measure_also("c3", 0, 1, steps=30, warmup=3)
             except Exception as ex:
                 out["also_c3"] = {"error": repr(ex)[:300]}
+            try:   # B independent planners of the headline configuration in one launch per stage
+                out["also_batched"] = measure_batched("c2", solo_ms=out["ms_per_step"])
+            except Exception as ex:
+                out["also_batched"] = {"error": repr(ex)[:300]}
             try:   # the reference's float64 arithmetic on the same workload (strict-parity mode, generic kernels)
                 out["also_f64"] = measure_f64("c2")
             except Exception as ex:

@@ -288,7 +288,9 @@ class MpcController(ModelBasedController, StatefulController, ABC):
             _, o = p.rollout_cost(np.asarray(obs, dtype=np.float64), torch.as_tensor(acts, dtype=p.dt, device=p.device),
                                   return_observations=True)
             return o.detach().cpu().numpy().astype(np.float64)[0, -1]
-        batch = self.simulate_trajectories(obs=obs, state=self.forward_model_state, action_sequences=acts)
+        # (two copies of the row: OpenLoopPolicy hands a single trajectory out row-wise, as the reference's does -- a host
+        #  model's batched predict wants the batch form)
+        batch = self.simulate_trajectories(obs=obs, state=self.forward_model_state, action_sequences=np.repeat(acts, 2, axis=0))
         return np.asarray(batch.as_array("observations"), dtype=np.float64)[0, -1]
 
     def _bind_models(self, world=1):

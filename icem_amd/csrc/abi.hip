@@ -260,6 +260,7 @@ int icem_destroy(icem_handle* h) {
     ahead_destroy(h);
     if (h->W_dev) (void)hipFree(h->W_dev);
     if (h->nonfinite_dev) (void)hipFree(h->nonfinite_dev);
+    if (h->batch_ctx && h->batch_ctx_free) h->batch_ctx_free(h->batch_ctx);
     if (h->actions_alt) (void)hipFree(h->actions_alt);
     if (h->host_stage) (void)hipHostFree(h->host_stage);
     if (h->ws_alt) (void)hipFree(h->ws_alt);

@@ -1893,6 +1893,44 @@ __device__ __forceinline__ void pack_records_body(const MergeSingleArgs& a, int 
     }
 }
 
+// ---- argument blocks read from DEVICE memory (the batched launches of icem_plan_step_batch) -----------------------------
+// A pointer that arrives through the kernel-argument segment is known to be a global address; one LOADED from memory is
+// generic, and every access through it becomes a flat_load / flat_store (both counters, no overlap with LDS traffic).  gptr
+// reads the 8 bytes AS a global-address-space pointer, so the accesses stay global_load / global_store: the same device code
+// as the kernels that take their block by value.
+template <class T>
+__device__ __forceinline__ T* gptr(T* const& field) {
+    typedef T __attribute__((address_space(1))) * GP;
+    return (T*)(*static_cast<const GP*>(static_cast<const void*>(&field)));   // (the 8 bytes re-read with a global pointer's type)
+}
+__device__ __forceinline__ FastSampleArgs from_device(const FastSampleArgs& m) {
+    FastSampleArgs s = m;
+    s.W = gptr(m.W), s.mean = gptr(m.mean), s.std = gptr(m.std), s.low = gptr(m.low), s.high = gptr(m.high), s.out = gptr(m.out);
+    s.elites_src = gptr(m.elites_src), s.raw_src = gptr(m.raw_src);
+    return s;
+}
+__device__ __forceinline__ FastRolloutArgs from_device(const FastRolloutArgs& m) {
+    FastRolloutArgs r = m;
+    r.Mp = gptr(m.Mp), r.perm = gptr(m.perm), r.obs0 = gptr(m.obs0), r.actions = gptr(m.actions), r.costs = gptr(m.costs);
+    r.part_c = gptr(m.part_c), r.part_i = gptr(m.part_i), r.part_k = gptr(m.part_k), r.dbg = nullptr, r.nonfinite = gptr(m.nonfinite);
+    return r;
+}
+__device__ __forceinline__ MergeSingleArgs from_device(const MergeSingleArgs& m) {
+    MergeSingleArgs a = m;
+    a.part_k = gptr(m.part_k), a.records = gptr(m.records), a.actions = gptr(m.actions);
+    a.xw.flags = nullptr, a.xw.status = nullptr, a.xw.records = nullptr;   // (world 1: nothing to wait for)
+    a.elites_cur = gptr(m.elites_cur), a.elites_cost_cur = gptr(m.elites_cost_cur);
+    a.elites_next = gptr(m.elites_next), a.elites_cost_next = gptr(m.elites_cost_next);
+    a.mean = gptr(m.mean), a.std = gptr(m.std), a.mean_out = gptr(m.mean_out), a.std_out = gptr(m.std_out);
+    a.low = gptr(m.low), a.high = gptr(m.high), a.executed = gptr(m.executed), a.best_cost = gptr(m.best_cost), a.dbg = nullptr;
+    return a;
+}
+__device__ __forceinline__ void add_base64(uint32_t& lo, uint32_t& hi, unsigned long long base) {
+    const unsigned long long v = (((unsigned long long)hi << 32) | lo) + base;
+    lo = (uint32_t)v;
+    hi = (uint32_t)(v >> 32);
+}
+
 // rollout launch shape: one 16-trajectory tile per wave while they fit, at most FAST_MAX_LISTS workgroups (= lists)
 inline void r16_shape(int n_rows, int* grid, int* waves) {
     const int tiles = std::max(1, (n_rows + 15) / 16);

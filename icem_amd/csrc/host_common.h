@@ -182,6 +182,10 @@ struct icem_handle {
         int disabled = -1;                   // ICEM_NOISE_AHEAD (latched at first use)
         int min_rows = 0;                    // ICEM_NOISE_AHEAD_MIN_ROWS
     } ahead;
+    // icem_plan_step_batch (plan.hip): the device array of the batch's argument blocks lives with the batch's FIRST handle
+    void* batch_ctx = nullptr;
+    void (*batch_ctx_free)(void*) = nullptr;
+    unsigned long long batch_uploads = 0;   // how often that array was (re)written (steady state: never)
     void* rccl_comm = nullptr;       // collective.hip: the RCCL communicator of icem_allgather_elites (world > 1)
     bool rccl_owned = false;         // ... created by icem_rccl_connect (destroyed with the handle) or adopted
 };
@@ -206,7 +210,7 @@ struct ProfScope {
     }
     ProfScope(const icem_handle* hc, int kind_, long long units_, hipStream_t st_)
         : h(const_cast<icem_handle*>(hc)), st(st_), kind(kind_), units(units_) {
-        if (!h->profiling) return;
+        if (!h->profiling || g_batch.rec) return;
         a = get(h);
         b = get(h);
         (void)hipEventRecord(a, st);

@@ -298,6 +298,41 @@ struct FastIterArgs {
     MergeSingleArgs m;  // merge prologue only: the PREVIOUS iteration's merge (last == 0), see sample_rollout_kernel
     PackPrev p;         // ... and its pack (sharded runs)
 };
+// ---- batched planners (icem_plan_step_batch; plan.hip) ----------------------------------------------------------------
+// B independent MPC problems of the same configuration advance together: every launch of the small-population path
+// (sample_rollout_kernel x opt_iters, then the last merge) is ONE launch for all of them -- blockIdx.y = the problem, its
+// argument block read from an array in device memory instead of the kernel-argument segment.  The host side of every
+// handle runs as for a solo step, with the three launchers below RECORDING their arguments (g_batch.rec != nullptr) instead
+// of launching; plan.hip then issues the batched launches.  Same device code (the kernels' bodies are shared), same bits
+// per problem.
+constexpr int ICEM_MAX_BATCH = 32;
+struct BatchBases {          // by value in the kernel-argument segment: the noise stream offset of this MPC step per problem
+    unsigned long long v[ICEM_MAX_BATCH];   // (the offsets in the argument blocks are stored RELATIVE to it: the blocks of a
+};                                          //  steady-state step are the previous same-parity step's, and are not uploaded again)
+struct BatchRecord {
+    int kind = 0;            // 1 sample_rollout, 2 merge_single, 3 merge_noise
+    // kind 1
+    FastIterArgs it;
+    int h = 0, d = 0, O = 0, model_kind = 0, rw = 0, grid = 0;
+    bool prologue = false;
+    // kinds 2, 3
+    MergeSingleArgs m;
+    FastSampleArgs z1, z2;
+};
+struct BatchState {
+    int mult = 1;                       // problems in the running batch: launch shapes are chosen for mult x the rows
+    std::vector<BatchRecord>* rec = nullptr;   // != nullptr: the launchers record here instead of launching
+    bool unsupported = false;           // a launcher without a batched form was reached while recording
+};
+extern thread_local BatchState g_batch;     // (plan.hip)
+struct MergeNoiseBatchArgs {
+    MergeSingleArgs a;
+    FastSampleArgs z1, z2;
+};
+// the batched launches: args[n] in DEVICE memory (offsets relative to bases.v[problem])
+void launch_sample_rollout_batch(const BatchRecord& shape, const FastIterArgs* args_dev, const BatchBases& bases, int n, hipStream_t st);
+void launch_merge_batch(const BatchRecord& shape, const MergeNoiseBatchArgs* args_dev, const BatchBases& bases, int n, hipStream_t st);
+
 // workgroups (= candidate lists) of that launch; 0 if this shape / generator / size has no single-launch kernel
 // (n_tail trailing shifted-elite rows; *tail_out > 0: that many rows behind the lists are scored through the cost array)
 int sample_rollout_lists(int h, int d, int O, int rounds, int n_rows, int n_tail = 0, int* tail_out = nullptr);

@@ -33,8 +33,11 @@ constexpr int sr_threads(int d, int rw) { return (((sr_quad(d, rw) ? 4 : 1) * 16
 
 // ARITH (FastRolloutArgs::arith): 1 = the model step on the 16-bit matrix cores (Tile16H) -- there is no VALU twin of
 // that arithmetic, so the slab is rolled out by RW waves of Tile16H whatever the sampling shape.
+// (the body is a device function: sample_rollout_kernel reads its argument block from the kernel-argument segment,
+//  sample_rollout_batch_kernel -- B problems in one launch, icem_plan_step_batch -- from an array in device memory)
 template <int H, int D, int O, int KIND, int ROUNDS, int RW, int KREG, bool REC, int ARITH>
-__global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sample_rollout_kernel(FastIterArgs a) {
+__device__ __forceinline__ void sample_rollout_body(const FastSampleArgs& sa, const FastRolloutArgs& ra, const MergeSingleArgs& am,
+                                                    const PackPrev& ap) {
     constexpr bool PM = KREG > 0;
     constexpr bool QS = sr_quad(D, RW);
     // T4: with quad sampling there are >= 4 * RW wavefronts in the workgroup anyway: the rollout runs on Tile4 (VALU +
@@ -63,28 +66,26 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
     __shared__ unsigned long long cand[PM ? 64 : 1];
     __shared__ int slot[PM ? 64 : 1];
     float* tile_rows = tilebuf + T16::SLACK;
-    const FastSampleArgs& sa = a.s;
-    const FastRolloutArgs& ra = a.r;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int n_rows = ra.n_rows;       // sa.n sampled rows, then sa.n_shift shifted elites
     // riding pack (sharded runs, merge-prologue launches only): workgroup 0 packs + pushes the previous iteration's records
-    const bool has_pack = PM && REC && a.p.part_k != nullptr;
+    const bool has_pack = PM && REC && ap.part_k != nullptr;
     if constexpr (PM && REC) {
         if (has_pack && blockIdx.x == 0) {
             MergeSingleArgs pk{};
-            pk.n_lists = a.p.n_lists;
-            pk.n_pool = a.p.n_pool;
-            pk.n_global = a.p.n_global;
-            pk.K = a.p.K;
+            pk.n_lists = ap.n_lists;
+            pk.n_pool = ap.n_pool;
+            pk.n_global = ap.n_global;
+            pk.K = ap.K;
             pk.h = H;
             pk.d = D;
-            pk.part_k = a.p.part_k;
-            pk.actions = a.p.actions;
-            pk.n_keep = a.p.n_keep;
-            pk.elites_cost_cur = a.p.keep_costs;
-            pk.keep_base = a.p.n_loc;
+            pk.part_k = ap.part_k;
+            pk.actions = ap.actions;
+            pk.n_keep = ap.n_keep;
+            pk.elites_cost_cur = ap.keep_costs;
+            pk.keep_base = ap.n_loc;
             // everybody else's prologue waits for this workgroup's push: its waves go first on their SIMDs
             __builtin_amdgcn_s_setprio(3);
             if (ra.dbg && tid == 0) ra.dbg[0] = wall_clock64();
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
             }
             __syncthreads();
             if (ra.dbg && tid == 0) ra.dbg[1] = wall_clock64();
-            pack_records_body<12>(pk, a.p.n_loc, a.p.shard_lo, a.p.records, a.p.px, tilebuf, sel, tid, NTT);
+            pack_records_body<12>(pk, ap.n_loc, ap.shard_lo, ap.records, ap.px, tilebuf, sel, tid, NTT);
             if (ra.dbg && tid == 0) ra.dbg[2] = wall_clock64();
             return;
         }
@@ -193,13 +194,13 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
             if constexpr (RW <= 4) __builtin_amdgcn_s_setprio(3);
             if constexpr (REC) {
                 if (ra.dbg && lane == 0 && wg == 0) ra.dbg[3] = wall_clock64();
-                merge_select_records(a.m, lane, cand, sel, slot, (ra.dbg && wg == 0) ? ra.dbg + 7 : nullptr);
+                merge_select_records(am, lane, cand, sel, slot, (ra.dbg && wg == 0) ? ra.dbg + 7 : nullptr);
                 if (ra.dbg && lane == 0 && wg == 0) ra.dbg[4] = wall_clock64();
             }
             else if constexpr (RW >= 8)  // 13 waves share the register file: the low-register selection
-                merge_select_stream(a.m, lane, cand, sel);
+                merge_select_stream(am, lane, cand, sel);
             else
-                merge_select<KREG, (RW == 1)>(a.m, lane, cand, sel);
+                merge_select<KREG, (RW == 1)>(am, lane, cand, sel);
         }
     }
     if (PM) {  // now the rest of the inputs: in flight across the barriers below
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
     const float* rd0 = nullptr;
     if constexpr (!T4) rd0 = tile.read_ptr(tilebuf + (wave < RW ? wave : 0) * 16 * HD, lane, HD);
     if constexpr (PM) {
-        const MergeSingleArgs& m = a.m;
+        const MergeSingleArgs& m = am;
         __syncthreads();
         if (ra.dbg && tid == 0 && wg == 0) ra.dbg[5] = wall_clock64();
         // all threads: gather the elite rows + refit (icem.py:201-211) -> this workgroup's mean / std
@@ -340,6 +341,27 @@ __global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sampl
     if (ra.dbg && tid == 0 && wg == 0) ra.dbg[14] = wall_clock64();
 }
 
+
+template <int H, int D, int O, int KIND, int ROUNDS, int RW, int KREG, bool REC, int ARITH>
+__global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sample_rollout_kernel(FastIterArgs a) {
+    sample_rollout_body<H, D, O, KIND, ROUNDS, RW, KREG, REC, ARITH>(a.s, a.r, a.m, a.p);
+}
+
+// B problems in one launch: blockIdx.y = the problem, its argument block in device memory (scalar loads: the index is
+// uniform), the sampling calls' stream offsets stored relative to the step's base of that problem (BatchBases)
+template <int H, int D, int O, int KIND, int ROUNDS, int RW, int KREG, int ARITH>
+__global__ __launch_bounds__(sr_threads(D, RW) + (KREG > 0 ? 64 : 0)) void sample_rollout_batch_kernel(const FastIterArgs* __restrict__ args,
+                                                                                                      BatchBases bases) {
+    const FastIterArgs& a = args[blockIdx.y];
+    FastSampleArgs s = from_device(a.s);
+    const unsigned long long base = bases.v[blockIdx.y];
+    add_base64(s.off_lo, s.off_hi, base);
+    add_base64(s.off2_lo, s.off2_hi, base);
+    const FastRolloutArgs r = from_device(a.r);
+    const MergeSingleArgs m = from_device(a.m);
+    sample_rollout_body<H, D, O, KIND, ROUNDS, RW, KREG, false, ARITH>(s, r, m, a.p);
+}
+
 }  // namespace
 
 // rollout waves a single-launch workgroup can hold for this shape: 16 * RW * D sampling threads (+ 64) within 1024
@@ -368,6 +390,18 @@ static bool sample_rollout_shape(int h, int d, int O, int rounds, int n_rows, in
     const int max_rw = opt_i(OPT_FUSE_MAX_RW);  // read per call: the path-equivalence test flips it between planners
     int grid, rw, tail = 0;
     r16_shape(n_rows, &grid, &rw);
+    const int mult = g_batch.mult;
+    if (mult > 1) {
+        // a batch of `mult` problems of this size in one launch (icem_plan_step_batch): the slab size the chip would get for
+        // all their rows together, the workgroup count of ONE problem (blockIdx.y is the problem); no tail shape
+        int g_all, rw_all;
+        r16_shape(n_rows * mult, &g_all, &rw_all);
+        const int cap = opt_i(OPT_BATCH_MAX_RW);
+        rw = std::min(std::max(rw, rw_all), std::min(cap > 0 ? cap : 8, single_launch_max_rw(h, d)));
+        while (rw > 1 && rw > single_launch_max_rw(h, d)) rw /= 2;
+        grid = (std::max(1, (n_rows + 15) / 16) + rw - 1) / rw;
+        if (grid > FAST_MAX_LISTS) return false;
+    } else
     if (n_tail > 0 && n_tail <= 64) {
         int g2, w2;
         r16_shape(n_rows - n_tail, &g2, &w2);
@@ -414,6 +448,19 @@ void launch_sample_rollout(const FastIterArgs& a, int h, int d, int O, int kind,
     int grid, rw;
     // (the tail shape only where the caller chose it -- it sets list_wgs then: the list count is the caller's contract)
     if (!sample_rollout_shape(h, d, O, 10, a.r.n_rows, a.r.list_wgs > 0 ? a.s.n_shift : 0, &grid, &rw)) return;
+    if (g_batch.rec) {   // icem_plan_step_batch: recorded, launched for all problems at once (launch_sample_rollout_batch)
+        if (merge_prologue && a.m.records) {
+            g_batch.unsupported = true;
+            return;
+        }
+        BatchRecord r;
+        r.kind = 1;
+        r.it = a;
+        r.h = h, r.d = d, r.O = O, r.model_kind = kind, r.rw = rw, r.grid = grid;
+        r.prologue = merge_prologue;
+        g_batch.rec->push_back(r);
+        return;
+    }
     if (merge_prologue && a.m.records && a.p.part_k) grid += 1;  // workgroup 0: the riding pack
 #define XK(HH, DD, OO, WW, KR, RC)                                                                                      \
     {                                                                                                                   \
@@ -440,6 +487,48 @@ void launch_sample_rollout(const FastIterArgs& a, int h, int d, int O, int kind,
             if (merge_prologue) XK(HH, DD, OO, WW, 12, false)                \
             XK(HH, DD, OO, WW, 0, false)                                     \
         }                                                                    \
+    }
+#define XR(HH, DD, OO)                   \
+    if (h == HH && d == DD && O == OO) { \
+        XW(HH, DD, OO, 1)                \
+        XW(HH, DD, OO, 2)                \
+        XW(HH, DD, OO, 4)                \
+        XW(HH, DD, OO, 8)                \
+    }
+    ICEM_FAST_SHAPES(XR)
+#undef XR
+#undef XW
+#undef XK
+}
+
+// ... and the same launch for n problems (blockIdx.y): shape = one problem's record (all equal: plan.hip checked)
+void launch_sample_rollout_batch(const BatchRecord& s, const FastIterArgs* args_dev, const BatchBases& bases, int n, hipStream_t st) {
+    const int h = s.h, d = s.d, O = s.O, kind = s.model_kind, rw = s.rw, arith = s.it.r.arith;
+    const dim3 grid(s.grid, n);
+#define XK(HH, DD, OO, WW, KR)                                                                                          \
+    {                                                                                                                   \
+        constexpr int NT = sr_threads(DD, WW) + (KR > 0 ? 64 : 0);                                                     \
+        if constexpr (OO <= 20) {                                                                                       \
+            if (arith == 1) {                                                                                           \
+                if (kind == 1)                                                                                          \
+                    hipLaunchKernelGGL((sample_rollout_batch_kernel<HH, DD, OO, 1, 10, WW, KR, 1>), grid, dim3(NT), 0, st, args_dev, bases); \
+                else                                                                                                    \
+                    hipLaunchKernelGGL((sample_rollout_batch_kernel<HH, DD, OO, 0, 10, WW, KR, 1>), grid, dim3(NT), 0, st, args_dev, bases); \
+                return;                                                                                                 \
+            }                                                                                                           \
+        }                                                                                                               \
+        if (kind == 1)                                                                                                  \
+            hipLaunchKernelGGL((sample_rollout_batch_kernel<HH, DD, OO, 1, 10, WW, KR, 0>), grid, dim3(NT), 0, st, args_dev, bases); \
+        else                                                                                                            \
+            hipLaunchKernelGGL((sample_rollout_batch_kernel<HH, DD, OO, 0, 10, WW, KR, 0>), grid, dim3(NT), 0, st, args_dev, bases); \
+        return;                                                                                                         \
+    }
+#define XW(HH, DD, OO, WW)                                  \
+    if constexpr (WW <= single_launch_max_rw(HH, DD)) {     \
+        if (rw == WW) {                                     \
+            if (s.prologue) XK(HH, DD, OO, WW, 12)          \
+            XK(HH, DD, OO, WW, 0)                           \
+        }                                                   \
     }
 #define XR(HH, DD, OO)                   \
     if (h == HH && d == DD && O == OO) { \

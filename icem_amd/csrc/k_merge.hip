@@ -121,6 +121,45 @@ __global__ __launch_bounds__(MERGE_WG) void merge_noise_kernel(MergeSingleArgs a
     }
 }
 
+// The same launch for B problems at once (icem_plan_step_batch): blockIdx.y = the problem, its arguments in device memory,
+// the noise calls' stream offsets relative to the step's base of that problem.  z1.n == 0 for every problem: merge only.
+template <int H, int KREG>
+__global__ __launch_bounds__(MERGE_WG) void merge_noise_batch_kernel(const MergeNoiseBatchArgs* __restrict__ args, BatchBases bases, int wgs1) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const MergeNoiseBatchArgs& g = args[blockIdx.y];
+    if (blockIdx.x == 0) {
+        const MergeSingleArgs a = from_device(g.a);
+        merge_single_body<KREG, false>(a, smem_raw);
+        return;
+    }
+    const bool second = (int)blockIdx.x > wgs1;
+    const FastSampleArgs z = from_device(second ? g.z2 : g.z1);
+    float* tile = reinterpret_cast<float*>(smem_raw);
+    const int d = z.d, hd = H * d, tpw = MERGE_WG / d, tid = threadIdx.x;
+    const int n_base = ((int)blockIdx.x - 1 - (second ? wgs1 : 0)) * tpw;
+    const int n_here = cmin(tpw, z.n - n_base);
+    if (n_here <= 0) return;
+    uint32_t off_lo = z.off_lo, off_hi = z.off_hi;
+    add_base64(off_lo, off_hi, bases.v[blockIdx.y]);
+    if (tid < n_here * d) {
+        const int nl = tid / d;
+        const int j = tid - nl * d;
+        float* trow = tile + nl * hd + j;
+        sample_row<H, 10>(z.W, (unsigned)(z.first_index + n_base + nl), (unsigned)j, off_lo, off_hi, z.seed_lo, z.seed_hi,
+                          [&](int t, float y) { trow[t * d] = y; }, z.white != 0);
+    }
+    __syncthreads();
+    float* gdst = z.out + (size_t)n_base * hd;
+    const int total = n_here * hd;
+    if ((hd & 3) == 0) {
+        const float4* t4 = reinterpret_cast<const float4*>(tile);
+        float4* g4 = reinterpret_cast<float4*>(gdst);
+        for (int e = tid; e < total / 4; e += MERGE_WG) g4[e] = t4[e];
+    } else {
+        for (int e = tid; e < total; e += MERGE_WG) gdst[e] = tile[e];
+    }
+}
+
 // Sharded runs: this rank's K best candidates (same selection) packed as records (pack_records_body) -- a launch of
 // its own where the pack cannot ride in the next iteration's launch (sample_rollout_kernel's workgroup 0).
 // bytes of LDS the pack kernel may use to stage the K records for the push (larger records: separate push launch)
@@ -265,6 +304,15 @@ bool merge_noise_ok(const MergeSingleArgs& a, int rounds) {
 }
 
 void launch_merge_noise(const MergeSingleArgs& a, const FastSampleArgs& z, const FastSampleArgs& z2, hipStream_t st) {
+    if (g_batch.rec) {   // icem_plan_step_batch: recorded, launched for all problems at once (launch_merge_batch)
+        BatchRecord r;
+        r.kind = 3;
+        r.m = a;
+        r.z1 = z;
+        r.z2 = z2;
+        g_batch.rec->push_back(r);
+        return;
+    }
     const int tpw = MERGE_WG / z.d;
     const int wgs1 = (z.n + tpw - 1) / tpw, wgs2 = z2.n > 0 ? (z2.n + tpw - 1) / tpw : 0;
     const int grid = 1 + wgs1 + wgs2;
@@ -278,7 +326,38 @@ void launch_merge_noise(const MergeSingleArgs& a, const FastSampleArgs& z, const
 #undef X
 }
 
+// n problems' last merges (+ the next step's first noise, kind 3) in one launch; the lists form with K <= 11 only
+void launch_merge_batch(const BatchRecord& s, const MergeNoiseBatchArgs* args_dev, const BatchBases& bases, int n, hipStream_t st) {
+    const MergeSingleArgs& a = s.m;
+    int wgs1 = 0, wgs2 = 0, tpw = 1;
+    if (s.kind == 3) {
+        tpw = MERGE_WG / s.z1.d;
+        wgs1 = (s.z1.n + tpw - 1) / tpw;
+        wgs2 = s.z2.n > 0 ? (s.z2.n + tpw - 1) / tpw : 0;
+    }
+    const dim3 grid(1 + wgs1 + wgs2, n);
+    const size_t lds = std::max((size_t)a.h * a.d, s.kind == 3 ? (size_t)tpw * s.z1.h * s.z1.d : (size_t)0) * sizeof(float);
+#define X(HH)                                                                                                              \
+    if (a.h == HH) {                                                                                                       \
+        hipLaunchKernelGGL((merge_noise_batch_kernel<HH, 12>), grid, dim3(MERGE_WG), lds, st, args_dev, bases, wgs1);      \
+        return;                                                                                                            \
+    }
+    ICEM_FAST_HORIZONS(X)
+#undef X
+}
+
 void launch_merge_single(const MergeSingleArgs& a, hipStream_t st) {
+    if (g_batch.rec) {
+        if (a.records || a.K + 1 > 12) {
+            g_batch.unsupported = true;
+            return;
+        }
+        BatchRecord r;
+        r.kind = 2;
+        r.m = a;
+        g_batch.rec->push_back(r);
+        return;
+    }
     const size_t lds = (size_t)a.h * a.d * sizeof(float);
     if (a.records) {
         if (a.K + 1 <= 12)

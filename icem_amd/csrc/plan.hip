@@ -22,6 +22,8 @@ __global__ void publish_result_kernel(const float* executed, const float* best_c
 
 namespace icem {
 
+thread_local BatchState g_batch;   // icem_plan_step_batch: launch-shape hint + the recording launchers (icem_fused.h)
+
 // Build the permuted, zero-padded [A ; B] operand of the matrix-pipe rollout (lazily: it depends on
 // both icem_set_model and icem_set_cost).  Observation entries are reordered so that the linear cost
 // term reads column 0 and the flip term column 0 or 1 -- static registers in the kernel.
@@ -185,6 +187,10 @@ static int one_launch_lists(const icem_handle* h, int n_rows, int n_tail = 0, in
 int launch_fast_rollout(icem_handle* h, int n_rows, int n_cand, int K, const void* obs0, const void* actions,
                         void* costs, float* part_c, int* part_i, hipStream_t st, int* lists_out,
                         unsigned long long* part_k, int n_tail, int* tail_out) {
+    if (g_batch.rec) {   // (no batched form: icem_plan_step_batch checks its configurations up front; belt and braces)
+        g_batch.unsupported = true;
+        return fail(ICEM_E_UNSUPPORTED, "icem_plan_step_batch: this configuration's rollout launch has no batched form");
+    }
     int rc = ensure_fast_model(h);
     if (rc) return rc;
     if (tail_out) *tail_out = 0;
@@ -311,6 +317,10 @@ int launch_fast_sample(const icem_handle* h, int n, long long first_index, const
                        const void* low, const void* high, uint64_t offset, int row0_mean, void* out, hipStream_t st,
                        int n_shift, const void* elites_src, uint64_t offset2) {
     if (n <= 0 && n_shift <= 0) return ICEM_OK;
+    if (g_batch.rec) {
+        g_batch.unsupported = true;
+        return fail(ICEM_E_UNSUPPORTED, "icem_plan_step_batch: this configuration's sampling launch has no batched form");
+    }
     const FastSampleArgs a = fast_sample_args(h, n, first_index, mean, std, low, high, offset, row0_mean, out, n_shift,
                                               elites_src, offset2);
     {
@@ -334,6 +344,10 @@ bool prologue_possible(const icem_handle* h, int n_rows) {
 
 // a stashed merge that found no launch to ride in
 int launch_pending_merge(icem_handle* h, hipStream_t st) {
+    if (g_batch.rec) {
+        g_batch.unsupported = true;
+        return fail(ICEM_E_UNSUPPORTED, "icem_plan_step_batch: a merge found no launch to ride in");
+    }
     const MergeSingleArgs& m = h->pm_args;
     if (m.records == nullptr) {
         ProfScope prof(h, ICEM_K_MERGE_REFIT, m.n_lists * m.K + m.n_keep, st);
@@ -1472,6 +1486,187 @@ int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step,
     if (check_handle(h)) return ICEM_E_INVALID;
     return disarm_on_error(h, plan_step_body(h, b, mpc_step, stream));
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// icem_plan_step_batch: B independent planners, one launch per stage for all of them
+// ---------------------------------------------------------------------------------------------------------------------
+// The reference runs several controllers side by side (parallel episodes: icem/misc/rollout_utils.py:46-58, 129-152), each
+// its own get_action (icem.py:106-189).  At the metric's population (N = 4096) one problem leaves the chip mostly empty and a
+// step is a chain of six launch latencies; B problems of one configuration share those six launches: the host side of
+// every handle runs exactly as for icem_plan_step -- same buffers, same ping-pong, same noise offsets -- with the launchers
+// recording their argument blocks (g_batch.rec), then every stage is ONE launch with blockIdx.y = the problem and the
+// blocks in a device array (one upload per step, skipped when nothing but the step number changed: the offsets are stored
+// relative to the step's base, which travels in the kernel arguments).  Slab sizes are chosen for all rows together.
+struct BatchCtx {
+    void* dev = nullptr;
+    size_t cap = 0;
+    std::vector<unsigned char> shadow;   // what the device array holds
+};
+static void batch_ctx_free(void* p) {
+    BatchCtx* c = (BatchCtx*)p;
+    if (!c) return;
+    if (c->dev) (void)hipFree(c->dev);
+    delete c;
+}
+
+static void sub_base(uint32_t& lo, uint32_t& hi, unsigned long long base) {
+    const unsigned long long v = (((unsigned long long)hi << 32) | lo) - base;
+    lo = (uint32_t)v;
+    hi = (uint32_t)(v >> 32);
+}
+
+// does this handle's step consist of single-launch iterations with merge prologues and one last merge? (the path
+// decisions of plan_step_body / plan_iter_local_t / plan_iter_merge_t, evaluated without launching anything)
+static const char* batch_ineligible(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step) {
+    const icem_config& c = h->cfg;
+    const int K = c.num_elites;
+    if (c.world != 1) return "world must be 1";
+    if (c.dtype != ICEM_F32 || !h->use_fast) return "dtype f32 on the throughput kernels only";
+    if (b->z_r || b->z_i || b->z_r_shift || b->z_i_shift) return "external noise is not batched";
+    if (h->profiling || h->dbg) return "per-kernel profiling / debug stamps are per handle: switch them off";
+    if (gemm_rollout(h) || h->hn_tile || h->Of == 0) return "only the 16-trajectory tile kernels (o <= 20 shapes) are batched";
+    if (!fast_rollout_ok(h, K) || !fast_sample_ok(h) || K + 1 > 12 || c.rng_rounds != 10) return "shape outside the single-launch kernels";
+    if (h->pm_pending || h->pk_pending) return "a deferred merge is pending: finish the MPC step first";
+    if (c.opt_iters < 1) return "opt_iters";
+    if (ahead_eligible(h, b)) return "populations that take the noise-ahead launches (> 8192 rows per iteration) are not batched: they fill the chip alone";
+    for (int it = 0; it < c.opt_iters; ++it) {
+        const int n_extra = (it == 0 && c.shift_elites && mpc_step > 0) ? h->n_reuse : 0;
+        if (n_extra * c.act_dim > 256) return "too many shifted elites for the sampling launch";
+        if (one_launch_lists(h, h->pop[it] + n_extra, n_extra) <= 0) return "an iteration's population has no single-launch kernel";
+        if (it > 0 && !prologue_possible(h, h->pop[it])) return "an iteration cannot carry the previous merge in its prologue";
+    }
+    return nullptr;
+}
+
+extern "C" int icem_plan_step_batch(icem_handle* const* handles, int32_t n, const icem_plan_buffers* buffers, int32_t mpc_step, void* stream) {
+    if (!handles || !buffers || n < 1 || n > ICEM_MAX_BATCH) return fail(ICEM_E_INVALID, "null argument / n outside [1, 32]");
+    for (int i = 0; i < n; ++i)
+        if (!handles[i]) return fail(ICEM_E_INVALID, "null handle");
+    if (n == 1) return icem_plan_step(handles[0], &buffers[0], mpc_step, stream);
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i; ++j)
+            if (handles[i] == handles[j]) return fail(ICEM_E_INVALID, "the same handle twice in one batch");
+    // one configuration (every launch shape and template instantiation is shared); models, costs, seeds, bounds, observations differ
+    const icem_handle* h0 = handles[0];
+    for (int i = 0; i < n; ++i) {
+        icem_handle* h = handles[i];
+        const icem_config &a = h->cfg, &r = h0->cfg;
+        if (a.horizon != r.horizon || a.act_dim != r.act_dim || a.num_traj != r.num_traj || a.num_elites != r.num_elites ||
+            a.elites_size != r.elites_size || a.opt_iters != r.opt_iters || a.use_mean_actions != r.use_mean_actions ||
+            a.keep_previous_elites != r.keep_previous_elites || a.shift_elites != r.shift_elites || a.factor_decrease != r.factor_decrease ||
+            a.fraction_reused != r.fraction_reused || a.rng_rounds != r.rng_rounds || a.dtype != r.dtype || a.world != r.world ||
+            (a.noise_beta > 0) != (r.noise_beta > 0))
+            return fail(ICEM_E_INVALID, "icem_plan_step_batch: the handles must share one configuration (horizon, act_dim, populations, elites, flags)");
+        int rc = check_plan(h, &buffers[i], mpc_step, 0, st);
+        if (rc) return rc;
+        if (h->Of != h0->Of || h->model_kind != h0->model_kind || h->tile_arith != h0->tile_arith)
+            return fail(ICEM_E_INVALID, "icem_plan_step_batch: the handles must share the model's width and kind and the tile arithmetic");
+    }
+    struct MultGuard {
+        MultGuard(int m) { g_batch.mult = m; g_batch.unsupported = false; }
+        ~MultGuard() { g_batch.mult = 1; g_batch.rec = nullptr; }
+    } guard(n);
+    for (int i = 0; i < n; ++i)
+        if (const char* why = batch_ineligible(handles[i], &buffers[i], mpc_step))
+            return fail(ICEM_E_UNSUPPORTED, std::string("icem_plan_step_batch: ") + why);
+    // ---- the host side of every problem's step, recorded ----
+    std::vector<std::vector<BatchRecord>> recs(n);
+    int rc = ICEM_OK;
+    for (int i = 0; i < n && rc == ICEM_OK; ++i) {
+        g_batch.rec = &recs[i];
+        rc = disarm_on_error(handles[i], plan_step_body(handles[i], &buffers[i], mpc_step, stream));
+    }
+    g_batch.rec = nullptr;
+    if (rc == ICEM_OK && g_batch.unsupported) rc = fail(ICEM_E_UNSUPPORTED, "icem_plan_step_batch: a launch without a batched form was reached");
+    const size_t L = recs[0].size();
+    for (int i = 0; i < n && rc == ICEM_OK; ++i) {
+        if (recs[i].size() != L || L == 0) rc = fail(ICEM_E_STATE, "icem_plan_step_batch: the problems' steps took different launches");
+        for (size_t l = 0; l < L && rc == ICEM_OK; ++l) {
+            const BatchRecord &x = recs[i][l], &y = recs[0][l];
+            bool same = x.kind == y.kind;
+            if (same && x.kind == 1)
+                same = x.h == y.h && x.d == y.d && x.O == y.O && x.model_kind == y.model_kind && x.rw == y.rw && x.grid == y.grid &&
+                       x.prologue == y.prologue && x.it.r.arith == y.it.r.arith;
+            if (same && x.kind != 1)
+                same = x.m.h == y.m.h && x.m.d == y.m.d && (x.kind == 2 || (x.z1.n == y.z1.n && x.z2.n == y.z2.n && x.z1.d == y.z1.d && x.z1.h == y.z1.h));
+            if (!same) rc = fail(ICEM_E_STATE, "icem_plan_step_batch: the problems' launches differ in shape");
+        }
+    }
+    if (rc != ICEM_OK) {   // nothing was launched: the handles' half-armed state goes
+        for (int i = 0; i < n; ++i) (void)disarm_on_error(handles[i], rc);
+        return rc;
+    }
+    // ---- argument blocks: offsets relative to each problem's base of this step, one array per launch ----
+    BatchBases bases{};
+    for (int i = 0; i < n; ++i)
+        bases.v[i] = (handles[i]->episode << 32) + (unsigned long long)mpc_step * (unsigned long long)(handles[i]->cfg.opt_iters + 1);
+    std::vector<size_t> at(L);
+    size_t bytes = 0;
+    for (size_t l = 0; l < L; ++l) {
+        at[l] = bytes;
+        const size_t one = recs[0][l].kind == 1 ? sizeof(FastIterArgs) : sizeof(MergeNoiseBatchArgs);
+        bytes += ((one * (size_t)n + 255) / 256) * 256;
+    }
+    std::vector<unsigned char> blob(bytes, 0);
+    for (size_t l = 0; l < L; ++l)
+        for (int i = 0; i < n; ++i) {
+            BatchRecord& r = recs[i][l];
+            if (r.kind == 1) {
+                FastIterArgs a = r.it;
+                if (a.s.n_shift == 0) a.s.off2_lo = (uint32_t)bases.v[i], a.s.off2_hi = (uint32_t)(bases.v[i] >> 32);   // (unused: kept at relative 0)
+                sub_base(a.s.off_lo, a.s.off_hi, bases.v[i]);
+                sub_base(a.s.off2_lo, a.s.off2_hi, bases.v[i]);
+                std::memcpy(blob.data() + at[l] + (size_t)i * sizeof(FastIterArgs), &a, sizeof(a));
+            } else {
+                MergeNoiseBatchArgs g{};
+                g.a = r.m;
+                if (r.kind == 3) {
+                    g.z1 = r.z1;
+                    g.z2 = r.z2;
+                    sub_base(g.z1.off_lo, g.z1.off_hi, bases.v[i]);
+                    sub_base(g.z2.off_lo, g.z2.off_hi, bases.v[i]);
+                    g.z1.off2_lo = g.z1.off2_hi = g.z2.off2_lo = g.z2.off2_hi = 0;
+                } else {
+                    g.z1.n = g.z2.n = 0;
+                }
+                std::memcpy(blob.data() + at[l] + (size_t)i * sizeof(MergeNoiseBatchArgs), &g, sizeof(g));
+            }
+        }
+    icem_handle* owner = handles[0];
+    BatchCtx* ctx = (BatchCtx*)owner->batch_ctx;
+    if (!ctx) {
+        ctx = new BatchCtx();
+        owner->batch_ctx = ctx;
+        owner->batch_ctx_free = batch_ctx_free;
+    }
+    if (ctx->cap < bytes) {
+        if (ctx->dev) (void)hipFree(ctx->dev);
+        ctx->dev = nullptr;
+        ctx->cap = 0;
+        ctx->shadow.clear();
+        ICEM_HIP_TRY(hipMalloc(&ctx->dev, bytes + 4096));
+        ctx->cap = bytes + 4096;
+    }
+    if (ctx->shadow.size() != bytes || std::memcmp(ctx->shadow.data(), blob.data(), bytes) != 0) {
+        // (pageable source: the runtime stages it before returning; ordered behind the previous step's launches on `st`)
+        ICEM_HIP_TRY(hipMemcpyAsync(ctx->dev, blob.data(), bytes, hipMemcpyHostToDevice, st));
+        ctx->shadow = blob;
+        ++owner->batch_uploads;
+    }
+    // ---- the launches ----
+    for (size_t l = 0; l < L; ++l) {
+        const BatchRecord& s = recs[0][l];
+        const unsigned char* base = (const unsigned char*)ctx->dev + at[l];
+        if (s.kind == 1) launch_sample_rollout_batch(s, (const FastIterArgs*)base, bases, n, st);
+        else launch_merge_batch(s, (const MergeNoiseBatchArgs*)base, bases, n, st);
+        ICEM_HIP_TRY(hipGetLastError());
+    }
+    return ICEM_OK;
+}
+
+extern "C" int64_t icem_batch_uploads(const icem_handle* h) { return h ? (int64_t)h->batch_uploads : 0; }
 
 // MpcICem.get_action as one call for a host caller: observation in, executed action (+ its pool's best cost) out.
 // The handle owns a small pinned, device-mapped block [obs | action, best cost | flag].  On the f32 fast path the first

@@ -442,6 +442,38 @@ class IcemPlanner:
                 L.check(merge(h, cb, step, it, st))
         self.mpc_step += 1
 
+    # ------------------------------------------------------------------ B independent planners, one launch per stage
+    @staticmethod
+    def plan_step_batch(planners: Sequence["IcemPlanner"], observations=None):
+        """One MPC step of every planner of ``planners`` (one configuration; models, costs, seeds and observations of their
+        own) as ``icem_plan_step_batch``: the reference's parallel episodes (icem/misc/rollout_utils.py:46-58, 129-152),
+        every stage one launch for all of them.  ``observations``: one per planner (``None``: already in ``planner.obs0``).
+        Each planner's buffers afterwards are bit for bit those of its own :meth:`plan_step`.  Returns the executed actions
+        (device tensors, no host sync)."""
+        pls = list(planners)
+        n = len(pls)
+        if n == 0:
+            return []
+        lib = pls[0].lib
+        step = pls[0].mpc_step
+        for i, pl in enumerate(pls):
+            pl._ensure_buffers()
+            if pl.mpc_step != step:
+                raise ValueError("the planners of a batch advance together: same mpc_step")
+            pl._cb.z_r = pl._cb.z_i = pl._cb.z_r_shift = pl._cb.z_i_shift = None
+            if observations is not None:
+                pl.obs0.copy_(torch.as_tensor(np.asarray(observations[i], dtype=np.float64), dtype=pl.dt), non_blocking=False)
+        hs = (C.c_void_p * n)(*[pl._h for pl in pls])
+        bs = (L.IcemPlanBuffersC * n)(*[pl._cb for pl in pls])
+        L.check(lib.icem_plan_step_batch(hs, n, bs, step, pls[0]._stream()))
+        for pl in pls:
+            pl.mpc_step += 1
+        return [pl.executed for pl in pls]
+
+    @property
+    def batch_uploads(self) -> int:
+        return int(self.lib.icem_batch_uploads(self._h))
+
     # ------------------------------------------------------------------ in-library elite exchange (world > 1)
     def connect_exchange(self, group=None):
         """Set up the in-library elite exchange between the ranks' processes (``icem_exchange_create`` /

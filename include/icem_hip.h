@@ -391,6 +391,19 @@ int icem_plan_step_sharded(icem_handle* h, const icem_plan_buffers* b, int32_t m
  * (the body of MpcICem.get_action, icem.py:123-175). */
 int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, void* stream);
 
+/* B independent planners of ONE configuration -- the reference's parallel episodes, each its own get_action
+ * (icem/misc/rollout_utils.py:46-58, 129-152; icem.py:106-189) -- advanced by one MPC step together: every stage of the
+ * small-population path is one launch for all of them (grid.y = the problem), so the step's chain of launch latencies is paid
+ * once per batch instead of once per problem.  handles[i] with buffers[i]: exactly the arguments icem_plan_step takes; every
+ * problem's outputs (executed action, best cost, mean, std, elites, pool, costs) are bit for bit those of its own
+ * icem_plan_step.  The handles must share horizon, act_dim, populations, elites, flags, model width / kind and tile
+ * arithmetic; models, costs, seeds, bounds and observations are per problem.  world == 1, f32, device noise, o <= 20 tile
+ * shapes, populations that take the single-launch kernel (<= 8192 rows per iteration): otherwise ICEM_E_UNSUPPORTED and
+ * nothing is launched.  n in [1, 32]; n == 1 is icem_plan_step.  No host synchronisation; one small host-to-device copy
+ * on `stream` when the argument blocks changed (the first steps). */
+int icem_plan_step_batch(icem_handle* const* handles, int32_t n, const icem_plan_buffers* buffers, int32_t mpc_step, void* stream);
+int64_t icem_batch_uploads(const icem_handle* h); /* how often handles[0]'s argument array was (re)written (measurement) */
+
 /* Wide observations (32 < obs_dim <= 384; HumanoidStandup's o = 378, environments/mujoco.py:241-277): which matrix-pipe
  * arithmetic the rollout's model step (the GEMM of abstract_models.py:31-53's predict at this width) runs in.  The modes
  * are NAMES, not an accuracy order:
