@@ -24,6 +24,16 @@ namespace icem {
 
 thread_local BatchState g_batch;   // icem_plan_step_batch: launch-shape hint + the recording launchers (icem_fused.h)
 
+// An argument block with EVERY byte defined (padding included): icem_plan_step_batch keeps the blocks of the previous
+// same-parity step and compares bytes to decide whether the device copy is still good.  (Members with a non-zero default:
+// MergeSingleArgs::keep_base, FastRolloutArgs::act_mag / m_scale / b_scale.)
+template <class T>
+static T zeroed_args() {
+    T t;
+    std::memset((void*)&t, 0, sizeof(T));
+    return t;
+}
+
 // Build the permuted, zero-padded [A ; B] operand of the matrix-pipe rollout (lazily: it depends on
 // both icem_set_model and icem_set_cost).  Observation entries are reordered so that the linear cost
 // term reads column 0 and the flip term column 0 or 1 -- static registers in the kernel.
@@ -146,7 +156,7 @@ bool fast_rollout_ok(const icem_handle* h, int K) {
 
 FastRolloutArgs fast_rollout_args(const icem_handle* h, int n_rows, int n_cand, int K, const void* obs0,
                                   const void* actions, void* costs, float* part_c, int* part_i) {
-    FastRolloutArgs a;
+    FastRolloutArgs a = zeroed_args<FastRolloutArgs>();
     a.n_rows = n_rows;
     a.n_cand = n_cand;
     a.K = K;
@@ -288,7 +298,7 @@ bool fast_sample_ok(const icem_handle* h) {
 FastSampleArgs fast_sample_args(const icem_handle* h, int n, long long first_index, const void* mean, const void* std,
                                 const void* low, const void* high, uint64_t offset, int row0_mean, void* out,
                                 int n_shift, const void* elites_src, uint64_t offset2) {
-    FastSampleArgs a;
+    FastSampleArgs a = zeroed_args<FastSampleArgs>();
     a.n = n;
     a.h = h->cfg.horizon;
     a.d = h->cfg.act_dim;
@@ -504,7 +514,8 @@ int plan_iter_local_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
             h->pk_pending = false;
             if (one > 0) {
                 // small populations: sample + rollout + top-K in one launch
-                FastIterArgs fa;
+                FastIterArgs fa = zeroed_args<FastIterArgs>();
+                fa.m.keep_base = -1;
                 if (prologue) fa.m = h->pm_args;
                 if (ride) fa.p = h->pk_args;
                 fa.s = fast_sample_args(h, n_loc, lo, b->mean, b->std, b->low, b->high, off, row0, actions,
@@ -660,7 +671,8 @@ int plan_iter_merge_t(icem_handle* h, const icem_plan_buffers* b, int mpc_step, 
     T* elc = el + (size_t)2 * K * hd;
     if constexpr (std::is_same<T, float>::value) {
         if (c.world == 1 && h->fast_lists > 0) {
-            MergeSingleArgs m;
+            MergeSingleArgs m = zeroed_args<MergeSingleArgs>();
+            m.keep_base = -1;
             m.n_lists = h->fast_lists;
             m.n_keep = (it > 0 && c.keep_previous_elites) ? h->n_reuse : 0;
             const int n_extra = (it == 0 && c.shift_elites && mpc_step > 0) ? h->n_reuse : 0;
@@ -1499,14 +1511,17 @@ int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step,
 // blocks in a device array (one upload per step, skipped when nothing but the step number changed: the offsets are stored
 // relative to the step's base, which travels in the kernel arguments).  Slab sizes are chosen for all rows together.
 struct BatchCtx {
-    void* dev = nullptr;
-    size_t cap = 0;
-    std::vector<unsigned char> shadow;   // what the device array holds
+    // two arrays, by the parity of the MPC step: the elite buffers ping-pong per ITERATION, so with an odd iteration count
+    // consecutive steps' blocks differ in those pointers and every second step's are the same again
+    void* dev[2] = {nullptr, nullptr};
+    size_t cap[2] = {0, 0};
+    std::vector<unsigned char> shadow[2];   // what each device array holds
 };
 static void batch_ctx_free(void* p) {
     BatchCtx* c = (BatchCtx*)p;
     if (!c) return;
-    if (c->dev) (void)hipFree(c->dev);
+    for (void* d : c->dev)
+        if (d) (void)hipFree(d);
     delete c;
 }
 
@@ -1641,24 +1656,28 @@ extern "C" int icem_plan_step_batch(icem_handle* const* handles, int32_t n, cons
         owner->batch_ctx = ctx;
         owner->batch_ctx_free = batch_ctx_free;
     }
-    if (ctx->cap < bytes) {
-        if (ctx->dev) (void)hipFree(ctx->dev);
-        ctx->dev = nullptr;
-        ctx->cap = 0;
-        ctx->shadow.clear();
-        ICEM_HIP_TRY(hipMalloc(&ctx->dev, bytes + 4096));
-        ctx->cap = bytes + 4096;
+    const int slot = mpc_step & 1;
+    if (ctx->cap[slot] < bytes) {
+        if (ctx->dev[slot]) {
+            ICEM_HIP_TRY(hipStreamSynchronize(st));   // (launches of an earlier step may still read the old array)
+            (void)hipFree(ctx->dev[slot]);
+        }
+        ctx->dev[slot] = nullptr;
+        ctx->cap[slot] = 0;
+        ctx->shadow[slot].clear();
+        ICEM_HIP_TRY(hipMalloc(&ctx->dev[slot], bytes + 4096));
+        ctx->cap[slot] = bytes + 4096;
     }
-    if (ctx->shadow.size() != bytes || std::memcmp(ctx->shadow.data(), blob.data(), bytes) != 0) {
-        // (pageable source: the runtime stages it before returning; ordered behind the previous step's launches on `st`)
-        ICEM_HIP_TRY(hipMemcpyAsync(ctx->dev, blob.data(), bytes, hipMemcpyHostToDevice, st));
-        ctx->shadow = blob;
+    if (ctx->shadow[slot].size() != bytes || std::memcmp(ctx->shadow[slot].data(), blob.data(), bytes) != 0) {
+        // (pageable source: the runtime stages it before returning; ordered behind the earlier steps' launches on `st`)
+        ICEM_HIP_TRY(hipMemcpyAsync(ctx->dev[slot], blob.data(), bytes, hipMemcpyHostToDevice, st));
+        ctx->shadow[slot] = blob;
         ++owner->batch_uploads;
     }
     // ---- the launches ----
     for (size_t l = 0; l < L; ++l) {
         const BatchRecord& s = recs[0][l];
-        const unsigned char* base = (const unsigned char*)ctx->dev + at[l];
+        const unsigned char* base = (const unsigned char*)ctx->dev[slot] + at[l];
         if (s.kind == 1) launch_sample_rollout_batch(s, (const FastIterArgs*)base, bases, n, st);
         else launch_merge_batch(s, (const MergeNoiseBatchArgs*)base, bases, n, st);
         ICEM_HIP_TRY(hipGetLastError());

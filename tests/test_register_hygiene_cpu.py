@@ -18,6 +18,9 @@ ALLOWED = [
     (r"sample_rollout_kernel<\d+, \d+, \d+, [01], 10, 2, 12, false, [01]>", 60,
      "two-tile slabs of the single-launch kernel (8k-16k rows): its selection wave spills; measured and left alone in "
      "EXPERIMENTS R3.13 -- 89-90 us per MPC step at N = 12 000-16 000, no faster path for those populations"),
+    (r"sample_rollout_batch_kernel<\d+, \d+, \d+, [01], 10, 2, 12, [01]>", 60,
+     "the same body as sample_rollout_kernel<..., 2, 12, false, ...> (icem_plan_step_batch reads its argument blocks from device "
+     "memory): the same spills at two-tile slabs; a batch takes that slab size only between 2 and 4 problems of <= 2048 rows"),
     (r"iter_ahead_kernel<30, 6, 17, [01], [48], [012], 1>", 16,
      "the fp16-plane tile (Tile16H: two operand planes of the model and of the state) on the 128 registers of the noise-ahead "
      "launch: 9-14 spills, at the staging points every ten steps -- and the launch wins by 11-14 %: 140.8 vs 157.2 us per MPC "
