@@ -139,6 +139,7 @@ SYMBOLS = [
     ("icem_profile_overhead", C.c_int, [_VP, _I32, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("icem_plan_step_batch", C.c_int, [C.POINTER(_H), _I32, C.POINTER(IcemPlanBuffersC), _I32, _VP]),
     ("icem_batch_uploads", C.c_int64, [_H]),
+    ("icem_step_status", C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int32), _VP]),
     ("icem_tile_growth", C.c_double, [_H]),
     ("icem_nonfinite_costs", C.c_int, [_H, C.POINTER(C.c_int64), _VP]),
     ("icem_set_option", C.c_int, [C.c_char_p, C.c_double]),

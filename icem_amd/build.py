@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 UNITS = ["generic_kernels.hip", "plan.hip", "abi.hip", "exchange.hip", "k_sample.hip", "k_rollout.hip", "k_merge.hip",
          "k_iter_small.hip", "icem_rssm.hip", "icem_rssm_split.hip", "k_rollout_wide.hip", "collective.hip", "k_rollout_ahead.hip",
-         "k_rollout_wide_split.hip", "k_rollout_hn.hip"]
+         "k_rollout_wide_split.hip", "k_rollout_hn.hip", "k_step_xcd.hip"]
 OUT = os.path.join(HERE, "libicem_hip.so")
 # the same objects with exchange.hip compiled under -DICEM_FAULT_INJECTION (ICEM_XCHG_FAIL drills: tests/test_gpu_exchange_faults.py
 # loads it through ICEM_HIP_LIB); the product library carries no fault injection

@@ -261,6 +261,8 @@ int icem_destroy(icem_handle* h) {
     if (h->W_dev) (void)hipFree(h->W_dev);
     if (h->nonfinite_dev) (void)hipFree(h->nonfinite_dev);
     if (h->batch_ctx && h->batch_ctx_free) h->batch_ctx_free(h->batch_ctx);
+    for (void* p : {h->sx.state, h->sx.raw, h->sx.pre[0], h->sx.pre[1], h->sx.shift})
+        if (p) (void)hipFree(p);
     if (h->actions_alt) (void)hipFree(h->actions_alt);
     if (h->host_stage) (void)hipHostFree(h->host_stage);
     if (h->ws_alt) (void)hipFree(h->ws_alt);

@@ -1188,21 +1188,28 @@ __device__ __forceinline__ int keep_index0(const MergeSingleArgs& a) { return a.
 // inserted into their lanes' first lists (a KREG-step compare-exchange chain, 0.56 us).  Measured per caller: the last
 // merge 6.52 -> 6.21 us and the one-tile single-launch kernel 10.07 -> 9.80 us with it, but the two- and four-tile
 // single-launch kernels +0.8 / +0.5 us per launch (N = 8192: 83.3 -> 87.7 us per MPC step) -- those keep the insertion.
-template <int KREG, bool KEPT_APART = false>
+// COH: every load of another workgroup's data bypasses this CU's L1 (sc1: served by the L2) -- for callers INSIDE a launch whose
+// lists were written by other workgroups of the same launch (step_xcd_kernel); LISTS: lists per lane (64 x LISTS >= n_lists).
+template <bool COH, class T>
+__device__ __forceinline__ T ld_coh(const T* p) {
+    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <int KREG, bool KEPT_APART = false, bool COH = false, int LISTS = LPL>
 __device__ __forceinline__ void merge_select(const MergeSingleArgs& a, int lane, unsigned long long* cand,
                                              unsigned long long* sel) {
-    unsigned long long k[LPL][KREG];
+    unsigned long long k[LISTS][KREG];
     // (the kept elite's cost comes from another buffer: requested first, consumed behind the lists)
-    const float keep_cost = a.elites_cost_cur ? a.elites_cost_cur[lane < a.n_keep ? lane : 0] : 0.f;
+    const float keep_cost = a.elites_cost_cur ? ld_coh<COH>(a.elites_cost_cur + (lane < a.n_keep ? lane : 0)) : 0.f;
 #pragma unroll
-    for (int l = 0; l < LPL; ++l) {
+    for (int l = 0; l < LISTS; ++l) {
         const int list = lane + l * 64;
 #pragma unroll
         for (int i = 0; i < KREG; ++i)
-            k[l][i] = a.part_k[(size_t)(i < a.K ? i : 0) * a.n_lists + (list < a.n_lists ? list : 0)];
+            k[l][i] = ld_coh<COH>(a.part_k + (size_t)(i < a.K ? i : 0) * a.n_lists + (list < a.n_lists ? list : 0));
     }
 #pragma unroll
-    for (int l = 0; l < LPL; ++l) {
+    for (int l = 0; l < LISTS; ++l) {
         const bool has_list = lane + l * 64 < a.n_lists;
 #pragma unroll
         for (int i = 0; i < KREG; ++i) k[l][i] = (has_list && i < a.K) ? k[l][i] : KEY_SENTINEL;
@@ -1232,22 +1239,22 @@ __device__ __forceinline__ void merge_select(const MergeSingleArgs& a, int lane,
     if (a.dbg && threadIdx.x == 0) a.dbg[2] = wall_clock64();
     unsigned long long mine = k[0][0];
 #pragma unroll
-    for (int l = 1; l < LPL; ++l) mine = k[l][0] < mine ? k[l][0] : mine;
+    for (int l = 1; l < LISTS; ++l) mine = k[l][0] < mine ? k[l][0] : mine;
     const unsigned srt = wave_sort64_u32((unsigned)(mine >> 32), lane);
     const unsigned T = __shfl(srt, a.K - 1, 64);
     unsigned n_cand = 0;  // wave-uniform
 #pragma unroll
     for (int i = 0; i < KREG; ++i) {
-        bool p[LPL];
+        bool p[LISTS];
         bool any_lane = false;
 #pragma unroll
-        for (int l = 0; l < LPL; ++l) {
+        for (int l = 0; l < LISTS; ++l) {
             p[l] = (unsigned)(k[l][i] >> 32) <= T && k[l][i] != KEY_SENTINEL;
             any_lane |= p[l];
         }
         if (__ballot(any_lane) == 0) break;
 #pragma unroll
-        for (int l = 0; l < LPL; ++l) {
+        for (int l = 0; l < LISTS; ++l) {
             const unsigned long long m = __ballot(p[l]);
             if (m != 0) {
                 const unsigned pos = n_cand + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -1276,7 +1283,7 @@ __device__ __forceinline__ void merge_select(const MergeSingleArgs& a, int lane,
         for (int r = 0; r < a.K; ++r) {
             unsigned long long head = k[0][0];
 #pragma unroll
-            for (int l = 1; l < LPL; ++l) head = k[l][0] < head ? k[l][0] : head;
+            for (int l = 1; l < LISTS; ++l) head = k[l][0] < head ? k[l][0] : head;
             if constexpr (KEPT_APART) head = kept < head ? kept : head;
             const unsigned long long best = wave_min_u64(head);
             if (best != KEY_SENTINEL) {  // keys embed the trajectory index: exactly one (lane, list) matches
@@ -1284,7 +1291,7 @@ __device__ __forceinline__ void merge_select(const MergeSingleArgs& a, int lane,
                     if (kept == best) kept = KEY_SENTINEL;
                 }
 #pragma unroll
-                for (int l = 0; l < LPL; ++l) {
+                for (int l = 0; l < LISTS; ++l) {
                     if (k[l][0] == best) {
 #pragma unroll
                         for (int i = 0; i + 1 < KREG; ++i) k[l][i] = k[l][i + 1];

@@ -182,6 +182,20 @@ struct icem_handle {
         int disabled = -1;                   // ICEM_NOISE_AHEAD (latched at first use)
         int min_rows = 0;                    // ICEM_NOISE_AHEAD_MIN_ROWS
     } ahead;
+    // the step of a small population as one launch inside one XCD (plan.hip::plan_step_xcd; k_step_xcd.hip)
+    struct StepXcd {
+        void* state = nullptr;         // counters (zero between launches)
+        void* raw = nullptr;           // raw noise of iterations 0 .. iters - 1 of the running step: [sum pop][h*d]
+        void* pre[2] = {nullptr, nullptr};   // iteration 0's noise of the NEXT step, by the parity of that step
+        void* shift = nullptr;         // [16][h*d] rows + [16] costs of the shifted elites
+        unsigned long long launches = 0;
+        bool pre_valid = false;        // pre[pre_step & 1] holds the noise of (pre_episode, pre_step), enqueued on pre_stream
+        uint64_t pre_episode = 0;
+        int pre_step = -1;
+        hipStream_t pre_stream = nullptr;
+        bool disabled = false;         // a bounded wait ran out once (icem_step_status): the handle keeps to the launches per iteration
+        int cus = 0;                   // compute units of the device (the kernel is built around 8 XCDs x 32)
+    } sx;
     // icem_plan_step_batch (plan.hip): the device array of the batch's argument blocks lives with the batch's FIRST handle
     void* batch_ctx = nullptr;
     void (*batch_ctx_free)(void*) = nullptr;

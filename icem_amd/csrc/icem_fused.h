@@ -333,6 +333,49 @@ struct MergeNoiseBatchArgs {
 void launch_sample_rollout_batch(const BatchRecord& shape, const FastIterArgs* args_dev, const BatchBases& bases, int n, hipStream_t st);
 void launch_merge_batch(const BatchRecord& shape, const MergeNoiseBatchArgs* args_dev, const BatchBases& bases, int n, hipStream_t st);
 
+// ---- the whole MPC step of a small population as ONE launch inside one XCD (k_step_xcd.hip; plan.hip::plan_step_xcd) ------
+constexpr int STEP_XCD_MAX_ITERS = 8, STEP_XCD_MAX_SEG = STEP_XCD_MAX_ITERS + 1;
+struct StepXcdArgs {
+    FastRolloutArgs r;            // model, cost, obs0, costs, K, arithmetic (actions / part_k / n_rows: set per iteration by the kernel)
+    int iters, K, n_reuse, n_shift, keep, use_mean, white, g0;
+    int pop[STEP_XCD_MAX_ITERS];  // rows of iteration it (<= 4096)
+    float alpha, init_std;
+    float* pool[2];               // pool of iteration it = pool[(iters - 1 - it) & 1] (the last iteration's: the caller's)
+    unsigned long long* lists[2]; // [K][32] keys of iteration it = lists[it & 1]
+    float* elites;                // [2][K][h*d]
+    float* elites_cost;           // [2][K]
+    const float* mean;            // the step's first distribution ...
+    const float* std;
+    float* mean_out;              // ... and what the epilogue leaves (the same buffers)
+    float* std_out;
+    const float* low;
+    const float* high;
+    float* executed;
+    float* best_cost;
+    // colored noise: segment s < iters = iteration s of this step (seg_n == 0: drawn by the previous step's launch), segment
+    // iters = iteration 0 of the NEXT step
+    const float* W;
+    uint32_t seed_lo, seed_hi;
+    int n_seg, n_jobs;
+    int seg_n[STEP_XCD_MAX_SEG], seg_chunk0[STEP_XCD_MAX_SEG + 1];
+    uint32_t seg_off_lo[STEP_XCD_MAX_SEG], seg_off_hi[STEP_XCD_MAX_SEG];
+    float* seg_out[STEP_XCD_MAX_SEG];
+    const float* raw[STEP_XCD_MAX_ITERS];   // where the members find iteration it's raw rows
+    // the shifted elites (icem.py:91-104): previous elite set, noise stream of the call, rows / costs of their own
+    const float* shift_src;
+    uint32_t shift_off_lo, shift_off_hi;
+    float* shift_rows;            // [16][h*d]
+    float* shift_costs;           // [16]
+    unsigned* state;              // step_xcd_state_bytes()
+    unsigned bar_base;            // the members' barrier counter before this launch (cumulative over the handle's launches)
+    unsigned max_polls;
+};
+size_t step_xcd_state_bytes();
+int step_xcd_max_rows();
+int step_xcd_rows_per_member();
+bool step_xcd_supported(int h, int d, int O, int K);
+void launch_step_xcd(const StepXcdArgs& a, int h, int d, int O, int kind, hipStream_t st);
+
 // workgroups (= candidate lists) of that launch; 0 if this shape / generator / size has no single-launch kernel
 // (n_tail trailing shifted-elite rows; *tail_out > 0: that many rows behind the lists are scored through the cost array)
 int sample_rollout_lists(int h, int d, int O, int rounds, int n_rows, int n_tail = 0, int* tail_out = nullptr);

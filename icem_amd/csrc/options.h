@@ -33,6 +33,7 @@ namespace icem {
     X(RSSM_SPLIT, "rssm_split", 1.0)                                                                                       \
     X(RSSM_SPLIT_MAX_N, "rssm_split_max_n", 65536.0)                                                                       \
     X(RSSM_SPLIT_TT, "rssm_split_tt", 0.0)                                                                                 \
+    X(STEP_XCD, "step_xcd", 0.0)                     /* 1: populations <= 4096 rows take ONE launch per MPC step inside one XCD (k_step_xcd.hip: bit-equal, measured SLOWER -- 87 vs 61 us; EXPERIMENTS R6.4) */ \
     X(BATCH_MAX_RW, "batch_max_rw", 0.0)             /* icem_plan_step_batch: cap of the tiles per workgroup (0: as one population of all rows) */ \
     X(XCHG_LOOPBACK, "xchg_loopback", 0.0)           /* 1: time one rank without its peers (tools/sharded_rank_bench.py) */ \
     X(XCHG_MAX_POLLS, "xchg_max_polls", 0.0)         /* bound of the exchange's device-side waits (0: the default) */

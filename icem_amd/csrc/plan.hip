@@ -1434,12 +1434,158 @@ int icem_plan_step_sharded(icem_handle* h, const icem_plan_buffers* b, int32_t m
     return disarm_on_error(h, plan_step_sharded_body(h, b, mpc_step, stream));
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The step of a small population as ONE launch inside one XCD (k_step_xcd.hip)
+// ---------------------------------------------------------------------------------------------------------------------
+static bool step_xcd_eligible(icem_handle* h, const icem_plan_buffers* b) {
+    const icem_config& c = h->cfg;
+    if (!opt_i(OPT_STEP_XCD) || h->sx.disabled || g_batch.rec) return false;
+    if (c.world != 1 || c.dtype != ICEM_F32 || !h->use_fast || b->z_r != nullptr || c.rng_rounds != 10) return false;
+    if (h->dbg != nullptr && !opt_i(OPT_AHEAD_STAMPS)) return false;   // (another kernel is under study; option ahead_stamps = 1: this one's stamps)
+    if (gemm_rollout(h) || h->hn_tile || h->Of == 0 || !fast_rollout_ok(h, c.num_elites) || !fast_sample_ok(h)) return false;
+    if (!step_xcd_supported(c.horizon, c.act_dim, h->Of, c.num_elites) || c.opt_iters > STEP_XCD_MAX_ITERS) return false;
+    for (int n : h->pop)
+        if (n > step_xcd_max_rows()) return false;
+    if (h->n_reuse > 16 || h->n_reuse > c.num_elites) return false;
+    if (h->sx.cus == 0) {
+        hipDeviceProp_t p;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) {
+            (void)hipGetLastError();
+            h->sx.cus = -1;
+        } else {
+            h->sx.cus = p.multiProcessorCount;
+        }
+    }
+    return h->sx.cus == 256;   // 8 XCDs x 32 CUs, one workgroup each (a partitioned or masked device keeps the launches per iteration)
+}
+
+static int plan_step_xcd(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, hipStream_t st) {
+    const icem_config& c = h->cfg;
+    icem_handle::StepXcd& X = h->sx;
+    const int iters = c.opt_iters, K = c.num_elites, hd = h->hd;
+    int rc = ensure_fast_model(h);
+    if (rc) return rc;
+    // buffers of the handle: the partner pool and list array of the launches-per-iteration path, raw noise, shift rows, state
+    if (iters > 1 && !h->actions_alt) ICEM_HIP_TRY(hipMalloc(&h->actions_alt, icem_plan_buffer_bytes(h, ICEM_BUF_ACTIONS)));
+    if (iters > 1 && !h->ws_alt) ICEM_HIP_TRY(hipMalloc(&h->ws_alt, icem_plan_buffer_bytes(h, ICEM_BUF_WORKSPACE)));
+    size_t rows_all = 0;
+    for (int n : h->pop) rows_all += (size_t)n;
+    if (!X.raw) ICEM_HIP_TRY(hipMalloc(&X.raw, (rows_all + 16) * hd * sizeof(float)));
+    for (void*& p : X.pre)
+        if (!p) ICEM_HIP_TRY(hipMalloc(&p, ((size_t)h->pop[0] + 16) * hd * sizeof(float)));
+    if (!X.shift) ICEM_HIP_TRY(hipMalloc(&X.shift, ((size_t)16 * hd + 64) * sizeof(float)));
+    if (!X.state) {
+        ICEM_HIP_TRY(hipMalloc(&X.state, step_xcd_state_bytes()));
+        ICEM_HIP_TRY(hipMemset(X.state, 0, step_xcd_state_bytes()));
+    }
+    StepXcdArgs a;
+    std::memset((void*)&a, 0, sizeof(a));
+    a.r = fast_rollout_args(h, 0, 0, K, b->obs0, nullptr, b->costs, nullptr, nullptr);
+    a.iters = iters;
+    a.K = K;
+    a.n_reuse = h->n_reuse;
+    a.n_shift = (c.shift_elites && mpc_step > 0 && h->n_reuse > 0) ? h->n_reuse : 0;
+    a.keep = c.keep_previous_elites ? 1 : 0;
+    a.use_mean = c.use_mean_actions ? 1 : 0;
+    a.white = c.noise_beta <= 0 ? 1 : 0;
+    a.g0 = (int)(((long long)mpc_step * iters) & 1);
+    for (int it = 0; it < iters; ++it) a.pop[it] = h->pop[it];
+    a.alpha = (float)c.alpha;
+    a.init_std = (float)c.init_std;
+    a.pool[0] = (float*)b->actions;
+    a.pool[1] = (float*)(iters > 1 ? h->actions_alt : b->actions);
+    a.lists[0] = (unsigned long long*)b->workspace;
+    a.lists[1] = (unsigned long long*)(iters > 1 ? h->ws_alt : b->workspace);
+    a.elites = (float*)b->elites;
+    a.elites_cost = a.elites + (size_t)2 * K * hd;
+    a.mean = (const float*)b->mean;
+    a.std = (const float*)b->std;
+    a.mean_out = (float*)b->mean;
+    a.std_out = (float*)b->std;
+    a.low = (const float*)b->low;
+    a.high = (const float*)b->high;
+    a.executed = (float*)b->executed;
+    a.best_cost = (float*)b->best_cost;
+    a.W = (const float*)h->W_dev;
+    a.seed_lo = (uint32_t)c.seed;
+    a.seed_hi = (uint32_t)(c.seed >> 32);
+    const uint64_t call_base = (h->episode << 32) + (uint64_t)mpc_step * (uint64_t)(iters + 1);
+    // iteration 0's noise: drawn by the previous step's launch on this stream, or here
+    const bool pre0 = X.pre_valid && X.pre_episode == h->episode && X.pre_step == mpc_step && X.pre_stream == st;
+    const int rpm = step_xcd_rows_per_member();
+    a.n_seg = iters + 1;
+    size_t at = 0;
+    int chunks = 0;
+    for (int s = 0; s <= iters; ++s) {
+        const bool next0 = s == iters;
+        const int n = next0 ? h->pop[0] : ((s == 0 && pre0) ? 0 : h->pop[s]);
+        const uint64_t off = next0 ? call_base + (uint64_t)(iters + 1) : call_base + (uint64_t)s;
+        a.seg_n[s] = n;
+        a.seg_off_lo[s] = (uint32_t)off;
+        a.seg_off_hi[s] = (uint32_t)(off >> 32);
+        a.seg_chunk0[s] = chunks;
+        chunks += (n + rpm - 1) / rpm;
+        if (next0) {
+            a.seg_out[s] = (float*)X.pre[(mpc_step + 1) & 1];
+        } else {
+            a.seg_out[s] = (float*)X.raw + at * hd;
+            a.raw[s] = (s == 0 && pre0) ? (const float*)X.pre[mpc_step & 1] : a.seg_out[s];
+            at += (size_t)h->pop[s];
+        }
+    }
+    a.seg_chunk0[iters + 1] = chunks;
+    a.n_jobs = chunks + (a.n_shift > 0 ? 1 : 0);
+    a.shift_src = a.elites + (size_t)a.g0 * K * hd;   // the previous step's elite set
+    const uint64_t soff = call_base + (uint64_t)iters;
+    a.shift_off_lo = (uint32_t)soff;
+    a.shift_off_hi = (uint32_t)(soff >> 32);
+    a.shift_rows = (float*)X.shift;
+    a.shift_costs = (float*)X.shift + (size_t)16 * hd + 32;   // (a cache line of its own behind the rows)
+    a.state = (unsigned*)X.state;
+    a.bar_base = (unsigned)(X.launches * (unsigned long long)iters * 32ull);
+    a.max_polls = 1u << 22;
+    long long units = 0;
+    for (int n : h->pop) units += (long long)n * c.horizon;
+    {
+        ProfScope prof(h, ICEM_K_SAMPLE_ROLLOUT, units, st);
+        launch_step_xcd(a, c.horizon, c.act_dim, h->Of, h->model_kind, st);
+    }
+    ICEM_HIP_TRY(hipGetLastError());
+    ++X.launches;
+    X.pre_valid = true;
+    X.pre_episode = h->episode;
+    X.pre_step = mpc_step + 1;
+    X.pre_stream = st;
+    // what the launches-per-iteration path keeps across steps does not describe this step
+    h->ahead.pre_valid = h->ahead.tail_pending = false;
+    h->fast_lists = 0;
+    return ICEM_OK;
+}
+
+extern "C" int icem_step_status(icem_handle* h, int64_t* xcd_launches_out, int32_t* timed_out_out, void* stream) {
+    if (check_handle(h)) return ICEM_E_INVALID;
+    if (xcd_launches_out) *xcd_launches_out = (int64_t)h->sx.launches;
+    unsigned v = 0;
+    if (h->sx.state) {
+        hipStream_t st = (hipStream_t)stream;
+        ICEM_HIP_TRY(hipMemcpyAsync(&v, (const unsigned*)h->sx.state + 28, sizeof(v), hipMemcpyDeviceToHost, st));
+        ICEM_HIP_TRY(hipStreamSynchronize(st));
+    }
+    if (v) h->sx.disabled = true;
+    if (timed_out_out) *timed_out_out = v ? 1 : 0;
+    return ICEM_OK;
+}
+
 static int plan_step_body(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step, void* stream) {
     if (h->cfg.world != 1) return fail(ICEM_E_INVALID, "icem_plan_step is the world == 1 path; use iter_local/iter_merge");
     int rc = check_plan(h, b, mpc_step, 0, (hipStream_t)stream);
     if (rc) return rc;
     const icem_config& c = h->cfg;
     const int iters = c.opt_iters;
+    if (step_xcd_eligible(h, b)) return plan_step_xcd(h, b, mpc_step, (hipStream_t)stream);
+    h->sx.pre_valid = false;   // (a step on the launches-per-iteration path: the noise a one-launch step drew ahead is not its)
     if (ahead_eligible(h, b)) return plan_step_ahead(h, b, mpc_step, (hipStream_t)stream);
     // f32, device noise: iteration it's merge may ride in the prologue of iteration it+1's launch.  That launch
     // reads pool / lists / distribution of iteration it while writing its own, so consecutive iterations alternate

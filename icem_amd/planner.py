@@ -350,6 +350,13 @@ class IcemPlanner:
         (``icem_tile_growth``): what decides whether the fp16-plane tiles are served (<= 2^10)."""
         return float(self.lib.icem_tile_growth(self._h))
 
+    def step_status(self) -> Tuple[int, bool]:
+        """(MPC steps served by the one-launch kernel of small populations, whether one of its bounded waits ever ran out)
+        -- ``icem_step_status``; synchronises the launch stream."""
+        n, t = C.c_int64(), C.c_int32()
+        L.check(self.lib.icem_step_status(self._h, C.byref(n), C.byref(t), self._stream()))
+        return int(n.value), bool(t.value)
+
     def nonfinite_costs(self) -> int:
         """Trajectories since the planner was made whose cost left a tile kernel NaN (``icem_nonfinite_costs``;
         synchronises the launch stream)."""

@@ -404,6 +404,15 @@ int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step,
 int icem_plan_step_batch(icem_handle* const* handles, int32_t n, const icem_plan_buffers* buffers, int32_t mpc_step, void* stream);
 int64_t icem_batch_uploads(const icem_handle* h); /* how often handles[0]'s argument array was (re)written (measurement) */
 
+/* Under option step_xcd = 1 (icem_set_option; OFF by default: built, bit for bit the default path's results, and measured
+ * slower -- 87 against 61 us per MPC step at N = 4096, EXPERIMENTS R6.4) icem_plan_step / icem_get_action serve a small
+ * population (every iteration <= 4096 rows, the o <= 20 tile shapes, f32, device noise, a 256-CU device) with ONE launch per
+ * MPC step whose rollout workgroups all sit on one XCD and meet at the iteration boundaries inside its L2 (k_step_xcd.hip);
+ * every wait of that launch is bounded.  icem_step_status: how many such launches the handle has issued and whether a wait
+ * ever ran out (then that step's outputs are not valid, and the handle keeps to one launch per iteration from here on).
+ * Copies one word back and synchronises `stream`. */
+int icem_step_status(icem_handle* h, int64_t* xcd_launches_out, int32_t* timed_out_out, void* stream);
+
 /* Wide observations (32 < obs_dim <= 384; HumanoidStandup's o = 378, environments/mujoco.py:241-277): which matrix-pipe
  * arithmetic the rollout's model step (the GEMM of abstract_models.py:31-53's predict at this width) runs in.  The modes
  * are NAMES, not an accuracy order:

@@ -21,6 +21,11 @@ ALLOWED = [
     (r"sample_rollout_batch_kernel<\d+, \d+, \d+, [01], 10, 2, 12, [01]>", 60,
      "the same body as sample_rollout_kernel<..., 2, 12, false, ...> (icem_plan_step_batch reads its argument blocks from device "
      "memory): the same spills at two-tile slabs; a batch takes that slab size only between 2 and 4 problems of <= 2048 rows"),
+    (r"step_xcd_kernel<\d+, \d+, \d+, [01], [01]>", 56,
+     "the one-launch step inside one XCD (option step_xcd = 1, OFF by default): 9-50 spills around the raw-noise vectors it keeps "
+     "in registers across the merge -- and not what decides it: eight rollout waves on one CU are pipe-bound at 6.6 us per "
+     "iteration against 3.9 for a lone wave per CU; it measured 87 against 61 us per MPC step and is not the shipped path "
+     "(EXPERIMENTS R6.4)"),
     (r"iter_ahead_kernel<30, 6, 17, [01], [48], [012], 1>", 16,
      "the fp16-plane tile (Tile16H: two operand planes of the model and of the state) on the 128 registers of the noise-ahead "
      "launch: 9-14 spills, at the staging points every ten steps -- and the launch wins by 11-14 %: 140.8 vs 157.2 us per MPC "
