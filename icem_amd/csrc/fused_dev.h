@@ -1410,6 +1410,64 @@ __device__ __forceinline__ void merge_select_records(const MergeSingleArgs& a, i
     (void)cand;
 }
 
+// The same selection by the WHOLE workgroup (round 6): the K rounds of a wave minimum above are a chain of K dependent
+// reductions -- 3.7 us for K = 10 on the critical path of every sharded launch (stamps: EXPERIMENTS R6.5) -- while the
+// workgroup's other waves wait at the barrier behind it.  Here ONE wave (`stager`) waits for the exchange and parks the keys
+// (<= 128 records + <= 64 kept elites) in LDS; then every thread counts for one (candidate, part): a key's place is the
+// number of smaller keys (keys embed the global row: all different), places < K go straight to sel / slot.  Two barriers
+// and a dozen compares per thread.  Called by ALL `nthr` threads of the workgroup at one point; ends behind a barrier.
+__device__ __forceinline__ void merge_select_records_wg(const MergeSingleArgs& a, bool stager, int lane, int tid, int nthr,
+                                                        unsigned long long* sel, int* slot, long long* stamp = nullptr) {
+    __shared__ unsigned long long rk_keys[192];
+    __shared__ unsigned rk_rank[192];
+    const int K = a.K, rs = a.h * a.d + 2;
+    if (stager) {
+        xchg_wait(a.xw, lane);  // in-library exchange: the peers' records of this iteration have landed
+        if (stamp && lane == 0) *stamp = wall_clock64();
+        auto rec_key = [&](int e) -> unsigned long long {
+            if (e >= a.n_rec) return KEY_SENTINEL;
+            const float* rec = a.records + (size_t)e * rs;
+            return make_key(rec[0], reinterpret_cast<const int*>(rec + 1)[0]);
+        };
+        rk_keys[lane] = rec_key(lane);
+        rk_keys[64 + lane] = rec_key(lane + 64);
+        rk_keys[128 + lane] = lane < a.n_keep ? make_key(a.elites_cost_cur[lane], a.n_global + lane) : KEY_SENTINEL;
+        rk_rank[lane] = rk_rank[64 + lane] = rk_rank[128 + lane] = 0u;
+        sel[lane] = KEY_SENTINEL;   // fewer than K live candidates: reference behaviour undefined, stay in bounds
+        slot[lane] = 0;
+    }
+    __syncthreads();
+    // live candidate c: record c (c < n_rec) at rk_keys[c], kept elite c - n_rec at rk_keys[128 + c - n_rec]
+    const int n_rec = a.n_rec, n_live = n_rec + a.n_keep;
+    auto at = [&](int c) { return c < n_rec ? c : 128 + (c - n_rec); };
+    int parts = n_live > 0 ? nthr / n_live : 1;
+    parts = parts < 1 ? 1 : (parts > 8 ? 8 : parts);
+    if (n_live > 0 && tid < n_live * parts) {
+        const int c = tid % n_live, p = tid / n_live;
+        const unsigned long long mine = rk_keys[at(c)];
+        unsigned cnt = 0;
+        for (int j = p; j < n_live; j += parts) cnt += rk_keys[at(j)] < mine ? 1u : 0u;
+        if (cnt) atomicAdd(&rk_rank[at(c)], cnt);
+    }
+    if (n_live > nthr)   // (never with the shipped workgroup sizes: n_live <= 192; kept for completeness)
+        for (int c = nthr + tid; c < n_live; c += nthr) {
+            const unsigned long long mine = rk_keys[at(c)];
+            unsigned cnt = 0;
+            for (int j = 0; j < n_live; ++j) cnt += rk_keys[at(j)] < mine ? 1u : 0u;
+            rk_rank[at(c)] = cnt;
+        }
+    __syncthreads();
+    for (int c = tid; c < n_live; c += nthr) {
+        const unsigned long long mine = rk_keys[at(c)];
+        const unsigned r = rk_rank[at(c)];
+        if (mine != KEY_SENTINEL && r < (unsigned)K) {
+            sel[r] = mine;
+            slot[r] = c;   // (record number; n_rec + e for kept elite e)
+        }
+    }
+    __syncthreads();
+}
+
 // The same selection spread over the NW wavefronts of a workgroup, for a merge prologue that has NOTHING to hide behind
 // (rollout16_ahead_kernel: every wave waits for the distribution).  merge_select_stream walks the lists with dependent
 // loads -- a dozen L2 round trips, 12-14 us when exposed (measured) -- and merge_select holds all 4 x K keys of a lane in

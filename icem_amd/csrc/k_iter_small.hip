@@ -193,9 +193,8 @@ __device__ __forceinline__ void sample_rollout_body(const FastSampleArgs& sa, co
             // rollout waves the sampling is the longer one and the priority costs 0.7 us)
             if constexpr (RW <= 4) __builtin_amdgcn_s_setprio(3);
             if constexpr (REC) {
+                // (the records: staged by this wave, ranked by ALL threads behind the sampling -- merge_select_records_wg below)
                 if (ra.dbg && lane == 0 && wg == 0) ra.dbg[3] = wall_clock64();
-                merge_select_records(am, lane, cand, sel, slot, (ra.dbg && wg == 0) ? ra.dbg + 7 : nullptr);
-                if (ra.dbg && lane == 0 && wg == 0) ra.dbg[4] = wall_clock64();
             }
             else if constexpr (RW >= 8)  // 13 waves share the register file: the low-register selection
                 merge_select_stream(am, lane, cand, sel);
@@ -211,7 +210,12 @@ __device__ __forceinline__ void sample_rollout_body(const FastSampleArgs& sa, co
     if constexpr (!T4) rd0 = tile.read_ptr(tilebuf + (wave < RW ? wave : 0) * 16 * HD, lane, HD);
     if constexpr (PM) {
         const MergeSingleArgs& m = am;
-        __syncthreads();
+        if constexpr (REC) {
+            merge_select_records_wg(am, tid >= NT, lane, tid, NTT, sel, slot, (ra.dbg && wg == 0) ? ra.dbg + 7 : nullptr);
+            if (ra.dbg && tid == 0 && wg == 0) ra.dbg[4] = wall_clock64();
+        } else {
+            __syncthreads();
+        }
         if (ra.dbg && tid == 0 && wg == 0) ra.dbg[5] = wall_clock64();
         // all threads: gather the elite rows + refit (icem.py:201-211) -> this workgroup's mean / std
         const float* rows[KREG > 0 ? KREG : 1];

@@ -28,14 +28,14 @@ __device__ __forceinline__ void merge_single_body(const MergeSingleArgs& a, unsi
         om[i] = (pre && e < hd) ? a.mean[e] : 0.f;
         os[i] = (pre && e < hd) ? a.std[e] : 0.f;
     }
-    if (tid < 64) {
-        if constexpr (REC)
-            merge_select_records(a, lane, cand, sel, slot);
-        else
-            merge_select<KREG, true>(a, lane, cand, sel);
+    if constexpr (REC) {
+        merge_select_records_wg(a, tid < 64, lane, tid, MERGE_WG, sel, slot);   // (all threads: the records' keys ranked by counting)
+        if (a.dbg && threadIdx.x == 0) a.dbg[4] = wall_clock64();
+    } else {
+        if (tid < 64) merge_select<KREG, true>(a, lane, cand, sel);
+        if (a.dbg && threadIdx.x == 0) a.dbg[4] = wall_clock64();
+        __syncthreads();
     }
-    if (a.dbg && threadIdx.x == 0) a.dbg[4] = wall_clock64();
-    __syncthreads();
     // ---- all 4 waves: gather + refit (icem.py:201-211); row pointers first, then all K loads in flight ----
     const float* rows[KREG];
     merge_rows<KREG, REC>(a, sel, slot, rows);

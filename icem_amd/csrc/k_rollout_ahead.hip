@@ -103,8 +103,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
             pack_records_body<KREG>(pk, args.p.n_loc, args.p.shard_lo, args.p.records, args.p.px, stage, sel, tid, NTT);
             __syncthreads();
             const MergeSingleArgs& m = args.m;
-            if (wave == 0) merge_select_records(m, lane, cand, sel, slot);
-            __syncthreads();
+            merge_select_records_wg(m, wave == 0, lane, tid, NTT, sel, slot);
             const float* rows[KREG];
             merge_rows<KREG, true>(m, sel, slot, rows);
             for (int e = tid; e < HD; e += NTT) {

@@ -190,8 +190,7 @@ __global__ __launch_bounds__(SWG + 64) void sample_folded_merge_kernel(FastSampl
                 // XCDs' L2s are not coherent inside a launch; then one agent-scope flag).  Hundreds of workgroups each
                 // reading the same 7 KB of records from uncached memory was the slowest part of this launch.
                 __syncthreads();
-                if (tid >= SWG) merge_select_records(m, lane, cand, sel, slot);
-                __syncthreads();
+                merge_select_records_wg(m, tid >= SWG, lane, tid, NTT, sel, slot);
                 const float* rows[KREG];
                 merge_rows<KREG, true>(m, sel, slot, rows);
                 for (int e = tid; e < hd; e += NTT) {
@@ -232,16 +231,15 @@ __global__ __launch_bounds__(SWG + 64) void sample_folded_merge_kernel(FastSampl
                 __builtin_amdgcn_s_sleep(16);
             if (polls > args.m.xw.max_polls && lane == 0 && args.m.xw.status)
                 __hip_atomic_store(args.m.xw.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        } else if constexpr (REC) {
-            merge_select_records(m, lane, cand, sel, slot);
-        } else {
+        } else if constexpr (!REC) {
             merge_select_stream(m, lane, cand, sel);
         }
     } else if (has_row) {
         sample_row<H, ROUNDS>(a.W, (unsigned)(a.first_index + n_base + nl), (unsigned)j, a.off_lo, a.off_hi, a.seed_lo,
                               a.seed_hi, [&](int t, float y) { trow[t * d] = y; }, a.white != 0);
     }
-    __syncthreads();
+    if (REC && !published) merge_select_records_wg(m, tid >= SWG, lane, tid, NTT, sel, slot);   // (the records' keys ranked by all threads)
+    else __syncthreads();
     if (published) {
         for (int e = tid; e < 2 * hd; e += NTT) ms[e] = __hip_atomic_load(args.p.pub + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
