@@ -447,6 +447,12 @@ def timed_steps(pl, steps, warmup, world, spread=None):
         try:
             run_steps(pl, n, world)
         except L.IcemError as ex:
+            # Only the in-library exchange has no collective INSIDE a step: a rank may leave the block early and meet its peers at
+            # the all-reduce below.  On the RCCL / host-driven paths the peers are inside a step's all-gather: leaving it would
+            # deadlock them -- there the error ends this rank (and with it the run: the launcher takes the others down).
+            safe = getattr(pl, "leaves_block_safely", None)   # (the CPU test's stand-in planner says so itself)
+            if world > 1 and not (bool(getattr(pl, "_exchange", False)) if safe is None else safe):
+                raise
             failed = 1.0
             print(f"bench.py: rank {pl.cfg.rank}: {ex}", file=sys.stderr)
         sync()
@@ -469,6 +475,7 @@ def timed_steps(pl, steps, warmup, world, spread=None):
             el, failed = float(t[0].item()), float(t[1].item())
             if not failed and float(t[2].item()) != -float(t[3].item()):
                 failed = 1.0
+                pl._degrade_reason = "the ranks' distributions differed after a timed block (records stale or torn on some rank)"
                 if spread is not None:
                     spread["_ranks_disagreed"] = spread.get("_ranks_disagreed", 0) + 1
                 if pl.cfg.rank == 0:
@@ -560,7 +567,7 @@ def measure_also(name, rank=0, world=1, steps=200, warmup=20, global_n=None):
     return out
 
 
-def measure_batched(name="c2", batches=(2, 4, 8), steps=100, warmup=10, solo_ms=None):
+def measure_batched(name="c2", batches=(2, 4, 8, 16), steps=100, warmup=12, solo_ms=None):
     """B independent planners of the headline configuration (different models' seeds, costs and observations; the reference's
     parallel episodes, icem/misc/rollout_utils.py:46-58, 129-152) advanced by icem_plan_step_batch: every stage one launch for
     all of them.  Per B: ms per (batched) MPC step, aggregate traj-steps/s over all problems, the whole loop's algorithmic

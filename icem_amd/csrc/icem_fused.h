@@ -310,7 +310,7 @@ struct BatchBases {          // by value in the kernel-argument segment: the noi
     unsigned long long v[ICEM_MAX_BATCH];   // (the offsets in the argument blocks are stored RELATIVE to it: the blocks of a
 };                                          //  steady-state step are the previous same-parity step's, and are not uploaded again)
 struct BatchRecord {
-    int kind = 0;            // 1 sample_rollout, 2 merge_single, 3 merge_noise
+    int kind = 0;            // 1 sample_rollout, 2 merge_single, 3 merge_noise, 4 iter_ahead (rw = waves per workgroup, grid = rollout workgroups)
     // kind 1
     FastIterArgs it;
     int h = 0, d = 0, O = 0, model_kind = 0, rw = 0, grid = 0;
@@ -318,9 +318,12 @@ struct BatchRecord {
     // kinds 2, 3
     MergeSingleArgs m;
     FastSampleArgs z1, z2;
+    // kind 4
+    IterAheadArgs ia;
 };
 struct BatchState {
     int mult = 1;                       // problems in the running batch: launch shapes are chosen for mult x the rows
+    bool ahead = false;                 // ... and the batch may take the noise-ahead launches where all its rows together fill them
     std::vector<BatchRecord>* rec = nullptr;   // != nullptr: the launchers record here instead of launching
     bool unsupported = false;           // a launcher without a batched form was reached while recording
 };
@@ -332,6 +335,7 @@ struct MergeNoiseBatchArgs {
 // the batched launches: args[n] in DEVICE memory (offsets relative to bases.v[problem])
 void launch_sample_rollout_batch(const BatchRecord& shape, const FastIterArgs* args_dev, const BatchBases& bases, int n, hipStream_t st);
 void launch_merge_batch(const BatchRecord& shape, const MergeNoiseBatchArgs* args_dev, const BatchBases& bases, int n, hipStream_t st);
+void launch_iter_ahead_batch(const BatchRecord& shape, const IterAheadArgs* args_dev, const BatchBases& bases, int n, hipStream_t st);
 
 // ---- the whole MPC step of a small population as ONE launch inside one XCD (k_step_xcd.hip; plan.hip::plan_step_xcd) ------
 constexpr int STEP_XCD_MAX_ITERS = 8, STEP_XCD_MAX_SEG = STEP_XCD_MAX_ITERS + 1;

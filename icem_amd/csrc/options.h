@@ -34,6 +34,8 @@ namespace icem {
     X(RSSM_SPLIT_MAX_N, "rssm_split_max_n", 65536.0)                                                                       \
     X(RSSM_SPLIT_TT, "rssm_split_tt", 0.0)                                                                                 \
     X(STEP_XCD, "step_xcd", 0.0)                     /* 1: populations <= 4096 rows take ONE launch per MPC step inside one XCD (k_step_xcd.hip: bit-equal, measured SLOWER -- 87 vs 61 us; EXPERIMENTS R6.4) */ \
+    X(BATCH_AHEAD, "batch_ahead", 1.0)               /* icem_plan_step_batch: 0 = always the single-launch kernels (never the noise-ahead launches) */ \
+    X(BATCH_AHEAD_MIN_ROWS, "batch_ahead_min_rows", 49152.0)   /* ... from this many rows of all problems' first iterations together */ \
     X(BATCH_MAX_RW, "batch_max_rw", 0.0)             /* icem_plan_step_batch: cap of the tiles per workgroup (0: as one population of all rows) */ \
     X(XCHG_LOOPBACK, "xchg_loopback", 0.0)           /* 1: time one rank without its peers (tools/sharded_rank_bench.py) */ \
     X(XCHG_MAX_POLLS, "xchg_max_polls", 0.0)         /* bound of the exchange's device-side waits (0: the default) */

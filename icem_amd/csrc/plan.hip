@@ -956,7 +956,8 @@ static int plan_step_ahead(icem_handle* h, const icem_plan_buffers* b, int mpc_s
             n1_done = (hit && iters > 1 && A.next1_pool == pool_of(1)) ? std::min(A.next1_rows, h->pop[1]) : 0;
             A.next1_rows = 0;
         }
-        IterAheadArgs ia{};
+        IterAheadArgs ia = zeroed_args<IterAheadArgs>();
+        ia.m.keep_base = -1;
         ia.r = fast_rollout_args(h, n, n, K, b->obs0, pool, b->costs, nullptr, nullptr);
         ia.r.part_k = (unsigned long long*)bb.workspace;
         ia.dbg_slot = it;
@@ -988,7 +989,7 @@ static int plan_step_ahead(icem_handle* h, const icem_plan_buffers* b, int mpc_s
             const int n_here = h->pop[0] - n_tail;
             ia.z = noise_args(n_here, off0, np);
             A.tail_pending = n_tail > 0;
-            A.tail2_args = FastSampleArgs{};
+            A.tail2_args = zeroed_args<FastSampleArgs>();
             A.tail2_args.n = 0;
             if (n_tail > 0) {
                 A.tail_args = noise_args(n_tail, off0, (float*)np + (size_t)n_here * hd);
@@ -1033,6 +1034,7 @@ static int plan_step_ahead(icem_handle* h, const icem_plan_buffers* b, int mpc_s
         h->merge_mean_out = h->merge_std_out = nullptr;
         if (rc) return rc;
         if (last && A.tail_pending) {  // (the merge could not take it along: launches of their own)
+            if (g_batch.rec) g_batch.unsupported = true;   // (icem_plan_step_batch: these would run AHEAD of the recorded launches)
             launch_noise_rows(A.tail_args, c.rng_rounds, st);
             if (A.tail2_args.n > 0) launch_noise_rows(A.tail2_args, c.rng_rounds, st);
             ICEM_HIP_TRY(hipGetLastError());
@@ -1657,11 +1659,12 @@ int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step,
 // blocks in a device array (one upload per step, skipped when nothing but the step number changed: the offsets are stored
 // relative to the step's base, which travels in the kernel arguments).  Slab sizes are chosen for all rows together.
 struct BatchCtx {
-    // two arrays, by the parity of the MPC step: the elite buffers ping-pong per ITERATION, so with an odd iteration count
-    // consecutive steps' blocks differ in those pointers and every second step's are the same again
-    void* dev[2] = {nullptr, nullptr};
-    size_t cap[2] = {0, 0};
-    std::vector<unsigned char> shadow[2];   // what each device array holds
+    // six arrays, by the MPC step modulo 6: the elite buffers ping-pong per ITERATION (with an odd iteration count every second
+    // step's blocks are the same again), the noise-ahead launches rotate three pools per step: 2 x 3 steps close every cycle
+    static constexpr int SLOTS = 6;
+    void* dev[SLOTS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t cap[SLOTS] = {0, 0, 0, 0, 0, 0};
+    std::vector<unsigned char> shadow[SLOTS];   // what each device array holds
 };
 static void batch_ctx_free(void* p) {
     BatchCtx* c = (BatchCtx*)p;
@@ -1690,7 +1693,18 @@ static const char* batch_ineligible(icem_handle* h, const icem_plan_buffers* b, 
     if (!fast_rollout_ok(h, K) || !fast_sample_ok(h) || K + 1 > 12 || c.rng_rounds != 10) return "shape outside the single-launch kernels";
     if (h->pm_pending || h->pk_pending) return "a deferred merge is pending: finish the MPC step first";
     if (c.opt_iters < 1) return "opt_iters";
-    if (ahead_eligible(h, b)) return "populations that take the noise-ahead launches (> 8192 rows per iteration) are not batched: they fill the chip alone";
+    // (g_batch.mult is set: the shapes below are the batch's.)  Where every iteration's rows of ALL problems together fill the
+    // noise-ahead launch (>= 4 waves per rollout workgroup), the batch takes that path -- rollout, next noise and shifted elites
+    // as roles of one launch (k_rollout_ahead.hip), 107 against 130 us per step at eight problems of 4096 rows -- provided a
+    // problem ALONE does not take it (a population above 8192 rows fills the chip by itself: not batched)
+    {
+        const bool ah = g_batch.ahead;
+        g_batch.ahead = false;
+        const bool alone = ahead_eligible(h, b);
+        g_batch.ahead = ah;
+        if (alone) return "populations that take the noise-ahead launches alone (> 8192 rows per iteration) are not batched: they fill the chip by themselves";
+    }
+    if (ahead_eligible(h, b)) return nullptr;   // (false without g_batch.ahead: option batch_ahead = 0)
     for (int it = 0; it < c.opt_iters; ++it) {
         const int n_extra = (it == 0 && c.shift_elites && mpc_step > 0) ? h->n_reuse : 0;
         if (n_extra * c.act_dim > 256) return "too many shifted elites for the sampling launch";
@@ -1726,9 +1740,15 @@ extern "C" int icem_plan_step_batch(icem_handle* const* handles, int32_t n, cons
             return fail(ICEM_E_INVALID, "icem_plan_step_batch: the handles must share the model's width and kind and the tile arithmetic");
     }
     struct MultGuard {
-        MultGuard(int m) { g_batch.mult = m; g_batch.unsupported = false; }
-        ~MultGuard() { g_batch.mult = 1; g_batch.rec = nullptr; }
-    } guard(n);
+        MultGuard(int m, long long rows0) {
+            g_batch.mult = m;
+            g_batch.unsupported = false;
+            // the noise-ahead launches from where they measure faster than the single-launch kernels: 12 problems of 4096 rows
+            // (160 against 161 us per step; 16: 194 against 212; 8: 129 against 128; 6: 115 against 100 -- EXPERIMENTS R6.3)
+            g_batch.ahead = opt_i(OPT_BATCH_AHEAD) != 0 && (double)m * (double)rows0 >= opt(OPT_BATCH_AHEAD_MIN_ROWS);
+        }
+        ~MultGuard() { g_batch.mult = 1; g_batch.rec = nullptr; g_batch.ahead = false; }
+    } guard(n, h0->pop.empty() ? 0 : h0->pop[0]);
     for (int i = 0; i < n; ++i)
         if (const char* why = batch_ineligible(handles[i], &buffers[i], mpc_step))
             return fail(ICEM_E_UNSUPPORTED, std::string("icem_plan_step_batch: ") + why);
@@ -1750,7 +1770,11 @@ extern "C" int icem_plan_step_batch(icem_handle* const* handles, int32_t n, cons
             if (same && x.kind == 1)
                 same = x.h == y.h && x.d == y.d && x.O == y.O && x.model_kind == y.model_kind && x.rw == y.rw && x.grid == y.grid &&
                        x.prologue == y.prologue && x.it.r.arith == y.it.r.arith;
-            if (same && x.kind != 1)
+            if (same && x.kind == 4)
+                same = x.h == y.h && x.d == y.d && x.O == y.O && x.model_kind == y.model_kind && x.rw == y.rw && x.grid == y.grid &&
+                       x.ia.has_merge == y.ia.has_merge && x.ia.r.arith == y.ia.r.arith && x.ia.z.n == y.ia.z.n &&
+                       x.ia.s.n_shift == y.ia.s.n_shift && x.ia.n_noise == y.ia.n_noise;
+            if (same && x.kind != 1 && x.kind != 4)
                 same = x.m.h == y.m.h && x.m.d == y.m.d && (x.kind == 2 || (x.z1.n == y.z1.n && x.z2.n == y.z2.n && x.z1.d == y.z1.d && x.z1.h == y.z1.h));
             if (!same) rc = fail(ICEM_E_STATE, "icem_plan_step_batch: the problems' launches differ in shape");
         }
@@ -1767,7 +1791,7 @@ extern "C" int icem_plan_step_batch(icem_handle* const* handles, int32_t n, cons
     size_t bytes = 0;
     for (size_t l = 0; l < L; ++l) {
         at[l] = bytes;
-        const size_t one = recs[0][l].kind == 1 ? sizeof(FastIterArgs) : sizeof(MergeNoiseBatchArgs);
+        const size_t one = recs[0][l].kind == 1 ? sizeof(FastIterArgs) : recs[0][l].kind == 4 ? sizeof(IterAheadArgs) : sizeof(MergeNoiseBatchArgs);
         bytes += ((one * (size_t)n + 255) / 256) * 256;
     }
     std::vector<unsigned char> blob(bytes, 0);
@@ -1780,14 +1804,32 @@ extern "C" int icem_plan_step_batch(icem_handle* const* handles, int32_t n, cons
                 sub_base(a.s.off_lo, a.s.off_hi, bases.v[i]);
                 sub_base(a.s.off2_lo, a.s.off2_hi, bases.v[i]);
                 std::memcpy(blob.data() + at[l] + (size_t)i * sizeof(FastIterArgs), &a, sizeof(a));
+            } else if (r.kind == 4) {
+                IterAheadArgs a = r.ia;
+                a.r.dbg = nullptr;
+                if (a.z.n > 0) sub_base(a.z.off_lo, a.z.off_hi, bases.v[i]);
+                else a.z.off_lo = a.z.off_hi = 0;
+                if (a.s.n_shift > 0) {
+                    sub_base(a.s.off_lo, a.s.off_hi, bases.v[i]);
+                    sub_base(a.s.off2_lo, a.s.off2_hi, bases.v[i]);
+                } else {
+                    a.s.off_lo = a.s.off_hi = a.s.off2_lo = a.s.off2_hi = 0;
+                }
+                unsigned char* dst = blob.data() + at[l] + (size_t)i * sizeof(IterAheadArgs);
+                std::memcpy(dst, &a, sizeof(a));
+                // (the struct's tail padding is not carried by its copies: defined here, or every step's block "changes")
+                constexpr size_t tail = offsetof(IterAheadArgs, dbg_slot) + sizeof(int);
+                std::memset(dst + tail, 0, sizeof(IterAheadArgs) - tail);
             } else {
                 MergeNoiseBatchArgs g{};
                 g.a = r.m;
                 if (r.kind == 3) {
                     g.z1 = r.z1;
                     g.z2 = r.z2;
-                    sub_base(g.z1.off_lo, g.z1.off_hi, bases.v[i]);
-                    sub_base(g.z2.off_lo, g.z2.off_hi, bases.v[i]);
+                    if (g.z1.n > 0) sub_base(g.z1.off_lo, g.z1.off_hi, bases.v[i]);
+                    else g.z1.off_lo = g.z1.off_hi = 0;
+                    if (g.z2.n > 0) sub_base(g.z2.off_lo, g.z2.off_hi, bases.v[i]);
+                    else g.z2.off_lo = g.z2.off_hi = 0;
                     g.z1.off2_lo = g.z1.off2_hi = g.z2.off2_lo = g.z2.off2_hi = 0;
                 } else {
                     g.z1.n = g.z2.n = 0;
@@ -1802,7 +1844,7 @@ extern "C" int icem_plan_step_batch(icem_handle* const* handles, int32_t n, cons
         owner->batch_ctx = ctx;
         owner->batch_ctx_free = batch_ctx_free;
     }
-    const int slot = mpc_step & 1;
+    const int slot = mpc_step % BatchCtx::SLOTS;
     if (ctx->cap[slot] < bytes) {
         if (ctx->dev[slot]) {
             ICEM_HIP_TRY(hipStreamSynchronize(st));   // (launches of an earlier step may still read the old array)
@@ -1815,6 +1857,18 @@ extern "C" int icem_plan_step_batch(icem_handle* const* handles, int32_t n, cons
         ctx->cap[slot] = bytes + 4096;
     }
     if (ctx->shadow[slot].size() != bytes || std::memcmp(ctx->shadow[slot].data(), blob.data(), bytes) != 0) {
+        if (opt_i(OPT_AHEAD_STAMPS) && ctx->shadow[slot].size() == bytes) {   // development: which bytes moved
+            int shown = 0;
+            for (size_t l = 0; l < L && shown < 12; ++l) {
+                const size_t one = recs[0][l].kind == 1 ? sizeof(FastIterArgs) : recs[0][l].kind == 4 ? sizeof(IterAheadArgs) : sizeof(MergeNoiseBatchArgs);
+                for (size_t o = 0; o < one * (size_t)n && shown < 12; ++o)
+                    if (blob[at[l] + o] != ctx->shadow[slot][at[l] + o]) {
+                        std::fprintf(stderr, "batch args changed: step %d launch %zu kind %d problem %zu byte %zu\n", mpc_step, l, recs[0][l].kind, o / one, o % one);
+                        ++shown;
+                        o = (o / 8 + 1) * 8 - 1;
+                    }
+            }
+        }
         // (pageable source: the runtime stages it before returning; ordered behind the earlier steps' launches on `st`)
         ICEM_HIP_TRY(hipMemcpyAsync(ctx->dev[slot], blob.data(), bytes, hipMemcpyHostToDevice, st));
         ctx->shadow[slot] = blob;
@@ -1825,6 +1879,7 @@ extern "C" int icem_plan_step_batch(icem_handle* const* handles, int32_t n, cons
         const BatchRecord& s = recs[0][l];
         const unsigned char* base = (const unsigned char*)ctx->dev[slot] + at[l];
         if (s.kind == 1) launch_sample_rollout_batch(s, (const FastIterArgs*)base, bases, n, st);
+        else if (s.kind == 4) launch_iter_ahead_batch(s, (const IterAheadArgs*)base, bases, n, st);
         else launch_merge_batch(s, (const MergeNoiseBatchArgs*)base, bases, n, st);
         ICEM_HIP_TRY(hipGetLastError());
     }

@@ -538,7 +538,10 @@ class IcemPlanner:
         if was_exchange:
             status = self.exchange_status()[0] | int(getattr(self, "_xchg_status_seen", 0))   # read and clear
             self._xchg_status_seen = 0
-            self.exchange_error = f"run time: a wait for a peer's elite records timed out (status word {status})"
+            why = getattr(self, "_degrade_reason", None)   # (set by the caller when the trigger was not a timeout)
+            self._degrade_reason = None
+            self.exchange_error = (f"run time: {why} (status word {status})" if why and not (status & 1) else
+                                   f"run time: a wait for a peer's elite records timed out (status word {status})")
             L.check(self.lib.icem_exchange_disable(self._h))
             self._exchange = False
         elif getattr(self, "_rccl", False):

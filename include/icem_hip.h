@@ -398,8 +398,9 @@ int icem_plan_step(icem_handle* h, const icem_plan_buffers* b, int32_t mpc_step,
  * problem's outputs (executed action, best cost, mean, std, elites, pool, costs) are bit for bit those of its own
  * icem_plan_step.  The handles must share horizon, act_dim, populations, elites, flags, model width / kind and tile
  * arithmetic; models, costs, seeds, bounds and observations are per problem.  world == 1, f32, device noise, o <= 20 tile
- * shapes, populations that take the single-launch kernel (<= 8192 rows per iteration): otherwise ICEM_E_UNSUPPORTED and
- * nothing is launched.  n in [1, 32]; n == 1 is icem_plan_step.  No host synchronisation; one small host-to-device copy
+ * shapes, populations that take the single-launch kernel alone (<= 8192 rows per iteration): otherwise ICEM_E_UNSUPPORTED and
+ * nothing is launched.  (From 49 152 rows of all problems together the batch takes the noise-ahead launches of large
+ * populations -- k_rollout_ahead.hip -- instead of the single-launch kernels: measured faster from there on.)  n in [1, 32]; n == 1 is icem_plan_step.  No host synchronisation; one small host-to-device copy
  * on `stream` when the argument blocks changed (the first steps). */
 int icem_plan_step_batch(icem_handle* const* handles, int32_t n, const icem_plan_buffers* buffers, int32_t mpc_step, void* stream);
 int64_t icem_batch_uploads(const icem_handle* h); /* how often handles[0]'s argument array was (re)written (measurement) */

@@ -123,6 +123,7 @@ class _StandInPlanner:
         self.cfg = SimpleNamespace(rank=rank, world=2)
         self.path, self.calls, self.fail_rank, self.fail_from = "ipc", 0, fail_rank, fail_from
         self._exchange = False    # (no status word to read: the failure shows as an exception)
+        self.leaves_block_safely = True   # the in-library exchange has no collective inside a step (bench.timed_steps)
         self.degraded = []
 
     def plan_step_resident(self):

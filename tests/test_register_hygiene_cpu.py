@@ -21,6 +21,11 @@ ALLOWED = [
     (r"sample_rollout_batch_kernel<\d+, \d+, \d+, [01], 10, 2, 12, [01]>", 60,
      "the same body as sample_rollout_kernel<..., 2, 12, false, ...> (icem_plan_step_batch reads its argument blocks from device "
      "memory): the same spills at two-tile slabs; a batch takes that slab size only between 2 and 4 problems of <= 2048 rows"),
+    (r"iter_ahead_batch_kernel<30, 6, 1[78], [01], [48], [01], [01]>", 32,
+     "the noise-ahead launch with its argument block read from device memory (icem_plan_step_batch, eight or more problems of "
+     "4096 rows): the text of iter_ahead_kernel (iter_ahead_body.h) with the block's scalars held across the roles -- 9-23 "
+     "spills on 128 registers, the same class as the by-value kernel's, and the batch is faster with it than on the "
+     "single-launch kernels (EXPERIMENTS R6.3)"),
     (r"step_xcd_kernel<\d+, \d+, \d+, [01], [01]>", 56,
      "the one-launch step inside one XCD (option step_xcd = 1, OFF by default): 9-50 spills around the raw-noise vectors it keeps "
      "in registers across the merge -- and not what decides it: eight rollout waves on one CU are pipe-bound at 6.6 us per "

@@ -11,7 +11,9 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG-rec
 mkdir -p $OUT
 cd $ROOT
-timeout 1200 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.txt 2>&1; tail -1 $OUT/pytest_gpu.txt
+rm -f $ROOT/gpurun_out/literal_bounds.jsonl
+timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.txt 2>&1; tail -1 $OUT/pytest_gpu.txt
+cp $ROOT/gpurun_out/literal_bounds.jsonl $OUT/literal_bounds.jsonl 2> /dev/null
 for w in c2 c4 c3 c5; do timeout 900 bash tools/profile_round.sh $TAG $w > /dev/null 2>&1; done
 cd $ROOT
 timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 300 $OUT/bench_default.json
@@ -22,11 +24,12 @@ for w in door relocate fpp; do timeout 300 python bench.py --workload $w --no-al
 # first-contact drills of the records' path: two ranks on this box's GPU(s), every injected failure must end on a fallback path
 {
   for f in none connect selftest:0 timeout:1:40; do
-    if [ $f = none ]; then unset ICEM_XCHG_FAIL; else export ICEM_XCHG_FAIL=$f; fi
+    # (the product library carries no fault injection: the drills load its twin, libicem_hip_faults.so)
+    if [ $f = none ]; then unset ICEM_XCHG_FAIL ICEM_HIP_LIB; else export ICEM_XCHG_FAIL=$f ICEM_HIP_LIB=$ROOT/icem_amd/libicem_hip_faults.so; fi
     echo "# ICEM_XCHG_FAIL=$f python bench.py --gpus 2 --steps 30 --warmup 5 --no-cpu-baseline --no-also  ->  exchange / timed_region of the line"
     ICEM_XCHG_MAX_POLLS=20000 timeout 300 python bench.py --gpus 2 --steps 30 --warmup 5 --no-cpu-baseline --no-also 2> /dev/null | grep '^{' | python -c "import sys, json; j = json.loads(sys.stdin.read()); print(json.dumps({'ms_per_step': j['ms_per_step'], 'exchange': j['exchange'], 'timed_region': j['timed_region']}))"
   done
-  unset ICEM_XCHG_FAIL
+  unset ICEM_XCHG_FAIL ICEM_HIP_LIB
   echo "# tools/dbg/shared_gpu_worlds.py 2 4 8: the exchange between 2 / 4 / 8 PROCESSES sharing this GPU, at a population whose workgroups are resident together"
   timeout 300 python tools/dbg/shared_gpu_worlds.py 2 4 8 2>&1 | grep "^world\|^shared"
   echo "# ... every rank on its own slice of the CUs (ICEM_SHARED_SLICES=1), 8 processes: N = 65 536 global (BASELINE configs[3]; Door 49 152), then 65 536 PER RANK (N = 524 288 global; Door 393 216)"
@@ -69,6 +72,25 @@ for w in door relocate fpp; do timeout 300 python bench.py --workload $w --no-al
   timeout 300 python tools/dbg/hn_terms_time.py 2>&1 | grep "terms="
   echo "# tools/dbg/hn_check.py (MPC step of the shipped shapes)"
   timeout 300 python tools/dbg/hn_check.py 2>&1 | grep "MPC step"
+  echo "# round 6: tools/dbg/sharded_stamps.py 8 4096 (one sharded launch itemised, records ranked by the whole workgroup)"
+  timeout 120 python tools/dbg/sharded_stamps.py 8 4096 2>&1 | grep -v amdgpu.ids
+  echo "# round 6: tools/dbg/xcd_stamps.py / xcd_step_check.py (the one-launch step inside one XCD, option step_xcd = 1: stamps, bit-equality, time)"
+  timeout 120 python tools/dbg/xcd_stamps.py 4096 5 2>&1 | grep -v amdgpu.ids
+  timeout 300 python tools/dbg/xcd_step_check.py 2>&1 | grep -v amdgpu.ids | tail -6
+  echo "# round 6: tools/ubench/xcd_barrier (a 32-arrival barrier inside one XCD)"
+  (cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o xcd_barrier xcd_barrier.hip 2> /dev/null; timeout 120 ./xcd_barrier)
+  echo "# round 6: tools/dbg/batch_host_time.py (icem_plan_step_batch: host enqueue time against the step's GPU time)"
+  timeout 300 python tools/dbg/batch_host_time.py 2>&1 | grep "B="
+  echo "# round 6: icem_plan_step_batch by launch family (option batch_ahead: noise-ahead launches from 49152 rows on / never)"
+  timeout 600 python - <<'PYEOF' 2>&1 | grep "batch_ahead"
+import bench
+from icem_amd import _lib as L
+for ah in (1, 0):
+    L.reset_options(); L.set_option("batch_ahead", ah); L.set_option("batch_ahead_min_rows", 0)
+    j = bench.measure_batched("c2", batches=(6, 8, 12, 16, 32), solo_ms=0.0611)
+    for b, r in j["by_B"].items():
+        print("batch_ahead (forced)" if ah else "batch_ahead off", "B", b, round(r["ms_per_batched_mpc_step"] * 1e3, 1), "us per batched step,", round(r["aggregate_vs_solo_steps"], 2), "x the solo steps; uploads", r["argument_uploads_in_timed_steps"])
+PYEOF
   echo "# tools/ubench/lds_ring (the learned-dynamics weight ring: registers vs LDS)"
   (cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o lds_ring lds_ring.hip 2> /dev/null; timeout 120 ./lds_ring)
 } > $OUT/tool_lines.txt 2>&1
