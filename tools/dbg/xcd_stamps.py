@@ -8,6 +8,7 @@ from icem_amd import _lib as L
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 L.set_option("ahead_stamps", 1)
+L.set_option("step_xcd", 1)   # (off by default: the path under study here)
 env = halfcheetah_env(17)
 model = DeviceSyntheticModel.make(17, 6)
 pl = IcemPlanner(IcemConfig(horizon=30, act_dim=6, num_traj=N, opt_iters=ITERS, dtype="f32", seed=1), env.action_space.low, env.action_space.high)

@@ -72,6 +72,8 @@ for w in door relocate fpp; do timeout 300 python bench.py --workload $w --no-al
   timeout 300 python tools/dbg/hn_terms_time.py 2>&1 | grep "terms="
   echo "# tools/dbg/hn_check.py (MPC step of the shipped shapes)"
   timeout 300 python tools/dbg/hn_check.py 2>&1 | grep "MPC step"
+  echo "# tools/dbg/ahead_stamps.py 65536 (c4: every role of every launch of an MPC step)"
+  timeout 200 python tools/dbg/ahead_stamps.py 65536 2>&1 | grep -v amdgpu.ids
   echo "# round 6: tools/dbg/sharded_stamps.py 8 4096 (one sharded launch itemised, records ranked by the whole workgroup)"
   timeout 120 python tools/dbg/sharded_stamps.py 8 4096 2>&1 | grep -v amdgpu.ids
   echo "# round 6: tools/dbg/xcd_stamps.py / xcd_step_check.py (the one-launch step inside one XCD, option step_xcd = 1: stamps, bit-equality, time)"
