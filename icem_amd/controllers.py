@@ -577,6 +577,50 @@ class MpcICemHip(MpcController):
                 observations=obs, states=self.forward_model_state, actions=executed_action)
         return executed_action
 
+    @staticmethod
+    def get_action_batch(controllers, observations, states=None, mode="train"):
+        """``get_action`` of several controllers of ONE configuration at once -- the reference's parallel episodes, each
+        controller its own ``get_action`` (icem/misc/rollout_utils.py:46-58, 129-152) -- through ``icem_plan_step_batch``:
+        every stage of the planning step is one launch for all of them.  Each controller ends in exactly the state its own
+        ``get_action(observations[i], states[i])`` leaves (same executed action, bit for bit; same hooks).  Device path with
+        device noise only; anything else: call ``get_action`` per controller."""
+        ctrls = list(controllers)
+        n = len(ctrls)
+        states = [None] * n if states is None else list(states)
+        for c in ctrls:
+            if not c.was_reset:
+                raise AttributeError("beginning_of_rollout() needs to be called before")
+            if not c.device_path or c._noise_fn() is not None or c.planner.cfg.world != 1 or c.verbose:
+                raise NotImplementedError("get_action_batch: device path, Philox noise, one GPU, not verbose")
+        for c, ob, stt in zip(ctrls, observations, states):
+            c.forward_model_state = c.forward_model.got_actual_observation_and_env_state(
+                observation=ob, env_state=stt, model_state=c.forward_model_state)
+        IcemPlanner.plan_step_batch([c.planner for c in ctrls], observations)
+        host = torch.stack([torch.cat([c.planner.executed, c.planner.best_cost]) for c in ctrls]).cpu().numpy().astype(np.float64)  # one D2H sync
+        # what icem_get_action reports for a solo step: non-finite costs out of a finite observation (ICEM_E_RANGE)
+        from ._lib import IcemError, ICEM_E_RANGE
+        for c, ob in zip(ctrls, observations):
+            seen = c.planner.nonfinite_costs()
+            fresh, c._nonfinite_seen = seen - getattr(c, "_nonfinite_seen", 0), seen
+            if fresh and np.all(np.isfinite(np.asarray(ob, dtype=np.float64))):
+                raise IcemError(ICEM_E_RANGE, f"{fresh} trajectories of this MPC step came back with a non-finite cost from a finite observation")
+        out = []
+        for i, (c, ob) in enumerate(zip(ctrls, observations)):
+            executed_action, c.last_min_cost = host[i, :-1].copy(), float(host[i, -1])
+            if c._new_mean_is_overridden(MpcICemHip):
+                best = c.elite_samples.as_array("actions")[0]
+                new_last = np.asarray(c.compute_new_mean(obs=c._last_predicted_observation(ob, best)), dtype=np.float64)
+                p = c.planner
+                p.mean[-1].copy_(torch.as_tensor(new_last.reshape(p.d), dtype=p.dt, device=p.device))
+            c.logger.log(c.last_min_cost, key="Expected_trajectory_cost")
+            if c.do_visualize_plan:
+                bt = c.best_trajectory(ob)
+                c.visualize_plan(obs=bt["observations"], state=c.forward_model_state, acts=bt["actions"])
+            if c.forward_model_state is not None:
+                _, c.forward_model_state, _ = c.forward_model.predict(observations=ob, states=c.forward_model_state, actions=executed_action)
+            out.append(executed_action)
+        return out
+
     def compute_new_mean(self, obs):
         """icem.py:191-192: the last row of the shifted mean (``obs``: the best trajectory's last predicted observation).
         The default keeps the last row -- which is what the device epilogue (``icem_shift``) computes, so nothing is

@@ -141,3 +141,30 @@ def test_what_a_batch_cannot_do_is_refused_before_anything_runs():
     torch.cuda.synchronize()
     for x, y in zip(_state(a) + _state(b), _state(ref[0]) + _state(ref[1])):
         assert np.array_equal(x, y)
+
+
+def test_controllers_get_action_batch_equals_their_own_get_action():
+    """The host mirror of the batch: ``MpcICemHip.get_action_batch(controllers, observations)`` leaves every controller where its
+    own ``get_action`` would (the reference's parallel episodes, rollout_utils.py:129-152) -- same executed actions, bit for bit."""
+    from icem_amd import DeviceSyntheticModel, MpcICemHip, halfcheetah_env
+
+    def make(i):
+        env = halfcheetah_env(17)
+        c = MpcICemHip(env=env, forward_model=DeviceSyntheticModel.make(17, 6, seed_a=30 + i, seed_b=40 + i), horizon=30,
+                       num_simulated_trajectories=2048, factor_decrease_num=1.25, cost_along_trajectory="sum", seed=9 + i,
+                       action_sampler_params=dict(alpha=0.1, elites_size=10, opt_iterations=3, init_std=0.5, use_mean_actions=True,
+                                                  keep_previous_elites=True, shift_elites_over_time=True, fraction_elites_reused=0.3,
+                                                  noise_beta=0.25))
+        c.beginning_of_rollout(observation=np.zeros(17), state=None, mode="train")
+        return c
+    solo = [make(i) for i in range(4)]
+    batch = [make(i) for i in range(4)]
+    rs = np.random.RandomState(3)
+    for s in range(4):
+        obs = [0.1 * rs.randn(17) for _ in range(4)]
+        want = [c.get_action(ob, None) for c, ob in zip(solo, obs)]
+        got = MpcICemHip.get_action_batch(batch, obs)
+        for w, g in zip(want, got):
+            assert g.dtype == np.float64 and np.array_equal(w, g)
+        for a, b in zip(solo, batch):
+            assert np.array_equal(a.mean, b.mean) and a.last_min_cost == b.last_min_cost
