@@ -157,7 +157,7 @@ def test_quoted_numbers_follow_from_the_tracked_profiles():
     profiles/ (tools/doc_numbers.py): the committed documents must be what the script generates, not hand copies."""
     import subprocess
     import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "doc_numbers.py"), "r05", "--check"], capture_output=True, text=True)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "doc_numbers.py"), "r06", "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
 
 
