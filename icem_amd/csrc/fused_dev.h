@@ -539,6 +539,7 @@ struct Tile16 {
         st.acc_s = 0.f;
         st.acc_b = INFINITY;
     }
+    template <bool PLANES_FIRST = false>   // (Tile16H's issue-order flag: nothing to reorder here, f32 MFMAs and the vector pipe are one)
     __device__ __forceinline__ void step(State& st, const float* rd) const {
         float xv[NKX];
 #pragma unroll
@@ -795,6 +796,11 @@ struct Tile16H {
         st.acc_s = 0.f;
         st.acc_b = INFINITY;
     }
+    // PLANES_FIRST: the operand planes and the MFMAs in front of the step's cost block (which needs the OLD state only and then
+    // sits in the MFMAs' shadow) -- same operations, same bits, another issue order.  For the kernels with a lone tile wave per
+    // SIMD and registers to spare (the single-launch kernel: c2 61.1 -> 60.4 us per MPC step, EXPERIMENTS R6.11); on the 128
+    // registers of the noise-ahead launch it costs two more spilled registers and moves nothing, so that one keeps the old order.
+    template <bool PLANES_FIRST = false>
     __device__ __forceinline__ void step(State& st, const float* rd) const {
         float xv[NKX];
 #pragma unroll
@@ -805,6 +811,23 @@ struct Tile16H {
                 if (r / 4 == q) v = (g == r % 4) ? st.xr[r] : v;
             xv[q] = v;
         }
+        f32x4 nxt;
+        auto model_step = [&]() {
+            // the B operand planes: own columns, then the extras (x their scale)
+            unsigned bH[4], bL[4];
+            split_pair_f16_scaled(st.cur[0][0], invM, st.cur[0][1], invM, bH[0], bL[0]);
+            split_pair_f16_scaled(st.cur[0][2], invM, st.cur[0][3], invM, bH[1], bL[1]);
+            if (NKX >= 2) split_pair_f16_scaled(xv[0], sc[0], xv[NKX >= 2 ? 1 : 0], sc[NKX >= 2 ? 1 : 0], bH[2], bL[2]);
+            else split_pair_f16_scaled(xv[0], sc[0], 0.f, 0.f, bH[2], bL[2]);
+            if (NKX == 4) split_pair_f16_scaled(xv[NKX > 2 ? 2 : 0], sc[NKX > 2 ? 2 : 0], xv[NKX > 3 ? 3 : 0], sc[NKX > 3 ? 3 : 0], bH[3], bL[3]);
+            else if (NKX == 3) split_pair_f16_scaled(xv[NKX > 2 ? 2 : 0], sc[NKX > 2 ? 2 : 0], 0.f, 0.f, bH[3], bL[3]);
+            else bH[3] = bL[3] = 0u;
+            nxt = f32x4{0.f, 0.f, 0.f, 0.f};
+            nxt = mfma_f16_32(aL, bH, nxt);
+            nxt = mfma_f16_32(aH, bL, nxt);
+            nxt = mfma_f16_32(aH, bH, nxt);
+        };
+        if (PLANES_FIRST) model_step();
         // step cost (Tile16's, on the scaled state: flip_th and lin_w carry S).  [ang > th] + [ang < -th] = [|ang| > th]
         // for th >= 0 (update_paths keeps handles with a negative threshold on the exact tile)
         const float ang = ang_is_col1 ? st.cur[0][1] : st.cur[0][0];
@@ -830,19 +853,7 @@ struct Tile16H {
         for (int r = 1; r < REM; ++r) pr[r] = reduce_groups(pr[r]);
         st.acc_s = __builtin_fmaf(st.acc_s, ksum, c);
         st.acc_b = __builtin_fminf(c, st.acc_b);   // (a NaN step cost is skipped, as by Tile16's compare)
-        // the B operand planes: own columns, then the extras (x their scale)
-        unsigned bH[4], bL[4];
-        split_pair_f16_scaled(st.cur[0][0], invM, st.cur[0][1], invM, bH[0], bL[0]);
-        split_pair_f16_scaled(st.cur[0][2], invM, st.cur[0][3], invM, bH[1], bL[1]);
-        if (NKX >= 2) split_pair_f16_scaled(xv[0], sc[0], xv[NKX >= 2 ? 1 : 0], sc[NKX >= 2 ? 1 : 0], bH[2], bL[2]);
-        else split_pair_f16_scaled(xv[0], sc[0], 0.f, 0.f, bH[2], bL[2]);
-        if (NKX == 4) split_pair_f16_scaled(xv[NKX > 2 ? 2 : 0], sc[NKX > 2 ? 2 : 0], xv[NKX > 3 ? 3 : 0], sc[NKX > 3 ? 3 : 0], bH[3], bL[3]);
-        else if (NKX == 3) split_pair_f16_scaled(xv[NKX > 2 ? 2 : 0], sc[NKX > 2 ? 2 : 0], 0.f, 0.f, bH[3], bL[3]);
-        else bH[3] = bL[3] = 0u;
-        f32x4 nxt = f32x4{0.f, 0.f, 0.f, 0.f};
-        nxt = mfma_f16_32(aL, bH, nxt);
-        nxt = mfma_f16_32(aH, bL, nxt);
-        nxt = mfma_f16_32(aH, bH, nxt);
+        if (!PLANES_FIRST) model_step();
         if (KIND == 1) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) st.cur[0][v] = fast_tanh(nxt[v] * invT) * T;
@@ -1717,14 +1728,14 @@ __device__ __forceinline__ void note_nonfinite(const FastRolloutArgs& a, float c
 
 // One wave rolls its 16 trajectories of the slab out of the LDS tile, stores the costs and folds them into its
 // running candidate list.
-template <typename Tile, int H, int D>
+template <typename Tile, int H, int D, bool PLANES_FIRST = false>
 __device__ __forceinline__ unsigned long long rollout_slab(Tile& tile, const FastRolloutArgs& ra, const float* rd0, int row,
                                                            int n_rows, unsigned long long run_key, bool first, int lane) {
     const bool live = row < n_rows;
     typename Tile::State st;
     tile.init(st);
 #pragma unroll
-    for (int t = 0; t < H; ++t) tile.step(st, rd0 + t * D);
+    for (int t = 0; t < H; ++t) tile.template step<PLANES_FIRST>(st, rd0 + t * D);
     const float cost = tile.cost(st);
     if (live && lane < 16) ra.costs[row] = cost;
     note_nonfinite(ra, cost, live && lane < 16);

@@ -336,7 +336,7 @@ __device__ __forceinline__ void sample_rollout_body(const FastSampleArgs& sa, co
     } else {
         if (wave < RW) {
             tile.load_obs(obs_stage);
-            run_key = rollout_slab<Tile, H, D>(tile, ra, rd0, base + wave * 16 + (lane & 15), n_rows, run_key, true, lane);
+            run_key = rollout_slab<Tile, H, D, true>(tile, ra, rd0, base + wave * 16 + (lane & 15), n_rows, run_key, true, lane);
             if (ra.dbg && tid == 0 && wg == 0) ra.dbg[12] = wall_clock64();
         }
         if (ra.dbg && tid == 0 && wg == 0) ra.dbg[13] = wall_clock64();
