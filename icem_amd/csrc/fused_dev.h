@@ -430,6 +430,7 @@ template <> struct VecOf<2> { using type = float2; };
 // and the sample+rollout kernel, so both produce the same bits for the same actions.
 template <int H, int D, int O, int KIND>
 struct Tile16 {
+    static constexpr bool LONE_STEP = false;   // (Tile16H's hand-ordered step for a lone wave: none here)
     // O <= 20: ONE 16-column output tile on the matrix pipe + up to 4 extra columns as permlane-reduced dot products;
     // 20 < O <= 28: TWO output tiles (columns 0..15 and 16..31, zero padded), no extra columns.
     static constexpr int NT = O > 20 ? 2 : 1;
@@ -678,6 +679,7 @@ struct Tile16H {
     static constexpr int SLACK = 4, TAIL = 8;
     static constexpr int ZROW = OP + D;
     static_assert(O >= 16 && O <= 20 && NKX <= 4, "one 16-column tile, at most 16 extra contraction entries");
+    static constexpr bool LONE_STEP = REM == 1 && NKX == 2;   // shapes step_lone() is written for (o = 17, d <= 7)
 
     unsigned aH[4], aL[4];              // model operand planes: slots 8g .. 8g+7 as four fp16 pairs
     float wR[REM > 0 ? REM : 1][4 + NKX];   // f32 weights of this lane's entries into output column 16 + r (the extras' scaled in load_obs)
@@ -864,6 +866,95 @@ struct Tile16H {
 #pragma unroll
             for (int r = 0; r < REM; ++r) st.xr[r] = pr[r];
         }
+    }
+    // The step as a LONE wave wants it issued (one tile per CU: the single-launch kernel at the metric's population).  A lone
+    // wave pays 3.5 ns for an instruction that waits for the one in front of it and 2.0-2.2 ns for one of four interleaved
+    // chains (tools/ubench/lone_wave_ilp.hip), and the compiler, which schedules for a SIMD full of waves, leaves the step's
+    // chains one behind the other: the 17th column's six dependent fmas, the cost's seven, the planes.  Here they are written
+    // INTERLEAVED -- the column's chain (the step's longest: six fmas, the reduction, the select, the plane of the next step) as
+    // the spine, a plane and a cost instruction beside each link -- and fenced (sched_barrier) so that the order survives.
+    // Same operations on the same operands in the same per-value order as step(): the same bits.  `raw`: the step's two extra
+    // entries as read from the tile, replaced by the next step's (requested at the top: nothing crosses a fence).
+    __device__ __forceinline__ void step_lone(State& st, float (&raw)[NKX], const float* rd_next) const {
+        static_assert(REM == 1 && NKX == 2, "written for one extra column and two extra entries per lane");
+#define ICEM_FENCE() __builtin_amdgcn_sched_barrier(0)
+        const float c0 = st.cur[0][0], c1 = st.cur[0][1], c2 = st.cur[0][2], c3 = st.cur[0][3];
+        const float xv0 = (g == 0) ? st.xr[0] : raw[0], xv1 = raw[1];
+        const float n0 = rd_next[xoff[0]], n1 = rd_next[xoff[1]];
+        auto cvt = [](f32x2_t v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t)); };
+        auto res = [](float x, float s_, unsigned h, bool upper) {
+            float r;
+            if (upper) asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(s_), "v"(h));
+            else asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(s_), "v"(h));
+            return r;
+        };
+        // link 1
+        const f32x2_t m01 = f32x2_t{c0 * invM, c1 * invM}, m23 = f32x2_t{c2 * invM, c3 * invM};
+        float p = __builtin_fmaf(c0, wR[0][0], 0.f);
+        const float ang = ang_is_col1 ? c1 : c0;
+        ICEM_FENCE();
+        // link 2
+        unsigned bH[4], bL[4];
+        bH[0] = cvt(m01);
+        bH[1] = cvt(m23);
+        p = __builtin_fmaf(c1, wR[0][1], p);
+        const bool flipped = __builtin_fabsf(ang) > flip_th;
+        ICEM_FENCE();
+        // link 3
+        const f32x2_t m45 = f32x2_t{xv0 * sc[0], xv1 * sc[1]};
+        p = __builtin_fmaf(c2, wR[0][2], p);
+        float c = flipped ? pen : 0.f;
+        const float s0 = xv0 * xv0;
+        ICEM_FENCE();
+        // link 4
+        bH[2] = cvt(m45);
+        bH[3] = 0u;
+        p = __builtin_fmaf(c3, wR[0][3], p);
+        c = __builtin_fmaf(s0, cw[0], c);
+        const float s1 = xv1 * xv1;
+        ICEM_FENCE();
+        f32x4 nxt = mfma_f16_32(aL, bH, f32x4{0.f, 0.f, 0.f, 0.f});
+        // link 5
+        const float r0 = res(c0, invM, bH[0], false), r1 = res(c1, invM, bH[0], true);
+        p = __builtin_fmaf(xv0, wR[0][4], p);
+        c = __builtin_fmaf(s1, cw[1], c);
+        ICEM_FENCE();
+        // link 6
+        const float r2 = res(c2, invM, bH[1], false), r3 = res(c3, invM, bH[1], true);
+        p = __builtin_fmaf(xv1, wR[0][5], p);
+        c = __builtin_fmaf(lin_w, c0, c);
+        ICEM_FENCE();
+        // the planes' residuals beside the reduction's first exchange
+        const float r4 = res(xv0, sc[0], bH[2], false), r5 = res(xv1, sc[1], bH[2], true);
+        bL[0] = cvt(f32x2_t{r0, r1});
+        bL[1] = cvt(f32x2_t{r2, r3});
+        ICEM_FENCE();
+        bL[2] = cvt(f32x2_t{r4, r5});
+        bL[3] = 0u;
+        nxt = mfma_f16_32(aH, bL, nxt);
+        ICEM_FENCE();
+        // (an MFMA that accumulates onto the one in front of it holds the wave's issue until that one is through: the
+        // reduction's first exchange goes between the two) -- reduce_groups_pair(p, c), in two halves
+        auto x32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(c), false, false);
+        const float half = __uint_as_float(x32[0]) + __uint_as_float(x32[1]);
+        ICEM_FENCE();
+        nxt = mfma_f16_32(aH, bH, nxt);
+        ICEM_FENCE();
+        auto x16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(half), __float_as_uint(half), false, false);
+        p = c = __uint_as_float(x16[0]) + __uint_as_float(x16[1]);
+        st.acc_s = __builtin_fmaf(st.acc_s, ksum, c);
+        st.acc_b = __builtin_fminf(c, st.acc_b);
+        if (KIND == 1) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) st.cur[0][v] = fast_tanh(nxt[v] * invT) * T;
+            st.xr[0] = fast_tanh(p * invT) * T;
+        } else {
+            st.cur[0] = nxt;
+            st.xr[0] = p;
+        }
+        raw[0] = n0;
+        raw[1] = n1;
+#undef ICEM_FENCE
     }
     __device__ __forceinline__ float cost(const State& st) const {
         const float v = use_min ? st.acc_b : st.acc_s;
@@ -1734,8 +1825,14 @@ __device__ __forceinline__ unsigned long long rollout_slab(Tile& tile, const Fas
     const bool live = row < n_rows;
     typename Tile::State st;
     tile.init(st);
+    if constexpr (PLANES_FIRST && Tile::LONE_STEP) {
+        float raw[2] = {rd0[tile.xoff[0]], rd0[tile.xoff[1]]};
 #pragma unroll
-    for (int t = 0; t < H; ++t) tile.template step<PLANES_FIRST>(st, rd0 + t * D);
+        for (int t = 0; t < H; ++t) tile.step_lone(st, raw, rd0 + (t + 1 < H ? t + 1 : t) * D);
+    } else {
+#pragma unroll
+        for (int t = 0; t < H; ++t) tile.template step<PLANES_FIRST>(st, rd0 + t * D);
+    }
     const float cost = tile.cost(st);
     if (live && lane < 16) ra.costs[row] = cost;
     note_nonfinite(ra, cost, live && lane < 16);
