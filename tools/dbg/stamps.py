@@ -34,7 +34,7 @@ print("merge  [us from kernel start]: lists loaded %.2f | keep merged %.2f | thr
 # (stamp 12, "wave 0 rolled out", exists only on the Tile16 path; the Tile4 path of small populations goes straight to 13)
 print("single [us from kernel start]: staged %.2f | sampled %.2f | tile->HBM issued %.2f | rolled out %.2f | end %.2f"
       % (acc[9], acc[10], acc[11], acc[13], acc[14]))
-print("       model wave through its steps (stamp 12; the two-wave step of one-tile workgroups: the cost wave ends at 'rolled out'): %.2f" % acc[12])
+print("       wave 0 through its 30 steps (stamp 12, in front of the top-K push and the list): %.2f" % acc[12])
 print("gap end(single, wg 0) -> start(merge): %.2f us" % acc[15])
 print("(with ITERS > 1 the stamps are those of the LAST iteration: the single-launch kernel then carries the previous merge in its prologue"
       " and 'sampled' includes selection + gather + refit + affine map)")
