@@ -1957,6 +1957,7 @@ struct StreamT {
         }
         typename Tile::State st;
         tile.init(st);
+        float xraw[2] = {0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < H; ++t) {
             if (t % TC == 0) {
@@ -1985,8 +1986,10 @@ struct StreamT {
                     if (st_on[m]) *reinterpret_cast<Vec*>(pool + voff[m] + ch * CB) = out;
                 }
                 asm volatile("" ::: "memory");
+                if constexpr (Tile::LONE_STEP) { xraw[0] = rd0[tile.xoff[0]]; xraw[1] = rd0[tile.xoff[1]]; }
             }
-            tile.step(st, rd0 + (t % TC) * D);
+            if constexpr (Tile::LONE_STEP) tile.step_lone(st, xraw, rd0 + ((t + 1) % TC ? (t + 1) % TC : t % TC) * D);
+            else tile.step(st, rd0 + (t % TC) * D);
         }
         const float cost = tile.cost(st);
         if (live && lane < 16) a.costs[row] = cost;

@@ -103,9 +103,10 @@ def test_every_kernel_is_accounted_for(spills):
 
 def test_the_benchmarked_instantiations_do_not_spill(spills):
     """The instantiations the bench lines run (c2, c4, c3, c5) stay at <= 4 spilled registers -- c4's noise-ahead launch on the
-    fp16-plane tile at <= 12, none of them between the MFMAs of a tile's step chain (the spilled values belong to the merge
+    fp16-plane tile at <= 13 (9 without the merge prologue, 13 with it since the step is the hand-interleaved one there too:
+    EXPERIMENTS R6.15), none of them between the MFMAs of a tile's step chain (the spilled values belong to the merge
     prologue and the noise role, which share the launch's 128 registers: tools/dbg/kernel_isa.py)."""
-    for pat, cap in ((r"iter_ahead_kernel<30, 6, 17, 0, 8, [01], 0>", 4), (r"iter_ahead_kernel<30, 6, 17, 0, 8, [01], 1>", 12),
+    for pat, cap in ((r"iter_ahead_kernel<30, 6, 17, 0, 8, [01], 0>", 4), (r"iter_ahead_kernel<30, 6, 17, 0, 8, [01], 1>", 13),
                      (r"sample_rollout_kernel<30, 6, 17, 0, 10, 1, (0|12), false, 0>", 4),
                      (r"rssm_split_kernel<1>", 4), (r"merge_noise_kernel", 4), (r"merge_single_kernel", 4)):
         hit = {k: v for k, v in spills.items() if re.search(pat, k)}
