@@ -1477,6 +1477,75 @@ __device__ __forceinline__ void merge_select_stream(const MergeSingleArgs& a, in
     }
 }
 
+// The selection for ONE wave of a launch that has 128 registers (the noise-ahead launch's merge prologue): the lists' first
+// DEPTH keys in registers -- one load round, like merge_select; the survivors at or below the threshold are a prefix of every
+// (sorted) list and rarely reach past the second depth -- and whatever lies deeper fetched only where a list still has a
+// survivor at depth DEPTH - 1 (dependent loads, L2-resident by then).  More than 64 survivors: the streaming form's tournament.
+// Same result as merge_select (the K smallest keys, ascending; keys are all different).
+template <int DEPTH>
+__device__ __forceinline__ void merge_select_shallow(const MergeSingleArgs& a, int lane, unsigned long long* cand,
+                                                     unsigned long long* sel) {
+    const int K = a.K, nl = a.n_lists;
+    const float keep_cost = a.elites_cost_cur ? a.elites_cost_cur[lane < a.n_keep ? lane : 0] : 0.f;
+    unsigned long long k[LPL][DEPTH];
+#pragma unroll
+    for (int l = 0; l < LPL; ++l) {
+        const int list = lane + l * 64;
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) k[l][i] = a.part_k[(size_t)(i < K ? i : 0) * nl + (list < nl ? list : 0)];
+    }
+#pragma unroll
+    for (int l = 0; l < LPL; ++l) {
+        const bool has_list = lane + l * 64 < nl;
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) k[l][i] = (has_list && i < K) ? k[l][i] : KEY_SENTINEL;
+    }
+    const unsigned long long kept = lane < a.n_keep ? make_key(keep_cost, keep_index0(a) + lane) : KEY_SENTINEL;
+    unsigned long long mine = k[0][0];
+#pragma unroll
+    for (int l = 1; l < LPL; ++l) mine = k[l][0] < mine ? k[l][0] : mine;
+    const unsigned srt = wave_sort64_u32((unsigned)(mine >> 32), lane);
+    const unsigned T = __shfl(srt, K - 1, 64);   // (cost halves: keys that tie with T in cost all survive)
+    unsigned n_cand = 0;  // wave-uniform
+    auto offer = [&](unsigned long long key) {
+        const bool p = (unsigned)(key >> 32) <= T && key != KEY_SENTINEL;
+        const unsigned long long m = __ballot(p);
+        if (m != 0) {
+            const unsigned pos = n_cand + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (p && pos < 64) cand[pos] = key;
+            n_cand += (unsigned)__popcll(m);
+        }
+        return m != 0;
+    };
+    bool deeper[LPL];   // (wave-uniform) list group l still had a survivor at the last depth held in registers
+#pragma unroll
+    for (int l = 0; l < LPL; ++l) {
+        deeper[l] = true;
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i)
+            if (deeper[l]) deeper[l] = offer(k[l][i]);
+    }
+#pragma unroll 1
+    for (int l = 0; l < LPL; ++l) {
+        if (!deeper[l]) continue;
+#pragma unroll 1
+        for (int i = DEPTH; i < K; ++i) {
+            const int list = lane + l * 64;
+            const unsigned long long v = list < nl ? a.part_k[(size_t)i * nl + list] : KEY_SENTINEL;
+            if (!offer(v)) break;
+        }
+    }
+    offer(kept);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    if (n_cand <= 64) {
+        unsigned long long key = lane < (int)n_cand ? *((volatile unsigned long long*)&cand[lane]) : KEY_SENTINEL;
+        key = wave_sort_n(key, lane, n_cand);
+        if (lane < K) sel[lane] = key;
+    } else {
+        merge_select_stream(a, lane, cand, sel);   // (its own threshold pass again, then the tournament: more than 64 ties)
+    }
+}
+
 // Sharded runs: the candidates are n_rec <= 128 all-gathered records {cost, gidx, actions} (+ kept elites).  Two
 // records and one kept elite per lane; same threshold selection; slot[r] receives the record number of selected key
 // r (n_rec + e for kept elite e).  Ties cannot occur: keys embed the global trajectory index.

@@ -199,17 +199,13 @@
     if constexpr (PM == 1) {
         // all waves share the selection: one cold round trip instead of a dozen dependent ones (the kept elites' costs,
         // stage 2's other input, travel with it)
-        const bool by_rank = merge_select_split_by_rank<WAVES>(args.m);   // (uniform) the K best by counting, all waves
-        const float keep_cost = by_rank ? merge_keep_cost_split<WAVES>(args.m, lane, wave) : merge_keep_cost(args.m, lane);
-        merge_select_split_stage1<KREG>(args.m, lane, wave, WAVES, cand, wsel);
-        if (by_rank) merge_select_split_keep<WAVES>(args.m, lane, wave, wsel, sel, keep_cost);
-        // (this wave's first noise vectors: requested behind its keys, in flight across the barriers below)
+        // ONE wave selects, the lists' first three depths in registers (merge_select_shallow): 4.7 us from the launch's entry where
+        // the selection shared by all eight waves -- stage 1 per wave, a barrier, stage 2 -- took 5.5-6.2 (c4 146.5 -> 140.8 us
+        // per MPC step, EXPERIMENTS R6.17); the others request their first noise vectors and wait at the barrier below.
+        // (the streaming single-wave form, which re-reads the lists depth by depth: 7.7 us, R6.16)
+        if (wave == 0) merge_select_shallow<3>(args.m, lane, cand, sel);
         if (tile0 < tiles) stream.first_loads(args.pool, a.n_rows, tile0, pre);
-        if (stamps) stamps[1] = wall_clock64();
-        __syncthreads();
-        if (stamps) stamps[2] = wall_clock64();
-        if (by_rank) merge_select_split_rank<WAVES>(args.m, lane, wave, wsel, sel);
-        else if (wave == 0) merge_select_split_stage2(args.m, lane, WAVES, wsel, cand, sel, keep_cost);
+        if (stamps) stamps[1] = stamps[2] = wall_clock64();
     } else if constexpr (PM == 2) {
         // sharded: the pack role merges for everybody -- wait for its flag (bounded like every exchange wait)
         if (tile0 < tiles) stream.first_loads(args.pool, a.n_rows, tile0, pre);

@@ -1585,6 +1585,32 @@ def test_nan_costs_rank_last_with_index_tie_break(N, dtype):
     assert O.topk_sorted(np.full(last_pool, np.nan), K).tolist() == list(range(K))
 
 
+def test_every_cost_tied_in_the_noise_ahead_launch():
+    """The same at N = 65 536 (f32): the noise-ahead launch's prologue selects on ONE wave with the lists' first three depths
+    in registers (merge_select_shallow) -- with every key tied at +inf all of them survive the threshold: the walk past the
+    third depth and, beyond 64 survivors, the tournament of the streaming form; the K elites must be rows 0 .. K-1 again."""
+    from icem_amd import DeviceSyntheticModel, IcemConfig, IcemPlanner, halfcheetah_env
+    env = halfcheetah_env(17)
+    model = DeviceSyntheticModel.make(17, 6, kind=0)
+    for keep in (False, True):
+        pl = IcemPlanner(IcemConfig(horizon=30, act_dim=6, num_traj=65536, opt_iters=3, dtype="f32", seed=1,
+                                    keep_previous_elites=keep, shift_elites=False), env.action_space.low, env.action_space.high)
+        pl.set_model(model.kind, model.A, model.B)
+        pl.set_cost_spec(env.cost_spec)
+        pl.reset()
+        ob = 0.1 * np.random.RandomState(0).randn(17)
+        ob[8] = np.nan
+        executed = np_(pl.plan_step(ob))
+        torch.cuda.synchronize()
+        K = pl.K
+        assert np.isinf(np_(pl.best_cost)).all() and np.isfinite(np_(pl.mean)).all() and np.isfinite(np_(pl.std)).all()
+        elite_actions, elite_costs = pl.current_elites()
+        assert np.isinf(np_(elite_costs)).all()
+        if not keep:   # (kept elites carry indices behind the pool's: with them the first K pool rows still win the ties)
+            assert np.array_equal(np_(elite_actions), np_(pl.actions[:K]))
+            assert np.array_equal(executed, np_(pl.actions[0, 0]))
+
+
 # ---------------------------------------------------------------------------------------------
 # f-3: the random-shooting baseline MpcRandom
 # ---------------------------------------------------------------------------------------------
