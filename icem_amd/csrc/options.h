@@ -21,7 +21,7 @@ namespace icem {
     X(NOISE_AHEAD_MIN_ROWS, "noise_ahead_min_rows", 0.0)                                                                \
     X(NOISE_AHEAD_SHARDED, "noise_ahead_sharded", 1.0)                                                                     \
     X(AHEAD_STAMPS, "ahead_stamps", 0.0)                                                                                   \
-    X(AHEAD_TAIL_FRAC, "ahead_tail_frac", 0.6)                                                                             \
+    X(AHEAD_TAIL_FRAC, "ahead_tail_frac", 0.4)                                                                             \
     X(AHEAD_NEXT1_FRAC, "ahead_next1_frac", 0.3)                                                                           \
     X(AHEAD_NOISE_LDS_KB, "ahead_noise_lds_kb", -1.0)                                                                      \
     X(PREDRAW, "predraw", 1.0)                       /* 0: iteration 0 of small populations samples its own noise */       \

@@ -198,7 +198,7 @@ def test_options_are_set_through_the_abi_not_the_environment(lib, monkeypatch):
     assert "fuse_max_rw" in names and "noise_ahead" in names and len(names) >= 20
     assert not any("arith" in n for n in names)   # no option selects an arithmetic: that is per handle
     L.reset_options()
-    assert L.get_option("fuse_max_rw") == 8.0 and L.get_option("ahead_tail_frac") == 0.6
+    assert L.get_option("fuse_max_rw") == 8.0 and L.get_option("ahead_tail_frac") == 0.4
     L.set_option("fuse_max_rw", 0)
     assert L.get_option("fuse_max_rw") == 0.0
     with pytest.raises(L.IcemError):
