@@ -199,7 +199,7 @@ __device__ __forceinline__ void sample_rollout_body(const FastSampleArgs& sa, co
             else if constexpr (RW >= 8)  // 13 waves share the register file: the low-register selection
                 merge_select_stream(am, lane, cand, sel);
             else
-                merge_select<KREG, (RW == 1)>(am, lane, cand, sel);
+                merge_select_shallow<3>(am, lane, cand, sel);
         }
     }
     if (PM) {  // now the rest of the inputs: in flight across the barriers below

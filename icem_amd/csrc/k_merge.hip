@@ -32,7 +32,7 @@ __device__ __forceinline__ void merge_single_body(const MergeSingleArgs& a, unsi
         merge_select_records_wg(a, tid < 64, lane, tid, MERGE_WG, sel, slot);   // (all threads: the records' keys ranked by counting)
         if (a.dbg && threadIdx.x == 0) a.dbg[4] = wall_clock64();
     } else {
-        if (tid < 64) merge_select<KREG, true>(a, lane, cand, sel);
+        if (tid < 64) merge_select_shallow<3>(a, lane, cand, sel);
         if (a.dbg && threadIdx.x == 0) a.dbg[4] = wall_clock64();
         __syncthreads();
     }

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(SWG + 64) void sample_folded_merge_kernel(FastSampl
             pk.keep_base = args.p.n_loc;
             // everybody else's prologue waits for this workgroup's push: its waves go first on their SIMDs
             __builtin_amdgcn_s_setprio(3);
-            if (tid >= SWG) merge_select_stream(pk, lane, cand, sel);
+            if (tid >= SWG) merge_select_shallow<3>(pk, lane, cand, sel);
             __syncthreads();
             pack_records_body<KREG>(pk, args.p.n_loc, args.p.shard_lo, args.p.records, args.p.px, smem, sel, tid, NTT);
             if (args.p.pub != nullptr) {
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(SWG + 64) void sample_folded_merge_kernel(FastSampl
             if (polls > args.m.xw.max_polls && lane == 0 && args.m.xw.status)
                 __hip_atomic_store(args.m.xw.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         } else if constexpr (!REC) {
-            merge_select_stream(m, lane, cand, sel);
+            merge_select_shallow<3>(m, lane, cand, sel);
         }
     } else if (has_row) {
         sample_row<H, ROUNDS>(a.W, (unsigned)(a.first_index + n_base + nl), (unsigned)j, a.off_lo, a.off_hi, a.seed_lo,
