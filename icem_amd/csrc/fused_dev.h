@@ -1787,16 +1787,23 @@ template <int KREG, bool REC>
 __device__ __forceinline__ void merge_rows(const MergeSingleArgs& a, const unsigned long long* sel, const int* slot,
                                            const float* (&rows)[KREG]) {
     const int hd = a.h * a.d;
+    // ONE LDS read per lane (lane r: selected key / slot r), then a v_readlane per row: read one by one through the same
+    // uniform address, the K entries were K dependent LDS round trips in front of the gather's loads (0.3 us of the merge
+    // prologue's chain: EXPERIMENTS R6.20); the pointers themselves are scalar arithmetic either way.
+    // ... and lane r also works out row r's address (one set of vector instructions for all K rows instead of K sets of a
+    // dozen scalar ones in front of the first load); the 64-bit addresses come back through v_readlane.
+    const int lane = (int)(threadIdx.x & 63);
+    const int v = REC ? slot[lane < a.K ? lane : 0] : key_idx(sel[lane < a.K ? lane : 0]);
+    const float* mine;
+    if (REC) mine = v < a.n_rec ? a.records + (size_t)v * (hd + 2) + 2 : a.elites_cur + (size_t)(v - a.n_rec) * hd;   // sharded run: candidates are records
+    else mine = v < a.n_pool ? a.actions + (size_t)v * hd : a.elites_cur + (size_t)(v - a.n_global) * hd;
+    const unsigned long long bits = (unsigned long long)(size_t)mine;
 #pragma unroll
     for (int r = 0; r < KREG; ++r) {
         const int rr = r < a.K ? r : 0;
-        if (REC) {  // sharded run: candidates are records
-            const int e = slot[rr];
-            rows[r] = e < a.n_rec ? a.records + (size_t)e * (hd + 2) + 2 : a.elites_cur + (size_t)(e - a.n_rec) * hd;
-        } else {
-            const int g = key_idx(sel[rr]);
-            rows[r] = g < a.n_pool ? a.actions + (size_t)g * hd : a.elites_cur + (size_t)(g - a.n_global) * hd;
-        }
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, rr);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), rr);
+        rows[r] = reinterpret_cast<const float*>((size_t)(((unsigned long long)hi << 32) | lo));
     }
 }
 
