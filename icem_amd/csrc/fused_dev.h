@@ -53,8 +53,8 @@ constexpr unsigned long long KEY_SENTINEL = 0xFF8000007FFFFFFFull;  // (+inf, IN
 // 4 / 8), v_permlane16/32_swap across rows (16 / 32): no LDS-crossbar shuffles
 template <int CTRL>
 __device__ __forceinline__ unsigned long long dpp_u64(unsigned long long x) {
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)x, CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(x >> 32), CTRL, 0xF, 0xF, false);
+    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)x, (int)(unsigned)x, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(x >> 32), (int)(unsigned)(x >> 32), CTRL, 0xF, 0xF, true);
     return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
 }
 template <int J>
@@ -87,59 +87,84 @@ __device__ __forceinline__ unsigned long long xor_partner(unsigned long long k, 
     }
 }
 
+// which lanes keep the SMALLER key of their pair in the (SIZE, J) compare-exchange step: block (lane & SIZE) == 0 sorts
+// ascending, lane (lane & J) == 0 is the pair's lower one -- a compile-time 64-bit lane mask.  The step then is: the compare's
+// lane mask XOR this constant on the scalar unit, and one select per word under the resulting mask (inverse ballot) -- where
+// working the two predicates out per lane cost three vector instructions a step and scalar registers spilled around them
+// (the 21 steps of the selection's threshold sort were 0.6 us of a lone wave: EXPERIMENTS R6.21).  Same compares, same result.
 template <int SIZE, int J>
+constexpr unsigned long long take_min_lanes() {
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l)
+        if (((l & SIZE) == 0) == ((l & J) == 0)) m |= 1ull << l;
+    return m;
+}
+// LANE_MASK: the predicate applied as the compile-time lane mask (above) -- the default; false: worked out per lane, the form the
+// Door / Relocate / FetchPickAndPlace tile kernel keeps for its one slab sort per tile: with the lane-mask form in it the
+// Relocate launch ran 40 -> 52 us (EXPERIMENTS R6.21; same instruction counts, no spills: not understood, measured twice).
+template <int SIZE, int J, bool LANE_MASK = true>
 __device__ __forceinline__ unsigned long long bitonic_step(unsigned long long k, int lane) {
     const unsigned long long o = xor_partner<J>(k, lane);
-    const bool up = (lane & SIZE) == 0;  // this block sorts ascending
-    const bool lower = (lane & J) == 0;  // this lane keeps the smaller of the pair
-    const bool take_min = (up == lower);
-    const bool o_less = o < k;
-    return (take_min == o_less) ? o : k;
+    if constexpr (LANE_MASK) {
+        constexpr unsigned long long TAKE_MIN = take_min_lanes<SIZE, J>();
+        const unsigned long long o_less = __builtin_amdgcn_ballot_w64(o < k);
+        const bool take_o = __builtin_amdgcn_inverse_ballot_w64(~(o_less ^ TAKE_MIN));   // take_min == o_less
+        return take_o ? o : k;
+    } else {
+        const bool up = (lane & SIZE) == 0;  // this block sorts ascending
+        const bool lower = (lane & J) == 0;  // this lane keeps the smaller of the pair
+        const bool take_min = (up == lower);
+        const bool o_less = o < k;
+        return (take_min == o_less) ? o : k;
+    }
 }
 
-template <int SIZE, int J>
+template <int SIZE, int J, bool LANE_MASK = true>
 __device__ __forceinline__ unsigned long long bitonic_merge(unsigned long long k, int lane) {
-    k = bitonic_step<SIZE, J>(k, lane);
-    if constexpr (J > 1) k = bitonic_merge<SIZE, J / 2>(k, lane);
+    k = bitonic_step<SIZE, J, LANE_MASK>(k, lane);
+    if constexpr (J > 1) k = bitonic_merge<SIZE, J / 2, LANE_MASK>(k, lane);
     return k;
 }
 
 // ascending bitonic sort of one key per lane across the 64-lane wave (21 compare-exchange steps)
+template <bool LANE_MASK = true>
 __device__ __forceinline__ unsigned long long wave_sort64(unsigned long long k, int lane) {
-    k = bitonic_merge<2, 1>(k, lane);
-    k = bitonic_merge<4, 2>(k, lane);
-    k = bitonic_merge<8, 4>(k, lane);
-    k = bitonic_merge<16, 8>(k, lane);
-    k = bitonic_merge<32, 16>(k, lane);
-    k = bitonic_merge<64, 32>(k, lane);
+    k = bitonic_merge<2, 1, LANE_MASK>(k, lane);
+    k = bitonic_merge<4, 2, LANE_MASK>(k, lane);
+    k = bitonic_merge<8, 4, LANE_MASK>(k, lane);
+    k = bitonic_merge<16, 8, LANE_MASK>(k, lane);
+    k = bitonic_merge<32, 16, LANE_MASK>(k, lane);
+    k = bitonic_merge<64, 32, LANE_MASK>(k, lane);
     return k;
 }
 
 // ... when only lanes < NKEYS (16 or 32) hold keys and every other lane holds KEY_SENTINEL (the maximum): block 0 of
 // every stage sorts ascending, so after the stages up to NKEYS the later ones would move nothing -- 10 or 15 steps
-template <int NKEYS>
+template <int NKEYS, bool LANE_MASK = true>
 __device__ __forceinline__ unsigned long long wave_sort_first(unsigned long long k, int lane) {
     static_assert(NKEYS == 16 || NKEYS == 32 || NKEYS == 64, "keys in the first 16 / 32 / 64 lanes");
-    k = bitonic_merge<2, 1>(k, lane);
-    k = bitonic_merge<4, 2>(k, lane);
-    k = bitonic_merge<8, 4>(k, lane);
-    k = bitonic_merge<16, 8>(k, lane);
-    if constexpr (NKEYS >= 32) k = bitonic_merge<32, 16>(k, lane);
-    if constexpr (NKEYS >= 64) k = bitonic_merge<64, 32>(k, lane);
+    k = bitonic_merge<2, 1, LANE_MASK>(k, lane);
+    k = bitonic_merge<4, 2, LANE_MASK>(k, lane);
+    k = bitonic_merge<8, 4, LANE_MASK>(k, lane);
+    k = bitonic_merge<16, 8, LANE_MASK>(k, lane);
+    if constexpr (NKEYS >= 32) k = bitonic_merge<32, 16, LANE_MASK>(k, lane);
+    if constexpr (NKEYS >= 64) k = bitonic_merge<64, 32, LANE_MASK>(k, lane);
     return k;
 }
 
 // n (wave-uniform) keys in the first lanes, sentinels behind: the shortest network that sorts them
+template <bool LANE_MASK = true>
 __device__ __forceinline__ unsigned long long wave_sort_n(unsigned long long k, int lane, unsigned n) {
-    if (n <= 16) return wave_sort_first<16>(k, lane);
-    if (n <= 32) return wave_sort_first<32>(k, lane);
-    return wave_sort64(k, lane);
+    if (n <= 16) return wave_sort_first<16, LANE_MASK>(k, lane);
+    if (n <= 32) return wave_sort_first<32, LANE_MASK>(k, lane);
+    return wave_sort64<LANE_MASK>(k, lane);
 }
 
 // the same network on 32-bit keys (half the moves): used where only the ORDER STATISTIC of the keys' cost halves matters
 template <int CTRL>
 __device__ __forceinline__ unsigned dpp_u32(unsigned x) {
-    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, false);
+    // (bound_ctrl: every lane of these permutations has a source lane, so no "old" value to preload the destination with)
+    return (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xF, 0xF, true);
 }
 template <int J>
 __device__ __forceinline__ unsigned xor_partner32(unsigned k, int lane) {
@@ -164,8 +189,9 @@ __device__ __forceinline__ unsigned xor_partner32(unsigned k, int lane) {
 template <int SIZE, int J>
 __device__ __forceinline__ unsigned bitonic_merge32(unsigned k, int lane) {
     const unsigned o = xor_partner32<J>(k, lane);
-    const bool take_min = ((lane & SIZE) == 0) == ((lane & J) == 0);
-    k = (take_min == (o < k)) ? o : k;
+    constexpr unsigned long long TAKE_MIN = take_min_lanes<SIZE, J>();
+    const unsigned long long o_less = __builtin_amdgcn_ballot_w64(o < k);
+    k = __builtin_amdgcn_inverse_ballot_w64(~(o_less ^ TAKE_MIN)) ? o : k;   // take_min == (o < k)
     if constexpr (J > 1) k = bitonic_merge32<SIZE, J / 2>(k, lane);
     return k;
 }
@@ -1135,6 +1161,7 @@ struct Tile4 {
 
 // a tile's 16 keys (lanes 0..15, the rest sentinels) join the wave's running sorted top-K: lanes 16..16+K-1 carry
 // the running list, one sort
+template <bool LANE_MASK = true>
 __device__ __forceinline__ unsigned long long topk_push16(unsigned long long run_key, unsigned long long key, bool first,
                                                           int K, int lane) {
     if (!first) {
@@ -1142,7 +1169,7 @@ __device__ __forceinline__ unsigned long long topk_push16(unsigned long long run
         if (lane >= 16 && lane < 16 + K) key = prev;
     }
     // keys in lanes 0..15 (first tile) or 0..15+K, sentinels behind: the shortest network that covers them
-    return wave_sort_n(key, lane, first ? 16u : 16u + (unsigned)K);
+    return wave_sort_n<LANE_MASK>(key, lane, first ? 16u : 16u + (unsigned)K);
 }
 
 // one sorted list per workgroup out of the first WAVES waves' running lists (K <= 32 keys each, ascending in lanes 0..K-1):

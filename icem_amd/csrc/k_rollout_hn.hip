@@ -471,7 +471,7 @@ __global__ __launch_bounds__(128 * PAIRS) void rollout_hn_pair_kernel(HnArgs a) 
             note_nonfinite(a.r, cost, live && lane < 16);
             if (a.r.K > 0) {
                 const unsigned long long key = (lane < 16 && live && row < a.r.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
-                run_key = topk_push16(run_key, key, first, a.r.K, lane);
+                run_key = topk_push16<false>(run_key, key, first, a.r.K, lane);   // (the per-lane predicate: see bitonic_step)
             }
             first = false;
         }
@@ -758,7 +758,7 @@ void rollout_hn_split_kernel(HnArgs a) {
             note_nonfinite(a.r, cost, live && lane < 16);
             if (a.r.K > 0) {
                 const unsigned long long key = (lane < 16 && live && row < a.r.n_cand) ? make_key(cost, row) : KEY_SENTINEL;
-                run_key = topk_push16(run_key, key, first, a.r.K, lane);
+                run_key = topk_push16<false>(run_key, key, first, a.r.K, lane);   // (the per-lane predicate: see bitonic_step)
             }
             first = false;
         }
